@@ -1,0 +1,421 @@
+"""ORACLE (test infrastructure only — never imported by the product path; only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may use it).
+
+CPU PyTorch fp32 restatement of the gcp_tree forward pass, structured like the reference so it can be read
+side by side with it (paths relative to /root/reference):
+
+  BaseGCPModel.forward / run_encoder / get_end_ind / run_auxilliary_models   gcp/prediction/models/base_gcp.py:140-262
+  TreeModel.predict_sequence / _create_initial_nodes                         gcp/prediction/models/tree/tree.py:26-67
+  SubgoalTreeLayer.produce_tree (recursion, interleave, bf/df access)        gcp/prediction/utils/tree_utils.py:21-108,202-232
+  TreeModule.produce_subgoal / compute_matching                              gcp/prediction/models/tree/tree_module.py:67-147
+  SplitLinTreeHiddenStatePredictorModel.forward                              gcp/prediction/models/tree/tree_lstm.py:43-49
+  Inference.forward (posterior gather)                                       gcp/prediction/models/tree/inference.py:16-36
+  BalancedBinding / get_matched_sequence / prune_sequence                    gcp/prediction/models/tree/frame_binding.py:28-99
+  TreeDenseRec.forward, BalancedEvalBinding.get_all_samples                  tree_dense_rec.py:41-44, gcp/evaluation/evaluation_matching.py:192-206
+
+PARITY UNPINNED at the `blox` boundary: the conv encoder/decoder, Predictor MLPs, LSTM cell wrapper,
+variational heads and losses live in the un-vendored `blox` submodule (empty directory in the reference, no
+pin recoverable), and the reference has no tests or golden vectors.  Those blocks follow THIS build's written
+spec (DESIGN.md "Model spec"; video-gcp_amd/params.py holds the parameter table).  The in-tree logic above is
+restated from the cited lines; its integer part is pinned by oracle/tree_index_oracle.py's known answers.
+
+torch-1.3 semantics the reference pins (requirements.txt:18) are made explicit: Long/Long midpoint truncates
+(frame_binding.py:52-54); argmax over an all-zero column returns 0.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------------------------------------------
+# building blocks (this build's spec of the absent blox modules)
+# ---------------------------------------------------------------------------------------------------
+def _lrelu(x, hp):
+    return F.leaky_relu(x, hp.leaky_slope)
+
+
+def _bn(x, sd, prefix, hp, training):
+    """BatchNorm (normalization='batch', base_model.py:49).  training=True uses batch statistics."""
+    return F.batch_norm(x, sd[f"{prefix}.running_mean"].clone(), sd[f"{prefix}.running_var"].clone(),
+                        sd[f"{prefix}.weight"], sd[f"{prefix}.bias"], training=training, momentum=0.0, eps=hp.bn_eps)
+
+
+def predictor(sd, prefix, hp, *inputs):
+    """Predictor / BaseProcessingNet on [R, C] rows: multi-input = concat on dim 1 (misc.py:48, cost_mdl.py:145)."""
+    x = torch.cat(inputs, dim=1) if len(inputs) > 1 else inputs[0]
+    x = _lrelu(F.linear(x, sd[f"{prefix}.input.linear.weight"], sd[f"{prefix}.input.linear.bias"]), hp)
+    i = 0
+    while f"{prefix}.pyramid-{i}.linear.weight" in sd:
+        x = F.linear(x, sd[f"{prefix}.pyramid-{i}.linear.weight"], sd[f"{prefix}.pyramid-{i}.linear.bias"])
+        x = F.group_norm(x, hp.gn_groups, sd[f"{prefix}.pyramid-{i}.norm.weight"],
+                         sd[f"{prefix}.pyramid-{i}.norm.bias"], hp.gn_eps)
+        x = _lrelu(x, hp)
+        i += 1
+    return F.linear(x, sd[f"{prefix}.head.linear.weight"], sd[f"{prefix}.head.linear.bias"])
+
+
+def encoder(sd, hp, x, training):
+    """Encoder(hp) call contract: `enc, skips = encoder(x[F,C,H,W])` (base_gcp.py:188,208-209).
+    enc is [F, nz_enc, 1, 1]; skips[i] is the output of module i (or None), head excluded."""
+    n = int(math.log2(hp.img_sz))
+    names = ["input"] + [f"pyramid-{i}" for i in range(n - 3)]
+    skips = []
+    for i, name in enumerate(names):
+        x = F.conv2d(x, sd[f"encoder.net.{name}.conv.weight"], sd[f"encoder.net.{name}.conv.bias"], stride=2, padding=1)
+        if f"encoder.net.{name}.norm.weight" in sd:
+            x = _bn(x, sd, f"encoder.net.{name}.norm", hp, training)
+        x = _lrelu(x, hp)
+        skips.append(x if (hp.use_skips and i % hp.skips_stride == 0) else None)
+    x = F.conv2d(x, sd["encoder.net.head.weight"], sd["encoder.net.head.bias"])
+    return x, skips
+
+
+def decoder_features(sd, hp, e, skips, training):
+    """ConvDecoder: e [F, nz_enc] -> feature [F, ngf, H, W].  `skips` are per-frame tensors (already broadcast)."""
+    n = int(math.log2(hp.img_sz))
+    x = F.conv_transpose2d(e[:, :, None, None], sd["decoder.net.input.conv.weight"], sd["decoder.net.input.conv.bias"])
+    x = _lrelu(_bn(x, sd, "decoder.net.input.norm", hp, training), hp)
+    blocks = [(f"pyramid-{i}", (i + 1) if (hp.use_skips and (i + 1) % hp.skips_stride == 0) else -1)
+              for i in reversed(range(n - 3))]
+    blocks.append(("additional_conv_layer", 0 if hp.use_skips else -1))
+    for name, skip_idx in blocks:
+        if skip_idx >= 0:
+            x = torch.cat([x, skips[skip_idx]], dim=1)
+        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        x = F.conv2d(x, sd[f"decoder.net.{name}.conv.weight"], sd[f"decoder.net.{name}.conv.bias"], padding=1)
+        x = _lrelu(_bn(x, sd, f"decoder.net.{name}.norm", hp, training), hp)
+    return x
+
+
+def dlm_split(l, hp):
+    """l [F, 10*nmix, H, W] -> logits [F,nmix,H,W], means/log_scales/coeffs [F,3,nmix,H,W] (PixelCNN++ layout)."""
+    nm = hp.n_mixtures
+    logits = l[:, :nm]
+    rest = l[:, nm:].reshape(l.shape[0], 3, 3 * nm, l.shape[2], l.shape[3])
+    means = rest[:, :, :nm]
+    log_scales = torch.clamp(rest[:, :, nm:2 * nm], min=-7.0)
+    coeffs = torch.tanh(rest[:, :, 2 * nm:3 * nm])
+    return logits, means, log_scales, coeffs
+
+
+def dlm_mean(l, hp):
+    """`images` of the discrete-logistic-mixture head: mixture-weighted component means, with the colour
+    coupling evaluated at the means, clamped to [-1, 1]."""
+    logits, means, _, coeffs = dlm_split(l, hp)
+    pi = torch.softmax(logits, dim=1)
+    m_r = means[:, 0]
+    m_g = means[:, 1] + coeffs[:, 0] * m_r
+    m_b = means[:, 2] + coeffs[:, 1] * m_r + coeffs[:, 2] * m_g
+    img = torch.stack([(pi * m_r).sum(1), (pi * m_g).sum(1), (pi * m_b).sum(1)], dim=1)
+    return torch.clamp(img, -1.0, 1.0)
+
+
+def dlm_nll(l, x, hp):
+    """Per-pixel negative log-likelihood [F, H, W] of x [F,3,H,W] in [-1,1] (PixelCNN++ discretized logistic mix)."""
+    logits, means, log_scales, coeffs = dlm_split(l, hp)
+    xr, xg, xb = x[:, 0:1], x[:, 1:2], x[:, 2:3]
+    m = torch.stack([means[:, 0], means[:, 1] + coeffs[:, 0] * xr,
+                     means[:, 2] + coeffs[:, 1] * xr + coeffs[:, 2] * xg], dim=1)       # [F,3,nm,H,W]
+    xc = x[:, :, None] - m
+    inv = torch.exp(-log_scales)
+    plus_in = inv * (xc + 1.0 / 255.0)
+    min_in = inv * (xc - 1.0 / 255.0)
+    cdf_plus, cdf_min = torch.sigmoid(plus_in), torch.sigmoid(min_in)
+    log_cdf_plus = plus_in - F.softplus(plus_in)
+    log_one_minus_cdf_min = -F.softplus(min_in)
+    cdf_delta = cdf_plus - cdf_min
+    mid_in = inv * xc
+    log_pdf_mid = mid_in - log_scales - 2.0 * F.softplus(mid_in)
+    xx = x[:, :, None].expand_as(xc)
+    inner = torch.where(cdf_delta > 1e-5, torch.log(torch.clamp(cdf_delta, min=1e-12)), log_pdf_mid - math.log(127.5))
+    log_probs = torch.where(xx < -0.999, log_cdf_plus, torch.where(xx > 0.999, log_one_minus_cdf_min, inner))
+    log_probs = log_probs.sum(1) + torch.log_softmax(logits, dim=1)
+    return -torch.logsumexp(log_probs, dim=1)
+
+
+def decode_frames(sd, hp, e, skips, training):
+    """DecoderModule.forward on flat frames: {'images', 'distr'}."""
+    feat = decoder_features(sd, hp, e, skips, training)
+    head = F.conv2d(feat, sd["decoder.gen_head.conv.weight"], sd["decoder.gen_head.conv.bias"], padding=1)
+    if hp.decoder_distribution == "gaussian":
+        img = torch.tanh(head)
+        return dict(images=img, distr=img)
+    return dict(images=dlm_mean(head, hp), distr=head)
+
+
+def decode_seq(sd, hp, inputs, enc, training):
+    """DecoderModule.decode_seq(inputs, enc[B,N,nz,1,1]) (tree_dense_rec.py:42): skips of I_0 broadcast over the
+    node axis, decoder batch-applied (frames flattened b-major)."""
+    B, N = enc.shape[:2]
+    skips = [None if s is None else s.repeat_interleave(N, 0) for s in inputs["skips"]]
+    out = decode_frames(sd, hp, enc.reshape(B * N, -1), skips, training)
+    return {k: v.reshape(B, N, *v.shape[1:]) for k, v in out.items()}
+
+
+def seq_encoder(sd, hp, enc_seq, training):
+    """ConvSeqEncodingModule (base_gcp.py:133-134): [B,T,C] -> conv1d stack over time -> [B,T,C]."""
+    x = enc_seq.transpose(1, 2)
+    pad = hp.conv_inf_enc_kernel_size // 2
+    x = _lrelu(F.conv1d(x, sd["inf_encoder.net.input.conv.weight"], sd["inf_encoder.net.input.conv.bias"], padding=pad), hp)
+    i = 0
+    while f"inf_encoder.net.pyramid-{i}.conv.weight" in sd:
+        x = F.conv1d(x, sd[f"inf_encoder.net.pyramid-{i}.conv.weight"], sd[f"inf_encoder.net.pyramid-{i}.conv.bias"], padding=pad)
+        x = _lrelu(_bn(x, sd, f"inf_encoder.net.pyramid-{i}.norm", hp, training), hp)
+        i += 1
+    x = F.conv1d(x, sd["inf_encoder.net.head.conv.weight"], sd["inf_encoder.net.head.conv.bias"], padding=pad)
+    return x.transpose(1, 2).contiguous()
+
+
+def tree_lstm_step(sd, p, hp, hidden1, hidden2, pred_input):
+    """SplitLinTreeHiddenStatePredictorModel.forward (tree_lstm.py:43-49) + HiddenStatePredictorModel (spec)."""
+    nl, H = hp.n_lstm_layers, hp.nz_mid_lstm
+    ch1 = [c for h in torch.chunk(hidden1, nl, 1) for c in torch.chunk(h, 2, 1)]
+    ch2 = [c for h in torch.chunk(hidden2, nl, 1) for c in torch.chunk(h, 2, 1)]
+    proj = [F.linear(torch.cat([a, b], 1), sd[f"{p}.subgoal_pred.projections.{j}.weight"],
+                     sd[f"{p}.subgoal_pred.projections.{j}.bias"]) for j, (a, b) in enumerate(zip(ch1, ch2))]
+    hidden = torch.cat(proj, dim=1)
+    x = F.linear(torch.cat(pred_input, 1), sd[f"{p}.subgoal_pred.embed.weight"], sd[f"{p}.subgoal_pred.embed.bias"])
+    new_hidden = []
+    for i, hl in enumerate(torch.chunk(hidden, nl, 1)):
+        h, c = torch.chunk(hl, 2, 1)
+        gates = F.linear(x, sd[f"{p}.subgoal_pred.lstm.{i}.weight_ih"], sd[f"{p}.subgoal_pred.lstm.{i}.bias_ih"]) + \
+            F.linear(h, sd[f"{p}.subgoal_pred.lstm.{i}.weight_hh"], sd[f"{p}.subgoal_pred.lstm.{i}.bias_hh"])
+        gi, gf, gg, go = torch.chunk(gates, 4, 1)
+        c = torch.sigmoid(gf) * c + torch.sigmoid(gi) * torch.tanh(gg)
+        h = torch.sigmoid(go) * torch.tanh(c)
+        new_hidden += [h, c]
+        x = h
+    out = F.linear(x, sd[f"{p}.subgoal_pred.out.weight"], sd[f"{p}.subgoal_pred.out.bias"])
+    return torch.cat(new_hidden, 1), out
+
+
+# ---------------------------------------------------------------------------------------------------
+# tree container helpers (tree_utils.py)
+# ---------------------------------------------------------------------------------------------------
+def _interleave(t1, t2):
+    """tree_utils.py:202-205."""
+    return torch.stack((t1, t2), dim=2).view(t1.shape[0], 2 * t1.shape[1], *t1.shape[2:])
+
+
+def _depthfirst2layers(x, dim=1):
+    """tree_utils.py:222-232."""
+    n = x.shape[dim]
+    depth = int(math.log2(n + 1))
+    out = []
+    for _ in range(depth):
+        out.append(x.index_select(dim, torch.arange(0, x.shape[dim], 2)))
+        x = x.index_select(dim, torch.arange(1, x.shape[dim], 2))
+    return list(reversed(out))
+
+
+def _bf_to_df(x_bf, depth):
+    """get_attr_df (tree_utils.py:79-92): stack nodes in in-order traversal."""
+    idx = torch.empty(2 ** depth - 1, dtype=torch.long)
+    for l in range(depth):
+        for j in range(2 ** l):
+            idx[(2 * j + 1) * 2 ** (depth - 1 - l) - 1] = 2 ** l - 1 + j
+    return x_bf.index_select(1, idx)
+
+
+def _trunc_mid(tl, tr):
+    """BalancedBinding.comp_timestep on Long tensors under torch 1.3 (frame_binding.py:52-54)."""
+    s = tl + tr
+    return torch.where(s >= 0, s // 2, -((-s) // 2))
+
+
+# ---------------------------------------------------------------------------------------------------
+# forward
+# ---------------------------------------------------------------------------------------------------
+def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, phase="train"):
+    """BaseGCPModel.forward for TreeModel (base_gcp.py:140-161).
+
+    inputs: dict with I_0, I_g [B,3,H,W]; end_ind int64 [B]; optional start_ind, traj_seq [B,T,3,H,W], pad_mask,
+            z [B,N,nz_vae] (depth-first node order, tree.py:38).
+    noise:  eps [B,N,nz_vae] in breadth-first node order for the reparametrised samples (replaces torch RNG so
+            the HIP path can be fed identical numbers).
+    sample_prior: val_mode() switch (base_gcp.py:44-53).
+    training_bn: BatchNorm uses batch statistics (model.train(), as train.py:157 and val :205-214 run it);
+            False = running stats (model.eval(), planner_policy.py:51).
+    """
+    out = {}
+    inp = dict(inputs)
+    B = inp["I_0"].shape[0]
+    L, T = hp.hierarchy_levels, hp.max_seq_len
+    N = 2 ** L - 1
+    if "start_ind" not in inp:
+        inp["start_ind"] = torch.zeros(B, dtype=torch.long)                     # base_gcp.py:181-182
+
+    # ---- run_encoder (base_gcp.py:184-213) -----------------------------------------------------
+    if "traj_seq" in inp:
+        ts = inp["traj_seq"]
+        enc, _ = encoder(sd, hp, ts.reshape(B * T, *ts.shape[2:]), training_bn)   # batch_apply, :188
+        inp["enc_traj_seq"] = enc.reshape(B, T, -1)
+        inp["inf_enc_seq"] = seq_encoder(sd, hp, inp["enc_traj_seq"], training_bn)   # :199
+    e0, skips = encoder(sd, hp, inp["I_0"], training_bn)                         # :208
+    eg, _ = encoder(sd, hp, inp["I_g"], training_bn)                             # :209
+    inp["e_0"], inp["e_g"], inp["skips"] = e0[:, :, 0, 0], eg[:, :, 0, 0], skips
+
+    # ---- get_end_ind (base_gcp.py:215-229); parity runs feed end_ind --------------------
+    if hp.regress_length:
+        out["seq_len_logits"] = predictor(sd, "length_pred.p", hp, inp["e_0"], inp["e_g"])   # misc.py:45-51
+    end_ind = inp["end_ind"]
+    out["end_ind"] = end_ind
+
+    # ---- predict_sequence (tree.py:42-67) ------------------------------------------------------------
+    layer_z = None
+    if "z" in inp:
+        layer_z = _depthfirst2layers(inp["z"], 1)                               # tree_utils.py:31 (layers[-depth])
+    noise_layers = None
+    if noise is not None:
+        noise_layers, s = [], 0
+        for l in range(L):
+            noise_layers.append(noise[:, s:s + 2 ** l])
+            s += 2 ** l
+    # _create_initial_nodes (tree.py:26-35); get_init_inds (frame_binding.py:62-65): Long tensors
+    left = dict(e_g_prime=inp["e_0"][:, None], match_timesteps=torch.zeros(B, 1, dtype=torch.long) - 1, hidden=None)
+    right = dict(e_g_prime=inp["e_g"][:, None], match_timesteps=end_ind[:, None] + 1, hidden=None)
+    start_inds = inp["start_ind"][:, None].float()
+    end_inds = end_ind[:, None].float()
+    layers = []
+    for l in range(L):                                                          # produce_tree recursion, depth = L - l
+        p = f"tree_module.tree_modules.{l if hp.untied_layers else 0}"          # untied_layers_tree.py:14-15
+        n = 2 ** l
+        R = B * n
+        flat = lambda x: x.reshape(R, *x.shape[2:])                             # batch_apply: b-major merge
+        e_l, e_r = flat(left["e_g_prime"]), flat(right["e_g_prime"])
+        sg = {}
+        pz = predictor(sd, f"{p}.prior", hp, e_l, e_r)                          # tree_module.py:77
+        sg["p_z_mu"], sg["p_z_log_sigma"] = pz[:, :hp.nz_vae], pz[:, hp.nz_vae:]
+        if layer_z is not None:                                                 # :79-82
+            z = flat(layer_z[l])
+            if hp.prior_type == "learned":
+                z = sg["p_z_mu"] + torch.exp(sg["p_z_log_sigma"]) * z
+        elif sample_prior:                                                      # :83-84
+            z = sg["p_z_mu"] + torch.exp(sg["p_z_log_sigma"]) * flat(noise_layers[l])
+        else:                                                                   # :86-94 inference
+            mt = _trunc_mid(left["match_timesteps"], right["match_timesteps"])
+            sg["match_timesteps"] = mt.reshape(R)
+            ts_idx = mt.float().long()                                          # inference.py:29-30
+            e_tilde = torch.gather(inp["inf_enc_seq"], 1, ts_idx[:, :, None].expand(B, n, hp.nz_enc))   # batchwise_index
+            qz = predictor(sd, f"{p}.inference.q", hp, e_l, e_r, flat(e_tilde))  # inference.py:35
+            sg["q_z_mu"], sg["q_z_log_sigma"] = qz[:, :hp.nz_vae], qz[:, hp.nz_vae:]
+            z = sg["q_z_mu"] + torch.exp(sg["q_z_log_sigma"]) * flat(noise_layers[l])
+        sg["z"] = z
+        pred_input = [e_l, e_r, z]
+        if hp.context_every_step:                                               # :97-101
+            pred_input += [inp["e_0"].repeat_interleave(n, 0), inp["e_g"].repeat_interleave(n, 0)]
+        if left["hidden"] is None and right["hidden"] is None:                  # :104-105
+            init = predictor(sd, f"{p}.lstm_initializer.net", hp, e_l, e_r, z)
+            hl, hr = torch.chunk(init, 2, 1)
+            left["hidden"], right["hidden"] = hl.reshape(B, n, -1), hr.reshape(B, n, -1)
+        hidden, e_g_prime = tree_lstm_step(sd, p, hp, flat(left["hidden"]), flat(right["hidden"]), pred_input)   # :107-108
+        sg["hidden"], sg["e_g_prime"] = hidden, e_g_prime
+        sg["ind"] = (flat(start_inds) + flat(end_inds)) / 2                     # :113
+        sg = {k: v.reshape(B, n, *v.shape[1:]) for k, v in sg.items()}
+        layers.append(sg)
+        # child layer inputs (tree_utils.py:37-44)
+        new_left = {k: _interleave(left[k], sg[k]) for k in ("e_g_prime", "hidden")}
+        new_right = {k: _interleave(sg[k], right[k]) for k in ("e_g_prime", "hidden")}
+        if "match_timesteps" in sg:
+            new_left["match_timesteps"] = _interleave(left["match_timesteps"], sg["match_timesteps"])
+            new_right["match_timesteps"] = _interleave(sg["match_timesteps"], right["match_timesteps"])
+        else:
+            new_left["match_timesteps"], new_right["match_timesteps"] = None, None
+        start_inds, end_inds = _interleave(start_inds, sg["ind"]), _interleave(sg["ind"], end_inds)
+        left, right = new_left, new_right
+
+    bf = {k: torch.cat([lay[k] for lay in layers], 1) for k in layers[0].keys()}          # get_attr_bf
+    # dense_rec = TreeDenseRec.forward (tree_dense_rec.py:41-44)
+    dec = decode_seq(sd, hp, inp, bf["e_g_prime"], training_bn)
+    bf.update(dec)
+    out["tree_bf"] = bf
+
+    # ---- balanced matching (tree_module.py:132-147, frame_binding.py:42-60) ---------------------------
+    tl = torch.zeros(B, 1, dtype=torch.long) - 1
+    tr = end_ind[:, None] + 1
+    c_layers, t_layers = [], []
+    for l in range(L):
+        t = _trunc_mid(tl, tr)
+        c = F.one_hot(t, T).float()
+        c[tl == t] = 0
+        c[tr == t] = 0
+        c_layers.append(c)
+        t_layers.append(t)
+        tl, tr = _interleave(tl, t), _interleave(t, tr)
+    match_dist = torch.cat(c_layers, 1)                                         # [B,N,T] bf
+    out["match_dist"] = match_dist
+    out["timesteps_bf"] = torch.cat(t_layers, 1)
+    out["p_n"] = match_dist.sum(2).clamp(0, 1)                                   # tree_module.py:147
+
+    # ---- pruning ---------------------------------------------------------------------------------------
+    df_lat = _bf_to_df(bf["e_g_prime"], L)
+    out["existence"] = predictor(sd, "tree_module.tree_modules.0.binding.existence_predictor", hp,
+                                 df_lat.reshape(B * N, -1)).reshape(B, N)         # frame_binding.py:71
+    # balanced: pruned_prediction overwritten by BalancedEvalBinding.get_all_samples (tree.py:62-65)
+    leave_df = _bf_to_df(match_dist.bool().any(-1)[:, :, None], L)[:, :, 0]
+    img_df = _bf_to_df(bf["images"], L)
+    out["leave_df"] = leave_df
+    out["pruned_prediction"] = [img_df[i][leave_df[i]] for i in range(B)]
+    out["model_enc_seq_list"] = [df_lat[i][leave_df[i]] for i in range(B)]        # base_gcp.py:366-368 ('e_g_prime')
+
+    # ---- matched sequence for the loss (frame_binding.py:28-34, 88-99) ---------------------------------
+    if "traj_seq" in inp and phase == "train":
+        idx = match_dist.argmax(1)                                               # [B,T], 0 on padded frames (D5)
+        out["matched_idx"] = idx
+        gi = idx[:, :, None, None, None]
+        out["soft_matched_estimates"] = torch.gather(bf["images"], 1, gi.expand(B, T, *bf["images"].shape[2:]))
+        out["matched_distr"] = torch.gather(bf["distr"], 1, gi.expand(B, T, *bf["distr"].shape[2:]))
+
+    # ---- run_auxilliary_models (base_gcp.py:234-262) ---------------------------------------------------
+    mes = torch.nn.utils.rnn.pad_sequence(out["model_enc_seq_list"], batch_first=True)   # :242
+    out["model_enc_seq"] = mes
+    if hp.attach_state_regressor:
+        out["regressed_state"] = predictor(sd, "state_regressor", hp, mes.reshape(-1, mes.shape[-1])).reshape(B, mes.shape[1], -1)
+    if hp.attach_inv_mdl and phase == "train":
+        # InverseModel.full_seq_forward (inverse_mdl.py:110-134), train_im0_enc=True
+        e1 = mes[:, 1:]
+        e0s = inp["enc_traj_seq"][:, :-1][:, :e1.shape[1]] if "enc_traj_seq" in inp else mes[:, :-1]
+        a = predictor(sd, "inv_mdl.action_pred", hp, torch.cat([e0s, e1], 2).reshape(-1, 2 * hp.nz_enc))
+        out["actions"] = a.reshape(B, e1.shape[1], -1)
+    out["inputs"] = inp
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# losses (base_gcp.py:264-304, tree_module.py:116-157, inference.py:38-43, frame_binding.py:80-99, misc.py:53-56)
+# ---------------------------------------------------------------------------------------------------
+def losses(sd, hp, inputs, out):
+    """Loss dict {name: (value, weight)} and the normalised total.  Reduction spec: value = sum over all
+    non-batch dims of (error * weights), mean over batch — so total / prod(traj_seq.shape[1:]) is per-pixel nats."""
+    B, T = inputs["traj_seq"].shape[:2]
+    res = {}
+    bf = out["tree_bf"]
+    pm = inputs["pad_mask"]
+    tgt = inputs["traj_seq"]
+    if hp.decoder_distribution == "gaussian":
+        ls = sd["decoder.log_sigma"]
+        err = 0.5 * ((tgt - out["matched_distr"]) / torch.exp(ls)) ** 2 + ls + 0.5 * math.log(2 * math.pi)
+        nll = (err.sum((2, 3, 4)) * pm).sum() / B
+    else:
+        d = out["matched_distr"]
+        nllpp = dlm_nll(d.reshape(B * T, *d.shape[2:]), tgt.reshape(B * T, *tgt.shape[2:]), hp).reshape(B, T, -1)
+        nll = (nllpp.sum(2) * pm).sum() / B
+    res["dense_img_rec"] = (nll, hp.dense_img_rec_weight)
+    # KL(q || p) over all nodes (inference.py:38-43), analytic gaussian, clamped below free_nats per dim
+    mq, lq, mp, lp = bf["q_z_mu"], bf["q_z_log_sigma"], bf["p_z_mu"], bf["p_z_log_sigma"]
+    kl = lp - lq + (torch.exp(2 * lq) + (mq - mp) ** 2) / (2 * torch.exp(2 * lp)) - 0.5
+    kl = torch.clamp(kl, min=hp.free_nats)
+    res["kl"] = (kl.sum() / B, hp.kl_weight)
+    if hp.regress_length:
+        res["len_pred"] = (F.cross_entropy(out["seq_len_logits"], inputs["end_ind"]), hp.length_pred_weight)
+    # existence BCE (frame_binding.py:80-86): target = tree.df.match_dist.sum(2)
+    tgt_ex = out["leave_df"].float()
+    res["existence_predictor"] = (F.binary_cross_entropy_with_logits(out["existence"], tgt_ex), 1.0)
+    if hp.attach_state_regressor and "traj_seq_states" in inputs:
+        rl = out["regressed_state"].shape[1]
+        e = (out["regressed_state"] - inputs["traj_seq_states"][:, :rl]) ** 2 * pm[:, :rl, None]
+        res["state_regression"] = (e.mean(), 1.0)
+    total = sum(v * w for v, w in res.values() if w > 0)
+    total = total / float(torch.tensor(tgt.shape[1:]).prod())                    # base_gcp.py:299-301
+    return res, total
