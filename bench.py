@@ -1,0 +1,141 @@
+#!/usr/bin/env python
+"""bench.py — predicted frames/sec of the gcp_tree hot path on MI355X (BASELINE.json metric).
+
+One "step" = one forward pass of the goal-conditioned hierarchical predictor over one synthetic batch of
+BASELINE.json configs[1] (25-room gcp_tree, 64x64x3, seq_len 80, batch 16 per GPU): encoder over B*T frames,
+L=7 tree levels (posterior path), decoder over all B*127 tree nodes, balanced binding + matched/pruned gathers
+and the auxiliary heads — everything `model(inputs)` runs (train.py:205-214 / cem_simulator.py:29-31).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (a port: the reference itself cannot run) on a bounded sample of the same
+    workload: c2 shapes with batch 2, timed on the host cores."""
+    import torch
+    import video_gcp_amd as V
+    from oracle import gcp_model_oracle as O
+    from helpers import make_inputs
+    hp = V.config("c2", batch_size=2)
+    sd = V.init_params(hp, seed=0)
+    inputs, noise, _ = make_inputs(hp, seed=0, variant="A")
+    with torch.no_grad():
+        O.forward(sd, hp, inputs, noise=noise, training_bn=True)      # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            O.forward(sd, hp, inputs, noise=noise, training_bn=True)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > seconds_budget or n >= 10:
+                break
+    fps = n * hp.batch_size * hp.max_seq_len / dt
+    return {"value": round(fps, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} forward passes of oracle/gcp_model_oracle.py at c2 shapes with batch 2 "
+                      f"(64x64, T=80, 127 nodes/seq), torch {torch.__version__} CPU fp32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="sequences per GPU (configs[1]: 16)")
+    ap.add_argument("--eval-bn", action="store_true", help="running-stat BatchNorm (planner mode) instead of batch stats")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import video_gcp_amd as V
+    from video_gcp_amd.model import GCPTreeModel
+    from helpers import make_inputs
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1:
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    hp = V.config("c2", batch_size=args.batch)
+    model = GCPTreeModel(hp, params=V.init_params(hp, seed=0), device=dev)      # same seed on every rank = replicas
+    model.train(not args.eval_bn)
+    # the path shards by sequence: every rank predicts its own batch of independent sequences (weak scaling), no
+    # data-path collective in the forward
+    inputs, noise, _ = make_inputs(hp, seed=100 + rank, variant="A")
+    dinp = {k: v.to(dev) for k, v in inputs.items()}
+    dnoise = noise.to(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        model(dinp, "train", noise=dnoise)
+    torch.cuda.synchronize()
+
+    model.set_timed_op("dec.head")
+    model(dinp, "train", noise=dnoise)          # builds the split graphs
+    torch.cuda.synchronize()
+    model.timed_op_ms()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model(dinp, "train", noise=dnoise)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    head_ms = model.timed_op_ms()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        frames = world * hp.batch_size * hp.max_seq_len * args.steps
+        value = frames / elapsed
+        F = hp.batch_size * hp.n_nodes
+        head_flops = 2.0 * hp.img_sz * hp.img_sz * hp.head_channels * hp.ngf * 9 * F      # algorithmic, per launch
+        avg_ms = sum(head_ms) / len(head_ms)
+        achieved = head_flops / (avg_ms * 1e-3) / 1e12
+        line = {
+            "metric": "predicted frames/sec, 64x64x3 seq_len=80 gcp_tree (inference forward, posterior path)",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 25-room gcp_tree forward, 64x64x3, seq_len 80, batch 16/GPU, "
+                                   "L=7 (127 nodes/seq decoded), discrete-logistic-mixture head, "
+                                   + ("running-stat" if args.eval_bn else "batch-stat") + " BatchNorm",
+                       "batch_per_gpu": hp.batch_size, "seq_len": hp.max_seq_len, "img": hp.img_sz,
+                       "nodes_per_seq": hp.n_nodes, "parallelism": f"dp{world} (independent sequences, no collective)"},
+            "roofline": {"kernel": "conv3x3_kernel<false,16,7,0> (decoder output head, 16->100 ch @64x64 + fused mixture mean)",
+                         "bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": head_flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

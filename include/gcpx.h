@@ -1,0 +1,236 @@
+/*
+ * gcpx.h — C-ABI of libgcpx.so: the MI355X (gfx950) hot path of the goal-conditioned hierarchical video
+ * predictor (gcp_tree).  Plain pointers and sizes only; every pointer marked "dev" is a device (HBM) pointer
+ * owned by the caller.  The library allocates nothing on the hot path and never synchronises; every launch
+ * is enqueued on the caller's stream.  Every function returns 0 on success, a negative gcpx_status otherwise;
+ * gcpx_last_error() gives the text.
+ *
+ * The reference (orybkin/video-gcp, mounted at /root/reference) has no FFI/plugin layer — its boundary is
+ * Python duck typing.  Each entry point therefore cites the reference call site whose device
+ * work it replaces.
+ */
+#ifndef GCPX_H
+#define GCPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCPX_VERSION 1
+
+typedef enum gcpx_status {
+    GCPX_OK = 0,
+    GCPX_ERR_INVALID_ARG = -1,
+    GCPX_ERR_UNSUPPORTED = -2,
+    GCPX_ERR_HIP = -3,
+    GCPX_ERR_COMM = -4
+} gcpx_status;
+
+typedef enum gcpx_act { GCPX_ACT_NONE = 0, GCPX_ACT_LRELU = 1, GCPX_ACT_TANH = 2 } gcpx_act;
+
+int gcpx_version(void);
+const char* gcpx_last_error(void);
+/* number of workgroups a persistent conv launch will use (size of the stats_partial first dim) */
+int gcpx_conv_grid(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Convolution stacks.
+ *   replaces blox.torch.encoder_decoder.Encoder / DecoderModule as called at
+ *   gcp/prediction/models/base_gcp.py:188,208-209 (encoder) and
+ *   gcp/prediction/models/tree/tree_dense_rec.py:42 (decoder.decode_seq over all tree nodes).
+ * Activations are fp32 NHWC [F][H][W][C].  A conv's input is the channel concatenation of up to two sources
+ * (decoder features ++ skip activations of I_0, broadcast over the node axis with frame_div); each source is
+ * passed RAW (pre-normalisation) with the per-channel affine (BatchNorm folded to scale/shift) and
+ * LeakyReLU applied while the tile is staged ("normalise on load").
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct gcpx_conv_src {
+    const float* ptr;    /* dev: NHWC [F / frame_div][Hin][Win][C] */
+    const float* scale;  /* dev: [C] or NULL (identity) */
+    const float* shift;  /* dev: [C] or NULL */
+    int32_t C;           /* channels of this source (multiple of 16) */
+    int32_t frame_div;   /* source frame = f / frame_div (1 = per-frame; N = broadcast over N nodes) */
+    int32_t act;         /* gcpx_act applied after the affine */
+    int32_t _pad;
+} gcpx_conv_src;
+
+typedef enum gcpx_head_mode {
+    GCPX_HEAD_RAW = 0,      /* store conv output NHWC [F][H][W][CT*16] (kernel channel order), + bias, + out_act */
+    GCPX_HEAD_DLM_MEAN = 1, /* discrete-logistic-mixture mean -> images NCHW [F][3][H][W]; nothing else written */
+    GCPX_HEAD_DLM_BOTH = 2, /* both of the above */
+    GCPX_HEAD_TANH_NCHW = 3 /* gaussian head: tanh(first 3 channels) -> images NCHW */
+} gcpx_head_mode;
+
+typedef struct gcpx_conv_args {
+    gcpx_conv_src src[2];
+    int32_t nsrc;
+    int32_t F;              /* output frames */
+    int32_t Hin, Win;       /* source spatial size */
+    int32_t Hout, Wout;     /* output spatial size (2x source when upsample, 1/2 for the stride-2 encoder conv) */
+    int32_t Cin;            /* sum of source channels */
+    int32_t Cout;           /* real output channels; stored channel pitch is out_pitch */
+    int32_t out_pitch;      /* floats between consecutive pixels of `out` */
+    int32_t upsample;       /* 1: bilinear x2 (align_corners=False) before the 3x3 conv */
+    int32_t out_act;        /* gcpx_act in the epilogue (layers without a norm) */
+    int32_t head_mode;      /* gcpx_head_mode (conv3x3 only) */
+    const float* wpk;       /* dev: weights in MFMA fragment order (see video-gcp_amd/packing.py) */
+    const float* bias;      /* dev: [CT*16], zero padded */
+    float* out;             /* dev: NHWC raw output (may be NULL for GCPX_HEAD_DLM_MEAN) */
+    float* images;          /* dev: NCHW [F][3][H][W] for the head modes that produce images */
+    float* stats_partial;   /* dev: [gcpx_conv_grid()][2][CT*16] per-workgroup sum / sum-of-squares of the
+                               raw output for training-mode BatchNorm, or NULL */
+} gcpx_conv_args;
+
+/* decoder block: (bilinear x2 upsample +) 3x3 conv, pad 1 */
+int gcpx_conv3x3(const gcpx_conv_args* a, void* stream);
+/* encoder block: 4x4 conv, stride 2, pad 1 (NHWC sources) */
+int gcpx_conv4x4s2(const gcpx_conv_args* a, void* stream);
+/* first encoder block: same conv on the NCHW 3-channel image tensor the model API receives.
+   x: dev NCHW [F][3][Hin][Win]; out NHWC [F][Hin/2][Win/2][Cout] with bias + out_act applied. */
+int gcpx_conv4x4s2_image(const float* x, const float* wpk, const float* bias, float* out,
+                         int32_t F, int32_t Hin, int32_t Win, int32_t Cout, int32_t out_act, void* stream);
+
+/* BatchNorm statistics -> (scale, shift):  scale = gamma * rsqrt(var + eps), shift = beta - mean * scale.
+   partial: dev [n_partial][2][pitch] (fp32 partial sums written by the conv / gemm epilogues); column n
+   belongs to channel n % C (pitch is a multiple of C); count = elements per channel.  If running_mean/var are non-NULL they are updated with `momentum` (training). */
+int gcpx_bn_finalize(const float* partial, int32_t n_partial, int32_t pitch, int32_t C, double count,
+                     const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                     float* running_mean, float* running_var, float momentum, void* stream);
+/* eval-mode fold: scale/shift from running statistics */
+int gcpx_bn_fold(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                 float eps, int32_t C, float* scale, float* shift, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Row GEMM with gathered, concatenated inputs:  out[r, :] = epi( concat_s X_s[map_s(r), :] @ W^T + bias ).
+ *   replaces the Linear/LSTMCell/Conv1d/ConvTranspose(1x1->4x4)/Conv(4x4 valid) launches issued from
+ *   gcp/prediction/models/tree/tree_lstm.py:43-49 (split_linear merge + HiddenStatePredictorModel),
+ *   gcp/prediction/models/base_gcp.py:199 (ConvSeqEncodingModule) and the encoder head / decoder input.
+ * Row r = (b, j), b = r / rpb, j = r % rpb.  A source row is ptr + b*sb + (j+shift)*sr  (zeros when j+shift is
+ * outside [0, rpb)), or ptr + rowidx[r]*sr when rowidx is given (batchwise_index gather, inference.py:27-33).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct gcpx_row_src {
+    const float* ptr;
+    const int32_t* rowidx;  /* dev: [M] absolute row indices, or NULL */
+    const float* scale;     /* dev: per-channel affine on load, channel = k % cmod; NULL = identity */
+    const float* shiftv;
+    int64_t sb, sr;         /* strides in floats */
+    int32_t width;          /* K extent of this source (multiple of 16) */
+    int32_t shift;          /* row shift inside the batch (conv1d taps) */
+    int32_t act;
+    int32_t cmod;
+} gcpx_row_src;
+
+typedef enum gcpx_gemm_epi {
+    GCPX_EPI_NONE = 0,
+    GCPX_EPI_LRELU = 1,
+    GCPX_EPI_LSTM = 2    /* N = 4H gate-interleaved (n = 4u+g, g in i,f,g,o): writes h, c; see below */
+} gcpx_gemm_epi;
+
+typedef struct gcpx_gemm_args {
+    gcpx_row_src src[6];
+    int32_t nsrc;
+    int32_t M, N, K, rpb;
+    const float* wpk;       /* dev: [K/16][N/16][64][4] fragment-packed W[N][K] */
+    const float* bias;      /* dev: [N] or NULL */
+    float* out;             /* dev: row r at out + b*ob + j*orow (NONE / LRELU) */
+    int64_t ob, orow;
+    int32_t epi;
+    int32_t _pad0;
+    float* stats_partial;   /* dev: [gcpx_gemm_row_blocks(M, N)][2][N] per-row-block sum / sum of squares
+                               of the output columns (training-mode BatchNorm), or NULL */
+    /* LSTM epilogue: c' = sig(f)*c + sig(i)*tanh(g); h' = sig(o)*tanh(c') */
+    const float* c_prev;    /* row r at c_prev + r*c_prev_stride */
+    int64_t c_prev_stride;
+    float* h_out;           /* row r at h_out + b*hb + j*hrow ; c_out likewise */
+    float* c_out;
+    int64_t hb, hrow;
+    float* h_copy;          /* optional dense copy of h: row r at h_copy + r*H (input of the next layer) */
+} gcpx_gemm_args;
+
+int gcpx_gemm(const gcpx_gemm_args* a, void* stream);
+/* number of row blocks gcpx_gemm uses for an M x N problem (first dim of stats_partial) */
+int gcpx_gemm_row_blocks(int32_t M, int32_t N);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused Predictor MLP:  input(in->mid, LReLU), n_mid x (mid->mid, GroupNorm(8), LReLU), head(mid->out).
+ *   replaces blox.torch.subnetworks.Predictor as called at tree_module.py:77 (prior), inference.py:35
+ *   (posterior), tree_module.py:105 (MLP LSTM initialiser), misc.py:48 (length), frame_binding.py:71
+ *   (existence), base_gcp.py:256 (state regressor), inverse_mdl.py:126 and cost_mdl.py:63.
+ * One wavefront owns 16 rows end to end; hidden activations never leave LDS.
+ * GCPX_MLP_GAUSS: out = 2*nz, mu = out[:nz], log_sigma = out[nz:]; additionally z = mu + exp(log_sigma) * eps
+ * (Gaussian.sample / reparametrize, tree_module.py:79-94).
+ * ------------------------------------------------------------------------------------------------- */
+typedef enum gcpx_mlp_epi { GCPX_MLP_PLAIN = 0, GCPX_MLP_GAUSS = 1 } gcpx_mlp_epi;
+
+typedef struct gcpx_mlp_args {
+    gcpx_row_src src[4];
+    int32_t nsrc;
+    int32_t M, rpb;
+    int32_t in_dim, mid, n_mid, out_dim;
+    const float* w_in;      /* dev: fragment-packed [in_dim/16][mid/16][64][4] */
+    const float* b_in;      /* [mid] */
+    const float* w_mid;     /* dev: n_mid x fragment-packed [mid/16][mid/16][64][4] */
+    const float* b_mid;     /* [n_mid][mid] */
+    const float* gn_gamma;  /* [n_mid][mid] */
+    const float* gn_beta;   /* [n_mid][mid] */
+    const float* w_out;     /* dev: fragment-packed [mid/16][out_pad/16][64][4] */
+    const float* b_out;     /* [out_pad] */
+    float gn_eps;
+    float lrelu_slope;
+    int32_t epi;
+    int32_t out_split;      /* columns per output block (0 = out_dim): n -> block n / out_split */
+    float* out;             /* row r, col n at out + (n/out_split)*oblk + b*ob + j*orow + n % out_split */
+    int64_t ob, orow, oblk;
+    /* GAUSS */
+    const float* eps;       /* row r at eps + b*eb + j*erow, [nz] */
+    int64_t eb, erow;
+    float* z;               /* row r at z + b*zb + j*zrow, [nz] */
+    int64_t zb, zrow;
+} gcpx_mlp_args;
+
+int gcpx_mlp(const gcpx_mlp_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Balanced frame binding — integer bookkeeping, bit-exact with
+ *   gcp/prediction/models/tree/frame_binding.py:42-65 (BalancedBinding, torch-1.3 Long/Long truncation),
+ *   gcp/prediction/models/tree/frame_binding.py:28-34 (argmax gather) and
+ *   gcp/evaluation/evaluation_matching.py:192-206 (BalancedEvalBinding.get_all_samples).
+ * Tree nodes are addressed by depth-first position p in [0, N) (N = 2^L - 1).
+ *   node_t      [B][N]  timestep of node p (int32)
+ *   leave       [B][N]  1 if the node is kept (its c_n_prime row is non-zero)
+ *   frame2node  [B][T]  depth-first position matched to frame t; for padded frames the ROOT (argmax of an
+ *                       all-zero column = bf index 0)
+ *   etilde_row  [L-level blocks, bf order: level l holds B*2^l entries, b-major]  b*T + node timestep:
+ *               absolute row of inf_enc_seq[B*T] gathered for the posterior (inference.py:27-33)
+ *   seq_len     [B]     end_ind + 1
+ * ------------------------------------------------------------------------------------------------- */
+int gcpx_balanced_binding(const int64_t* end_ind, int32_t B, int32_t L, int32_t T, int32_t* node_t,
+                          int32_t* leave, int32_t* frame2node, int32_t* etilde_row, int32_t* seq_len,
+                          void* stream);
+
+/* out[b][t] = src[b][idx[b][t] + idx_offset] for rows of `row_floats` floats (matched / pruned sequences);
+   src has N rows per batch element; rows with idx < 0 are zero-filled (pad_sequence, base_gcp.py:242). */
+int gcpx_gather_rows(const float* src, const int32_t* idx, float* out, int32_t B, int32_t T, int32_t N,
+                     int32_t idx_offset, int64_t row_floats, void* stream);
+/* compaction of kept nodes: dst_idx[b][k] = k-th depth-first position with leave==1 (k < seq_len[b]), else -1 */
+int gcpx_compact_index(const int32_t* leave, int32_t B, int32_t N, int32_t T, int32_t* dst_idx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * hipGraph helpers: capture a launch sequence once, replay it per step.
+ * ------------------------------------------------------------------------------------------------- */
+int gcpx_graph_begin(void* stream);
+int gcpx_graph_end(void* stream, void** graph_exec);
+int gcpx_graph_launch(void* graph_exec, void* stream);
+int gcpx_graph_destroy(void* graph_exec);
+
+/* event timing on the caller's stream (bench.py measures the dominant kernel with these) */
+int gcpx_event_create(void** ev);
+int gcpx_event_record(void* ev, void* stream);
+int gcpx_event_elapsed_ms(void* start, void* stop, float* ms);
+int gcpx_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCPX_H */

@@ -1,0 +1,82 @@
+"""CPU checks of the drop-in boundary: libgcpx.so loads, exports every symbol include/gcpx.h declares, and the
+ctypes structs have the same layout as the C structs (no compute calls — there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "gcpx.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from video_gcp_amd import runtime
+    if not os.path.exists(runtime.LIB_PATH):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
+    return runtime.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    from video_gcp_amd import runtime
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(gcpx_[a-z0-9_]+)\s*\(", text))
+    assert declared, "no declarations parsed"
+    bound = {name for name, _, _ in runtime.SYMBOLS}
+    assert declared == bound, (declared - bound, bound - declared)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.gcpx_version() == 1
+
+
+def test_struct_layout_matches_header():
+    from video_gcp_amd import runtime as rt
+    src = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "gcpx.h"
+    int main(void) {
+      printf("%zu %zu %zu %zu %zu\n", sizeof(gcpx_conv_src), sizeof(gcpx_conv_args), sizeof(gcpx_row_src),
+             sizeof(gcpx_gemm_args), sizeof(gcpx_mlp_args));
+      printf("%zu %zu %zu %zu\n", offsetof(gcpx_conv_args, wpk), offsetof(gcpx_conv_args, stats_partial),
+             offsetof(gcpx_gemm_args, wpk), offsetof(gcpx_gemm_args, h_copy));
+      printf("%zu %zu %zu %zu\n", offsetof(gcpx_mlp_args, w_in), offsetof(gcpx_mlp_args, gn_eps),
+             offsetof(gcpx_mlp_args, out), offsetof(gcpx_mlp_args, zrow));
+      return 0;
+    }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    got = [int(x) for x in out]
+    want = [C.sizeof(rt.ConvSrc), C.sizeof(rt.ConvArgs), C.sizeof(rt.RowSrc), C.sizeof(rt.GemmArgs), C.sizeof(rt.MlpArgs),
+            rt.ConvArgs.wpk.offset, rt.ConvArgs.stats_partial.offset, rt.GemmArgs.wpk.offset, rt.GemmArgs.h_copy.offset,
+            rt.MlpArgs.w_in.offset, rt.MlpArgs.gn_eps.offset, rt.MlpArgs.out.offset, rt.MlpArgs.zrow.offset]
+    assert got == want, (got, want)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from video_gcp_amd import runtime as rt
+    with pytest.raises(rt.GcpxError):
+        rt.load_library(str(tmp_path / "nope.so"))
+
+
+def test_invalid_args_are_rejected_without_a_gpu(lib):
+    """argument validation happens before any HIP call"""
+    from video_gcp_amd import runtime as rt
+    a = rt.GemmArgs()
+    assert lib.gcpx_gemm(C.byref(a), None) == -1
+    assert b"nsrc" in lib.gcpx_last_error()
+    m = rt.MlpArgs()
+    assert lib.gcpx_mlp(C.byref(m), None) == -1
+    c = rt.ConvArgs()
+    assert lib.gcpx_conv3x3(C.byref(c), None) == -1

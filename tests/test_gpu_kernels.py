@@ -1,0 +1,324 @@
+"""-m gpu: each C-ABI entry point against a plain PyTorch fp32 (CPU) reference of the same op.
+Tolerances are fp32-roundoff class (different summation order only)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from video_gcp_amd import runtime as rt, packing as pk
+    lib = rt.load_library()
+    assert torch.cuda.is_available()
+    return rt, pk, lib, torch.device("cuda")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rowsrc(rt, t, sb, sr, width, **kw):
+    s = rt.RowSrc()
+    s.ptr, s.sb, s.sr, s.width = t.data_ptr() if hasattr(t, "data_ptr") else t, sb, sr, width
+    for k, v in kw.items():
+        setattr(s, k, v.data_ptr() if hasattr(v, "data_ptr") else v)
+    return s
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 128, 256), (70, 512, 128), (200, 2048, 1024), (1024, 64, 64)])
+def test_gemm_plain(env, M, N, K):
+    rt, pk, lib, dev = env
+    torch.manual_seed(M + N)
+    x, w, b = torch.randn(M, K), torch.randn(N, K) / K ** 0.5, torch.randn(N)
+    want = F.linear(x, w, b)
+    xd, wp, bd = x.to(dev), pk.pack_gemm(w).to(dev), b.to(dev)
+    out = torch.full((M, N), float("nan"), device=dev)
+    a = rt.GemmArgs()
+    a.src[0] = _rowsrc(rt, xd, 0, K, K)
+    a.nsrc, a.M, a.N, a.K, a.rpb = 1, M, N, K, M
+    a.wpk, a.bias, a.out, a.ob, a.orow = wp.data_ptr(), bd.data_ptr(), out.data_ptr(), 0, N
+    rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm")
+    torch.cuda.synchronize()
+    assert_close(out, want, atol=2e-5, rtol=1e-5, name="gemm")
+
+
+def test_gemm_sources_shift_affine_stats(env):
+    """conv1d-over-time form: three shifted sources, affine+LReLU on load, LReLU epilogue, stats partials."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(3)
+    B, T, Cc, N = 3, 20, 32, 48
+    x = torch.randn(B, T, Cc)
+    sc, sh = torch.rand(Cc) + 0.5, torch.randn(Cc) * 0.1
+    w = torch.randn(N, Cc, 3) / (3 * Cc) ** 0.5
+    b = torch.randn(N)
+    xa = F.leaky_relu(x * sc + sh, 0.2)
+    want = F.conv1d(xa.transpose(1, 2), w, b, padding=1).transpose(1, 2)
+    xd, scd, shd = x.to(dev), sc.to(dev), sh.to(dev)
+    wp = pk.pack_gemm(w.permute(0, 2, 1).reshape(N, 3 * Cc)).to(dev)
+    bd = b.to(dev)
+    out = torch.zeros(B * T, N, device=dev)
+    a = rt.GemmArgs()
+    for i, d in enumerate((-1, 0, 1)):
+        a.src[i] = _rowsrc(rt, xd, T * Cc, Cc, Cc, shift=d, scale=scd, shiftv=shd, act=rt.ACT_LRELU, cmod=Cc)
+    a.nsrc, a.M, a.N, a.K, a.rpb = 3, B * T, N, 3 * Cc, T
+    nrb = lib.gcpx_gemm_row_blocks(B * T, N)
+    st = torch.zeros(nrb, 2, N, device=dev)
+    a.wpk, a.bias, a.out, a.ob, a.orow = wp.data_ptr(), bd.data_ptr(), out.data_ptr(), T * N, N
+    a.stats_partial = st.data_ptr()
+    rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm")
+    torch.cuda.synchronize()
+    assert_close(out.view(B, T, N), want, atol=2e-5, rtol=1e-5, name="conv1d-gemm")
+    s = st.sum(0).cpu()
+    assert_close(s[0], want.reshape(-1, N).sum(0), atol=1e-3, name="stats sum")
+    assert_close(s[1], (want.reshape(-1, N) ** 2).sum(0), atol=1e-3, rtol=1e-5, name="stats sumsq")
+    # finalize -> scale/shift of a BatchNorm over those rows
+    gamma, beta = torch.rand(N) + 0.5, torch.randn(N)
+    scale, shift = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    rt.check(lib.gcpx_bn_finalize(st.data_ptr(), nrb, N, N, float(B * T), gamma.to(dev).data_ptr(), beta.to(dev).data_ptr(),
+                                  1e-5, scale.data_ptr(), shift.data_ptr(), None, None, 0.0, _stream()), "bn_finalize")
+    torch.cuda.synchronize()
+    flat = want.reshape(-1, N)
+    mean, var = flat.mean(0), flat.var(0, unbiased=False)
+    wsc = gamma / torch.sqrt(var + 1e-5)
+    assert_close(scale, wsc, atol=1e-5, rtol=1e-4, name="bn scale")
+    assert_close(shift, beta - mean * wsc, atol=1e-5, rtol=1e-4, name="bn shift")
+
+
+def test_gemm_lstm_epilogue(env):
+    rt, pk, lib, dev = env
+    torch.manual_seed(5)
+    M, H = 40, 64
+    x, h, c = torch.randn(M, H), torch.randn(M, H), torch.randn(M, H)
+    cell = torch.nn.LSTMCell(H, H)
+    with torch.no_grad():
+        h1, c1 = cell(x, (h, c))
+    w, b = pk.lstm_gate_interleave(cell.weight_ih.detach(), cell.weight_hh.detach(), cell.bias_ih.detach(), cell.bias_hh.detach())
+    wp, bd = pk.pack_gemm(w).to(dev), b.to(dev)
+    xd, hd, cd = x.to(dev), h.to(dev), c.to(dev)
+    ho, co, hc = (torch.zeros(M, H, device=dev) for _ in range(3))
+    a = rt.GemmArgs()
+    a.src[0] = _rowsrc(rt, xd, 0, H, H)
+    a.src[1] = _rowsrc(rt, hd, 0, H, H)
+    a.nsrc, a.M, a.N, a.K, a.rpb = 2, M, 4 * H, 2 * H, M
+    a.wpk, a.bias, a.epi = wp.data_ptr(), bd.data_ptr(), rt.EPI_LSTM
+    a.c_prev, a.c_prev_stride, a.h_out, a.c_out, a.hb, a.hrow, a.h_copy = cd.data_ptr(), H, ho.data_ptr(), co.data_ptr(), 0, H, hc.data_ptr()
+    rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm lstm")
+    torch.cuda.synchronize()
+    assert_close(ho, h1, atol=1e-5, name="h")
+    assert_close(co, c1, atol=1e-5, name="c")
+    assert_close(hc, h1, atol=1e-5, name="h_copy")
+
+
+def _predictor_ref(x, Ws, n_mid, groups=8):
+    h = F.leaky_relu(F.linear(x, Ws["w_in"], Ws["b_in"]), 0.2)
+    for i in range(n_mid):
+        h = F.linear(h, Ws["w_mid"][i], Ws["b_mid"][i])
+        h = F.leaky_relu(F.group_norm(h, groups, Ws["g"][i], Ws["be"][i], 1e-5), 0.2)
+    return F.linear(h, Ws["w_out"], Ws["b_out"])
+
+
+@pytest.mark.parametrize("mid,in_dims,out_dim,M,gauss", [(128, (128, 128), 80, 37, False), (128, (128, 128, 128), 512, 50, True),
+                                                         (32, (128, 128, 256), 1536, 16, False), (128, (128,), 1, 100, False)])
+def test_mlp(env, mid, in_dims, out_dim, M, gauss):
+    rt, pk, lib, dev = env
+    torch.manual_seed(mid + out_dim)
+    n_mid, K = 3, sum(in_dims)
+    xs = [torch.randn(M, d) for d in in_dims]
+    Ws = dict(w_in=torch.randn(mid, K) / K ** 0.5, b_in=torch.randn(mid) * 0.1,
+              w_mid=torch.randn(n_mid, mid, mid) / mid ** 0.5, b_mid=torch.randn(n_mid, mid) * 0.1,
+              g=torch.rand(n_mid, mid) + 0.5, be=torch.randn(n_mid, mid) * 0.1,
+              w_out=torch.randn(out_dim, mid) / mid ** 0.5, b_out=torch.randn(out_dim) * 0.1)
+    want = _predictor_ref(torch.cat(xs, 1), Ws, n_mid)
+    out_pad = (out_dim + 15) // 16 * 16
+    d = {k: v.to(dev) for k, v in dict(
+        w_in=pk.pack_gemm(Ws["w_in"]), b_in=Ws["b_in"], w_mid=torch.stack([pk.pack_gemm(Ws["w_mid"][i]) for i in range(n_mid)]),
+        b_mid=Ws["b_mid"], g=Ws["g"], be=Ws["be"], w_out=pk.pack_gemm(Ws["w_out"]), b_out=pk.pad_vec(Ws["b_out"], out_pad)).items()}
+    xd = [x.to(dev) for x in xs]
+    out = torch.full((M, out_dim), float("nan"), device=dev)
+    a = rt.MlpArgs()
+    for i, x in enumerate(xd):
+        a.src[i] = _rowsrc(rt, x, 0, in_dims[i], in_dims[i])
+    a.nsrc, a.M, a.rpb, a.in_dim, a.mid, a.n_mid, a.out_dim = len(xd), M, M, K, mid, n_mid, out_dim
+    a.w_in, a.b_in, a.w_mid, a.b_mid = d["w_in"].data_ptr(), d["b_in"].data_ptr(), d["w_mid"].data_ptr(), d["b_mid"].data_ptr()
+    a.gn_gamma, a.gn_beta, a.w_out, a.b_out = d["g"].data_ptr(), d["be"].data_ptr(), d["w_out"].data_ptr(), d["b_out"].data_ptr()
+    a.gn_eps, a.lrelu_slope = 1e-5, 0.2
+    a.out, a.ob, a.orow = out.data_ptr(), 0, out_dim
+    if gauss:
+        nz = out_dim // 2
+        eps = torch.randn(M, nz)
+        epsd, z = eps.to(dev), torch.zeros(M, nz, device=dev)
+        a.epi, a.eps, a.eb, a.erow, a.z, a.zb, a.zrow = rt.MLP_GAUSS, epsd.data_ptr(), 0, nz, z.data_ptr(), 0, nz
+    rt.check(lib.gcpx_mlp(C.byref(a), _stream()), "mlp")
+    torch.cuda.synchronize()
+    assert_close(out, want, atol=3e-5, rtol=1e-5, name="mlp out")
+    if gauss:
+        assert_close(z, want[:, :nz] + torch.exp(want[:, nz:]) * eps, atol=5e-5, rtol=1e-5, name="z")
+
+
+def _conv_args(rt, srcs, **kw):
+    a = rt.ConvArgs()
+    cin = 0
+    for i, (t, Cc, fdiv, sc, sh, act) in enumerate(srcs):
+        s = a.src[i]
+        s.ptr, s.C, s.frame_div, s.act = t.data_ptr(), Cc, fdiv, act
+        s.scale = sc.data_ptr() if sc is not None else None
+        s.shift = sh.data_ptr() if sh is not None else None
+        cin += Cc
+    a.nsrc, a.Cin = len(srcs), cin
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if hasattr(v, "data_ptr") else v)
+    return a
+
+
+@pytest.mark.parametrize("Hin,c_prev,c_skip,cout,Fr,nodes", [(32, 16, 16, 16, 6, 3), (16, 32, 0, 16, 5, 1), (8, 64, 64, 32, 6, 2),
+                                                             (4, 128, 0, 64, 7, 1), (4, 64, 64, 32, 6, 3), (8, 32, 0, 16, 4, 1)])
+def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes):
+    """decoder block: concat(prev, skip broadcast over nodes) -> affine+LReLU -> bilinear x2 -> conv3x3 (+ stats)."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(Hin + cout)
+    x = torch.randn(Fr, c_prev, Hin, Hin)
+    sc, sh = torch.rand(c_prev) + 0.5, torch.randn(c_prev) * 0.2
+    xin = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)
+    srcs_ref = [xin]
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    srcs = [(xd, c_prev, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)]
+    if c_skip:
+        sk = torch.randn(Fr // nodes, c_skip, Hin, Hin)
+        srcs_ref.append(sk.repeat_interleave(nodes, 0))
+        skd = sk.permute(0, 2, 3, 1).contiguous().to(dev)
+        srcs.append((skd, c_skip, nodes, None, None, rt.ACT_NONE))
+    cin = c_prev + c_skip
+    w, b = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.randn(cout) * 0.1
+    want = F.conv2d(F.interpolate(torch.cat(srcs_ref, 1), scale_factor=2, mode="bilinear", align_corners=False), w, b, padding=1)
+    wp, bd = pk.pack_conv3x3(w, 32).to(dev), pk.pad_vec(b, cout).to(dev)
+    out = torch.full((Fr, 2 * Hin, 2 * Hin, cout), float("nan"), device=dev)
+    G = lib.gcpx_conv_grid()
+    st = torch.full((G, 2, cout), float("nan"), device=dev)
+    a = _conv_args(rt, srcs, F=Fr, Hin=Hin, Win=Hin, Hout=2 * Hin, Wout=2 * Hin, Cout=cout, out_pitch=cout, upsample=1,
+                   head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out, stats_partial=st)
+    rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "conv3x3")
+    torch.cuda.synchronize()
+    assert_close(out.permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5, name="conv3x3 up")
+    s = st.sum(0).cpu()
+    assert_close(s[0], want.sum((0, 2, 3)), atol=2e-2, rtol=1e-4, name="stats sum")
+    assert_close(s[1], (want ** 2).sum((0, 2, 3)), atol=2e-2, rtol=1e-4, name="stats sumsq")
+
+
+@pytest.mark.parametrize("S,Fr", [(32, 3), (64, 2)])
+def test_conv3x3_head_dlm(env, S, Fr):
+    """output head: 16 -> 100 channels; raw parameters (kernel order) + fused mixture mean vs the oracle's formulas."""
+    rt, pk, lib, dev = env
+    from oracle import gcp_model_oracle as O
+    from video_gcp_amd import config
+    hp = config("c1")
+    torch.manual_seed(S)
+    x = torch.randn(Fr, 16, S, S)
+    sc, sh = torch.rand(16) + 0.5, torch.randn(16) * 0.2
+    xin = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)
+    w, b = torch.randn(100, 16, 3, 3) / 12.0, torch.randn(100) * 0.1
+    head = F.conv2d(xin, w, b, padding=1)
+    want_img = O.dlm_mean(head, hp)
+    perm = pk.dlm_channel_perm(10)
+    permt = torch.tensor(perm)
+    wp = pk.pack_conv3x3(w, 16, perm=perm).to(dev)
+    bk = torch.zeros(len(perm))
+    bk[permt >= 0] = b[permt[permt >= 0]]
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    raw = torch.full((Fr, S, S, len(perm)), float("nan"), device=dev)
+    img = torch.full((Fr, 3, S, S), float("nan"), device=dev)
+    a = _conv_args(rt, [(xd, 16, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=S, Win=S, Hout=S, Wout=S, Cout=100,
+                   out_pitch=len(perm), upsample=0, head_mode=rt.HEAD_DLM_BOTH, wpk=wp, bias=bk.to(dev), out=raw, images=img)
+    rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head")
+    torch.cuda.synchronize()
+    slots = torch.nonzero(permt >= 0)[:, 0]
+    inv = torch.empty(100, dtype=torch.long)
+    inv[permt[slots]] = slots
+    got = raw.cpu().index_select(-1, inv).permute(0, 3, 1, 2)
+    assert_close(got, head, atol=2e-5, rtol=1e-5, name="head raw")
+    assert_close(img, want_img, atol=1e-5, name="dlm mean")
+    # mean-only mode writes the same images
+    img2 = torch.full((Fr, 3, S, S), float("nan"), device=dev)
+    a.head_mode, a.out, a.images = rt.HEAD_DLM_MEAN, None, img2.data_ptr()
+    rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head mean")
+    torch.cuda.synchronize()
+    assert torch.equal(img2, img)
+
+
+@pytest.mark.parametrize("Hin,cin,cout,Fr", [(32, 16, 32, 5), (16, 32, 64, 3), (8, 64, 128, 9), (16, 16, 32, 2)])
+def test_conv4x4s2(env, Hin, cin, cout, Fr):
+    rt, pk, lib, dev = env
+    torch.manual_seed(Hin + cin)
+    x = torch.randn(Fr, cin, Hin, Hin)
+    sc, sh = torch.rand(cin) + 0.5, torch.randn(cin) * 0.2
+    w, b = torch.randn(cout, cin, 4, 4) / (16 * cin) ** 0.5, torch.randn(cout) * 0.1
+    want = F.conv2d(F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2), w, b, stride=2, padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = torch.full((Fr, Hin // 2, Hin // 2, cout), float("nan"), device=dev)
+    G = lib.gcpx_conv_grid()
+    st = torch.full((G, 2, cout), float("nan"), device=dev)
+    a = _conv_args(rt, [(xd, cin, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=Hin, Win=Hin, Hout=Hin // 2, Wout=Hin // 2,
+                   Cout=cout, out_pitch=cout, wpk=pk.pack_conv4x4(w).to(dev), bias=b.to(dev), out=out, stats_partial=st)
+    rt.check(lib.gcpx_conv4x4s2(C.byref(a), _stream()), "conv4x4s2")
+    torch.cuda.synchronize()
+    assert_close(out.permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5, name="conv4x4s2")
+    assert_close(st.sum(0)[0], want.sum((0, 2, 3)), atol=1e-2, rtol=1e-4, name="stats")
+
+
+@pytest.mark.parametrize("S,Fr", [(32, 5), (64, 3)])
+def test_conv4x4s2_image(env, S, Fr):
+    rt, pk, lib, dev = env
+    torch.manual_seed(S)
+    x = torch.rand(Fr, 3, S, S) * 2 - 1
+    w, b = torch.randn(16, 3, 4, 4) / 7.0, torch.randn(16) * 0.1
+    want = F.leaky_relu(F.conv2d(x, w, b, stride=2, padding=1), 0.2)
+    out = torch.full((Fr, S // 2, S // 2, 16), float("nan"), device=dev)
+    xd, wp, bd = x.to(dev), pk.pack_conv4x4_image(w).to(dev), b.to(dev)
+    rt.check(lib.gcpx_conv4x4s2_image(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), Fr, S, S, 16, rt.ACT_LRELU,
+                                      _stream()), "conv image")
+    torch.cuda.synchronize()
+    assert_close(out.permute(0, 3, 1, 2), want, atol=1e-5, rtol=1e-5, name="conv image")
+
+
+def test_balanced_binding_bit_exact(env):
+    rt, pk, lib, dev = env
+    from oracle import tree_index_oracle as TI
+    import numpy as np
+    for L, T in [(3, 7), (5, 20), (7, 80), (8, 200)]:
+        ends = list(range(0, min(T, 2 ** L - 1)))
+        B = len(ends)
+        N = 2 ** L - 1
+        end = torch.tensor(ends, dtype=torch.long, device=dev)
+        node_t, leave = torch.zeros(B, N, dtype=torch.int32, device=dev), torch.zeros(B, N, dtype=torch.int32, device=dev)
+        f2n, et = torch.zeros(B, T, dtype=torch.int32, device=dev), torch.zeros(B * N, dtype=torch.int32, device=dev)
+        sl, kept = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, T, dtype=torch.int32, device=dev)
+        rt.check(lib.gcpx_balanced_binding(end.data_ptr(), B, L, T, node_t.data_ptr(), leave.data_ptr(), f2n.data_ptr(),
+                                           et.data_ptr(), sl.data_ptr(), _stream()), "binding")
+        rt.check(lib.gcpx_compact_index(leave.data_ptr(), B, N, T, kept.data_ptr(), _stream()), "compact")
+        torch.cuda.synchronize()
+        perm = TI.bf2df_perm(L)
+        ts_bf = TI.balanced_timesteps_bf(ends, L, T)
+        md = TI.balanced_match_dist(ends, L, T)
+        want_t = np.zeros_like(ts_bf)
+        want_t[:, perm] = ts_bf
+        assert np.array_equal(node_t.cpu().numpy(), want_t)
+        assert np.array_equal(leave.cpu().numpy().astype(bool), TI.leave_mask_df(ends, L, T))
+        want_f2n = perm[TI.matched_node_index(md)]
+        assert np.array_equal(f2n.cpu().numpy(), want_f2n)
+        assert np.array_equal(sl.cpu().numpy(), np.array(ends) + 1)
+        k = kept.cpu().numpy()
+        for b, e in enumerate(ends):
+            assert np.array_equal(k[b, :e + 1], np.nonzero(TI.leave_mask_df([e], L, T)[0])[0])
+            assert np.all(k[b, e + 1:] == -1)
+        # posterior gather rows, bf order per level
+        off = 0
+        for l in range(L):
+            n = 2 ** l
+            blk = et[B * (n - 1):B * (n - 1) + B * n].cpu().numpy().reshape(B, n)
+            assert np.array_equal(blk, np.arange(B)[:, None] * T + np.clip(ts_bf[:, off:off + n], 0, T - 1))
+            off += n

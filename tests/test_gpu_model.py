@@ -1,0 +1,135 @@
+"""-m gpu: the HIP forward (through the C-ABI, as the model API drives it) against the CPU oracle on identical
+weights, inputs and noise.  Integer bookkeeping must be bit-exact; floating point within the tolerances written
+below (fp32 everywhere; differences are summation order only).  BASELINE.json: pixel MSE within 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_inputs, assert_close
+
+pytestmark = pytest.mark.gpu
+
+LAT_ATOL, LAT_RTOL = 5e-5, 1e-4      # latents / hidden states / distribution parameters
+PIX_ATOL = 2e-5                      # decoded pixels in [-1, 1]
+
+
+def _build(cfg, **over):
+    import video_gcp_amd as V
+    from video_gcp_amd.model import GCPTreeModel
+    hp = V.config(cfg, **over)
+    sd = V.init_params(hp, seed=1, randomize_affine=True)
+    model = GCPTreeModel(hp, params=sd, device="cuda", materialize_distr=True)
+    return hp, sd, model
+
+
+def _check_common(hp, model, out, ref, posterior):
+    from oracle import tree_index_oracle as TI
+    bf = ref["tree_bf"]
+    tree = out.tree
+    assert_close(tree.bf.e_g_prime, bf["e_g_prime"], LAT_ATOL, LAT_RTOL, "e_g_prime")
+    assert_close(tree.bf.hidden_state, bf["hidden"], LAT_ATOL, LAT_RTOL, "hidden_state")
+    assert_close(tree.bf.z, bf["z"], LAT_ATOL, LAT_RTOL, "z")
+    assert_close(tree.bf.p_z_mu, bf["p_z_mu"], LAT_ATOL, LAT_RTOL, "p_z.mu")
+    assert_close(tree.bf.p_z_log_sigma, bf["p_z_log_sigma"], LAT_ATOL, LAT_RTOL, "p_z.log_sigma")
+    if posterior:
+        assert_close(tree.bf.q_z_mu, bf["q_z_mu"], LAT_ATOL, LAT_RTOL, "q_z.mu")
+        assert_close(tree.bf.q_z_log_sigma, bf["q_z_log_sigma"], LAT_ATOL, LAT_RTOL, "q_z.log_sigma")
+    assert_close(tree.bf.images, bf["images"], PIX_ATOL, 0, "images")
+    if hp.decoder_distribution == "discrete_logistic_mixture":
+        assert_close(tree.bf.distr, bf["distr"], LAT_ATOL, LAT_RTOL, "distr")
+    mse = float(((tree.bf.images.cpu() - bf["images"]) ** 2).mean())
+    assert mse < 1e-9, mse
+    assert_close(out.seq_len_logits, ref["seq_len_logits"], LAT_ATOL, LAT_RTOL, "seq_len_logits")
+    assert_close(out.existence_predictor.existence, ref["existence"], LAT_ATOL, LAT_RTOL, "existence")
+    # integer bookkeeping: bit-exact
+    raw = out.raw
+    assert np.array_equal(raw["leave"].cpu().numpy().astype(bool), ref["leave_df"].numpy())
+    assert np.array_equal(raw["node_t"].cpu().numpy(), TI.balanced_timesteps_bf(ref["end_ind"].numpy(), hp.hierarchy_levels,
+                          hp.max_seq_len)[:, np.argsort(TI.bf2df_perm(hp.hierarchy_levels))])
+    pruned = model.pruned_prediction(out)
+    assert [p.shape[0] for p in pruned] == [p.shape[0] for p in ref["pruned_prediction"]]
+    for a, b in zip(pruned, ref["pruned_prediction"]):
+        assert_close(a, b, PIX_ATOL, 0, "pruned_prediction")
+    aux = model.aux_outputs(out)
+    assert_close(aux.model_enc_seq, ref["model_enc_seq"], LAT_ATOL, LAT_RTOL, "model_enc_seq")
+    assert_close(aux.regressed_state, ref["regressed_state"], LAT_ATOL, LAT_RTOL, "regressed_state")
+    if "actions" in ref:
+        assert_close(aux.actions, ref["actions"], LAT_ATOL, LAT_RTOL, "actions")
+
+
+@pytest.mark.parametrize("training_bn", [False, True])
+@pytest.mark.parametrize("variant", ["A", "B"])
+def test_posterior_forward_c1(training_bn, variant):
+    from oracle import gcp_model_oracle as O
+    hp, sd, model = _build("c1")
+    model.train(training_bn)
+    inputs, noise, _ = make_inputs(hp, seed=2, variant=variant)
+    ref = O.forward(sd, hp, inputs, noise=noise, training_bn=training_bn)
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    out = model(dev_in, "train", noise=noise.cuda())
+    torch.cuda.synchronize()
+    _check_common(hp, model, out, ref, posterior=True)
+    assert_close(out.soft_matched_estimates, ref["soft_matched_estimates"], PIX_ATOL, 0, "soft_matched_estimates")
+    from oracle import tree_index_oracle as TI
+    want_f2n = TI.bf2df_perm(hp.hierarchy_levels)[ref["matched_idx"].numpy()]
+    assert np.array_equal(out.raw["frame2node"].cpu().numpy(), want_f2n)
+    # graph replay gives the same bits as the first (eager + captured) run
+    img1 = out.images_df.clone()
+    out2 = model(dev_in, "train", noise=noise.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(out2.images_df, img1)
+
+
+def test_prior_and_given_z_c1():
+    """planning paths: val_mode() prior sampling, and candidate latents z fed in depth-first order
+    (cem_simulator.py:19-31), both with eval-mode BatchNorm (planner_policy.py:51)."""
+    from oracle import gcp_model_oracle as O
+    hp, sd, model = _build("c1")
+    model.eval()
+    inputs, noise, z = make_inputs(hp, seed=3, variant="A")
+    plan_in = {k: inputs[k] for k in ("I_0", "I_g", "end_ind", "start_ind")}
+    ref = O.forward(sd, hp, plan_in, noise=noise, sample_prior=True, training_bn=False)
+    with model.val_mode():
+        out = model({k: v.cuda() for k, v in plan_in.items()}, "train", noise=noise.cuda())
+    torch.cuda.synchronize()
+    _check_common(hp, model, out, ref, posterior=False)
+    zin = dict(plan_in, z=z)
+    ref = O.forward(sd, hp, zin, training_bn=False)
+    with model.val_mode():
+        out = model({k: v.cuda() for k, v in zin.items()}, "train")
+    torch.cuda.synchronize()
+    _check_common(hp, model, out, ref, posterior=False)
+
+
+def test_gaussian_decoder_c1():
+    from oracle import gcp_model_oracle as O
+    hp, sd, model = _build("c1", decoder_distribution="gaussian")
+    model.train(True)
+    inputs, noise, _ = make_inputs(hp, seed=4, variant="B")
+    ref = O.forward(sd, hp, inputs, noise=noise, training_bn=True)
+    out = model({k: v.cuda() for k, v in inputs.items()}, "train", noise=noise.cuda())
+    torch.cuda.synchronize()
+    assert_close(out.tree.bf.images, ref["tree_bf"]["images"], PIX_ATOL, 0, "images")
+
+
+def test_posterior_forward_c2_full_size():
+    """BASELINE.json configs[1]: 64x64, T=80, B=16 (L=7, 127 nodes) against the oracle run on the host cores."""
+    from oracle import gcp_model_oracle as O
+    hp, sd, model = _build("c2", batch_size=4)
+    model.train(True)
+    inputs, noise, _ = make_inputs(hp, seed=5, variant="B")
+    with torch.no_grad():
+        ref = O.forward(sd, hp, inputs, noise=noise, training_bn=True)
+    out = model({k: v.cuda() for k, v in inputs.items()}, "train", noise=noise.cuda())
+    torch.cuda.synchronize()
+    _check_common(hp, model, out, ref, posterior=True)
+    # size-independent properties at full size
+    lens = out.raw["seq_len"].cpu()
+    assert torch.equal(lens, inputs["end_ind"].int() + 1)
+    kept = out.raw["kept_idx"].cpu()
+    f2n = out.raw["frame2node"].cpu()
+    for b in range(hp.batch_size):
+        n = int(lens[b])
+        assert torch.equal(kept[b, :n], f2n[b, :n])          # k-th kept node (temporal order) is matched to frame k
+        assert torch.all(kept[b, :n][1:] > kept[b, :n][:-1])   # strictly increasing depth-first positions
+        assert torch.all(kept[b, n:] == -1)

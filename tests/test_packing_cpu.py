@@ -1,0 +1,67 @@
+"""Host-side weight packing: the fragment-order tensors must hold exactly the documented elements."""
+import torch
+
+from video_gcp_amd import packing as pk
+
+
+def test_pack_gemm_layout():
+    torch.manual_seed(0)
+    w = torch.randn(48, 64)
+    p = pk.pack_gemm(w)
+    assert p.shape == (4, 3, 64, 4)
+    for kg, nt, lane, s in [(0, 0, 0, 0), (3, 2, 63, 3), (1, 1, 17, 2), (2, 0, 40, 1)]:
+        n, k = nt * 16 + lane % 16, kg * 16 + (lane // 16) * 4 + s
+        assert p[kg, nt, lane, s] == w[n, k]
+
+
+def test_pack_gemm_pads_rows():
+    w = torch.randn(2, 32)
+    p = pk.pack_gemm(w)
+    assert p.shape == (2, 1, 64, 4)
+    assert p[0, 0, 2, 0] == 0 and p[0, 0, 1, 0] == w[1, 0]
+
+
+def test_pack_conv3x3_layout_and_padding():
+    torch.manual_seed(1)
+    w = torch.randn(20, 64, 3, 3)
+    p = pk.pack_conv3x3(w, 32)
+    assert p.shape == (2 * 9 * 2 + 1, 2, 64, 4)
+    assert torch.all(p[-1] == 0)
+    for chunk, tap, cgl, ct, lane, s in [(0, 0, 0, 0, 0, 0), (1, 8, 1, 1, 3, 3), (0, 4, 1, 0, 33, 2)]:
+        co, ci = ct * 16 + lane % 16, chunk * 32 + cgl * 16 + (lane // 16) * 4 + s
+        v = w[co, ci, tap // 3, tap % 3] if co < 20 else 0.0
+        assert p[(chunk * 9 + tap) * 2 + cgl, ct, lane, s] == v
+    assert p[0, 1, 4, 0] == 0      # co = 20: padding row
+
+
+def test_dlm_perm_is_a_partial_permutation():
+    perm = pk.dlm_channel_perm(10)
+    assert len(perm) == 112
+    real = [c for c in perm if c >= 0]
+    assert sorted(real) == list(range(100))
+    # slot 8k..8k+6 = logit_k, mean_{r,g,b}, coeff_{0,1,2}
+    k = 3
+    assert perm[8 * k:8 * k + 8] == [k, 10 + k, 40 + k, 70 + k, 30 + k, 60 + k, 90 + k, -1]
+
+
+def test_lstm_gate_interleave():
+    H = 8
+    w_ih, w_hh = torch.randn(4 * H, H), torch.randn(4 * H, H)
+    b_ih, b_hh = torch.randn(4 * H), torch.randn(4 * H)
+    w, b = pk.lstm_gate_interleave(w_ih, w_hh, b_ih, b_hh)
+    u, g = 5, 2
+    assert torch.equal(w[4 * u + g, :H], w_ih[g * H + u]) and torch.equal(w[4 * u + g, H:], w_hh[g * H + u])
+    assert b[4 * u + g] == b_ih[g * H + u] + b_hh[g * H + u]
+
+
+def test_pack_conv4x4_and_image():
+    w = torch.randn(32, 16, 4, 4)
+    p = pk.pack_conv4x4(w)
+    assert p.shape == (16, 1, 2, 64, 4)
+    tap, cg, ct, lane, s = 7, 0, 1, 37, 2
+    assert p[tap, cg, ct, lane, s] == w[ct * 16 + lane % 16, (lane // 16) * 4 + s, tap // 4, tap % 4]
+    wi = torch.randn(16, 3, 4, 4)
+    q = pk.pack_conv4x4_image(wi)
+    assert q.shape == (12, 1, 64)
+    ci, ky, lane = 2, 3, 50
+    assert q[ci * 4 + ky, 0, lane] == wi[lane % 16, ci, ky, lane // 16]

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libgcpx.so (gfx950 only) in-tree: video-gcp_amd/libgcpx.so
+set -e
+cd "$(dirname "$0")"
+OUT=../libgcpx.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-variable ${GCPX_EXTRA_FLAGS}"
+mkdir -p build
+pids=()
+for f in conv3x3 conv_enc gemm mlp misc; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.cuh -nt build/$f.o ] || [ ../../include/gcpx.h -nt build/$f.o ]; then
+    hipcc $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
+echo "built $(realpath $OUT)"

@@ -1,0 +1,67 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, f32-input MFMA 16x16x4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gcpx.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// D[16x16] += A[16x4] * B[4x16], exact f32 (v_mfma_f32_16x16x4_f32, 32-cycle issue).
+//   A operand: lane l holds A[i = l & 15][k = l >> 4]
+//   B operand: lane l holds B[k = l >> 4][j = l & 15]
+//   D: lane l, reg r holds D[i = (l >> 4) * 4 + r][j = l & 15]
+// All kernels here put OUTPUT CHANNELS on the A/i side and PIXELS/ROWS on the B/j side, so a lane ends up
+// with 4 consecutive output channels of one pixel/row -> one 16-byte store, and per-row epilogues
+// (LSTM gates, GroupNorm groups, mixture parameters) stay inside a lane or a 4-lane column.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    if (act == GCPX_ACT_LRELU) return lrelu(x, 0.2f);
+    if (act == GCPX_ACT_TANH) return tanhf(x);
+    return x;
+}
+
+__device__ __forceinline__ float4 affine_act4(float4 v, const float* __restrict__ scale,
+                                              const float* __restrict__ shift, int c, int act) {
+    if (scale) {
+        const float4 s = *reinterpret_cast<const float4*>(scale + c);
+        const float4 t = *reinterpret_cast<const float4*>(shift + c);
+        v.x = fmaf(v.x, s.x, t.x); v.y = fmaf(v.y, s.y, t.y); v.z = fmaf(v.z, s.z, t.z); v.w = fmaf(v.w, s.w, t.w);
+    }
+    if (act == GCPX_ACT_LRELU) {
+        v.x = lrelu(v.x, 0.2f); v.y = lrelu(v.y, 0.2f); v.z = lrelu(v.z, 0.2f); v.w = lrelu(v.w, 0.2f);
+    }
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// sum over the 16 lanes that share (lane >> 4): butterflies inside a 16-lane row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+void gcpx_set_error(const char* fmt, ...);
+#define GCPX_CHECK_ARG(cond, msg)                         \
+    do {                                                  \
+        if (!(cond)) {                                    \
+            gcpx_set_error("%s: %s", __func__, msg);      \
+            return GCPX_ERR_INVALID_ARG;                  \
+        }                                                 \
+    } while (0)
+#define GCPX_CHECK_LAUNCH()                                                        \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            gcpx_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return GCPX_ERR_HIP;                                                   \
+        }                                                                          \
+    } while (0)

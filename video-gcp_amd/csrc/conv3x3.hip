@@ -1,0 +1,398 @@
+// Decoder conv blocks on gfx950: (bilinear x2 upsample ->) 3x3 conv as an implicit GEMM on f32 MFMA.
+//
+// Replaces blox ConvDecoder blocks + gen_head as called through DecoderModule.decode_seq
+// (/root/reference/gcp/prediction/models/tree/tree_dense_rec.py:42) — this build's spec of those blocks is in
+// DESIGN.md "Model spec" (upsample = nn.Upsample(scale_factor=2, bilinear, align_corners=False), conv 3x3 pad 1).
+//
+// Work decomposition (one persistent 256-thread workgroup = 4 wavefronts):
+//   * a tile is 256 output pixels (TH x TW pixels of TF frames); the (upsampled, channel-concatenated,
+//     BatchNorm+LeakyReLU-applied) input region incl. the 1-pixel halo is staged ONCE in LDS per 32-channel chunk;
+//   * each wavefront owns 4 pixel groups (16 pixels = the MFMA j side) x all CT output-channel groups
+//     (16 channels = the MFMA i side); per (tap, 16 input channels) it issues one ds_read_b128 per pixel
+//     group, one coalesced 1 KiB global load per channel group (weights pre-packed in fragment order, L2
+//     resident) and 4*4*CT v_mfma_f32_16x16x4_f32;
+//   * K is permuted so that lane (j, kk) consumes input channels 4*kk .. 4*kk+3 of its pixel — exactly one
+//     16-byte LDS read — the packed weights use the same permutation.
+//   * epilogue: bias, then either the raw NHWC store (+ per-workgroup BatchNorm partial sums) or, for the
+//     output head, the discrete-logistic-mixture mean computed in registers (4-lane column shuffles).
+#include "common.cuh"
+
+namespace {
+
+template <int TILE> struct TileShape;
+template <> struct TileShape<0> { static constexpr int TH = 8, TW = 32, TF = 1; };
+template <> struct TileShape<1> { static constexpr int TH = 16, TW = 16, TF = 1; };
+template <> struct TileShape<2> { static constexpr int TH = 8, TW = 8, TF = 4; };
+
+template <bool UP, int CC, int CT, int TILE>
+struct ConvCfg {
+    using TS = TileShape<TILE>;
+    static constexpr int TH = TS::TH, TW = TS::TW, TF = TS::TF;
+    static constexpr int RH = TH + 2, RW = TW + 2;          // staged hi-res region (halo 1)
+    static constexpr int LH = TH / 2 + 2, LW = TW / 2 + 2;  // low-res patch feeding the upsample
+    static constexpr int CCP = CC + 4;                      // padded channel pitch in LDS (bank spread)
+    static constexpr int C4 = CC / 4;
+    static constexpr int HI_FLOATS = TF * RH * RW * CCP;
+    static constexpr int RAW_FLOATS = UP ? TF * LH * LW * CC : 0;
+    static constexpr int RED_FLOATS = 4 * 2 * CT * 16;      // cross-wave stats reduction
+    static constexpr int LDS_BYTES = (HI_FLOATS + RAW_FLOATS) * 4;
+};
+
+__device__ __forceinline__ float4 load_src4(const gcpx_conv_args& a, int f, int sy, int sx, int cglob) {
+    const int c0 = a.src[0].C;
+    const bool first = cglob < c0;
+    const gcpx_conv_src& s = first ? a.src[0] : a.src[1];
+    const int cl = first ? cglob : cglob - c0;
+    const float* p = s.ptr + (((size_t)(f / s.frame_div) * a.Hin + sy) * a.Win + sx) * s.C + cl;
+    float4 v = *reinterpret_cast<const float4*>(p);
+    return affine_act4(v, s.scale, s.shift, cl, s.act);
+}
+
+template <bool UP, int CC, int CT, int TILE>
+__global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty,
+                                                      const int ntiles) {
+    using Cfg = ConvCfg<UP, CC, CT, TILE>;
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, TF = Cfg::TF, RH = Cfg::RH, RW = Cfg::RW;
+    constexpr int LH = Cfg::LH, LW = Cfg::LW, CCP = Cfg::CCP, C4 = Cfg::C4;
+    constexpr int NSTEP = 9 * (CC / 16);
+
+    extern __shared__ float4 smem4[];
+    float* hi = reinterpret_cast<float*>(smem4);
+    float* raw = hi + Cfg::HI_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int nchunk = a.Cin / CC;
+    const int Hout = a.Hout, Wout = a.Wout, F = a.F;
+
+    // per-lane pixel of each of its 4 pixel groups, inside the tile
+    int pixoff[4], pfl[4], py[4], px[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const int p = (wave * 4 + pt) * 16 + j;
+        pfl[pt] = p / (TH * TW);
+        const int rem = p % (TH * TW);
+        py[pt] = rem / TW;
+        px[pt] = rem % TW;
+        pixoff[pt] = ((pfl[pt] * RH + py[pt]) * RW + px[pt]) * CCP + q * 4;
+    }
+    const float4* wbase = reinterpret_cast<const float4*>(a.wpk) + lane;
+
+    // BatchNorm partial sums: only the upsampling blocks are followed by a norm
+    f32x4 st1[UP ? CT : 1], st2[UP ? CT : 1];
+#pragma unroll
+    for (int ct = 0; ct < (UP ? CT : 1); ++ct) { st1[ct] = f32x4{0, 0, 0, 0}; st2[ct] = f32x4{0, 0, 0, 0}; }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % ntx;
+        const int t2 = tile / ntx;
+        const int ty = t2 % nty;
+        const int fg = t2 / nty;
+        const int f0 = fg * TF, y0 = ty * TH, x0 = tx * TW;
+
+        f32x4 acc[CT][4];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
+
+        float4 wnext[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) wnext[ct] = wbase[ct * 64];
+
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            __syncthreads();   // previous chunk's / tile's LDS reads are done
+            if constexpr (UP) {
+                const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+                for (int idx = tid; idx < TF * LH * LW * C4; idx += 256) {
+                    const int c4 = idx % C4;
+                    int t = idx / C4;
+                    const int rx = t % LW; t /= LW;
+                    const int ry = t % LH;
+                    const int fl = t / LH;
+                    const int f = f0 + fl;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (f < F) {
+                        const int sy = min(max(ly0 + ry, 0), a.Hin - 1);
+                        const int sx = min(max(lx0 + rx, 0), a.Win - 1);
+                        v = load_src4(a, f, sy, sx, chunk * CC + c4 * 4);
+                    }
+                    *reinterpret_cast<float4*>(raw + ((fl * LH + ry) * LW + rx) * CC + c4 * 4) = v;
+                }
+                __syncthreads();
+                for (int idx = tid; idx < TF * RH * RW * C4; idx += 256) {
+                    const int c4 = idx % C4;
+                    int t = idx / C4;
+                    const int rx = t % RW; t /= RW;
+                    const int ry = t % RH;
+                    const int fl = t / RH;
+                    const int Y = y0 - 1 + ry, X = x0 - 1 + rx;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (Y >= 0 && Y < Hout && X >= 0 && X < Wout) {
+                        // torch area_pixel_compute_source_index, align_corners=False, scale 0.5
+                        const float h1r = fmaxf(0.5f * ((float)Y + 0.5f) - 0.5f, 0.f);
+                        const float w1r = fmaxf(0.5f * ((float)X + 0.5f) - 0.5f, 0.f);
+                        const int h1 = (int)h1r, w1 = (int)w1r;
+                        const float lh1 = h1r - (float)h1, lw1 = w1r - (float)w1;
+                        const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+                        const int r0 = h1 - ly0, r1 = r0 + ((h1 < a.Hin - 1) ? 1 : 0);
+                        const int c0 = w1 - lx0, c1 = c0 + ((w1 < a.Win - 1) ? 1 : 0);
+                        const float* rb = raw + (fl * LH) * LW * CC + c4 * 4;
+                        const float4 a00 = *reinterpret_cast<const float4*>(rb + (r0 * LW + c0) * CC);
+                        const float4 a01 = *reinterpret_cast<const float4*>(rb + (r0 * LW + c1) * CC);
+                        const float4 a10 = *reinterpret_cast<const float4*>(rb + (r1 * LW + c0) * CC);
+                        const float4 a11 = *reinterpret_cast<const float4*>(rb + (r1 * LW + c1) * CC);
+                        v.x = lh0 * (lw0 * a00.x + lw1 * a01.x) + lh1 * (lw0 * a10.x + lw1 * a11.x);
+                        v.y = lh0 * (lw0 * a00.y + lw1 * a01.y) + lh1 * (lw0 * a10.y + lw1 * a11.y);
+                        v.z = lh0 * (lw0 * a00.z + lw1 * a01.z) + lh1 * (lw0 * a10.z + lw1 * a11.z);
+                        v.w = lh0 * (lw0 * a00.w + lw1 * a01.w) + lh1 * (lw0 * a10.w + lw1 * a11.w);
+                    }
+                    *reinterpret_cast<float4*>(hi + ((fl * RH + ry) * RW + rx) * CCP + c4 * 4) = v;
+                }
+            } else {
+                for (int idx = tid; idx < TF * RH * RW * C4; idx += 256) {
+                    const int c4 = idx % C4;
+                    int t = idx / C4;
+                    const int rx = t % RW; t /= RW;
+                    const int ry = t % RH;
+                    const int fl = t / RH;
+                    const int Y = y0 - 1 + ry, X = x0 - 1 + rx, f = f0 + fl;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (f < F && Y >= 0 && Y < Hout && X >= 0 && X < Wout)
+                        v = load_src4(a, f, Y, X, chunk * CC + c4 * 4);
+                    *reinterpret_cast<float4*>(hi + ((fl * RH + ry) * RW + rx) * CCP + c4 * 4) = v;
+                }
+            }
+            __syncthreads();
+
+            // ---- MFMA main loop over (tap, 16-channel group) ----
+            // Weights are double-buffered in registers one step ahead; the stream of steps is contiguous across
+            // chunks and the packed buffer carries one zero step of padding, so the prefetch never branches.
+            const float4* wp = wbase + (size_t)chunk * NSTEP * CT * 64;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int tapoff = ((tap / 3) * RW + (tap % 3)) * CCP;
+#pragma unroll
+                for (int cgl = 0; cgl < CC / 16; ++cgl) {
+                    const int st = tap * (CC / 16) + cgl;
+                    float4 wcur[CT];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) wcur[ct] = wnext[ct];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) wnext[ct] = wp[((st + 1) * CT + ct) * 64];
+                    float4 b[4];
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt)
+                        b[pt] = *reinterpret_cast<const float4*>(hi + pixoff[pt] + tapoff + cgl * 16);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                        for (int pt = 0; pt < 4; ++pt) {
+                            acc[ct][pt] = mfma16(wcur[ct].x, b[pt].x, acc[ct][pt]);
+                            acc[ct][pt] = mfma16(wcur[ct].y, b[pt].y, acc[ct][pt]);
+                            acc[ct][pt] = mfma16(wcur[ct].z, b[pt].z, acc[ct][pt]);
+                            acc[ct][pt] = mfma16(wcur[ct].w, b[pt].w, acc[ct][pt]);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue ----
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float4 bv = *reinterpret_cast<const float4*>(a.bias + ct * 16 + q * 4);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                acc[ct][pt][0] += bv.x; acc[ct][pt][1] += bv.y; acc[ct][pt][2] += bv.z; acc[ct][pt][3] += bv.w;
+            }
+        }
+        const int mode = a.head_mode;
+        if (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) {
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                const int f = f0 + pfl[pt];
+                if (f >= F) continue;
+                float* op = a.out + (((size_t)f * Hout + (y0 + py[pt])) * Wout + (x0 + px[pt])) * a.out_pitch;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int c = ct * 16 + q * 4;
+                    if (c < a.out_pitch) {
+                        f32x4 v = acc[ct][pt];
+                        if (a.out_act == GCPX_ACT_LRELU) {
+                            v[0] = lrelu(v[0], 0.2f); v[1] = lrelu(v[1], 0.2f); v[2] = lrelu(v[2], 0.2f); v[3] = lrelu(v[3], 0.2f);
+                        }
+                        *reinterpret_cast<float4*>(op + c) = make_float4(v[0], v[1], v[2], v[3]);
+                        if constexpr (UP) {
+                            if (a.stats_partial) {
+                                st1[ct] += v;
+                                st2[ct] += v * v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (CT >= 5) {
+            if (mode == GCPX_HEAD_DLM_MEAN || mode == GCPX_HEAD_DLM_BOTH) {
+                // kernel channel order: slot 8k..8k+7 = {logit_k, mu_r, mu_g, mu_b, c0, c1, c2, pad}, k = 0..9;
+                // lanes with even q hold the first half of mixture 2*ct + q/2, lane+16 holds the second half.
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    float lg[5], mr[5], mg[5], mb[5];
+#pragma unroll
+                    for (int ct = 0; ct < 5; ++ct) {
+                        const f32x4 v = acc[ct][pt];
+                        const float o0 = __shfl_xor(v[0], 16), o1 = __shfl_xor(v[1], 16), o2 = __shfl_xor(v[2], 16);
+                        const float c0 = tanhf(o0), c1 = tanhf(o1), c2 = tanhf(o2);
+                        lg[ct] = v[0];
+                        mr[ct] = v[1];
+                        mg[ct] = v[2] + c0 * mr[ct];
+                        mb[ct] = v[3] + c1 * mr[ct] + c2 * mg[ct];
+                    }
+                    float m = lg[0];
+#pragma unroll
+                    for (int ct = 1; ct < 5; ++ct) m = fmaxf(m, lg[ct]);
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                    float S = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
+#pragma unroll
+                    for (int ct = 0; ct < 5; ++ct) {
+                        const float w = __expf(lg[ct] - m);
+                        S += w; Sr += w * mr[ct]; Sg += w * mg[ct]; Sb += w * mb[ct];
+                    }
+                    S += __shfl_xor(S, 32); Sr += __shfl_xor(Sr, 32); Sg += __shfl_xor(Sg, 32); Sb += __shfl_xor(Sb, 32);
+                    const int f = f0 + pfl[pt];
+                    if (q == 0 && f < F) {
+                        const float inv = 1.f / S;
+                        const size_t plane = (size_t)Hout * Wout;
+                        float* ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + py[pt]) * Wout + (x0 + px[pt]);
+                        ip[0] = fminf(fmaxf(Sr * inv, -1.f), 1.f);
+                        ip[plane] = fminf(fmaxf(Sg * inv, -1.f), 1.f);
+                        ip[2 * plane] = fminf(fmaxf(Sb * inv, -1.f), 1.f);
+                    }
+                }
+            }
+        }
+        if (mode == GCPX_HEAD_TANH_NCHW) {
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                const int f = f0 + pfl[pt];
+                if (q == 0 && f < F) {
+                    const size_t plane = (size_t)Hout * Wout;
+                    float* ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + py[pt]) * Wout + (x0 + px[pt]);
+                    ip[0] = tanhf(acc[0][pt][0]);
+                    ip[plane] = tanhf(acc[0][pt][1]);
+                    ip[2 * plane] = tanhf(acc[0][pt][2]);
+                }
+            }
+        }
+    }
+
+    // ---- per-workgroup BatchNorm partial sums (deterministic: no atomics) ----
+    if (UP && a.stats_partial) {
+        __syncthreads();
+        float* red = hi;   // [4 waves][2][CT*16]
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = row16_sum(st1[ct][r]);
+                const float s2 = row16_sum(st2[ct][r]);
+                if (j == 0) {
+                    red[(wave * 2 + 0) * CT * 16 + ct * 16 + q * 4 + r] = s1;
+                    red[(wave * 2 + 1) * CT * 16 + ct * 16 + q * 4 + r] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * CT * 16) {
+            const int which = tid / (CT * 16), c = tid % (CT * 16);
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * CT * 16 + c];
+            a.stats_partial[((size_t)blockIdx.x * 2 + which) * CT * 16 + c] = s;
+        }
+    }
+}
+
+int g_conv_grid = 0;
+
+template <bool UP, int CC, int CT, int TILE>
+int launch(const gcpx_conv_args* a, hipStream_t stream) {
+    using Cfg = ConvCfg<UP, CC, CT, TILE>;
+    if (a->Hout % Cfg::TH || a->Wout % Cfg::TW) {
+        gcpx_set_error("conv3x3: output %dx%d not divisible by tile %dx%d", a->Hout, a->Wout, Cfg::TH, Cfg::TW);
+        return GCPX_ERR_UNSUPPORTED;
+    }
+    const int ntx = a->Wout / Cfg::TW, nty = a->Hout / Cfg::TH;
+    const int nfg = (a->F + Cfg::TF - 1) / Cfg::TF;
+    const int ntiles = ntx * nty * nfg;
+    auto kern = conv3x3_kernel<UP, CC, CT, TILE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) {
+            gcpx_set_error("conv3x3: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    int grid = gcpx_conv_grid();
+    // stats_partial has gcpx_conv_grid() rows and every one of them must be written
+    if (!a->stats_partial && grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, *a, ntx, nty, ntiles);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+}  // namespace
+
+extern "C" int gcpx_conv_grid(void) {
+    if (g_conv_grid == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+        }
+        g_conv_grid = cus * 2;
+    }
+    return g_conv_grid;
+}
+
+extern "C" int gcpx_conv3x3(const gcpx_conv_args* a, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(a != nullptr, "null args");
+    GCPX_CHECK_ARG(a->nsrc == 1 || a->nsrc == 2, "nsrc must be 1 or 2");
+    GCPX_CHECK_ARG(a->src[0].C % 16 == 0 && (a->nsrc == 1 || a->src[1].C % 16 == 0), "source channels must be multiples of 16");
+    GCPX_CHECK_ARG(a->Cin == a->src[0].C + (a->nsrc == 2 ? a->src[1].C : 0), "Cin != sum of sources");
+    GCPX_CHECK_ARG(a->wpk && a->bias, "weights/bias missing");
+    GCPX_CHECK_ARG(a->F > 0, "F <= 0");
+    if (a->upsample) GCPX_CHECK_ARG(a->Hout == 2 * a->Hin && a->Wout == 2 * a->Win, "upsample: Hout != 2*Hin");
+    else GCPX_CHECK_ARG(a->Hout == a->Hin && a->Wout == a->Win, "no upsample: Hout != Hin");
+    const int CT = (a->Cout + 15) / 16;
+    const bool need_out = a->head_mode == GCPX_HEAD_RAW || a->head_mode == GCPX_HEAD_DLM_BOTH;
+    GCPX_CHECK_ARG(!need_out || a->out, "out is NULL");
+    GCPX_CHECK_ARG(need_out || a->images, "images is NULL");
+    GCPX_CHECK_ARG(!need_out || a->out_pitch % 4 == 0, "out_pitch % 4");
+    const int W = a->Wout;
+    if (!a->upsample) {
+        GCPX_CHECK_ARG(a->Cin == 16, "non-upsampling 3x3 conv (output head) expects 16 input channels");
+        if (W % 32 == 0) {
+            if (CT == 7) return launch<false, 16, 7, 0>(a, stream);
+            if (CT == 1) return launch<false, 16, 1, 0>(a, stream);
+        }
+    } else {
+        GCPX_CHECK_ARG(a->Cin % 32 == 0, "upsampling 3x3 conv expects Cin % 32 == 0");
+        GCPX_CHECK_ARG(a->head_mode == GCPX_HEAD_RAW, "decoder blocks store raw output");
+        if (W % 32 == 0 && CT == 1) return launch<true, 32, 1, 0>(a, stream);
+        if (W == 16 && CT == 1) return launch<true, 32, 1, 1>(a, stream);
+        if (W == 16 && CT == 2) return launch<true, 32, 2, 1>(a, stream);
+        if (W == 8 && CT == 2) return launch<true, 32, 2, 2>(a, stream);
+        if (W == 8 && CT == 4) return launch<true, 32, 4, 2>(a, stream);
+    }
+    gcpx_set_error("conv3x3: unsupported shape (up=%d Cin=%d Cout=%d W=%d)", a->upsample, a->Cin, a->Cout, W);
+    return GCPX_ERR_UNSUPPORTED;
+}

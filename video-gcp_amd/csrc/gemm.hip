@@ -1,0 +1,220 @@
+// Row GEMM with gathered / concatenated / shifted inputs and fused epilogues, on f32 MFMA (gfx950).
+//
+//   out[r, n] = epi( sum_s sum_k X_s[map_s(r), k] * W[n, koff_s + k] + bias[n] )
+//
+// Replaces the Linear / LSTMCell / Conv1d / 1x1->4x4 ConvTranspose / 4x4-valid Conv launches of
+//   /root/reference/gcp/prediction/models/tree/tree_lstm.py:43-49   (split_linear merge, HiddenStatePredictorModel)
+//   /root/reference/gcp/prediction/models/base_gcp.py:199           (ConvSeqEncodingModule, conv over time)
+//   encoder head / decoder input block (blox, absent; spec in DESIGN.md).
+//
+// Layout: output columns n sit on the MFMA i side (A operand = weights, pre-packed in fragment order so a
+// wavefront's load of 16 columns x 16 k is one coalesced 1 KiB read), rows sit on the j side (B operand: lane
+// (j, kk) reads 16 B = 4 consecutive k of its row, with the producer's BatchNorm affine + LeakyReLU applied on
+// load).  A lane ends with 4 consecutive columns of one row: with gate-interleaved LSTM weights (n = 4u + gate)
+// the whole cell update for (row, unit u) is lane-local.  No LDS, no barriers: wavefronts are independent.
+#include "common.cuh"
+
+namespace {
+
+template <int PR, int CR, bool LSTM>
+__global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int NT = a.N / 16;
+    const int nt0 = (blockIdx.y * 4 + wave) * CR;
+    if (nt0 >= NT) return;
+    const int rowblk = blockIdx.x;
+    const int M = a.M, rpb = a.rpb;
+
+    int rr[PR], rb[PR], rj[PR];
+    bool rv[PR];
+#pragma unroll
+    for (int pt = 0; pt < PR; ++pt) {
+        rr[pt] = (rowblk * PR + pt) * 16 + j;
+        rv[pt] = rr[pt] < M;
+        const int r = rv[pt] ? rr[pt] : 0;
+        rb[pt] = r / rpb;
+        rj[pt] = r % rpb;
+    }
+
+    f32x4 acc[CR][PR];
+#pragma unroll
+    for (int ct = 0; ct < CR; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
+
+    const float4* wbase = reinterpret_cast<const float4*>(a.wpk) + (size_t)nt0 * 64 + lane;
+    int kg0 = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+        const gcpx_row_src src = a.src[s];
+        const float* bp[PR];
+        bool ok[PR];
+#pragma unroll
+        for (int pt = 0; pt < PR; ++pt) {
+            ok[pt] = rv[pt];
+            size_t off = 0;
+            if (src.rowidx) {
+                off = (size_t)src.rowidx[rv[pt] ? rr[pt] : 0] * src.sr;
+            } else {
+                const int jj = rj[pt] + src.shift;
+                ok[pt] = ok[pt] && jj >= 0 && jj < rpb;
+                off = (size_t)rb[pt] * src.sb + (size_t)(ok[pt] ? jj : 0) * src.sr;
+            }
+            bp[pt] = src.ptr + off + q * 4;
+        }
+        const int nkg = src.width / 16;
+
+        for (int kg = 0; kg < nkg; ++kg) {
+            float4 b[PR];
+#pragma unroll
+            for (int pt = 0; pt < PR; ++pt) {
+                b[pt] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[pt]) {
+                    b[pt] = *reinterpret_cast<const float4*>(bp[pt] + kg * 16);
+                    if (src.scale || src.act)
+                        b[pt] = affine_act4(b[pt], src.scale, src.shiftv, (kg * 16 + q * 4) % src.cmod, src.act);
+                }
+            }
+            const float4* wp = wbase + (size_t)(kg0 + kg) * NT * 64;
+#pragma unroll
+            for (int ct = 0; ct < CR; ++ct) {
+                const float4 w = wp[ct * 64];
+#pragma unroll
+                for (int pt = 0; pt < PR; ++pt) {
+                    acc[ct][pt] = mfma16(w.x, b[pt].x, acc[ct][pt]);
+                    acc[ct][pt] = mfma16(w.y, b[pt].y, acc[ct][pt]);
+                    acc[ct][pt] = mfma16(w.z, b[pt].z, acc[ct][pt]);
+                    acc[ct][pt] = mfma16(w.w, b[pt].w, acc[ct][pt]);
+                }
+            }
+        }
+        kg0 += nkg;
+    }
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int ct = 0; ct < CR; ++ct) {
+        const int n = (nt0 + ct) * 16 + q * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + n);
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pt = 0; pt < PR; ++pt) {
+            f32x4 v = acc[ct][pt];
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            if constexpr (LSTM) {
+                if (rv[pt]) {
+                    const int u = (nt0 + ct) * 4 + q;    // hidden unit of this lane; regs = gates i, f, g, o
+                    const float cp = a.c_prev[(size_t)rr[pt] * a.c_prev_stride + u];
+                    const float ig = sigmoidf_(v[0]), fg = sigmoidf_(v[1]), gg = tanhf(v[2]), og = sigmoidf_(v[3]);
+                    const float c = fg * cp + ig * gg;
+                    const float h = og * tanhf(c);
+                    const size_t o = (size_t)rb[pt] * a.hb + (size_t)rj[pt] * a.hrow + u;
+                    a.h_out[o] = h;
+                    a.c_out[o] = c;
+                    if (a.h_copy) a.h_copy[(size_t)rr[pt] * (a.N / 4) + u] = h;
+                }
+            } else {
+                if (a.epi == GCPX_EPI_LRELU) {
+                    v[0] = lrelu(v[0], 0.2f); v[1] = lrelu(v[1], 0.2f); v[2] = lrelu(v[2], 0.2f); v[3] = lrelu(v[3], 0.2f);
+                }
+                if (rv[pt]) {
+                    float* op = a.out + (size_t)rb[pt] * a.ob + (size_t)rj[pt] * a.orow + n;
+                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (a.stats_partial) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+                    }
+                }
+            }
+        }
+        if constexpr (!LSTM) {
+            if (a.stats_partial) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t1 = row16_sum(s1[r]);
+                    const float t2 = row16_sum(s2[r]);
+                    if (j == 0) {
+                        a.stats_partial[((size_t)rowblk * 2 + 0) * a.N + n + r] = t1;
+                        a.stats_partial[((size_t)rowblk * 2 + 1) * a.N + n + r] = t2;
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct TileChoice { int pr, cr; };
+
+TileChoice choose_tile(int M, int N) {
+    const int prs[3] = {4, 2, 1}, crs[3] = {4, 2, 1};
+    TileChoice best{1, 1};
+    long best_wg = -1;
+    // candidates by decreasing tile area; take the first that fills the chip, else the one with most workgroups
+    for (int area = 16; area >= 1; area /= 2) {
+        for (int pi = 0; pi < 3; ++pi)
+            for (int ci = 0; ci < 3; ++ci) {
+                const int pr = prs[pi], cr = crs[ci];
+                if (pr * cr != area) continue;
+                if (N % (16 * cr)) continue;
+                const long rbk = (M + 16 * pr - 1) / (16 * pr);
+                const long cbk = (N / 16 + 4 * cr - 1) / (4 * cr);
+                const long wg = rbk * cbk;
+                if (wg >= 384) return TileChoice{pr, cr};
+                if (wg > best_wg) { best_wg = wg; best = TileChoice{pr, cr}; }
+            }
+    }
+    return best;
+}
+
+template <int PR, int CR>
+void launch_t(const gcpx_gemm_args* a, hipStream_t stream) {
+    const int rbk = (a->M + 16 * PR - 1) / (16 * PR);
+    const int cbk = (a->N / 16 + 4 * CR - 1) / (4 * CR);
+    if (a->epi == GCPX_EPI_LSTM)
+        hipLaunchKernelGGL((gemm_kernel<PR, CR, true>), dim3(rbk, cbk), dim3(256), 0, stream, *a);
+    else
+        hipLaunchKernelGGL((gemm_kernel<PR, CR, false>), dim3(rbk, cbk), dim3(256), 0, stream, *a);
+}
+
+}  // namespace
+
+extern "C" int gcpx_gemm_row_blocks(int32_t M, int32_t N) {
+    const TileChoice t = choose_tile(M, N);
+    return (M + 16 * t.pr - 1) / (16 * t.pr);
+}
+
+extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(a != nullptr, "null args");
+    GCPX_CHECK_ARG(a->nsrc >= 1 && a->nsrc <= 6, "nsrc out of range");
+    GCPX_CHECK_ARG(a->M > 0 && a->N > 0 && a->N % 16 == 0 && a->rpb > 0, "bad M/N/rpb");
+    int ksum = 0;
+    for (int s = 0; s < a->nsrc; ++s) {
+        GCPX_CHECK_ARG(a->src[s].ptr != nullptr, "source pointer is NULL");
+        GCPX_CHECK_ARG(a->src[s].width > 0 && a->src[s].width % 16 == 0, "source width must be a multiple of 16");
+        GCPX_CHECK_ARG(!(a->src[s].scale || a->src[s].act) || a->src[s].cmod > 0, "cmod must be set with scale/act");
+        ksum += a->src[s].width;
+    }
+    GCPX_CHECK_ARG(ksum == a->K, "K != sum of source widths");
+    GCPX_CHECK_ARG(a->wpk != nullptr, "weights missing");
+    if (a->epi == GCPX_EPI_LSTM) {
+        GCPX_CHECK_ARG(a->c_prev && a->h_out && a->c_out, "LSTM epilogue needs c_prev/h_out/c_out");
+    } else {
+        GCPX_CHECK_ARG(a->out != nullptr, "out is NULL");
+    }
+    const TileChoice t = choose_tile(a->M, a->N);
+    switch (t.pr * 10 + t.cr) {
+        case 44: launch_t<4, 4>(a, stream); break;
+        case 42: launch_t<4, 2>(a, stream); break;
+        case 41: launch_t<4, 1>(a, stream); break;
+        case 24: launch_t<2, 4>(a, stream); break;
+        case 22: launch_t<2, 2>(a, stream); break;
+        case 21: launch_t<2, 1>(a, stream); break;
+        case 14: launch_t<1, 4>(a, stream); break;
+        case 12: launch_t<1, 2>(a, stream); break;
+        default: launch_t<1, 1>(a, stream); break;
+    }
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}

@@ -1,0 +1,273 @@
+// Small kernels: BatchNorm statistics finalisation, balanced frame binding (integer, bit-exact), gathers,
+// plus the library's error string, hipGraph and event helpers.
+#include "common.cuh"
+
+#include <cstdarg>
+#include <cstdio>
+
+// ---------------------------------------------------------------------------------------------------
+// error handling
+// ---------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void gcpx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* gcpx_last_error(void) { return g_err; }
+extern "C" int gcpx_version(void) { return GCPX_VERSION; }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm: partial sums -> scale / shift
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ partial, const int n_partial,
+                                                          const int pitch, const int C, const double count,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* running_mean, float* running_var,
+                                                          const float momentum) {
+    const int c = blockIdx.x;
+    const int rep = pitch / C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < n_partial * rep; i += 256) {
+        const int p = i / rep, k = i % rep;
+        s1 += (double)partial[((size_t)p * 2 + 0) * pitch + k * C + c];
+        s2 += (double)partial[((size_t)p * 2 + 1) * pitch + k * C + c];
+    }
+    __shared__ double r1[256], r2[256];
+    r1[threadIdx.x] = s1;
+    r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            r1[threadIdx.x] += r1[threadIdx.x + s];
+            r2[threadIdx.x] += r2[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = r1[0] / count;
+        double var = r2[0] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ void bn_fold_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
+                               const float* __restrict__ gamma, const float* __restrict__ beta, const float eps,
+                               const int C, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = gamma[c] / sqrtf(rv[c] + eps);
+        scale[c] = sc;
+        shift[c] = beta[c] - rm[c] * sc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// balanced binding.  Node at depth-first position p: level l = L-1-ctz(p+1), index j = (p+1) >> (L-l).
+// Descend from the root with the reference's midpoint rule t = trunc((t_l + t_r) / 2) on int64
+// (frame_binding.py:52-54 under torch 1.3).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long trunc_mid(long long tl, long long tr) {
+    const long long s = tl + tr;
+    return s >= 0 ? s / 2 : -((-s) / 2);
+}
+
+__global__ void __launch_bounds__(256) balanced_binding_kernel(const int64_t* __restrict__ end_ind, const int B,
+                                                               const int L, const int T, int32_t* __restrict__ node_t,
+                                                               int32_t* __restrict__ leave,
+                                                               int32_t* __restrict__ frame2node,
+                                                               int32_t* __restrict__ etilde_row,
+                                                               int32_t* __restrict__ seq_len) {
+    const int b = blockIdx.x;
+    const int N = (1 << L) - 1;
+    const long long end = end_ind[b];
+    const int root = (N - 1) / 2;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) frame2node[(size_t)b * T + t] = root;   // D5: argmax of zeros = bf 0
+    if (threadIdx.x == 0) seq_len[b] = (int32_t)(end + 1);
+    __syncthreads();
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+        const int tz = __ffs(p + 1) - 1;
+        const int l = L - 1 - tz;
+        const int jn = (p + 1) >> (tz + 1);
+        long long tl = -1, tr = end + 1, t = 0;    // get_init_inds, frame_binding.py:62-65
+        for (int k = 0; k <= l; ++k) {
+            t = trunc_mid(tl, tr);
+            if (k == l) break;
+            if ((jn >> (l - 1 - k)) & 1) tl = t; else tr = t;
+        }
+        const int keep = !(t == tl || t == tr);     // frame_binding.py:47-48
+        node_t[(size_t)b * N + p] = (int32_t)t;
+        leave[(size_t)b * N + p] = keep;
+        if (keep && t >= 0 && t < T) frame2node[(size_t)b * T + t] = p;
+        if (etilde_row) {
+            long long tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+            etilde_row[(size_t)B * ((1 << l) - 1) + (size_t)b * (1 << l) + jn] = (int32_t)(b * T + tc);
+        }
+    }
+}
+
+__global__ void compact_index_kernel(const int32_t* __restrict__ leave, const int B, const int N, const int T,
+                                     int32_t* __restrict__ dst) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int k = 0;
+    for (int p = 0; p < N; ++p)
+        if (leave[(size_t)b * N + p]) {
+            if (k < T) dst[(size_t)b * T + k] = p;
+            ++k;
+        }
+    for (; k < T; ++k) dst[(size_t)b * T + k] = -1;
+}
+
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          float* __restrict__ out, const int T, const int N,
+                                                          const int idx_offset, const long long row4) {
+    const int bt = blockIdx.x;
+    const int b = bt / T;
+    const int i = idx[bt];
+    float4* o = reinterpret_cast<float4*>(out) + (size_t)bt * row4;
+    if (i < 0) {
+        for (long long k = threadIdx.x; k < row4; k += blockDim.x) o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        const float4* s = reinterpret_cast<const float4*>(src) + ((size_t)b * N + i + idx_offset) * row4;
+        for (long long k = threadIdx.x; k < row4; k += blockDim.x) o[k] = s[k];
+    }
+}
+
+}  // namespace
+
+extern "C" int gcpx_bn_finalize(const float* partial, int32_t n_partial, int32_t pitch, int32_t C, double count,
+                                const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                                float* running_mean, float* running_var, float momentum, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(partial && gamma && beta && scale && shift, "null pointer");
+    GCPX_CHECK_ARG(n_partial > 0 && C > 0 && pitch >= C && pitch % C == 0 && count > 0, "bad sizes");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, partial, n_partial, pitch, C, count, gamma,
+                       beta, eps, scale, shift, running_mean, running_var, momentum);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_bn_fold(const float* running_mean, const float* running_var, const float* gamma,
+                            const float* beta, float eps, int32_t C, float* scale, float* shift, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(running_mean && running_var && gamma && beta && scale && shift && C > 0, "null pointer / C <= 0");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, running_mean, running_var, gamma, beta,
+                       eps, C, scale, shift);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_balanced_binding(const int64_t* end_ind, int32_t B, int32_t L, int32_t T, int32_t* node_t,
+                                     int32_t* leave, int32_t* frame2node, int32_t* etilde_row, int32_t* seq_len,
+                                     void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(end_ind && node_t && leave && frame2node && seq_len, "null pointer");
+    GCPX_CHECK_ARG(B > 0 && L > 0 && L < 20 && T > 0, "bad sizes");
+    hipLaunchKernelGGL(balanced_binding_kernel, dim3(B), dim3(256), 0, stream, end_ind, B, L, T, node_t, leave,
+                       frame2node, etilde_row, seq_len);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_compact_index(const int32_t* leave, int32_t B, int32_t N, int32_t T, int32_t* dst_idx,
+                                  void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(leave && dst_idx && B > 0 && N > 0 && T > 0, "null pointer / bad sizes");
+    hipLaunchKernelGGL(compact_index_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, leave, B, N, T, dst_idx);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_gather_rows(const float* src, const int32_t* idx, float* out, int32_t B, int32_t T, int32_t N,
+                                int32_t idx_offset, int64_t row_floats, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(src && idx && out && B > 0 && T > 0 && N > 0, "null pointer / bad sizes");
+    GCPX_CHECK_ARG(row_floats > 0 && row_floats % 4 == 0, "row_floats must be a positive multiple of 4");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(B * T), dim3(256), 0, stream, src, idx, out, T, N,
+                       idx_offset, (long long)(row_floats / 4));
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// hipGraph + events
+// ---------------------------------------------------------------------------------------------------
+#define GCPX_HIP(call)                                                            \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            gcpx_set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e_)); \
+            return GCPX_ERR_HIP;                                                  \
+        }                                                                         \
+    } while (0)
+
+extern "C" int gcpx_graph_begin(void* stream) {
+    GCPX_HIP(hipStreamBeginCapture(reinterpret_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal));
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_graph_end(void* stream, void** graph_exec) {
+    GCPX_CHECK_ARG(graph_exec != nullptr, "graph_exec is NULL");
+    hipGraph_t graph = nullptr;
+    GCPX_HIP(hipStreamEndCapture(reinterpret_cast<hipStream_t>(stream), &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        gcpx_set_error("gcpx_graph_end: hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return GCPX_ERR_HIP;
+    }
+    *graph_exec = exec;
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_graph_launch(void* graph_exec, void* stream) {
+    GCPX_HIP(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), reinterpret_cast<hipStream_t>(stream)));
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_graph_destroy(void* graph_exec) {
+    GCPX_HIP(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec)));
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_event_create(void** ev) {
+    GCPX_CHECK_ARG(ev != nullptr, "ev is NULL");
+    hipEvent_t e;
+    GCPX_HIP(hipEventCreate(&e));
+    *ev = e;
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_event_record(void* ev, void* stream) {
+    GCPX_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), reinterpret_cast<hipStream_t>(stream)));
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_event_elapsed_ms(void* start, void* stop, float* ms) {
+    GCPX_CHECK_ARG(ms != nullptr, "ms is NULL");
+    GCPX_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
+    GCPX_HIP(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_event_destroy(void* ev) {
+    GCPX_HIP(hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)));
+    return GCPX_OK;
+}

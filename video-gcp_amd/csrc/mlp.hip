@@ -1,0 +1,231 @@
+// Fused Predictor MLP on gfx950: input(in->mid, LReLU), n_mid x (mid->mid, GroupNorm(8), LReLU), head(mid->out)
+// with an optional reparametrised-Gaussian epilogue.  One wavefront carries 16 rows through every layer; hidden
+// activations live in LDS, GroupNorm statistics are reduced with in-lane adds + two 4-lane-column shuffles.
+//
+// Replaces blox.torch.subnetworks.Predictor (absent; spec in DESIGN.md) at the call sites
+//   /root/reference/gcp/prediction/models/tree/tree_module.py:77   (prior p(z | e_l, e_r))
+//   /root/reference/gcp/prediction/models/tree/inference.py:27-35  (gather e_tilde + posterior q)
+//   /root/reference/gcp/prediction/models/tree/tree_module.py:79-94 (sample / reparametrize)
+//   /root/reference/gcp/prediction/models/tree/tree_module.py:105  (MLP LSTM initialiser)
+//   misc.py:48, frame_binding.py:71, base_gcp.py:256, inverse_mdl.py:126, cost_mdl.py:63 (heads).
+#include "common.cuh"
+
+namespace {
+
+template <int MID>
+__global__ void __launch_bounds__(64) mlp_kernel(const gcpx_mlp_args a) {
+    constexpr int NTM = MID / 16;
+    constexpr int PITCH = MID + 4;
+    constexpr int CPG = MID / 8;    // channels per GroupNorm group (gn_groups = 8)
+    static_assert(CPG == 4 || CPG == 16, "GroupNorm group must be one lane (4) or one 16-channel tile");
+    __shared__ float4 hid4[2 * 16 * PITCH / 4];
+    float* hid = reinterpret_cast<float*>(hid4);
+
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int r = blockIdx.x * 16 + j;
+    const bool rv = r < a.M;
+    const int rs = rv ? r : 0;
+    const int rb = rs / a.rpb, rj = rs % a.rpb;
+    const float slope = a.lrelu_slope;
+
+    f32x4 acc[NTM];
+#pragma unroll
+    for (int nt = 0; nt < NTM; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+
+    // ---- input layer: gathered global sources ----
+    {
+        const float4* wbase = reinterpret_cast<const float4*>(a.w_in) + lane;
+        int kg0 = 0;
+        for (int s = 0; s < a.nsrc; ++s) {
+            const gcpx_row_src src = a.src[s];
+            bool ok = rv;
+            size_t off;
+            if (src.rowidx) {
+                off = (size_t)src.rowidx[rs] * src.sr;
+            } else {
+                const int jj = rj + src.shift;
+                ok = ok && jj >= 0 && jj < a.rpb;
+                off = (size_t)rb * src.sb + (size_t)(ok ? jj : 0) * src.sr;
+            }
+            const float* bp = src.ptr + off + q * 4;
+            const int nkg = src.width / 16;
+            for (int kg = 0; kg < nkg; ++kg) {
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) {
+                    b = *reinterpret_cast<const float4*>(bp + kg * 16);
+                    if (src.scale || src.act)
+                        b = affine_act4(b, src.scale, src.shiftv, (kg * 16 + q * 4) % src.cmod, src.act);
+                }
+                const float4* wp = wbase + (size_t)(kg0 + kg) * NTM * 64;
+#pragma unroll
+                for (int nt = 0; nt < NTM; ++nt) {
+                    const float4 w = wp[nt * 64];
+                    acc[nt] = mfma16(w.x, b.x, acc[nt]);
+                    acc[nt] = mfma16(w.y, b.y, acc[nt]);
+                    acc[nt] = mfma16(w.z, b.z, acc[nt]);
+                    acc[nt] = mfma16(w.w, b.w, acc[nt]);
+                }
+            }
+            kg0 += nkg;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTM; ++nt) {
+            const float4 bv = *reinterpret_cast<const float4*>(a.b_in + nt * 16 + q * 4);
+            float4 v = make_float4(lrelu(acc[nt][0] + bv.x, slope), lrelu(acc[nt][1] + bv.y, slope),
+                                   lrelu(acc[nt][2] + bv.z, slope), lrelu(acc[nt][3] + bv.w, slope));
+            *reinterpret_cast<float4*>(hid + j * PITCH + nt * 16 + q * 4) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- hidden layers: mid -> mid, GroupNorm, LReLU ----
+    int cur = 0;
+    for (int l = 0; l < a.n_mid; ++l) {
+        const float* hin = hid + cur * 16 * PITCH;
+        float* hout = hid + (cur ^ 1) * 16 * PITCH;
+        const float4* wbase = reinterpret_cast<const float4*>(a.w_mid) + (size_t)l * NTM * NTM * 64 + lane;
+#pragma unroll
+        for (int nt = 0; nt < NTM; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kg = 0; kg < NTM; ++kg) {
+            const float4 b = *reinterpret_cast<const float4*>(hin + j * PITCH + kg * 16 + q * 4);
+#pragma unroll
+            for (int nt = 0; nt < NTM; ++nt) {
+                const float4 w = wbase[(kg * NTM + nt) * 64];
+                acc[nt] = mfma16(w.x, b.x, acc[nt]);
+                acc[nt] = mfma16(w.y, b.y, acc[nt]);
+                acc[nt] = mfma16(w.z, b.z, acc[nt]);
+                acc[nt] = mfma16(w.w, b.w, acc[nt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTM; ++nt) {
+            const int c = nt * 16 + q * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(a.b_mid + l * MID + c);
+            const float4 gv = *reinterpret_cast<const float4*>(a.gn_gamma + l * MID + c);
+            const float4 be = *reinterpret_cast<const float4*>(a.gn_beta + l * MID + c);
+            float v0 = acc[nt][0] + bv.x, v1 = acc[nt][1] + bv.y, v2 = acc[nt][2] + bv.z, v3 = acc[nt][3] + bv.w;
+            float sum = (v0 + v1) + (v2 + v3);
+            if (CPG == 16) { sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32); }
+            const float mean = sum * (1.f / CPG);
+            const float d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean;
+            float ss = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            if (CPG == 16) { ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32); }
+            const float rstd = rsqrtf(ss * (1.f / CPG) + a.gn_eps);
+            float4 o = make_float4(lrelu(d0 * rstd * gv.x + be.x, slope), lrelu(d1 * rstd * gv.y + be.y, slope),
+                                   lrelu(d2 * rstd * gv.z + be.z, slope), lrelu(d3 * rstd * gv.w + be.w, slope));
+            *reinterpret_cast<float4*>(hout + j * PITCH + c) = o;
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+
+    // ---- head: mid -> out ----
+    const float* hin = hid + cur * 16 * PITCH;
+    float4 b[NTM];
+#pragma unroll
+    for (int kg = 0; kg < NTM; ++kg) b[kg] = *reinterpret_cast<const float4*>(hin + j * PITCH + kg * 16 + q * 4);
+    const int out_pad = (a.out_dim + 15) & ~15;
+    const int NTO = out_pad / 16;
+    const float4* wbase = reinterpret_cast<const float4*>(a.w_out) + lane;
+    const int split = a.out_split > 0 ? a.out_split : a.out_dim;
+    float* orow = a.out ? a.out + (size_t)rb * a.ob + (size_t)rj * a.orow : nullptr;
+
+    if (a.epi == GCPX_MLP_GAUSS) {
+        const int nz = a.out_dim / 2;
+        const int NTZ = nz / 16;
+        const float* erow = a.eps + (size_t)rb * a.eb + (size_t)rj * a.erow;
+        float* zrow = a.z + (size_t)rb * a.zb + (size_t)rj * a.zrow;
+        for (int nt = 0; nt < NTZ; ++nt) {
+            f32x4 am = f32x4{0, 0, 0, 0}, al = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int kg = 0; kg < NTM; ++kg) {
+                const float4 wm = wbase[(kg * NTO + nt) * 64];
+                const float4 wl = wbase[(kg * NTO + nt + NTZ) * 64];
+                am = mfma16(wm.x, b[kg].x, am); al = mfma16(wl.x, b[kg].x, al);
+                am = mfma16(wm.y, b[kg].y, am); al = mfma16(wl.y, b[kg].y, al);
+                am = mfma16(wm.z, b[kg].z, am); al = mfma16(wl.z, b[kg].z, al);
+                am = mfma16(wm.w, b[kg].w, am); al = mfma16(wl.w, b[kg].w, al);
+            }
+            if (rv) {
+                const int n = nt * 16 + q * 4;
+                const float4 bm = *reinterpret_cast<const float4*>(a.b_out + n);
+                const float4 bl = *reinterpret_cast<const float4*>(a.b_out + nz + n);
+                const float4 mu = make_float4(am[0] + bm.x, am[1] + bm.y, am[2] + bm.z, am[3] + bm.w);
+                const float4 ls = make_float4(al[0] + bl.x, al[1] + bl.y, al[2] + bl.z, al[3] + bl.w);
+                if (orow) {
+                    *reinterpret_cast<float4*>(orow + n) = mu;
+                    *reinterpret_cast<float4*>(orow + nz + n) = ls;
+                }
+                const float4 e = *reinterpret_cast<const float4*>(erow + n);
+                float4 z;
+                z.x = mu.x + expf(ls.x) * e.x; z.y = mu.y + expf(ls.y) * e.y;
+                z.z = mu.z + expf(ls.z) * e.z; z.w = mu.w + expf(ls.w) * e.w;
+                *reinterpret_cast<float4*>(zrow + n) = z;
+            }
+        }
+    } else {
+        for (int nt = 0; nt < NTO; ++nt) {
+            f32x4 ao = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int kg = 0; kg < NTM; ++kg) {
+                const float4 w = wbase[(kg * NTO + nt) * 64];
+                ao = mfma16(w.x, b[kg].x, ao);
+                ao = mfma16(w.y, b[kg].y, ao);
+                ao = mfma16(w.z, b[kg].z, ao);
+                ao = mfma16(w.w, b[kg].w, ao);
+            }
+            if (rv) {
+                const int n = nt * 16 + q * 4;
+                if (n < a.out_dim) {
+                    const float4 bv = *reinterpret_cast<const float4*>(a.b_out + n);
+                    const float v[4] = {ao[0] + bv.x, ao[1] + bv.y, ao[2] + bv.z, ao[3] + bv.w};
+                    const int blk = n / split, nn = n % split;
+                    float* op = orow + (size_t)blk * a.oblk + nn;
+                    if (n + 3 < a.out_dim && nn + 3 < split && (((uintptr_t)op) & 15) == 0) {
+                        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int nk = n + k;
+                            if (nk < a.out_dim) orow[(size_t)(nk / split) * a.oblk + nk % split] = v[k];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gcpx_mlp(const gcpx_mlp_args* a, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(a != nullptr, "null args");
+    GCPX_CHECK_ARG(a->nsrc >= 1 && a->nsrc <= 4, "nsrc out of range");
+    GCPX_CHECK_ARG(a->M > 0 && a->rpb > 0, "bad M/rpb");
+    int ksum = 0;
+    for (int s = 0; s < a->nsrc; ++s) {
+        GCPX_CHECK_ARG(a->src[s].ptr != nullptr, "source pointer is NULL");
+        GCPX_CHECK_ARG(a->src[s].width > 0 && a->src[s].width % 16 == 0, "source width must be a multiple of 16");
+        ksum += a->src[s].width;
+    }
+    GCPX_CHECK_ARG(ksum == a->in_dim, "in_dim != sum of source widths");
+    GCPX_CHECK_ARG(a->w_in && a->b_in && a->w_out && a->b_out, "weights missing");
+    GCPX_CHECK_ARG(a->n_mid == 0 || (a->w_mid && a->b_mid && a->gn_gamma && a->gn_beta), "hidden-layer weights missing");
+    if (a->epi == GCPX_MLP_GAUSS) {
+        GCPX_CHECK_ARG(a->out_dim % 32 == 0 && a->eps && a->z, "GAUSS epilogue needs out_dim % 32 == 0, eps, z");
+    } else {
+        GCPX_CHECK_ARG(a->out != nullptr, "out is NULL");
+    }
+    const int grid = (a->M + 15) / 16;
+    if (a->mid == 128) hipLaunchKernelGGL(mlp_kernel<128>, dim3(grid), dim3(64), 0, stream, *a);
+    else if (a->mid == 32) hipLaunchKernelGGL(mlp_kernel<32>, dim3(grid), dim3(64), 0, stream, *a);
+    else {
+        gcpx_set_error("gcpx_mlp: unsupported mid=%d (128 or 32)", a->mid);
+        return GCPX_ERR_UNSUPPORTED;
+    }
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}

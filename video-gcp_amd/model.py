@@ -1,0 +1,719 @@
+"""Host side of the gcp_tree hot path: mirrors the reference's model API
+(/root/reference/gcp/prediction/models/base_gcp.py:29-304, models/tree/tree.py:14-77) and drives the HIP kernels of
+libgcpx.so through ctypes.  torch owns device memory and streams only — every FLOP of the forward runs in
+csrc/*.hip; there is no eager/PyTorch fallback.
+
+Data layout in HBM (fp32):
+  * conv activations NHWC; conv outputs are stored RAW (pre-BatchNorm) and the consumer applies the folded
+    per-channel affine + LeakyReLU while it stages its tile ("normalise on load");
+  * the subgoal tree lives in "position layout": a sequence of P = 2^L + 1 slots per batch element — slot 0 is the
+    start frame latent e_0, slot 2^L the goal latent e_g, and tree node (level l, index j) sits at slot
+    (2j+1) * 2^(L-1-l), i.e. at its depth-first (= temporal) position + 1.  The parents of a node are the slots
+    +-2^(L-1-l) away, so the reference's interleave / bf<->df shuffles (tree_utils.py:37-44, 79-108, 202-232)
+    become strides in the kernels' row maps and no data is ever moved between levels;
+  * decoded images are [B, N, 3, H, W] in depth-first node order (the reference's `tree.df.images`).
+"""
+import ctypes as C
+from contextlib import contextmanager
+
+import torch
+
+from . import packing as pk
+from . import runtime as rt
+from .hparams import GCPHParams
+from .params import init_params, encoder_layers, encoder_skip_layers, decoder_layers
+
+
+def _addr(t, off_elems=0):
+    return t.data_ptr() + 4 * off_elems
+
+
+class _Plan:
+    """A recorded launch sequence (C entry point + argument struct); replayed eagerly or under a hipGraph."""
+
+    def __init__(self):
+        self.ops = []
+        self.keep = []       # keeps argument structs / tensors alive
+        self.graph = None
+
+    def add(self, name, fn, *args):
+        self.ops.append((name, fn, args))
+
+    def run(self, stream):
+        for name, fn, args in self.ops:
+            st = fn(*args, stream)
+            if st != 0:
+                rt.check(st, name)
+
+
+class Outputs(dict):
+    """AttrDict-like container (the reference returns blox.AttrDict)."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class GCPTreeModel:
+    """TreeModel(params, logger) counterpart.  `model(inputs, phase)` -> Outputs."""
+
+    def __init__(self, hp: GCPHParams, params=None, device="cuda", seed=0, materialize_distr=False):
+        self._hp = hp
+        self.device = torch.device(device)
+        self.lib = rt.load_library()          # raises if the HIP extension is missing
+        assert hp.matching_type == "balanced" and hp.tree_lstm == "split_linear" and hp.lstm_init == "mlp"
+        self.sd = {k: v.to(self.device) for k, v in (params or init_params(hp, seed)).items()}
+        self.training = True                  # BatchNorm uses batch statistics (reference trains and validates so)
+        self._sample_prior = False            # ProbabilisticModel._sample_prior (switched by val_mode)
+        self._use_pred_length = False
+        self.materialize_distr = materialize_distr
+        self._bufs = {}
+        self._plans = {}
+        self.use_graph = True
+        self._timed_op = None                 # name of one plan op bracketed by HIP events (bench.py roofline)
+        self._timed_events = []
+        self._pack_all()
+
+    # ------------------------------------------------------------------------------------------------
+    # reference API surface
+    # ------------------------------------------------------------------------------------------------
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    @contextmanager
+    def val_mode(self, pred_length=True):
+        """base_gcp.py:44-53: sample from the prior instead of the posterior."""
+        self._sample_prior, self._use_pred_length = True, pred_length
+        try:
+            yield
+        finally:
+            self._sample_prior, self._use_pred_length = False, False
+
+    def state_dict(self):
+        return dict(self.sd)
+
+    def load_state_dict(self, sd, strict=True):
+        for k, v in sd.items():
+            if k in self.sd:
+                self.sd[k].copy_(v)
+            elif strict:
+                raise KeyError(k)
+        self._pack_all()
+        self._plans.clear()
+
+    def __call__(self, inputs, phase="train", noise=None):
+        return self.forward(inputs, phase, noise)
+
+    # ------------------------------------------------------------------------------------------------
+    # weight packing
+    # ------------------------------------------------------------------------------------------------
+    def _pack_predictor(self, prefix, out_dim):
+        sd = self.sd
+        mid = sd[f"{prefix}.input.linear.weight"].shape[0]
+        n_mid = 0
+        while f"{prefix}.pyramid-{n_mid}.linear.weight" in sd:
+            n_mid += 1
+        out_pad = (out_dim + 15) // 16 * 16
+        d = dict(mid=mid, n_mid=n_mid, out_dim=out_dim, in_dim=sd[f"{prefix}.input.linear.weight"].shape[1])
+        d["w_in"] = pk.pack_gemm(sd[f"{prefix}.input.linear.weight"])
+        d["b_in"] = sd[f"{prefix}.input.linear.bias"].contiguous()
+        if n_mid:
+            d["w_mid"] = torch.stack([pk.pack_gemm(sd[f"{prefix}.pyramid-{i}.linear.weight"]) for i in range(n_mid)]).contiguous()
+            d["b_mid"] = torch.stack([sd[f"{prefix}.pyramid-{i}.linear.bias"] for i in range(n_mid)]).contiguous()
+            d["gn_g"] = torch.stack([sd[f"{prefix}.pyramid-{i}.norm.weight"] for i in range(n_mid)]).contiguous()
+            d["gn_b"] = torch.stack([sd[f"{prefix}.pyramid-{i}.norm.bias"] for i in range(n_mid)]).contiguous()
+        d["w_out"] = pk.pack_gemm(sd[f"{prefix}.head.linear.weight"])
+        d["b_out"] = pk.pad_vec(sd[f"{prefix}.head.linear.bias"], out_pad)
+        return d
+
+    def _pack_all(self):
+        hp, sd = self._hp, self.sd
+        P = {}
+        layers, c_top = encoder_layers(hp)
+        self._enc_layers, self._c_top = layers, c_top
+        P["enc.input.w"] = pk.pack_conv4x4_image(sd["encoder.net.input.conv.weight"])
+        P["enc.input.b"] = sd["encoder.net.input.conv.bias"].contiguous()
+        for name, cin, cout, norm in layers[1:]:
+            P[f"enc.{name}.w"] = pk.pack_conv4x4(sd[f"encoder.net.{name}.conv.weight"])
+            P[f"enc.{name}.b"] = sd[f"encoder.net.{name}.conv.bias"].contiguous()
+        wh = sd["encoder.net.head.weight"]                         # [nz, C, 4, 4] -> K = (y, x, c) of NHWC 4x4xC
+        P["enc.head.w"] = pk.pack_gemm(wh.permute(0, 2, 3, 1).reshape(hp.nz_enc, 16 * c_top))
+        P["enc.head.b"] = sd["encoder.net.head.bias"].contiguous()
+        wt = sd["decoder.net.input.conv.weight"]                   # ConvTranspose2d [nz, Cd, 4, 4] -> n = (y, x, co)
+        P["dec.input.w"] = pk.pack_gemm(wt.permute(2, 3, 1, 0).reshape(16 * c_top, hp.nz_enc))
+        P["dec.input.b"] = sd["decoder.net.input.conv.bias"].repeat(16).contiguous()
+        for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
+            P[f"dec.{name}.w"] = pk.pack_conv3x3(sd[f"decoder.net.{name}.conv.weight"], 32)
+            P[f"dec.{name}.b"] = pk.pad_vec(sd[f"decoder.net.{name}.conv.bias"], (cout + 15) // 16 * 16)
+        hw, hb = sd["decoder.gen_head.conv.weight"], sd["decoder.gen_head.conv.bias"]
+        if hp.decoder_distribution == "discrete_logistic_mixture":
+            perm = pk.dlm_channel_perm(hp.n_mixtures)
+            self._dlm_perm = torch.tensor(perm, device=self.device)
+            P["dec.head.w"] = pk.pack_conv3x3(hw, 16, perm=perm)
+            bk = torch.zeros(len(perm), device=self.device)
+            valid = self._dlm_perm >= 0
+            bk[valid] = hb[self._dlm_perm[valid]]
+            P["dec.head.b"] = bk
+            self._head_pitch = len(perm)
+        else:
+            P["dec.head.w"] = pk.pack_conv3x3(hw, 16)
+            P["dec.head.b"] = pk.pad_vec(hb, 16)
+            self._head_pitch = 16
+        for nm in ["input"] + [f"pyramid-{i}" for i in range(hp.conv_inf_enc_layers)] + ["head"]:
+            w = sd[f"inf_encoder.net.{nm}.conv.weight"]            # [Cout, Cin, k] -> K = (tap, ci)
+            P[f"seq.{nm}.w"] = pk.pack_gemm(w.permute(0, 2, 1).reshape(w.shape[0], -1))
+            P[f"seq.{nm}.b"] = sd[f"inf_encoder.net.{nm}.conv.bias"].contiguous()
+        if hp.regress_length:
+            P["length_pred"] = self._pack_predictor("length_pred.p", hp.max_seq_len)
+        if hp.attach_state_regressor:
+            P["state_regressor"] = self._pack_predictor("state_regressor", hp.state_dim)
+        if hp.attach_inv_mdl:
+            P["inv_mdl"] = self._pack_predictor("inv_mdl.action_pred", hp.n_actions)
+        if hp.attach_cost_mdl:
+            P["cost_mdl"] = self._pack_predictor("cost_mdl.cost_pred", 1)
+        P["existence"] = self._pack_predictor("tree_module.tree_modules.0.binding.existence_predictor", 1)
+        H = hp.nz_mid_lstm
+        for l in range(hp.hierarchy_levels if hp.untied_layers else 1):
+            p = f"tree_module.tree_modules.{l}"
+            T = {}
+            T["prior"] = self._pack_predictor(f"{p}.prior", 2 * hp.nz_vae)
+            T["q"] = self._pack_predictor(f"{p}.inference.q", 2 * hp.nz_vae)
+            T["embed.w"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.embed.weight"])
+            T["embed.b"] = sd[f"{p}.subgoal_pred.embed.bias"].contiguous()
+            for i in range(hp.n_lstm_layers):
+                w, b = pk.lstm_gate_interleave(sd[f"{p}.subgoal_pred.lstm.{i}.weight_ih"], sd[f"{p}.subgoal_pred.lstm.{i}.weight_hh"],
+                                               sd[f"{p}.subgoal_pred.lstm.{i}.bias_ih"], sd[f"{p}.subgoal_pred.lstm.{i}.bias_hh"])
+                T[f"lstm{i}.w"], T[f"lstm{i}.b"] = pk.pack_gemm(w), b
+            T["out.w"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.out.weight"])
+            T["out.b"] = sd[f"{p}.subgoal_pred.out.bias"].contiguous()
+            for j in range(2 * hp.n_lstm_layers):
+                T[f"proj{j}.w"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.projections.{j}.weight"])
+                T[f"proj{j}.b"] = sd[f"{p}.subgoal_pred.projections.{j}.bias"].contiguous()
+            if l == 0:
+                T["init"] = self._pack_predictor(f"{p}.lstm_initializer.net", 2 * hp.lstm_state_dim)
+            P[f"tree{l}"] = T
+        self.pk = P
+
+    # ------------------------------------------------------------------------------------------------
+    # buffers and plan-building helpers
+    # ------------------------------------------------------------------------------------------------
+    def _buf(self, name, shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    @staticmethod
+    def _rowsrc(ptr, sb, sr, width, shift=0, rowidx=None, scale=None, shiftv=None, act=0, cmod=0):
+        s = rt.RowSrc()
+        s.ptr, s.rowidx = ptr, (rowidx.data_ptr() if rowidx is not None else None)
+        s.scale = scale.data_ptr() if scale is not None else None
+        s.shiftv = shiftv.data_ptr() if shiftv is not None else None
+        s.sb, s.sr, s.width, s.shift, s.act, s.cmod = sb, sr, width, shift, act, cmod
+        return s
+
+    def _gemm(self, plan, name, srcs, M, N, rpb, wpk, bias, out=None, ob=0, orow=0, epi=rt.EPI_NONE,
+              stats=None, lstm=None):
+        a = rt.GemmArgs()
+        for i, s in enumerate(srcs):
+            a.src[i] = s
+        a.nsrc, a.M, a.N, a.K, a.rpb = len(srcs), M, N, sum(s.width for s in srcs), rpb
+        a.wpk, a.bias = wpk.data_ptr(), (bias.data_ptr() if bias is not None else None)
+        a.out, a.ob, a.orow, a.epi = out, ob, orow, epi
+        a.stats_partial = stats.data_ptr() if stats is not None else None
+        if lstm is not None:
+            a.c_prev, a.c_prev_stride, a.h_out, a.c_out, a.hb, a.hrow, a.h_copy = lstm
+        plan.keep.append(a)
+        plan.add(name, self.lib.gcpx_gemm, C.byref(a))
+
+    def _mlp(self, plan, name, W, srcs, M, rpb, out=None, ob=0, orow=0, oblk=0, out_split=0, gauss=None):
+        hp = self._hp
+        a = rt.MlpArgs()
+        for i, s in enumerate(srcs):
+            a.src[i] = s
+        a.nsrc, a.M, a.rpb = len(srcs), M, rpb
+        a.in_dim, a.mid, a.n_mid, a.out_dim = W["in_dim"], W["mid"], W["n_mid"], W["out_dim"]
+        assert a.in_dim == sum(s.width for s in srcs), (name, a.in_dim)
+        a.w_in, a.b_in = W["w_in"].data_ptr(), W["b_in"].data_ptr()
+        if W["n_mid"]:
+            a.w_mid, a.b_mid = W["w_mid"].data_ptr(), W["b_mid"].data_ptr()
+            a.gn_gamma, a.gn_beta = W["gn_g"].data_ptr(), W["gn_b"].data_ptr()
+        a.w_out, a.b_out = W["w_out"].data_ptr(), W["b_out"].data_ptr()
+        a.gn_eps, a.lrelu_slope = hp.gn_eps, hp.leaky_slope
+        a.out, a.ob, a.orow, a.oblk, a.out_split = out, ob, orow, oblk, out_split
+        a.epi = rt.MLP_PLAIN
+        if gauss is not None:
+            a.epi = rt.MLP_GAUSS
+            a.eps, a.eb, a.erow, a.z, a.zb, a.zrow = gauss
+        plan.keep.append(a)
+        plan.add(name, self.lib.gcpx_mlp, C.byref(a))
+
+    def _bn(self, plan, tag, prefix, C_, stats, n_partial, pitch, count):
+        """(scale, shift) of a BatchNorm: batch statistics when training, running statistics otherwise."""
+        sd, hp = self.sd, self._hp
+        scale, shift = self._buf(f"{tag}.scale", (C_,)), self._buf(f"{tag}.shift", (C_,))
+        g, b = sd[f"{prefix}.weight"], sd[f"{prefix}.bias"]
+        if self.training:
+            plan.add(f"bn_finalize:{tag}", self.lib.gcpx_bn_finalize, stats.data_ptr(), n_partial, pitch, C_,
+                     C.c_double(float(count)), g.data_ptr(), b.data_ptr(), C.c_float(hp.bn_eps), scale.data_ptr(),
+                     shift.data_ptr(), None, None, C.c_float(0.0))
+        else:
+            plan.add(f"bn_fold:{tag}", self.lib.gcpx_bn_fold, sd[f"{prefix}.running_mean"].data_ptr(),
+                     sd[f"{prefix}.running_var"].data_ptr(), g.data_ptr(), b.data_ptr(), C.c_float(hp.bn_eps), C_,
+                     scale.data_ptr(), shift.data_ptr())
+        return scale, shift
+
+    def _conv_args(self, srcs, F, Hin, Win, Hout, Wout, Cout, out_pitch, wpk, bias, out, upsample=0, out_act=0,
+                   head_mode=rt.HEAD_RAW, images=None, stats=None):
+        a = rt.ConvArgs()
+        cin = 0
+        for i, (t_ptr, C_, fdiv, scale, shift, act) in enumerate(srcs):
+            s = a.src[i]
+            s.ptr, s.C, s.frame_div, s.act = t_ptr, C_, fdiv, act
+            s.scale = scale.data_ptr() if scale is not None else None
+            s.shift = shift.data_ptr() if shift is not None else None
+            cin += C_
+        a.nsrc, a.F, a.Hin, a.Win, a.Hout, a.Wout, a.Cin, a.Cout = len(srcs), F, Hin, Win, Hout, Wout, cin, Cout
+        a.out_pitch, a.upsample, a.out_act, a.head_mode = out_pitch, upsample, out_act, head_mode
+        a.wpk, a.bias = wpk.data_ptr(), bias.data_ptr()
+        a.out = out.data_ptr() if out is not None else None
+        a.images = images.data_ptr() if images is not None else None
+        a.stats_partial = stats.data_ptr() if stats is not None else None
+        return a
+
+    # ------------------------------------------------------------------------------------------------
+    # plan: encoder
+    # ------------------------------------------------------------------------------------------------
+    def _plan_encoder(self, plan, tag, x_ptr, F, out_ptr, out_ob, out_orow, out_rpb):
+        """Encoder over F NCHW frames at x_ptr; writes the nz_enc latent of frame r=(b,j) to
+        out_ptr + b*out_ob + j*out_orow.  Returns the skip sources {module index: (tensor, C, scale, shift, act)}."""
+        hp, P, lib = self._hp, self.pk, self.lib
+        G = lib.gcpx_conv_grid()
+        S = hp.img_sz
+        skip_idx = encoder_skip_layers(hp)
+        skips = {}
+        a0 = self._buf(f"{tag}.a0", (F, S // 2, S // 2, hp.ngf))
+        plan.add(f"enc.input:{tag}", lib.gcpx_conv4x4s2_image, x_ptr, P["enc.input.w"].data_ptr(),
+                 P["enc.input.b"].data_ptr(), a0.data_ptr(), F, S, S, hp.ngf, rt.ACT_LRELU)
+        prev = (a0.data_ptr(), hp.ngf, 1, None, None, rt.ACT_NONE)
+        if 0 in skip_idx:
+            skips[0] = (a0, hp.ngf, None, None, rt.ACT_NONE)
+        res = S // 2
+        for li, (name, cin, cout, norm) in enumerate(self._enc_layers[1:], start=1):
+            r = self._buf(f"{tag}.r{li}", (F, res // 2, res // 2, cout))
+            stats = self._buf(f"{tag}.st{li}", (G, 2, cout)) if self.training else None
+            a = self._conv_args([prev], F, res, res, res // 2, res // 2, cout, cout, P[f"enc.{name}.w"],
+                                P[f"enc.{name}.b"], r, stats=stats)
+            plan.keep.append(a)
+            plan.add(f"enc.{name}:{tag}", lib.gcpx_conv4x4s2, C.byref(a))
+            res //= 2
+            scale, shift = self._bn(plan, f"{tag}.bn{li}", f"encoder.net.{name}.norm", cout, stats, G, cout,
+                                    F * res * res)
+            prev = (r.data_ptr(), cout, 1, scale, shift, rt.ACT_LRELU)
+            if li in skip_idx:
+                skips[li] = (r, cout, scale, shift, rt.ACT_LRELU)
+        assert res == 4
+        ctop = self._c_top
+        src = self._rowsrc(prev[0], 16 * ctop, 16 * ctop, 16 * ctop, scale=prev[3], shiftv=prev[4], act=prev[5], cmod=ctop)
+        # rows are frames; caller's row map decides where each latent lands
+        src.sb, src.sr = out_rpb * 16 * ctop, 16 * ctop
+        self._gemm(plan, f"enc.head:{tag}", [src], F, hp.nz_enc, out_rpb, P["enc.head.w"], P["enc.head.b"],
+                   out=out_ptr, ob=out_ob, orow=out_orow)
+        return skips
+
+    # ------------------------------------------------------------------------------------------------
+    # plan: whole forward
+    # ------------------------------------------------------------------------------------------------
+    def _build_plan(self, key, tin):
+        hp, P, lib = self._hp, self.pk, self.lib
+        B, has_traj, has_z, sample_prior, phase = key[0], key[1], key[2], key[3], key[4]
+        L, T, N = hp.hierarchy_levels, hp.max_seq_len, hp.n_nodes
+        nz, nv, H, SD = hp.nz_enc, hp.nz_vae, hp.nz_mid_lstm, hp.lstm_state_dim
+        PS = 2 ** L + 1                                     # slots per batch element
+        plan = _Plan()
+        G = lib.gcpx_conv_grid()
+
+        E = self._buf("E", (B, PS, nz))
+        Hid = self._buf("Hid", (B, PS, SD))
+        Z = self._buf("Z", (B, PS, nv))
+        PZ = self._buf("PZ", (B, PS, 2 * nv))
+        QZ = self._buf("QZ", (B, PS, 2 * nv))
+        node_t = self._buf("node_t", (B, N), torch.int32)
+        leave = self._buf("leave", (B, N), torch.int32)
+        f2n = self._buf("frame2node", (B, T), torch.int32)
+        etrow = self._buf("etilde_row", (B * N,), torch.int32)
+        seq_len = self._buf("seq_len", (B,), torch.int32)
+        kept_idx = self._buf("kept_idx", (B, T), torch.int32)
+
+        # ---- integer bookkeeping (frame_binding.py:42-65, evaluation_matching.py:192-206) ----
+        plan.add("balanced_binding", lib.gcpx_balanced_binding, tin["end_ind"].data_ptr(), B, L, T, node_t.data_ptr(),
+                 leave.data_ptr(), f2n.data_ptr(), etrow.data_ptr(), seq_len.data_ptr())
+        plan.add("compact_index", lib.gcpx_compact_index, leave.data_ptr(), B, N, T, kept_idx.data_ptr())
+
+        # ---- run_encoder (base_gcp.py:184-213) ----
+        enc_traj = inf_enc = None
+        if has_traj:
+            enc_traj = self._buf("enc_traj", (B * T, nz))
+            self._plan_encoder(plan, "traj", tin["traj_seq"].data_ptr(), B * T, enc_traj.data_ptr(), T * nz, nz, T)
+            # ConvSeqEncodingModule: three conv1d over time as shifted-row GEMMs
+            y1 = self._buf("seq.y1", (B * T, hp.nz_mid))
+            y2 = self._buf("seq.y2", (B * T, hp.nz_mid))
+            inf_enc = self._buf("inf_enc_seq", (B * T, nz))
+            taps = lambda t, w, **kw: [self._rowsrc(t.data_ptr(), T * w, w, w, shift=d, **kw) for d in (-1, 0, 1)]
+            self._gemm(plan, "seq.input", taps(enc_traj, nz), B * T, hp.nz_mid, T, P["seq.input.w"], P["seq.input.b"],
+                       out=y1.data_ptr(), ob=T * hp.nz_mid, orow=hp.nz_mid, epi=rt.EPI_LRELU)
+            assert hp.conv_inf_enc_layers == 1
+            nrb = lib.gcpx_gemm_row_blocks(B * T, hp.nz_mid)
+            st = self._buf("seq.st", (nrb, 2, hp.nz_mid)) if self.training else None
+            self._gemm(plan, "seq.pyramid-0", taps(y1, hp.nz_mid), B * T, hp.nz_mid, T, P["seq.pyramid-0.w"],
+                       P["seq.pyramid-0.b"], out=y2.data_ptr(), ob=T * hp.nz_mid, orow=hp.nz_mid, stats=st)
+            sc, sh = self._bn(plan, "seq.bn", "inf_encoder.net.pyramid-0.norm", hp.nz_mid, st, nrb, hp.nz_mid, B * T)
+            self._gemm(plan, "seq.head", taps(y2, hp.nz_mid, scale=sc, shiftv=sh, act=rt.ACT_LRELU, cmod=hp.nz_mid),
+                       B * T, nz, T, P["seq.head.w"], P["seq.head.b"], out=inf_enc.data_ptr(), ob=T * nz, orow=nz)
+        skips = self._plan_encoder(plan, "I0", tin["I_0"].data_ptr(), B, _addr(E), PS * nz, 0, 1)
+        self._plan_encoder(plan, "Ig", tin["I_g"].data_ptr(), B, _addr(E, 2 ** L * nz), PS * nz, 0, 1)
+        e0 = lambda: self._rowsrc(_addr(E), PS * nz, 0, nz)
+        eg = lambda: self._rowsrc(_addr(E, 2 ** L * nz), PS * nz, 0, nz)
+
+        # ---- get_end_ind: length predictor (misc.py:45-51) ----
+        outs = {}
+        if hp.regress_length:
+            logits = self._buf("seq_len_logits", (B, T))
+            self._mlp(plan, "length_pred", P["length_pred"], [e0(), eg()], B, 1, out=logits.data_ptr(), ob=T, orow=0)
+            outs["seq_len_logits"] = logits
+
+        # ---- predict_sequence: level-serial tree (tree_utils.py:21-44, tree_module.py:67-114) ----
+        for l in range(L):
+            W = P[f"tree{l if hp.untied_layers else 0}"]
+            s = 2 ** (L - 1 - l)
+            n = 2 ** l
+            M = B * n
+            nodeoff = lambda w: s * w                       # first node of this level inside a batch element
+            el = lambda: self._rowsrc(_addr(E), PS * nz, 2 * s * nz, nz)
+            er = lambda: self._rowsrc(_addr(E, 2 * s * nz), PS * nz, 2 * s * nz, nz)
+            pz_out = (_addr(PZ, nodeoff(2 * nv)), PS * 2 * nv, 2 * s * 2 * nv)
+            z_map = (_addr(Z, nodeoff(nv)), PS * nv, 2 * s * nv)
+            if has_z:
+                # given latents in depth-first order (tree.py:38); reparametrised with the learned prior (:79-82)
+                g = (_addr(tin["z"], (s - 1) * nv), N * nv, 2 * s * nv) + z_map
+                self._mlp(plan, f"prior{l}", W["prior"], [el(), er()], M, n, out=pz_out[0], ob=pz_out[1], orow=pz_out[2], gauss=g)
+            elif sample_prior:
+                g = (_addr(tin["eps"], (n - 1) * nv), N * nv, nv) + z_map
+                self._mlp(plan, f"prior{l}", W["prior"], [el(), er()], M, n, out=pz_out[0], ob=pz_out[1], orow=pz_out[2], gauss=g)
+            else:
+                self._mlp(plan, f"prior{l}", W["prior"], [el(), er()], M, n, out=pz_out[0], ob=pz_out[1], orow=pz_out[2])
+                # posterior: gather inf_enc_seq at the node's matched timestep (inference.py:27-33)
+                et = self._rowsrc(inf_enc.data_ptr(), 0, nz, nz, rowidx=etrow[B * (n - 1):])
+                g = (_addr(tin["eps"], (n - 1) * nv), N * nv, nv) + z_map
+                self._mlp(plan, f"posterior{l}", W["q"], [el(), er(), et], M, n, out=_addr(QZ, nodeoff(2 * nv)),
+                          ob=PS * 2 * nv, orow=2 * s * 2 * nv, gauss=g)
+            zs = lambda: self._rowsrc(z_map[0], z_map[1], z_map[2], nv)
+            if l == 0:
+                # MLPLSTMCellInitializer (tree_module.py:104-105): (h_left, h_right) -> slots 0 and 2^L
+                self._mlp(plan, "lstm_init", W["init"], [el(), er(), zs()], M, n, out=_addr(Hid), ob=PS * SD, orow=0,
+                          oblk=2 ** L * SD, out_split=SD)
+            # split_linear merge of the parents' hidden states (tree_lstm.py:43-48)
+            nl = hp.n_lstm_layers
+            merged = self._buf(f"merged{l}", (M, 2 * nl * H))
+            for jj in range(2 * nl):
+                h1 = self._rowsrc(_addr(Hid, jj * H), PS * SD, 2 * s * SD, H)
+                h2 = self._rowsrc(_addr(Hid, 2 * s * SD + jj * H), PS * SD, 2 * s * SD, H)
+                self._gemm(plan, f"merge{l}.{jj}", [h1, h2], M, H, n, W[f"proj{jj}.w"], W[f"proj{jj}.b"],
+                           out=_addr(merged, jj * H), ob=n * 2 * nl * H, orow=2 * nl * H)
+            # input embedding of [e_l, e_r, z, e_0, e_g] (tree_module.py:97-101)
+            x = self._buf(f"x{l}.0", (M, H))
+            srcs = [el(), er(), zs()] + ([e0(), eg()] if hp.context_every_step else [])
+            self._gemm(plan, f"embed{l}", srcs, M, H, n, W["embed.w"], W["embed.b"], out=x.data_ptr(), ob=n * H, orow=H)
+            for i in range(nl):
+                xn = self._buf(f"x{l}.{i + 1}", (M, H))
+                xs = self._rowsrc(x.data_ptr(), n * H, H, H)
+                hs = self._rowsrc(_addr(merged, 2 * i * H), n * 2 * nl * H, 2 * nl * H, H)
+                lstm = (_addr(merged, (2 * i + 1) * H), 2 * nl * H, _addr(Hid, nodeoff(SD) + 2 * i * H),
+                        _addr(Hid, nodeoff(SD) + (2 * i + 1) * H), PS * SD, 2 * s * SD, xn.data_ptr())
+                self._gemm(plan, f"lstm{l}.{i}", [xs, hs], M, 4 * H, n, W[f"lstm{i}.w"], W[f"lstm{i}.b"],
+                           epi=rt.EPI_LSTM, lstm=lstm)
+                x = xn
+            self._gemm(plan, f"out{l}", [self._rowsrc(x.data_ptr(), n * H, H, H)], M, nz, n, W["out.w"], W["out.b"],
+                       out=_addr(E, nodeoff(nz)), ob=PS * nz, orow=2 * s * nz)
+
+        # ---- dense_rec: decode every node (tree_dense_rec.py:41-44) ----
+        F = B * N
+        S = hp.img_sz
+        ctop = self._c_top
+        d0 = self._buf("dec.d0", (F, 4, 4, ctop))
+        nrb = lib.gcpx_gemm_row_blocks(F, 16 * ctop)
+        st = self._buf("dec.st0", (nrb, 2, 16 * ctop)) if self.training else None
+        self._gemm(plan, "dec.input", [self._rowsrc(_addr(E, nz), PS * nz, nz, nz)], F, 16 * ctop, N, P["dec.input.w"],
+                   P["dec.input.b"], out=d0.data_ptr(), ob=N * 16 * ctop, orow=16 * ctop, stats=st)
+        sc, sh = self._bn(plan, "dec.bn0", "decoder.net.input.norm", ctop, st, nrb, 16 * ctop, F * 16)
+        prev = (d0.data_ptr(), ctop, 1, sc, sh, rt.ACT_LRELU)
+        res = 4
+        for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
+            srcs = [prev]
+            if skip_idx >= 0:
+                t, C_, ssc, ssh, sact = skips[skip_idx]
+                assert C_ == c_skip and t.shape[1] == res
+                srcs.append((t.data_ptr(), C_, N, ssc, ssh, sact))      # skips of I_0 broadcast over the node axis
+            o = self._buf(f"dec.{name}", (F, 2 * res, 2 * res, cout))
+            st = self._buf(f"dec.st.{name}", (G, 2, (cout + 15) // 16 * 16)) if self.training else None
+            a = self._conv_args(srcs, F, res, res, 2 * res, 2 * res, cout, cout, P[f"dec.{name}.w"], P[f"dec.{name}.b"],
+                                o, upsample=1, stats=st)
+            plan.keep.append(a)
+            plan.add(f"dec.{name}", lib.gcpx_conv3x3, C.byref(a))
+            res *= 2
+            sc, sh = self._bn(plan, f"dec.bn.{name}", f"decoder.net.{name}.norm", cout, st, G,
+                              (cout + 15) // 16 * 16, F * res * res)
+            prev = (o.data_ptr(), cout, 1, sc, sh, rt.ACT_LRELU)
+        assert res == S
+        images = self._buf("images_df", (B, N, hp.input_nc, S, S))
+        distr = None
+        if hp.decoder_distribution == "discrete_logistic_mixture":
+            mode = rt.HEAD_DLM_BOTH if self.materialize_distr else rt.HEAD_DLM_MEAN
+            if self.materialize_distr:
+                distr = self._buf("distr_df", (B, N, S, S, self._head_pitch))
+        else:
+            mode = rt.HEAD_TANH_NCHW
+        a = self._conv_args([prev], F, S, S, S, S, hp.head_channels, self._head_pitch, P["dec.head.w"], P["dec.head.b"],
+                            distr, upsample=0, head_mode=mode, images=images)
+        plan.keep.append(a)
+        plan.add("dec.head", lib.gcpx_conv3x3, C.byref(a))
+        outs["images_df"], outs["distr_df_kernel_order"] = images, distr
+
+        # ---- pruning / matching gathers ----
+        row = hp.input_nc * S * S
+        if has_traj and phase == "train":
+            matched = self._buf("matched_images", (B, T, hp.input_nc, S, S))
+            plan.add("gather.matched", lib.gcpx_gather_rows, images.data_ptr(), f2n.data_ptr(), matched.data_ptr(), B, T, N,
+                     0, row)
+            outs["soft_matched_estimates"] = matched
+        pruned = self._buf("pruned_images", (B, T, hp.input_nc, S, S))
+        plan.add("gather.pruned", lib.gcpx_gather_rows, images.data_ptr(), kept_idx.data_ptr(), pruned.data_ptr(), B, T, N, 0,
+                 row)
+        mes = self._buf("model_enc_seq", (B, T, nz))
+        plan.add("gather.model_enc_seq", lib.gcpx_gather_rows, E.data_ptr(), kept_idx.data_ptr(), mes.data_ptr(), B, T, PS, 1,
+                 nz)
+        outs["pruned_padded"], outs["model_enc_seq_padded"] = pruned, mes
+        # existence predictor over depth-first latents (frame_binding.py:67-78)
+        exist = self._buf("existence", (B, N))
+        self._mlp(plan, "existence", P["existence"], [self._rowsrc(_addr(E, nz), PS * nz, nz, nz)], F, N,
+                  out=exist.data_ptr(), ob=N, orow=1)
+        outs["existence"] = exist
+
+        # ---- run_auxilliary_models (base_gcp.py:234-262) ----
+        if hp.attach_state_regressor:
+            rs = self._buf("regressed_state", (B, T, hp.state_dim))
+            self._mlp(plan, "state_regressor", P["state_regressor"], [self._rowsrc(mes.data_ptr(), T * nz, nz, nz)],
+                      B * T, T, out=rs.data_ptr(), ob=T * hp.state_dim, orow=hp.state_dim)
+            outs["regressed_state_padded"] = rs
+        if hp.attach_inv_mdl and phase == "train":
+            # InverseModel.full_seq_forward (inverse_mdl.py:110-134)
+            act = self._buf("actions", (B, T - 1, hp.n_actions))
+            first = enc_traj if has_traj else mes
+            s0 = self._rowsrc(first.data_ptr(), T * nz, nz, nz)
+            s1 = self._rowsrc(_addr(mes, nz), T * nz, nz, nz)
+            self._mlp(plan, "inv_mdl", P["inv_mdl"], [s0, s1], B * (T - 1), T - 1, out=act.data_ptr(),
+                      ob=(T - 1) * hp.n_actions, orow=hp.n_actions)
+            outs["actions_padded"] = act
+
+        outs.update(E=E, Hid=Hid, Z=Z, PZ=PZ, QZ=QZ, node_t=node_t, leave=leave, frame2node=f2n, seq_len=seq_len,
+                    kept_idx=kept_idx, enc_traj_seq=enc_traj, inf_enc_seq=inf_enc)
+        plan.outs = outs
+        return plan
+
+    # ------------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, inputs, phase="train", noise=None):
+        """BaseGCPModel.forward (base_gcp.py:140-161).
+
+        inputs: dict with I_0, I_g [B,3,H,W], end_ind int64 [B]; optional traj_seq [B,T,3,H,W], z [B,N,nz_vae]
+        (depth-first node order).  `noise` [B,N,nz_vae] (breadth-first node order) replaces the RNG draws of
+        Gaussian.sample(); when None it is drawn with torch.randn on the device.
+        """
+        hp = self._hp
+        B = inputs["I_0"].shape[0]
+        has_traj = "traj_seq" in inputs and not self._sample_prior
+        has_z = "z" in inputs
+        if not has_traj and not has_z and not self._sample_prior:
+            raise ValueError("posterior path needs traj_seq (or use val_mode() / feed z)")
+        if "end_ind" not in inputs:
+            raise ValueError("end_ind must be fed (sampled lengths are not part of the hot path, SURVEY D3)")
+        tin = {}
+        for k in ("I_0", "I_g", "end_ind") + (("traj_seq",) if has_traj else ()) + (("z",) if has_z else ()):
+            t = inputs[k]
+            want = torch.int64 if k == "end_ind" else torch.float32
+            if t.device != self.device or t.dtype != want or not t.is_contiguous():
+                t = t.to(device=self.device, dtype=want).contiguous()
+            tin[k] = t
+        if not has_z:
+            # the draws of Gaussian.sample() live in a persistent buffer so the captured graph stays valid
+            eps = self._buf("eps", (B, hp.n_nodes, hp.nz_vae))
+            if noise is None:
+                eps.normal_()
+            else:
+                eps.copy_(noise)
+            tin["eps"] = eps
+        key = (B, has_traj, has_z, self._sample_prior, phase, self.training, self.materialize_distr)
+        ptrs = tuple(sorted((k, v.data_ptr()) for k, v in tin.items()))
+        cached = self._plans.get(key)
+        if cached is None or cached[0] != ptrs:
+            if cached is not None and cached[1].graph is not None:
+                self.lib.gcpx_graph_destroy(cached[1].graph)
+            plan = self._build_plan(key, tin)
+            plan.keep.append(tin)
+            self._plans[key] = (ptrs, plan)
+        plan = self._plans[key][1]
+        stream = rt.current_stream()
+        if self._timed_op is not None:
+            self._run_timed(plan, stream)
+        elif self.use_graph:
+            if plan.graph is None:
+                plan.run(stream)                      # warm-up (sets kernel attributes) outside capture
+                plan.graph = self._capture(plan.ops, stream)
+            rt.check(self.lib.gcpx_graph_launch(plan.graph, stream), "graph_launch")
+        else:
+            plan.run(stream)
+        return self._wrap_outputs(plan.outs, tin, phase)
+
+    def _capture(self, ops, stream):
+        rt.check(self.lib.gcpx_graph_begin(stream), "graph_begin")
+        for name, fn, args in ops:
+            st = fn(*args, stream)
+            if st != 0:
+                rt.check(st, name)
+        g = C.c_void_p()
+        rt.check(self.lib.gcpx_graph_end(stream, C.byref(g)), "graph_end")
+        return g
+
+    # ---- one op of the plan bracketed by HIP events on the launch stream (roofline measurement) ----
+    def set_timed_op(self, name):
+        self._timed_op = name
+        self._timed_events = []
+
+    def _run_timed(self, plan, stream):
+        names = [n for n, _, _ in plan.ops]
+        i = names.index(self._timed_op)
+        if getattr(plan, "split", None) is None:
+            plan.run(stream)
+            plan.split = (self._capture(plan.ops[:i], stream), self._capture(plan.ops[i + 1:], stream))
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        rt.check(self.lib.gcpx_event_create(C.byref(e0)), "event_create")
+        rt.check(self.lib.gcpx_event_create(C.byref(e1)), "event_create")
+        rt.check(self.lib.gcpx_graph_launch(plan.split[0], stream), "graph_launch")
+        rt.check(self.lib.gcpx_event_record(e0, stream), "event_record")
+        name, fn, args = plan.ops[i]
+        rt.check(fn(*args, stream), name)
+        rt.check(self.lib.gcpx_event_record(e1, stream), "event_record")
+        rt.check(self.lib.gcpx_graph_launch(plan.split[1], stream), "graph_launch")
+        self._timed_events.append((e0, e1))
+
+    def timed_op_ms(self):
+        """Durations (ms) of the timed op for every forward since set_timed_op(); synchronises."""
+        out = []
+        for e0, e1 in self._timed_events:
+            ms = C.c_float()
+            rt.check(self.lib.gcpx_event_elapsed_ms(e0, e1, C.byref(ms)), "event_elapsed")
+            out.append(ms.value)
+            self.lib.gcpx_event_destroy(e0)
+            self.lib.gcpx_event_destroy(e1)
+        self._timed_events = []
+        return out
+
+    def _wrap_outputs(self, o, tin, phase):
+        hp = self._hp
+        out = Outputs()
+        out.end_ind = tin["end_ind"]
+        out.raw = o
+        out.images_df = o["images_df"]
+        if "seq_len_logits" in o:
+            out.seq_len_logits = o["seq_len_logits"]
+        out.existence_predictor = Outputs(existence=o["existence"])
+        if "soft_matched_estimates" in o:
+            out.soft_matched_estimates = o["soft_matched_estimates"]
+        out.tree = TreeView(self, o)
+        out.dense_rec = Outputs()
+        out._lazy = (o, tin)
+        return out
+
+    # ---- ragged views: these synchronise (they read seq_len on the host), keep them out of timed regions ----
+    def pruned_prediction(self, out):
+        """outputs.pruned_prediction: list of [len_b, 3, H, W] (tree.py:62-65)."""
+        o = out.raw
+        lens = o["seq_len"].tolist()
+        return [o["pruned_padded"][b, :lens[b]] for b in range(len(lens))]
+
+    def aux_outputs(self, out):
+        o = out.raw
+        m = int(o["seq_len"].max().item())
+        res = Outputs(model_enc_seq=o["model_enc_seq_padded"][:, :m])
+        if "regressed_state_padded" in o:
+            res.regressed_state = o["regressed_state_padded"][:, :m]
+        if "actions_padded" in o:
+            res.actions = o["actions_padded"][:, :m - 1]
+        return res
+
+
+class TreeView:
+    """`outputs.tree` with `.bf` / `.df` accessors (tree_utils.py:165-199).  Depth-first order is the native
+    layout; breadth-first views are index_selects."""
+
+    def __init__(self, model, o):
+        self._m, self._o = model, o
+        hp = model._hp
+        L = hp.hierarchy_levels
+        self.depth = L
+        idx = torch.empty(2 ** L - 1, dtype=torch.long)
+        for l in range(L):
+            for j in range(2 ** l):
+                idx[2 ** l - 1 + j] = (2 * j + 1) * 2 ** (L - 1 - l) - 1
+        self._bf2df = idx.to(model.device)
+
+    def _df(self, name):
+        o, hp = self._o, self._m._hp
+        nv = hp.nz_vae
+        N = hp.n_nodes
+        if name == "images":
+            return o["images_df"]
+        if name == "e_g_prime":
+            return o["E"][:, 1:1 + N]
+        if name == "hidden_state":
+            return o["Hid"][:, 1:1 + N]
+        if name == "z":
+            return o["Z"][:, 1:1 + N]
+        if name in ("p_z_mu", "p_z_log_sigma", "q_z_mu", "q_z_log_sigma"):
+            t = o["PZ" if name.startswith("p_") else "QZ"][:, 1:1 + N]
+            return t[..., :nv] if name.endswith("mu") else t[..., nv:]
+        if name == "match_timesteps":
+            return o["node_t"]
+        if name == "distr":
+            d = o["distr_df_kernel_order"]
+            if d is None:
+                raise KeyError("distr not materialised: build the model with materialize_distr=True")
+            perm = self._m._dlm_perm
+            inv = torch.empty(hp.head_channels, dtype=torch.long, device=d.device)
+            slots = torch.nonzero(perm >= 0)[:, 0]
+            inv[perm[slots]] = slots
+            return d.index_select(-1, inv).permute(0, 1, 4, 2, 3)
+        raise KeyError(name)
+
+    class _Acc:
+        def __init__(self, tree, bf):
+            self._t, self._bf = tree, bf
+
+        def __getattr__(self, name):
+            v = self._t._df(name)
+            return v.index_select(1, self._t._bf2df) if self._bf else v
+
+        __getitem__ = __getattr__
+
+    @property
+    def df(self):
+        return TreeView._Acc(self, False)
+
+    @property
+    def bf(self):
+        return TreeView._Acc(self, True)

@@ -1,0 +1,129 @@
+"""Weight packing into MFMA fragment order (done once at model build; pure index shuffling).
+
+All hot kernels put output channels / GEMM columns on the MFMA i side, so the A operand of
+v_mfma_f32_16x16x4_f32 is a weight tile:  lane l holds W[n = 16*nt + (l & 15)][k] for the 4 k-values
+k = 16*kg + 4*(l >> 4) + s, s = 0..3 (one float4).  A packed tensor is therefore [steps][tiles][64 lanes][4]:
+each (step, tile) is one coalesced 1 KiB wavefront load.  See csrc/common.cuh for the operand maps.
+"""
+import torch
+
+_LANE = torch.arange(64)
+_LI = _LANE % 16          # i (row inside the 16-wide tile)
+_LQ = _LANE // 16         # kk
+
+
+def _pad_rows(w, rows):
+    if w.shape[0] == rows:
+        return w
+    pad = torch.zeros((rows - w.shape[0],) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    return torch.cat([w, pad], 0)
+
+
+def pack_gemm(w):
+    """w [N, K] (N % 16 == 0 after zero padding, K % 16 == 0) -> [K/16][N/16][64][4]."""
+    N, K = w.shape
+    assert K % 16 == 0, (N, K)
+    NT = (N + 15) // 16
+    w = _pad_rows(w, NT * 16)
+    dev = w.device
+    kg = torch.arange(K // 16, device=dev)[:, None, None, None]
+    nt = torch.arange(NT, device=dev)[None, :, None, None]
+    li = _LI.to(dev)[None, None, :, None]
+    lq = _LQ.to(dev)[None, None, :, None]
+    s = torch.arange(4, device=dev)[None, None, None, :]
+    return w[nt * 16 + li, kg * 16 + lq * 4 + s].contiguous()
+
+
+def pack_conv3x3(w, cc, perm=None):
+    """w [Cout, Cin, 3, 3] -> [Cin/cc * 9 * cc/16 + 1][CT][64][4]; the trailing zero step pads the prefetch.
+    perm: optional list mapping kernel channel slot -> canonical output channel (or -1 for an empty slot)."""
+    Cout, Cin = w.shape[:2]
+    assert Cin % cc == 0 and cc % 16 == 0
+    dev = w.device
+    if perm is not None:
+        perm_t = torch.as_tensor(perm, device=dev)
+        wk = torch.zeros((len(perm), Cin, 3, 3), dtype=w.dtype, device=dev)
+        valid = perm_t >= 0
+        wk[valid] = w[perm_t[valid]]
+        w = wk
+    CT = (w.shape[0] + 15) // 16
+    w = _pad_rows(w, CT * 16).reshape(CT * 16, Cin, 9)
+    nch, ncg = Cin // cc, cc // 16
+    chunk = torch.arange(nch, device=dev)[:, None, None, None, None, None]
+    tap = torch.arange(9, device=dev)[None, :, None, None, None, None]
+    cgl = torch.arange(ncg, device=dev)[None, None, :, None, None, None]
+    ct = torch.arange(CT, device=dev)[None, None, None, :, None, None]
+    li = _LI.to(dev)[None, None, None, None, :, None]
+    lq = _LQ.to(dev)[None, None, None, None, :, None]
+    s = torch.arange(4, device=dev)[None, None, None, None, None, :]
+    out = w[ct * 16 + li, chunk * cc + cgl * 16 + lq * 4 + s, tap]          # [nch, 9, ncg, CT, 64, 4]
+    out = out.reshape(nch * 9 * ncg, CT, 64, 4)
+    pad = torch.zeros((1, CT, 64, 4), dtype=w.dtype, device=dev)
+    return torch.cat([out, pad], 0).contiguous()
+
+
+def pack_conv4x4(w):
+    """w [Cout, Cin, 4, 4] (Cin % 16 == 0, Cout % 16 == 0) -> [16 taps][Cin/16][CT][64][4]."""
+    Cout, Cin = w.shape[:2]
+    assert Cin % 16 == 0 and Cout % 16 == 0
+    dev = w.device
+    CT = Cout // 16
+    w = w.reshape(Cout, Cin, 16)
+    tap = torch.arange(16, device=dev)[:, None, None, None, None]
+    cg = torch.arange(Cin // 16, device=dev)[None, :, None, None, None]
+    ct = torch.arange(CT, device=dev)[None, None, :, None, None]
+    li = _LI.to(dev)[None, None, None, :, None]
+    lq = _LQ.to(dev)[None, None, None, :, None]
+    s = torch.arange(4, device=dev)[None, None, None, None, :]
+    return w[ct * 16 + li, cg * 16 + lq * 4 + s, tap].contiguous()
+
+
+def pack_conv4x4_image(w):
+    """First encoder layer, w [16, 3, 4, 4] -> [3*4 (ci, ky)][CT=1][64]: lane (i, kk) holds w[i][ci][ky][kx = kk]."""
+    Cout, Cin = w.shape[:2]
+    assert Cin == 3 and Cout % 16 == 0
+    dev = w.device
+    CT = Cout // 16
+    ci = torch.arange(3, device=dev)[:, None, None, None]
+    ky = torch.arange(4, device=dev)[None, :, None, None]
+    ct = torch.arange(CT, device=dev)[None, None, :, None]
+    li = _LI.to(dev)[None, None, None, :]
+    lq = _LQ.to(dev)[None, None, None, :]
+    return w[ct * 16 + li, ci, ky, lq].reshape(12, CT, 64).contiguous()
+
+
+def pad_vec(v, n):
+    if v.shape[0] == n:
+        return v.contiguous()
+    out = torch.zeros(n, dtype=v.dtype, device=v.device)
+    out[:v.shape[0]] = v
+    return out
+
+
+# ---- discrete-logistic-mixture head: kernel channel order ------------------------------------------------
+def dlm_channel_perm(n_mix=10):
+    """Kernel slot -> canonical head channel (PixelCNN++ order: [logits(nm) | per colour c: means(nm),
+    log_scales(nm), coeffs(nm)]).  Slots 8k..8k+7 = {logit_k, mean_r, mean_g, mean_b, coeff0, coeff1, coeff2, -},
+    then the 3*nm log_scales; padded to a multiple of 16.  The layout puts everything the mixture MEAN needs for
+    mixture k into lanes (q, q+1) of one 16-channel MFMA tile (csrc/conv3x3.hip epilogue)."""
+    nm = n_mix
+    assert nm == 10, "kernel epilogue is written for 10 mixtures (5 MFMA tiles x 2 mixtures)"
+    perm = []
+    for k in range(nm):
+        perm += [k, nm + 0 * 3 * nm + k, nm + 1 * 3 * nm + k, nm + 2 * 3 * nm + k,
+                 nm + 0 * 3 * nm + 2 * nm + k, nm + 1 * 3 * nm + 2 * nm + k, nm + 2 * 3 * nm + 2 * nm + k, -1]
+    for c in range(3):
+        for k in range(nm):
+            perm.append(nm + c * 3 * nm + nm + k)
+    while len(perm) % 16:
+        perm.append(-1)
+    return perm
+
+
+def lstm_gate_interleave(w_ih, w_hh, b_ih, b_hh):
+    """[4H, H] x2 (torch gate order i, f, g, o) -> W [4H, 2H] with row n = 4u + gate, bias [4H] likewise."""
+    H = w_ih.shape[1]
+    w = torch.cat([w_ih, w_hh], dim=1)                      # [4H, 2H], K = [x | h]
+    w = w.view(4, H, 2 * H).permute(1, 0, 2).reshape(4 * H, 2 * H)
+    b = (b_ih + b_hh).view(4, H).t().reshape(4 * H)
+    return w.contiguous(), b.contiguous()

@@ -1,0 +1,121 @@
+"""ctypes binding of libgcpx.so (the C-ABI declared in include/gcpx.h).
+
+The product path has NO fallback: if the HIP library is missing or a symbol is absent, importing callers fail
+loudly.  torch is used only to own device memory and to provide the current HIP stream.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgcpx.so")
+
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+HEAD_RAW, HEAD_DLM_MEAN, HEAD_DLM_BOTH, HEAD_TANH_NCHW = 0, 1, 2, 3
+EPI_NONE, EPI_LRELU, EPI_LSTM = 0, 1, 2
+MLP_PLAIN, MLP_GAUSS = 0, 1
+
+vp = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+
+
+class ConvSrc(C.Structure):
+    _fields_ = [("ptr", vp), ("scale", vp), ("shift", vp), ("C", i32), ("frame_div", i32), ("act", i32), ("_pad", i32)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("src", ConvSrc * 2), ("nsrc", i32), ("F", i32), ("Hin", i32), ("Win", i32), ("Hout", i32),
+                ("Wout", i32), ("Cin", i32), ("Cout", i32), ("out_pitch", i32), ("upsample", i32), ("out_act", i32),
+                ("head_mode", i32), ("wpk", vp), ("bias", vp), ("out", vp), ("images", vp), ("stats_partial", vp)]
+
+
+class RowSrc(C.Structure):
+    _fields_ = [("ptr", vp), ("rowidx", vp), ("scale", vp), ("shiftv", vp), ("sb", i64), ("sr", i64),
+                ("width", i32), ("shift", i32), ("act", i32), ("cmod", i32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("src", RowSrc * 6), ("nsrc", i32), ("M", i32), ("N", i32), ("K", i32), ("rpb", i32),
+                ("wpk", vp), ("bias", vp), ("out", vp), ("ob", i64), ("orow", i64), ("epi", i32), ("_pad0", i32),
+                ("stats_partial", vp), ("c_prev", vp), ("c_prev_stride", i64), ("h_out", vp), ("c_out", vp),
+                ("hb", i64), ("hrow", i64), ("h_copy", vp)]
+
+
+class MlpArgs(C.Structure):
+    _fields_ = [("src", RowSrc * 4), ("nsrc", i32), ("M", i32), ("rpb", i32), ("in_dim", i32), ("mid", i32),
+                ("n_mid", i32), ("out_dim", i32), ("w_in", vp), ("b_in", vp), ("w_mid", vp), ("b_mid", vp),
+                ("gn_gamma", vp), ("gn_beta", vp), ("w_out", vp), ("b_out", vp), ("gn_eps", C.c_float),
+                ("lrelu_slope", C.c_float), ("epi", i32), ("out_split", i32), ("out", vp), ("ob", i64), ("orow", i64),
+                ("oblk", i64), ("eps", vp), ("eb", i64), ("erow", i64), ("z", vp), ("zb", i64), ("zrow", i64)]
+
+
+# every symbol include/gcpx.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("gcpx_version", C.c_int, []),
+    ("gcpx_last_error", C.c_char_p, []),
+    ("gcpx_conv_grid", C.c_int, []),
+    ("gcpx_conv3x3", C.c_int, [C.POINTER(ConvArgs), vp]),
+    ("gcpx_conv4x4s2", C.c_int, [C.POINTER(ConvArgs), vp]),
+    ("gcpx_conv4x4s2_image", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    ("gcpx_bn_finalize", C.c_int, [vp, i32, i32, i32, C.c_double, vp, vp, C.c_float, vp, vp, vp, vp, C.c_float, vp]),
+    ("gcpx_bn_fold", C.c_int, [vp, vp, vp, vp, C.c_float, i32, vp, vp, vp]),
+    ("gcpx_gemm", C.c_int, [C.POINTER(GemmArgs), vp]),
+    ("gcpx_gemm_row_blocks", C.c_int, [i32, i32]),
+    ("gcpx_mlp", C.c_int, [C.POINTER(MlpArgs), vp]),
+    ("gcpx_balanced_binding", C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    ("gcpx_gather_rows", C.c_int, [vp, vp, vp, i32, i32, i32, i32, i64, vp]),
+    ("gcpx_compact_index", C.c_int, [vp, i32, i32, i32, vp, vp]),
+    ("gcpx_graph_begin", C.c_int, [vp]),
+    ("gcpx_graph_end", C.c_int, [vp, C.POINTER(vp)]),
+    ("gcpx_graph_launch", C.c_int, [vp, vp]),
+    ("gcpx_graph_destroy", C.c_int, [vp]),
+    ("gcpx_event_create", C.c_int, [C.POINTER(vp)]),
+    ("gcpx_event_record", C.c_int, [vp, vp]),
+    ("gcpx_event_elapsed_ms", C.c_int, [vp, vp, C.POINTER(C.c_float)]),
+    ("gcpx_event_destroy", C.c_int, [vp]),
+]
+
+_lib = None
+
+
+class GcpxError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libgcpx.so and bind every symbol; raises if the library or any symbol is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise GcpxError(f"HIP extension not built: {p} is missing (run `python -c 'import __graft_entry__ as g; g.build()'`"
+                        " or video-gcp_amd/csrc/build.sh). There is no CPU fallback.")
+    lib = C.CDLL(p)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def lib():
+    return load_library()
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().gcpx_last_error()
+        raise GcpxError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
