@@ -79,8 +79,9 @@ def test_gemm_sources_shift_affine_stats(env):
     assert_close(s[1], (want.reshape(-1, N) ** 2).sum(0), atol=1e-3, rtol=1e-5, name="stats sumsq")
     # finalize -> scale/shift of a BatchNorm over those rows
     gamma, beta = torch.rand(N) + 0.5, torch.randn(N)
+    gd, btd = gamma.to(dev), beta.to(dev)
     scale, shift = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
-    rt.check(lib.gcpx_bn_finalize(st.data_ptr(), nrb, N, N, float(B * T), gamma.to(dev).data_ptr(), beta.to(dev).data_ptr(),
+    rt.check(lib.gcpx_bn_finalize(st.data_ptr(), nrb, N, N, float(B * T), gd.data_ptr(), btd.data_ptr(),
                                   1e-5, scale.data_ptr(), shift.data_ptr(), None, None, 0.0, _stream()), "bn_finalize")
     torch.cuda.synchronize()
     flat = want.reshape(-1, N)
@@ -163,6 +164,7 @@ def test_mlp(env, mid, in_dims, out_dim, M, gauss):
 
 def _conv_args(rt, srcs, **kw):
     a = rt.ConvArgs()
+    a._keep = (srcs, kw)          # device tensors must outlive the launch (the struct only holds raw pointers)
     cin = 0
     for i, (t, Cc, fdiv, sc, sh, act) in enumerate(srcs):
         s = a.src[i]

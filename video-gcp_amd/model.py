@@ -68,6 +68,9 @@ class GCPTreeModel:
         self._bufs = {}
         self._plans = {}
         self.use_graph = True
+        # hipGraph capture is not allowed on the legacy default stream: the model launches on its own stream
+        # and orders it against the caller's current stream with events (wait_stream), never a host sync
+        self._stream = torch.cuda.Stream(device=self.device)
         self._timed_op = None                 # name of one plan op bracketed by HIP events (bench.py roofline)
         self._timed_events = []
         self._pack_all()
@@ -567,7 +570,9 @@ class GCPTreeModel:
             plan.keep.append(tin)
             self._plans[key] = (ptrs, plan)
         plan = self._plans[key][1]
-        stream = rt.current_stream()
+        caller = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(caller)
+        stream = self._stream.cuda_stream
         if self._timed_op is not None:
             self._run_timed(plan, stream)
         elif self.use_graph:
@@ -577,6 +582,7 @@ class GCPTreeModel:
             rt.check(self.lib.gcpx_graph_launch(plan.graph, stream), "graph_launch")
         else:
             plan.run(stream)
+        caller.wait_stream(self._stream)
         return self._wrap_outputs(plan.outs, tin, phase)
 
     def _capture(self, ops, stream):
