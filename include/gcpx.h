@@ -136,7 +136,9 @@ typedef struct gcpx_gemm_args {
     float* out;             /* dev: row r at out + b*ob + j*orow (NONE / LRELU) */
     int64_t ob, orow;
     int32_t epi;
-    int32_t _pad0;
+    int32_t nbatch;         /* 0/1: single problem; >1: blockIdx.z = b runs the same M x N x K problem with every source
+                               pointer advanced by b*z_src_off, weights by b*z_w_off, bias by b*z_bias_off and out by
+                               b*z_out_off floats (the 2*n_lstm_layers split_linear projections in one launch) */
     float* stats_partial;   /* dev: [gcpx_gemm_row_blocks(M, N)][2][N] per-row-block sum / sum of squares
                                of the output columns (training-mode BatchNorm), or NULL */
     /* LSTM epilogue: c' = sig(f)*c + sig(i)*tanh(g); h' = sig(o)*tanh(c') */
@@ -146,6 +148,7 @@ typedef struct gcpx_gemm_args {
     float* c_out;
     int64_t hb, hrow;
     float* h_copy;          /* optional dense copy of h: row r at h_copy + r*H (input of the next layer) */
+    int64_t z_src_off, z_w_off, z_bias_off, z_out_off;
 } gcpx_gemm_args;
 
 int gcpx_gemm(const gcpx_gemm_args* a, void* stream);

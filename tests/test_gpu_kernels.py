@@ -324,3 +324,26 @@ def test_balanced_binding_bit_exact(env):
             blk = et[B * (n - 1):B * (n - 1) + B * n].cpu().numpy().reshape(B, n)
             assert np.array_equal(blk, np.arange(B)[:, None] * T + np.clip(ts_bf[:, off:off + n], 0, T - 1))
             off += n
+
+
+def test_gemm_batched_projections(env):
+    """blockIdx.z batching: the 2*n_lstm_layers split_linear projections (tree_lstm.py:46-47) in one launch."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(11)
+    M, H, nb = 24, 64, 6
+    h1, h2 = torch.randn(M, nb * H), torch.randn(M, nb * H)
+    Ws, bs = torch.randn(nb, H, 2 * H) / (2 * H) ** 0.5, torch.randn(nb, H)
+    want = torch.cat([F.linear(torch.cat([h1[:, z * H:(z + 1) * H], h2[:, z * H:(z + 1) * H]], 1), Ws[z], bs[z]) for z in range(nb)], 1)
+    h1d, h2d = h1.to(dev), h2.to(dev)
+    wp = torch.stack([pk.pack_gemm(Ws[z]) for z in range(nb)]).contiguous().to(dev)
+    bd = bs.contiguous().to(dev)
+    out = torch.full((M, nb * H), float("nan"), device=dev)
+    a = rt.GemmArgs()
+    a.src[0] = _rowsrc(rt, h1d, 0, nb * H, H)
+    a.src[1] = _rowsrc(rt, h2d, 0, nb * H, H)
+    a.nsrc, a.M, a.N, a.K, a.rpb = 2, M, H, 2 * H, M
+    a.wpk, a.bias, a.out, a.ob, a.orow = wp.data_ptr(), bd.data_ptr(), out.data_ptr(), 0, nb * H
+    a.nbatch, a.z_src_off, a.z_w_off, a.z_bias_off, a.z_out_off = nb, H, wp[0].numel(), H, H
+    rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm batched")
+    torch.cuda.synchronize()
+    assert_close(out, want, atol=2e-5, rtol=1e-5, name="batched gemm")

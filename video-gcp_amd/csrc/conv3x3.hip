@@ -48,13 +48,24 @@ __device__ __forceinline__ float4 load_src4(const gcpx_conv_args& a, int f, int 
     return affine_act4(v, s.scale, s.shift, cl, s.act);
 }
 
+// tanh via one v_exp + one v_rcp (coefficients of the mixture colour coupling; |err| ~1e-7)
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float e = __expf(2.f * x);
+    return 1.f - 2.f * __frcp_rn(e + 1.f);
+}
+
 template <bool UP, int CC, int CT, int TILE>
 __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty,
-                                                      const int ntiles) {
+                                                         const int ntiles) {
     using Cfg = ConvCfg<UP, CC, CT, TILE>;
     constexpr int TH = Cfg::TH, TW = Cfg::TW, TF = Cfg::TF, RH = Cfg::RH, RW = Cfg::RW;
     constexpr int LH = Cfg::LH, LW = Cfg::LW, CCP = Cfg::CCP, C4 = Cfg::C4;
     constexpr int NSTEP = 9 * (CC / 16);
+    // staging slots (one float4 each) fetched from global per (tile, chunk): the low-res patch when upsampling,
+    // the haloed region itself otherwise
+    constexpr int SH = UP ? LH : RH, SW = UP ? LW : RW;
+    constexpr int NSLOT = TF * SH * SW * C4;
+    constexpr int NS = (NSLOT + 255) / 256;
 
     extern __shared__ float4 smem4[];
     float* hi = reinterpret_cast<float*>(smem4);
@@ -77,6 +88,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
         px[pt] = rem % TW;
         pixoff[pt] = ((pfl[pt] * RH + py[pt]) * RW + px[pt]) * CCP + q * 4;
     }
+    // staging slot k of this thread: float4 index tid + 256*k of the staged region (decode = constant divisions)
+    auto slot = [&](int k, int& c4, int& rx, int& ry, int& fl, int& lds) {
+        const int idx = tid + 256 * k;
+        c4 = idx % C4;
+        int t = idx / C4;
+        rx = t % SW; t /= SW;
+        ry = t % SH;
+        fl = (idx < NSLOT) ? t / SH : -1;               // -1: slot does not exist
+        lds = UP ? ((fl * LH + ry) * LW + rx) * CC + c4 * 4 : ((fl * RH + ry) * RW + rx) * CCP + c4 * 4;
+    };
     const float4* wbase = reinterpret_cast<const float4*>(a.wpk) + lane;
 
     // BatchNorm partial sums: only the upsampling blocks are followed by a norm
@@ -84,43 +105,87 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
 #pragma unroll
     for (int ct = 0; ct < (UP ? CT : 1); ++ct) { st1[ct] = f32x4{0, 0, 0, 0}; st2[ct] = f32x4{0, 0, 0, 0}; }
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- software pipeline over stages (tile, chunk): the global loads of stage s+1 are in flight while the
+    //      MFMAs of stage s run; only the register -> LDS write (+ the LDS -> LDS upsample) is exposed ----
+    float4 pre[NS];
+    unsigned pre_ok = 0;
+    auto tile_origin = [&](int tile, int& f0, int& y0, int& x0) {
         const int tx = tile % ntx;
         const int t2 = tile / ntx;
-        const int ty = t2 % nty;
-        const int fg = t2 / nty;
-        const int f0 = fg * TF, y0 = ty * TH, x0 = tx * TW;
+        f0 = (t2 / nty) * TF; y0 = (t2 % nty) * TH; x0 = tx * TW;
+    };
+    auto issue_loads = [&](int tile, int chunk) {
+        int f0, y0, x0;
+        tile_origin(tile, f0, y0, x0);
+        pre_ok = 0;
+        const int c0 = a.src[0].C;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int s_c4, s_rx, s_ry, s_fl, s_lds;
+            slot(k, s_c4, s_rx, s_ry, s_fl, s_lds);
+            if (s_fl < 0) continue;
+            const int f = f0 + s_fl;
+            int sy, sx;
+            bool ok = f < F;
+            if constexpr (UP) {
+                sy = min(max(y0 / 2 - 1 + s_ry, 0), a.Hin - 1);
+                sx = min(max(x0 / 2 - 1 + s_rx, 0), a.Win - 1);
+            } else {
+                sy = y0 - 1 + s_ry;
+                sx = x0 - 1 + s_rx;
+                ok = ok && sy >= 0 && sy < Hout && sx >= 0 && sx < Wout;
+            }
+            if (ok) {
+                const int cg = chunk * CC + s_c4 * 4;
+                const bool first = cg < c0;
+                const gcpx_conv_src& sr = first ? a.src[0] : a.src[1];
+                const int cl = first ? cg : cg - c0;
+                pre[k] = *reinterpret_cast<const float4*>(
+                    sr.ptr + (((size_t)(f / sr.frame_div) * a.Hin + sy) * a.Win + sx) * sr.C + cl);
+                pre_ok |= 1u << k;
+            }
+        }
+    };
+    auto write_stage = [&](int chunk) {
+        const int c0 = a.src[0].C;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            int s_c4, s_rx, s_ry, s_fl, s_lds;
+            slot(k, s_c4, s_rx, s_ry, s_fl, s_lds);
+            if (s_fl < 0) continue;
+            float4 v = pre[k];
+            if (pre_ok & (1u << k)) {
+                const int cg = chunk * CC + s_c4 * 4;
+                const bool first = cg < c0;
+                const gcpx_conv_src& sr = first ? a.src[0] : a.src[1];
+                v = affine_act4(v, sr.scale, sr.shift, first ? cg : cg - c0, sr.act);
+            }
+            *reinterpret_cast<float4*>((UP ? raw : hi) + s_lds) = v;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue_loads(tile, 0);
+    for (; tile < ntiles; tile += gridDim.x) {
+        int f0, y0, x0;
+        tile_origin(tile, f0, y0, x0);
 
         f32x4 acc[CT][4];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
-
         float4 wnext[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) wnext[ct] = wbase[ct * 64];
 
         for (int chunk = 0; chunk < nchunk; ++chunk) {
-            __syncthreads();   // previous chunk's / tile's LDS reads are done
+            __syncthreads();   // previous stage's LDS reads are done
+            write_stage(chunk);
             if constexpr (UP) {
-                const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
-                for (int idx = tid; idx < TF * LH * LW * C4; idx += 256) {
-                    const int c4 = idx % C4;
-                    int t = idx / C4;
-                    const int rx = t % LW; t /= LW;
-                    const int ry = t % LH;
-                    const int fl = t / LH;
-                    const int f = f0 + fl;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (f < F) {
-                        const int sy = min(max(ly0 + ry, 0), a.Hin - 1);
-                        const int sx = min(max(lx0 + rx, 0), a.Win - 1);
-                        v = load_src4(a, f, sy, sx, chunk * CC + c4 * 4);
-                    }
-                    *reinterpret_cast<float4*>(raw + ((fl * LH + ry) * LW + rx) * CC + c4 * 4) = v;
-                }
                 __syncthreads();
+                const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
                 for (int idx = tid; idx < TF * RH * RW * C4; idx += 256) {
                     const int c4 = idx % C4;
                     int t = idx / C4;
@@ -150,21 +215,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
                     }
                     *reinterpret_cast<float4*>(hi + ((fl * RH + ry) * RW + rx) * CCP + c4 * 4) = v;
                 }
-            } else {
-                for (int idx = tid; idx < TF * RH * RW * C4; idx += 256) {
-                    const int c4 = idx % C4;
-                    int t = idx / C4;
-                    const int rx = t % RW; t /= RW;
-                    const int ry = t % RH;
-                    const int fl = t / RH;
-                    const int Y = y0 - 1 + ry, X = x0 - 1 + rx, f = f0 + fl;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (f < F && Y >= 0 && Y < Hout && X >= 0 && X < Wout)
-                        v = load_src4(a, f, Y, X, chunk * CC + c4 * 4);
-                    *reinterpret_cast<float4*>(hi + ((fl * RH + ry) * RW + rx) * CCP + c4 * 4) = v;
-                }
             }
             __syncthreads();
+            // next stage's global loads go out now and land while the MFMAs below run
+            if (chunk + 1 < nchunk) issue_loads(tile, chunk + 1);
+            else if (tile + (int)gridDim.x < ntiles) issue_loads(tile + gridDim.x, 0);
 
             // ---- MFMA main loop over (tap, 16-channel group) ----
             // Weights are double-buffered in registers one step ahead; the stream of steps is contiguous across
@@ -245,7 +300,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
                     for (int ct = 0; ct < 5; ++ct) {
                         const f32x4 v = acc[ct][pt];
                         const float o0 = __shfl_xor(v[0], 16), o1 = __shfl_xor(v[1], 16), o2 = __shfl_xor(v[2], 16);
-                        const float c0 = tanhf(o0), c1 = tanhf(o1), c2 = tanhf(o2);
+                        const float c0 = fast_tanh(o0), c1 = fast_tanh(o1), c2 = fast_tanh(o2);
                         lg[ct] = v[0];
                         mr[ct] = v[1];
                         mg[ct] = v[2] + c0 * mr[ct];

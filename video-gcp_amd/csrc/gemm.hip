@@ -43,48 +43,62 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
 #pragma unroll
         for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
 
-    const float4* wbase = reinterpret_cast<const float4*>(a.wpk) + (size_t)nt0 * 64 + lane;
+    const int zb = blockIdx.z;
+    const float4* wbase = reinterpret_cast<const float4*>(a.wpk + (size_t)zb * a.z_w_off) + (size_t)nt0 * 64 + lane;
     int kg0 = 0;
     for (int s = 0; s < a.nsrc; ++s) {
         const gcpx_row_src src = a.src[s];
         const float* bp[PR];
-        bool ok[PR];
+        float mask[PR];
 #pragma unroll
         for (int pt = 0; pt < PR; ++pt) {
-            ok[pt] = rv[pt];
+            bool ok = rv[pt];
             size_t off = 0;
             if (src.rowidx) {
                 off = (size_t)src.rowidx[rv[pt] ? rr[pt] : 0] * src.sr;
             } else {
                 const int jj = rj[pt] + src.shift;
-                ok[pt] = ok[pt] && jj >= 0 && jj < rpb;
-                off = (size_t)rb[pt] * src.sb + (size_t)(ok[pt] ? jj : 0) * src.sr;
+                ok = ok && jj >= 0 && jj < rpb;
+                off = (size_t)rb[pt] * src.sb + (size_t)(ok ? jj : 0) * src.sr;
             }
-            bp[pt] = src.ptr + off + q * 4;
+            // rows that do not exist read a valid (clamped) row and are zeroed by the mask: no divergent loads
+            mask[pt] = ok ? 1.f : 0.f;
+            bp[pt] = src.ptr + (size_t)zb * a.z_src_off + off + q * 4;
         }
         const int nkg = src.width / 16;
-
-        for (int kg = 0; kg < nkg; ++kg) {
-            float4 b[PR];
+        const bool xf = src.scale || src.act;
+        constexpr int UK = (PR * CR >= 8) ? 2 : 4;      // k-groups whose loads are issued together
+        for (int kg = 0; kg < nkg; kg += UK) {
+            float4 b[UK][PR], w[UK][CR];
 #pragma unroll
-            for (int pt = 0; pt < PR; ++pt) {
-                b[pt] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok[pt]) {
-                    b[pt] = *reinterpret_cast<const float4*>(bp[pt] + kg * 16);
-                    if (src.scale || src.act)
-                        b[pt] = affine_act4(b[pt], src.scale, src.shiftv, (kg * 16 + q * 4) % src.cmod, src.act);
-                }
+            for (int u = 0; u < UK; ++u) {
+                const int k = (kg + u < nkg) ? kg + u : nkg - 1;
+#pragma unroll
+                for (int pt = 0; pt < PR; ++pt) b[u][pt] = *reinterpret_cast<const float4*>(bp[pt] + k * 16);
+                const float4* wp = wbase + (size_t)(kg0 + k) * NT * 64;
+#pragma unroll
+                for (int ct = 0; ct < CR; ++ct) w[u][ct] = wp[ct * 64];
             }
-            const float4* wp = wbase + (size_t)(kg0 + kg) * NT * 64;
 #pragma unroll
-            for (int ct = 0; ct < CR; ++ct) {
-                const float4 w = wp[ct * 64];
+            for (int u = 0; u < UK; ++u) {
+                if (kg + u < nkg) {
 #pragma unroll
-                for (int pt = 0; pt < PR; ++pt) {
-                    acc[ct][pt] = mfma16(w.x, b[pt].x, acc[ct][pt]);
-                    acc[ct][pt] = mfma16(w.y, b[pt].y, acc[ct][pt]);
-                    acc[ct][pt] = mfma16(w.z, b[pt].z, acc[ct][pt]);
-                    acc[ct][pt] = mfma16(w.w, b[pt].w, acc[ct][pt]);
+                    for (int pt = 0; pt < PR; ++pt) {
+                        float4 bb = b[u][pt];
+                        if (xf) bb = affine_act4(bb, src.scale, src.shiftv, ((kg + u) * 16 + q * 4) % src.cmod, src.act);
+                        bb.x *= mask[pt]; bb.y *= mask[pt]; bb.z *= mask[pt]; bb.w *= mask[pt];
+                        b[u][pt] = bb;
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < CR; ++ct) {
+#pragma unroll
+                        for (int pt = 0; pt < PR; ++pt) {
+                            acc[ct][pt] = mfma16(w[u][ct].x, b[u][pt].x, acc[ct][pt]);
+                            acc[ct][pt] = mfma16(w[u][ct].y, b[u][pt].y, acc[ct][pt]);
+                            acc[ct][pt] = mfma16(w[u][ct].z, b[u][pt].z, acc[ct][pt]);
+                            acc[ct][pt] = mfma16(w[u][ct].w, b[u][pt].w, acc[ct][pt]);
+                        }
+                    }
                 }
             }
         }
@@ -96,7 +110,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
     for (int ct = 0; ct < CR; ++ct) {
         const int n = (nt0 + ct) * 16 + q * 4;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + n);
+        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + (size_t)zb * a.z_bias_off + n);
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int pt = 0; pt < PR; ++pt) {
@@ -119,7 +133,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
                     v[0] = lrelu(v[0], 0.2f); v[1] = lrelu(v[1], 0.2f); v[2] = lrelu(v[2], 0.2f); v[3] = lrelu(v[3], 0.2f);
                 }
                 if (rv[pt]) {
-                    float* op = a.out + (size_t)rb[pt] * a.ob + (size_t)rj[pt] * a.orow + n;
+                    float* op = a.out + (size_t)zb * a.z_out_off + (size_t)rb[pt] * a.ob + (size_t)rj[pt] * a.orow + n;
                     *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
                     if (a.stats_partial) {
 #pragma unroll
@@ -146,7 +160,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
 
 struct TileChoice { int pr, cr; };
 
-TileChoice choose_tile(int M, int N) {
+TileChoice choose_tile(int M, int N, int nb = 1) {
     const int prs[3] = {4, 2, 1}, crs[3] = {4, 2, 1};
     TileChoice best{1, 1};
     long best_wg = -1;
@@ -159,7 +173,7 @@ TileChoice choose_tile(int M, int N) {
                 if (N % (16 * cr)) continue;
                 const long rbk = (M + 16 * pr - 1) / (16 * pr);
                 const long cbk = (N / 16 + 4 * cr - 1) / (4 * cr);
-                const long wg = rbk * cbk;
+                const long wg = rbk * cbk * nb;
                 if (wg >= 384) return TileChoice{pr, cr};
                 if (wg > best_wg) { best_wg = wg; best = TileChoice{pr, cr}; }
             }
@@ -171,10 +185,11 @@ template <int PR, int CR>
 void launch_t(const gcpx_gemm_args* a, hipStream_t stream) {
     const int rbk = (a->M + 16 * PR - 1) / (16 * PR);
     const int cbk = (a->N / 16 + 4 * CR - 1) / (4 * CR);
+    const int nb = a->nbatch > 1 ? a->nbatch : 1;
     if (a->epi == GCPX_EPI_LSTM)
-        hipLaunchKernelGGL((gemm_kernel<PR, CR, true>), dim3(rbk, cbk), dim3(256), 0, stream, *a);
+        hipLaunchKernelGGL((gemm_kernel<PR, CR, true>), dim3(rbk, cbk, nb), dim3(256), 0, stream, *a);
     else
-        hipLaunchKernelGGL((gemm_kernel<PR, CR, false>), dim3(rbk, cbk), dim3(256), 0, stream, *a);
+        hipLaunchKernelGGL((gemm_kernel<PR, CR, false>), dim3(rbk, cbk, nb), dim3(256), 0, stream, *a);
 }
 
 }  // namespace
@@ -203,7 +218,8 @@ extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
     } else {
         GCPX_CHECK_ARG(a->out != nullptr, "out is NULL");
     }
-    const TileChoice t = choose_tile(a->M, a->N);
+    GCPX_CHECK_ARG(a->nbatch <= 1 || (a->epi != GCPX_EPI_LSTM && !a->stats_partial), "nbatch > 1 only for plain epilogues");
+    const TileChoice t = choose_tile(a->M, a->N, a->nbatch > 1 ? a->nbatch : 1);
     switch (t.pr * 10 + t.cr) {
         case 44: launch_t<4, 4>(a, stream); break;
         case 42: launch_t<4, 2>(a, stream); break;

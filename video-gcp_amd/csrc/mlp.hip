@@ -1,6 +1,8 @@
 // Fused Predictor MLP on gfx950: input(in->mid, LReLU), n_mid x (mid->mid, GroupNorm(8), LReLU), head(mid->out)
-// with an optional reparametrised-Gaussian epilogue.  One wavefront carries 16 rows through every layer; hidden
-// activations live in LDS, GroupNorm statistics are reduced with in-lane adds + two 4-lane-column shuffles.
+// with an optional reparametrised-Gaussian epilogue.  One 256-thread workgroup carries 16 rows through every
+// layer: the four wavefronts split the output columns of each layer, hidden activations live in LDS, GroupNorm
+// statistics are reduced with in-lane adds + two 4-lane-column shuffles (a group = one 16-column MFMA tile).
+// The (wide) head layer can additionally be split over blockIdx.y; the cheap hidden layers are then recomputed.
 //
 // Replaces blox.torch.subnetworks.Predictor (absent; spec in DESIGN.md) at the call sites
 //   /root/reference/gcp/prediction/models/tree/tree_module.py:77   (prior p(z | e_l, e_r))
@@ -13,29 +15,33 @@
 namespace {
 
 template <int MID>
-__global__ void __launch_bounds__(64) mlp_kernel(const gcpx_mlp_args a) {
-    constexpr int NTM = MID / 16;
+__global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
+    constexpr int NTM = MID / 16;                    // column tiles of a hidden layer
+    constexpr int NW = NTM >= 4 ? 4 : NTM;           // wavefronts that own hidden-layer tiles
+    constexpr int TPW = NTM / NW;                    // tiles per wavefront
     constexpr int PITCH = MID + 4;
-    constexpr int CPG = MID / 8;    // channels per GroupNorm group (gn_groups = 8)
+    constexpr int CPG = MID / 8;                     // channels per GroupNorm group (gn_groups = 8)
     static_assert(CPG == 4 || CPG == 16, "GroupNorm group must be one lane (4) or one 16-channel tile");
     __shared__ float4 hid4[2 * 16 * PITCH / 4];
     float* hid = reinterpret_cast<float*>(hid4);
 
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int r = blockIdx.x * 16 + j;
     const bool rv = r < a.M;
     const int rs = rv ? r : 0;
     const int rb = rs / a.rpb, rj = rs % a.rpb;
     const float slope = a.lrelu_slope;
+    const bool owner = wave < NW;
+    const int nt0 = wave * TPW;
 
-    f32x4 acc[NTM];
+    f32x4 acc[TPW];
 #pragma unroll
-    for (int nt = 0; nt < NTM; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+    for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0, 0, 0, 0};
 
     // ---- input layer: gathered global sources ----
-    {
-        const float4* wbase = reinterpret_cast<const float4*>(a.w_in) + lane;
+    if (owner) {
+        const float4* wbase = reinterpret_cast<const float4*>(a.w_in) + (size_t)nt0 * 64 + lane;
         int kg0 = 0;
         for (int s = 0; s < a.nsrc; ++s) {
             const gcpx_row_src src = a.src[s];
@@ -49,32 +55,44 @@ __global__ void __launch_bounds__(64) mlp_kernel(const gcpx_mlp_args a) {
                 off = (size_t)rb * src.sb + (size_t)(ok ? jj : 0) * src.sr;
             }
             const float* bp = src.ptr + off + q * 4;
+            const float mask = ok ? 1.f : 0.f;
             const int nkg = src.width / 16;
-            for (int kg = 0; kg < nkg; ++kg) {
-                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) {
-                    b = *reinterpret_cast<const float4*>(bp + kg * 16);
-                    if (src.scale || src.act)
-                        b = affine_act4(b, src.scale, src.shiftv, (kg * 16 + q * 4) % src.cmod, src.act);
-                }
-                const float4* wp = wbase + (size_t)(kg0 + kg) * NTM * 64;
+            const bool xf = src.scale || src.act;
+            for (int kg = 0; kg < nkg; kg += 4) {
+                // issue the whole batch of loads first (independent), then the MFMAs
+                float4 b[4], w[4][TPW];
 #pragma unroll
-                for (int nt = 0; nt < NTM; ++nt) {
-                    const float4 w = wp[nt * 64];
-                    acc[nt] = mfma16(w.x, b.x, acc[nt]);
-                    acc[nt] = mfma16(w.y, b.y, acc[nt]);
-                    acc[nt] = mfma16(w.z, b.z, acc[nt]);
-                    acc[nt] = mfma16(w.w, b.w, acc[nt]);
+                for (int u = 0; u < 4; ++u) {
+                    const int k = (kg + u < nkg) ? kg + u : nkg - 1;
+                    b[u] = *reinterpret_cast<const float4*>(bp + k * 16);
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) w[u][t] = wbase[((size_t)(kg0 + k) * NTM + t) * 64];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (kg + u < nkg) {
+                        float4 bb = b[u];
+                        if (xf) bb = affine_act4(bb, src.scale, src.shiftv, ((kg + u) * 16 + q * 4) % src.cmod, src.act);
+                        bb.x *= mask; bb.y *= mask; bb.z *= mask; bb.w *= mask;
+#pragma unroll
+                        for (int t = 0; t < TPW; ++t) {
+                            acc[t] = mfma16(w[u][t].x, bb.x, acc[t]);
+                            acc[t] = mfma16(w[u][t].y, bb.y, acc[t]);
+                            acc[t] = mfma16(w[u][t].z, bb.z, acc[t]);
+                            acc[t] = mfma16(w[u][t].w, bb.w, acc[t]);
+                        }
+                    }
                 }
             }
             kg0 += nkg;
         }
 #pragma unroll
-        for (int nt = 0; nt < NTM; ++nt) {
-            const float4 bv = *reinterpret_cast<const float4*>(a.b_in + nt * 16 + q * 4);
-            float4 v = make_float4(lrelu(acc[nt][0] + bv.x, slope), lrelu(acc[nt][1] + bv.y, slope),
-                                   lrelu(acc[nt][2] + bv.z, slope), lrelu(acc[nt][3] + bv.w, slope));
-            *reinterpret_cast<float4*>(hid + j * PITCH + nt * 16 + q * 4) = v;
+        for (int t = 0; t < TPW; ++t) {
+            const int c = (nt0 + t) * 16 + q * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(a.b_in + c);
+            float4 v = make_float4(lrelu(acc[t][0] + bv.x, slope), lrelu(acc[t][1] + bv.y, slope),
+                                   lrelu(acc[t][2] + bv.z, slope), lrelu(acc[t][3] + bv.w, slope));
+            *reinterpret_cast<float4*>(hid + j * PITCH + c) = v;
         }
     }
     __syncthreads();
@@ -84,44 +102,51 @@ __global__ void __launch_bounds__(64) mlp_kernel(const gcpx_mlp_args a) {
     for (int l = 0; l < a.n_mid; ++l) {
         const float* hin = hid + cur * 16 * PITCH;
         float* hout = hid + (cur ^ 1) * 16 * PITCH;
-        const float4* wbase = reinterpret_cast<const float4*>(a.w_mid) + (size_t)l * NTM * NTM * 64 + lane;
+        if (owner) {
+            const float4* wbase = reinterpret_cast<const float4*>(a.w_mid) + ((size_t)l * NTM * NTM + nt0) * 64 + lane;
+            float4 w[NTM][TPW], b[NTM];
 #pragma unroll
-        for (int nt = 0; nt < NTM; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+            for (int kg = 0; kg < NTM; ++kg) {
 #pragma unroll
-        for (int kg = 0; kg < NTM; ++kg) {
-            const float4 b = *reinterpret_cast<const float4*>(hin + j * PITCH + kg * 16 + q * 4);
-#pragma unroll
-            for (int nt = 0; nt < NTM; ++nt) {
-                const float4 w = wbase[(kg * NTM + nt) * 64];
-                acc[nt] = mfma16(w.x, b.x, acc[nt]);
-                acc[nt] = mfma16(w.y, b.y, acc[nt]);
-                acc[nt] = mfma16(w.z, b.z, acc[nt]);
-                acc[nt] = mfma16(w.w, b.w, acc[nt]);
+                for (int t = 0; t < TPW; ++t) w[kg][t] = wbase[(kg * NTM + t) * 64];
+                b[kg] = *reinterpret_cast<const float4*>(hin + j * PITCH + kg * 16 + q * 4);
             }
-        }
 #pragma unroll
-        for (int nt = 0; nt < NTM; ++nt) {
-            const int c = nt * 16 + q * 4;
-            const float4 bv = *reinterpret_cast<const float4*>(a.b_mid + l * MID + c);
-            const float4 gv = *reinterpret_cast<const float4*>(a.gn_gamma + l * MID + c);
-            const float4 be = *reinterpret_cast<const float4*>(a.gn_beta + l * MID + c);
-            float v0 = acc[nt][0] + bv.x, v1 = acc[nt][1] + bv.y, v2 = acc[nt][2] + bv.z, v3 = acc[nt][3] + bv.w;
-            float sum = (v0 + v1) + (v2 + v3);
-            if (CPG == 16) { sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32); }
-            const float mean = sum * (1.f / CPG);
-            const float d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean;
-            float ss = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-            if (CPG == 16) { ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32); }
-            const float rstd = rsqrtf(ss * (1.f / CPG) + a.gn_eps);
-            float4 o = make_float4(lrelu(d0 * rstd * gv.x + be.x, slope), lrelu(d1 * rstd * gv.y + be.y, slope),
-                                   lrelu(d2 * rstd * gv.z + be.z, slope), lrelu(d3 * rstd * gv.w + be.w, slope));
-            *reinterpret_cast<float4*>(hout + j * PITCH + c) = o;
+            for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int kg = 0; kg < NTM; ++kg) {
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    acc[t] = mfma16(w[kg][t].x, b[kg].x, acc[t]);
+                    acc[t] = mfma16(w[kg][t].y, b[kg].y, acc[t]);
+                    acc[t] = mfma16(w[kg][t].z, b[kg].z, acc[t]);
+                    acc[t] = mfma16(w[kg][t].w, b[kg].w, acc[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int c = (nt0 + t) * 16 + q * 4;
+                const float4 bv = *reinterpret_cast<const float4*>(a.b_mid + l * MID + c);
+                const float4 gv = *reinterpret_cast<const float4*>(a.gn_gamma + l * MID + c);
+                const float4 be = *reinterpret_cast<const float4*>(a.gn_beta + l * MID + c);
+                const float v0 = acc[t][0] + bv.x, v1 = acc[t][1] + bv.y, v2 = acc[t][2] + bv.z, v3 = acc[t][3] + bv.w;
+                float sum = (v0 + v1) + (v2 + v3);
+                if (CPG == 16) { sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32); }
+                const float mean = sum * (1.f / CPG);
+                const float d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean;
+                float ss = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                if (CPG == 16) { ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32); }
+                const float rstd = rsqrtf(ss * (1.f / CPG) + a.gn_eps);
+                float4 o = make_float4(lrelu(d0 * rstd * gv.x + be.x, slope), lrelu(d1 * rstd * gv.y + be.y, slope),
+                                       lrelu(d2 * rstd * gv.z + be.z, slope), lrelu(d3 * rstd * gv.w + be.w, slope));
+                *reinterpret_cast<float4*>(hout + j * PITCH + c) = o;
+            }
         }
         cur ^= 1;
         __syncthreads();
     }
 
-    // ---- head: mid -> out ----
+    // ---- head: mid -> out; column tiles are dealt round-robin to (blockIdx.y, wave) ----
     const float* hin = hid + cur * 16 * PITCH;
     float4 b[NTM];
 #pragma unroll
@@ -131,22 +156,27 @@ __global__ void __launch_bounds__(64) mlp_kernel(const gcpx_mlp_args a) {
     const float4* wbase = reinterpret_cast<const float4*>(a.w_out) + lane;
     const int split = a.out_split > 0 ? a.out_split : a.out_dim;
     float* orow = a.out ? a.out + (size_t)rb * a.ob + (size_t)rj * a.orow : nullptr;
+    const int tstart = blockIdx.y * 4 + wave, tstride = gridDim.y * 4;
 
     if (a.epi == GCPX_MLP_GAUSS) {
         const int nz = a.out_dim / 2;
         const int NTZ = nz / 16;
         const float* erow = a.eps + (size_t)rb * a.eb + (size_t)rj * a.erow;
         float* zrow = a.z + (size_t)rb * a.zb + (size_t)rj * a.zrow;
-        for (int nt = 0; nt < NTZ; ++nt) {
+        for (int nt = tstart; nt < NTZ; nt += tstride) {
+            float4 wm[NTM], wl[NTM];
+#pragma unroll
+            for (int kg = 0; kg < NTM; ++kg) {
+                wm[kg] = wbase[(kg * NTO + nt) * 64];
+                wl[kg] = wbase[(kg * NTO + nt + NTZ) * 64];
+            }
             f32x4 am = f32x4{0, 0, 0, 0}, al = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int kg = 0; kg < NTM; ++kg) {
-                const float4 wm = wbase[(kg * NTO + nt) * 64];
-                const float4 wl = wbase[(kg * NTO + nt + NTZ) * 64];
-                am = mfma16(wm.x, b[kg].x, am); al = mfma16(wl.x, b[kg].x, al);
-                am = mfma16(wm.y, b[kg].y, am); al = mfma16(wl.y, b[kg].y, al);
-                am = mfma16(wm.z, b[kg].z, am); al = mfma16(wl.z, b[kg].z, al);
-                am = mfma16(wm.w, b[kg].w, am); al = mfma16(wl.w, b[kg].w, al);
+                am = mfma16(wm[kg].x, b[kg].x, am); al = mfma16(wl[kg].x, b[kg].x, al);
+                am = mfma16(wm[kg].y, b[kg].y, am); al = mfma16(wl[kg].y, b[kg].y, al);
+                am = mfma16(wm[kg].z, b[kg].z, am); al = mfma16(wl[kg].z, b[kg].z, al);
+                am = mfma16(wm[kg].w, b[kg].w, am); al = mfma16(wl[kg].w, b[kg].w, al);
             }
             if (rv) {
                 const int n = nt * 16 + q * 4;
@@ -166,15 +196,17 @@ __global__ void __launch_bounds__(64) mlp_kernel(const gcpx_mlp_args a) {
             }
         }
     } else {
-        for (int nt = 0; nt < NTO; ++nt) {
+        for (int nt = tstart; nt < NTO; nt += tstride) {
+            float4 w[NTM];
+#pragma unroll
+            for (int kg = 0; kg < NTM; ++kg) w[kg] = wbase[(kg * NTO + nt) * 64];
             f32x4 ao = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int kg = 0; kg < NTM; ++kg) {
-                const float4 w = wbase[(kg * NTO + nt) * 64];
-                ao = mfma16(w.x, b[kg].x, ao);
-                ao = mfma16(w.y, b[kg].y, ao);
-                ao = mfma16(w.z, b[kg].z, ao);
-                ao = mfma16(w.w, b[kg].w, ao);
+                ao = mfma16(w[kg].x, b[kg].x, ao);
+                ao = mfma16(w[kg].y, b[kg].y, ao);
+                ao = mfma16(w[kg].z, b[kg].z, ao);
+                ao = mfma16(w[kg].w, b[kg].w, ao);
             }
             if (rv) {
                 const int n = nt * 16 + q * 4;
@@ -219,9 +251,13 @@ extern "C" int gcpx_mlp(const gcpx_mlp_args* a, void* stream_) {
     } else {
         GCPX_CHECK_ARG(a->out != nullptr, "out is NULL");
     }
-    const int grid = (a->M + 15) / 16;
-    if (a->mid == 128) hipLaunchKernelGGL(mlp_kernel<128>, dim3(grid), dim3(64), 0, stream, *a);
-    else if (a->mid == 32) hipLaunchKernelGGL(mlp_kernel<32>, dim3(grid), dim3(64), 0, stream, *a);
+    const int gx = (a->M + 15) / 16;
+    // split a wide head over blockIdx.y when there are few row blocks (the LSTM initialiser: 16 rows x 6144 cols)
+    const int head_tiles = ((a->epi == GCPX_MLP_GAUSS ? a->out_dim / 2 : a->out_dim) + 15) / 16;
+    int gy = 1;
+    while (gy < 32 && gx * gy < 256 && head_tiles / (4 * gy) >= 2) gy *= 2;
+    if (a->mid == 128) hipLaunchKernelGGL(mlp_kernel<128>, dim3(gx, gy), dim3(256), 0, stream, *a);
+    else if (a->mid == 32) hipLaunchKernelGGL(mlp_kernel<32>, dim3(gx, gy), dim3(256), 0, stream, *a);
     else {
         gcpx_set_error("gcpx_mlp: unsupported mid=%d (128 or 32)", a->mid);
         return GCPX_ERR_UNSUPPORTED;

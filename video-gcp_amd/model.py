@@ -191,9 +191,9 @@ class GCPTreeModel:
                 T[f"lstm{i}.w"], T[f"lstm{i}.b"] = pk.pack_gemm(w), b
             T["out.w"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.out.weight"])
             T["out.b"] = sd[f"{p}.subgoal_pred.out.bias"].contiguous()
-            for j in range(2 * hp.n_lstm_layers):
-                T[f"proj{j}.w"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.projections.{j}.weight"])
-                T[f"proj{j}.b"] = sd[f"{p}.subgoal_pred.projections.{j}.bias"].contiguous()
+            nproj = 2 * hp.n_lstm_layers
+            T["proj.w"] = torch.stack([pk.pack_gemm(sd[f"{p}.subgoal_pred.projections.{j}.weight"]) for j in range(nproj)]).contiguous()
+            T["proj.b"] = torch.stack([sd[f"{p}.subgoal_pred.projections.{j}.bias"] for j in range(nproj)]).contiguous()
             if l == 0:
                 T["init"] = self._pack_predictor(f"{p}.lstm_initializer.net", 2 * hp.lstm_state_dim)
             P[f"tree{l}"] = T
@@ -220,7 +220,7 @@ class GCPTreeModel:
         return s
 
     def _gemm(self, plan, name, srcs, M, N, rpb, wpk, bias, out=None, ob=0, orow=0, epi=rt.EPI_NONE,
-              stats=None, lstm=None):
+              stats=None, lstm=None, batch=None):
         a = rt.GemmArgs()
         for i, s in enumerate(srcs):
             a.src[i] = s
@@ -230,6 +230,8 @@ class GCPTreeModel:
         a.stats_partial = stats.data_ptr() if stats is not None else None
         if lstm is not None:
             a.c_prev, a.c_prev_stride, a.h_out, a.c_out, a.hb, a.hrow, a.h_copy = lstm
+        if batch is not None:
+            a.nbatch, a.z_src_off, a.z_w_off, a.z_bias_off, a.z_out_off = batch
         plan.keep.append(a)
         plan.add(name, self.lib.gcpx_gemm, C.byref(a))
 
@@ -422,11 +424,12 @@ class GCPTreeModel:
             # split_linear merge of the parents' hidden states (tree_lstm.py:43-48)
             nl = hp.n_lstm_layers
             merged = self._buf(f"merged{l}", (M, 2 * nl * H))
-            for jj in range(2 * nl):
-                h1 = self._rowsrc(_addr(Hid, jj * H), PS * SD, 2 * s * SD, H)
-                h2 = self._rowsrc(_addr(Hid, 2 * s * SD + jj * H), PS * SD, 2 * s * SD, H)
-                self._gemm(plan, f"merge{l}.{jj}", [h1, h2], M, H, n, W[f"proj{jj}.w"], W[f"proj{jj}.b"],
-                           out=_addr(merged, jj * H), ob=n * 2 * nl * H, orow=2 * nl * H)
+            # all 2*n_lstm_layers projections in one launch: blockIdx.z = projection index
+            h1 = self._rowsrc(_addr(Hid), PS * SD, 2 * s * SD, H)
+            h2 = self._rowsrc(_addr(Hid, 2 * s * SD), PS * SD, 2 * s * SD, H)
+            self._gemm(plan, f"merge{l}", [h1, h2], M, H, n, W["proj.w"], W["proj.b"], out=_addr(merged),
+                       ob=n * 2 * nl * H, orow=2 * nl * H,
+                       batch=(2 * nl, H, W["proj.w"][0].numel(), H, H))
             # input embedding of [e_l, e_r, z, e_0, e_g] (tree_module.py:97-101)
             x = self._buf(f"x{l}.0", (M, H))
             srcs = [el(), er(), zs()] + ([e0(), eg()] if hp.context_every_step else [])

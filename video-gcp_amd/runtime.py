@@ -36,9 +36,10 @@ class RowSrc(C.Structure):
 
 class GemmArgs(C.Structure):
     _fields_ = [("src", RowSrc * 6), ("nsrc", i32), ("M", i32), ("N", i32), ("K", i32), ("rpb", i32),
-                ("wpk", vp), ("bias", vp), ("out", vp), ("ob", i64), ("orow", i64), ("epi", i32), ("_pad0", i32),
+                ("wpk", vp), ("bias", vp), ("out", vp), ("ob", i64), ("orow", i64), ("epi", i32), ("nbatch", i32),
                 ("stats_partial", vp), ("c_prev", vp), ("c_prev_stride", i64), ("h_out", vp), ("c_out", vp),
-                ("hb", i64), ("hrow", i64), ("h_copy", vp)]
+                ("hb", i64), ("hrow", i64), ("h_copy", vp), ("z_src_off", i64), ("z_w_off", i64),
+                ("z_bias_off", i64), ("z_out_off", i64)]
 
 
 class MlpArgs(C.Structure):
