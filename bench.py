@@ -61,15 +61,13 @@ def main():
     from video_gcp_amd.model import GCPTreeModel
     from helpers import make_inputs
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from video_gcp_amd import dist as D
     if args.gpus > 1:
-        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert int(os.environ.get("WORLD_SIZE", "1")) == args.gpus, \
+            f"launch with python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}"
+        rank, local_rank, world = D.init_from_env("nccl")      # "nccl" is RCCL on ROCm
     else:
+        rank, local_rank, world = 0, 0, 1
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
@@ -78,7 +76,7 @@ def main():
     model.train(not args.eval_bn)
     # the path shards by sequence: every rank predicts its own batch of independent sequences (weak scaling), no
     # data-path collective in the forward
-    inputs, noise, _ = make_inputs(hp, seed=100 + rank, variant="A")
+    inputs, noise, _ = make_inputs(hp, seed=D.shard_seed(100, rank), variant="A")
     dinp = {k: v.to(dev) for k, v in inputs.items()}
     dnoise = noise.to(dev)
 
@@ -103,10 +101,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     head_ms = model.timed_op_ms()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed, device=dev)
 
     if rank == 0:
         frames = world * hp.batch_size * hp.max_seq_len * args.steps

@@ -371,6 +371,216 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------
+// Output head (3x3 conv, 16 input channels, no upsample): wave-autonomous variant.
+//   * the packed weights (9 steps x CT KiB) are loaded into LDS once per 512-thread workgroup (1 per CU);
+//   * every wavefront then works alone on items of 2 rows x 32 pixels: it stages its own haloed 4 x 34 x 16ch
+//     region in a wave-private LDS buffer (global loads prefetched in registers during the previous item's MFMAs),
+//     runs 9 x 4 x CT x 4 MFMAs with weights and activations both read from LDS, and finishes the mixture mean in
+//     registers.  No barrier in steady state: the 8 wavefronts of a CU drift apart, so one wave's staging / epilogue
+//     VALU work overlaps the other waves' MFMAs on the same SIMD.
+// -----------------------------------------------------------------------------------------------------------
+template <int CT>
+struct HeadCfg {
+    static constexpr int RW = 34, RH = 4, CCP = 20;
+    static constexpr int REGION_FLOATS = RH * RW * CCP;                 // 2720 floats per wave
+    static constexpr int W_FLOAT4 = 9 * CT * 64;
+    static constexpr int LDS_BYTES = W_FLOAT4 * 16 + 8 * REGION_FLOATS * 4;
+    static constexpr int NS = (RH * RW * 4 + 63) / 64;                   // float4 slots per lane
+};
+
+template <int CT>
+__global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_args a, const int items_per_wave,
+                                                              const int nitems) {
+    using Cfg = HeadCfg<CT>;
+    constexpr int RW = Cfg::RW, RH = Cfg::RH, CCP = Cfg::CCP, NS = Cfg::NS;
+    extern __shared__ float4 smem4[];
+    float4* wl = smem4;                                                   // [9][CT][64] float4
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* reg = reinterpret_cast<float*>(smem4 + Cfg::W_FLOAT4) + wave * Cfg::REGION_FLOATS;
+    const int j = lane & 15, q = lane >> 4;
+    const int H = a.Hout, W = a.Wout, F = a.F;
+    const int ncb = W / 32, nrp = H / 2;
+
+    for (int i = tid; i < Cfg::W_FLOAT4; i += 512) wl[i] = reinterpret_cast<const float4*>(a.wpk)[i];
+    __syncthreads();
+
+    int pixoff[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) pixoff[pt] = ((pt >> 1) * RW + (pt & 1) * 16 + j) * CCP + q * 4;
+    const gcpx_conv_src sr = a.src[0];
+
+    const int gw = blockIdx.x * 8 + wave;
+    int item = gw * items_per_wave;
+    const int item_end = min(item + items_per_wave, nitems);
+
+    float4 pre[NS];
+    unsigned pre_ok = 0;
+    auto origin = [&](int it, int& f, int& y0, int& x0) {
+        const int cb = it % ncb;
+        const int t = it / ncb;
+        y0 = (t % nrp) * 2; f = t / nrp; x0 = cb * 32;
+    };
+    auto issue_loads = [&](int it) {
+        int f, y0, x0;
+        origin(it, f, y0, x0);
+        pre_ok = 0;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int idx = lane + 64 * k;
+            const int c4 = idx & 3, t = idx >> 2;
+            const int rx = t % RW, ry = t / RW;
+            const int sy = y0 - 1 + ry, sx = x0 - 1 + rx;
+            if (idx < RH * RW * 4 && sy >= 0 && sy < H && sx >= 0 && sx < W) {
+                pre[k] = *reinterpret_cast<const float4*>(sr.ptr + (((size_t)f * H + sy) * W + sx) * 16 + c4 * 4);
+                pre_ok |= 1u << k;
+            }
+        }
+    };
+    if (item < item_end) issue_loads(item);
+
+    for (; item < item_end; ++item) {
+        int f, y0, x0;
+        origin(item, f, y0, x0);
+        // registers -> wave-private LDS region (BatchNorm affine + LeakyReLU of the producer applied here; the
+        // zero padding of the conv stays exactly zero)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int idx = lane + 64 * k;
+            if (idx < RH * RW * 4) {
+                float4 v = pre[k];
+                if (pre_ok & (1u << k)) v = affine_act4(v, sr.scale, sr.shift, (idx & 3) * 4, sr.act);
+                *reinterpret_cast<float4*>(reg + (idx >> 2) * CCP + (idx & 3) * 4) = v;
+            }
+        }
+        if (item + 1 < item_end) issue_loads(item + 1);
+
+        f32x4 acc[CT][4];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int tapoff = ((tap / 3) * RW + (tap % 3)) * CCP;
+            float4 b[4];
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) b[pt] = *reinterpret_cast<const float4*>(reg + pixoff[pt] + tapoff);
+            const float4* wp = wl + tap * CT * 64 + lane;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const float4 w = wp[ct * 64];
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    acc[ct][pt] = mfma16(w.x, b[pt].x, acc[ct][pt]);
+                    acc[ct][pt] = mfma16(w.y, b[pt].y, acc[ct][pt]);
+                    acc[ct][pt] = mfma16(w.z, b[pt].z, acc[ct][pt]);
+                    acc[ct][pt] = mfma16(w.w, b[pt].w, acc[ct][pt]);
+                }
+            }
+        }
+
+        // ---- epilogue ----
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float4 bv = *reinterpret_cast<const float4*>(a.bias + ct * 16 + q * 4);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                acc[ct][pt][0] += bv.x; acc[ct][pt][1] += bv.y; acc[ct][pt][2] += bv.z; acc[ct][pt][3] += bv.w;
+            }
+        }
+        const int mode = a.head_mode;
+        const size_t plane = (size_t)H * W;
+        if (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) {
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                float* op = a.out + (((size_t)f * H + (y0 + (pt >> 1))) * W + (x0 + (pt & 1) * 16 + j)) * a.out_pitch;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int c = ct * 16 + q * 4;
+                    if (c < a.out_pitch) {
+                        const f32x4 v = acc[ct][pt];
+                        *reinterpret_cast<float4*>(op + c) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        }
+        if constexpr (CT >= 5) {
+            if (mode == GCPX_HEAD_DLM_MEAN || mode == GCPX_HEAD_DLM_BOTH) {
+                // kernel channel order: slot 8k..8k+7 = {logit_k, mu_r, mu_g, mu_b, c0, c1, c2, pad}, k = 0..9;
+                // lanes with even q hold the first half of mixture 2*ct + q/2, lane+16 holds the second half.
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    float lg[5], mr[5], mg[5], mb[5];
+#pragma unroll
+                    for (int ct = 0; ct < 5; ++ct) {
+                        const f32x4 v = acc[ct][pt];
+                        const float o0 = __shfl_xor(v[0], 16), o1 = __shfl_xor(v[1], 16), o2 = __shfl_xor(v[2], 16);
+                        const float c0 = fast_tanh(o0), c1 = fast_tanh(o1), c2 = fast_tanh(o2);
+                        lg[ct] = v[0];
+                        mr[ct] = v[1];
+                        mg[ct] = v[2] + c0 * mr[ct];
+                        mb[ct] = v[3] + c1 * mr[ct] + c2 * mg[ct];
+                    }
+                    float m = lg[0];
+#pragma unroll
+                    for (int ct = 1; ct < 5; ++ct) m = fmaxf(m, lg[ct]);
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                    float S = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
+#pragma unroll
+                    for (int ct = 0; ct < 5; ++ct) {
+                        const float w = __expf(lg[ct] - m);
+                        S += w; Sr += w * mr[ct]; Sg += w * mg[ct]; Sb += w * mb[ct];
+                    }
+                    S += __shfl_xor(S, 32); Sr += __shfl_xor(Sr, 32); Sg += __shfl_xor(Sg, 32); Sb += __shfl_xor(Sb, 32);
+                    if (q == 0) {
+                        const float inv = 1.f / S;
+                        float* ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + (pt >> 1)) * W + (x0 + (pt & 1) * 16 + j);
+                        ip[0] = fminf(fmaxf(Sr * inv, -1.f), 1.f);
+                        ip[plane] = fminf(fmaxf(Sg * inv, -1.f), 1.f);
+                        ip[2 * plane] = fminf(fmaxf(Sb * inv, -1.f), 1.f);
+                    }
+                }
+            }
+        }
+        if (mode == GCPX_HEAD_TANH_NCHW) {
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                if (q == 0) {
+                    float* ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + (pt >> 1)) * W + (x0 + (pt & 1) * 16 + j);
+                    ip[0] = tanhf(acc[0][pt][0]);
+                    ip[plane] = tanhf(acc[0][pt][1]);
+                    ip[2 * plane] = tanhf(acc[0][pt][2]);
+                }
+            }
+        }
+    }
+}
+
+template <int CT>
+int launch_head(const gcpx_conv_args* a, hipStream_t stream) {
+    using Cfg = HeadCfg<CT>;
+    auto kern = conv3x3_head_kernel<CT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) {
+            gcpx_set_error("conv3x3 head: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const int nitems = a->F * (a->Hout / 2) * (a->Wout / 32);
+    int grid = gcpx_conv_grid() / 2;                     // one 512-thread workgroup per CU
+    if (grid * 8 > nitems) grid = (nitems + 7) / 8;
+    const int ipw = (nitems + grid * 8 - 1) / (grid * 8);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, stream, *a, ipw, nitems);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
 int g_conv_grid = 0;
 
 template <bool UP, int CC, int CT, int TILE>
@@ -435,9 +645,10 @@ extern "C" int gcpx_conv3x3(const gcpx_conv_args* a, void* stream_) {
     const int W = a->Wout;
     if (!a->upsample) {
         GCPX_CHECK_ARG(a->Cin == 16, "non-upsampling 3x3 conv (output head) expects 16 input channels");
-        if (W % 32 == 0) {
-            if (CT == 7) return launch<false, 16, 7, 0>(a, stream);
-            if (CT == 1) return launch<false, 16, 1, 0>(a, stream);
+        GCPX_CHECK_ARG(a->nsrc == 1 && a->src[0].frame_div == 1, "output head takes one per-frame source");
+        if (W % 32 == 0 && a->Hout % 2 == 0) {
+            if (CT == 7) return launch_head<7>(a, stream);
+            if (CT == 1) return launch_head<1>(a, stream);
         }
     } else {
         GCPX_CHECK_ARG(a->Cin % 32 == 0, "upsampling 3x3 conv expects Cin % 32 == 0");
