@@ -227,6 +227,14 @@ int gcpx_graph_end(void* stream, void** graph_exec);
 int gcpx_graph_launch(void* graph_exec, void* stream);
 int gcpx_graph_destroy(void* graph_exec);
 
+/* side streams for the independent branches of the forward (the I_0 / I_g encoder passes, the per-level
+   split_linear merge and prior next to the posterior chain, the aux heads next to the decoder).  Under
+   gcpx_graph_begin/_end a gcpx_event_record on the capturing stream followed by gcpx_stream_wait_event on a side
+   stream forks the capture; the reverse joins it, so the branches become parallel paths of the hipGraph. */
+int gcpx_stream_create(void** stream);
+int gcpx_stream_destroy(void* stream);
+int gcpx_stream_wait_event(void* stream, void* ev);
+
 /* event timing on the caller's stream (bench.py measures the dominant kernel with these) */
 int gcpx_event_create(void** ev);
 int gcpx_event_record(void* ev, void* stream);

@@ -17,6 +17,8 @@
 //     output head, the discrete-logistic-mixture mean computed in registers (4-lane column shuffles).
 #include "common.cuh"
 
+#include <type_traits>
+
 namespace {
 
 template <int TILE> struct TileShape;
@@ -457,12 +459,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
         if (item + 1 < item_end) issue_loads(item + 1);
 
         f32x4 acc[CT][4];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
+        // one (tap) step: 4 ds_read_b128 of activations + CT of weights, 4*4*CT MFMAs.  The first step starts the
+        // accumulators from the inline constant 0 (no v_mov zero-fill: VALU issue slots are as scarce as MFMA slots,
+        // f32 MFMA and VALU do not overlap on a SIMD).
+        auto step = [&](const int tap, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             const int tapoff = ((tap / 3) * RW + (tap % 3)) * CCP;
             float4 b[4];
 #pragma unroll
@@ -473,13 +474,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
                 const float4 w = wp[ct * 64];
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) {
-                    acc[ct][pt] = mfma16(w.x, b[pt].x, acc[ct][pt]);
+                    if constexpr (FIRST) acc[ct][pt] = mfma16(w.x, b[pt].x, f32x4{0, 0, 0, 0});
+                    else acc[ct][pt] = mfma16(w.x, b[pt].x, acc[ct][pt]);
                     acc[ct][pt] = mfma16(w.y, b[pt].y, acc[ct][pt]);
                     acc[ct][pt] = mfma16(w.z, b[pt].z, acc[ct][pt]);
                     acc[ct][pt] = mfma16(w.w, b[pt].w, acc[ct][pt]);
                 }
             }
-        }
+        };
+        step(0, std::true_type{});
+#pragma unroll 1
+        for (int tap = 1; tap < 9; ++tap) step(tap, std::false_type{});
 
         // ---- epilogue ----
 #pragma unroll

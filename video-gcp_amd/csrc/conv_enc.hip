@@ -57,26 +57,39 @@ __global__ void __launch_bounds__(256) conv4x4s2_kernel(const gcpx_conv_args a, 
                 inb[pt] = pv[pt] && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
                 bp[pt] = s.ptr + (((size_t)pf[pt] * Hin + (inb[pt] ? iy : 0)) * Win + (inb[pt] ? ix : 0)) * Cin + q * 4;
             }
-            for (int cg = 0; cg < ncg; ++cg) {
-                float4 b[PR];
+            // loads of UK channel groups go out together, then their MFMAs (latency-bound otherwise)
+            constexpr int UK = (CT >= 8) ? 1 : (CT >= 4 ? 2 : 4);
+            for (int cg = 0; cg < ncg; cg += UK) {
+                float4 b[UK][PR], w[UK][CT];
 #pragma unroll
-                for (int pt = 0; pt < PR; ++pt) {
-                    b[pt] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (inb[pt]) {
-                        b[pt] = *reinterpret_cast<const float4*>(bp[pt] + cg * 16);
-                        b[pt] = affine_act4(b[pt], s.scale, s.shift, cg * 16 + q * 4, s.act);
-                    }
+                for (int u = 0; u < UK; ++u) {
+                    const int c = (cg + u < ncg) ? cg + u : ncg - 1;
+#pragma unroll
+                    for (int pt = 0; pt < PR; ++pt) b[u][pt] = *reinterpret_cast<const float4*>(bp[pt] + c * 16);
+                    const float4* wp = wbase + (size_t)(tap * ncg + c) * CT * 64;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) w[u][ct] = wp[ct * 64];
                 }
-                const float4* wp = wbase + (size_t)(tap * ncg + cg) * CT * 64;
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const float4 w = wp[ct * 64];
+                for (int u = 0; u < UK; ++u) {
+                    if (cg + u < ncg) {
 #pragma unroll
-                    for (int pt = 0; pt < PR; ++pt) {
-                        acc[ct][pt] = mfma16(w.x, b[pt].x, acc[ct][pt]);
-                        acc[ct][pt] = mfma16(w.y, b[pt].y, acc[ct][pt]);
-                        acc[ct][pt] = mfma16(w.z, b[pt].z, acc[ct][pt]);
-                        acc[ct][pt] = mfma16(w.w, b[pt].w, acc[ct][pt]);
+                        for (int pt = 0; pt < PR; ++pt) {
+                            float4 bb = affine_act4(b[u][pt], s.scale, s.shift, (cg + u) * 16 + q * 4, s.act);
+                            const float m = inb[pt] ? 1.f : 0.f;     // conv zero padding stays exactly zero
+                            bb.x *= m; bb.y *= m; bb.z *= m; bb.w *= m;
+                            b[u][pt] = bb;
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                            for (int pt = 0; pt < PR; ++pt) {
+                                acc[ct][pt] = mfma16(w[u][ct].x, b[u][pt].x, acc[ct][pt]);
+                                acc[ct][pt] = mfma16(w[u][ct].y, b[u][pt].y, acc[ct][pt]);
+                                acc[ct][pt] = mfma16(w[u][ct].z, b[u][pt].z, acc[ct][pt]);
+                                acc[ct][pt] = mfma16(w[u][ct].w, b[u][pt].w, acc[ct][pt]);
+                            }
+                        }
                     }
                 }
             }

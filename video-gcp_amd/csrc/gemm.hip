@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
         }
         const int nkg = src.width / 16;
         const bool xf = src.scale || src.act;
-        constexpr int UK = (PR * CR >= 8) ? 2 : 4;      // k-groups whose loads are issued together
+        constexpr int UK = (PR * CR >= 8) ? 2 : (PR * CR >= 4) ? 4 : 8;   // k-groups whose loads are issued together
         for (int kg = 0; kg < nkg; kg += UK) {
             float4 b[UK][PR], w[UK][CR];
 #pragma unroll
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
 #pragma unroll
                     for (int pt = 0; pt < PR; ++pt) {
                         float4 bb = b[u][pt];
-                        if (xf) bb = affine_act4(bb, src.scale, src.shiftv, ((kg + u) * 16 + q * 4) % src.cmod, src.act);
+                        if (xf) bb = affine_act4(bb, src.scale, src.shiftv, ((kg + u) * 16 + q * 4) & (src.cmod - 1), src.act);
                         bb.x *= mask[pt]; bb.y *= mask[pt]; bb.z *= mask[pt]; bb.w *= mask[pt];
                         b[u][pt] = bb;
                     }
@@ -174,7 +174,7 @@ TileChoice choose_tile(int M, int N, int nb = 1) {
                 const long rbk = (M + 16 * pr - 1) / (16 * pr);
                 const long cbk = (N / 16 + 4 * cr - 1) / (4 * cr);
                 const long wg = rbk * cbk * nb;
-                if (wg >= 384) return TileChoice{pr, cr};
+                if (wg >= 200) return TileChoice{pr, cr};
                 if (wg > best_wg) { best_wg = wg; best = TileChoice{pr, cr}; }
             }
     }
@@ -208,7 +208,9 @@ extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
     for (int s = 0; s < a->nsrc; ++s) {
         GCPX_CHECK_ARG(a->src[s].ptr != nullptr, "source pointer is NULL");
         GCPX_CHECK_ARG(a->src[s].width > 0 && a->src[s].width % 16 == 0, "source width must be a multiple of 16");
-        GCPX_CHECK_ARG(!(a->src[s].scale || a->src[s].act) || a->src[s].cmod > 0, "cmod must be set with scale/act");
+        GCPX_CHECK_ARG(!(a->src[s].scale || a->src[s].act) ||
+                           (a->src[s].cmod > 0 && (a->src[s].cmod & (a->src[s].cmod - 1)) == 0),
+                       "cmod must be a power of two when scale/act is set");
         ksum += a->src[s].width;
     }
     GCPX_CHECK_ARG(ksum == a->K, "K != sum of source widths");

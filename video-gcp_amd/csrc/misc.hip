@@ -247,6 +247,24 @@ extern "C" int gcpx_graph_destroy(void* graph_exec) {
     return GCPX_OK;
 }
 
+extern "C" int gcpx_stream_create(void** stream) {
+    GCPX_CHECK_ARG(stream != nullptr, "stream is NULL");
+    hipStream_t s;
+    GCPX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_stream_destroy(void* stream) {
+    GCPX_HIP(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_stream_wait_event(void* stream, void* ev) {
+    GCPX_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<hipEvent_t>(ev), 0));
+    return GCPX_OK;
+}
+
 extern "C" int gcpx_event_create(void** ev) {
     GCPX_CHECK_ARG(ev != nullptr, "ev is NULL");
     hipEvent_t e;

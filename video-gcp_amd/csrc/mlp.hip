@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
                 for (int u = 0; u < 4; ++u) {
                     if (kg + u < nkg) {
                         float4 bb = b[u];
-                        if (xf) bb = affine_act4(bb, src.scale, src.shiftv, ((kg + u) * 16 + q * 4) % src.cmod, src.act);
+                        if (xf) bb = affine_act4(bb, src.scale, src.shiftv, ((kg + u) * 16 + q * 4) & (src.cmod - 1), src.act);
                         bb.x *= mask; bb.y *= mask; bb.z *= mask; bb.w *= mask;
 #pragma unroll
                         for (int t = 0; t < TPW; ++t) {

@@ -28,22 +28,55 @@ def _addr(t, off_elems=0):
     return t.data_ptr() + 4 * off_elems
 
 
-class _Plan:
-    """A recorded launch sequence (C entry point + argument struct); replayed eagerly or under a hipGraph."""
+N_LANES = 3
 
-    def __init__(self):
-        self.ops = []
+
+class _Plan:
+    """A recorded launch sequence (C entry point + argument struct) over up to N_LANES streams: lane 0 is the
+    model's main stream, lanes 1.. are side streams for independent branches.  `fork`/`join` order the lanes with
+    events; under hipGraph capture they become parallel paths of the graph.  Replayed eagerly or as a graph."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.ops = []        # (name, fn, args, lane) | ("@fork"/"@join", None, (lanes, events), 0)
         self.keep = []       # keeps argument structs / tensors alive
         self.graph = None
+        self.lane = 0
 
     def add(self, name, fn, *args):
-        self.ops.append((name, fn, args))
+        self.ops.append((name, fn, args, self.lane))
 
-    def run(self, stream):
-        for name, fn, args in self.ops:
-            st = fn(*args, stream)
-            if st != 0:
-                rt.check(st, name)
+    def _events(self, n):
+        evs = []
+        for _ in range(n):
+            e = C.c_void_p()
+            rt.check(self.lib.gcpx_event_create(C.byref(e)), "event_create")
+            evs.append(e)
+        return evs
+
+    def fork(self, lanes):
+        self.ops.append(("@fork", None, (tuple(lanes), self._events(1)), 0))
+
+    def join(self, lanes):
+        self.ops.append(("@join", None, (tuple(lanes), self._events(len(lanes))), 0))
+
+    def run(self, streams, ops=None):
+        lib = self.lib
+        for name, fn, args, lane in (self.ops if ops is None else ops):
+            if name == "@fork":
+                lanes, evs = args
+                rt.check(lib.gcpx_event_record(evs[0], streams[0]), "fork")
+                for l in lanes:
+                    rt.check(lib.gcpx_stream_wait_event(streams[l], evs[0]), "fork")
+            elif name == "@join":
+                lanes, evs = args
+                for l, e in zip(lanes, evs):
+                    rt.check(lib.gcpx_event_record(e, streams[l]), "join")
+                    rt.check(lib.gcpx_stream_wait_event(streams[0], e), "join")
+            else:
+                st = fn(*args, streams[lane])
+                if st != 0:
+                    rt.check(st, name)
 
 
 class Outputs(dict):
@@ -71,6 +104,12 @@ class GCPTreeModel:
         # hipGraph capture is not allowed on the legacy default stream: the model launches on its own stream
         # and orders it against the caller's current stream with events (wait_stream), never a host sync
         self._stream = torch.cuda.Stream(device=self.device)
+        self._streams = [self._stream.cuda_stream]
+        for _ in range(N_LANES - 1):
+            sp = C.c_void_p()
+            with torch.cuda.device(self.device):
+                rt.check(self.lib.gcpx_stream_create(C.byref(sp)), "stream_create")
+            self._streams.append(sp)
         self._timed_op = None                 # name of one plan op bracketed by HIP events (bench.py roofline)
         self._timed_events = []
         self._pack_all()
@@ -339,7 +378,7 @@ class GCPTreeModel:
         L, T, N = hp.hierarchy_levels, hp.max_seq_len, hp.n_nodes
         nz, nv, H, SD = hp.nz_enc, hp.nz_vae, hp.nz_mid_lstm, hp.lstm_state_dim
         PS = 2 ** L + 1                                     # slots per batch element
-        plan = _Plan()
+        plan = _Plan(lib)
         G = lib.gcpx_conv_grid()
 
         E = self._buf("E", (B, PS, nz))
@@ -361,6 +400,13 @@ class GCPTreeModel:
 
         # ---- run_encoder (base_gcp.py:184-213) ----
         enc_traj = inf_enc = None
+        # three independent encoder passes (separate BatchNorm statistics, base_gcp.py:188,208,209) on three lanes
+        plan.fork([1, 2])
+        plan.lane = 1
+        skips = self._plan_encoder(plan, "I0", tin["I_0"].data_ptr(), B, _addr(E), PS * nz, 0, 1)
+        plan.lane = 2
+        self._plan_encoder(plan, "Ig", tin["I_g"].data_ptr(), B, _addr(E, 2 ** L * nz), PS * nz, 0, 1)
+        plan.lane = 0
         if has_traj:
             enc_traj = self._buf("enc_traj", (B * T, nz))
             self._plan_encoder(plan, "traj", tin["traj_seq"].data_ptr(), B * T, enc_traj.data_ptr(), T * nz, nz, T)
@@ -379,8 +425,7 @@ class GCPTreeModel:
             sc, sh = self._bn(plan, "seq.bn", "inf_encoder.net.pyramid-0.norm", hp.nz_mid, st, nrb, hp.nz_mid, B * T)
             self._gemm(plan, "seq.head", taps(y2, hp.nz_mid, scale=sc, shiftv=sh, act=rt.ACT_LRELU, cmod=hp.nz_mid),
                        B * T, nz, T, P["seq.head.w"], P["seq.head.b"], out=inf_enc.data_ptr(), ob=T * nz, orow=nz)
-        skips = self._plan_encoder(plan, "I0", tin["I_0"].data_ptr(), B, _addr(E), PS * nz, 0, 1)
-        self._plan_encoder(plan, "Ig", tin["I_g"].data_ptr(), B, _addr(E, 2 ** L * nz), PS * nz, 0, 1)
+        plan.join([1, 2])
         e0 = lambda: self._rowsrc(_addr(E), PS * nz, 0, nz)
         eg = lambda: self._rowsrc(_addr(E, 2 ** L * nz), PS * nz, 0, nz)
 
@@ -402,6 +447,26 @@ class GCPTreeModel:
             er = lambda: self._rowsrc(_addr(E, 2 * s * nz), PS * nz, 2 * s * nz, nz)
             pz_out = (_addr(PZ, nodeoff(2 * nv)), PS * 2 * nv, 2 * s * 2 * nv)
             z_map = (_addr(Z, nodeoff(nv)), PS * nv, 2 * s * nv)
+            nl = hp.n_lstm_layers
+            merged = self._buf(f"merged{l}", (M, 2 * nl * H))
+
+            def plan_merge():
+                # split_linear merge of the parents' hidden states (tree_lstm.py:43-48): all 2*n_lstm_layers
+                # projections in one launch, blockIdx.z = projection index
+                h1 = self._rowsrc(_addr(Hid), PS * SD, 2 * s * SD, H)
+                h2 = self._rowsrc(_addr(Hid, 2 * s * SD), PS * SD, 2 * s * SD, H)
+                self._gemm(plan, f"merge{l}", [h1, h2], M, H, n, W["proj.w"], W["proj.b"], out=_addr(merged),
+                           ob=n * 2 * nl * H, orow=2 * nl * H, batch=(2 * nl, H, W["proj.w"][0].numel(), H, H))
+
+            # lanes: 0 = the chain that produces z and the embedding, 1 = parent-state merge (needs only the
+            # previous level), 2 = the prior when it is off the critical path (posterior mode)
+            side = ([1] if l > 0 else []) + ([2] if not (has_z or sample_prior) else [])
+            if side:
+                plan.fork(side)
+            if l > 0:
+                plan.lane = 1
+                plan_merge()
+                plan.lane = 0
             if has_z:
                 # given latents in depth-first order (tree.py:38); reparametrised with the learned prior (:79-82)
                 g = (_addr(tin["z"], (s - 1) * nv), N * nv, 2 * s * nv) + z_map
@@ -410,7 +475,9 @@ class GCPTreeModel:
                 g = (_addr(tin["eps"], (n - 1) * nv), N * nv, nv) + z_map
                 self._mlp(plan, f"prior{l}", W["prior"], [el(), er()], M, n, out=pz_out[0], ob=pz_out[1], orow=pz_out[2], gauss=g)
             else:
+                plan.lane = 2
                 self._mlp(plan, f"prior{l}", W["prior"], [el(), er()], M, n, out=pz_out[0], ob=pz_out[1], orow=pz_out[2])
+                plan.lane = 0
                 # posterior: gather inf_enc_seq at the node's matched timestep (inference.py:27-33)
                 et = self._rowsrc(inf_enc.data_ptr(), 0, nz, nz, rowidx=etrow[B * (n - 1):])
                 g = (_addr(tin["eps"], (n - 1) * nv), N * nv, nv) + z_map
@@ -421,19 +488,13 @@ class GCPTreeModel:
                 # MLPLSTMCellInitializer (tree_module.py:104-105): (h_left, h_right) -> slots 0 and 2^L
                 self._mlp(plan, "lstm_init", W["init"], [el(), er(), zs()], M, n, out=_addr(Hid), ob=PS * SD, orow=0,
                           oblk=2 ** L * SD, out_split=SD)
-            # split_linear merge of the parents' hidden states (tree_lstm.py:43-48)
-            nl = hp.n_lstm_layers
-            merged = self._buf(f"merged{l}", (M, 2 * nl * H))
-            # all 2*n_lstm_layers projections in one launch: blockIdx.z = projection index
-            h1 = self._rowsrc(_addr(Hid), PS * SD, 2 * s * SD, H)
-            h2 = self._rowsrc(_addr(Hid, 2 * s * SD), PS * SD, 2 * s * SD, H)
-            self._gemm(plan, f"merge{l}", [h1, h2], M, H, n, W["proj.w"], W["proj.b"], out=_addr(merged),
-                       ob=n * 2 * nl * H, orow=2 * nl * H,
-                       batch=(2 * nl, H, W["proj.w"][0].numel(), H, H))
+                plan_merge()
             # input embedding of [e_l, e_r, z, e_0, e_g] (tree_module.py:97-101)
             x = self._buf(f"x{l}.0", (M, H))
             srcs = [el(), er(), zs()] + ([e0(), eg()] if hp.context_every_step else [])
             self._gemm(plan, f"embed{l}", srcs, M, H, n, W["embed.w"], W["embed.b"], out=x.data_ptr(), ob=n * H, orow=H)
+            if side:
+                plan.join(side)
             for i in range(nl):
                 xn = self._buf(f"x{l}.{i + 1}", (M, H))
                 xs = self._rowsrc(x.data_ptr(), n * H, H, H)
@@ -445,6 +506,36 @@ class GCPTreeModel:
                 x = xn
             self._gemm(plan, f"out{l}", [self._rowsrc(x.data_ptr(), n * H, H, H)], M, nz, n, W["out.w"], W["out.b"],
                        out=_addr(E, nodeoff(nz)), ob=PS * nz, orow=2 * s * nz)
+
+        # ---- latent-space heads: independent of the decoder, run next to it on lane 1 ----
+        F = B * N
+        plan.fork([1])
+        plan.lane = 1
+        mes = self._buf("model_enc_seq", (B, T, nz))
+        plan.add("gather.model_enc_seq", lib.gcpx_gather_rows, E.data_ptr(), kept_idx.data_ptr(), mes.data_ptr(), B, T, PS, 1,
+                 nz)
+        outs["model_enc_seq_padded"] = mes
+        # existence predictor over depth-first latents (frame_binding.py:67-78)
+        exist = self._buf("existence", (B, N))
+        self._mlp(plan, "existence", P["existence"], [self._rowsrc(_addr(E, nz), PS * nz, nz, nz)], F, N,
+                  out=exist.data_ptr(), ob=N, orow=1)
+        outs["existence"] = exist
+        # run_auxilliary_models (base_gcp.py:234-262)
+        if hp.attach_state_regressor:
+            rs = self._buf("regressed_state", (B, T, hp.state_dim))
+            self._mlp(plan, "state_regressor", P["state_regressor"], [self._rowsrc(mes.data_ptr(), T * nz, nz, nz)],
+                      B * T, T, out=rs.data_ptr(), ob=T * hp.state_dim, orow=hp.state_dim)
+            outs["regressed_state_padded"] = rs
+        if hp.attach_inv_mdl and phase == "train":
+            # InverseModel.full_seq_forward (inverse_mdl.py:110-134)
+            act = self._buf("actions", (B, T - 1, hp.n_actions))
+            first = enc_traj if has_traj else mes
+            s0 = self._rowsrc(first.data_ptr(), T * nz, nz, nz)
+            s1 = self._rowsrc(_addr(mes, nz), T * nz, nz, nz)
+            self._mlp(plan, "inv_mdl", P["inv_mdl"], [s0, s1], B * (T - 1), T - 1, out=act.data_ptr(),
+                      ob=(T - 1) * hp.n_actions, orow=hp.n_actions)
+            outs["actions_padded"] = act
+        plan.lane = 0
 
         # ---- dense_rec: decode every node (tree_dense_rec.py:41-44) ----
         F = B * N
@@ -486,10 +577,11 @@ class GCPTreeModel:
         a = self._conv_args([prev], F, S, S, S, S, hp.head_channels, self._head_pitch, P["dec.head.w"], P["dec.head.b"],
                             distr, upsample=0, head_mode=mode, images=images)
         plan.keep.append(a)
+        plan.join([1])           # the latent-space heads overlapped the decoder blocks; the head runs alone
         plan.add("dec.head", lib.gcpx_conv3x3, C.byref(a))
         outs["images_df"], outs["distr_df_kernel_order"] = images, distr
 
-        # ---- pruning / matching gathers ----
+        # ---- pruning / matching gathers of decoded frames ----
         row = hp.input_nc * S * S
         if has_traj and phase == "train":
             matched = self._buf("matched_images", (B, T, hp.input_nc, S, S))
@@ -499,31 +591,7 @@ class GCPTreeModel:
         pruned = self._buf("pruned_images", (B, T, hp.input_nc, S, S))
         plan.add("gather.pruned", lib.gcpx_gather_rows, images.data_ptr(), kept_idx.data_ptr(), pruned.data_ptr(), B, T, N, 0,
                  row)
-        mes = self._buf("model_enc_seq", (B, T, nz))
-        plan.add("gather.model_enc_seq", lib.gcpx_gather_rows, E.data_ptr(), kept_idx.data_ptr(), mes.data_ptr(), B, T, PS, 1,
-                 nz)
-        outs["pruned_padded"], outs["model_enc_seq_padded"] = pruned, mes
-        # existence predictor over depth-first latents (frame_binding.py:67-78)
-        exist = self._buf("existence", (B, N))
-        self._mlp(plan, "existence", P["existence"], [self._rowsrc(_addr(E, nz), PS * nz, nz, nz)], F, N,
-                  out=exist.data_ptr(), ob=N, orow=1)
-        outs["existence"] = exist
-
-        # ---- run_auxilliary_models (base_gcp.py:234-262) ----
-        if hp.attach_state_regressor:
-            rs = self._buf("regressed_state", (B, T, hp.state_dim))
-            self._mlp(plan, "state_regressor", P["state_regressor"], [self._rowsrc(mes.data_ptr(), T * nz, nz, nz)],
-                      B * T, T, out=rs.data_ptr(), ob=T * hp.state_dim, orow=hp.state_dim)
-            outs["regressed_state_padded"] = rs
-        if hp.attach_inv_mdl and phase == "train":
-            # InverseModel.full_seq_forward (inverse_mdl.py:110-134)
-            act = self._buf("actions", (B, T - 1, hp.n_actions))
-            first = enc_traj if has_traj else mes
-            s0 = self._rowsrc(first.data_ptr(), T * nz, nz, nz)
-            s1 = self._rowsrc(_addr(mes, nz), T * nz, nz, nz)
-            self._mlp(plan, "inv_mdl", P["inv_mdl"], [s0, s1], B * (T - 1), T - 1, out=act.data_ptr(),
-                      ob=(T - 1) * hp.n_actions, orow=hp.n_actions)
-            outs["actions_padded"] = act
+        outs["pruned_padded"] = pruned
 
         outs.update(E=E, Hid=Hid, Z=Z, PZ=PZ, QZ=QZ, node_t=node_t, leave=leave, frame2node=f2n, seq_len=seq_len,
                     kept_idx=kept_idx, enc_traj_seq=enc_traj, inf_enc_seq=inf_enc)
@@ -580,20 +648,17 @@ class GCPTreeModel:
             self._run_timed(plan, stream)
         elif self.use_graph:
             if plan.graph is None:
-                plan.run(stream)                      # warm-up (sets kernel attributes) outside capture
-                plan.graph = self._capture(plan.ops, stream)
+                plan.run(self._streams)               # warm-up (sets kernel attributes) outside capture
+                plan.graph = self._capture(plan, plan.ops, stream)
             rt.check(self.lib.gcpx_graph_launch(plan.graph, stream), "graph_launch")
         else:
-            plan.run(stream)
+            plan.run(self._streams)
         caller.wait_stream(self._stream)
         return self._wrap_outputs(plan.outs, tin, phase)
 
-    def _capture(self, ops, stream):
+    def _capture(self, plan, ops, stream):
         rt.check(self.lib.gcpx_graph_begin(stream), "graph_begin")
-        for name, fn, args in ops:
-            st = fn(*args, stream)
-            if st != 0:
-                rt.check(st, name)
+        plan.run(self._streams, ops)
         g = C.c_void_p()
         rt.check(self.lib.gcpx_graph_end(stream, C.byref(g)), "graph_end")
         return g
@@ -604,21 +669,43 @@ class GCPTreeModel:
         self._timed_events = []
 
     def _run_timed(self, plan, stream):
-        names = [n for n, _, _ in plan.ops]
+        names = [op[0] for op in plan.ops]
         i = names.index(self._timed_op)
         if getattr(plan, "split", None) is None:
-            plan.run(stream)
-            plan.split = (self._capture(plan.ops[:i], stream), self._capture(plan.ops[i + 1:], stream))
+            plan.run(self._streams)
+            assert plan.ops[i][3] == 0, "the timed op must be on the main lane"
+            plan.split = (self._capture(plan, plan.ops[:i], stream), self._capture(plan, plan.ops[i + 1:], stream))
         e0, e1 = C.c_void_p(), C.c_void_p()
         rt.check(self.lib.gcpx_event_create(C.byref(e0)), "event_create")
         rt.check(self.lib.gcpx_event_create(C.byref(e1)), "event_create")
         rt.check(self.lib.gcpx_graph_launch(plan.split[0], stream), "graph_launch")
         rt.check(self.lib.gcpx_event_record(e0, stream), "event_record")
-        name, fn, args = plan.ops[i]
+        name, fn, args, _ = plan.ops[i]
         rt.check(fn(*args, stream), name)
         rt.check(self.lib.gcpx_event_record(e1, stream), "event_record")
         rt.check(self.lib.gcpx_graph_launch(plan.split[1], stream), "graph_launch")
         self._timed_events.append((e0, e1))
+
+    def profile_ops(self, inputs, phase="train", noise=None, repeats=5):
+        """Per-op device time of the current plan (eager launches bracketed by events): [(name, microseconds)].
+        Tuning aid; not used on the hot path."""
+        self.forward(inputs, phase, noise)
+        torch.cuda.synchronize()
+        plan = [v[1] for v in self._plans.values()][-1]
+        res = []
+        with torch.cuda.stream(self._stream):
+            for name, fn, args, _ in plan.ops:
+                if name.startswith("@"):
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                rt.check(fn(*args, self._stream.cuda_stream), name)
+                e0.record(self._stream)
+                for _ in range(repeats):
+                    rt.check(fn(*args, self._stream.cuda_stream), name)
+                e1.record(self._stream)
+                self._stream.synchronize()
+                res.append((name, 1e3 * e0.elapsed_time(e1) / repeats))
+        return res
 
     def timed_op_ms(self):
         """Durations (ms) of the timed op for every forward since set_timed_op(); synchronises."""

@@ -70,6 +70,9 @@ SYMBOLS = [
     ("gcpx_graph_end", C.c_int, [vp, C.POINTER(vp)]),
     ("gcpx_graph_launch", C.c_int, [vp, vp]),
     ("gcpx_graph_destroy", C.c_int, [vp]),
+    ("gcpx_stream_create", C.c_int, [C.POINTER(vp)]),
+    ("gcpx_stream_destroy", C.c_int, [vp]),
+    ("gcpx_stream_wait_event", C.c_int, [vp, vp]),
     ("gcpx_event_create", C.c_int, [C.POINTER(vp)]),
     ("gcpx_event_record", C.c_int, [vp, vp]),
     ("gcpx_event_elapsed_ms", C.c_int, [vp, vp, C.POINTER(C.c_float)]),
