@@ -80,6 +80,9 @@ typedef struct gcpx_conv_args {
     float* images;          /* dev: NCHW [F][3][H][W] for the head modes that produce images */
     float* stats_partial;   /* dev: [gcpx_conv_grid()][2][CT*16] per-workgroup sum / sum-of-squares of the
                                raw output for training-mode BatchNorm, or NULL */
+    const int32_t* raw_row_map; /* dev: [F] or NULL (output head only): frame f stores its raw parameters at row
+                               raw_row_map[f] of `out`, or not at all when the entry is negative — only the nodes matched
+                               to a ground-truth frame need their distribution parameters (frame_binding.py:91-92) */
 } gcpx_conv_args;
 
 /* decoder block: (bilinear x2 upsample +) 3x3 conv, pad 1 */
@@ -207,10 +210,11 @@ int gcpx_mlp(const gcpx_mlp_args* a, void* stream);
  *   etilde_row  [L-level blocks, bf order: level l holds B*2^l entries, b-major]  b*T + node timestep:
  *               absolute row of inf_enc_seq[B*T] gathered for the posterior (inference.py:27-33)
  *   seq_len     [B]     end_ind + 1
+ *   node2row    [B][N]  b*T + timestep for kept nodes, -1 otherwise (row of the matched-frame arrays; may be NULL)
  * ------------------------------------------------------------------------------------------------- */
 int gcpx_balanced_binding(const int64_t* end_ind, int32_t B, int32_t L, int32_t T, int32_t* node_t,
                           int32_t* leave, int32_t* frame2node, int32_t* etilde_row, int32_t* seq_len,
-                          void* stream);
+                          int32_t* node2row, void* stream);
 
 /* out[b][t] = src[b][idx[b][t] + idx_offset] for rows of `row_floats` floats (matched / pruned sequences);
    src has N rows per batch element; rows with idx < 0 are zero-filled (pad_sequence, base_gcp.py:242). */
@@ -218,6 +222,44 @@ int gcpx_gather_rows(const float* src, const int32_t* idx, float* out, int32_t B
                      int32_t idx_offset, int64_t row_floats, void* stream);
 /* compaction of kept nodes: dst_idx[b][k] = k-th depth-first position with leave==1 (k < seq_len[b]), else -1 */
 int gcpx_compact_index(const int32_t* leave, int32_t B, int32_t N, int32_t T, int32_t* dst_idx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Losses (deterministic reductions).
+ *   gcpx_dlm_nll:  decoder.nll(matched distr, traj_seq) of frame_binding.py:88-99 for the discrete-logistic-mixture head:
+ *                  params [rows][npix][pitch] in the head kernel's channel order, target NCHW [rows][3][npix];
+ *                  nll_out[row] = sum over pixels of the negative log-likelihood; rows whose row_weight (pad_mask) is 0
+ *                  are skipped and report 0.
+ *   gcpx_gauss_nll: the same for the gaussian head (mu = images).
+ *   gcpx_kl_gauss: KLDivLoss2(q_z, p_z) of inference.py:38-43: per batch element, sum over nodes and dims of
+ *                  max(KL, free_nats); q/p rows are [mu | log_sigma] at base + b*batch_stride + n*node_stride.
+ *   gcpx_loss_combine: length CE (misc.py:53-56), existence BCE (frame_binding.py:80-86), state L2
+ *                  (base_gcp.py:281-286), the weighted total of get_total_loss (base_gcp.py:294-304).
+ *                  out[0..6] = dense_img_rec, kl, len_pred, existence_predictor, state_regression, total, nll.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct gcpx_loss_args {
+    const float* nll_bt;          /* [B*T] */
+    const float* pad_mask;        /* [B*T] */
+    const float* kl_b;            /* [B] or NULL */
+    const float* len_logits;      /* [B][T] or NULL */
+    const int64_t* end_ind;       /* [B] */
+    const float* existence;       /* [B][N] logits or NULL */
+    const int32_t* leave;         /* [B][N] */
+    const float* regressed_state; /* [B][T][state_dim] or NULL */
+    const float* state_target;    /* [B][T][state_dim] or NULL */
+    const int32_t* seq_len;       /* [B] */
+    float* out;                   /* [8] */
+    int32_t B, T, N, state_dim;
+    float w_rec, w_kl, w_len, w_exist, w_state;
+    float total_div;
+} gcpx_loss_args;
+
+int gcpx_dlm_nll(const float* params, const float* target, const float* row_weight, float* nll_out, int32_t rows,
+                 int32_t npix, int32_t pitch, int32_t n_mix, void* stream);
+int gcpx_gauss_nll(const float* mu, const float* target, const float* log_sigma, float* nll_out, int32_t rows,
+                   int32_t nelem, void* stream);
+int gcpx_kl_gauss(const float* qz, const float* pz, int32_t B, int32_t N, int32_t nz, int64_t batch_stride,
+                  int64_t node_stride, float free_nats, float* kl_out, void* stream);
+int gcpx_loss_combine(const gcpx_loss_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * hipGraph helpers: capture a launch sequence once, replay it per step.

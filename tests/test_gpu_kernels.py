@@ -299,8 +299,9 @@ def test_balanced_binding_bit_exact(env):
         node_t, leave = torch.zeros(B, N, dtype=torch.int32, device=dev), torch.zeros(B, N, dtype=torch.int32, device=dev)
         f2n, et = torch.zeros(B, T, dtype=torch.int32, device=dev), torch.zeros(B * N, dtype=torch.int32, device=dev)
         sl, kept = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, T, dtype=torch.int32, device=dev)
+        n2r = torch.zeros(B, N, dtype=torch.int32, device=dev)
         rt.check(lib.gcpx_balanced_binding(end.data_ptr(), B, L, T, node_t.data_ptr(), leave.data_ptr(), f2n.data_ptr(),
-                                           et.data_ptr(), sl.data_ptr(), _stream()), "binding")
+                                           et.data_ptr(), sl.data_ptr(), n2r.data_ptr(), _stream()), "binding")
         rt.check(lib.gcpx_compact_index(leave.data_ptr(), B, N, T, kept.data_ptr(), _stream()), "compact")
         torch.cuda.synchronize()
         perm = TI.bf2df_perm(L)
@@ -313,6 +314,8 @@ def test_balanced_binding_bit_exact(env):
         want_f2n = perm[TI.matched_node_index(md)]
         assert np.array_equal(f2n.cpu().numpy(), want_f2n)
         assert np.array_equal(sl.cpu().numpy(), np.array(ends) + 1)
+        lv = TI.leave_mask_df(ends, L, T)
+        assert np.array_equal(n2r.cpu().numpy(), np.where(lv, np.arange(B)[:, None] * T + want_t, -1))
         k = kept.cpu().numpy()
         for b, e in enumerate(ends):
             assert np.array_equal(k[b, :e + 1], np.nonzero(TI.leave_mask_df([e], L, T)[0])[0])

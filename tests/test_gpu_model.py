@@ -133,3 +133,31 @@ def test_posterior_forward_c2_full_size():
         assert torch.equal(kept[b, :n], f2n[b, :n])          # k-th kept node (temporal order) is matched to frame k
         assert torch.all(kept[b, :n][1:] > kept[b, :n][:-1])   # strictly increasing depth-first positions
         assert torch.all(kept[b, n:] == -1)
+
+
+@pytest.mark.parametrize("materialize", [False, True])
+@pytest.mark.parametrize("dist", ["discrete_logistic_mixture", "gaussian"])
+def test_losses_c1(dist, materialize):
+    """ELBO terms and the normalised total (base_gcp.py:264-304) against the oracle.  Stated tolerance: relative 2e-5
+    on every loss value (fp32 sums of ~1e5 per-pixel terms), absolute 1e-6 on the per-pixel total."""
+    from oracle import gcp_model_oracle as O
+    import video_gcp_amd as V
+    from video_gcp_amd.model import GCPTreeModel
+    hp = V.config("c1", decoder_distribution=dist)
+    sd = V.init_params(hp, seed=1, randomize_affine=True)
+    model = GCPTreeModel(hp, params=sd, device="cuda", materialize_distr=materialize)
+    model.train(True)
+    inputs, noise, _ = make_inputs(hp, seed=7, variant="B")
+    ref_out = O.forward(sd, hp, inputs, noise=noise, training_bn=True)
+    ref_losses, ref_total = O.losses(sd, hp, inputs, ref_out)
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    out = model(dev_in, "train", noise=noise.cuda())
+    losses = model.loss(dev_in, out)
+    total = model.get_total_loss(dev_in, losses)
+    torch.cuda.synchronize()
+    for name, (val, w) in ref_losses.items():
+        got = float(losses[name].value)
+        assert abs(got - float(val)) <= 2e-5 * abs(float(val)) + 1e-6, (name, got, float(val))
+        assert losses[name].weight == w
+    assert abs(float(total.value) - float(ref_total)) <= 2e-5 * abs(float(ref_total)) + 1e-6
+    assert abs(float(losses["nll"].value) - float(ref_losses["dense_img_rec"][0] + ref_losses["kl"][0])) <= 1e-4 * abs(float(losses["nll"].value))

@@ -6,7 +6,7 @@ OUT=../libgcpx.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-variable ${GCPX_EXTRA_FLAGS}"
 mkdir -p build
 pids=()
-for f in conv3x3 conv_enc gemm mlp misc; do
+for f in conv3x3 conv_enc gemm mlp misc loss; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.cuh -nt build/$f.o ] || [ ../../include/gcpx.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)

@@ -497,10 +497,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
         }
         const int mode = a.head_mode;
         const size_t plane = (size_t)H * W;
-        if (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) {
+        const int orow = a.raw_row_map ? a.raw_row_map[f] : f;
+        if ((mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) && orow >= 0) {
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
-                float* op = a.out + (((size_t)f * H + (y0 + (pt >> 1))) * W + (x0 + (pt & 1) * 16 + j)) * a.out_pitch;
+                float* op = a.out + (((size_t)orow * H + (y0 + (pt >> 1))) * W + (x0 + (pt & 1) * 16 + j)) * a.out_pitch;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const int c = ct * 16 + q * 4;

@@ -1,0 +1,261 @@
+// Losses of the gcp_tree forward on gfx950 (all reductions deterministic: fixed trees, no atomics).
+//
+// Replaces, for matching_type='balanced':
+//   decoder.nll(matched distr, traj_seq, weights=pad_mask)          /root/reference/gcp/prediction/models/tree/frame_binding.py:88-99
+//   KLDivLoss2(q_z, p_z) over all tree nodes                        /root/reference/gcp/prediction/models/tree/inference.py:38-43
+//   CELogitsLoss (length), BCELogitsLoss (existence), L2Loss (state) misc.py:53-56, frame_binding.py:80-86, base_gcp.py:281-286
+//   get_total_loss                                                  /root/reference/gcp/prediction/models/base_gcp.py:294-304
+// The loss formulas (blox.torch.losses is absent) follow DESIGN.md "Model spec": value = sum over non-batch dims of
+// error * weight, mean over the batch.
+#include "common.cuh"
+
+namespace {
+
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------------
+// discretised-logistic-mixture NLL of one frame per workgroup.
+// params: [rows][H*W][pitch] in the head kernel's channel order (packing.dlm_channel_perm):
+//   slot 8k..8k+6 = logit_k, mean_r, mean_g, mean_b, coeff0, coeff1, coeff2 ; slot 80 + 10c + k = log_scale_{c,k}
+// A wavefront stages 16 pixels x pitch floats in LDS with coalesced 16-byte loads; lane (j = pixel, q) evaluates
+// mixtures q, q+4, q+8 and the 4-lane column combines them with a logsumexp.
+// ---------------------------------------------------------------------------------------------------
+template <int NMIX, int PITCH>
+__global__ void __launch_bounds__(256) dlm_nll_kernel(const float* __restrict__ params, const float* __restrict__ target,
+                                                      const float* __restrict__ row_weight, float* __restrict__ nll_out,
+                                                      const int npix) {
+    __shared__ float4 stage4[4 * 16 * PITCH / 4];
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    float acc = 0.f;
+    if (row_weight == nullptr || row_weight[row] != 0.f) {
+        float* st = reinterpret_cast<float*>(stage4) + wave * 16 * PITCH;
+        const float* prow = params + (size_t)row * npix * PITCH;
+        const float* trow = target + (size_t)row * 3 * npix;
+        constexpr int F4 = 16 * PITCH / 4;
+        for (int p0 = wave * 16; p0 < npix; p0 += 64) {
+            const float4* src = reinterpret_cast<const float4*>(prow + (size_t)p0 * PITCH);
+            for (int i = lane; i < F4; i += 64) reinterpret_cast<float4*>(st)[i] = src[i];
+            __builtin_amdgcn_wave_barrier();
+            const float* pp = st + j * PITCH;
+            const float xr = trow[p0 + j], xg = trow[npix + p0 + j], xb = trow[2 * npix + p0 + j];
+            // log-softmax denominators over all mixtures (every lane reads the 10 logits of its pixel)
+            float lmax = pp[0];
+#pragma unroll
+            for (int k = 1; k < NMIX; ++k) lmax = fmaxf(lmax, pp[8 * k]);
+            float lsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < NMIX; ++k) lsum += expf(pp[8 * k] - lmax);
+            const float lse_logits = lmax + logf(lsum);
+            float lp[3];
+            int nk = 0;
+            for (int k = q; k < NMIX; k += 4, ++nk) {
+                const float* m = pp + 8 * k;
+                const float c0 = tanhf(m[4]), c1 = tanhf(m[5]), c2 = tanhf(m[6]);
+                const float mean[3] = {m[1], m[2] + c0 * xr, m[3] + c1 * xr + c2 * xg};
+                const float x[3] = {xr, xg, xb};
+                float s = m[0] - lse_logits;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float ls = fmaxf(pp[80 + 10 * c + k], -7.f);
+                    const float xc = x[c] - mean[c];
+                    const float inv = expf(-ls);
+                    const float plus_in = inv * (xc + 1.f / 255.f), min_in = inv * (xc - 1.f / 255.f);
+                    const float cdf_delta = sigmoid_acc(plus_in) - sigmoid_acc(min_in);
+                    const float mid_in = inv * xc;
+                    float v;
+                    if (x[c] < -0.999f) v = plus_in - softplusf_(plus_in);
+                    else if (x[c] > 0.999f) v = -softplusf_(min_in);
+                    else if (cdf_delta > 1e-5f) v = logf(fmaxf(cdf_delta, 1e-12f));
+                    else v = mid_in - ls - 2.f * softplusf_(mid_in) - 4.8481163864f;   // log(127.5)
+                    s += v;
+                }
+                lp[nk] = s;
+            }
+            float mx = lp[0];
+            for (int i = 1; i < nk; ++i) mx = fmaxf(mx, lp[i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float se = 0.f;
+            for (int i = 0; i < nk; ++i) se += expf(lp[i] - mx);
+            se += __shfl_xor(se, 16);
+            se += __shfl_xor(se, 32);
+            if (q == 0) acc -= mx + logf(se);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // deterministic reduction: 16 pixel lanes of q == 0, then the 4 waves
+    acc = row16_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) nll_out[row] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// gaussian decoder: 0.5 * ((x - mu) / sigma)^2 + log_sigma + 0.5 * log(2 pi), summed over one frame per workgroup
+__global__ void __launch_bounds__(256) gauss_nll_kernel(const float* __restrict__ mu, const float* __restrict__ target,
+                                                        const float* __restrict__ log_sigma, float* __restrict__ nll_out,
+                                                        const int nelem) {
+    __shared__ float red[256];
+    const int row = blockIdx.x;
+    const float ls = log_sigma[0];
+    const float inv = expf(-ls);
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nelem; i += 256) {
+        const float d = (target[(size_t)row * nelem + i] - mu[(size_t)row * nelem + i]) * inv;
+        acc += 0.5f * d * d + ls + 0.9189385332f;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) nll_out[row] = red[0];
+}
+
+// analytic KL(q || p) of diagonal Gaussians, clamped below at free_nats per dimension, summed per batch element
+__global__ void __launch_bounds__(256) kl_kernel(const float* __restrict__ qz, const float* __restrict__ pz, const int N,
+                                                 const int nz, const long long batch_stride, const long long node_stride,
+                                                 const float free_nats, float* __restrict__ kl_out) {
+    __shared__ float red[256];
+    const int b = blockIdx.x;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < N * nz; i += 256) {
+        const int n = i / nz, d = i % nz;
+        const float* q = qz + (size_t)b * batch_stride + (size_t)n * node_stride;
+        const float* p = pz + (size_t)b * batch_stride + (size_t)n * node_stride;
+        const float mq = q[d], lq = q[nz + d], mp = p[d], lp = p[nz + d];
+        const float diff = mq - mp;
+        const float kl = lp - lq + (expf(2.f * lq) + diff * diff) / (2.f * expf(2.f * lp)) - 0.5f;
+        acc += fmaxf(kl, free_nats);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) kl_out[b] = red[0];
+}
+
+__device__ float block_sum(float v, float* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// one workgroup: the small losses and the weighted total
+__global__ void __launch_bounds__(256) loss_combine_kernel(const gcpx_loss_args a) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int B = a.B, T = a.T, N = a.N;
+    // dense_img_rec: sum_bt pad_mask * nll / B
+    float v = 0.f;
+    for (int i = tid; i < B * T; i += 256) v += a.nll_bt[i] * a.pad_mask[i];
+    const float rec = block_sum(v, red) / B;
+    v = 0.f;
+    for (int i = tid; i < B; i += 256) v += a.kl_b[i];
+    const float kl = a.kl_b ? block_sum(v, red) / B : 0.f;
+    // length prediction: cross entropy of seq_len_logits [B,T] against end_ind (misc.py:53-56)
+    float ce = 0.f;
+    if (a.len_logits) {
+        v = 0.f;
+        for (int b = tid; b < B; b += 256) {
+            const float* l = a.len_logits + (size_t)b * T;
+            float m = l[0];
+            for (int t = 1; t < T; ++t) m = fmaxf(m, l[t]);
+            float s = 0.f;
+            for (int t = 0; t < T; ++t) s += expf(l[t] - m);
+            v += m + logf(s) - l[a.end_ind[b]];
+        }
+        ce = block_sum(v, red) / B;
+    }
+    // existence: BCE with logits against the keep mask in depth-first order (frame_binding.py:80-86)
+    float bce = 0.f;
+    if (a.existence) {
+        v = 0.f;
+        for (int i = tid; i < B * N; i += 256) {
+            const float x = a.existence[i], y = a.leave[i] ? 1.f : 0.f;
+            v += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+        }
+        bce = block_sum(v, red) / (B * N);
+    }
+    // state regression: mean over [B, max_len, state_dim] of pad_mask * (pred - target)^2 (base_gcp.py:281-286)
+    float sreg = 0.f;
+    if (a.regressed_state && a.state_target) {
+        int maxlen = 0;
+        for (int b = 0; b < B; ++b) maxlen = max(maxlen, a.seq_len[b]);
+        v = 0.f;
+        const int sd = a.state_dim;
+        for (int i = tid; i < B * maxlen * sd; i += 256) {
+            const int d = i % sd, t = (i / sd) % maxlen, b = i / (sd * maxlen);
+            const float e = a.regressed_state[((size_t)b * T + t) * sd + d] - a.state_target[((size_t)b * T + t) * sd + d];
+            v += a.pad_mask[b * T + t] * e * e;
+        }
+        sreg = block_sum(v, red) / (B * maxlen * sd);
+    }
+    if (tid == 0) {
+        a.out[0] = rec; a.out[1] = kl; a.out[2] = ce; a.out[3] = bce; a.out[4] = sreg;
+        float total = 0.f;
+        if (a.w_rec > 0.f) total += a.w_rec * rec;
+        if (a.w_kl > 0.f) total += a.w_kl * kl;
+        if (a.w_len > 0.f) total += a.w_len * ce;
+        if (a.w_exist > 0.f) total += a.w_exist * bce;
+        if (a.w_state > 0.f) total += a.w_state * sreg;
+        a.out[5] = total / a.total_div;      // base_gcp.py:299-301: / prod(traj_seq.shape[1:])
+        a.out[6] = rec + kl;                 // nll upper bound (base_gcp.py:289-290)
+    }
+}
+
+}  // namespace
+
+extern "C" int gcpx_dlm_nll(const float* params, const float* target, const float* row_weight, float* nll_out,
+                            int32_t rows, int32_t npix, int32_t pitch, int32_t n_mix, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(params && target && nll_out && rows > 0, "null pointer / rows <= 0");
+    GCPX_CHECK_ARG(npix % 64 == 0, "pixels per frame must be a multiple of 64");
+    if (n_mix != 10 || pitch != 112) {
+        gcpx_set_error("gcpx_dlm_nll: only n_mix=10 with the 112-slot head layout is built");
+        return GCPX_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((dlm_nll_kernel<10, 112>), dim3(rows), dim3(256), 0, stream, params, target, row_weight, nll_out, npix);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_gauss_nll(const float* mu, const float* target, const float* log_sigma, float* nll_out, int32_t rows,
+                              int32_t nelem, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(mu && target && log_sigma && nll_out && rows > 0 && nelem > 0, "null pointer / bad sizes");
+    hipLaunchKernelGGL(gauss_nll_kernel, dim3(rows), dim3(256), 0, stream, mu, target, log_sigma, nll_out, nelem);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_kl_gauss(const float* qz, const float* pz, int32_t B, int32_t N, int32_t nz, int64_t batch_stride,
+                             int64_t node_stride, float free_nats, float* kl_out, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(qz && pz && kl_out && B > 0 && N > 0 && nz > 0, "null pointer / bad sizes");
+    hipLaunchKernelGGL(kl_kernel, dim3(B), dim3(256), 0, stream, qz, pz, N, nz, (long long)batch_stride,
+                       (long long)node_stride, free_nats, kl_out);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_loss_combine(const gcpx_loss_args* a, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(a && a->nll_bt && a->pad_mask && a->out, "null pointer");
+    GCPX_CHECK_ARG(a->B > 0 && a->T > 0 && a->total_div > 0, "bad sizes");
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(256), 0, stream, *a);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}

@@ -92,7 +92,8 @@ __global__ void __launch_bounds__(256) balanced_binding_kernel(const int64_t* __
                                                                int32_t* __restrict__ leave,
                                                                int32_t* __restrict__ frame2node,
                                                                int32_t* __restrict__ etilde_row,
-                                                               int32_t* __restrict__ seq_len) {
+                                                               int32_t* __restrict__ seq_len,
+                                                               int32_t* __restrict__ node2row) {
     const int b = blockIdx.x;
     const int N = (1 << L) - 1;
     const long long end = end_ind[b];
@@ -114,6 +115,7 @@ __global__ void __launch_bounds__(256) balanced_binding_kernel(const int64_t* __
         node_t[(size_t)b * N + p] = (int32_t)t;
         leave[(size_t)b * N + p] = keep;
         if (keep && t >= 0 && t < T) frame2node[(size_t)b * T + t] = p;
+        if (node2row) node2row[(size_t)b * N + p] = (keep && t >= 0 && t < T) ? (int32_t)(b * T + t) : -1;
         if (etilde_row) {
             long long tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
             etilde_row[(size_t)B * ((1 << l) - 1) + (size_t)b * (1 << l) + jn] = (int32_t)(b * T + tc);
@@ -175,12 +177,12 @@ extern "C" int gcpx_bn_fold(const float* running_mean, const float* running_var,
 
 extern "C" int gcpx_balanced_binding(const int64_t* end_ind, int32_t B, int32_t L, int32_t T, int32_t* node_t,
                                      int32_t* leave, int32_t* frame2node, int32_t* etilde_row, int32_t* seq_len,
-                                     void* stream_) {
+                                     int32_t* node2row, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(end_ind && node_t && leave && frame2node && seq_len, "null pointer");
     GCPX_CHECK_ARG(B > 0 && L > 0 && L < 20 && T > 0, "bad sizes");
     hipLaunchKernelGGL(balanced_binding_kernel, dim3(B), dim3(256), 0, stream, end_ind, B, L, T, node_t, leave,
-                       frame2node, etilde_row, seq_len);
+                       frame2node, etilde_row, seq_len, node2row);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -392,10 +392,11 @@ class GCPTreeModel:
         etrow = self._buf("etilde_row", (B * N,), torch.int32)
         seq_len = self._buf("seq_len", (B,), torch.int32)
         kept_idx = self._buf("kept_idx", (B, T), torch.int32)
+        node2row = self._buf("node2row", (B, N), torch.int32)
 
         # ---- integer bookkeeping (frame_binding.py:42-65, evaluation_matching.py:192-206) ----
         plan.add("balanced_binding", lib.gcpx_balanced_binding, tin["end_ind"].data_ptr(), B, L, T, node_t.data_ptr(),
-                 leave.data_ptr(), f2n.data_ptr(), etrow.data_ptr(), seq_len.data_ptr())
+                 leave.data_ptr(), f2n.data_ptr(), etrow.data_ptr(), seq_len.data_ptr(), node2row.data_ptr())
         plan.add("compact_index", lib.gcpx_compact_index, leave.data_ptr(), B, N, T, kept_idx.data_ptr())
 
         # ---- run_encoder (base_gcp.py:184-213) ----
@@ -567,15 +568,25 @@ class GCPTreeModel:
             prev = (o.data_ptr(), cout, 1, sc, sh, rt.ACT_LRELU)
         assert res == S
         images = self._buf("images_df", (B, N, hp.input_nc, S, S))
-        distr = None
-        if hp.decoder_distribution == "discrete_logistic_mixture":
-            mode = rt.HEAD_DLM_BOTH if self.materialize_distr else rt.HEAD_DLM_MEAN
+        distr = matched_distr = None
+        with_loss = key[7]
+        dlm = hp.decoder_distribution == "discrete_logistic_mixture"
+        head_out, row_map = None, None
+        if dlm:
+            mode = rt.HEAD_DLM_MEAN
             if self.materialize_distr:
-                distr = self._buf("distr_df", (B, N, S, S, self._head_pitch))
+                mode, distr = rt.HEAD_DLM_BOTH, self._buf("distr_df", (B, N, S, S, self._head_pitch))
+                head_out = distr
+            elif with_loss:
+                # only the nodes matched to a ground-truth frame keep their distribution parameters
+                # (frame_binding.py:91-92): row b*T+t of matched_distr <- node matched to frame t
+                mode, matched_distr = rt.HEAD_DLM_BOTH, self._buf("matched_distr", (B, T, S, S, self._head_pitch))
+                head_out, row_map = matched_distr, node2row
         else:
             mode = rt.HEAD_TANH_NCHW
         a = self._conv_args([prev], F, S, S, S, S, hp.head_channels, self._head_pitch, P["dec.head.w"], P["dec.head.b"],
-                            distr, upsample=0, head_mode=mode, images=images)
+                            head_out, upsample=0, head_mode=mode, images=images)
+        a.raw_row_map = row_map.data_ptr() if row_map is not None else None
         plan.keep.append(a)
         plan.join([1])           # the latent-space heads overlapped the decoder blocks; the head runs alone
         plan.add("dec.head", lib.gcpx_conv3x3, C.byref(a))
@@ -592,6 +603,39 @@ class GCPTreeModel:
         plan.add("gather.pruned", lib.gcpx_gather_rows, images.data_ptr(), kept_idx.data_ptr(), pruned.data_ptr(), B, T, N, 0,
                  row)
         outs["pruned_padded"] = pruned
+
+        # ---- losses (base_gcp.py:264-304, tree_module.py:116-157) ----
+        if with_loss:
+            nll_bt = self._buf("nll_bt", (B, T))
+            if dlm:
+                if matched_distr is None:       # materialize_distr: gather the matched rows out of the full tensor
+                    matched_distr = self._buf("matched_distr", (B, T, S, S, self._head_pitch))
+                    plan.add("gather.matched_distr", lib.gcpx_gather_rows, distr.data_ptr(), f2n.data_ptr(),
+                             matched_distr.data_ptr(), B, T, N, 0, S * S * self._head_pitch)
+                plan.add("loss.dlm_nll", lib.gcpx_dlm_nll, matched_distr.data_ptr(), tin["traj_seq"].data_ptr(),
+                         tin["pad_mask"].data_ptr(), nll_bt.data_ptr(), B * T, S * S, self._head_pitch, hp.n_mixtures)
+            else:
+                plan.add("loss.gauss_nll", lib.gcpx_gauss_nll, outs["soft_matched_estimates"].data_ptr(),
+                         tin["traj_seq"].data_ptr(), self.sd["decoder.log_sigma"].data_ptr(), nll_bt.data_ptr(), B * T,
+                         hp.input_nc * S * S)
+            kl_b = self._buf("kl_b", (B,))
+            plan.add("loss.kl", lib.gcpx_kl_gauss, _addr(QZ, 2 * nv), _addr(PZ, 2 * nv), B, N, nv, PS * 2 * nv, 2 * nv,
+                     C.c_float(hp.free_nats), kl_b.data_ptr())
+            la = rt.LossArgs()
+            la.nll_bt, la.pad_mask, la.kl_b = nll_bt.data_ptr(), tin["pad_mask"].data_ptr(), kl_b.data_ptr()
+            la.len_logits = outs["seq_len_logits"].data_ptr() if "seq_len_logits" in outs else None
+            la.end_ind, la.existence, la.leave = tin["end_ind"].data_ptr(), outs["existence"].data_ptr(), leave.data_ptr()
+            if "regressed_state_padded" in outs and "traj_seq_states" in tin:
+                la.regressed_state, la.state_target = outs["regressed_state_padded"].data_ptr(), tin["traj_seq_states"].data_ptr()
+            la.seq_len = seq_len.data_ptr()
+            loss_out = self._buf("losses", (8,), zero=True)
+            la.out, la.B, la.T, la.N, la.state_dim = loss_out.data_ptr(), B, T, N, hp.state_dim
+            la.w_rec, la.w_kl, la.w_len, la.w_exist, la.w_state = hp.dense_img_rec_weight, hp.kl_weight, hp.length_pred_weight, 1.0, 1.0
+            la.total_div = float(T * hp.input_nc * S * S)
+            plan.keep.append(la)
+            plan.add("loss.combine", lib.gcpx_loss_combine, C.byref(la))
+            outs["losses"], outs["nll_bt"], outs["kl_b"] = loss_out, nll_bt, kl_b
+            outs["matched_distr_kernel_order"] = matched_distr
 
         outs.update(E=E, Hid=Hid, Z=Z, PZ=PZ, QZ=QZ, node_t=node_t, leave=leave, frame2node=f2n, seq_len=seq_len,
                     kept_idx=kept_idx, enc_traj_seq=enc_traj, inf_enc_seq=inf_enc)
@@ -617,7 +661,9 @@ class GCPTreeModel:
         if "end_ind" not in inputs:
             raise ValueError("end_ind must be fed (sampled lengths are not part of the hot path, SURVEY D3)")
         tin = {}
-        for k in ("I_0", "I_g", "end_ind") + (("traj_seq",) if has_traj else ()) + (("z",) if has_z else ()):
+        with_loss = has_traj and phase == "train" and "pad_mask" in inputs
+        opt = tuple(k for k in ("pad_mask", "traj_seq_states") if with_loss and k in inputs)
+        for k in ("I_0", "I_g", "end_ind") + (("traj_seq",) if has_traj else ()) + (("z",) if has_z else ()) + opt:
             t = inputs[k]
             want = torch.int64 if k == "end_ind" else torch.float32
             if t.device != self.device or t.dtype != want or not t.is_contiguous():
@@ -631,7 +677,7 @@ class GCPTreeModel:
             else:
                 eps.copy_(noise)
             tin["eps"] = eps
-        key = (B, has_traj, has_z, self._sample_prior, phase, self.training, self.materialize_distr)
+        key = (B, has_traj, has_z, self._sample_prior, phase, self.training, self.materialize_distr, with_loss)
         ptrs = tuple(sorted((k, v.data_ptr()) for k, v in tin.items()))
         cached = self._plans.get(key)
         if cached is None or cached[0] != ptrs:
@@ -734,6 +780,32 @@ class GCPTreeModel:
         out.dense_rec = Outputs()
         out._lazy = (o, tin)
         return out
+
+    # ---- losses: computed inside the forward graph when traj_seq + pad_mask are fed in phase 'train' ----
+    LOSS_NAMES = ("dense_img_rec", "kl", "len_pred", "existence_predictor", "state_regression")
+
+    def loss(self, inputs, outputs, log_error_arr=False):
+        """BaseGCPModel.loss + TreeModule.loss (base_gcp.py:264-292, tree_module.py:116-157): {name: (value, weight)}."""
+        raw = outputs.raw
+        if "losses" not in raw:
+            raise ValueError("losses need traj_seq and pad_mask in the inputs of a phase='train' forward")
+        hp, lv = self._hp, raw["losses"]
+        w = dict(dense_img_rec=hp.dense_img_rec_weight, kl=hp.kl_weight, len_pred=hp.length_pred_weight,
+                 existence_predictor=1.0, state_regression=1.0)
+        res = Outputs()
+        for i, name in enumerate(self.LOSS_NAMES):
+            if name == "len_pred" and not hp.regress_length:
+                continue
+            if name == "state_regression" and ("regressed_state_padded" not in raw or "traj_seq_states" not in inputs):
+                continue
+            res[name] = Outputs(value=lv[i], weight=w[name])
+        res["nll"] = Outputs(value=lv[6], weight=0.0)               # base_gcp.py:289-290
+        res["_total"] = lv[5]
+        return res
+
+    def get_total_loss(self, inputs, losses):
+        """base_gcp.py:294-304: sum of weight * value over weights > 0, divided by prod(traj_seq.shape[1:])."""
+        return Outputs(value=losses["_total"])
 
     # ---- ragged views: these synchronise (they read seq_len on the host), keep them out of timed regions ----
     def pruned_prediction(self, out):

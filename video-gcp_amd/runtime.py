@@ -26,7 +26,15 @@ class ConvSrc(C.Structure):
 class ConvArgs(C.Structure):
     _fields_ = [("src", ConvSrc * 2), ("nsrc", i32), ("F", i32), ("Hin", i32), ("Win", i32), ("Hout", i32),
                 ("Wout", i32), ("Cin", i32), ("Cout", i32), ("out_pitch", i32), ("upsample", i32), ("out_act", i32),
-                ("head_mode", i32), ("wpk", vp), ("bias", vp), ("out", vp), ("images", vp), ("stats_partial", vp)]
+                ("head_mode", i32), ("wpk", vp), ("bias", vp), ("out", vp), ("images", vp), ("stats_partial", vp),
+                ("raw_row_map", vp)]
+
+
+class LossArgs(C.Structure):
+    _fields_ = [("nll_bt", vp), ("pad_mask", vp), ("kl_b", vp), ("len_logits", vp), ("end_ind", vp), ("existence", vp),
+                ("leave", vp), ("regressed_state", vp), ("state_target", vp), ("seq_len", vp), ("out", vp),
+                ("B", i32), ("T", i32), ("N", i32), ("state_dim", i32), ("w_rec", C.c_float), ("w_kl", C.c_float),
+                ("w_len", C.c_float), ("w_exist", C.c_float), ("w_state", C.c_float), ("total_div", C.c_float)]
 
 
 class RowSrc(C.Structure):
@@ -63,7 +71,11 @@ SYMBOLS = [
     ("gcpx_gemm", C.c_int, [C.POINTER(GemmArgs), vp]),
     ("gcpx_gemm_row_blocks", C.c_int, [i32, i32]),
     ("gcpx_mlp", C.c_int, [C.POINTER(MlpArgs), vp]),
-    ("gcpx_balanced_binding", C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    ("gcpx_balanced_binding", C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    ("gcpx_dlm_nll", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    ("gcpx_gauss_nll", C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
+    ("gcpx_kl_gauss", C.c_int, [vp, vp, i32, i32, i32, i64, i64, C.c_float, vp, vp]),
+    ("gcpx_loss_combine", C.c_int, [C.POINTER(LossArgs), vp]),
     ("gcpx_gather_rows", C.c_int, [vp, vp, vp, i32, i32, i32, i32, i64, vp]),
     ("gcpx_compact_index", C.c_int, [vp, i32, i32, i32, vp, vp]),
     ("gcpx_graph_begin", C.c_int, [vp]),
