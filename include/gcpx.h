@@ -220,6 +220,13 @@ int gcpx_balanced_binding(const int64_t* end_ind, int32_t B, int32_t L, int32_t 
    src has N rows per batch element; rows with idx < 0 are zero-filled (pad_sequence, base_gcp.py:242). */
 int gcpx_gather_rows(const float* src, const int32_t* idx, float* out, int32_t B, int32_t T, int32_t N,
                      int32_t idx_offset, int64_t row_floats, void* stream);
+/* Learned pairwise cost over a rollout (LearnedCostEstimate, gcp/planning/cem/cost_fcn.py:88-95):
+   gcpx_seq_pairs builds the "next" operand nxt[i][t] = lat[i][t+1] (t+1 < len_i) else goal[i] (goal == NULL: the
+   sequence's own last latent); the cost MLP runs on (lat, nxt) rows; gcpx_masked_row_sum adds the first len_i
+   per-step costs of every candidate. */
+int gcpx_seq_pairs(const float* lat, const int32_t* lengths, const float* goal, float* nxt, int32_t n, int32_t T,
+                   int32_t nz, void* stream);
+int gcpx_masked_row_sum(const float* vals, const int32_t* lengths, float* out, int32_t n, int32_t T, void* stream);
 /* compaction of kept nodes: dst_idx[b][k] = k-th depth-first position with leave==1 (k < seq_len[b]), else -1 */
 int gcpx_compact_index(const int32_t* leave, int32_t B, int32_t N, int32_t T, int32_t* dst_idx, void* stream);
 

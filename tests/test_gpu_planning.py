@@ -1,0 +1,86 @@
+"""-m gpu: planning path (simulator rollout, learned cost, CEM loop) through the HIP kernels vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_inputs, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import video_gcp_amd as V
+    from video_gcp_amd.model import GCPTreeModel
+    hp = V.config("c1")
+    sd = V.init_params(hp, seed=1, randomize_affine=True)
+    model = GCPTreeModel(hp, params=sd, device="cuda")
+    model.eval()                                         # planner_policy.py:51
+    return hp, sd, model
+
+
+def _env_images(hp, seed):
+    rng = np.random.RandomState(seed)
+    return (rng.randint(0, 256, size=(1, hp.img_sz, hp.img_sz, 3)).astype(np.uint8),
+            rng.randint(0, 256, size=(1, hp.img_sz, hp.img_sz, 3)).astype(np.uint8))
+
+
+def test_simulator_rollout_matches_oracle(setup):
+    from oracle import gcp_model_oracle as O
+    from video_gcp_amd.planning import GCPImageSimulator, env2planner
+    hp, sd, model = setup
+    state, goal = _env_images(hp, 0)
+    n, T = 3, hp.max_seq_len
+    z = torch.randn(n, hp.n_nodes, hp.nz_vae, generator=torch.Generator().manual_seed(0))
+    sim = GCPImageSimulator(model, append_latent=True)
+    got = sim.rollout(state, goal, z.numpy(), T)
+    inp = dict(I_0=env2planner(np.repeat(state, n, 0)), I_g=env2planner(np.repeat(goal, n, 0)), z=z,
+               end_ind=torch.full((n,), T - 1, dtype=torch.long), start_ind=torch.zeros(n, dtype=torch.long))
+    ref = O.forward(sd, hp, inp, training_bn=False)
+    assert len(got.predictions) == n
+    for i in range(n):
+        want = torch.cat((ref["pruned_prediction"][i].reshape(T, -1), ref["model_enc_seq_list"][i]), -1)   # cem_simulator.py:54-59
+        assert got.predictions[i].shape == (T, 3 * hp.img_sz ** 2 + hp.nz_enc)
+        assert_close(got.predictions[i], want, 5e-5, 1e-4, "predictions")
+        assert_close(got.latents[i], ref["model_enc_seq"][i], 5e-5, 1e-4, "latents")
+        assert_close(got.states[i], ref["regressed_state"][i], 5e-5, 1e-4, "states")
+        assert_close(got.actions[i], ref["actions"][i], 5e-5, 1e-4, "actions")
+
+
+def test_learned_cost_matches_oracle(setup):
+    from oracle import gcp_model_oracle as O
+    from video_gcp_amd.planning import LearnedCostEstimate
+    hp, sd, model = setup
+    cost = LearnedCostEstimate(model)
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.randn(37, hp.nz_enc, generator=g), torch.randn(37, hp.nz_enc, generator=g)
+    want = O.predictor(sd, "cost_mdl.cost_pred", hp, a, b)               # TestTimeCostModel.forward, cost_mdl.py:138-145
+    assert_close(cost(a.numpy(), b.numpy()), want, 3e-5, 1e-4, "pair cost")
+    # list branch (cost_fcn.py:88-95): sum over pairs of cat(seq, goal)
+    seqs = [torch.randn(l, hp.nz_enc, generator=g) for l in (5, 2, 9)]
+    goals = [torch.randn(1, hp.nz_enc, generator=g) for _ in seqs]
+    want = []
+    for s, gl in zip(seqs, goals):
+        full = torch.cat((s, gl))
+        want.append(float(O.predictor(sd, "cost_mdl.cost_pred", hp, full[:-1], full[1:]).sum()))
+    got = cost([s.numpy() for s in seqs], [gl.numpy() for gl in goals])
+    assert_close(got, np.array(want, dtype=np.float32), 1e-4, 1e-4, "sequence cost")
+
+
+def test_cem_planner_runs_and_is_deterministic(setup):
+    from video_gcp_amd.planning import GCPImageSimulator, LearnedCostEstimate, SimpleTreeCEMSampler, CEMPlanner
+    hp, sd, model = setup
+    state, goal = _env_images(hp, 2)
+    res = []
+    for _ in range(2):
+        sampler = SimpleTreeCEMSampler(float("inf"), None, hp.nz_vae, 1.0, n_level_hierarchy=hp.hierarchy_levels, device="cuda", seed=11)
+        planner = CEMPlanner(GCPImageSimulator(model), LearnedCostEstimate(model), sampler, n_iters=2, batch_size=16,
+                             elite_frac=0.25, max_seq_len=hp.max_seq_len)
+        plan, actions, latents, score = planner(state, goal)
+        res.append((plan, actions, latents, score, [l.elite_scores.cpu().numpy() for l in planner.logs]))
+    assert res[0][0].shape == (hp.max_seq_len, 3 * hp.img_sz ** 2 + hp.nz_enc)
+    assert res[0][1].shape == (hp.max_seq_len - 1, hp.n_actions)
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][3] == res[1][3]
+    for a, b in zip(res[0][4], res[1][4]):
+        assert np.array_equal(a, b)
+    assert np.all(np.diff(res[0][4][0]) >= 0)            # elites come out sorted by cost

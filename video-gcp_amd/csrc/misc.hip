@@ -151,7 +151,50 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
     }
 }
 
+// nxt[i][t] = lat[i][t+1] for t+1 < len_i, else the goal latent: second argument rows of the learned pairwise cost
+// (LearnedCostEstimate list branch, cost_fcn.py:88-95: pairs of torch.cat((seq, goal)))
+__global__ void seq_pairs_kernel(const float* __restrict__ lat, const int32_t* __restrict__ lengths,
+                                 const float* __restrict__ goal, float* __restrict__ nxt, const int T, const int nz4) {
+    const int it = blockIdx.x;
+    const int i = it / T, t = it % T;
+    const int len = lengths[i];
+    const float4* src;
+    if (t + 1 < len) src = reinterpret_cast<const float4*>(lat) + ((size_t)i * T + t + 1) * nz4;
+    else if (goal) src = reinterpret_cast<const float4*>(goal) + (size_t)i * nz4;
+    else src = reinterpret_cast<const float4*>(lat) + ((size_t)i * T + (len > 0 ? len - 1 : 0)) * nz4;
+    float4* dst = reinterpret_cast<float4*>(nxt) + (size_t)it * nz4;
+    for (int k = threadIdx.x; k < nz4; k += blockDim.x) dst[k] = src[k];
+}
+
+__global__ void masked_row_sum_kernel(const float* __restrict__ vals, const int32_t* __restrict__ lengths,
+                                      float* __restrict__ out, const int n, const int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    const int len = min(lengths[i], T);
+    for (int t = 0; t < len; ++t) s += vals[(size_t)i * T + t];
+    out[i] = s;
+}
+
 }  // namespace
+
+extern "C" int gcpx_seq_pairs(const float* lat, const int32_t* lengths, const float* goal, float* nxt, int32_t n,
+                              int32_t T, int32_t nz, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(lat && lengths && nxt && n > 0 && T > 0 && nz > 0 && nz % 4 == 0, "null pointer / bad sizes");
+    hipLaunchKernelGGL(seq_pairs_kernel, dim3(n * T), dim3(64), 0, stream, lat, lengths, goal, nxt, T, nz / 4);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_masked_row_sum(const float* vals, const int32_t* lengths, float* out, int32_t n, int32_t T,
+                                   void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(vals && lengths && out && n > 0 && T > 0, "null pointer / bad sizes");
+    hipLaunchKernelGGL(masked_row_sum_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, vals, lengths, out, n, T);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
 
 extern "C" int gcpx_bn_finalize(const float* partial, int32_t n_partial, int32_t pitch, int32_t C, double count,
                                 const float* gamma, const float* beta, float eps, float* scale, float* shift,

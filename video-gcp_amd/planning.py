@@ -1,0 +1,209 @@
+"""CEM planning over the gcp_tree predictor: host-side mirror of the reference's planning stack with the rollout,
+the learned cost and the elite selection kept on the device, and the candidate population sharded across ranks.
+
+Reference (paths relative to /root/reference):
+  GCPSimulator.rollout / GCPImageSimulator        gcp/planning/cem/cem_simulator.py:14-96
+  CEMPlanner.__call__ / _rollout / _get_best_rollouts  gcp/planning/cem/cem_planner.py:55-135
+  FlatCEMSampler / SimpleTreeCEMSampler           gcp/planning/cem/sampler.py:33-76
+  LearnedCostEstimate                             gcp/planning/cem/cost_fcn.py:79-101
+  TestTimeCostModel.forward                       gcp/prediction/models/auxilliary_models/cost_mdl.py:138-145
+
+Deviations, on purpose:
+  * D2 (cem_planner.py:115-122 drops the remainder of `batch_size // max_rollout_bs`): every candidate is evaluated.
+  * D3 (val_mode(pred_length=True) samples a length although end_ind is fed): the rollout length is `rollout_len`.
+  * The reference moves every rollout to numpy (~2 GB per 512-candidate call, cem_simulator.py:68-70).  `rollout()` keeps
+    that contract; the planner itself uses `rollout_device()` and only the final plan crosses to the host.
+  * Multi-GPU: candidates are sharded over ranks; every rank draws the SAME population from a shared
+    seed, rolls out its own slice, and one all-gather of the per-candidate costs lets all ranks pick identical elites.
+"""
+import numpy as np
+import torch
+
+from . import dist as D
+from . import runtime as rt
+from .model import Outputs
+
+
+def env2planner(img):
+    """GCPImageSimulator._env2planner (cem_simulator.py:87-96): env image(s) -> NCHW in [-1, 1]."""
+    img = torch.as_tensor(img, dtype=torch.float32)
+    if img.max() > 1.0:
+        img = img / 255.0
+    if img.dim() == 5:
+        img = img[0]
+    if img.dim() == 4:
+        img = img.permute(0, 3, 1, 2)
+    return img * 2 - 1.0
+
+
+class GCPImageSimulator:
+    """Simulator interface of the planner: candidate latents -> model rollouts."""
+
+    def __init__(self, model, append_latent=True):
+        self._model = model
+        self._append_latent = append_latent
+
+    def rollout_device(self, state, goal_state, samples, rollout_len):
+        """Device-resident rollout.  state/goal_state: env images [1,H,W,3]; samples [n, N, nz_vae] (depth-first node
+        order, tree.py:38).  Returns padded device tensors + lengths."""
+        m = self._model
+        n = samples.shape[0]
+        I0 = env2planner(np.repeat(np.asarray(state), n, 0) if not torch.is_tensor(state) else state.repeat(n, 1, 1, 1))
+        Ig = env2planner(np.repeat(np.asarray(goal_state), n, 0) if not torch.is_tensor(goal_state) else goal_state.repeat(n, 1, 1, 1))
+        z = torch.as_tensor(samples, dtype=torch.float32, device=m.device)
+        inp = dict(I_0=I0.to(m.device), I_g=Ig.to(m.device), z=z,
+                   end_ind=torch.full((n,), rollout_len - 1, dtype=torch.long, device=m.device))
+        with m.val_mode(pred_length=False):
+            out = m(inp, "train")                    # cem_simulator.py:29-31 (phase defaults to 'train')
+        raw = out.raw
+        return Outputs(images=raw["pruned_padded"], latents=raw["model_enc_seq_padded"], lengths=raw["seq_len"],
+                       actions=raw.get("actions_padded"), states=raw.get("regressed_state_padded"),
+                       e_goal=raw["E"][:, -1], out=out)
+
+    def rollout(self, state, goal_state, samples, rollout_len, prune=False):
+        """Reference contract (cem_simulator.py:14-43): lists of numpy arrays, one per candidate."""
+        r = self.rollout_device(state, goal_state, samples, rollout_len)
+        lens = r.lengths.tolist()
+        n = len(lens)
+        img = r.images.reshape(n, r.images.shape[1], -1)
+        preds = []
+        for i, l in enumerate(lens):
+            p = img[i, :l]
+            if self._append_latent and not prune:
+                p = torch.cat((p, r.latents[i, :l]), dim=-1)      # cem_simulator.py:54-59: image ++ latent
+            elif prune:
+                p = r.images[i, :l]
+            preds.append(p.cpu().numpy())
+        cap = lambda t, off=0: [t[i, :max(l - off, 0)].cpu().numpy() for i, l in enumerate(lens)]
+        return Outputs(predictions=preds, actions=cap(r.actions, 1) if r.actions is not None else None,
+                       states=cap(r.states) if r.states is not None else None, latents=cap(r.latents))
+
+
+class LearnedCostEstimate:
+    """Learned pairwise cost on latents (cost_fcn.py:79-101) backed by the model's `cost_mdl.cost_pred` Predictor."""
+
+    def __init__(self, model):
+        self._model = model
+        self.lib = model.lib
+
+    @property
+    def input_dim(self):
+        return self._model._hp.nz_enc
+
+    def pair_cost(self, enc1, enc2):
+        """cost of moving from enc1 to enc2, rows [R, nz] -> [R, 1]."""
+        return self._model.predictor_rows("cost_mdl", torch.as_tensor(enc1), torch.as_tensor(enc2))
+
+    def __call__(self, start_enc, goal_enc):
+        if isinstance(start_enc, np.ndarray):                       # single start/goal pairs
+            return self.pair_cost(start_enc, goal_enc).cpu().numpy()
+        if isinstance(start_enc, list):                             # summed cost per sequence
+            T = max(s.shape[0] for s in start_enc)
+            n, nz = len(start_enc), start_enc[0].shape[-1]
+            lat = torch.zeros(n, T, nz)
+            for i, s in enumerate(start_enc):
+                lat[i, :s.shape[0]] = torch.as_tensor(s)
+            goal = torch.stack([torch.as_tensor(g).reshape(-1, nz)[0] for g in goal_enc])
+            lens = torch.tensor([s.shape[0] for s in start_enc], dtype=torch.int32)
+            dev = self._model.device
+            return self.sequence_cost_device(lat.to(dev), lens.to(dev), goal.to(dev)).cpu().numpy()
+        raise ValueError("Dimensionality of input to learned cost function not supported!")
+
+    def sequence_cost_device(self, lat, lengths, goal=None):
+        """sum_t cost(lat[i,t], next) over the first len_i steps, next = lat[i,t+1] or the goal latent after the last
+        step (cost_fcn.py:91-94).  lat [n,T,nz], lengths int32 [n], goal [n,nz] -> [n]."""
+        n, T, nz = lat.shape
+        dev = lat.device
+        lat = lat.contiguous()
+        nxt = torch.empty_like(lat)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        g = goal.contiguous() if goal is not None else None
+        rt.check(self.lib.gcpx_seq_pairs(lat.data_ptr(), lengths.data_ptr(), g.data_ptr() if g is not None else None,
+                                         nxt.data_ptr(), n, T, nz, stream), "seq_pairs")
+        per_step = self._model.predictor_rows("cost_mdl", lat.reshape(n * T, nz), nxt.reshape(n * T, nz))
+        out = torch.empty(n, device=dev)
+        rt.check(self.lib.gcpx_masked_row_sum(per_step.data_ptr(), lengths.data_ptr(), out.data_ptr(), n, T, stream),
+                 "masked_row_sum")
+        return out
+
+
+class FlatCEMSampler:
+    """Gaussian sampler over [n_steps, dim] (sampler.py:33-48), on the device, seedable so that all ranks of a
+    sharded planner draw the same population."""
+
+    def __init__(self, clip_val, n_steps, action_dim, initial_std, device="cuda", seed=0):
+        self._clip_val, self._n_steps, self._action_dim, self._initial_std = clip_val, n_steps, action_dim, initial_std
+        self.device = torch.device(device)
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(seed)
+        self.init()
+
+    def init(self):
+        self.mean = torch.zeros(self._n_steps, self._action_dim, device=self.device)
+        self.std = self._initial_std * torch.ones(self._n_steps, self._action_dim, device=self.device)
+
+    def sample(self, n_samples):
+        eps = torch.randn(n_samples, self._n_steps, self._action_dim, device=self.device, generator=self._gen)
+        raw = self.mean[None] + self.std[None] * eps
+        return raw.clamp(-self._clip_val, self._clip_val) if np.isfinite(self._clip_val) else raw
+
+    def fit(self, data, scores=None):
+        self.mean = data.mean(0)                                    # np.mean / np.std(axis=0), sampler.py:44-46
+        self.std = data.std(0, unbiased=False)
+
+    def get_dists(self):
+        return Outputs(mean=self.mean, std=self.std)
+
+
+class SimpleTreeCEMSampler(FlatCEMSampler):
+    """All 2^L - 1 tree latents optimised at once (sampler.py:68-76)."""
+
+    def __init__(self, clip_val, n_steps, action_dim, initial_std, n_level_hierarchy, **kw):
+        super().__init__(clip_val, 2 ** n_level_hierarchy - 1, action_dim, initial_std, **kw)
+
+
+def select_elites(scores, n_elite):
+    """cem_planner.py:129-130: indices of the n_elite lowest scores (stable, like numpy argsort on ties)."""
+    return torch.argsort(scores, stable=True)[:n_elite]
+
+
+class CEMPlanner:
+    """Flat CEM over tree latents with device-resident rollouts and sharded candidates (cem_planner.py:55-135)."""
+
+    def __init__(self, simulator, cost, sampler, n_iters=3, batch_size=512, elite_frac=0.1, max_seq_len=80,
+                 goal_in_cost=True):
+        self._sim, self._cost, self._sampler = simulator, cost, sampler
+        self.n_iters, self.batch_size, self.elite_frac, self.max_seq_len = n_iters, batch_size, elite_frac, max_seq_len
+        self.goal_in_cost = goal_in_cost
+        self.logs = []
+
+    def _shard(self, n):
+        world = D.dist.get_world_size() if D.dist.is_initialized() else 1
+        rank = D.dist.get_rank() if D.dist.is_initialized() else 0
+        assert n % world == 0, "candidate population must divide evenly over ranks"
+        per = n // world
+        return rank * per, per
+
+    def evaluate(self, state, goal_state, samples):
+        """costs [n] of all candidates: this rank rolls out its slice, one all-gather assembles the vector."""
+        lo, per = self._shard(samples.shape[0])
+        r = self._sim.rollout_device(state, goal_state, samples[lo:lo + per], self.max_seq_len)
+        local = self._cost.sequence_cost_device(r.latents, r.lengths, r.e_goal if self.goal_in_cost else None)
+        return D.all_gather_costs(local), r
+
+    def __call__(self, state, goal_state):
+        self._sampler.init()
+        n_elite = max(int(self.batch_size * self.elite_frac), 1)
+        best_samples = best_scores = None
+        self.logs = []
+        for _ in range(self.n_iters):
+            samples = self._sampler.sample(self.batch_size)          # identical on every rank (shared seed)
+            scores, _ = self.evaluate(state, goal_state, samples)
+            idx = select_elites(scores, n_elite)
+            best_samples, best_scores = samples[idx], scores[idx]
+            self._sampler.fit(best_samples, best_scores)
+            self.logs.append(Outputs(elite_scores=best_scores.clone(), mean_score=scores.mean()))
+        # final rollout of the best candidate (cem_planner.py:81-96); every rank computes it (tiny batch)
+        final = self._sim.rollout(state, goal_state, best_samples[:1].cpu().numpy(), self.max_seq_len)
+        actions = final.actions[0] if final.actions is not None else None
+        return final.predictions[0], actions, final.latents[0], float(best_scores[0])

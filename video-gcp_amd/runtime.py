@@ -78,6 +78,8 @@ SYMBOLS = [
     ("gcpx_loss_combine", C.c_int, [C.POINTER(LossArgs), vp]),
     ("gcpx_gather_rows", C.c_int, [vp, vp, vp, i32, i32, i32, i32, i64, vp]),
     ("gcpx_compact_index", C.c_int, [vp, i32, i32, i32, vp, vp]),
+    ("gcpx_seq_pairs", C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    ("gcpx_masked_row_sum", C.c_int, [vp, vp, vp, i32, i32, vp]),
     ("gcpx_graph_begin", C.c_int, [vp]),
     ("gcpx_graph_end", C.c_int, [vp, C.POINTER(vp)]),
     ("gcpx_graph_launch", C.c_int, [vp, vp]),
