@@ -84,3 +84,20 @@ def test_cem_planner_runs_and_is_deterministic(setup):
     for a, b in zip(res[0][4], res[1][4]):
         assert np.array_equal(a, b)
     assert np.all(np.diff(res[0][4][0]) >= 0)            # elites come out sorted by cost
+
+
+def test_hierarchical_cem_planner(setup):
+    """HierarchicalImageCEMPlanner flow (cem_planner.py:166-218) on the HIP model: one tree level fixed per iteration."""
+    from video_gcp_amd.planning import GCPImageSimulator, LearnedCostEstimate, HierarchicalCEMPlanner
+    hp, sd, model = setup
+    state, goal = _env_images(hp, 3)
+    np.random.seed(0)
+    planner = HierarchicalCEMPlanner(GCPImageSimulator(model), LearnedCostEstimate(model), hp.hierarchy_levels, [3, 2],
+                                     n_ll_samples=2, action_dim=hp.nz_vae, max_seq_len=hp.max_seq_len)
+    plan, actions, latents, score = planner(state, goal)
+    assert planner.fully_optimized
+    assert plan.shape == (hp.max_seq_len, 3 * hp.img_sz ** 2 + hp.nz_enc) and latents.shape == (hp.max_seq_len, hp.nz_enc)
+    assert np.isfinite(score) and len(planner.logs) == 3
+    # per-iteration plans grow: start/subgoal/goal, then 5 frames, then the dense sequence (+ appended goal)
+    lens = [l.elite_rollouts[0].shape[0] for l in planner.logs]
+    assert lens[0] <= lens[1] <= lens[2]

@@ -207,3 +207,72 @@ class CEMPlanner:
         final = self._sim.rollout(state, goal_state, best_samples[:1].cpu().numpy(), self.max_seq_len)
         actions = final.actions[0] if final.actions is not None else None
         return final.predictions[0], actions, final.latents[0], float(best_scores[0])
+
+
+class ImageHierarchicalTreeCEMSampler:
+    """sampler.py:79-143: draws come from the hierarchical latent optimizer, one tree level is fixed per iteration."""
+
+    def __init__(self, clip_val, n_steps, action_dim, initial_std, n_level_hierarchy, sampling_rates_per_layer,
+                 subgoal_cost_fcn, ll_cost_fcn, n_ll_samples):
+        from .tree_latent_search import ImageHierarchicalTreeLatentOptimizer
+        self._cls = ImageHierarchicalTreeLatentOptimizer
+        self._clip_val, self._action_dim, self._n_levels = clip_val, action_dim, n_level_hierarchy
+        self._rates, self._sub_cost, self._ll_cost, self._n_ll = list(sampling_rates_per_layer), subgoal_cost_fcn, ll_cost_fcn, n_ll_samples
+        assert n_level_hierarchy >= len(self._rates)
+        self.init()
+
+    def init(self):
+        self._optimizer = self._cls(self._action_dim, self._rates.copy(), self._n_levels, self._sub_cost, self._ll_cost, self._n_ll)
+
+    def sample(self, n_samples=None):
+        return np.clip(self._optimizer.sample(), -self._clip_val, self._clip_val)
+
+    def optimize(self, rollouts, goal):
+        best_rollout, best_cost = self._optimizer.optimize(rollouts, goal)
+        if (best_rollout[-1] != goal[0].transpose(2, 0, 1)).any():      # sampler.py:138-139
+            best_rollout = np.concatenate((best_rollout, goal.transpose(0, 3, 1, 2)))
+        if not hasattr(best_cost, "__len__"):
+            best_cost = [best_cost]
+        return [best_rollout], best_cost
+
+    def fit(self, *args, **kwargs):
+        pass
+
+    append_latent = True
+
+    @property
+    def fully_optimized(self):
+        return self._optimizer.fully_optimized
+
+
+class HierarchicalCEMPlanner:
+    """HierarchicalImageCEMPlanner (cem_planner.py:166-218 with :55-96): n_iters = len(sampling_rates) + 1 rounds of
+    sample -> rollout -> optimise one level.  Populations are tiny (10, 10, 5 in the 25-room config), so ranks run
+    replicas; the flat `CEMPlanner` is the sharded one."""
+
+    def __init__(self, simulator, cost, n_level_hierarchy, sampling_rates_per_layer, n_ll_samples=5, action_dim=256,
+                 max_seq_len=80, clip_val=float("inf")):
+        self._sim, self.max_seq_len = simulator, max_seq_len
+        self.n_iters = len(sampling_rates_per_layer) + 1
+        self._sampler = ImageHierarchicalTreeCEMSampler(clip_val, max_seq_len, action_dim, 1.0, n_level_hierarchy,
+                                                        sampling_rates_per_layer, cost, cost, n_ll_samples)
+        self.logs = []
+
+    def __call__(self, state, goal_state):
+        self._sampler.init()
+        self.logs = []
+        goal = np.asarray(goal_state)
+        best_samples = best_scores = None
+        for _ in range(self.n_iters):
+            samples = self._sampler.sample()
+            rollouts = self._sim.rollout(state, goal, samples, self.max_seq_len)
+            best_rollouts, best_scores = self._sampler.optimize(rollouts.predictions, goal)     # cem_planner.py:215
+            best_samples = self._sampler.sample()                                               # :216
+            self.logs.append(Outputs(elite_rollouts=best_rollouts, elite_scores=best_scores))
+        final = self._sim.rollout(state, goal, best_samples, self.max_seq_len)
+        actions = final.actions[0] if final.actions is not None else None
+        return final.predictions[0], actions, final.latents[0], float(np.asarray(best_scores[0]).reshape(-1)[0])
+
+    @property
+    def fully_optimized(self):
+        return self._sampler.fully_optimized

@@ -1,0 +1,184 @@
+"""Hierarchical latent search for tree-structured predictors (host side, numpy).
+
+Behavioural mirror of the reference's `ImageHierarchicalTreeLatentOptimizer` / `HierarchicalTreeLatentOptimizer`
+(/root/reference/gcp/planning/tree_optimizer.py:7-260): the top `len(sampling_rates)` tree levels are optimised one
+level per CEM iteration by scoring each sampled subgoal with a pairwise cost to both parents (:86-132); what remains
+below is optimised jointly as dense "segments" (:79-84, 175-180).  Pinned bit-exactly — RNG draw order included — by
+tests/golden/ref_tree_optimizer.npz, which was produced by executing the reference class
+(tests/golden/make_ref_planner_goldens.py).
+
+Layout contract (tree_optimizer.py:45-68): `sample()` returns [n, 2^depth - 1, latent_dim] with the
+node axis in depth-first (in-order) order, i.e. [left subtree | this node | right subtree] — what
+`GCPTreeModel.forward` expects for `inputs['z']`.
+
+Written as an explicit search-state tree plus free functions instead of the reference's self-recursive class.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+
+@dataclass
+class _Level:
+    """Search state of one position in the hierarchy."""
+    depth: int
+    n_samples: int
+    n_latents: int
+    left: Optional[List["_Level"]] = None      # one child search per sample (None at the dense bottom)
+    right: Optional[List["_Level"]] = None
+    done: bool = False
+    best_z: Optional[np.ndarray] = None        # [n_latents, dim] once optimised
+    last_draw: Optional[np.ndarray] = None     # [k, n_latents, dim] most recent draw
+
+
+def _build(rates, depth, n_dense):
+    if rates:
+        k = rates[0]
+        return _Level(depth, k, 1, [_build(rates[1:], depth - 1, n_dense) for _ in range(k)],
+                      [_build(rates[1:], depth - 1, n_dense) for _ in range(k)])
+    return _Level(depth, n_dense, 2 ** depth - 1)
+
+
+class HierarchicalTreeLatentOptimizer:
+    """Same constructor / methods as the reference class (image variant: states are flattened 3xRxR images)."""
+
+    def __init__(self, latent_dim, sampling_rates, depth, subgoal_cost_fcn, ll_cost_fcn, final_layer_samples,
+                 image_states=True):
+        self._dim = latent_dim
+        self._pair_cost = subgoal_cost_fcn
+        self._seq_cost = ll_cost_fcn
+        self._image_states = image_states
+        self._root = _build(list(sampling_rates), depth, final_layer_samples)
+
+    # ------------------------------------------------------------------ sampling
+    def sample(self):
+        return self._draw(self._root, False)
+
+    def _draw(self, lv, below):
+        if lv.done:
+            z = lv.best_z.copy()[None]
+        else:
+            z = np.random.normal(loc=np.zeros((lv.n_latents, self._dim)), scale=np.ones((lv.n_latents, self._dim)),
+                                 size=(lv.n_samples, lv.n_latents, self._dim))
+            if below:                      # below the level being optimised only one latent is decoded
+                z = z[:1]
+            lv.last_draw = z.copy()
+        child_below = below or not lv.done
+        if lv.left is None:
+            return z
+        rows = []
+        for cl, cr, zi in zip(lv.left, lv.right, z):
+            zl, zr = self._draw(cl, child_below), self._draw(cr, child_below)
+            assert zl.shape == zr.shape
+            mid = np.tile(zi[0], (zl.shape[0], 1, 1))
+            rows.append(np.concatenate([zl, mid, zr], axis=1))      # depth-first: left | node | right
+        return np.concatenate(rows)
+
+    # ------------------------------------------------------------------ rollout helpers
+    def _split(self, rollouts):
+        d = self._pair_cost.input_dim
+        states, latents = [], []
+        for r in rollouts:
+            s = r[..., :-d]
+            if self._image_states:
+                assert s.ndim == 2
+                res = int(np.sqrt(s.shape[1] / 3))
+                s = s.reshape(s.shape[0], 3, res, res)
+            states.append(s)
+            latents.append(r[..., -d:])
+        return states, latents
+
+    def _segment_inputs(self, rollouts, goal):
+        states, latents = self._split(rollouts)
+        if self._image_states:
+            if goal.ndim > 2:              # raw goal image: score against each rollout's own last latent
+                goals = [l[-1:] for l in latents]
+            else:
+                goals = [self._split([goal[None]])[1][0] for _ in latents]
+            return latents, goals
+        joined = goal.shape[-1] == rollouts[0].shape[-1]
+        return states, (self._split([goal])[0][0] if joined else goal)
+
+    def _best_segment(self, rollouts, goal):
+        seqs, goals = self._segment_inputs(rollouts, goal)
+        cost = self._seq_cost(seqs, goals)
+        k = int(np.argmin(cost))
+        return self._split(rollouts)[0][k], cost[k], k
+
+    # ------------------------------------------------------------------ optimisation
+    def optimize(self, all_rollouts, goal):
+        return self._opt(self._root, all_rollouts, goal)
+
+    def _opt(self, lv, rollouts, goal):
+        if lv.left is None:
+            best, cost, k = self._best_segment(rollouts, goal)
+            lv.best_z, lv.done = lv.last_draw[k], True
+            return best, cost
+        if not lv.done:
+            return self._opt_subgoal(lv, rollouts, goal)
+        return self._opt_children(lv, rollouts, goal)
+
+    def _opt_subgoal(self, lv, rollouts, goal):
+        states, latents = self._split(rollouts)
+        joined = goal.shape[-1] == rollouts[0].shape[-1]          # goal given as a (state ++ latent) vector
+        mids = [int(np.floor(s.shape[0] / 2)) for s in states]
+        start_s = np.stack([s[0] for s in states])
+        start_l = np.stack([l[0] for l in latents])
+        sub_s = np.stack([s[m] for s, m in zip(states, mids)])
+        sub_l = np.stack([l[m] for l, m in zip(latents, mids)])
+        if joined:
+            gs, gl = self._split([goal[None]])
+            goal_s = np.stack([gs[0][0] for _ in states])
+            goal_l = np.stack([gl[0][0] for _ in latents])
+        else:
+            goal_s = np.stack([goal for _ in states])
+            goal_l = np.stack([l[-1] for l in latents])
+        total = self._pair_cost(start_l, sub_l) + self._pair_cost(sub_l, goal_l)
+        k = int(np.argmin(total))
+        lv.best_z = lv.last_draw[k]
+        plan = [start_s[k]]
+        if (sub_s[k] != plan[-1]).any():                          # identical when the sequence is too short
+            plan.append(sub_s[k])
+        if not joined:                                            # the final goal is appended exactly once
+            g = goal_s[k]
+            plan.append(g if g.shape == plan[-1].shape else g[0].transpose(2, 0, 1))
+        lv.left, lv.right = lv.left[:1], lv.right[:1]             # keep only the winning branch
+        lv.n_samples, lv.done = 1, True
+        return np.stack(plan), total[k]
+
+    def _opt_children(self, lv, rollouts, goal):
+        results = []
+        for cl, cr, group in zip(lv.left, lv.right, np.array_split(rollouts, lv.n_samples)):
+            group = [r for r in group]
+            short = []
+            for i, r in enumerate(group):
+                if r.shape[0] < 3:                                # nothing left to expand hierarchically
+                    short.append(r)
+                    group[i] = np.stack([np.full_like(r[0], np.inf), np.zeros_like(r[0]), np.full_like(r[0], np.inf)])
+            cut = [int(np.floor(r.shape[0] / 2)) for r in group]
+            subgoal = group[0][cut[0]]
+            lr, lc = self._opt(cl, [r[:c] for r, c in zip(group, cut)], subgoal)
+            rr, rc = self._opt(cr, [r[c:] for r, c in zip(group, cut)], goal)
+            best, cost = np.concatenate([lr, rr]), lc + rc
+            if short:
+                sb, sc, _ = self._best_segment(short, goal)
+                if sc < cost or np.isnan(cost):
+                    best, cost = sb, sc
+            results.append((best, cost))
+        k = int(np.argmin(np.array([c for _, c in results])))
+        return results[k]
+
+    @property
+    def fully_optimized(self):
+        def full(lv):
+            if lv.left is None:
+                return lv.done
+            return lv.done and all(full(c) for c in lv.left) and all(full(c) for c in lv.right)
+        return full(self._root)
+
+
+class ImageHierarchicalTreeLatentOptimizer(HierarchicalTreeLatentOptimizer):
+    def __init__(self, *args, **kw):
+        kw.setdefault("image_states", True)
+        super().__init__(*args, **kw)
