@@ -77,7 +77,8 @@ def main():
     # the path shards by sequence: every rank predicts its own batch of independent sequences (weak scaling), no
     # data-path collective in the forward
     inputs, noise, _ = make_inputs(hp, seed=D.shard_seed(100, rank), variant="A")
-    dinp = {k: v.to(dev) for k, v in inputs.items()}
+    # headline = pure prediction forward: without pad_mask the model does not run its loss kernels
+    dinp = {k: v.to(dev) for k, v in inputs.items() if k in ("traj_seq", "I_0", "I_g", "end_ind", "start_ind")}
     dnoise = noise.to(dev)
 
     for _ in range(max(args.warmup, 1)):

@@ -87,8 +87,9 @@ typedef struct gcpx_conv_args {
 
 /* decoder block: (bilinear x2 upsample +) 3x3 conv, pad 1 */
 int gcpx_conv3x3(const gcpx_conv_args* a, void* stream);
-/* encoder block: 4x4 conv, stride 2, pad 1 (NHWC sources) */
+/* encoder block: 4x4 conv, stride 2, pad 1 (NHWC sources); its stats_partial has gcpx_conv4x4s2_grid() rows */
 int gcpx_conv4x4s2(const gcpx_conv_args* a, void* stream);
+int gcpx_conv4x4s2_grid(void);
 /* first encoder block: same conv on the NCHW 3-channel image tensor the model API receives.
    x: dev NCHW [F][3][Hin][Win]; out NHWC [F][Hin/2][Win/2][Cout] with bias + out_act applied. */
 int gcpx_conv4x4s2_image(const float* x, const float* wpk, const float* bias, float* out,

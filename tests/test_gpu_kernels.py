@@ -262,7 +262,7 @@ def test_conv4x4s2(env, Hin, cin, cout, Fr):
     want = F.conv2d(F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2), w, b, stride=2, padding=1)
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
     out = torch.full((Fr, Hin // 2, Hin // 2, cout), float("nan"), device=dev)
-    G = lib.gcpx_conv_grid()
+    G = lib.gcpx_conv4x4s2_grid()
     st = torch.full((G, 2, cout), float("nan"), device=dev)
     a = _conv_args(rt, [(xd, cin, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=Hin, Win=Hin, Hout=Hin // 2, Wout=Hin // 2,
                    Cout=cout, out_pitch=cout, wpk=pk.pack_conv4x4(w).to(dev), bias=b.to(dev), out=out, stats_partial=st)

@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
             if constexpr (UP) {
                 __syncthreads();
                 const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+#pragma unroll 4
                 for (int idx = tid; idx < TF * RH * RW * C4; idx += 256) {
                     const int c4 = idx % C4;
                     int t = idx / C4;

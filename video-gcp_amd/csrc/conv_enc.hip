@@ -11,29 +11,36 @@
 
 namespace {
 
-// generic NHWC layer: Cin % 16 == 0
-template <int CT>
+// generic NHWC layer: Cin % 16 == 0.
+// A 256-thread workgroup owns WP*PRW pixel groups (16 pixels each); its 4 wavefronts are arranged WC x WP:
+// wave (wc, wp) computes CTW output-channel tiles [wc*CTW, (wc+1)*CTW) for PRW pixel groups.  Spreading the channel
+// tiles over wavefronts (instead of giving every wavefront all channels of a few pixels) divides the L2->L1 weight
+// traffic by WC: with all-channels-per-wave the layer was L2-bandwidth bound (each wave re-read the whole filter
+// bank, 131-524 KB, for 32 pixels).
+template <int CTW, int PRW, int WC, int WP>
 __global__ void __launch_bounds__(256) conv4x4s2_kernel(const gcpx_conv_args a, const int ngroups) {
-    constexpr int PR = 2;
+    static_assert(WC * WP == 4, "4 wavefronts");
+    constexpr int CT = CTW * WC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave % WC, wp = wave / WC;
     const int j = lane & 15, q = lane >> 4;
     const int Hin = a.Hin, Win = a.Win, Hout = a.Hout, Wout = a.Wout, Cin = a.Cin;
     const int ncg = Cin / 16;
     const int npix = a.F * Hout * Wout;
     const gcpx_conv_src s = a.src[0];
-    const float4* wbase = reinterpret_cast<const float4*>(a.wpk) + lane;
+    const float4* wbase = reinterpret_cast<const float4*>(a.wpk) + (size_t)wc * CTW * 64 + lane;
 
-    f32x4 st1[CT], st2[CT];
+    f32x4 st1[CTW], st2[CTW];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) { st1[ct] = f32x4{0, 0, 0, 0}; st2[ct] = f32x4{0, 0, 0, 0}; }
+    for (int ct = 0; ct < CTW; ++ct) { st1[ct] = f32x4{0, 0, 0, 0}; st2[ct] = f32x4{0, 0, 0, 0}; }
 
-    const int nblk = (ngroups + 4 * PR - 1) / (4 * PR);
+    const int nblk = (ngroups + WP * PRW - 1) / (WP * PRW);
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        int pf[PR], poy[PR], pox[PR];
-        bool pv[PR];
+        int pf[PRW], poy[PRW], pox[PRW];
+        bool pv[PRW];
 #pragma unroll
-        for (int pt = 0; pt < PR; ++pt) {
-            const int p = ((blk * 4 + wave) * PR + pt) * 16 + j;
+        for (int pt = 0; pt < PRW; ++pt) {
+            const int p = ((blk * WP + wp) * PRW + pt) * 16 + j;
             pv[pt] = p < npix;
             const int pp = pv[pt] ? p : 0;
             pox[pt] = pp % Wout;
@@ -41,97 +48,89 @@ __global__ void __launch_bounds__(256) conv4x4s2_kernel(const gcpx_conv_args a, 
             poy[pt] = t % Hout;
             pf[pt] = t / Hout;
         }
-        f32x4 acc[CT][PR];
+        f32x4 acc[CTW][PRW];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int ct = 0; ct < CTW; ++ct)
 #pragma unroll
-            for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
+            for (int pt = 0; pt < PRW; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
 
         for (int tap = 0; tap < 16; ++tap) {
             const int ky = tap >> 2, kx = tap & 3;
-            const float* bp[PR];
-            bool inb[PR];
+            const float* bp[PRW];
+            float msk[PRW];
 #pragma unroll
-            for (int pt = 0; pt < PR; ++pt) {
+            for (int pt = 0; pt < PRW; ++pt) {
                 const int iy = 2 * poy[pt] - 1 + ky, ix = 2 * pox[pt] - 1 + kx;
-                inb[pt] = pv[pt] && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
-                bp[pt] = s.ptr + (((size_t)pf[pt] * Hin + (inb[pt] ? iy : 0)) * Win + (inb[pt] ? ix : 0)) * Cin + q * 4;
+                const bool inb = pv[pt] && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+                msk[pt] = inb ? 1.f : 0.f;                      // conv zero padding stays exactly zero
+                bp[pt] = s.ptr + (((size_t)pf[pt] * Hin + (inb ? iy : 0)) * Win + (inb ? ix : 0)) * Cin + q * 4;
             }
-            // loads of UK channel groups go out together, then their MFMAs (latency-bound otherwise)
-            constexpr int UK = (CT >= 8) ? 1 : (CT >= 4 ? 2 : 4);
-            for (int cg = 0; cg < ncg; cg += UK) {
-                float4 b[UK][PR], w[UK][CT];
+            for (int cg = 0; cg < ncg; ++cg) {
+                float4 b[PRW], w[CTW];
 #pragma unroll
-                for (int u = 0; u < UK; ++u) {
-                    const int c = (cg + u < ncg) ? cg + u : ncg - 1;
+                for (int pt = 0; pt < PRW; ++pt) b[pt] = *reinterpret_cast<const float4*>(bp[pt] + cg * 16);
+                const float4* wp_ = wbase + (size_t)(tap * ncg + cg) * CT * 64;
 #pragma unroll
-                    for (int pt = 0; pt < PR; ++pt) b[u][pt] = *reinterpret_cast<const float4*>(bp[pt] + c * 16);
-                    const float4* wp = wbase + (size_t)(tap * ncg + c) * CT * 64;
+                for (int ct = 0; ct < CTW; ++ct) w[ct] = wp_[ct * 64];
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) w[u][ct] = wp[ct * 64];
+                for (int pt = 0; pt < PRW; ++pt) {
+                    float4 bb = affine_act4(b[pt], s.scale, s.shift, cg * 16 + q * 4, s.act);
+                    bb.x *= msk[pt]; bb.y *= msk[pt]; bb.z *= msk[pt]; bb.w *= msk[pt];
+                    b[pt] = bb;
                 }
 #pragma unroll
-                for (int u = 0; u < UK; ++u) {
-                    if (cg + u < ncg) {
+                for (int ct = 0; ct < CTW; ++ct) {
 #pragma unroll
-                        for (int pt = 0; pt < PR; ++pt) {
-                            float4 bb = affine_act4(b[u][pt], s.scale, s.shift, (cg + u) * 16 + q * 4, s.act);
-                            const float m = inb[pt] ? 1.f : 0.f;     // conv zero padding stays exactly zero
-                            bb.x *= m; bb.y *= m; bb.z *= m; bb.w *= m;
-                            b[u][pt] = bb;
-                        }
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) {
-#pragma unroll
-                            for (int pt = 0; pt < PR; ++pt) {
-                                acc[ct][pt] = mfma16(w[u][ct].x, b[u][pt].x, acc[ct][pt]);
-                                acc[ct][pt] = mfma16(w[u][ct].y, b[u][pt].y, acc[ct][pt]);
-                                acc[ct][pt] = mfma16(w[u][ct].z, b[u][pt].z, acc[ct][pt]);
-                                acc[ct][pt] = mfma16(w[u][ct].w, b[u][pt].w, acc[ct][pt]);
-                            }
-                        }
+                    for (int pt = 0; pt < PRW; ++pt) {
+                        acc[ct][pt] = mfma16(w[ct].x, b[pt].x, acc[ct][pt]);
+                        acc[ct][pt] = mfma16(w[ct].y, b[pt].y, acc[ct][pt]);
+                        acc[ct][pt] = mfma16(w[ct].z, b[pt].z, acc[ct][pt]);
+                        acc[ct][pt] = mfma16(w[ct].w, b[pt].w, acc[ct][pt]);
                     }
                 }
             }
         }
 #pragma unroll
-        for (int pt = 0; pt < PR; ++pt) {
+        for (int pt = 0; pt < PRW; ++pt) {
             if (!pv[pt]) continue;
-            const size_t p = (size_t)((blk * 4 + wave) * PR + pt) * 16 + j;
+            const size_t p = (size_t)((blk * WP + wp) * PRW + pt) * 16 + j;
             float* op = a.out + p * a.out_pitch;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const float4 bv = *reinterpret_cast<const float4*>(a.bias + ct * 16 + q * 4);
+            for (int ct = 0; ct < CTW; ++ct) {
+                const int c = (wc * CTW + ct) * 16 + q * 4;
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
                 f32x4 v = acc[ct][pt];
                 v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                 if (a.out_act == GCPX_ACT_LRELU) {
                     v[0] = lrelu(v[0], 0.2f); v[1] = lrelu(v[1], 0.2f); v[2] = lrelu(v[2], 0.2f); v[3] = lrelu(v[3], 0.2f);
                 }
-                *reinterpret_cast<float4*>(op + ct * 16 + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(op + c) = make_float4(v[0], v[1], v[2], v[3]);
                 if (a.stats_partial) { st1[ct] += v; st2[ct] += v * v; }
             }
         }
     }
     if (a.stats_partial) {
-        __shared__ float red[4 * 2 * CT * 16];
+        // deterministic per-workgroup partial sums: lanes of a row, then the WP wavefronts that share channels
+        __shared__ float red[WP * 2 * CT * 16];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
+        for (int ct = 0; ct < CTW; ++ct) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float s1 = row16_sum(st1[ct][r]);
                 const float s2 = row16_sum(st2[ct][r]);
                 if (j == 0) {
-                    red[(wave * 2 + 0) * CT * 16 + ct * 16 + q * 4 + r] = s1;
-                    red[(wave * 2 + 1) * CT * 16 + ct * 16 + q * 4 + r] = s2;
+                    const int c = (wc * CTW + ct) * 16 + q * 4 + r;
+                    red[(wp * 2 + 0) * CT * 16 + c] = s1;
+                    red[(wp * 2 + 1) * CT * 16 + c] = s2;
                 }
             }
         }
         __syncthreads();
-        if (tid < 2 * CT * 16) {
-            const int which = tid / (CT * 16), c = tid % (CT * 16);
+        for (int i = tid; i < 2 * CT * 16; i += 256) {
+            const int which = i / (CT * 16), c = i % (CT * 16);
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) sum += red[(w * 2 + which) * CT * 16 + c];
+            for (int w = 0; w < WP; ++w) sum += red[(w * 2 + which) * CT * 16 + c];
             a.stats_partial[((size_t)blockIdx.x * 2 + which) * CT * 16 + c] = sum;
         }
     }
@@ -210,6 +209,8 @@ __global__ void __launch_bounds__(256) conv4x4s2_image_kernel(const float* __res
 
 }  // namespace
 
+extern "C" int gcpx_conv4x4s2_grid(void) { return gcpx_conv_grid() * 4; }
+
 extern "C" int gcpx_conv4x4s2(const gcpx_conv_args* a, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(a != nullptr, "null args");
@@ -220,15 +221,19 @@ extern "C" int gcpx_conv4x4s2(const gcpx_conv_args* a, void* stream_) {
     GCPX_CHECK_ARG(a->wpk && a->bias && a->out && a->F > 0, "null pointer / F <= 0");
     const int npix = a->F * a->Hout * a->Wout;
     const int ngroups = (npix + 15) / 16;
-    int grid = gcpx_conv_grid();
-    const int nblk = (ngroups + 7) / 8;
-    // stats_partial has gcpx_conv_grid() rows: all of them must be written
-    if (!a->stats_partial && grid > nblk) grid = nblk;
+    // these kernels hide their global-load latency with occupancy, not with LDS staging: 8 workgroups per CU
+    int grid = gcpx_conv4x4s2_grid();
     const int CT = a->Cout / 16;
+    const int per_blk = (CT == 2) ? 16 : 8;      // pixel groups per workgroup (WP * PRW)
+    const int nblk = (ngroups + per_blk - 1) / per_blk;
+    // stats_partial has gcpx_conv4x4s2_grid() rows: all of them must be written
+    if (!a->stats_partial && grid > nblk) grid = nblk;
     switch (CT) {
-        case 2: hipLaunchKernelGGL(conv4x4s2_kernel<2>, dim3(grid), dim3(256), 0, stream, *a, ngroups); break;
-        case 4: hipLaunchKernelGGL(conv4x4s2_kernel<4>, dim3(grid), dim3(256), 0, stream, *a, ngroups); break;
-        case 8: hipLaunchKernelGGL(conv4x4s2_kernel<8>, dim3(grid), dim3(256), 0, stream, *a, ngroups); break;
+        case 2: hipLaunchKernelGGL((conv4x4s2_kernel<1, 8, 2, 2>), dim3(grid), dim3(256), 0, stream, *a, ngroups); break;
+        // the deeper layers have few output pixels (20k at 4x4): keep every wavefront on all channels of 32 pixels so
+        // that there are enough workgroups; measured 105 / 121 us vs 191 / 199 us with channel-split wavefronts (c2)
+        case 4: hipLaunchKernelGGL((conv4x4s2_kernel<4, 2, 1, 4>), dim3(grid), dim3(256), 0, stream, *a, ngroups); break;
+        case 8: hipLaunchKernelGGL((conv4x4s2_kernel<8, 2, 1, 4>), dim3(grid), dim3(256), 0, stream, *a, ngroups); break;
         default:
             gcpx_set_error("conv4x4s2: unsupported Cout=%d", a->Cout);
             return GCPX_ERR_UNSUPPORTED;

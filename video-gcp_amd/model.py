@@ -336,7 +336,7 @@ class GCPTreeModel:
         """Encoder over F NCHW frames at x_ptr; writes the nz_enc latent of frame r=(b,j) to
         out_ptr + b*out_ob + j*out_orow.  Returns the skip sources {module index: (tensor, C, scale, shift, act)}."""
         hp, P, lib = self._hp, self.pk, self.lib
-        G = lib.gcpx_conv_grid()
+        G = lib.gcpx_conv4x4s2_grid()
         S = hp.img_sz
         skip_idx = encoder_skip_layers(hp)
         skips = {}

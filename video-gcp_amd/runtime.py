@@ -65,6 +65,7 @@ SYMBOLS = [
     ("gcpx_conv_grid", C.c_int, []),
     ("gcpx_conv3x3", C.c_int, [C.POINTER(ConvArgs), vp]),
     ("gcpx_conv4x4s2", C.c_int, [C.POINTER(ConvArgs), vp]),
+    ("gcpx_conv4x4s2_grid", C.c_int, []),
     ("gcpx_conv4x4s2_image", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     ("gcpx_bn_finalize", C.c_int, [vp, i32, i32, i32, C.c_double, vp, vp, C.c_float, vp, vp, vp, vp, C.c_float, vp]),
     ("gcpx_bn_fold", C.c_int, [vp, vp, vp, vp, C.c_float, i32, vp, vp, vp]),
