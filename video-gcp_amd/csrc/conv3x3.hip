@@ -187,37 +187,64 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
             write_stage(chunk);
             if constexpr (UP) {
                 __syncthreads();
-                const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
-#pragma unroll 4
-                for (int idx = tid; idx < TF * RH * RW * C4; idx += 256) {
-                    const int c4 = idx % C4;
-                    int t = idx / C4;
-                    const int rx = t % RW; t /= RW;
-                    const int ry = t % RH;
-                    const int fl = t / RH;
-                    const int Y = y0 - 1 + ry, X = x0 - 1 + rx;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (Y >= 0 && Y < Hout && X >= 0 && X < Wout) {
-                        // torch area_pixel_compute_source_index, align_corners=False, scale 0.5
-                        const float h1r = fmaxf(0.5f * ((float)Y + 0.5f) - 0.5f, 0.f);
-                        const float w1r = fmaxf(0.5f * ((float)X + 0.5f) - 0.5f, 0.f);
-                        const int h1 = (int)h1r, w1 = (int)w1r;
-                        const float lh1 = h1r - (float)h1, lw1 = w1r - (float)w1;
-                        const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
-                        const int r0 = h1 - ly0, r1 = r0 + ((h1 < a.Hin - 1) ? 1 : 0);
-                        const int c0 = w1 - lx0, c1 = c0 + ((w1 < a.Win - 1) ? 1 : 0);
-                        const float* rb = raw + (fl * LH) * LW * CC + c4 * 4;
-                        const float4 a00 = *reinterpret_cast<const float4*>(rb + (r0 * LW + c0) * CC);
-                        const float4 a01 = *reinterpret_cast<const float4*>(rb + (r0 * LW + c1) * CC);
-                        const float4 a10 = *reinterpret_cast<const float4*>(rb + (r1 * LW + c0) * CC);
-                        const float4 a11 = *reinterpret_cast<const float4*>(rb + (r1 * LW + c1) * CC);
-                        v.x = lh0 * (lw0 * a00.x + lw1 * a01.x) + lh1 * (lw0 * a10.x + lw1 * a11.x);
-                        v.y = lh0 * (lw0 * a00.y + lw1 * a01.y) + lh1 * (lw0 * a10.y + lw1 * a11.y);
-                        v.z = lh0 * (lw0 * a00.z + lw1 * a01.z) + lh1 * (lw0 * a10.z + lw1 * a11.z);
-                        v.w = lh0 * (lw0 * a00.w + lw1 * a01.w) + lh1 * (lw0 * a10.w + lw1 * a11.w);
-                    }
-                    *reinterpret_cast<float4*>(hi + ((fl * RH + ry) * RW + rx) * CCP + c4 * 4) = v;
+                // ---- bilinear x2 (align_corners=False) from the replicate-clamped low-res patch, LDS -> LDS ----
+                // With even tile origins the source rows/weights depend only on the position inside the tile:
+                //   hi row ry  <- raw rows (ry>>1, (ry>>1)+1) with weight (ry odd ? .75 : .25) on the lower one,
+                // same along x.  (At the image border torch evaluates 1*in[0] + 0*in[1]; the clamped patch gives
+                // .25*in[0] + .75*in[0]: identical up to one rounding.)  Thread map: c4 = tid & 7 (4 channels),
+                // 32 positions per pass; no integer division or float index math in the loop.
+                const int c4 = tid & (C4 - 1);
+                const int p = tid >> 3;                                   // 0..31  (C4 == 8)
+                static_assert(C4 == 8, "upsampling blocks stage 32-channel chunks");
+                constexpr int RPP = 32 / (TW * TF);                       // hi rows covered per pass (1 or 2)
+                static_assert(RPP == 1 || (RPP == 2 && TF == 1), "tile shapes: 8x32, 16x16, 8x8x4");
+                const int fl = (TF > 1) ? p / TW : 0;
+                const int rx = p % TW;                                    // TW is a power of two
+                const int rsub = (RPP == 2) ? (p / TW) : 0;               // row inside the pass
+                const float lx1 = (rx & 1) ? 0.75f : 0.25f, lx0w = 1.f - lx1;
+                const float* rbase = raw + ((fl * LH) * LW + (rx >> 1)) * CC + c4 * 4;
+                float* hbase = hi + ((fl * RH) * RW + rx) * CCP + c4 * 4;
+                auto lerp4 = [&](const float* r, float wx1, float wx0, float wy1, float wy0) {
+                    const float4 a00 = *reinterpret_cast<const float4*>(r);
+                    const float4 a01 = *reinterpret_cast<const float4*>(r + CC);
+                    const float4 a10 = *reinterpret_cast<const float4*>(r + LW * CC);
+                    const float4 a11 = *reinterpret_cast<const float4*>(r + LW * CC + CC);
+                    float4 v;
+                    v.x = wy0 * (wx0 * a00.x + wx1 * a01.x) + wy1 * (wx0 * a10.x + wx1 * a11.x);
+                    v.y = wy0 * (wx0 * a00.y + wx1 * a01.y) + wy1 * (wx0 * a10.y + wx1 * a11.y);
+                    v.z = wy0 * (wx0 * a00.z + wx1 * a01.z) + wy1 * (wx0 * a10.z + wx1 * a11.z);
+                    v.w = wy0 * (wx0 * a00.w + wx1 * a01.w) + wy1 * (wx0 * a10.w + wx1 * a11.w);
+                    return v;
+                };
+                const bool top = (y0 == 0), bot = (y0 + TH == Hout), lft = (x0 == 0), rgt = (x0 + TW == Wout);
+                // main part: columns 1..TW of the staged region (hi-res x0 .. x0+TW-1 -> region column rx+1)
+#pragma unroll 2
+                for (int k = 0; k < RH / RPP; ++k) {
+                    const int ry = k * RPP + rsub;
+                    // region column c = rx + 1 <-> hi-res X = x0 + rx: source columns ((rx+1)>>1, +1), weight by parity
+                    const int cx = rx + 1;
+                    const float wx1 = (cx & 1) ? 0.75f : 0.25f, wx0 = 1.f - wx1;
+                    const float wy1 = (ry & 1) ? 0.75f : 0.25f, wy0 = 1.f - wy1;
+                    const float* r = raw + ((fl * LH + (ry >> 1)) * LW + (cx >> 1)) * CC + c4 * 4;
+                    float4 v = lerp4(r, wx1, wx0, wy1, wy0);
+                    const bool zero = (top && ry == 0) || (bot && ry == RH - 1);
+                    if (zero) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(hi + ((fl * RH + ry) * RW + cx) * CCP + c4 * 4) = v;
                 }
+                // the two halo columns (region columns 0 and RW-1)
+                for (int e = p; e < TF * RH * 2; e += 32) {
+                    const int side = e & 1;
+                    const int ry = (e >> 1) % RH, f2 = (e >> 1) / RH;
+                    const int cx = side ? RW - 1 : 0;
+                    const float wx1 = (cx & 1) ? 0.75f : 0.25f, wx0 = 1.f - wx1;
+                    const float wy1 = (ry & 1) ? 0.75f : 0.25f, wy0 = 1.f - wy1;
+                    const float* r = raw + ((f2 * LH + (ry >> 1)) * LW + (cx >> 1)) * CC + c4 * 4;
+                    float4 v = lerp4(r, wx1, wx0, wy1, wy0);
+                    const bool zero = (top && ry == 0) || (bot && ry == RH - 1) || (lft && side == 0) || (rgt && side == 1);
+                    if (zero) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(hi + ((f2 * RH + ry) * RW + cx) * CCP + c4 * 4) = v;
+                }
+                (void)lx1; (void)lx0w; (void)rbase; (void)hbase;
             }
             __syncthreads();
             // next stage's global loads go out now and land while the MFMAs below run
