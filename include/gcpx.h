@@ -78,15 +78,17 @@ typedef struct gcpx_conv_args {
     const float* bias;      /* dev: [CT*16], zero padded */
     float* out;             /* dev: NHWC raw output (may be NULL for GCPX_HEAD_DLM_MEAN) */
     float* images;          /* dev: NCHW [F][3][H][W] for the head modes that produce images */
-    float* stats_partial;   /* dev: [gcpx_conv_grid()][2][CT*16] per-workgroup sum / sum-of-squares of the
+    float* stats_partial;   /* dev: [gcpx_conv3x3_grid(a) or gcpx_conv4x4s2_grid()][2][CT*16] per-workgroup sum / sum-of-squares of the
                                raw output for training-mode BatchNorm, or NULL */
     const int32_t* raw_row_map; /* dev: [F] or NULL (output head only): frame f stores its raw parameters at row
                                raw_row_map[f] of `out`, or not at all when the entry is negative — only the nodes matched
                                to a ground-truth frame need their distribution parameters (frame_binding.py:91-92) */
 } gcpx_conv_args;
 
-/* decoder block: (bilinear x2 upsample +) 3x3 conv, pad 1 */
+/* decoder block: (bilinear x2 upsample +) 3x3 conv, pad 1.  gcpx_conv3x3_grid(a) = number of workgroups that launch
+   will use = rows of a->stats_partial (a->stats_partial must already be non-NULL in the query if it will be). */
 int gcpx_conv3x3(const gcpx_conv_args* a, void* stream);
+int gcpx_conv3x3_grid(const gcpx_conv_args* a);
 /* encoder block: 4x4 conv, stride 2, pad 1 (NHWC sources); its stats_partial has gcpx_conv4x4s2_grid() rows */
 int gcpx_conv4x4s2(const gcpx_conv_args* a, void* stream);
 int gcpx_conv4x4s2_grid(void);

@@ -200,10 +200,12 @@ def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes):
     want = F.conv2d(F.interpolate(torch.cat(srcs_ref, 1), scale_factor=2, mode="bilinear", align_corners=False), w, b, padding=1)
     wp, bd = pk.pack_conv3x3(w, 32).to(dev), pk.pad_vec(b, cout).to(dev)
     out = torch.full((Fr, 2 * Hin, 2 * Hin, cout), float("nan"), device=dev)
-    G = lib.gcpx_conv_grid()
-    st = torch.full((G, 2, cout), float("nan"), device=dev)
     a = _conv_args(rt, srcs, F=Fr, Hin=Hin, Win=Hin, Hout=2 * Hin, Wout=2 * Hin, Cout=cout, out_pitch=cout, upsample=1,
-                   head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out, stats_partial=st)
+                   head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out, stats_partial=out)
+    G = lib.gcpx_conv3x3_grid(C.byref(a))
+    assert G > 0
+    st = torch.full((G, 2, cout), float("nan"), device=dev)
+    a.stats_partial = st.data_ptr()
     rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "conv3x3")
     torch.cuda.synchronize()
     assert_close(out.permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5, name="conv3x3 up")

@@ -13,5 +13,5 @@ for f in conv3x3 conv_enc gemm mlp misc loss; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC build/conv3x3.o build/conv_enc.o build/gemm.o build/mlp.o build/misc.o build/loss.o -o $OUT
 echo "built $(realpath $OUT)"

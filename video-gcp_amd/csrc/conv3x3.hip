@@ -25,6 +25,7 @@ template <int TILE> struct TileShape;
 template <> struct TileShape<0> { static constexpr int TH = 8, TW = 32, TF = 1; };
 template <> struct TileShape<1> { static constexpr int TH = 16, TW = 16, TF = 1; };
 template <> struct TileShape<2> { static constexpr int TH = 8, TW = 8, TF = 4; };
+template <> struct TileShape<3> { static constexpr int TH = 8, TW = 16, TF = 1; };   // 128 pixels: more workgroups per CU
 
 template <bool UP, int CC, int CT, int TILE>
 struct ConvCfg {
@@ -32,12 +33,16 @@ struct ConvCfg {
     static constexpr int TH = TS::TH, TW = TS::TW, TF = TS::TF;
     static constexpr int RH = TH + 2, RW = TW + 2;          // staged hi-res region (halo 1)
     static constexpr int LH = TH / 2 + 2, LW = TW / 2 + 2;  // low-res patch feeding the upsample
-    static constexpr int CCP = CC + 4;                      // padded channel pitch in LDS (bank spread)
+    // padded channel pitch in LDS.  (A pitch of 40 floats makes the B-operand ds_read_b128 conflict-free — 36 is 2-way —
+    // but measured no gain: these kernels are VALU+MFMA issue bound, not LDS bound.)
+    static constexpr int CCP = CC + 4;
     static constexpr int C4 = CC / 4;
     static constexpr int HI_FLOATS = TF * RH * RW * CCP;
     static constexpr int RAW_FLOATS = UP ? TF * LH * LW * CC : 0;
     static constexpr int RED_FLOATS = 4 * 2 * CT * 16;      // cross-wave stats reduction
     static constexpr int LDS_BYTES = (HI_FLOATS + RAW_FLOATS) * 4;
+    static constexpr int PR = TH * TW * TF / 64;            // pixel groups per wavefront (4 wavefronts)
+    static constexpr int MIN_WAVES = (TILE == 3) ? 3 : 2;   // waves per SIMD the register allocation must allow
 };
 
 __device__ __forceinline__ float4 load_src4(const gcpx_conv_args& a, int f, int sy, int sx, int cglob) {
@@ -57,9 +62,10 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 
 template <bool UP, int CC, int CT, int TILE>
-__global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty,
-                                                         const int ntiles) {
+__global__ void __launch_bounds__(256, (ConvCfg<UP, CC, CT, TILE>::MIN_WAVES))
+conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty, const int ntiles) {
     using Cfg = ConvCfg<UP, CC, CT, TILE>;
+    constexpr int PR = Cfg::PR;
     constexpr int TH = Cfg::TH, TW = Cfg::TW, TF = Cfg::TF, RH = Cfg::RH, RW = Cfg::RW;
     constexpr int LH = Cfg::LH, LW = Cfg::LW, CCP = Cfg::CCP, C4 = Cfg::C4;
     constexpr int NSTEP = 9 * (CC / 16);
@@ -80,10 +86,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
     const int Hout = a.Hout, Wout = a.Wout, F = a.F;
 
     // per-lane pixel of each of its 4 pixel groups, inside the tile
-    int pixoff[4], pfl[4], py[4], px[4];
+    int pixoff[PR], pfl[PR], py[PR], px[PR];
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-        const int p = (wave * 4 + pt) * 16 + j;
+    for (int pt = 0; pt < PR; ++pt) {
+        const int p = (wave * PR + pt) * 16 + j;
         pfl[pt] = p / (TH * TW);
         const int rem = p % (TH * TW);
         py[pt] = rem / TW;
@@ -173,17 +179,19 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
         int f0, y0, x0;
         tile_origin(tile, f0, y0, x0);
 
-        f32x4 acc[CT][4];
+        f32x4 acc[CT][PR];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
+            for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
         float4 wnext[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) wnext[ct] = wbase[ct * 64];
 
         for (int chunk = 0; chunk < nchunk; ++chunk) {
-            __syncthreads();   // previous stage's LDS reads are done
+            // UP: the low-res patch `raw` is not read by the MFMA phase, so it can be written while other wavefronts
+            // are still in the previous stage's MFMAs; one barrier then covers both "raw complete" and "hi free".
+            if constexpr (!UP) __syncthreads();   // previous stage's LDS reads of `hi` are done
             write_stage(chunk);
             if constexpr (UP) {
                 __syncthreads();
@@ -226,7 +234,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
                     const float wx1 = (cx & 1) ? 0.75f : 0.25f, wx0 = 1.f - wx1;
                     const float wy1 = (ry & 1) ? 0.75f : 0.25f, wy0 = 1.f - wy1;
                     const float* r = raw + ((fl * LH + (ry >> 1)) * LW + (cx >> 1)) * CC + c4 * 4;
+#ifdef GCPX_ABLATE_NOUPSAMPLE
+                    float4 v = *reinterpret_cast<const float4*>(r);
+#else
                     float4 v = lerp4(r, wx1, wx0, wy1, wy0);
+#endif
                     const bool zero = (top && ry == 0) || (bot && ry == RH - 1);
                     if (zero) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     *reinterpret_cast<float4*>(hi + ((fl * RH + ry) * RW + cx) * CCP + c4 * 4) = v;
@@ -255,6 +267,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
             // Weights are double-buffered in registers one step ahead; the stream of steps is contiguous across
             // chunks and the packed buffer carries one zero step of padding, so the prefetch never branches.
             const float4* wp = wbase + (size_t)chunk * NSTEP * CT * 64;
+#ifdef GCPX_ABLATE_NOMFMA
+            if (a.F < 0)
+#endif
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 const int tapoff = ((tap / 3) * RW + (tap % 3)) * CCP;
@@ -266,14 +281,14 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
                     for (int ct = 0; ct < CT; ++ct) wcur[ct] = wnext[ct];
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) wnext[ct] = wp[((st + 1) * CT + ct) * 64];
-                    float4 b[4];
+                    float4 b[PR];
 #pragma unroll
-                    for (int pt = 0; pt < 4; ++pt)
+                    for (int pt = 0; pt < PR; ++pt)
                         b[pt] = *reinterpret_cast<const float4*>(hi + pixoff[pt] + tapoff + cgl * 16);
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
-                        for (int pt = 0; pt < 4; ++pt) {
+                        for (int pt = 0; pt < PR; ++pt) {
                             acc[ct][pt] = mfma16(wcur[ct].x, b[pt].x, acc[ct][pt]);
                             acc[ct][pt] = mfma16(wcur[ct].y, b[pt].y, acc[ct][pt]);
                             acc[ct][pt] = mfma16(wcur[ct].z, b[pt].z, acc[ct][pt]);
@@ -289,14 +304,14 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
         for (int ct = 0; ct < CT; ++ct) {
             const float4 bv = *reinterpret_cast<const float4*>(a.bias + ct * 16 + q * 4);
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
+            for (int pt = 0; pt < PR; ++pt) {
                 acc[ct][pt][0] += bv.x; acc[ct][pt][1] += bv.y; acc[ct][pt][2] += bv.z; acc[ct][pt][3] += bv.w;
             }
         }
         const int mode = a.head_mode;
         if (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) {
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
+            for (int pt = 0; pt < PR; ++pt) {
                 const int f = f0 + pfl[pt];
                 if (f >= F) continue;
                 float* op = a.out + (((size_t)f * Hout + (y0 + py[pt])) * Wout + (x0 + px[pt])) * a.out_pitch;
@@ -324,7 +339,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
                 // kernel channel order: slot 8k..8k+7 = {logit_k, mu_r, mu_g, mu_b, c0, c1, c2, pad}, k = 0..9;
                 // lanes with even q hold the first half of mixture 2*ct + q/2, lane+16 holds the second half.
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) {
+                for (int pt = 0; pt < PR; ++pt) {
                     float lg[5], mr[5], mg[5], mb[5];
 #pragma unroll
                     for (int ct = 0; ct < 5; ++ct) {
@@ -361,7 +376,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(const gcpx_conv_args a,
         }
         if (mode == GCPX_HEAD_TANH_NCHW) {
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
+            for (int pt = 0; pt < PR; ++pt) {
                 const int f = f0 + pfl[pt];
                 if (q == 0 && f < F) {
                     const size_t plane = (size_t)Hout * Wout;
@@ -618,7 +633,7 @@ int launch_head(const gcpx_conv_args* a, hipStream_t stream) {
 int g_conv_grid = 0;
 
 template <bool UP, int CC, int CT, int TILE>
-int launch(const gcpx_conv_args* a, hipStream_t stream) {
+int launch(const gcpx_conv_args* a, hipStream_t stream, bool query_only = false) {
     using Cfg = ConvCfg<UP, CC, CT, TILE>;
     if (a->Hout % Cfg::TH || a->Wout % Cfg::TW) {
         gcpx_set_error("conv3x3: output %dx%d not divisible by tile %dx%d", a->Hout, a->Wout, Cfg::TH, Cfg::TW);
@@ -638,9 +653,11 @@ int launch(const gcpx_conv_args* a, hipStream_t stream) {
         }
         attr_set = true;
     }
-    int grid = gcpx_conv_grid();
-    // stats_partial has gcpx_conv_grid() rows and every one of them must be written
+    // persistent grid: CUs x resident workgroups per CU for this variant; with stats_partial every one of the
+    // gcpx_conv3x3_grid(a) rows must be written, so the grid is not clamped to the tile count then
+    int grid = (gcpx_conv_grid() / 2) * ((TILE == 3) ? 4 : 2);
     if (!a->stats_partial && grid > ntiles) grid = ntiles;
+    if (query_only) return grid;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, *a, ntx, nty, ntiles);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
@@ -661,8 +678,7 @@ extern "C" int gcpx_conv_grid(void) {
     return g_conv_grid;
 }
 
-extern "C" int gcpx_conv3x3(const gcpx_conv_args* a, void* stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool query_only) {
     GCPX_CHECK_ARG(a != nullptr, "null args");
     GCPX_CHECK_ARG(a->nsrc == 1 || a->nsrc == 2, "nsrc must be 1 or 2");
     GCPX_CHECK_ARG(a->src[0].C % 16 == 0 && (a->nsrc == 1 || a->src[1].C % 16 == 0), "source channels must be multiples of 16");
@@ -681,18 +697,24 @@ extern "C" int gcpx_conv3x3(const gcpx_conv_args* a, void* stream_) {
         GCPX_CHECK_ARG(a->Cin == 16, "non-upsampling 3x3 conv (output head) expects 16 input channels");
         GCPX_CHECK_ARG(a->nsrc == 1 && a->src[0].frame_div == 1, "output head takes one per-frame source");
         if (W % 32 == 0 && a->Hout % 2 == 0) {
-            if (CT == 7) return launch_head<7>(a, stream);
-            if (CT == 1) return launch_head<1>(a, stream);
+            if (CT == 7) return query_only ? gcpx_conv_grid() / 2 : launch_head<7>(a, stream);
+            if (CT == 1) return query_only ? gcpx_conv_grid() / 2 : launch_head<1>(a, stream);
         }
     } else {
         GCPX_CHECK_ARG(a->Cin % 32 == 0, "upsampling 3x3 conv expects Cin % 32 == 0");
         GCPX_CHECK_ARG(a->head_mode == GCPX_HEAD_RAW, "decoder blocks store raw output");
-        if (W % 32 == 0 && CT == 1) return launch<true, 32, 1, 0>(a, stream);
-        if (W == 16 && CT == 1) return launch<true, 32, 1, 1>(a, stream);
-        if (W == 16 && CT == 2) return launch<true, 32, 2, 1>(a, stream);
-        if (W == 8 && CT == 2) return launch<true, 32, 2, 2>(a, stream);
-        if (W == 8 && CT == 4) return launch<true, 32, 4, 2>(a, stream);
+        if (W % 32 == 0 && CT == 1) return launch<true, 32, 1, 3>(a, stream, query_only);
+        if (W == 16 && CT == 1) return launch<true, 32, 1, 1>(a, stream, query_only);
+        if (W == 16 && CT == 2) return launch<true, 32, 2, 1>(a, stream, query_only);
+        if (W == 8 && CT == 2) return launch<true, 32, 2, 2>(a, stream, query_only);
+        if (W == 8 && CT == 4) return launch<true, 32, 4, 2>(a, stream, query_only);
     }
     gcpx_set_error("conv3x3: unsupported shape (up=%d Cin=%d Cout=%d W=%d)", a->upsample, a->Cin, a->Cout, W);
     return GCPX_ERR_UNSUPPORTED;
 }
+
+extern "C" int gcpx_conv3x3(const gcpx_conv_args* a, void* stream_) {
+    return conv3x3_dispatch(a, reinterpret_cast<hipStream_t>(stream_), false);
+}
+
+extern "C" int gcpx_conv3x3_grid(const gcpx_conv_args* a) { return conv3x3_dispatch(a, nullptr, true); }

@@ -557,14 +557,17 @@ class GCPTreeModel:
                 assert C_ == c_skip and t.shape[1] == res
                 srcs.append((t.data_ptr(), C_, N, ssc, ssh, sact))      # skips of I_0 broadcast over the node axis
             o = self._buf(f"dec.{name}", (F, 2 * res, 2 * res, cout))
-            st = self._buf(f"dec.st.{name}", (G, 2, (cout + 15) // 16 * 16)) if self.training else None
+            cpad = (cout + 15) // 16 * 16
             a = self._conv_args(srcs, F, res, res, 2 * res, 2 * res, cout, cout, P[f"dec.{name}.w"], P[f"dec.{name}.b"],
-                                o, upsample=1, stats=st)
+                                o, upsample=1, stats=(o if self.training else None))     # placeholder pointer for the query
+            Gl = lib.gcpx_conv3x3_grid(C.byref(a))
+            assert Gl > 0, rt.lib().gcpx_last_error()
+            st = self._buf(f"dec.st.{name}", (Gl, 2, cpad)) if self.training else None
+            a.stats_partial = st.data_ptr() if st is not None else None
             plan.keep.append(a)
             plan.add(f"dec.{name}", lib.gcpx_conv3x3, C.byref(a))
             res *= 2
-            sc, sh = self._bn(plan, f"dec.bn.{name}", f"decoder.net.{name}.norm", cout, st, G,
-                              (cout + 15) // 16 * 16, F * res * res)
+            sc, sh = self._bn(plan, f"dec.bn.{name}", f"decoder.net.{name}.norm", cout, st, Gl, cpad, F * res * res)
             prev = (o.data_ptr(), cout, 1, sc, sh, rt.ACT_LRELU)
         assert res == S
         images = self._buf("images_df", (B, N, hp.input_nc, S, S))

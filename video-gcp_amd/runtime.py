@@ -64,6 +64,7 @@ SYMBOLS = [
     ("gcpx_last_error", C.c_char_p, []),
     ("gcpx_conv_grid", C.c_int, []),
     ("gcpx_conv3x3", C.c_int, [C.POINTER(ConvArgs), vp]),
+    ("gcpx_conv3x3_grid", C.c_int, [C.POINTER(ConvArgs)]),
     ("gcpx_conv4x4s2", C.c_int, [C.POINTER(ConvArgs), vp]),
     ("gcpx_conv4x4s2_grid", C.c_int, []),
     ("gcpx_conv4x4s2_image", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
