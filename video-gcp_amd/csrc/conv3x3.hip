@@ -419,7 +419,7 @@ conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty, const int n
 // -----------------------------------------------------------------------------------------------------------
 // Output head (3x3 conv, 16 input channels, no upsample): wave-autonomous variant.
 //   * the packed weights (9 steps x CT KiB) are loaded into LDS once per 512-thread workgroup (1 per CU);
-//   * every wavefront then works alone on items of 2 rows x 32 pixels: it stages its own haloed 4 x 34 x 16ch
+//   * every wavefront then works alone on items of 4 rows x 16 pixels: it stages its own haloed 6 x 18 x 16ch
 //     region in a wave-private LDS buffer (global loads prefetched in registers during the previous item's MFMAs),
 //     runs 9 x 4 x CT x 4 MFMAs with weights and activations both read from LDS, and finishes the mixture mean in
 //     registers.  No barrier in steady state: the 8 wavefronts of a CU drift apart, so one wave's staging / epilogue
@@ -427,8 +427,8 @@ conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty, const int n
 // -----------------------------------------------------------------------------------------------------------
 template <int CT>
 struct HeadCfg {
-    static constexpr int RW = 34, RH = 4, CCP = 20;
-    static constexpr int REGION_FLOATS = RH * RW * CCP;                 // 2720 floats per wave
+    static constexpr int RW = 18, RH = 6, CCP = 20;        // item = 4 rows x 16 pixels (+ halo): 1.69x staged / output pixel
+    static constexpr int REGION_FLOATS = RH * RW * CCP;                 // 2160 floats per wave
     static constexpr int W_FLOAT4 = 9 * CT * 64;
     static constexpr int LDS_BYTES = W_FLOAT4 * 16 + 8 * REGION_FLOATS * 4;
     static constexpr int NS = (RH * RW * 4 + 63) / 64;                   // float4 slots per lane
@@ -445,14 +445,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
     float* reg = reinterpret_cast<float*>(smem4 + Cfg::W_FLOAT4) + wave * Cfg::REGION_FLOATS;
     const int j = lane & 15, q = lane >> 4;
     const int H = a.Hout, W = a.Wout, F = a.F;
-    const int ncb = W / 32, nrp = H / 2;
+    const int ncb = W / 16, nrp = H / 4;
 
     for (int i = tid; i < Cfg::W_FLOAT4; i += 512) wl[i] = reinterpret_cast<const float4*>(a.wpk)[i];
     __syncthreads();
 
     int pixoff[4];
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) pixoff[pt] = ((pt >> 1) * RW + (pt & 1) * 16 + j) * CCP + q * 4;
+    for (int pt = 0; pt < 4; ++pt) pixoff[pt] = (pt * RW + j) * CCP + q * 4;
     const gcpx_conv_src sr = a.src[0];
 
     const int gw = blockIdx.x * 8 + wave;
@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
     auto origin = [&](int it, int& f, int& y0, int& x0) {
         const int cb = it % ncb;
         const int t = it / ncb;
-        y0 = (t % nrp) * 2; f = t / nrp; x0 = cb * 32;
+        y0 = (t % nrp) * 4; f = t / nrp; x0 = cb * 16;
     };
     auto issue_loads = [&](int it) {
         int f, y0, x0;
@@ -505,29 +505,44 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
         // one (tap) step: 4 ds_read_b128 of activations + CT of weights, 4*4*CT MFMAs.  The first step starts the
         // accumulators from the inline constant 0 (no v_mov zero-fill: VALU issue slots are as scarce as MFMA slots,
         // f32 MFMA and VALU do not overlap on a SIMD).
+        // activations for the NEXT tap are fetched while the current tap's MFMAs run (the LDS round trip at every step
+        // boundary was an un-overlapped bubble whenever the partner wavefront was not in its MFMA phase)
+        float4 bnext[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) bnext[pt] = *reinterpret_cast<const float4*>(reg + pixoff[pt]);
         auto step = [&](const int tap, auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;
-            const int tapoff = ((tap / 3) * RW + (tap % 3)) * CCP;
             float4 b[4];
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) b[pt] = *reinterpret_cast<const float4*>(reg + pixoff[pt] + tapoff);
+            for (int pt = 0; pt < 4; ++pt) b[pt] = bnext[pt];
             const float4* wp = wl + tap * CT * 64 + lane;
+            float4 w[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) w[ct] = wp[ct * 64];
+            {   // tap + 1 (for tap == 8 this reads one row past the wave's region: in-range LDS, value unused)
+                const int t1 = tap + 1;
+                const int tapoff = ((t1 / 3) * RW + (t1 % 3)) * CCP;
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) bnext[pt] = *reinterpret_cast<const float4*>(reg + pixoff[pt] + tapoff);
+            }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const float4 w = wp[ct * 64];
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) {
-                    if constexpr (FIRST) acc[ct][pt] = mfma16(w.x, b[pt].x, f32x4{0, 0, 0, 0});
-                    else acc[ct][pt] = mfma16(w.x, b[pt].x, acc[ct][pt]);
-                    acc[ct][pt] = mfma16(w.y, b[pt].y, acc[ct][pt]);
-                    acc[ct][pt] = mfma16(w.z, b[pt].z, acc[ct][pt]);
-                    acc[ct][pt] = mfma16(w.w, b[pt].w, acc[ct][pt]);
+                    if constexpr (FIRST) acc[ct][pt] = mfma16(w[ct].x, b[pt].x, f32x4{0, 0, 0, 0});
+                    else acc[ct][pt] = mfma16(w[ct].x, b[pt].x, acc[ct][pt]);
+                    acc[ct][pt] = mfma16(w[ct].y, b[pt].y, acc[ct][pt]);
+                    acc[ct][pt] = mfma16(w[ct].z, b[pt].z, acc[ct][pt]);
+                    acc[ct][pt] = mfma16(w[ct].w, b[pt].w, acc[ct][pt]);
                 }
             }
         };
+        // the wavefront that is in its MFMA phase outranks its SIMD partner's staging / epilogue VALU work
+        __builtin_amdgcn_s_setprio(1);
         step(0, std::true_type{});
 #pragma unroll 1
         for (int tap = 1; tap < 9; ++tap) step(tap, std::false_type{});
+        __builtin_amdgcn_s_setprio(0);
 
         // ---- epilogue ----
 #pragma unroll
@@ -544,7 +559,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
         if ((mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) && orow >= 0) {
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
-                float* op = a.out + (((size_t)orow * H + (y0 + (pt >> 1))) * W + (x0 + (pt & 1) * 16 + j)) * a.out_pitch;
+                float* op = a.out + (((size_t)orow * H + (y0 + pt)) * W + (x0 + j)) * a.out_pitch;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const int c = ct * 16 + q * 4;
@@ -557,20 +572,34 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
         }
         if constexpr (CT >= 5) {
             if (mode == GCPX_HEAD_DLM_MEAN || mode == GCPX_HEAD_DLM_BOTH) {
-                // kernel channel order: slot 8k..8k+7 = {logit_k, mu_r, mu_g, mu_b, c0, c1, c2, pad}, k = 0..9;
-                // lanes with even q hold the first half of mixture 2*ct + q/2, lane+16 holds the second half.
+                // kernel channel order: slot 8k..8k+7 = {logit_k, mu_r, mu_g, mu_b, c0, c1, c2, pad}, k = 0..9: in tile ct the
+                // even 16-lane rows (q = 0, 2) hold the first half of mixtures 2ct, 2ct+1 and the odd rows (q = 1, 3) the
+                // coefficient half.  One v_permlane16_swap per register exchanges "my odd-row half of pixel group s" with
+                // "the partner's even-row half of pixel group s+2": afterwards EVERY lane owns both halves of one pixel —
+                // even rows pixel groups 0/1, odd rows pixel groups 2/3 — so the mixture math runs on all 64 lanes for two
+                // pixel groups instead of on 32 lanes for four.
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) {
+                for (int ct = 0; ct < 5; ++ct)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ct][s2][r]),
+                                                                             __float_as_uint(acc[ct][s2 + 2][r]), false, false);
+                            acc[ct][s2][r] = __uint_as_float(sw[0]);
+                            acc[ct][s2 + 2][r] = __uint_as_float(sw[1]);
+                        }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
                     float lg[5], mr[5], mg[5], mb[5];
 #pragma unroll
                     for (int ct = 0; ct < 5; ++ct) {
-                        const f32x4 v = acc[ct][pt];
-                        const float o0 = __shfl_xor(v[0], 16), o1 = __shfl_xor(v[1], 16), o2 = __shfl_xor(v[2], 16);
-                        const float c0 = fast_tanh(o0), c1 = fast_tanh(o1), c2 = fast_tanh(o2);
-                        lg[ct] = v[0];
-                        mr[ct] = v[1];
-                        mg[ct] = v[2] + c0 * mr[ct];
-                        mb[ct] = v[3] + c1 * mr[ct] + c2 * mg[ct];
+                        const f32x4 e = acc[ct][s2], o = acc[ct][s2 + 2];
+                        const float c0 = fast_tanh(o[0]), c1 = fast_tanh(o[1]), c2 = fast_tanh(o[2]);
+                        lg[ct] = e[0];
+                        mr[ct] = e[1];
+                        mg[ct] = e[2] + c0 * mr[ct];
+                        mb[ct] = e[3] + c1 * mr[ct] + c2 * mg[ct];
                     }
                     float m = lg[0];
 #pragma unroll
@@ -583,9 +612,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
                         S += w; Sr += w * mr[ct]; Sg += w * mg[ct]; Sb += w * mb[ct];
                     }
                     S += __shfl_xor(S, 32); Sr += __shfl_xor(Sr, 32); Sg += __shfl_xor(Sg, 32); Sb += __shfl_xor(Sb, 32);
-                    if (q == 0) {
+                    if (q < 2) {
+                        const int pt = s2 + 2 * q;        // q = 0: pixel groups 0, 1 ; q = 1: pixel groups 2, 3
                         const float inv = 1.f / S;
-                        float* ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + (pt >> 1)) * W + (x0 + (pt & 1) * 16 + j);
+                        float* ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + pt) * W + (x0 + j);
                         ip[0] = fminf(fmaxf(Sr * inv, -1.f), 1.f);
                         ip[plane] = fminf(fmaxf(Sg * inv, -1.f), 1.f);
                         ip[2 * plane] = fminf(fmaxf(Sb * inv, -1.f), 1.f);
@@ -597,7 +627,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
                 if (q == 0) {
-                    float* ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + (pt >> 1)) * W + (x0 + (pt & 1) * 16 + j);
+                    float* ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + pt) * W + (x0 + j);
                     ip[0] = tanhf(acc[0][pt][0]);
                     ip[plane] = tanhf(acc[0][pt][1]);
                     ip[2 * plane] = tanhf(acc[0][pt][2]);
@@ -621,7 +651,7 @@ int launch_head(const gcpx_conv_args* a, hipStream_t stream) {
         }
         attr_set = true;
     }
-    const int nitems = a->F * (a->Hout / 2) * (a->Wout / 32);
+    const int nitems = a->F * (a->Hout / 4) * (a->Wout / 16);
     int grid = gcpx_conv_grid() / 2;                     // one 512-thread workgroup per CU
     if (grid * 8 > nitems) grid = (nitems + 7) / 8;
     const int ipw = (nitems + grid * 8 - 1) / (grid * 8);
@@ -696,7 +726,7 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
     if (!a->upsample) {
         GCPX_CHECK_ARG(a->Cin == 16, "non-upsampling 3x3 conv (output head) expects 16 input channels");
         GCPX_CHECK_ARG(a->nsrc == 1 && a->src[0].frame_div == 1, "output head takes one per-frame source");
-        if (W % 32 == 0 && a->Hout % 2 == 0) {
+        if (W % 16 == 0 && a->Hout % 4 == 0) {
             if (CT == 7) return query_only ? gcpx_conv_grid() / 2 : launch_head<7>(a, stream);
             if (CT == 1) return query_only ? gcpx_conv_grid() / 2 : launch_head<1>(a, stream);
         }
