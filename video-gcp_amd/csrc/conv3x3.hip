@@ -267,6 +267,7 @@ conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty, const int n
             // Weights are double-buffered in registers one step ahead; the stream of steps is contiguous across
             // chunks and the packed buffer carries one zero step of padding, so the prefetch never branches.
             const float4* wp = wbase + (size_t)chunk * NSTEP * CT * 64;
+            __builtin_amdgcn_s_setprio(1);      // MFMA phase outranks the staging VALU of co-resident workgroups
 #ifdef GCPX_ABLATE_NOMFMA
             if (a.F < 0)
 #endif
@@ -297,6 +298,7 @@ conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty, const int n
                     }
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
         }
 
         // ---- epilogue ----
