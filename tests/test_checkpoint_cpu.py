@@ -1,0 +1,41 @@
+"""CPU: checkpoint format helpers (train.py:113-122, checkpoint_handler.py:31-74) with a stand-in model object."""
+import os
+
+import torch
+
+from video_gcp_amd import checkpoint as ck
+
+
+class _M:
+    def __init__(self):
+        self.sd = {"encoder.net.input.conv.weight": torch.randn(4, 3), "cost_mdl.cost_pred.head.linear.bias": torch.randn(1)}
+
+    def state_dict(self):
+        return dict(self.sd)
+
+    def load_state_dict(self, sd, strict=True):
+        for k, v in sd.items():
+            if k in self.sd:
+                self.sd[k] = v.clone()
+            elif strict:
+                raise KeyError(k)
+
+
+def test_roundtrip_and_prefix_filter(tmp_path):
+    a = _M()
+    for ep in (0, 3, 12):
+        ck.save_checkpoint(a, str(tmp_path), ep, global_step=10 * ep)
+    latest = ck.get_resume_ckpt_file("latest", str(tmp_path))
+    assert os.path.basename(latest) == "weights_ep12.pth"
+    assert os.path.basename(ck.get_resume_ckpt_file(3, str(tmp_path))) == "weights_ep3.pth"
+    raw = torch.load(latest)
+    assert set(raw) == {"epoch", "global_step", "state_dict", "optimizer"}
+    b = _M()
+    step, ep, _ = ck.load_weights(latest, b)
+    assert (step, ep) == (120, 12)
+    assert all(torch.equal(a.sd[k], b.sd[k]) for k in a.sd)
+    c = _M()
+    before = c.sd["encoder.net.input.conv.weight"].clone()
+    ck.load_weights(latest, c, submodule_name="cost_mdl")
+    assert torch.equal(c.sd["cost_mdl.cost_pred.head.linear.bias"], a.sd["cost_mdl.cost_pred.head.linear.bias"])
+    assert torch.equal(c.sd["encoder.net.input.conv.weight"], before)

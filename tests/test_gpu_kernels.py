@@ -198,7 +198,7 @@ def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes):
     cin = c_prev + c_skip
     w, b = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.randn(cout) * 0.1
     want = F.conv2d(F.interpolate(torch.cat(srcs_ref, 1), scale_factor=2, mode="bilinear", align_corners=False), w, b, padding=1)
-    wp, bd = pk.pack_conv3x3(w, 32).to(dev), pk.pad_vec(b, cout).to(dev)
+    wp, bd = pk.pack_conv3x3(w, 16 if cout == 16 else 32).to(dev), pk.pad_vec(b, cout).to(dev)
     out = torch.full((Fr, 2 * Hin, 2 * Hin, cout), float("nan"), device=dev)
     a = _conv_args(rt, srcs, F=Fr, Hin=Hin, Win=Hin, Hout=2 * Hin, Wout=2 * Hin, Cout=cout, out_pitch=cout, upsample=1,
                    head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out, stats_partial=out)

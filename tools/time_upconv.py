@@ -17,7 +17,7 @@ def run(name, Fr, Hin, c_prev, c_skip, cout, nodes):
         n = 2
     cin = c_prev + c_skip
     w = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5
-    wp, b = pk.pack_conv3x3(w, 32).to(dev), torch.zeros((cout + 15) // 16 * 16, device=dev)
+    wp, b = pk.pack_conv3x3(w, 16 if cout == 16 else 32).to(dev), torch.zeros((cout + 15) // 16 * 16, device=dev)
     out = torch.empty(Fr, 2 * Hin, 2 * Hin, cout, device=dev)
     a.nsrc, a.F, a.Hin, a.Win, a.Hout, a.Wout, a.Cin, a.Cout, a.out_pitch, a.upsample = n, Fr, Hin, Hin, 2 * Hin, 2 * Hin, cin, cout, cout, 1
     a.wpk, a.bias, a.out, a.stats_partial = wp.data_ptr(), b.data_ptr(), out.data_ptr(), out.data_ptr()

@@ -429,8 +429,9 @@ conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty, const int n
 // -----------------------------------------------------------------------------------------------------------
 template <int CT>
 struct HeadCfg {
-    static constexpr int RW = 18, RH = 6, CCP = 20;        // item = 4 rows x 16 pixels (+ halo): 1.69x staged / output pixel
-    static constexpr int REGION_FLOATS = RH * RW * CCP;                 // 2160 floats per wave
+    static constexpr int RW = 18, RH = 6, CCP = 24;        // item = 4 rows x 16 pixels (+ halo): 1.69x staged / output pixel;
+                                                             // pitch 24 floats: conflict-free ds_read_b128 of the B operand
+    static constexpr int REGION_FLOATS = RH * RW * CCP;                 // 2592 floats per wave
     static constexpr int W_FLOAT4 = 9 * CT * 64;
     static constexpr int LDS_BYTES = W_FLOAT4 * 16 + 8 * REGION_FLOATS * 4;
     static constexpr int NS = (RH * RW * 4 + 63) / 64;                   // float4 slots per lane
@@ -443,7 +444,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
     constexpr int RW = Cfg::RW, RH = Cfg::RH, CCP = Cfg::CCP, NS = Cfg::NS;
     extern __shared__ float4 smem4[];
     float4* wl = smem4;                                                   // [9][CT][64] float4
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-level indices in SGPRs (SALU, not VALU)
     float* reg = reinterpret_cast<float*>(smem4 + Cfg::W_FLOAT4) + wave * Cfg::REGION_FLOATS;
     const int j = lane & 15, q = lane >> 4;
     const int H = a.Hout, W = a.Wout, F = a.F;
@@ -468,19 +470,25 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
         const int t = it / ncb;
         y0 = (t % nrp) * 4; f = t / nrp; x0 = cb * 16;
     };
+    int s_ry[NS], s_rx[NS];                               // staging slot -> (row, col) of the region, tile independent
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int t = (lane + 64 * k) >> 2;
+        s_rx[k] = t % RW;
+        s_ry[k] = t / RW;
+    }
     auto issue_loads = [&](int it) {
         int f, y0, x0;
         origin(it, f, y0, x0);
         pre_ok = 0;
+        const float* base = sr.ptr + (size_t)f * H * W * 16;                  // wave-uniform (scalar)
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int idx = lane + 64 * k;
-            const int c4 = idx & 3, t = idx >> 2;
-            const int rx = t % RW, ry = t / RW;
-            const int sy = y0 - 1 + ry, sx = x0 - 1 + rx;
+            const int sy = y0 - 1 + s_ry[k], sx = x0 - 1 + s_rx[k];
             if (idx < RH * RW * 4 && sy >= 0 && sy < H && sx >= 0 && sx < W) {
-                pre[k] = *reinterpret_cast<const float4*>(sr.ptr + (((size_t)f * H + sy) * W + sx) * 16 + c4 * 4);
+                pre[k] = *reinterpret_cast<const float4*>(base + (unsigned)((__umul24(sy, W) + sx) * 16 + (idx & 3) * 4));
                 pre_ok |= 1u << k;
             }
         }
@@ -662,6 +670,224 @@ int launch_head(const gcpx_conv_args* a, hipStream_t stream) {
     return GCPX_OK;
 }
 
+// -----------------------------------------------------------------------------------------------------------
+// Decoder blocks with 16 output channels (additional_conv_layer, pyramid-0): wave-autonomous variant of the
+// upsample + concat + BN/LReLU-on-load + 3x3 conv.  Same idea as the head kernel: one 512-thread workgroup per CU
+// holds the packed weights in LDS; every wavefront owns items of 4 rows x 16 output pixels, stages the 4 x 10
+// low-res patch (16 channels per chunk) and its bilinear 6 x 18 up-sampling in wave-private LDS, and runs
+// 9 x 4 x 4 MFMAs per chunk.  No workgroup barrier in steady state.
+// -----------------------------------------------------------------------------------------------------------
+struct UpWaveCfg {
+    static constexpr int RW = 18, RH = 6, LW = 10, LH = 4, CC = 16, CCP = 24;   // pitch 24: conflict-free B-operand reads
+    static constexpr int RAW_FLOATS = LH * LW * CC;          // 640
+    static constexpr int HI_FLOATS = RH * RW * CCP;          // 2592
+    static constexpr int WAVE_FLOATS = RAW_FLOATS + HI_FLOATS;
+    static constexpr int NS = (LH * LW * 4 + 63) / 64;       // raw float4 slots per lane (3)
+    static int lds_bytes(int nchunk) { return nchunk * 9 * 64 * 16 + 8 * WAVE_FLOATS * 4 + 8 * 2 * 16 * 4; }
+};
+
+__global__ void __launch_bounds__(512, 2) conv3x3_up16_kernel(const gcpx_conv_args a, const int items_per_wave,
+                                                              const int nitems) {
+    using Cfg = UpWaveCfg;
+    constexpr int RW = Cfg::RW, RH = Cfg::RH, LW = Cfg::LW, LH = Cfg::LH, CC = Cfg::CC, CCP = Cfg::CCP, NS = Cfg::NS;
+    extern __shared__ float4 smem4[];
+    const int nchunk = a.Cin / CC;
+    float4* wl = smem4;                                                       // [nchunk][9][64] float4
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-level indices live in SGPRs: item decode / pointer bases then cost SALU, not VALU, issue slots
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* wbuf = reinterpret_cast<float*>(smem4 + nchunk * 9 * 64) + wave * Cfg::WAVE_FLOATS;
+    float* raw = wbuf;
+    float* hi = wbuf + Cfg::RAW_FLOATS;
+    float* red = reinterpret_cast<float*>(smem4 + nchunk * 9 * 64) + 8 * Cfg::WAVE_FLOATS;   // [8 waves][2][16]
+    const int j = lane & 15, q = lane >> 4;
+    const int H = a.Hout, W = a.Wout, F = a.F, Hin = a.Hin, Win = a.Win;
+    const int ncb = W / 16, nrq = H / 4;
+
+    for (int i = tid; i < nchunk * 9 * 64; i += 512) wl[i] = reinterpret_cast<const float4*>(a.wpk)[i];
+    __syncthreads();
+
+    int pixoff[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) pixoff[pt] = (pt * RW + j) * CCP + q * 4;
+    const int c0 = a.src[0].C;
+
+    const int gw = blockIdx.x * 8 + wave;
+    int item = gw * items_per_wave;
+    const int item_end = min(item + items_per_wave, nitems);
+
+    auto origin = [&](int it, int& f, int& y0, int& x0) {
+        const int cb = it % ncb;
+        const int t = it / ncb;
+        y0 = (t % nrq) * 4; f = t / nrq; x0 = cb * 16;
+    };
+    // raw-patch slot k of this lane: float4 index lane + 64k -> (row, col, 4-channel group); tile independent
+    int s_ry[NS], s_rx[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int t = (lane + 64 * k) >> 2;
+        s_rx[k] = t % LW;
+        s_ry[k] = t / LW;
+    }
+    float4 pre[NS];
+    auto issue_loads = [&](int it, int chunk) {
+        int f, y0, x0;
+        origin(it, f, y0, x0);
+        const int cg = chunk * CC;
+        const bool first = cg < c0;
+        const gcpx_conv_src& sr = first ? a.src[0] : a.src[1];
+        const int cl = first ? cg : cg - c0;
+        const int srcC = sr.C;
+        const float* base = sr.ptr + (size_t)(f / sr.frame_div) * Hin * Win * srcC + cl;     // wave-uniform (scalar)
+        const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int idx = lane + 64 * k;
+            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < LH * LW * 4) {
+                const int sy = min(max(ly0 + s_ry[k], 0), Hin - 1);          // replicate clamp (bilinear border rule)
+                const int sx = min(max(lx0 + s_rx[k], 0), Win - 1);
+                const unsigned off = __umul24(__umul24(sy, Win) + sx, srcC) + (idx & 3) * 4;
+                pre[k] = *reinterpret_cast<const float4*>(base + off);
+            }
+        }
+    };
+
+    f32x4 st1 = f32x4{0, 0, 0, 0}, st2 = f32x4{0, 0, 0, 0};
+    if (item < item_end) issue_loads(item, 0);
+
+    for (; item < item_end; ++item) {
+        int f, y0, x0;
+        origin(item, f, y0, x0);
+        f32x4 acc[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) acc[pt] = f32x4{0, 0, 0, 0};
+        const bool top = (y0 == 0), bot = (y0 + 4 == H), lft = (x0 == 0), rgt = (x0 + 16 == W);
+
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            // ---- registers -> raw patch (BatchNorm affine + LeakyReLU of the producer applied here) ----
+            {
+                const int cg = chunk * CC;
+                const bool first = cg < c0;
+                const gcpx_conv_src& sr = first ? a.src[0] : a.src[1];
+                const int cl = first ? cg : cg - c0;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int idx = lane + 64 * k;
+                    if (idx < LH * LW * 4)
+                        *reinterpret_cast<float4*>(raw + idx * 4) = affine_act4(pre[k], sr.scale, sr.shift, cl + (idx & 3) * 4, sr.act);
+                }
+            }
+            // next stage's loads go out now
+            if (chunk + 1 < nchunk) issue_loads(item, chunk + 1);
+            else if (item + 1 < item_end) issue_loads(item + 1, 0);
+            // ---- bilinear x2 into the haloed 6 x 18 region (see conv3x3_kernel for the index algebra) ----
+            {
+                const int c4 = lane & 3, p = lane >> 2;                      // 16 columns per pass
+                auto lerp_store = [&](int ry, int cx, bool zero) {
+                    const float wx1 = (cx & 1) ? 0.75f : 0.25f, wx0 = 1.f - wx1;
+                    const float wy1 = (ry & 1) ? 0.75f : 0.25f, wy0 = 1.f - wy1;
+                    const float* r = raw + (((ry >> 1) * LW + (cx >> 1)) * CC + c4 * 4);
+                    const float4 a00 = *reinterpret_cast<const float4*>(r);
+                    const float4 a01 = *reinterpret_cast<const float4*>(r + CC);
+                    const float4 a10 = *reinterpret_cast<const float4*>(r + LW * CC);
+                    const float4 a11 = *reinterpret_cast<const float4*>(r + LW * CC + CC);
+                    float4 v;
+                    v.x = wy0 * (wx0 * a00.x + wx1 * a01.x) + wy1 * (wx0 * a10.x + wx1 * a11.x);
+                    v.y = wy0 * (wx0 * a00.y + wx1 * a01.y) + wy1 * (wx0 * a10.y + wx1 * a11.y);
+                    v.z = wy0 * (wx0 * a00.z + wx1 * a01.z) + wy1 * (wx0 * a10.z + wx1 * a11.z);
+                    v.w = wy0 * (wx0 * a00.w + wx1 * a01.w) + wy1 * (wx0 * a10.w + wx1 * a11.w);
+                    if (zero) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(hi + (ry * RW + cx) * CCP + c4 * 4) = v;
+                };
+#ifndef GCPX_ABLATE_NOUPSAMPLE
+#pragma unroll
+                for (int ry = 0; ry < RH; ++ry)
+                    lerp_store(ry, p + 1, (top && ry == 0) || (bot && ry == RH - 1));
+#endif
+                if (p < 12) {                                               // the two halo columns: 6 rows x 2 sides
+                    const int ry = p >> 1, side = p & 1;
+                    lerp_store(ry, side ? RW - 1 : 0,
+                               (top && ry == 0) || (bot && ry == RH - 1) || (lft && side == 0) || (rgt && side == 1));
+                }
+            }
+            // ---- MFMAs: 9 taps x 4 pixel groups x 4 k-steps ----
+            const float4* wp = wl + chunk * 9 * 64 + lane;
+            __builtin_amdgcn_s_setprio(1);
+#ifdef GCPX_ABLATE_NOMFMA
+            if (a.F < 0)
+#endif
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int tapoff = ((tap / 3) * RW + (tap % 3)) * CCP;
+                const float4 w = wp[tap * 64];
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    const float4 b = *reinterpret_cast<const float4*>(hi + pixoff[pt] + tapoff);
+                    acc[pt] = mfma16(w.x, b.x, acc[pt]);
+                    acc[pt] = mfma16(w.y, b.y, acc[pt]);
+                    acc[pt] = mfma16(w.z, b.z, acc[pt]);
+                    acc[pt] = mfma16(w.w, b.w, acc[pt]);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // ---- epilogue: bias, raw NHWC store, BatchNorm partial sums ----
+        const float4 bv = *reinterpret_cast<const float4*>(a.bias + q * 4);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            f32x4 v = acc[pt];
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            float* obase = a.out + ((size_t)f * H + y0) * W * 16;                     // wave-uniform
+            *reinterpret_cast<float4*>(obase + (unsigned)((pt * W + x0 + j) * 16 + q * 4)) = make_float4(v[0], v[1], v[2], v[3]);
+            st1 += v;
+            st2 += v * v;
+        }
+    }
+    if (a.stats_partial) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s1 = row16_sum(st1[r]);
+            const float s2 = row16_sum(st2[r]);
+            if (j == 0) {
+                red[(wave * 2 + 0) * 16 + q * 4 + r] = s1;
+                red[(wave * 2 + 1) * 16 + q * 4 + r] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int which = tid >> 4, c = tid & 15;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += red[(w * 2 + which) * 16 + c];
+            a.stats_partial[((size_t)blockIdx.x * 2 + which) * 16 + c] = sum;
+        }
+    }
+}
+
+int launch_up16(const gcpx_conv_args* a, hipStream_t stream, bool query_only) {
+    const int nchunk = a->Cin / 16;
+    const int lds = UpWaveCfg::lds_bytes(nchunk);
+    int grid = gcpx_conv_grid() / 2;                      // one 512-thread workgroup per CU
+    const int nitems = a->F * (a->Hout / 4) * (a->Wout / 16);
+    if (!a->stats_partial && grid * 8 > nitems) grid = (nitems + 7) / 8;
+    if (query_only) return grid;
+    static int lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_up16_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            gcpx_set_error("conv3x3 up16: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
+        lds_set = lds;
+    }
+    const int ipw = (nitems + grid * 8 - 1) / (grid * 8);
+    hipLaunchKernelGGL(conv3x3_up16_kernel, dim3(grid), dim3(512), lds, stream, *a, ipw, nitems);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
 int g_conv_grid = 0;
 
 template <bool UP, int CC, int CT, int TILE>
@@ -735,8 +961,12 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
     } else {
         GCPX_CHECK_ARG(a->Cin % 32 == 0, "upsampling 3x3 conv expects Cin % 32 == 0");
         GCPX_CHECK_ARG(a->head_mode == GCPX_HEAD_RAW, "decoder blocks store raw output");
-        if (W % 32 == 0 && CT == 1) return launch<true, 32, 1, 3>(a, stream, query_only);
-        if (W == 16 && CT == 1) return launch<true, 32, 1, 1>(a, stream, query_only);
+        // 16-output-channel blocks: wave-autonomous kernel; its weights are packed in 16-channel chunks
+        // (packing.pack_conv3x3(w, 16)), every other block in 32-channel chunks
+        if (a->Cout == 16) {
+            GCPX_CHECK_ARG(W % 16 == 0 && a->Hout % 4 == 0 && a->out_pitch == 16 && a->Cin <= 64, "16-channel block shape");
+            return launch_up16(a, stream, query_only);
+        }
         if (W == 16 && CT == 2) return launch<true, 32, 2, 1>(a, stream, query_only);
         if (W == 8 && CT == 2) return launch<true, 32, 2, 2>(a, stream, query_only);
         if (W == 8 && CT == 4) return launch<true, 32, 4, 2>(a, stream, query_only);

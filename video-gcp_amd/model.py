@@ -187,7 +187,8 @@ class GCPTreeModel:
         P["dec.input.w"] = pk.pack_gemm(wt.permute(2, 3, 1, 0).reshape(16 * c_top, hp.nz_enc))
         P["dec.input.b"] = sd["decoder.net.input.conv.bias"].repeat(16).contiguous()
         for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
-            P[f"dec.{name}.w"] = pk.pack_conv3x3(sd[f"decoder.net.{name}.conv.weight"], 32)
+            # 16-output-channel blocks run the wave-autonomous kernel, which walks the input in 16-channel chunks
+            P[f"dec.{name}.w"] = pk.pack_conv3x3(sd[f"decoder.net.{name}.conv.weight"], 16 if cout == 16 else 32)
             P[f"dec.{name}.b"] = pk.pad_vec(sd[f"decoder.net.{name}.conv.bias"], (cout + 15) // 16 * 16)
         hw, hb = sd["decoder.gen_head.conv.weight"], sd["decoder.gen_head.conv.bias"]
         if hp.decoder_distribution == "discrete_logistic_mixture":
