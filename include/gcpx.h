@@ -230,6 +230,19 @@ int gcpx_gather_rows(const float* src, const int32_t* idx, float* out, int32_t B
 int gcpx_seq_pairs(const float* lat, const int32_t* lengths, const float* goal, float* nxt, int32_t n, int32_t T,
                    int32_t nz, void* stream);
 int gcpx_masked_row_sum(const float* vals, const int32_t* lengths, float* out, int32_t n, int32_t T, void* stream);
+/* dst[b][r] = src[b][r] for r < rows, rows of row_floats floats, independent batch strides (in rows): assembling
+   images = cat(I_0, decoded) of the sequential model (sequential.py:57) without a torch.cat */
+int gcpx_copy_rows(const float* src, float* dst, int32_t B, int32_t rows, int64_t row_floats, int64_t src_batch_rows,
+                   int64_t dst_batch_rows, void* stream);
+/* Gaussian.sample() for a recurrent cell's [mu | log_sigma] rows: z = mu + exp(log_sigma) * eps, rows r = (b, j) at
+   base + b*{m,e,z}b + j*{m,e,z}r  (VRNN step of sequential.py:51-54) */
+int gcpx_gauss_sample(const float* muls, int64_t mb, int64_t mr, const float* eps, int64_t eb, int64_t er, float* z,
+                      int64_t zb, int64_t zr, int32_t M, int32_t rpb, int32_t nz, void* stream);
+/* idx[b][t] = t (t <= end_ind[b]) else -1; seq_len[b] = end_ind[b] + 1: prefix selection of the sequential model
+   (sequential.py:88-93,130-131) in the same form as gcpx_compact_index */
+int gcpx_seq_index(const int64_t* end_ind, int32_t B, int32_t T, int32_t* idx, int32_t* seq_len, void* stream);
+/* graph-capturable memset(0) (recurrent state reset, lstm_init='zero') */
+int gcpx_fill_zero(void* ptr, int64_t nbytes, void* stream);
 /* compaction of kept nodes: dst_idx[b][k] = k-th depth-first position with leave==1 (k < seq_len[b]), else -1 */
 int gcpx_compact_index(const int32_t* leave, int32_t B, int32_t N, int32_t T, int32_t* dst_idx, void* stream);
 
@@ -268,7 +281,8 @@ int gcpx_dlm_nll(const float* params, const float* target, const float* row_weig
 int gcpx_gauss_nll(const float* mu, const float* target, const float* log_sigma, float* nll_out, int32_t rows,
                    int32_t nelem, void* stream);
 int gcpx_kl_gauss(const float* qz, const float* pz, int32_t B, int32_t N, int32_t nz, int64_t batch_stride,
-                  int64_t node_stride, float free_nats, float* kl_out, void* stream);
+                  int64_t node_stride, float free_nats, const float* node_weight /* b*weight_bstride + n, or NULL */,
+                  int64_t weight_bstride, float* kl_out, void* stream);
 int gcpx_loss_combine(const gcpx_loss_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------

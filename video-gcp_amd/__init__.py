@@ -5,4 +5,4 @@ for gfx950 behind a C-ABI shared library (include/gcpx.h), loaded with ctypes.  
 device memory, streams and torch.distributed.
 """
 from .hparams import GCPHParams, config  # noqa: F401
-from .params import param_table, init_params, n_parameters  # noqa: F401
+from .params import param_table, init_params, n_parameters, param_table_sequential, init_params_sequential  # noqa: F401

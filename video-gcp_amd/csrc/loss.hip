@@ -119,7 +119,8 @@ __global__ void __launch_bounds__(256) gauss_nll_kernel(const float* __restrict_
 // analytic KL(q || p) of diagonal Gaussians, clamped below at free_nats per dimension, summed per batch element
 __global__ void __launch_bounds__(256) kl_kernel(const float* __restrict__ qz, const float* __restrict__ pz, const int N,
                                                  const int nz, const long long batch_stride, const long long node_stride,
-                                                 const float free_nats, float* __restrict__ kl_out) {
+                                                 const float free_nats, const float* __restrict__ node_weight,
+                                                 const long long weight_bstride, float* __restrict__ kl_out) {
     __shared__ float red[256];
     const int b = blockIdx.x;
     float acc = 0.f;
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(256) kl_kernel(const float* __restrict__ qz, c
         const float mq = q[d], lq = q[nz + d], mp = p[d], lp = p[nz + d];
         const float diff = mq - mp;
         const float kl = lp - lq + (expf(2.f * lq) + diff * diff) / (2.f * expf(2.f * lp)) - 0.5f;
-        acc += fmaxf(kl, free_nats);
+        acc += fmaxf(kl, free_nats) * (node_weight ? node_weight[(size_t)b * weight_bstride + n] : 1.f);
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -242,11 +243,12 @@ extern "C" int gcpx_gauss_nll(const float* mu, const float* target, const float*
 }
 
 extern "C" int gcpx_kl_gauss(const float* qz, const float* pz, int32_t B, int32_t N, int32_t nz, int64_t batch_stride,
-                             int64_t node_stride, float free_nats, float* kl_out, void* stream_) {
+                             int64_t node_stride, float free_nats, const float* node_weight, int64_t weight_bstride,
+                             float* kl_out, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(qz && pz && kl_out && B > 0 && N > 0 && nz > 0, "null pointer / bad sizes");
     hipLaunchKernelGGL(kl_kernel, dim3(B), dim3(256), 0, stream, qz, pz, N, nz, (long long)batch_stride,
-                       (long long)node_stride, free_nats, kl_out);
+                       (long long)node_stride, free_nats, node_weight, (long long)weight_bstride, kl_out);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -166,6 +166,39 @@ __global__ void seq_pairs_kernel(const float* __restrict__ lat, const int32_t* _
     for (int k = threadIdx.x; k < nz4; k += blockDim.x) dst[k] = src[k];
 }
 
+__global__ void __launch_bounds__(256) copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                        const int rows, const long long row4, const long long sbr,
+                                                        const long long dbr) {
+    const int b = blockIdx.x / rows, r = blockIdx.x % rows;
+    const float4* s = reinterpret_cast<const float4*>(src) + ((size_t)b * sbr + r) * row4;
+    float4* d = reinterpret_cast<float4*>(dst) + ((size_t)b * dbr + r) * row4;
+    for (long long k = threadIdx.x; k < row4; k += blockDim.x) d[k] = s[k];
+}
+
+// z[r] = mu[r] + exp(log_sigma[r]) * eps[r] for rows r = (b, j) with independent row maps (Gaussian.sample)
+__global__ void gauss_sample_kernel(const float* __restrict__ muls, const long long mb, const long long mr,
+                                    const float* __restrict__ eps, const long long eb, const long long er,
+                                    float* __restrict__ z, const long long zb, const long long zr, const int M,
+                                    const int rpb, const int nz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * nz) return;
+    const int r = i / nz, d = i % nz;
+    const int b = r / rpb, j = r % rpb;
+    const float* m = muls + (size_t)b * mb + (size_t)j * mr;
+    z[(size_t)b * zb + (size_t)j * zr + d] = m[d] + expf(m[nz + d]) * eps[(size_t)b * eb + (size_t)j * er + d];
+}
+
+// idx[b][t] = t for t <= end_ind[b], -1 after (pad_sequence of a prefix), seq_len[b] = end_ind[b] + 1
+__global__ void seq_index_kernel(const int64_t* __restrict__ end_ind, const int B, const int T, int32_t* __restrict__ idx,
+                                 int32_t* __restrict__ seq_len) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    const int b = i / T, t = i % T;
+    const long long e = end_ind[b];
+    idx[i] = (t <= e) ? t : -1;
+    if (t == 0) seq_len[b] = (int32_t)(e + 1);
+}
+
 __global__ void masked_row_sum_kernel(const float* __restrict__ vals, const int32_t* __restrict__ lengths,
                                       float* __restrict__ out, const int n, const int T) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,6 +217,44 @@ extern "C" int gcpx_seq_pairs(const float* lat, const int32_t* lengths, const fl
     GCPX_CHECK_ARG(lat && lengths && nxt && n > 0 && T > 0 && nz > 0 && nz % 4 == 0, "null pointer / bad sizes");
     hipLaunchKernelGGL(seq_pairs_kernel, dim3(n * T), dim3(64), 0, stream, lat, lengths, goal, nxt, T, nz / 4);
     GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_copy_rows(const float* src, float* dst, int32_t B, int32_t rows, int64_t row_floats,
+                              int64_t src_batch_rows, int64_t dst_batch_rows, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(src && dst && B > 0 && rows > 0 && row_floats > 0 && row_floats % 4 == 0, "null pointer / bad sizes");
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(B * rows), dim3(256), 0, stream, src, dst, rows, (long long)(row_floats / 4),
+                       (long long)src_batch_rows, (long long)dst_batch_rows);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_gauss_sample(const float* muls, int64_t mb, int64_t mr, const float* eps, int64_t eb, int64_t er,
+                                 float* z, int64_t zb, int64_t zr, int32_t M, int32_t rpb, int32_t nz, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(muls && eps && z && M > 0 && rpb > 0 && nz > 0, "null pointer / bad sizes");
+    hipLaunchKernelGGL(gauss_sample_kernel, dim3((M * nz + 255) / 256), dim3(256), 0, stream, muls, (long long)mb,
+                       (long long)mr, eps, (long long)eb, (long long)er, z, (long long)zb, (long long)zr, M, rpb, nz);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_seq_index(const int64_t* end_ind, int32_t B, int32_t T, int32_t* idx, int32_t* seq_len, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(end_ind && idx && seq_len && B > 0 && T > 0, "null pointer / bad sizes");
+    hipLaunchKernelGGL(seq_index_kernel, dim3((B * T + 255) / 256), dim3(256), 0, stream, end_ind, B, T, idx, seq_len);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_fill_zero(void* ptr, int64_t nbytes, void* stream_) {
+    GCPX_CHECK_ARG(ptr && nbytes > 0, "null pointer / bad size");
+    hipError_t e = hipMemsetAsync(ptr, 0, (size_t)nbytes, reinterpret_cast<hipStream_t>(stream_));
+    if (e != hipSuccess) {
+        gcpx_set_error("gcpx_fill_zero: %s", hipGetErrorString(e));
+        return GCPX_ERR_HIP;
+    }
     return GCPX_OK;
 }
 

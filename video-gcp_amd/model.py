@@ -92,8 +92,8 @@ class GCPTreeModel:
         self._hp = hp
         self.device = torch.device(device)
         self.lib = rt.load_library()          # raises if the HIP extension is missing
-        assert hp.matching_type == "balanced" and hp.tree_lstm == "split_linear" and hp.lstm_init == "mlp"
-        self.sd = {k: v.to(self.device) for k, v in (params or init_params(hp, seed)).items()}
+        self._check_hp(hp)
+        self.sd = {k: v.to(self.device) for k, v in (params or self._default_params(hp, seed)).items()}
         self.training = True                  # BatchNorm uses batch statistics (reference trains and validates so)
         self._sample_prior = False            # ProbabilisticModel._sample_prior (switched by val_mode)
         self._use_pred_length = False
@@ -113,6 +113,15 @@ class GCPTreeModel:
         self._timed_op = None                 # name of one plan op bracketed by HIP events (bench.py roofline)
         self._timed_events = []
         self._pack_all()
+
+    def _check_hp(self, hp):
+        assert hp.matching_type == "balanced" and hp.tree_lstm == "split_linear" and hp.lstm_init == "mlp"
+
+    def _n_latents(self):
+        return self._hp.n_nodes
+
+    def _default_params(self, hp, seed):
+        return init_params(hp, seed)
 
     # ------------------------------------------------------------------------------------------------
     # reference API surface
@@ -216,6 +225,24 @@ class GCPTreeModel:
             P["inv_mdl"] = self._pack_predictor("inv_mdl.action_pred", hp.n_actions)
         if hp.attach_cost_mdl:
             P["cost_mdl"] = self._pack_predictor("cost_mdl.cost_pred", 1)
+        self._pack_latent_model(P)
+        self.pk = P
+
+    def _pack_hsp(self, prefix, n_layers):
+        """embed Linear + n gate-interleaved LSTM layers + out Linear of one recurrent predictor."""
+        sd, T = self.sd, {}
+        T["embed.w"] = pk.pack_gemm(sd[f"{prefix}.embed.weight"])
+        T["embed.b"] = sd[f"{prefix}.embed.bias"].contiguous()
+        for i in range(n_layers):
+            w, b = pk.lstm_gate_interleave(sd[f"{prefix}.lstm.{i}.weight_ih"], sd[f"{prefix}.lstm.{i}.weight_hh"],
+                                           sd[f"{prefix}.lstm.{i}.bias_ih"], sd[f"{prefix}.lstm.{i}.bias_hh"])
+            T[f"lstm{i}.w"], T[f"lstm{i}.b"] = pk.pack_gemm(w), b
+        T["out.w"] = pk.pack_gemm(sd[f"{prefix}.out.weight"])
+        T["out.b"] = sd[f"{prefix}.out.bias"].contiguous()
+        return T
+
+    def _pack_latent_model(self, P):
+        hp, sd = self._hp, self.sd
         P["existence"] = self._pack_predictor("tree_module.tree_modules.0.binding.existence_predictor", 1)
         H = hp.nz_mid_lstm
         for l in range(hp.hierarchy_levels if hp.untied_layers else 1):
@@ -237,7 +264,6 @@ class GCPTreeModel:
             if l == 0:
                 T["init"] = self._pack_predictor(f"{p}.lstm_initializer.net", 2 * hp.lstm_state_dim)
             P[f"tree{l}"] = T
-        self.pk = P
 
     # ------------------------------------------------------------------------------------------------
     # buffers and plan-building helpers
@@ -369,6 +395,42 @@ class GCPTreeModel:
         self._gemm(plan, f"enc.head:{tag}", [src], F, hp.nz_enc, out_rpb, P["enc.head.w"], P["enc.head.b"],
                    out=out_ptr, ob=out_ob, orow=out_orow)
         return skips
+
+    def _plan_decoder_features(self, plan, e_src, F, rpb, skips):
+        """ConvDecoder up to (not including) the output head over F latents given by the row source `e_src` (rows are
+        (b, j), j < rpb); the skip activations of I_0 are broadcast over the rpb frames of a sequence.  Returns the head's
+        input source tuple (raw 16-channel features + their BatchNorm affine)."""
+        hp, P, lib = self._hp, self.pk, self.lib
+        ctop = self._c_top
+        d0 = self._buf("dec.d0", (F, 4, 4, ctop))
+        nrb = lib.gcpx_gemm_row_blocks(F, 16 * ctop)
+        st = self._buf("dec.st0", (nrb, 2, 16 * ctop)) if self.training else None
+        self._gemm(plan, "dec.input", [e_src], F, 16 * ctop, rpb, P["dec.input.w"], P["dec.input.b"], out=d0.data_ptr(),
+                   ob=rpb * 16 * ctop, orow=16 * ctop, stats=st)
+        sc, sh = self._bn(plan, "dec.bn0", "decoder.net.input.norm", ctop, st, nrb, 16 * ctop, F * 16)
+        prev = (d0.data_ptr(), ctop, 1, sc, sh, rt.ACT_LRELU)
+        res = 4
+        for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
+            srcs = [prev]
+            if skip_idx >= 0:
+                t, C_, ssc, ssh, sact = skips[skip_idx]
+                assert C_ == c_skip and t.shape[1] == res
+                srcs.append((t.data_ptr(), C_, rpb, ssc, ssh, sact))    # skips of I_0 broadcast over the sequence's frames
+            o = self._buf(f"dec.{name}", (F, 2 * res, 2 * res, cout))
+            cpad = (cout + 15) // 16 * 16
+            a = self._conv_args(srcs, F, res, res, 2 * res, 2 * res, cout, cout, P[f"dec.{name}.w"], P[f"dec.{name}.b"],
+                                o, upsample=1, stats=(o if self.training else None))     # placeholder pointer for the query
+            Gl = lib.gcpx_conv3x3_grid(C.byref(a))
+            assert Gl > 0, rt.lib().gcpx_last_error()
+            st = self._buf(f"dec.st.{name}", (Gl, 2, cpad)) if self.training else None
+            a.stats_partial = st.data_ptr() if st is not None else None
+            plan.keep.append(a)
+            plan.add(f"dec.{name}", lib.gcpx_conv3x3, C.byref(a))
+            res *= 2
+            sc, sh = self._bn(plan, f"dec.bn.{name}", f"decoder.net.{name}.norm", cout, st, Gl, cpad, F * res * res)
+            prev = (o.data_ptr(), cout, 1, sc, sh, rt.ACT_LRELU)
+        assert res == hp.img_sz
+        return prev
 
     # ------------------------------------------------------------------------------------------------
     # plan: whole forward
@@ -542,35 +604,7 @@ class GCPTreeModel:
         # ---- dense_rec: decode every node (tree_dense_rec.py:41-44) ----
         F = B * N
         S = hp.img_sz
-        ctop = self._c_top
-        d0 = self._buf("dec.d0", (F, 4, 4, ctop))
-        nrb = lib.gcpx_gemm_row_blocks(F, 16 * ctop)
-        st = self._buf("dec.st0", (nrb, 2, 16 * ctop)) if self.training else None
-        self._gemm(plan, "dec.input", [self._rowsrc(_addr(E, nz), PS * nz, nz, nz)], F, 16 * ctop, N, P["dec.input.w"],
-                   P["dec.input.b"], out=d0.data_ptr(), ob=N * 16 * ctop, orow=16 * ctop, stats=st)
-        sc, sh = self._bn(plan, "dec.bn0", "decoder.net.input.norm", ctop, st, nrb, 16 * ctop, F * 16)
-        prev = (d0.data_ptr(), ctop, 1, sc, sh, rt.ACT_LRELU)
-        res = 4
-        for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
-            srcs = [prev]
-            if skip_idx >= 0:
-                t, C_, ssc, ssh, sact = skips[skip_idx]
-                assert C_ == c_skip and t.shape[1] == res
-                srcs.append((t.data_ptr(), C_, N, ssc, ssh, sact))      # skips of I_0 broadcast over the node axis
-            o = self._buf(f"dec.{name}", (F, 2 * res, 2 * res, cout))
-            cpad = (cout + 15) // 16 * 16
-            a = self._conv_args(srcs, F, res, res, 2 * res, 2 * res, cout, cout, P[f"dec.{name}.w"], P[f"dec.{name}.b"],
-                                o, upsample=1, stats=(o if self.training else None))     # placeholder pointer for the query
-            Gl = lib.gcpx_conv3x3_grid(C.byref(a))
-            assert Gl > 0, rt.lib().gcpx_last_error()
-            st = self._buf(f"dec.st.{name}", (Gl, 2, cpad)) if self.training else None
-            a.stats_partial = st.data_ptr() if st is not None else None
-            plan.keep.append(a)
-            plan.add(f"dec.{name}", lib.gcpx_conv3x3, C.byref(a))
-            res *= 2
-            sc, sh = self._bn(plan, f"dec.bn.{name}", f"decoder.net.{name}.norm", cout, st, Gl, cpad, F * res * res)
-            prev = (o.data_ptr(), cout, 1, sc, sh, rt.ACT_LRELU)
-        assert res == S
+        prev = self._plan_decoder_features(plan, self._rowsrc(_addr(E, nz), PS * nz, nz, nz), F, N, skips)
         images = self._buf("images_df", (B, N, hp.input_nc, S, S))
         distr = matched_distr = None
         with_loss = key[7]
@@ -624,7 +658,7 @@ class GCPTreeModel:
                          hp.input_nc * S * S)
             kl_b = self._buf("kl_b", (B,))
             plan.add("loss.kl", lib.gcpx_kl_gauss, _addr(QZ, 2 * nv), _addr(PZ, 2 * nv), B, N, nv, PS * 2 * nv, 2 * nv,
-                     C.c_float(hp.free_nats), kl_b.data_ptr())
+                     C.c_float(hp.free_nats), None, 0, kl_b.data_ptr())
             la = rt.LossArgs()
             la.nll_bt, la.pad_mask, la.kl_b = nll_bt.data_ptr(), tin["pad_mask"].data_ptr(), kl_b.data_ptr()
             la.len_logits = outs["seq_len_logits"].data_ptr() if "seq_len_logits" in outs else None
@@ -666,7 +700,7 @@ class GCPTreeModel:
             raise ValueError("end_ind must be fed (sampled lengths are not part of the hot path, SURVEY D3)")
         tin = {}
         with_loss = has_traj and phase == "train" and "pad_mask" in inputs
-        opt = tuple(k for k in ("pad_mask", "traj_seq_states") if with_loss and k in inputs)
+        opt = tuple(k for k in ("pad_mask", "traj_seq_states", "w0") if with_loss and k in inputs)
         # inputs are copied into persistent buffers (one D2D copy; 63 MB for traj_seq at c2 = ~25 us) so that the
         # captured graph — which bakes in device pointers — stays valid whatever tensors the caller passes
         tin = {}
@@ -678,7 +712,7 @@ class GCPTreeModel:
             tin[k] = buf
         if not has_z:
             # the draws of Gaussian.sample() live in a persistent buffer as well
-            eps = self._buf("eps", (B, hp.n_nodes, hp.nz_vae))
+            eps = self._buf("eps", (B, self._n_latents(), hp.nz_vae))
             if noise is None:
                 eps.normal_()
             else:

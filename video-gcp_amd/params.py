@@ -149,10 +149,14 @@ def init_params(hp, seed=0, device="cpu", randomize_affine=False):
     xavier: U(-a, a), a = sqrt(6 / (fan_in + fan_out)); lstm: U(-1/sqrt(H), 1/sqrt(H)) (torch LSTMCell default).
     `randomize_affine=True` perturbs biases / norm affine / running stats so parity tests exercise them.
     """
+    return _init_from_table(param_table(hp), hp, seed, device, randomize_affine)
+
+
+def _init_from_table(table, hp, seed, device, randomize_affine):
     g = torch.Generator(device="cpu").manual_seed(seed)
     out = OrderedDict()
     H = hp.nz_mid_lstm
-    for name, (shape, kind) in param_table(hp).items():
+    for name, (shape, kind) in table.items():
         if kind in ("xavier", "xavier_t"):
             rf = 1
             for s in shape[2:]:
@@ -186,3 +190,36 @@ def n_parameters(hp):
             k *= s
         n += k
     return n
+
+
+# ---------------------------------------------------------------------------------------------------
+# gcp_sequential (flat VRNN baseline): /root/reference/gcp/prediction/models/sequential.py:13-131
+# ---------------------------------------------------------------------------------------------------
+def _hsp(tab, prefix, in_dim, out_dim, H, n_layers):
+    """HiddenStatePredictorModel-style cell: embed Linear, n LSTMCells, out Linear (build spec of the absent blox
+    VRNNCell's three recurrent nets)."""
+    tab[f"{prefix}.embed.weight"] = ((H, in_dim), "xavier")
+    tab[f"{prefix}.embed.bias"] = ((H,), "zeros")
+    for i in range(n_layers):
+        tab[f"{prefix}.lstm.{i}.weight_ih"] = ((4 * H, H), "lstm")
+        tab[f"{prefix}.lstm.{i}.weight_hh"] = ((4 * H, H), "lstm")
+        tab[f"{prefix}.lstm.{i}.bias_ih"] = ((4 * H,), "lstm")
+        tab[f"{prefix}.lstm.{i}.bias_hh"] = ((4 * H,), "lstm")
+    tab[f"{prefix}.out.weight"] = ((out_dim, H), "xavier")
+    tab[f"{prefix}.out.bias"] = ((out_dim,), "zeros")
+
+
+def param_table_sequential(hp):
+    """Same encoder / decoder / heads as the tree model; the tree modules are replaced by the VRNN cell
+    (sequential.py:28: VRNNCell(hp, nz_enc, context = 2*nz_enc, ...))."""
+    tab = OrderedDict((k, v) for k, v in param_table(hp).items() if not k.startswith("tree_module."))
+    ctx = 2 * hp.nz_enc if hp.context_every_step else 0
+    p = "dense_rec.lstm.cell"
+    _hsp(tab, f"{p}.prior_lstm", hp.nz_enc + ctx, 2 * hp.nz_vae, hp.nz_mid_lstm, hp.n_lstm_layers)
+    _hsp(tab, f"{p}.inf_lstm", hp.nz_enc + ctx, 2 * hp.nz_vae, hp.nz_mid_lstm, hp.n_lstm_layers)
+    _hsp(tab, f"{p}.gen_lstm", hp.nz_enc + hp.nz_vae + ctx, hp.nz_enc, hp.nz_mid_lstm, hp.n_lstm_layers)
+    return tab
+
+
+def init_params_sequential(hp, seed=0, device="cpu", randomize_affine=False):
+    return _init_from_table(param_table_sequential(hp), hp, seed, device, randomize_affine)

@@ -76,7 +76,11 @@ SYMBOLS = [
     ("gcpx_balanced_binding", C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     ("gcpx_dlm_nll", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     ("gcpx_gauss_nll", C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
-    ("gcpx_kl_gauss", C.c_int, [vp, vp, i32, i32, i32, i64, i64, C.c_float, vp, vp]),
+    ("gcpx_kl_gauss", C.c_int, [vp, vp, i32, i32, i32, i64, i64, C.c_float, vp, i64, vp, vp]),
+    ("gcpx_gauss_sample", C.c_int, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, vp]),
+    ("gcpx_seq_index", C.c_int, [vp, i32, i32, vp, vp, vp]),
+    ("gcpx_fill_zero", C.c_int, [vp, i64, vp]),
+    ("gcpx_copy_rows", C.c_int, [vp, vp, i32, i32, i64, i64, i64, vp]),
     ("gcpx_loss_combine", C.c_int, [C.POINTER(LossArgs), vp]),
     ("gcpx_gather_rows", C.c_int, [vp, vp, vp, i32, i32, i32, i32, i64, vp]),
     ("gcpx_compact_index", C.c_int, [vp, i32, i32, i32, vp, vp]),

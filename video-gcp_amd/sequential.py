@@ -1,0 +1,235 @@
+"""gcp_sequential: the flat VRNN goal-conditioned predictor, host side.
+
+Mirrors /root/reference/gcp/prediction/models/sequential.py:13-131 (SequentialRecModule / SequentialModel) on top of the
+same encoder / decoder / head kernels as the tree model.  The VRNN cell (blox.torch.models.vrnn.VRNNCell, absent) follows
+this build's spec (oracle/gcp_sequential_oracle.py): three recurrent nets (embed Linear -> n LSTMCells -> out
+Linear) with zero initial state, run T-1 steps from x_0 = e_0.  Each step is 16 small launches (batch rows = B); the prior
+chain runs on a side lane next to the posterior chain.  Weight streaming dominates (3 nets x 3 layers x 4H x 2H floats per
+step), so this path is HBM/L2 bound, not MFMA bound.
+"""
+import ctypes as C
+
+import torch
+
+from . import runtime as rt
+from .model import GCPTreeModel, Outputs, _Plan, _addr
+from .params import init_params_sequential
+
+
+class GCPSequentialModel(GCPTreeModel):
+    def _check_hp(self, hp):
+        assert hp.lstm_init in ("zero", "mlp")          # the cell state always starts at zero (hyperparameters.py:96)
+
+    def _default_params(self, hp, seed):
+        return init_params_sequential(hp, seed)
+
+    def _n_latents(self):
+        return self._hp.max_seq_len - 1
+
+    def _pack_latent_model(self, P):
+        hp = self._hp
+        p = "dense_rec.lstm.cell"
+        for net in ("prior_lstm", "inf_lstm", "gen_lstm"):
+            P[net] = self._pack_hsp(f"{p}.{net}", hp.n_lstm_layers)
+
+    # ------------------------------------------------------------------------------------------------
+    def _plan_hsp(self, plan, name, W, srcs, B, state, par, out_ptr, out_ob, N_out):
+        """One step of a recurrent predictor: embed, n LSTM layers (state ping-pong `par` -> 1-par), out."""
+        hp = self._hp
+        H, nl = hp.nz_mid_lstm, hp.n_lstm_layers
+        x = self._buf(f"{name}.x0", (B, H))
+        self._gemm(plan, f"{name}.embed", srcs, B, H, 1, W["embed.w"], W["embed.b"], out=x.data_ptr(), ob=H, orow=0)
+        for i in range(nl):
+            xn = self._buf(f"{name}.x{i + 1}", (B, H))
+            s_in, s_out = state[par][i], state[1 - par][i]             # [B, 2H] = [h | c]
+            xs = self._rowsrc(x.data_ptr(), H, 0, H)
+            hs = self._rowsrc(s_in.data_ptr(), 2 * H, 0, H)
+            lstm = (_addr(s_in, H), 2 * H, s_out.data_ptr(), _addr(s_out, H), 2 * H, 0, xn.data_ptr())
+            self._gemm(plan, f"{name}.lstm{i}", [xs, hs], B, 4 * H, 1, W[f"lstm{i}.w"], W[f"lstm{i}.b"], epi=rt.EPI_LSTM,
+                       lstm=lstm)
+            x = xn
+        self._gemm(plan, f"{name}.out", [self._rowsrc(x.data_ptr(), H, 0, H)], B, N_out, 1, W["out.w"], W["out.b"],
+                   out=out_ptr, ob=out_ob, orow=0)
+
+    def _build_plan(self, key, tin):
+        hp, P, lib = self._hp, self.pk, self.lib
+        B, has_traj, has_z, sample_prior, phase, with_loss = key[0], key[1], key[2], key[3], key[4], key[7]
+        T, nz, nv, H, nl = hp.max_seq_len, hp.nz_enc, hp.nz_vae, hp.nz_mid_lstm, hp.n_lstm_layers
+        S = hp.img_sz
+        plan = _Plan(lib)
+        X = self._buf("seq.X", (B, T, nz))                   # X[:, 0] = e_0, X[:, 1:] = encodings
+        EG = self._buf("seq.EG", (B, nz))
+        PZ = self._buf("seq.PZ", (B, T - 1, 2 * nv))
+        QZ = self._buf("seq.QZ", (B, T - 1, 2 * nv), zero=True)
+        Z = self._buf("seq.Z", (B, T - 1, nv))
+        idx = self._buf("seq.idx", (B, T), torch.int32)
+        seq_len = self._buf("seq.len", (B,), torch.int32)
+        plan.add("seq_index", lib.gcpx_seq_index, tin["end_ind"].data_ptr(), B, T, idx.data_ptr(), seq_len.data_ptr())
+
+        # ---- run_encoder (base_gcp.py:184-213) ----
+        enc_traj = None
+        plan.fork([1, 2])
+        plan.lane = 1
+        skips = self._plan_encoder(plan, "I0", tin["I_0"].data_ptr(), B, _addr(X), T * nz, 0, 1)
+        plan.lane = 2
+        self._plan_encoder(plan, "Ig", tin["I_g"].data_ptr(), B, _addr(EG), nz, 0, 1)
+        plan.lane = 0
+        if has_traj:
+            enc_traj = self._buf("enc_traj", (B * T, nz))
+            self._plan_encoder(plan, "traj", tin["traj_seq"].data_ptr(), B * T, enc_traj.data_ptr(), T * nz, nz, T)
+        plan.join([1, 2])
+        outs = {}
+        e0 = lambda: self._rowsrc(_addr(X), T * nz, 0, nz)
+        eg = lambda: self._rowsrc(_addr(EG), nz, 0, nz)
+        if hp.regress_length:
+            logits = self._buf("seq_len_logits", (B, T))
+            self._mlp(plan, "length_pred", P["length_pred"], [e0(), eg()], B, 1, out=logits.data_ptr(), ob=T, orow=0)
+            outs["seq_len_logits"] = logits
+
+        # ---- VRNN rollout (sequential.py:49-54) ----
+        state = {net: [[self._buf(f"{net}.s{par}.{i}", (B, 2 * H)) for i in range(nl)] for par in range(2)]
+                 for net in ("prior_lstm", "inf_lstm", "gen_lstm")}
+        for net in state:
+            for i in range(nl):
+                plan.add(f"zero.{net}.{i}", lib.gcpx_fill_zero, state[net][0][i].data_ptr(), B * 2 * H * 4)
+        ctx = (lambda: [e0(), eg()]) if hp.context_every_step else (lambda: [])
+        posterior = has_traj and not sample_prior and not has_z
+        for t in range(T - 1):
+            par = t & 1
+            xt = lambda: self._rowsrc(_addr(X, t * nz), T * nz, 0, nz)
+            plan.fork([1])
+            plan.lane = 1
+            self._plan_hsp(plan, f"prior{t}", P["prior_lstm"], [xt()] + ctx(), B, state["prior_lstm"], par,
+                           _addr(PZ, t * 2 * nv), (T - 1) * 2 * nv, 2 * nv)
+            plan.lane = 0
+            if has_traj:
+                xp = self._rowsrc(_addr(enc_traj, (t + 1) * nz), T * nz, 0, nz)
+                self._plan_hsp(plan, f"inf{t}", P["inf_lstm"], [xp] + ctx(), B, state["inf_lstm"], par,
+                               _addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 2 * nv)
+            plan.join([1])
+            zt = (_addr(Z, t * nv), (T - 1) * nv, 0)
+            if has_z:
+                zsrc = self._rowsrc(_addr(tin["z"], t * nv), (T - 1) * nv, 0, nv)
+            else:
+                muls = QZ if posterior else PZ
+                plan.add(f"sample{t}", lib.gcpx_gauss_sample, _addr(muls, t * 2 * nv), (T - 1) * 2 * nv, 0,
+                         _addr(tin["eps"], t * nv), tin["eps"].shape[1] * nv, 0, zt[0], zt[1], zt[2], B, 1, nv)
+                zsrc = self._rowsrc(zt[0], zt[1], zt[2], nv)
+            self._plan_hsp(plan, f"gen{t}", P["gen_lstm"], [xt(), zsrc] + ctx(), B, state["gen_lstm"], par,
+                           _addr(X, (t + 1) * nz), T * nz, nz)
+
+        # ---- latent-space heads next to the decoder ----
+        plan.fork([1])
+        plan.lane = 1
+        mes = self._buf("model_enc_seq", (B, T, nz))
+        plan.add("gather.model_enc_seq", lib.gcpx_gather_rows, X.data_ptr(), idx.data_ptr(), mes.data_ptr(), B, T, T, 0, nz)
+        outs["model_enc_seq_padded"] = mes
+        if hp.attach_state_regressor:
+            rs = self._buf("regressed_state", (B, T, hp.state_dim))
+            self._mlp(plan, "state_regressor", P["state_regressor"], [self._rowsrc(mes.data_ptr(), T * nz, nz, nz)],
+                      B * T, T, out=rs.data_ptr(), ob=T * hp.state_dim, orow=hp.state_dim)
+            outs["regressed_state_padded"] = rs
+        if hp.attach_inv_mdl and phase == "train":
+            act = self._buf("actions", (B, T - 1, hp.n_actions))
+            first = enc_traj if has_traj else mes
+            s0 = self._rowsrc(first.data_ptr(), T * nz, nz, nz)
+            s1 = self._rowsrc(_addr(mes, nz), T * nz, nz, nz)
+            self._mlp(plan, "inv_mdl", P["inv_mdl"], [s0, s1], B * (T - 1), T - 1, out=act.data_ptr(),
+                      ob=(T - 1) * hp.n_actions, orow=hp.n_actions)
+            outs["actions_padded"] = act
+        plan.lane = 0
+
+        # ---- decoder over the T-1 predicted latents of every sequence (sequential.py:56) ----
+        F = B * (T - 1)
+        prev = self._plan_decoder_features(plan, self._rowsrc(_addr(X, nz), T * nz, nz, nz), F, T - 1, skips)
+        dec_images = self._buf("seq.dec_images", (B, T - 1, hp.input_nc, S, S))
+        dlm = hp.decoder_distribution == "discrete_logistic_mixture"
+        head_out = row_map = matched = None
+        if dlm:
+            mode = rt.HEAD_DLM_MEAN
+            if with_loss or self.materialize_distr:
+                # parameters of frame (b, t) land in row b*T + t + 1: aligned with the target frame traj_seq[b, t+1]
+                mode, matched = rt.HEAD_DLM_BOTH, self._buf("matched_distr", (B, T, S, S, self._head_pitch))
+                head_out = matched
+                row_map = self._buf("seq.row_map", (F,), torch.int32)
+                row_map.copy_((torch.arange(B)[:, None] * T + torch.arange(1, T)[None]).reshape(-1).to(torch.int32))
+        else:
+            mode = rt.HEAD_TANH_NCHW
+        a = self._conv_args([prev], F, S, S, S, S, hp.head_channels, self._head_pitch, P["dec.head.w"], P["dec.head.b"],
+                            head_out, upsample=0, head_mode=mode, images=dec_images)
+        a.raw_row_map = row_map.data_ptr() if row_map is not None else None
+        plan.keep.append(a)
+        plan.join([1])
+        plan.add("dec.head", lib.gcpx_conv3x3, C.byref(a))
+        # images = cat(I_0, decoded) (sequential.py:57)
+        row = hp.input_nc * S * S
+        images = self._buf("seq.images", (B, T, hp.input_nc, S, S))
+        plan.add("cat.I0", lib.gcpx_copy_rows, tin["I_0"].data_ptr(), images.data_ptr(), B, 1, row, 1, T)
+        plan.add("cat.dec", lib.gcpx_copy_rows, dec_images.data_ptr(), _addr(images, row), B, T - 1, row, T - 1, T)
+        outs.update(images=images, X=X, PZ=PZ, QZ=QZ, Z=Z, seq_len=seq_len, matched_distr_kernel_order=matched)
+
+        # ---- losses (sequential.py:60-68) ----
+        if with_loss:
+            nll_bt = self._buf("nll_bt", (B, T))
+            if dlm:
+                plan.add("loss.dlm_nll", lib.gcpx_dlm_nll, matched.data_ptr(), tin["traj_seq"].data_ptr(), tin["w0"].data_ptr(),
+                         nll_bt.data_ptr(), B * T, S * S, self._head_pitch, hp.n_mixtures)
+            else:
+                # rows (b, 0) compare I_0 with itself-as-target and carry weight 0 in the combine below
+                plan.add("loss.gauss_nll", lib.gcpx_gauss_nll, images.data_ptr(), tin["traj_seq"].data_ptr(),
+                         self.sd["decoder.log_sigma"].data_ptr(), nll_bt.data_ptr(), B * T, row)
+            kl_b = self._buf("kl_b", (B,))
+            plan.add("loss.kl", lib.gcpx_kl_gauss, QZ.data_ptr(), PZ.data_ptr(), B, T - 1, nv, (T - 1) * 2 * nv, 2 * nv,
+                     C.c_float(hp.free_nats), _addr(tin["pad_mask"], 1), T, kl_b.data_ptr())
+            la = rt.LossArgs()
+            la.nll_bt, la.pad_mask, la.kl_b = nll_bt.data_ptr(), tin["w0"].data_ptr(), kl_b.data_ptr()   # frame 0 weighs 0
+            la.len_logits = outs["seq_len_logits"].data_ptr() if "seq_len_logits" in outs else None
+            la.end_ind, la.seq_len = tin["end_ind"].data_ptr(), seq_len.data_ptr()
+            loss_out = self._buf("losses", (8,), zero=True)
+            la.out, la.B, la.T, la.N, la.state_dim = loss_out.data_ptr(), B, T, T - 1, hp.state_dim
+            la.w_rec, la.w_kl, la.w_len, la.w_exist, la.w_state = hp.dense_img_rec_weight, hp.kl_weight, hp.length_pred_weight, 0.0, 0.0
+            la.total_div = float(T * hp.input_nc * S * S)
+            plan.keep.append(la)
+            plan.add("loss.combine", lib.gcpx_loss_combine, C.byref(la))
+            outs["losses"], outs["nll_bt"], outs["kl_b"] = loss_out, nll_bt, kl_b
+        outs["enc_traj_seq"] = enc_traj
+        plan.outs = outs
+        return plan
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, inputs, phase="train", noise=None):
+        """noise: eps [B, T-1, nz_vae] for the per-step Gaussian samples; inputs['z'] [B, T-1, nz_vae] feeds latents."""
+        if "pad_mask" in inputs and "traj_seq" in inputs and phase == "train":
+            # NLL row weights: frame 0 is the conditioning frame, never reconstructed (sequential.py:63-66)
+            pm = inputs["pad_mask"].to(self.device, torch.float32)
+            w0 = pm.clone()
+            w0[:, 0] = 0
+            inputs = dict(inputs, w0=w0)
+        return super().forward(inputs, phase, noise)
+
+    def _wrap_outputs(self, o, tin, phase):
+        out = Outputs()
+        out.end_ind, out.raw = tin["end_ind"], o
+        out.dense_rec = Outputs(images=o["images"], encodings=o["X"][:, 1:], p_z=o["PZ"], q_z=o["QZ"], z=o["Z"])
+        if "seq_len_logits" in o:
+            out.seq_len_logits = o["seq_len_logits"]
+        return out
+
+    def pruned_prediction(self, out):
+        lens = out.raw["seq_len"].tolist()
+        return [out.raw["images"][b, :lens[b]] for b in range(len(lens))]
+
+    LOSS_NAMES = ("dense_img_rec", "kl", "len_pred")
+
+    def loss(self, inputs, outputs, log_error_arr=False):
+        raw = outputs.raw
+        if "losses" not in raw:
+            raise ValueError("losses need traj_seq and pad_mask in the inputs of a phase='train' forward")
+        hp, lv = self._hp, raw["losses"]
+        res = Outputs()
+        res["dense_img_rec"] = Outputs(value=lv[0], weight=hp.dense_img_rec_weight)
+        res["kl"] = Outputs(value=lv[1], weight=hp.kl_weight)
+        if hp.regress_length:
+            res["len_pred"] = Outputs(value=lv[2], weight=hp.length_pred_weight)
+        res["_total"] = lv[5]
+        return res
