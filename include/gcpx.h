@@ -83,6 +83,8 @@ typedef struct gcpx_conv_args {
     const int32_t* raw_row_map; /* dev: [F] or NULL (output head only): frame f stores its raw parameters at row
                                raw_row_map[f] of `out`, or not at all when the entry is negative — only the nodes matched
                                to a ground-truth frame need their distribution parameters (frame_binding.py:91-92) */
+    const int32_t* src_row_map; /* dev: [F] or NULL (non-upsampling convs and gcpx_conv_stage): frame f reads source frame
+                               src_row_map[f]; a negative entry reads zeros (backward of the matched-frame gather) */
 } gcpx_conv_args;
 
 /* decoder block: (bilinear x2 upsample +) 3x3 conv, pad 1.  gcpx_conv3x3_grid(a) = number of workgroups that launch
@@ -102,7 +104,8 @@ int gcpx_conv4x4s2_image(const float* x, const float* wpk, const float* bias, fl
    belongs to channel n % C (pitch is a multiple of C); count = elements per channel.  If running_mean/var are non-NULL they are updated with `momentum` (training). */
 int gcpx_bn_finalize(const float* partial, int32_t n_partial, int32_t pitch, int32_t C, double count,
                      const float* gamma, const float* beta, float eps, float* scale, float* shift,
-                     float* running_mean, float* running_var, float momentum, void* stream);
+                     float* running_mean, float* running_var, float momentum, float* mean_out, float* rstd_out,
+                     void* stream);   /* mean_out / rstd_out: [C] batch statistics kept for the backward pass, or NULL */
 /* eval-mode fold: scale/shift from running statistics */
 int gcpx_bn_fold(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
                  float eps, int32_t C, float* scale, float* shift, void* stream);
@@ -155,6 +158,7 @@ typedef struct gcpx_gemm_args {
     int64_t hb, hrow;
     float* h_copy;          /* optional dense copy of h: row r at h_copy + r*H (input of the next layer) */
     int64_t z_src_off, z_w_off, z_bias_off, z_out_off;
+    float* gates_out;       /* LSTM epilogue, optional: activated gates [M][H][4] = (i, f, g, o) kept for the backward pass */
 } gcpx_gemm_args;
 
 int gcpx_gemm(const gcpx_gemm_args* a, void* stream);
@@ -196,6 +200,9 @@ typedef struct gcpx_mlp_args {
     int64_t eb, erow;
     float* z;               /* row r at z + b*zb + j*zrow, [nz] */
     int64_t zb, zrow;
+    float* save;            /* optional, training: hidden activations kept for the backward pass, dense rows:
+                               [0]: a_0 = LReLU(input layer) [M][mid]; then per hidden layer l: u_l (pre-GroupNorm) [M][mid]
+                               and a_l (post GroupNorm + LReLU) [M][mid]  ->  (1 + 2*n_mid) * M * mid floats */
 } gcpx_mlp_args;
 
 int gcpx_mlp(const gcpx_mlp_args* a, void* stream);
@@ -284,6 +291,171 @@ int gcpx_kl_gauss(const float* qz, const float* pz, int32_t B, int32_t N, int32_
                   int64_t node_stride, float free_nats, const float* node_weight /* b*weight_bstride + n, or NULL */,
                   int64_t weight_bstride, float* kl_out, void* stream);
 int gcpx_loss_combine(const gcpx_loss_args* a, void* stream);
+
+
+/* ===================================================================================================
+ * Training step: explicit backward pass, optimizer.
+ *   replaces `losses.total.value.backward(); optimizer.step()` of gcp/prediction/train.py:155-163 (torch autograd +
+ *   blox.torch.radam.RAdam, gcp_builder.py:178-179).  There is no autograd here: every gradient is a launch.
+ * Data gradients of Linear / conv layers reuse gcpx_gemm / gcpx_conv3x3 with transposed weight packs.
+ * ================================================================================================= */
+
+/* ---- weight gradients: dW[n][k] = sum_r dY[r][n] * X[r][k] ---- */
+typedef enum gcpx_wgrad_mode {
+    GCPX_WG_ROWS = 0,      /* X row r at x + b*sb + (j+shift)*sr (b = r / rpb, j = r % rpb; zero outside [0,rpb)) or x + rowidx[r]*sr */
+    GCPX_WG_CONV1D = 1,    /* k = (tap, ci), 3 taps along j: X[r][k] = x[b][j + tap - 1][ci] */
+    GCPX_WG_CONV3X3 = 2,   /* k = (tap, ci): rows are pixels (f, y, x) of an NHWC [F][H][W][Cin] tensor, pad 1 */
+    GCPX_WG_CONV4X4S2 = 3  /* k = (tap, ci), 16 taps: rows are output pixels (f, oy, ox) of the stride-2 conv over NHWC [F][H][W][Cin] */
+} gcpx_wgrad_mode;
+typedef enum gcpx_wgrad_map {
+    GCPX_WMAP_LINEAR = 0,  /* dst[n*ldw + k_off + k] */
+    GCPX_WMAP_CONV = 1,    /* k = (tap, ci): dst[(n_map[n]*Cin + ci)*ntap + tap]   (torch conv weight [Cout][Cin][taps]) */
+    GCPX_WMAP_CONVT = 2    /* n = (tap, co), k = ci: dst[(k*Cout + co)*ntap + tap] (ConvTranspose2d weight [Cin][Cout][taps]) */
+} gcpx_wgrad_map;
+
+typedef struct gcpx_wgrad_args {
+    const float* dy;        /* dev: [R][ldy] output gradient rows (dense) */
+    const float* x;         /* dev: input operand (see mode) */
+    const int32_t* rowidx;  /* ROWS: absolute row gather, or NULL */
+    const int32_t* frame_map; /* conv modes: X frame = frame_map[f] (negative: zeros), or NULL */
+    const float* scale;     /* per-channel affine + activation applied to X on load (channel = k % cmod, or ci), or NULL */
+    const float* shiftv;
+    float* out;             /* direct: dW[n*ldw + k_off + k]; partial: [nsplit][n_valid][K] */
+    int64_t ldy, sb, sr, ldw;
+    int64_t dy_sb;          /* 0: dy rows are dense (row r at dy + r*ldy); else row (b, j) at dy + b*dy_sb + j*ldy, b = r / dy_rpb */
+    int32_t R, N, n_valid;  /* rows; columns of dy to read (N % 4 == 0 when > 16); rows of dW to write */
+    int32_t K, mode, Cin, H, W, rpb, shift, act, cmod;
+    int32_t k_off, accumulate, partial, nsplit;
+    int32_t dy_rpb, _pad;
+} gcpx_wgrad_args;
+
+int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream);
+int gcpx_wgrad_reduce(const float* partial, int32_t nsplit, int32_t N, int32_t K, float* dst, int32_t map_mode, int32_t Cin,
+                      int32_t ntap, int32_t Cout, const int32_t* n_map, int64_t ldw, int32_t k_off, int32_t accumulate,
+                      void* stream);
+/* bias gradient: dst[n] (+)= sum_r dy[r][n] (rows addressed like gcpx_wgrad_args.dy); dst2 = optional second destination
+   (LSTM b_ih and b_hh); with nsplit > 1 the row range is split and partial [nsplit][N] is written instead of dst */
+int gcpx_colsum(const float* dy, int64_t ldy, int32_t R, int32_t N, int32_t dy_rpb, int64_t dy_sb, int32_t nsplit, float* partial,
+                float* dst, float* dst2, int32_t accumulate, void* stream);
+/* dst[i] (+)= sum_{p < n} partial[p*stride + i], i < len (per-workgroup partial sums of norm parameters) */
+int gcpx_reduce_partials(const float* partial, int32_t n, int64_t stride, int32_t len, float* dst, int32_t accumulate, void* stream);
+
+/* ---- LSTM cell backward (HiddenStatePredictorModel inside tree_lstm.py:43-49) ---- */
+typedef struct gcpx_lstm_bwd_args {
+    const float* gates;     /* [M][H][4] activated gates saved by the forward (gcpx_gemm_args.gates_out) */
+    const float* c_prev;    /* row r at c_prev + r*c_prev_stride */
+    const float* c_new;     /* row (b, j) at c_new + b*pb + j*prow */
+    const float* dh_dense;  /* [M] rows at dh_dense + r*dh_stride: gradient from the layer above, or NULL */
+    const float* dh_pos;    /* gradient w.r.t. the stored hidden state h (from the children), at dh_pos + b*pb + j*prow, or NULL */
+    const float* dc_pos;    /* same for the stored cell state c, or NULL */
+    float* dgates;          /* [M][4H] pre-activation gate gradients, torch gate-major order (i | f | g | o) */
+    float* dc_prev;         /* row r at dc_prev + r*dcp_stride */
+    int64_t c_prev_stride, pb, prow, dh_stride, dcp_stride;
+    int32_t M, H, rpb, _pad;
+} gcpx_lstm_bwd_args;
+int gcpx_lstm_bwd(const gcpx_lstm_bwd_args* a, void* stream);
+
+/* ---- Predictor MLP pieces ---- */
+/* GroupNorm + LeakyReLU backward on dense rows: du = dGN(u) applied to da * lrelu'; partial: [gcpx_gn_bwd_blocks(M)][2][C]
+   per-workgroup sums of (d gamma, d beta) */
+int gcpx_gn_lrelu_bwd(const float* u, const float* da, const float* gamma, const float* beta, float* du, float* partial,
+                      int32_t M, int32_t C, int32_t groups, float eps, float slope, void* stream);
+int gcpx_gn_bwd_blocks(int32_t M);
+/* dx[i] = dy[i] * (a[i] > 0 ? 1 : slope) */
+int gcpx_lrelu_bwd(const float* a, const float* dy, float* dx, int64_t n, float slope, void* stream);
+
+/* ---- latent variables ---- */
+/* d KL(q||p) (inference.py:38-43): writes d q / d p rows ([mu | log_sigma]) at the same addresses as qz / pz rows */
+int gcpx_kl_bwd(const float* qz, const float* pz, float* dqz, float* dpz, int32_t B, int32_t N, int32_t nz, int64_t batch_stride,
+                int64_t node_stride, float free_nats, float coef, void* stream);
+/* one tree level: dq_out[r] = dqz_pos[r] + [dz, dz * exp(log_sigma_q) * eps] (reparametrised sample backward,
+   tree_module.py:86-94), dp_out[r] = dpz_pos[r]; rows r = (b, j) of the level; *_pos at base + b*pb + j*prow;
+   dz = dz0[r*ldz0 ..] (+ dz1[r*ldz1 ..]); eps at eps + b*eb + j*erow */
+int gcpx_latent_bwd(const float* dqz_pos, const float* dpz_pos, const float* qz_pos, int64_t pb, int64_t prow, const float* eps,
+                    int64_t eb, int64_t erow, const float* dz0, int64_t ldz0, const float* dz1, int64_t ldz1, float* dq_out,
+                    float* dp_out, int32_t M, int32_t rpb, int32_t nz, void* stream);
+
+/* gradients of one level's inputs accumulated into the parents' slots of a position-layout buffer (the backward of
+   tree_utils.py:37-44 interleave + the context broadcast of tree_module.py:97-101) */
+typedef struct gcpx_tree_accum_src {
+    const float* ptr;       /* dense [B*n][ld] */
+    int64_t ld;
+    int32_t off_left, off_right, off_ctx0, off_ctxg;   /* column offsets of the e_l / e_r / e_0 / e_g parts, -1 = absent */
+    int32_t dst_col;        /* column offset inside the destination row */
+    int32_t _pad;
+} gcpx_tree_accum_src;
+typedef struct gcpx_tree_accum_args {
+    gcpx_tree_accum_src src[6];
+    float* dst;             /* slot 0 of batch element 0 */
+    int64_t dst_sb;         /* floats between batch elements */
+    int64_t slot_stride;    /* floats between consecutive parent slots of this level */
+    int32_t nsrc, B, n, width;
+} gcpx_tree_accum_args;
+int gcpx_tree_accum(const gcpx_tree_accum_args* a, void* stream);
+/* backward of the posterior's batchwise_index gather (inference.py:27-33): out[b][t] = sum over nodes p with node_t[b][p] == t
+   of det[b][p] (rows of nz floats at det + b*db + p*dp) */
+int gcpx_timestep_scatter(const float* det, int64_t db, int64_t dp, const int32_t* node_t, float* out, int32_t B, int32_t N,
+                          int32_t T, int32_t nz, void* stream);
+
+/* dst row (b, j) at dst + b*dst_sb + j*dst_sr  +=  src1[r] (+ src2[r]), dense sources [B*rpb][width] */
+int gcpx_add_rows(float* dst, int64_t dst_sb, int64_t dst_sr, const float* src1, const float* src2, int32_t B, int32_t rpb,
+                  int32_t width, void* stream);
+/* out[b][t] = idx[b][t] + b*stride (per-sequence node index -> absolute frame index) */
+int gcpx_index_offset(const int32_t* idx, int32_t* out, int32_t B, int32_t T, int32_t stride, void* stream);
+
+/* ---- conv stacks ---- */
+/* gradient w.r.t. the raw (pre-norm) output of a layer from the gradient w.r.t. its activated output:
+   dy = (T(da) + add) * act'(scale*r + shift), where T is identity, the transposed bilinear x2 upsample (up = 1) and / or
+   the sum over `fsum` consecutive frames (backward of the skip broadcast); with mean/rstd also the per-workgroup partial
+   sums [gcpx_act_bwd_blocks()][2][C] of (dy, dy * x_hat) the BatchNorm backward needs. */
+typedef struct gcpx_actbwd_args {
+    const float* da;        /* NHWC [F*fsum][H*(1+up)][W*(1+up)][ldc], channels c_off .. c_off+C */
+    const float* add;       /* [F][H][W][C] or NULL */
+    const float* r;         /* [F][H][W][C] raw output (or activated output when scale == NULL) or NULL (no activation) */
+    const float* scale;
+    const float* shift;
+    const float* mean;      /* [C] batch statistics, or NULL (no norm: no partial sums) */
+    const float* rstd;
+    float* dy;              /* [F][H][W][C] */
+    float* stats_partial;
+    int64_t ldc;
+    int32_t c_off, up, fsum, act, F, H, W, C;
+} gcpx_actbwd_args;
+int gcpx_act_bwd(const gcpx_actbwd_args* a, void* stream);
+int gcpx_act_bwd_blocks(void);
+/* BatchNorm backward, second half: coef[0..C) = gamma*rstd, coef[C..2C) = mean(dy), coef[2C..3C) = mean(dy*x_hat);
+   d gamma / d beta written (accumulated) to the gradient buffers */
+int gcpx_bn_bwd_finalize(const float* partial, int32_t n_partial, int32_t C, double count, const float* gamma, const float* rstd,
+                         float* coef, float* dgamma, float* dbeta, int32_t accumulate, void* stream);
+/* dr = coef0 * (dy - coef1 - x_hat * coef2), in place over dy; channel = index % C */
+int gcpx_bn_bwd_apply(float* dy, const float* r, const float* mean, const float* rstd, const float* coef, int64_t n, int32_t C,
+                      void* stream);
+/* materialise the (upsampled, concatenated, normalised + activated) input of a 3x3 conv block for its weight gradient:
+   uses src / nsrc / F / Hin / Win / Hout / Wout / Cin / upsample / src_row_map / out of gcpx_conv_args; out NHWC [F][Hout][Wout][Cin] */
+int gcpx_conv_stage(const gcpx_conv_args* a, void* stream);
+/* backward of the stride-2 4x4 conv w.r.t. its input: dx[f][iy][ix][ci] = sum of the (at most 4) taps of
+   dcol [F*H/2*W/2][16*Cin] (k = (tap, ci)) that touched the pixel */
+int gcpx_col2im4x4s2(const float* dcol, float* dx, int32_t F, int32_t H, int32_t W, int32_t Cin, void* stream);
+/* im2col of the NCHW 3-channel image for the first encoder conv's weight gradient: col [F*H/2*W/2][48], k = (ci, ky, kx) */
+int gcpx_im2col_image(const float* x, float* col, int32_t F, int32_t H, int32_t W, void* stream);
+
+/* ---- loss gradients ---- */
+/* d NLL / d params of the discretised logistic mixture (same layouts as gcpx_dlm_nll); row gradient scaled by
+   row_weight[row] * scale; rows with weight 0 are zero-filled */
+int gcpx_dlm_nll_bwd(const float* params, const float* target, const float* row_weight, float scale, float* dparams, int32_t rows,
+                     int32_t npix, int32_t pitch, int32_t n_mix, void* stream);
+/* d total / d logits of the length CE, existence BCE and state L2 heads (same arguments as gcpx_loss_combine);
+   dlen [B][ceil16(T)] (pad columns zero), dexist [B*N][16] (column 0), dstate [B*T][16] (columns < state_dim); NULL outputs are skipped */
+int gcpx_loss_heads_bwd(const gcpx_loss_args* a, float* dlen, float* dexist, float* dstate, void* stream);
+
+/* ---- parameters ---- */
+/* dst[i] = theta[idx0[i]] (+ theta[idx1[i]]), negative index = 0: every fragment-packed weight arena is a gather of the
+   canonical flat parameter vector (video-gcp_amd/packing.py), refreshed once per optimizer step */
+int gcpx_repack(const float* theta, const int32_t* idx0, const int32_t* idx1, float* dst, int64_t n, void* stream);
+/* RAdam (Liu et al. 2019; blox.torch.radam.RAdam as used by gcp_builder.py:178-179): state[0] = step counter (float),
+   incremented by this call; rectified update when the variance is tractable (rho_t > 5), momentum SGD otherwise */
+int gcpx_radam_step(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, float* state, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * hipGraph helpers: capture a launch sequence once, replay it per step.

@@ -227,7 +227,7 @@ def _trunc_mid(tl, tr):
 # ---------------------------------------------------------------------------------------------------
 # forward
 # ---------------------------------------------------------------------------------------------------
-def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, phase="train"):
+def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, phase="train", taps=None):
     """BaseGCPModel.forward for TreeModel (base_gcp.py:140-161).
 
     inputs: dict with I_0, I_g [B,3,H,W]; end_ind int64 [B]; optional start_ind, traj_seq [B,T,3,H,W], pad_mask,
@@ -240,6 +240,13 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     """
     out = {}
     inp = dict(inputs)
+
+    def tap(name, t):
+        """debug hook: keep intermediate tensors (and their gradients) for the gradient-parity tools"""
+        if taps is not None and torch.is_tensor(t) and t.requires_grad:
+            t.retain_grad()
+            taps[name] = t
+        return t
     B = inp["I_0"].shape[0]
     L, T = hp.hierarchy_levels, hp.max_seq_len
     N = 2 ** L - 1
@@ -250,15 +257,17 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     if "traj_seq" in inp:
         ts = inp["traj_seq"]
         enc, _ = encoder(sd, hp, ts.reshape(B * T, *ts.shape[2:]), training_bn)   # batch_apply, :188
-        inp["enc_traj_seq"] = enc.reshape(B, T, -1)
-        inp["inf_enc_seq"] = seq_encoder(sd, hp, inp["enc_traj_seq"], training_bn)   # :199
+        inp["enc_traj_seq"] = tap("enc_traj_seq", enc.reshape(B, T, -1))
+        inp["inf_enc_seq"] = tap("inf_enc_seq", seq_encoder(sd, hp, inp["enc_traj_seq"], training_bn))   # :199
     e0, skips = encoder(sd, hp, inp["I_0"], training_bn)                         # :208
     eg, _ = encoder(sd, hp, inp["I_g"], training_bn)                             # :209
-    inp["e_0"], inp["e_g"], inp["skips"] = e0[:, :, 0, 0], eg[:, :, 0, 0], skips
+    inp["e_0"], inp["e_g"], inp["skips"] = tap("e_0", e0[:, :, 0, 0]), tap("e_g", eg[:, :, 0, 0]), skips
+    for i, sk in enumerate(skips):
+        tap(f"skip{i}", sk)
 
     # ---- get_end_ind (base_gcp.py:215-229); parity runs feed end_ind --------------------
     if hp.regress_length:
-        out["seq_len_logits"] = predictor(sd, "length_pred.p", hp, inp["e_0"], inp["e_g"])   # misc.py:45-51
+        out["seq_len_logits"] = tap("seq_len_logits", predictor(sd, "length_pred.p", hp, inp["e_0"], inp["e_g"]))   # misc.py:45-51
     end_ind = inp["end_ind"]
     out["end_ind"] = end_ind
 
@@ -313,6 +322,9 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
         sg["hidden"], sg["e_g_prime"] = hidden, e_g_prime
         sg["ind"] = (flat(start_inds) + flat(end_inds)) / 2                     # :113
         sg = {k: v.reshape(B, n, *v.shape[1:]) for k, v in sg.items()}
+        for k in ("e_g_prime", "hidden", "z", "q_z_mu", "q_z_log_sigma", "p_z_mu", "p_z_log_sigma"):
+            if k in sg:
+                tap(f"{k}.{l}", sg[k])
         layers.append(sg)
         # child layer inputs (tree_utils.py:37-44)
         new_left = {k: _interleave(left[k], sg[k]) for k in ("e_g_prime", "hidden")}
@@ -327,6 +339,7 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
 
     bf = {k: torch.cat([lay[k] for lay in layers], 1) for k in layers[0].keys()}          # get_attr_bf
     # dense_rec = TreeDenseRec.forward (tree_dense_rec.py:41-44)
+    tap("bf_e_g_prime", bf["e_g_prime"])
     dec = decode_seq(sd, hp, inp, bf["e_g_prime"], training_bn)
     bf.update(dec)
     out["tree_bf"] = bf
@@ -365,13 +378,14 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
         out["matched_idx"] = idx
         gi = idx[:, :, None, None, None]
         out["soft_matched_estimates"] = torch.gather(bf["images"], 1, gi.expand(B, T, *bf["images"].shape[2:]))
-        out["matched_distr"] = torch.gather(bf["distr"], 1, gi.expand(B, T, *bf["distr"].shape[2:]))
+        out["matched_distr"] = tap("matched_distr", torch.gather(bf["distr"], 1, gi.expand(B, T, *bf["distr"].shape[2:])))
 
     # ---- run_auxilliary_models (base_gcp.py:234-262) ---------------------------------------------------
     mes = torch.nn.utils.rnn.pad_sequence(out["model_enc_seq_list"], batch_first=True)   # :242
     out["model_enc_seq"] = mes
     if hp.attach_state_regressor:
-        out["regressed_state"] = predictor(sd, "state_regressor", hp, mes.reshape(-1, mes.shape[-1])).reshape(B, mes.shape[1], -1)
+        reg_in = mes.detach()                                                     # base_gcp.py:253-255 (supervised_decoder=False)
+        out["regressed_state"] = predictor(sd, "state_regressor", hp, reg_in.reshape(-1, mes.shape[-1])).reshape(B, mes.shape[1], -1)
     if hp.attach_inv_mdl and phase == "train":
         # InverseModel.full_seq_forward (inverse_mdl.py:110-134), train_im0_enc=True
         e1 = mes[:, 1:]
@@ -385,6 +399,18 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
 # ---------------------------------------------------------------------------------------------------
 # losses (base_gcp.py:264-304, tree_module.py:116-157, inference.py:38-43, frame_binding.py:80-99, misc.py:53-56)
 # ---------------------------------------------------------------------------------------------------
+def gradients(sd, hp, inputs, noise, taps=None):
+    """d total_loss / d parameter for every trainable parameter, by torch autograd over this oracle's forward + losses
+    (what `losses.total.value.backward()` of train.py:159-161 produces).  Returns ({name: grad}, loss dict, total)."""
+    names = [k for k in sd if not (k.endswith("running_mean") or k.endswith("running_var"))]
+    leaf = {k: (sd[k].detach().clone().requires_grad_(True) if k in names else sd[k]) for k in sd}
+    out = forward(leaf, hp, inputs, noise=noise, training_bn=True, phase="train", taps=taps)
+    res, total = losses(leaf, hp, inputs, out)
+    grads = torch.autograd.grad(total, [leaf[k] for k in names], allow_unused=True)
+    g = {k: (torch.zeros_like(leaf[k]) if gr is None else gr) for k, gr in zip(names, grads)}
+    return g, res, total, out
+
+
 def losses(sd, hp, inputs, out):
     """Loss dict {name: (value, weight)} and the normalised total.  Reduction spec: value = sum over all
     non-batch dims of (error * weights), mean over batch — so total / prod(traj_seq.shape[1:]) is per-pixel nats."""

@@ -49,6 +49,12 @@ def test_struct_layout_matches_header():
              offsetof(gcpx_gemm_args, wpk), offsetof(gcpx_gemm_args, h_copy));
       printf("%zu %zu %zu %zu\n", offsetof(gcpx_mlp_args, w_in), offsetof(gcpx_mlp_args, gn_eps),
              offsetof(gcpx_mlp_args, out), offsetof(gcpx_mlp_args, zrow));
+      printf("%zu %zu %zu %zu %zu\n", sizeof(gcpx_wgrad_args), sizeof(gcpx_lstm_bwd_args), sizeof(gcpx_tree_accum_args),
+             sizeof(gcpx_actbwd_args), sizeof(gcpx_loss_args));
+      printf("%zu %zu %zu %zu %zu\n", offsetof(gcpx_wgrad_args, ldy), offsetof(gcpx_wgrad_args, dy_rpb),
+             offsetof(gcpx_lstm_bwd_args, dcp_stride), offsetof(gcpx_tree_accum_args, dst), offsetof(gcpx_actbwd_args, ldc));
+      printf("%zu %zu %zu\n", offsetof(gcpx_conv_args, src_row_map), offsetof(gcpx_gemm_args, gates_out),
+             offsetof(gcpx_mlp_args, save));
       return 0;
     }'''
     with tempfile.TemporaryDirectory() as d:
@@ -60,7 +66,11 @@ def test_struct_layout_matches_header():
     got = [int(x) for x in out]
     want = [C.sizeof(rt.ConvSrc), C.sizeof(rt.ConvArgs), C.sizeof(rt.RowSrc), C.sizeof(rt.GemmArgs), C.sizeof(rt.MlpArgs),
             rt.ConvArgs.wpk.offset, rt.ConvArgs.stats_partial.offset, rt.GemmArgs.wpk.offset, rt.GemmArgs.h_copy.offset,
-            rt.MlpArgs.w_in.offset, rt.MlpArgs.gn_eps.offset, rt.MlpArgs.out.offset, rt.MlpArgs.zrow.offset]
+            rt.MlpArgs.w_in.offset, rt.MlpArgs.gn_eps.offset, rt.MlpArgs.out.offset, rt.MlpArgs.zrow.offset,
+            C.sizeof(rt.WgradArgs), C.sizeof(rt.LstmBwdArgs), C.sizeof(rt.TreeAccumArgs), C.sizeof(rt.ActBwdArgs),
+            C.sizeof(rt.LossArgs), rt.WgradArgs.ldy.offset, rt.WgradArgs.dy_rpb.offset, rt.LstmBwdArgs.dcp_stride.offset,
+            rt.TreeAccumArgs.dst.offset, rt.ActBwdArgs.ldc.offset, rt.ConvArgs.src_row_map.offset,
+            rt.GemmArgs.gates_out.offset, rt.MlpArgs.save.offset]
     assert got == want, (got, want)
 
 
@@ -80,3 +90,8 @@ def test_invalid_args_are_rejected_without_a_gpu(lib):
     assert lib.gcpx_mlp(C.byref(m), None) == -1
     c = rt.ConvArgs()
     assert lib.gcpx_conv3x3(C.byref(c), None) == -1
+    w = rt.WgradArgs()
+    assert lib.gcpx_wgrad(C.byref(w), None) == -1
+    assert lib.gcpx_lstm_bwd(C.byref(rt.LstmBwdArgs()), None) == -1
+    assert lib.gcpx_act_bwd(C.byref(rt.ActBwdArgs()), None) == -1
+    assert lib.gcpx_radam_step(None, None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 1.0, None) == -1

@@ -1,0 +1,835 @@
+// Element-wise / gather pieces of the explicit backward pass of the gcp_tree training step on gfx950
+// (the reference leaves all of this to torch autograd: /root/reference/gcp/prediction/train.py:155-163).
+// Everything here is HBM- or latency-bound bookkeeping between the MFMA launches (gcpx_gemm / gcpx_conv3x3 with
+// transposed packs for data gradients, gcpx_wgrad for weight gradients).  All reductions are deterministic
+// (per-workgroup partial sums combined in a fixed order; no atomics).
+#include "common.cuh"
+
+namespace {
+
+constexpr int ACT_BLOCKS = 1024;   // workgroups of the activation-backward kernels (= rows of their stats partials)
+constexpr int GN_ROWS_PER_BLOCK = 64;
+
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------------
+// LSTM cell backward
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lstm_bwd_kernel(const gcpx_lstm_bwd_args a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.M * a.H) return;
+    const int r = idx / a.H, u = idx % a.H;
+    const int b = r / a.rpb, j = r % a.rpb;
+    const size_t pos = (size_t)b * a.pb + (size_t)j * a.prow + u;
+    const float4 g = *reinterpret_cast<const float4*>(a.gates + (size_t)idx * 4);   // i, f, g, o (activated)
+    const float c = a.c_new[pos];
+    const float cp = a.c_prev[(size_t)r * a.c_prev_stride + u];
+    float dh = 0.f, dc = 0.f;
+    if (a.dh_dense) dh += a.dh_dense[(size_t)r * a.dh_stride + u];
+    if (a.dh_pos) dh += a.dh_pos[pos];
+    if (a.dc_pos) dc += a.dc_pos[pos];
+    const float tc = tanhf(c);
+    dc += dh * g.w * (1.f - tc * tc);
+    const float di = dc * g.z * g.x * (1.f - g.x);
+    const float df = dc * cp * g.y * (1.f - g.y);
+    const float dg = dc * g.x * (1.f - g.z * g.z);
+    const float dout = dh * tc * g.w * (1.f - g.w);
+    float* dgr = a.dgates + (size_t)r * 4 * a.H + u;
+    dgr[0] = di;
+    dgr[a.H] = df;
+    dgr[2 * a.H] = dg;
+    dgr[3 * a.H] = dout;
+    a.dc_prev[(size_t)r * a.dcp_stride + u] = dc * g.y;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm + LeakyReLU backward: one wavefront per row, lane handles channels lane, lane + 64, ...
+// ---------------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256) gn_lrelu_bwd_kernel(const float* __restrict__ u, const float* __restrict__ da,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ du, float* __restrict__ partial, const int M,
+                                                           const int groups, const float eps, const float slope) {
+    constexpr int PER = (C + 63) / 64;           // channels per lane
+    __shared__ float red[4][2][C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cpg = C / groups;                   // channels per group: a power of two <= 16 here
+    float gsum[PER], bsum[PER], gam[PER], bet[PER];
+#pragma unroll
+    for (int p = 0; p < PER; ++p) {
+        const int c = lane + 64 * p;
+        gsum[p] = bsum[p] = 0.f;
+        gam[p] = c < C ? gamma[c] : 0.f;
+        bet[p] = c < C ? beta[c] : 0.f;
+    }
+    const int row0 = blockIdx.x * GN_ROWS_PER_BLOCK;
+    for (int rr = wave; rr < GN_ROWS_PER_BLOCK; rr += 4) {
+        const int r = row0 + rr;
+        if (r >= M) break;
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const int c = lane + 64 * p;
+            const bool ok = c < C;
+            const float x = ok ? u[(size_t)r * C + c] : 0.f;
+            // group statistics: lanes of one group are contiguous (cpg <= 16 divides 64)
+            float s = x;
+            for (int m = 1; m < cpg; m <<= 1) s += __shfl_xor(s, m);
+            const float mean = s / cpg;
+            const float d = x - mean;
+            float ss = d * d;
+            for (int m = 1; m < cpg; m <<= 1) ss += __shfl_xor(ss, m);
+            const float rstd = rsqrtf(ss / cpg + eps);
+            const float xh = d * rstd;
+            const float y = xh * gam[p] + bet[p];
+            float dy = ok ? da[(size_t)r * C + c] : 0.f;
+            dy *= (y > 0.f ? 1.f : slope);
+            gsum[p] += dy * xh;
+            bsum[p] += dy;
+            const float dxh = dy * gam[p];
+            float m1 = dxh, m2 = dxh * xh;
+            for (int m = 1; m < cpg; m <<= 1) { m1 += __shfl_xor(m1, m); m2 += __shfl_xor(m2, m); }
+            m1 /= cpg; m2 /= cpg;
+            if (ok) du[(size_t)r * C + c] = rstd * (dxh - m1 - xh * m2);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PER; ++p) {
+        const int c = lane + 64 * p;
+        if (c < C) { red[wave][0][c] = gsum[p]; red[wave][1][c] = bsum[p]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i % C;
+        partial[((size_t)blockIdx.x * 2 + which) * C + c] =
+            (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+__global__ void __launch_bounds__(256) lrelu_bwd_kernel(const float* __restrict__ a, const float* __restrict__ dy,
+                                                        float* __restrict__ dx, const long long n, const float slope) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dx[i] = dy[i] * (a[i] > 0.f ? 1.f : slope);
+}
+
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, const int n, const long long stride,
+                                                              const int len, float* __restrict__ dst, const int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    float s = 0.f;
+    for (int p = 0; p < n; ++p) s += partial[(size_t)p * stride + i];
+    dst[i] = accumulate ? dst[i] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// latent variables
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) kl_bwd_kernel(const float* __restrict__ qz, const float* __restrict__ pz,
+                                                     float* __restrict__ dqz, float* __restrict__ dpz, const int N, const int nz,
+                                                     const long long batch_stride, const long long node_stride,
+                                                     const float free_nats, const float coef, const int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int d = idx % nz, n = (idx / nz) % N, b = idx / (nz * N);
+    const size_t o = (size_t)b * batch_stride + (size_t)n * node_stride;
+    const float mq = qz[o + d], lq = qz[o + nz + d], mp = pz[o + d], lp = pz[o + nz + d];
+    const float diff = mq - mp;
+    const float e2q = expf(2.f * lq), ie2p = expf(-2.f * lp);
+    const float kl = lp - lq + (e2q + diff * diff) * 0.5f * ie2p - 0.5f;
+    const float g = kl > free_nats ? coef : 0.f;        // clamp(min=free_nats): no gradient below the floor
+    dqz[o + d] = g * diff * ie2p;
+    dpz[o + d] = -g * diff * ie2p;
+    dqz[o + nz + d] = g * (e2q * ie2p - 1.f);
+    dpz[o + nz + d] = g * (1.f - (e2q + diff * diff) * ie2p);
+}
+
+__global__ void __launch_bounds__(256) latent_bwd_kernel(const float* __restrict__ dqz_pos, const float* __restrict__ dpz_pos,
+                                                         const float* __restrict__ qz_pos, const long long pb, const long long prow,
+                                                         const float* __restrict__ eps, const long long eb, const long long erow,
+                                                         const float* __restrict__ dz0, const long long ldz0,
+                                                         const float* __restrict__ dz1, const long long ldz1,
+                                                         float* __restrict__ dq_out, float* __restrict__ dp_out, const int M,
+                                                         const int rpb, const int nz) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * nz) return;
+    const int r = idx / nz, d = idx % nz;
+    const int b = r / rpb, j = r % rpb;
+    const size_t o = (size_t)b * pb + (size_t)j * prow;
+    float dz = dz0[(size_t)r * ldz0 + d];
+    if (dz1) dz += dz1[(size_t)r * ldz1 + d];
+    const float ls = qz_pos[o + nz + d];
+    const float e = eps[(size_t)b * eb + (size_t)j * erow + d];
+    dq_out[(size_t)r * 2 * nz + d] = dqz_pos[o + d] + dz;
+    dq_out[(size_t)r * 2 * nz + nz + d] = dqz_pos[o + nz + d] + dz * expf(ls) * e;
+    dp_out[(size_t)r * 2 * nz + d] = dpz_pos[o + d];
+    dp_out[(size_t)r * 2 * nz + nz + d] = dpz_pos[o + nz + d];
+}
+
+// grid: (ceil(width/64), n + 1 parent slots, B)
+__global__ void __launch_bounds__(64) tree_accum_kernel(const gcpx_tree_accum_args a) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= a.width) return;
+    const int k = blockIdx.y, b = blockIdx.z, n = a.n;
+    for (int s = 0; s < a.nsrc; ++s) {
+        const gcpx_tree_accum_src src = a.src[s];
+        float acc = 0.f;
+        if (k < n && src.off_left >= 0) acc += src.ptr[(size_t)(b * n + k) * src.ld + src.off_left + c];
+        if (k >= 1 && src.off_right >= 0) acc += src.ptr[(size_t)(b * n + k - 1) * src.ld + src.off_right + c];
+        if (k == 0 && src.off_ctx0 >= 0)
+            for (int i = 0; i < n; ++i) acc += src.ptr[(size_t)(b * n + i) * src.ld + src.off_ctx0 + c];
+        if (k == n && src.off_ctxg >= 0)
+            for (int i = 0; i < n; ++i) acc += src.ptr[(size_t)(b * n + i) * src.ld + src.off_ctxg + c];
+        float* d = a.dst + (size_t)b * a.dst_sb + (size_t)k * a.slot_stride + src.dst_col + c;
+        *d += acc;
+    }
+}
+
+__global__ void __launch_bounds__(128) timestep_scatter_kernel(const float* __restrict__ det, const long long db, const long long dp,
+                                                               const int* __restrict__ node_t, float* __restrict__ out, const int N,
+                                                               const int T, const int nz) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    for (int c = threadIdx.x; c < nz; c += 128) {
+        float s = 0.f;
+        for (int p = 0; p < N; ++p)
+            if (node_t[b * N + p] == t) s += det[(size_t)b * db + (size_t)p * dp + c];
+        out[((size_t)b * T + t) * nz + c] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) add_rows_kernel(float* __restrict__ dst, const long long dst_sb, const long long dst_sr,
+                                                       const float* __restrict__ src1, const float* __restrict__ src2,
+                                                       const int rpb, const int width, const int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % width, r = idx / width;
+    const int b = r / rpb, j = r % rpb;
+    float v = src1[idx];
+    if (src2) v += src2[idx];
+    dst[(size_t)b * dst_sb + (size_t)j * dst_sr + c] += v;
+}
+
+__global__ void __launch_bounds__(256) index_offset_kernel(const int* __restrict__ idx, int* __restrict__ out, const int T,
+                                                           const int stride, const int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = idx[i] + (i / T) * stride;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv stacks
+// ---------------------------------------------------------------------------------------------------
+// items = float4 groups of the output [F][H][W][C]; a thread keeps a fixed channel group (1024 % C == 0)
+__global__ void __launch_bounds__(256) act_bwd_kernel(const gcpx_actbwd_args a) {
+    const int C = a.C, C4 = C / 4;
+    const long long total = (long long)a.F * a.H * a.W * C4;
+    const int c = (threadIdx.x * 4) % C;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 mu = sh, rs = sc;
+    if (a.scale) { sc = *reinterpret_cast<const float4*>(a.scale + c); sh = *reinterpret_cast<const float4*>(a.shift + c); }
+    if (a.mean) { mu = *reinterpret_cast<const float4*>(a.mean + c); rs = *reinterpret_cast<const float4*>(a.rstd + c); }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int Hd = a.up ? 2 * a.H : a.H, Wd = a.up ? 2 * a.W : a.W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long p = i / C4;
+        const int x = (int)(p % a.W); p /= a.W;
+        const int y = (int)(p % a.H);
+        const int f = (int)(p / a.H);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int fs = 0; fs < a.fsum; ++fs) {
+            const float* base = a.da + ((size_t)(f * a.fsum + fs) * Hd * Wd) * a.ldc + a.c_off + c;
+            if (a.up) {
+#pragma unroll
+                for (int ty = 0; ty < 4; ++ty) {
+                    const int yy = min(max(2 * y - 1 + ty, 0), Hd - 1);
+                    const float wy = (ty == 0 || ty == 3) ? 0.25f : 0.75f;
+#pragma unroll
+                    for (int tx = 0; tx < 4; ++tx) {
+                        const int xx = min(max(2 * x - 1 + tx, 0), Wd - 1);
+                        const float w = wy * ((tx == 0 || tx == 3) ? 0.25f : 0.75f);
+                        const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)yy * Wd + xx) * a.ldc);
+                        g.x += w * v.x; g.y += w * v.y; g.z += w * v.z; g.w += w * v.w;
+                    }
+                }
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)y * Wd + x) * a.ldc);
+                g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+            }
+        }
+        const size_t o = (size_t)i * 4;
+        if (a.add) {
+            const float4 v = *reinterpret_cast<const float4*>(a.add + o);
+            g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+        }
+        if (a.r) {
+            const float4 rv = *reinterpret_cast<const float4*>(a.r + o);
+            const float yv[4] = {fmaf(rv.x, sc.x, sh.x), fmaf(rv.y, sc.y, sh.y), fmaf(rv.z, sc.z, sh.z), fmaf(rv.w, sc.w, sh.w)};
+            float gv[4] = {g.x, g.y, g.z, g.w};
+            const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+            const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, ss[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (a.act == GCPX_ACT_LRELU) gv[k] *= (yv[k] > 0.f ? 1.f : 0.2f);
+                s1[k] += gv[k];
+                s2[k] += gv[k] * (rr[k] - mm[k]) * ss[k];
+            }
+            g = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        }
+        *reinterpret_cast<float4*>(a.dy + o) = g;
+    }
+    if (a.stats_partial) {
+        __shared__ float red[256][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[threadIdx.x][k] = s1[k]; red[threadIdx.x][4 + k] = s2[k]; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += 256) {
+            const int which = i / C, ch = i % C;
+            float s = 0.f;
+            for (int t = ch / 4; t < 256; t += C4) s += red[t][which * 4 + (ch & 3)];
+            a.stats_partial[((size_t)blockIdx.x * 2 + which) * C + ch] = s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ partial, const int n_partial, const int C,
+                                                              const double count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ rstd, float* __restrict__ coef,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              const int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < n_partial; ++p) {
+        s1 += partial[((size_t)p * 2 + 0) * C + c];
+        s2 += partial[((size_t)p * 2 + 1) * C + c];
+    }
+    coef[c] = gamma[c] * rstd[c];
+    coef[C + c] = (float)(s1 / count);
+    coef[2 * C + c] = (float)(s2 / count);
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ r,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ coef, const long long n4, const int C) {
+    const int c = (threadIdx.x * 4) % C;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 k1 = *reinterpret_cast<const float4*>(coef + c), m1 = *reinterpret_cast<const float4*>(coef + C + c);
+    const float4 m2 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 g = reinterpret_cast<float4*>(dy)[i];
+        const float4 rv = reinterpret_cast<const float4*>(r)[i];
+        g.x = k1.x * (g.x - m1.x - (rv.x - mu.x) * rs.x * m2.x);
+        g.y = k1.y * (g.y - m1.y - (rv.y - mu.y) * rs.y * m2.y);
+        g.z = k1.z * (g.z - m1.z - (rv.z - mu.z) * rs.z * m2.z);
+        g.w = k1.w * (g.w - m1.w - (rv.w - mu.w) * rs.w * m2.w);
+        reinterpret_cast<float4*>(dy)[i] = g;
+    }
+}
+
+// out[f][Y][X][c] = (upsampled) concat of the normalised + activated sources
+__global__ void __launch_bounds__(256) conv_stage_kernel(const gcpx_conv_args a) {
+    const int C4 = a.Cin / 4;
+    const long long total = (long long)a.F * a.Hout * a.Wout * C4;
+    const int c0 = a.src[0].C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cg = (int)(i % C4) * 4;
+        long long p = i / C4;
+        const int X = (int)(p % a.Wout); p /= a.Wout;
+        const int Y = (int)(p % a.Hout);
+        int f = (int)(p / a.Hout);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.src_row_map) f = a.src_row_map[f];
+        if (f >= 0) {
+            const bool first = cg < c0;
+            const gcpx_conv_src& s = first ? a.src[0] : a.src[1];
+            const int cl = first ? cg : cg - c0;
+            const float* base = s.ptr + (size_t)(f / s.frame_div) * a.Hin * a.Win * s.C + cl;
+            auto ld = [&](int y, int x) {
+                const float4 t = *reinterpret_cast<const float4*>(base + ((size_t)y * a.Win + x) * s.C);
+                return affine_act4(t, s.scale, s.shift, cl, s.act);
+            };
+            if (a.upsample) {
+                // align_corners=False x2: Y even -> rows (Y/2 - 1, Y/2) weights (.25, .75); odd -> (Y/2, Y/2 + 1) weights (.75, .25)
+                const int y0 = (Y & 1) ? Y / 2 : Y / 2 - 1, x0 = (X & 1) ? X / 2 : X / 2 - 1;
+                const float wy1 = (Y & 1) ? 0.25f : 0.75f, wx1 = (X & 1) ? 0.25f : 0.75f;
+                const int ya = max(y0, 0), yb = min(y0 + 1, a.Hin - 1), xa = max(x0, 0), xb = min(x0 + 1, a.Win - 1);
+                const float4 v00 = ld(ya, xa), v01 = ld(ya, xb), v10 = ld(yb, xa), v11 = ld(yb, xb);
+                const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+                v.x = wy0 * (wx0 * v00.x + wx1 * v01.x) + wy1 * (wx0 * v10.x + wx1 * v11.x);
+                v.y = wy0 * (wx0 * v00.y + wx1 * v01.y) + wy1 * (wx0 * v10.y + wx1 * v11.y);
+                v.z = wy0 * (wx0 * v00.z + wx1 * v01.z) + wy1 * (wx0 * v10.z + wx1 * v11.z);
+                v.w = wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
+            } else {
+                v = ld(Y, X);
+            }
+        }
+        reinterpret_cast<float4*>(a.out)[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) col2im4x4s2_kernel(const float* __restrict__ dcol, float* __restrict__ dx, const int F,
+                                                          const int H, const int W, const int Cin) {
+    const int C4 = Cin / 4;
+    const long long total = (long long)F * H * W * C4;
+    const int Ho = H / 2, Wo = W / 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        long long p = i / C4;
+        const int ix = (int)(p % W); p /= W;
+        const int iy = (int)(p % H);
+        const int f = (int)(p / H);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ky = ((iy + 1) & 1) + 2 * a;
+            const int oy = (iy + 1 - ky) / 2;
+            if (iy + 1 - ky < 0 || oy >= Ho) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int kx = ((ix + 1) & 1) + 2 * b;
+                const int ox = (ix + 1 - kx) / 2;
+                if (ix + 1 - kx < 0 || ox >= Wo) continue;
+                const float4 v = *reinterpret_cast<const float4*>(dcol + (((size_t)f * Ho + oy) * Wo + ox) * 16 * Cin +
+                                                                  (ky * 4 + kx) * Cin + c);
+                g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+            }
+        }
+        reinterpret_cast<float4*>(dx)[i] = g;
+    }
+}
+
+__global__ void __launch_bounds__(256) im2col_image_kernel(const float* __restrict__ x, float* __restrict__ col, const int F,
+                                                           const int H, const int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)F * Ho * Wo * 48;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int k = (int)(i % 48);
+        long long p = i / 48;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int f = (int)(p / Ho);
+        const int ci = k / 16, ky = (k / 4) & 3, kx = k & 3;
+        const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
+        float v = 0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)f * 3 + ci) * H + iy) * W + ix];
+        col[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// loss gradients
+// ---------------------------------------------------------------------------------------------------
+// Mirror of dlm_nll_kernel (loss.hip): a wavefront stages 16 pixels x PITCH parameters in LDS, lane (j = pixel, q)
+// owns mixtures q, q+4, q+8, overwrites its slots with the gradients, and the tile goes out with coalesced stores.
+template <int NMIX, int PITCH>
+__global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restrict__ params, const float* __restrict__ target,
+                                                          const float* __restrict__ row_weight, const float scale,
+                                                          float* __restrict__ dparams, const int npix) {
+    __shared__ float4 stage4[4 * 16 * PITCH / 4];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    constexpr int F4 = 16 * PITCH / 4;
+    float* st = reinterpret_cast<float*>(stage4) + wave * 16 * PITCH;
+    float* drow = dparams + (size_t)row * npix * PITCH;
+    const float coef = (row_weight ? row_weight[row] : 1.f) * scale;
+    if (coef == 0.f) {
+        for (int p0 = wave * 16; p0 < npix; p0 += 64) {
+            float4* dst = reinterpret_cast<float4*>(drow + (size_t)p0 * PITCH);
+            for (int i = lane; i < F4; i += 64) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const float* prow = params + (size_t)row * npix * PITCH;
+    const float* trow = target + (size_t)row * 3 * npix;
+    for (int p0 = wave * 16; p0 < npix; p0 += 64) {
+        const float4* src = reinterpret_cast<const float4*>(prow + (size_t)p0 * PITCH);
+        for (int i = lane; i < F4; i += 64) reinterpret_cast<float4*>(st)[i] = src[i];
+        __builtin_amdgcn_wave_barrier();
+        float* pp = st + j * PITCH;
+        const float xr = trow[p0 + j], xg = trow[npix + p0 + j], xb = trow[2 * npix + p0 + j];
+        float lmax = pp[0];
+#pragma unroll
+        for (int k = 1; k < NMIX; ++k) lmax = fmaxf(lmax, pp[8 * k]);
+        float lsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NMIX; ++k) lsum += expf(pp[8 * k] - lmax);
+        const float lse_logits = lmax + logf(lsum);
+        float lp[3], gm[3][3], gs[3][3], cf[3][3], lg[3];
+        int nk = 0;
+        for (int k = q; k < NMIX; k += 4, ++nk) {
+            const float* m = pp + 8 * k;
+            const float c0 = tanhf(m[4]), c1 = tanhf(m[5]), c2 = tanhf(m[6]);
+            cf[nk][0] = c0; cf[nk][1] = c1; cf[nk][2] = c2;
+            const float mean[3] = {m[1], m[2] + c0 * xr, m[3] + c1 * xr + c2 * xg};
+            const float x[3] = {xr, xg, xb};
+            lg[nk] = m[0];
+            float s = m[0] - lse_logits;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float raw = pp[80 + 10 * c + k];
+                const float ls = fmaxf(raw, -7.f);
+                const float xc = x[c] - mean[c];
+                const float inv = expf(-ls);
+                const float plus_in = inv * (xc + 1.f / 255.f), min_in = inv * (xc - 1.f / 255.f);
+                const float sp = sigmoid_acc(plus_in), sm = sigmoid_acc(min_in);
+                const float cdf_delta = sp - sm;
+                const float mid_in = inv * xc;
+                float v, dm, ds;     // value, d v / d mean, d v / d log_scale
+                if (x[c] < -0.999f) {
+                    v = plus_in - (plus_in > 20.f ? plus_in : log1pf(expf(plus_in)));
+                    dm = -inv * (1.f - sp);
+                    ds = -plus_in * (1.f - sp);
+                } else if (x[c] > 0.999f) {
+                    v = -(min_in > 20.f ? min_in : log1pf(expf(min_in)));
+                    dm = inv * sm;
+                    ds = min_in * sm;
+                } else if (cdf_delta > 1e-5f) {
+                    v = logf(fmaxf(cdf_delta, 1e-12f));
+                    const float pp_ = sp * (1.f - sp), pm_ = sm * (1.f - sm);
+                    dm = -inv * (pp_ - pm_) / cdf_delta;
+                    ds = -(plus_in * pp_ - min_in * pm_) / cdf_delta;
+                } else {
+                    const float smid = sigmoid_acc(mid_in);
+                    v = mid_in - ls - 2.f * (mid_in > 20.f ? mid_in : log1pf(expf(mid_in))) - 4.8481163864f;
+                    dm = -inv * (1.f - 2.f * smid);
+                    ds = -mid_in * (1.f - 2.f * smid) - 1.f;
+                }
+                if (raw < -7.f) ds = 0.f;          // clamp(min=-7) blocks the gradient
+                s += v;
+                gm[nk][c] = dm;
+                gs[nk][c] = ds;
+            }
+            lp[nk] = s;
+        }
+        float mx = lp[0];
+        for (int i = 1; i < nk; ++i) mx = fmaxf(mx, lp[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float se = 0.f;
+        for (int i = 0; i < nk; ++i) se += expf(lp[i] - mx);
+        se += __shfl_xor(se, 16);
+        se += __shfl_xor(se, 32);
+        const float inv_se = 1.f / se;
+        __builtin_amdgcn_wave_barrier();           // every lane has read the logits of its pixel
+        nk = 0;
+        for (int k = q; k < NMIX; k += 4, ++nk) {
+            const float w = expf(lp[nk] - mx) * inv_se;            // responsibility of mixture k
+            const float pik = expf(lg[nk] - lse_logits);
+            float* m = pp + 8 * k;
+            const float gw = -coef * w;                             // d(-logsumexp)/d s_k
+            m[0] = coef * (pik - w);
+            m[1] = gw * gm[nk][0];
+            m[2] = gw * gm[nk][1];
+            m[3] = gw * gm[nk][2];
+            m[4] = gw * gm[nk][1] * xr * (1.f - cf[nk][0] * cf[nk][0]);
+            m[5] = gw * gm[nk][2] * xr * (1.f - cf[nk][1] * cf[nk][1]);
+            m[6] = gw * gm[nk][2] * xg * (1.f - cf[nk][2] * cf[nk][2]);
+            m[7] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pp[80 + 10 * c + k] = gw * gs[nk][c];
+        }
+        if (q == 0)
+            for (int s = 80 + 3 * NMIX; s < PITCH; ++s) pp[s] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        float4* dst = reinterpret_cast<float4*>(drow + (size_t)p0 * PITCH);
+        for (int i = lane; i < F4; i += 64) dst[i] = reinterpret_cast<float4*>(st)[i];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void __launch_bounds__(256) loss_heads_bwd_kernel(const gcpx_loss_args a, float* __restrict__ dlen,
+                                                             float* __restrict__ dexist, float* __restrict__ dstate) {
+    const int B = a.B, T = a.T, N = a.N;
+    const float inv_div = 1.f / a.total_div;
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    if (dlen && a.len_logits) {
+        const int ldl = (T + 15) & ~15;              // rows padded to the GEMM K granularity, pad columns zero
+        for (int i = tid; i < B * ldl; i += nth) {
+            const int b = i / ldl, t = i % ldl;
+            float v = 0.f;
+            if (t < T) {
+                const float* lg = a.len_logits + (size_t)b * T;
+                float mx = lg[0];
+                for (int k = 1; k < T; ++k) mx = fmaxf(mx, lg[k]);
+                float se = 0.f;
+                for (int k = 0; k < T; ++k) se += expf(lg[k] - mx);
+                const float p = expf(lg[t] - mx) / se;
+                v = (p - (t == (int)a.end_ind[b] ? 1.f : 0.f)) * a.w_len * inv_div / B;
+            }
+            dlen[i] = v;
+        }
+    }
+    if (dexist && a.existence) {
+        for (int i = tid; i < B * N * 16; i += nth) {
+            const int r = i / 16, c = i % 16;
+            float v = 0.f;
+            if (c == 0) v = (sigmoid_acc(a.existence[r]) - (a.leave[r] ? 1.f : 0.f)) * a.w_exist * inv_div / (float)(B * N);
+            dexist[i] = v;
+        }
+    }
+    if (dstate && a.regressed_state && a.state_target) {
+        int rl = 0;
+        for (int b = 0; b < B; ++b) rl = max(rl, a.seq_len[b]);
+        const float k = 2.f * a.w_state * inv_div / (float)(B * rl * a.state_dim);
+        for (int i = tid; i < B * T * 16; i += nth) {
+            const int r = i / 16, c = i % 16;
+            const int t = r % T;
+            float v = 0.f;
+            if (c < a.state_dim && t < rl) {
+                const float pm = a.pad_mask[r];
+                v = k * pm * (a.regressed_state[(size_t)r * a.state_dim + c] - a.state_target[(size_t)r * a.state_dim + c]);
+            }
+            dstate[i] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// parameters
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) repack_kernel(const float* __restrict__ theta, const int* __restrict__ idx0,
+                                                     const int* __restrict__ idx1, float* __restrict__ dst, const long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int a = idx0[i];
+        float v = a >= 0 ? theta[a] : 0.f;
+        if (idx1) {
+            const int b = idx1[i];
+            if (b >= 0) v += theta[b];
+        }
+        dst[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) radam_kernel(float* __restrict__ theta, const float* __restrict__ grad,
+                                                    float* __restrict__ m, float* __restrict__ v, const float* __restrict__ state,
+                                                    const long long n, const float lr, const float beta1, const float beta2,
+                                                    const float eps, const float grad_scale) {
+    const float t = state[0] + 1.f;
+    const float b2t = powf(beta2, t), b1t = powf(beta1, t);
+    const float sma_max = 2.f / (1.f - beta2) - 1.f;
+    const float sma = sma_max - 2.f * t * b2t / (1.f - b2t);
+    const bool rect = sma >= 5.f;
+    float step;
+    if (rect) step = sqrtf((1.f - b2t) * (sma - 4.f) / (sma_max - 4.f) * (sma - 2.f) / sma * sma_max / (sma_max - 2.f)) / (1.f - b1t);
+    else step = 1.f / (1.f - b1t);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float g = grad[i] * grad_scale;
+        const float mi = beta1 * m[i] + (1.f - beta1) * g;
+        const float vi = beta2 * v[i] + (1.f - beta2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        theta[i] -= rect ? lr * step * mi / (sqrtf(vi) + eps) : lr * step * mi;
+    }
+}
+
+__global__ void radam_tick_kernel(float* state) { state[0] += 1.f; }
+
+int blocks_for(long long items, int cap = 4096) {
+    long long b = (items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+#define STREAM() hipStream_t stream = reinterpret_cast<hipStream_t>(stream_)
+
+extern "C" int gcpx_lstm_bwd(const gcpx_lstm_bwd_args* a, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(a && a->gates && a->c_prev && a->c_new && a->dgates && a->dc_prev, "missing pointer");
+    GCPX_CHECK_ARG(a->M > 0 && a->H > 0 && a->rpb > 0, "bad sizes");
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((a->M * a->H + 255) / 256), dim3(256), 0, stream, *a);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_gn_bwd_blocks(int32_t M) { return (M + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK; }
+
+extern "C" int gcpx_gn_lrelu_bwd(const float* u, const float* da, const float* gamma, const float* beta, float* du, float* partial,
+                                 int32_t M, int32_t C, int32_t groups, float eps, float slope, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(u && da && gamma && beta && du && partial && M > 0, "missing pointer");
+    GCPX_CHECK_ARG(groups > 0 && C % groups == 0 && (C / groups) <= 16 && ((C / groups) & (C / groups - 1)) == 0,
+                   "channels per group must be a power of two <= 16");
+    const int nb = gcpx_gn_bwd_blocks(M);
+    if (C == 128) hipLaunchKernelGGL(gn_lrelu_bwd_kernel<128>, dim3(nb), dim3(256), 0, stream, u, da, gamma, beta, du, partial, M, groups, eps, slope);
+    else if (C == 32) hipLaunchKernelGGL(gn_lrelu_bwd_kernel<32>, dim3(nb), dim3(256), 0, stream, u, da, gamma, beta, du, partial, M, groups, eps, slope);
+    else { gcpx_set_error("gcpx_gn_lrelu_bwd: unsupported C=%d (128 or 32)", C); return GCPX_ERR_UNSUPPORTED; }
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_lrelu_bwd(const float* a, const float* dy, float* dx, int64_t n, float slope, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(a && dy && dx && n > 0, "bad arguments");
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, dy, dx, (long long)n, slope);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_reduce_partials(const float* partial, int32_t n, int64_t stride, int32_t len, float* dst, int32_t accumulate,
+                                    void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(partial && dst && n > 0 && len > 0, "bad arguments");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 255) / 256), dim3(256), 0, stream, partial, n, (long long)stride, len, dst,
+                       accumulate);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_kl_bwd(const float* qz, const float* pz, float* dqz, float* dpz, int32_t B, int32_t N, int32_t nz,
+                           int64_t batch_stride, int64_t node_stride, float free_nats, float coef, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(qz && pz && dqz && dpz && B > 0 && N > 0 && nz > 0, "bad arguments");
+    const int total = B * N * nz;
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, qz, pz, dqz, dpz, N, nz,
+                       (long long)batch_stride, (long long)node_stride, free_nats, coef, total);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_latent_bwd(const float* dqz_pos, const float* dpz_pos, const float* qz_pos, int64_t pb, int64_t prow,
+                               const float* eps, int64_t eb, int64_t erow, const float* dz0, int64_t ldz0, const float* dz1,
+                               int64_t ldz1, float* dq_out, float* dp_out, int32_t M, int32_t rpb, int32_t nz, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(dqz_pos && dpz_pos && qz_pos && eps && dz0 && dq_out && dp_out && M > 0 && rpb > 0 && nz > 0, "bad arguments");
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3((M * nz + 255) / 256), dim3(256), 0, stream, dqz_pos, dpz_pos, qz_pos, (long long)pb,
+                       (long long)prow, eps, (long long)eb, (long long)erow, dz0, (long long)ldz0, dz1, (long long)ldz1, dq_out,
+                       dp_out, M, rpb, nz);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_tree_accum(const gcpx_tree_accum_args* a, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(a && a->dst && a->nsrc >= 1 && a->nsrc <= 6 && a->B > 0 && a->n > 0 && a->width > 0, "bad arguments");
+    hipLaunchKernelGGL(tree_accum_kernel, dim3((a->width + 63) / 64, a->n + 1, a->B), dim3(64), 0, stream, *a);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_timestep_scatter(const float* det, int64_t db, int64_t dp, const int32_t* node_t, float* out, int32_t B,
+                                     int32_t N, int32_t T, int32_t nz, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(det && node_t && out && B > 0 && N > 0 && T > 0 && nz > 0, "bad arguments");
+    hipLaunchKernelGGL(timestep_scatter_kernel, dim3(T, B), dim3(128), 0, stream, det, (long long)db, (long long)dp, node_t, out, N, T, nz);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_add_rows(float* dst, int64_t dst_sb, int64_t dst_sr, const float* src1, const float* src2, int32_t B,
+                             int32_t rpb, int32_t width, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(dst && src1 && B > 0 && rpb > 0 && width > 0, "bad arguments");
+    const int total = B * rpb * width;
+    hipLaunchKernelGGL(add_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, dst, (long long)dst_sb, (long long)dst_sr,
+                       src1, src2, rpb, width, total);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_index_offset(const int32_t* idx, int32_t* out, int32_t B, int32_t T, int32_t stride, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(idx && out && B > 0 && T > 0, "bad arguments");
+    hipLaunchKernelGGL(index_offset_kernel, dim3((B * T + 255) / 256), dim3(256), 0, stream, idx, out, T, stride, B * T);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_act_bwd_blocks(void) { return ACT_BLOCKS; }
+
+extern "C" int gcpx_act_bwd(const gcpx_actbwd_args* a, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(a && a->da && a->dy, "missing pointer");
+    GCPX_CHECK_ARG(a->F > 0 && a->H > 0 && a->W > 0 && a->C >= 4 && (a->C & (a->C - 1)) == 0 && a->C <= 1024, "C must be a power of two in [4, 1024]");
+    GCPX_CHECK_ARG(a->fsum >= 1 && a->ldc % 4 == 0 && a->c_off % 4 == 0, "bad fsum / ldc / c_off");
+    GCPX_CHECK_ARG(!a->stats_partial || (a->mean && a->rstd && a->r), "stats need r, mean, rstd");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ACT_BLOCKS), dim3(256), 0, stream, *a);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_bn_bwd_finalize(const float* partial, int32_t n_partial, int32_t C, double count, const float* gamma,
+                                    const float* rstd, float* coef, float* dgamma, float* dbeta, int32_t accumulate, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(partial && gamma && rstd && coef && n_partial > 0 && C > 0 && count > 0, "bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, n_partial, C, count, gamma, rstd,
+                       coef, dgamma, dbeta, accumulate);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_bn_bwd_apply(float* dy, const float* r, const float* mean, const float* rstd, const float* coef, int64_t n,
+                                 int32_t C, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(dy && r && mean && rstd && coef && n > 0 && n % 4 == 0, "bad arguments");
+    GCPX_CHECK_ARG(C >= 4 && (C & (C - 1)) == 0 && C <= 1024, "C must be a power of two in [4, 1024]");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, stream, dy, r, mean, rstd, coef, (long long)(n / 4), C);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_conv_stage(const gcpx_conv_args* a, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(a && a->out && a->nsrc >= 1 && a->nsrc <= 2 && a->F > 0, "bad arguments");
+    GCPX_CHECK_ARG(a->Cin % 4 == 0 && a->src[0].C % 4 == 0, "channels % 4");
+    GCPX_CHECK_ARG(a->Cin == a->src[0].C + (a->nsrc == 2 ? a->src[1].C : 0), "Cin != sum of sources");
+    if (a->upsample) GCPX_CHECK_ARG(a->Hout == 2 * a->Hin && a->Wout == 2 * a->Win, "upsample: Hout != 2*Hin");
+    else GCPX_CHECK_ARG(a->Hout == a->Hin && a->Wout == a->Win, "no upsample: Hout != Hin");
+    const long long items = (long long)a->F * a->Hout * a->Wout * (a->Cin / 4);
+    hipLaunchKernelGGL(conv_stage_kernel, dim3(blocks_for(items, 16384)), dim3(256), 0, stream, *a);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_col2im4x4s2(const float* dcol, float* dx, int32_t F, int32_t H, int32_t W, int32_t Cin, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(dcol && dx && F > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 4 == 0, "bad arguments");
+    hipLaunchKernelGGL(col2im4x4s2_kernel, dim3(blocks_for((long long)F * H * W * (Cin / 4), 16384)), dim3(256), 0, stream, dcol, dx, F, H, W, Cin);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_im2col_image(const float* x, float* col, int32_t F, int32_t H, int32_t W, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(x && col && F > 0 && H % 2 == 0 && W % 2 == 0, "bad arguments");
+    hipLaunchKernelGGL(im2col_image_kernel, dim3(blocks_for((long long)F * (H / 2) * (W / 2) * 48, 16384)), dim3(256), 0, stream, x, col, F, H, W);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_dlm_nll_bwd(const float* params, const float* target, const float* row_weight, float scale, float* dparams,
+                                int32_t rows, int32_t npix, int32_t pitch, int32_t n_mix, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(params && target && dparams && rows > 0, "bad arguments");
+    GCPX_CHECK_ARG(n_mix == 10 && pitch == 112 && npix % 64 == 0, "supports 10 mixtures, pitch 112, npix % 64 == 0");
+    hipLaunchKernelGGL((dlm_nll_bwd_kernel<10, 112>), dim3(rows), dim3(256), 0, stream, params, target, row_weight, scale, dparams, npix);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_loss_heads_bwd(const gcpx_loss_args* a, float* dlen, float* dexist, float* dstate, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(a && a->seq_len && a->end_ind && a->pad_mask, "missing pointer");
+    hipLaunchKernelGGL(loss_heads_bwd_kernel, dim3(64), dim3(256), 0, stream, *a, dlen, dexist, dstate);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_repack(const float* theta, const int32_t* idx0, const int32_t* idx1, float* dst, int64_t n, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(theta && idx0 && dst && n > 0, "bad arguments");
+    hipLaunchKernelGGL(repack_kernel, dim3(blocks_for(n, 16384)), dim3(256), 0, stream, theta, idx0, idx1, dst, (long long)n);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_radam_step(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, float* state, int64_t n, float lr,
+                               float beta1, float beta2, float eps, float grad_scale, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(theta && grad && exp_avg && exp_avg_sq && state && n > 0, "bad arguments");
+    hipLaunchKernelGGL(radam_kernel, dim3(blocks_for(n, 16384)), dim3(256), 0, stream, theta, grad, exp_avg, exp_avg_sq, state,
+                       (long long)n, lr, beta1, beta2, eps, grad_scale);
+    hipLaunchKernelGGL(radam_tick_kernel, dim3(1), dim3(1), 0, stream, state);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}

@@ -133,9 +133,12 @@ conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty, const int n
             int s_c4, s_rx, s_ry, s_fl, s_lds;
             slot(k, s_c4, s_rx, s_ry, s_fl, s_lds);
             if (s_fl < 0) continue;
-            const int f = f0 + s_fl;
+            int f = f0 + s_fl;
             int sy, sx;
             bool ok = f < F;
+            if constexpr (!UP) {
+                if (ok && a.src_row_map) { f = a.src_row_map[f]; ok = f >= 0; }
+            }
             if constexpr (UP) {
                 sy = min(max(y0 / 2 - 1 + s_ry, 0), a.Hin - 1);
                 sx = min(max(x0 / 2 - 1 + s_rx, 0), a.Win - 1);
@@ -952,12 +955,24 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
     GCPX_CHECK_ARG(!need_out || a->out_pitch % 4 == 0, "out_pitch % 4");
     const int W = a->Wout;
     if (!a->upsample) {
-        GCPX_CHECK_ARG(a->Cin == 16, "non-upsampling 3x3 conv (output head) expects 16 input channels");
-        GCPX_CHECK_ARG(a->nsrc == 1 && a->src[0].frame_div == 1, "output head takes one per-frame source");
-        if (W % 16 == 0 && a->Hout % 4 == 0) {
+        GCPX_CHECK_ARG(a->nsrc == 1 && a->src[0].frame_div == 1, "non-upsampling 3x3 conv takes one per-frame source");
+        if (a->Cin == 16 && !a->src_row_map && W % 16 == 0 && a->Hout % 4 == 0) {
             if (CT == 7) return query_only ? gcpx_conv_grid() / 2 : launch_head<7>(a, stream);
             if (CT == 1) return query_only ? gcpx_conv_grid() / 2 : launch_head<1>(a, stream);
         }
+        // data gradients of the decoder blocks (3x3 conv with the transposed, flipped weights): workgroup-tiled kernel
+        GCPX_CHECK_ARG(a->head_mode == GCPX_HEAD_RAW && !a->stats_partial, "plain 3x3 conv stores raw output, no statistics");
+        const int tile = W >= 32 ? 0 : (W == 16 ? 1 : (W == 8 ? 2 : -1));
+#define GCPX_PLAIN(CC_, CT_)                                                            \
+        do {                                                                            \
+            if (tile == 0) return launch<false, CC_, CT_, 0>(a, stream, query_only);    \
+            if (tile == 1) return launch<false, CC_, CT_, 1>(a, stream, query_only);    \
+            if (tile == 2) return launch<false, CC_, CT_, 2>(a, stream, query_only);    \
+        } while (0)
+        if (a->Cin % 16 == 0 && CT == 4) GCPX_PLAIN(16, 4);
+        if (a->Cin % 16 == 0 && CT == 2) GCPX_PLAIN(16, 2);
+        if (a->Cin % 16 == 0 && CT == 1) GCPX_PLAIN(16, 1);
+#undef GCPX_PLAIN
     } else {
         GCPX_CHECK_ARG(a->Cin % 32 == 0, "upsampling 3x3 conv expects Cin % 32 == 0");
         GCPX_CHECK_ARG(a->head_mode == GCPX_HEAD_RAW, "decoder blocks store raw output");

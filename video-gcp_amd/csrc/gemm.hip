@@ -127,6 +127,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
                     a.h_out[o] = h;
                     a.c_out[o] = c;
                     if (a.h_copy) a.h_copy[(size_t)rr[pt] * (a.N / 4) + u] = h;
+                    if (a.gates_out)
+                        *reinterpret_cast<float4*>(a.gates_out + ((size_t)rr[pt] * (a.N / 4) + u) * 4) = make_float4(ig, fg, gg, og);
                 }
             } else {
                 if (a.epi == GCPX_EPI_LRELU) {

@@ -31,7 +31,8 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ beta, const float eps,
                                                           float* __restrict__ scale, float* __restrict__ shift,
                                                           float* running_mean, float* running_var,
-                                                          const float momentum) {
+                                                          const float momentum, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out) {
     const int c = blockIdx.x;
     const int rep = pitch / C;
     double s1 = 0.0, s2 = 0.0;
@@ -58,6 +59,7 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
         const float sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
         scale[c] = sc;
         shift[c] = beta[c] - (float)mean * sc;
+        if (mean_out) { mean_out[c] = (float)mean; rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps)); }
         if (running_mean) {
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
@@ -269,12 +271,14 @@ extern "C" int gcpx_masked_row_sum(const float* vals, const int32_t* lengths, fl
 
 extern "C" int gcpx_bn_finalize(const float* partial, int32_t n_partial, int32_t pitch, int32_t C, double count,
                                 const float* gamma, const float* beta, float eps, float* scale, float* shift,
-                                float* running_mean, float* running_var, float momentum, void* stream_) {
+                                float* running_mean, float* running_var, float momentum, float* mean_out,
+                                float* rstd_out, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(partial && gamma && beta && scale && shift, "null pointer");
+    GCPX_CHECK_ARG((mean_out == nullptr) == (rstd_out == nullptr), "mean_out and rstd_out go together");
     GCPX_CHECK_ARG(n_partial > 0 && C > 0 && pitch >= C && pitch % C == 0 && count > 0, "bad sizes");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, partial, n_partial, pitch, C, count, gamma,
-                       beta, eps, scale, shift, running_mean, running_var, momentum);
+                       beta, eps, scale, shift, running_mean, running_var, momentum, mean_out, rstd_out);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

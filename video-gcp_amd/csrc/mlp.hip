@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
             float4 v = make_float4(lrelu(acc[t][0] + bv.x, slope), lrelu(acc[t][1] + bv.y, slope),
                                    lrelu(acc[t][2] + bv.z, slope), lrelu(acc[t][3] + bv.w, slope));
             *reinterpret_cast<float4*>(hid + j * PITCH + c) = v;
+            if (a.save && rv && blockIdx.y == 0) *reinterpret_cast<float4*>(a.save + (size_t)r * MID + c) = v;
         }
     }
     __syncthreads();
@@ -140,6 +141,11 @@ __global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
                 float4 o = make_float4(lrelu(d0 * rstd * gv.x + be.x, slope), lrelu(d1 * rstd * gv.y + be.y, slope),
                                        lrelu(d2 * rstd * gv.z + be.z, slope), lrelu(d3 * rstd * gv.w + be.w, slope));
                 *reinterpret_cast<float4*>(hout + j * PITCH + c) = o;
+                if (a.save && rv && blockIdx.y == 0) {
+                    float* sv = a.save + (size_t)(1 + 2 * l) * a.M * MID + (size_t)r * MID + c;
+                    *reinterpret_cast<float4*>(sv) = make_float4(v0, v1, v2, v3);
+                    *reinterpret_cast<float4*>(sv + (size_t)a.M * MID) = o;
+                }
             }
         }
         cur ^= 1;

@@ -1,0 +1,262 @@
+// Weight gradients on gfx950 f32 MFMA:   dW[n][k] = sum_r dY[r][n] * X[r][k]      ("TN" GEMM, reduction over rows)
+//
+// Backward of every Linear / LSTMCell / Conv1d / Conv2d of the gcp_tree training step
+// (/root/reference/gcp/prediction/train.py:155-163 `losses.total.value.backward()`; the reference relies on torch
+// autograd, this build has no autograd: each wgrad is an explicit launch of this kernel).
+//
+// Both operands are row-major with the reduction index r as the slow dimension, so the MFMA k index (4 rows per
+// step) is the strided one and the i / j sides are contiguous in memory.  A lane loads 16 B = 4 consecutive columns
+// of its row for each operand and treats them as 4 different MFMA tiles (tile t holds columns 4*i + t): one pair of
+// float4 loads feeds 16 MFMAs and a wavefront owns a 64 x 64 block of dW.  X can be addressed as plain rows (with
+// gather / shift, like gcpx_row_src) or as the implicit im2col of a conv1d(3) / conv3x3(pad 1) / conv4x4(stride 2,
+// pad 1) input in NHWC, optionally with the producer's BatchNorm affine + LeakyReLU applied on load.
+// The row range can be split over blockIdx.z; partial results are combined by gcpx_wgrad_reduce in a fixed order
+// (deterministic), which also maps (n, k) to the canonical torch parameter layout.
+#include "common.cuh"
+
+namespace {
+
+__device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
+
+template <int TA>
+__global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ij = lane & 15, kk = lane >> 4;
+    const int k0 = (blockIdx.x * 4 + wave) * 64;
+    if (k0 >= a.K) return;                       // no barriers below: whole wavefronts may leave
+    const int n0 = blockIdx.y * (TA == 4 ? 64 : 16);
+    const int nsplit = gridDim.z;
+    const int rows_per = (((a.R + nsplit - 1) / nsplit) + 3) & ~3;
+    const int r_begin = blockIdx.z * rows_per;
+    const int r_end = min(a.R, r_begin + rows_per);
+
+    // ---- per-lane constants of the X (B operand) column group ----
+    const int kcol = k0 + 4 * ij;
+    const bool kvalid = kcol < a.K;
+    int tap = 0, ci = kcol;
+    if (a.mode != GCPX_WG_ROWS) {
+        tap = kvalid ? kcol / a.Cin : 0;
+        ci = kcol - tap * a.Cin;
+    }
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool xf = a.scale != nullptr;
+    if (xf && kvalid) {
+        const int c = (a.mode == GCPX_WG_ROWS) ? (kcol & (a.cmod - 1)) : ci;
+        sc = *reinterpret_cast<const float4*>(a.scale + c);
+        sh = *reinterpret_cast<const float4*>(a.shiftv + c);
+    }
+    const int act = a.act;
+    const int lw = ilog2(a.W > 0 ? a.W : 1), lh = ilog2(a.H > 0 ? a.H : 1);
+    int dyo = 0, dxo = 0;
+    if (a.mode == GCPX_WG_CONV3X3) { dyo = tap / 3 - 1; dxo = tap % 3 - 1; }
+    if (a.mode == GCPX_WG_CONV4X4S2) { dyo = tap / 4 - 1; dxo = tap % 4 - 1; }
+    const int shift = (a.mode == GCPX_WG_CONV1D) ? tap - 1 : a.shift;
+    const bool dense = (a.mode == GCPX_WG_ROWS) && a.rowidx == nullptr && a.shift == 0 && a.sb == a.sr * a.rpb;
+
+    // ---- A operand column(s) ----
+    const int ncol = n0 + (TA == 4 ? 4 * ij : ij);
+    const bool nvalid = ncol < a.N;
+
+    f32x4 acc[TA][4];
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = f32x4{0, 0, 0, 0};
+
+    constexpr int UNR = 2;
+    for (int r0 = r_begin; r0 < r_end; r0 += 4 * UNR) {
+        float4 av[UNR], bv[UNR];
+        bool bok[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int row = r0 + 4 * u + kk;
+            const bool rvalid = row < r_end;
+            av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bok[u] = false;
+            if (rvalid && nvalid) {
+                const float* ap;
+                if (a.dy_sb) {
+                    const int b = row / a.dy_rpb;
+                    ap = a.dy + (size_t)b * a.dy_sb + (size_t)(row - b * a.dy_rpb) * a.ldy + ncol;
+                } else {
+                    ap = a.dy + (size_t)row * a.ldy + ncol;
+                }
+                if (TA == 4) av[u] = *reinterpret_cast<const float4*>(ap);
+                else av[u].x = *ap;
+            }
+            if (rvalid && kvalid) {
+                const float* xp = nullptr;
+                if (a.mode == GCPX_WG_ROWS || a.mode == GCPX_WG_CONV1D) {
+                    if (dense) {
+                        xp = a.x + (size_t)row * a.sr + ci;
+                    } else if (a.rowidx) {
+                        xp = a.x + (size_t)a.rowidx[row] * a.sr + ci;
+                    } else {
+                        const int b = row / a.rpb, j = row - b * a.rpb + shift;
+                        if (j >= 0 && j < a.rpb) xp = a.x + (size_t)b * a.sb + (size_t)j * a.sr + ci;
+                    }
+                } else if (a.mode == GCPX_WG_CONV3X3) {
+                    const int x = row & (a.W - 1), y = (row >> lw) & (a.H - 1);
+                    int f = row >> (lw + lh);
+                    if (a.frame_map) f = a.frame_map[f];
+                    const int iy = y + dyo, ix = x + dxo;
+                    if (f >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                        xp = a.x + (((size_t)f * a.H + iy) * a.W + ix) * a.Cin + ci;
+                } else {   // 4x4 stride 2 pad 1: rows are output pixels (H/2 x W/2), X is the H x W input
+                    const int ox = row & ((a.W >> 1) - 1), oy = (row >> (lw - 1)) & ((a.H >> 1) - 1);
+                    int f = row >> (lw + lh - 2);
+                    if (a.frame_map) f = a.frame_map[f];
+                    const int iy = 2 * oy + dyo, ix = 2 * ox + dxo;
+                    if (f >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                        xp = a.x + (((size_t)f * a.H + iy) * a.W + ix) * a.Cin + ci;
+                }
+                if (xp) { bv[u] = *reinterpret_cast<const float4*>(xp); bok[u] = true; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            float4 b = bv[u];
+            if (bok[u] && (xf || act)) {
+                b.x = fmaf(b.x, sc.x, sh.x); b.y = fmaf(b.y, sc.y, sh.y); b.z = fmaf(b.z, sc.z, sh.z); b.w = fmaf(b.w, sc.w, sh.w);
+                if (act == GCPX_ACT_LRELU) { b.x = lrelu(b.x, 0.2f); b.y = lrelu(b.y, 0.2f); b.z = lrelu(b.z, 0.2f); b.w = lrelu(b.w, 0.2f); }
+            }
+            const float aa[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
+            const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = mfma16(aa[ta], bb[tb], acc[ta][tb]);
+        }
+    }
+
+    // ---- store: lane holds dW[n][k .. k+3] for n = n0 + {TA==4: 16*kk + 4*reg + ta | 4*kk + reg}, k = k0 + 4*ij ----
+    if (!kvalid) return;
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int n = n0 + (TA == 4 ? 16 * kk + 4 * reg + ta : 4 * kk + reg);
+            if (n >= a.n_valid) continue;
+            float4 v = make_float4(acc[ta][0][reg], acc[ta][1][reg], acc[ta][2][reg], acc[ta][3][reg]);
+            float* op;
+            if (a.partial) op = a.out + ((size_t)blockIdx.z * a.n_valid + n) * a.K + kcol;
+            else op = a.out + (size_t)n * a.ldw + a.k_off + kcol;
+            if (!a.partial && a.accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(op);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4*>(op) = v;
+        }
+    }
+}
+
+// partial [nsplit][N][K] -> dst in the canonical parameter layout
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, const int nsplit, const int N,
+                                                           const int K, float* __restrict__ dst, const int map_mode,
+                                                           const int Cin, const int ntap, const int Cout,
+                                                           const int* __restrict__ n_map, const long long ldw,
+                                                           const int k_off, const int accumulate) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * K) return;
+    const int n = (int)(idx / K), k = (int)(idx % K);
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += partial[(size_t)z * N * K + idx];
+    long long o;
+    if (map_mode == GCPX_WMAP_LINEAR) {
+        o = (long long)n * ldw + k_off + k;
+    } else if (map_mode == GCPX_WMAP_CONV) {          // k = (tap, ci) -> w[n][ci][tap]
+        const int nn = n_map ? n_map[n] : n;
+        if (nn < 0) return;
+        const int tap = k / Cin, ci = k % Cin;
+        o = ((long long)nn * Cin + ci) * ntap + tap;
+    } else {                                           // ConvTranspose 1x1 -> 4x4: n = (tap, co), k = ci -> w[ci][co][tap]
+        const int tap = n / Cout, co = n % Cout;
+        o = ((long long)k * Cout + co) * ntap + tap;
+    }
+    dst[o] = accumulate ? dst[o] + s : s;
+}
+
+// column sums: db[n] (+)= sum_r dY[r][n]; one workgroup per 64 columns (x) and row split (y), 4 wavefronts split the rows
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ dy, const long long ldy, const int R, const int N,
+                                                     const int dy_rpb, const long long dy_sb, float* __restrict__ partial,
+                                                     float* __restrict__ dst, float* __restrict__ dst2, const int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int nsplit = gridDim.y;
+    const int rows_per = (R + nsplit - 1) / nsplit;
+    const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+    float s = 0.f;
+    if (n < N) {
+        for (int r = r0 + wave; r < r1; r += 4) {
+            size_t o;
+            if (dy_sb) { const int b = r / dy_rpb; o = (size_t)b * dy_sb + (size_t)(r - b * dy_rpb) * ldy; }
+            else o = (size_t)r * ldy;
+            s += dy[o + n];
+        }
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && n < N) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (nsplit > 1) {
+            partial[(size_t)blockIdx.y * N + n] = t;
+        } else {
+            dst[n] = accumulate ? dst[n] + t : t;
+            if (dst2) dst2[n] = accumulate ? dst2[n] + t : t;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(a != nullptr, "null args");
+    GCPX_CHECK_ARG(a->dy && a->x && a->out, "dy / x / out is NULL");
+    GCPX_CHECK_ARG(a->R > 0 && a->N > 0 && a->K > 0 && a->K % 4 == 0, "bad R/N/K (K % 4)");
+    GCPX_CHECK_ARG(a->n_valid > 0 && a->n_valid <= a->N, "n_valid out of range");
+    GCPX_CHECK_ARG(a->nsplit >= 1 && (a->partial || a->nsplit == 1), "row splits need partial output");
+    GCPX_CHECK_ARG(a->mode >= GCPX_WG_ROWS && a->mode <= GCPX_WG_CONV4X4S2, "bad mode");
+    GCPX_CHECK_ARG(a->dy_sb == 0 || a->dy_rpb > 0, "dy_rpb <= 0");
+    if (a->mode == GCPX_WG_ROWS || a->mode == GCPX_WG_CONV1D) GCPX_CHECK_ARG(a->rpb > 0, "rpb <= 0");
+    if (a->mode != GCPX_WG_ROWS) GCPX_CHECK_ARG(a->Cin > 0 && a->Cin % 4 == 0 && a->K % a->Cin == 0, "conv modes: K = ntap * Cin");
+    if (a->mode == GCPX_WG_CONV3X3 || a->mode == GCPX_WG_CONV4X4S2)
+        GCPX_CHECK_ARG(a->H > 1 && a->W > 1 && (a->H & (a->H - 1)) == 0 && (a->W & (a->W - 1)) == 0, "conv modes: H, W powers of two");
+    GCPX_CHECK_ARG(!a->scale || a->mode != GCPX_WG_ROWS || (a->cmod > 0 && (a->cmod & (a->cmod - 1)) == 0), "cmod must be a power of two");
+    const int kch = (a->K + 63) / 64;
+    const bool wide = a->N > 16;
+    GCPX_CHECK_ARG(!wide || (a->N % 4 == 0 && a->ldy % 4 == 0), "N > 16 needs N % 4 == 0 and ldy % 4 == 0");
+    GCPX_CHECK_ARG(a->partial || (a->ldw % 4 == 0 && a->k_off % 4 == 0), "direct output needs ldw, k_off % 4 == 0");
+    dim3 grid((kch + 3) / 4, wide ? (a->N + 63) / 64 : 1, a->nsplit);
+    if (wide) hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, stream, *a);
+    else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, stream, *a);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_wgrad_reduce(const float* partial, int32_t nsplit, int32_t N, int32_t K, float* dst, int32_t map_mode,
+                                 int32_t Cin, int32_t ntap, int32_t Cout, const int32_t* n_map, int64_t ldw, int32_t k_off,
+                                 int32_t accumulate, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(partial && dst && nsplit >= 1 && N > 0 && K > 0, "bad arguments");
+    GCPX_CHECK_ARG(map_mode >= GCPX_WMAP_LINEAR && map_mode <= GCPX_WMAP_CONVT, "bad map_mode");
+    const long long total = (long long)N * K;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, nsplit, N, K,
+                       dst, map_mode, Cin, ntap, Cout, n_map, (long long)ldw, k_off, accumulate);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_colsum(const float* dy, int64_t ldy, int32_t R, int32_t N, int32_t dy_rpb, int64_t dy_sb, int32_t nsplit,
+                           float* partial, float* dst, float* dst2, int32_t accumulate, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(dy && R > 0 && N > 0 && nsplit >= 1, "bad arguments");
+    GCPX_CHECK_ARG(nsplit > 1 ? partial != nullptr : dst != nullptr, "missing output");
+    GCPX_CHECK_ARG(dy_sb == 0 || dy_rpb > 0, "dy_rpb <= 0");
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, nsplit), dim3(256), 0, stream, dy, (long long)ldy, R, N, dy_rpb,
+                       (long long)dy_sb, partial, dst, dst2, accumulate);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}

@@ -42,6 +42,7 @@ class _Plan:
         self.keep = []       # keeps argument structs / tensors alive
         self.graph = None
         self.lane = 0
+        self.rec = {}        # buffers / records the backward plan is built from (training step)
 
     def add(self, name, fn, *args):
         self.ops.append((name, fn, args, self.lane))
@@ -93,7 +94,7 @@ class GCPTreeModel:
         self.device = torch.device(device)
         self.lib = rt.load_library()          # raises if the HIP extension is missing
         self._check_hp(hp)
-        self.sd = {k: v.to(self.device) for k, v in (params or self._default_params(hp, seed)).items()}
+        self._flatten_params(params or self._default_params(hp, seed))
         self.training = True                  # BatchNorm uses batch statistics (reference trains and validates so)
         self._sample_prior = False            # ProbabilisticModel._sample_prior (switched by val_mode)
         self._use_pred_length = False
@@ -110,9 +111,25 @@ class GCPTreeModel:
             with torch.cuda.device(self.device):
                 rt.check(self.lib.gcpx_stream_create(C.byref(sp)), "stream_create")
             self._streams.append(sp)
+        self.save_for_backward = False        # training step: forward plans keep what the backward pass needs
         self._timed_op = None                 # name of one plan op bracketed by HIP events (bench.py roofline)
         self._timed_events = []
         self._pack_all()
+
+    def _flatten_params(self, params):
+        """All parameters live in ONE flat fp32 vector `theta` (canonical torch layouts, 16-byte aligned segments);
+        `self.sd` holds views.  The optimizer, the gradient all-reduce and the re-pack gather work on the flat vector."""
+        off, self._poff = 0, {}
+        for k, v in params.items():
+            self._poff[k] = (off, tuple(v.shape))
+            off += (v.numel() + 3) // 4 * 4
+        self.theta = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.sd = {}
+        for k, v in params.items():
+            o, shp = self._poff[k]
+            view = self.theta[o:o + v.numel()].view(shp)
+            view.copy_(v)
+            self.sd[k] = view
 
     def _check_hp(self, hp):
         assert hp.matching_type == "balanced" and hp.tree_lstm == "split_linear" and hp.lstm_init == "mlp"
@@ -161,7 +178,7 @@ class GCPTreeModel:
     # weight packing
     # ------------------------------------------------------------------------------------------------
     def _pack_predictor(self, prefix, out_dim):
-        sd = self.sd
+        sd = self._psd
         mid = sd[f"{prefix}.input.linear.weight"].shape[0]
         n_mid = 0
         while f"{prefix}.pyramid-{n_mid}.linear.weight" in sd:
@@ -180,7 +197,17 @@ class GCPTreeModel:
         return d
 
     def _pack_all(self):
-        hp, sd = self._hp, self.sd
+        """(Re)build every fragment-packed weight from the canonical parameters.  Once a parameter arena exists
+        (training: `build_arena`), re-packing is ONE gather launch over the flat parameter vector."""
+        if getattr(self, "_arena", None) is not None:
+            self.repack()
+            return
+        self.pk = self._pack_tree(self.sd)
+
+    def _pack_tree(self, sd):
+        """Pure index shuffling of `sd` (any dtype) into the kernels' layouts: {name: tensor | nested dict}."""
+        hp = self._hp
+        self._psd = sd
         P = {}
         layers, c_top = encoder_layers(hp)
         self._enc_layers, self._c_top = layers, c_top
@@ -204,9 +231,10 @@ class GCPTreeModel:
             perm = pk.dlm_channel_perm(hp.n_mixtures)
             self._dlm_perm = torch.tensor(perm, device=self.device)
             P["dec.head.w"] = pk.pack_conv3x3(hw, 16, perm=perm)
-            bk = torch.zeros(len(perm), device=self.device)
-            valid = self._dlm_perm >= 0
-            bk[valid] = hb[self._dlm_perm[valid]]
+            bk = torch.zeros(len(perm), device=hb.device, dtype=hb.dtype)
+            permd = self._dlm_perm.to(hb.device)
+            valid = permd >= 0
+            bk[valid] = hb[permd[valid]]
             P["dec.head.b"] = bk
             self._head_pitch = len(perm)
         else:
@@ -226,11 +254,63 @@ class GCPTreeModel:
         if hp.attach_cost_mdl:
             P["cost_mdl"] = self._pack_predictor("cost_mdl.cost_pred", 1)
         self._pack_latent_model(P)
-        self.pk = P
+        return P
+
+    # ---- parameter arena: every packed weight is a gather of the flat parameter vector ----
+    def build_arena(self, extra_pack=None):
+        """Probe the (linear, 0/1) packing map once with index-valued parameters, then keep all packed weights in one
+        arena refreshed by gcpx_repack.  `extra_pack(sd) -> dict` adds more packs (the transposed ones of the backward)."""
+        dev = self.device
+        def probe(only_hh):
+            sd = {}
+            for k, (o, shp) in self._poff.items():
+                n = 1
+                for d in shp:
+                    n *= d
+                hh = k.endswith("bias_hh")
+                if hh == only_hh:
+                    sd[k] = (torch.arange(n, device=dev, dtype=torch.float64) + (o + 1)).view(shp)
+                else:
+                    sd[k] = torch.zeros(shp, device=dev, dtype=torch.float64)
+            P = self._pack_tree(sd)
+            X = extra_pack(sd) if extra_pack is not None else {}
+            return P, X
+        (P0, X0), (P1, X1) = probe(False), probe(True)
+        leaves = []
+        def walk(d0, d1, path):
+            for k in d0:
+                if isinstance(d0[k], dict):
+                    walk(d0[k], d1[k], path + (k,))
+                elif torch.is_tensor(d0[k]):
+                    leaves.append((path + (k,), d0, d0[k], d1[k]))
+        walk(P0, P1, ("P",))
+        walk(X0, X1, ("X",))
+        total = sum((t.numel() + 3) // 4 * 4 for _, _, t, _ in leaves)
+        self._arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        idx0 = torch.full((total,), -1, dtype=torch.int32, device=dev)
+        idx1 = torch.full((total,), -1, dtype=torch.int32, device=dev)
+        off = 0
+        for path, holder, t0, t1 in leaves:
+            n = t0.numel()
+            idx0[off:off + n] = (t0.reshape(-1) - 1).to(torch.int32)
+            idx1[off:off + n] = (t1.reshape(-1) - 1).to(torch.int32)
+            holder[path[-1]] = self._arena[off:off + n].view(t0.shape)
+            off += (n + 3) // 4 * 4
+        self._arena_idx0, self._arena_idx1 = idx0, idx1
+        self._psd = self.sd
+        self.pk = P0
+        self._plans.clear()
+        self.repack()
+        return X0
+
+    def repack(self, stream=None):
+        st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        rt.check(self.lib.gcpx_repack(self.theta.data_ptr(), self._arena_idx0.data_ptr(), self._arena_idx1.data_ptr(),
+                                      self._arena.data_ptr(), self._arena.numel(), st), "repack")
 
     def _pack_hsp(self, prefix, n_layers):
         """embed Linear + n gate-interleaved LSTM layers + out Linear of one recurrent predictor."""
-        sd, T = self.sd, {}
+        sd, T = self._psd, {}
         T["embed.w"] = pk.pack_gemm(sd[f"{prefix}.embed.weight"])
         T["embed.b"] = sd[f"{prefix}.embed.bias"].contiguous()
         for i in range(n_layers):
@@ -242,7 +322,7 @@ class GCPTreeModel:
         return T
 
     def _pack_latent_model(self, P):
-        hp, sd = self._hp, self.sd
+        hp, sd = self._hp, self._psd
         P["existence"] = self._pack_predictor("tree_module.tree_modules.0.binding.existence_predictor", 1)
         H = hp.nz_mid_lstm
         for l in range(hp.hierarchy_levels if hp.untied_layers else 1):
@@ -296,6 +376,10 @@ class GCPTreeModel:
         a.stats_partial = stats.data_ptr() if stats is not None else None
         if lstm is not None:
             a.c_prev, a.c_prev_stride, a.h_out, a.c_out, a.hb, a.hrow, a.h_copy = lstm
+            if self.save_for_backward:
+                g = self._buf(f"gates.{name}", (M, N))
+                a.gates_out = g.data_ptr()
+                plan.rec[f"gates:{name}"] = g
         if batch is not None:
             a.nbatch, a.z_src_off, a.z_w_off, a.z_bias_off, a.z_out_off = batch
         plan.keep.append(a)
@@ -320,6 +404,10 @@ class GCPTreeModel:
         if gauss is not None:
             a.epi = rt.MLP_GAUSS
             a.eps, a.eb, a.erow, a.z, a.zb, a.zrow = gauss
+        if self.save_for_backward:
+            sv = self._buf(f"save.{name}", (1 + 2 * W["n_mid"], M, W["mid"]))
+            a.save = sv.data_ptr()
+            plan.rec[f"mlp:{name}"] = dict(W=W, srcs=srcs, M=M, rpb=rpb, save=sv)
         plan.keep.append(a)
         plan.add(name, self.lib.gcpx_mlp, C.byref(a))
 
@@ -329,9 +417,13 @@ class GCPTreeModel:
         scale, shift = self._buf(f"{tag}.scale", (C_,)), self._buf(f"{tag}.shift", (C_,))
         g, b = sd[f"{prefix}.weight"], sd[f"{prefix}.bias"]
         if self.training:
+            mean = rstd = None
+            if self.save_for_backward:
+                mean, rstd = self._buf(f"{tag}.mean", (C_,)), self._buf(f"{tag}.rstd", (C_,))
+                plan.rec[f"bn:{tag}"] = dict(prefix=prefix, C=C_, count=count, scale=scale, shift=shift, mean=mean, rstd=rstd)
             plan.add(f"bn_finalize:{tag}", self.lib.gcpx_bn_finalize, stats.data_ptr(), n_partial, pitch, C_,
                      C.c_double(float(count)), g.data_ptr(), b.data_ptr(), C.c_float(hp.bn_eps), scale.data_ptr(),
-                     shift.data_ptr(), None, None, C.c_float(0.0))
+                     shift.data_ptr(), None, None, C.c_float(0.0), rt.ptr(mean), rt.ptr(rstd))
         else:
             plan.add(f"bn_fold:{tag}", self.lib.gcpx_bn_fold, sd[f"{prefix}.running_mean"].data_ptr(),
                      sd[f"{prefix}.running_var"].data_ptr(), g.data_ptr(), b.data_ptr(), C.c_float(hp.bn_eps), C_,
@@ -368,6 +460,8 @@ class GCPTreeModel:
         skip_idx = encoder_skip_layers(hp)
         skips = {}
         a0 = self._buf(f"{tag}.a0", (F, S // 2, S // 2, hp.ngf))
+        enc_rec = dict(F=F, x_ptr=x_ptr, a0=a0, r={}, out=(out_ptr, out_ob, out_orow, out_rpb))
+        plan.rec[f"enc:{tag}"] = enc_rec
         plan.add(f"enc.input:{tag}", lib.gcpx_conv4x4s2_image, x_ptr, P["enc.input.w"].data_ptr(),
                  P["enc.input.b"].data_ptr(), a0.data_ptr(), F, S, S, hp.ngf, rt.ACT_LRELU)
         prev = (a0.data_ptr(), hp.ngf, 1, None, None, rt.ACT_NONE)
@@ -376,6 +470,7 @@ class GCPTreeModel:
         res = S // 2
         for li, (name, cin, cout, norm) in enumerate(self._enc_layers[1:], start=1):
             r = self._buf(f"{tag}.r{li}", (F, res // 2, res // 2, cout))
+            enc_rec["r"][li] = r
             stats = self._buf(f"{tag}.st{li}", (G, 2, cout)) if self.training else None
             a = self._conv_args([prev], F, res, res, res // 2, res // 2, cout, cout, P[f"enc.{name}.w"],
                                 P[f"enc.{name}.b"], r, stats=stats)
@@ -403,6 +498,7 @@ class GCPTreeModel:
         hp, P, lib = self._hp, self.pk, self.lib
         ctop = self._c_top
         d0 = self._buf("dec.d0", (F, 4, 4, ctop))
+        plan.rec["dec"] = dict(F=F, rpb=rpb, e_src=e_src, d0=d0, blocks=[], skips=skips)
         nrb = lib.gcpx_gemm_row_blocks(F, 16 * ctop)
         st = self._buf("dec.st0", (nrb, 2, 16 * ctop)) if self.training else None
         self._gemm(plan, "dec.input", [e_src], F, 16 * ctop, rpb, P["dec.input.w"], P["dec.input.b"], out=d0.data_ptr(),
@@ -426,6 +522,8 @@ class GCPTreeModel:
             a.stats_partial = st.data_ptr() if st is not None else None
             plan.keep.append(a)
             plan.add(f"dec.{name}", lib.gcpx_conv3x3, C.byref(a))
+            plan.rec["dec"]["blocks"].append(dict(name=name, srcs=srcs, out=o, res_in=res, cout=cout, c_prev=c_prev, c_skip=c_skip,
+                                                  skip_idx=skip_idx))
             res *= 2
             sc, sh = self._bn(plan, f"dec.bn.{name}", f"decoder.net.{name}.norm", cout, st, Gl, cpad, F * res * res)
             prev = (o.data_ptr(), cout, 1, sc, sh, rt.ACT_LRELU)
@@ -676,7 +774,10 @@ class GCPTreeModel:
             outs["matched_distr_kernel_order"] = matched_distr
 
         outs.update(E=E, Hid=Hid, Z=Z, PZ=PZ, QZ=QZ, node_t=node_t, leave=leave, frame2node=f2n, seq_len=seq_len,
-                    kept_idx=kept_idx, enc_traj_seq=enc_traj, inf_enc_seq=inf_enc)
+                    kept_idx=kept_idx, enc_traj_seq=enc_traj, inf_enc_seq=inf_enc, node2row=node2row, etilde_row=etrow)
+        plan.rec.update(head_src=prev, tin=tin, key=key)
+        if with_loss:
+            plan.rec["loss_args"] = la
         plan.outs = outs
         return plan
 

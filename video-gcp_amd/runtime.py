@@ -27,7 +27,7 @@ class ConvArgs(C.Structure):
     _fields_ = [("src", ConvSrc * 2), ("nsrc", i32), ("F", i32), ("Hin", i32), ("Win", i32), ("Hout", i32),
                 ("Wout", i32), ("Cin", i32), ("Cout", i32), ("out_pitch", i32), ("upsample", i32), ("out_act", i32),
                 ("head_mode", i32), ("wpk", vp), ("bias", vp), ("out", vp), ("images", vp), ("stats_partial", vp),
-                ("raw_row_map", vp)]
+                ("raw_row_map", vp), ("src_row_map", vp)]
 
 
 class LossArgs(C.Structure):
@@ -47,7 +47,7 @@ class GemmArgs(C.Structure):
                 ("wpk", vp), ("bias", vp), ("out", vp), ("ob", i64), ("orow", i64), ("epi", i32), ("nbatch", i32),
                 ("stats_partial", vp), ("c_prev", vp), ("c_prev_stride", i64), ("h_out", vp), ("c_out", vp),
                 ("hb", i64), ("hrow", i64), ("h_copy", vp), ("z_src_off", i64), ("z_w_off", i64),
-                ("z_bias_off", i64), ("z_out_off", i64)]
+                ("z_bias_off", i64), ("z_out_off", i64), ("gates_out", vp)]
 
 
 class MlpArgs(C.Structure):
@@ -55,8 +55,41 @@ class MlpArgs(C.Structure):
                 ("n_mid", i32), ("out_dim", i32), ("w_in", vp), ("b_in", vp), ("w_mid", vp), ("b_mid", vp),
                 ("gn_gamma", vp), ("gn_beta", vp), ("w_out", vp), ("b_out", vp), ("gn_eps", C.c_float),
                 ("lrelu_slope", C.c_float), ("epi", i32), ("out_split", i32), ("out", vp), ("ob", i64), ("orow", i64),
-                ("oblk", i64), ("eps", vp), ("eb", i64), ("erow", i64), ("z", vp), ("zb", i64), ("zrow", i64)]
+                ("oblk", i64), ("eps", vp), ("eb", i64), ("erow", i64), ("z", vp), ("zb", i64), ("zrow", i64), ("save", vp)]
 
+
+class WgradArgs(C.Structure):
+    _fields_ = [("dy", vp), ("x", vp), ("rowidx", vp), ("frame_map", vp), ("scale", vp), ("shiftv", vp), ("out", vp),
+                ("ldy", i64), ("sb", i64), ("sr", i64), ("ldw", i64), ("dy_sb", i64), ("R", i32), ("N", i32), ("n_valid", i32),
+                ("K", i32), ("mode", i32), ("Cin", i32), ("H", i32), ("W", i32), ("rpb", i32), ("shift", i32),
+                ("act", i32), ("cmod", i32), ("k_off", i32), ("accumulate", i32), ("partial", i32), ("nsplit", i32),
+                ("dy_rpb", i32), ("_pad", i32)]
+
+
+class LstmBwdArgs(C.Structure):
+    _fields_ = [("gates", vp), ("c_prev", vp), ("c_new", vp), ("dh_dense", vp), ("dh_pos", vp), ("dc_pos", vp),
+                ("dgates", vp), ("dc_prev", vp), ("c_prev_stride", i64), ("pb", i64), ("prow", i64), ("dh_stride", i64),
+                ("dcp_stride", i64), ("M", i32), ("H", i32), ("rpb", i32), ("_pad", i32)]
+
+
+class TreeAccumSrc(C.Structure):
+    _fields_ = [("ptr", vp), ("ld", i64), ("off_left", i32), ("off_right", i32), ("off_ctx0", i32), ("off_ctxg", i32),
+                ("dst_col", i32), ("_pad", i32)]
+
+
+class TreeAccumArgs(C.Structure):
+    _fields_ = [("src", TreeAccumSrc * 6), ("dst", vp), ("dst_sb", i64), ("slot_stride", i64), ("nsrc", i32), ("B", i32),
+                ("n", i32), ("width", i32)]
+
+
+class ActBwdArgs(C.Structure):
+    _fields_ = [("da", vp), ("add", vp), ("r", vp), ("scale", vp), ("shift", vp), ("mean", vp), ("rstd", vp), ("dy", vp),
+                ("stats_partial", vp), ("ldc", i64), ("c_off", i32), ("up", i32), ("fsum", i32), ("act", i32), ("F", i32),
+                ("H", i32), ("W", i32), ("C", i32)]
+
+
+WG_ROWS, WG_CONV1D, WG_CONV3X3, WG_CONV4X4S2 = 0, 1, 2, 3
+WMAP_LINEAR, WMAP_CONV, WMAP_CONVT = 0, 1, 2
 
 # every symbol include/gcpx.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -68,7 +101,7 @@ SYMBOLS = [
     ("gcpx_conv4x4s2", C.c_int, [C.POINTER(ConvArgs), vp]),
     ("gcpx_conv4x4s2_grid", C.c_int, []),
     ("gcpx_conv4x4s2_image", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-    ("gcpx_bn_finalize", C.c_int, [vp, i32, i32, i32, C.c_double, vp, vp, C.c_float, vp, vp, vp, vp, C.c_float, vp]),
+    ("gcpx_bn_finalize", C.c_int, [vp, i32, i32, i32, C.c_double, vp, vp, C.c_float, vp, vp, vp, vp, C.c_float, vp, vp, vp]),
     ("gcpx_bn_fold", C.c_int, [vp, vp, vp, vp, C.c_float, i32, vp, vp, vp]),
     ("gcpx_gemm", C.c_int, [C.POINTER(GemmArgs), vp]),
     ("gcpx_gemm_row_blocks", C.c_int, [i32, i32]),
@@ -86,6 +119,31 @@ SYMBOLS = [
     ("gcpx_compact_index", C.c_int, [vp, i32, i32, i32, vp, vp]),
     ("gcpx_seq_pairs", C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     ("gcpx_masked_row_sum", C.c_int, [vp, vp, vp, i32, i32, vp]),
+    ("gcpx_wgrad", C.c_int, [C.POINTER(WgradArgs), vp]),
+    ("gcpx_wgrad_reduce", C.c_int, [vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, i64, i32, i32, vp]),
+    ("gcpx_colsum", C.c_int, [vp, i64, i32, i32, i32, i64, i32, vp, vp, vp, i32, vp]),
+    ("gcpx_reduce_partials", C.c_int, [vp, i32, i64, i32, vp, i32, vp]),
+    ("gcpx_lstm_bwd", C.c_int, [C.POINTER(LstmBwdArgs), vp]),
+    ("gcpx_gn_lrelu_bwd", C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float, vp]),
+    ("gcpx_gn_bwd_blocks", C.c_int, [i32]),
+    ("gcpx_lrelu_bwd", C.c_int, [vp, vp, vp, i64, C.c_float, vp]),
+    ("gcpx_kl_bwd", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i64, i64, C.c_float, C.c_float, vp]),
+    ("gcpx_latent_bwd", C.c_int, [vp, vp, vp, i64, i64, vp, i64, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp]),
+    ("gcpx_tree_accum", C.c_int, [C.POINTER(TreeAccumArgs), vp]),
+    ("gcpx_timestep_scatter", C.c_int, [vp, i64, i64, vp, vp, i32, i32, i32, i32, vp]),
+    ("gcpx_add_rows", C.c_int, [vp, i64, i64, vp, vp, i32, i32, i32, vp]),
+    ("gcpx_index_offset", C.c_int, [vp, vp, i32, i32, i32, vp]),
+    ("gcpx_act_bwd", C.c_int, [C.POINTER(ActBwdArgs), vp]),
+    ("gcpx_act_bwd_blocks", C.c_int, []),
+    ("gcpx_bn_bwd_finalize", C.c_int, [vp, i32, i32, C.c_double, vp, vp, vp, vp, vp, i32, vp]),
+    ("gcpx_bn_bwd_apply", C.c_int, [vp, vp, vp, vp, vp, i64, i32, vp]),
+    ("gcpx_conv_stage", C.c_int, [C.POINTER(ConvArgs), vp]),
+    ("gcpx_col2im4x4s2", C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    ("gcpx_im2col_image", C.c_int, [vp, vp, i32, i32, i32, vp]),
+    ("gcpx_dlm_nll_bwd", C.c_int, [vp, vp, vp, C.c_float, vp, i32, i32, i32, i32, vp]),
+    ("gcpx_loss_heads_bwd", C.c_int, [C.POINTER(LossArgs), vp, vp, vp, vp]),
+    ("gcpx_repack", C.c_int, [vp, vp, vp, vp, i64, vp]),
+    ("gcpx_radam_step", C.c_int, [vp, vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     ("gcpx_graph_begin", C.c_int, [vp]),
     ("gcpx_graph_end", C.c_int, [vp, C.POINTER(vp)]),
     ("gcpx_graph_launch", C.c_int, [vp, vp]),

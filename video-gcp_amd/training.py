@@ -1,0 +1,643 @@
+"""Training step of the gcp_tree model on MI355X: forward + explicit backward + RAdam, all in HIP.
+
+Mirrors the reference's inner loop (/root/reference/gcp/prediction/train.py:155-163):
+    optimizer.zero_grad(); output = model(inputs); losses = model.loss(...); total = model.get_total_loss(...)
+    total.value.backward(); optimizer.step()
+with optimizer = RAdam(lr, betas=(adam_beta, 0.999)) (gcp_builder.py:88-89,178-179; gradient_clip defaults to None).
+
+The reference leans on torch autograd; here the backward pass is a second recorded launch plan, generated from the
+records the forward plan leaves behind (`plan.rec`), and replayed as a hipGraph:
+  * data gradients of Linear / Conv1d / ConvTranspose / strided-conv layers: gcpx_gemm with transposed weight packs;
+    of the decoder's 3x3 convs: gcpx_conv3x3 with flipped + transposed packs;
+  * weight gradients: gcpx_wgrad (f32 MFMA "TN" GEMM; convs as implicit im2col);
+  * everything in between (LSTM cell, GroupNorm, BatchNorm, bilinear upsample, skips broadcast, interleave, sampling,
+    losses): csrc/backward.hip.
+Gradients land in ONE flat fp32 vector laid out like `model.theta` (so the data-parallel all-reduce is a single RCCL
+call over one buffer) and the optimizer + the re-pack of the MFMA-ordered weights are one launch each.
+"""
+import ctypes as C
+
+import torch
+
+from . import packing as pk
+from . import runtime as rt
+from .model import _Plan, _addr, N_LANES
+from .params import decoder_layers
+
+
+def _c16(n):
+    return (n + 15) // 16 * 16
+
+
+class GCPTrainStep:
+    """`step(inputs)` = one optimisation step of `model` (GCPTreeModel) on one minibatch; `backward(inputs)` stops
+    after the gradients (tests)."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+        hp = model._hp
+        assert hp.decoder_distribution == "discrete_logistic_mixture", "training path implements the DLM head"
+        assert hp.matching_type == "balanced"
+        self.m = model
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.pg = process_group
+        model.train()
+        model.save_for_backward = True
+        self.grad = torch.zeros_like(model.theta)
+        self.exp_avg = torch.zeros_like(model.theta)
+        self.exp_avg_sq = torch.zeros_like(model.theta)
+        self.opt_state = torch.zeros(4, device=model.device)
+        self.bk = model.build_arena(self._pack_backward)
+        self._bplans = {}
+        self._zeros = torch.zeros(256, device=model.device)
+
+    # ------------------------------------------------------------------------------------------------
+    # transposed weight packs (data-gradient GEMMs / convs)
+    # ------------------------------------------------------------------------------------------------
+    def _pack_predictor_T(self, sd, prefix, splits):
+        """splits: list of (col0, width) groups of the input layer whose gradients go to different places."""
+        T = {}
+        w_out = sd[f"{prefix}.head.linear.weight"]
+        od = w_out.shape[0]
+        w_out = pk._pad_rows(w_out, _c16(od))
+        T["wT_out"] = pk.pack_gemm(w_out.t().contiguous())                 # [N = mid][K = out_pad]
+        l = 0
+        while f"{prefix}.pyramid-{l}.linear.weight" in sd:
+            T[f"wT_mid{l}"] = pk.pack_gemm(sd[f"{prefix}.pyramid-{l}.linear.weight"].t().contiguous())
+            l += 1
+        w_in = sd[f"{prefix}.input.linear.weight"]
+        for i, (c0, w) in enumerate(splits):
+            T[f"wT_in{i}"] = pk.pack_gemm(w_in[:, c0:c0 + w].t().contiguous())   # [N = w][K = mid]
+        return T
+
+    def _pack_backward(self, sd):
+        m, hp = self.m, self.m._hp
+        nz, nv, H = hp.nz_enc, hp.nz_vae, hp.nz_mid_lstm
+        X = {}
+        layers, ctop = m._enc_layers, m._c_top
+        for name, cin, cout, norm in layers[1:]:
+            w = sd[f"encoder.net.{name}.conv.weight"]                       # [co, ci, 4, 4] -> [n = (tap, ci)][k = co]
+            X[f"enc.{name}.wT"] = pk.pack_gemm(w.permute(2, 3, 1, 0).reshape(16 * cin, cout))
+        wh = sd["encoder.net.head.weight"]                                   # [nz, c, 4, 4] -> [n = (tap, c)][k = nz]
+        X["enc.head.wT"] = pk.pack_gemm(wh.permute(2, 3, 1, 0).reshape(16 * ctop, nz))
+        wt = sd["decoder.net.input.conv.weight"]                             # [nz, co, 4, 4] -> [n = nz][k = (tap, co)]
+        X["dec.input.wT"] = pk.pack_gemm(wt.permute(0, 2, 3, 1).reshape(nz, 16 * ctop))
+        for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
+            w = sd[f"decoder.net.{name}.conv.weight"]                       # dgrad = 3x3 conv with w^T flipped
+            wT = w.flip(2, 3).transpose(0, 1).contiguous()                  # [cin, cout, 3, 3]
+            cin = wT.shape[0]
+            for h in range((cin + 63) // 64):
+                X[f"dec.{name}.wT{h}"] = pk.pack_conv3x3(wT[64 * h:64 * (h + 1)], 16)
+        hw = sd["decoder.gen_head.conv.weight"]                              # [100, 16, 3, 3]; inputs of the dgrad = kernel slots
+        perm = torch.as_tensor(pk.dlm_channel_perm(hp.n_mixtures), device=hw.device)
+        wk = torch.zeros((len(perm),) + tuple(hw.shape[1:]), dtype=hw.dtype, device=hw.device)
+        wk[perm >= 0] = hw[perm[perm >= 0]]
+        X["dec.head.wT"] = pk.pack_conv3x3(wk.flip(2, 3).transpose(0, 1).contiguous(), 16)
+        for nm in ["input"] + [f"pyramid-{i}" for i in range(hp.conv_inf_enc_layers)] + ["head"]:
+            w = sd[f"inf_encoder.net.{nm}.conv.weight"]                     # [co, ci, 3] -> [n = ci][k = (tap, co)]
+            X[f"seq.{nm}.wT"] = pk.pack_gemm(w.permute(1, 2, 0).reshape(w.shape[1], -1))
+        if hp.regress_length:
+            X["length_pred"] = self._pack_predictor_T(sd, "length_pred.p", [(0, 2 * nz)])
+        if hp.attach_state_regressor:
+            X["state_regressor"] = self._pack_predictor_T(sd, "state_regressor", [])
+        X["existence"] = self._pack_predictor_T(sd, "tree_module.tree_modules.0.binding.existence_predictor", [(0, nz)])
+        for l in range(hp.hierarchy_levels if hp.untied_layers else 1):
+            p = f"tree_module.tree_modules.{l}"
+            T = {}
+            T["prior"] = self._pack_predictor_T(sd, f"{p}.prior", [(0, 2 * nz)])
+            T["q"] = self._pack_predictor_T(sd, f"{p}.inference.q", [(0, 2 * nz), (2 * nz, nz)])
+            T["embed.wT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.embed.weight"].t().contiguous())
+            for i in range(hp.n_lstm_layers):
+                T[f"lstm{i}.wxT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.lstm.{i}.weight_ih"].t().contiguous())   # [H][4H]
+                T[f"lstm{i}.whT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.lstm.{i}.weight_hh"].t().contiguous())
+            T["out.wT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.out.weight"].t().contiguous())                     # [H][nz]
+            T["proj.wT"] = torch.stack([pk.pack_gemm(sd[f"{p}.subgoal_pred.projections.{j}.weight"].t().contiguous())
+                                        for j in range(2 * hp.n_lstm_layers)]).contiguous()                     # [2H][H] each
+            if l == 0:
+                T["init"] = self._pack_predictor_T(sd, f"{p}.lstm_initializer.net", [(0, 2 * nz + nv)])
+            X[f"tree{l}"] = T
+        return X
+
+    # ------------------------------------------------------------------------------------------------
+    # plan-building helpers
+    # ------------------------------------------------------------------------------------------------
+    def g(self, name, off=0):
+        """device address of the gradient of parameter `name`"""
+        return self.grad.data_ptr() + 4 * (self.m._poff[name][0] + off)
+
+    def _wgrad(self, plan, tag, dy, ldy, R, N, x, K, dst, ldw=0, k_off=0, n_valid=None, mode=rt.WG_ROWS, rpb=None, sb=0, sr=0,
+               shift=0, rowidx=None, frame_map=None, scale=None, shiftv=None, act=0, cmod=0, Cin=0, H=0, W=0, dy_rpb=0,
+               dy_sb=0, wmap=rt.WMAP_LINEAR, ntap=1, Cout=0, n_map=None):
+        lib, m = self.m.lib, self.m
+        a = rt.WgradArgs()
+        n_valid = N if n_valid is None else n_valid
+        a.dy, a.x, a.ldy, a.R, a.N, a.n_valid, a.K, a.mode = dy, x, ldy, R, N, n_valid, K, mode
+        a.rowidx = rowidx.data_ptr() if rowidx is not None else None
+        a.frame_map = frame_map.data_ptr() if frame_map is not None else None
+        a.scale = scale.data_ptr() if scale is not None else None
+        a.shiftv = shiftv.data_ptr() if shiftv is not None else None
+        a.sb, a.sr, a.rpb, a.shift, a.act, a.cmod = sb, sr, (rpb if rpb is not None else R), shift, act, cmod
+        a.Cin, a.H, a.W, a.dy_rpb, a.dy_sb = Cin, H, W, dy_rpb, dy_sb
+        waves = ((K + 63) // 64) * ((N + 63) // 64 if N > 16 else 1)
+        nsplit = max(1, min(2048 // waves, R // 128))
+        if wmap == rt.WMAP_LINEAR and nsplit == 1 and ldw % 4 == 0 and k_off % 4 == 0:
+            a.out, a.ldw, a.k_off, a.accumulate, a.partial, a.nsplit = dst, ldw, k_off, 1, 0, 1
+            plan.keep.append(a)
+            plan.add(f"bw.wgrad:{tag}", lib.gcpx_wgrad, C.byref(a))
+            return
+        part = m._buf(f"bw.part:{tag}", (nsplit, n_valid, K))
+        a.out, a.partial, a.nsplit = part.data_ptr(), 1, nsplit
+        plan.keep.append(a)
+        plan.add(f"bw.wgrad:{tag}", lib.gcpx_wgrad, C.byref(a))
+        plan.add(f"bw.wreduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, n_valid, K, dst, wmap, Cin, ntap, Cout,
+                 (n_map.data_ptr() if n_map is not None else None), ldw, k_off, 1)
+
+    def _colsum(self, plan, tag, dy, ldy, R, N, dst, dst2=None, dy_rpb=0, dy_sb=0, n_map=None):
+        lib, m = self.m.lib, self.m
+        nsplit = max(1, min(256, R // 2048))
+        if nsplit == 1 and n_map is None:
+            plan.add(f"bw.colsum:{tag}", lib.gcpx_colsum, dy, ldy, R, N, dy_rpb, dy_sb, 1, None, dst, dst2, 1)
+            return
+        assert dst2 is None
+        nsplit = max(nsplit, 2)
+        part = m._buf(f"bw.cpart:{tag}", (nsplit, N))
+        plan.add(f"bw.colsum:{tag}", lib.gcpx_colsum, dy, ldy, R, N, dy_rpb, dy_sb, nsplit, part.data_ptr(), None, None, 0)
+        if n_map is None:
+            plan.add(f"bw.creduce:{tag}", lib.gcpx_reduce_partials, part.data_ptr(), nsplit, N, N, dst, 1)
+        else:   # bias of the output head: kernel slot -> canonical channel
+            plan.add(f"bw.creduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, N, 1, dst, rt.WMAP_CONV, 1, 1, 0,
+                     n_map.data_ptr(), 0, 0, 1)
+
+    def _dgemm(self, plan, tag, srcs, M, N, rpb, wpk, out, ob, orow, batch=None):
+        """data-gradient GEMM: out = concat(srcs) @ packed(W^T)"""
+        self.m._gemm(plan, f"bw.dgrad:{tag}", srcs, M, N, rpb, wpk, None, out=out, ob=ob, orow=orow, batch=batch)
+
+    def _dense(self, ptr, ld, width, M):
+        return self.m._rowsrc(ptr, M * ld, ld, width)
+
+    def _bn_bwd(self, plan, tag, bn, da, ldc, c_off, up, r, F, Hh, Ww, add=None):
+        """activation + BatchNorm backward of one conv block: returns the buffer holding d(raw conv output)."""
+        m, lib, hp = self.m, self.m.lib, self.m._hp
+        Cc = bn["C"]
+        dy = m._buf(f"bw.dy:{tag}", (F, Hh, Ww, Cc))
+        nb = lib.gcpx_act_bwd_blocks()
+        st = m._buf(f"bw.st:{tag}", (nb, 2, Cc))
+        a = rt.ActBwdArgs()
+        a.da, a.add, a.r = da, (add.data_ptr() if add is not None else None), r.data_ptr()
+        a.scale, a.shift, a.mean, a.rstd = bn["scale"].data_ptr(), bn["shift"].data_ptr(), bn["mean"].data_ptr(), bn["rstd"].data_ptr()
+        a.dy, a.stats_partial, a.ldc, a.c_off, a.up, a.fsum, a.act = dy.data_ptr(), st.data_ptr(), ldc, c_off, up, 1, rt.ACT_LRELU
+        a.F, a.H, a.W, a.C = F, Hh, Ww, Cc
+        plan.keep.append(a)
+        plan.add(f"bw.act:{tag}", lib.gcpx_act_bwd, C.byref(a))
+        coef = m._buf(f"bw.coef:{tag}", (3, Cc))
+        pre = bn["prefix"]
+        plan.add(f"bw.bnfin:{tag}", lib.gcpx_bn_bwd_finalize, st.data_ptr(), nb, Cc, C.c_double(float(F * Hh * Ww)),
+                 m.sd[f"{pre}.weight"].data_ptr(), bn["rstd"].data_ptr(), coef.data_ptr(), self.g(f"{pre}.weight"),
+                 self.g(f"{pre}.bias"), 1)
+        plan.add(f"bw.bnapply:{tag}", lib.gcpx_bn_bwd_apply, dy.data_ptr(), r.data_ptr(), bn["mean"].data_ptr(),
+                 bn["rstd"].data_ptr(), coef.data_ptr(), F * Hh * Ww * Cc, Cc)
+        return dy
+
+    def _mlp_bwd(self, plan, tag, prefix, rec, T, dout, ldo, dx_outs):
+        """Backward of one Predictor MLP.  dout: dense [M][ldo] gradient of the head output (pad columns zero).
+        dx_outs: one (out_ptr, ob, orow) per input split packed in T (wT_in{i}); rows (b, j) with the forward's rpb."""
+        m, lib, hp = self.m, self.m.lib, self.m._hp
+        W, srcs, M, rpb, save = rec["W"], rec["srcs"], rec["M"], rec["rpb"], rec["save"]
+        mid, n_mid, out_dim, in_dim = W["mid"], W["n_mid"], W["out_dim"], W["in_dim"]
+        out_pad = _c16(out_dim)
+        assert ldo == out_pad
+        sv = lambda i: save.data_ptr() + 4 * i * M * mid
+        a_ptr = [sv(0)] + [sv(2 + 2 * l) for l in range(n_mid)]
+        u_ptr = [sv(1 + 2 * l) for l in range(n_mid)]
+        # head
+        self._wgrad(plan, f"{tag}.out", dout, ldo, M, out_pad, a_ptr[n_mid], mid, self.g(f"{prefix}.head.linear.weight"),
+                    ldw=mid, n_valid=out_dim, sr=mid, sb=M * mid, rpb=M)
+        self._colsum(plan, f"{tag}.out", dout, ldo, M, out_dim, self.g(f"{prefix}.head.linear.bias"))
+        da = m._buf(f"bw.{tag}.da", (M, mid))
+        du = m._buf(f"bw.{tag}.du", (M, mid))
+        self._dgemm(plan, f"{tag}.out", [self._dense(dout, ldo, out_pad, M)], M, mid, M, T["wT_out"], da.data_ptr(), 0, mid)
+        for l in reversed(range(n_mid)):
+            nb = lib.gcpx_gn_bwd_blocks(M)
+            part = m._buf(f"bw.{tag}.gnpart", (nb, 2, mid))
+            pre = f"{prefix}.pyramid-{l}"
+            plan.add(f"bw.gn:{tag}.{l}", lib.gcpx_gn_lrelu_bwd, u_ptr[l], da.data_ptr(), m.sd[f"{pre}.norm.weight"].data_ptr(),
+                     m.sd[f"{pre}.norm.bias"].data_ptr(), du.data_ptr(), part.data_ptr(), M, mid, hp.gn_groups,
+                     C.c_float(hp.gn_eps), C.c_float(hp.leaky_slope))
+            plan.add(f"bw.gnred:{tag}.{l}", lib.gcpx_reduce_partials, part.data_ptr(), nb, 2 * mid, mid, self.g(f"{pre}.norm.weight"), 1)
+            plan.add(f"bw.gnred2:{tag}.{l}", lib.gcpx_reduce_partials, part.data_ptr() + 4 * mid, nb, 2 * mid, mid,
+                     self.g(f"{pre}.norm.bias"), 1)
+            self._wgrad(plan, f"{tag}.mid{l}", du.data_ptr(), mid, M, mid, a_ptr[l], mid, self.g(f"{pre}.linear.weight"), ldw=mid,
+                        sr=mid, sb=M * mid, rpb=M)
+            self._colsum(plan, f"{tag}.mid{l}", du.data_ptr(), mid, M, mid, self.g(f"{pre}.linear.bias"))
+            self._dgemm(plan, f"{tag}.mid{l}", [self._dense(du.data_ptr(), mid, mid, M)], M, mid, M, T[f"wT_mid{l}"], da.data_ptr(), 0, mid)
+        du0 = m._buf(f"bw.{tag}.du0", (M, mid))
+        plan.add(f"bw.lrelu:{tag}", lib.gcpx_lrelu_bwd, a_ptr[0], da.data_ptr(), du0.data_ptr(), M * mid, C.c_float(hp.leaky_slope))
+        self._colsum(plan, f"{tag}.in", du0.data_ptr(), mid, M, mid, self.g(f"{prefix}.input.linear.bias"))
+        koff = 0
+        for i, s in enumerate(srcs):
+            self._wgrad(plan, f"{tag}.in{i}", du0.data_ptr(), mid, M, mid, s.ptr, s.width, self.g(f"{prefix}.input.linear.weight"),
+                        ldw=in_dim, k_off=koff, rpb=rpb, sb=s.sb, sr=s.sr, shift=s.shift,
+                        rowidx=_PtrHolder(s.rowidx) if s.rowidx else None)
+            koff += s.width
+        for i, (optr, ob, orow) in enumerate(dx_outs):
+            wT = T[f"wT_in{i}"]
+            width = wT.shape[1] * 16
+            self._dgemm(plan, f"{tag}.in{i}", [self.m._rowsrc(du0.data_ptr(), rpb * mid, mid, mid)], M, width, rpb, wT, optr, ob, orow)
+
+    # ------------------------------------------------------------------------------------------------
+    # the backward plan
+    # ------------------------------------------------------------------------------------------------
+    def _build_backward(self, fplan):
+        m, hp, lib = self.m, self.m._hp, self.m.lib
+        rec, o = fplan.rec, fplan.outs
+        key, tin = rec["key"], rec["tin"]
+        B = key[0]
+        L, T, N = hp.hierarchy_levels, hp.max_seq_len, hp.n_nodes
+        nz, nv, H, SD, nl = hp.nz_enc, hp.nz_vae, hp.nz_mid_lstm, hp.lstm_state_dim, hp.n_lstm_layers
+        PS = 2 ** L + 1
+        S = hp.img_sz
+        pitch = m._head_pitch
+        div = float(T * hp.input_nc * S * S)
+        plan = _Plan(lib)
+        E, Hid, QZ, PZ = o["E"], o["Hid"], o["QZ"], o["PZ"]
+        buf = m._buf
+        zero = lambda t: plan.add("bw.zero", lib.gcpx_fill_zero, t.data_ptr(), t.numel() * 4)
+
+        dE, dHid = buf("bw.dE", (B, PS, nz)), buf("bw.dHid", (B, PS, SD))
+        dET = buf("bw.dET", (B, PS, nz))
+        dQZ, dPZ = buf("bw.dQZ", (B, PS, 2 * nv)), buf("bw.dPZ", (B, PS, 2 * nv))
+        zero(self.grad); zero(dE); zero(dHid)
+
+        # ---- loss gradients (base_gcp.py:264-304) ----
+        la = rec["loss_args"]
+        dMD = buf("bw.dMD", (B * T, S, S, pitch))
+        md = o["matched_distr_kernel_order"]
+        plan.add("bw.dlm_nll", lib.gcpx_dlm_nll_bwd, md.data_ptr(), tin["traj_seq"].data_ptr(), tin["pad_mask"].data_ptr(),
+                 C.c_float(hp.dense_img_rec_weight / (B * div)), dMD.data_ptr(), B * T, S * S, pitch, hp.n_mixtures)
+        plan.add("bw.kl", lib.gcpx_kl_bwd, _addr(QZ, 2 * nv), _addr(PZ, 2 * nv), _addr(dQZ, 2 * nv), _addr(dPZ, 2 * nv), B, N, nv,
+                 PS * 2 * nv, 2 * nv, C.c_float(hp.free_nats), C.c_float(hp.kl_weight / (B * div)))
+        ldl = _c16(T)
+        dlen = buf("bw.dlen", (B, ldl)) if hp.regress_length else None
+        dexist = buf("bw.dexist", (B * N, 16))
+        has_state = "regressed_state_padded" in o and "traj_seq_states" in tin
+        dstate = buf("bw.dstate", (B * T, 16)) if has_state else None
+        plan.add("bw.heads", lib.gcpx_loss_heads_bwd, C.byref(la), rt.ptr(dlen), dexist.data_ptr(), rt.ptr(dstate))
+
+        # ---- latent-space heads ----
+        if hp.regress_length:
+            dXl = buf("bw.dX.len", (B, 2 * nz))
+            self._mlp_bwd(plan, "length_pred", "length_pred.p", rec["mlp:length_pred"], self.bk["length_pred"], dlen.data_ptr(), ldl,
+                          [(dXl.data_ptr(), 2 * nz, 0)])
+            self._tree_accum(plan, "len", dE, PS * nz, 2 ** L * nz, B, 1, nz, [(dXl.data_ptr(), 2 * nz, 0, nz, -1, -1, 0)])
+        dE_ex = buf("bw.dE_ex", (B * N, nz))
+        self._mlp_bwd(plan, "existence", "tree_module.tree_modules.0.binding.existence_predictor", rec["mlp:existence"],
+                      self.bk["existence"], dexist.data_ptr(), 16, [(dE_ex.data_ptr(), N * nz, nz)])
+        if has_state:   # input detached (base_gcp.py:253-256): parameter gradients only
+            self._mlp_bwd(plan, "state_regressor", "state_regressor", rec["mlp:state_regressor"], self.bk["state_regressor"],
+                          dstate.data_ptr(), 16, [])
+
+        # ---- decoder (tree_dense_rec.py:42 backward) ----
+        dE_dec, dskip = self._decoder_backward(plan, fplan, dMD, B)
+        plan.add("bw.addrows", lib.gcpx_add_rows, _addr(dE, nz), PS * nz, nz, dE_dec.data_ptr(), dE_ex.data_ptr(), B, N, nz)
+
+        # ---- tree levels, leaves first (tree_utils.py:21-44 backward) ----
+        pid = hp.pred_inp_dim
+        for l in reversed(range(L)):
+            li = l if hp.untied_layers else 0
+            Wt = self.bk[f"tree{li}"]
+            p = f"tree_module.tree_modules.{li}"
+            sp = f"{p}.subgoal_pred"
+            s, n = 2 ** (L - 1 - l), 2 ** l
+            M = B * n
+            dEn = _addr(dE, s * nz)
+            # out linear
+            self._colsum(plan, f"out{l}", dEn, 2 * s * nz, M, nz, self.g(f"{sp}.out.bias"), dy_rpb=n, dy_sb=PS * nz)
+            x_top = buf(f"x{l}.{nl}", (M, H))
+            self._wgrad(plan, f"out{l}", dEn, 2 * s * nz, M, nz, x_top.data_ptr(), H, self.g(f"{sp}.out.weight"), ldw=H, sr=H,
+                        sb=M * H, rpb=M, dy_rpb=n, dy_sb=PS * nz)
+            dxt = buf(f"bw.dxt{l}", (M, H))
+            self._dgemm(plan, f"out{l}", [m._rowsrc(dEn, PS * nz, 2 * s * nz, nz)], M, H, n, Wt["out.wT"], dxt.data_ptr(), n * H, H)
+            merged = buf(f"merged{l}", (M, 2 * nl * H))
+            dmerged = buf(f"bw.dmerged{l}", (M, 2 * nl * H))
+            dh_src = dxt
+            for i in reversed(range(nl)):
+                dg = buf(f"bw.dgates{l}.{i}", (M, 4 * H))
+                a = rt.LstmBwdArgs()
+                a.gates = rec[f"gates:lstm{l}.{i}"].data_ptr()
+                a.c_prev, a.c_prev_stride = _addr(merged, (2 * i + 1) * H), 2 * nl * H
+                a.c_new, a.pb, a.prow = _addr(Hid, s * SD + (2 * i + 1) * H), PS * SD, 2 * s * SD
+                a.dh_dense, a.dh_stride = dh_src.data_ptr(), H
+                a.dh_pos, a.dc_pos = _addr(dHid, s * SD + 2 * i * H), _addr(dHid, s * SD + (2 * i + 1) * H)
+                a.dgates, a.dc_prev, a.dcp_stride = dg.data_ptr(), _addr(dmerged, (2 * i + 1) * H), 2 * nl * H
+                a.M, a.H, a.rpb = M, H, n
+                plan.keep.append(a)
+                plan.add(f"bw.lstm{l}.{i}", lib.gcpx_lstm_bwd, C.byref(a))
+                x_i = buf(f"x{l}.{i}", (M, H))
+                self._wgrad(plan, f"lstm{l}.{i}.ih", dg.data_ptr(), 4 * H, M, 4 * H, x_i.data_ptr(), H,
+                            self.g(f"{sp}.lstm.{i}.weight_ih"), ldw=H, sr=H, sb=M * H, rpb=M)
+                self._wgrad(plan, f"lstm{l}.{i}.hh", dg.data_ptr(), 4 * H, M, 4 * H, _addr(merged, 2 * i * H), H,
+                            self.g(f"{sp}.lstm.{i}.weight_hh"), ldw=H, sr=2 * nl * H, sb=M * 2 * nl * H, rpb=M)
+                self._colsum(plan, f"lstm{l}.{i}", dg.data_ptr(), 4 * H, M, 4 * H, self.g(f"{sp}.lstm.{i}.bias_ih"),
+                             dst2=self.g(f"{sp}.lstm.{i}.bias_hh"))
+                dxi = buf(f"bw.dxi{l}.{i}", (M, H))
+                src = [self._dense(dg.data_ptr(), 4 * H, 4 * H, M)]
+                self._dgemm(plan, f"lstm{l}.{i}.x", src, M, H, M, Wt[f"lstm{i}.wxT"], dxi.data_ptr(), 0, H)
+                self._dgemm(plan, f"lstm{l}.{i}.h", src, M, H, M, Wt[f"lstm{i}.whT"], _addr(dmerged, 2 * i * H), 0, 2 * nl * H)
+                dh_src = dxi
+            dx0 = dh_src
+            # embedding of [e_l, e_r, z, e_0, e_g]
+            self._colsum(plan, f"embed{l}", dx0.data_ptr(), H, M, H, self.g(f"{sp}.embed.bias"))
+            el = m._rowsrc(_addr(E), PS * nz, 2 * s * nz, nz)
+            er = m._rowsrc(_addr(E, 2 * s * nz), PS * nz, 2 * s * nz, nz)
+            zs = m._rowsrc(_addr(o["Z"], s * nv), PS * nv, 2 * s * nv, nv)
+            esrcs = [el, er, zs]
+            if hp.context_every_step:
+                esrcs += [m._rowsrc(_addr(E), PS * nz, 0, nz), m._rowsrc(_addr(E, 2 ** L * nz), PS * nz, 0, nz)]
+            koff = 0
+            for i, sc in enumerate(esrcs):
+                self._wgrad(plan, f"embed{l}.{i}", dx0.data_ptr(), H, M, H, sc.ptr, sc.width, self.g(f"{sp}.embed.weight"), ldw=pid,
+                            k_off=koff, rpb=n, sb=sc.sb, sr=sc.sr)
+                koff += sc.width
+            dpi = buf(f"bw.dpi{l}", (M, pid))
+            self._dgemm(plan, f"embed{l}", [self._dense(dx0.data_ptr(), H, H, M)], M, pid, M, Wt["embed.wT"], dpi.data_ptr(), 0, pid)
+            # split_linear merge of the parents' hidden states
+            for j in range(2 * nl):
+                dmj = _addr(dmerged, j * H)
+                self._colsum(plan, f"proj{l}.{j}", dmj, 2 * nl * H, M, H, self.g(f"{sp}.projections.{j}.bias"))
+                for side, base in ((0, j * H), (1, 2 * s * SD + j * H)):
+                    self._wgrad(plan, f"proj{l}.{j}.{side}", dmj, 2 * nl * H, M, H, _addr(Hid, base), H,
+                                self.g(f"{sp}.projections.{j}.weight"), ldw=2 * H, k_off=side * H, rpb=n, sb=PS * SD, sr=2 * s * SD)
+            dpar = buf(f"bw.dpar{l}", (2 * nl, M, 2 * H))
+            self._dgemm(plan, f"merge{l}", [m._rowsrc(dmerged.data_ptr(), n * 2 * nl * H, 2 * nl * H, H)], M, 2 * H, n, Wt["proj.wT"],
+                        dpar.data_ptr(), n * 2 * H, 2 * H, batch=(2 * nl, H, Wt["proj.wT"][0].numel(), 0, M * 2 * H))
+            self._tree_accum(plan, f"hid{l}", dHid, PS * SD, 2 * s * SD, B, n, H,
+                             [(dpar.data_ptr() + 4 * j * M * 2 * H, 2 * H, 0, H, -1, -1, j * H) for j in range(2 * nl)])
+            dXi = None
+            if l == 0:
+                # MLP LSTM initialiser (tree_module.py:104-105): outputs live in Hid slots 0 and 2^L
+                dinit = buf("bw.dinit", (B, 2 * SD))
+                plan.add("bw.dinit.l", lib.gcpx_copy_rows, _addr(dHid), dinit.data_ptr(), B, 1, SD, PS, 2)
+                plan.add("bw.dinit.r", lib.gcpx_copy_rows, _addr(dHid, 2 ** L * SD), _addr(dinit, SD), B, 1, SD, PS, 2)
+                dXi = buf("bw.dX.init", (B, 2 * nz + nv))
+                self._mlp_bwd(plan, "lstm_init", f"{p}.lstm_initializer.net", rec["mlp:lstm_init"], Wt["init"], dinit.data_ptr(),
+                              2 * SD, [(dXi.data_ptr(), (2 * nz + nv), 0)])
+            # sampled latent: z = mu_q + exp(log_sigma_q) * eps (tree_module.py:86-94)
+            dq, dp = buf(f"bw.dq{l}", (M, 2 * nv)), buf(f"bw.dp{l}", (M, 2 * nv))
+            plan.add(f"bw.latent{l}", lib.gcpx_latent_bwd, _addr(dQZ, s * 2 * nv), _addr(dPZ, s * 2 * nv), _addr(QZ, s * 2 * nv),
+                     PS * 2 * nv, 2 * s * 2 * nv, _addr(tin["eps"], (n - 1) * nv), N * nv, nv, _addr(dpi, 2 * nz), pid,
+                     (_addr(dXi, 2 * nz) if dXi is not None else None), 2 * nz + nv, dq.data_ptr(), dp.data_ptr(), M, n, nv)
+            dXq, dXp = buf(f"bw.dXq{l}", (M, 2 * nz)), buf(f"bw.dXp{l}", (M, 2 * nz))
+            self._mlp_bwd(plan, f"posterior{l}", f"{p}.inference.q", rec[f"mlp:posterior{l}"], Wt["q"], dq.data_ptr(), 2 * nv,
+                          [(dXq.data_ptr(), n * 2 * nz, 2 * nz), (_addr(dET, s * nz), PS * nz, 2 * s * nz)])
+            self._mlp_bwd(plan, f"prior{l}", f"{p}.prior", rec[f"mlp:prior{l}"], Wt["prior"], dp.data_ptr(), 2 * nv,
+                          [(dXp.data_ptr(), n * 2 * nz, 2 * nz)])
+            ctx = (2 * nz + nv, 3 * nz + nv) if hp.context_every_step else (-1, -1)
+            srcs = [(dpi.data_ptr(), pid, 0, nz, ctx[0], ctx[1], 0), (dXq.data_ptr(), 2 * nz, 0, nz, -1, -1, 0),
+                    (dXp.data_ptr(), 2 * nz, 0, nz, -1, -1, 0)]
+            if dXi is not None:
+                srcs.append((dXi.data_ptr(), 2 * nz + nv, 0, nz, -1, -1, 0))
+            self._tree_accum(plan, f"E{l}", dE, PS * nz, 2 * s * nz, B, n, nz, srcs)
+
+        # ---- temporal inference encoder + image encoders (base_gcp.py:184-213 backward) ----
+        d_inf = buf("bw.d_inf", (B * T, nz))
+        plan.add("bw.tscatter", lib.gcpx_timestep_scatter, _addr(dET, nz), PS * nz, nz, o["node_t"].data_ptr(), d_inf.data_ptr(),
+                 B, N, T, nz)
+        d_enc_traj = self._seq_backward(plan, fplan, d_inf, B)
+        self._encoder_backward(plan, fplan, "traj", d_enc_traj.data_ptr(), nz, 0, 0, {})
+        self._encoder_backward(plan, fplan, "I0", _addr(dE), nz, 1, PS * nz, dskip)
+        self._encoder_backward(plan, fplan, "Ig", _addr(dE, 2 ** L * nz), nz, 1, PS * nz, {})
+        plan.outs = dict(dE=dE, dHid=dHid, dET=dET, dQZ=dQZ, dPZ=dPZ, dMD=dMD, d_inf=d_inf, d_enc_traj=d_enc_traj, dE_dec=dE_dec,
+                         dE_ex=dE_ex, dlen=dlen, dexist=dexist, dstate=dstate)
+        return plan
+
+    def _tree_accum(self, plan, tag, dst, dst_sb, slot_stride, B, n, width, srcs):
+        a = rt.TreeAccumArgs()
+        for i, (ptr, ld, ol, orr, c0, cg, dcol) in enumerate(srcs):
+            s = a.src[i]
+            s.ptr, s.ld, s.off_left, s.off_right, s.off_ctx0, s.off_ctxg, s.dst_col = ptr, ld, ol, orr, c0, cg, dcol
+        a.dst, a.dst_sb, a.slot_stride, a.nsrc, a.B, a.n, a.width = dst.data_ptr(), dst_sb, slot_stride, len(srcs), B, n, width
+        plan.keep.append(a)
+        plan.add(f"bw.accum:{tag}", self.m.lib.gcpx_tree_accum, C.byref(a))
+
+    # ---- decoder ----
+    def _decoder_backward(self, plan, fplan, dMD, B):
+        m, hp, lib = self.m, self.m._hp, self.m.lib
+        rec, o = fplan.rec, fplan.outs
+        T, N, nz, L = hp.max_seq_len, hp.n_nodes, hp.nz_enc, hp.hierarchy_levels
+        PS = 2 ** L + 1
+        S, pitch = hp.img_sz, m._head_pitch
+        buf = m._buf
+        dec = rec["dec"]
+        F, rpb = dec["F"], dec["rpb"]
+        ngf = hp.ngf
+        perm32 = buf("bw.dlm_perm", (pitch,), torch.int32)
+        perm32.copy_(m._dlm_perm.to(torch.int32))
+        # output head: weight gradient over the matched frames, data gradient to every node frame
+        f2n_abs = buf("bw.f2n_abs", (B, T), torch.int32)
+        plan.add("bw.f2n_abs", lib.gcpx_index_offset, o["frame2node"].data_ptr(), f2n_abs.data_ptr(), B, T, N)
+        featA = buf("bw.featA", (B * T, S, S, ngf))
+        a = m._conv_args([rec["head_src"]], B * T, S, S, S, S, ngf, ngf, self._zeros, self._zeros, featA)
+        a.src_row_map = f2n_abs.data_ptr()
+        plan.keep.append(a)
+        plan.add("bw.stage:head", lib.gcpx_conv_stage, C.byref(a))
+        self._wgrad(plan, "dec.head", dMD.data_ptr(), pitch, B * T * S * S, pitch, featA.data_ptr(), 9 * ngf,
+                    self.g("decoder.gen_head.conv.weight"), mode=rt.WG_CONV3X3, Cin=ngf, H=S, W=S, wmap=rt.WMAP_CONV, ntap=9,
+                    n_map=perm32)
+        self._colsum(plan, "dec.head", dMD.data_ptr(), pitch, B * T * S * S, pitch, self.g("decoder.gen_head.conv.bias"), n_map=perm32)
+        dA = buf("bw.dA.head", (F, S, S, ngf))
+        a = m._conv_args([(dMD.data_ptr(), pitch, 1, None, None, rt.ACT_NONE)], F, S, S, S, S, ngf, ngf, self.bk["dec.head.wT"],
+                         self._zeros, dA)
+        a.src_row_map = o["node2row"].data_ptr()
+        plan.keep.append(a)
+        plan.add("bw.dgrad:dec.head", lib.gcpx_conv3x3, C.byref(a))
+
+        gin = (dA.data_ptr(), ngf, 0)            # (pointer, channel pitch, upsampled?) of the incoming gradient
+        dskip = {}
+        for blk in reversed(dec["blocks"]):
+            name, res_in, cout, c_prev, c_skip = blk["name"], blk["res_in"], blk["cout"], blk["c_prev"], blk["c_skip"]
+            res = 2 * res_in
+            cin = c_prev + c_skip
+            bn = rec[f"bn:dec.bn.{name}"]
+            dy = self._bn_bwd(plan, f"dec.{name}", bn, gin[0], gin[1], 0, gin[2], blk["out"], F, res, res)
+            U = buf(f"bw.U.{name}", (F, res, res, cin))
+            a = m._conv_args(blk["srcs"], F, res_in, res_in, res, res, cin, cin, self._zeros, self._zeros, U, upsample=1)
+            plan.keep.append(a)
+            plan.add(f"bw.stage:{name}", lib.gcpx_conv_stage, C.byref(a))
+            self._wgrad(plan, f"dec.{name}", dy.data_ptr(), cout, F * res * res, cout, U.data_ptr(), 9 * cin,
+                        self.g(f"decoder.net.{name}.conv.weight"), mode=rt.WG_CONV3X3, Cin=cin, H=res, W=res, wmap=rt.WMAP_CONV,
+                        ntap=9)
+            dU = buf(f"bw.dU.{name}", (F, res, res, cin))
+            for h in range((cin + 63) // 64):
+                ch = min(64, cin - 64 * h)
+                a = m._conv_args([(dy.data_ptr(), cout, 1, None, None, rt.ACT_NONE)], F, res, res, res, res, ch, cin,
+                                 self.bk[f"dec.{name}.wT{h}"], self._zeros, dU)
+                a.out = dU.data_ptr() + 4 * 64 * h
+                plan.keep.append(a)
+                plan.add(f"bw.dgrad:dec.{name}.{h}", lib.gcpx_conv3x3, C.byref(a))
+            if c_skip:
+                ds = buf(f"bw.dskip.{name}", (B, res_in, res_in, c_skip))
+                a = rt.ActBwdArgs()
+                a.da, a.dy, a.ldc, a.c_off, a.up, a.fsum, a.act = dU.data_ptr(), ds.data_ptr(), cin, c_prev, 1, rpb, rt.ACT_NONE
+                a.F, a.H, a.W, a.C = B, res_in, res_in, c_skip
+                plan.keep.append(a)
+                plan.add(f"bw.skip:{name}", lib.gcpx_act_bwd, C.byref(a))
+                dskip[blk["skip_idx"]] = ds
+            gin = (dU.data_ptr(), cin, 1)
+        # input block: ConvTranspose 1x1 -> 4x4 as a GEMM + BatchNorm
+        ctop = m._c_top
+        bn0 = rec["bn:dec.bn0"]
+        dy0 = self._bn_bwd(plan, "dec.input", bn0, gin[0], gin[1], 0, gin[2], dec["d0"], F, 4, 4)
+        self._wgrad(plan, "dec.input", dy0.data_ptr(), 16 * ctop, F, 16 * ctop, _addr(fplan.outs["E"], nz), nz,
+                    self.g("decoder.net.input.conv.weight"), rpb=rpb, sb=PS * nz, sr=nz, wmap=rt.WMAP_CONVT, ntap=16, Cout=ctop)
+        dE_dec = buf("bw.dE_dec", (F, nz))
+        self._dgemm(plan, "dec.input", [self._dense(dy0.data_ptr(), 16 * ctop, 16 * ctop, F)], F, nz, F, self.bk["dec.input.wT"],
+                    dE_dec.data_ptr(), 0, nz)
+        return dE_dec, dskip
+
+    # ---- ConvSeqEncodingModule (base_gcp.py:199) ----
+    def _seq_backward(self, plan, fplan, d_inf, B):
+        m, hp, lib = self.m, self.m._hp, self.m.lib
+        rec, o = fplan.rec, fplan.outs
+        T, nz, nm = hp.max_seq_len, hp.nz_enc, hp.nz_mid
+        buf = m._buf
+        R = B * T
+        y1, y2, enc_traj = buf("seq.y1", (R, nm)), buf("seq.y2", (R, nm)), o["enc_traj_seq"]
+        bn = rec["bn:seq.bn"]
+        taps = lambda ptr, w: [m._rowsrc(ptr, T * w, w, w, shift=1 - tap) for tap in range(3)]
+        pre = "inf_encoder.net"
+        self._wgrad(plan, "seq.head", d_inf.data_ptr(), nz, R, nz, y2.data_ptr(), 3 * nm, self.g(f"{pre}.head.conv.weight"),
+                    mode=rt.WG_CONV1D, Cin=nm, rpb=T, sb=T * nm, sr=nm, scale=bn["scale"], shiftv=bn["shift"], act=rt.ACT_LRELU,
+                    wmap=rt.WMAP_CONV, ntap=3)
+        self._colsum(plan, "seq.head", d_inf.data_ptr(), nz, R, nz, self.g(f"{pre}.head.conv.bias"))
+        da2 = buf("bw.seq.da2", (R, nm))
+        self._dgemm(plan, "seq.head", taps(d_inf.data_ptr(), nz), R, nm, T, self.bk["seq.head.wT"], da2.data_ptr(), T * nm, nm)
+        dy2 = self._bn_bwd(plan, "seq.bn", bn, da2.data_ptr(), nm, 0, 0, y2, R, 1, 1)
+        self._wgrad(plan, "seq.pyr", dy2.data_ptr(), nm, R, nm, y1.data_ptr(), 3 * nm, self.g(f"{pre}.pyramid-0.conv.weight"),
+                    mode=rt.WG_CONV1D, Cin=nm, rpb=T, sb=T * nm, sr=nm, wmap=rt.WMAP_CONV, ntap=3)
+        da1 = buf("bw.seq.da1", (R, nm))
+        self._dgemm(plan, "seq.pyr", taps(dy2.data_ptr(), nm), R, nm, T, self.bk["seq.pyramid-0.wT"], da1.data_ptr(), T * nm, nm)
+        du1 = buf("bw.seq.du1", (R, nm))
+        plan.add("bw.seq.lrelu", lib.gcpx_lrelu_bwd, y1.data_ptr(), da1.data_ptr(), du1.data_ptr(), R * nm, C.c_float(hp.leaky_slope))
+        self._wgrad(plan, "seq.input", du1.data_ptr(), nm, R, nm, enc_traj.data_ptr(), 3 * nz, self.g(f"{pre}.input.conv.weight"),
+                    mode=rt.WG_CONV1D, Cin=nz, rpb=T, sb=T * nz, sr=nz, wmap=rt.WMAP_CONV, ntap=3)
+        self._colsum(plan, "seq.input", du1.data_ptr(), nm, R, nm, self.g(f"{pre}.input.conv.bias"))
+        d_enc = buf("bw.d_enc_traj", (R, nz))
+        self._dgemm(plan, "seq.input", taps(du1.data_ptr(), nm), R, nz, T, self.bk["seq.input.wT"], d_enc.data_ptr(), T * nz, nz)
+        return d_enc
+
+    # ---- conv encoder (one of the three passes) ----
+    def _encoder_backward(self, plan, fplan, tag, dlat, ldy, dy_rpb, dy_sb, dskip):
+        m, hp, lib = self.m, self.m._hp, self.m.lib
+        rec = fplan.rec
+        er = rec[f"enc:{tag}"]
+        F, S, nz = er["F"], hp.img_sz, hp.nz_enc
+        buf = m._buf
+        layers, ctop = m._enc_layers, m._c_top
+        nlay = len(layers)
+        top = nlay - 1
+        r_top, bn_top = er["r"][top], rec[f"bn:{tag}.bn{top}"]
+        K = 16 * ctop
+        self._wgrad(plan, f"enc.head:{tag}", dlat, ldy, F, nz, r_top.data_ptr(), K, self.g("encoder.net.head.weight"), rpb=F, sb=0, sr=K,
+                    scale=bn_top["scale"], shiftv=bn_top["shift"], act=rt.ACT_LRELU, cmod=ctop, dy_rpb=dy_rpb, dy_sb=dy_sb,
+                    wmap=rt.WMAP_CONV, Cin=ctop, ntap=16)
+        self._colsum(plan, f"enc.head:{tag}", dlat, ldy, F, nz, self.g("encoder.net.head.bias"), dy_rpb=dy_rpb, dy_sb=dy_sb)
+        dA = buf(f"bw.{tag}.dA{top}", (F, 4, 4, ctop))
+        if dy_rpb:
+            src = m._rowsrc(dlat, dy_sb, 0, nz)
+            self._dgemm(plan, f"enc.head:{tag}", [src], F, K, 1, self.bk["enc.head.wT"], dA.data_ptr(), K, 0)
+        else:
+            self._dgemm(plan, f"enc.head:{tag}", [self._dense(dlat, ldy, nz, F)], F, K, F, self.bk["enc.head.wT"], dA.data_ptr(), 0, K)
+        res = 4
+        for li in reversed(range(1, nlay)):
+            name, cin, cout, _ = layers[li]
+            r = er["r"][li]
+            bn = rec[f"bn:{tag}.bn{li}"]
+            dy = self._bn_bwd(plan, f"{tag}.{name}", bn, dA.data_ptr(), cout, 0, 0, r, F, res, res, add=dskip.get(li))
+            if li == 1:
+                x, sc, sh, act = er["a0"], None, None, rt.ACT_NONE
+            else:
+                pbn = rec[f"bn:{tag}.bn{li - 1}"]
+                x, sc, sh, act = er["r"][li - 1], pbn["scale"], pbn["shift"], rt.ACT_LRELU
+            self._wgrad(plan, f"enc.{name}:{tag}", dy.data_ptr(), cout, F * res * res, cout, x.data_ptr(), 16 * cin,
+                        self.g(f"encoder.net.{name}.conv.weight"), mode=rt.WG_CONV4X4S2, Cin=cin, H=2 * res, W=2 * res, scale=sc,
+                        shiftv=sh, act=act, wmap=rt.WMAP_CONV, ntap=16)
+            dcol = buf(f"bw.{tag}.dcol{li}", (F * res * res, 16 * cin))
+            R = F * res * res
+            self._dgemm(plan, f"enc.{name}:{tag}", [self._dense(dy.data_ptr(), cout, cout, R)], R, 16 * cin, R, self.bk[f"enc.{name}.wT"],
+                        dcol.data_ptr(), 0, 16 * cin)
+            dA = buf(f"bw.{tag}.dA{li - 1}", (F, 2 * res, 2 * res, cin))
+            plan.add(f"bw.col2im:{tag}.{li}", lib.gcpx_col2im4x4s2, dcol.data_ptr(), dA.data_ptr(), F, 2 * res, 2 * res, cin)
+            res *= 2
+        # first layer: conv on the NCHW image + LeakyReLU (no norm)
+        ngf = hp.ngf
+        du0 = buf(f"bw.{tag}.du0", (F, res, res, ngf))
+        a = rt.ActBwdArgs()
+        a.da, a.r, a.dy = dA.data_ptr(), er["a0"].data_ptr(), du0.data_ptr()
+        a.add = dskip[0].data_ptr() if 0 in dskip else None
+        a.ldc, a.c_off, a.up, a.fsum, a.act, a.F, a.H, a.W, a.C = ngf, 0, 0, 1, rt.ACT_LRELU, F, res, res, ngf
+        plan.keep.append(a)
+        plan.add(f"bw.act:{tag}.input", lib.gcpx_act_bwd, C.byref(a))
+        col = buf(f"bw.{tag}.col", (F * res * res, 48))
+        plan.add(f"bw.im2col:{tag}", lib.gcpx_im2col_image, er["x_ptr"], col.data_ptr(), F, S, S)
+        R = F * res * res
+        self._wgrad(plan, f"enc.input:{tag}", du0.data_ptr(), ngf, R, ngf, col.data_ptr(), 48, self.g("encoder.net.input.conv.weight"),
+                    ldw=48, sr=48, sb=R * 48, rpb=R)
+        self._colsum(plan, f"enc.input:{tag}", du0.data_ptr(), ngf, R, ngf, self.g("encoder.net.input.conv.bias"))
+
+    # ------------------------------------------------------------------------------------------------
+    # running
+    # ------------------------------------------------------------------------------------------------
+    def backward(self, inputs, noise=None):
+        """forward (phase 'train', losses on device) + backward; gradients in self.grad.  Returns the forward outputs."""
+        m = self.m
+        out = m.forward(inputs, "train", noise)
+        if "losses" not in out.raw:
+            raise ValueError("the training step needs traj_seq and pad_mask")
+        key = [k for k, v in m._plans.items() if v[1].outs is out.raw][0]
+        if key not in self._bplans:
+            self._bplans[key] = self._build_backward(m._plans[key][1])
+        bplan = self._bplans[key]
+        caller = torch.cuda.current_stream(m.device)
+        m._stream.wait_stream(caller)
+        stream = m._stream.cuda_stream
+        if m.use_graph:
+            if bplan.graph is None:
+                bplan.run(m._streams)
+                bplan.graph = m._capture(bplan, bplan.ops, stream)
+            rt.check(m.lib.gcpx_graph_launch(bplan.graph, stream), "graph_launch")
+        else:
+            bplan.run(m._streams)
+        caller.wait_stream(m._stream)
+        self.last_bplan = bplan
+        return out
+
+    def optimizer_step(self):
+        """RAdam on the flat vectors + one re-pack gather (gcp_builder.py:88-89,178-179)."""
+        m = self.m
+        st = torch.cuda.current_stream(m.device).cuda_stream
+        scale = 1.0
+        if self.pg is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.grad, group=self.pg)                # one RCCL all-reduce over the flat gradient (sum)
+            scale = 1.0 / dist.get_world_size(self.pg)
+        rt.check(m.lib.gcpx_radam_step(m.theta.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                       self.opt_state.data_ptr(), m.theta.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                       scale, st), "radam")
+        m.repack(st)
+
+    def step(self, inputs, noise=None):
+        out = self.backward(inputs, noise)
+        self.optimizer_step()
+        return out
+
+    def named_grads(self):
+        return {k: self.grad[o:o + int(torch.tensor(shp).prod())].view(shp) for k, (o, shp) in self.m._poff.items()}
+
+
+class _PtrHolder:
+    """wraps a raw device address so helper signatures that expect tensors (`.data_ptr()`) can take it"""
+
+    def __init__(self, p):
+        self._p = p
+
+    def data_ptr(self):
+        return self._p
