@@ -1,0 +1,113 @@
+"""Training step on MI355X (HIP forward + explicit backward + RAdam) against torch autograd over the CPU oracle.
+
+The reference's loop: optimizer.zero_grad -> model(inputs) -> loss -> total -> backward -> optimizer.step
+(/root/reference/gcp/prediction/train.py:155-163).  Stated tolerances: a parameter gradient may differ from the autograd
+gradient by 1e-3 of that gradient's max-abs (+5e-7 absolute: conv biases in front of a BatchNorm have an exactly-zero
+gradient which autograd reports as ~1e-7 rounding noise); after optimizer steps the parameters may differ by 2e-3 * lr
+per step (RAdam's normalised update magnifies tiny gradient differences where |g| ~ eps)."""
+import pytest
+import torch
+
+from helpers import make_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name, graph, **over):
+    import video_gcp_amd as V
+    from video_gcp_amd.model import GCPTreeModel
+    from video_gcp_amd.training import GCPTrainStep
+    hp = V.config(name, **over)
+    sd = V.init_params(hp, seed=1, randomize_affine=True)
+    model = GCPTreeModel(hp, params=sd, device="cuda")
+    model.use_graph = graph
+    return hp, sd, model, GCPTrainStep(model, lr=1e-3)
+
+
+def _compare_grads(gref, got, rtol=1e-3, atol=5e-7):
+    bad = []
+    for k, g in gref.items():
+        h = got[k].cpu()
+        err, scale = float((h - g).abs().max()), float(g.abs().max())
+        if err > rtol * scale + atol:
+            bad.append((k, err, scale))
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_gradients_match_autograd_c1(graph):
+    from oracle import gcp_model_oracle as O
+    hp, sd, model, tr = _setup("c1", graph)
+    inputs, noise, _ = make_inputs(hp, seed=7, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    for _ in range(2):                      # second call replays the captured graphs
+        out = tr.backward(dev_in, noise.cuda())
+    torch.cuda.synchronize()
+    gref, res, total, _ = O.gradients(sd, hp, inputs, noise)
+    assert abs(float(out.raw["losses"][5]) - float(total)) <= 2e-5 * abs(float(total))
+    _compare_grads(gref, tr.named_grads())
+
+
+def test_gradients_full_length_sequences_c1():
+    """variant A: every sequence uses all T frames (the planner's shape, cem_simulator.py:22)"""
+    from oracle import gcp_model_oracle as O
+    hp, sd, model, tr = _setup("c1", False, batch_size=3)
+    inputs, noise, _ = make_inputs(hp, seed=3, variant="A")
+    tr.backward({k: v.cuda() for k, v in inputs.items()}, noise.cuda())
+    torch.cuda.synchronize()
+    gref, _, _, _ = O.gradients(sd, hp, inputs, noise)
+    _compare_grads(gref, tr.named_grads())
+
+
+def test_radam_kernel_matches_oracle():
+    from oracle.radam_oracle import RAdamOracle
+    from video_gcp_amd import runtime as rt
+    lib = rt.load_library()
+    g = torch.Generator().manual_seed(0)
+    n = 10007
+    theta = torch.randn(n, generator=g)
+    ref = {"p": theta.clone()}
+    opt = RAdamOracle(lr=1e-2)
+    th, m, v, st = theta.cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda(), torch.zeros(4).cuda()
+    for step in range(8):                   # crosses the rho_t >= 5 switch (t = 6 for beta2 = 0.999)
+        grad = torch.randn(n, generator=g) * (10.0 ** (step % 3 - 2))
+        opt.step(ref, {"p": grad})
+        gd = grad.cuda()
+        rt.check(lib.gcpx_radam_step(th.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), st.data_ptr(), n, 1e-2, 0.9, 0.999,
+                                     1e-8, 1.0, torch.cuda.current_stream().cuda_stream), "radam")
+        torch.cuda.synchronize()
+        assert float((th.cpu() - ref["p"]).abs().max()) < 2e-6, step
+    assert float(st[0]) == 8.0
+
+
+def test_two_training_steps_c1():
+    """losses of two consecutive optimisation steps and the updated parameters against the oracle loop"""
+    from oracle import gcp_model_oracle as O
+    from oracle.radam_oracle import RAdamOracle
+    hp, sd, model, tr = _setup("c1", True)
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    opt = RAdamOracle(lr=1e-3)
+    for step in range(2):
+        inputs, noise, _ = make_inputs(hp, seed=20 + step, variant="B")
+        out = tr.step({k: v.cuda() for k, v in inputs.items()}, noise.cuda())
+        torch.cuda.synchronize()
+        gref, res, total, _ = O.gradients(ref_sd, hp, inputs, noise)
+        assert abs(float(out.raw["losses"][5]) - float(total)) <= 5e-5 * abs(float(total)), step
+        opt.step(ref_sd, gref)
+        worst = max(float((model.sd[k].cpu() - ref_sd[k]).abs().max()) for k in gref)
+        assert worst <= 2e-3 * 1e-3 * (step + 1) + 1e-7, (step, worst)
+
+
+def test_training_step_c2_shapes_runs_and_decreases_loss():
+    """full-size shapes (64x64, T=80, L=7; batch 4 to bound the run time): finite gradients, loss goes down on a fixed batch"""
+    hp, sd, model, tr = _setup("c2", True, batch_size=4)
+    tr.lr = 2e-3
+    inputs, noise, _ = make_inputs(hp, seed=5, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    losses = []
+    for _ in range(6):
+        out = tr.step(dev_in, noise.cuda())
+        losses.append(float(out.raw["losses"][5]))
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert torch.isfinite(tr.grad).all()
+    assert losses[-1] < losses[0], losses

@@ -293,18 +293,28 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ rstd, float* __restrict__ coef,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               const int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int p = 0; p < n_partial; ++p) {
+    for (int p = threadIdx.x; p < n_partial; p += 256) {
         s1 += partial[((size_t)p * 2 + 0) * C + c];
         s2 += partial[((size_t)p * 2 + 1) * C + c];
     }
-    coef[c] = gamma[c] * rstd[c];
-    coef[C + c] = (float)(s1 / count);
-    coef[2 * C + c] = (float)(s2 / count);
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+    r1[threadIdx.x] = s1;
+    r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { r1[threadIdx.x] += r1[threadIdx.x + s]; r2[threadIdx.x] += r2[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        s1 = r1[0]; s2 = r2[0];
+        coef[c] = gamma[c] * rstd[c];
+        coef[C + c] = (float)(s1 / count);
+        coef[2 * C + c] = (float)(s2 / count);
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+    }
 }
 
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ r,
@@ -423,8 +433,11 @@ __global__ void __launch_bounds__(256) im2col_image_kernel(const float* __restri
 template <int NMIX, int PITCH>
 __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restrict__ params, const float* __restrict__ target,
                                                           const float* __restrict__ row_weight, const float scale,
-                                                          float* __restrict__ dparams, const int npix) {
+                                                          float* __restrict__ dparams, float* __restrict__ colsum,
+                                                          const int npix) {
     __shared__ float4 stage4[4 * 16 * PITCH / 4];
+    __shared__ float csum[4][2][64];
+    float cs0 = 0.f, cs1 = 0.f;                    // column sums of this row's gradients: columns lane, lane + 64
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
@@ -437,6 +450,8 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
             float4* dst = reinterpret_cast<float4*>(drow + (size_t)p0 * PITCH);
             for (int i = lane; i < F4; i += 64) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if (colsum)
+            for (int i = tid; i < PITCH; i += 256) colsum[(size_t)row * PITCH + i] = 0.f;
         return;
     }
     const float* prow = params + (size_t)row * npix * PITCH;
@@ -533,7 +548,23 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
         __builtin_amdgcn_wave_barrier();
         float4* dst = reinterpret_cast<float4*>(drow + (size_t)p0 * PITCH);
         for (int i = lane; i < F4; i += 64) dst[i] = reinterpret_cast<float4*>(st)[i];
+        if (colsum) {
+#pragma unroll
+            for (int px = 0; px < 16; ++px) {
+                cs0 += st[px * PITCH + lane];
+                if (lane + 64 < PITCH) cs1 += st[px * PITCH + lane + 64];
+            }
+        }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (colsum) {
+        csum[wave][0][lane] = cs0;
+        csum[wave][1][lane] = cs1;
+        __syncthreads();
+        for (int i = tid; i < PITCH; i += 256) {
+            const int h = i >> 6, l = i & 63;
+            colsum[(size_t)row * PITCH + i] = (csum[0][h][l] + csum[1][h][l]) + (csum[2][h][l] + csum[3][h][l]);
+        }
     }
 }
 
@@ -752,7 +783,7 @@ extern "C" int gcpx_bn_bwd_finalize(const float* partial, int32_t n_partial, int
                                     const float* rstd, float* coef, float* dgamma, float* dbeta, int32_t accumulate, void* stream_) {
     STREAM();
     GCPX_CHECK_ARG(partial && gamma && rstd && coef && n_partial > 0 && C > 0 && count > 0, "bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, n_partial, C, count, gamma, rstd,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, partial, n_partial, C, count, gamma, rstd,
                        coef, dgamma, dbeta, accumulate);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
@@ -798,11 +829,11 @@ extern "C" int gcpx_im2col_image(const float* x, float* col, int32_t F, int32_t 
 }
 
 extern "C" int gcpx_dlm_nll_bwd(const float* params, const float* target, const float* row_weight, float scale, float* dparams,
-                                int32_t rows, int32_t npix, int32_t pitch, int32_t n_mix, void* stream_) {
+                                float* colsum, int32_t rows, int32_t npix, int32_t pitch, int32_t n_mix, void* stream_) {
     STREAM();
     GCPX_CHECK_ARG(params && target && dparams && rows > 0, "bad arguments");
     GCPX_CHECK_ARG(n_mix == 10 && pitch == 112 && npix % 64 == 0, "supports 10 mixtures, pitch 112, npix % 64 == 0");
-    hipLaunchKernelGGL((dlm_nll_bwd_kernel<10, 112>), dim3(rows), dim3(256), 0, stream, params, target, row_weight, scale, dparams, npix);
+    hipLaunchKernelGGL((dlm_nll_bwd_kernel<10, 112>), dim3(rows), dim3(256), 0, stream, params, target, row_weight, scale, dparams, colsum, npix);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

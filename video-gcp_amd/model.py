@@ -43,6 +43,7 @@ class _Plan:
         self.graph = None
         self.lane = 0
         self.rec = {}        # buffers / records the backward plan is built from (training step)
+        self.deferred = []   # ops waiting to be issued on a side lane (training.py)
 
     def add(self, name, fn, *args):
         self.ops.append((name, fn, args, self.lane))

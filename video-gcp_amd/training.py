@@ -48,6 +48,8 @@ class GCPTrainStep:
         self.opt_state = torch.zeros(4, device=model.device)
         self.bk = model.build_arena(self._pack_backward)
         self._bplans = {}
+        self.side_lanes = bool(hp.untied_layers)   # tied levels accumulate into the same weights: keep them on one lane
+        self.wgrad_waves = 8192               # wavefronts a split weight-gradient launch aims for (latency hiding)
         self._zeros = torch.zeros(256, device=model.device)
 
     # ------------------------------------------------------------------------------------------------
@@ -120,6 +122,32 @@ class GCPTrainStep:
     # ------------------------------------------------------------------------------------------------
     # plan-building helpers
     # ------------------------------------------------------------------------------------------------
+    # Weight / bias gradients are off the critical path (only data gradients chain): they are queued and issued on the
+    # side lanes after the producing stage, so under hipGraph capture they become parallel branches of the graph.
+    def _side(self, plan, name, fn, *args):
+        plan.deferred.append((name, fn, args))
+
+    def _flush(self, plan):
+        if not plan.deferred:
+            return
+        if not self.side_lanes:
+            for name, fn, args in plan.deferred:
+                plan.add(name, fn, *args)
+            plan.deferred = []
+            return
+        lanes = list(range(1, N_LANES))
+        plan.fork(lanes)
+        # ops of one tag (wgrad + its reduce) stay on one lane, in order
+        lane_of = plan.rec.setdefault("_lane_of", {})
+        for name, fn, args in plan.deferred:
+            tag = name.split(":")[1] if ":" in name else name
+            if tag not in lane_of:
+                lane_of[tag] = lanes[len(lane_of) % len(lanes)]
+            plan.lane = lane_of[tag]
+            plan.add(name, fn, *args)
+        plan.lane = 0
+        plan.deferred = []
+
     def g(self, name, off=0):
         """device address of the gradient of parameter `name`"""
         return self.grad.data_ptr() + 4 * (self.m._poff[name][0] + off)
@@ -138,34 +166,34 @@ class GCPTrainStep:
         a.sb, a.sr, a.rpb, a.shift, a.act, a.cmod = sb, sr, (rpb if rpb is not None else R), shift, act, cmod
         a.Cin, a.H, a.W, a.dy_rpb, a.dy_sb = Cin, H, W, dy_rpb, dy_sb
         waves = ((K + 63) // 64) * ((N + 63) // 64 if N > 16 else 1)
-        nsplit = max(1, min(2048 // waves, R // 128))
+        nsplit = max(1, min(self.wgrad_waves // waves, R // 256))
         if wmap == rt.WMAP_LINEAR and nsplit == 1 and ldw % 4 == 0 and k_off % 4 == 0:
             a.out, a.ldw, a.k_off, a.accumulate, a.partial, a.nsplit = dst, ldw, k_off, 1, 0, 1
             plan.keep.append(a)
-            plan.add(f"bw.wgrad:{tag}", lib.gcpx_wgrad, C.byref(a))
+            self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad, C.byref(a))
             return
         part = m._buf(f"bw.part:{tag}", (nsplit, n_valid, K))
         a.out, a.partial, a.nsplit = part.data_ptr(), 1, nsplit
         plan.keep.append(a)
-        plan.add(f"bw.wgrad:{tag}", lib.gcpx_wgrad, C.byref(a))
-        plan.add(f"bw.wreduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, n_valid, K, dst, wmap, Cin, ntap, Cout,
-                 (n_map.data_ptr() if n_map is not None else None), ldw, k_off, 1)
+        self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad, C.byref(a))
+        self._side(plan, f"bw.wreduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, n_valid, K, dst, wmap, Cin, ntap, Cout,
+                   (n_map.data_ptr() if n_map is not None else None), ldw, k_off, 1)
 
     def _colsum(self, plan, tag, dy, ldy, R, N, dst, dst2=None, dy_rpb=0, dy_sb=0, n_map=None):
         lib, m = self.m.lib, self.m
         nsplit = max(1, min(256, R // 2048))
         if nsplit == 1 and n_map is None:
-            plan.add(f"bw.colsum:{tag}", lib.gcpx_colsum, dy, ldy, R, N, dy_rpb, dy_sb, 1, None, dst, dst2, 1)
+            self._side(plan, f"bw.colsum:{tag}", lib.gcpx_colsum, dy, ldy, R, N, dy_rpb, dy_sb, 1, None, dst, dst2, 1)
             return
         assert dst2 is None
         nsplit = max(nsplit, 2)
         part = m._buf(f"bw.cpart:{tag}", (nsplit, N))
-        plan.add(f"bw.colsum:{tag}", lib.gcpx_colsum, dy, ldy, R, N, dy_rpb, dy_sb, nsplit, part.data_ptr(), None, None, 0)
+        self._side(plan, f"bw.colsum:{tag}", lib.gcpx_colsum, dy, ldy, R, N, dy_rpb, dy_sb, nsplit, part.data_ptr(), None, None, 0)
         if n_map is None:
-            plan.add(f"bw.creduce:{tag}", lib.gcpx_reduce_partials, part.data_ptr(), nsplit, N, N, dst, 1)
+            self._side(plan, f"bw.creduce:{tag}", lib.gcpx_reduce_partials, part.data_ptr(), nsplit, N, N, dst, 1)
         else:   # bias of the output head: kernel slot -> canonical channel
-            plan.add(f"bw.creduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, N, 1, dst, rt.WMAP_CONV, 1, 1, 0,
-                     n_map.data_ptr(), 0, 0, 1)
+            self._side(plan, f"bw.creduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, N, 1, dst, rt.WMAP_CONV, 1, 1, 0,
+                       n_map.data_ptr(), 0, 0, 1)
 
     def _dgemm(self, plan, tag, srcs, M, N, rpb, wpk, out, ob, orow, batch=None):
         """data-gradient GEMM: out = concat(srcs) @ packed(W^T)"""
@@ -212,22 +240,23 @@ class GCPTrainStep:
         self._wgrad(plan, f"{tag}.out", dout, ldo, M, out_pad, a_ptr[n_mid], mid, self.g(f"{prefix}.head.linear.weight"),
                     ldw=mid, n_valid=out_dim, sr=mid, sb=M * mid, rpb=M)
         self._colsum(plan, f"{tag}.out", dout, ldo, M, out_dim, self.g(f"{prefix}.head.linear.bias"))
-        da = m._buf(f"bw.{tag}.da", (M, mid))
-        du = m._buf(f"bw.{tag}.du", (M, mid))
+        da = m._buf(f"bw.{tag}.da{n_mid}", (M, mid))
         self._dgemm(plan, f"{tag}.out", [self._dense(dout, ldo, out_pad, M)], M, mid, M, T["wT_out"], da.data_ptr(), 0, mid)
         for l in reversed(range(n_mid)):
             nb = lib.gcpx_gn_bwd_blocks(M)
-            part = m._buf(f"bw.{tag}.gnpart", (nb, 2, mid))
+            part = m._buf(f"bw.{tag}.gnpart{l}", (nb, 2, mid))
+            du = m._buf(f"bw.{tag}.du{l + 1}", (M, mid))
             pre = f"{prefix}.pyramid-{l}"
             plan.add(f"bw.gn:{tag}.{l}", lib.gcpx_gn_lrelu_bwd, u_ptr[l], da.data_ptr(), m.sd[f"{pre}.norm.weight"].data_ptr(),
                      m.sd[f"{pre}.norm.bias"].data_ptr(), du.data_ptr(), part.data_ptr(), M, mid, hp.gn_groups,
                      C.c_float(hp.gn_eps), C.c_float(hp.leaky_slope))
-            plan.add(f"bw.gnred:{tag}.{l}", lib.gcpx_reduce_partials, part.data_ptr(), nb, 2 * mid, mid, self.g(f"{pre}.norm.weight"), 1)
-            plan.add(f"bw.gnred2:{tag}.{l}", lib.gcpx_reduce_partials, part.data_ptr() + 4 * mid, nb, 2 * mid, mid,
-                     self.g(f"{pre}.norm.bias"), 1)
+            self._side(plan, f"bw.gnred:{tag}.{l}", lib.gcpx_reduce_partials, part.data_ptr(), nb, 2 * mid, mid, self.g(f"{pre}.norm.weight"), 1)
+            self._side(plan, f"bw.gnred2:{tag}.{l}", lib.gcpx_reduce_partials, part.data_ptr() + 4 * mid, nb, 2 * mid, mid,
+                       self.g(f"{pre}.norm.bias"), 1)
             self._wgrad(plan, f"{tag}.mid{l}", du.data_ptr(), mid, M, mid, a_ptr[l], mid, self.g(f"{pre}.linear.weight"), ldw=mid,
                         sr=mid, sb=M * mid, rpb=M)
             self._colsum(plan, f"{tag}.mid{l}", du.data_ptr(), mid, M, mid, self.g(f"{pre}.linear.bias"))
+            da = m._buf(f"bw.{tag}.da{l}", (M, mid))
             self._dgemm(plan, f"{tag}.mid{l}", [self._dense(du.data_ptr(), mid, mid, M)], M, mid, M, T[f"wT_mid{l}"], da.data_ptr(), 0, mid)
         du0 = m._buf(f"bw.{tag}.du0", (M, mid))
         plan.add(f"bw.lrelu:{tag}", lib.gcpx_lrelu_bwd, a_ptr[0], da.data_ptr(), du0.data_ptr(), M * mid, C.c_float(hp.leaky_slope))
@@ -272,7 +301,8 @@ class GCPTrainStep:
         dMD = buf("bw.dMD", (B * T, S, S, pitch))
         md = o["matched_distr_kernel_order"]
         plan.add("bw.dlm_nll", lib.gcpx_dlm_nll_bwd, md.data_ptr(), tin["traj_seq"].data_ptr(), tin["pad_mask"].data_ptr(),
-                 C.c_float(hp.dense_img_rec_weight / (B * div)), dMD.data_ptr(), B * T, S * S, pitch, hp.n_mixtures)
+                 C.c_float(hp.dense_img_rec_weight / (B * div)), dMD.data_ptr(), buf("bw.dMD.colsum", (B * T, pitch)).data_ptr(),
+                 B * T, S * S, pitch, hp.n_mixtures)
         plan.add("bw.kl", lib.gcpx_kl_bwd, _addr(QZ, 2 * nv), _addr(PZ, 2 * nv), _addr(dQZ, 2 * nv), _addr(dPZ, 2 * nv), B, N, nv,
                  PS * 2 * nv, 2 * nv, C.c_float(hp.free_nats), C.c_float(hp.kl_weight / (B * div)))
         ldl = _c16(T)
@@ -295,8 +325,10 @@ class GCPTrainStep:
             self._mlp_bwd(plan, "state_regressor", "state_regressor", rec["mlp:state_regressor"], self.bk["state_regressor"],
                           dstate.data_ptr(), 16, [])
 
+        self._flush(plan)
         # ---- decoder (tree_dense_rec.py:42 backward) ----
         dE_dec, dskip = self._decoder_backward(plan, fplan, dMD, B)
+        self._flush(plan)
         plan.add("bw.addrows", lib.gcpx_add_rows, _addr(dE, nz), PS * nz, nz, dE_dec.data_ptr(), dE_ex.data_ptr(), B, N, nz)
 
         # ---- tree levels, leaves first (tree_utils.py:21-44 backward) ----
@@ -396,15 +428,21 @@ class GCPTrainStep:
             if dXi is not None:
                 srcs.append((dXi.data_ptr(), 2 * nz + nv, 0, nz, -1, -1, 0))
             self._tree_accum(plan, f"E{l}", dE, PS * nz, 2 * s * nz, B, n, nz, srcs)
+            self._flush(plan)
 
         # ---- temporal inference encoder + image encoders (base_gcp.py:184-213 backward) ----
         d_inf = buf("bw.d_inf", (B * T, nz))
         plan.add("bw.tscatter", lib.gcpx_timestep_scatter, _addr(dET, nz), PS * nz, nz, o["node_t"].data_ptr(), d_inf.data_ptr(),
                  B, N, T, nz)
         d_enc_traj = self._seq_backward(plan, fplan, d_inf, B)
+        self._flush(plan)
         self._encoder_backward(plan, fplan, "traj", d_enc_traj.data_ptr(), nz, 0, 0, {})
+        self._flush(plan)
         self._encoder_backward(plan, fplan, "I0", _addr(dE), nz, 1, PS * nz, dskip)
         self._encoder_backward(plan, fplan, "Ig", _addr(dE, 2 ** L * nz), nz, 1, PS * nz, {})
+        self._flush(plan)
+        if self.side_lanes:
+            plan.join(list(range(1, N_LANES)))
         plan.outs = dict(dE=dE, dHid=dHid, dET=dET, dQZ=dQZ, dPZ=dPZ, dMD=dMD, d_inf=d_inf, d_enc_traj=d_enc_traj, dE_dec=dE_dec,
                          dE_ex=dE_ex, dlen=dlen, dexist=dexist, dstate=dstate)
         return plan
@@ -442,7 +480,9 @@ class GCPTrainStep:
         self._wgrad(plan, "dec.head", dMD.data_ptr(), pitch, B * T * S * S, pitch, featA.data_ptr(), 9 * ngf,
                     self.g("decoder.gen_head.conv.weight"), mode=rt.WG_CONV3X3, Cin=ngf, H=S, W=S, wmap=rt.WMAP_CONV, ntap=9,
                     n_map=perm32)
-        self._colsum(plan, "dec.head", dMD.data_ptr(), pitch, B * T * S * S, pitch, self.g("decoder.gen_head.conv.bias"), n_map=perm32)
+        # bias: per-frame column sums come out of the NLL backward kernel
+        self._colsum(plan, "dec.head", buf("bw.dMD.colsum", (B * T, pitch)).data_ptr(), pitch, B * T, pitch,
+                     self.g("decoder.gen_head.conv.bias"), n_map=perm32)
         dA = buf("bw.dA.head", (F, S, S, ngf))
         a = m._conv_args([(dMD.data_ptr(), pitch, 1, None, None, rt.ACT_NONE)], F, S, S, S, S, ngf, ngf, self.bk["dec.head.wT"],
                          self._zeros, dA)
@@ -482,6 +522,7 @@ class GCPTrainStep:
                 plan.add(f"bw.skip:{name}", lib.gcpx_act_bwd, C.byref(a))
                 dskip[blk["skip_idx"]] = ds
             gin = (dU.data_ptr(), cin, 1)
+            self._flush(plan)
         # input block: ConvTranspose 1x1 -> 4x4 as a GEMM + BatchNorm
         ctop = m._c_top
         bn0 = rec["bn:dec.bn0"]
