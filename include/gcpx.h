@@ -333,6 +333,11 @@ int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream);
 int gcpx_wgrad_reduce(const float* partial, int32_t nsplit, int32_t N, int32_t K, float* dst, int32_t map_mode, int32_t Cin,
                       int32_t ntap, int32_t Cout, const int32_t* n_map, int64_t ldw, int32_t k_off, int32_t accumulate,
                       void* stream);
+/* LDS-tiled weight gradient of a 3x3 conv (pad 1): dy [F*H*W][ldy] (Cout rounded up to 16 columns are read), u NHWC
+   [F][H][W][Cin]; writes partial [grid][ceil16(Cout)][9*Cin] (k = tap*Cin + ci), one row block per persistent workgroup,
+   to be combined by gcpx_wgrad_reduce(map CONV).  H, W powers of two, W in {8, 16, 32k}. */
+int gcpx_wgrad_conv3x3(const float* dy, int32_t ldy, const float* u, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                       float* partial, int32_t grid, void* stream);
 /* bias gradient: dst[n] (+)= sum_r dy[r][n] (rows addressed like gcpx_wgrad_args.dy); dst2 = optional second destination
    (LSTM b_ih and b_hh); with nsplit > 1 the row range is split and partial [nsplit][N] is written instead of dst */
 int gcpx_colsum(const float* dy, int64_t ldy, int32_t R, int32_t N, int32_t dy_rpb, int64_t dy_sb, int32_t nsplit, float* partial,

@@ -8,7 +8,7 @@
 namespace {
 
 constexpr int ACT_BLOCKS = 1024;   // workgroups of the activation-backward kernels (= rows of their stats partials)
-constexpr int GN_ROWS_PER_BLOCK = 64;
+constexpr int GN_ROWS_PER_BLOCK = 8;
 
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
 

@@ -151,17 +151,27 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
     }
 }
 
-// partial [nsplit][N][K] -> dst in the canonical parameter layout
+// partial [nsplit][N][K] -> dst in the canonical parameter layout.  A workgroup owns 16 consecutive outputs; 16 thread
+// groups split the partial index and are combined through LDS in a fixed order.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, const int nsplit, const int N,
                                                            const int K, float* __restrict__ dst, const int map_mode,
                                                            const int Cin, const int ntap, const int Cout,
                                                            const int* __restrict__ n_map, const long long ldw,
                                                            const int k_off, const int accumulate) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)N * K) return;
-    const int n = (int)(idx / K), k = (int)(idx % K);
+    __shared__ float red[16][17];
+    const int oi = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const long long total = (long long)N * K;
+    const long long idx = (long long)blockIdx.x * 16 + oi;
     float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += partial[(size_t)z * N * K + idx];
+    if (idx < total)
+        for (int z = zl; z < nsplit; z += 16) s += partial[(size_t)z * total + idx];
+    red[zl][oi] = s;
+    __syncthreads();
+    if (zl != 0 || idx >= total) return;
+    s = 0.f;
+#pragma unroll
+    for (int z = 0; z < 16; ++z) s += red[z][oi];
+    const int n = (int)(idx / K), k = (int)(idx % K);
     long long o;
     if (map_mode == GCPX_WMAP_LINEAR) {
         o = (long long)n * ldw + k_off + k;
@@ -243,7 +253,7 @@ extern "C" int gcpx_wgrad_reduce(const float* partial, int32_t nsplit, int32_t N
     GCPX_CHECK_ARG(partial && dst && nsplit >= 1 && N > 0 && K > 0, "bad arguments");
     GCPX_CHECK_ARG(map_mode >= GCPX_WMAP_LINEAR && map_mode <= GCPX_WMAP_CONVT, "bad map_mode");
     const long long total = (long long)N * K;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, nsplit, N, K,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, partial, nsplit, N, K,
                        dst, map_mode, Cin, ntap, Cout, n_map, (long long)ldw, k_off, accumulate);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;

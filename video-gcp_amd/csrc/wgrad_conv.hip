@@ -1,0 +1,205 @@
+// Weight gradient of the decoder's 3x3 convs (pad 1) on gfx950 f32 MFMA, LDS-tiled:
+//     dW[n][tap][ci] = sum over pixels p of dY[p][n] * U[p + tap][ci]
+// (backward of blox ConvDecoder blocks / gen_head as called through /root/reference/gcp/prediction/models/tree/
+//  tree_dense_rec.py:42; the reference gets this from cuDNN via torch autograd).
+//
+// The generic gcpx_wgrad kernel reads both operands from global memory for every 64x64 block of dW (16 FLOP/B: L2
+// bound).  Here a persistent workgroup stages a TH x TW pixel tile of dY and the haloed (TH+2) x (TW+2) region of U in
+// LDS once and computes ALL taps / channels of dW for it:
+//   * MFMA i side = output channel n (A operand: lane (i, kk) reads dY[pixel p0+kk][n]), j side = input channel ci
+//     (B operand: lane (kk, j) reads U[pixel p0+kk shifted by the tap][ci]); the MFMA k index walks 4 pixels of a row;
+//   * wavefront w owns the (tap, ci-tile) groups g = w, w + NW, ... for all NT n-tiles; accumulators stay in registers
+//     across the whole launch and are written once as a partial [workgroup][n][tap*Cin + ci]; gcpx_wgrad_reduce sums the
+//     partials in a fixed order (deterministic) and maps them to the torch weight layout;
+//   * the next tile's global loads are issued before the MFMA phase of the current one.
+#include "common.cuh"
+
+namespace {
+
+template <int NT, int CIT, int NW>
+struct WCfg {
+    static constexpr int G = 9 * CIT;                       // (tap, ci-tile) groups
+    static constexpr int GPW = (G + NW - 1) / NW;            // groups per wavefront
+    static constexpr int N = NT * 16, CC = CIT * 16;
+    static constexpr int NP = (N % 32 == 16) ? N : N + 16;   // LDS pitches = 16 mod 32: conflict-free operand reads
+    static constexpr int CP = (CC % 32 == 16) ? CC : CC + 16;
+};
+
+template <int NT, int CIT, int NW, int TW>
+__global__ void __launch_bounds__(NW * 64) wgrad_conv3x3_kernel(const float* __restrict__ dy, const float* __restrict__ u,
+                                                                float* __restrict__ partial, const int F, const int H,
+                                                                const int W, const int Cin, const int ldy, const int TH) {
+    using Cfg = WCfg<NT, CIT, NW>;
+    constexpr int GPW = Cfg::GPW, N = Cfg::N, CC = Cfg::CC, NP = Cfg::NP, CP = Cfg::CP, G = Cfg::G;
+    constexpr int NTH = NW * 64;
+    extern __shared__ float4 smem4[];
+    float* sdy = reinterpret_cast<float*>(smem4);            // [PX][NP]
+    constexpr int RW = TW + 2;
+    const int PX = TH * TW, RH = TH + 2;
+    float* su = sdy + PX * NP;                               // [RH*RW][CP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ij = lane & 15, kk = lane >> 4;
+    const int ci0 = blockIdx.y * CC;                         // this workgroup's input-channel chunk
+    const int ntx = W / TW, nty = H / TH;
+    const int ntiles = F * nty * ntx;
+
+    f32x4 acc[GPW][NT];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[g][nt] = f32x4{0, 0, 0, 0};
+
+    // per-group LDS offsets of the B operand (tap shift + channel tile), in floats
+    int boff[GPW];
+    bool gok[GPW];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        const int gi = wave + g * NW;
+        gok[g] = gi < G;
+        const int tap = gok[g] ? gi / CIT : 0, cit = gok[g] ? gi % CIT : 0;
+        boff[g] = ((tap / 3) * RW + (tap % 3)) * CP + cit * 16 + ij;
+    }
+
+    // staging slots: dY tile = PX * N/4 float4, U region = RH*RW * CC/4 float4
+    constexpr int N4 = N / 4, C4 = CC / 4;
+    constexpr int MAXS = (NT == 7) ? 13 : 8;                  // float4 slots per thread kept in flight
+    const int ndy = PX * N4, nu = RH * RW * C4;
+    const int nslot = ndy + nu;
+    float4 pre[MAXS];
+
+    auto issue = [&](int tile) {
+        const int tx = tile % ntx;
+        const int t2 = tile / ntx;
+        const int f = t2 / nty, y0 = (t2 % nty) * TH, x0 = tx * TW;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const int idx = tid + s * NTH;
+            pre[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < ndy) {
+                const int p = idx / N4, c4 = idx % N4;
+                const int py = p / TW, px = p % TW;
+                pre[s] = *reinterpret_cast<const float4*>(dy + (((size_t)f * H + y0 + py) * W + x0 + px) * ldy + c4 * 4);
+            } else if (idx < nslot) {
+                const int k = idx - ndy;
+                const int r = k / C4, c4 = k % C4;
+                const int ry = r / RW, rx = r % RW;
+                const int y = y0 - 1 + ry, x = x0 - 1 + rx;
+                if (y >= 0 && y < H && x >= 0 && x < W)
+                    pre[s] = *reinterpret_cast<const float4*>(u + (((size_t)f * H + y) * W + x) * Cin + ci0 + c4 * 4);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const int idx = tid + s * NTH;
+            if (idx < ndy) {
+                const int p = idx / N4, c4 = idx % N4;
+                *reinterpret_cast<float4*>(sdy + p * NP + c4 * 4) = pre[s];
+            } else if (idx < nslot) {
+                const int k = idx - ndy;
+                const int r = k / C4, c4 = k % C4;
+                *reinterpret_cast<float4*>(su + r * CP + c4 * 4) = pre[s];
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                      // previous tile's operand reads are done
+        commit();
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        __builtin_amdgcn_s_setprio(1);
+        for (int p0 = 0; p0 < PX; p0 += 4) {
+            const int p = p0 + kk;
+            const int py = p / TW, px = p % TW;
+            const float* ap = sdy + p * NP + ij;
+            const float* bp = su + (py * RW + px) * CP;
+            float a[NT], b[GPW];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) a[nt] = ap[nt * 16];
+#pragma unroll
+            for (int g = 0; g < GPW; ++g) b[g] = bp[boff[g]];
+#pragma unroll
+            for (int g = 0; g < GPW; ++g) {
+                if (gok[g]) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[g][nt] = mfma16(a[nt], b[g], acc[g][nt]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    // partial [blockIdx.x][n][K = 9*Cin]: lane holds n = nt*16 + 4*kk + reg, k = tap*Cin + ci0 + cit*16 + ij
+    const int K = 9 * Cin;
+    float* out = partial + (size_t)blockIdx.x * N * K;
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        const int gi = wave + g * NW;
+        if (gi >= G) continue;
+        const int tap = gi / CIT, cit = gi % CIT;
+        const int k = tap * Cin + ci0 + cit * 16 + ij;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(nt * 16 + 4 * kk + r) * K + k] = acc[g][nt][r];
+    }
+}
+
+template <int NT, int CIT, int NW, int TW>
+int launch_wc2(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream) {
+    using Cfg = WCfg<NT, CIT, NW>;
+    int TH = 64 / TW;
+    if (TH > H) TH = H;
+    const int PX = TH * TW;
+    const int nslot = PX * (Cfg::N / 4) + (TH + 2) * (TW + 2) * (Cfg::CC / 4);
+    constexpr int MAXS = (NT == 7) ? 13 : 8;
+    if (nslot > MAXS * NW * 64 || PX % 4 || W % TW || H % TH) {
+        gcpx_set_error("gcpx_wgrad_conv3x3: unsupported tile (H=%d W=%d N=%d)", H, W, Cfg::N);
+        return GCPX_ERR_UNSUPPORTED;
+    }
+    const size_t lds = ((size_t)PX * Cfg::NP + (size_t)(TH + 2) * (TW + 2) * Cfg::CP) * 4;
+    auto kern = wgrad_conv3x3_kernel<NT, CIT, NW, TW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid, Cin / Cfg::CC), dim3(NW * 64), lds, stream, dy, u, partial, F, H, W, Cin, ldy, TH);
+    return GCPX_OK;
+}
+
+template <int NT, int CIT, int NW>
+int launch_wc(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream) {
+    if (W >= 32 && W % 32 == 0) return launch_wc2<NT, CIT, NW, 32>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    if (W == 16) return launch_wc2<NT, CIT, NW, 16>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    if (W == 8) return launch_wc2<NT, CIT, NW, 8>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    gcpx_set_error("gcpx_wgrad_conv3x3: unsupported width %d", W);
+    return GCPX_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// partial: [grid][N][9*Cin] (N = Cout rounded up to 16); every workgroup row is written (zeros if it had no tile)
+extern "C" int gcpx_wgrad_conv3x3(const float* dy, int32_t ldy, const float* u, int32_t F, int32_t H, int32_t W, int32_t Cin,
+                                  int32_t Cout, float* partial, int32_t grid, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(dy && u && partial && F > 0 && grid > 0, "bad arguments");
+    GCPX_CHECK_ARG(ldy % 4 == 0 && Cin % 16 == 0, "ldy % 4, Cin % 16");
+    const int NT = (Cout + 15) / 16;
+    GCPX_CHECK_ARG(ldy >= NT * 16, "dy rows must hold Cout rounded up to 16 columns");
+    int st = GCPX_ERR_UNSUPPORTED;
+    if (NT == 7 && Cin == 16) st = launch_wc<7, 1, 3>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    else if (NT == 1 && Cin % 32 == 0) st = launch_wc<1, 2, 4>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    else if (NT == 1) st = launch_wc<1, 1, 3>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    else if (NT == 2 && Cin % 32 == 0) st = launch_wc<2, 2, 4>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    else if (NT == 4 && Cin % 32 == 0) st = launch_wc<4, 2, 4>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    else gcpx_set_error("gcpx_wgrad_conv3x3: unsupported Cout=%d Cin=%d", Cout, Cin);
+    if (st != GCPX_OK) return st;
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}

@@ -120,6 +120,7 @@ SYMBOLS = [
     ("gcpx_seq_pairs", C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     ("gcpx_masked_row_sum", C.c_int, [vp, vp, vp, i32, i32, vp]),
     ("gcpx_wgrad", C.c_int, [C.POINTER(WgradArgs), vp]),
+    ("gcpx_wgrad_conv3x3", C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     ("gcpx_wgrad_reduce", C.c_int, [vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, i64, i32, i32, vp]),
     ("gcpx_colsum", C.c_int, [vp, i64, i32, i32, i32, i64, i32, vp, vp, vp, i32, vp]),
     ("gcpx_reduce_partials", C.c_int, [vp, i32, i64, i32, vp, i32, vp]),

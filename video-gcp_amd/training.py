@@ -166,7 +166,7 @@ class GCPTrainStep:
         a.sb, a.sr, a.rpb, a.shift, a.act, a.cmod = sb, sr, (rpb if rpb is not None else R), shift, act, cmod
         a.Cin, a.H, a.W, a.dy_rpb, a.dy_sb = Cin, H, W, dy_rpb, dy_sb
         waves = ((K + 63) // 64) * ((N + 63) // 64 if N > 16 else 1)
-        nsplit = max(1, min(self.wgrad_waves // waves, R // 256))
+        nsplit = max(1, min(self.wgrad_waves // waves, R // 256, 512))
         if wmap == rt.WMAP_LINEAR and nsplit == 1 and ldw % 4 == 0 and k_off % 4 == 0:
             a.out, a.ldw, a.k_off, a.accumulate, a.partial, a.nsplit = dst, ldw, k_off, 1, 0, 1
             plan.keep.append(a)
@@ -178,6 +178,18 @@ class GCPTrainStep:
         self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad, C.byref(a))
         self._side(plan, f"bw.wreduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, n_valid, K, dst, wmap, Cin, ntap, Cout,
                    (n_map.data_ptr() if n_map is not None else None), ldw, k_off, 1)
+
+    def _wgrad_conv3(self, plan, tag, dy, ldy, u, F, Hh, Ww, Cin, Cout, dst, n_map=None):
+        """LDS-tiled 3x3 conv weight gradient (decoder blocks / output head) + its deterministic reduction"""
+        lib, m = self.m.lib, self.m
+        N16 = _c16(Cout)
+        ych = Cin // 32 if (Cin % 32 == 0 and N16 != 112) else Cin // 16
+        ntiles = F * max(1, (Hh * Ww) // 64)
+        grid = max(1, min((lib.gcpx_conv_grid() // 2) * 3 // ych, ntiles))
+        part = m._buf(f"bw.part:{tag}", (grid, N16, 9 * Cin))
+        self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad_conv3x3, dy, ldy, u, F, Hh, Ww, Cin, Cout, part.data_ptr(), grid)
+        self._side(plan, f"bw.wreduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), grid, N16, 9 * Cin, dst, rt.WMAP_CONV, Cin, 9, 0,
+                   (n_map.data_ptr() if n_map is not None else None), 0, 0, 1)
 
     def _colsum(self, plan, tag, dy, ldy, R, N, dst, dst2=None, dy_rpb=0, dy_sb=0, n_map=None):
         lib, m = self.m.lib, self.m
@@ -477,9 +489,8 @@ class GCPTrainStep:
         a.src_row_map = f2n_abs.data_ptr()
         plan.keep.append(a)
         plan.add("bw.stage:head", lib.gcpx_conv_stage, C.byref(a))
-        self._wgrad(plan, "dec.head", dMD.data_ptr(), pitch, B * T * S * S, pitch, featA.data_ptr(), 9 * ngf,
-                    self.g("decoder.gen_head.conv.weight"), mode=rt.WG_CONV3X3, Cin=ngf, H=S, W=S, wmap=rt.WMAP_CONV, ntap=9,
-                    n_map=perm32)
+        self._wgrad_conv3(plan, "dec.head", dMD.data_ptr(), pitch, featA.data_ptr(), B * T, S, S, ngf, pitch,
+                          self.g("decoder.gen_head.conv.weight"), n_map=perm32)
         # bias: per-frame column sums come out of the NLL backward kernel
         self._colsum(plan, "dec.head", buf("bw.dMD.colsum", (B * T, pitch)).data_ptr(), pitch, B * T, pitch,
                      self.g("decoder.gen_head.conv.bias"), n_map=perm32)
@@ -502,9 +513,8 @@ class GCPTrainStep:
             a = m._conv_args(blk["srcs"], F, res_in, res_in, res, res, cin, cin, self._zeros, self._zeros, U, upsample=1)
             plan.keep.append(a)
             plan.add(f"bw.stage:{name}", lib.gcpx_conv_stage, C.byref(a))
-            self._wgrad(plan, f"dec.{name}", dy.data_ptr(), cout, F * res * res, cout, U.data_ptr(), 9 * cin,
-                        self.g(f"decoder.net.{name}.conv.weight"), mode=rt.WG_CONV3X3, Cin=cin, H=res, W=res, wmap=rt.WMAP_CONV,
-                        ntap=9)
+            self._wgrad_conv3(plan, f"dec.{name}", dy.data_ptr(), cout, U.data_ptr(), F, res, res, cin, cout,
+                              self.g(f"decoder.net.{name}.conv.weight"))
             dU = buf(f"bw.dU.{name}", (F, res, res, cin))
             for h in range((cin + 63) // 64):
                 ch = min(64, cin - 64 * h)
