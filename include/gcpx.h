@@ -326,7 +326,12 @@ typedef struct gcpx_wgrad_args {
     int32_t R, N, n_valid;  /* rows; columns of dy to read (N % 4 == 0 when > 16); rows of dW to write */
     int32_t K, mode, Cin, H, W, rpb, shift, act, cmod;
     int32_t k_off, accumulate, partial, nsplit;
-    int32_t dy_rpb, _pad;
+    int32_t dy_rpb;
+    int32_t nbatch;         /* > 1 (direct mode): blockIdx.z = b runs the same problem with dy advanced by b*z_dy_off, x by b*z_x_off,
+                               out by b*z_out_off and dbias by b*z_bias_off floats (the 2*n_lstm_layers split_linear projections) */
+    float* dbias;           /* optional (direct mode): dbias[n] (+)= sum_r dy[r][n], fused bias gradient */
+    float* dbias2;          /* optional second destination of the same sums (LSTM b_ih / b_hh; not batched) */
+    int64_t z_dy_off, z_x_off, z_out_off, z_bias_off;
 } gcpx_wgrad_args;
 
 int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream);

@@ -51,7 +51,7 @@ def test_struct_layout_matches_header():
              offsetof(gcpx_mlp_args, out), offsetof(gcpx_mlp_args, zrow));
       printf("%zu %zu %zu %zu %zu\n", sizeof(gcpx_wgrad_args), sizeof(gcpx_lstm_bwd_args), sizeof(gcpx_tree_accum_args),
              sizeof(gcpx_actbwd_args), sizeof(gcpx_loss_args));
-      printf("%zu %zu %zu %zu %zu\n", offsetof(gcpx_wgrad_args, ldy), offsetof(gcpx_wgrad_args, dy_rpb),
+      printf("%zu %zu %zu %zu %zu\n", offsetof(gcpx_wgrad_args, ldy), offsetof(gcpx_wgrad_args, z_bias_off),
              offsetof(gcpx_lstm_bwd_args, dcp_stride), offsetof(gcpx_tree_accum_args, dst), offsetof(gcpx_actbwd_args, ldc));
       printf("%zu %zu %zu\n", offsetof(gcpx_conv_args, src_row_map), offsetof(gcpx_gemm_args, gates_out),
              offsetof(gcpx_mlp_args, save));
@@ -68,7 +68,7 @@ def test_struct_layout_matches_header():
             rt.ConvArgs.wpk.offset, rt.ConvArgs.stats_partial.offset, rt.GemmArgs.wpk.offset, rt.GemmArgs.h_copy.offset,
             rt.MlpArgs.w_in.offset, rt.MlpArgs.gn_eps.offset, rt.MlpArgs.out.offset, rt.MlpArgs.zrow.offset,
             C.sizeof(rt.WgradArgs), C.sizeof(rt.LstmBwdArgs), C.sizeof(rt.TreeAccumArgs), C.sizeof(rt.ActBwdArgs),
-            C.sizeof(rt.LossArgs), rt.WgradArgs.ldy.offset, rt.WgradArgs.dy_rpb.offset, rt.LstmBwdArgs.dcp_stride.offset,
+            C.sizeof(rt.LossArgs), rt.WgradArgs.ldy.offset, rt.WgradArgs.z_bias_off.offset, rt.LstmBwdArgs.dcp_stride.offset,
             rt.TreeAccumArgs.dst.offset, rt.ActBwdArgs.ldc.offset, rt.ConvArgs.src_row_map.offset,
             rt.GemmArgs.gates_out.offset, rt.MlpArgs.save.offset]
     assert got == want, (got, want)

@@ -191,7 +191,11 @@ conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty, const int n
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) wnext[ct] = wbase[ct * 64];
 
-        for (int chunk = 0; chunk < nchunk; ++chunk) {
+        // data-gradient launches: frames without a source row (tree nodes not matched to a ground-truth frame) are zero
+        bool skip = false;
+        if constexpr (!UP && TF == 1) skip = a.src_row_map != nullptr && a.src_row_map[f0] < 0;
+        if (skip && tile + (int)gridDim.x < ntiles) issue_loads(tile + gridDim.x, 0);
+        for (int chunk = 0; chunk < (skip ? 0 : nchunk); ++chunk) {
             // UP: the low-res patch `raw` is not read by the MFMA phase, so it can be written while other wavefronts
             // are still in the previous stage's MFMAs; one barrier then covers both "raw complete" and "hi free".
             if constexpr (!UP) __syncthreads();   // previous stage's LDS reads of `hi` are done

@@ -25,10 +25,16 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
     const int k0 = (blockIdx.x * 4 + wave) * 64;
     if (k0 >= a.K) return;                       // no barriers below: whole wavefronts may leave
     const int n0 = blockIdx.y * (TA == 4 ? 64 : 16);
-    const int nsplit = gridDim.z;
+    // blockIdx.z = row split (partial mode) or batch index (nbatch > 1: independent problems with strided pointers)
+    const int zb = a.nbatch > 1 ? blockIdx.z : 0;
+    const int nsplit = a.nbatch > 1 ? 1 : gridDim.z;
+    const int zs = a.nbatch > 1 ? 0 : blockIdx.z;
     const int rows_per = (((a.R + nsplit - 1) / nsplit) + 3) & ~3;
-    const int r_begin = blockIdx.z * rows_per;
+    const int r_begin = zs * rows_per;
     const int r_end = min(a.R, r_begin + rows_per);
+    const float* __restrict__ dyp = a.dy + (size_t)zb * a.z_dy_off;
+    const float* __restrict__ xpb = a.x + (size_t)zb * a.z_x_off;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);          // bias gradient: column sums of dy (wavefronts with k0 == 0)
 
     // ---- per-lane constants of the X (B operand) column group ----
     const int kcol = k0 + 4 * ij;
@@ -78,9 +84,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
                 const float* ap;
                 if (a.dy_sb) {
                     const int b = row / a.dy_rpb;
-                    ap = a.dy + (size_t)b * a.dy_sb + (size_t)(row - b * a.dy_rpb) * a.ldy + ncol;
+                    ap = dyp + (size_t)b * a.dy_sb + (size_t)(row - b * a.dy_rpb) * a.ldy + ncol;
                 } else {
-                    ap = a.dy + (size_t)row * a.ldy + ncol;
+                    ap = dyp + (size_t)row * a.ldy + ncol;
                 }
                 if (TA == 4) av[u] = *reinterpret_cast<const float4*>(ap);
                 else av[u].x = *ap;
@@ -89,12 +95,12 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
                 const float* xp = nullptr;
                 if (a.mode == GCPX_WG_ROWS || a.mode == GCPX_WG_CONV1D) {
                     if (dense) {
-                        xp = a.x + (size_t)row * a.sr + ci;
+                        xp = xpb + (size_t)row * a.sr + ci;
                     } else if (a.rowidx) {
-                        xp = a.x + (size_t)a.rowidx[row] * a.sr + ci;
+                        xp = xpb + (size_t)a.rowidx[row] * a.sr + ci;
                     } else {
                         const int b = row / a.rpb, j = row - b * a.rpb + shift;
-                        if (j >= 0 && j < a.rpb) xp = a.x + (size_t)b * a.sb + (size_t)j * a.sr + ci;
+                        if (j >= 0 && j < a.rpb) xp = xpb + (size_t)b * a.sb + (size_t)j * a.sr + ci;
                     }
                 } else if (a.mode == GCPX_WG_CONV3X3) {
                     const int x = row & (a.W - 1), y = (row >> lw) & (a.H - 1);
@@ -121,6 +127,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
                 b.x = fmaf(b.x, sc.x, sh.x); b.y = fmaf(b.y, sc.y, sh.y); b.z = fmaf(b.z, sc.z, sh.z); b.w = fmaf(b.w, sc.w, sh.w);
                 if (act == GCPX_ACT_LRELU) { b.x = lrelu(b.x, 0.2f); b.y = lrelu(b.y, 0.2f); b.z = lrelu(b.z, 0.2f); b.w = lrelu(b.w, 0.2f); }
             }
+            bsum.x += av[u].x; bsum.y += av[u].y; bsum.z += av[u].z; bsum.w += av[u].w;
             const float aa[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
             const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
@@ -130,6 +137,23 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
         }
     }
 
+    // ---- bias gradient (direct mode): sum the 4 row classes kk, lane (ij, kk == 0) owns columns ncol .. ----
+    if (a.dbias && k0 == 0 && !a.partial) {
+        bsum.x += __shfl_xor(bsum.x, 16); bsum.y += __shfl_xor(bsum.y, 16); bsum.z += __shfl_xor(bsum.z, 16); bsum.w += __shfl_xor(bsum.w, 16);
+        bsum.x += __shfl_xor(bsum.x, 32); bsum.y += __shfl_xor(bsum.y, 32); bsum.z += __shfl_xor(bsum.z, 32); bsum.w += __shfl_xor(bsum.w, 32);
+        if (kk == 0) {
+            const float bs[4] = {bsum.x, bsum.y, bsum.z, bsum.w};
+#pragma unroll
+            for (int t = 0; t < (TA == 4 ? 4 : 1); ++t) {
+                const int n = ncol + t;
+                if (n < a.n_valid) {
+                    float* d1 = a.dbias + (size_t)zb * a.z_bias_off + n;
+                    *d1 = a.accumulate ? *d1 + bs[t] : bs[t];
+                    if (a.dbias2) { float* d2 = a.dbias2 + n; *d2 = a.accumulate ? *d2 + bs[t] : bs[t]; }
+                }
+            }
+        }
+    }
     // ---- store: lane holds dW[n][k .. k+3] for n = n0 + {TA==4: 16*kk + 4*reg + ta | 4*kk + reg}, k = k0 + 4*ij ----
     if (!kvalid) return;
 #pragma unroll
@@ -141,7 +165,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
             float4 v = make_float4(acc[ta][0][reg], acc[ta][1][reg], acc[ta][2][reg], acc[ta][3][reg]);
             float* op;
             if (a.partial) op = a.out + ((size_t)blockIdx.z * a.n_valid + n) * a.K + kcol;
-            else op = a.out + (size_t)n * a.ldw + a.k_off + kcol;
+            else op = a.out + (size_t)zb * a.z_out_off + (size_t)n * a.ldw + a.k_off + kcol;
             if (!a.partial && a.accumulate) {
                 const float4 o = *reinterpret_cast<const float4*>(op);
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -228,6 +252,8 @@ extern "C" int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream_) {
     GCPX_CHECK_ARG(a->R > 0 && a->N > 0 && a->K > 0 && a->K % 4 == 0, "bad R/N/K (K % 4)");
     GCPX_CHECK_ARG(a->n_valid > 0 && a->n_valid <= a->N, "n_valid out of range");
     GCPX_CHECK_ARG(a->nsplit >= 1 && (a->partial || a->nsplit == 1), "row splits need partial output");
+    GCPX_CHECK_ARG(a->nbatch <= 1 || (!a->partial && a->nsplit == 1), "batched launches write directly");
+    GCPX_CHECK_ARG(!a->dbias || !a->partial, "fused bias gradient needs direct output");
     GCPX_CHECK_ARG(a->mode >= GCPX_WG_ROWS && a->mode <= GCPX_WG_CONV4X4S2, "bad mode");
     GCPX_CHECK_ARG(a->dy_sb == 0 || a->dy_rpb > 0, "dy_rpb <= 0");
     if (a->mode == GCPX_WG_ROWS || a->mode == GCPX_WG_CONV1D) GCPX_CHECK_ARG(a->rpb > 0, "rpb <= 0");
@@ -239,7 +265,7 @@ extern "C" int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream_) {
     const bool wide = a->N > 16;
     GCPX_CHECK_ARG(!wide || (a->N % 4 == 0 && a->ldy % 4 == 0), "N > 16 needs N % 4 == 0 and ldy % 4 == 0");
     GCPX_CHECK_ARG(a->partial || (a->ldw % 4 == 0 && a->k_off % 4 == 0), "direct output needs ldw, k_off % 4 == 0");
-    dim3 grid((kch + 3) / 4, wide ? (a->N + 63) / 64 : 1, a->nsplit);
+    dim3 grid((kch + 3) / 4, wide ? (a->N + 63) / 64 : 1, a->nbatch > 1 ? a->nbatch : a->nsplit);
     if (wide) hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, stream, *a);
     else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, stream, *a);
     GCPX_CHECK_LAUNCH();

@@ -63,7 +63,8 @@ class WgradArgs(C.Structure):
                 ("ldy", i64), ("sb", i64), ("sr", i64), ("ldw", i64), ("dy_sb", i64), ("R", i32), ("N", i32), ("n_valid", i32),
                 ("K", i32), ("mode", i32), ("Cin", i32), ("H", i32), ("W", i32), ("rpb", i32), ("shift", i32),
                 ("act", i32), ("cmod", i32), ("k_off", i32), ("accumulate", i32), ("partial", i32), ("nsplit", i32),
-                ("dy_rpb", i32), ("_pad", i32)]
+                ("dy_rpb", i32), ("nbatch", i32), ("dbias", vp), ("dbias2", vp), ("z_dy_off", i64), ("z_x_off", i64),
+                ("z_out_off", i64), ("z_bias_off", i64)]
 
 
 class LstmBwdArgs(C.Structure):

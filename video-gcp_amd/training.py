@@ -154,7 +154,9 @@ class GCPTrainStep:
 
     def _wgrad(self, plan, tag, dy, ldy, R, N, x, K, dst, ldw=0, k_off=0, n_valid=None, mode=rt.WG_ROWS, rpb=None, sb=0, sr=0,
                shift=0, rowidx=None, frame_map=None, scale=None, shiftv=None, act=0, cmod=0, Cin=0, H=0, W=0, dy_rpb=0,
-               dy_sb=0, wmap=rt.WMAP_LINEAR, ntap=1, Cout=0, n_map=None):
+               dy_sb=0, wmap=rt.WMAP_LINEAR, ntap=1, Cout=0, n_map=None, dbias=None, dbias2=None, batch=None):
+        """dbias / dbias2: gradient addresses of the layer's bias(es) (column sums of dy), fused into the launch when it
+        writes directly, a separate gcpx_colsum otherwise.  batch = (nbatch, z_dy_off, z_x_off, z_out_off, z_bias_off)."""
         lib, m = self.m.lib, self.m
         a = rt.WgradArgs()
         n_valid = N if n_valid is None else n_valid
@@ -167,11 +169,18 @@ class GCPTrainStep:
         a.Cin, a.H, a.W, a.dy_rpb, a.dy_sb = Cin, H, W, dy_rpb, dy_sb
         waves = ((K + 63) // 64) * ((N + 63) // 64 if N > 16 else 1)
         nsplit = max(1, min(self.wgrad_waves // waves, R // 256, 512))
+        if batch is not None:
+            nsplit = 1
+            a.nbatch, a.z_dy_off, a.z_x_off, a.z_out_off, a.z_bias_off = batch
         if wmap == rt.WMAP_LINEAR and nsplit == 1 and ldw % 4 == 0 and k_off % 4 == 0:
             a.out, a.ldw, a.k_off, a.accumulate, a.partial, a.nsplit = dst, ldw, k_off, 1, 0, 1
+            a.dbias, a.dbias2 = dbias, dbias2
             plan.keep.append(a)
             self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad, C.byref(a))
             return
+        assert batch is None
+        if dbias is not None:
+            self._colsum(plan, tag, dy, ldy, R, n_valid, dbias, dst2=dbias2, dy_rpb=dy_rpb, dy_sb=dy_sb)
         part = m._buf(f"bw.part:{tag}", (nsplit, n_valid, K))
         a.out, a.partial, a.nsplit = part.data_ptr(), 1, nsplit
         plan.keep.append(a)
@@ -250,8 +259,7 @@ class GCPTrainStep:
         u_ptr = [sv(1 + 2 * l) for l in range(n_mid)]
         # head
         self._wgrad(plan, f"{tag}.out", dout, ldo, M, out_pad, a_ptr[n_mid], mid, self.g(f"{prefix}.head.linear.weight"),
-                    ldw=mid, n_valid=out_dim, sr=mid, sb=M * mid, rpb=M)
-        self._colsum(plan, f"{tag}.out", dout, ldo, M, out_dim, self.g(f"{prefix}.head.linear.bias"))
+                    ldw=mid, n_valid=out_dim, sr=mid, sb=M * mid, rpb=M, dbias=self.g(f"{prefix}.head.linear.bias"))
         da = m._buf(f"bw.{tag}.da{n_mid}", (M, mid))
         self._dgemm(plan, f"{tag}.out", [self._dense(dout, ldo, out_pad, M)], M, mid, M, T["wT_out"], da.data_ptr(), 0, mid)
         for l in reversed(range(n_mid)):
@@ -266,18 +274,17 @@ class GCPTrainStep:
             self._side(plan, f"bw.gnred2:{tag}.{l}", lib.gcpx_reduce_partials, part.data_ptr() + 4 * mid, nb, 2 * mid, mid,
                        self.g(f"{pre}.norm.bias"), 1)
             self._wgrad(plan, f"{tag}.mid{l}", du.data_ptr(), mid, M, mid, a_ptr[l], mid, self.g(f"{pre}.linear.weight"), ldw=mid,
-                        sr=mid, sb=M * mid, rpb=M)
-            self._colsum(plan, f"{tag}.mid{l}", du.data_ptr(), mid, M, mid, self.g(f"{pre}.linear.bias"))
+                        sr=mid, sb=M * mid, rpb=M, dbias=self.g(f"{pre}.linear.bias"))
             da = m._buf(f"bw.{tag}.da{l}", (M, mid))
             self._dgemm(plan, f"{tag}.mid{l}", [self._dense(du.data_ptr(), mid, mid, M)], M, mid, M, T[f"wT_mid{l}"], da.data_ptr(), 0, mid)
         du0 = m._buf(f"bw.{tag}.du0", (M, mid))
         plan.add(f"bw.lrelu:{tag}", lib.gcpx_lrelu_bwd, a_ptr[0], da.data_ptr(), du0.data_ptr(), M * mid, C.c_float(hp.leaky_slope))
-        self._colsum(plan, f"{tag}.in", du0.data_ptr(), mid, M, mid, self.g(f"{prefix}.input.linear.bias"))
         koff = 0
         for i, s in enumerate(srcs):
             self._wgrad(plan, f"{tag}.in{i}", du0.data_ptr(), mid, M, mid, s.ptr, s.width, self.g(f"{prefix}.input.linear.weight"),
                         ldw=in_dim, k_off=koff, rpb=rpb, sb=s.sb, sr=s.sr, shift=s.shift,
-                        rowidx=_PtrHolder(s.rowidx) if s.rowidx else None)
+                        rowidx=_PtrHolder(s.rowidx) if s.rowidx else None,
+                        dbias=(self.g(f"{prefix}.input.linear.bias") if i == 0 else None))
             koff += s.width
         for i, (optr, ob, orow) in enumerate(dx_outs):
             wT = T[f"wT_in{i}"]
@@ -354,10 +361,9 @@ class GCPTrainStep:
             M = B * n
             dEn = _addr(dE, s * nz)
             # out linear
-            self._colsum(plan, f"out{l}", dEn, 2 * s * nz, M, nz, self.g(f"{sp}.out.bias"), dy_rpb=n, dy_sb=PS * nz)
             x_top = buf(f"x{l}.{nl}", (M, H))
             self._wgrad(plan, f"out{l}", dEn, 2 * s * nz, M, nz, x_top.data_ptr(), H, self.g(f"{sp}.out.weight"), ldw=H, sr=H,
-                        sb=M * H, rpb=M, dy_rpb=n, dy_sb=PS * nz)
+                        sb=M * H, rpb=M, dy_rpb=n, dy_sb=PS * nz, dbias=self.g(f"{sp}.out.bias"))
             dxt = buf(f"bw.dxt{l}", (M, H))
             self._dgemm(plan, f"out{l}", [m._rowsrc(dEn, PS * nz, 2 * s * nz, nz)], M, H, n, Wt["out.wT"], dxt.data_ptr(), n * H, H)
             merged = buf(f"merged{l}", (M, 2 * nl * H))
@@ -377,11 +383,10 @@ class GCPTrainStep:
                 plan.add(f"bw.lstm{l}.{i}", lib.gcpx_lstm_bwd, C.byref(a))
                 x_i = buf(f"x{l}.{i}", (M, H))
                 self._wgrad(plan, f"lstm{l}.{i}.ih", dg.data_ptr(), 4 * H, M, 4 * H, x_i.data_ptr(), H,
-                            self.g(f"{sp}.lstm.{i}.weight_ih"), ldw=H, sr=H, sb=M * H, rpb=M)
+                            self.g(f"{sp}.lstm.{i}.weight_ih"), ldw=H, sr=H, sb=M * H, rpb=M,
+                            dbias=self.g(f"{sp}.lstm.{i}.bias_ih"), dbias2=self.g(f"{sp}.lstm.{i}.bias_hh"))
                 self._wgrad(plan, f"lstm{l}.{i}.hh", dg.data_ptr(), 4 * H, M, 4 * H, _addr(merged, 2 * i * H), H,
                             self.g(f"{sp}.lstm.{i}.weight_hh"), ldw=H, sr=2 * nl * H, sb=M * 2 * nl * H, rpb=M)
-                self._colsum(plan, f"lstm{l}.{i}", dg.data_ptr(), 4 * H, M, 4 * H, self.g(f"{sp}.lstm.{i}.bias_ih"),
-                             dst2=self.g(f"{sp}.lstm.{i}.bias_hh"))
                 dxi = buf(f"bw.dxi{l}.{i}", (M, H))
                 src = [self._dense(dg.data_ptr(), 4 * H, 4 * H, M)]
                 self._dgemm(plan, f"lstm{l}.{i}.x", src, M, H, M, Wt[f"lstm{i}.wxT"], dxi.data_ptr(), 0, H)
@@ -389,7 +394,6 @@ class GCPTrainStep:
                 dh_src = dxi
             dx0 = dh_src
             # embedding of [e_l, e_r, z, e_0, e_g]
-            self._colsum(plan, f"embed{l}", dx0.data_ptr(), H, M, H, self.g(f"{sp}.embed.bias"))
             el = m._rowsrc(_addr(E), PS * nz, 2 * s * nz, nz)
             er = m._rowsrc(_addr(E, 2 * s * nz), PS * nz, 2 * s * nz, nz)
             zs = m._rowsrc(_addr(o["Z"], s * nv), PS * nv, 2 * s * nv, nv)
@@ -399,17 +403,20 @@ class GCPTrainStep:
             koff = 0
             for i, sc in enumerate(esrcs):
                 self._wgrad(plan, f"embed{l}.{i}", dx0.data_ptr(), H, M, H, sc.ptr, sc.width, self.g(f"{sp}.embed.weight"), ldw=pid,
-                            k_off=koff, rpb=n, sb=sc.sb, sr=sc.sr)
+                            k_off=koff, rpb=n, sb=sc.sb, sr=sc.sr, dbias=(self.g(f"{sp}.embed.bias") if i == 0 else None))
                 koff += sc.width
             dpi = buf(f"bw.dpi{l}", (M, pid))
             self._dgemm(plan, f"embed{l}", [self._dense(dx0.data_ptr(), H, H, M)], M, pid, M, Wt["embed.wT"], dpi.data_ptr(), 0, pid)
             # split_linear merge of the parents' hidden states
-            for j in range(2 * nl):
-                dmj = _addr(dmerged, j * H)
-                self._colsum(plan, f"proj{l}.{j}", dmj, 2 * nl * H, M, H, self.g(f"{sp}.projections.{j}.bias"))
-                for side, base in ((0, j * H), (1, 2 * s * SD + j * H)):
-                    self._wgrad(plan, f"proj{l}.{j}.{side}", dmj, 2 * nl * H, M, H, _addr(Hid, base), H,
-                                self.g(f"{sp}.projections.{j}.weight"), ldw=2 * H, k_off=side * H, rpb=n, sb=PS * SD, sr=2 * s * SD)
+            # all 2*n_lstm_layers projections in one launch per parent side (blockIdx.z = projection)
+            po = [m._poff[f"{sp}.projections.{j}.weight"][0] for j in range(2 * nl)]
+            bo = [m._poff[f"{sp}.projections.{j}.bias"][0] for j in range(2 * nl)]
+            zw, zb = po[1] - po[0], bo[1] - bo[0]
+            assert all(po[j + 1] - po[j] == zw and bo[j + 1] - bo[j] == zb for j in range(2 * nl - 1))
+            for side, base in ((0, 0), (1, 2 * s * SD)):
+                self._wgrad(plan, f"proj{l}.{side}", dmerged.data_ptr(), 2 * nl * H, M, H, _addr(Hid, base), H,
+                            self.g(f"{sp}.projections.0.weight"), ldw=2 * H, k_off=side * H, rpb=n, sb=PS * SD, sr=2 * s * SD,
+                            dbias=(self.g(f"{sp}.projections.0.bias") if side == 0 else None), batch=(2 * nl, H, H, zw, zb))
             dpar = buf(f"bw.dpar{l}", (2 * nl, M, 2 * H))
             self._dgemm(plan, f"merge{l}", [m._rowsrc(dmerged.data_ptr(), n * 2 * nl * H, 2 * nl * H, H)], M, 2 * H, n, Wt["proj.wT"],
                         dpar.data_ptr(), n * 2 * H, 2 * H, batch=(2 * nl, H, Wt["proj.wT"][0].numel(), 0, M * 2 * H))
