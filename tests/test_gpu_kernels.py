@@ -82,7 +82,7 @@ def test_gemm_sources_shift_affine_stats(env):
     gd, btd = gamma.to(dev), beta.to(dev)
     scale, shift = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
     rt.check(lib.gcpx_bn_finalize(st.data_ptr(), nrb, N, N, float(B * T), gd.data_ptr(), btd.data_ptr(),
-                                  1e-5, scale.data_ptr(), shift.data_ptr(), None, None, 0.0, _stream()), "bn_finalize")
+                                  1e-5, scale.data_ptr(), shift.data_ptr(), None, None, 0.0, None, None, _stream()), "bn_finalize")
     torch.cuda.synchronize()
     flat = want.reshape(-1, N)
     mean, var = flat.mean(0), flat.var(0, unbiased=False)
