@@ -490,6 +490,60 @@ int gcpx_event_record(void* ev, void* stream);
 int gcpx_event_elapsed_ms(void* start, void* stop, float* ms);
 int gcpx_event_destroy(void* ev);
 
+/* ===================================================================================================
+ * Adaptive (soft-DTW) frame binding + attentive inference — the long-horizon configuration
+ *   (experiments/prediction/base_configs/gcp_adaptive.py:6-11: matching_type='dtw_image', attentive_inference=True).
+ * ================================================================================================= */
+
+/* Masked single-query multi-head attention of the attentive posterior
+ *   (blox MultiheadAttention as called at adaptive_binding/attentive_inference.py:81; q / k / v already projected):
+ *   row r = (b, j), b = r / rpb:  score[h][t] = q[r][h] . k[b][t][h] / sqrt(dk / heads) / temperature[0],
+ *   frames outside [start_ind[b], end_ind[b]] masked out, softmax over t, out[r][h] = sum_t a[h][t] v[b][t][h].
+ *   q [M][dk], k [B][T][dk], v [B][T][nz], out [M][nz] dense; att [M][T] = head-averaged weights or NULL;
+ *   start_ind NULL = 0. */
+int gcpx_attention(const float* q, const float* k, const float* v, const int64_t* start_ind, const int64_t* end_ind,
+                   const float* temperature, float* out, float* att, int32_t M, int32_t rpb, int32_t T, int32_t dk, int32_t nz,
+                   int32_t heads, void* stream);
+
+/* batch_cdist(x, y, reduction='sum') of adaptive.py:44 / binding_loss.py:24 (blox.torch.ops.batch_cdist): squared L2 distance
+ *   out[b][n][t] = max(0, |x[b][n]|^2 + |y[b][t]|^2 - 2 x[b][n] . y[b][t]),  x [B][N][K], y [B][T][K], K % 32 == 0.
+ *   f32 MFMA GEMM with gcpx_cdist_splits(K) deterministic split-K partials: partial [splits][B][N][T], xnorm [B*N], ynorm [B*T]
+ *   are caller-owned scratch. */
+int gcpx_cdist_splits(int64_t K);
+int gcpx_cdist(const float* x, const float* y, int32_t B, int32_t N, int32_t T, int64_t K, float* partial, float* xnorm,
+               float* ynorm, float* out, void* stream);
+
+/* soft_dtw(cost / temp, end_ind) + normalize(w, 1) of adaptive.py:50-58 (probabilistic_dtw.py:11-122), float64 inside:
+ *   cost[b][n][t] = (dsum[b][n][t] / D) / temp[0]  ('mean' reduction of the cdist, then the matching temperature);
+ *   w[b][n][t] = P(node n is aligned with frame t) under the Gibbs distribution over monotone alignments without horizontal
+ *   moves that start at (0, 0) and end at (N-1, end_ind[b]), divided by max(sum over nodes, 1e-7).  Depth-first node order.
+ *   acc: caller-owned scratch, float64 [2*B][N][T] (forward and backward accumulators).  Needs N >= T, T <= 1024. */
+int gcpx_soft_dtw(const float* dsum, float D, const float* temp, const int64_t* end_ind, int32_t B, int32_t N, int32_t T,
+                  double* acc, float* w, void* stream);
+
+/* Bookkeeping on the matching distribution w [B][N = 2^L - 1][T] (depth-first):
+ *   frame2node [B][T]  depth-first position of argmax over nodes, first maximum in BREADTH-first order
+ *                      (tree.bf.match_dist.argmax(1), frame_binding.py:30; all-zero column -> root)
+ *   matched_idx [B][T] the same for t <= end_ind[b], -1 beyond (get_matched_pruned_seqs, base_gcp.py:358-366), or NULL
+ *   best_t [B][N]      argmax over frames (adaptive.py:119); entropy [B][N] = -sum p log p; p_n [B][N] = clamp(sum p, 0, 1)
+ *                      (tree_module.py:145-147) */
+int gcpx_match_stats(const float* w, const int64_t* end_ind, int32_t B, int32_t L, int32_t T, int32_t* frame2node,
+                     int32_t* matched_idx, int32_t* best_t, float* entropy, float* p_n, void* stream);
+
+/* AdaptiveBinding.prune_sequence (adaptive.py:62-77): node p > 0 is dropped when sigmoid(dist[b][p-1]) > threshold.
+ *   leave [B][N]; kept_idx [B][N] = depth-first positions of kept nodes then -1; count [B]; target [B][N-1] (or NULL) =
+ *   best_t[p] == best_t[p-1], the BCE target of adaptive.py:118-122. */
+int gcpx_distance_prune(const float* dist, float threshold, const int32_t* best_t, int32_t B, int32_t N, int32_t* leave,
+                        int32_t* kept_idx, int32_t* count, int32_t* target, void* stream);
+
+/* LossAveragingCriterion.loss (binding_loss.py:19-42) before pad_mask / batch mean:
+ *   nll_bt[b][t] = sum_n w[b][n][t] * (0.5 * dsum[b][n][t] * exp(-log_sigma)^2 + D * (log_sigma + 0.5 log 2 pi)) */
+int gcpx_averaging_nll(const float* dsum, const float* w, const float* log_sigma, float D, int32_t B, int32_t N, int32_t T,
+                       float* nll_bt, void* stream);
+
+/* LossAveragingCriterion.get_soft_estimates (binding_loss.py:44-58): out[b][t][:] = sum_n w[b][n][t] * x[b][n][:], rows of D floats */
+int gcpx_soft_average(const float* w, const float* x, float* out, int32_t B, int32_t N, int32_t T, int64_t D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,8 @@ import math
 import torch
 import torch.nn.functional as F
 
+from . import adaptive_oracle as AD
+
 
 # ---------------------------------------------------------------------------------------------------
 # building blocks (this build's spec of the absent blox modules)
@@ -153,17 +155,18 @@ def decode_seq(sd, hp, inputs, enc, training):
     return {k: v.reshape(B, N, *v.shape[1:]) for k, v in out.items()}
 
 
-def seq_encoder(sd, hp, enc_seq, training):
+def seq_encoder(sd, hp, enc_seq, training, prefix="inf_encoder"):
     """ConvSeqEncodingModule (base_gcp.py:133-134): [B,T,C] -> conv1d stack over time -> [B,T,C]."""
     x = enc_seq.transpose(1, 2)
     pad = hp.conv_inf_enc_kernel_size // 2
-    x = _lrelu(F.conv1d(x, sd["inf_encoder.net.input.conv.weight"], sd["inf_encoder.net.input.conv.bias"], padding=pad), hp)
+    q = f"{prefix}.net"
+    x = _lrelu(F.conv1d(x, sd[f"{q}.input.conv.weight"], sd[f"{q}.input.conv.bias"], padding=pad), hp)
     i = 0
-    while f"inf_encoder.net.pyramid-{i}.conv.weight" in sd:
-        x = F.conv1d(x, sd[f"inf_encoder.net.pyramid-{i}.conv.weight"], sd[f"inf_encoder.net.pyramid-{i}.conv.bias"], padding=pad)
-        x = _lrelu(_bn(x, sd, f"inf_encoder.net.pyramid-{i}.norm", hp, training), hp)
+    while f"{q}.pyramid-{i}.conv.weight" in sd:
+        x = F.conv1d(x, sd[f"{q}.pyramid-{i}.conv.weight"], sd[f"{q}.pyramid-{i}.conv.bias"], padding=pad)
+        x = _lrelu(_bn(x, sd, f"{q}.pyramid-{i}.norm", hp, training), hp)
         i += 1
-    x = F.conv1d(x, sd["inf_encoder.net.head.conv.weight"], sd["inf_encoder.net.head.conv.bias"], padding=pad)
+    x = F.conv1d(x, sd[f"{q}.head.conv.weight"], sd[f"{q}.head.conv.bias"], padding=pad)
     return x.transpose(1, 2).contiguous()
 
 
@@ -224,6 +227,77 @@ def _trunc_mid(tl, tr):
     return torch.where(s >= 0, s // 2, -((-s) // 2))
 
 
+def _balanced_matching_and_pruning(sd, hp, inp, out, bf, df_lat, img_df, end_ind, phase, tap):
+    B, L, T, N = end_ind.shape[0], hp.hierarchy_levels, hp.max_seq_len, hp.n_nodes
+    # ---- balanced matching (tree_module.py:132-147, frame_binding.py:42-60) ---------------------------
+    tl = torch.zeros(B, 1, dtype=torch.long) - 1
+    tr = end_ind[:, None] + 1
+    c_layers, t_layers = [], []
+    for l in range(L):
+        t = _trunc_mid(tl, tr)
+        c = F.one_hot(t, T).float()
+        c[tl == t] = 0
+        c[tr == t] = 0
+        c_layers.append(c)
+        t_layers.append(t)
+        tl, tr = _interleave(tl, t), _interleave(t, tr)
+    match_dist = torch.cat(c_layers, 1)                                         # [B,N,T] bf
+    out["match_dist"] = match_dist
+    out["timesteps_bf"] = torch.cat(t_layers, 1)
+    out["p_n"] = match_dist.sum(2).clamp(0, 1)                                   # tree_module.py:147
+
+    # ---- pruning ---------------------------------------------------------------------------------------
+    out["existence"] = predictor(sd, "tree_module.tree_modules.0.binding.existence_predictor", hp,
+                                 df_lat.reshape(B * N, -1)).reshape(B, N)         # frame_binding.py:71
+    # balanced: pruned_prediction overwritten by BalancedEvalBinding.get_all_samples (tree.py:62-65)
+    leave_df = _bf_to_df(match_dist.bool().any(-1)[:, :, None], L)[:, :, 0]
+    out["leave_df"] = leave_df
+    out["pruned_prediction"] = [img_df[i][leave_df[i]] for i in range(B)]
+    out["model_enc_seq_list"] = [df_lat[i][leave_df[i]] for i in range(B)]        # base_gcp.py:366-368 ('e_g_prime')
+
+    # ---- matched sequence for the loss (frame_binding.py:28-34, 88-99) ---------------------------------
+    if "traj_seq" in inp and phase == "train":
+        idx = match_dist.argmax(1)                                               # [B,T], 0 on padded frames (D5)
+        out["matched_idx"] = idx
+        gi = idx[:, :, None, None, None]
+        out["soft_matched_estimates"] = torch.gather(bf["images"], 1, gi.expand(B, T, *bf["images"].shape[2:]))
+        out["matched_distr"] = tap("matched_distr", torch.gather(bf["distr"], 1, gi.expand(B, T, *bf["distr"].shape[2:])))
+
+
+
+def _bf_of_df(x_df, depth):
+    """depthfirst2breadthfirst (tree_utils.py:217-219) on dim 1."""
+    return torch.cat(_depthfirst2layers(x_df, 1), 1)
+
+
+def _adaptive_matching_and_pruning(sd, hp, inp, out, bf, df_lat, img_df, end_ind, phase):
+    """AdaptiveBinding (adaptive.py:32-77) + TreeModule.compute_matching (tree_module.py:132-147) +
+    get_matched_pruned_seqs for 'dtw' (base_gcp.py:358-366)."""
+    B, L, T, N = end_ind.shape[0], hp.hierarchy_levels, hp.max_seq_len, hp.n_nodes
+    if "traj_seq" in inp and phase == "train":                                   # tree.py:54-56
+        w_df, cost_df = AD.get_w(hp, sd, img_df, inp["traj_seq"], end_ind)
+        match_dist = _bf_of_df(w_df, L)                                          # adaptive.py:60
+        out["match_dist"], out["match_dist_df"], out["cost_df"] = match_dist, w_df, cost_df
+        out["entropy"] = AD.safe_entropy(match_dist, -1)                         # tree_module.py:145
+        out["p_n"] = match_dist.sum(2).clamp(0, 1)                               # :147
+    # prune_sequence (adaptive.py:62-77)
+    pb = "tree_module.tree_modules.0.binding.distance_predictor"
+    dist = predictor(sd, pb, hp, df_lat[:, :-1].reshape(B * (N - 1), -1), df_lat[:, 1:].reshape(B * (N - 1), -1)).reshape(B, N - 1)
+    out["distances"] = dist
+    close = torch.sigmoid(dist) > hp.learned_pruning_threshold
+    close = torch.cat([torch.zeros_like(close[:, :1]), close], 1)
+    out["leave_df"] = ~close
+    out["pruned_prediction"] = [img_df[i][~close[i]] for i in range(B)]
+    if "match_dist" in out:                                                      # train: matched latents up to end_ind
+        idx = out["match_dist"].argmax(1)                                        # frame_binding.py:30 (bf order, first max)
+        out["matched_idx"] = idx
+        matched = torch.gather(bf["e_g_prime"], 1, idx[:, :, None].expand(B, T, bf["e_g_prime"].shape[2]))
+        out["model_enc_seq_list"] = [matched[i, :int(end_ind[i]) + 1] for i in range(B)]
+        out["soft_matched_estimates"] = AD.soft_estimates(out["match_dist"], bf["images"])   # adaptive.py:130-131
+    else:                                                                        # get_predicted_pruned_seqs (tree.py:69-70)
+        out["model_enc_seq_list"] = [df_lat[i][~close[i]] for i in range(B)]
+
+
 # ---------------------------------------------------------------------------------------------------
 # forward
 # ---------------------------------------------------------------------------------------------------
@@ -259,6 +333,8 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
         enc, _ = encoder(sd, hp, ts.reshape(B * T, *ts.shape[2:]), training_bn)   # batch_apply, :188
         inp["enc_traj_seq"] = tap("enc_traj_seq", enc.reshape(B, T, -1))
         inp["inf_enc_seq"] = tap("inf_enc_seq", seq_encoder(sd, hp, inp["enc_traj_seq"], training_bn))   # :199
+        if hp.attentive_inference:                                                # :200 (only the attentive posterior reads it)
+            inp["inf_enc_key_seq"] = AD.attn_key_encoder(sd, hp, inp["enc_traj_seq"], seq_encoder, training_bn)
     e0, skips = encoder(sd, hp, inp["I_0"], training_bn)                         # :208
     eg, _ = encoder(sd, hp, inp["I_g"], training_bn)                             # :209
     inp["e_0"], inp["e_g"], inp["skips"] = tap("e_0", e0[:, :, 0, 0]), tap("e_g", eg[:, :, 0, 0]), skips
@@ -284,6 +360,8 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     # _create_initial_nodes (tree.py:26-35); get_init_inds (frame_binding.py:62-65): Long tensors
     left = dict(e_g_prime=inp["e_0"][:, None], match_timesteps=torch.zeros(B, 1, dtype=torch.long) - 1, hidden=None)
     right = dict(e_g_prime=inp["e_g"][:, None], match_timesteps=end_ind[:, None] + 1, hidden=None)
+    if hp.attentive_inference:                                                  # tree.py:29
+        left["match_timesteps"] = right["match_timesteps"] = None
     start_inds = inp["start_ind"][:, None].float()
     end_inds = end_ind[:, None].float()
     layers = []
@@ -303,11 +381,17 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
         elif sample_prior:                                                      # :83-84
             z = sg["p_z_mu"] + torch.exp(sg["p_z_log_sigma"]) * flat(noise_layers[l])
         else:                                                                   # :86-94 inference
-            mt = _trunc_mid(left["match_timesteps"], right["match_timesteps"])
-            sg["match_timesteps"] = mt.reshape(R)
-            ts_idx = mt.float().long()                                          # inference.py:29-30
-            e_tilde = torch.gather(inp["inf_enc_seq"], 1, ts_idx[:, :, None].expand(B, n, hp.nz_enc))   # batchwise_index
-            qz = predictor(sd, f"{p}.inference.q", hp, e_l, e_r, flat(e_tilde))  # inference.py:35
+            if hp.attentive_inference:                                          # :87-88, attentive_inference.py:16-32
+                e_tilde, gamma = AD.attention(sd, f"{p}.inference.attention", hp, predictor, inp["inf_enc_seq"],
+                                              inp["inf_enc_key_seq"], [e_l, e_r], inp["start_ind"], end_ind)
+                sg["gamma"] = gamma
+            else:
+                mt = _trunc_mid(left["match_timesteps"], right["match_timesteps"])
+                sg["match_timesteps"] = mt.reshape(R)
+                ts_idx = mt.float().long()                                          # inference.py:29-30
+                e_tilde = flat(torch.gather(inp["inf_enc_seq"], 1, ts_idx[:, :, None].expand(B, n, hp.nz_enc)))   # batchwise_index
+            sg["e_tilde"] = e_tilde
+            qz = predictor(sd, f"{p}.inference.q", hp, e_l, e_r, e_tilde)        # inference.py:35
             sg["q_z_mu"], sg["q_z_log_sigma"] = qz[:, :hp.nz_vae], qz[:, hp.nz_vae:]
             z = sg["q_z_mu"] + torch.exp(sg["q_z_log_sigma"]) * flat(noise_layers[l])
         sg["z"] = z
@@ -329,7 +413,7 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
         # child layer inputs (tree_utils.py:37-44)
         new_left = {k: _interleave(left[k], sg[k]) for k in ("e_g_prime", "hidden")}
         new_right = {k: _interleave(sg[k], right[k]) for k in ("e_g_prime", "hidden")}
-        if "match_timesteps" in sg:
+        if "match_timesteps" in sg and left["match_timesteps"] is not None:
             new_left["match_timesteps"] = _interleave(left["match_timesteps"], sg["match_timesteps"])
             new_right["match_timesteps"] = _interleave(sg["match_timesteps"], right["match_timesteps"])
         else:
@@ -344,41 +428,12 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     bf.update(dec)
     out["tree_bf"] = bf
 
-    # ---- balanced matching (tree_module.py:132-147, frame_binding.py:42-60) ---------------------------
-    tl = torch.zeros(B, 1, dtype=torch.long) - 1
-    tr = end_ind[:, None] + 1
-    c_layers, t_layers = [], []
-    for l in range(L):
-        t = _trunc_mid(tl, tr)
-        c = F.one_hot(t, T).float()
-        c[tl == t] = 0
-        c[tr == t] = 0
-        c_layers.append(c)
-        t_layers.append(t)
-        tl, tr = _interleave(tl, t), _interleave(t, tr)
-    match_dist = torch.cat(c_layers, 1)                                         # [B,N,T] bf
-    out["match_dist"] = match_dist
-    out["timesteps_bf"] = torch.cat(t_layers, 1)
-    out["p_n"] = match_dist.sum(2).clamp(0, 1)                                   # tree_module.py:147
-
-    # ---- pruning ---------------------------------------------------------------------------------------
     df_lat = _bf_to_df(bf["e_g_prime"], L)
-    out["existence"] = predictor(sd, "tree_module.tree_modules.0.binding.existence_predictor", hp,
-                                 df_lat.reshape(B * N, -1)).reshape(B, N)         # frame_binding.py:71
-    # balanced: pruned_prediction overwritten by BalancedEvalBinding.get_all_samples (tree.py:62-65)
-    leave_df = _bf_to_df(match_dist.bool().any(-1)[:, :, None], L)[:, :, 0]
     img_df = _bf_to_df(bf["images"], L)
-    out["leave_df"] = leave_df
-    out["pruned_prediction"] = [img_df[i][leave_df[i]] for i in range(B)]
-    out["model_enc_seq_list"] = [df_lat[i][leave_df[i]] for i in range(B)]        # base_gcp.py:366-368 ('e_g_prime')
-
-    # ---- matched sequence for the loss (frame_binding.py:28-34, 88-99) ---------------------------------
-    if "traj_seq" in inp and phase == "train":
-        idx = match_dist.argmax(1)                                               # [B,T], 0 on padded frames (D5)
-        out["matched_idx"] = idx
-        gi = idx[:, :, None, None, None]
-        out["soft_matched_estimates"] = torch.gather(bf["images"], 1, gi.expand(B, T, *bf["images"].shape[2:]))
-        out["matched_distr"] = tap("matched_distr", torch.gather(bf["distr"], 1, gi.expand(B, T, *bf["distr"].shape[2:])))
+    if hp.adaptive:
+        _adaptive_matching_and_pruning(sd, hp, inp, out, bf, df_lat, img_df, end_ind, phase)
+    else:
+        _balanced_matching_and_pruning(sd, hp, inp, out, bf, df_lat, img_df, end_ind, phase, tap)
 
     # ---- run_auxilliary_models (base_gcp.py:234-262) ---------------------------------------------------
     mes = torch.nn.utils.rnn.pad_sequence(out["model_enc_seq_list"], batch_first=True)   # :242
@@ -419,7 +474,9 @@ def losses(sd, hp, inputs, out):
     bf = out["tree_bf"]
     pm = inputs["pad_mask"]
     tgt = inputs["traj_seq"]
-    if hp.decoder_distribution == "gaussian":
+    if hp.adaptive:                                                              # adaptive.py:126-135, binding_loss.py:19-42
+        nll = AD.averaging_loss(hp, sd, bf["images"], tgt, out["match_dist"], pm)
+    elif hp.decoder_distribution == "gaussian":
         ls = sd["decoder.log_sigma"]
         err = 0.5 * ((tgt - out["matched_distr"]) / torch.exp(ls)) ** 2 + ls + 0.5 * math.log(2 * math.pi)
         nll = (err.sum((2, 3, 4)) * pm).sum() / B
@@ -435,9 +492,16 @@ def losses(sd, hp, inputs, out):
     res["kl"] = (kl.sum() / B, hp.kl_weight)
     if hp.regress_length:
         res["len_pred"] = (F.cross_entropy(out["seq_len_logits"], inputs["end_ind"]), hp.length_pred_weight)
-    # existence BCE (frame_binding.py:80-86): target = tree.df.match_dist.sum(2)
-    tgt_ex = out["leave_df"].float()
-    res["existence_predictor"] = (F.binary_cross_entropy_with_logits(out["existence"], tgt_ex), 1.0)
+    if hp.adaptive:
+        # learned pruning (adaptive.py:118-122): target 1 where consecutive depth-first nodes share their best frame
+        best = out["match_dist_df"].argmax(-1)
+        tgt_d = (best[:, 1:] == best[:, :-1]).float()
+        res["distance_predictor"] = (F.binary_cross_entropy_with_logits(out["distances"], tgt_d), 1.0)
+        res["entropy"] = (out["entropy"].mean(), hp.entropy_weight)                 # tree_module.py:128
+    else:
+        # existence BCE (frame_binding.py:80-86): target = tree.df.match_dist.sum(2)
+        tgt_ex = out["leave_df"].float()
+        res["existence_predictor"] = (F.binary_cross_entropy_with_logits(out["existence"], tgt_ex), 1.0)
     if hp.attach_state_regressor and "traj_seq_states" in inputs:
         rl = out["regressed_state"].shape[1]
         e = (out["regressed_state"] - inputs["traj_seq_states"][:, :rl]) ** 2 * pm[:, :rl, None]

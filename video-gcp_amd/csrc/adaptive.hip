@@ -1,0 +1,455 @@
+// Adaptive (soft-DTW) frame binding and attentive inference of the long-horizon configuration (c5):
+//   image cost matrix (batch_cdist)  -> f32 MFMA "NT" GEMM with split-K partials + norm epilogue
+//   soft-DTW forward / backward sweep -> float64, one workgroup per (sequence, direction), row-parallel
+//   expected edge frequencies, column normalisation, argmax / entropy bookkeeping, averaging loss
+//   masked single-query multi-head attention over the encoded sequence
+// Reference: gcp/prediction/models/adaptive_binding/{adaptive,probabilistic_dtw,binding_loss,attentive_inference}.py
+#include "common.cuh"
+
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// attention: one wavefront per query row r = (b, j); keys / values of sequence b = r / rpb
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, const int64_t* __restrict__ start_ind,
+                                                        const int64_t* __restrict__ end_ind,
+                                                        const float* __restrict__ temperature, float* __restrict__ out,
+                                                        float* __restrict__ att, const int M, const int rpb, const int T,
+                                                        const int dk, const int nz, const int heads) {
+    extern __shared__ float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    const bool valid = r < M;
+    float* p = smem + (size_t)wave * T;
+    const int b = valid ? r / rpb : 0;
+    const int s = start_ind ? (int)start_ind[b] : 0, e = (int)end_ind[b];
+    const float* kb = k + (size_t)b * T * dk;
+    const float* vb = v + (size_t)b * T * nz;
+    const int dh = dk / heads, vh = nz / heads;
+    const float sq = sqrtf((float)dh), temp = temperature[0];
+    for (int h = 0; h < heads; ++h) {
+        float mx = -INFINITY;
+        if (valid) {
+            const float* qr = q + (size_t)r * dk + h * dh;
+            for (int t = lane; t < T; t += 64) {
+                const float* kr = kb + (size_t)t * dk + h * dh;
+                float d = 0.f;
+                for (int i = 0; i < dh; ++i) d = fmaf(qr[i], kr[i], d);
+                float sc = d / sq / temp;
+                if (t < s || t > e) sc = -INFINITY;
+                p[t] = sc;
+                mx = fmaxf(mx, sc);
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        if (valid)
+            for (int t = lane; t < T; t += 64) {
+                const float ex = (p[t] == -INFINITY) ? 0.f : expf(p[t] - mx);
+                p[t] = ex;
+                sum += ex;
+            }
+        sum = wave_sum(sum);
+        if (valid)
+            for (int t = lane; t < T; t += 64) {
+                const float a = p[t] / sum;
+                p[t] = a;
+                if (att) att[(size_t)r * T + t] = (h == 0 ? 0.f : att[(size_t)r * T + t]) + a / (float)heads;
+            }
+        __syncthreads();
+        if (valid)
+            for (int c = lane; c < vh; c += 64) {
+                const float* vc = vb + h * vh + c;
+                float acc = 0.f;
+                int t = s < 0 ? 0 : s;
+                const int te = e >= T ? T - 1 : e;
+                for (; t + 3 <= te; t += 4) {
+                    const float x0 = vc[(size_t)t * nz], x1 = vc[(size_t)(t + 1) * nz], x2 = vc[(size_t)(t + 2) * nz],
+                                x3 = vc[(size_t)(t + 3) * nz];
+                    acc = fmaf(p[t], x0, acc); acc = fmaf(p[t + 1], x1, acc); acc = fmaf(p[t + 2], x2, acc); acc = fmaf(p[t + 3], x3, acc);
+                }
+                for (; t <= te; ++t) acc = fmaf(p[t], vc[(size_t)t * nz], acc);
+                out[(size_t)r * nz + h * vh + c] = acc;
+            }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// batch_cdist: P[s][b][n][t] = sum over K-chunk s of X[b][n][k] * Y[b][t][k]   (f32 MFMA, frames on the i side)
+// workgroup = 4 wavefronts, tile 64 nodes x 64 frames, K staged through LDS 32 at a time
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cdist_gemm_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                         float* __restrict__ P, const int B, const int N, const int T,
+                                                         const int K, const int kchunk, const int tiles_t) {
+    __shared__ float sX[64][36];
+    __shared__ float sY[64][36];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n0 = (blockIdx.x / tiles_t) * 64, t0 = (blockIdx.x % tiles_t) * 64;
+    const int ks = blockIdx.y, b = blockIdx.z;
+    const float* Xb = X + (size_t)b * N * K;
+    const float* Yb = Y + (size_t)b * T * K;
+    const int nsub = (wave >> 1) * 32, tsub = (wave & 1) * 32;
+    const int li = lane & 15, kk = lane >> 4;
+    f32x4 acc[2][2];
+    for (int a = 0; a < 2; ++a)
+        for (int c = 0; c < 2; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int kbeg = ks * kchunk;
+    for (int k0 = kbeg; k0 < kbeg + kchunk; k0 += 32) {
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
+            float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vy = vx;
+            if (n0 + row < N) vx = *reinterpret_cast<const float4*>(Xb + (size_t)(n0 + row) * K + k0 + 4 * c4);
+            if (t0 + row < T) vy = *reinterpret_cast<const float4*>(Yb + (size_t)(t0 + row) * K + k0 + 4 * c4);
+            *reinterpret_cast<float4*>(&sX[row][4 * c4]) = vx;
+            *reinterpret_cast<float4*>(&sY[row][4 * c4]) = vy;
+        }
+        __syncthreads();
+        for (int kg = 0; kg < 2; ++kg) {
+            float4 ft[2], fn[2];
+            for (int a = 0; a < 2; ++a) {
+                ft[a] = *reinterpret_cast<const float4*>(&sY[tsub + 16 * a + li][16 * kg + 4 * kk]);
+                fn[a] = *reinterpret_cast<const float4*>(&sX[nsub + 16 * a + li][16 * kg + 4 * kk]);
+            }
+            for (int a = 0; a < 2; ++a)
+                for (int c = 0; c < 2; ++c) {
+                    acc[a][c] = mfma16(ft[a].x, fn[c].x, acc[a][c]);
+                    acc[a][c] = mfma16(ft[a].y, fn[c].y, acc[a][c]);
+                    acc[a][c] = mfma16(ft[a].z, fn[c].z, acc[a][c]);
+                    acc[a][c] = mfma16(ft[a].w, fn[c].w, acc[a][c]);
+                }
+        }
+        __syncthreads();
+    }
+    float* Pb = P + ((size_t)ks * B + b) * N * T;
+    for (int a = 0; a < 2; ++a)
+        for (int c = 0; c < 2; ++c) {
+            const int n = n0 + nsub + 16 * c + li;
+            if (n >= N) continue;
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + tsub + 16 * a + 4 * kk + r;
+                if (t < T) Pb[(size_t)n * T + t] = acc[a][c][r];
+            }
+        }
+}
+
+__global__ void __launch_bounds__(256) row_sumsq_kernel(const float* __restrict__ x, const long long K4, float* __restrict__ out) {
+    __shared__ float red[256];
+    const float4* xr = reinterpret_cast<const float4*>(x) + (size_t)blockIdx.x * K4;
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < K4; i += 256) {
+        const float4 v = xr[i];
+        s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256) cdist_finish_kernel(const float* __restrict__ P, const int nsplit,
+                                                           const float* __restrict__ xn, const float* __restrict__ yn,
+                                                           float* __restrict__ out, const int B, const int N, const int T) {
+    const size_t total = (size_t)B * N * T;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int t = (int)(i % T);
+        const size_t bn = i / T;
+        const int b = (int)(bn / N);
+        float dot = 0.f;
+        for (int s = 0; s < nsplit; ++s) dot += P[(size_t)s * total + i];
+        const float d = xn[bn] + yn[(size_t)b * T + t] - 2.f * dot;
+        out[i] = d > 0.f ? d : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// soft-DTW sweeps (probabilistic_dtw.py:11-73 on the stacked forward / flipped problems, :101-106).
+// 'nohor' transitions only come from the previous row, so a row is computed in parallel: thread j keeps D[i-1][j] in a
+// register and reads D[i-1][j-1] from LDS.  Same recurrence as the reference's anti-diagonal sweep.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lse2(const double a, const double b) {
+    double m = fmax(a, b);
+    if (isinf(m)) m = 0.0;
+    return log(exp(a - m) + exp(b - m)) + m;
+}
+
+__device__ __forceinline__ double neg_cost(const float dsum, const float D, const float temp) {
+    const float mean = dsum / D;
+    return -(double)(mean / temp);
+}
+
+__global__ void dtw_sweep_kernel(const float* __restrict__ dsum, const float D, const float* __restrict__ temp_p,
+                                 const int64_t* __restrict__ end_ind, double* __restrict__ acc, const int B, const int r,
+                                 const int c) {
+    extern __shared__ double sh[];
+    const int dir = blockIdx.x / B, b = blockIdx.x % B;
+    const int j = threadIdx.x;
+    const int cp = blockDim.x;
+    const int end = (int)end_ind[b];
+    const int begin = dir ? c - end - 1 : 0;
+    const float temp = temp_p[0];
+    const float* Cb = dsum + (size_t)b * r * c;
+    double* Ab = acc + (size_t)blockIdx.x * r * c;
+    const int sj = dir ? c - 1 - j : j;
+    double prev = -INFINITY;
+    for (int i = 0; i < r; ++i) {
+        const int si = dir ? r - 1 - i : i;
+        double cur = -INFINITY;
+        if (j < c) {
+            const double cij = neg_cost(Cb[(size_t)si * c + sj], D, temp);
+            if (i == 0) {
+                cur = (j == begin) ? cij : -INFINITY;
+            } else {
+                const double left = j > 0 ? sh[((i - 1) & 1) * cp + j - 1] : -INFINITY;
+                cur = cij + lse2(prev, left);
+            }
+            sh[(i & 1) * cp + j] = cur;
+            Ab[(size_t)si * c + sj] = cur;
+        }
+        prev = cur;
+        __syncthreads();
+    }
+}
+
+// expected edge frequencies w = exp(fwd + bwd - C - z) (probabilistic_dtw.py:108-114), then normalised over the node axis
+// (adaptive.py:58).  One workgroup per sequence, threads over frames.
+__global__ void dtw_combine_kernel(const float* __restrict__ dsum, const float D, const float* __restrict__ temp_p,
+                                   const int64_t* __restrict__ end_ind, const double* __restrict__ acc, float* __restrict__ w,
+                                   const int B, const int r, const int c) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t >= c) return;
+    const float temp = temp_p[0];
+    const double* F = acc + (size_t)b * r * c;
+    const double* Bw = acc + (size_t)(B + b) * r * c;
+    const float* Cb = dsum + (size_t)b * r * c;
+    float* wb = w + (size_t)b * r * c;
+    const double z = F[(size_t)(r - 1) * c + (int)end_ind[b]];
+    float colsum = 0.f;
+    for (int n = 0; n < r; ++n) {
+        const size_t o = (size_t)n * c + t;
+        const double e = F[o] + Bw[o] - neg_cost(Cb[o], D, temp);
+        const float wv = (float)exp(e - z);
+        wb[o] = wv;
+        colsum += wv;
+    }
+    const float den = fmaxf(colsum, 1e-7f);
+    for (int n = 0; n < r; ++n) wb[(size_t)n * c + t] /= den;
+}
+
+// breadth-first index q -> depth-first position
+__device__ __forceinline__ int bf2df(const int q, const int L) {
+    const int l = 31 - __clz(q + 1);
+    const int jj = q + 1 - (1 << l);
+    return (2 * jj + 1) * (1 << (L - 1 - l)) - 1;
+}
+
+// per frame: node with the largest matching probability, first maximum in breadth-first order (frame_binding.py:30)
+__global__ void __launch_bounds__(256) match_argmax_kernel(const float* __restrict__ w, const int64_t* __restrict__ end_ind,
+                                                           int32_t* __restrict__ frame2node, int32_t* __restrict__ matched_idx,
+                                                           const int B, const int L, const int T) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * T) return;
+    const int b = i / T, t = i % T;
+    const int N = (1 << L) - 1;
+    const float* wb = w + (size_t)b * N * T + t;
+    float best = -INFINITY;
+    int bp = 0;
+    for (int q = 0; q < N; ++q) {
+        const int p = bf2df(q, L);
+        const float v = wb[(size_t)p * T];
+        if (v > best) { best = v; bp = p; }
+    }
+    frame2node[i] = bp;
+    if (matched_idx) matched_idx[i] = t <= (int)end_ind[b] ? bp : -1;
+}
+
+// per node: best frame (first maximum), entropy of its matching distribution, existence probability (tree_module.py:145-147)
+__global__ void __launch_bounds__(256) match_node_stats_kernel(const float* __restrict__ w, int32_t* __restrict__ best_t,
+                                                               float* __restrict__ entropy, float* __restrict__ p_n,
+                                                               const int BN, const int T) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= BN) return;
+    const float* wr = w + (size_t)i * T;
+    float best = -INFINITY, ent = 0.f, s = 0.f;
+    int bt = 0;
+    for (int t = 0; t < T; ++t) {
+        const float v = wr[t];
+        if (v > best) { best = v; bt = t; }
+        if (v > 0.f) ent -= v * logf(v);
+        s += v;
+    }
+    best_t[i] = bt;
+    entropy[i] = ent;
+    p_n[i] = fminf(fmaxf(s, 0.f), 1.f);
+}
+
+// learned pruning (adaptive.py:62-77): keep node p unless sigmoid(distance[p-1]) > threshold; compaction of kept positions;
+// BCE target 1 where consecutive nodes share their best frame (adaptive.py:118-122)
+__global__ void distance_prune_kernel(const float* __restrict__ dist, const float thr, const int32_t* __restrict__ best_t,
+                                      int32_t* __restrict__ leave, int32_t* __restrict__ kept_idx, int32_t* __restrict__ count,
+                                      int32_t* __restrict__ target, const int B, const int N) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int k = 0;
+    for (int p = 0; p < N; ++p) {
+        int keep = 1;
+        if (p > 0) {
+            const float x = dist[(size_t)b * (N - 1) + p - 1];
+            keep = !(1.f / (1.f + expf(-x)) > thr);
+            if (target) target[(size_t)b * (N - 1) + p - 1] = best_t[(size_t)b * N + p] == best_t[(size_t)b * N + p - 1];
+        }
+        leave[(size_t)b * N + p] = keep;
+        if (keep) kept_idx[(size_t)b * N + k++] = p;
+    }
+    count[b] = k;
+    for (; k < N; ++k) kept_idx[(size_t)b * N + k] = -1;
+}
+
+// LossAveragingCriterion (binding_loss.py:19-42): nll_bt[b][t] = sum_n w[b][n][t] * (0.5 * d * exp(-ls)^2 + D * (ls + 0.5 log 2pi))
+__global__ void __launch_bounds__(256) averaging_nll_kernel(const float* __restrict__ dsum, const float* __restrict__ w,
+                                                            const float* __restrict__ log_sigma, const float D,
+                                                            float* __restrict__ nll_bt, const int B, const int N, const int T) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * T) return;
+    const int b = i / T, t = i % T;
+    const float ls = log_sigma[0];
+    const float iv = expf(-ls), c0 = D * (ls + 0.91893853320467274178f);
+    const size_t base = (size_t)b * N * T + t;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const size_t o = base + (size_t)n * T;
+        s += (0.5f * dsum[o] * (iv * iv) + c0) * w[o];
+    }
+    nll_bt[i] = s;
+}
+
+// soft_average (binding_loss.py:44-52): out[b][t][d] = sum_n w[b][n][t] * x[b][n][d]; 32 frames x 256 elements per workgroup
+__global__ void __launch_bounds__(256) soft_average_kernel(const float* __restrict__ w, const float* __restrict__ x,
+                                                           float* __restrict__ out, const int N, const int T, const long long Dd) {
+    __shared__ float sw[32];
+    const int b = blockIdx.z, t0 = blockIdx.y * 32;
+    const long long d = (long long)blockIdx.x * 256 + threadIdx.x;
+    float acc[32];
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    for (int n = 0; n < N; ++n) {
+        __syncthreads();
+        if (threadIdx.x < 32) sw[threadIdx.x] = (t0 + threadIdx.x < T) ? w[((size_t)b * N + n) * T + t0 + threadIdx.x] : 0.f;
+        __syncthreads();
+        const float xv = d < Dd ? x[((size_t)b * N + n) * Dd + d] : 0.f;
+        for (int i = 0; i < 32; ++i) acc[i] = fmaf(sw[i], xv, acc[i]);
+    }
+    if (d < Dd)
+        for (int i = 0; i < 32; ++i)
+            if (t0 + i < T) out[((size_t)b * T + t0 + i) * Dd + d] = acc[i];
+}
+
+}  // namespace
+
+extern "C" int gcpx_attention(const float* q, const float* k, const float* v, const int64_t* start_ind, const int64_t* end_ind,
+                              const float* temperature, float* out, float* att, int32_t M, int32_t rpb, int32_t T, int32_t dk,
+                              int32_t nz, int32_t heads, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(q && k && v && end_ind && temperature && out, "null pointer");
+    GCPX_CHECK_ARG(M > 0 && rpb > 0 && T > 0 && T <= 4096 && heads > 0 && dk % heads == 0 && nz % heads == 0, "bad sizes");
+    hipLaunchKernelGGL(attention_kernel, dim3((M + 3) / 4), dim3(256), 4 * T * sizeof(float), stream, q, k, v, start_ind, end_ind,
+                       temperature, out, att, M, rpb, T, dk, nz, heads);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_cdist_splits(int64_t K) {
+    for (int s = 8; s > 1; s >>= 1)
+        if (K % (32 * s) == 0) return s;
+    return 1;
+}
+
+extern "C" int gcpx_cdist(const float* x, const float* y, int32_t B, int32_t N, int32_t T, int64_t K, float* partial, float* xnorm,
+                          float* ynorm, float* out, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(x && y && partial && xnorm && ynorm && out, "null pointer");
+    GCPX_CHECK_ARG(B > 0 && N > 0 && T > 0 && K > 0 && K % 32 == 0, "K must be a positive multiple of 32");
+    const int ns = gcpx_cdist_splits(K);
+    const int tiles_n = (N + 63) / 64, tiles_t = (T + 63) / 64;
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3(B * N), dim3(256), 0, stream, x, (long long)(K / 4), xnorm);
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3(B * T), dim3(256), 0, stream, y, (long long)(K / 4), ynorm);
+    hipLaunchKernelGGL(cdist_gemm_kernel, dim3(tiles_n * tiles_t, ns, B), dim3(256), 0, stream, x, y, partial, B, N, T, (int)K,
+                       (int)(K / ns), tiles_t);
+    const size_t total = (size_t)B * N * T;
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(cdist_finish_kernel, dim3(grid), dim3(256), 0, stream, partial, ns, xnorm, ynorm, out, B, N, T);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_soft_dtw(const float* dsum, float D, const float* temp, const int64_t* end_ind, int32_t B, int32_t N, int32_t T,
+                             double* acc, float* w, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(dsum && temp && end_ind && acc && w, "null pointer");
+    GCPX_CHECK_ARG(B > 0 && N >= T && T > 0, "needs at least as many nodes as frames (probabilistic_dtw.py:36)");
+    if (T > 1024) {
+        gcpx_set_error("gcpx_soft_dtw: sequences longer than 1024 frames are not built");
+        return GCPX_ERR_UNSUPPORTED;
+    }
+    const int threads = (T + 63) / 64 * 64;
+    hipLaunchKernelGGL(dtw_sweep_kernel, dim3(2 * B), dim3(threads), 2 * threads * sizeof(double), stream, dsum, D, temp, end_ind,
+                       acc, B, N, T);
+    hipLaunchKernelGGL(dtw_combine_kernel, dim3(B), dim3(threads), 0, stream, dsum, D, temp, end_ind, acc, w, B, N, T);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_match_stats(const float* w, const int64_t* end_ind, int32_t B, int32_t L, int32_t T, int32_t* frame2node,
+                                int32_t* matched_idx, int32_t* best_t, float* entropy, float* p_n, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(w && end_ind && frame2node && best_t && entropy && p_n, "null pointer");
+    GCPX_CHECK_ARG(B > 0 && L > 0 && L < 16 && T > 0, "bad sizes");
+    const int N = (1 << L) - 1;
+    hipLaunchKernelGGL(match_argmax_kernel, dim3((B * T + 255) / 256), dim3(256), 0, stream, w, end_ind, frame2node, matched_idx, B, L, T);
+    hipLaunchKernelGGL(match_node_stats_kernel, dim3((B * N + 255) / 256), dim3(256), 0, stream, w, best_t, entropy, p_n, B * N, T);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_distance_prune(const float* dist, float threshold, const int32_t* best_t, int32_t B, int32_t N, int32_t* leave,
+                                   int32_t* kept_idx, int32_t* count, int32_t* target, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(dist && leave && kept_idx && count && B > 0 && N > 1, "null pointer / bad sizes");
+    GCPX_CHECK_ARG(!target || best_t, "targets need best_t");
+    hipLaunchKernelGGL(distance_prune_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, dist, threshold, best_t, leave, kept_idx, count,
+                       target, B, N);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_averaging_nll(const float* dsum, const float* w, const float* log_sigma, float D, int32_t B, int32_t N, int32_t T,
+                                  float* nll_bt, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(dsum && w && log_sigma && nll_bt && B > 0 && N > 0 && T > 0, "null pointer / bad sizes");
+    hipLaunchKernelGGL(averaging_nll_kernel, dim3((B * T + 255) / 256), dim3(256), 0, stream, dsum, w, log_sigma, D, nll_bt, B, N, T);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_soft_average(const float* w, const float* x, float* out, int32_t B, int32_t N, int32_t T, int64_t D, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(w && x && out && B > 0 && N > 0 && T > 0 && D > 0, "null pointer / bad sizes");
+    hipLaunchKernelGGL(soft_average_kernel, dim3((unsigned)((D + 255) / 256), (T + 31) / 32, B), dim3(256), 0, stream, w, x, out, N, T,
+                       (long long)D);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}

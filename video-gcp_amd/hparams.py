@@ -35,7 +35,9 @@ class GCPHParams:
     init_mlp_mid_sz: int = 32          # hyperparameters.py:28
     conv_inf_enc_kernel_size: int = 3  # hyperparameters.py:22
     conv_inf_enc_layers: int = 1       # hyperparameters.py:23
-    nz_attn_key: int = 32
+    nz_attn_key: int = 32              # hyperparameters.py:26
+    n_attention_heads: int = 1         # hyperparameters.py:24
+    n_attention_layers: int = 1        # hyperparameters.py:25
     # architecture
     use_skips: bool = True
     skips_stride: int = 2
@@ -44,7 +46,13 @@ class GCPHParams:
     lstm_init: str = "mlp"
     seq_enc: str = "conv"
     context_every_step: bool = True
-    matching_type: str = "balanced"
+    matching_type: str = "balanced"    # or "dtw_image" (adaptive binding, base_configs/gcp_adaptive.py:8)
+    attentive_inference: bool = False  # base_configs/gcp_adaptive.py:10
+    attention_temperature: float = 1.0  # hyperparameters.py:60 (learn_attn_temp=True: a parameter)
+    matching_temp: float = 1.0         # hyperparameters.py:94 (learn_matching_temp=False in gcp_adaptive.py:9)
+    learned_pruning_threshold: float = 0.5   # hyperparameters.py:116
+    top_bias: float = 1.0              # hyperparameters.py:100
+    leaves_bias: float = 0.0           # hyperparameters.py:99
     decoder_distribution: str = "discrete_logistic_mixture"   # or "gaussian"
     n_mixtures: int = 10               # build spec (PixelCNN++ default)
     prior_type: str = "learned"
@@ -72,6 +80,12 @@ class GCPHParams:
         assert self.img_sz in (32, 64, 128)
         assert self.nz_mid % self.gn_groups == 0 and self.init_mlp_mid_sz % self.gn_groups == 0
         assert self.decoder_distribution in ("discrete_logistic_mixture", "gaussian")
+        assert self.matching_type in ("balanced", "dtw_image")
+        assert self.nz_attn_key % self.n_attention_heads == 0 and self.nz_enc % self.n_attention_heads == 0
+
+    @property
+    def adaptive(self):
+        return self.matching_type.startswith("dtw")
 
     # ---- derived sizes ----
     @property
@@ -110,7 +124,10 @@ def config(name, **over):
         "c2": dict(batch_size=16, max_seq_len=80, img_sz=64),
         "c3": dict(batch_size=16, max_seq_len=80, img_sz=64),      # per-GPU shard of 128
         "c4": dict(batch_size=64, max_seq_len=80, img_sz=64),      # per-GPU shard of 512 candidates
-        "c5": dict(batch_size=8, max_seq_len=200, img_sz=64),      # per-GPU shard of 64
+        "c5": dict(batch_size=8, max_seq_len=200, img_sz=64,       # per-GPU shard of 64; adaptive binding + attentive
+                   matching_type="dtw_image", attentive_inference=True),       # inference (base_configs/gcp_adaptive.py:6-11)
+        "c5s": dict(batch_size=2, max_seq_len=12, img_sz=32,       # small adaptive case for parity tests (L=4, N=15)
+                    matching_type="dtw_image", attentive_inference=True),
         "tiny": dict(batch_size=2, max_seq_len=6, img_sz=32, nz_mid_lstm=64, n_lstm_layers=2,
                      nz_vae=32, nz_enc=32, nz_mid=32),
     }[name]

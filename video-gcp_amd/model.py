@@ -133,7 +133,12 @@ class GCPTreeModel:
             self.sd[k] = view
 
     def _check_hp(self, hp):
-        assert hp.matching_type == "balanced" and hp.tree_lstm == "split_linear" and hp.lstm_init == "mlp"
+        assert hp.matching_type in ("balanced", "dtw_image") and hp.tree_lstm == "split_linear" and hp.lstm_init == "mlp"
+        if hp.attentive_inference:
+            assert hp.n_attention_layers == 1, "one attention layer is built (hyperparameters.py:25 default)"
+        if hp.adaptive:
+            assert hp.top_bias == 1.0 and hp.leaves_bias == 0.0, "WeightsHacker biases are not built (defaults only)"
+            assert hp.entropy_weight == 0.0, "the matching entropy is reported, not optimised (hyperparameters.py default)"
 
     def _n_latents(self):
         return self._hp.n_nodes
@@ -242,10 +247,15 @@ class GCPTreeModel:
             P["dec.head.w"] = pk.pack_conv3x3(hw, 16)
             P["dec.head.b"] = pk.pad_vec(hb, 16)
             self._head_pitch = 16
-        for nm in ["input"] + [f"pyramid-{i}" for i in range(hp.conv_inf_enc_layers)] + ["head"]:
-            w = sd[f"inf_encoder.net.{nm}.conv.weight"]            # [Cout, Cin, k] -> K = (tap, ci)
-            P[f"seq.{nm}.w"] = pk.pack_gemm(w.permute(0, 2, 1).reshape(w.shape[0], -1))
-            P[f"seq.{nm}.b"] = sd[f"inf_encoder.net.{nm}.conv.bias"].contiguous()
+        seq_encs = [("seq", "inf_encoder")] + ([("kseq", "inf_key_encoder.0")] if hp.attentive_inference else [])
+        for tag, pre in seq_encs:
+            for nm in ["input"] + [f"pyramid-{i}" for i in range(hp.conv_inf_enc_layers)] + ["head"]:
+                w = sd[f"{pre}.net.{nm}.conv.weight"]              # [Cout, Cin, k] -> K = (tap, ci)
+                P[f"{tag}.{nm}.w"] = pk.pack_gemm(w.permute(0, 2, 1).reshape(w.shape[0], -1))
+                P[f"{tag}.{nm}.b"] = sd[f"{pre}.net.{nm}.conv.bias"].contiguous()
+        if hp.attentive_inference:
+            P["kseq.key.w"] = pk.pack_gemm(sd["inf_key_encoder.1.linear.weight"])
+            P["kseq.key.b"] = sd["inf_key_encoder.1.linear.bias"].contiguous()
         if hp.regress_length:
             P["length_pred"] = self._pack_predictor("length_pred.p", hp.max_seq_len)
         if hp.attach_state_regressor:
@@ -324,8 +334,18 @@ class GCPTreeModel:
 
     def _pack_latent_model(self, P):
         hp, sd = self._hp, self._psd
-        P["existence"] = self._pack_predictor("tree_module.tree_modules.0.binding.existence_predictor", 1)
+        if hp.adaptive:
+            P["distance"] = self._pack_predictor("tree_module.tree_modules.0.binding.distance_predictor", 1)
+        else:
+            P["existence"] = self._pack_predictor("tree_module.tree_modules.0.binding.existence_predictor", 1)
         H = hp.nz_mid_lstm
+        n_mod = hp.hierarchy_levels if hp.untied_layers else 1
+        if hp.attentive_inference:
+            # key / value projections of every level's attention stacked: one batched launch each (blockIdx.z = level)
+            att = lambda l, nm: sd[f"tree_module.tree_modules.{l}.inference.attention.attention_layers.0.{nm}"]
+            for nm in ("k_proj", "v_proj"):
+                P[f"attn.{nm}.w"] = torch.stack([pk.pack_gemm(att(l, f"{nm}.weight")) for l in range(n_mod)]).contiguous()
+                P[f"attn.{nm}.b"] = torch.stack([att(l, f"{nm}.bias") for l in range(n_mod)]).contiguous()
         for l in range(hp.hierarchy_levels if hp.untied_layers else 1):
             p = f"tree_module.tree_modules.{l}"
             T = {}
@@ -344,6 +364,13 @@ class GCPTreeModel:
             T["proj.b"] = torch.stack([sd[f"{p}.subgoal_pred.projections.{j}.bias"] for j in range(nproj)]).contiguous()
             if l == 0:
                 T["init"] = self._pack_predictor(f"{p}.lstm_initializer.net", 2 * hp.lstm_state_dim)
+            if hp.attentive_inference:
+                a = f"{p}.inference.attention"
+                T["attn.query"] = self._pack_predictor(f"{a}.query_net", hp.nz_attn_key)
+                for nm, key in (("q_proj", f"{a}.attention_layers.0.q_proj"), ("out_proj", f"{a}.attention_layers.0.out_proj"),
+                                ("out", f"{a}.out")):
+                    T[f"attn.{nm}.w"] = pk.pack_gemm(sd[f"{key}.weight"])
+                    T[f"attn.{nm}.b"] = sd[f"{key}.bias"].contiguous()
             P[f"tree{l}"] = T
 
     # ------------------------------------------------------------------------------------------------
@@ -492,6 +519,51 @@ class GCPTreeModel:
                    out=out_ptr, ob=out_ob, orow=out_orow)
         return skips
 
+    def _plan_seq_encoder(self, plan, tag, prefix, enc_traj, out, B):
+        """ConvSeqEncodingModule (base_gcp.py:130-134): three conv1d over time as shifted-row GEMMs."""
+        hp, P, lib = self._hp, self.pk, self.lib
+        T, nz = hp.max_seq_len, hp.nz_enc
+        y1 = self._buf(f"{tag}.y1", (B * T, hp.nz_mid))
+        y2 = self._buf(f"{tag}.y2", (B * T, hp.nz_mid))
+        taps = lambda t, w, **kw: [self._rowsrc(t.data_ptr(), T * w, w, w, shift=d, **kw) for d in (-1, 0, 1)]
+        self._gemm(plan, f"{tag}.input", taps(enc_traj, nz), B * T, hp.nz_mid, T, P[f"{tag}.input.w"], P[f"{tag}.input.b"],
+                   out=y1.data_ptr(), ob=T * hp.nz_mid, orow=hp.nz_mid, epi=rt.EPI_LRELU)
+        assert hp.conv_inf_enc_layers == 1
+        nrb = lib.gcpx_gemm_row_blocks(B * T, hp.nz_mid)
+        st = self._buf(f"{tag}.st", (nrb, 2, hp.nz_mid)) if self.training else None
+        self._gemm(plan, f"{tag}.pyramid-0", taps(y1, hp.nz_mid), B * T, hp.nz_mid, T, P[f"{tag}.pyramid-0.w"],
+                   P[f"{tag}.pyramid-0.b"], out=y2.data_ptr(), ob=T * hp.nz_mid, orow=hp.nz_mid, stats=st)
+        sc, sh = self._bn(plan, f"{tag}.bn", f"{prefix}.net.pyramid-0.norm", hp.nz_mid, st, nrb, hp.nz_mid, B * T)
+        self._gemm(plan, f"{tag}.head", taps(y2, hp.nz_mid, scale=sc, shiftv=sh, act=rt.ACT_LRELU, cmod=hp.nz_mid),
+                   B * T, nz, T, P[f"{tag}.head.w"], P[f"{tag}.head.b"], out=out.data_ptr(), ob=T * nz, orow=nz)
+
+    def _plan_attention(self, plan, l, W, el, er, M, n, B, Kp, Vp, tin):
+        """Attention.forward for one tree level (attentive_inference.py:47-86, one layer, mask = the sequence's own
+        [start_ind, end_ind]): query MLP -> q_proj -> masked softmax over the T frames -> out_proj -> Attention.out.
+        Returns the row source of e_tilde [M, nz_enc]; the attention weights (gamma) stay in plan.rec."""
+        hp, lib = self._hp, self.lib
+        T, nz, dk = hp.max_seq_len, hp.nz_enc, hp.nz_attn_key
+        li = l if hp.untied_layers else 0
+        qin = self._buf(f"attn.qin{l}", (M, dk))
+        self._mlp(plan, f"attn.query{l}", W["attn.query"], [el, er], M, n, out=qin.data_ptr(), ob=n * dk, orow=dk)
+        dense = lambda t, w: self._rowsrc(t.data_ptr(), 0, w, w)
+        qp = self._buf(f"attn.q{l}", (M, dk))
+        self._gemm(plan, f"attn.q_proj{l}", [dense(qin, dk)], M, dk, M, W["attn.q_proj.w"], W["attn.q_proj.b"],
+                   out=qp.data_ptr(), ob=0, orow=dk)
+        o = self._buf(f"attn.o{l}", (M, nz))
+        gamma = self._buf(f"attn.gamma{l}", (M, T))
+        temp = self.sd[f"tree_module.tree_modules.{li}.inference.attention.attention_layers.0.temperature"]
+        plan.add(f"attn{l}", lib.gcpx_attention, qp.data_ptr(), _addr(Kp, li * B * T * dk), _addr(Vp, li * B * T * nz), None,
+                 tin["end_ind"].data_ptr(), temp.data_ptr(), o.data_ptr(), gamma.data_ptr(), M, n, T, dk, nz, hp.n_attention_heads)
+        raw = self._buf(f"attn.raw{l}", (M, nz))
+        self._gemm(plan, f"attn.out_proj{l}", [dense(o, nz)], M, nz, M, W["attn.out_proj.w"], W["attn.out_proj.b"],
+                   out=raw.data_ptr(), ob=0, orow=nz)
+        et = self._buf(f"attn.e_tilde{l}", (M, nz))
+        self._gemm(plan, f"attn.out{l}", [dense(raw, nz)], M, nz, M, W["attn.out.w"], W["attn.out.b"], out=et.data_ptr(), ob=0, orow=nz)
+        plan.rec.setdefault("gamma", {})[l] = gamma
+        plan.rec.setdefault("e_tilde", {})[l] = et
+        return self._rowsrc(et.data_ptr(), n * nz, nz, nz)          # rows (b, j) of the level, as the posterior MLP walks them
+
     def _plan_decoder_features(self, plan, e_src, F, rpb, skips):
         """ConvDecoder up to (not including) the output head over F latents given by the row source `e_src` (rows are
         (b, j), j < rpb); the skip activations of I_0 are broadcast over the rpb frames of a sequence.  Returns the head's
@@ -556,10 +628,15 @@ class GCPTreeModel:
         kept_idx = self._buf("kept_idx", (B, T), torch.int32)
         node2row = self._buf("node2row", (B, N), torch.int32)
 
-        # ---- integer bookkeeping (frame_binding.py:42-65, evaluation_matching.py:192-206) ----
-        plan.add("balanced_binding", lib.gcpx_balanced_binding, tin["end_ind"].data_ptr(), B, L, T, node_t.data_ptr(),
-                 leave.data_ptr(), f2n.data_ptr(), etrow.data_ptr(), seq_len.data_ptr(), node2row.data_ptr())
-        plan.add("compact_index", lib.gcpx_compact_index, leave.data_ptr(), B, N, T, kept_idx.data_ptr())
+        adaptive, attentive = hp.adaptive, hp.attentive_inference
+        if adaptive:
+            # learned pruning keeps up to N nodes (adaptive.py:62-77): the kept-position table is N wide
+            kept_idx = self._buf("kept_idx", (B, N), torch.int32)
+        else:
+            # ---- integer bookkeeping (frame_binding.py:42-65, evaluation_matching.py:192-206) ----
+            plan.add("balanced_binding", lib.gcpx_balanced_binding, tin["end_ind"].data_ptr(), B, L, T, node_t.data_ptr(),
+                     leave.data_ptr(), f2n.data_ptr(), etrow.data_ptr(), seq_len.data_ptr(), node2row.data_ptr())
+            plan.add("compact_index", lib.gcpx_compact_index, leave.data_ptr(), B, N, T, kept_idx.data_ptr())
 
         # ---- run_encoder (base_gcp.py:184-213) ----
         enc_traj = inf_enc = None
@@ -573,21 +650,25 @@ class GCPTreeModel:
         if has_traj:
             enc_traj = self._buf("enc_traj", (B * T, nz))
             self._plan_encoder(plan, "traj", tin["traj_seq"].data_ptr(), B * T, enc_traj.data_ptr(), T * nz, nz, T)
-            # ConvSeqEncodingModule: three conv1d over time as shifted-row GEMMs
-            y1 = self._buf("seq.y1", (B * T, hp.nz_mid))
-            y2 = self._buf("seq.y2", (B * T, hp.nz_mid))
             inf_enc = self._buf("inf_enc_seq", (B * T, nz))
-            taps = lambda t, w, **kw: [self._rowsrc(t.data_ptr(), T * w, w, w, shift=d, **kw) for d in (-1, 0, 1)]
-            self._gemm(plan, "seq.input", taps(enc_traj, nz), B * T, hp.nz_mid, T, P["seq.input.w"], P["seq.input.b"],
-                       out=y1.data_ptr(), ob=T * hp.nz_mid, orow=hp.nz_mid, epi=rt.EPI_LRELU)
-            assert hp.conv_inf_enc_layers == 1
-            nrb = lib.gcpx_gemm_row_blocks(B * T, hp.nz_mid)
-            st = self._buf("seq.st", (nrb, 2, hp.nz_mid)) if self.training else None
-            self._gemm(plan, "seq.pyramid-0", taps(y1, hp.nz_mid), B * T, hp.nz_mid, T, P["seq.pyramid-0.w"],
-                       P["seq.pyramid-0.b"], out=y2.data_ptr(), ob=T * hp.nz_mid, orow=hp.nz_mid, stats=st)
-            sc, sh = self._bn(plan, "seq.bn", "inf_encoder.net.pyramid-0.norm", hp.nz_mid, st, nrb, hp.nz_mid, B * T)
-            self._gemm(plan, "seq.head", taps(y2, hp.nz_mid, scale=sc, shiftv=sh, act=rt.ACT_LRELU, cmod=hp.nz_mid),
-                       B * T, nz, T, P["seq.head.w"], P["seq.head.b"], out=inf_enc.data_ptr(), ob=T * nz, orow=nz)
+            self._plan_seq_encoder(plan, "seq", "inf_encoder", enc_traj, inf_enc, B)
+            if attentive:
+                # attention keys: second temporal encoder + per-frame Linear (base_gcp.py:122-123, :200); then the key /
+                # value projections of every level's attention in one batched launch each
+                dk = hp.nz_attn_key
+                n_mod = L if hp.untied_layers else 1
+                kenc = self._buf("inf_key_enc", (B * T, nz))
+                self._plan_seq_encoder(plan, "kseq", "inf_key_encoder.0", enc_traj, kenc, B)
+                keys = self._buf("inf_enc_key_seq", (B * T, dk))
+                dense = lambda t, w: self._rowsrc(t.data_ptr(), 0, w, w)
+                self._gemm(plan, "kseq.key", [dense(kenc, nz)], B * T, dk, B * T, P["kseq.key.w"], P["kseq.key.b"],
+                           out=keys.data_ptr(), ob=0, orow=dk)
+                Kp = self._buf("attn.K", (n_mod, B * T, dk))
+                Vp = self._buf("attn.V", (n_mod, B * T, nz))
+                self._gemm(plan, "attn.k_proj", [dense(keys, dk)], B * T, dk, B * T, P["attn.k_proj.w"], P["attn.k_proj.b"],
+                           out=Kp.data_ptr(), ob=0, orow=dk, batch=(n_mod, 0, P["attn.k_proj.w"][0].numel(), dk, B * T * dk))
+                self._gemm(plan, "attn.v_proj", [dense(inf_enc, nz)], B * T, nz, B * T, P["attn.v_proj.w"], P["attn.v_proj.b"],
+                           out=Vp.data_ptr(), ob=0, orow=nz, batch=(n_mod, 0, P["attn.v_proj.w"][0].numel(), nz, B * T * nz))
         plan.join([1, 2])
         e0 = lambda: self._rowsrc(_addr(E), PS * nz, 0, nz)
         eg = lambda: self._rowsrc(_addr(E, 2 ** L * nz), PS * nz, 0, nz)
@@ -641,8 +722,12 @@ class GCPTreeModel:
                 plan.lane = 2
                 self._mlp(plan, f"prior{l}", W["prior"], [el(), er()], M, n, out=pz_out[0], ob=pz_out[1], orow=pz_out[2])
                 plan.lane = 0
-                # posterior: gather inf_enc_seq at the node's matched timestep (inference.py:27-33)
-                et = self._rowsrc(inf_enc.data_ptr(), 0, nz, nz, rowidx=etrow[B * (n - 1):])
+                if attentive:
+                    # AttentiveInference (attentive_inference.py:16-32): e_tilde = attention over the encoded sequence
+                    et = self._plan_attention(plan, l, W, el(), er(), M, n, B, Kp, Vp, tin)
+                else:
+                    # posterior: gather inf_enc_seq at the node's matched timestep (inference.py:27-33)
+                    et = self._rowsrc(inf_enc.data_ptr(), 0, nz, nz, rowidx=etrow[B * (n - 1):])
                 g = (_addr(tin["eps"], (n - 1) * nv), N * nv, nv) + z_map
                 self._mlp(plan, f"posterior{l}", W["q"], [el(), er(), et], M, n, out=_addr(QZ, nodeoff(2 * nv)),
                           ob=PS * 2 * nv, orow=2 * s * 2 * nv, gauss=g)
@@ -672,32 +757,50 @@ class GCPTreeModel:
 
         # ---- latent-space heads: independent of the decoder, run next to it on lane 1 ----
         F = B * N
+        matching = adaptive and has_traj and phase == "train"        # soft-DTW binding is computed (tree.py:54-56)
+
+        def plan_aux(idx, Wd):
+            """run_auxilliary_models (base_gcp.py:234-262) on the pruned / matched latent sequence given by idx [B, Wd]"""
+            mes = self._buf("model_enc_seq", (B, Wd, nz))
+            plan.add("gather.model_enc_seq", lib.gcpx_gather_rows, E.data_ptr(), idx.data_ptr(), mes.data_ptr(), B, Wd, PS, 1, nz)
+            outs["model_enc_seq_padded"] = mes
+            if hp.attach_state_regressor:
+                rs = self._buf("regressed_state", (B, Wd, hp.state_dim))
+                self._mlp(plan, "state_regressor", P["state_regressor"], [self._rowsrc(mes.data_ptr(), Wd * nz, nz, nz)],
+                          B * Wd, Wd, out=rs.data_ptr(), ob=Wd * hp.state_dim, orow=hp.state_dim)
+                outs["regressed_state_padded"] = rs
+            if hp.attach_inv_mdl and phase == "train":
+                # InverseModel.full_seq_forward (inverse_mdl.py:110-134)
+                act = self._buf("actions", (B, Wd - 1, hp.n_actions))
+                first = enc_traj if has_traj else mes
+                s0 = self._rowsrc(first.data_ptr(), (T if has_traj else Wd) * nz, nz, nz)
+                s1 = self._rowsrc(_addr(mes, nz), Wd * nz, nz, nz)
+                self._mlp(plan, "inv_mdl", P["inv_mdl"], [s0, s1], B * (Wd - 1), Wd - 1, out=act.data_ptr(),
+                          ob=(Wd - 1) * hp.n_actions, orow=hp.n_actions)
+                outs["actions_padded"] = act
+
         plan.fork([1])
         plan.lane = 1
-        mes = self._buf("model_enc_seq", (B, T, nz))
-        plan.add("gather.model_enc_seq", lib.gcpx_gather_rows, E.data_ptr(), kept_idx.data_ptr(), mes.data_ptr(), B, T, PS, 1,
-                 nz)
-        outs["model_enc_seq_padded"] = mes
-        # existence predictor over depth-first latents (frame_binding.py:67-78)
-        exist = self._buf("existence", (B, N))
-        self._mlp(plan, "existence", P["existence"], [self._rowsrc(_addr(E, nz), PS * nz, nz, nz)], F, N,
-                  out=exist.data_ptr(), ob=N, orow=1)
-        outs["existence"] = exist
-        # run_auxilliary_models (base_gcp.py:234-262)
-        if hp.attach_state_regressor:
-            rs = self._buf("regressed_state", (B, T, hp.state_dim))
-            self._mlp(plan, "state_regressor", P["state_regressor"], [self._rowsrc(mes.data_ptr(), T * nz, nz, nz)],
-                      B * T, T, out=rs.data_ptr(), ob=T * hp.state_dim, orow=hp.state_dim)
-            outs["regressed_state_padded"] = rs
-        if hp.attach_inv_mdl and phase == "train":
-            # InverseModel.full_seq_forward (inverse_mdl.py:110-134)
-            act = self._buf("actions", (B, T - 1, hp.n_actions))
-            first = enc_traj if has_traj else mes
-            s0 = self._rowsrc(first.data_ptr(), T * nz, nz, nz)
-            s1 = self._rowsrc(_addr(mes, nz), T * nz, nz, nz)
-            self._mlp(plan, "inv_mdl", P["inv_mdl"], [s0, s1], B * (T - 1), T - 1, out=act.data_ptr(),
-                      ob=(T - 1) * hp.n_actions, orow=hp.n_actions)
-            outs["actions_padded"] = act
+        if adaptive:
+            # learned pruning (adaptive.py:62-77): distance predictor on consecutive depth-first latents
+            dist = self._buf("distances", (B, N - 1))
+            self._mlp(plan, "distance", P["distance"], [self._rowsrc(_addr(E, nz), PS * nz, nz, nz),
+                                                        self._rowsrc(_addr(E, 2 * nz), PS * nz, nz, nz)],
+                      B * (N - 1), N - 1, out=dist.data_ptr(), ob=N - 1, orow=1)
+            pruned_len = self._buf("pruned_len", (B,), torch.int32)
+            plan.add("distance_prune", lib.gcpx_distance_prune, dist.data_ptr(), C.c_float(hp.learned_pruning_threshold), None, B, N,
+                     leave.data_ptr(), kept_idx.data_ptr(), pruned_len.data_ptr(), None)
+            outs["distances"], outs["pruned_len"] = dist, pruned_len
+            if not matching:
+                plan_aux(kept_idx, N)                    # get_predicted_pruned_seqs (tree.py:69-70)
+                outs["aux_len"] = pruned_len
+        else:
+            plan_aux(kept_idx, T)
+            # existence predictor over depth-first latents (frame_binding.py:67-78)
+            exist = self._buf("existence", (B, N))
+            self._mlp(plan, "existence", P["existence"], [self._rowsrc(_addr(E, nz), PS * nz, nz, nz)], F, N,
+                      out=exist.data_ptr(), ob=N, orow=1)
+            outs["existence"] = exist
         plan.lane = 0
 
         # ---- dense_rec: decode every node (tree_dense_rec.py:41-44) ----
@@ -714,7 +817,7 @@ class GCPTreeModel:
             if self.materialize_distr:
                 mode, distr = rt.HEAD_DLM_BOTH, self._buf("distr_df", (B, N, S, S, self._head_pitch))
                 head_out = distr
-            elif with_loss:
+            elif with_loss and not adaptive:
                 # only the nodes matched to a ground-truth frame keep their distribution parameters
                 # (frame_binding.py:91-92): row b*T+t of matched_distr <- node matched to frame t
                 mode, matched_distr = rt.HEAD_DLM_BOTH, self._buf("matched_distr", (B, T, S, S, self._head_pitch))
@@ -731,20 +834,53 @@ class GCPTreeModel:
 
         # ---- pruning / matching gathers of decoded frames ----
         row = hp.input_nc * S * S
-        if has_traj and phase == "train":
+        if matching:
+            # AdaptiveBinding.get_w (adaptive.py:32-60): image cost matrix -> soft-DTW posterior over alignments -> w
+            ns = lib.gcpx_cdist_splits(row)
+            dsum = self._buf("cdist.dsum", (B, N, T))
+            plan.add("cdist", lib.gcpx_cdist, images.data_ptr(), tin["traj_seq"].data_ptr(), B, N, T, row,
+                     self._buf("cdist.part", (ns, B, N, T)).data_ptr(), self._buf("cdist.xn", (B * N,)).data_ptr(),
+                     self._buf("cdist.yn", (B * T,)).data_ptr(), dsum.data_ptr())
+            wdf = self._buf("match_dist_df", (B, N, T))
+            temp = self.sd["tree_module.tree_modules.0.binding.temp"]
+            plan.add("soft_dtw", lib.gcpx_soft_dtw, dsum.data_ptr(), C.c_float(float(row)), temp.data_ptr(), tin["end_ind"].data_ptr(),
+                     B, N, T, self._buf("dtw.acc", (2 * B, N, T), torch.float64).data_ptr(), wdf.data_ptr())
+            matched_idx = self._buf("matched_idx", (B, T), torch.int32)
+            best_t = self._buf("best_t", (B, N), torch.int32)
+            entropy, p_n = self._buf("entropy", (B, N)), self._buf("p_n", (B, N))
+            plan.add("match_stats", lib.gcpx_match_stats, wdf.data_ptr(), tin["end_ind"].data_ptr(), B, L, T, f2n.data_ptr(),
+                     matched_idx.data_ptr(), best_t.data_ptr(), entropy.data_ptr(), p_n.data_ptr())
+            dist_tgt = self._buf("distance_target", (B, N - 1), torch.int32)
+            plan.add("distance_target", lib.gcpx_distance_prune, outs["distances"].data_ptr(),
+                     C.c_float(hp.learned_pruning_threshold), best_t.data_ptr(), B, N, leave.data_ptr(), kept_idx.data_ptr(),
+                     outs["pruned_len"].data_ptr(), dist_tgt.data_ptr())
+            plan.add("seq_len", lib.gcpx_seq_index, tin["end_ind"].data_ptr(), B, T, self._buf("seq_idx", (B, T), torch.int32).data_ptr(),
+                     seq_len.data_ptr())
+            plan_aux(matched_idx, T)                     # get_matched_pruned_seqs for 'dtw' (base_gcp.py:358-366)
+            ent_sum = self._buf("entropy_sum", (1,))
+            plan.add("entropy_sum", lib.gcpx_reduce_partials, entropy.data_ptr(), B * N, 1, 1, ent_sum.data_ptr(), 0)
+            outs["entropy_sum"] = ent_sum
+            outs.update(cdist_sum=dsum, match_dist_df=wdf, matched_idx=matched_idx, best_t=best_t, entropy_df=entropy, p_n_df=p_n,
+                        distance_target=dist_tgt, aux_len=seq_len)
+        elif has_traj and phase == "train":
             matched = self._buf("matched_images", (B, T, hp.input_nc, S, S))
             plan.add("gather.matched", lib.gcpx_gather_rows, images.data_ptr(), f2n.data_ptr(), matched.data_ptr(), B, T, N,
                      0, row)
             outs["soft_matched_estimates"] = matched
-        pruned = self._buf("pruned_images", (B, T, hp.input_nc, S, S))
-        plan.add("gather.pruned", lib.gcpx_gather_rows, images.data_ptr(), kept_idx.data_ptr(), pruned.data_ptr(), B, T, N, 0,
+        Wp = N if adaptive else T
+        pruned = self._buf("pruned_images", (B, Wp, hp.input_nc, S, S))
+        plan.add("gather.pruned", lib.gcpx_gather_rows, images.data_ptr(), kept_idx.data_ptr(), pruned.data_ptr(), B, Wp, N, 0,
                  row)
         outs["pruned_padded"] = pruned
 
         # ---- losses (base_gcp.py:264-304, tree_module.py:116-157) ----
         if with_loss:
             nll_bt = self._buf("nll_bt", (B, T))
-            if dlm:
+            if adaptive:
+                # LossAveragingCriterion.loss (binding_loss.py:19-42)
+                plan.add("loss.averaging_nll", lib.gcpx_averaging_nll, dsum.data_ptr(), wdf.data_ptr(),
+                         self.sd["decoder.log_sigma"].data_ptr(), C.c_float(float(row)), B, N, T, nll_bt.data_ptr())
+            elif dlm:
                 if matched_distr is None:       # materialize_distr: gather the matched rows out of the full tensor
                     matched_distr = self._buf("matched_distr", (B, T, S, S, self._head_pitch))
                     plan.add("gather.matched_distr", lib.gcpx_gather_rows, distr.data_ptr(), f2n.data_ptr(),
@@ -761,12 +897,16 @@ class GCPTreeModel:
             la = rt.LossArgs()
             la.nll_bt, la.pad_mask, la.kl_b = nll_bt.data_ptr(), tin["pad_mask"].data_ptr(), kl_b.data_ptr()
             la.len_logits = outs["seq_len_logits"].data_ptr() if "seq_len_logits" in outs else None
-            la.end_ind, la.existence, la.leave = tin["end_ind"].data_ptr(), outs["existence"].data_ptr(), leave.data_ptr()
+            la.end_ind = tin["end_ind"].data_ptr()
+            if adaptive:     # BCE of the learned-pruning logits against "same best frame" (adaptive.py:118-122), N - 1 pairs
+                la.existence, la.leave = outs["distances"].data_ptr(), dist_tgt.data_ptr()
+            else:
+                la.existence, la.leave = outs["existence"].data_ptr(), leave.data_ptr()
             if "regressed_state_padded" in outs and "traj_seq_states" in tin:
                 la.regressed_state, la.state_target = outs["regressed_state_padded"].data_ptr(), tin["traj_seq_states"].data_ptr()
             la.seq_len = seq_len.data_ptr()
             loss_out = self._buf("losses", (8,), zero=True)
-            la.out, la.B, la.T, la.N, la.state_dim = loss_out.data_ptr(), B, T, N, hp.state_dim
+            la.out, la.B, la.T, la.N, la.state_dim = loss_out.data_ptr(), B, T, (N - 1 if adaptive else N), hp.state_dim
             la.w_rec, la.w_kl, la.w_len, la.w_exist, la.w_state = hp.dense_img_rec_weight, hp.kl_weight, hp.length_pred_weight, 1.0, 1.0
             la.total_div = float(T * hp.input_nc * S * S)
             plan.keep.append(la)
@@ -912,13 +1052,21 @@ class GCPTreeModel:
         out.images_df = o["images_df"]
         if "seq_len_logits" in o:
             out.seq_len_logits = o["seq_len_logits"]
-        out.existence_predictor = Outputs(existence=o["existence"])
+        if "existence" in o:
+            out.existence_predictor = Outputs(existence=o["existence"])
+        if "distances" in o:
+            out.distance_predictor = Outputs(distances=o["distances"])           # adaptive.py:69
         if "soft_matched_estimates" in o:
             out.soft_matched_estimates = o["soft_matched_estimates"]
+        if "match_dist_df" in o:
+            out.entropy = o["entropy_df"].index_select(1, TreeView.bf2df_index(hp.hierarchy_levels, self.device))
         out.tree = TreeView(self, o)
         out.dense_rec = Outputs()
         out._lazy = (o, tin)
         return out
+
+    def _plans_rec(self, o):
+        return [v[1].rec for v in self._plans.values() if v[1].outs is o][0]
 
     # ---- eager helpers used by the planner (cost model / inverse model on arbitrary rows) ----
     def predictor_rows(self, name, *inputs):
@@ -962,9 +1110,14 @@ class GCPTreeModel:
         for i, name in enumerate(self.LOSS_NAMES):
             if name == "len_pred" and not hp.regress_length:
                 continue
+            if name == "existence_predictor" and hp.adaptive:
+                name = "distance_predictor"                  # adaptive.py:118-122 takes the slot of the existence BCE
+                w[name] = 1.0
             if name == "state_regression" and ("regressed_state_padded" not in raw or "traj_seq_states" not in inputs):
                 continue
             res[name] = Outputs(value=lv[i], weight=w[name])
+        if hp.adaptive:                                             # tree_module.py:128 (entropy_weight = 0: logged only)
+            res["entropy"] = Outputs(value=raw["entropy_sum"][0] / raw["entropy_df"].numel(), weight=hp.entropy_weight)
         res["nll"] = Outputs(value=lv[6], weight=0.0)               # base_gcp.py:289-290
         res["_total"] = lv[5]
         return res
@@ -977,12 +1130,23 @@ class GCPTreeModel:
     def pruned_prediction(self, out):
         """outputs.pruned_prediction: list of [len_b, 3, H, W] (tree.py:62-65)."""
         o = out.raw
-        lens = o["seq_len"].tolist()
+        lens = o["pruned_len" if "pruned_len" in o else "seq_len"].tolist()
         return [o["pruned_padded"][b, :lens[b]] for b in range(len(lens))]
+
+    def soft_matched_estimates(self, out):
+        """LossAveragingCriterion.get_soft_estimates (binding_loss.py:44-58): per-frame average of the node images under
+        the matching distribution (visualisation only, so computed on demand — one launch on the caller's stream)."""
+        o = out.raw
+        w, x = o["match_dist_df"], o["images_df"]
+        B, N, T = w.shape
+        res = torch.empty((B, T) + tuple(x.shape[2:]), device=self.device)
+        rt.check(self.lib.gcpx_soft_average(w.data_ptr(), x.data_ptr(), res.data_ptr(), B, N, T, x[0, 0].numel(),
+                                            torch.cuda.current_stream(self.device).cuda_stream), "soft_average")
+        return res
 
     def aux_outputs(self, out):
         o = out.raw
-        m = int(o["seq_len"].max().item())
+        m = int(o["aux_len" if "aux_len" in o else "seq_len"].max().item())
         res = Outputs(model_enc_seq=o["model_enc_seq_padded"][:, :m])
         if "regressed_state_padded" in o:
             res.regressed_state = o["regressed_state_padded"][:, :m]
@@ -1006,6 +1170,15 @@ class TreeView:
                 idx[2 ** l - 1 + j] = (2 * j + 1) * 2 ** (L - 1 - l) - 1
         self._bf2df = idx.to(model.device)
 
+    @staticmethod
+    def bf2df_index(L, device):
+        """depth-first position of every breadth-first node index"""
+        idx = torch.empty(2 ** L - 1, dtype=torch.long)
+        for l in range(L):
+            for j in range(2 ** l):
+                idx[2 ** l - 1 + j] = (2 * j + 1) * 2 ** (L - 1 - l) - 1
+        return idx.to(device)
+
     def _df(self, name):
         o, hp = self._o, self._m._hp
         nv = hp.nz_vae
@@ -1023,6 +1196,17 @@ class TreeView:
             return t[..., :nv] if name.endswith("mu") else t[..., nv:]
         if name == "match_timesteps":
             return o["node_t"]
+        if name == "match_dist":                      # adaptive binding: tree.bf.match_dist = depthfirst2breadthfirst(w) (adaptive.py:60)
+            return o["match_dist_df"]
+        if name == "p_n":
+            return o["p_n_df"]
+        if name in ("gamma", "e_tilde"):              # attentive posterior (attentive_inference.py:31); stored per level
+            rec = self._m._plans_rec(o)[name]
+            B = o["E"].shape[0]
+            bf = torch.cat([rec[l].view(B, 2 ** l, -1) for l in range(self.depth)], 1)
+            inv = torch.empty_like(self._bf2df)
+            inv[self._bf2df] = torch.arange(len(inv), device=inv.device)
+            return bf.index_select(1, inv)
         if name == "distr":
             d = o["distr_df_kernel_order"]
             if d is None:

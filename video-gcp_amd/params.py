@@ -95,8 +95,8 @@ def param_table(hp):
         _bn(tab, f"decoder.net.{name}.norm", cout)
     tab["decoder.gen_head.conv.weight"] = ((hp.head_channels, hp.ngf, 3, 3), "xavier")
     tab["decoder.gen_head.conv.bias"] = ((hp.head_channels,), "zeros")
-    if hp.decoder_distribution == "gaussian":
-        tab["decoder.log_sigma"] = ((1,), "zeros")
+    if hp.decoder_distribution == "gaussian" or hp.adaptive:
+        tab["decoder.log_sigma"] = ((1,), "zeros")           # adaptive loss reads decoder.log_sigma (adaptive.py:133)
     # ---- temporal inference encoder (ConvSeqEncodingModule, base_gcp.py:130-134) -----------------
     k = hp.conv_inf_enc_kernel_size
     tab["inf_encoder.net.input.conv.weight"] = ((hp.nz_mid, hp.nz_enc, k), "xavier")
@@ -107,6 +107,20 @@ def param_table(hp):
         _bn(tab, f"inf_encoder.net.pyramid-{i}.norm", hp.nz_mid)
     tab["inf_encoder.net.head.conv.weight"] = ((hp.nz_enc, hp.nz_mid, k), "xavier")
     tab["inf_encoder.net.head.conv.bias"] = ((hp.nz_enc,), "zeros")
+    if hp.attentive_inference:
+        # inf_key_encoder = Sequential(ConvSeqEncodingModule, AttnKeyEncodingModule) (base_gcp.py:122-123); it is only
+        # read by the attentive posterior, so the balanced model does not allocate it
+        q = "inf_key_encoder.0.net"
+        tab[f"{q}.input.conv.weight"] = ((hp.nz_mid, hp.nz_enc, k), "xavier")
+        tab[f"{q}.input.conv.bias"] = ((hp.nz_mid,), "zeros")
+        for i in range(hp.conv_inf_enc_layers):
+            tab[f"{q}.pyramid-{i}.conv.weight"] = ((hp.nz_mid, hp.nz_mid, k), "xavier")
+            tab[f"{q}.pyramid-{i}.conv.bias"] = ((hp.nz_mid,), "zeros")
+            _bn(tab, f"{q}.pyramid-{i}.norm", hp.nz_mid)
+        tab[f"{q}.head.conv.weight"] = ((hp.nz_enc, hp.nz_mid, k), "xavier")
+        tab[f"{q}.head.conv.bias"] = ((hp.nz_enc,), "zeros")
+        tab["inf_key_encoder.1.linear.weight"] = ((hp.nz_attn_key, hp.nz_enc), "xavier")
+        tab["inf_key_encoder.1.linear.bias"] = ((hp.nz_attn_key,), "zeros")
     # ---- heads ---------------------------------------------------------------------------------
     npl = hp.n_processing_layers
     if hp.regress_length:
@@ -136,10 +150,30 @@ def param_table(hp):
         for j in range(2 * hp.n_lstm_layers):
             tab[f"{p}.subgoal_pred.projections.{j}.weight"] = ((H, 2 * H), "xavier")
             tab[f"{p}.subgoal_pred.projections.{j}.bias"] = ((H,), "zeros")
+        if hp.attentive_inference:
+            # AttentiveInference.attention (attentive_inference.py:38-45)
+            a = f"{p}.inference.attention"
+            dk = hp.nz_attn_key
+            _predictor(tab, f"{a}.query_net", 2 * hp.nz_enc, dk, hp.nz_mid, npl)
+            for i in range(hp.n_attention_layers):
+                m = f"{a}.attention_layers.{i}"
+                for nm, (o, ii) in dict(q_proj=(dk, dk), k_proj=(dk, dk), v_proj=(hp.nz_enc, hp.nz_enc),
+                                        out_proj=(hp.nz_enc, hp.nz_enc)).items():
+                    tab[f"{m}.{nm}.weight"] = ((o, ii), "xavier")
+                    tab[f"{m}.{nm}.bias"] = ((o,), "zeros")
+                tab[f"{m}.temperature"] = ((1,), ("const", hp.attention_temperature))
+                _predictor(tab, f"{a}.predictor_layers.{i}", hp.nz_enc, dk, hp.nz_mid, 2)
+            tab[f"{a}.out.weight"] = ((hp.nz_enc, hp.nz_enc), "xavier")
+            tab[f"{a}.out.bias"] = ((hp.nz_enc,), "zeros")
         if l == 0:
             _predictor(tab, f"{p}.lstm_initializer.net", 2 * hp.nz_enc + hp.nz_vae, 2 * hp.lstm_state_dim,
                        hp.init_mlp_mid_sz, hp.init_mlp_layers)
-            _predictor(tab, f"{p}.binding.existence_predictor", hp.nz_enc, 1, hp.nz_mid, npl)
+            if hp.adaptive:
+                # AdaptiveBinding.build_network (adaptive.py:18-30)
+                _predictor(tab, f"{p}.binding.distance_predictor", 2 * hp.nz_enc, 1, hp.nz_mid, npl)
+                tab[f"{p}.binding.temp"] = ((1,), ("const", hp.matching_temp))
+            else:
+                _predictor(tab, f"{p}.binding.existence_predictor", hp.nz_enc, 1, hp.nz_mid, npl)
     return tab
 
 
@@ -174,6 +208,8 @@ def _init_from_table(table, hp, seed, device, randomize_affine):
             t = torch.ones(shape)
             if randomize_affine:
                 t = 1.0 + (torch.rand(shape, generator=g) * 2 - 1) * 0.25
+        elif isinstance(kind, tuple) and kind[0] == "const":
+            t = torch.full(shape, float(kind[1]))
         else:
             raise ValueError(kind)
         out[name] = t.to(device=device, dtype=torch.float32).contiguous()

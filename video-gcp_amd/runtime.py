@@ -146,6 +146,14 @@ SYMBOLS = [
     ("gcpx_loss_heads_bwd", C.c_int, [C.POINTER(LossArgs), vp, vp, vp, vp]),
     ("gcpx_repack", C.c_int, [vp, vp, vp, vp, i64, vp]),
     ("gcpx_radam_step", C.c_int, [vp, vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
+    ("gcpx_attention", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    ("gcpx_cdist_splits", C.c_int, [i64]),
+    ("gcpx_cdist", C.c_int, [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp]),
+    ("gcpx_soft_dtw", C.c_int, [vp, C.c_float, vp, vp, i32, i32, i32, vp, vp, vp]),
+    ("gcpx_match_stats", C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    ("gcpx_distance_prune", C.c_int, [vp, C.c_float, vp, i32, i32, vp, vp, vp, vp, vp]),
+    ("gcpx_averaging_nll", C.c_int, [vp, vp, vp, C.c_float, i32, i32, i32, vp, vp]),
+    ("gcpx_soft_average", C.c_int, [vp, vp, vp, i32, i32, i32, i64, vp]),
     ("gcpx_graph_begin", C.c_int, [vp]),
     ("gcpx_graph_end", C.c_int, [vp, C.POINTER(vp)]),
     ("gcpx_graph_launch", C.c_int, [vp, vp]),
