@@ -56,3 +56,45 @@ def test_two_rank_gloo_path():
     assert c0 == c1 == [0.0, 1.0, 2.0, 3.0, 10.0, 11.0, 12.0, 13.0]
     assert el0 == el1 == [0, 1, 2]
     assert v0 == v1 == 2 * 2 * 20 * 5 / 2.0          # whole-job frames / slowest-rank time
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from video_gcp_amd import dist as D
+    from oracle.radam_oracle import RAdamOracle
+    D.init_from_env("gloo")
+    g = torch.Generator().manual_seed(0)
+    theta = {"p": torch.randn(1000, generator=g)}                 # same initial weights on every rank
+    opt = RAdamOracle(lr=1e-2)
+    for step in range(3):
+        gl = torch.Generator().manual_seed(100 * step + rank)    # every rank: gradient of its own shard
+        grad = torch.randn(1000, generator=gl)
+        scale = D.all_reduce_sum_(grad)
+        opt.step(theta, {"p": grad * scale})
+    q.put((rank, theta["p"].clone()))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce_keeps_replicas_identical():
+    """the training step's only collective: sum all-reduce of the flat gradient, 1/world folded into the update"""
+    from oracle.radam_oracle import RAdamOracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert torch.equal(res[0], res[1])
+    g = torch.Generator().manual_seed(0)
+    theta = {"p": torch.randn(1000, generator=g)}
+    opt = RAdamOracle(lr=1e-2)
+    for step in range(3):
+        gs = [torch.randn(1000, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(2)]
+        opt.step(theta, {"p": (gs[0] + gs[1]) * 0.5})
+    assert torch.allclose(res[0], theta["p"], atol=1e-6)

@@ -59,3 +59,12 @@ def all_gather_costs(local_costs):
 
 def aggregate_throughput(units_per_rank_step, steps, world, elapsed_max):
     return world * units_per_rank_step * steps / elapsed_max
+
+
+def all_reduce_sum_(flat, group=None):
+    """Data-parallel gradient exchange: ONE all-reduce (sum) over the flat fp32 gradient vector, in
+    place.  Returns the factor 1 / world the optimizer kernel folds into its update, so the mean costs no extra pass."""
+    if not dist.is_initialized():
+        return 1.0
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / dist.get_world_size(group)

@@ -1,0 +1,162 @@
+"""Training entry point: `python -m video_gcp_amd.train --path <exp_dir> [flags]` — the counterpart of
+/root/reference/gcp/prediction/train.py (ModelTrainer.run / train / train_epoch / val / save_checkpoint / resume, :24-213)
+with the flags of gcp/prediction/training/gcp_builder.py:188-247 that concern the device path.
+
+What is replaced: `output = model(inputs); losses = model.loss(...); total.backward(); optimizer.step()` (train.py:155-163)
+runs as `GCPTrainStep.step` (HIP forward + explicit backward + RAdam, training.py); data-parallel training is one process
+per GPU (launch with `python -m torch.distributed.run --nproc-per-node N -m video_gcp_amd.train ...`), every rank on its own
+shard, gradients averaged with ONE RCCL all-reduce over the flat gradient vector (gcp_builder.py:71-78 used nn.DataParallel).
+What is NOT here (out of the hot path): HDF5 datasets, TensorBoard logging, the control evaluation.  The
+experiment directory holds `conf.json` ({"config": "c2", "overrides": {...}, "num_epochs": n, "lr": x, "batches_per_epoch": k});
+`--feed_random_data 1` (the reference's own debug flag, gcp_builder.py:239) feeds the seeded synthetic batches of SURVEY §8d,
+which is the only data source this build ships; `dataset` may also be any iterable of input dicts passed to ModelTrainer.
+"""
+import argparse
+import json
+import os
+import time
+
+import torch
+
+
+def get_cmd_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--path", help="path to the experiment directory (conf.json; weights/ is created inside)")
+    p.add_argument("--config", default=None, help="named configuration (c1..c5) when there is no conf.json")
+    p.add_argument("--dont_save", default=False, type=int)
+    p.add_argument("--resume", default="", type=str, help="'latest', an epoch number or a checkpoint path")
+    p.add_argument("--train", default=True, type=int, help="if 0, runs one validation epoch")
+    p.add_argument("--skip_first_val", default=False, type=int)
+    p.add_argument("--gpu", default=-1, type=int)
+    p.add_argument("--strict_weight_loading", default=True, type=int)
+    p.add_argument("--deterministic", default=False, type=int)
+    p.add_argument("--log_outputs_interval", default=10, type=int)
+    p.add_argument("--feed_random_data", default=True, type=int)
+    p.add_argument("--verbose_timing", default=False, type=int)
+    p.add_argument("--num_epochs", default=None, type=int)
+    p.add_argument("--batches_per_epoch", default=None, type=int)
+    return p.parse_args(argv)
+
+
+class SyntheticLoader:
+    """Seeded synthetic batches: a different shard per rank, a different batch per step."""
+
+    def __init__(self, hp, n_batches, seed, device, variant="B"):
+        self.hp, self.n, self.seed, self.device, self.variant = hp, n_batches, seed, device, variant
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        from .synthetic import make_inputs
+        for i in range(self.n):
+            inputs, _, _ = make_inputs(self.hp, seed=self.seed + i, variant=self.variant)
+            yield {k: v.to(self.device) for k, v in inputs.items()}
+
+
+class ModelTrainer:
+    def __init__(self, args=None, train_loader=None, val_loader=None):
+        from . import dist as D
+        from .hparams import config
+        from .model import GCPTreeModel
+        from .params import init_params
+        from .training import GCPTrainStep
+        self.cmd_args = args = args if args is not None else get_cmd_args()
+        conf = {}
+        if args.path and os.path.exists(os.path.join(args.path, "conf.json")):
+            conf = json.load(open(os.path.join(args.path, "conf.json")))
+        name = args.config or conf.get("config", "c2")
+        self.exp_path = args.path or os.path.join("experiments", name)
+        self.rank, self.local_rank, self.world = D.init_from_env()
+        if args.gpu >= 0:
+            self.local_rank = args.gpu
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
+        self.hp = hp = config(name, **conf.get("overrides", {}))
+        self.num_epochs = args.num_epochs if args.num_epochs is not None else conf.get("num_epochs", 1)
+        nb = args.batches_per_epoch if args.batches_per_epoch is not None else conf.get("batches_per_epoch", 10)
+        seed = 0 if args.deterministic else conf.get("seed", 0)
+        # same initial weights on every rank (same seed) = the broadcast of DataParallel replicas
+        self.model = GCPTreeModel(hp, params=init_params(hp, seed=seed), device=self.device)
+        pg = torch.distributed.group.WORLD if self.world > 1 else None
+        self.trainer = GCPTrainStep(self.model, lr=conf.get("lr", 1e-3), betas=(conf.get("adam_beta", 0.9), 0.999), process_group=pg)
+        if not args.feed_random_data and train_loader is None:
+            raise ValueError("no dataset reader ships with this build: pass --feed_random_data 1 or give ModelTrainer a loader")
+        self.train_loader = train_loader or SyntheticLoader(hp, nb, 1000 + 100000 * self.rank, self.device)
+        self.val_loader = val_loader or SyntheticLoader(hp, max(1, nb // 5), 500000 + 100000 * self.rank, self.device)
+        self.global_step = 0
+        self.log = []
+
+    # ---- train.py:28-54 ----
+    def run(self):
+        start_epoch = 0
+        if self.cmd_args.resume:
+            start_epoch = self.resume(self.cmd_args.resume)
+        if self.cmd_args.train:
+            self.train(start_epoch)
+        else:
+            self.val()
+
+    # ---- train.py:56-70, checkpoint_handler.py:31-74 ----
+    def resume(self, ckpt, path=None):
+        from . import checkpoint as CK
+        folder = os.path.join(self.exp_path if path is None else path, "weights")
+        f = CK.get_resume_ckpt_file(ckpt, folder)
+        self.global_step, epoch, opt = CK.load_weights(f, self.model, strict=bool(self.cmd_args.strict_weight_loading))
+        if opt is not None:
+            self.trainer.load_optimizer_state(opt)
+        self.model.train()
+        return epoch + 1
+
+    # ---- train.py:95-104 ----
+    def train(self, start_epoch):
+        if not self.cmd_args.skip_first_val:
+            self.val()
+        for epoch in range(start_epoch, self.num_epochs):
+            self.train_epoch(epoch)
+            if not self.cmd_args.dont_save and self.rank == 0:
+                self.save_checkpoint(epoch)
+            self.val()
+
+    # ---- train.py:106-115 ----
+    def save_checkpoint(self, epoch):
+        from . import checkpoint as CK
+        return CK.save_checkpoint(self.model, os.path.join(self.exp_path, "weights"), epoch, self.global_step,
+                                  self.trainer.optimizer_state())
+
+    # ---- train.py:132-193 ----
+    def train_epoch(self, epoch):
+        self.model.train()
+        end = time.time()
+        for batch_idx, inputs in enumerate(self.train_loader):
+            out = self.trainer.step(inputs)            # zero_grad, forward, loss, backward, (all-reduce), optimizer.step
+            if self.global_step % self.cmd_args.log_outputs_interval == 0:
+                total = float(out.raw["losses"][5])    # the only host sync of the loop, on logging steps
+                self.log.append((self.global_step, total))
+                if self.rank == 0:
+                    print("itr: {} Train Epoch: {} [{}/{}]\tLoss: {:.6f}\t{:.3f}s/batch".format(
+                        self.global_step, epoch, batch_idx, len(self.train_loader), total,
+                        (time.time() - end) / max(1, self.cmd_args.log_outputs_interval)), flush=True)
+                end = time.time()
+            self.global_step += 1
+
+    # ---- train.py:195-238: prior-sampled prediction (val_mode) + the training forward for the NLL, no gradient ----
+    def val(self):
+        tot, n = 0.0, 0
+        start = time.time()
+        for inputs in self.val_loader:
+            with self.model.val_mode(pred_length=False):
+                self.model(inputs, "test")
+            out = self.model(inputs)
+            losses = self.model.loss(inputs, out)
+            tot += float(self.model.get_total_loss(inputs, losses).value)
+            n += 1
+        avg = tot / max(n, 1)
+        self.last_val = avg
+        if self.rank == 0:
+            print("\nTest set: Average loss: {:.4f} in {:.2f}s\n".format(avg, time.time() - start), flush=True)
+        return avg
+
+
+if __name__ == "__main__":
+    ModelTrainer().run()

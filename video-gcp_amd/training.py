@@ -674,9 +674,8 @@ class GCPTrainStep:
         st = torch.cuda.current_stream(m.device).cuda_stream
         scale = 1.0
         if self.pg is not None:
-            import torch.distributed as dist
-            dist.all_reduce(self.grad, group=self.pg)                # one RCCL all-reduce over the flat gradient (sum)
-            scale = 1.0 / dist.get_world_size(self.pg)
+            from .dist import all_reduce_sum_
+            scale = all_reduce_sum_(self.grad, self.pg)              # one RCCL all-reduce over the flat gradient (sum)
         rt.check(m.lib.gcpx_radam_step(m.theta.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                        self.opt_state.data_ptr(), m.theta.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
                                        scale, st), "radam")
@@ -686,6 +685,17 @@ class GCPTrainStep:
         out = self.backward(inputs, noise)
         self.optimizer_step()
         return out
+
+    def optimizer_state(self):
+        """optimizer.state_dict() counterpart (train.py:111): flat first / second moments + step counter"""
+        return {"exp_avg": self.exp_avg.detach().cpu(), "exp_avg_sq": self.exp_avg_sq.detach().cpu(),
+                "state": self.opt_state.detach().cpu(), "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps}
+
+    def load_optimizer_state(self, st):
+        self.exp_avg.copy_(st["exp_avg"])
+        self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        self.opt_state.copy_(st["state"])
+        self.lr, self.betas, self.eps = st["lr"], tuple(st["betas"]), st["eps"]
 
     def named_grads(self):
         return {k: self.grad[o:o + int(torch.tensor(shp).prod())].view(shp) for k, (o, shp) in self.m._poff.items()}
