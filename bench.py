@@ -46,6 +46,93 @@ def cpu_baseline(seconds_budget=20.0):
                       f"(64x64, T=80, 127 nodes/seq), torch {torch.__version__} CPU fp32, {dt:.1f} s"}
 
 
+def _timed(fn, steps, warmup, world, dev):
+    """barrier + sync on both sides, max over ranks (same rule as the headline measurement)"""
+    import torch
+    import torch.distributed as dist
+    from video_gcp_amd import dist as D
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return D.max_over_ranks(time.perf_counter() - t0, device=dev) / steps
+
+
+def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
+    """Secondary measurements of SURVEY.md §8(d): (iii) training step (forward + backward + RAdam, RCCL all-reduce of the
+    flat gradient when N > 1), (ii) one CEM planning iteration over 512 candidates sharded over the ranks, and the
+    adaptive-binding forward of configs[4].  Each is whole-job predicted frames/s; failures are reported, not hidden."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import video_gcp_amd as V
+    from video_gcp_amd.model import GCPTreeModel
+    from helpers import make_inputs
+    res = {}
+    k = max(3, min(args.steps, 10))
+    model.set_timed_op(None)
+    try:
+        from video_gcp_amd.training import GCPTrainStep
+        tr = GCPTrainStep(model, process_group=(dist.group.WORLD if world > 1 else None))
+        full = {k_: v.to(dev) for k_, v in inputs.items()}
+        dt = _timed(lambda: tr.step(full, dnoise), k, 2, world, dev)
+        res["train_step"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
+                             "ms_per_step": round(1e3 * dt, 3), "workload": "configs[2] shard: forward + ELBO losses + backward + "
+                             "RAdam, batch 16/GPU" + (", one RCCL all-reduce of the flat fp32 gradient per step" if world > 1 else ""),
+                             "grad_mbytes": round(tr.grad.numel() * 4 / 1e6, 1)}
+        del tr
+    except Exception as e:  # noqa: BLE001
+        res["train_step"] = {"error": repr(e)[:300]}
+    try:
+        from video_gcp_amd.planning import GCPImageSimulator, LearnedCostEstimate, SimpleTreeCEMSampler, CEMPlanner
+        hp4 = V.config("c4")
+        m4 = GCPTreeModel(hp4, params=V.init_params(hp4, seed=0), device=dev)
+        m4.eval()
+        rng = np.random.RandomState(0)
+        state = rng.randint(0, 256, size=(1, hp4.img_sz, hp4.img_sz, 3)).astype(np.uint8)
+        goal = rng.randint(0, 256, size=(1, hp4.img_sz, hp4.img_sz, 3)).astype(np.uint8)
+        n = 512
+        sampler = SimpleTreeCEMSampler(float("inf"), None, hp4.nz_vae, 1.0, n_level_hierarchy=hp4.hierarchy_levels, device=dev, seed=1)
+        planner = CEMPlanner(GCPImageSimulator(m4), LearnedCostEstimate(m4), sampler, n_iters=1, batch_size=n, elite_frac=0.1,
+                             max_seq_len=hp4.max_seq_len)
+
+        def it():
+            s = sampler.sample(n)
+            scores, _ = planner.evaluate(state, goal, s)
+            sampler.fit(s[torch.argsort(scores)[: n // 10]])
+        dt = _timed(it, 3, 1, world, dev)
+        res["planning_iteration"] = {"value": round(n * hp4.max_seq_len / dt, 1), "unit": "frames/s", "ms_per_iteration": round(1e3 * dt, 2),
+                                     "candidates_per_s": round(n / dt, 1), "workload": "configs[3]: one CEM iteration, 512 candidates x "
+                                     "horizon 80 sharded over the ranks, rollout + learned cost on device, one all-gather of costs"}
+        del planner, m4
+    except Exception as e:  # noqa: BLE001
+        res["planning_iteration"] = {"error": repr(e)[:300]}
+    try:
+        hp5 = V.config("c5")
+        m5 = GCPTreeModel(hp5, params=V.init_params(hp5, seed=0), device=dev)
+        i5, n5, _ = make_inputs(hp5, seed=200 + rank, variant="A")
+        d5 = {k_: v.to(dev) for k_, v in i5.items()}
+        n5 = n5.to(dev)
+        dt = _timed(lambda: m5(d5, "train", noise=n5), k, 2, world, dev)
+        res["adaptive_forward"] = {"value": round(world * hp5.batch_size * hp5.max_seq_len / dt, 1), "unit": "frames/s",
+                                   "ms_per_step": round(1e3 * dt, 3), "workload": "configs[4] shard: adaptive (soft-DTW) binding + "
+                                   "attentive inference forward with losses, 64x64, seq_len 200, L=8 (255 nodes), batch 8/GPU"}
+        del m5
+    except Exception as e:  # noqa: BLE001
+        res["adaptive_forward"] = {"error": repr(e)[:300]}
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,6 +141,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="sequences per GPU (configs[1]: 16)")
     ap.add_argument("--eval-bn", action="store_true", help="running-stat BatchNorm (planner mode) instead of batch stats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (training step, CEM "
+                    "planning iteration, adaptive-binding forward) reported under \"also\"")
     args = ap.parse_args()
 
     import torch
@@ -105,6 +194,10 @@ def main():
     head_ms = model.timed_op_ms()
     elapsed = D.max_over_ranks(elapsed, device=dev)
 
+    also = None
+    if not args.no_extras:
+        also = extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev)
+
     if rank == 0:
         frames = world * hp.batch_size * hp.max_seq_len * args.steps
         value = frames / elapsed
@@ -131,6 +224,8 @@ def main():
                          "traffic": HEAD_TRAFFIC_BYTES if (hp.batch_size == 16 and not args.eval_bn) else None,
                          "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": head_flops},
         }
+        if also is not None:
+            line["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
