@@ -215,7 +215,7 @@ def main():
                                    + ("running-stat" if args.eval_bn else "batch-stat") + " BatchNorm",
                        "batch_per_gpu": hp.batch_size, "seq_len": hp.max_seq_len, "img": hp.img_sz,
                        "nodes_per_seq": hp.n_nodes, "parallelism": f"dp{world} (independent sequences, no collective)"},
-            "roofline": {"kernel": "conv3x3_head_kernel<7> (decoder output head, 3x3 conv 16->100 ch @64x64 + fused mixture mean)",
+            "roofline": {"kernel": "conv3x3_head_kernel<6, true> (decoder output head, 3x3 conv 16->100 ch @64x64 = 6 MFMA tiles + 4-channel 4x4x1 remainder, fused mixture mean)",
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                          # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_head_kernel.json):

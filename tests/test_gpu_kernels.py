@@ -230,7 +230,7 @@ def test_conv3x3_head_dlm(env, S, Fr):
     want_img = O.dlm_mean(head, hp)
     perm = pk.dlm_channel_perm(10)
     permt = torch.tensor(perm)
-    wp = pk.pack_conv3x3(w, 16, perm=perm).to(dev)
+    wp = pk.pack_dlm_head(w, perm).to(dev)
     bk = torch.zeros(len(perm))
     bk[permt >= 0] = b[permt[permt >= 0]]
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)

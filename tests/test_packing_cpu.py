@@ -39,9 +39,24 @@ def test_dlm_perm_is_a_partial_permutation():
     assert len(perm) == 112
     real = [c for c in perm if c >= 0]
     assert sorted(real) == list(range(100))
-    # slot 8k..8k+6 = logit_k, mean_{r,g,b}, coeff_{0,1,2}
+    # slot 8k..8k+7 = logit_k, mean_{r,g,b}, coeff_{0,1,2}, log_scale_r; then log_scale_g, log_scale_b; 12 empty slots
     k = 3
-    assert perm[8 * k:8 * k + 8] == [k, 10 + k, 40 + k, 70 + k, 30 + k, 60 + k, 90 + k, -1]
+    assert perm[8 * k:8 * k + 8] == [k, 10 + k, 40 + k, 70 + k, 30 + k, 60 + k, 90 + k, 20 + k]
+    assert perm[80 + k] == 50 + k and perm[90 + k] == 80 + k and perm[100:] == [-1] * 12
+    for c in range(3):
+        assert perm[pk.dlm_log_scale_slot(c, k)] == 10 + 30 * c + 10 + k
+
+
+def test_pack_dlm_head_remainder_tile():
+    torch.manual_seed(2)
+    w = torch.randn(100, 16, 3, 3)
+    perm = pk.dlm_channel_perm(10)
+    p = pk.pack_dlm_head(w, perm)
+    assert p.shape == (10, 7, 64, 4) and torch.all(p[-1] == 0)
+    assert torch.equal(p[:, :6], pk.pack_conv3x3(w, 16, perm=perm)[:, :6])
+    tap, kg, c, s_ = 5, 2, 3, 1
+    assert p[tap, 6, kg * 4 + c, s_] == w[perm[96 + c], 4 * kg + s_, tap // 3, tap % 3]
+    assert torch.all(p[:, 6, 16:] == 0)
 
 
 def test_lstm_gate_interleave():

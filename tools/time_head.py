@@ -10,7 +10,7 @@ x = torch.randn(Fr, S, S, 16, device=dev)
 sc, sh = torch.rand(16, device=dev) + 0.5, torch.randn(16, device=dev) * 0.2
 w, b = torch.randn(100, 16, 3, 3) / 12.0, torch.randn(100) * 0.1
 perm = pk.dlm_channel_perm(10)
-wp = pk.pack_conv3x3(w, 16, perm=perm).to(dev)
+wp = pk.pack_dlm_head(w, perm).to(dev)
 permt = torch.tensor(perm)
 bk = torch.zeros(len(perm)); bk[permt >= 0] = b[permt[permt >= 0]]; bk = bk.to(dev)
 img = torch.zeros(Fr, 3, S, S, device=dev)

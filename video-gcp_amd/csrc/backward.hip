@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
             float s = m[0] - lse_logits;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float raw = pp[80 + 10 * c + k];
+                const float raw = pp[c == 0 ? 8 * k + 7 : 70 + 10 * c + k];     // packing.dlm_log_scale_slot
                 const float ls = fmaxf(raw, -7.f);
                 const float xc = x[c] - mean[c];
                 const float inv = expf(-ls);
@@ -539,12 +539,11 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
             m[4] = gw * gm[nk][1] * xr * (1.f - cf[nk][0] * cf[nk][0]);
             m[5] = gw * gm[nk][2] * xr * (1.f - cf[nk][1] * cf[nk][1]);
             m[6] = gw * gm[nk][2] * xg * (1.f - cf[nk][2] * cf[nk][2]);
-            m[7] = 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) pp[80 + 10 * c + k] = gw * gs[nk][c];
+            for (int c = 0; c < 3; ++c) pp[c == 0 ? 8 * k + 7 : 70 + 10 * c + k] = gw * gs[nk][c];
         }
         if (q == 0)
-            for (int s = 80 + 3 * NMIX; s < PITCH; ++s) pp[s] = 0.f;
+            for (int s = 80 + 2 * NMIX; s < PITCH; ++s) pp[s] = 0.f;
         __builtin_amdgcn_wave_barrier();
         float4* dst = reinterpret_cast<float4*>(drow + (size_t)p0 * PITCH);
         for (int i = lane; i < F4; i += 64) dst[i] = reinterpret_cast<float4*>(st)[i];

@@ -434,21 +434,31 @@ conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty, const int n
 //     registers.  No barrier in steady state: the 8 wavefronts of a CU drift apart, so one wave's staging / epilogue
 //     VALU work overlaps the other waves' MFMAs on the same SIMD.
 // -----------------------------------------------------------------------------------------------------------
-template <int CT>
+//   * REM: the output channels are CT full 16-channel MFMA tiles plus a 4-channel remainder (the 100-channel mixture head =
+//     6 x 16 + 4).  The remainder runs on v_mfma_f32_4x4x1_16b_f32 — 16 independent 4x4 outer products per instruction:
+//     A = the 4 remainder channels (same in every block), B = one pixel per lane — i.e. 4 channels x 64 pixels x 1 k at the
+//     same FLOP rate as the 16x16x4 tile, so no MFMA cycle is spent on padded channels (a 7th full tile would waste 12 / 16).
+//     Its weights sit in the storage of weight tile CT: float4 index kg * 4 + c holds W[16 CT + c][k = 4 kg .. 4 kg + 3].
+template <int CT, bool REM>
 struct HeadCfg {
     static constexpr int RW = 18, RH = 6, CCP = 24;        // item = 4 rows x 16 pixels (+ halo): 1.69x staged / output pixel;
                                                              // pitch 24 floats: conflict-free ds_read_b128 of the B operand
     static constexpr int REGION_FLOATS = RH * RW * CCP;                 // 2592 floats per wave
-    static constexpr int W_FLOAT4 = 9 * CT * 64;
+    static constexpr int WT = CT + (REM ? 1 : 0);                       // weight tiles per tap in LDS
+    static constexpr int W_FLOAT4 = 9 * WT * 64;
     static constexpr int LDS_BYTES = W_FLOAT4 * 16 + 8 * REGION_FLOATS * 4;
     static constexpr int NS = (RH * RW * 4 + 63) / 64;                   // float4 slots per lane
 };
 
-template <int CT>
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+template <int CT, bool REM>
 __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_args a, const int items_per_wave,
                                                               const int nitems) {
-    using Cfg = HeadCfg<CT>;
-    constexpr int RW = Cfg::RW, RH = Cfg::RH, CCP = Cfg::CCP, NS = Cfg::NS;
+    using Cfg = HeadCfg<CT, REM>;
+    constexpr int RW = Cfg::RW, RH = Cfg::RH, CCP = Cfg::CCP, NS = Cfg::NS, WT = Cfg::WT;
     extern __shared__ float4 smem4[];
     float4* wl = smem4;                                                   // [9][CT][64] float4
     const int tid = threadIdx.x, lane = tid & 63;
@@ -464,6 +474,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
     int pixoff[4];
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) pixoff[pt] = (pt * RW + j) * CCP + q * 4;
+    const int rem_pix = (q * RW + j) * CCP;               // remainder: lane = pixel (row q, column j) of the item
     const gcpx_conv_src sr = a.src[0];
 
     const int gw = blockIdx.x * 8 + wave;
@@ -519,6 +530,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
         if (item + 1 < item_end) issue_loads(item + 1);
 
         f32x4 acc[CT][4];
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
         // one (tap) step: 4 ds_read_b128 of activations + CT of weights, 4*4*CT MFMAs.  The first step starts the
         // accumulators from the inline constant 0 (no v_mov zero-fill: VALU issue slots are as scarce as MFMA slots,
         // f32 MFMA and VALU do not overlap on a SIMD).
@@ -532,10 +544,19 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
             float4 b[4];
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) b[pt] = bnext[pt];
-            const float4* wp = wl + tap * CT * 64 + lane;
+            const float4* wp = wl + tap * WT * 64 + lane;
             float4 w[CT];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) w[ct] = wp[ct * 64];
+            [[maybe_unused]] float4 rw[4], rb[4];
+            if constexpr (REM) {
+                const int tapoff0 = ((tap / 3) * RW + (tap % 3)) * CCP;
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    rw[kg] = wl[(tap * WT + CT) * 64 + kg * 4 + (lane & 3)];
+                    rb[kg] = *reinterpret_cast<const float4*>(reg + rem_pix + tapoff0 + kg * 4);
+                }
+            }
             {   // tap + 1 (for tap == 8 this reads one row past the wave's region: in-range LDS, value unused)
                 const int t1 = tap + 1;
                 const int tapoff = ((t1 / 3) * RW + (t1 % 3)) * CCP;
@@ -551,6 +572,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
                     acc[ct][pt] = mfma16(w[ct].y, b[pt].y, acc[ct][pt]);
                     acc[ct][pt] = mfma16(w[ct].z, b[pt].z, acc[ct][pt]);
                     acc[ct][pt] = mfma16(w[ct].w, b[pt].w, acc[ct][pt]);
+                }
+            }
+            if constexpr (REM) {
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    acc4 = mfma4(rw[kg].x, rb[kg].x, acc4);
+                    acc4 = mfma4(rw[kg].y, rb[kg].y, acc4);
+                    acc4 = mfma4(rw[kg].z, rb[kg].z, acc4);
+                    acc4 = mfma4(rw[kg].w, rb[kg].w, acc4);
                 }
             }
         };
@@ -585,6 +615,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
                         *reinterpret_cast<float4*>(op + c) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                 }
+            }
+            if constexpr (REM) {       // lane = pixel (row q, column j): its 4 remainder channels
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + CT * 16);
+                float* op = a.out + (((size_t)orow * H + (y0 + q)) * W + (x0 + j)) * a.out_pitch + CT * 16;
+                *reinterpret_cast<float4*>(op) = make_float4(acc4[0] + bv.x, acc4[1] + bv.y, acc4[2] + bv.z, acc4[3] + bv.w);
             }
         }
         if constexpr (CT >= 5) {
@@ -654,10 +689,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
     }
 }
 
-template <int CT>
+template <int CT, bool REM>
 int launch_head(const gcpx_conv_args* a, hipStream_t stream) {
-    using Cfg = HeadCfg<CT>;
-    auto kern = conv3x3_head_kernel<CT>;
+    using Cfg = HeadCfg<CT, REM>;
+    auto kern = conv3x3_head_kernel<CT, REM>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -961,8 +996,12 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
     if (!a->upsample) {
         GCPX_CHECK_ARG(a->nsrc == 1 && a->src[0].frame_div == 1, "non-upsampling 3x3 conv takes one per-frame source");
         if (a->Cin == 16 && !a->src_row_map && W % 16 == 0 && a->Hout % 4 == 0) {
-            if (CT == 7) return query_only ? gcpx_conv_grid() / 2 : launch_head<7>(a, stream);
-            if (CT == 1) return query_only ? gcpx_conv_grid() / 2 : launch_head<1>(a, stream);
+            // 100-channel mixture head: 6 full tiles + the 4-channel remainder (weights packed by packing.pack_dlm_head)
+            if (a->Cout == 100) {
+                GCPX_CHECK_ARG(!need_out || a->out_pitch >= 100, "mixture head: out_pitch < 100");
+                return query_only ? gcpx_conv_grid() / 2 : launch_head<6, true>(a, stream);
+            }
+            if (CT == 1) return query_only ? gcpx_conv_grid() / 2 : launch_head<1, false>(a, stream);
         }
         // data gradients of the decoder blocks (3x3 conv with the transposed, flipped weights): workgroup-tiled kernel
         GCPX_CHECK_ARG(a->head_mode == GCPX_HEAD_RAW && !a->stats_partial, "plain 3x3 conv stores raw output, no statistics");

@@ -236,7 +236,7 @@ class GCPTreeModel:
         if hp.decoder_distribution == "discrete_logistic_mixture":
             perm = pk.dlm_channel_perm(hp.n_mixtures)
             self._dlm_perm = torch.tensor(perm, device=self.device)
-            P["dec.head.w"] = pk.pack_conv3x3(hw, 16, perm=perm)
+            P["dec.head.w"] = pk.pack_dlm_head(hw, perm)
             bk = torch.zeros(len(perm), device=hb.device, dtype=hb.dtype)
             permd = self._dlm_perm.to(hb.device)
             valid = permd >= 0

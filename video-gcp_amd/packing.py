@@ -103,21 +103,48 @@ def pad_vec(v, n):
 # ---- discrete-logistic-mixture head: kernel channel order ------------------------------------------------
 def dlm_channel_perm(n_mix=10):
     """Kernel slot -> canonical head channel (PixelCNN++ order: [logits(nm) | per colour c: means(nm),
-    log_scales(nm), coeffs(nm)]).  Slots 8k..8k+7 = {logit_k, mean_r, mean_g, mean_b, coeff0, coeff1, coeff2, -},
-    then the 3*nm log_scales; padded to a multiple of 16.  The layout puts everything the mixture MEAN needs for
-    mixture k into lanes (q, q+1) of one 16-channel MFMA tile (csrc/conv3x3.hip epilogue)."""
+    log_scales(nm), coeffs(nm)]), -1 for an empty slot.  100 real channels in slots 0..99, memory pitch 112:
+      slots 8k..8k+7 = {logit_k, mean_r, mean_g, mean_b, coeff0, coeff1, coeff2, log_scale_r} of mixture k (k < 10),
+      slots 80+k / 90+k = log_scale_g / log_scale_b of mixture k, slots 100..111 empty.
+    Everything the mixture MEAN needs for mixture k sits in lanes (q, q+1) of one 16-channel MFMA tile (csrc/conv3x3.hip
+    epilogue); the channels fill 6 full MFMA tiles + a 4-channel remainder (slots 96..99) with no padding inside."""
     nm = n_mix
     assert nm == 10, "kernel epilogue is written for 10 mixtures (5 MFMA tiles x 2 mixtures)"
+    base = lambda c: nm + c * 3 * nm
     perm = []
     for k in range(nm):
-        perm += [k, nm + 0 * 3 * nm + k, nm + 1 * 3 * nm + k, nm + 2 * 3 * nm + k,
-                 nm + 0 * 3 * nm + 2 * nm + k, nm + 1 * 3 * nm + 2 * nm + k, nm + 2 * 3 * nm + 2 * nm + k, -1]
-    for c in range(3):
+        perm += [k, base(0) + k, base(1) + k, base(2) + k, base(0) + 2 * nm + k, base(1) + 2 * nm + k, base(2) + 2 * nm + k,
+                 base(0) + nm + k]
+    for c in (1, 2):
         for k in range(nm):
-            perm.append(nm + c * 3 * nm + nm + k)
+            perm.append(base(c) + nm + k)
     while len(perm) % 16:
         perm.append(-1)
     return perm
+
+
+def dlm_log_scale_slot(c, k, n_mix=10):
+    """slot of log_scale_{c,k} (the same rule is compiled into csrc/loss.hip and csrc/backward.hip)"""
+    return 8 * k + 7 if c == 0 else 80 + 10 * (c - 1) + k
+
+
+def pack_dlm_head(w, perm):
+    """Output-head weights w [100, 16, 3, 3] for conv3x3_head_kernel<6, REM>: [9 taps + 1][7][64][4].  Tiles 0..5 are the
+    ordinary fragment packs of slots 0..95; the storage of tile 6 holds the 4-channel remainder (slots 96..99) for the
+    4x4x1 MFMA: float4 index kg * 4 + c = W[slot 96 + c][ci = 4 kg .. 4 kg + 3] (indices >= 16 unused)."""
+    full = pack_conv3x3(w, 16, perm=perm)                      # [10, 7, 64, 4]; tile 6 = slots 96..111 in fragment order
+    assert full.shape[1] == 7 and w.shape[1] == 16
+    dev = w.device
+    perm_t = torch.as_tensor(perm, device=dev)
+    rem = w[perm_t[96:100]].reshape(4, 16, 9)                  # [c, ci, tap]
+    idx = torch.arange(16, device=dev)
+    kg, c = idx // 4, idx % 4
+    s = torch.arange(4, device=dev)
+    tile = rem[c[:, None], (4 * kg)[:, None] + s[None, :], :]  # [16, 4, 9]
+    out = full.clone()
+    out[:9, 6] = 0
+    out[:9, 6, :16] = tile.permute(2, 0, 1)
+    return out.contiguous()
 
 
 def lstm_gate_interleave(w_ih, w_hh, b_ih, b_hh):
