@@ -393,8 +393,30 @@ class GCPTreeModel:
         s.sb, s.sr, s.width, s.shift, s.act, s.cmod = sb, sr, width, shift, act, cmod
         return s
 
+    @staticmethod
+    def _dense_rows(srcs, rpb, M):
+        """One row per batch element (tree level 0, the I_0 / I_g encoder heads): the kernels tile rows inside a batch
+        element, so rpb = 1 would mean one-row tiles.  Re-express the same addresses as ONE batch element of M rows
+        (row stride = the old batch stride): the MFMA tiles are full again and the launch is one workgroup column."""
+        if rpb != 1 or M == 1 or any(s.shift != 0 for s in srcs):
+            return srcs, rpb, False
+        out = []
+        for s in srcs:
+            t = rt.RowSrc()
+            t.ptr, t.rowidx, t.scale, t.shiftv = s.ptr, s.rowidx, s.scale, s.shiftv
+            t.sb, t.sr = 0, (s.sr if s.rowidx else s.sb)
+            t.width, t.shift, t.act, t.cmod = s.width, s.shift, s.act, s.cmod
+            out.append(t)
+        return out, M, True
+
     def _gemm(self, plan, name, srcs, M, N, rpb, wpk, bias, out=None, ob=0, orow=0, epi=rt.EPI_NONE,
               stats=None, lstm=None, batch=None):
+        srcs, rpb, dense = self._dense_rows(srcs, rpb, M)
+        if dense:
+            ob, orow = 0, ob
+            if lstm is not None:
+                c_prev, c_prev_stride, h_out, c_out, hb, hrow, h_copy = lstm
+                lstm = (c_prev, c_prev_stride, h_out, c_out, 0, hb, h_copy)
         a = rt.GemmArgs()
         for i, s in enumerate(srcs):
             a.src[i] = s
@@ -415,6 +437,13 @@ class GCPTreeModel:
 
     def _mlp(self, plan, name, W, srcs, M, rpb, out=None, ob=0, orow=0, oblk=0, out_split=0, gauss=None):
         hp = self._hp
+        rec_srcs, rec_rpb = srcs, rpb            # the backward plan addresses rows the way the caller does
+        srcs, rpb, dense = self._dense_rows(srcs, rpb, M)
+        if dense:
+            ob, orow = 0, ob
+            if gauss is not None:
+                eps, eb, erow, z, zb, zrow = gauss
+                gauss = (eps, 0, eb, z, 0, zb)
         a = rt.MlpArgs()
         for i, s in enumerate(srcs):
             a.src[i] = s
@@ -435,7 +464,7 @@ class GCPTreeModel:
         if self.save_for_backward:
             sv = self._buf(f"save.{name}", (1 + 2 * W["n_mid"], M, W["mid"]))
             a.save = sv.data_ptr()
-            plan.rec[f"mlp:{name}"] = dict(W=W, srcs=srcs, M=M, rpb=rpb, save=sv)
+            plan.rec[f"mlp:{name}"] = dict(W=W, srcs=rec_srcs, M=M, rpb=rec_rpb, save=sv)
         plan.keep.append(a)
         plan.add(name, self.lib.gcpx_mlp, C.byref(a))
 
