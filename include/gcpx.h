@@ -544,6 +544,15 @@ int gcpx_averaging_nll(const float* dsum, const float* w, const float* log_sigma
 /* LossAveragingCriterion.get_soft_estimates (binding_loss.py:44-58): out[b][t][:] = sum_n w[b][n][t] * x[b][n][:], rows of D floats */
 int gcpx_soft_average(const float* w, const float* x, float* out, int32_t B, int32_t N, int32_t T, int64_t D, void* stream);
 
+/* Evaluation alignment: basic_dtw + _traceback of gcp/evaluation/dtw_utils.py:77-95,201-218 (the C version is
+ *   gcp/evaluation/cutils.pyx:22-29) as used by DTWEvalBinding.get_single_matches (gcp/evaluation/evaluation_matching.py:133-146).
+ *   cost [B][N][T] float32 (mean squared distance estimate n vs target t); sequence b uses rows < n_len[b] and columns < t_len[b]
+ *   (NULL = N / T).  acc [B][N][T] float64 accumulated cost; inds [B][T] = for every target frame the estimate with the smallest
+ *   accumulated cost among the path cells of its column (-1 beyond t_len); path [B][2][N+T] = (rows | columns) from the END of
+ *   the path to its start, path_len [B]; dist [B] = acc[n-1][t-1] / (n + t). */
+int gcpx_dtw_align(const float* cost, const int32_t* n_len, const int32_t* t_len, int32_t B, int32_t N, int32_t T, double* acc,
+                   int32_t* inds, int32_t* path, int32_t* path_len, double* dist, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

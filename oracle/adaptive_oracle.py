@@ -109,6 +109,15 @@ def basic_dtw(C):
     return D[-1, -1] / (r + c), D[1:, 1:], _traceback(D)
 
 
+def dtw_matches(cost):
+    """DTWEvalBinding.get_single_matches (evaluation_matching.py:133-146) after the cdist: cost [n_estimates, n_targets] ->
+    (normalised distance, accumulated cost, path, for every target the estimate chosen)."""
+    d, D, path = basic_dtw(np.asarray(cost))
+    match = np.full_like(D, np.inf)
+    match[path[0], path[1]] = D[path[0], path[1]]
+    return d, D, path, np.argmin(match, axis=0)
+
+
 # ---------------------------------------------------------------------------------------------------
 # blox-side helpers: THIS build's spec
 # ---------------------------------------------------------------------------------------------------

@@ -55,3 +55,13 @@ def test_batch_cdist_is_squared_l2():
     want = ((a[:, :, None] - b[:, None]) ** 2).flatten(3).sum(-1)
     assert torch.allclose(A.batch_cdist(a, b, "sum"), want, atol=1e-4)
     assert torch.allclose(A.batch_cdist(a, b, "mean"), want / 48, atol=1e-5)
+
+
+def test_dtw_matches_pick_path_cells():
+    """DTWEvalBinding.get_single_matches: the chosen estimate of every target frame lies on the DTW path"""
+    rng = np.random.RandomState(3)
+    C = rng.rand(15, 9)
+    d, D, path, inds = A.dtw_matches(C)
+    cells = set(zip(path[0].tolist(), path[1].tolist()))
+    assert all((int(inds[j]), j) in cells for j in range(9))
+    assert inds[0] == 0 and np.all(np.diff(inds) >= 0)

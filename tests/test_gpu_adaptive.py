@@ -284,3 +284,58 @@ def test_adaptive_c5_full_size_properties():
             assert float(w[b, :, e + 1:].abs().max()) == 0.0
         assert int(out.raw["frame2node"][b, 0]) == 0 and int(out.raw["frame2node"][b, e]) == hp.n_nodes - 1   # path end points
     assert all(math.isfinite(float(v.value)) for k, v in losses.items() if k != "_total")
+
+
+def test_dtw_align_kernel_matches_reference_goldens():
+    """accumulated cost, path and normalised distance against outputs of the reference's basic_dtw (dtw_utils.py) executed
+    in the build container; chosen frames against the oracle's restatement of get_single_matches"""
+    from oracle import adaptive_oracle as A
+    rt, lib = _lib()
+    for i in range(int(G["bd_n"])):
+        C64 = G[f"bd{i}_C"]
+        C = torch.tensor(C64.astype(np.float32))
+        n, t = C.shape
+        cd = C[None].contiguous().cuda()
+        acc = torch.zeros(1, n, t, dtype=torch.float64, device="cuda")
+        inds = torch.zeros(1, t, dtype=torch.int32, device="cuda")
+        path = torch.zeros(1, 2, n + t, dtype=torch.int32, device="cuda")
+        plen, dist = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.float64, device="cuda")
+        rt.check(lib.gcpx_dtw_align(cd.data_ptr(), None, None, 1, n, t, acc.data_ptr(), inds.data_ptr(), path.data_ptr(),
+                                    plen.data_ptr(), dist.data_ptr(), _st()), "dtw_align")
+        torch.cuda.synchronize()
+        d_ref, D_ref, path_ref, inds_ref = A.dtw_matches(C.numpy())       # float32 costs, float64 accumulation
+        assert np.max(np.abs(acc[0].cpu().numpy() - D_ref)) < 1e-12
+        L = int(plen[0])
+        got_p = path[0, :, :L].cpu().numpy()[:, ::-1]
+        assert np.array_equal(got_p[0], path_ref[0]) and np.array_equal(got_p[1], path_ref[1])
+        assert np.array_equal(inds[0].cpu().numpy(), inds_ref) and abs(float(dist[0]) - d_ref) < 1e-12
+        # the float64 goldens of the reference differ from the float32-cost run only by the cost rounding
+        assert np.max(np.abs(D_ref - G[f"bd{i}_D"])) < 1e-5 * (n + t)
+        assert np.array_equal(path_ref[0], G[f"bd{i}_p0"]) and np.array_equal(path_ref[1], G[f"bd{i}_p1"])
+
+
+def test_dtw_eval_binding_c5s():
+    """DTWEvalBinding over a batch (ragged target lengths) against the oracle applied per sequence"""
+    from oracle import adaptive_oracle as A
+    from video_gcp_amd.evaluation import DTWEvalBinding, mse_cropped
+    hp, sd, model = _build("c5s")
+    model.eval()
+    inputs, noise, _ = make_inputs(hp, seed=21, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    with model.val_mode():
+        out = model(dev_in, "test", noise=noise.cuda())
+    gen, info = DTWEvalBinding(model).get_all_samples(out, dev_in)
+    torch.cuda.synchronize()
+    est = out.images_df.cpu()
+    for b in range(hp.batch_size):
+        e = int(inputs["end_ind"][b])
+        cost = A.batch_cdist(est[b:b + 1], inputs["traj_seq"][b:b + 1, :e + 1], "mean")[0].numpy()
+        d, D, path, inds = A.dtw_matches(cost)
+        got_cost = info.cost[b, :, :e + 1].cpu().numpy()
+        # the decision variables are discrete: compare them only where the cost matrices agree to rounding
+        assert np.max(np.abs(got_cost - cost)) < 2e-6
+        assert np.array_equal(info.inds[b, :e + 1].cpu().numpy(), inds)
+        assert gen[b].shape[0] == e + 1
+        assert_close(gen[b], est[b][inds], 0, 0, "gen_images")
+    m = mse_cropped(gen, dev_in)
+    assert len(m) == hp.batch_size and all(np.isfinite(x) or inputs["end_ind"][i] < 2 for i, x in enumerate(m))

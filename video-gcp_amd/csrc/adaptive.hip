@@ -358,6 +358,60 @@ __global__ void __launch_bounds__(256) soft_average_kernel(const float* __restri
             if (t0 + i < T) out[((size_t)b * T + t0 + i) * Dd + d] = acc[i];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// hard DTW of the evaluation harness (dtw_utils.py:77-95 basic_dtw + :201-218 _traceback, as used by
+// DTWEvalBinding.get_single_matches, evaluation_matching.py:133-146).  One workgroup per sequence; anti-diagonal
+// wavefront in float64 over the float32 cost matrix; traceback and per-frame best node by one thread.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dtw_align_kernel(const float* __restrict__ cost, const int32_t* __restrict__ n_len,
+                                                        const int32_t* __restrict__ t_len, double* __restrict__ acc,
+                                                        int32_t* __restrict__ inds, int32_t* __restrict__ path,
+                                                        int32_t* __restrict__ path_len, double* __restrict__ dist,
+                                                        const int N, const int T) {
+    const int b = blockIdx.x;
+    const int n = n_len ? n_len[b] : N, t = t_len ? t_len[b] : T;
+    const float* C = cost + (size_t)b * N * T;
+    double* D = acc + (size_t)b * N * T;
+    for (int dg = 0; dg < n + t - 1; ++dg) {
+        const int ilo = dg - (t - 1) > 0 ? dg - (t - 1) : 0, ihi = dg < n - 1 ? dg : n - 1;
+        for (int i = ilo + threadIdx.x; i <= ihi; i += 256) {
+            const int j = dg - i;
+            double m;
+            if (i == 0 && j == 0) m = 0.0;
+            else {
+                const double a0 = (i > 0 && j > 0) ? D[(size_t)(i - 1) * T + j - 1] : INFINITY;
+                const double a1 = i > 0 ? D[(size_t)(i - 1) * T + j] : INFINITY;
+                const double a2 = j > 0 ? D[(size_t)i * T + j - 1] : INFINITY;
+                m = fmin(a0, fmin(a1, a2));
+            }
+            D[(size_t)i * T + j] = (double)C[(size_t)i * T + j] + m;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    int32_t* pb = path + (size_t)b * 2 * (N + T);
+    int i = n - 1, j = t - 1, len = 0;
+    for (int jj = 0; jj < T; ++jj) inds[(size_t)b * T + jj] = -1;
+    double best = INFINITY;
+    int cur_col = j;
+    while (true) {
+        pb[len] = i; pb[(N + T) + len] = j; ++len;                 // stored end -> start; the host view reverses it
+        if (j != cur_col) { cur_col = j; best = INFINITY; }
+        const double v = D[(size_t)i * T + j];
+        if (v <= best) { best = v; inds[(size_t)b * T + j] = i; }   // argmin over the column's path cells, first minimum
+        if (i == 0 && j == 0) break;
+        const double a0 = (i > 0 && j > 0) ? D[(size_t)(i - 1) * T + j - 1] : INFINITY;
+        const double a1 = i > 0 ? D[(size_t)(i - 1) * T + j] : INFINITY;
+        const double a2 = j > 0 ? D[(size_t)i * T + j - 1] : INFINITY;
+        if (a0 <= a1 && a0 <= a2) { --i; --j; }                     // np.argmin: first minimum of (diag, up, left)
+        else if (a1 <= a2) --i;
+        else --j;
+    }
+    path_len[b] = len;
+    dist[b] = D[(size_t)(n - 1) * T + (t - 1)] / (double)(n + t);
+}
+
 }  // namespace
 
 extern "C" int gcpx_attention(const float* q, const float* k, const float* v, const int64_t* start_ind, const int64_t* end_ind,
@@ -450,6 +504,15 @@ extern "C" int gcpx_soft_average(const float* w, const float* x, float* out, int
     GCPX_CHECK_ARG(w && x && out && B > 0 && N > 0 && T > 0 && D > 0, "null pointer / bad sizes");
     hipLaunchKernelGGL(soft_average_kernel, dim3((unsigned)((D + 255) / 256), (T + 31) / 32, B), dim3(256), 0, stream, w, x, out, N, T,
                        (long long)D);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_dtw_align(const float* cost, const int32_t* n_len, const int32_t* t_len, int32_t B, int32_t N, int32_t T,
+                              double* acc, int32_t* inds, int32_t* path, int32_t* path_len, double* dist, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(cost && acc && inds && path && path_len && dist && B > 0 && N > 0 && T > 0, "null pointer / bad sizes");
+    hipLaunchKernelGGL(dtw_align_kernel, dim3(B), dim3(256), 0, stream, cost, n_len, t_len, acc, inds, path, path_len, dist, N, T);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

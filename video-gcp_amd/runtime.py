@@ -154,6 +154,7 @@ SYMBOLS = [
     ("gcpx_distance_prune", C.c_int, [vp, C.c_float, vp, i32, i32, vp, vp, vp, vp, vp]),
     ("gcpx_averaging_nll", C.c_int, [vp, vp, vp, C.c_float, i32, i32, i32, vp, vp]),
     ("gcpx_soft_average", C.c_int, [vp, vp, vp, i32, i32, i32, i64, vp]),
+    ("gcpx_dtw_align", C.c_int, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     ("gcpx_graph_begin", C.c_int, [vp]),
     ("gcpx_graph_end", C.c_int, [vp, C.POINTER(vp)]),
     ("gcpx_graph_launch", C.c_int, [vp, vp]),
