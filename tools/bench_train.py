@@ -55,7 +55,7 @@ def main():
             res[nm] = res.get(nm, 0.0) + 1e3 * e0.elapsed_time(e1) / 3
     tot = sum(res.values())
     print(f"backward plan: {len(plan.ops)} launches, sum of op times {tot / 1e3:.2f} ms")
-    for nm, us in sorted(res.items(), key=lambda kv: -kv[1])[:40]:
+    for nm, us in sorted(res.items(), key=lambda kv: -kv[1])[:int(os.environ.get('TOP', '40'))]:
         print(f"  {nm:40s} {us:9.1f} us")
     groups = {}
     for nm, us in res.items():

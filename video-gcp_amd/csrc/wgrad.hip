@@ -18,12 +18,15 @@ namespace {
 
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 
-template <int TA>
+// RS (row split inside the workgroup): small dW (few 64 x 64 tiles) with many rows would leave the chip idle and every
+// wavefront in a long latency-bound loop; there the 4 wavefronts of a workgroup share ONE tile, take every 4th row chunk
+// and are combined through LDS in a fixed order (deterministic), instead of owning 4 different K tiles.
+template <int TA, bool RS>
 __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ij = lane & 15, kk = lane >> 4;
-    const int k0 = (blockIdx.x * 4 + wave) * 64;
-    if (k0 >= a.K) return;                       // no barriers below: whole wavefronts may leave
+    const int k0 = RS ? blockIdx.x * 64 : (blockIdx.x * 4 + wave) * 64;
+    if (!RS && k0 >= a.K) return;                // no barriers below (non-RS): whole wavefronts may leave
     const int n0 = blockIdx.y * (TA == 4 ? 64 : 16);
     // blockIdx.z = row split (partial mode) or batch index (nbatch > 1: independent problems with strided pointers)
     const int zb = a.nbatch > 1 ? blockIdx.z : 0;
@@ -70,9 +73,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
         for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = f32x4{0, 0, 0, 0};
 
     constexpr int UNR = 2;
-    for (int r0 = r_begin; r0 < r_end; r0 += 4 * UNR) {
-        float4 av[UNR], bv[UNR];
-        bool bok[UNR];
+    auto load = [&](const int r0, float4 (&av)[UNR], float4 (&bv)[UNR], bool (&bok)[UNR]) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int row = r0 + 4 * u + kk;
@@ -120,6 +121,15 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
                 if (xp) { bv[u] = *reinterpret_cast<const float4*>(xp); bok[u] = true; }
             }
         }
+    };
+    // software pipeline: the loads of the next row chunk are in flight while the current chunk's 32 MFMAs run
+    const int rstep = (RS ? 4 : 1) * 4 * UNR;
+    float4 av[UNR], bv[UNR], avn[UNR], bvn[UNR];
+    bool bok[UNR], bokn[UNR];
+    int r0 = r_begin + (RS ? wave * 4 * UNR : 0);
+    if (r0 < r_end) load(r0, av, bv, bok);
+    for (; r0 < r_end; r0 += rstep) {
+        if (r0 + rstep < r_end) load(r0 + rstep, avn, bvn, bokn);
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             float4 b = bv[u];
@@ -134,6 +144,35 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
             for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
                 for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = mfma16(aa[ta], bb[tb], acc[ta][tb]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { av[u] = avn[u]; bv[u] = bvn[u]; bok[u] = bokn[u]; }
+    }
+
+    if constexpr (RS) {
+        // combine the 4 row classes in wavefront order (fixed -> deterministic): waves 1..3 park their accumulators in LDS
+        __shared__ float4 racc[3][TA * 4 + 1][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb)
+                    racc[wave - 1][ta * 4 + tb][lane] = make_float4(acc[ta][tb][0], acc[ta][tb][1], acc[ta][tb][2], acc[ta][tb][3]);
+            racc[wave - 1][TA * 4][lane] = bsum;
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) {
+                    const float4 v = racc[w][ta * 4 + tb][lane];
+                    acc[ta][tb][0] += v.x; acc[ta][tb][1] += v.y; acc[ta][tb][2] += v.z; acc[ta][tb][3] += v.w;
+                }
+            const float4 v = racc[w][TA * 4][lane];
+            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
         }
     }
 
@@ -211,34 +250,56 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     dst[o] = accumulate ? dst[o] + s : s;
 }
 
-// column sums: db[n] (+)= sum_r dY[r][n]; one workgroup per 64 columns (x) and row split (y), 4 wavefronts split the rows
+// column sums: db[n] (+)= sum_r dY[r][n].  A workgroup owns a chunk of rows and up to 256 float4 column groups: thread
+// (rr, c4) walks rows rr, rr + RPI, ... of the chunk with 4 independent float4 loads in flight, the RPI row classes are
+// combined through LDS in a fixed order.  gridDim.y = row chunks: > 1 writes partial [chunks][N] (deterministic second pass),
+// 1 writes dst directly.
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ dy, const long long ldy, const int R, const int N,
                                                      const int dy_rpb, const long long dy_sb, float* __restrict__ partial,
-                                                     float* __restrict__ dst, float* __restrict__ dst2, const int accumulate) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + lane;
-    const int nsplit = gridDim.y;
-    const int rows_per = (R + nsplit - 1) / nsplit;
+                                                     float* __restrict__ dst, float* __restrict__ dst2, const int accumulate,
+                                                     const int tpr_log2) {
+    __shared__ float4 red[256];
+    const int tpr = 1 << tpr_log2, rpi = 256 >> tpr_log2;         // threads per row, rows per iteration
+    const int c4 = blockIdx.x * tpr + (threadIdx.x & (tpr - 1)), rr = threadIdx.x >> tpr_log2;
+    const int nchunk = gridDim.y;
+    const int rows_per = (R + nchunk - 1) / nchunk;
     const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
-    float s = 0.f;
-    if (n < N) {
-        for (int r = r0 + wave; r < r1; r += 4) {
-            size_t o;
-            if (dy_sb) { const int b = r / dy_rpb; o = (size_t)b * dy_sb + (size_t)(r - b * dy_rpb) * ldy; }
-            else o = (size_t)r * ldy;
-            s += dy[o + n];
+    const bool cvalid = 4 * c4 < N;
+    auto row_ptr = [&](int r) -> const float* {
+        if (dy_sb) { const int b = r / dy_rpb; return dy + (size_t)b * dy_sb + (size_t)(r - b * dy_rpb) * ldy + 4 * c4; }
+        return dy + (size_t)r * ldy + 4 * c4;
+    };
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cvalid) {
+        int r = r0 + rr;
+        for (; r + 3 * rpi < r1; r += 4 * rpi) {
+            const float4 v0 = *reinterpret_cast<const float4*>(row_ptr(r));
+            const float4 v1 = *reinterpret_cast<const float4*>(row_ptr(r + rpi));
+            const float4 v2 = *reinterpret_cast<const float4*>(row_ptr(r + 2 * rpi));
+            const float4 v3 = *reinterpret_cast<const float4*>(row_ptr(r + 3 * rpi));
+            s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+            s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; r < r1; r += rpi) {
+            const float4 v = *reinterpret_cast<const float4*>(row_ptr(r));
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
-    red[wave][lane] = s;
+    red[threadIdx.x] = s;
     __syncthreads();
-    if (wave == 0 && n < N) {
-        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        if (nsplit > 1) {
-            partial[(size_t)blockIdx.y * N + n] = t;
-        } else {
-            dst[n] = accumulate ? dst[n] + t : t;
-            if (dst2) dst2[n] = accumulate ? dst2[n] + t : t;
+    if (rr != 0 || !cvalid) return;
+    for (int k = 1; k < rpi; ++k) {
+        const float4 v = red[(k << tpr_log2) + (threadIdx.x & (tpr - 1))];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float o[4] = {s.x, s.y, s.z, s.w};
+    for (int t = 0; t < 4; ++t) {
+        const int n = 4 * c4 + t;
+        if (n >= N) break;
+        if (nchunk > 1) partial[(size_t)blockIdx.y * N + n] = o[t];
+        else {
+            dst[n] = accumulate ? dst[n] + o[t] : o[t];
+            if (dst2) dst2[n] = accumulate ? dst2[n] + o[t] : o[t];
         }
     }
 }
@@ -265,9 +326,20 @@ extern "C" int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream_) {
     const bool wide = a->N > 16;
     GCPX_CHECK_ARG(!wide || (a->N % 4 == 0 && a->ldy % 4 == 0), "N > 16 needs N % 4 == 0 and ldy % 4 == 0");
     GCPX_CHECK_ARG(a->partial || (a->ldw % 4 == 0 && a->k_off % 4 == 0), "direct output needs ldw, k_off % 4 == 0");
-    dim3 grid((kch + 3) / 4, wide ? (a->N + 63) / 64 : 1, a->nbatch > 1 ? a->nbatch : a->nsplit);
-    if (wide) hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, stream, *a);
-    else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, stream, *a);
+    const int nch = wide ? (a->N + 63) / 64 : 1;
+    const int nz = a->nbatch > 1 ? a->nbatch : a->nsplit;
+    // few tiles x many rows: share each tile between the 4 wavefronts of a workgroup (row split inside the workgroup)
+    const long long rows_per = (a->R + a->nsplit - 1) / a->nsplit;
+    const bool rs = (long long)((kch + 3) / 4) * nch * nz < 512 && rows_per >= 64;
+    if (rs) {
+        dim3 grid(kch, nch, nz);
+        if (wide) hipLaunchKernelGGL((wgrad_kernel<4, true>), grid, dim3(256), 0, stream, *a);
+        else hipLaunchKernelGGL((wgrad_kernel<1, true>), grid, dim3(256), 0, stream, *a);
+    } else {
+        dim3 grid((kch + 3) / 4, nch, nz);
+        if (wide) hipLaunchKernelGGL((wgrad_kernel<4, false>), grid, dim3(256), 0, stream, *a);
+        else hipLaunchKernelGGL((wgrad_kernel<1, false>), grid, dim3(256), 0, stream, *a);
+    }
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }
@@ -291,8 +363,12 @@ extern "C" int gcpx_colsum(const float* dy, int64_t ldy, int32_t R, int32_t N, i
     GCPX_CHECK_ARG(dy && R > 0 && N > 0 && nsplit >= 1, "bad arguments");
     GCPX_CHECK_ARG(nsplit > 1 ? partial != nullptr : dst != nullptr, "missing output");
     GCPX_CHECK_ARG(dy_sb == 0 || dy_rpb > 0, "dy_rpb <= 0");
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, nsplit), dim3(256), 0, stream, dy, (long long)ldy, R, N, dy_rpb,
-                       (long long)dy_sb, partial, dst, dst2, accumulate);
+    GCPX_CHECK_ARG(ldy % 4 == 0 && dy_sb % 4 == 0 && ldy >= ((N + 3) & ~3), "column sums read float4: ldy, dy_sb % 4 == 0, ldy >= N rounded up");
+    const int c4 = (N + 3) / 4;
+    int tl = 0;
+    while ((1 << tl) < c4 && tl < 8) ++tl;                 // threads per row = next power of two >= N / 4, at most 256
+    hipLaunchKernelGGL(colsum_kernel, dim3((c4 + (1 << tl) - 1) >> tl, nsplit), dim3(256), 0, stream, dy, (long long)ldy, R, N,
+                       dy_rpb, (long long)dy_sb, partial, dst, dst2, accumulate, tl);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

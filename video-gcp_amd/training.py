@@ -202,17 +202,23 @@ class GCPTrainStep:
 
     def _colsum(self, plan, tag, dy, ldy, R, N, dst, dst2=None, dy_rpb=0, dy_sb=0, n_map=None):
         lib, m = self.m.lib, self.m
-        nsplit = max(1, min(256, R // 2048))
+        # a workgroup covers 256 / max(1, N / 4 rounded up to a power of two) rows per iteration: give every chunk ~16 iterations
+        tpr = 1
+        while tpr < N // 4 and tpr < 256:
+            tpr *= 2
+        nsplit = max(1, min(1024, R // (16 * (256 // tpr))))
         if nsplit == 1 and n_map is None:
             self._side(plan, f"bw.colsum:{tag}", lib.gcpx_colsum, dy, ldy, R, N, dy_rpb, dy_sb, 1, None, dst, dst2, 1)
             return
-        assert dst2 is None
         nsplit = max(nsplit, 2)
         part = m._buf(f"bw.cpart:{tag}", (nsplit, N))
         self._side(plan, f"bw.colsum:{tag}", lib.gcpx_colsum, dy, ldy, R, N, dy_rpb, dy_sb, nsplit, part.data_ptr(), None, None, 0)
         if n_map is None:
             self._side(plan, f"bw.creduce:{tag}", lib.gcpx_reduce_partials, part.data_ptr(), nsplit, N, N, dst, 1)
+            if dst2 is not None:
+                self._side(plan, f"bw.creduce2:{tag}", lib.gcpx_reduce_partials, part.data_ptr(), nsplit, N, N, dst2, 1)
         else:   # bias of the output head: kernel slot -> canonical channel
+            assert dst2 is None
             self._side(plan, f"bw.creduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, N, 1, dst, rt.WMAP_CONV, 1, 1, 0,
                        n_map.data_ptr(), 0, 0, 1)
 
