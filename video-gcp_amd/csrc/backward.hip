@@ -111,12 +111,22 @@ __global__ void __launch_bounds__(256) lrelu_bwd_kernel(const float* __restrict_
     if (i < n) dx[i] = dy[i] * (a[i] > 0.f ? 1.f : slope);
 }
 
+// dst[i] (+)= sum_p partial[p * stride + i]: a workgroup owns 16 outputs, its 16 thread groups take every 16th partial and
+// are combined through LDS in a fixed order (deterministic)
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, const int n, const long long stride,
                                                               const int len, float* __restrict__ dst, const int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= len) return;
+    __shared__ float red[16][17];
+    const int oi = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + oi;
     float s = 0.f;
-    for (int p = 0; p < n; ++p) s += partial[(size_t)p * stride + i];
+    if (i < len)
+        for (int p = zl; p < n; p += 16) s += partial[(size_t)p * stride + i];
+    red[zl][oi] = s;
+    __syncthreads();
+    if (zl != 0 || i >= len) return;
+    s = 0.f;
+#pragma unroll
+    for (int z = 0; z < 16; ++z) s += red[z][oi];
     dst[i] = accumulate ? dst[i] + s : s;
 }
 
@@ -700,7 +710,7 @@ extern "C" int gcpx_reduce_partials(const float* partial, int32_t n, int64_t str
                                     void* stream_) {
     STREAM();
     GCPX_CHECK_ARG(partial && dst && n > 0 && len > 0, "bad arguments");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 255) / 256), dim3(256), 0, stream, partial, n, (long long)stride, len, dst,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 15) / 16), dim3(256), 0, stream, partial, n, (long long)stride, len, dst,
                        accumulate);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
