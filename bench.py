@@ -126,7 +126,13 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
         res["adaptive_forward"] = {"value": round(world * hp5.batch_size * hp5.max_seq_len / dt, 1), "unit": "frames/s",
                                    "ms_per_step": round(1e3 * dt, 3), "workload": "configs[4] shard: adaptive (soft-DTW) binding + "
                                    "attentive inference forward with losses, 64x64, seq_len 200, L=8 (255 nodes), batch 8/GPU"}
-        del m5
+        from video_gcp_amd.training import GCPTrainStep
+        tr5 = GCPTrainStep(m5, process_group=(dist.group.WORLD if world > 1 else None))
+        dt = _timed(lambda: tr5.step(d5, n5), max(3, k // 2), 2, world, dev)
+        res["adaptive_train_step"] = {"value": round(world * hp5.batch_size * hp5.max_seq_len / dt, 1), "unit": "frames/s",
+                                      "ms_per_step": round(1e3 * dt, 3), "workload": "configs[4] shard: forward + losses + backward "
+                                      "+ RAdam of the adaptive model, batch 8/GPU" + (", RCCL all-reduce of the flat gradient" if world > 1 else "")}
+        del tr5, m5
     except Exception as e:  # noqa: BLE001
         res["adaptive_forward"] = {"error": repr(e)[:300]}
     torch.cuda.empty_cache()

@@ -553,6 +553,25 @@ int gcpx_soft_average(const float* w, const float* x, float* out, int32_t B, int
 int gcpx_dtw_align(const float* cost, const int32_t* n_len, const int32_t* t_len, int32_t B, int32_t N, int32_t T, double* acc,
                    int32_t* inds, int32_t* path, int32_t* path_len, double* dist, void* stream);
 
+/* ---- backward of the adaptive path (training step of config c5) ---- */
+/* d images of LossAveragingCriterion.loss (binding_loss.py:19-42), the matching weights being constants (adaptive.py:50 detaches):
+ *   dimg[b][n][:] = coef * exp(-2 log_sigma) * (images[b][n][:] * sum_t wp - sum_t wp[b][n][t] * traj[b][t][:]),  wp = w * pad_mask;
+ *   dlog_sigma[0] += coef * sum w * pad * (D - dsum * exp(-2 log_sigma)).  coef = d total / d (per-sequence loss value). */
+int gcpx_averaging_nll_bwd(const float* w, const float* pad_mask, const float* images, const float* traj, const float* dsum,
+                           const float* log_sigma, float coef, int32_t B, int32_t N, int32_t T, int64_t D, float* dimg,
+                           float* dlog_sigma, void* stream);
+/* backward of the mixture mean (`images` of the discrete-logistic-mixture head): params / dparams [rows][npix][pitch] in the head's
+ *   slot order, dimg NCHW [rows][3][npix]; colsum [rows][pitch] (per-frame column sums for the bias gradient) or NULL */
+int gcpx_dlm_mean_bwd(const float* params, const float* dimg, float* dparams, float* colsum, int32_t rows, int32_t npix, int32_t pitch,
+                      int32_t n_mix, void* stream);
+/* backward of gcpx_attention (one head): from d_out [M][nz] and the saved weights att [M][T]:
+ *   dS [M][T] (scratch, gradient w.r.t. the scaled scores), dq [M][dk], dtemp_row [M] (per-row terms of d temperature),
+ *   dK [B][T] rows of dk floats with leading dimension ldk, dV [B][T] rows of nz floats with leading dimension ldv
+ *   (gradients of the projected keys / values summed over the rows of a sequence). */
+int gcpx_attention_bwd(const float* q, const float* k, const float* v, const float* att, const float* d_out, const int64_t* end_ind,
+                       const float* temperature, float* dS, float* dq, float* dtemp_row, float* dK, int64_t ldk, float* dV, int64_t ldv,
+                       int32_t M, int32_t rpb, int32_t T, int32_t dk, int32_t nz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -339,3 +339,50 @@ def test_dtw_eval_binding_c5s():
         assert_close(gen[b], est[b][inds], 0, 0, "gen_images")
     m = mse_cropped(gen, dev_in)
     assert len(m) == hp.batch_size and all(np.isfinite(x) or inputs["end_ind"][i] < 2 for i, x in enumerate(m))
+
+
+def _compare_grads(gref, got, rtol=1e-3, atol=5e-7):
+    bad = []
+    for k, g in gref.items():
+        h = got[k].cpu()
+        err, scale = float((h - g).abs().max()), float(g.abs().max())
+        if err > rtol * scale + atol:
+            bad.append((k, err, scale))
+    assert not bad, bad[:12]
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_adaptive_gradients_match_autograd_c5s(graph):
+    """training step of the adaptive model (explicit backward through the averaging loss, the mixture mean, the attentive
+    posterior and both temporal encoders) against torch autograd over the oracle.  Stated tolerance: 1e-3 of each gradient's
+    max-abs (+5e-7), as for the balanced model (tests/test_gpu_training.py)."""
+    from oracle import gcp_model_oracle as O
+    from video_gcp_amd.training import GCPTrainStep
+    hp, sd, model = _build("c5s")
+    sd["tree_module.tree_modules.0.binding.temp"].fill_(0.3)
+    model.load_state_dict({"tree_module.tree_modules.0.binding.temp": sd["tree_module.tree_modules.0.binding.temp"]}, strict=False)
+    model.use_graph = graph
+    tr = GCPTrainStep(model, lr=1e-3)
+    inputs, noise, _ = make_inputs(hp, seed=31, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    for _ in range(2):
+        out = tr.backward(dev_in, noise.cuda())
+    torch.cuda.synchronize()
+    gref, res, total, _ = O.gradients(sd, hp, inputs, noise)
+    assert abs(float(out.raw["losses"][5]) - float(total)) <= 1e-4 * abs(float(total))
+    _compare_grads(gref, tr.named_grads())
+
+
+def test_adaptive_training_step_c5_shapes_decreases_loss():
+    """configs[4] shapes (64x64, T=200, L=8; batch 2): finite gradients, the loss goes down on a fixed batch"""
+    from video_gcp_amd.training import GCPTrainStep
+    hp, sd, model = _build("c5", batch_size=2)
+    tr = GCPTrainStep(model, lr=2e-3)
+    inputs, noise, _ = make_inputs(hp, seed=32, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    losses = []
+    for _ in range(5):
+        out = tr.step(dev_in, noise.cuda())
+        losses.append(float(out.raw["losses"][5]))
+    assert all(math.isfinite(x) for x in losses) and bool(torch.isfinite(tr.grad).all())
+    assert losses[-1] < losses[0], losses

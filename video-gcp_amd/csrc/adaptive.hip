@@ -338,26 +338,6 @@ __global__ void __launch_bounds__(256) averaging_nll_kernel(const float* __restr
     nll_bt[i] = s;
 }
 
-// soft_average (binding_loss.py:44-52): out[b][t][d] = sum_n w[b][n][t] * x[b][n][d]; 32 frames x 256 elements per workgroup
-__global__ void __launch_bounds__(256) soft_average_kernel(const float* __restrict__ w, const float* __restrict__ x,
-                                                           float* __restrict__ out, const int N, const int T, const long long Dd) {
-    __shared__ float sw[32];
-    const int b = blockIdx.z, t0 = blockIdx.y * 32;
-    const long long d = (long long)blockIdx.x * 256 + threadIdx.x;
-    float acc[32];
-    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
-    for (int n = 0; n < N; ++n) {
-        __syncthreads();
-        if (threadIdx.x < 32) sw[threadIdx.x] = (t0 + threadIdx.x < T) ? w[((size_t)b * N + n) * T + t0 + threadIdx.x] : 0.f;
-        __syncthreads();
-        const float xv = d < Dd ? x[((size_t)b * N + n) * Dd + d] : 0.f;
-        for (int i = 0; i < 32; ++i) acc[i] = fmaf(sw[i], xv, acc[i]);
-    }
-    if (d < Dd)
-        for (int i = 0; i < 32; ++i)
-            if (t0 + i < T) out[((size_t)b * T + t0 + i) * Dd + d] = acc[i];
-}
-
 // ---------------------------------------------------------------------------------------------------
 // hard DTW of the evaluation harness (dtw_utils.py:77-95 basic_dtw + :201-218 _traceback, as used by
 // DTWEvalBinding.get_single_matches, evaluation_matching.py:133-146).  One workgroup per sequence; anti-diagonal
@@ -410,6 +390,262 @@ __global__ void __launch_bounds__(256) dtw_align_kernel(const float* __restrict_
     }
     path_len[b] = len;
     dist[b] = D[(size_t)(n - 1) * T + (t - 1)] / (double)(n + t);
+}
+
+// ===================================================================================================
+// Backward pass of the adaptive path (training step)
+// ===================================================================================================
+
+// d images of LossAveragingCriterion.loss (binding_loss.py:19-42) and generalised weighted sums:
+//   acc[b][o][d] = sum_k wk(b, k, o) * y[b][k][d],  wk = w[b][k * ws_k + o * ws_o] * (kmask ? kmask[b][k] : 1)
+//   out = sub ? coef * (sub[b][o][d] * (sum_k wk) - acc) : acc
+// soft average (forward, visualisation): k = node, o = frame;  averaging-loss gradient: k = frame, o = node, sub = images.
+__global__ void __launch_bounds__(256) weighted_rows_kernel(const float* __restrict__ w, const long long ws_k, const long long ws_o,
+                                                            const long long ws_b, const float* __restrict__ kmask,
+                                                            const float* __restrict__ y, const float* __restrict__ sub,
+                                                            const float* __restrict__ log_sigma, const float coef,
+                                                            float* __restrict__ out, const int Kn, const int On, const long long Dd) {
+    __shared__ float sw[32];
+    const int b = blockIdx.z, o0 = blockIdx.y * 32;
+    const long long d = (long long)blockIdx.x * 256 + threadIdx.x;
+    float acc[32];
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    float wsum = 0.f;                                   // threads < 32: sum_k wk for output o0 + tid
+    for (int k = 0; k < Kn; ++k) {
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float v = 0.f;
+            if (o0 + threadIdx.x < On) {
+                v = w[(size_t)b * ws_b + (size_t)k * ws_k + (size_t)(o0 + threadIdx.x) * ws_o];
+                if (kmask) v *= kmask[(size_t)b * Kn + k];
+            }
+            sw[threadIdx.x] = v;
+            wsum += v;
+        }
+        __syncthreads();
+        const float xv = d < Dd ? y[((size_t)b * Kn + k) * Dd + d] : 0.f;
+        for (int i = 0; i < 32; ++i) acc[i] = fmaf(sw[i], xv, acc[i]);
+    }
+    if (sub) {
+        __syncthreads();
+        if (threadIdx.x < 32) sw[threadIdx.x] = wsum;
+        __syncthreads();
+    }
+    if (d >= Dd) return;
+    const float c = sub ? coef * expf(-2.f * log_sigma[0]) : 1.f;
+    for (int i = 0; i < 32; ++i) {
+        if (o0 + i >= On) break;
+        const size_t oidx = ((size_t)b * On + o0 + i) * Dd + d;
+        out[oidx] = sub ? c * (sub[oidx] * sw[i] - acc[i]) : acc[i];
+    }
+}
+
+// d loss / d log_sigma of the averaging criterion: sum over (b, n, t) of w * pad * (D - d * exp(-2 ls)) * coef, accumulated into dst
+__global__ void __launch_bounds__(256) averaging_dls_kernel(const float* __restrict__ dsum, const float* __restrict__ w,
+                                                            const float* __restrict__ pad, const float* __restrict__ log_sigma,
+                                                            const float D, const float coef, float* __restrict__ dst,
+                                                            const int B, const int N, const int T) {
+    __shared__ float red[256];
+    const float s2 = expf(-2.f * log_sigma[0]);
+    float acc = 0.f;
+    const size_t total = (size_t)B * N * T;
+    for (size_t i = threadIdx.x; i < total; i += 256) {
+        const int t = (int)(i % T);
+        const int b = (int)(i / ((size_t)N * T));
+        acc += w[i] * pad[(size_t)b * T + t] * (D - dsum[i] * s2);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dst[0] += coef * red[0];
+}
+
+// Backward of the mixture MEAN (images of the discrete-logistic-mixture head; oracle dlm_mean): params [F][npix][PITCH] in the
+// head's slot order, dimg NCHW [F][3][npix] -> dparams [F][npix][PITCH] (+ per-frame column sums for the bias gradient).
+// A wavefront stages 16 pixels x PITCH parameters in LDS; lane (j = pixel, q) owns mixtures q, q + 4, q + 8.
+template <int NMIX, int PITCH>
+__global__ void __launch_bounds__(256) dlm_mean_bwd_kernel(const float* __restrict__ params, const float* __restrict__ dimg,
+                                                           float* __restrict__ dparams, float* __restrict__ colsum, const int npix) {
+    __shared__ float4 stage4[4 * 16 * PITCH / 4];
+    __shared__ float csum[4][2][64];
+    float cs0 = 0.f, cs1 = 0.f;
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    constexpr int F4 = 16 * PITCH / 4;
+    float* st = reinterpret_cast<float*>(stage4) + wave * 16 * PITCH;
+    const float* prow = params + (size_t)row * npix * PITCH;
+    const float* grow = dimg + (size_t)row * 3 * npix;
+    float* drow = dparams + (size_t)row * npix * PITCH;
+    for (int p0 = wave * 16; p0 < npix; p0 += 64) {
+        const float4* src = reinterpret_cast<const float4*>(prow + (size_t)p0 * PITCH);
+        for (int i = lane; i < F4; i += 64) reinterpret_cast<float4*>(st)[i] = src[i];
+        __builtin_amdgcn_wave_barrier();
+        float* pp = st + j * PITCH;
+        float lmax = pp[0];
+#pragma unroll
+        for (int k = 1; k < NMIX; ++k) lmax = fmaxf(lmax, pp[8 * k]);
+        float lsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NMIX; ++k) lsum += expf(pp[8 * k] - lmax);
+        float pi[3], Mr[3], Mg[3], Mb[3], cf[3][3];
+        float Sr = 0.f, Sg = 0.f, Sb = 0.f;
+        int nk = 0;
+        for (int k = q; k < NMIX; k += 4, ++nk) {
+            const float* m = pp + 8 * k;
+            const float c0 = tanhf(m[4]), c1 = tanhf(m[5]), c2 = tanhf(m[6]);
+            cf[nk][0] = c0; cf[nk][1] = c1; cf[nk][2] = c2;
+            pi[nk] = expf(m[0] - lmax) / lsum;
+            Mr[nk] = m[1];
+            Mg[nk] = m[2] + c0 * Mr[nk];
+            Mb[nk] = m[3] + c1 * Mr[nk] + c2 * Mg[nk];
+            Sr += pi[nk] * Mr[nk]; Sg += pi[nk] * Mg[nk]; Sb += pi[nk] * Mb[nk];
+        }
+        Sr += __shfl_xor(Sr, 16); Sr += __shfl_xor(Sr, 32);
+        Sg += __shfl_xor(Sg, 16); Sg += __shfl_xor(Sg, 32);
+        Sb += __shfl_xor(Sb, 16); Sb += __shfl_xor(Sb, 32);
+        // clamp(-1, 1) of the forward blocks the gradient outside the interval
+        const float gr = (Sr >= -1.f && Sr <= 1.f) ? grow[p0 + j] : 0.f;
+        const float gg = (Sg >= -1.f && Sg <= 1.f) ? grow[npix + p0 + j] : 0.f;
+        const float gb = (Sb >= -1.f && Sb <= 1.f) ? grow[2 * npix + p0 + j] : 0.f;
+        float dpi[3], dot = 0.f;
+        for (int i = 0; i < nk; ++i) {
+            dpi[i] = gr * Mr[i] + gg * Mg[i] + gb * Mb[i];
+            dot += pi[i] * dpi[i];
+        }
+        dot += __shfl_xor(dot, 16);
+        dot += __shfl_xor(dot, 32);
+        __builtin_amdgcn_wave_barrier();           // every lane has read the logits of its pixel
+        nk = 0;
+        for (int k = q; k < NMIX; k += 4, ++nk) {
+            float* m = pp + 8 * k;
+            const float dMb = gb * pi[nk];
+            const float dMg = gg * pi[nk] + dMb * cf[nk][2];
+            const float dMr = gr * pi[nk] + dMb * cf[nk][1] + dMg * cf[nk][0];
+            m[0] = pi[nk] * (dpi[nk] - dot);
+            m[1] = dMr;
+            m[2] = dMg;
+            m[3] = dMb;
+            m[4] = dMg * Mr[nk] * (1.f - cf[nk][0] * cf[nk][0]);
+            m[5] = dMb * Mr[nk] * (1.f - cf[nk][1] * cf[nk][1]);
+            m[6] = dMb * Mg[nk] * (1.f - cf[nk][2] * cf[nk][2]);
+            m[7] = 0.f;                               // log_scale_r: the mean does not depend on the scales
+        }
+        if (q == 0)
+            for (int s = 8 * NMIX; s < PITCH; ++s) pp[s] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        float4* dst = reinterpret_cast<float4*>(drow + (size_t)p0 * PITCH);
+        for (int i = lane; i < F4; i += 64) dst[i] = reinterpret_cast<float4*>(st)[i];
+        if (colsum) {
+#pragma unroll
+            for (int px = 0; px < 16; ++px) {
+                cs0 += st[px * PITCH + lane];
+                if (lane + 64 < PITCH) cs1 += st[px * PITCH + lane + 64];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (colsum) {
+        csum[wave][0][lane] = cs0;
+        csum[wave][1][lane] = cs1;
+        __syncthreads();
+        for (int i = tid; i < PITCH; i += 256) {
+            const int h = i >> 6, l = i & 63;
+            colsum[(size_t)row * PITCH + i] = (csum[0][h][l] + csum[1][h][l]) + (csum[2][h][l] + csum[3][h][l]);
+        }
+    }
+}
+
+// attention backward, per query row (one wavefront): dS[r][t] = a_t * (dA_t - sum_t a_t dA_t) with dA_t = dO[r] . V[b][t];
+// dq[r] = sum_t dS_t K[b][t] / (sqrt(dk) temp); dtemp_row[r] = -sum_t dS_t score_t / temp   (one head)
+__global__ void __launch_bounds__(256) attention_bwd_row_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, const float* __restrict__ att,
+                                                                const float* __restrict__ d_out, const int64_t* __restrict__ end_ind,
+                                                                const float* __restrict__ temperature, float* __restrict__ dS,
+                                                                float* __restrict__ dq, float* __restrict__ dtemp_row, const int M,
+                                                                const int rpb, const int T, const int dk, const int nz) {
+    extern __shared__ float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    const bool valid = r < M;
+    float* p = smem + (size_t)wave * T;
+    const int b = valid ? r / rpb : 0;
+    const int e = (int)end_ind[b];
+    const int te = e >= T ? T - 1 : e;
+    const float* kb = k + (size_t)b * T * dk;
+    const float* vb = v + (size_t)b * T * nz;
+    const float sq = sqrtf((float)dk), temp = temperature[0];
+    float dot = 0.f;
+    if (valid) {
+        const float* dor = d_out + (size_t)r * nz;
+        for (int t = lane; t < T; t += 64) {
+            float da = 0.f;
+            if (t <= te) {
+                const float* vr = vb + (size_t)t * nz;
+                for (int c = 0; c < nz; ++c) da = fmaf(dor[c], vr[c], da);
+            }
+            p[t] = da;
+            dot += att[(size_t)r * T + t] * da;
+        }
+    }
+    dot = wave_sum(dot);
+    float dtp = 0.f;
+    if (valid) {
+        const float* qr = q + (size_t)r * dk;
+        for (int t = lane; t < T; t += 64) {
+            const float a = att[(size_t)r * T + t];
+            const float ds = a * (p[t] - dot);
+            p[t] = ds;
+            dS[(size_t)r * T + t] = ds;
+            if (t <= te && ds != 0.f) {
+                const float* kr = kb + (size_t)t * dk;
+                float sc = 0.f;
+                for (int i = 0; i < dk; ++i) sc = fmaf(qr[i], kr[i], sc);
+                dtp -= ds * (sc / sq / temp) / temp;
+            }
+        }
+    }
+    dtp = wave_sum(dtp);
+    __syncthreads();
+    if (valid) {
+        if (lane == 0) dtemp_row[r] = dtp;
+        for (int i = lane; i < dk; i += 64) {
+            float acc = 0.f;
+            for (int t = 0; t <= te; ++t) acc = fmaf(p[t], kb[(size_t)t * dk + i], acc);
+            dq[(size_t)r * dk + i] = acc / sq / temp;
+        }
+    }
+}
+
+// attention backward, per (sequence, frame): dK[b][t][:] = sum_j dS[(b, j)][t] q[(b, j)][:] / (sqrt(dk) temp),
+// dV[b][t][:] = sum_j a[(b, j)][t] dO[(b, j)][:]; rows of dK / dV have leading dimensions ldk / ldv (level blocks side by side)
+__global__ void __launch_bounds__(192) attention_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ att,
+                                                               const float* __restrict__ dS, const float* __restrict__ d_out,
+                                                               const float* __restrict__ temperature, float* __restrict__ dK,
+                                                               const long long ldk, float* __restrict__ dV, const long long ldv,
+                                                               const int rpb, const int T, const int dk, const int nz) {
+    const int bt = blockIdx.x, b = bt / T, t = bt % T;
+    const int c = threadIdx.x;
+    if (c >= dk + nz) return;
+    const float sc = 1.f / sqrtf((float)dk) / temperature[0];
+    float acc = 0.f;
+    if (c < dk) {
+        for (int j = 0; j < rpb; ++j) {
+            const size_t r = (size_t)b * rpb + j;
+            acc = fmaf(dS[r * T + t], q[r * dk + c], acc);
+        }
+        dK[(size_t)bt * ldk + c] = acc * sc;
+    } else {
+        const int cc = c - dk;
+        for (int j = 0; j < rpb; ++j) {
+            const size_t r = (size_t)b * rpb + j;
+            acc = fmaf(att[r * T + t], d_out[r * nz + cc], acc);
+        }
+        dV[(size_t)bt * ldv + cc] = acc;
+    }
 }
 
 }  // namespace
@@ -502,8 +738,9 @@ extern "C" int gcpx_averaging_nll(const float* dsum, const float* w, const float
 extern "C" int gcpx_soft_average(const float* w, const float* x, float* out, int32_t B, int32_t N, int32_t T, int64_t D, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(w && x && out && B > 0 && N > 0 && T > 0 && D > 0, "null pointer / bad sizes");
-    hipLaunchKernelGGL(soft_average_kernel, dim3((unsigned)((D + 255) / 256), (T + 31) / 32, B), dim3(256), 0, stream, w, x, out, N, T,
-                       (long long)D);
+    hipLaunchKernelGGL(weighted_rows_kernel, dim3((unsigned)((D + 255) / 256), (T + 31) / 32, B), dim3(256), 0, stream, w,
+                       (long long)T, 1LL, (long long)N * T, (const float*)nullptr, x, (const float*)nullptr, (const float*)nullptr, 1.f,
+                       out, N, T, (long long)D);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }
@@ -513,6 +750,45 @@ extern "C" int gcpx_dtw_align(const float* cost, const int32_t* n_len, const int
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(cost && acc && inds && path && path_len && dist && B > 0 && N > 0 && T > 0, "null pointer / bad sizes");
     hipLaunchKernelGGL(dtw_align_kernel, dim3(B), dim3(256), 0, stream, cost, n_len, t_len, acc, inds, path, path_len, dist, N, T);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_averaging_nll_bwd(const float* w, const float* pad_mask, const float* images, const float* traj, const float* dsum,
+                                      const float* log_sigma, float coef, int32_t B, int32_t N, int32_t T, int64_t D, float* dimg,
+                                      float* dlog_sigma, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(w && pad_mask && images && traj && dsum && log_sigma && dimg && dlog_sigma, "null pointer");
+    GCPX_CHECK_ARG(B > 0 && N > 0 && T > 0 && D > 0, "bad sizes");
+    hipLaunchKernelGGL(weighted_rows_kernel, dim3((unsigned)((D + 255) / 256), (N + 31) / 32, B), dim3(256), 0, stream, w, 1LL,
+                       (long long)T, (long long)N * T, pad_mask, traj, images, log_sigma, coef, dimg, T, N, (long long)D);
+    hipLaunchKernelGGL(averaging_dls_kernel, dim3(1), dim3(256), 0, stream, dsum, w, pad_mask, log_sigma, (float)D, coef, dlog_sigma, B,
+                       N, T);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_dlm_mean_bwd(const float* params, const float* dimg, float* dparams, float* colsum, int32_t rows, int32_t npix,
+                                 int32_t pitch, int32_t n_mix, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(params && dimg && dparams && rows > 0, "bad arguments");
+    GCPX_CHECK_ARG(n_mix == 10 && pitch == 112 && npix % 64 == 0, "supports 10 mixtures, pitch 112, npix % 64 == 0");
+    hipLaunchKernelGGL((dlm_mean_bwd_kernel<10, 112>), dim3(rows), dim3(256), 0, stream, params, dimg, dparams, colsum, npix);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_attention_bwd(const float* q, const float* k, const float* v, const float* att, const float* d_out,
+                                  const int64_t* end_ind, const float* temperature, float* dS, float* dq, float* dtemp_row, float* dK,
+                                  int64_t ldk, float* dV, int64_t ldv, int32_t M, int32_t rpb, int32_t T, int32_t dk, int32_t nz,
+                                  void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(q && k && v && att && d_out && end_ind && temperature && dS && dq && dtemp_row && dK && dV, "null pointer");
+    GCPX_CHECK_ARG(M > 0 && rpb > 0 && M % rpb == 0 && T > 0 && T <= 4096 && dk + nz <= 192, "bad sizes (one head, dk + nz <= 192)");
+    hipLaunchKernelGGL(attention_bwd_row_kernel, dim3((M + 3) / 4), dim3(256), 4 * T * sizeof(float), stream, q, k, v, att, d_out,
+                       end_ind, temperature, dS, dq, dtemp_row, M, rpb, T, dk, nz);
+    hipLaunchKernelGGL(attention_bwd_kv_kernel, dim3((M / rpb) * T), dim3(192), 0, stream, q, att, dS, d_out, temperature, dK,
+                       (long long)ldk, dV, (long long)ldv, rpb, T, dk, nz);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

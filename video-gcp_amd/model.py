@@ -591,6 +591,7 @@ class GCPTreeModel:
         self._gemm(plan, f"attn.out{l}", [dense(raw, nz)], M, nz, M, W["attn.out.w"], W["attn.out.b"], out=et.data_ptr(), ob=0, orow=nz)
         plan.rec.setdefault("gamma", {})[l] = gamma
         plan.rec.setdefault("e_tilde", {})[l] = et
+        plan.rec.setdefault("attn", {})[l] = dict(qin=qin, qp=qp, o=o, raw=raw, gamma=gamma, et=et, M=M, n=n, li=li, temp=temp)
         return self._rowsrc(et.data_ptr(), n * nz, nz, nz)          # rows (b, j) of the level, as the posterior MLP walks them
 
     def _plan_decoder_features(self, plan, e_src, F, rpb, skips):
@@ -698,6 +699,7 @@ class GCPTreeModel:
                            out=Kp.data_ptr(), ob=0, orow=dk, batch=(n_mod, 0, P["attn.k_proj.w"][0].numel(), dk, B * T * dk))
                 self._gemm(plan, "attn.v_proj", [dense(inf_enc, nz)], B * T, nz, B * T, P["attn.v_proj.w"], P["attn.v_proj.b"],
                            out=Vp.data_ptr(), ob=0, orow=nz, batch=(n_mod, 0, P["attn.v_proj.w"][0].numel(), nz, B * T * nz))
+                plan.rec["attn_kv"] = dict(Kp=Kp, Vp=Vp, keys=keys, kenc=kenc, n_mod=n_mod)
         plan.join([1, 2])
         e0 = lambda: self._rowsrc(_addr(E), PS * nz, 0, nz)
         eg = lambda: self._rowsrc(_addr(E, 2 ** L * nz), PS * nz, 0, nz)
@@ -843,7 +845,8 @@ class GCPTreeModel:
         head_out, row_map = None, None
         if dlm:
             mode = rt.HEAD_DLM_MEAN
-            if self.materialize_distr:
+            if self.materialize_distr or (adaptive and self.save_for_backward and with_loss):
+                # (adaptive training: the backward of the mixture mean needs the raw parameters of every node)
                 mode, distr = rt.HEAD_DLM_BOTH, self._buf("distr_df", (B, N, S, S, self._head_pitch))
                 head_out = distr
             elif with_loss and not adaptive:

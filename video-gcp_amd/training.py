@@ -36,7 +36,8 @@ class GCPTrainStep:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
         hp = model._hp
         assert hp.decoder_distribution == "discrete_logistic_mixture", "training path implements the DLM head"
-        assert hp.matching_type == "balanced"
+        if hp.attentive_inference:
+            assert hp.n_attention_heads == 1, "attention backward is built for one head (hyperparameters.py:24 default)"
         self.m = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.pg = process_group
@@ -101,7 +102,20 @@ class GCPTrainStep:
             X["length_pred"] = self._pack_predictor_T(sd, "length_pred.p", [(0, 2 * nz)])
         if hp.attach_state_regressor:
             X["state_regressor"] = self._pack_predictor_T(sd, "state_regressor", [])
-        X["existence"] = self._pack_predictor_T(sd, "tree_module.tree_modules.0.binding.existence_predictor", [(0, nz)])
+        if hp.adaptive:
+            X["distance"] = self._pack_predictor_T(sd, "tree_module.tree_modules.0.binding.distance_predictor", [(0, nz), (nz, nz)])
+        else:
+            X["existence"] = self._pack_predictor_T(sd, "tree_module.tree_modules.0.binding.existence_predictor", [(0, nz)])
+        if hp.attentive_inference:
+            for nm in ["input"] + [f"pyramid-{i}" for i in range(hp.conv_inf_enc_layers)] + ["head"]:
+                w = sd[f"inf_key_encoder.0.net.{nm}.conv.weight"]
+                X[f"kseq.{nm}.wT"] = pk.pack_gemm(w.permute(1, 2, 0).reshape(w.shape[1], -1))
+            X["kseq.key.wT"] = pk.pack_gemm(sd["inf_key_encoder.1.linear.weight"].t().contiguous())                # [nz][dk]
+            n_mod = hp.hierarchy_levels if hp.untied_layers else 1
+            att = lambda l, nm: sd[f"tree_module.tree_modules.{l}.inference.attention.attention_layers.0.{nm}.weight"]
+            # d keys = [dK'_0 | dK'_1 | ...] @ [Wk_0; Wk_1; ...]: one GEMM over the level blocks laid side by side
+            X["attn.k_proj.wT"] = pk.pack_gemm(torch.cat([att(l, "k_proj") for l in range(n_mod)], 0).t().contiguous())   # [dk][n_mod*dk]
+            X["attn.v_proj.wT"] = pk.pack_gemm(torch.cat([att(l, "v_proj") for l in range(n_mod)], 0).t().contiguous())   # [nz][n_mod*nz]
         for l in range(hp.hierarchy_levels if hp.untied_layers else 1):
             p = f"tree_module.tree_modules.{l}"
             T = {}
@@ -116,6 +130,12 @@ class GCPTrainStep:
                                         for j in range(2 * hp.n_lstm_layers)]).contiguous()                     # [2H][H] each
             if l == 0:
                 T["init"] = self._pack_predictor_T(sd, f"{p}.lstm_initializer.net", [(0, 2 * nz + nv)])
+            if hp.attentive_inference:
+                a = f"{p}.inference.attention"
+                T["attn.query"] = self._pack_predictor_T(sd, f"{a}.query_net", [(0, 2 * nz)])
+                T["attn.q_proj.wT"] = pk.pack_gemm(sd[f"{a}.attention_layers.0.q_proj.weight"].t().contiguous())
+                T["attn.out_proj.wT"] = pk.pack_gemm(sd[f"{a}.attention_layers.0.out_proj.weight"].t().contiguous())
+                T["attn.out.wT"] = pk.pack_gemm(sd[f"{a}.out.weight"].t().contiguous())
             X[f"tree{l}"] = T
         return X
 
@@ -323,16 +343,31 @@ class GCPTrainStep:
 
         # ---- loss gradients (base_gcp.py:264-304) ----
         la = rec["loss_args"]
-        dMD = buf("bw.dMD", (B * T, S, S, pitch))
-        md = o["matched_distr_kernel_order"]
-        plan.add("bw.dlm_nll", lib.gcpx_dlm_nll_bwd, md.data_ptr(), tin["traj_seq"].data_ptr(), tin["pad_mask"].data_ptr(),
-                 C.c_float(hp.dense_img_rec_weight / (B * div)), dMD.data_ptr(), buf("bw.dMD.colsum", (B * T, pitch)).data_ptr(),
-                 B * T, S * S, pitch, hp.n_mixtures)
+        adaptive, attentive = hp.adaptive, hp.attentive_inference
+        if adaptive:
+            # LossAveragingCriterion (binding_loss.py:19-42): gradient w.r.t. the decoded image of EVERY node, then back through
+            # the mixture mean to the head's raw parameters; the matching weights are constants (adaptive.py:50 detaches)
+            Dd = hp.input_nc * S * S
+            dImg = buf("bw.dImg", (B, N, hp.input_nc, S, S))
+            plan.add("bw.avg_nll", lib.gcpx_averaging_nll_bwd, o["match_dist_df"].data_ptr(), tin["pad_mask"].data_ptr(),
+                     o["images_df"].data_ptr(), tin["traj_seq"].data_ptr(), o["cdist_sum"].data_ptr(),
+                     m.sd["decoder.log_sigma"].data_ptr(), C.c_float(hp.dense_img_rec_weight / (B * div)), B, N, T, Dd, dImg.data_ptr(),
+                     self.g("decoder.log_sigma"))
+            dMD = buf("bw.dMD", (B * N, S, S, pitch))
+            plan.add("bw.dlm_mean", lib.gcpx_dlm_mean_bwd, o["distr_df_kernel_order"].data_ptr(), dImg.data_ptr(), dMD.data_ptr(),
+                     buf("bw.dMD.colsum", (B * N, pitch)).data_ptr(), B * N, S * S, pitch, hp.n_mixtures)
+        else:
+            dMD = buf("bw.dMD", (B * T, S, S, pitch))
+            md = o["matched_distr_kernel_order"]
+            plan.add("bw.dlm_nll", lib.gcpx_dlm_nll_bwd, md.data_ptr(), tin["traj_seq"].data_ptr(), tin["pad_mask"].data_ptr(),
+                     C.c_float(hp.dense_img_rec_weight / (B * div)), dMD.data_ptr(), buf("bw.dMD.colsum", (B * T, pitch)).data_ptr(),
+                     B * T, S * S, pitch, hp.n_mixtures)
         plan.add("bw.kl", lib.gcpx_kl_bwd, _addr(QZ, 2 * nv), _addr(PZ, 2 * nv), _addr(dQZ, 2 * nv), _addr(dPZ, 2 * nv), B, N, nv,
                  PS * 2 * nv, 2 * nv, C.c_float(hp.free_nats), C.c_float(hp.kl_weight / (B * div)))
         ldl = _c16(T)
         dlen = buf("bw.dlen", (B, ldl)) if hp.regress_length else None
-        dexist = buf("bw.dexist", (B * N, 16))
+        Nex = N - 1 if adaptive else N                  # adaptive: the BCE is over the N - 1 consecutive-node pairs (adaptive.py:118-122)
+        dexist = buf("bw.dexist", (B * Nex, 16))
         has_state = "regressed_state_padded" in o and "traj_seq_states" in tin
         dstate = buf("bw.dstate", (B * T, 16)) if has_state else None
         plan.add("bw.heads", lib.gcpx_loss_heads_bwd, C.byref(la), rt.ptr(dlen), dexist.data_ptr(), rt.ptr(dstate))
@@ -343,9 +378,14 @@ class GCPTrainStep:
             self._mlp_bwd(plan, "length_pred", "length_pred.p", rec["mlp:length_pred"], self.bk["length_pred"], dlen.data_ptr(), ldl,
                           [(dXl.data_ptr(), 2 * nz, 0)])
             self._tree_accum(plan, "len", dE, PS * nz, 2 ** L * nz, B, 1, nz, [(dXl.data_ptr(), 2 * nz, 0, nz, -1, -1, 0)])
-        dE_ex = buf("bw.dE_ex", (B * N, nz))
-        self._mlp_bwd(plan, "existence", "tree_module.tree_modules.0.binding.existence_predictor", rec["mlp:existence"],
-                      self.bk["existence"], dexist.data_ptr(), 16, [(dE_ex.data_ptr(), N * nz, nz)])
+        if adaptive:
+            dE_d0, dE_d1 = buf("bw.dE_d0", (B * Nex, nz)), buf("bw.dE_d1", (B * Nex, nz))
+            self._mlp_bwd(plan, "distance", "tree_module.tree_modules.0.binding.distance_predictor", rec["mlp:distance"],
+                          self.bk["distance"], dexist.data_ptr(), 16, [(dE_d0.data_ptr(), Nex * nz, nz), (dE_d1.data_ptr(), Nex * nz, nz)])
+        else:
+            dE_ex = buf("bw.dE_ex", (B * N, nz))
+            self._mlp_bwd(plan, "existence", "tree_module.tree_modules.0.binding.existence_predictor", rec["mlp:existence"],
+                          self.bk["existence"], dexist.data_ptr(), 16, [(dE_ex.data_ptr(), N * nz, nz)])
         if has_state:   # input detached (base_gcp.py:253-256): parameter gradients only
             self._mlp_bwd(plan, "state_regressor", "state_regressor", rec["mlp:state_regressor"], self.bk["state_regressor"],
                           dstate.data_ptr(), 16, [])
@@ -354,7 +394,19 @@ class GCPTrainStep:
         # ---- decoder (tree_dense_rec.py:42 backward) ----
         dE_dec, dskip = self._decoder_backward(plan, fplan, dMD, B)
         self._flush(plan)
-        plan.add("bw.addrows", lib.gcpx_add_rows, _addr(dE, nz), PS * nz, nz, dE_dec.data_ptr(), dE_ex.data_ptr(), B, N, nz)
+        if adaptive:
+            plan.add("bw.addrows", lib.gcpx_add_rows, _addr(dE, nz), PS * nz, nz, dE_dec.data_ptr(), None, B, N, nz)
+            # distance predictor inputs were (node p, node p + 1), p < N - 1 (adaptive.py:66-67)
+            plan.add("bw.addrows.d0", lib.gcpx_add_rows, _addr(dE, nz), PS * nz, nz, dE_d0.data_ptr(), None, B, Nex, nz)
+            plan.add("bw.addrows.d1", lib.gcpx_add_rows, _addr(dE, 2 * nz), PS * nz, nz, dE_d1.data_ptr(), None, B, Nex, nz)
+        else:
+            plan.add("bw.addrows", lib.gcpx_add_rows, _addr(dE, nz), PS * nz, nz, dE_dec.data_ptr(), dE_ex.data_ptr(), B, N, nz)
+        if attentive:
+            kv = rec["attn_kv"]
+            n_mod, dk = kv["n_mod"], hp.nz_attn_key
+            dKp, dVp = buf("bw.dKp", (B * T, n_mod * dk)), buf("bw.dVp", (B * T, n_mod * nz))
+            if n_mod < L:       # tied levels accumulate: not built
+                raise NotImplementedError("attentive training with tied tree layers")
 
         # ---- tree levels, leaves first (tree_utils.py:21-44 backward) ----
         pid = hp.pred_inp_dim
@@ -443,8 +495,13 @@ class GCPTrainStep:
                      PS * 2 * nv, 2 * s * 2 * nv, _addr(tin["eps"], (n - 1) * nv), N * nv, nv, _addr(dpi, 2 * nz), pid,
                      (_addr(dXi, 2 * nz) if dXi is not None else None), 2 * nz + nv, dq.data_ptr(), dp.data_ptr(), M, n, nv)
             dXq, dXp = buf(f"bw.dXq{l}", (M, 2 * nz)), buf(f"bw.dXp{l}", (M, 2 * nz))
+            dEt_l = buf(f"bw.dEt{l}", (M, nz)) if attentive else None
+            et_out = (dEt_l.data_ptr(), n * nz, nz) if attentive else (_addr(dET, s * nz), PS * nz, 2 * s * nz)
             self._mlp_bwd(plan, f"posterior{l}", f"{p}.inference.q", rec[f"mlp:posterior{l}"], Wt["q"], dq.data_ptr(), 2 * nv,
-                          [(dXq.data_ptr(), n * 2 * nz, 2 * nz), (_addr(dET, s * nz), PS * nz, 2 * s * nz)])
+                          [(dXq.data_ptr(), n * 2 * nz, 2 * nz), et_out])
+            dXa = None
+            if attentive:
+                dXa = self._attention_backward(plan, fplan, l, Wt, dEt_l, dKp, dVp, B)
             self._mlp_bwd(plan, f"prior{l}", f"{p}.prior", rec[f"mlp:prior{l}"], Wt["prior"], dp.data_ptr(), 2 * nv,
                           [(dXp.data_ptr(), n * 2 * nz, 2 * nz)])
             ctx = (2 * nz + nv, 3 * nz + nv) if hp.context_every_step else (-1, -1)
@@ -452,14 +509,38 @@ class GCPTrainStep:
                     (dXp.data_ptr(), 2 * nz, 0, nz, -1, -1, 0)]
             if dXi is not None:
                 srcs.append((dXi.data_ptr(), 2 * nz + nv, 0, nz, -1, -1, 0))
+            if dXa is not None:
+                srcs.append((dXa.data_ptr(), 2 * nz, 0, nz, -1, -1, 0))
             self._tree_accum(plan, f"E{l}", dE, PS * nz, 2 * s * nz, B, n, nz, srcs)
             self._flush(plan)
 
         # ---- temporal inference encoder + image encoders (base_gcp.py:184-213 backward) ----
         d_inf = buf("bw.d_inf", (B * T, nz))
-        plan.add("bw.tscatter", lib.gcpx_timestep_scatter, _addr(dET, nz), PS * nz, nz, o["node_t"].data_ptr(), d_inf.data_ptr(),
-                 B, N, T, nz)
+        if attentive:
+            # values: d inf_enc_seq = [dV'_0 | dV'_1 | ...] @ [Wv_0; ...]; keys: the same through k_proj, the per-frame key Linear
+            # and the second temporal encoder (base_gcp.py:122-123, :200)
+            dense = lambda t, w: m._rowsrc(t.data_ptr(), 0, w, w)
+            self._dgemm(plan, "attn.v_proj", [dense(dVp, n_mod * nz)], B * T, nz, B * T, self.bk["attn.v_proj.wT"], d_inf.data_ptr(), 0, nz)
+            dkeys = buf("bw.dkeys", (B * T, dk))
+            self._dgemm(plan, "attn.k_proj", [dense(dKp, n_mod * dk)], B * T, dk, B * T, self.bk["attn.k_proj.wT"], dkeys.data_ptr(), 0, dk)
+            for l in range(n_mod):
+                a_ = f"tree_module.tree_modules.{l}.inference.attention.attention_layers.0"
+                self._wgrad(plan, f"attn.k_proj{l}", _addr(dKp, l * dk), n_mod * dk, B * T, dk, kv["keys"].data_ptr(), dk,
+                            self.g(f"{a_}.k_proj.weight"), ldw=dk, sr=dk, sb=B * T * dk, rpb=B * T, dbias=self.g(f"{a_}.k_proj.bias"))
+                self._wgrad(plan, f"attn.v_proj{l}", _addr(dVp, l * nz), n_mod * nz, B * T, nz, o["inf_enc_seq"].data_ptr(), nz,
+                            self.g(f"{a_}.v_proj.weight"), ldw=nz, sr=nz, sb=B * T * nz, rpb=B * T, dbias=self.g(f"{a_}.v_proj.bias"))
+            self._wgrad(plan, "kseq.key", dkeys.data_ptr(), dk, B * T, dk, kv["kenc"].data_ptr(), nz,
+                        self.g("inf_key_encoder.1.linear.weight"), ldw=nz, sr=nz, sb=B * T * nz, rpb=B * T,
+                        dbias=self.g("inf_key_encoder.1.linear.bias"))
+            dkenc = buf("bw.dkenc", (B * T, nz))
+            self._dgemm(plan, "kseq.key", [dense(dkeys, dk)], B * T, nz, B * T, self.bk["kseq.key.wT"], dkenc.data_ptr(), 0, nz)
+            d_enc_key = self._seq_backward(plan, fplan, dkenc, B, tag="kseq", prefix="inf_key_encoder.0.net")
+        else:
+            plan.add("bw.tscatter", lib.gcpx_timestep_scatter, _addr(dET, nz), PS * nz, nz, o["node_t"].data_ptr(), d_inf.data_ptr(),
+                     B, N, T, nz)
         d_enc_traj = self._seq_backward(plan, fplan, d_inf, B)
+        if attentive:
+            plan.add("bw.addrows.kenc", lib.gcpx_add_rows, d_enc_traj.data_ptr(), T * nz, nz, d_enc_key.data_ptr(), None, B, T, nz)
         self._flush(plan)
         self._encoder_backward(plan, fplan, "traj", d_enc_traj.data_ptr(), nz, 0, 0, {})
         self._flush(plan)
@@ -469,7 +550,7 @@ class GCPTrainStep:
         if self.side_lanes:
             plan.join(list(range(1, N_LANES)))
         plan.outs = dict(dE=dE, dHid=dHid, dET=dET, dQZ=dQZ, dPZ=dPZ, dMD=dMD, d_inf=d_inf, d_enc_traj=d_enc_traj, dE_dec=dE_dec,
-                         dE_ex=dE_ex, dlen=dlen, dexist=dexist, dstate=dstate)
+                         dE_ex=(None if adaptive else dE_ex), dlen=dlen, dexist=dexist, dstate=dstate)
         return plan
 
     def _tree_accum(self, plan, tag, dst, dst_sb, slot_stride, B, n, width, srcs):
@@ -494,23 +575,28 @@ class GCPTrainStep:
         ngf = hp.ngf
         perm32 = buf("bw.dlm_perm", (pitch,), torch.int32)
         perm32.copy_(m._dlm_perm.to(torch.int32))
-        # output head: weight gradient over the matched frames, data gradient to every node frame
-        f2n_abs = buf("bw.f2n_abs", (B, T), torch.int32)
-        plan.add("bw.f2n_abs", lib.gcpx_index_offset, o["frame2node"].data_ptr(), f2n_abs.data_ptr(), B, T, N)
-        featA = buf("bw.featA", (B * T, S, S, ngf))
-        a = m._conv_args([rec["head_src"]], B * T, S, S, S, S, ngf, ngf, self._zeros, self._zeros, featA)
-        a.src_row_map = f2n_abs.data_ptr()
+        # output head: weight gradient over the frames that carry a loss gradient, data gradient to every node frame.
+        # balanced: the matched frames (row b*T+t of dMD <- node matched to frame t); adaptive: every node frame
+        all_frames = hp.adaptive
+        R = F if all_frames else B * T
+        featA = buf("bw.featA", (R, S, S, ngf))
+        a = m._conv_args([rec["head_src"]], R, S, S, S, S, ngf, ngf, self._zeros, self._zeros, featA)
+        if not all_frames:
+            f2n_abs = buf("bw.f2n_abs", (B, T), torch.int32)
+            plan.add("bw.f2n_abs", lib.gcpx_index_offset, o["frame2node"].data_ptr(), f2n_abs.data_ptr(), B, T, N)
+            a.src_row_map = f2n_abs.data_ptr()
         plan.keep.append(a)
         plan.add("bw.stage:head", lib.gcpx_conv_stage, C.byref(a))
-        self._wgrad_conv3(plan, "dec.head", dMD.data_ptr(), pitch, featA.data_ptr(), B * T, S, S, ngf, pitch,
+        self._wgrad_conv3(plan, "dec.head", dMD.data_ptr(), pitch, featA.data_ptr(), R, S, S, ngf, pitch,
                           self.g("decoder.gen_head.conv.weight"), n_map=perm32)
-        # bias: per-frame column sums come out of the NLL backward kernel
-        self._colsum(plan, "dec.head", buf("bw.dMD.colsum", (B * T, pitch)).data_ptr(), pitch, B * T, pitch,
+        # bias: per-frame column sums come out of the loss-gradient kernel
+        self._colsum(plan, "dec.head", buf("bw.dMD.colsum", (R, pitch)).data_ptr(), pitch, R, pitch,
                      self.g("decoder.gen_head.conv.bias"), n_map=perm32)
         dA = buf("bw.dA.head", (F, S, S, ngf))
         a = m._conv_args([(dMD.data_ptr(), pitch, 1, None, None, rt.ACT_NONE)], F, S, S, S, S, ngf, ngf, self.bk["dec.head.wT"],
                          self._zeros, dA)
-        a.src_row_map = o["node2row"].data_ptr()
+        if not all_frames:
+            a.src_row_map = o["node2row"].data_ptr()
         plan.keep.append(a)
         plan.add("bw.dgrad:dec.head", lib.gcpx_conv3x3, C.byref(a))
 
@@ -558,35 +644,75 @@ class GCPTrainStep:
         return dE_dec, dskip
 
     # ---- ConvSeqEncodingModule (base_gcp.py:199) ----
-    def _seq_backward(self, plan, fplan, d_inf, B):
+    def _seq_backward(self, plan, fplan, d_inf, B, tag="seq", prefix="inf_encoder.net"):
+        """backward of one ConvSeqEncodingModule (`tag` = "seq": inf_encoder, "kseq": the attention-key encoder)"""
         m, hp, lib = self.m, self.m._hp, self.m.lib
         rec, o = fplan.rec, fplan.outs
         T, nz, nm = hp.max_seq_len, hp.nz_enc, hp.nz_mid
         buf = m._buf
         R = B * T
-        y1, y2, enc_traj = buf("seq.y1", (R, nm)), buf("seq.y2", (R, nm)), o["enc_traj_seq"]
-        bn = rec["bn:seq.bn"]
+        y1, y2, enc_traj = buf(f"{tag}.y1", (R, nm)), buf(f"{tag}.y2", (R, nm)), o["enc_traj_seq"]
+        bn = rec[f"bn:{tag}.bn"]
         taps = lambda ptr, w: [m._rowsrc(ptr, T * w, w, w, shift=1 - tap) for tap in range(3)]
-        pre = "inf_encoder.net"
-        self._wgrad(plan, "seq.head", d_inf.data_ptr(), nz, R, nz, y2.data_ptr(), 3 * nm, self.g(f"{pre}.head.conv.weight"),
+        pre = prefix
+        self._wgrad(plan, f"{tag}.head", d_inf.data_ptr(), nz, R, nz, y2.data_ptr(), 3 * nm, self.g(f"{pre}.head.conv.weight"),
                     mode=rt.WG_CONV1D, Cin=nm, rpb=T, sb=T * nm, sr=nm, scale=bn["scale"], shiftv=bn["shift"], act=rt.ACT_LRELU,
                     wmap=rt.WMAP_CONV, ntap=3)
-        self._colsum(plan, "seq.head", d_inf.data_ptr(), nz, R, nz, self.g(f"{pre}.head.conv.bias"))
-        da2 = buf("bw.seq.da2", (R, nm))
-        self._dgemm(plan, "seq.head", taps(d_inf.data_ptr(), nz), R, nm, T, self.bk["seq.head.wT"], da2.data_ptr(), T * nm, nm)
-        dy2 = self._bn_bwd(plan, "seq.bn", bn, da2.data_ptr(), nm, 0, 0, y2, R, 1, 1)
-        self._wgrad(plan, "seq.pyr", dy2.data_ptr(), nm, R, nm, y1.data_ptr(), 3 * nm, self.g(f"{pre}.pyramid-0.conv.weight"),
+        self._colsum(plan, f"{tag}.head", d_inf.data_ptr(), nz, R, nz, self.g(f"{pre}.head.conv.bias"))
+        da2 = buf(f"bw.{tag}.da2", (R, nm))
+        self._dgemm(plan, f"{tag}.head", taps(d_inf.data_ptr(), nz), R, nm, T, self.bk[f"{tag}.head.wT"], da2.data_ptr(), T * nm, nm)
+        dy2 = self._bn_bwd(plan, f"{tag}.bn", bn, da2.data_ptr(), nm, 0, 0, y2, R, 1, 1)
+        self._wgrad(plan, f"{tag}.pyr", dy2.data_ptr(), nm, R, nm, y1.data_ptr(), 3 * nm, self.g(f"{pre}.pyramid-0.conv.weight"),
                     mode=rt.WG_CONV1D, Cin=nm, rpb=T, sb=T * nm, sr=nm, wmap=rt.WMAP_CONV, ntap=3)
-        da1 = buf("bw.seq.da1", (R, nm))
-        self._dgemm(plan, "seq.pyr", taps(dy2.data_ptr(), nm), R, nm, T, self.bk["seq.pyramid-0.wT"], da1.data_ptr(), T * nm, nm)
-        du1 = buf("bw.seq.du1", (R, nm))
-        plan.add("bw.seq.lrelu", lib.gcpx_lrelu_bwd, y1.data_ptr(), da1.data_ptr(), du1.data_ptr(), R * nm, C.c_float(hp.leaky_slope))
-        self._wgrad(plan, "seq.input", du1.data_ptr(), nm, R, nm, enc_traj.data_ptr(), 3 * nz, self.g(f"{pre}.input.conv.weight"),
+        da1 = buf(f"bw.{tag}.da1", (R, nm))
+        self._dgemm(plan, f"{tag}.pyr", taps(dy2.data_ptr(), nm), R, nm, T, self.bk[f"{tag}.pyramid-0.wT"], da1.data_ptr(), T * nm, nm)
+        du1 = buf(f"bw.{tag}.du1", (R, nm))
+        plan.add(f"bw.{tag}.lrelu", lib.gcpx_lrelu_bwd, y1.data_ptr(), da1.data_ptr(), du1.data_ptr(), R * nm, C.c_float(hp.leaky_slope))
+        self._wgrad(plan, f"{tag}.input", du1.data_ptr(), nm, R, nm, enc_traj.data_ptr(), 3 * nz, self.g(f"{pre}.input.conv.weight"),
                     mode=rt.WG_CONV1D, Cin=nz, rpb=T, sb=T * nz, sr=nz, wmap=rt.WMAP_CONV, ntap=3)
-        self._colsum(plan, "seq.input", du1.data_ptr(), nm, R, nm, self.g(f"{pre}.input.conv.bias"))
-        d_enc = buf("bw.d_enc_traj", (R, nz))
-        self._dgemm(plan, "seq.input", taps(du1.data_ptr(), nm), R, nz, T, self.bk["seq.input.wT"], d_enc.data_ptr(), T * nz, nz)
+        self._colsum(plan, f"{tag}.input", du1.data_ptr(), nm, R, nm, self.g(f"{pre}.input.conv.bias"))
+        d_enc = buf(f"bw.d_enc_traj.{tag}", (R, nz))
+        self._dgemm(plan, f"{tag}.input", taps(du1.data_ptr(), nm), R, nz, T, self.bk[f"{tag}.input.wT"], d_enc.data_ptr(), T * nz, nz)
         return d_enc
+
+    # ---- attention of the attentive posterior (attentive_inference.py:47-86), one tree level ----
+    def _attention_backward(self, plan, fplan, l, Wt, dEt, dKp, dVp, B):
+        """dEt [M, nz] = gradient of e_tilde.  Writes this level's column block of dKp / dVp (projected keys / values) and
+        returns dXa [M, 2 nz], the gradient w.r.t. the query network's inputs (e_l | e_r)."""
+        m, hp, lib = self.m, self.m._hp, self.m.lib
+        rec = fplan.rec
+        ar = rec["attn"][l]
+        kv = rec["attn_kv"]
+        M, n, li = ar["M"], ar["n"], ar["li"]
+        T, nz, dk = hp.max_seq_len, hp.nz_enc, hp.nz_attn_key
+        n_mod = kv["n_mod"]
+        buf = m._buf
+        a_ = f"tree_module.tree_modules.{li}.inference.attention"
+        dense = lambda t, w: m._rowsrc(t.data_ptr(), 0, w, w)
+        lin = lambda tag, dy, x, N, K, name: self._wgrad(plan, tag, dy.data_ptr(), N, M, N, x.data_ptr(), K, self.g(f"{name}.weight"),
+                                                         ldw=K, sr=K, sb=M * K, rpb=M, dbias=self.g(f"{name}.bias"))
+        # e_tilde = out(raw); raw = out_proj(o)
+        lin(f"attn.out{l}", dEt, ar["raw"], nz, nz, f"{a_}.out")
+        draw = buf(f"bw.attn.draw{l}", (M, nz))
+        self._dgemm(plan, f"attn.out{l}", [dense(dEt, nz)], M, nz, M, Wt["attn.out.wT"], draw.data_ptr(), 0, nz)
+        lin(f"attn.out_proj{l}", draw, ar["o"], nz, nz, f"{a_}.attention_layers.0.out_proj")
+        do = buf(f"bw.attn.do{l}", (M, nz))
+        self._dgemm(plan, f"attn.out_proj{l}", [dense(draw, nz)], M, nz, M, Wt["attn.out_proj.wT"], do.data_ptr(), 0, nz)
+        # softmax attention
+        dS, dqp, dtr = buf(f"bw.attn.dS{l}", (M, T)), buf(f"bw.attn.dq{l}", (M, dk)), buf(f"bw.attn.dtemp{l}", (M,))
+        plan.add(f"bw.attn{l}", lib.gcpx_attention_bwd, ar["qp"].data_ptr(), _addr(kv["Kp"], li * B * T * dk), _addr(kv["Vp"], li * B * T * nz),
+                 ar["gamma"].data_ptr(), do.data_ptr(), fplan.rec["tin"]["end_ind"].data_ptr(), ar["temp"].data_ptr(), dS.data_ptr(),
+                 dqp.data_ptr(), dtr.data_ptr(), _addr(dKp, li * dk), n_mod * dk, _addr(dVp, li * nz), n_mod * nz, M, n, T, dk, nz)
+        self._side(plan, f"bw.attn.dtemp:{l}", lib.gcpx_reduce_partials, dtr.data_ptr(), M, 1, 1,
+                   self.g(f"{a_}.attention_layers.0.temperature"), 1)
+        # q' = q_proj(query MLP(e_l, e_r))
+        lin(f"attn.q_proj{l}", dqp, ar["qin"], dk, dk, f"{a_}.attention_layers.0.q_proj")
+        dqin = buf(f"bw.attn.dqin{l}", (M, dk))
+        self._dgemm(plan, f"attn.q_proj{l}", [dense(dqp, dk)], M, dk, M, Wt["attn.q_proj.wT"], dqin.data_ptr(), 0, dk)
+        dXa = buf(f"bw.dXa{l}", (M, 2 * nz))
+        self._mlp_bwd(plan, f"attn.query{l}", f"{a_}.query_net", rec[f"mlp:attn.query{l}"], Wt["attn.query"], dqin.data_ptr(), dk,
+                      [(dXa.data_ptr(), n * 2 * nz, 2 * nz)])
+        return dXa
 
     # ---- conv encoder (one of the three passes) ----
     def _encoder_backward(self, plan, fplan, tag, dlat, ldy, dy_rpb, dy_sb, dskip):
