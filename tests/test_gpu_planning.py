@@ -101,3 +101,16 @@ def test_hierarchical_cem_planner(setup):
     # per-iteration plans grow: start/subgoal/goal, then 5 frames, then the dense sequence (+ appended goal)
     lens = [l.elite_rollouts[0].shape[0] for l in planner.logs]
     assert lens[0] <= lens[1] <= lens[2]
+
+
+def test_plan_entry_point_cem_and_hierarchical(tmp_path):
+    """`python -m video_gcp_amd.plan` counterpart of the planner call behind planning/run.py: plans for seeded start / goal pairs"""
+    import numpy as np
+    from video_gcp_amd.plan import main
+    out = str(tmp_path / "plans")
+    res = main(["--config", "c1", "--nstart_goal_pairs", "2", "--candidates", "32", "--iters", "2", "--out", out])
+    assert len(res) == 2 and all(np.isfinite(r["cost"]) and r["plan_len"] >= 3 for r in res)
+    z = np.load(out + "/plan_0.npz")
+    assert z["image_plan"].shape[0] == res[0]["plan_len"] and z["latents"].shape[0] == res[0]["plan_len"]
+    res = main(["--config", "c1", "--nstart_goal_pairs", "1", "--planner", "hierarchical"])
+    assert len(res) == 1 and np.isfinite(res[0]["cost"])
