@@ -481,6 +481,8 @@ int gcpx_graph_destroy(void* graph_exec);
    gcpx_graph_begin/_end a gcpx_event_record on the capturing stream followed by gcpx_stream_wait_event on a side
    stream forks the capture; the reverse joins it, so the branches become parallel paths of the hipGraph. */
 int gcpx_stream_create(void** stream);
+/* level < 0: highest priority of the device, 0: middle, > 0: lowest (side lanes that must not delay the critical chain) */
+int gcpx_stream_create_priority(void** stream, int level);
 int gcpx_stream_destroy(void* stream);
 int gcpx_stream_wait_event(void* stream, void* ev);
 

@@ -27,3 +27,15 @@ busy += cur_e - cur_s
 print("GPU non-idle %.2f ms" % (busy / 1e6))
 for nm, (d, n) in sorted(k.items(), key=lambda kv: -kv[1][0])[:top]:
     print("  %-72s %4d calls %8.2f ms" % (nm, n, d / 1e6))
+
+if len(sys.argv) > 3:      # timeline of one queue: python tools/trace_summary.py trace.csv 0 <queue id> [min_us]
+    qid, min_us = sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 100.0
+    prev_end = t0
+    for r in seg:
+        if r['Queue_Id'] != qid:
+            continue
+        s_, e_ = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        gap, dur = (s_ - prev_end) / 1e3, (e_ - s_) / 1e3
+        if gap > min_us or dur > min_us:
+            print("  t=%8.1f us  gap %7.1f  dur %7.1f  %s" % ((s_ - t0) / 1e3, gap, dur, r['Kernel_Name'].replace('(anonymous namespace)::', '')[:60]))
+        prev_end = max(prev_end, e_)

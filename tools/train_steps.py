@@ -11,6 +11,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 hp = V.config("c2")
 model = GCPTreeModel(hp, device="cuda")
 tr = GCPTrainStep(model)
+model.use_graph = os.environ.get('NOGRAPH') is None
+tr.backward_graph = os.environ.get('BGRAPH') is not None
+tr.side_priority = int(os.environ.get('SIDEPRIO', '0'))
+if os.environ.get('NOSIDE'):
+    tr.side_lanes = False
 inputs, noise, _ = make_inputs(hp, seed=0, variant="A")
 dev_in = {k: v.cuda() for k, v in inputs.items()}
 for _ in range(3):
@@ -21,3 +26,9 @@ for _ in range(n):
     tr.step(dev_in)
 torch.cuda.synchronize()
 print(f"{(time.perf_counter() - t0) / n * 1e3:.2f} ms/step")
+# host issue time per step (async launches; no sync inside)
+torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    t1 = time.perf_counter(); tr.step(dev_in); ts.append(time.perf_counter() - t1); torch.cuda.synchronize()
+print("host issue time per step: %.2f ms (min %.2f)" % (sum(ts) / len(ts) * 1e3, min(ts) * 1e3))

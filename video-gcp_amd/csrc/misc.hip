@@ -375,6 +375,17 @@ extern "C" int gcpx_stream_create(void** stream) {
     return GCPX_OK;
 }
 
+extern "C" int gcpx_stream_create_priority(void** stream, int level) {
+    GCPX_CHECK_ARG(stream != nullptr, "stream is NULL");
+    int least = 0, greatest = 0;                              // numerically: greatest priority <= least priority
+    GCPX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int prio = level < 0 ? greatest : (level > 0 ? least : (least + greatest) / 2);
+    hipStream_t s;
+    GCPX_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+    *stream = s;
+    return GCPX_OK;
+}
+
 extern "C" int gcpx_stream_destroy(void* stream) {
     GCPX_HIP(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
     return GCPX_OK;

@@ -51,6 +51,13 @@ class GCPTrainStep:
         self._bplans = {}
         self.side_lanes = bool(hp.untied_layers)   # tied levels accumulate into the same weights: keep them on one lane
         self.wgrad_waves = 8192               # wavefronts a split weight-gradient launch aims for (latency hiding)
+        # The backward plan is replayed EAGERLY over real streams by default: as parallel branches of one hipGraph the runtime
+        # maps nodes of the critical chain onto the same hardware queue as multi-millisecond weight-gradient kernels and
+        # serialises them (measured: 32.0 ms / step as a graph, 28.0 ms eager, c2).
+        self.backward_graph = False
+        self.n_side = int(__import__("os").environ.get("GCPX_NSIDE", N_LANES - 1))   # side lanes of the backward plan
+        self.side_priority = 0                # middle priority; lowest (> 0) starves the side lanes: 40.9 ms / step
+        self._lanes = None
         self._zeros = torch.zeros(256, device=model.device)
 
     # ------------------------------------------------------------------------------------------------
@@ -155,7 +162,7 @@ class GCPTrainStep:
                 plan.add(name, fn, *args)
             plan.deferred = []
             return
-        lanes = list(range(1, N_LANES))
+        lanes = list(range(1, 1 + self.n_side))
         plan.fork(lanes)
         # ops of one tag (wgrad + its reduce) stay on one lane, in order
         lane_of = plan.rec.setdefault("_lane_of", {})
@@ -548,7 +555,7 @@ class GCPTrainStep:
         self._encoder_backward(plan, fplan, "Ig", _addr(dE, 2 ** L * nz), nz, 1, PS * nz, {})
         self._flush(plan)
         if self.side_lanes:
-            plan.join(list(range(1, N_LANES)))
+            plan.join(list(range(1, 1 + self.n_side)))
         plan.outs = dict(dE=dE, dHid=dHid, dET=dET, dQZ=dQZ, dPZ=dPZ, dMD=dMD, d_inf=d_inf, d_enc_traj=d_enc_traj, dE_dec=dE_dec,
                          dE_ex=(None if adaptive else dE_ex), dlen=dlen, dexist=dexist, dstate=dstate)
         return plan
@@ -789,16 +796,30 @@ class GCPTrainStep:
         caller = torch.cuda.current_stream(m.device)
         m._stream.wait_stream(caller)
         stream = m._stream.cuda_stream
-        if m.use_graph:
+        if m.use_graph and self.backward_graph:
             if bplan.graph is None:
                 bplan.run(m._streams)
                 bplan.graph = m._capture(bplan, bplan.ops, stream)
             rt.check(m.lib.gcpx_graph_launch(bplan.graph, stream), "graph_launch")
         else:
-            bplan.run(m._streams)
+            bplan.run(self._backward_streams())
         caller.wait_stream(m._stream)
         self.last_bplan = bplan
         return out
+
+    def _backward_streams(self):
+        """lane 0 = the model's stream, side lanes = the model's own side streams: the process then uses four streams in all
+        (torch's, the model's three), one per hardware queue of the default runtime configuration — extra streams get
+        multiplexed onto the same queues and serialise the lanes again (measured: +4 ms / step)."""
+        if self._lanes is None:
+            m = self.m
+            self._lanes = list(m._streams[:1 + self.n_side])
+            for _ in range(1 + self.n_side - len(self._lanes)):
+                sp = C.c_void_p()
+                with torch.cuda.device(m.device):
+                    rt.check(m.lib.gcpx_stream_create_priority(C.byref(sp), int(self.side_priority)), "stream_create")
+                self._lanes.append(sp)
+        return self._lanes
 
     def optimizer_step(self):
         """RAdam on the flat vectors + one re-pack gather (gcp_builder.py:88-89,178-179)."""
