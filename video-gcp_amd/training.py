@@ -55,6 +55,9 @@ class GCPTrainStep:
         # maps nodes of the critical chain onto the same hardware queue as multi-millisecond weight-gradient kernels and
         # serialises them (measured: 32.0 ms / step as a graph, 28.0 ms eager, c2).
         self.backward_graph = False
+        # posterior / prior / merge chains of a level on three lanes: measured SLOWER (30.0 vs 28.2 ms / step) — the side lanes are
+        # busy with the previous level's weight gradients, so the forked chains queue behind them.  Kept for experiments.
+        self.parallel_level_chains = False
         self.n_side = int(__import__("os").environ.get("GCPX_NSIDE", N_LANES - 1))   # side lanes of the backward plan
         self.side_priority = 0                # middle priority; lowest (> 0) starves the side lanes: 40.9 ms / step
         self._lanes = None
@@ -472,22 +475,29 @@ class GCPTrainStep:
                 koff += sc.width
             dpi = buf(f"bw.dpi{l}", (M, pid))
             self._dgemm(plan, f"embed{l}", [self._dense(dx0.data_ptr(), H, H, M)], M, pid, M, Wt["embed.wT"], dpi.data_ptr(), 0, pid)
-            # split_linear merge of the parents' hidden states
-            # all 2*n_lstm_layers projections in one launch per parent side (blockIdx.z = projection)
-            po = [m._poff[f"{sp}.projections.{j}.weight"][0] for j in range(2 * nl)]
-            bo = [m._poff[f"{sp}.projections.{j}.bias"][0] for j in range(2 * nl)]
-            zw, zb = po[1] - po[0], bo[1] - bo[0]
-            assert all(po[j + 1] - po[j] == zw and bo[j + 1] - bo[j] == zb for j in range(2 * nl - 1))
-            for side, base in ((0, 0), (1, 2 * s * SD)):
-                self._wgrad(plan, f"proj{l}.{side}", dmerged.data_ptr(), 2 * nl * H, M, H, _addr(Hid, base), H,
-                            self.g(f"{sp}.projections.0.weight"), ldw=2 * H, k_off=side * H, rpb=n, sb=PS * SD, sr=2 * s * SD,
-                            dbias=(self.g(f"{sp}.projections.0.bias") if side == 0 else None), batch=(2 * nl, H, H, zw, zb))
-            dpar = buf(f"bw.dpar{l}", (2 * nl, M, 2 * H))
-            self._dgemm(plan, f"merge{l}", [m._rowsrc(dmerged.data_ptr(), n * 2 * nl * H, 2 * nl * H, H)], M, 2 * H, n, Wt["proj.wT"],
-                        dpar.data_ptr(), n * 2 * H, 2 * H, batch=(2 * nl, H, Wt["proj.wT"][0].numel(), 0, M * 2 * H))
-            self._tree_accum(plan, f"hid{l}", dHid, PS * SD, 2 * s * SD, B, n, H,
-                             [(dpar.data_ptr() + 4 * j * M * 2 * H, 2 * H, 0, H, -1, -1, j * H) for j in range(2 * nl)])
+            def merge_backward():
+                # split_linear merge of the parents' hidden states
+                # all 2*n_lstm_layers projections in one launch per parent side (blockIdx.z = projection)
+                po = [m._poff[f"{sp}.projections.{j}.weight"][0] for j in range(2 * nl)]
+                bo = [m._poff[f"{sp}.projections.{j}.bias"][0] for j in range(2 * nl)]
+                zw, zb = po[1] - po[0], bo[1] - bo[0]
+                assert all(po[j + 1] - po[j] == zw and bo[j + 1] - bo[j] == zb for j in range(2 * nl - 1))
+                for side, base in ((0, 0), (1, 2 * s * SD)):
+                    self._wgrad(plan, f"proj{l}.{side}", dmerged.data_ptr(), 2 * nl * H, M, H, _addr(Hid, base), H,
+                                self.g(f"{sp}.projections.0.weight"), ldw=2 * H, k_off=side * H, rpb=n, sb=PS * SD, sr=2 * s * SD,
+                                dbias=(self.g(f"{sp}.projections.0.bias") if side == 0 else None), batch=(2 * nl, H, H, zw, zb))
+                dpar = buf(f"bw.dpar{l}", (2 * nl, M, 2 * H))
+                self._dgemm(plan, f"merge{l}", [m._rowsrc(dmerged.data_ptr(), n * 2 * nl * H, 2 * nl * H, H)], M, 2 * H, n, Wt["proj.wT"],
+                            dpar.data_ptr(), n * 2 * H, 2 * H, batch=(2 * nl, H, Wt["proj.wT"][0].numel(), 0, M * 2 * H))
+                self._tree_accum(plan, f"hid{l}", dHid, PS * SD, 2 * s * SD, B, n, H,
+                                 [(dpar.data_ptr() + 4 * j * M * 2 * H, 2 * H, 0, H, -1, -1, j * H) for j in range(2 * nl)])
+
+            # Below the root the three remaining chains of a level are independent: posterior MLP (+ attention), prior MLP,
+            # parent-state merge.  They run on three lanes (each ~10 dependent launches) and meet again at the accumulation.
+            split = self.parallel_level_chains and self.side_lanes and l > 0
             dXi = None
+            if not split:
+                merge_backward()
             if l == 0:
                 # MLP LSTM initialiser (tree_module.py:104-105): outputs live in Hid slots 0 and 2^L
                 dinit = buf("bw.dinit", (B, 2 * SD))
@@ -504,13 +514,22 @@ class GCPTrainStep:
             dXq, dXp = buf(f"bw.dXq{l}", (M, 2 * nz)), buf(f"bw.dXp{l}", (M, 2 * nz))
             dEt_l = buf(f"bw.dEt{l}", (M, nz)) if attentive else None
             et_out = (dEt_l.data_ptr(), n * nz, nz) if attentive else (_addr(dET, s * nz), PS * nz, 2 * s * nz)
+            if split:
+                plan.fork([1, 2])
+                plan.lane = 1
             self._mlp_bwd(plan, f"posterior{l}", f"{p}.inference.q", rec[f"mlp:posterior{l}"], Wt["q"], dq.data_ptr(), 2 * nv,
                           [(dXq.data_ptr(), n * 2 * nz, 2 * nz), et_out])
             dXa = None
             if attentive:
                 dXa = self._attention_backward(plan, fplan, l, Wt, dEt_l, dKp, dVp, B)
+            if split:
+                plan.lane = 2
             self._mlp_bwd(plan, f"prior{l}", f"{p}.prior", rec[f"mlp:prior{l}"], Wt["prior"], dp.data_ptr(), 2 * nv,
                           [(dXp.data_ptr(), n * 2 * nz, 2 * nz)])
+            if split:
+                plan.lane = 0
+                merge_backward()
+                plan.join([1, 2])
             ctx = (2 * nz + nv, 3 * nz + nv) if hp.context_every_step else (-1, -1)
             srcs = [(dpi.data_ptr(), pid, 0, nz, ctx[0], ctx[1], 0), (dXq.data_ptr(), 2 * nz, 0, nz, -1, -1, 0),
                     (dXp.data_ptr(), 2 * nz, 0, nz, -1, -1, 0)]
