@@ -161,3 +161,21 @@ def test_losses_c1(dist, materialize):
         assert losses[name].weight == w
     assert abs(float(total.value) - float(ref_total)) <= 2e-5 * abs(float(ref_total)) + 1e-6
     assert abs(float(losses["nll"].value) - float(ref_losses["dense_img_rec"][0] + ref_losses["kl"][0])) <= 1e-4 * abs(float(losses["nll"].value))
+
+
+@pytest.mark.parametrize("cfg", [dict(img_sz=64, batch_size=1, max_seq_len=3), dict(img_sz=32, batch_size=3, max_seq_len=33)])
+def test_edge_shapes(cfg):
+    """smallest tree (T=3: L=2, 3 nodes, one sequence) and a sequence length just past a power of two (T=33: L=6, 63 nodes for
+    33 frames, ragged batch): decoded nodes and the total loss against the oracle"""
+    from oracle import gcp_model_oracle as O
+    hp, sd, model = _build("c1", **cfg)
+    model.train(True)
+    inputs, noise, _ = make_inputs(hp, seed=2, variant="B")
+    ref = O.forward(sd, hp, inputs, noise=noise, training_bn=True)
+    _, ref_total = O.losses(sd, hp, inputs, ref)
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    out = model(dev_in, "train", noise=noise.cuda())
+    torch.cuda.synchronize()
+    _check_common(hp, model, out, ref, posterior=True)
+    total = float(model.get_total_loss(dev_in, model.loss(dev_in, out)).value)
+    assert abs(total - float(ref_total)) <= 2e-5 * abs(float(ref_total)) + 1e-6

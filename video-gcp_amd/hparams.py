@@ -77,7 +77,7 @@ class GCPHParams:
         if self.hierarchy_levels < 0:
             # train.py:80-81
             self.hierarchy_levels = int(math.ceil(math.log2(self.max_seq_len)))
-        assert self.img_sz in (32, 64, 128)
+        assert self.img_sz in (32, 64), "decoder kernels are built for 32x32 (reference default, base_model.py:41) and 64x64"
         assert self.nz_mid % self.gn_groups == 0 and self.init_mlp_mid_sz % self.gn_groups == 0
         assert self.decoder_distribution in ("discrete_logistic_mixture", "gaussian")
         assert self.matching_type in ("balanced", "dtw_image")
