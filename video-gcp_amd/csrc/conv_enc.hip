@@ -9,6 +9,8 @@
 // pre-packed in fragment order (one coalesced 1 KiB load per 16 output channels per step).
 #include "common.cuh"
 
+#include <cstdlib>
+
 namespace {
 
 // generic NHWC layer: Cin % 16 == 0.
@@ -136,6 +138,234 @@ __global__ void __launch_bounds__(256) conv4x4s2_kernel(const gcpx_conv_args a, 
     }
 }
 
+// LDS-resident variant for the layers whose whole input frame(s) fit in LDS (every encoder layer after the first at 32 x 32
+// and 64 x 64 images).  A workgroup stages FPB complete input frames once — coalesced 16-byte loads, the producer's BatchNorm
+// affine + LeakyReLU applied ONCE per element instead of once per tap — and computes all their output pixels from LDS:
+// NG = FPB * HOUT^2 / 16 pixel groups over WP wavefront rows, COUT / 16 channel tiles over WC wavefront columns, so a weight
+// fragment fetched from L2 feeds PGW pixel groups (the direct-from-global kernel above re-fetched activations 4x through L1
+// and was L2-bound on the filter bank).  Out-of-image taps read a zero pixel kept behind the frames.
+// FPB = most frames a workgroup stages at once; the launch picks fpb <= FPB so that the workgroups fill the CUs in whole rounds
+// (1280 frames over 256 CUs: 5 frames each = one round, instead of 160 workgroups of 8).  ZP: out-of-image taps read a zero
+// pixel kept behind the frames; without it (layers whose frame + zero pixel would not let two workgroups share a CU's LDS)
+// the loaded value is replaced by zero instead.
+template <int CIN, int COUT, int HIN, int FPB, int WP, int WC, bool ZP>
+struct EncLdsCfg {
+    static constexpr int HOUT = HIN / 2, CT = COUT / 16, CTW = CT / WC, NCG = CIN / 16, CINP = CIN + 4;
+    static constexpr int NG = FPB * HOUT * HOUT / 16, PGW = (NG + WP - 1) / WP;
+    static constexpr int FRAME_PIX = HIN * HIN;
+    static constexpr int LDS_BYTES = (FPB * FRAME_PIX * CINP + (ZP ? CINP : 0)) * 4;    // at the largest group
+    static constexpr int lds_bytes(int fpb) { return (fpb * FRAME_PIX * CINP + (ZP ? CINP : 0)) * 4; }
+    static_assert(WP * WC == 4 && CT % WC == 0 && (HOUT * HOUT) % 16 == 0, "tiling");
+};
+
+template <int CIN, int COUT, int HIN, int FPB, int WP, int WC, bool ZP>
+__global__ void __launch_bounds__(256) conv4x4s2_lds_kernel(const gcpx_conv_args a, const int nblk, const int nrows, const int fpb) {
+    using Cfg = EncLdsCfg<CIN, COUT, HIN, FPB, WP, WC, ZP>;
+    constexpr int HOUT = Cfg::HOUT, CT = Cfg::CT, CTW = Cfg::CTW, NCG = Cfg::NCG, CINP = Cfg::CINP, PGW = Cfg::PGW;
+    constexpr int FRAME_PIX = Cfg::FRAME_PIX, C4 = CIN / 4;
+    const int tot4 = fpb * FRAME_PIX * C4;
+    const int ngrp = fpb * HOUT * HOUT / 16;             // pixel groups of a full workgroup, dealt round-robin to the WP rows
+    const int npg = __builtin_amdgcn_readfirstlane((ngrp - (int)((threadIdx.x >> 6) % WP) + WP - 1) / WP);   // groups of this wavefront
+    extern __shared__ float4 enc_smem4[];
+    float* lds = reinterpret_cast<float*>(enc_smem4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave % WP, wc = wave / WP;
+    const int j = lane & 15, q = lane >> 4;
+    const gcpx_conv_src s = a.src[0];
+    const float4* wbase = reinterpret_cast<const float4*>(a.wpk) + (size_t)wc * CTW * 64 + lane;
+    const int zero_off = fpb * FRAME_PIX * CINP;         // float offset of the zero pixel (behind the staged frames)
+    if (ZP && tid < CINP) lds[zero_off + tid] = 0.f;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s.scale) {
+        sc4 = *reinterpret_cast<const float4*>(s.scale + 4 * (tid % (CIN / 4)));
+        sh4 = *reinterpret_cast<const float4*>(s.shift + 4 * (tid % (CIN / 4)));
+    }
+
+    f32x4 st1[CTW], st2[CTW];
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) { st1[ct] = f32x4{0, 0, 0, 0}; st2[ct] = f32x4{0, 0, 0, 0}; }
+
+    // per pixel group of this wavefront: LDS offset of input pixel (2 oy - 1, 2 ox - 1) + this lane's 4-channel slice, tap validity
+    int base[PGW], fl_[PGW], pin_[PGW];
+    unsigned vmask[PGW];                                   // bit ky (0..3): row valid, bit 4 + kx: column valid
+#pragma unroll
+    for (int pt = 0; pt < PGW; ++pt) {
+        const int p = (wp + pt * WP) * 16 + j;             // pixel index inside the workgroup's frames (group wp + pt * WP)
+        const int fl = p / (HOUT * HOUT), pin = p % (HOUT * HOUT);
+        const int oy = pin / HOUT, ox = pin % HOUT;
+        fl_[pt] = fl; pin_[pt] = pin;
+        base[pt] = ((fl * HIN + 2 * oy - 1) * HIN + 2 * ox - 1) * CINP + 4 * q;
+        unsigned m = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (2 * oy - 1 + k >= 0 && 2 * oy - 1 + k < HIN) m |= 1u << k;
+            if (2 * ox - 1 + k >= 0 && 2 * ox - 1 + k < HIN) m |= 16u << k;
+        }
+        vmask[pt] = m;
+    }
+
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int f0 = blk * fpb;
+        __syncthreads();                                    // the previous iteration's operand reads are done
+        const float4* src = reinterpret_cast<const float4*>(s.ptr) + (size_t)f0 * FRAME_PIX * C4;
+        const int nvalid4 = min(fpb, a.F - f0) * FRAME_PIX * C4;
+        // 8 independent 16-byte loads in flight per thread (a load -> affine -> store loop is one HBM latency per iteration);
+        // 256 % C4 == 0, so a thread always handles the same 4 channels: its scale / shift live in registers
+        static_assert(256 % C4 == 0, "staging batches");
+#pragma unroll 1
+        for (int i0 = 0; i0 < tot4; i0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = i0 + k * 256 + tid;
+                v[k] = idx < nvalid4 ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = i0 + k * 256 + tid;
+                const int c4 = idx % C4, pix = idx / C4;
+                if (idx < nvalid4) {
+                    float4 x = v[k];
+                    x.x = fmaf(x.x, sc4.x, sh4.x); x.y = fmaf(x.y, sc4.y, sh4.y); x.z = fmaf(x.z, sc4.z, sh4.z); x.w = fmaf(x.w, sc4.w, sh4.w);
+                    if (s.act == GCPX_ACT_LRELU) { x.x = lrelu(x.x, 0.2f); x.y = lrelu(x.y, 0.2f); x.z = lrelu(x.z, 0.2f); x.w = lrelu(x.w, 0.2f); }
+                    v[k] = x;
+                }
+                if (idx < tot4) *reinterpret_cast<float4*>(lds + pix * CINP + 4 * c4) = v[k];
+            }
+        }
+        __syncthreads();
+
+        f32x4 acc[CTW][PGW];
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PGW; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
+        auto fetch = [&](const int step, float4 (&w)[CTW], float4 (&b)[PGW]) {
+            const int tap = step / NCG, cg = step % NCG;
+            const int ky = tap >> 2, kx = tap & 3;
+            const int tapoff = (ky * HIN + kx) * CINP + cg * 16;
+            const float4* wp_ = wbase + (size_t)step * CT * 64;
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) w[ct] = wp_[ct * 64];
+#pragma unroll
+            for (int pt = 0; pt < PGW; ++pt) {
+                if (pt >= npg) break;                         // wave-uniform: this wavefront's pixel groups beyond the staged frames
+                const bool ok = ((vmask[pt] >> ky) & 1u) && ((vmask[pt] >> (4 + kx)) & 1u);
+                if constexpr (ZP) {
+                    const int off = ok ? base[pt] + tapoff : zero_off + 4 * q;
+                    b[pt] = *reinterpret_cast<const float4*>(lds + off);
+                } else {
+                    const float4 t = *reinterpret_cast<const float4*>(lds + (ok ? base[pt] + tapoff : 4 * q));
+                    b[pt] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        auto mm = [&](const float4 (&w)[CTW], const float4 (&b)[PGW]) {
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) {
+#pragma unroll
+                for (int pt = 0; pt < PGW; ++pt) {
+                    if (pt >= npg) break;
+                    acc[ct][pt] = mfma16(w[ct].x, b[pt].x, acc[ct][pt]);
+                    acc[ct][pt] = mfma16(w[ct].y, b[pt].y, acc[ct][pt]);
+                    acc[ct][pt] = mfma16(w[ct].z, b[pt].z, acc[ct][pt]);
+                    acc[ct][pt] = mfma16(w[ct].w, b[pt].w, acc[ct][pt]);
+                }
+            }
+        };
+        // two register sets in ping-pong (no copies: a copy lets the scheduler pull the wait for the NEXT step's loads in front of
+        // this step's MFMAs): the operands of step s + 1 are in flight during the 64 MFMAs of step s
+        float4 wA[CTW], bA[PGW], wB[CTW], bB[PGW];
+        constexpr int NSTEP = 16 * NCG;
+        static_assert(NSTEP % 2 == 0, "ping-pong");
+        fetch(0, wA, bA);
+#pragma unroll 1
+        for (int step = 0; step < NSTEP; step += 2) {
+            fetch(step + 1, wB, bB);
+            mm(wA, bA);
+            if (step + 2 < NSTEP) fetch(step + 2, wA, bA);
+            mm(wB, bB);
+        }
+#pragma unroll
+        for (int pt = 0; pt < PGW; ++pt) {
+            const int f = f0 + fl_[pt];
+            if (f >= a.F || wp + pt * WP >= ngrp) continue;
+            float* op = a.out + ((size_t)f * HOUT * HOUT + pin_[pt]) * COUT;
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) {
+                const int c = (wc * CTW + ct) * 16 + q * 4;
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
+                f32x4 v = acc[ct][pt];
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                if (a.out_act == GCPX_ACT_LRELU) {
+                    v[0] = lrelu(v[0], 0.2f); v[1] = lrelu(v[1], 0.2f); v[2] = lrelu(v[2], 0.2f); v[3] = lrelu(v[3], 0.2f);
+                }
+                *reinterpret_cast<float4*>(op + c) = make_float4(v[0], v[1], v[2], v[3]);
+                if (a.stats_partial) { st1[ct] += v; st2[ct] += v * v; }
+            }
+        }
+    }
+    if (a.stats_partial) {
+        __syncthreads();
+        float* red = lds;                                   // [WP][2][CT*16], the frames are no longer needed
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = row16_sum(st1[ct][r]);
+                const float s2 = row16_sum(st2[ct][r]);
+                if (j == 0) {
+                    const int c = (wc * CTW + ct) * 16 + q * 4 + r;
+                    red[(wp * 2 + 0) * CT * 16 + c] = s1;
+                    red[(wp * 2 + 1) * CT * 16 + c] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * CT * 16; i += 256) {
+            const int which = i / (CT * 16), c = i % (CT * 16);
+            float sum = 0.f;
+#pragma unroll
+            for (int w_ = 0; w_ < WP; ++w_) sum += red[(w_ * 2 + which) * CT * 16 + c];
+            a.stats_partial[((size_t)blockIdx.x * 2 + which) * CT * 16 + c] = sum;
+            // rows of workgroups that were not launched (every launched one carries its frames in LDS): zero
+            for (int r = blockIdx.x + gridDim.x; r < nrows; r += gridDim.x) a.stats_partial[((size_t)r * 2 + which) * CT * 16 + c] = 0.f;
+        }
+    }
+}
+
+template <int CIN, int COUT, int HIN, int FPB, int WP, int WC, bool ZP>
+int launch_enc_lds(const gcpx_conv_args* a, hipStream_t stream) {
+    using Cfg = EncLdsCfg<CIN, COUT, HIN, FPB, WP, WC, ZP>;
+    auto kern = conv4x4s2_lds_kernel<CIN, COUT, HIN, FPB, WP, WC, ZP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) {
+            gcpx_set_error("conv4x4s2 (LDS): hipFuncSetAttribute(%d B): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    // frames per workgroup: the most loaded CU should carry as few frames as possible (workgroups are dealt round-robin to the
+    // CUs); among equals the larger group (weight fragments are fetched once per group; measured at 1280 frames: 4x4 layer
+    // 62 us with 5 frames / workgroup, 97 us with 1)
+    const int cus = gcpx_conv_grid() / 2;
+    int fpb = 1;
+    long best = -1;
+    for (int c = 1; c <= FPB; ++c) {
+        const int nb = (a->F + c - 1) / c;
+        const long cost = (long)((nb + cus - 1) / cus) * c;
+        if (best < 0 || cost <= best) { best = cost; fpb = c; }
+    }
+    if (const char* e = getenv("GCPX_ENC_FPB")) { const int v = atoi(e); if (v >= 1 && v <= FPB) fpb = v; }
+    const int nblk = (a->F + fpb - 1) / fpb;
+    // stats_partial has gcpx_conv4x4s2_grid() rows and all of them must be written: the launched workgroups zero the others
+    const int nrows = gcpx_conv4x4s2_grid();
+    const int grid = nblk < nrows ? nblk : nrows;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::lds_bytes(fpb), stream, *a, nblk, nrows, fpb);
+    return GCPX_OK;
+}
+
 // first layer: NCHW 3-channel image, K ordered (ci, ky) x kx so that one MFMA consumes the 4 kx taps
 template <int CT>
 __global__ void __launch_bounds__(256) conv4x4s2_image_kernel(const float* __restrict__ x,
@@ -228,6 +458,19 @@ extern "C" int gcpx_conv4x4s2(const gcpx_conv_args* a, void* stream_) {
     const int nblk = (ngroups + per_blk - 1) / per_blk;
     // stats_partial has gcpx_conv4x4s2_grid() rows: all of them must be written
     if (!a->stats_partial && grid > nblk) grid = nblk;
+    if (a->Hin == a->Win && !getenv("GCPX_ENC_DIRECT")) {
+        int st = 1;
+        if (a->Cin == 16 && a->Cout == 32 && a->Hin == 32) st = launch_enc_lds<16, 32, 32, 1, 4, 1, false>(a, stream);
+        else if (a->Cin == 32 && a->Cout == 64 && a->Hin == 16) st = launch_enc_lds<32, 64, 16, 4, 4, 1, true>(a, stream);
+        else if (a->Cin == 64 && a->Cout == 128 && a->Hin == 8) st = launch_enc_lds<64, 128, 8, 8, 1, 4, true>(a, stream);
+        else if (a->Cin == 16 && a->Cout == 32 && a->Hin == 16) st = launch_enc_lds<16, 32, 16, 4, 4, 1, true>(a, stream);
+        else if (a->Cin == 32 && a->Cout == 64 && a->Hin == 8) st = launch_enc_lds<32, 64, 8, 16, 4, 1, true>(a, stream);
+        if (st <= 0) {
+            if (st < 0) return st;
+            GCPX_CHECK_LAUNCH();
+            return GCPX_OK;
+        }
+    }
     switch (CT) {
         case 2: hipLaunchKernelGGL((conv4x4s2_kernel<1, 8, 2, 2>), dim3(grid), dim3(256), 0, stream, *a, ngroups); break;
         // the deeper layers have few output pixels (20k at 4x4): keep every wavefront on all channels of 32 pixels so
