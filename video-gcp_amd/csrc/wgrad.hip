@@ -122,14 +122,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
             }
         }
     };
-    // software pipeline: the loads of the next row chunk are in flight while the current chunk's 32 MFMAs run
+    // software pipeline with two register sets in ping-pong: the loads of the next row chunk are in flight while the current
+    // chunk's 32 MFMAs run (no register copies — a copy lets the scheduler pull the wait for the next chunk in front of them)
     const int rstep = (RS ? 4 : 1) * 4 * UNR;
-    float4 av[UNR], bv[UNR], avn[UNR], bvn[UNR];
-    bool bok[UNR], bokn[UNR];
-    int r0 = r_begin + (RS ? wave * 4 * UNR : 0);
-    if (r0 < r_end) load(r0, av, bv, bok);
-    for (; r0 < r_end; r0 += rstep) {
-        if (r0 + rstep < r_end) load(r0 + rstep, avn, bvn, bokn);
+    auto mm = [&](const float4 (&av)[UNR], const float4 (&bv)[UNR], const bool (&bok)[UNR]) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             float4 b = bv[u];
@@ -145,8 +141,17 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
 #pragma unroll
                 for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = mfma16(aa[ta], bb[tb], acc[ta][tb]);
         }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) { av[u] = avn[u]; bv[u] = bvn[u]; bok[u] = bokn[u]; }
+    };
+    float4 avA[UNR], bvA[UNR], avB[UNR], bvB[UNR];
+    bool bokA[UNR], bokB[UNR];
+    int r0 = r_begin + (RS ? wave * 4 * UNR : 0);
+    if (r0 < r_end) load(r0, avA, bvA, bokA);
+    for (; r0 < r_end; r0 += 2 * rstep) {
+        const bool more = r0 + rstep < r_end;
+        if (more) load(r0 + rstep, avB, bvB, bokB);
+        mm(avA, bvA, bokA);
+        if (r0 + 2 * rstep < r_end) load(r0 + 2 * rstep, avA, bvA, bokA);
+        if (more) mm(avB, bvB, bokB);
     }
 
     if constexpr (RS) {
