@@ -14,15 +14,21 @@
 // the whole cell update for (row, unit u) is lane-local.  No LDS, no barriers: wavefronts are independent.
 #include "common.cuh"
 
+#include <cstdlib>
+
 namespace {
 
-template <int PR, int CR, bool LSTM>
+// KS (K split inside the workgroup): with few rows a wavefront streams its whole weight column alone and the launch is bound by
+// the bytes ONE wavefront keeps in flight (8 KiB per ~1.5 us HBM round trip: 13 us for K = 1024 whatever M).  There the four
+// wavefronts of a workgroup share one 16 x 16 output tile, take every 4th batch of k-groups and are summed through LDS in a
+// fixed order — 4x the bytes in flight, a quarter of the dependent round trips.
+template <int PR, int CR, bool LSTM, bool KS = false>
 __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int NT = a.N / 16;
-    const int nt0 = (blockIdx.y * 4 + wave) * CR;
-    if (nt0 >= NT) return;
+    const int nt0 = KS ? blockIdx.y * CR : (blockIdx.y * 4 + wave) * CR;
+    if (!KS && nt0 >= NT) return;
     const int rowblk = blockIdx.x;
     const int M = a.M, rpb = a.rpb;
 
@@ -68,7 +74,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
         const int nkg = src.width / 16;
         const bool xf = src.scale || src.act;
         constexpr int UK = (PR * CR >= 8) ? 2 : (PR * CR >= 4) ? 4 : 8;   // k-groups whose loads are issued together
-        for (int kg = 0; kg < nkg; kg += UK) {
+        for (int kg = KS ? wave * UK : 0; kg < nkg; kg += (KS ? 4 : 1) * UK) {
             float4 b[UK][PR], w[UK][CR];
 #pragma unroll
             for (int u = 0; u < UK; ++u) {
@@ -103,6 +109,28 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
             }
         }
         kg0 += nkg;
+    }
+
+    if constexpr (KS) {
+        __shared__ float4 part[3][CR * PR][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int ct = 0; ct < CR; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PR; ++pt)
+                    part[wave - 1][ct * PR + pt][lane] = make_float4(acc[ct][pt][0], acc[ct][pt][1], acc[ct][pt][2], acc[ct][pt][3]);
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w_ = 0; w_ < 3; ++w_)
+#pragma unroll
+            for (int ct = 0; ct < CR; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PR; ++pt) {
+                    const float4 v = part[w_][ct * PR + pt][lane];
+                    acc[ct][pt][0] += v.x; acc[ct][pt][1] += v.y; acc[ct][pt][2] += v.z; acc[ct][pt][3] += v.w;
+                }
     }
 
     // ---- epilogue ----
@@ -173,6 +201,7 @@ TileChoice choose_tile(int M, int N, int nb = 1) {
                 const int pr = prs[pi], cr = crs[ci];
                 if (pr * cr != area) continue;
                 if (N % (16 * cr)) continue;
+                if (pr > 1 && 16 * pr > ((M + 15) & ~15)) continue;      // row tiles that would be entirely masked
                 const long rbk = (M + 16 * pr - 1) / (16 * pr);
                 const long cbk = (N / 16 + 4 * cr - 1) / (4 * cr);
                 const long wg = rbk * cbk * nb;
@@ -224,6 +253,19 @@ extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
     }
     GCPX_CHECK_ARG(a->nbatch <= 1 || (a->epi != GCPX_EPI_LSTM && !a->stats_partial), "nbatch > 1 only for plain epilogues");
     const TileChoice t = choose_tile(a->M, a->N, a->nbatch > 1 ? a->nbatch : 1);
+    if (t.pr == 1 && t.cr == 1 && a->K >= 256 && !getenv("GCPX_GEMM_NOKS")) {
+        // few rows: split K over the wavefronts of a workgroup when that still leaves the launch small
+        const long nb = a->nbatch > 1 ? a->nbatch : 1;
+        const long rbk = (a->M + 15) / 16, nt = a->N / 16;
+        if (rbk * nt * nb <= 1024) {
+            if (a->epi == GCPX_EPI_LSTM)
+                hipLaunchKernelGGL((gemm_kernel<1, 1, true, true>), dim3(rbk, nt, nb), dim3(256), 0, stream, *a);
+            else
+                hipLaunchKernelGGL((gemm_kernel<1, 1, false, true>), dim3(rbk, nt, nb), dim3(256), 0, stream, *a);
+            GCPX_CHECK_LAUNCH();
+            return GCPX_OK;
+        }
+    }
     switch (t.pr * 10 + t.cr) {
         case 44: launch_t<4, 4>(a, stream); break;
         case 42: launch_t<4, 2>(a, stream); break;
