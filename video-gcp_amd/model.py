@@ -662,11 +662,13 @@ class GCPTreeModel:
         if adaptive:
             # learned pruning keeps up to N nodes (adaptive.py:62-77): the kept-position table is N wide
             kept_idx = self._buf("kept_idx", (B, N), torch.int32)
-        else:
-            # ---- integer bookkeeping (frame_binding.py:42-65, evaluation_matching.py:192-206) ----
-            plan.add("balanced_binding", lib.gcpx_balanced_binding, tin["end_ind"].data_ptr(), B, L, T, node_t.data_ptr(),
-                     leave.data_ptr(), f2n.data_ptr(), etrow.data_ptr(), seq_len.data_ptr(), node2row.data_ptr())
-            plan.add("compact_index", lib.gcpx_compact_index, leave.data_ptr(), B, N, T, kept_idx.data_ptr())
+        def plan_bookkeeping():
+            # ---- integer bookkeeping (frame_binding.py:42-65, evaluation_matching.py:192-206): first needed by the tree's
+            # posterior gather, so it rides on a side lane next to an encoder pass instead of in front of the trajectory encoder
+            if not adaptive:
+                plan.add("balanced_binding", lib.gcpx_balanced_binding, tin["end_ind"].data_ptr(), B, L, T, node_t.data_ptr(),
+                         leave.data_ptr(), f2n.data_ptr(), etrow.data_ptr(), seq_len.data_ptr(), node2row.data_ptr())
+                plan.add("compact_index", lib.gcpx_compact_index, leave.data_ptr(), B, N, T, kept_idx.data_ptr())
 
         # ---- run_encoder (base_gcp.py:184-213) ----
         enc_traj = inf_enc = None
@@ -675,6 +677,7 @@ class GCPTreeModel:
         plan.lane = 1
         skips = self._plan_encoder(plan, "I0", tin["I_0"].data_ptr(), B, _addr(E), PS * nz, 0, 1)
         plan.lane = 2
+        plan_bookkeeping()
         self._plan_encoder(plan, "Ig", tin["I_g"].data_ptr(), B, _addr(E, 2 ** L * nz), PS * nz, 0, 1)
         plan.lane = 0
         if has_traj:
