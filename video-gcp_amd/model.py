@@ -813,8 +813,12 @@ class GCPTreeModel:
                           ob=(Wd - 1) * hp.n_actions, orow=hp.n_actions)
                 outs["actions_padded"] = act
 
-        plan.fork([1])
-        plan.lane = 1
+        # The latent-space heads are ~60 us of small launches.  Beside the decoder blocks (persistent grids, two workgroups per
+        # CU) they cost more than that in interference (pyramid-2: 317 us beside them, 200 us alone), so they run in front.
+        heads_lane = 0
+        if heads_lane:
+            plan.fork([1])
+        plan.lane = heads_lane
         if adaptive:
             # learned pruning (adaptive.py:62-77): distance predictor on consecutive depth-first latents
             dist = self._buf("distances", (B, N - 1))
@@ -863,7 +867,8 @@ class GCPTreeModel:
                             head_out, upsample=0, head_mode=mode, images=images)
         a.raw_row_map = row_map.data_ptr() if row_map is not None else None
         plan.keep.append(a)
-        plan.join([1])           # the latent-space heads overlapped the decoder blocks; the head runs alone
+        if heads_lane:
+            plan.join([1])       # the latent-space heads overlapped the decoder blocks; the head runs alone
         plan.add("dec.head", lib.gcpx_conv3x3, C.byref(a))
         outs["images_df"], outs["distr_df_kernel_order"] = images, distr
 
