@@ -985,29 +985,34 @@ class GCPTreeModel:
         opt = tuple(k for k in ("pad_mask", "traj_seq_states", "w0") if with_loss and k in inputs)
         # inputs are copied into persistent buffers (one D2D copy; 63 MB for traj_seq at c2 = ~25 us) so that the
         # captured graph — which bakes in device pointers — stays valid whatever tensors the caller passes
+        # The copies are enqueued on the MODEL's stream (ordered behind the caller's stream by one event), so the launch that
+        # follows needs no second cross-stream hand-over before its first kernel.
+        caller = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(caller)
         tin = {}
-        for k in ("I_0", "I_g", "end_ind") + (("traj_seq",) if has_traj else ()) + (("z",) if has_z else ()) + opt:
-            t = inputs[k]
-            want = torch.int64 if k == "end_ind" else torch.float32
-            buf = self._buf("in." + k, tuple(t.shape), want)
-            buf.copy_(t, non_blocking=True)
-            tin[k] = buf
-        if not has_z:
-            # the draws of Gaussian.sample() live in a persistent buffer as well
-            eps = self._buf("eps", (B, self._n_latents(), hp.nz_vae))
-            if noise is None:
-                eps.normal_()
-            else:
-                eps.copy_(noise)
-            tin["eps"] = eps
+        with torch.cuda.stream(self._stream):
+            for k in ("I_0", "I_g", "end_ind") + (("traj_seq",) if has_traj else ()) + (("z",) if has_z else ()) + opt:
+                t = inputs[k]
+                want = torch.int64 if k == "end_ind" else torch.float32
+                buf = self._buf("in." + k, tuple(t.shape), want)
+                buf.copy_(t, non_blocking=True)
+                t.record_stream(self._stream)
+                tin[k] = buf
+            if not has_z:
+                # the draws of Gaussian.sample() live in a persistent buffer as well
+                eps = self._buf("eps", (B, self._n_latents(), hp.nz_vae))
+                if noise is None:
+                    eps.normal_()
+                else:
+                    eps.copy_(noise)
+                    noise.record_stream(self._stream)
+                tin["eps"] = eps
         key = (B, has_traj, has_z, self._sample_prior, phase, self.training, self.materialize_distr, with_loss)
         if key not in self._plans:
             plan = self._build_plan(key, tin)
             plan.keep.append(tin)
             self._plans[key] = (None, plan)
         plan = self._plans[key][1]
-        caller = torch.cuda.current_stream(self.device)
-        self._stream.wait_stream(caller)
         stream = self._stream.cuda_stream
         if self._timed_op is not None:
             self._run_timed(plan, stream)
