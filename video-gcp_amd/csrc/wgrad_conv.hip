@@ -68,41 +68,49 @@ __global__ void __launch_bounds__(NW * 64) wgrad_conv3x3_kernel(const float* __r
     const int nslot = ndy + nu;
     float4 pre[MAXS];
 
+    // staging slots are the same for every tile: global offsets relative to the tile origin, LDS offsets and (for the haloed U
+    // region) the position inside the region are computed once, not per tile (the divisions by N / 4 = 28 etc. dominated the VALU
+    // count of the kernel: 2.3 - 13 VALU instructions per MFMA in the PMC counters)
+    int goff[MAXS], loff[MAXS];
+    short sry[MAXS], srx[MAXS];                              // < 0: dY slot; else region row / column of a U slot
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        const int idx = tid + s * NTH;
+        goff[s] = 0; loff[s] = -1; sry[s] = -1; srx[s] = -1;
+        if (idx < ndy) {
+            const int p = idx / N4, c4 = idx % N4;
+            goff[s] = ((p / TW) * W + (p % TW)) * ldy + c4 * 4;
+            loff[s] = p * NP + c4 * 4;
+        } else if (idx < nslot) {
+            const int k = idx - ndy;
+            const int r = k / C4, c4 = k % C4;
+            sry[s] = (short)(r / RW); srx[s] = (short)(r % RW);
+            goff[s] = ((r / RW - 1) * W + (r % RW - 1)) * Cin + c4 * 4;
+            loff[s] = PX * NP + r * CP + c4 * 4;
+        }
+    }
     auto issue = [&](int tile) {
         const int tx = tile % ntx;
         const int t2 = tile / ntx;
         const int f = t2 / nty, y0 = (t2 % nty) * TH, x0 = tx * TW;
+        const float* dyb = dy + (((size_t)f * H + y0) * W + x0) * ldy;
+        const float* ub = u + (((size_t)f * H + y0) * W + x0) * Cin + ci0;
 #pragma unroll
         for (int s = 0; s < MAXS; ++s) {
-            const int idx = tid + s * NTH;
             pre[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < ndy) {
-                const int p = idx / N4, c4 = idx % N4;
-                const int py = p / TW, px = p % TW;
-                pre[s] = *reinterpret_cast<const float4*>(dy + (((size_t)f * H + y0 + py) * W + x0 + px) * ldy + c4 * 4);
-            } else if (idx < nslot) {
-                const int k = idx - ndy;
-                const int r = k / C4, c4 = k % C4;
-                const int ry = r / RW, rx = r % RW;
-                const int y = y0 - 1 + ry, x = x0 - 1 + rx;
-                if (y >= 0 && y < H && x >= 0 && x < W)
-                    pre[s] = *reinterpret_cast<const float4*>(u + (((size_t)f * H + y) * W + x) * Cin + ci0 + c4 * 4);
+            if (loff[s] < 0) continue;
+            if (sry[s] < 0) {
+                pre[s] = *reinterpret_cast<const float4*>(dyb + goff[s]);
+            } else {
+                const int y = y0 - 1 + sry[s], x = x0 - 1 + srx[s];
+                if (y >= 0 && y < H && x >= 0 && x < W) pre[s] = *reinterpret_cast<const float4*>(ub + goff[s]);
             }
         }
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int s = 0; s < MAXS; ++s) {
-            const int idx = tid + s * NTH;
-            if (idx < ndy) {
-                const int p = idx / N4, c4 = idx % N4;
-                *reinterpret_cast<float4*>(sdy + p * NP + c4 * 4) = pre[s];
-            } else if (idx < nslot) {
-                const int k = idx - ndy;
-                const int r = k / C4, c4 = k % C4;
-                *reinterpret_cast<float4*>(su + r * CP + c4 * 4) = pre[s];
-            }
-        }
+        for (int s = 0; s < MAXS; ++s)
+            if (loff[s] >= 0) *reinterpret_cast<float4*>(sdy + loff[s]) = pre[s];
     };
 
     int tile = blockIdx.x;
@@ -113,16 +121,18 @@ __global__ void __launch_bounds__(NW * 64) wgrad_conv3x3_kernel(const float* __r
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
         __builtin_amdgcn_s_setprio(1);
-        for (int p0 = 0; p0 < PX; p0 += 4) {
+        // operands of the next 4-pixel step are read while the current step's MFMAs run (two register sets, no copies)
+        auto rd = [&](const int p0, float (&a)[NT], float (&b)[GPW]) {
             const int p = p0 + kk;
             const int py = p / TW, px = p % TW;
             const float* ap = sdy + p * NP + ij;
             const float* bp = su + (py * RW + px) * CP;
-            float a[NT], b[GPW];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) a[nt] = ap[nt * 16];
 #pragma unroll
             for (int g = 0; g < GPW; ++g) b[g] = bp[boff[g]];
+        };
+        auto mm = [&](const float (&a)[NT], const float (&b)[GPW]) {
 #pragma unroll
             for (int g = 0; g < GPW; ++g) {
                 if (gok[g]) {
@@ -130,6 +140,14 @@ __global__ void __launch_bounds__(NW * 64) wgrad_conv3x3_kernel(const float* __r
                     for (int nt = 0; nt < NT; ++nt) acc[g][nt] = mfma16(a[nt], b[g], acc[g][nt]);
                 }
             }
+        };
+        float aA[NT], bA[GPW], aB[NT], bB[GPW];
+        rd(0, aA, bA);
+        for (int p0 = 0; p0 < PX; p0 += 8) {               // PX % 8 == 0 (TH * TW = 64 or H * W >= 64)
+            rd(p0 + 4, aB, bB);
+            mm(aA, bA);
+            if (p0 + 8 < PX) rd(p0 + 8, aA, bA);
+            mm(aB, bB);
         }
         __builtin_amdgcn_s_setprio(0);
     }
@@ -158,7 +176,7 @@ int launch_wc2(const float* dy, const float* u, float* partial, int F, int H, in
     const int PX = TH * TW;
     const int nslot = PX * (Cfg::N / 4) + (TH + 2) * (TW + 2) * (Cfg::CC / 4);
     constexpr int MAXS = (NT == 7) ? 13 : 8;
-    if (nslot > MAXS * NW * 64 || PX % 4 || W % TW || H % TH) {
+    if (nslot > MAXS * NW * 64 || PX % 8 || W % TW || H % TH) {
         gcpx_set_error("gcpx_wgrad_conv3x3: unsupported tile (H=%d W=%d N=%d)", H, W, Cfg::N);
         return GCPX_ERR_UNSUPPORTED;
     }
