@@ -1209,20 +1209,23 @@ class TreeView:
         hp = model._hp
         L = hp.hierarchy_levels
         self.depth = L
-        idx = torch.empty(2 ** L - 1, dtype=torch.long)
-        for l in range(L):
-            for j in range(2 ** l):
-                idx[2 ** l - 1 + j] = (2 * j + 1) * 2 ** (L - 1 - l) - 1
-        self._bf2df = idx.to(model.device)
+        self._bf2df = TreeView.bf2df_index(L, model.device)
+
+    _BF2DF = {}
 
     @staticmethod
     def bf2df_index(L, device):
-        """depth-first position of every breadth-first node index"""
-        idx = torch.empty(2 ** L - 1, dtype=torch.long)
-        for l in range(L):
-            for j in range(2 ** l):
-                idx[2 ** l - 1 + j] = (2 * j + 1) * 2 ** (L - 1 - l) - 1
-        return idx.to(device)
+        """depth-first position of every breadth-first node index.  Cached per (L, device): building it per forward meant a
+        pageable host-to-device copy behind the forward on the caller's stream, i.e. a host sync in every model call."""
+        key = (L, str(device))
+        t = TreeView._BF2DF.get(key)
+        if t is None:
+            idx = torch.empty(2 ** L - 1, dtype=torch.long)
+            for l in range(L):
+                for j in range(2 ** l):
+                    idx[2 ** l - 1 + j] = (2 * j + 1) * 2 ** (L - 1 - l) - 1
+            t = TreeView._BF2DF[key] = idx.to(device)
+        return t
 
     def _df(self, name):
         o, hp = self._o, self._m._hp
