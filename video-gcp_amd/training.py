@@ -55,6 +55,9 @@ class GCPTrainStep:
         # maps nodes of the critical chain onto the same hardware queue as multi-millisecond weight-gradient kernels and
         # serialises them (measured: 32.0 ms / step as a graph, 28.0 ms eager, c2).
         self.backward_graph = False
+        # posterior / prior / merge chains of a level on three lanes: measured SLOWER (30.0 vs 28.2 ms / step) — the side lanes are
+        # busy with the previous level's weight gradients, so the forked chains queue behind them.  Kept for experiments.
+        self.parallel_level_chains = False
         self.n_side = int(__import__("os").environ.get("GCPX_NSIDE", N_LANES - 1))   # side lanes of the backward plan
         self.side_priority = 0                # middle priority; lowest (> 0) starves the side lanes: 40.9 ms / step
         self._lanes = None
