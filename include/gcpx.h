@@ -452,9 +452,10 @@ int gcpx_im2col_image(const float* x, float* col, int32_t F, int32_t H, int32_t 
 /* ---- loss gradients ---- */
 /* d NLL / d params of the discretised logistic mixture (same layouts as gcpx_dlm_nll); row gradient scaled by
    row_weight[row] * scale; rows with weight 0 are zero-filled.  colsum (optional): [rows][pitch] per-row sums over the
-   pixels of dparams (the output head's bias gradient, summed over rows by gcpx_colsum) */
+   pixels of dparams (the output head's bias gradient, summed over rows by gcpx_colsum).  nll_out (optional): [rows] the same
+   values gcpx_dlm_nll writes — the training step evaluates loss and gradient in ONE pass over the 2.3 GB of parameters */
 int gcpx_dlm_nll_bwd(const float* params, const float* target, const float* row_weight, float scale, float* dparams, float* colsum,
-                     int32_t rows, int32_t npix, int32_t pitch, int32_t n_mix, void* stream);
+                     float* nll_out, int32_t rows, int32_t npix, int32_t pitch, int32_t n_mix, void* stream);
 /* d total / d logits of the length CE, existence BCE and state L2 heads (same arguments as gcpx_loss_combine);
    dlen [B][ceil16(T)] (pad columns zero), dexist [B*N][16] (column 0), dstate [B*T][16] (columns < state_dim); NULL outputs are skipped */
 int gcpx_loss_heads_bwd(const gcpx_loss_args* a, float* dlen, float* dexist, float* dstate, void* stream);

@@ -444,10 +444,12 @@ template <int NMIX, int PITCH>
 __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restrict__ params, const float* __restrict__ target,
                                                           const float* __restrict__ row_weight, const float scale,
                                                           float* __restrict__ dparams, float* __restrict__ colsum,
-                                                          const int npix) {
+                                                          float* __restrict__ nll_out, const int npix) {
     __shared__ float4 stage4[4 * 16 * PITCH / 4];
     __shared__ float csum[4][2][64];
+    __shared__ float nred[4];
     float cs0 = 0.f, cs1 = 0.f;                    // column sums of this row's gradients: columns lane, lane + 64
+    float nacc = 0.f;                              // the row's negative log-likelihood (training: forward and backward in one pass)
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
@@ -462,6 +464,7 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
         }
         if (colsum)
             for (int i = tid; i < PITCH; i += 256) colsum[(size_t)row * PITCH + i] = 0.f;
+        if (nll_out && tid == 0) nll_out[row] = 0.f;
         return;
     }
     const float* prow = params + (size_t)row * npix * PITCH;
@@ -535,6 +538,7 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
         se += __shfl_xor(se, 16);
         se += __shfl_xor(se, 32);
         const float inv_se = 1.f / se;
+        if (q == 0) nacc -= mx + logf(se);
         __builtin_amdgcn_wave_barrier();           // every lane has read the logits of its pixel
         nk = 0;
         for (int k = q; k < NMIX; k += 4, ++nk) {
@@ -574,6 +578,12 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
             const int h = i >> 6, l = i & 63;
             colsum[(size_t)row * PITCH + i] = (csum[0][h][l] + csum[1][h][l]) + (csum[2][h][l] + csum[3][h][l]);
         }
+    }
+    if (nll_out) {                                  // same reduction order as dlm_nll_kernel (loss.hip)
+        nacc = row16_sum(nacc);
+        if (lane == 0) nred[wave] = nacc;
+        __syncthreads();
+        if (tid == 0) nll_out[row] = (nred[0] + nred[1]) + (nred[2] + nred[3]);
     }
 }
 
@@ -838,11 +848,12 @@ extern "C" int gcpx_im2col_image(const float* x, float* col, int32_t F, int32_t 
 }
 
 extern "C" int gcpx_dlm_nll_bwd(const float* params, const float* target, const float* row_weight, float scale, float* dparams,
-                                float* colsum, int32_t rows, int32_t npix, int32_t pitch, int32_t n_mix, void* stream_) {
+                                float* colsum, float* nll_out, int32_t rows, int32_t npix, int32_t pitch, int32_t n_mix, void* stream_) {
     STREAM();
     GCPX_CHECK_ARG(params && target && dparams && rows > 0, "bad arguments");
     GCPX_CHECK_ARG(n_mix == 10 && pitch == 112 && npix % 64 == 0, "supports 10 mixtures, pitch 112, npix % 64 == 0");
-    hipLaunchKernelGGL((dlm_nll_bwd_kernel<10, 112>), dim3(rows), dim3(256), 0, stream, params, target, row_weight, scale, dparams, colsum, npix);
+    hipLaunchKernelGGL((dlm_nll_bwd_kernel<10, 112>), dim3(rows), dim3(256), 0, stream, params, target, row_weight, scale, dparams, colsum,
+                       nll_out, npix);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -925,8 +925,19 @@ class GCPTreeModel:
                     matched_distr = self._buf("matched_distr", (B, T, S, S, self._head_pitch))
                     plan.add("gather.matched_distr", lib.gcpx_gather_rows, distr.data_ptr(), f2n.data_ptr(),
                              matched_distr.data_ptr(), B, T, N, 0, S * S * self._head_pitch)
-                plan.add("loss.dlm_nll", lib.gcpx_dlm_nll, matched_distr.data_ptr(), tin["traj_seq"].data_ptr(),
-                         tin["pad_mask"].data_ptr(), nll_bt.data_ptr(), B * T, S * S, self._head_pitch, hp.n_mixtures)
+                if self.save_for_backward:
+                    # training step: loss and its gradient w.r.t. the matched parameters in one pass (the backward plan reuses
+                    # dMD); d total / d nll_bt = w_rec * pad_mask / (B * prod(traj_seq.shape[1:])) (base_gcp.py:299-301)
+                    dMD = self._buf("bw.dMD", (B * T, S, S, self._head_pitch))
+                    div = float(T * hp.input_nc * S * S)
+                    plan.add("loss.dlm_nll+bwd", lib.gcpx_dlm_nll_bwd, matched_distr.data_ptr(), tin["traj_seq"].data_ptr(),
+                             tin["pad_mask"].data_ptr(), C.c_float(hp.dense_img_rec_weight / (B * div)), dMD.data_ptr(),
+                             self._buf("bw.dMD.colsum", (B * T, self._head_pitch)).data_ptr(), nll_bt.data_ptr(), B * T, S * S,
+                             self._head_pitch, hp.n_mixtures)
+                    plan.rec["nll_bwd_fused"] = True
+                else:
+                    plan.add("loss.dlm_nll", lib.gcpx_dlm_nll, matched_distr.data_ptr(), tin["traj_seq"].data_ptr(),
+                             tin["pad_mask"].data_ptr(), nll_bt.data_ptr(), B * T, S * S, self._head_pitch, hp.n_mixtures)
             else:
                 plan.add("loss.gauss_nll", lib.gcpx_gauss_nll, outs["soft_matched_estimates"].data_ptr(),
                          tin["traj_seq"].data_ptr(), self.sd["decoder.log_sigma"].data_ptr(), nll_bt.data_ptr(), B * T,

@@ -142,7 +142,7 @@ SYMBOLS = [
     ("gcpx_conv_stage", C.c_int, [C.POINTER(ConvArgs), vp]),
     ("gcpx_col2im4x4s2", C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     ("gcpx_im2col_image", C.c_int, [vp, vp, i32, i32, i32, vp]),
-    ("gcpx_dlm_nll_bwd", C.c_int, [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, i32, vp]),
+    ("gcpx_dlm_nll_bwd", C.c_int, [vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, vp]),
     ("gcpx_loss_heads_bwd", C.c_int, [C.POINTER(LossArgs), vp, vp, vp, vp]),
     ("gcpx_repack", C.c_int, [vp, vp, vp, vp, i64, vp]),
     ("gcpx_radam_step", C.c_int, [vp, vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),

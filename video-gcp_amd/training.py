@@ -368,10 +368,11 @@ class GCPTrainStep:
                      buf("bw.dMD.colsum", (B * N, pitch)).data_ptr(), B * N, S * S, pitch, hp.n_mixtures)
         else:
             dMD = buf("bw.dMD", (B * T, S, S, pitch))
-            md = o["matched_distr_kernel_order"]
-            plan.add("bw.dlm_nll", lib.gcpx_dlm_nll_bwd, md.data_ptr(), tin["traj_seq"].data_ptr(), tin["pad_mask"].data_ptr(),
-                     C.c_float(hp.dense_img_rec_weight / (B * div)), dMD.data_ptr(), buf("bw.dMD.colsum", (B * T, pitch)).data_ptr(),
-                     B * T, S * S, pitch, hp.n_mixtures)
+            if not rec.get("nll_bwd_fused"):        # otherwise the forward plan already produced dMD together with the loss
+                md = o["matched_distr_kernel_order"]
+                plan.add("bw.dlm_nll", lib.gcpx_dlm_nll_bwd, md.data_ptr(), tin["traj_seq"].data_ptr(), tin["pad_mask"].data_ptr(),
+                         C.c_float(hp.dense_img_rec_weight / (B * div)), dMD.data_ptr(), buf("bw.dMD.colsum", (B * T, pitch)).data_ptr(),
+                         None, B * T, S * S, pitch, hp.n_mixtures)
         plan.add("bw.kl", lib.gcpx_kl_bwd, _addr(QZ, 2 * nv), _addr(PZ, 2 * nv), _addr(dQZ, 2 * nv), _addr(dPZ, 2 * nv), B, N, nv,
                  PS * 2 * nv, 2 * nv, C.c_float(hp.free_nats), C.c_float(hp.kl_weight / (B * div)))
         ldl = _c16(T)
