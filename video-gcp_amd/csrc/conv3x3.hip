@@ -35,7 +35,7 @@ struct ConvCfg {
     static constexpr int LH = TH / 2 + 2, LW = TW / 2 + 2;  // low-res patch feeding the upsample
     // padded channel pitch in LDS.  (A pitch of 40 floats makes the B-operand ds_read_b128 conflict-free — 36 is 2-way —
     // but measured no gain: these kernels are VALU+MFMA issue bound, not LDS bound.)
-    static constexpr int CCP = CC + 4;
+    static constexpr int CCP = (CC == 16) ? 24 : CC + 4;   // 16-channel chunks: pitch 24 (conflict-free b128 operand reads, as in the head kernel)
     static constexpr int C4 = CC / 4;
     static constexpr int HI_FLOATS = TF * RH * RW * CCP;
     static constexpr int RAW_FLOATS = UP ? TF * LH * LW * CC : 0;
@@ -450,6 +450,8 @@ struct HeadCfg {
     static constexpr int NS = (RH * RW * 4 + 63) / 64;                   // float4 slots per lane
 };
 
+__device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
@@ -708,6 +710,212 @@ int launch_head(const gcpx_conv_args* a, hipStream_t stream) {
     if (grid * 8 > nitems) grid = (nitems + 7) / 8;
     const int ipw = (nitems + grid * 8 - 1) / (grid * 8);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, stream, *a, ipw, nitems);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// Plain 3x3 conv at full resolution with several 16-channel input chunks (the data gradients of the output head,
+// 112 -> 16, and of the 16-channel decoder blocks, 16 -> 32): the wave-autonomous scheme of the head kernel with a
+// chunk loop inside the item.  All chunks' weights stay in LDS; a wavefront stages one 6 x 18 x 16ch region per chunk
+// (the next chunk's / next item's global loads are in flight during the current chunk's MFMAs) and keeps the CT x 4
+// accumulator tiles in registers across chunks.  Frames whose src_row_map entry is negative are zero-filled
+// without touching the source (nodes that are not matched to a ground-truth frame carry no loss gradient).
+// -----------------------------------------------------------------------------------------------------------
+template <int CT>
+struct WaveCfg {
+    static constexpr int RW = 18, RH = 6, CCP = 24;
+    static constexpr int REGION_FLOATS = RH * RW * CCP;
+    static constexpr int NS = (RH * RW * 4 + 63) / 64;
+    // + one region row: the tap-ahead operand fetch of the last tap reads one row past the last wave's region
+    static int lds_bytes(int nchunk) { return nchunk * 9 * CT * 64 * 16 + 8 * REGION_FLOATS * 4 + RW * CCP * 4; }
+};
+
+template <int CT>
+__global__ void __launch_bounds__(512, 2) conv3x3_wave_kernel(const gcpx_conv_args a, const int nitems) {
+    using Cfg = WaveCfg<CT>;
+    constexpr int RW = Cfg::RW, RH = Cfg::RH, CCP = Cfg::CCP, NS = Cfg::NS;
+    extern __shared__ float4 smem4[];
+    const int nchunk = a.Cin / 16;
+    const int wfloat4 = nchunk * 9 * CT * 64;
+    float4* wl = smem4;                                                   // [nchunk][9][CT][64] float4
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* reg = reinterpret_cast<float*>(smem4 + wfloat4) + wave * Cfg::REGION_FLOATS;
+    const int j = lane & 15, q = lane >> 4;
+    const int H = a.Hout, W = a.Wout;
+    const int ncb = W / 16, nrp = H / 4;
+    const gcpx_conv_src sr = a.src[0];
+    const int Cs = sr.C;                                                  // channel pitch of the source
+
+    for (int i = tid; i < wfloat4; i += 512) wl[i] = reinterpret_cast<const float4*>(a.wpk)[i];
+    __syncthreads();
+
+    const float* bbase = reg + j * CCP + q * 4;           // B operand of (region row r, tap column dx): + (r * RW + dx) * CCP
+
+    // items are dealt round-robin over all wavefronts of the grid: at any moment the whole chip works on neighbouring items of
+    // the same few frames, so frames that are skipped (negative src_row_map) cost every wavefront the same
+    // consecutive workgroup ids go to different XCDs (separate L2s): renumber so that each XCD owns a contiguous run of items per
+    // round — whole frames — and the halo rows shared by vertically adjacent items are L2 hits instead of second HBM reads
+    const int stride = gridDim.x * 8;
+    const int lb = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
+    int item = lb * 8 + wave;
+
+    float4 pre[NS];
+    unsigned pre_ok = 0;
+    auto origin = [&](int it, int& f, int& y0, int& x0) {
+        const int cb = it % ncb;
+        const int t = it / ncb;
+        y0 = (t % nrp) * 4; f = t / nrp; x0 = cb * 16;
+    };
+    auto frame_of = [&](int it) { return it / (ncb * nrp); };
+    int s_ry[NS], s_rx[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int t = (lane + 64 * k) >> 2;
+        s_rx[k] = t % RW;
+        s_ry[k] = t / RW;
+    }
+    auto issue_loads = [&](int it, int chunk, int srow) {
+        int f, y0, x0;
+        origin(it, f, y0, x0);
+        pre_ok = 0;
+        if (srow < 0) return;                                             // zero-filled item: nothing to stage
+        const float* base = sr.ptr + (size_t)srow * H * W * Cs + chunk * 16;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int idx = lane + 64 * k;
+            const int sy = y0 - 1 + s_ry[k], sx = x0 - 1 + s_rx[k];
+            if (idx < RH * RW * 4 && sy >= 0 && sy < H && sx >= 0 && sx < W) {
+                pre[k] = *reinterpret_cast<const float4*>(base + (unsigned)((__umul24(sy, W) + sx) * Cs + (idx & 3) * 4));
+                pre_ok |= 1u << k;
+            }
+        }
+    };
+    // the source row of the NEXT item is fetched one item ahead (a dependent load in front of every prefetch would
+    // serialise two memory latencies)
+    int srow = 0, srow_next_v = 0;
+    if (item < nitems) {
+        srow = a.src_row_map ? __builtin_amdgcn_readfirstlane(a.src_row_map[frame_of(item)]) : frame_of(item);
+        issue_loads(item, 0, srow);
+    }
+
+    for (; item < nitems; item += stride) {
+        int f, y0, x0;
+        origin(item, f, y0, x0);
+        const bool has_next = item + stride < nitems;
+        if (has_next) srow_next_v = a.src_row_map ? a.src_row_map[frame_of(item + stride)] : frame_of(item + stride);
+        if (srow < 0) {
+            srow = __builtin_amdgcn_readfirstlane(srow_next_v);
+            if (has_next) issue_loads(item + stride, 0, srow);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                float* op = a.out + (((size_t)f * H + (y0 + pt)) * W + (x0 + j)) * a.out_pitch;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    *reinterpret_cast<float4*>(op + ct * 16 + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            continue;
+        }
+        f32x4 acc[CT][4];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int idx = lane + 64 * k;
+                if (idx < RH * RW * 4) {
+                    float4 v = pre[k];
+                    if (pre_ok & (1u << k)) v = affine_act4(v, sr.scale, sr.shift, chunk * 16 + (idx & 3) * 4, sr.act);
+                    *reinterpret_cast<float4*>(reg + (idx >> 2) * CCP + (idx & 3) * 4) = v;
+                }
+            }
+            if (chunk + 1 < nchunk) issue_loads(item, chunk + 1, srow);
+            else {
+                srow = __builtin_amdgcn_readfirstlane(srow_next_v);
+                if (has_next) issue_loads(item + stride, 0, srow);
+            }
+
+            // every operand of the chunk is requested up front: 9 x CT weight fragments and the 6 x 3 distinct activation
+            // fragments (tap (dy, dx) of pixel row pt reads region row pt + dy, so the 9 x 4 (tap, row) pairs share 18 loads).
+            // LDS returns in order and the MFMAs below consume the rows in the order they were requested, so only the first
+            // few loads are exposed; the sched_barrier keeps the compiler from sinking the loads back next to their uses.
+            const float4* wc = wl + chunk * 9 * CT * 64 + lane;
+            float4 w[9][CT], bv[6][3];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) w[dx][ct] = wc[(dx * CT + ct) * 64];
+                bv[0][dx] = *reinterpret_cast<const float4*>(bbase + dx * CCP);
+            }
+#pragma unroll
+            for (int r = 1; r < 6; ++r) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    if (r < 3) {
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) w[r * 3 + dx][ct] = wc[((r * 3 + dx) * CT + ct) * 64];
+                    }
+                    bv[r][dx] = *reinterpret_cast<const float4*>(bbase + (r * RW + dx) * CCP);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        // the (dy, pt = r - dy) pairs of one region row are independent accumulator chains: interleaved
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int pt = r - dy;
+                            if (pt < 0 || pt > 3) continue;
+#pragma unroll
+                            for (int ct = 0; ct < CT; ++ct)
+                                acc[ct][pt] = mfma16(f4get(w[dy * 3 + dx][ct], kk), f4get(bv[r][dx], kk), acc[ct][pt]);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            float* op = a.out + (((size_t)f * H + (y0 + pt)) * W + (x0 + j)) * a.out_pitch;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const float4 bs = *reinterpret_cast<const float4*>(a.bias + ct * 16 + q * 4);
+                const f32x4 v = acc[ct][pt];
+                *reinterpret_cast<float4*>(op + ct * 16 + q * 4) = make_float4(v[0] + bs.x, v[1] + bs.y, v[2] + bs.z, v[3] + bs.w);
+            }
+        }
+    }
+}
+
+template <int CT>
+int launch_wave(const gcpx_conv_args* a, hipStream_t stream) {
+    using Cfg = WaveCfg<CT>;
+    auto kern = conv3x3_wave_kernel<CT>;
+    const int lds = Cfg::lds_bytes(a->Cin / 16);
+    static int attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            gcpx_set_error("conv3x3 wave: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
+        attr_lds = lds;
+    }
+    const int nitems = a->F * (a->Hout / 4) * (a->Wout / 16);
+    int grid = gcpx_conv_grid() / 2;                     // one 512-thread workgroup per CU
+    if (grid * 8 > nitems) grid = (nitems + 7) / 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, nitems);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }
@@ -1005,6 +1213,12 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
         }
         // data gradients of the decoder blocks (3x3 conv with the transposed, flipped weights): workgroup-tiled kernel
         GCPX_CHECK_ARG(a->head_mode == GCPX_HEAD_RAW && !a->stats_partial, "plain 3x3 conv stores raw output, no statistics");
+        static const bool tiled_only = getenv("GCPX_DGRAD_TILED") != nullptr;
+        if (!tiled_only && W % 16 == 0 && a->Hout % 4 == 0 && a->Cout == 16 * CT && a->out_pitch % 4 == 0 && CT == 1 &&
+            (CT == 1 ? WaveCfg<1>::lds_bytes(a->Cin / 16) : WaveCfg<2>::lds_bytes(a->Cin / 16)) <= 152 * 1024 && (a->Cin / 16) * CT >= 2) {
+            if (query_only) return gcpx_conv_grid() / 2;
+            return CT == 1 ? launch_wave<1>(a, stream) : launch_wave<2>(a, stream);
+        }
         const int tile = W >= 32 ? 0 : (W == 16 ? 1 : (W == 8 ? 2 : -1));
 #define GCPX_PLAIN(CC_, CT_)                                                            \
         do {                                                                            \
