@@ -25,7 +25,12 @@ struct WCfg {
     static constexpr int CP = (CC % 32 == 16) ? CC : CC + 16;
 };
 
-template <int NT, int CIT, int NW, int TW>
+// BAL (output head: NT = 7 n-tiles, 9 taps, NW = 4): the 63 (tap, n-tile) accumulator tiles are dealt 16 / 16 / 16 / 15 over the four
+// wavefronts instead of 3 taps x 7 tiles over three.  The three-wave version needed 240 registers (two wavefronts per SIMD), so a CU held
+// two workgroups = 6 wavefronts = 2 / 2 / 1 / 1 per SIMD and the 768-workgroup grid ran as 1.5 rounds; 2 x 4 balanced wavefronts per CU fill
+// every SIMD's MFMA pipe in one round.
+//   wavefront w < 3: taps 3w .. 3w+2 x n-tiles 0 .. 4, plus (tap 3w, n-tile 5);   wavefront 3: n-tile 6 x 9 taps + n-tile 5 x taps {1,2,4,5,7,8}
+template <int NT, int CIT, int NW, int TW, bool BAL = false>
 __global__ void __launch_bounds__(NW * 64) wgrad_conv3x3_kernel(const float* __restrict__ dy, const float* __restrict__ u,
                                                                 float* __restrict__ partial, const int F, const int H,
                                                                 const int W, const int Cin, const int ldy, const int TH) {
@@ -44,11 +49,13 @@ __global__ void __launch_bounds__(NW * 64) wgrad_conv3x3_kernel(const float* __r
     const int ntx = W / TW, nty = H / TH;
     const int ntiles = F * nty * ntx;
 
-    f32x4 acc[GPW][NT];
+    static_assert(!BAL || (NT == 7 && CIT == 1 && NW == 4), "balanced unit split is written for the 112-column output head");
+    constexpr int NACC_G = BAL ? 1 : GPW, NACC_N = BAL ? 16 : NT;
+    f32x4 acc[NACC_G][NACC_N];
 #pragma unroll
-    for (int g = 0; g < GPW; ++g)
+    for (int g = 0; g < NACC_G; ++g)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[g][nt] = f32x4{0, 0, 0, 0};
+        for (int nt = 0; nt < NACC_N; ++nt) acc[g][nt] = f32x4{0, 0, 0, 0};
 
     // per-group LDS offsets of the B operand (tap shift + channel tile), in floats
     int boff[GPW];
@@ -63,7 +70,7 @@ __global__ void __launch_bounds__(NW * 64) wgrad_conv3x3_kernel(const float* __r
 
     // staging slots: dY tile = PX * N/4 float4, U region = RH*RW * CC/4 float4
     constexpr int N4 = N / 4, C4 = CC / 4;
-    constexpr int MAXS = (NT == 7) ? 13 : 8;                  // float4 slots per thread kept in flight
+    constexpr int MAXS = (NT == 7) ? (BAL ? 10 : 13) : 8;     // float4 slots per thread kept in flight
     const int ndy = PX * N4, nu = RH * RW * C4;
     const int nslot = ndy + nu;
     float4 pre[MAXS];
@@ -121,6 +128,67 @@ __global__ void __launch_bounds__(NW * 64) wgrad_conv3x3_kernel(const float* __r
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (BAL) {
+            auto tapoff = [&](int tap) { return ((tap / 3) * RW + (tap % 3)) * CP + ij; };
+            auto opnd = [&](const int p0, const float*& ap, const float*& bp) {
+                const int p = p0 + kk;
+                ap = sdy + p * NP + ij;
+                bp = su + ((p / TW) * RW + (p % TW)) * CP;
+            };
+            if (wave < 3) {
+                const int bo0 = tapoff(3 * wave), bo1 = tapoff(3 * wave + 1), bo2 = tapoff(3 * wave + 2);
+                auto rd = [&](const int p0, float (&a)[6], float (&b)[3]) {
+                    const float *ap, *bp;
+                    opnd(p0, ap, bp);
+#pragma unroll
+                    for (int nt = 0; nt < 6; ++nt) a[nt] = ap[nt * 16];
+                    b[0] = bp[bo0]; b[1] = bp[bo1]; b[2] = bp[bo2];
+                };
+                auto mm = [&](const float (&a)[6], const float (&b)[3]) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < 5; ++nt) acc[0][t * 5 + nt] = mfma16(a[nt], b[t], acc[0][t * 5 + nt]);
+                    acc[0][15] = mfma16(a[5], b[0], acc[0][15]);
+                };
+                float aA[6], bA[3], aB[6], bB[3];
+                rd(0, aA, bA);
+                for (int p0 = 0; p0 < PX; p0 += 8) {
+                    rd(p0 + 4, aB, bB);
+                    mm(aA, bA);
+                    if (p0 + 8 < PX) rd(p0 + 8, aA, bA);
+                    mm(aB, bB);
+                }
+            } else {
+                auto rd = [&](const int p0, float (&a)[2], float (&b)[9]) {
+                    const float *ap, *bp;
+                    opnd(p0, ap, bp);
+                    a[0] = ap[5 * 16]; a[1] = ap[6 * 16];
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) b[tap] = bp[((tap / 3) * RW + (tap % 3)) * CP + ij];
+                };
+                auto mm = [&](const float (&a)[2], const float (&b)[9]) {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        acc[0][tap] = mfma16(a[1], b[tap], acc[0][tap]);
+                        if (tap % 3 != 0) {
+                            const int k5 = 9 + (tap / 3) * 2 + (tap % 3) - 1;
+                            acc[0][k5] = mfma16(a[0], b[tap], acc[0][k5]);
+                        }
+                    }
+                };
+                float aA[2], bA[9], aB[2], bB[9];
+                rd(0, aA, bA);
+                for (int p0 = 0; p0 < PX; p0 += 8) {
+                    rd(p0 + 4, aB, bB);
+                    mm(aA, bA);
+                    if (p0 + 8 < PX) rd(p0 + 8, aA, bA);
+                    mm(aB, bB);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            continue;
+        }
         // operands of the next 4-pixel step are read while the current step's MFMAs run (two register sets, no copies)
         auto rd = [&](const int p0, float (&a)[NT], float (&b)[GPW]) {
             const int p = p0 + kk;
@@ -155,6 +223,27 @@ __global__ void __launch_bounds__(NW * 64) wgrad_conv3x3_kernel(const float* __r
     // partial [blockIdx.x][n][K = 9*Cin]: lane holds n = nt*16 + 4*kk + reg, k = tap*Cin + ci0 + cit*16 + ij
     const int K = 9 * Cin;
     float* out = partial + (size_t)blockIdx.x * N * K;
+    if constexpr (BAL) {
+        auto store = [&](const f32x4& v, int nt, int tap) {
+            const int k = tap * Cin + ci0 + ij;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(nt * 16 + 4 * kk + r) * K + k] = v[r];
+        };
+        if (wave < 3) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) store(acc[0][t * 5 + nt], nt, 3 * wave + t);
+            store(acc[0][15], 5, 3 * wave);
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                store(acc[0][tap], 6, tap);
+                if (tap % 3 != 0) store(acc[0][9 + (tap / 3) * 2 + (tap % 3) - 1], 5, tap);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < GPW; ++g) {
         const int gi = wave + g * NW;
@@ -168,20 +257,20 @@ __global__ void __launch_bounds__(NW * 64) wgrad_conv3x3_kernel(const float* __r
     }
 }
 
-template <int NT, int CIT, int NW, int TW>
+template <int NT, int CIT, int NW, int TW, bool BAL = false>
 int launch_wc2(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream) {
     using Cfg = WCfg<NT, CIT, NW>;
     int TH = 64 / TW;
     if (TH > H) TH = H;
     const int PX = TH * TW;
     const int nslot = PX * (Cfg::N / 4) + (TH + 2) * (TW + 2) * (Cfg::CC / 4);
-    constexpr int MAXS = (NT == 7) ? 13 : 8;
+    constexpr int MAXS = (NT == 7) ? (BAL ? 10 : 13) : 8;
     if (nslot > MAXS * NW * 64 || PX % 8 || W % TW || H % TH) {
         gcpx_set_error("gcpx_wgrad_conv3x3: unsupported tile (H=%d W=%d N=%d)", H, W, Cfg::N);
         return GCPX_ERR_UNSUPPORTED;
     }
     const size_t lds = ((size_t)PX * Cfg::NP + (size_t)(TH + 2) * (TW + 2) * Cfg::CP) * 4;
-    auto kern = wgrad_conv3x3_kernel<NT, CIT, NW, TW>;
+    auto kern = wgrad_conv3x3_kernel<NT, CIT, NW, TW, BAL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -191,11 +280,11 @@ int launch_wc2(const float* dy, const float* u, float* partial, int F, int H, in
     return GCPX_OK;
 }
 
-template <int NT, int CIT, int NW>
+template <int NT, int CIT, int NW, bool BAL = false>
 int launch_wc(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream) {
-    if (W >= 32 && W % 32 == 0) return launch_wc2<NT, CIT, NW, 32>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
-    if (W == 16) return launch_wc2<NT, CIT, NW, 16>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
-    if (W == 8) return launch_wc2<NT, CIT, NW, 8>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    if (W >= 32 && W % 32 == 0) return launch_wc2<NT, CIT, NW, 32, BAL>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    if (W == 16) return launch_wc2<NT, CIT, NW, 16, BAL>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    if (W == 8) return launch_wc2<NT, CIT, NW, 8, BAL>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
     gcpx_set_error("gcpx_wgrad_conv3x3: unsupported width %d", W);
     return GCPX_ERR_UNSUPPORTED;
 }
@@ -211,7 +300,7 @@ extern "C" int gcpx_wgrad_conv3x3(const float* dy, int32_t ldy, const float* u, 
     const int NT = (Cout + 15) / 16;
     GCPX_CHECK_ARG(ldy >= NT * 16, "dy rows must hold Cout rounded up to 16 columns");
     int st = GCPX_ERR_UNSUPPORTED;
-    if (NT == 7 && Cin == 16) st = launch_wc<7, 1, 3>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    if (NT == 7 && Cin == 16) st = launch_wc<7, 1, 4, true>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
     else if (NT == 1 && Cin % 32 == 0) st = launch_wc<1, 2, 4>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
     else if (NT == 1) st = launch_wc<1, 1, 3>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
     else if (NT == 2 && Cin % 32 == 0) st = launch_wc<2, 2, 4>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
