@@ -224,8 +224,8 @@ class GCPTrainStep:
         N16 = _c16(Cout)
         ych = Cin // 32 if (Cin % 32 == 0 and N16 != 112) else Cin // 16
         ntiles = F * max(1, (Hh * Ww) // 64)
-        # workgroups per CU that are resident at once (registers): 2 x 4 wavefronts for the 112-column head, 3 otherwise
-        per_cu = 2 if N16 == 112 else 3
+        # workgroups per CU that are resident at once (registers): 2 x 4 wavefronts for the 112-column head and the 64-column block (about 200 registers), 3 otherwise
+        per_cu = 2 if N16 in (112, 64) else 3
         grid = max(1, min((lib.gcpx_conv_grid() // 2) * per_cu // ych, ntiles))
         part = m._buf(f"bw.part:{tag}", (grid, N16, 9 * Cin))
         self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad_conv3x3, dy, ldy, u, F, Hh, Ww, Cin, Cout, part.data_ptr(), grid)
