@@ -335,6 +335,13 @@ typedef struct gcpx_wgrad_args {
 } gcpx_wgrad_args;
 
 int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream);
+/* Grouped launch of up to 64 independent direct-mode problems that use the same kernel variant (the small per-level weight gradients of
+   tree_module.py:67-114 / tree_lstm.py:43-49): gcpx_wgrad_classify gives the variant and workgroup count of one problem (host query);
+   tab: DEVICE copy of the descriptors, block_start: DEVICE [nprob] first workgroup of each problem, total_blocks = their sum.
+   The problems must write disjoint outputs. */
+int gcpx_wgrad_classify(const gcpx_wgrad_args* a, int32_t* variant, int32_t* nblocks);
+int gcpx_wgrad_group(const gcpx_wgrad_args* tab, const int32_t* block_start, int32_t nprob, int32_t total_blocks, int32_t variant,
+                     void* stream);
 int gcpx_wgrad_reduce(const float* partial, int32_t nsplit, int32_t N, int32_t K, float* dst, int32_t map_mode, int32_t Cin,
                       int32_t ntap, int32_t Cout, const int32_t* n_map, int64_t ldw, int32_t k_off, int32_t accumulate,
                       void* stream);
@@ -489,6 +496,7 @@ int gcpx_stream_wait_event(void* stream, void* ev);
 
 /* event timing on the caller's stream (bench.py measures the dominant kernel with these) */
 int gcpx_event_create(void** ev);
+int gcpx_event_create_sync(void** ev);   /* ordering only: no timing, device-scope release (lane fork / join) */
 int gcpx_event_record(void* ev, void* stream);
 int gcpx_event_elapsed_ms(void* start, void* stop, float* ms);
 int gcpx_event_destroy(void* ev);

@@ -404,6 +404,16 @@ extern "C" int gcpx_event_create(void** ev) {
     return GCPX_OK;
 }
 
+// ordering-only event (fork / join of the launch lanes): no timestamps, device-scope release — the default event flushes to
+// system scope at every record, which stalls the recording stream between two small kernels
+extern "C" int gcpx_event_create_sync(void** ev) {
+    GCPX_CHECK_ARG(ev != nullptr, "ev is NULL");
+    hipEvent_t e;
+    GCPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice));
+    *ev = e;
+    return GCPX_OK;
+}
+
 extern "C" int gcpx_event_record(void* ev, void* stream) {
     GCPX_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), reinterpret_cast<hipStream_t>(stream)));
     return GCPX_OK;

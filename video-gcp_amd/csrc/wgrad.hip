@@ -21,17 +21,19 @@ __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 // RS (row split inside the workgroup): small dW (few 64 x 64 tiles) with many rows would leave the chip idle and every
 // wavefront in a long latency-bound loop; there the 4 wavefronts of a workgroup share ONE tile, take every 4th row chunk
 // and are combined through LDS in a fixed order (deterministic), instead of owning 4 different K tiles.
+// (bx, by, bz, gz) = the workgroup's position in the problem's own grid: blockIdx / gridDim.z of a single-problem launch, or derived
+// from the block table of a grouped launch (gcpx_wgrad_group)
 template <int TA, bool RS>
-__global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
+__device__ __forceinline__ void wgrad_body(const gcpx_wgrad_args& a, const int bx, const int by, const int bz, const int gz) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ij = lane & 15, kk = lane >> 4;
-    const int k0 = RS ? blockIdx.x * 64 : (blockIdx.x * 4 + wave) * 64;
+    const int k0 = RS ? bx * 64 : (bx * 4 + wave) * 64;
     if (!RS && k0 >= a.K) return;                // no barriers below (non-RS): whole wavefronts may leave
-    const int n0 = blockIdx.y * (TA == 4 ? 64 : 16);
-    // blockIdx.z = row split (partial mode) or batch index (nbatch > 1: independent problems with strided pointers)
-    const int zb = a.nbatch > 1 ? blockIdx.z : 0;
-    const int nsplit = a.nbatch > 1 ? 1 : gridDim.z;
-    const int zs = a.nbatch > 1 ? 0 : blockIdx.z;
+    const int n0 = by * (TA == 4 ? 64 : 16);
+    // bz = row split (partial mode) or batch index (nbatch > 1: independent problems with strided pointers)
+    const int zb = a.nbatch > 1 ? bz : 0;
+    const int nsplit = a.nbatch > 1 ? 1 : gz;
+    const int zs = a.nbatch > 1 ? 0 : bz;
     const int rows_per = (((a.R + nsplit - 1) / nsplit) + 3) & ~3;
     const int r_begin = zs * rows_per;
     const int r_end = min(a.R, r_begin + rows_per);
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
             if (n >= a.n_valid) continue;
             float4 v = make_float4(acc[ta][0][reg], acc[ta][1][reg], acc[ta][2][reg], acc[ta][3][reg]);
             float* op;
-            if (a.partial) op = a.out + ((size_t)blockIdx.z * a.n_valid + n) * a.K + kcol;
+            if (a.partial) op = a.out + ((size_t)bz * a.n_valid + n) * a.K + kcol;
             else op = a.out + (size_t)zb * a.z_out_off + (size_t)n * a.ldw + a.k_off + kcol;
             if (!a.partial && a.accumulate) {
                 const float4 o = *reinterpret_cast<const float4*>(op);
@@ -217,6 +219,34 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
             *reinterpret_cast<float4*>(op) = v;
         }
     }
+}
+
+template <int TA, bool RS>
+__global__ void __launch_bounds__(256) wgrad_kernel(const gcpx_wgrad_args a) {
+    wgrad_body<TA, RS>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
+}
+
+__host__ __device__ inline void wgrad_grid(const gcpx_wgrad_args& a, bool rs, int& gx, int& gy, int& gz) {
+    const int kch = (a.K + 63) / 64;
+    gx = rs ? kch : (kch + 3) / 4;
+    gy = a.N > 16 ? (a.N + 63) / 64 : 1;
+    gz = a.nbatch > 1 ? a.nbatch : a.nsplit;
+}
+
+// Grouped launch: the ~40 small weight-gradient GEMMs of one tree level (LSTM ih / hh, projections, embed slices, Predictor
+// layers) are independent problems of 1 - 64 workgroups each; launched one by one they cost 15 - 35 us apiece on a side lane
+// (launch + tail latency, not work).  One launch walks a device table of problem descriptors: block_start[p] is the first
+// workgroup of problem p.
+template <int TA, bool RS>
+__global__ void __launch_bounds__(256) wgrad_group_kernel(const gcpx_wgrad_args* __restrict__ tab, const int* __restrict__ block_start,
+                                                          const int nprob) {
+    int p = 0;
+    while (p + 1 < nprob && (int)blockIdx.x >= block_start[p + 1]) ++p;       // wave-uniform scan (nprob <= 64)
+    const gcpx_wgrad_args a = tab[p];
+    int gx, gy, gz;
+    wgrad_grid(a, RS, gx, gy, gz);
+    const int lb = blockIdx.x - block_start[p];
+    wgrad_body<TA, RS>(a, lb % gx, (lb / gx) % gy, lb / (gx * gy), gz);
 }
 
 // partial [nsplit][N][K] -> dst in the canonical parameter layout.  A workgroup owns 16 consecutive outputs; 16 thread
@@ -311,8 +341,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ d
 
 }  // namespace
 
-extern "C" int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+static int wgrad_check(const gcpx_wgrad_args* a) {
     GCPX_CHECK_ARG(a != nullptr, "null args");
     GCPX_CHECK_ARG(a->dy && a->x && a->out, "dy / x / out is NULL");
     GCPX_CHECK_ARG(a->R > 0 && a->N > 0 && a->K > 0 && a->K % 4 == 0, "bad R/N/K (K % 4)");
@@ -327,24 +356,61 @@ extern "C" int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream_) {
     if (a->mode == GCPX_WG_CONV3X3 || a->mode == GCPX_WG_CONV4X4S2)
         GCPX_CHECK_ARG(a->H > 1 && a->W > 1 && (a->H & (a->H - 1)) == 0 && (a->W & (a->W - 1)) == 0, "conv modes: H, W powers of two");
     GCPX_CHECK_ARG(!a->scale || a->mode != GCPX_WG_ROWS || (a->cmod > 0 && (a->cmod & (a->cmod - 1)) == 0), "cmod must be a power of two");
-    const int kch = (a->K + 63) / 64;
     const bool wide = a->N > 16;
     GCPX_CHECK_ARG(!wide || (a->N % 4 == 0 && a->ldy % 4 == 0), "N > 16 needs N % 4 == 0 and ldy % 4 == 0");
     GCPX_CHECK_ARG(a->partial || (a->ldw % 4 == 0 && a->k_off % 4 == 0), "direct output needs ldw, k_off % 4 == 0");
+    return GCPX_OK;
+}
+
+// kernel variant of a problem: bit 0 = wide (64-column A tiles), bit 1 = row split inside the workgroup
+static int wgrad_variant(const gcpx_wgrad_args* a) {
+    const int kch = (a->K + 63) / 64;
+    const bool wide = a->N > 16;
     const int nch = wide ? (a->N + 63) / 64 : 1;
     const int nz = a->nbatch > 1 ? a->nbatch : a->nsplit;
     // few tiles x many rows: share each tile between the 4 wavefronts of a workgroup (row split inside the workgroup)
     const long long rows_per = (a->R + a->nsplit - 1) / a->nsplit;
     const bool rs = (long long)((kch + 3) / 4) * nch * nz < 512 && rows_per >= 64;
-    if (rs) {
-        dim3 grid(kch, nch, nz);
-        if (wide) hipLaunchKernelGGL((wgrad_kernel<4, true>), grid, dim3(256), 0, stream, *a);
-        else hipLaunchKernelGGL((wgrad_kernel<1, true>), grid, dim3(256), 0, stream, *a);
-    } else {
-        dim3 grid((kch + 3) / 4, nch, nz);
-        if (wide) hipLaunchKernelGGL((wgrad_kernel<4, false>), grid, dim3(256), 0, stream, *a);
-        else hipLaunchKernelGGL((wgrad_kernel<1, false>), grid, dim3(256), 0, stream, *a);
-    }
+    return (wide ? 1 : 0) | (rs ? 2 : 0);
+}
+
+extern "C" int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int st = wgrad_check(a);
+    if (st != GCPX_OK) return st;
+    const int v = wgrad_variant(a);
+    int gx, gy, gz;
+    wgrad_grid(*a, (v & 2) != 0, gx, gy, gz);
+    const dim3 grid(gx, gy, gz);
+    if (v == 3) hipLaunchKernelGGL((wgrad_kernel<4, true>), grid, dim3(256), 0, stream, *a);
+    else if (v == 2) hipLaunchKernelGGL((wgrad_kernel<1, true>), grid, dim3(256), 0, stream, *a);
+    else if (v == 1) hipLaunchKernelGGL((wgrad_kernel<4, false>), grid, dim3(256), 0, stream, *a);
+    else hipLaunchKernelGGL((wgrad_kernel<1, false>), grid, dim3(256), 0, stream, *a);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_wgrad_classify(const gcpx_wgrad_args* a, int32_t* variant, int32_t* nblocks) {
+    const int st = wgrad_check(a);
+    if (st != GCPX_OK) return st;
+    GCPX_CHECK_ARG(variant && nblocks, "null output");
+    const int v = wgrad_variant(a);
+    int gx, gy, gz;
+    wgrad_grid(*a, (v & 2) != 0, gx, gy, gz);
+    *variant = v;
+    *nblocks = gx * gy * gz;
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_wgrad_group(const gcpx_wgrad_args* tab, const int32_t* block_start, int32_t nprob, int32_t total_blocks,
+                                int32_t variant, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(tab && block_start && nprob > 0 && nprob <= 64 && total_blocks > 0 && variant >= 0 && variant < 4, "bad arguments");
+    const dim3 grid(total_blocks);
+    if (variant == 3) hipLaunchKernelGGL((wgrad_group_kernel<4, true>), grid, dim3(256), 0, stream, tab, block_start, nprob);
+    else if (variant == 2) hipLaunchKernelGGL((wgrad_group_kernel<1, true>), grid, dim3(256), 0, stream, tab, block_start, nprob);
+    else if (variant == 1) hipLaunchKernelGGL((wgrad_group_kernel<4, false>), grid, dim3(256), 0, stream, tab, block_start, nprob);
+    else hipLaunchKernelGGL((wgrad_group_kernel<1, false>), grid, dim3(256), 0, stream, tab, block_start, nprob);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -52,7 +52,7 @@ class _Plan:
         evs = []
         for _ in range(n):
             e = C.c_void_p()
-            rt.check(self.lib.gcpx_event_create(C.byref(e)), "event_create")
+            rt.check(self.lib.gcpx_event_create_sync(C.byref(e)), "event_create")
             evs.append(e)
         return evs
 

@@ -121,6 +121,8 @@ SYMBOLS = [
     ("gcpx_seq_pairs", C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     ("gcpx_masked_row_sum", C.c_int, [vp, vp, vp, i32, i32, vp]),
     ("gcpx_wgrad", C.c_int, [C.POINTER(WgradArgs), vp]),
+    ("gcpx_wgrad_classify", C.c_int, [C.POINTER(WgradArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("gcpx_wgrad_group", C.c_int, [vp, vp, i32, i32, i32, vp]),
     ("gcpx_wgrad_conv3x3", C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     ("gcpx_wgrad_reduce", C.c_int, [vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, i64, i32, i32, vp]),
     ("gcpx_colsum", C.c_int, [vp, i64, i32, i32, i32, i64, i32, vp, vp, vp, i32, vp]),
@@ -167,6 +169,7 @@ SYMBOLS = [
     ("gcpx_stream_destroy", C.c_int, [vp]),
     ("gcpx_stream_wait_event", C.c_int, [vp, vp]),
     ("gcpx_event_create", C.c_int, [C.POINTER(vp)]),
+    ("gcpx_event_create_sync", C.c_int, [C.POINTER(vp)]),
     ("gcpx_event_record", C.c_int, [vp, vp]),
     ("gcpx_event_elapsed_ms", C.c_int, [vp, vp, C.POINTER(C.c_float)]),
     ("gcpx_event_destroy", C.c_int, [vp]),

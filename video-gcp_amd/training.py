@@ -16,6 +16,7 @@ Gradients land in ONE flat fp32 vector laid out like `model.theta` (so the data-
 call over one buffer) and the optimizer + the re-pack of the MFMA-ordered weights are one launch each.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -49,6 +50,7 @@ class GCPTrainStep:
         self.opt_state = torch.zeros(4, device=model.device)
         self.bk = model.build_arena(self._pack_backward)
         self._bplans = {}
+        self.group_wgrads = os.environ.get("GCPX_NO_WGROUP") is None   # one grouped launch per level and kernel variant
         self.side_lanes = bool(hp.untied_layers)   # tied levels accumulate into the same weights: keep them on one lane
         self.wgrad_waves = 8192               # wavefronts a split weight-gradient launch aims for (latency hiding)
         # The backward plan is replayed EAGERLY over real streams by default: as parallel branches of one hipGraph the runtime
@@ -167,6 +169,8 @@ class GCPTrainStep:
             return
         lanes = list(range(1, 1 + self.n_side))
         plan.fork(lanes)
+        if self.group_wgrads:
+            plan.deferred = self._group_wgrads(plan, plan.deferred)
         # ops of one tag (wgrad + its reduce) stay on one lane, in order
         lane_of = plan.rec.setdefault("_lane_of", {})
         for name, fn, args in plan.deferred:
@@ -177,6 +181,39 @@ class GCPTrainStep:
             plan.add(name, fn, *args)
         plan.lane = 0
         plan.deferred = []
+
+    def _group_wgrads(self, plan, deferred):
+        """The direct-mode gcpx_wgrad launches of one flush (the ~40 small weight gradients of a tree level) become ONE grouped
+        launch per kernel variant: descriptors and block table are uploaded once, when the plan is built."""
+        lib, m = self.m.lib, self.m
+        groups, rest = {}, []
+        for op in deferred:
+            name, fn, args = op
+            a = args[0]._obj if fn is lib.gcpx_wgrad else None
+            if a is None or a.partial:
+                rest.append(op)
+                continue
+            v, nb = C.c_int32(), C.c_int32()
+            rt.check(lib.gcpx_wgrad_classify(C.byref(a), C.byref(v), C.byref(nb)), name)
+            groups.setdefault(v.value, []).append((name, a, nb.value))
+        out = []
+        for v, items in sorted(groups.items()):
+            for c0 in range(0, len(items), 64):
+                chunk = items[c0:c0 + 64]
+                if len(chunk) == 1:
+                    out.append((chunk[0][0], lib.gcpx_wgrad, (C.byref(chunk[0][1]),)))
+                    continue
+                tab = (rt.WgradArgs * len(chunk))(*[it[1] for it in chunk])
+                raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(m.device)
+                starts, tot = [], 0
+                for it in chunk:
+                    starts.append(tot)
+                    tot += it[2]
+                bst = torch.tensor(starts, dtype=torch.int32, device=m.device)
+                plan.keep += [raw, bst]
+                gid = plan.rec["_ngroups"] = plan.rec.get("_ngroups", 0) + 1
+                out.append((f"bw.wgroup:g{gid}.v{v}x{len(chunk)}", lib.gcpx_wgrad_group, (raw.data_ptr(), bst.data_ptr(), len(chunk), tot, v)))
+        return out + rest
 
     def g(self, name, off=0):
         """device address of the gradient of parameter `name`"""
