@@ -339,7 +339,7 @@ int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream);
    tree_module.py:67-114 / tree_lstm.py:43-49): gcpx_wgrad_classify gives the variant and workgroup count of one problem (host query);
    tab: DEVICE copy of the descriptors, block_start: DEVICE [nprob] first workgroup of each problem, total_blocks = their sum.
    The problems must write disjoint outputs. */
-int gcpx_wgrad_classify(const gcpx_wgrad_args* a, int32_t* variant, int32_t* nblocks);
+int gcpx_wgrad_classify(const gcpx_wgrad_args* a, int32_t row_split, int32_t* variant, int32_t* nblocks);   /* row_split: -1 = this problem's own heuristic, 0 / 1 = force */
 int gcpx_wgrad_group(const gcpx_wgrad_args* tab, const int32_t* block_start, int32_t nprob, int32_t total_blocks, int32_t variant,
                      void* stream);
 int gcpx_wgrad_reduce(const float* partial, int32_t nsplit, int32_t N, int32_t K, float* dst, int32_t map_mode, int32_t Cin,

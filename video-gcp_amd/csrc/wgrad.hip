@@ -390,11 +390,13 @@ extern "C" int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream_) {
     return GCPX_OK;
 }
 
-extern "C" int gcpx_wgrad_classify(const gcpx_wgrad_args* a, int32_t* variant, int32_t* nblocks) {
+extern "C" int gcpx_wgrad_classify(const gcpx_wgrad_args* a, int32_t row_split, int32_t* variant, int32_t* nblocks) {
     const int st = wgrad_check(a);
     if (st != GCPX_OK) return st;
     GCPX_CHECK_ARG(variant && nblocks, "null output");
-    const int v = wgrad_variant(a);
+    int v = wgrad_variant(a);
+    if (row_split == 0) v &= 1;          // the caller fills the chip with the group: one wavefront per 64 x 64 tile
+    else if (row_split == 1) v |= 2;
     int gx, gy, gz;
     wgrad_grid(*a, (v & 2) != 0, gx, gy, gz);
     *variant = v;

@@ -50,6 +50,8 @@ class GCPTrainStep:
         self.opt_state = torch.zeros(4, device=model.device)
         self.bk = model.build_arena(self._pack_backward)
         self._bplans = {}
+        self.wgroup_min_blocks = int(os.environ.get("GCPX_WGROUP_MIN", "256"))
+        self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
         self.group_wgrads = os.environ.get("GCPX_NO_WGROUP") is None   # one grouped launch per level and kernel variant
         self.side_lanes = bool(hp.untied_layers)   # tied levels accumulate into the same weights: keep them on one lane
         self.wgrad_waves = 8192               # wavefronts a split weight-gradient launch aims for (latency hiding)
@@ -186,15 +188,24 @@ class GCPTrainStep:
         """The direct-mode gcpx_wgrad launches of one flush (the ~40 small weight gradients of a tree level) become ONE grouped
         launch per kernel variant: descriptors and block table are uploaded once, when the plan is built."""
         lib, m = self.m.lib, self.m
-        groups, rest = {}, []
+        groups, rest, cand = {}, [], []
+        v, nb = C.c_int32(), C.c_int32()
         for op in deferred:
             name, fn, args = op
             a = args[0]._obj if fn is lib.gcpx_wgrad else None
             if a is None or a.partial:
                 rest.append(op)
-                continue
-            v, nb = C.c_int32(), C.c_int32()
-            rt.check(lib.gcpx_wgrad_classify(C.byref(a), C.byref(v), C.byref(nb)), name)
+            else:
+                cand.append((name, a))
+        # the in-workgroup row split exists to fill the chip from ONE small problem; a group that already brings >= 1 workgroup
+        # per CU without it runs one wavefront per 64 x 64 tile instead (4x fewer, lighter workgroups)
+        total = 0
+        for name, a in cand:
+            rt.check(lib.gcpx_wgrad_classify(C.byref(a), 0, C.byref(v), C.byref(nb)), name)
+            total += nb.value
+        split = 0 if total >= self.wgroup_min_blocks else -1
+        for name, a in cand:
+            rt.check(lib.gcpx_wgrad_classify(C.byref(a), split, C.byref(v), C.byref(nb)), name)
             groups.setdefault(v.value, []).append((name, a, nb.value))
         out = []
         for v, items in sorted(groups.items()):
@@ -652,12 +663,15 @@ class GCPTrainStep:
             plan.add("bw.f2n_abs", lib.gcpx_index_offset, o["frame2node"].data_ptr(), f2n_abs.data_ptr(), B, T, N)
             a.src_row_map = f2n_abs.data_ptr()
         plan.keep.append(a)
-        plan.add("bw.stage:head", lib.gcpx_conv_stage, C.byref(a))
+        # the materialised conv input is only read by the weight gradient: both go to a side lane
+        self._side(plan, "bw.stage:dec.head", lib.gcpx_conv_stage, C.byref(a))
         self._wgrad_conv3(plan, "dec.head", dMD.data_ptr(), pitch, featA.data_ptr(), R, S, S, ngf, pitch,
                           self.g("decoder.gen_head.conv.weight"), n_map=perm32)
         # bias: per-frame column sums come out of the loss-gradient kernel
         self._colsum(plan, "dec.head", buf("bw.dMD.colsum", (R, pitch)).data_ptr(), pitch, R, pitch,
                      self.g("decoder.gen_head.conv.bias"), n_map=perm32)
+        if self.early_fork:
+            self._flush(plan)
         dA = buf("bw.dA.head", (F, S, S, ngf))
         a = m._conv_args([(dMD.data_ptr(), pitch, 1, None, None, rt.ACT_NONE)], F, S, S, S, S, ngf, ngf, self.bk["dec.head.wT"],
                          self._zeros, dA)
@@ -677,9 +691,11 @@ class GCPTrainStep:
             U = buf(f"bw.U.{name}", (F, res, res, cin))
             a = m._conv_args(blk["srcs"], F, res_in, res_in, res, res, cin, cin, self._zeros, self._zeros, U, upsample=1)
             plan.keep.append(a)
-            plan.add(f"bw.stage:{name}", lib.gcpx_conv_stage, C.byref(a))
+            self._side(plan, f"bw.stage:dec.{name}", lib.gcpx_conv_stage, C.byref(a))
             self._wgrad_conv3(plan, f"dec.{name}", dy.data_ptr(), cout, U.data_ptr(), F, res, res, cin, cout,
                               self.g(f"decoder.net.{name}.conv.weight"))
+            if self.early_fork:
+                self._flush(plan)
             dU = buf(f"bw.dU.{name}", (F, res, res, cin))
             for h in range((cin + 63) // 64):
                 ch = min(64, cin - 64 * h)
