@@ -378,6 +378,34 @@ int gcpx_lstm_bwd(const gcpx_lstm_bwd_args* a, void* stream);
 int gcpx_gn_lrelu_bwd(const float* u, const float* da, const float* gamma, const float* beta, float* du, float* partial,
                       int32_t M, int32_t C, int32_t groups, float eps, float slope, void* stream);
 int gcpx_gn_bwd_blocks(int32_t M);
+/* Fused data-gradient chain of one Predictor MLP (mirror of gcpx_mlp; backward of tree_module.py:77 / inference.py:27-35, which
+   the reference gets from autograd): dout [M][ldo] -> head^T -> (GroupNorm + LReLU backward -> mid_l^T) x n_mid -> LReLU
+   backward -> per input split dx_i = du0 @ W_in[:, split i].  `save` = the buffer gcpx_mlp_args.save filled in the forward.
+   Writes every du_l ([M][mid]; operands of the weight-gradient GEMMs), the per-workgroup GroupNorm parameter sums
+   gn_partial[l] [gcpx_mlp_bwd_blocks(M)][2][mid] (reduce with gcpx_reduce_partials) and the dx_i rows (b, j) at
+   out + b*ob + j*orow (b = r / rpb).  wT_*: gcpx_gemm packs of the transposed weights. */
+typedef struct gcpx_mlp_bwd_dx {
+    const float* wT;        /* pack of W_in[:, split]^T: [mid / 16][width / 16][64][4] */
+    float* out;
+    int64_t ob, orow;
+    int32_t width, _pad;
+} gcpx_mlp_bwd_dx;
+typedef struct gcpx_mlp_bwd_args {
+    const float* dout;
+    const float* save;
+    const float* wT_out;    /* [out_pad / 16][mid / 16][64][4] */
+    const float* wT_mid[4];
+    const float* gn_gamma[4];
+    const float* gn_beta[4];
+    float* du[5];           /* du[0]: input layer (after its LReLU backward); du[1 + l]: hidden layer l */
+    float* gn_partial[4];
+    gcpx_mlp_bwd_dx dx[4];
+    int64_t ldo;
+    int32_t M, rpb, mid, n_mid, out_pad, ndx;
+    float gn_eps, lrelu_slope;
+} gcpx_mlp_bwd_args;
+int gcpx_mlp_bwd(const gcpx_mlp_bwd_args* a, void* stream);
+int gcpx_mlp_bwd_blocks(int32_t M);
 /* dx[i] = dy[i] * (a[i] > 0 ? 1 : slope) */
 int gcpx_lrelu_bwd(const float* a, const float* dy, float* dx, int64_t n, float slope, void* stream);
 

@@ -58,6 +58,16 @@ class MlpArgs(C.Structure):
                 ("oblk", i64), ("eps", vp), ("eb", i64), ("erow", i64), ("z", vp), ("zb", i64), ("zrow", i64), ("save", vp)]
 
 
+class MlpBwdDx(C.Structure):
+    _fields_ = [("wT", vp), ("out", vp), ("ob", i64), ("orow", i64), ("width", i32), ("_pad", i32)]
+
+
+class MlpBwdArgs(C.Structure):
+    _fields_ = [("dout", vp), ("save", vp), ("wT_out", vp), ("wT_mid", vp * 4), ("gn_gamma", vp * 4), ("gn_beta", vp * 4),
+                ("du", vp * 5), ("gn_partial", vp * 4), ("dx", MlpBwdDx * 4), ("ldo", i64), ("M", i32), ("rpb", i32),
+                ("mid", i32), ("n_mid", i32), ("out_pad", i32), ("ndx", i32), ("gn_eps", C.c_float), ("lrelu_slope", C.c_float)]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [("dy", vp), ("x", vp), ("rowidx", vp), ("frame_map", vp), ("scale", vp), ("shiftv", vp), ("out", vp),
                 ("ldy", i64), ("sb", i64), ("sr", i64), ("ldw", i64), ("dy_sb", i64), ("R", i32), ("N", i32), ("n_valid", i32),
@@ -128,6 +138,8 @@ SYMBOLS = [
     ("gcpx_colsum", C.c_int, [vp, i64, i32, i32, i32, i64, i32, vp, vp, vp, i32, vp]),
     ("gcpx_reduce_partials", C.c_int, [vp, i32, i64, i32, vp, i32, vp]),
     ("gcpx_lstm_bwd", C.c_int, [C.POINTER(LstmBwdArgs), vp]),
+    ("gcpx_mlp_bwd", C.c_int, [C.POINTER(MlpBwdArgs), vp]),
+    ("gcpx_mlp_bwd_blocks", C.c_int, [i32]),
     ("gcpx_gn_lrelu_bwd", C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float, vp]),
     ("gcpx_gn_bwd_blocks", C.c_int, [i32]),
     ("gcpx_lrelu_bwd", C.c_int, [vp, vp, vp, i64, C.c_float, vp]),

@@ -52,6 +52,7 @@ class GCPTrainStep:
         self._bplans = {}
         self.wgroup_min_blocks = int(os.environ.get("GCPX_WGROUP_MIN", "256"))
         self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
+        self.fused_mlp_bwd = os.environ.get("GCPX_NO_FUSED_MLP_BWD") is None
         self.group_wgrads = os.environ.get("GCPX_NO_WGROUP") is None   # one grouped launch per level and kernel variant
         self.side_lanes = bool(hp.untied_layers)   # tied levels accumulate into the same weights: keep them on one lane
         self.wgrad_waves = 8192               # wavefronts a split weight-gradient launch aims for (latency hiding)
@@ -175,8 +176,10 @@ class GCPTrainStep:
             plan.deferred = self._group_wgrads(plan, plan.deferred)
         # ops of one tag (wgrad + its reduce) stay on one lane, in order
         lane_of = plan.rec.setdefault("_lane_of", {})
+        alias = plan.rec.get("_lane_alias", {})
         for name, fn, args in plan.deferred:
-            tag = name.split(":")[1] if ":" in name else name
+            tag = name.split(":", 1)[1] if ":" in name else name
+            tag = alias.get(tag, tag)
             if tag not in lane_of:
                 lane_of[tag] = lanes[len(lane_of) % len(lanes)]
             plan.lane = lane_of[tag]
@@ -193,7 +196,7 @@ class GCPTrainStep:
         for op in deferred:
             name, fn, args = op
             a = args[0]._obj if fn is lib.gcpx_wgrad else None
-            if a is None or a.partial:
+            if a is None:
                 rest.append(op)
             else:
                 cand.append((name, a))
@@ -223,7 +226,13 @@ class GCPTrainStep:
                 bst = torch.tensor(starts, dtype=torch.int32, device=m.device)
                 plan.keep += [raw, bst]
                 gid = plan.rec["_ngroups"] = plan.rec.get("_ngroups", 0) + 1
-                out.append((f"bw.wgroup:g{gid}.v{v}x{len(chunk)}", lib.gcpx_wgrad_group, (raw.data_ptr(), bst.data_ptr(), len(chunk), tot, v)))
+                gtag = f"g{gid}.v{v}x{len(chunk)}"
+                out.append((f"bw.wgroup:{gtag}", lib.gcpx_wgrad_group, (raw.data_ptr(), bst.data_ptr(), len(chunk), tot, v)))
+                # the reduction of a split problem's partials must follow the group on the same lane
+                alias = plan.rec.setdefault("_lane_alias", {})
+                for it in chunk:
+                    if it[1].partial:
+                        alias[it[0].split(":", 1)[1]] = gtag
         return out + rest
 
     def g(self, name, off=0):
@@ -346,6 +355,10 @@ class GCPTrainStep:
         # head
         self._wgrad(plan, f"{tag}.out", dout, ldo, M, out_pad, a_ptr[n_mid], mid, self.g(f"{prefix}.head.linear.weight"),
                     ldw=mid, n_valid=out_dim, sr=mid, sb=M * mid, rpb=M, dbias=self.g(f"{prefix}.head.linear.bias"))
+        if self.fused_mlp_bwd and mid in (128, 32) and n_mid <= 4 and len(dx_outs) <= 4 and out_pad <= 1024 and \
+                all(ob % 4 == 0 and orow % 4 == 0 for _, ob, orow in dx_outs):
+            self._mlp_bwd_fused(plan, tag, prefix, rec, T, dout, ldo, dx_outs, a_ptr)
+            return
         da = m._buf(f"bw.{tag}.da{n_mid}", (M, mid))
         self._dgemm(plan, f"{tag}.out", [self._dense(dout, ldo, out_pad, M)], M, mid, M, T["wT_out"], da.data_ptr(), 0, mid)
         for l in reversed(range(n_mid)):
@@ -376,6 +389,45 @@ class GCPTrainStep:
             wT = T[f"wT_in{i}"]
             width = wT.shape[1] * 16
             self._dgemm(plan, f"{tag}.in{i}", [self.m._rowsrc(du0.data_ptr(), rpb * mid, mid, mid)], M, width, rpb, wT, optr, ob, orow)
+
+    def _mlp_bwd_fused(self, plan, tag, prefix, rec, T, dout, ldo, dx_outs, a_ptr):
+        """The data-gradient chain of one Predictor as ONE launch (gcpx_mlp_bwd); weight gradients and the GroupNorm parameter
+        reductions stay on the side lanes (the head's weight gradient was queued by the caller)."""
+        m, lib, hp = self.m, self.m.lib, self.m._hp
+        W, srcs, M, rpb, save = rec["W"], rec["srcs"], rec["M"], rec["rpb"], rec["save"]
+        mid, n_mid, in_dim = W["mid"], W["n_mid"], W["in_dim"]
+        nb = lib.gcpx_mlp_bwd_blocks(M)
+        a = rt.MlpBwdArgs()
+        a.dout, a.save, a.wT_out, a.ldo = dout, save.data_ptr(), T["wT_out"].data_ptr(), ldo
+        a.M, a.rpb, a.mid, a.n_mid, a.out_pad, a.ndx = M, rpb, mid, n_mid, _c16(W["out_dim"]), len(dx_outs)
+        a.gn_eps, a.lrelu_slope = hp.gn_eps, hp.leaky_slope
+        du = [m._buf(f"bw.{tag}.du{l}", (M, mid)) for l in range(n_mid + 1)]
+        parts = [m._buf(f"bw.{tag}.gnpart{l}", (nb, 2, mid)) for l in range(n_mid)]
+        a.du[0] = du[0].data_ptr()
+        for l in range(n_mid):
+            pre = f"{prefix}.pyramid-{l}"
+            a.wT_mid[l] = T[f"wT_mid{l}"].data_ptr()
+            a.gn_gamma[l], a.gn_beta[l] = m.sd[f"{pre}.norm.weight"].data_ptr(), m.sd[f"{pre}.norm.bias"].data_ptr()
+            a.du[1 + l], a.gn_partial[l] = du[1 + l].data_ptr(), parts[l].data_ptr()
+        for i, (optr, ob, orow) in enumerate(dx_outs):
+            wT = T[f"wT_in{i}"]
+            a.dx[i].wT, a.dx[i].out, a.dx[i].ob, a.dx[i].orow, a.dx[i].width = wT.data_ptr(), optr, ob, orow, wT.shape[1] * 16
+        plan.keep.append(a)
+        plan.add(f"bw.mlp:{tag}", lib.gcpx_mlp_bwd, C.byref(a))
+        for l in reversed(range(n_mid)):
+            pre = f"{prefix}.pyramid-{l}"
+            self._side(plan, f"bw.gnred:{tag}.{l}", lib.gcpx_reduce_partials, parts[l].data_ptr(), nb, 2 * mid, mid, self.g(f"{pre}.norm.weight"), 1)
+            self._side(plan, f"bw.gnred2:{tag}.{l}", lib.gcpx_reduce_partials, parts[l].data_ptr() + 4 * mid, nb, 2 * mid, mid,
+                       self.g(f"{pre}.norm.bias"), 1)
+            self._wgrad(plan, f"{tag}.mid{l}", du[1 + l].data_ptr(), mid, M, mid, a_ptr[l], mid, self.g(f"{pre}.linear.weight"), ldw=mid,
+                        sr=mid, sb=M * mid, rpb=M, dbias=self.g(f"{pre}.linear.bias"))
+        koff = 0
+        for i, s in enumerate(srcs):
+            self._wgrad(plan, f"{tag}.in{i}", du[0].data_ptr(), mid, M, mid, s.ptr, s.width, self.g(f"{prefix}.input.linear.weight"),
+                        ldw=in_dim, k_off=koff, rpb=rpb, sb=s.sb, sr=s.sr, shift=s.shift,
+                        rowidx=_PtrHolder(s.rowidx) if s.rowidx else None,
+                        dbias=(self.g(f"{prefix}.input.linear.bias") if i == 0 else None))
+            koff += s.width
 
     # ------------------------------------------------------------------------------------------------
     # the backward plan
