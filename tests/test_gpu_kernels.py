@@ -352,3 +352,118 @@ def test_gemm_batched_projections(env):
     rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm batched")
     torch.cuda.synchronize()
     assert_close(out, want, atol=2e-5, rtol=1e-5, name="batched gemm")
+
+
+@pytest.mark.parametrize("mid,in_dims,out_dim,M,rpb", [(128, (256, 128), 512, 37, 37), (128, (256,), 512, 64, 8), (32, (128, 128), 80, 16, 16),
+                                                      (128, (128,), 1, 5, 5)])
+def test_mlp_bwd_fused(env, mid, in_dims, out_dim, M, rpb):
+    """gcpx_mlp (forward, with `save`) + gcpx_mlp_bwd against torch autograd over the same Predictor: every du_l, the GroupNorm
+    parameter sums and the input gradients (ragged last row block, rows addressed as (b, j))."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(mid + out_dim + M)
+    n_mid, K = 3, sum(in_dims)
+    xs = [torch.randn(M, d, requires_grad=True) for d in in_dims]
+    Ws = dict(w_in=torch.randn(mid, K) / K ** 0.5, b_in=torch.randn(mid) * 0.1,
+              w_mid=torch.randn(n_mid, mid, mid) / mid ** 0.5, b_mid=torch.randn(n_mid, mid) * 0.1,
+              g=(torch.rand(n_mid, mid) + 0.5).requires_grad_(), be=(torch.randn(n_mid, mid) * 0.1).requires_grad_(),
+              w_out=torch.randn(out_dim, mid) / mid ** 0.5, b_out=torch.randn(out_dim) * 0.1)
+    want = _predictor_ref(torch.cat(xs, 1), Ws, n_mid)
+    dout = torch.randn(M, out_dim)
+    grads = torch.autograd.grad(want, xs + [Ws["g"], Ws["be"]], dout)
+    out_pad = (out_dim + 15) // 16 * 16
+    d = {k: v.detach().to(dev) for k, v in dict(
+        w_in=pk.pack_gemm(Ws["w_in"]), b_in=Ws["b_in"], w_mid=torch.stack([pk.pack_gemm(Ws["w_mid"][i]) for i in range(n_mid)]),
+        b_mid=Ws["b_mid"], g=Ws["g"], be=Ws["be"], w_out=pk.pack_gemm(Ws["w_out"]), b_out=pk.pad_vec(Ws["b_out"], out_pad)).items()}
+    xd = [x.detach().to(dev) for x in xs]
+    out = torch.zeros(M, out_dim, device=dev)
+    save = torch.zeros(1 + 2 * n_mid, M, mid, device=dev)
+    a = rt.MlpArgs()
+    for i, x in enumerate(xd):
+        a.src[i] = _rowsrc(rt, x, 0, in_dims[i], in_dims[i])
+    a.nsrc, a.M, a.rpb, a.in_dim, a.mid, a.n_mid, a.out_dim = len(xd), M, M, K, mid, n_mid, out_dim
+    a.w_in, a.b_in, a.w_mid, a.b_mid = d["w_in"].data_ptr(), d["b_in"].data_ptr(), d["w_mid"].data_ptr(), d["b_mid"].data_ptr()
+    a.gn_gamma, a.gn_beta, a.w_out, a.b_out = d["g"].data_ptr(), d["be"].data_ptr(), d["w_out"].data_ptr(), d["b_out"].data_ptr()
+    a.gn_eps, a.lrelu_slope = 1e-5, 0.2
+    a.out, a.ob, a.orow, a.save = out.data_ptr(), 0, out_dim, save.data_ptr()
+    rt.check(lib.gcpx_mlp(C.byref(a), _stream()), "mlp")
+
+    w_out_pad = torch.cat([Ws["w_out"], torch.zeros(out_pad - out_dim, mid)], 0)
+    wT_out = pk.pack_gemm(w_out_pad.t().contiguous()).to(dev)
+    wT_mid = [pk.pack_gemm(Ws["w_mid"][l].t().contiguous()).to(dev) for l in range(n_mid)]
+    doutd = torch.zeros(M, out_pad, device=dev)
+    doutd[:, :out_dim] = dout.to(dev)
+    nb = lib.gcpx_mlp_bwd_blocks(M)
+    du = [torch.full((M, mid), float("nan"), device=dev) for _ in range(n_mid + 1)]
+    parts = [torch.full((nb, 2, mid), float("nan"), device=dev) for _ in range(n_mid)]
+    nbatch = M // rpb
+    b = rt.MlpBwdArgs()
+    b.dout, b.save, b.wT_out, b.ldo = doutd.data_ptr(), save.data_ptr(), wT_out.data_ptr(), out_pad
+    b.M, b.rpb, b.mid, b.n_mid, b.out_pad, b.ndx = M, rpb, mid, n_mid, out_pad, len(in_dims)
+    b.gn_eps, b.lrelu_slope = 1e-5, 0.2
+    b.du[0] = du[0].data_ptr()
+    for l in range(n_mid):
+        b.wT_mid[l], b.gn_gamma[l], b.gn_beta[l] = wT_mid[l].data_ptr(), d["g"][l].data_ptr(), d["be"][l].data_ptr()
+        b.du[1 + l], b.gn_partial[l] = du[1 + l].data_ptr(), parts[l].data_ptr()
+    dxs, wTs, c0 = [], [], 0
+    for i, w in enumerate(in_dims):
+        wTs.append(pk.pack_gemm(Ws["w_in"][:, c0:c0 + w].t().contiguous()).to(dev))
+        # rows (b, j) land in a padded [nbatch][rpb + 3][w + 16] buffer: exercises ob / orow
+        dxs.append(torch.full((nbatch, rpb + 3, w + 16), float("nan"), device=dev))
+        b.dx[i].wT, b.dx[i].out, b.dx[i].ob, b.dx[i].orow, b.dx[i].width = wTs[i].data_ptr(), dxs[i].data_ptr(), (rpb + 3) * (w + 16), w + 16, w
+        c0 += w
+    rt.check(lib.gcpx_mlp_bwd(C.byref(b), _stream()), "mlp_bwd")
+    torch.cuda.synchronize()
+    for i, w in enumerate(in_dims):
+        got = dxs[i][:, :rpb, :w].reshape(M, w)
+        assert_close(got, grads[i], atol=2e-4, rtol=1e-4, name=f"dx{i}")
+        assert torch.isnan(dxs[i][:, rpb:, :]).all() and torch.isnan(dxs[i][:, :, w:]).all(), "wrote outside the addressed rows"
+    for l in range(n_mid):
+        assert_close(parts[l][:, 0].sum(0), grads[len(in_dims)][l], atol=5e-4, rtol=1e-4, name=f"dgamma{l}")
+        assert_close(parts[l][:, 1].sum(0), grads[len(in_dims) + 1][l], atol=5e-4, rtol=1e-4, name=f"dbeta{l}")
+    assert not any(torch.isnan(t).any() for t in du)
+
+
+def test_wgrad_group_matches_single_launches(env):
+    """gcpx_wgrad_group over a table of direct and split problems == the same problems launched one by one (bit-exact: same kernel
+    body, same accumulation order)."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(7)
+    shapes = [(100, 128, 256, 1), (64, 512, 128, 1), (300, 64, 64, 2), (33, 16, 128, 1), (256, 128, 1024, 4)]    # R, N, K, nsplit
+    keep, probs = [], []
+    for (R, N, K, ns) in shapes:
+        dy, x = torch.randn(R, N, device=dev), torch.randn(R, K, device=dev)
+        outs = [torch.zeros(ns, N, K, device=dev) if ns > 1 else torch.zeros(N, K, device=dev) for _ in range(2)]
+        args = []
+        for o in outs:
+            a = rt.WgradArgs()
+            a.dy, a.x, a.ldy, a.R, a.N, a.n_valid, a.K, a.mode = dy.data_ptr(), x.data_ptr(), N, R, N, N, K, rt.WG_ROWS
+            a.sb, a.sr, a.rpb = R * K, K, R
+            a.out, a.ldw, a.accumulate, a.partial, a.nsplit = o.data_ptr(), K, (0 if ns > 1 else 1), (1 if ns > 1 else 0), ns
+            args.append(a)
+        keep += [dy, x, outs]
+        probs.append((args, outs, dy, x, ns))
+    for row_split in (0, -1):
+        by_variant = {}
+        v, nb = C.c_int32(), C.c_int32()
+        for args, outs, *_ in probs:
+            for o in outs:
+                o.zero_()
+            rt.check(lib.gcpx_wgrad(C.byref(args[0]), _stream()), "wgrad")          # note: its own heuristic variant
+            rt.check(lib.gcpx_wgrad_classify(C.byref(args[1]), row_split, C.byref(v), C.byref(nb)), "classify")
+            by_variant.setdefault(v.value, []).append((args[1], nb.value))
+        for var, items in by_variant.items():
+            tab = (rt.WgradArgs * len(items))(*[it[0] for it in items])
+            raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
+            starts, tot = [], 0
+            for it in items:
+                starts.append(tot)
+                tot += it[1]
+            bst = torch.tensor(starts, dtype=torch.int32, device=dev)
+            rt.check(lib.gcpx_wgrad_group(raw.data_ptr(), bst.data_ptr(), len(items), tot, var, _stream()), "wgrad_group")
+        torch.cuda.synchronize()
+        for args, outs, dy, x, ns in probs:
+            want = dy.t() @ x
+            got = outs[1].sum(0) if ns > 1 else outs[1]
+            assert_close(got, want, atol=2e-3, rtol=1e-4, name="grouped dW")
+            one = outs[0].sum(0) if ns > 1 else outs[0]
+            assert_close(got, one, atol=2e-4, rtol=1e-5, name="grouped vs single")
