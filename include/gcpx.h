@@ -85,6 +85,11 @@ typedef struct gcpx_conv_args {
                                to a ground-truth frame need their distribution parameters (frame_binding.py:91-92) */
     const int32_t* src_row_map; /* dev: [F] or NULL (non-upsampling convs and gcpx_conv_stage): frame f reads source frame
                                src_row_map[f]; a negative entry reads zeros (backward of the matched-frame gather) */
+    const int32_t* src_row_frames; /* dev: [n_src_rows] or NULL: the inverse of src_row_map (row r is read by frame src_row_frames[r]).
+                               Optional accelerator for the plain 3x3 conv: the kernel then walks the rows that exist instead of
+                               testing every frame, and zero-fills the frames whose src_row_map entry is negative up front */
+    int32_t n_src_rows;
+    int32_t _pad0;
 } gcpx_conv_args;
 
 /* decoder block: (bilinear x2 upsample +) 3x3 conv, pad 1.  gcpx_conv3x3_grid(a) = number of workgroups that launch
@@ -447,6 +452,9 @@ int gcpx_add_rows(float* dst, int64_t dst_sb, int64_t dst_sr, const float* src1,
                   int32_t width, void* stream);
 /* out[b][t] = idx[b][t] + b*stride (per-sequence node index -> absolute frame index) */
 int gcpx_index_offset(const int32_t* idx, int32_t* out, int32_t B, int32_t T, int32_t stride, void* stream);
+/* inv[r] = i for every i < n with fwd[i] = r >= 0 (fwd injective on its non-negative entries), -1 for rows nobody maps to:
+   the src_row_frames companion of a src_row_map (gcpx_conv_args) */
+int gcpx_index_inverse(const int32_t* fwd, int32_t n, int32_t* inv, int32_t n_inv, void* stream);
 
 /* ---- conv stacks ---- */
 /* gradient w.r.t. the raw (pre-norm) output of a layer from the gradient w.r.t. its activated output:

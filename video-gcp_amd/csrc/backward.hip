@@ -223,6 +223,19 @@ __global__ void __launch_bounds__(256) index_offset_kernel(const int* __restrict
     if (i < total) out[i] = idx[i] + (i / T) * stride;
 }
 
+__global__ void __launch_bounds__(256) index_fill_kernel(int* __restrict__ out, const int n, const int v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
+__global__ void __launch_bounds__(256) index_inverse_kernel(const int* __restrict__ fwd, const int n, int* __restrict__ inv, const int n_inv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int r = fwd[i];
+        if (r >= 0 && r < n_inv) inv[r] = i;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // conv stacks
 // ---------------------------------------------------------------------------------------------------
@@ -781,6 +794,15 @@ extern "C" int gcpx_index_offset(const int32_t* idx, int32_t* out, int32_t B, in
     STREAM();
     GCPX_CHECK_ARG(idx && out && B > 0 && T > 0, "bad arguments");
     hipLaunchKernelGGL(index_offset_kernel, dim3((B * T + 255) / 256), dim3(256), 0, stream, idx, out, T, stride, B * T);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_index_inverse(const int32_t* fwd, int32_t n, int32_t* inv, int32_t n_inv, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(fwd && inv && n > 0 && n_inv > 0, "bad arguments");
+    hipLaunchKernelGGL(index_fill_kernel, dim3((n_inv + 255) / 256), dim3(256), 0, stream, inv, n_inv, -1);
+    hipLaunchKernelGGL(index_inverse_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fwd, n, inv, n_inv);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

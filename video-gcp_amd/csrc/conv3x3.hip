@@ -731,7 +731,7 @@ struct WaveCfg {
     static int lds_bytes(int nchunk) { return nchunk * 9 * CT * 64 * 16 + 8 * REGION_FLOATS * 4 + RW * CCP * 4; }
 };
 
-template <int CT>
+template <int CT, int DEPTH>
 __global__ void __launch_bounds__(512, 2) conv3x3_wave_kernel(const gcpx_conv_args a, const int nitems) {
     using Cfg = WaveCfg<CT>;
     constexpr int RW = Cfg::RW, RH = Cfg::RH, CCP = Cfg::CCP, NS = Cfg::NS;
@@ -744,31 +744,32 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_kernel(const gcpx_conv_ar
     float* reg = reinterpret_cast<float*>(smem4 + wfloat4) + wave * Cfg::REGION_FLOATS;
     const int j = lane & 15, q = lane >> 4;
     const int H = a.Hout, W = a.Wout;
-    const int ncb = W / 16, nrp = H / 4;
+    const int ncb = W / 16, nrp = H / 4, ipf = ncb * nrp;
     const gcpx_conv_src sr = a.src[0];
     const int Cs = sr.C;                                                  // channel pitch of the source
 
     for (int i = tid; i < wfloat4; i += 512) wl[i] = reinterpret_cast<const float4*>(a.wpk)[i];
+    // frames without a source row get zeros; the main loop below only walks the rows that exist
+    if (a.src_row_frames) {
+        const int f4_per_frame = H * W * a.out_pitch / 4;
+        for (int f = blockIdx.x; f < a.F; f += gridDim.x) {
+            if (a.src_row_map[f] >= 0) continue;
+            float4* op = reinterpret_cast<float4*>(a.out + (size_t)f * H * W * a.out_pitch);
+            for (int i = tid; i < f4_per_frame; i += 512) op[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     __syncthreads();
 
     const float* bbase = reg + j * CCP + q * 4;           // B operand of (region row r, tap column dx): + (r * RW + dx) * CCP
 
-    // items are dealt round-robin over all wavefronts of the grid: at any moment the whole chip works on neighbouring items of
-    // the same few frames, so frames that are skipped (negative src_row_map) cost every wavefront the same
-    // consecutive workgroup ids go to different XCDs (separate L2s): renumber so that each XCD owns a contiguous run of items per
-    // round — whole frames — and the halo rows shared by vertically adjacent items are L2 hits instead of second HBM reads
+    // items are dealt round-robin over all wavefronts of the grid (consecutive workgroup ids sit on different XCDs: renumbered so
+    // that an XCD owns a contiguous run of items per round and the halo rows shared by vertically adjacent items are L2 hits)
     const int stride = gridDim.x * 8;
     const int lb = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
-    int item = lb * 8 + wave;
+    const int first = lb * 8 + wave;
+    const int nmine = first < nitems ? (nitems - first + stride - 1) / stride : 0;
+    const int nsteps = nmine * nchunk;
 
-    float4 pre[NS];
-    unsigned pre_ok = 0;
-    auto origin = [&](int it, int& f, int& y0, int& x0) {
-        const int cb = it % ncb;
-        const int t = it / ncb;
-        y0 = (t % nrp) * 4; f = t / nrp; x0 = cb * 16;
-    };
-    auto frame_of = [&](int it) { return it / (ncb * nrp); };
     int s_ry[NS], s_rx[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -776,132 +777,176 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_kernel(const gcpx_conv_ar
         s_rx[k] = t % RW;
         s_ry[k] = t / RW;
     }
-    auto issue_loads = [&](int it, int chunk, int srow) {
-        int f, y0, x0;
-        origin(it, f, y0, x0);
-        pre_ok = 0;
-        if (srow < 0) return;                                             // zero-filled item: nothing to stage
-        const float* base = sr.ptr + (size_t)srow * H * W * Cs + chunk * 16;
+    // item k of this wavefront -> (source row = index of the active frame, tile origin)
+    auto geom = [&](int k, int& srow, int& y0, int& x0) {
+        const int it = first + k * stride;
+        srow = it / ipf;
+        const int rem = it - srow * ipf;
+        y0 = (rem / ncb) * 4; x0 = (rem % ncb) * 16;
+    };
+
+    // ---- prefetch cursor: DEPTH (item, chunk) steps ahead of the compute cursor; per-item slot offsets computed once per item ----
+    int pk = 0, pchunk = 0;                               // step the next issue() will load
+    int poff[NS];                                         // float offset of the slot inside the source frame, < 0: outside the image
+    const float* pbase = sr.ptr;
+    // a source row that no frame reads (src_row_frames[row] < 0: padded time steps) is skipped: no loads, no MFMAs, no store.  The
+    // entry of the NEXT item is requested while the current one is set up, so the lookup never sits in front of a prefetch.
+    int pf_next_v = 0;
+    auto frame_of_item = [&](int k) { return a.src_row_frames[(first + k * stride) / ipf]; };
+    if (a.src_row_frames && nmine > 0) pf_next_v = frame_of_item(0);
+    auto enter_item = [&]() {                             // (pk) -> poff, pbase
+        int srow, y0, x0;
+        geom(pk, srow, y0, x0);
+        pbase = sr.ptr + (size_t)srow * H * W * Cs;
+        bool live = true;
+        if (a.src_row_frames) {
+            live = __builtin_amdgcn_readfirstlane(pf_next_v) >= 0;
+            if (pk + 1 < nmine) pf_next_v = frame_of_item(pk + 1);
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int idx = lane + 64 * k;
+            const int sy = y0 - 1 + s_ry[k], sx = x0 - 1 + s_rx[k];
+            const bool ok = live && idx < RH * RW * 4 && sy >= 0 && sy < H && sx >= 0 && sx < W;
+            poff[k] = ok ? (__umul24(sy, W) + sx) * Cs + (idx & 3) * 4 : -1;
+        }
+    };
+    auto issue = [&](float4 (&pre)[NS], unsigned& ok) {
+        if (pk >= nmine) return;
+        if (pchunk == 0) enter_item();
+        const float* base = pbase + pchunk * 16;
+        ok = 0;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int idx = lane + 64 * k;
-            const int sy = y0 - 1 + s_ry[k], sx = x0 - 1 + s_rx[k];
-            if (idx < RH * RW * 4 && sy >= 0 && sy < H && sx >= 0 && sx < W) {
-                pre[k] = *reinterpret_cast<const float4*>(base + (unsigned)((__umul24(sy, W) + sx) * Cs + (idx & 3) * 4));
-                pre_ok |= 1u << k;
+            if (poff[k] >= 0) {
+                pre[k] = *reinterpret_cast<const float4*>(base + (unsigned)poff[k]);
+                ok |= 1u << k;
             }
         }
+        if (++pchunk == nchunk) { pchunk = 0; ++pk; }
     };
-    // the source row of the NEXT item is fetched one item ahead (a dependent load in front of every prefetch would
-    // serialise two memory latencies)
-    int srow = 0, srow_next_v = 0;
-    if (item < nitems) {
-        srow = a.src_row_map ? __builtin_amdgcn_readfirstlane(a.src_row_map[frame_of(item)]) : frame_of(item);
-        issue_loads(item, 0, srow);
-    }
 
-    for (; item < nitems; item += stride) {
-        int f, y0, x0;
-        origin(item, f, y0, x0);
-        const bool has_next = item + stride < nitems;
-        if (has_next) srow_next_v = a.src_row_map ? a.src_row_map[frame_of(item + stride)] : frame_of(item + stride);
-        if (srow < 0) {
-            srow = __builtin_amdgcn_readfirstlane(srow_next_v);
-            if (has_next) issue_loads(item + stride, 0, srow);
+    f32x4 acc[CT][4];
+    int ck = 0, cchunk = 0;                               // compute cursor
+    int f_v = 0;                                          // output frame of the compute item: requested at its first chunk, used at its last
+    auto step = [&](float4 (&pre)[NS], unsigned& ok) {
+        if (__builtin_amdgcn_readfirstlane(ok) == 0) {    // skipped item (lane 0 of a live item always has slots inside the image)
+            issue(pre, ok);
+            if (++cchunk == nchunk) { cchunk = 0; ++ck; }
+            return;
+        }
+        // registers -> wave-private LDS region (producer's affine + activation applied here; conv zero padding stays zero)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int idx = lane + 64 * k;
+            if (idx < RH * RW * 4) {
+                float4 v = pre[k];
+                if (ok & (1u << k)) v = affine_act4(v, sr.scale, sr.shift, cchunk * 16 + (idx & 3) * 4, sr.act);
+                *reinterpret_cast<float4*>(reg + (idx >> 2) * CCP + (idx & 3) * 4) = v;
+            }
+        }
+        issue(pre, ok);                                   // this register set is free again: load the step DEPTH ahead
+        if (cchunk == 0) {
+            if (a.src_row_frames) f_v = a.src_row_frames[(first + ck * stride) / ipf];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // operands: the 9 x CT weight fragments of the chunk and the 6 x 3 distinct activation fragments (tap (dy, dx) of pixel row
+        // pt reads region row pt + dy: 18 loads serve 36 operand uses), requested three region rows ahead of their MFMAs in three
+        // rotating row buffers; the sched_barriers keep the compiler from sinking the loads next to their uses
+        const float4* wc = wl + cchunk * 9 * CT * 64 + lane;
+        float4 w[9][CT], b0[3], b1[3], b2[3];
+        auto ldrow = [&](int r, float4 (&b)[3]) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) b[dx] = *reinterpret_cast<const float4*>(bbase + (r * RW + dx) * CCP);
+        };
+        auto phase = [&](const int r, const float4 (&b)[3]) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int pt = r - dy;
+                        if (pt < 0 || pt > 3) continue;
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            acc[ct][pt] = mfma16(f4get(w[dy * 3 + dx][ct], kk), f4get(b[dx], kk), acc[ct][pt]);
+                    }
+                }
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) w[t][ct] = wc[(t * CT + ct) * 64];
+        ldrow(0, b0);
+#pragma unroll
+        for (int t = 3; t < 9; ++t)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) w[t][ct] = wc[(t * CT + ct) * 64];
+        ldrow(1, b1);
+        ldrow(2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        phase(0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        ldrow(3, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        phase(1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        ldrow(4, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        phase(2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        ldrow(5, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        phase(3, b0);
+        phase(4, b1);
+        phase(5, b2);
+        __builtin_amdgcn_s_setprio(0);
+
+        if (++cchunk == nchunk) {
+            int srow, y0, x0;
+            geom(ck, srow, y0, x0);
+            const int f = a.src_row_frames ? __builtin_amdgcn_readfirstlane(f_v) : srow;
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
                 float* op = a.out + (((size_t)f * H + (y0 + pt)) * W + (x0 + j)) * a.out_pitch;
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    *reinterpret_cast<float4*>(op + ct * 16 + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            continue;
-        }
-        f32x4 acc[CT][4];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int chunk = 0; chunk < nchunk; ++chunk) {
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int idx = lane + 64 * k;
-                if (idx < RH * RW * 4) {
-                    float4 v = pre[k];
-                    if (pre_ok & (1u << k)) v = affine_act4(v, sr.scale, sr.shift, chunk * 16 + (idx & 3) * 4, sr.act);
-                    *reinterpret_cast<float4*>(reg + (idx >> 2) * CCP + (idx & 3) * 4) = v;
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float4 bs = *reinterpret_cast<const float4*>(a.bias + ct * 16 + q * 4);
+                    const f32x4 v = acc[ct][pt];
+                    *reinterpret_cast<float4*>(op + ct * 16 + q * 4) = make_float4(v[0] + bs.x, v[1] + bs.y, v[2] + bs.z, v[3] + bs.w);
                 }
             }
-            if (chunk + 1 < nchunk) issue_loads(item, chunk + 1, srow);
-            else {
-                srow = __builtin_amdgcn_readfirstlane(srow_next_v);
-                if (has_next) issue_loads(item + stride, 0, srow);
-            }
+            cchunk = 0; ++ck;
+        }
+    };
 
-            // every operand of the chunk is requested up front: 9 x CT weight fragments and the 6 x 3 distinct activation
-            // fragments (tap (dy, dx) of pixel row pt reads region row pt + dy, so the 9 x 4 (tap, row) pairs share 18 loads).
-            // LDS returns in order and the MFMAs below consume the rows in the order they were requested, so only the first
-            // few loads are exposed; the sched_barrier keeps the compiler from sinking the loads back next to their uses.
-            const float4* wc = wl + chunk * 9 * CT * 64 + lane;
-            float4 w[9][CT], bv[6][3];
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) w[dx][ct] = wc[(dx * CT + ct) * 64];
-                bv[0][dx] = *reinterpret_cast<const float4*>(bbase + dx * CCP);
-            }
-#pragma unroll
-            for (int r = 1; r < 6; ++r) {
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    if (r < 3) {
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) w[r * 3 + dx][ct] = wc[((r * 3 + dx) * CT + ct) * 64];
-                    }
-                    bv[r][dx] = *reinterpret_cast<const float4*>(bbase + (r * RW + dx) * CCP);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        // the (dy, pt = r - dy) pairs of one region row are independent accumulator chains: interleaved
-#pragma unroll
-                        for (int dy = 0; dy < 3; ++dy) {
-                            const int pt = r - dy;
-                            if (pt < 0 || pt > 3) continue;
-#pragma unroll
-                            for (int ct = 0; ct < CT; ++ct)
-                                acc[ct][pt] = mfma16(f4get(w[dy * 3 + dx][ct], kk), f4get(bv[r][dx], kk), acc[ct][pt]);
-                        }
-                    }
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
+    float4 preA[NS];
+    unsigned okA = 0;
+    issue(preA, okA);
+    if constexpr (DEPTH == 2) {
+        float4 preB[NS];
+        unsigned okB = 0;
+        issue(preB, okB);
+        for (int s = 0; s < nsteps; s += 2) {
+            step(preA, okA);
+            if (s + 1 < nsteps) step(preB, okB);
         }
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            float* op = a.out + (((size_t)f * H + (y0 + pt)) * W + (x0 + j)) * a.out_pitch;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const float4 bs = *reinterpret_cast<const float4*>(a.bias + ct * 16 + q * 4);
-                const f32x4 v = acc[ct][pt];
-                *reinterpret_cast<float4*>(op + ct * 16 + q * 4) = make_float4(v[0] + bs.x, v[1] + bs.y, v[2] + bs.z, v[3] + bs.w);
-            }
-        }
+    } else {
+        for (int s = 0; s < nsteps; ++s) step(preA, okA);
     }
 }
 
-template <int CT>
+template <int CT, int DEPTH>
 int launch_wave(const gcpx_conv_args* a, hipStream_t stream) {
     using Cfg = WaveCfg<CT>;
-    auto kern = conv3x3_wave_kernel<CT>;
+    auto kern = conv3x3_wave_kernel<CT, DEPTH>;
     const int lds = Cfg::lds_bytes(a->Cin / 16);
     static int attr_lds = 0;
     if (lds > attr_lds) {
@@ -912,9 +957,12 @@ int launch_wave(const gcpx_conv_args* a, hipStream_t stream) {
         }
         attr_lds = lds;
     }
-    const int nitems = a->F * (a->Hout / 4) * (a->Wout / 16);
+    const int frames = a->src_row_frames ? a->n_src_rows : a->F;
+    const int nitems = frames * (a->Hout / 4) * (a->Wout / 16);
     int grid = gcpx_conv_grid() / 2;                     // one 512-thread workgroup per CU
-    if (grid * 8 > nitems) grid = (nitems + 7) / 8;
+    if (nitems == 0) grid = a->src_row_frames ? grid : 0;
+    else if (grid * 8 > nitems && !a->src_row_frames) grid = (nitems + 7) / 8;
+    if (grid == 0) return GCPX_OK;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, nitems);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
@@ -1214,10 +1262,14 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
         // data gradients of the decoder blocks (3x3 conv with the transposed, flipped weights): workgroup-tiled kernel
         GCPX_CHECK_ARG(a->head_mode == GCPX_HEAD_RAW && !a->stats_partial, "plain 3x3 conv stores raw output, no statistics");
         static const bool tiled_only = getenv("GCPX_DGRAD_TILED") != nullptr;
-        if (!tiled_only && W % 16 == 0 && a->Hout % 4 == 0 && a->Cout == 16 * CT && a->out_pitch % 4 == 0 && CT == 1 &&
-            (CT == 1 ? WaveCfg<1>::lds_bytes(a->Cin / 16) : WaveCfg<2>::lds_bytes(a->Cin / 16)) <= 152 * 1024 && (a->Cin / 16) * CT >= 2) {
+        static const int depth = getenv("GCPX_DGRAD_DEPTH") ? atoi(getenv("GCPX_DGRAD_DEPTH")) : 2;
+        GCPX_CHECK_ARG(!a->src_row_frames || (a->src_row_map && a->n_src_rows >= 0), "src_row_frames needs src_row_map and n_src_rows");
+        // wave-autonomous kernel: 16 output channels, several 16-channel chunks, every frame has a source row or the caller gave
+        // the inverse map
+        if (!tiled_only && W % 16 == 0 && a->Hout % 4 == 0 && a->Cout == 16 && a->out_pitch % 4 == 0 && CT == 1 && a->Cin >= 32 &&
+            (!a->src_row_map || a->src_row_frames) && WaveCfg<1>::lds_bytes(a->Cin / 16) <= 152 * 1024) {
             if (query_only) return gcpx_conv_grid() / 2;
-            return CT == 1 ? launch_wave<1>(a, stream) : launch_wave<2>(a, stream);
+            return depth == 2 ? launch_wave<1, 2>(a, stream) : launch_wave<1, 1>(a, stream);
         }
         const int tile = W >= 32 ? 0 : (W == 16 ? 1 : (W == 8 ? 2 : -1));
 #define GCPX_PLAIN(CC_, CT_)                                                            \

@@ -27,7 +27,7 @@ class ConvArgs(C.Structure):
     _fields_ = [("src", ConvSrc * 2), ("nsrc", i32), ("F", i32), ("Hin", i32), ("Win", i32), ("Hout", i32),
                 ("Wout", i32), ("Cin", i32), ("Cout", i32), ("out_pitch", i32), ("upsample", i32), ("out_act", i32),
                 ("head_mode", i32), ("wpk", vp), ("bias", vp), ("out", vp), ("images", vp), ("stats_partial", vp),
-                ("raw_row_map", vp), ("src_row_map", vp)]
+                ("raw_row_map", vp), ("src_row_map", vp), ("src_row_frames", vp), ("n_src_rows", i32), ("_pad0", i32)]
 
 
 class LossArgs(C.Structure):
@@ -149,6 +149,7 @@ SYMBOLS = [
     ("gcpx_timestep_scatter", C.c_int, [vp, i64, i64, vp, vp, i32, i32, i32, i32, vp]),
     ("gcpx_add_rows", C.c_int, [vp, i64, i64, vp, vp, i32, i32, i32, vp]),
     ("gcpx_index_offset", C.c_int, [vp, vp, i32, i32, i32, vp]),
+    ("gcpx_index_inverse", C.c_int, [vp, i32, vp, i32, vp]),
     ("gcpx_act_bwd", C.c_int, [C.POINTER(ActBwdArgs), vp]),
     ("gcpx_act_bwd_blocks", C.c_int, []),
     ("gcpx_bn_bwd_finalize", C.c_int, [vp, i32, i32, C.c_double, vp, vp, vp, vp, vp, i32, vp]),

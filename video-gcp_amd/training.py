@@ -729,6 +729,10 @@ class GCPTrainStep:
                          self._zeros, dA)
         if not all_frames:
             a.src_row_map = o["node2row"].data_ptr()
+            # inverse map: the kernel walks the B*T matched rows (padded rows, which no node maps to, are -1)
+            row2frame = buf("bw.row2frame", (B * T,), torch.int32)
+            plan.add("bw.row2frame", lib.gcpx_index_inverse, o["node2row"].data_ptr(), F, row2frame.data_ptr(), B * T)
+            a.src_row_frames, a.n_src_rows = row2frame.data_ptr(), B * T
         plan.keep.append(a)
         plan.add("bw.dgrad:dec.head", lib.gcpx_conv3x3, C.byref(a))
 
