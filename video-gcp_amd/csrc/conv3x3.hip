@@ -450,6 +450,8 @@ struct HeadCfg {
     static constexpr int NS = (RH * RW * 4 + 63) / 64;                   // float4 slots per lane
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -787,8 +789,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_kernel(const gcpx_conv_ar
 
     // ---- prefetch cursor: DEPTH (item, chunk) steps ahead of the compute cursor; per-item slot offsets computed once per item ----
     int pk = 0, pchunk = 0;                               // step the next issue() will load
-    int poff[NS];                                         // float offset of the slot inside the source frame, < 0: outside the image
+    unsigned poff[NS];                                    // byte offset of the slot inside the source frame; outside the image: beyond the buffer
+    unsigned pmask = 0;                                   // slots inside the image
     const float* pbase = sr.ptr;
+    const unsigned frame_bytes = (unsigned)H * W * Cs * 4;
     // a source row that no frame reads (src_row_frames[row] < 0: padded time steps) is skipped: no loads, no MFMAs, no store.  The
     // entry of the NEXT item is requested while the current one is set up, so the lookup never sits in front of a prefetch.
     int pf_next_v = 0;
@@ -803,26 +807,31 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_kernel(const gcpx_conv_ar
             live = __builtin_amdgcn_readfirstlane(pf_next_v) >= 0;
             if (pk + 1 < nmine) pf_next_v = frame_of_item(pk + 1);
         }
+        pmask = 0;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const int idx = lane + 64 * k;
             const int sy = y0 - 1 + s_ry[k], sx = x0 - 1 + s_rx[k];
             const bool ok = live && idx < RH * RW * 4 && sy >= 0 && sy < H && sx >= 0 && sx < W;
-            poff[k] = ok ? (__umul24(sy, W) + sx) * Cs + (idx & 3) * 4 : -1;
+            poff[k] = ok ? (unsigned)((__umul24(sy, W) + sx) * Cs + (idx & 3) * 4) * 4u : 0x80000000u;
+            pmask |= ok ? 1u << k : 0u;
         }
     };
+    // the staging loads are buffer loads against a per-frame descriptor: a slot outside the image carries an offset beyond the
+    // buffer and the hardware returns zeros — no per-slot branch, no zero-fill of the destination registers
     auto issue = [&](float4 (&pre)[NS], unsigned& ok) {
         if (pk >= nmine) return;
         if (pchunk == 0) enter_item();
-        const float* base = pbase + pchunk * 16;
-        ok = 0;
+        const unsigned long long pb = reinterpret_cast<unsigned long long>(pbase);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pb), hi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, frame_bytes, 0x00020000);
+        const int soff = pchunk * 64;
+        ok = pmask;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (poff[k] >= 0) {
-                pre[k] = *reinterpret_cast<const float4*>(base + (unsigned)poff[k]);
-                ok |= 1u << k;
-            }
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, poff[k], soff, 0);
+            pre[k] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
         if (++pchunk == nchunk) { pchunk = 0; ++pk; }
     };
