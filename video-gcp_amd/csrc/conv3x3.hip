@@ -867,55 +867,53 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_kernel(const gcpx_conv_ar
         // pt reads region row pt + dy: 18 loads serve 36 operand uses), requested three region rows ahead of their MFMAs in three
         // rotating row buffers; the sched_barriers keep the compiler from sinking the loads next to their uses
         const float4* wc = wl + cchunk * 9 * CT * 64 + lane;
-        float4 w[9][CT], b0[3], b1[3], b2[3];
-        auto ldrow = [&](int r, float4 (&b)[3]) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) b[dx] = *reinterpret_cast<const float4*>(bbase + (r * RW + dx) * CCP);
-        };
-        auto phase = [&](const int r, const float4 (&b)[3]) {
+        for (int ct = 0; ct < CT; ++ct) {                 // one 16-channel output tile at a time: 9 weight + 3 x 3 activation fragments live
+            float4 w[9], b0[3], b1[3], b2[3];
+            auto ldrow = [&](int r, float4 (&b)[3]) {
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
+                for (int dx = 0; dx < 3; ++dx) b[dx] = *reinterpret_cast<const float4*>(bbase + (r * RW + dx) * CCP);
+            };
+            auto phase = [&](const int r, const float4 (&b)[3]) {
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
+                for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const int pt = r - dy;
-                        if (pt < 0 || pt > 3) continue;
+                    for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                        for (int ct = 0; ct < CT; ++ct)
-                            acc[ct][pt] = mfma16(f4get(w[dy * 3 + dx][ct], kk), f4get(b[dx], kk), acc[ct][pt]);
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int pt = r - dy;
+                            if (pt < 0 || pt > 3) continue;
+                            acc[ct][pt] = mfma16(f4get(w[dy * 3 + dx], kk), f4get(b[dx], kk), acc[ct][pt]);
+                        }
                     }
                 }
-            }
-        };
+            };
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+            for (int t = 0; t < 3; ++t) w[t] = wc[(t * CT + ct) * 64];
+            ldrow(0, b0);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) w[t][ct] = wc[(t * CT + ct) * 64];
-        ldrow(0, b0);
-#pragma unroll
-        for (int t = 3; t < 9; ++t)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) w[t][ct] = wc[(t * CT + ct) * 64];
-        ldrow(1, b1);
-        ldrow(2, b2);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        phase(0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        ldrow(3, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        phase(1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        ldrow(4, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        phase(2, b2);
-        __builtin_amdgcn_sched_barrier(0);
-        ldrow(5, b2);
-        __builtin_amdgcn_sched_barrier(0);
-        phase(3, b0);
-        phase(4, b1);
-        phase(5, b2);
+            for (int t = 3; t < 9; ++t) w[t] = wc[(t * CT + ct) * 64];
+            ldrow(1, b1);
+            ldrow(2, b2);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldrow(3, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldrow(4, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(2, b2);
+            __builtin_amdgcn_sched_barrier(0);
+            ldrow(5, b2);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(3, b0);
+            phase(4, b1);
+            phase(5, b2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_s_setprio(0);
 
         if (++cchunk == nchunk) {
@@ -1279,6 +1277,12 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
             (!a->src_row_map || a->src_row_frames) && WaveCfg<1>::lds_bytes(a->Cin / 16) <= 152 * 1024) {
             if (query_only) return gcpx_conv_grid() / 2;
             return depth == 2 ? launch_wave<1, 2>(a, stream) : launch_wave<1, 1>(a, stream);
+        }
+        static const bool wave32 = getenv("GCPX_DGRAD_NOWAVE32") == nullptr;     // 32 output channels (16-channel decoder blocks): 874 vs 912 us tiled
+        if (wave32 && !tiled_only && W % 16 == 0 && a->Hout % 4 == 0 && a->Cout == 32 && a->out_pitch % 4 == 0 && a->Cin % 16 == 0 &&
+            (!a->src_row_map || a->src_row_frames) && WaveCfg<2>::lds_bytes(a->Cin / 16) <= 152 * 1024) {
+            if (query_only) return gcpx_conv_grid() / 2;
+            return launch_wave<2, 1>(a, stream);
         }
         const int tile = W >= 32 ? 0 : (W == 16 ? 1 : (W == 8 ? 2 : -1));
 #define GCPX_PLAIN(CC_, CT_)                                                            \
