@@ -650,15 +650,27 @@ __global__ void __launch_bounds__(256) loss_heads_bwd_kernel(const gcpx_loss_arg
 // ---------------------------------------------------------------------------------------------------
 // parameters
 // ---------------------------------------------------------------------------------------------------
+// four consecutive destination elements per thread (arena leaves are padded to multiples of 4): 16-byte index loads and stores
 __global__ void __launch_bounds__(256) repack_kernel(const float* __restrict__ theta, const int* __restrict__ idx0,
                                                      const int* __restrict__ idx1, float* __restrict__ dst, const long long n) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const int4 a = reinterpret_cast<const int4*>(idx0)[i];
+        float4 v = make_float4(a.x >= 0 ? theta[a.x] : 0.f, a.y >= 0 ? theta[a.y] : 0.f, a.z >= 0 ? theta[a.z] : 0.f,
+                               a.w >= 0 ? theta[a.w] : 0.f);
+        if (idx1) {
+            const int4 b = reinterpret_cast<const int4*>(idx1)[i];
+            if (b.x >= 0) v.x += theta[b.x];
+            if (b.y >= 0) v.y += theta[b.y];
+            if (b.z >= 0) v.z += theta[b.z];
+            if (b.w >= 0) v.w += theta[b.w];
+        }
+        reinterpret_cast<float4*>(dst)[i] = v;
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int a = idx0[i];
         float v = a >= 0 ? theta[a] : 0.f;
-        if (idx1) {
-            const int b = idx1[i];
-            if (b >= 0) v += theta[b];
-        }
+        if (idx1 && idx1[i] >= 0) v += theta[idx1[i]];
         dst[i] = v;
     }
 }
@@ -891,7 +903,8 @@ extern "C" int gcpx_loss_heads_bwd(const gcpx_loss_args* a, float* dlen, float* 
 extern "C" int gcpx_repack(const float* theta, const int32_t* idx0, const int32_t* idx1, float* dst, int64_t n, void* stream_) {
     STREAM();
     GCPX_CHECK_ARG(theta && idx0 && dst && n > 0, "bad arguments");
-    hipLaunchKernelGGL(repack_kernel, dim3(blocks_for(n, 16384)), dim3(256), 0, stream, theta, idx0, idx1, dst, (long long)n);
+    GCPX_CHECK_ARG((((uintptr_t)idx0 | (uintptr_t)idx1 | (uintptr_t)dst) & 15) == 0, "idx0 / idx1 / dst must be 16-byte aligned");
+    hipLaunchKernelGGL(repack_kernel, dim3(blocks_for((n + 3) / 4, 16384)), dim3(256), 0, stream, theta, idx0, idx1, dst, (long long)n);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

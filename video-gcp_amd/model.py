@@ -296,13 +296,19 @@ class GCPTreeModel:
                     leaves.append((path + (k,), d0, d0[k], d1[k]))
         walk(P0, P1, ("P",))
         walk(X0, X1, ("X",))
+        # leaves that sum two parameters (the fused LSTM biases b_ih + b_hh) go last: the bulk of the arena is then re-packed without
+        # reading a second index array
+        leaves.sort(key=lambda lf: bool((lf[3] > 0).any()))
         total = sum((t.numel() + 3) // 4 * 4 for _, _, t, _ in leaves)
         self._arena = torch.zeros(total, dtype=torch.float32, device=dev)
         idx0 = torch.full((total,), -1, dtype=torch.int32, device=dev)
         idx1 = torch.full((total,), -1, dtype=torch.int32, device=dev)
         off = 0
+        self._arena_split = None
         for path, holder, t0, t1 in leaves:
             n = t0.numel()
+            if self._arena_split is None and bool((t1 > 0).any()):
+                self._arena_split = off
             idx0[off:off + n] = (t0.reshape(-1) - 1).to(torch.int32)
             idx1[off:off + n] = (t1.reshape(-1) - 1).to(torch.int32)
             holder[path[-1]] = self._arena[off:off + n].view(t0.shape)
@@ -316,8 +322,13 @@ class GCPTreeModel:
 
     def repack(self, stream=None):
         st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
-        rt.check(self.lib.gcpx_repack(self.theta.data_ptr(), self._arena_idx0.data_ptr(), self._arena_idx1.data_ptr(),
-                                      self._arena.data_ptr(), self._arena.numel(), st), "repack")
+        n, sp = self._arena.numel(), self._arena_split
+        sp = n if sp is None else sp
+        if sp > 0:
+            rt.check(self.lib.gcpx_repack(self.theta.data_ptr(), self._arena_idx0.data_ptr(), None, self._arena.data_ptr(), sp, st), "repack")
+        if sp < n:
+            rt.check(self.lib.gcpx_repack(self.theta.data_ptr(), self._arena_idx0.data_ptr() + 4 * sp, self._arena_idx1.data_ptr() + 4 * sp,
+                                          self._arena.data_ptr() + 4 * sp, n - sp, st), "repack")
 
     def _pack_hsp(self, prefix, n_layers):
         """embed Linear + n gate-interleaved LSTM layers + out Linear of one recurrent predictor."""
