@@ -14,6 +14,7 @@
 // the whole cell update for (row, unit u) is lane-local.  No LDS, no barriers: wavefronts are independent.
 #include "common.cuh"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -194,6 +195,7 @@ TileChoice choose_tile(int M, int N, int nb = 1) {
     const int prs[3] = {4, 2, 1}, crs[3] = {4, 2, 1};
     TileChoice best{1, 1};
     long best_wg = -1;
+    static const long wg_min = getenv("GCPX_GEMM_WGMIN") ? atol(getenv("GCPX_GEMM_WGMIN")) : 200;
     // candidates by decreasing tile area; take the first that fills the chip, else the one with most workgroups
     for (int area = 16; area >= 1; area /= 2) {
         for (int pi = 0; pi < 3; ++pi)
@@ -205,7 +207,7 @@ TileChoice choose_tile(int M, int N, int nb = 1) {
                 const long rbk = (M + 16 * pr - 1) / (16 * pr);
                 const long cbk = (N / 16 + 4 * cr - 1) / (4 * cr);
                 const long wg = rbk * cbk * nb;
-                if (wg >= 200) return TileChoice{pr, cr};
+                if (wg >= wg_min) return TileChoice{pr, cr};
                 if (wg > best_wg) { best_wg = wg; best = TileChoice{pr, cr}; }
             }
     }
@@ -252,7 +254,11 @@ extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
         GCPX_CHECK_ARG(a->out != nullptr, "out is NULL");
     }
     GCPX_CHECK_ARG(a->nbatch <= 1 || (a->epi != GCPX_EPI_LSTM && !a->stats_partial), "nbatch > 1 only for plain epilogues");
-    const TileChoice t = choose_tile(a->M, a->N, a->nbatch > 1 ? a->nbatch : 1);
+    TileChoice t = choose_tile(a->M, a->N, a->nbatch > 1 ? a->nbatch : 1);
+    if (const char* ov = getenv("GCPX_GEMM_TILE")) {           // tuning aid: "pr,cr,minM"
+        int pr = 0, cr = 0, mm = 0;
+        if (sscanf(ov, "%d,%d,%d", &pr, &cr, &mm) == 3 && a->M >= mm && a->N % (16 * cr) == 0) t = TileChoice{pr, cr};
+    }
     if (t.pr == 1 && t.cr == 1 && a->K >= 256 && !getenv("GCPX_GEMM_NOKS")) {
         // few rows: split K over the wavefronts of a workgroup when that still leaves the launch small
         const long nb = a->nbatch > 1 ? a->nbatch : 1;
