@@ -400,63 +400,98 @@ __global__ void __launch_bounds__(256) dtw_align_kernel(const float* __restrict_
 //   acc[b][o][d] = sum_k wk(b, k, o) * y[b][k][d],  wk = w[b][k * ws_k + o * ws_o] * (kmask ? kmask[b][k] : 1)
 //   out = sub ? coef * (sub[b][o][d] * (sum_k wk) - acc) : acc
 // soft average (forward, visualisation): k = node, o = frame;  averaging-loss gradient: k = frame, o = node, sub = images.
+// f32 MFMA: outputs o on the i side (two 16-row tiles per workgroup), the D axis on the j side (a wavefront owns 64 consecutive
+// d), k walks the MFMA k index 4 at a time; operands go straight from global memory to registers (A = one weight per lane, B = one
+// element of row k per lane, 64-byte segments per 16 lanes).  The first version held 32 accumulators per thread and broadcast the
+// weights through LDS with two barriers per k: 1.22 ms at c5 (8 TFLOP/s of VALU) for 10 GFLOP.
 __global__ void __launch_bounds__(256) weighted_rows_kernel(const float* __restrict__ w, const long long ws_k, const long long ws_o,
                                                             const long long ws_b, const float* __restrict__ kmask,
                                                             const float* __restrict__ y, const float* __restrict__ sub,
                                                             const float* __restrict__ log_sigma, const float coef,
                                                             float* __restrict__ out, const int Kn, const int On, const long long Dd) {
-    __shared__ float sw[32];
     const int b = blockIdx.z, o0 = blockIdx.y * 32;
-    const long long d = (long long)blockIdx.x * 256 + threadIdx.x;
-    float acc[32];
-    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
-    float wsum = 0.f;                                   // threads < 32: sum_k wk for output o0 + tid
-    for (int k = 0; k < Kn; ++k) {
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            float v = 0.f;
-            if (o0 + threadIdx.x < On) {
-                v = w[(size_t)b * ws_b + (size_t)k * ws_k + (size_t)(o0 + threadIdx.x) * ws_o];
-                if (kmask) v *= kmask[(size_t)b * Kn + k];
-            }
-            sw[threadIdx.x] = v;
-            wsum += v;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ij = lane & 15, kk = lane >> 4;
+    const long long d0 = (long long)blockIdx.x * 256 + wave * 64;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float wsum[2] = {0.f, 0.f};
+    const float* wb = w + (size_t)b * ws_b;
+    const float* yb = y + (size_t)b * Kn * Dd;
+    bool ov[2], dv[4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) ov[it] = o0 + 16 * it + ij < On;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) dv[jt] = d0 + 16 * jt + ij < Dd;
+#pragma unroll 4
+    for (int k0 = 0; k0 < Kn; k0 += 4) {
+        const int k = k0 + kk;
+        const bool kv = k < Kn;
+        const float km = (kv && kmask) ? kmask[(size_t)b * Kn + k] : 1.f;
+        float a[2], bv[4];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+            a[it] = (kv && ov[it]) ? wb[(size_t)k * ws_k + (size_t)(o0 + 16 * it + ij) * ws_o] * km : 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) bv[jt] = (kv && dv[jt]) ? yb[(size_t)k * Dd + d0 + 16 * jt + ij] : 0.f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            wsum[it] += a[it];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) acc[it][jt] = mfma16(a[it], bv[jt], acc[it][jt]);
         }
-        __syncthreads();
-        const float xv = d < Dd ? y[((size_t)b * Kn + k) * Dd + d] : 0.f;
-        for (int i = 0; i < 32; ++i) acc[i] = fmaf(sw[i], xv, acc[i]);
     }
-    if (sub) {
-        __syncthreads();
-        if (threadIdx.x < 32) sw[threadIdx.x] = wsum;
-        __syncthreads();
-    }
-    if (d >= Dd) return;
     const float c = sub ? coef * expf(-2.f * log_sigma[0]) : 1.f;
-    for (int i = 0; i < 32; ++i) {
-        if (o0 + i >= On) break;
-        const size_t oidx = ((size_t)b * On + o0 + i) * Dd + d;
-        out[oidx] = sub ? c * (sub[oidx] * sw[i] - acc[i]) : acc[i];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        float s = wsum[it];                                  // sum over k of the weights of output o0 + 16 it + ij
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ws = __shfl(s, 4 * kk + r);          // the accumulator rows of this lane are outputs 4 kk + r
+            const int o = o0 + 16 * it + 4 * kk + r;
+            if (o >= On) continue;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const long long d = d0 + 16 * jt + ij;
+                if (d >= Dd) continue;
+                const size_t oidx = ((size_t)b * On + o) * Dd + d;
+                out[oidx] = sub ? c * (sub[oidx] * ws - acc[it][jt][r]) : acc[it][jt][r];
+            }
+        }
     }
 }
 
 // d loss / d log_sigma of the averaging criterion: sum over (b, n, t) of w * pad * (D - d * exp(-2 ls)) * coef, accumulated into dst
-__global__ void __launch_bounds__(256) averaging_dls_kernel(const float* __restrict__ dsum, const float* __restrict__ w,
-                                                            const float* __restrict__ pad, const float* __restrict__ log_sigma,
-                                                            const float D, const float coef, float* __restrict__ dst,
-                                                            const int B, const int N, const int T) {
-    __shared__ float red[256];
+__global__ void __launch_bounds__(1024) averaging_dls_kernel(const float* __restrict__ dsum, const float* __restrict__ w,
+                                                             const float* __restrict__ pad, const float* __restrict__ log_sigma,
+                                                             const float D, const float coef, float* __restrict__ dst,
+                                                             const int B, const int N, const int T) {
+    // one workgroup (deterministic sum); 1024 threads x 4 independent elements per trip keep enough loads in flight — the first
+    // version (256 threads, one element per trip) spent 1 ms in ~1600 dependent round trips
+    __shared__ float red[1024];
     const float s2 = expf(-2.f * log_sigma[0]);
-    float acc = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const size_t total = (size_t)B * N * T;
-    for (size_t i = threadIdx.x; i < total; i += 256) {
-        const int t = (int)(i % T);
-        const int b = (int)(i / ((size_t)N * T));
-        acc += w[i] * pad[(size_t)b * T + t] * (D - dsum[i] * s2);
+    const size_t NT = (size_t)N * T;
+    for (size_t i0 = threadIdx.x; i0 < total; i0 += 4096) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = i0 + 1024 * u;
+            if (i < total) {
+                const int t = (int)(i % T);
+                const int b = (int)(i / NT);
+                acc[u] += w[i] * pad[(size_t)b * T + t] * (D - dsum[i] * s2);
+            }
+        }
     }
-    red[threadIdx.x] = acc;
+    red[threadIdx.x] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
@@ -762,7 +797,7 @@ extern "C" int gcpx_averaging_nll_bwd(const float* w, const float* pad_mask, con
     GCPX_CHECK_ARG(B > 0 && N > 0 && T > 0 && D > 0, "bad sizes");
     hipLaunchKernelGGL(weighted_rows_kernel, dim3((unsigned)((D + 255) / 256), (N + 31) / 32, B), dim3(256), 0, stream, w, 1LL,
                        (long long)T, (long long)N * T, pad_mask, traj, images, log_sigma, coef, dimg, T, N, (long long)D);
-    hipLaunchKernelGGL(averaging_dls_kernel, dim3(1), dim3(256), 0, stream, dsum, w, pad_mask, log_sigma, (float)D, coef, dlog_sigma, B,
+    hipLaunchKernelGGL(averaging_dls_kernel, dim3(1), dim3(1024), 0, stream, dsum, w, pad_mask, log_sigma, (float)D, coef, dlog_sigma, B,
                        N, T);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
