@@ -20,8 +20,20 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// attention: one wavefront per query row r = (b, j); keys / values of sequence b = r / rpb
+// attention: one 256-thread workgroup per query row r = (b, j); keys / values of sequence b = r / rpb.
+// Scores: one key per thread (the dh-long dot as float4 loads); softmax over the T keys by workgroup reductions; values:
+// thread (c4, tg) sums 4 channels over the keys t = tg, tg + G, ... and the G partial sums are combined in a fixed order.
+// (The first version gave a row to one wavefront: 200 dependent loads per lane in the value loop, 31 us whatever the level.)
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_reduce(float v, float* red, const bool is_max) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ void __launch_bounds__(256) attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, const int64_t* __restrict__ start_ind,
                                                         const int64_t* __restrict__ end_ind,
@@ -29,60 +41,70 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* __restrict_
                                                         float* __restrict__ att, const int M, const int rpb, const int T,
                                                         const int dk, const int nz, const int heads) {
     extern __shared__ float smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + wave;
-    const bool valid = r < M;
-    float* p = smem + (size_t)wave * T;
-    const int b = valid ? r / rpb : 0;
+    float* p = smem;                                      // [T] scores -> probabilities
+    float* part = smem + ((T + 3) & ~3);                  // [256 * 4] partial value sums (16-byte aligned)
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int r = blockIdx.x;
+    const int b = r / rpb;
     const int s = start_ind ? (int)start_ind[b] : 0, e = (int)end_ind[b];
     const float* kb = k + (size_t)b * T * dk;
     const float* vb = v + (size_t)b * T * nz;
     const int dh = dk / heads, vh = nz / heads;
-    const float sq = sqrtf((float)dh), temp = temperature[0];
+    const float inv = 1.f / sqrtf((float)dh) / temperature[0];
+    const int c4n = vh / 4;                               // float4 channel groups of a head
+    const int G = 256 / c4n;                              // key groups in the value pass
     for (int h = 0; h < heads; ++h) {
+        const float* qr = q + (size_t)r * dk + h * dh;
         float mx = -INFINITY;
-        if (valid) {
-            const float* qr = q + (size_t)r * dk + h * dh;
-            for (int t = lane; t < T; t += 64) {
-                const float* kr = kb + (size_t)t * dk + h * dh;
-                float d = 0.f;
-                for (int i = 0; i < dh; ++i) d = fmaf(qr[i], kr[i], d);
-                float sc = d / sq / temp;
-                if (t < s || t > e) sc = -INFINITY;
-                p[t] = sc;
-                mx = fmaxf(mx, sc);
+        for (int t = tid; t < T; t += 256) {
+            const float* kr = kb + (size_t)t * dk + h * dh;
+            float d = 0.f;
+            for (int i = 0; i < dh; i += 4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(qr + i), b4 = *reinterpret_cast<const float4*>(kr + i);
+                d = fmaf(a4.x, b4.x, d); d = fmaf(a4.y, b4.y, d); d = fmaf(a4.z, b4.z, d); d = fmaf(a4.w, b4.w, d);
+            }
+            float sc = d * inv;
+            if (t < s || t > e) sc = -INFINITY;
+            p[t] = sc;
+            mx = fmaxf(mx, sc);
+        }
+        mx = block_reduce(mx, red, true);
+        float sum = 0.f;
+        for (int t = tid; t < T; t += 256) {
+            const float ex = (p[t] == -INFINITY) ? 0.f : expf(p[t] - mx);
+            p[t] = ex;
+            sum += ex;
+        }
+        sum = block_reduce(sum, red, false);
+        for (int t = tid; t < T; t += 256) {
+            const float a = p[t] / sum;
+            p[t] = a;
+            if (att) att[(size_t)r * T + t] = (h == 0 ? 0.f : att[(size_t)r * T + t]) + a / (float)heads;
+        }
+        __syncthreads();
+        const int c4 = tid % c4n, tg = tid / c4n;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tg < G) {
+            const int t0 = s < 0 ? 0 : s, te = e >= T ? T - 1 : e;
+            const float* vc = vb + h * vh + c4 * 4;
+#pragma unroll 4
+            for (int t = t0 + tg; t <= te; t += G) {
+                const float4 x = *reinterpret_cast<const float4*>(vc + (size_t)t * nz);
+                const float w = p[t];
+                acc.x = fmaf(w, x.x, acc.x); acc.y = fmaf(w, x.y, acc.y); acc.z = fmaf(w, x.z, acc.z); acc.w = fmaf(w, x.w, acc.w);
             }
         }
-        mx = wave_max(mx);
-        float sum = 0.f;
-        if (valid)
-            for (int t = lane; t < T; t += 64) {
-                const float ex = (p[t] == -INFINITY) ? 0.f : expf(p[t] - mx);
-                p[t] = ex;
-                sum += ex;
-            }
-        sum = wave_sum(sum);
-        if (valid)
-            for (int t = lane; t < T; t += 64) {
-                const float a = p[t] / sum;
-                p[t] = a;
-                if (att) att[(size_t)r * T + t] = (h == 0 ? 0.f : att[(size_t)r * T + t]) + a / (float)heads;
-            }
+        reinterpret_cast<float4*>(part)[tid] = acc;
         __syncthreads();
-        if (valid)
-            for (int c = lane; c < vh; c += 64) {
-                const float* vc = vb + h * vh + c;
-                float acc = 0.f;
-                int t = s < 0 ? 0 : s;
-                const int te = e >= T ? T - 1 : e;
-                for (; t + 3 <= te; t += 4) {
-                    const float x0 = vc[(size_t)t * nz], x1 = vc[(size_t)(t + 1) * nz], x2 = vc[(size_t)(t + 2) * nz],
-                                x3 = vc[(size_t)(t + 3) * nz];
-                    acc = fmaf(p[t], x0, acc); acc = fmaf(p[t + 1], x1, acc); acc = fmaf(p[t + 2], x2, acc); acc = fmaf(p[t + 3], x3, acc);
-                }
-                for (; t <= te; ++t) acc = fmaf(p[t], vc[(size_t)t * nz], acc);
-                out[(size_t)r * nz + h * vh + c] = acc;
+        if (tid < c4n) {
+            float4 o = reinterpret_cast<float4*>(part)[tid];
+            for (int g = 1; g < G; ++g) {
+                const float4 x = reinterpret_cast<float4*>(part)[g * c4n + tid];
+                o.x += x.x; o.y += x.y; o.z += x.z; o.w += x.w;
             }
+            *reinterpret_cast<float4*>(out + (size_t)r * nz + h * vh + tid * 4) = o;
+        }
         __syncthreads();
     }
 }
@@ -602,56 +624,76 @@ __global__ void __launch_bounds__(256) attention_bwd_row_kernel(const float* __r
                                                                 const float* __restrict__ temperature, float* __restrict__ dS,
                                                                 float* __restrict__ dq, float* __restrict__ dtemp_row, const int M,
                                                                 const int rpb, const int T, const int dk, const int nz) {
+    // one workgroup per query row (same decomposition as attention_kernel): one key per thread for the two dot products, the
+    // query gradient as (channel group, key group) partial sums combined in a fixed order
     extern __shared__ float smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + wave;
-    const bool valid = r < M;
-    float* p = smem + (size_t)wave * T;
-    const int b = valid ? r / rpb : 0;
+    float* p = smem;
+    float* part = smem + ((T + 3) & ~3);
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int r = blockIdx.x;
+    const int b = r / rpb;
     const int e = (int)end_ind[b];
     const int te = e >= T ? T - 1 : e;
     const float* kb = k + (size_t)b * T * dk;
     const float* vb = v + (size_t)b * T * nz;
     const float sq = sqrtf((float)dk), temp = temperature[0];
+    const float* dor = d_out + (size_t)r * nz;
+    const float* qr = q + (size_t)r * dk;
     float dot = 0.f;
-    if (valid) {
-        const float* dor = d_out + (size_t)r * nz;
-        for (int t = lane; t < T; t += 64) {
-            float da = 0.f;
-            if (t <= te) {
-                const float* vr = vb + (size_t)t * nz;
-                for (int c = 0; c < nz; ++c) da = fmaf(dor[c], vr[c], da);
+    for (int t = tid; t < T; t += 256) {
+        float da = 0.f;
+        if (t <= te) {
+            const float* vr = vb + (size_t)t * nz;
+            for (int c = 0; c < nz; c += 4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(dor + c), b4 = *reinterpret_cast<const float4*>(vr + c);
+                da = fmaf(a4.x, b4.x, da); da = fmaf(a4.y, b4.y, da); da = fmaf(a4.z, b4.z, da); da = fmaf(a4.w, b4.w, da);
             }
-            p[t] = da;
-            dot += att[(size_t)r * T + t] * da;
         }
+        p[t] = da;
+        dot += att[(size_t)r * T + t] * da;
     }
-    dot = wave_sum(dot);
+    dot = block_reduce(dot, red, false);
     float dtp = 0.f;
-    if (valid) {
-        const float* qr = q + (size_t)r * dk;
-        for (int t = lane; t < T; t += 64) {
-            const float a = att[(size_t)r * T + t];
-            const float ds = a * (p[t] - dot);
-            p[t] = ds;
-            dS[(size_t)r * T + t] = ds;
-            if (t <= te && ds != 0.f) {
-                const float* kr = kb + (size_t)t * dk;
-                float sc = 0.f;
-                for (int i = 0; i < dk; ++i) sc = fmaf(qr[i], kr[i], sc);
-                dtp -= ds * (sc / sq / temp) / temp;
+    for (int t = tid; t < T; t += 256) {
+        const float a = att[(size_t)r * T + t];
+        const float ds = a * (p[t] - dot);
+        p[t] = ds;
+        dS[(size_t)r * T + t] = ds;
+        if (t <= te && ds != 0.f) {
+            const float* kr = kb + (size_t)t * dk;
+            float sc = 0.f;
+            for (int i = 0; i < dk; i += 4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(qr + i), b4 = *reinterpret_cast<const float4*>(kr + i);
+                sc = fmaf(a4.x, b4.x, sc); sc = fmaf(a4.y, b4.y, sc); sc = fmaf(a4.z, b4.z, sc); sc = fmaf(a4.w, b4.w, sc);
             }
+            dtp -= ds * (sc / sq / temp) / temp;
         }
     }
-    dtp = wave_sum(dtp);
+    dtp = block_reduce(dtp, red, false);
+    if (tid == 0) dtemp_row[r] = dtp;
     __syncthreads();
-    if (valid) {
-        if (lane == 0) dtemp_row[r] = dtp;
-        for (int i = lane; i < dk; i += 64) {
-            float acc = 0.f;
-            for (int t = 0; t <= te; ++t) acc = fmaf(p[t], kb[(size_t)t * dk + i], acc);
-            dq[(size_t)r * dk + i] = acc / sq / temp;
+    const int c4n = dk / 4, G = 256 / c4n;
+    const int c4 = tid % c4n, tg = tid / c4n;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tg < G) {
+#pragma unroll 4
+        for (int t = tg; t <= te; t += G) {
+            const float4 x = *reinterpret_cast<const float4*>(kb + (size_t)t * dk + c4 * 4);
+            const float w = p[t];
+            acc.x = fmaf(w, x.x, acc.x); acc.y = fmaf(w, x.y, acc.y); acc.z = fmaf(w, x.z, acc.z); acc.w = fmaf(w, x.w, acc.w);
         }
+    }
+    reinterpret_cast<float4*>(part)[tid] = acc;
+    __syncthreads();
+    if (tid < c4n) {
+        float4 o = reinterpret_cast<float4*>(part)[tid];
+        for (int g = 1; g < G; ++g) {
+            const float4 x = reinterpret_cast<float4*>(part)[g * c4n + tid];
+            o.x += x.x; o.y += x.y; o.z += x.z; o.w += x.w;
+        }
+        const float sc = 1.f / sq / temp;
+        *reinterpret_cast<float4*>(dq + (size_t)r * dk + tid * 4) = make_float4(o.x * sc, o.y * sc, o.z * sc, o.w * sc);
     }
 }
 
@@ -691,7 +733,9 @@ extern "C" int gcpx_attention(const float* q, const float* k, const float* v, co
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(q && k && v && end_ind && temperature && out, "null pointer");
     GCPX_CHECK_ARG(M > 0 && rpb > 0 && T > 0 && T <= 4096 && heads > 0 && dk % heads == 0 && nz % heads == 0, "bad sizes");
-    hipLaunchKernelGGL(attention_kernel, dim3((M + 3) / 4), dim3(256), 4 * T * sizeof(float), stream, q, k, v, start_ind, end_ind,
+    GCPX_CHECK_ARG((dk / heads) % 4 == 0 && (nz / heads) % 4 == 0 && nz / heads <= 1024 && 256 % (nz / heads / 4) == 0,
+                   "head widths must be multiples of 4 and nz / heads / 4 a divisor of 256");
+    hipLaunchKernelGGL(attention_kernel, dim3(M), dim3(256), (T + 4 + 1024) * sizeof(float), stream, q, k, v, start_ind, end_ind,
                        temperature, out, att, M, rpb, T, dk, nz, heads);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
@@ -820,7 +864,8 @@ extern "C" int gcpx_attention_bwd(const float* q, const float* k, const float* v
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(q && k && v && att && d_out && end_ind && temperature && dS && dq && dtemp_row && dK && dV, "null pointer");
     GCPX_CHECK_ARG(M > 0 && rpb > 0 && M % rpb == 0 && T > 0 && T <= 4096 && dk + nz <= 192, "bad sizes (one head, dk + nz <= 192)");
-    hipLaunchKernelGGL(attention_bwd_row_kernel, dim3((M + 3) / 4), dim3(256), 4 * T * sizeof(float), stream, q, k, v, att, d_out,
+    GCPX_CHECK_ARG(dk % 4 == 0 && nz % 4 == 0 && 256 % (dk / 4) == 0, "dk, nz multiples of 4; dk / 4 a divisor of 256");
+    hipLaunchKernelGGL(attention_bwd_row_kernel, dim3(M), dim3(256), (T + 4 + 1024) * sizeof(float), stream, q, k, v, att, d_out,
                        end_ind, temperature, dS, dq, dtemp_row, M, rpb, T, dk, nz);
     hipLaunchKernelGGL(attention_bwd_kv_kernel, dim3((M / rpb) * T), dim3(192), 0, stream, q, att, dS, d_out, temperature, dK,
                        (long long)ldk, dV, (long long)ldv, rpb, T, dk, nz);
