@@ -380,6 +380,7 @@ __global__ void __launch_bounds__(256) conv4x4s2_image_kernel(const float* __res
     const int npix = F * Hout * Wout;
     const int ngroups = (npix + 15) / 16;
     const int nblk = (ngroups + 4 * PR - 1) / (4 * PR);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, F * 3 * Hin * Win * 4, 0x00020000);
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         int pf[PR], poy[PR], pox[PR];
         bool pv[PR];
@@ -398,23 +399,32 @@ __global__ void __launch_bounds__(256) conv4x4s2_image_kernel(const float* __res
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
+        // all 12 x PR taps are requested before the first MFMA: buffer loads against the image tensor, a tap outside the image
+        // carries an offset beyond the buffer and reads 0 (with one branch + wait per tap the launch was a chain of 12 memory
+        // latencies per 32 pixels: 92 us for the 63 MB trajectory batch)
+        float b[12][PR];
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci) {
+        for (int pt = 0; pt < PR; ++pt) {
+            const int ix = 2 * pox[pt] - 1 + q;
+            const bool xok = pv[pt] && ix >= 0 && ix < Win;
 #pragma unroll
-            for (int ky = 0; ky < 4; ++ky) {
-                float b[PR];
+            for (int ci = 0; ci < 3; ++ci) {
 #pragma unroll
-                for (int pt = 0; pt < PR; ++pt) {
-                    const int iy = 2 * poy[pt] - 1 + ky, ix = 2 * pox[pt] - 1 + q;
-                    const bool ok = pv[pt] && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
-                    b[pt] = ok ? x[(((size_t)pf[pt] * 3 + ci) * Hin + iy) * Win + ix] : 0.f;
+                for (int ky = 0; ky < 4; ++ky) {
+                    const int iy = 2 * poy[pt] - 1 + ky;
+                    const bool ok = xok && iy >= 0 && iy < Hin;
+                    const unsigned off = ok ? (unsigned)(((pf[pt] * 3 + ci) * Hin + iy) * Win + ix) * 4u : 0x80000000u;
+                    b[ci * 4 + ky][pt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
                 }
+            }
+        }
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const float w = wpk[((ci * 4 + ky) * CT + ct) * 64 + lane];
+        for (int t = 0; t < 12; ++t) {
 #pragma unroll
-                    for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma16(w, b[pt], acc[ct][pt]);
-                }
+            for (int ct = 0; ct < CT; ++ct) {
+                const float w = wpk[(t * CT + ct) * 64 + lane];
+#pragma unroll
+                for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma16(w, b[t][pt], acc[ct][pt]);
             }
         }
 #pragma unroll
@@ -491,6 +501,7 @@ extern "C" int gcpx_conv4x4s2_image(const float* x, const float* wpk, const floa
     GCPX_CHECK_ARG(x && wpk && bias && out && F > 0, "null pointer / F <= 0");
     GCPX_CHECK_ARG(Cout == 16, "first encoder layer: Cout must be 16 (ngf)");
     GCPX_CHECK_ARG(Hin % 2 == 0 && Win % 2 == 0, "even input size");
+    GCPX_CHECK_ARG((long long)F * 3 * Hin * Win * 4 < (1LL << 31), "image tensor must stay below 2 GiB (32-bit buffer offsets)");
     const int npix = F * (Hin / 2) * (Win / 2);
     const int nblk = ((npix + 15) / 16 + 7) / 8;
     int grid = gcpx_conv_grid() * 2;
