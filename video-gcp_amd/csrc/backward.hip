@@ -360,29 +360,38 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ d
 
 // out[f][Y][X][c] = (upsampled) concat of the normalised + activated sources
 __global__ void __launch_bounds__(256) conv_stage_kernel(const gcpx_conv_args a) {
+    // a thread keeps one 4-channel group for the whole launch (the grid stride is a multiple of Cin / 4, checked by the launcher):
+    // its source, affine parameters and channel offset are loop invariants; pixel indices are 32-bit
     const int C4 = a.Cin / 4;
-    const long long total = (long long)a.F * a.Hout * a.Wout * C4;
+    const unsigned npix = (unsigned)a.F * a.Hout * a.Wout;
     const int c0 = a.src[0].C;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cg = (int)(i % C4) * 4;
-        long long p = i / C4;
-        const int X = (int)(p % a.Wout); p /= a.Wout;
-        const int Y = (int)(p % a.Hout);
-        int f = (int)(p / a.Hout);
+    const unsigned gtid = blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gtid % C4) * 4;
+    const bool first = cg < c0;
+    const gcpx_conv_src s = first ? a.src[0] : a.src[1];
+    const int cl = first ? cg : cg - c0;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s.scale) { sc = *reinterpret_cast<const float4*>(s.scale + cl); sh = *reinterpret_cast<const float4*>(s.shift + cl); }
+    const bool aff = s.scale != nullptr, lre = s.act == GCPX_ACT_LRELU;
+    auto xf = [&](float4 t) {                              // affine_act4 with the parameters held in registers
+        if (aff) { t.x = fmaf(t.x, sc.x, sh.x); t.y = fmaf(t.y, sc.y, sh.y); t.z = fmaf(t.z, sc.z, sh.z); t.w = fmaf(t.w, sc.w, sh.w); }
+        if (lre) { t.x = lrelu(t.x, 0.2f); t.y = lrelu(t.y, 0.2f); t.z = lrelu(t.z, 0.2f); t.w = lrelu(t.w, 0.2f); }
+        return t;
+    };
+    const unsigned pstride = gridDim.x * 256 / C4;
+    const size_t plane = (size_t)a.Hin * a.Win * s.C;
+    for (unsigned p = gtid / C4; p < npix; p += pstride) {
+        const unsigned X = p % a.Wout, t_ = p / a.Wout;
+        const unsigned Y = t_ % a.Hout;
+        int f = (int)(t_ / a.Hout);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.src_row_map) f = a.src_row_map[f];
         if (f >= 0) {
-            const bool first = cg < c0;
-            const gcpx_conv_src& s = first ? a.src[0] : a.src[1];
-            const int cl = first ? cg : cg - c0;
-            const float* base = s.ptr + (size_t)(f / s.frame_div) * a.Hin * a.Win * s.C + cl;
-            auto ld = [&](int y, int x) {
-                const float4 t = *reinterpret_cast<const float4*>(base + ((size_t)y * a.Win + x) * s.C);
-                return affine_act4(t, s.scale, s.shift, cl, s.act);
-            };
+            const float* base = s.ptr + (size_t)(f / s.frame_div) * plane + cl;
+            auto ld = [&](int y, int x) { return xf(*reinterpret_cast<const float4*>(base + ((unsigned)y * a.Win + x) * s.C)); };
             if (a.upsample) {
                 // align_corners=False x2: Y even -> rows (Y/2 - 1, Y/2) weights (.25, .75); odd -> (Y/2, Y/2 + 1) weights (.75, .25)
-                const int y0 = (Y & 1) ? Y / 2 : Y / 2 - 1, x0 = (X & 1) ? X / 2 : X / 2 - 1;
+                const int y0 = (Y & 1) ? Y / 2 : (int)(Y / 2) - 1, x0 = (X & 1) ? X / 2 : (int)(X / 2) - 1;
                 const float wy1 = (Y & 1) ? 0.25f : 0.75f, wx1 = (X & 1) ? 0.25f : 0.75f;
                 const int ya = max(y0, 0), yb = min(y0 + 1, a.Hin - 1), xa = max(x0, 0), xb = min(x0 + 1, a.Win - 1);
                 const float4 v00 = ld(ya, xa), v01 = ld(ya, xb), v10 = ld(yb, xa), v11 = ld(yb, xb);
@@ -395,7 +404,7 @@ __global__ void __launch_bounds__(256) conv_stage_kernel(const gcpx_conv_args a)
                 v = ld(Y, X);
             }
         }
-        reinterpret_cast<float4*>(a.out)[i] = v;
+        reinterpret_cast<float4*>(a.out)[(size_t)p * C4 + cg / 4] = v;
     }
 }
 
@@ -860,6 +869,7 @@ extern "C" int gcpx_conv_stage(const gcpx_conv_args* a, void* stream_) {
     if (a->upsample) GCPX_CHECK_ARG(a->Hout == 2 * a->Hin && a->Wout == 2 * a->Win, "upsample: Hout != 2*Hin");
     else GCPX_CHECK_ARG(a->Hout == a->Hin && a->Wout == a->Win, "no upsample: Hout != Hin");
     const long long items = (long long)a->F * a->Hout * a->Wout * (a->Cin / 4);
+    GCPX_CHECK_ARG(256 % (a->Cin / 4) == 0 && (long long)a->F * a->Hout * a->Wout < (1LL << 31), "Cin / 4 must divide 256; < 2^31 pixels");
     hipLaunchKernelGGL(conv_stage_kernel, dim3(blocks_for(items, 16384)), dim3(256), 0, stream, *a);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
