@@ -467,3 +467,51 @@ def test_wgrad_group_matches_single_launches(env):
             assert_close(got, want, atol=2e-3, rtol=1e-4, name="grouped dW")
             one = outs[0].sum(0) if ns > 1 else outs[0]
             assert_close(got, one, atol=2e-4, rtol=1e-5, name="grouped vs single")
+
+
+@pytest.mark.parametrize("S,cin,cout,Fr,use_frames", [(32, 112, 16, 9, True), (32, 112, 16, 9, False), (64, 48, 16, 5, True),
+                                                      (32, 16, 32, 6, None), (64, 16, 32, 3, None)])
+def test_conv3x3_plain_row_maps(env, S, cin, cout, Fr, use_frames):
+    """Plain 3x3 conv (the data gradients of the training step): frames read source rows through src_row_map (negative: zeros);
+    with the inverse map from gcpx_index_inverse the wave-autonomous kernel walks the rows, without it the tiled kernel runs —
+    both against F.conv2d on the gathered rows.  A padded row that no frame reads must not leak into any frame."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(S + cin + Fr)
+    w = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5
+    wp, bd = pk.pack_conv3x3(w, 16).to(dev), torch.zeros(64, device=dev)
+    if use_frames is None:                                 # every frame has its own row
+        R, fmap = Fr, None
+    else:                                                  # frames 1, 4, ... have no row; one extra row (index 2) belongs to nobody
+        rows = [r for r in range(Fr) if r % 3 != 1]
+        R = len(rows) + 1
+        fmap = torch.full((Fr,), -1, dtype=torch.int32)
+        free = [r for r in range(R) if r != 2]
+        for f, r in zip(rows, free):
+            fmap[f] = r
+    x = torch.randn(R, cin, S, S)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = torch.full((Fr, S, S, cout), float("nan"), device=dev)
+    a = _conv_args(rt, [(xd, cin, 1, None, None, rt.ACT_NONE)], F=Fr, Hin=S, Win=S, Hout=S, Wout=S, Cout=cout, out_pitch=cout,
+                   upsample=0, head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out)
+    if fmap is not None:
+        fd = fmap.to(dev)
+        a.src_row_map = fd.data_ptr()
+        if use_frames:
+            inv = torch.full((R,), 12345, dtype=torch.int32, device=dev)
+            rt.check(lib.gcpx_index_inverse(fd.data_ptr(), Fr, inv.data_ptr(), R, _stream()), "index_inverse")
+            torch.cuda.synchronize()
+            want_inv = torch.full((R,), -1, dtype=torch.int32)
+            for f in range(Fr):
+                if fmap[f] >= 0:
+                    want_inv[fmap[f]] = f
+            assert torch.equal(inv.cpu(), want_inv)
+            a.src_row_frames, a.n_src_rows = inv.data_ptr(), R
+    rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "conv3x3 plain")
+    torch.cuda.synchronize()
+    full = F.conv2d(x, w, None, padding=1)
+    want = torch.zeros(Fr, cout, S, S)
+    for f in range(Fr):
+        r = f if fmap is None else int(fmap[f])
+        if r >= 0:
+            want[f] = full[r]
+    assert_close(out.permute(0, 3, 1, 2), want, atol=3e-5, rtol=1e-5, name="plain conv3x3")
