@@ -86,6 +86,33 @@ def test_cem_planner_runs_and_is_deterministic(setup):
     assert np.all(np.diff(res[0][4][0]) >= 0)            # elites come out sorted by cost
 
 
+def test_cem_scoring_without_decoder_is_identical(setup):
+    """The learned cost reads latents only (cost_fcn.py:84-97): scoring the candidates without running the image decoder gives
+    bit-identical costs, elites and returned plan as decoding every candidate (what the reference's simulator does)."""
+    from video_gcp_amd.planning import GCPImageSimulator, LearnedCostEstimate, SimpleTreeCEMSampler, CEMPlanner
+    hp, sd, model = setup
+    state, goal = _env_images(hp, 5)
+    res = []
+    for decode in (True, False):
+        sampler = SimpleTreeCEMSampler(float("inf"), None, hp.nz_vae, 1.0, n_level_hierarchy=hp.hierarchy_levels, device="cuda", seed=3)
+        planner = CEMPlanner(GCPImageSimulator(model), LearnedCostEstimate(model), sampler, n_iters=2, batch_size=16,
+                             elite_frac=0.25, max_seq_len=hp.max_seq_len, decode_candidates=decode)
+        s0 = sampler.sample(16)
+        scores, r = planner.evaluate(state, goal, s0)
+        assert (r.images is not None) == decode
+        plan, actions, latents, score = planner(state, goal)
+        res.append((scores.cpu().numpy(), plan, latents, score, [l.elite_scores.cpu().numpy() for l in planner.logs]))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
+    for a, b in zip(res[0][4], res[1][4]):
+        assert np.array_equal(a, b)
+    with pytest.raises(ValueError):                       # decode=False is a planner-only path
+        inputs, _, _ = make_inputs(hp, seed=0, variant="A")
+        with model.val_mode(decode=False):
+            model._sample_prior = False
+            model({k: v.cuda() for k, v in inputs.items()}, "train")
+
+
 def test_hierarchical_cem_planner(setup):
     """HierarchicalImageCEMPlanner flow (cem_planner.py:166-218) on the HIP model: one tree level fixed per iteration."""
     from video_gcp_amd.planning import GCPImageSimulator, LearnedCostEstimate, HierarchicalCEMPlanner

@@ -97,6 +97,7 @@ class GCPTreeModel:
         self._check_hp(hp)
         self._flatten_params(params or self._default_params(hp, seed))
         self.training = True                  # BatchNorm uses batch statistics (reference trains and validates so)
+        self._decode = True
         self._sample_prior = False            # ProbabilisticModel._sample_prior (switched by val_mode)
         self._use_pred_length = False
         self.materialize_distr = materialize_distr
@@ -157,13 +158,15 @@ class GCPTreeModel:
         return self.train(False)
 
     @contextmanager
-    def val_mode(self, pred_length=True):
-        """base_gcp.py:44-53: sample from the prior instead of the posterior."""
-        self._sample_prior, self._use_pred_length = True, pred_length
+    def val_mode(self, pred_length=True, decode=True):
+        """base_gcp.py:44-53: sample from the prior instead of the posterior.  decode=False (planner scoring): the latent tree,
+        pruning and the latent-space heads are computed but the image decoder is skipped — the learned planning cost only reads
+        latents (cost_fcn.py:84-97), images are decoded for the plan that is returned."""
+        self._sample_prior, self._use_pred_length, self._decode = True, pred_length, decode
         try:
             yield
         finally:
-            self._sample_prior, self._use_pred_length = False, False
+            self._sample_prior, self._use_pred_length, self._decode = False, False, True
 
     def state_dict(self):
         return dict(self.sd)
@@ -852,77 +855,79 @@ class GCPTreeModel:
             outs["existence"] = exist
         plan.lane = 0
 
-        # ---- dense_rec: decode every node (tree_dense_rec.py:41-44) ----
-        F = B * N
-        S = hp.img_sz
-        prev = self._plan_decoder_features(plan, self._rowsrc(_addr(E, nz), PS * nz, nz, nz), F, N, skips)
-        images = self._buf("images_df", (B, N, hp.input_nc, S, S))
-        distr = matched_distr = None
-        with_loss = key[7]
-        dlm = hp.decoder_distribution == "discrete_logistic_mixture"
-        head_out, row_map = None, None
-        if dlm:
-            mode = rt.HEAD_DLM_MEAN
-            if self.materialize_distr or (adaptive and self.save_for_backward and with_loss):
-                # (adaptive training: the backward of the mixture mean needs the raw parameters of every node)
-                mode, distr = rt.HEAD_DLM_BOTH, self._buf("distr_df", (B, N, S, S, self._head_pitch))
-                head_out = distr
-            elif with_loss and not adaptive:
-                # only the nodes matched to a ground-truth frame keep their distribution parameters
-                # (frame_binding.py:91-92): row b*T+t of matched_distr <- node matched to frame t
-                mode, matched_distr = rt.HEAD_DLM_BOTH, self._buf("matched_distr", (B, T, S, S, self._head_pitch))
-                head_out, row_map = matched_distr, node2row
-        else:
-            mode = rt.HEAD_TANH_NCHW
-        a = self._conv_args([prev], F, S, S, S, S, hp.head_channels, self._head_pitch, P["dec.head.w"], P["dec.head.b"],
-                            head_out, upsample=0, head_mode=mode, images=images)
-        a.raw_row_map = row_map.data_ptr() if row_map is not None else None
-        plan.keep.append(a)
-        if heads_lane:
-            plan.join([1])       # the latent-space heads overlapped the decoder blocks; the head runs alone
-        plan.add("dec.head", lib.gcpx_conv3x3, C.byref(a))
-        outs["images_df"], outs["distr_df_kernel_order"] = images, distr
+        decode, with_loss = key[8], key[7]
+        if decode:
+            # ---- dense_rec: decode every node (tree_dense_rec.py:41-44) ----
+            F = B * N
+            S = hp.img_sz
+            prev = self._plan_decoder_features(plan, self._rowsrc(_addr(E, nz), PS * nz, nz, nz), F, N, skips)
+            images = self._buf("images_df", (B, N, hp.input_nc, S, S))
+            distr = matched_distr = None
+            with_loss = key[7]
+            dlm = hp.decoder_distribution == "discrete_logistic_mixture"
+            head_out, row_map = None, None
+            if dlm:
+                mode = rt.HEAD_DLM_MEAN
+                if self.materialize_distr or (adaptive and self.save_for_backward and with_loss):
+                    # (adaptive training: the backward of the mixture mean needs the raw parameters of every node)
+                    mode, distr = rt.HEAD_DLM_BOTH, self._buf("distr_df", (B, N, S, S, self._head_pitch))
+                    head_out = distr
+                elif with_loss and not adaptive:
+                    # only the nodes matched to a ground-truth frame keep their distribution parameters
+                    # (frame_binding.py:91-92): row b*T+t of matched_distr <- node matched to frame t
+                    mode, matched_distr = rt.HEAD_DLM_BOTH, self._buf("matched_distr", (B, T, S, S, self._head_pitch))
+                    head_out, row_map = matched_distr, node2row
+            else:
+                mode = rt.HEAD_TANH_NCHW
+            a = self._conv_args([prev], F, S, S, S, S, hp.head_channels, self._head_pitch, P["dec.head.w"], P["dec.head.b"],
+                                head_out, upsample=0, head_mode=mode, images=images)
+            a.raw_row_map = row_map.data_ptr() if row_map is not None else None
+            plan.keep.append(a)
+            if heads_lane:
+                plan.join([1])       # the latent-space heads overlapped the decoder blocks; the head runs alone
+            plan.add("dec.head", lib.gcpx_conv3x3, C.byref(a))
+            outs["images_df"], outs["distr_df_kernel_order"] = images, distr
 
-        # ---- pruning / matching gathers of decoded frames ----
-        row = hp.input_nc * S * S
-        if matching:
-            # AdaptiveBinding.get_w (adaptive.py:32-60): image cost matrix -> soft-DTW posterior over alignments -> w
-            ns = lib.gcpx_cdist_splits(row)
-            dsum = self._buf("cdist.dsum", (B, N, T))
-            plan.add("cdist", lib.gcpx_cdist, images.data_ptr(), tin["traj_seq"].data_ptr(), B, N, T, row,
-                     self._buf("cdist.part", (ns, B, N, T)).data_ptr(), self._buf("cdist.xn", (B * N,)).data_ptr(),
-                     self._buf("cdist.yn", (B * T,)).data_ptr(), dsum.data_ptr())
-            wdf = self._buf("match_dist_df", (B, N, T))
-            temp = self.sd["tree_module.tree_modules.0.binding.temp"]
-            plan.add("soft_dtw", lib.gcpx_soft_dtw, dsum.data_ptr(), C.c_float(float(row)), temp.data_ptr(), tin["end_ind"].data_ptr(),
-                     B, N, T, self._buf("dtw.acc", (2 * B, N, T), torch.float64).data_ptr(), wdf.data_ptr())
-            matched_idx = self._buf("matched_idx", (B, T), torch.int32)
-            best_t = self._buf("best_t", (B, N), torch.int32)
-            entropy, p_n = self._buf("entropy", (B, N)), self._buf("p_n", (B, N))
-            plan.add("match_stats", lib.gcpx_match_stats, wdf.data_ptr(), tin["end_ind"].data_ptr(), B, L, T, f2n.data_ptr(),
-                     matched_idx.data_ptr(), best_t.data_ptr(), entropy.data_ptr(), p_n.data_ptr())
-            dist_tgt = self._buf("distance_target", (B, N - 1), torch.int32)
-            plan.add("distance_target", lib.gcpx_distance_prune, outs["distances"].data_ptr(),
-                     C.c_float(hp.learned_pruning_threshold), best_t.data_ptr(), B, N, leave.data_ptr(), kept_idx.data_ptr(),
-                     outs["pruned_len"].data_ptr(), dist_tgt.data_ptr())
-            plan.add("seq_len", lib.gcpx_seq_index, tin["end_ind"].data_ptr(), B, T, self._buf("seq_idx", (B, T), torch.int32).data_ptr(),
-                     seq_len.data_ptr())
-            plan_aux(matched_idx, T)                     # get_matched_pruned_seqs for 'dtw' (base_gcp.py:358-366)
-            ent_sum = self._buf("entropy_sum", (1,))
-            plan.add("entropy_sum", lib.gcpx_reduce_partials, entropy.data_ptr(), B * N, 1, 1, ent_sum.data_ptr(), 0)
-            outs["entropy_sum"] = ent_sum
-            outs.update(cdist_sum=dsum, match_dist_df=wdf, matched_idx=matched_idx, best_t=best_t, entropy_df=entropy, p_n_df=p_n,
-                        distance_target=dist_tgt, aux_len=seq_len)
-        elif has_traj and phase == "train":
-            matched = self._buf("matched_images", (B, T, hp.input_nc, S, S))
-            plan.add("gather.matched", lib.gcpx_gather_rows, images.data_ptr(), f2n.data_ptr(), matched.data_ptr(), B, T, N,
-                     0, row)
-            outs["soft_matched_estimates"] = matched
-        Wp = N if adaptive else T
-        pruned = self._buf("pruned_images", (B, Wp, hp.input_nc, S, S))
-        plan.add("gather.pruned", lib.gcpx_gather_rows, images.data_ptr(), kept_idx.data_ptr(), pruned.data_ptr(), B, Wp, N, 0,
-                 row)
-        outs["pruned_padded"] = pruned
+            # ---- pruning / matching gathers of decoded frames ----
+            row = hp.input_nc * S * S
+            if matching:
+                # AdaptiveBinding.get_w (adaptive.py:32-60): image cost matrix -> soft-DTW posterior over alignments -> w
+                ns = lib.gcpx_cdist_splits(row)
+                dsum = self._buf("cdist.dsum", (B, N, T))
+                plan.add("cdist", lib.gcpx_cdist, images.data_ptr(), tin["traj_seq"].data_ptr(), B, N, T, row,
+                         self._buf("cdist.part", (ns, B, N, T)).data_ptr(), self._buf("cdist.xn", (B * N,)).data_ptr(),
+                         self._buf("cdist.yn", (B * T,)).data_ptr(), dsum.data_ptr())
+                wdf = self._buf("match_dist_df", (B, N, T))
+                temp = self.sd["tree_module.tree_modules.0.binding.temp"]
+                plan.add("soft_dtw", lib.gcpx_soft_dtw, dsum.data_ptr(), C.c_float(float(row)), temp.data_ptr(), tin["end_ind"].data_ptr(),
+                         B, N, T, self._buf("dtw.acc", (2 * B, N, T), torch.float64).data_ptr(), wdf.data_ptr())
+                matched_idx = self._buf("matched_idx", (B, T), torch.int32)
+                best_t = self._buf("best_t", (B, N), torch.int32)
+                entropy, p_n = self._buf("entropy", (B, N)), self._buf("p_n", (B, N))
+                plan.add("match_stats", lib.gcpx_match_stats, wdf.data_ptr(), tin["end_ind"].data_ptr(), B, L, T, f2n.data_ptr(),
+                         matched_idx.data_ptr(), best_t.data_ptr(), entropy.data_ptr(), p_n.data_ptr())
+                dist_tgt = self._buf("distance_target", (B, N - 1), torch.int32)
+                plan.add("distance_target", lib.gcpx_distance_prune, outs["distances"].data_ptr(),
+                         C.c_float(hp.learned_pruning_threshold), best_t.data_ptr(), B, N, leave.data_ptr(), kept_idx.data_ptr(),
+                         outs["pruned_len"].data_ptr(), dist_tgt.data_ptr())
+                plan.add("seq_len", lib.gcpx_seq_index, tin["end_ind"].data_ptr(), B, T, self._buf("seq_idx", (B, T), torch.int32).data_ptr(),
+                         seq_len.data_ptr())
+                plan_aux(matched_idx, T)                     # get_matched_pruned_seqs for 'dtw' (base_gcp.py:358-366)
+                ent_sum = self._buf("entropy_sum", (1,))
+                plan.add("entropy_sum", lib.gcpx_reduce_partials, entropy.data_ptr(), B * N, 1, 1, ent_sum.data_ptr(), 0)
+                outs["entropy_sum"] = ent_sum
+                outs.update(cdist_sum=dsum, match_dist_df=wdf, matched_idx=matched_idx, best_t=best_t, entropy_df=entropy, p_n_df=p_n,
+                            distance_target=dist_tgt, aux_len=seq_len)
+            elif has_traj and phase == "train":
+                matched = self._buf("matched_images", (B, T, hp.input_nc, S, S))
+                plan.add("gather.matched", lib.gcpx_gather_rows, images.data_ptr(), f2n.data_ptr(), matched.data_ptr(), B, T, N,
+                         0, row)
+                outs["soft_matched_estimates"] = matched
+            Wp = N if adaptive else T
+            pruned = self._buf("pruned_images", (B, Wp, hp.input_nc, S, S))
+            plan.add("gather.pruned", lib.gcpx_gather_rows, images.data_ptr(), kept_idx.data_ptr(), pruned.data_ptr(), B, Wp, N, 0,
+                     row)
+            outs["pruned_padded"] = pruned
 
         # ---- losses (base_gcp.py:264-304, tree_module.py:116-157) ----
         if with_loss:
@@ -978,7 +983,7 @@ class GCPTreeModel:
 
         outs.update(E=E, Hid=Hid, Z=Z, PZ=PZ, QZ=QZ, node_t=node_t, leave=leave, frame2node=f2n, seq_len=seq_len,
                     kept_idx=kept_idx, enc_traj_seq=enc_traj, inf_enc_seq=inf_enc, node2row=node2row, etilde_row=etrow)
-        plan.rec.update(head_src=prev, tin=tin, key=key)
+        plan.rec.update(head_src=(prev if decode else None), tin=tin, key=key)
         if with_loss:
             plan.rec["loss_args"] = la
         plan.outs = outs
@@ -1029,7 +1034,9 @@ class GCPTreeModel:
                     eps.copy_(noise)
                     noise.record_stream(self._stream)
                 tin["eps"] = eps
-        key = (B, has_traj, has_z, self._sample_prior, phase, self.training, self.materialize_distr, with_loss)
+        if not self._decode and (with_loss or has_traj):
+            raise ValueError("decode=False is the planner's prior / given-z path: no ground-truth sequence, no losses")
+        key = (B, has_traj, has_z, self._sample_prior, phase, self.training, self.materialize_distr, with_loss, self._decode)
         if key not in self._plans:
             plan = self._build_plan(key, tin)
             plan.keep.append(tin)
@@ -1116,7 +1123,7 @@ class GCPTreeModel:
         out = Outputs()
         out.end_ind = tin["end_ind"]
         out.raw = o
-        out.images_df = o["images_df"]
+        out.images_df = o.get("images_df")            # None after val_mode(decode=False)
         if "seq_len_logits" in o:
             out.seq_len_logits = o["seq_len_logits"]
         if "existence" in o:

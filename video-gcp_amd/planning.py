@@ -43,20 +43,26 @@ class GCPImageSimulator:
         self._model = model
         self._append_latent = append_latent
 
-    def rollout_device(self, state, goal_state, samples, rollout_len):
+    def rollout_device(self, state, goal_state, samples, rollout_len, decode=True):
         """Device-resident rollout.  state/goal_state: env images [1,H,W,3]; samples [n, N, nz_vae] (depth-first node
-        order, tree.py:38).  Returns padded device tensors + lengths."""
+        order, tree.py:38).  Returns padded device tensors + lengths.  decode=False: latents only (images = None) — what the
+        CEM scoring loop needs; the decoder is 3/4 of the rollout's FLOPs."""
         m = self._model
         n = samples.shape[0]
-        I0 = env2planner(np.repeat(np.asarray(state), n, 0) if not torch.is_tensor(state) else state.repeat(n, 1, 1, 1))
-        Ig = env2planner(np.repeat(np.asarray(goal_state), n, 0) if not torch.is_tensor(goal_state) else goal_state.repeat(n, 1, 1, 1))
+        # the (single) start / goal image is converted once and broadcast on the device (cem_simulator.py:18 repeats it on the host:
+        # 512 x 64 x 64 x 3 numpy copies + two 25 MB pageable uploads were 42 ms of a 60 ms scoring rollout)
+        def bcast(img):
+            t = env2planner(np.asarray(img) if not torch.is_tensor(img) else img).to(m.device)
+            assert t.shape[0] in (1, n), "one image for all candidates, or one per candidate"
+            return t.expand(n, *t.shape[1:]) if t.shape[0] == 1 else t
+        I0, Ig = bcast(state), bcast(goal_state)
         z = torch.as_tensor(samples, dtype=torch.float32, device=m.device)
-        inp = dict(I_0=I0.to(m.device), I_g=Ig.to(m.device), z=z,
+        inp = dict(I_0=I0, I_g=Ig, z=z,
                    end_ind=torch.full((n,), rollout_len - 1, dtype=torch.long, device=m.device))
-        with m.val_mode(pred_length=False):
+        with m.val_mode(pred_length=False, decode=decode):
             out = m(inp, "train")                    # cem_simulator.py:29-31 (phase defaults to 'train', SURVEY D4)
         raw = out.raw
-        return Outputs(images=raw["pruned_padded"], latents=raw["model_enc_seq_padded"], lengths=raw["seq_len"],
+        return Outputs(images=raw.get("pruned_padded"), latents=raw["model_enc_seq_padded"], lengths=raw["seq_len"],
                        actions=raw.get("actions_padded"), states=raw.get("regressed_state_padded"),
                        e_goal=raw["E"][:, -1], out=out)
 
@@ -171,7 +177,11 @@ class CEMPlanner:
     """Flat CEM over tree latents with device-resident rollouts and sharded candidates (cem_planner.py:55-135)."""
 
     def __init__(self, simulator, cost, sampler, n_iters=3, batch_size=512, elite_frac=0.1, max_seq_len=80,
-                 goal_in_cost=True):
+                 goal_in_cost=True, decode_candidates=False):
+        # decode_candidates: also decode the images of every candidate while scoring (what the reference's simulator does,
+        # cem_simulator.py:29-59).  The learned cost reads latents only, so by default the images are decoded once, for the
+        # plan that is returned; scores, elites and the returned plan are the same either way.
+        self.decode_candidates = decode_candidates
         self._sim, self._cost, self._sampler = simulator, cost, sampler
         self.n_iters, self.batch_size, self.elite_frac, self.max_seq_len = n_iters, batch_size, elite_frac, max_seq_len
         self.goal_in_cost = goal_in_cost
@@ -187,7 +197,7 @@ class CEMPlanner:
     def evaluate(self, state, goal_state, samples):
         """costs [n] of all candidates: this rank rolls out its slice, one all-gather assembles the vector."""
         lo, per = self._shard(samples.shape[0])
-        r = self._sim.rollout_device(state, goal_state, samples[lo:lo + per], self.max_seq_len)
+        r = self._sim.rollout_device(state, goal_state, samples[lo:lo + per], self.max_seq_len, decode=self.decode_candidates)
         local = self._cost.sequence_cost_device(r.latents, r.lengths, r.e_goal if self.goal_in_cost else None)
         return D.all_gather_costs(local), r
 
