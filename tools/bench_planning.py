@@ -39,7 +39,7 @@ for _ in range(args.iters):
 torch.cuda.synchronize(); D.barrier()
 dt = D.max_over_ranks(time.perf_counter() - t0, device="cuda")
 if rank == 0:
-    print(json.dumps({"workload": "CEM iteration, 512 candidates x horizon 80 (gcp_tree, 64x64, L=7), eval-mode BN, prior path with given z",
+    print(json.dumps({"workload": "CEM iteration, 512 candidates x horizon 80 (gcp_tree, 64x64, L=7), eval-mode BN, prior path with given z; candidates scored on latents (planner default: the decoder runs for the returned plan only)",
                       "n_gpus": world, "candidates_per_s": round(args.candidates * args.iters / dt, 1),
                       "predicted_frames_per_s": round(args.candidates * hp.max_seq_len * args.iters / dt, 1),
                       "ms_per_iteration": round(1e3 * dt / args.iters, 2), "candidates_per_gpu": args.candidates // world}))
