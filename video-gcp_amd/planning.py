@@ -39,6 +39,8 @@ def env2planner(img):
 class GCPImageSimulator:
     """Simulator interface of the planner: candidate latents -> model rollouts."""
 
+    supports_latent_only = True      # rollout_device(..., decode=False) skips the image decoder
+
     def __init__(self, model, append_latent=True):
         self._model = model
         self._append_latent = append_latent
@@ -197,7 +199,10 @@ class CEMPlanner:
     def evaluate(self, state, goal_state, samples):
         """costs [n] of all candidates: this rank rolls out its slice, one all-gather assembles the vector."""
         lo, per = self._shard(samples.shape[0])
-        r = self._sim.rollout_device(state, goal_state, samples[lo:lo + per], self.max_seq_len, decode=self.decode_candidates)
+        if getattr(self._sim, "supports_latent_only", False):
+            r = self._sim.rollout_device(state, goal_state, samples[lo:lo + per], self.max_seq_len, decode=self.decode_candidates)
+        else:                                            # any simulator with the reference's interface
+            r = self._sim.rollout_device(state, goal_state, samples[lo:lo + per], self.max_seq_len)
         local = self._cost.sequence_cost_device(r.latents, r.lengths, r.e_goal if self.goal_in_cost else None)
         return D.all_gather_costs(local), r
 
