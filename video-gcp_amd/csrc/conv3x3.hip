@@ -591,8 +591,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
         // the wavefront that is in its MFMA phase outranks its SIMD partner's staging / epilogue VALU work
         __builtin_amdgcn_s_setprio(1);
         step(0, std::true_type{});
+        step(1, std::false_type{});
+        step(2, std::false_type{});
 #pragma unroll 1
-        for (int tap = 1; tap < 9; ++tap) step(tap, std::false_type{});
+        for (int tap = 3; tap < 9; tap += 3) {
+            step(tap, std::false_type{});
+            step(tap + 1, std::false_type{});
+            step(tap + 2, std::false_type{});
+        }
         __builtin_amdgcn_s_setprio(0);
 
         // ---- epilogue ----
