@@ -192,6 +192,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
 struct TileChoice { int pr, cr; };
 
 TileChoice choose_tile(int M, int N, int nb = 1) {
+    if (const char* ov = getenv("GCPX_GEMM_TILE")) {           // tuning aid: "pr,cr,minM" (also seen by gcpx_gemm_row_blocks)
+        int pr = 0, cr = 0, mm = 0;
+        if (sscanf(ov, "%d,%d,%d", &pr, &cr, &mm) == 3 && M >= mm && N % (16 * cr) == 0) return TileChoice{pr, cr};
+    }
     const int prs[3] = {4, 2, 1}, crs[3] = {4, 2, 1};
     TileChoice best{1, 1};
     long best_wg = -1;
@@ -254,11 +258,7 @@ extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
         GCPX_CHECK_ARG(a->out != nullptr, "out is NULL");
     }
     GCPX_CHECK_ARG(a->nbatch <= 1 || (a->epi != GCPX_EPI_LSTM && !a->stats_partial), "nbatch > 1 only for plain epilogues");
-    TileChoice t = choose_tile(a->M, a->N, a->nbatch > 1 ? a->nbatch : 1);
-    if (const char* ov = getenv("GCPX_GEMM_TILE")) {           // tuning aid: "pr,cr,minM"
-        int pr = 0, cr = 0, mm = 0;
-        if (sscanf(ov, "%d,%d,%d", &pr, &cr, &mm) == 3 && a->M >= mm && a->N % (16 * cr) == 0) t = TileChoice{pr, cr};
-    }
+    const TileChoice t = choose_tile(a->M, a->N, a->nbatch > 1 ? a->nbatch : 1);
     if (t.pr == 1 && t.cr == 1 && a->K >= 256 && !getenv("GCPX_GEMM_NOKS")) {
         // few rows: split K over the wavefronts of a workgroup when that still leaves the launch small
         const long nb = a->nbatch > 1 ? a->nbatch : 1;
