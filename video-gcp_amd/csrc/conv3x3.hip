@@ -487,10 +487,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_kernel(const gcpx_conv_ar
 
     float4 pre[NS];
     unsigned pre_ok = 0;
+    // items of a frame are walked column-block-major (top to bottom inside a 16-pixel column block): the two halo rows an item
+    // shares with the one below are re-read by the very next item of the same wavefront (cache hit) — strip-major order put them
+    // 4 items apart, beyond the L1 and, summed over a die, the L2
     auto origin = [&](int it, int& f, int& y0, int& x0) {
-        const int cb = it % ncb;
-        const int t = it / ncb;
-        y0 = (t % nrp) * 4; f = t / nrp; x0 = cb * 16;
+        const int strip = it % nrp;
+        const int t = it / nrp;
+        y0 = strip * 4; f = t / ncb; x0 = (t % ncb) * 16;
     };
     int s_ry[NS], s_rx[NS];                               // staging slot -> (row, col) of the region, tile independent
 #pragma unroll
