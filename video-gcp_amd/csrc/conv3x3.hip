@@ -1030,10 +1030,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_up16_kernel(const gcpx_conv_ar
     int item = gw * items_per_wave;
     const int item_end = min(item + items_per_wave, nitems);
 
-    auto origin = [&](int it, int& f, int& y0, int& x0) {
-        const int cb = it % ncb;
-        const int t = it / ncb;
-        y0 = (t % nrq) * 4; f = t / nrq; x0 = cb * 16;
+    auto origin = [&](int it, int& f, int& y0, int& x0) {          // column-block-major inside a frame (see the head kernel)
+        const int strip = it % nrq;
+        const int t = it / nrq;
+        y0 = strip * 4; f = t / ncb; x0 = (t % ncb) * 16;
     };
     // raw-patch slot k of this lane: float4 index lane + 64k -> (row, col, 4-channel group); tile independent
     int s_ry[NS], s_rx[NS];
