@@ -204,10 +204,11 @@ __global__ void __launch_bounds__(256) cdist_finish_kernel(const float* __restri
 // 'nohor' transitions only come from the previous row, so a row is computed in parallel: thread j keeps D[i-1][j] in a
 // register and reads D[i-1][j-1] from LDS.  Same recurrence as the reference's anti-diagonal sweep.
 // ---------------------------------------------------------------------------------------------------
+// log(e^a + e^b) = max + log1p(e^{-|a - b|}): one exp + one log1p in float64 on the dependent chain instead of two exp + log
 __device__ __forceinline__ double lse2(const double a, const double b) {
-    double m = fmax(a, b);
-    if (isinf(m)) m = 0.0;
-    return log(exp(a - m) + exp(b - m)) + m;
+    const double m = fmax(a, b), n = fmin(a, b);
+    if (isinf(m)) return m;                                 // both -inf (or one +inf): the sum is m
+    return m + log1p(exp(n - m));
 }
 
 __device__ __forceinline__ double neg_cost(const float dsum, const float D, const float temp) {
@@ -229,11 +230,16 @@ __global__ void dtw_sweep_kernel(const float* __restrict__ dsum, const float D, 
     double* Ab = acc + (size_t)blockIdx.x * r * c;
     const int sj = dir ? c - 1 - j : j;
     double prev = -INFINITY;
+    // the cost of row i + 1 is requested before row i is computed: the row step is a dependent chain (LDS exchange + barrier),
+    // the global load must not sit on it
+    float cnext = (j < c) ? Cb[(size_t)(dir ? r - 1 : 0) * c + sj] : 0.f;
     for (int i = 0; i < r; ++i) {
         const int si = dir ? r - 1 - i : i;
         double cur = -INFINITY;
+        const float craw = cnext;
+        if (j < c && i + 1 < r) cnext = Cb[(size_t)(dir ? r - 2 - i : i + 1) * c + sj];
         if (j < c) {
-            const double cij = neg_cost(Cb[(size_t)si * c + sj], D, temp);
+            const double cij = neg_cost(craw, D, temp);
             if (i == 0) {
                 cur = (j == begin) ? cij : -INFINITY;
             } else {
@@ -253,8 +259,10 @@ __global__ void dtw_sweep_kernel(const float* __restrict__ dsum, const float D, 
 __global__ void dtw_combine_kernel(const float* __restrict__ dsum, const float D, const float* __restrict__ temp_p,
                                    const int64_t* __restrict__ end_ind, const double* __restrict__ acc, float* __restrict__ w,
                                    const int B, const int r, const int c) {
-    const int b = blockIdx.x, t = threadIdx.x;
-    if (t >= c) return;
+    // blockDim = (cp, G): thread (t, g) takes the nodes n = g, g + G, ... of frame t; the G partial column sums are combined in a
+    // fixed order
+    extern __shared__ float csum[];                     // [G][cp]
+    const int b = blockIdx.x, t = threadIdx.x, g = threadIdx.y, cp = blockDim.x, G = blockDim.y;
     const float temp = temp_p[0];
     const double* F = acc + (size_t)b * r * c;
     const double* Bw = acc + (size_t)(B + b) * r * c;
@@ -262,15 +270,22 @@ __global__ void dtw_combine_kernel(const float* __restrict__ dsum, const float D
     float* wb = w + (size_t)b * r * c;
     const double z = F[(size_t)(r - 1) * c + (int)end_ind[b]];
     float colsum = 0.f;
-    for (int n = 0; n < r; ++n) {
-        const size_t o = (size_t)n * c + t;
-        const double e = F[o] + Bw[o] - neg_cost(Cb[o], D, temp);
-        const float wv = (float)exp(e - z);
-        wb[o] = wv;
-        colsum += wv;
+    if (t < c) {
+        for (int n = g; n < r; n += G) {
+            const size_t o = (size_t)n * c + t;
+            const double e = F[o] + Bw[o] - neg_cost(Cb[o], D, temp);
+            const float wv = (float)exp(e - z);
+            wb[o] = wv;
+            colsum += wv;
+        }
     }
-    const float den = fmaxf(colsum, 1e-7f);
-    for (int n = 0; n < r; ++n) wb[(size_t)n * c + t] /= den;
+    csum[g * cp + t] = colsum;
+    __syncthreads();
+    if (t >= c) return;
+    float tot = 0.f;
+    for (int k = 0; k < G; ++k) tot += csum[k * cp + t];
+    const float den = fmaxf(tot, 1e-7f);
+    for (int n = g; n < r; n += G) wb[(size_t)n * c + t] /= den;
 }
 
 // breadth-first index q -> depth-first position
@@ -777,7 +792,9 @@ extern "C" int gcpx_soft_dtw(const float* dsum, float D, const float* temp, cons
     const int threads = (T + 63) / 64 * 64;
     hipLaunchKernelGGL(dtw_sweep_kernel, dim3(2 * B), dim3(threads), 2 * threads * sizeof(double), stream, dsum, D, temp, end_ind,
                        acc, B, N, T);
-    hipLaunchKernelGGL(dtw_combine_kernel, dim3(B), dim3(threads), 0, stream, dsum, D, temp, end_ind, acc, w, B, N, T);
+    const int G = threads <= 256 ? 4 : (threads <= 512 ? 2 : 1);
+    hipLaunchKernelGGL(dtw_combine_kernel, dim3(B), dim3(threads, G), G * threads * sizeof(float), stream, dsum, D, temp, end_ind, acc, w,
+                       B, N, T);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }
