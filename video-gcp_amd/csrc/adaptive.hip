@@ -295,84 +295,120 @@ __device__ __forceinline__ int bf2df(const int q, const int L) {
     return (2 * jj + 1) * (1 << (L - 1 - l)) - 1;
 }
 
+// The bookkeeping kernels below give every output row to ONE WAVEFRONT whose lanes stride over the reduced axis (the first
+// versions looped serially per thread: 200 - 255 dependent loads each, 55 - 90 us per launch on an otherwise idle GPU at the tail of
+// the adaptive forward).  Reductions are butterflies in a fixed order; arg-max ties resolve to the smaller index like the serial loop.
+
 // per frame: node with the largest matching probability, first maximum in breadth-first order (frame_binding.py:30)
 __global__ void __launch_bounds__(256) match_argmax_kernel(const float* __restrict__ w, const int64_t* __restrict__ end_ind,
                                                            int32_t* __restrict__ frame2node, int32_t* __restrict__ matched_idx,
                                                            const int B, const int L, const int T) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B * T) return;
     const int b = i / T, t = i % T;
     const int N = (1 << L) - 1;
     const float* wb = w + (size_t)b * N * T + t;
     float best = -INFINITY;
-    int bp = 0;
-    for (int q = 0; q < N; ++q) {
-        const int p = bf2df(q, L);
-        const float v = wb[(size_t)p * T];
-        if (v > best) { best = v; bp = p; }
+    int bq = 0x7fffffff;
+    for (int q = lane; q < N; q += 64) {                  // increasing q inside a lane: strict > keeps the first maximum
+        const float v = wb[(size_t)bf2df(q, L) * T];
+        if (v > best) { best = v; bq = q; }
     }
-    frame2node[i] = bp;
-    if (matched_idx) matched_idx[i] = t <= (int)end_ind[b] ? bp : -1;
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oq = __shfl_xor(bq, o);
+        if (ov > best || (ov == best && oq < bq)) { best = ov; bq = oq; }
+    }
+    if (lane == 0) {
+        const int bp = (bq == 0x7fffffff) ? 0 : bf2df(bq, L);
+        frame2node[i] = bp;
+        if (matched_idx) matched_idx[i] = t <= (int)end_ind[b] ? bp : -1;
+    }
 }
 
 // per node: best frame (first maximum), entropy of its matching distribution, existence probability (tree_module.py:145-147)
 __global__ void __launch_bounds__(256) match_node_stats_kernel(const float* __restrict__ w, int32_t* __restrict__ best_t,
                                                                float* __restrict__ entropy, float* __restrict__ p_n,
                                                                const int BN, const int T) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= BN) return;
     const float* wr = w + (size_t)i * T;
     float best = -INFINITY, ent = 0.f, s = 0.f;
-    int bt = 0;
-    for (int t = 0; t < T; ++t) {
+    int bt = 0x7fffffff;
+    for (int t = lane; t < T; t += 64) {
         const float v = wr[t];
         if (v > best) { best = v; bt = t; }
         if (v > 0.f) ent -= v * logf(v);
         s += v;
     }
-    best_t[i] = bt;
-    entropy[i] = ent;
-    p_n[i] = fminf(fmaxf(s, 0.f), 1.f);
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int ot = __shfl_xor(bt, o);
+        if (ov > best || (ov == best && ot < bt)) { best = ov; bt = ot; }
+        ent += __shfl_xor(ent, o);
+        s += __shfl_xor(s, o);
+    }
+    if (lane == 0) {
+        best_t[i] = (bt == 0x7fffffff) ? 0 : bt;
+        entropy[i] = ent;
+        p_n[i] = fminf(fmaxf(s, 0.f), 1.f);
+    }
 }
 
 // learned pruning (adaptive.py:62-77): keep node p unless sigmoid(distance[p-1]) > threshold; compaction of kept positions;
-// BCE target 1 where consecutive nodes share their best frame (adaptive.py:118-122)
-__global__ void distance_prune_kernel(const float* __restrict__ dist, const float thr, const int32_t* __restrict__ best_t,
-                                      int32_t* __restrict__ leave, int32_t* __restrict__ kept_idx, int32_t* __restrict__ count,
-                                      int32_t* __restrict__ target, const int B, const int N) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// BCE target 1 where consecutive nodes share their best frame (adaptive.py:118-122).  One wavefront per sequence: 64 nodes per
+// trip, compaction by ballot + popcount (order preserved).
+__global__ void __launch_bounds__(64) distance_prune_kernel(const float* __restrict__ dist, const float thr, const int32_t* __restrict__ best_t,
+                                                            int32_t* __restrict__ leave, int32_t* __restrict__ kept_idx,
+                                                            int32_t* __restrict__ count, int32_t* __restrict__ target, const int B,
+                                                            const int N) {
+    const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= B) return;
     int k = 0;
-    for (int p = 0; p < N; ++p) {
-        int keep = 1;
-        if (p > 0) {
-            const float x = dist[(size_t)b * (N - 1) + p - 1];
-            keep = !(1.f / (1.f + expf(-x)) > thr);
-            if (target) target[(size_t)b * (N - 1) + p - 1] = best_t[(size_t)b * N + p] == best_t[(size_t)b * N + p - 1];
+    for (int p0 = 0; p0 < N; p0 += 64) {
+        const int p = p0 + lane;
+        int keep = 0;
+        if (p < N) {
+            keep = 1;
+            if (p > 0) {
+                const float x = dist[(size_t)b * (N - 1) + p - 1];
+                keep = !(1.f / (1.f + expf(-x)) > thr);
+                if (target) target[(size_t)b * (N - 1) + p - 1] = best_t[(size_t)b * N + p] == best_t[(size_t)b * N + p - 1];
+            }
+            leave[(size_t)b * N + p] = keep;
         }
-        leave[(size_t)b * N + p] = keep;
-        if (keep) kept_idx[(size_t)b * N + k++] = p;
+        const unsigned long long m = __ballot(keep);
+        if (keep) kept_idx[(size_t)b * N + k + __popcll(m & ((1ull << lane) - 1ull))] = p;
+        k += __popcll(m);
     }
-    count[b] = k;
-    for (; k < N; ++k) kept_idx[(size_t)b * N + k] = -1;
+    if (lane == 0) count[b] = k;
+    for (int q = k + lane; q < N; q += 64) kept_idx[(size_t)b * N + q] = -1;
 }
 
 // LossAveragingCriterion (binding_loss.py:19-42): nll_bt[b][t] = sum_n w[b][n][t] * (0.5 * d * exp(-ls)^2 + D * (ls + 0.5 log 2pi))
 __global__ void __launch_bounds__(256) averaging_nll_kernel(const float* __restrict__ dsum, const float* __restrict__ w,
                                                             const float* __restrict__ log_sigma, const float D,
                                                             float* __restrict__ nll_bt, const int B, const int N, const int T) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * T) return;
-    const int b = i / T, t = i % T;
+    // workgroup = 64 consecutive frames of one sequence x 4 node groups: coalesced rows, 4 partial sums combined in a fixed order
+    __shared__ float part[4][64];
+    const int tl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int tb = (T + 63) / 64;
+    const int b = blockIdx.x / tb, t = (blockIdx.x % tb) * 64 + tl;
     const float ls = log_sigma[0];
     const float iv = expf(-ls), c0 = D * (ls + 0.91893853320467274178f);
-    const size_t base = (size_t)b * N * T + t;
     float s = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const size_t o = base + (size_t)n * T;
-        s += (0.5f * dsum[o] * (iv * iv) + c0) * w[o];
+    if (t < T) {
+        const size_t base = (size_t)b * N * T + t;
+        for (int n = g; n < N; n += 4) {
+            const size_t o = base + (size_t)n * T;
+            s += (0.5f * dsum[o] * (iv * iv) + c0) * w[o];
+        }
     }
-    nll_bt[i] = s;
+    part[g][tl] = s;
+    __syncthreads();
+    if (g == 0 && t < T) nll_bt[(size_t)b * T + t] = (part[0][tl] + part[1][tl]) + (part[2][tl] + part[3][tl]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -805,8 +841,8 @@ extern "C" int gcpx_match_stats(const float* w, const int64_t* end_ind, int32_t 
     GCPX_CHECK_ARG(w && end_ind && frame2node && best_t && entropy && p_n, "null pointer");
     GCPX_CHECK_ARG(B > 0 && L > 0 && L < 16 && T > 0, "bad sizes");
     const int N = (1 << L) - 1;
-    hipLaunchKernelGGL(match_argmax_kernel, dim3((B * T + 255) / 256), dim3(256), 0, stream, w, end_ind, frame2node, matched_idx, B, L, T);
-    hipLaunchKernelGGL(match_node_stats_kernel, dim3((B * N + 255) / 256), dim3(256), 0, stream, w, best_t, entropy, p_n, B * N, T);
+    hipLaunchKernelGGL(match_argmax_kernel, dim3((B * T + 3) / 4), dim3(256), 0, stream, w, end_ind, frame2node, matched_idx, B, L, T);
+    hipLaunchKernelGGL(match_node_stats_kernel, dim3((B * N + 3) / 4), dim3(256), 0, stream, w, best_t, entropy, p_n, B * N, T);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }
@@ -816,7 +852,7 @@ extern "C" int gcpx_distance_prune(const float* dist, float threshold, const int
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(dist && leave && kept_idx && count && B > 0 && N > 1, "null pointer / bad sizes");
     GCPX_CHECK_ARG(!target || best_t, "targets need best_t");
-    hipLaunchKernelGGL(distance_prune_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, dist, threshold, best_t, leave, kept_idx, count,
+    hipLaunchKernelGGL(distance_prune_kernel, dim3(B), dim3(64), 0, stream, dist, threshold, best_t, leave, kept_idx, count,
                        target, B, N);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
@@ -826,7 +862,7 @@ extern "C" int gcpx_averaging_nll(const float* dsum, const float* w, const float
                                   float* nll_bt, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(dsum && w && log_sigma && nll_bt && B > 0 && N > 0 && T > 0, "null pointer / bad sizes");
-    hipLaunchKernelGGL(averaging_nll_kernel, dim3((B * T + 255) / 256), dim3(256), 0, stream, dsum, w, log_sigma, D, nll_bt, B, N, T);
+    hipLaunchKernelGGL(averaging_nll_kernel, dim3(B * ((T + 63) / 64)), dim3(256), 0, stream, dsum, w, log_sigma, D, nll_bt, B, N, T);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }
