@@ -11,6 +11,10 @@ constexpr int ACT_BLOCKS = 1024;   // workgroups of the activation-backward kern
 constexpr int GN_ROWS_PER_BLOCK = 8;
 
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
+// hardware exp / reciprocal (1 - 2 ulp): the mixture-likelihood kernels are VALU bound and full-precision expf / IEEE division cost
+// ~10 instructions each (16 division sequences and 37 exponentials in the loop body of dlm_nll_bwd_kernel)
+__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }
 
 // ---------------------------------------------------------------------------------------------------
 // LSTM cell backward
@@ -508,7 +512,7 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
         int nk = 0;
         for (int k = q; k < NMIX; k += 4, ++nk) {
             const float* m = pp + 8 * k;
-            const float c0 = tanhf(m[4]), c1 = tanhf(m[5]), c2 = tanhf(m[6]);
+            const float c0 = tanh_fast(m[4]), c1 = tanh_fast(m[5]), c2 = tanh_fast(m[6]);
             cf[nk][0] = c0; cf[nk][1] = c1; cf[nk][2] = c2;
             const float mean[3] = {m[1], m[2] + c0 * xr, m[3] + c1 * xr + c2 * xg};
             const float x[3] = {xr, xg, xb};
@@ -519,9 +523,9 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
                 const float raw = pp[c == 0 ? 8 * k + 7 : 70 + 10 * c + k];     // packing.dlm_log_scale_slot
                 const float ls = fmaxf(raw, -7.f);
                 const float xc = x[c] - mean[c];
-                const float inv = expf(-ls);
+                const float inv = __expf(-ls);
                 const float plus_in = inv * (xc + 1.f / 255.f), min_in = inv * (xc - 1.f / 255.f);
-                const float sp = sigmoid_acc(plus_in), sm = sigmoid_acc(min_in);
+                const float sp = sigmoid_fast(plus_in), sm = sigmoid_fast(min_in);
                 const float cdf_delta = sp - sm;
                 const float mid_in = inv * xc;
                 float v, dm, ds;     // value, d v / d mean, d v / d log_scale
@@ -536,10 +540,11 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
                 } else if (cdf_delta > 1e-5f) {
                     v = logf(fmaxf(cdf_delta, 1e-12f));
                     const float pp_ = sp * (1.f - sp), pm_ = sm * (1.f - sm);
-                    dm = -inv * (pp_ - pm_) / cdf_delta;
-                    ds = -(plus_in * pp_ - min_in * pm_) / cdf_delta;
+                    const float rcd = __frcp_rn(cdf_delta);
+                    dm = -inv * (pp_ - pm_) * rcd;
+                    ds = -(plus_in * pp_ - min_in * pm_) * rcd;
                 } else {
-                    const float smid = sigmoid_acc(mid_in);
+                    const float smid = sigmoid_fast(mid_in);
                     v = mid_in - ls - 2.f * (mid_in > 20.f ? mid_in : log1pf(expf(mid_in))) - 4.8481163864f;
                     dm = -inv * (1.f - 2.f * smid);
                     ds = -mid_in * (1.f - 2.f * smid) - 1.f;
@@ -559,7 +564,7 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
         for (int i = 0; i < nk; ++i) se += expf(lp[i] - mx);
         se += __shfl_xor(se, 16);
         se += __shfl_xor(se, 32);
-        const float inv_se = 1.f / se;
+        const float inv_se = __frcp_rn(se);
         if (q == 0) nacc -= mx + logf(se);
         __builtin_amdgcn_wave_barrier();           // every lane has read the logits of its pixel
         nk = 0;

@@ -13,6 +13,10 @@ namespace {
 
 __device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
+// hardware exp / reciprocal (1 - 2 ulp) for the VALU-bound mixture likelihood (same helpers as the fused value + gradient kernel in
+// backward.hip, so the two paths return the same loss)
+__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }
 
 // ---------------------------------------------------------------------------------------------------
 // discretised-logistic-mixture NLL of one frame per workgroup.
@@ -54,7 +58,7 @@ __global__ void __launch_bounds__(256) dlm_nll_kernel(const float* __restrict__ 
             int nk = 0;
             for (int k = q; k < NMIX; k += 4, ++nk) {
                 const float* m = pp + 8 * k;
-                const float c0 = tanhf(m[4]), c1 = tanhf(m[5]), c2 = tanhf(m[6]);
+                const float c0 = tanh_fast(m[4]), c1 = tanh_fast(m[5]), c2 = tanh_fast(m[6]);
                 const float mean[3] = {m[1], m[2] + c0 * xr, m[3] + c1 * xr + c2 * xg};
                 const float x[3] = {xr, xg, xb};
                 float s = m[0] - lse_logits;
@@ -62,9 +66,9 @@ __global__ void __launch_bounds__(256) dlm_nll_kernel(const float* __restrict__ 
                 for (int c = 0; c < 3; ++c) {
                     const float ls = fmaxf(pp[c == 0 ? 8 * k + 7 : 70 + 10 * c + k], -7.f);
                     const float xc = x[c] - mean[c];
-                    const float inv = expf(-ls);
+                    const float inv = __expf(-ls);
                     const float plus_in = inv * (xc + 1.f / 255.f), min_in = inv * (xc - 1.f / 255.f);
-                    const float cdf_delta = sigmoid_acc(plus_in) - sigmoid_acc(min_in);
+                    const float cdf_delta = sigmoid_fast(plus_in) - sigmoid_fast(min_in);
                     const float mid_in = inv * xc;
                     float v;
                     if (x[c] < -0.999f) v = plus_in - softplusf_(plus_in);
