@@ -10,6 +10,8 @@
 
 namespace {
 
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }   // = fast_tanh of the head kernel
+
 __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
@@ -621,15 +623,16 @@ __global__ void __launch_bounds__(256) dlm_mean_bwd_kernel(const float* __restri
         for (int k = 1; k < NMIX; ++k) lmax = fmaxf(lmax, pp[8 * k]);
         float lsum = 0.f;
 #pragma unroll
-        for (int k = 0; k < NMIX; ++k) lsum += expf(pp[8 * k] - lmax);
+        for (int k = 0; k < NMIX; ++k) lsum += __expf(pp[8 * k] - lmax);
+        const float rls = __frcp_rn(lsum);
         float pi[3], Mr[3], Mg[3], Mb[3], cf[3][3];
         float Sr = 0.f, Sg = 0.f, Sb = 0.f;
         int nk = 0;
         for (int k = q; k < NMIX; k += 4, ++nk) {
             const float* m = pp + 8 * k;
-            const float c0 = tanhf(m[4]), c1 = tanhf(m[5]), c2 = tanhf(m[6]);
+            const float c0 = tanh_fast(m[4]), c1 = tanh_fast(m[5]), c2 = tanh_fast(m[6]);   // the head's forward uses the same
             cf[nk][0] = c0; cf[nk][1] = c1; cf[nk][2] = c2;
-            pi[nk] = expf(m[0] - lmax) / lsum;
+            pi[nk] = __expf(m[0] - lmax) * rls;
             Mr[nk] = m[1];
             Mg[nk] = m[2] + c0 * Mr[nk];
             Mb[nk] = m[3] + c1 * Mr[nk] + c2 * Mg[nk];
