@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HEAD_TRAFFIC_BYTES = int((2 * 315310.7 + 97536.0) * 1024)   # measured, see "traffic" below
+HEAD_TRAFFIC_BYTES = int((2 * 328209.2 + 97536.0) * 1024)   # measured, see "traffic" below
 F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
 
 
@@ -237,7 +237,7 @@ def main():
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                          # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_head_kernel.json):
-                         # FETCH_SIZE 315311 KB x2 (gfx950 wide-load correction, MI355X_MICROARCH.md) + WRITE_SIZE 97536 KB;
+                         # FETCH_SIZE 328209 KB x2 (gfx950 wide-load correction, MI355X_MICROARCH.md) + WRITE_SIZE 97536 KB;
                          # algorithmic bytes = 532.7 MB in (16 ch f32 @64x64 x 2032 frames) + 99.9 MB out
                          "traffic": HEAD_TRAFFIC_BYTES if (hp.batch_size == 16 and not args.eval_bn) else None,
                          "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": head_flops},
