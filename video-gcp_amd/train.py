@@ -48,10 +48,14 @@ class SyntheticLoader:
         return self.n
 
     def __iter__(self):
-        from .synthetic import make_inputs
+        from .synthetic import make_inputs, make_inputs_device
+        on_gpu = torch.device(self.device).type == "cuda"
         for i in range(self.n):
-            inputs, _, _ = make_inputs(self.hp, seed=self.seed + i, variant=self.variant)
-            yield {k: v.to(self.device) for k, v in inputs.items()}
+            if on_gpu:                                   # drawn on the device: the host path is 9x slower than a training step
+                yield make_inputs_device(self.hp, self.seed + i, self.variant, self.device)
+            else:
+                inputs, _, _ = make_inputs(self.hp, seed=self.seed + i, variant=self.variant)
+                yield {k: v.to(self.device) for k, v in inputs.items()}
 
 
 class ModelTrainer:
