@@ -269,7 +269,8 @@ int gcpx_compact_index(const int32_t* leave, int32_t B, int32_t N, int32_t T, in
  *                  max(KL, free_nats); q/p rows are [mu | log_sigma] at base + b*batch_stride + n*node_stride.
  *   gcpx_loss_combine: length CE (misc.py:53-56), existence BCE (frame_binding.py:80-86), state L2
  *                  (base_gcp.py:281-286), the weighted total of get_total_loss (base_gcp.py:294-304).
- *                  out[0..6] = dense_img_rec, kl, len_pred, existence_predictor, state_regression, total, nll.
+ *                  out[0..8] = dense_img_rec, kl, len_pred, existence_predictor, state_regression, total, nll,
+ *                  action_reconst (inverse_mdl.py:181-191), cost_estimation (cost_mdl.py:59-62).
  * ------------------------------------------------------------------------------------------------- */
 typedef struct gcpx_loss_args {
     const float* nll_bt;          /* [B*T] */
@@ -282,10 +283,19 @@ typedef struct gcpx_loss_args {
     const float* regressed_state; /* [B][T][state_dim] or NULL */
     const float* state_target;    /* [B][T][state_dim] or NULL */
     const int32_t* seq_len;       /* [B] */
-    float* out;                   /* [8] */
+    float* out;                   /* [16] */
     int32_t B, T, N, state_dim;
     float w_rec, w_kl, w_len, w_exist, w_state;
     float total_div;
+    /* inverse model, sampled pair (inverse_mdl.py:136-191): action_pred [B][n_actions] against actions[b][inv_t0[b]] */
+    const float* action_pred;     /* [B][n_actions] or NULL */
+    const float* action_seq;      /* inputs.actions [B][T-1][n_actions] */
+    const int64_t* inv_t0;        /* [B] */
+    /* cost model (cost_mdl.py:42-62): cost_pred [B] against the ground-truth path cost [B] */
+    const float* cost_pred;       /* [B] or NULL */
+    const float* cost_target;     /* [B] */
+    int32_t n_actions;
+    float w_action, w_cost;
 } gcpx_loss_args;
 
 int gcpx_dlm_nll(const float* params, const float* target, const float* row_weight, float* nll_out, int32_t rows,
@@ -296,6 +306,30 @@ int gcpx_kl_gauss(const float* qz, const float* pz, int32_t B, int32_t N, int32_
                   int64_t node_stride, float free_nats, const float* node_weight /* b*weight_bstride + n, or NULL */,
                   int64_t weight_bstride, float* kl_out, void* stream);
 int gcpx_loss_combine(const gcpx_loss_args* a, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------------
+ * Auxiliary models, training-time paths, and the sampled sequence length (csrc/aux.hip).
+ * ------------------------------------------------------------------------------------------------- */
+/* InverseModel.sample_offsets (inverse_mdl.py:84-104) + CostModel._general_cost's index draws (cost_mdl.py:105-107) from four
+   uniform numbers per sequence, u [4][B] in [0,1):  inv_t0 in {0..end_ind-temp_dist}, inv_t1 = inv_t0 + {1..temp_dist},
+   cost_start in {0..end_ind-1}, cost_end in {cost_start+1..end_ind}.  (The reference draws with np.random; callers that
+   want its exact stream feed the indices instead.) */
+int gcpx_aux_sample_indices(const int64_t* end_ind, const float* u, int32_t B, int32_t temp_dist, int64_t* inv_t0, int64_t* inv_t1,
+                            int64_t* cost_start, int64_t* cost_end, void* stream);
+/* rows [4][B] (int32): absolute rows b*T + inv_t0, b*Wd + inv_t1, b*Wd + cost_start, b*Wd + cost_end — the gather-on-load
+   sources of `inv_mdl.action_pred(enc_traj_seq[b,t0], model_enc_seq[b,t1])` (inverse_mdl.py:149-169) and
+   `cost_mdl.cost_pred(model_enc_seq[b,start], model_enc_seq[b,end])` (cost_mdl.py:108-109, :50) */
+int gcpx_aux_index_rows(const int64_t* inv_t0, const int64_t* inv_t1, const int64_t* cost_start, const int64_t* cost_end, int32_t B,
+                        int32_t T, int32_t Wd, int32_t* rows, void* stream);
+/* ground-truth cost of CostModel._general_cost with EuclideanPathLength(dense_cost=True) (cost_mdl.py:110-111,
+   cost_fcn.py:14-21,49-54): out[b] = sum_{t=start}^{end-1} sum_row || x[b,t+1,row,:] - x[b,t,row,:] ||_2 over x [B][T][rows][row_len]
+   (images: rows = 3*H, row_len = W).  partial: scratch [B][rows]. */
+int gcpx_path_cost(const float* x, const int64_t* start_idx, const int64_t* end_idx, int32_t B, int32_t T, int32_t rows,
+                   int32_t row_len, float* partial, float* out, void* stream);
+/* get_end_ind under val_mode(pred_length=True) (base_gcp.py:219-226): end_ind[b] = max(min_len, inverse CDF of
+   softmax(logits[b]) at u[b]) — the OneHotCategorical draw (misc.py:49) with the uniform number fed in */
+int gcpx_sample_length(const float* logits, const float* u, int32_t B, int32_t T, int32_t min_len, int64_t* end_ind, void* stream);
 
 
 /* ===================================================================================================
@@ -502,6 +536,8 @@ int gcpx_dlm_nll_bwd(const float* params, const float* target, const float* row_
 /* d total / d logits of the length CE, existence BCE and state L2 heads (same arguments as gcpx_loss_combine);
    dlen [B][ceil16(T)] (pad columns zero), dexist [B*N][16] (column 0), dstate [B*T][16] (columns < state_dim); NULL outputs are skipped */
 int gcpx_loss_heads_bwd(const gcpx_loss_args* a, float* dlen, float* dexist, float* dstate, void* stream);
+/* same for the inverse-model and cost-model L2 heads: daction [B][16] (columns < n_actions), dcost [B][16] (column 0) */
+int gcpx_loss_aux_heads_bwd(const gcpx_loss_args* a, float* daction, float* dcost, void* stream);
 
 /* ---- parameters ---- */
 /* dst[i] = theta[idx0[i]] (+ theta[idx1[i]]), negative index = 0: every fragment-packed weight arena is a gather of the

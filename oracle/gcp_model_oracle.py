@@ -28,6 +28,7 @@ import torch
 import torch.nn.functional as F
 
 from . import adaptive_oracle as AD
+from . import aux_models_oracle as AX
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -301,7 +302,7 @@ def _adaptive_matching_and_pruning(sd, hp, inp, out, bf, df_lat, img_df, end_ind
 # ---------------------------------------------------------------------------------------------------
 # forward
 # ---------------------------------------------------------------------------------------------------
-def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, phase="train", taps=None):
+def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, phase="train", taps=None, use_pred_length=False):
     """BaseGCPModel.forward for TreeModel (base_gcp.py:140-161).
 
     inputs: dict with I_0, I_g [B,3,H,W]; end_ind int64 [B]; optional start_ind, traj_seq [B,T,3,H,W], pad_mask,
@@ -309,6 +310,10 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     noise:  eps [B,N,nz_vae] in breadth-first node order for the reparametrised samples (replaces torch RNG so
             the HIP path can be fed identical numbers).
     sample_prior: val_mode() switch (base_gcp.py:44-53).
+    use_pred_length: val_mode(pred_length=True): the sequence length is drawn from the length predictor (base_gcp.py:219-226);
+            needs inputs["len_u"] (one uniform draw per sequence).
+    Optional index inputs for the auxiliary models' training paths: inv_t0 / inv_t1 (inverse_mdl.py:84-104),
+            cost_start_idx / cost_end_idx (cost_mdl.py:105-107); see oracle/aux_models_oracle.py for their samplers.
     training_bn: BatchNorm uses batch statistics (model.train(), as train.py:157 and val :205-214 run it);
             False = running stats (model.eval(), planner_policy.py:51).
     """
@@ -344,7 +349,10 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     # ---- get_end_ind (base_gcp.py:215-229); parity runs feed end_ind --------------------
     if hp.regress_length:
         out["seq_len_logits"] = tap("seq_len_logits", predictor(sd, "length_pred.p", hp, inp["e_0"], inp["e_g"]))   # misc.py:45-51
-    end_ind = inp["end_ind"]
+    end_ind = inp.get("end_ind")
+    if hp.regress_length and use_pred_length and (hp.length_pred_weight > 0 or end_ind is None):
+        # base_gcp.py:221-222: the OneHotCategorical draw is fed as one uniform number per sequence (`len_u`)
+        end_ind = AX.sample_length(out["seq_len_logits"].detach(), inp["len_u"])
     out["end_ind"] = end_ind
 
     # ---- predict_sequence (tree.py:42-67) ------------------------------------------------------------
@@ -442,11 +450,30 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
         reg_in = mes.detach()                                                     # base_gcp.py:253-255 (supervised_decoder=False)
         out["regressed_state"] = predictor(sd, "state_regressor", hp, reg_in.reshape(-1, mes.shape[-1])).reshape(B, mes.shape[1], -1)
     if hp.attach_inv_mdl and phase == "train":
-        # InverseModel.full_seq_forward (inverse_mdl.py:110-134), train_im0_enc=True
-        e1 = mes[:, 1:]
-        e0s = inp["enc_traj_seq"][:, :-1][:, :e1.shape[1]] if "enc_traj_seq" in inp else mes[:, :-1]
-        a = predictor(sd, "inv_mdl.action_pred", hp, torch.cat([e0s, e1], 2).reshape(-1, 2 * hp.nz_enc))
-        out["actions"] = a.reshape(B, e1.shape[1], -1)
+        if sample_prior or hp.train_inv_mdl_full_seq:                             # base_gcp.py:250 (val_mode sets _inv_mdl_full_seq)
+            # InverseModel.full_seq_forward (inverse_mdl.py:116-134), train_im0_enc=True
+            e1 = mes[:, 1:]
+            e0s = inp["enc_traj_seq"][:, :-1][:, :e1.shape[1]] if "enc_traj_seq" in inp else mes[:, :-1]
+            a = predictor(sd, "inv_mdl.action_pred", hp, torch.cat([e0s, e1], 2).detach().reshape(-1, 2 * hp.nz_enc))   # detach_enc, :122-124
+            out["actions"] = a.reshape(B, e1.shape[1], -1)
+            if "actions" in inp:                                                  # :131-133
+                out["action_targets"], out["action_pad_mask"] = inp["actions"], inp["pad_mask"]
+        elif "inv_t0" in inp:
+            # InverseModel.forward, sampled pair (inverse_mdl.py:136-178); the np.random draws of sample_offsets are inputs
+            ar = torch.arange(B)
+            t0, t1 = inp["inv_t0"], inp["inv_t1"]
+            enc_im0 = inp["enc_traj_seq"][ar, t0].detach()                        # train_im0_enc and 'enc_traj_seq' in inputs, :149-150
+            enc_im1 = mes[ar, t1].detach()                                        # :153, detach_enc :160-162
+            out["actions"] = predictor(sd, "inv_mdl.action_pred", hp, enc_im0, enc_im1)       # [B, n_actions]
+            if "actions" in inp:
+                out["action_targets"] = inp["actions"][ar, t0]                    # index_input, aggregate_actions=False, :164
+    if hp.attach_cost_mdl and hp.run_cost_mdl and phase == "train" and "cost_start_idx" in inp and "traj_seq" in inp:
+        # CostModel.forward (cost_mdl.py:42-57) with _general_cost's np.random draws fed as inputs (:101-117)
+        ar = torch.arange(B)
+        s_idx, e_idx = inp["cost_start_idx"], inp["cost_end_idx"]
+        start, end = mes[ar, s_idx].detach(), mes[ar, e_idx].detach()
+        out["cost"] = predictor(sd, "cost_mdl.cost_pred", hp, torch.cat([start, end], dim=-1))
+        out["cost_target"] = torch.as_tensor(AX.euclidean_path_cost(inp["traj_seq"].detach().numpy(), s_idx.numpy(), e_idx.numpy()))
     out["inputs"] = inp
     return out
 
@@ -506,6 +533,13 @@ def losses(sd, hp, inputs, out):
         rl = out["regressed_state"].shape[1]
         e = (out["regressed_state"] - inputs["traj_seq_states"][:, :rl]) ** 2 * pm[:, :rl, None]
         res["state_regression"] = (e.mean(), 1.0)
+    if hp.attach_inv_mdl and "action_targets" in out:                             # base_gcp.py:275-276, inverse_mdl.py:181-191
+        a = out["actions"]
+        n = a.shape[1]
+        wgt = out["action_pad_mask"][:, :n, None] if "action_pad_mask" in out else 1.0
+        res["action_reconst"] = (AX.l2_loss(a, out["action_targets"][:, :n], wgt), hp.action_rec_weight)
+    if hp.attach_cost_mdl and hp.run_cost_mdl and "cost" in out:                 # base_gcp.py:279-280, cost_mdl.py:59-62
+        res["cost_estimation"] = (AX.l2_loss(out["cost"], out["cost_target"]), 1.0)
     total = sum(v * w for v, w in res.values() if w > 0)
     total = total / float(torch.tensor(tgt.shape[1:]).prod())                    # base_gcp.py:299-301
     return res, total

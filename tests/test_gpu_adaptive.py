@@ -254,7 +254,7 @@ def test_adaptive_prior_path_c5s():
     inputs, noise, _ = make_inputs(hp, seed=12, variant="A")
     plan_in = {k: inputs[k] for k in ("I_0", "I_g", "end_ind", "start_ind")}
     ref = O.forward(sd, hp, plan_in, noise=noise, sample_prior=True, training_bn=False)
-    with model.val_mode():
+    with model.val_mode(pred_length=False):
         out = model({k: v.cuda() for k, v in plan_in.items()}, "train", noise=noise.cuda())
     torch.cuda.synchronize()
     assert_close(out.tree.bf.images, ref["tree_bf"]["images"], PIX_ATOL, 0, "images")
@@ -322,7 +322,7 @@ def test_dtw_eval_binding_c5s():
     model.eval()
     inputs, noise, _ = make_inputs(hp, seed=21, variant="B")
     dev_in = {k: v.cuda() for k, v in inputs.items()}
-    with model.val_mode():
+    with model.val_mode(pred_length=False):
         out = model(dev_in, "test", noise=noise.cuda())
     gen, info = DTWEvalBinding(model).get_all_samples(out, dev_in)
     torch.cuda.synchronize()

@@ -54,7 +54,11 @@ def _check_common(hp, model, out, ref, posterior):
     assert_close(aux.model_enc_seq, ref["model_enc_seq"], LAT_ATOL, LAT_RTOL, "model_enc_seq")
     assert_close(aux.regressed_state, ref["regressed_state"], LAT_ATOL, LAT_RTOL, "regressed_state")
     if "actions" in ref:
+        # posterior path: ONE sampled frame pair per sequence (inverse_mdl.py:136-178); val_mode: the full sequence (:110-134)
         assert_close(aux.actions, ref["actions"], LAT_ATOL, LAT_RTOL, "actions")
+    if "cost" in ref:
+        assert_close(aux.cost, ref["cost"], LAT_ATOL, LAT_RTOL, "cost")
+        assert_close(aux.cost_target, ref["cost_target"], 0, 2e-6, "cost_target")      # float32 sum of ~1e4 row norms
 
 
 @pytest.mark.parametrize("training_bn", [False, True])
@@ -89,16 +93,48 @@ def test_prior_and_given_z_c1():
     inputs, noise, z = make_inputs(hp, seed=3, variant="A")
     plan_in = {k: inputs[k] for k in ("I_0", "I_g", "end_ind", "start_ind")}
     ref = O.forward(sd, hp, plan_in, noise=noise, sample_prior=True, training_bn=False)
-    with model.val_mode():
+    with model.val_mode(pred_length=False):
         out = model({k: v.cuda() for k, v in plan_in.items()}, "train", noise=noise.cuda())
     torch.cuda.synchronize()
     _check_common(hp, model, out, ref, posterior=False)
+    assert "actions" in ref and ref["actions"].dim() == 3          # val_mode: inverse model over the full sequence
     zin = dict(plan_in, z=z)
-    ref = O.forward(sd, hp, zin, training_bn=False)
-    with model.val_mode():
+    ref = O.forward(sd, hp, zin, sample_prior=True, training_bn=False)
+    with model.val_mode(pred_length=False):
         out = model({k: v.cuda() for k, v in zin.items()}, "train")
     torch.cuda.synchronize()
     _check_common(hp, model, out, ref, posterior=False)
+
+
+@pytest.mark.parametrize("feed_end_ind", [True, False])
+def test_sampled_sequence_length_c1(feed_end_ind):
+    """val_mode(pred_length=True) (base_gcp.py:219-226, what the planner's rollout runs under, cem_simulator.py:29-31): the sequence
+    length is a draw from the length predictor (clamped to >= 2) and REPLACES a fed end_ind; everything downstream — balanced
+    binding, pruning, the latent-space heads — follows the drawn length.  The categorical draw is fed as one uniform number per
+    sequence; lengths and the integer bookkeeping must be bit-exact."""
+    from oracle import gcp_model_oracle as O
+    hp, sd, model = _build("c1", batch_size=6)
+    model.eval()
+    inputs, noise, z = make_inputs(hp, seed=11, variant="A")
+    plan_in = {k: inputs[k] for k in ("I_0", "I_g", "start_ind")}
+    if feed_end_ind:
+        plan_in["end_ind"] = inputs["end_ind"]
+    plan_in["z"] = z
+    len_u = torch.tensor([0.03, 0.21, 0.48, 0.62, 0.87, 0.995])
+    ref = O.forward(sd, hp, dict(plan_in, len_u=len_u), sample_prior=True, training_bn=False, use_pred_length=True)
+    with model.val_mode():                                         # pred_length=True is the default, as in the reference
+        out = model({k: v.cuda() for k, v in dict(plan_in, len_u=len_u).items()}, "train")
+    torch.cuda.synchronize()
+    assert torch.equal(out.end_ind.cpu(), ref["end_ind"])
+    assert int(ref["end_ind"].min()) >= 2 and len(set(ref["end_ind"].tolist())) > 1
+    assert torch.equal(out.raw["seq_len"].cpu().long(), ref["end_ind"] + 1)
+    _check_common(hp, model, out, ref, posterior=False)
+    # without a fed draw the lengths come from the device RNG: still valid lengths
+    with model.val_mode():
+        out = model({k: v.cuda() for k, v in plan_in.items()}, "train")
+    torch.cuda.synchronize()
+    e = out.end_ind.cpu()
+    assert int(e.min()) >= 2 and int(e.max()) <= hp.max_seq_len - 1
 
 
 def test_gaussian_decoder_c1():

@@ -45,7 +45,13 @@ def test_gradients_match_autograd_c1(graph):
     torch.cuda.synchronize()
     gref, res, total, _ = O.gradients(sd, hp, inputs, noise)
     assert abs(float(out.raw["losses"][5]) - float(total)) <= 2e-5 * abs(float(total))
-    _compare_grads(gref, tr.named_grads())
+    got = tr.named_grads()
+    _compare_grads(gref, got)
+    # the inverse model and the cost model are trained (base_gcp.py:275-280): their heads receive a gradient
+    assert "action_reconst" in res and "cost_estimation" in res
+    for pre in ("inv_mdl.action_pred.", "cost_mdl.cost_pred."):
+        ks = [k for k in gref if k.startswith(pre)]
+        assert ks and all(float(got[k].abs().max()) > 0 for k in ks), pre
 
 
 def test_gradients_full_length_sequences_c1():

@@ -4,7 +4,7 @@
 //   expected edge frequencies, column normalisation, argmax / entropy bookkeeping, averaging loss
 //   masked single-query multi-head attention over the encoded sequence
 // Reference: gcp/prediction/models/adaptive_binding/{adaptive,probabilistic_dtw,binding_loss,attentive_inference}.py
-#include "common.cuh"
+#include "common.h"
 
 #include <math.h>
 

@@ -3,7 +3,7 @@
 // Everything here is HBM- or latency-bound bookkeeping between the MFMA launches (gcpx_gemm / gcpx_conv3x3 with
 // transposed packs for data gradients, gcpx_wgrad for weight gradients).  All reductions are deterministic
 // (per-workgroup partial sums combined in a fixed order; no atomics).
-#include "common.cuh"
+#include "common.h"
 
 namespace {
 
@@ -661,6 +661,31 @@ __global__ void __launch_bounds__(256) loss_heads_bwd_kernel(const gcpx_loss_arg
     }
 }
 
+// d total / d outputs of the inverse-model and cost-model heads (L2 means, inverse_mdl.py:181-191, cost_mdl.py:59-62)
+__global__ void __launch_bounds__(256) loss_aux_heads_bwd_kernel(const gcpx_loss_args a, float* __restrict__ daction,
+                                                                 float* __restrict__ dcost) {
+    const int B = a.B, T = a.T;
+    const float inv_div = 1.f / a.total_div;
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    if (daction && a.action_pred) {
+        const int na = a.n_actions;
+        const float k = 2.f * a.w_action * inv_div / (float)(B * na);
+        for (int i = tid; i < B * 16; i += nth) {
+            const int b = i / 16, c = i % 16;
+            float v = 0.f;
+            if (c < na) v = k * (a.action_pred[b * na + c] - a.action_seq[((size_t)b * (T - 1) + (int)a.inv_t0[b]) * na + c]);
+            daction[i] = v;
+        }
+    }
+    if (dcost && a.cost_pred) {
+        const float k = 2.f * a.w_cost * inv_div / (float)B;
+        for (int i = tid; i < B * 16; i += nth) {
+            const int b = i / 16, c = i % 16;
+            dcost[i] = c == 0 ? k * (a.cost_pred[b] - a.cost_target[b]) : 0.f;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // parameters
 // ---------------------------------------------------------------------------------------------------
@@ -911,6 +936,17 @@ extern "C" int gcpx_loss_heads_bwd(const gcpx_loss_args* a, float* dlen, float* 
     STREAM();
     GCPX_CHECK_ARG(a && a->seq_len && a->end_ind && a->pad_mask, "missing pointer");
     hipLaunchKernelGGL(loss_heads_bwd_kernel, dim3(64), dim3(256), 0, stream, *a, dlen, dexist, dstate);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_loss_aux_heads_bwd(const gcpx_loss_args* a, float* daction, float* dcost, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(a && a->B > 0 && a->total_div > 0, "bad arguments");
+    GCPX_CHECK_ARG(!(daction && a->action_pred) || (a->action_seq && a->inv_t0 && a->n_actions > 0 && a->n_actions <= 16),
+                   "inverse-model head needs action_seq, inv_t0 and 1..16 actions");
+    GCPX_CHECK_ARG(!(dcost && a->cost_pred) || a->cost_target, "cost-model head needs cost_target");
+    hipLaunchKernelGGL(loss_aux_heads_bwd_kernel, dim3(4), dim3(256), 0, stream, *a, daction, dcost);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

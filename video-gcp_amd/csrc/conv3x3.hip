@@ -15,7 +15,7 @@
 //     16-byte LDS read — the packed weights use the same permutation.
 //   * epilogue: bias, then either the raw NHWC store (+ per-workgroup BatchNorm partial sums) or, for the
 //     output head, the discrete-logistic-mixture mean computed in registers (4-lane column shuffles).
-#include "common.cuh"
+#include "common.h"
 
 #include <type_traits>
 

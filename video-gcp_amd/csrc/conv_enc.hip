@@ -7,7 +7,7 @@
 // skip LDS: each lane fetches its B fragment (one pixel, 4 consecutive input channels = 16 B) straight from
 // L2/HBM and applies the producer's BatchNorm affine + LeakyReLU on the fly ("normalise on load").  Weights come
 // pre-packed in fragment order (one coalesced 1 KiB load per 16 output channels per step).
-#include "common.cuh"
+#include "common.h"
 
 #include <cstdlib>
 

@@ -12,7 +12,7 @@
 // (j, kk) reads 16 B = 4 consecutive k of its row, with the producer's BatchNorm affine + LeakyReLU applied on
 // load).  A lane ends with 4 consecutive columns of one row: with gate-interleaved LSTM weights (n = 4u + gate)
 // the whole cell update for (row, unit u) is lane-local.  No LDS, no barriers: wavefronts are independent.
-#include "common.cuh"
+#include "common.h"
 
 #include <cstdio>
 #include <cstdlib>

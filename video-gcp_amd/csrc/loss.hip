@@ -7,7 +7,7 @@
 //   get_total_loss                                                  /root/reference/gcp/prediction/models/base_gcp.py:294-304
 // The loss formulas (blox.torch.losses is absent) follow DESIGN.md "Model spec": value = sum over non-batch dims of
 // error * weight, mean over the batch.
-#include "common.cuh"
+#include "common.h"
 
 namespace {
 
@@ -223,7 +223,30 @@ __global__ void __launch_bounds__(256) loss_combine_kernel(const gcpx_loss_args 
         }
         sreg = block_sum(v, red) / (B * maxlen * sd);
     }
+    // inverse model, sampled pair: mean over [B, n_actions] of (pred - actions[b, t0[b]])^2 (inverse_mdl.py:181-191, weights = 1)
+    float areg = 0.f;
+    if (a.action_pred) {
+        v = 0.f;
+        const int na = a.n_actions;
+        for (int i = tid; i < B * na; i += 256) {
+            const int b = i / na, d = i % na;
+            const float e = a.action_pred[i] - a.action_seq[((size_t)b * (T - 1) + (int)a.inv_t0[b]) * na + d];
+            v += e * e;
+        }
+        areg = block_sum(v, red) / (B * na);
+    }
+    // cost model: mean over [B, 1] of (cost - gt_cost)^2 (cost_mdl.py:59-62)
+    float creg = 0.f;
+    if (a.cost_pred) {
+        v = 0.f;
+        for (int i = tid; i < B; i += 256) {
+            const float e = a.cost_pred[i] - a.cost_target[i];
+            v += e * e;
+        }
+        creg = block_sum(v, red) / B;
+    }
     if (tid == 0) {
+        a.out[7] = areg; a.out[8] = creg;
         a.out[0] = rec; a.out[1] = kl; a.out[2] = ce; a.out[3] = bce; a.out[4] = sreg;
         float total = 0.f;
         if (a.w_rec > 0.f) total += a.w_rec * rec;
@@ -231,6 +254,8 @@ __global__ void __launch_bounds__(256) loss_combine_kernel(const gcpx_loss_args 
         if (a.w_len > 0.f) total += a.w_len * ce;
         if (a.w_exist > 0.f) total += a.w_exist * bce;
         if (a.w_state > 0.f) total += a.w_state * sreg;
+        if (a.w_action > 0.f) total += a.w_action * areg;
+        if (a.w_cost > 0.f) total += a.w_cost * creg;
         a.out[5] = total / a.total_div;      // base_gcp.py:299-301: / prod(traj_seq.shape[1:])
         a.out[6] = rec + kl;                 // nll upper bound (base_gcp.py:289-290)
     }

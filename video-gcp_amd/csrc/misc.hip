@@ -1,6 +1,6 @@
 // Small kernels: BatchNorm statistics finalisation, balanced frame binding (integer, bit-exact), gathers,
 // plus the library's error string, hipGraph and event helpers.
-#include "common.cuh"
+#include "common.h"
 
 #include <cstdarg>
 #include <cstdio>

@@ -10,7 +10,7 @@
 //   /root/reference/gcp/prediction/models/tree/tree_module.py:79-94 (sample / reparametrize)
 //   /root/reference/gcp/prediction/models/tree/tree_module.py:105  (MLP LSTM initialiser)
 //   misc.py:48, frame_binding.py:71, base_gcp.py:256, inverse_mdl.py:126, cost_mdl.py:63 (heads).
-#include "common.cuh"
+#include "common.h"
 
 namespace {
 

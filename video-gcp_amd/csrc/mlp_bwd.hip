@@ -7,7 +7,7 @@
 // (gcpx_gemm x 6, gcpx_gn_lrelu_bwd x 3, gcpx_lrelu_bwd) on the latency-bound chain of a tree level:
 //   backward of /root/reference/gcp/prediction/models/tree/tree_module.py:77 (prior), inference.py:27-35 (posterior),
 //   which the reference gets from torch autograd (train.py:157-160).
-#include "common.cuh"
+#include "common.h"
 
 namespace {
 

@@ -12,7 +12,7 @@
 // pad 1) input in NHWC, optionally with the producer's BatchNorm affine + LeakyReLU applied on load.
 // The row range can be split over blockIdx.z; partial results are combined by gcpx_wgrad_reduce in a fixed order
 // (deterministic), which also maps (n, k) to the canonical torch parameter layout.
-#include "common.cuh"
+#include "common.h"
 
 namespace {
 

@@ -12,7 +12,7 @@
 //     across the whole launch and are written once as a partial [workgroup][n][tap*Cin + ci]; gcpx_wgrad_reduce sums the
 //     partials in a fixed order (deterministic) and maps them to the torch weight layout;
 //   * the next tile's global loads are issued before the MFMA phase of the current one.
-#include "common.cuh"
+#include "common.h"
 
 namespace {
 

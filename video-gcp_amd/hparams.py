@@ -60,6 +60,9 @@ class GCPHParams:
     attach_state_regressor: bool = True
     attach_inv_mdl: bool = True
     attach_cost_mdl: bool = True
+    run_cost_mdl: bool = True          # hyperparameters.py:63
+    train_inv_mdl_full_seq: bool = False   # hyperparameters.py:108
+    inv_mdl_temp_dist: int = 1         # inverse_mdl.py:39 (InverseModel default 'temp_dist')
     # build spec for what blox would define
     leaky_slope: float = 0.2
     bn_eps: float = 1e-5
@@ -70,6 +73,7 @@ class GCPHParams:
     length_pred_weight: float = 1.0
     dense_img_rec_weight: float = 1.0
     entropy_weight: float = 0.0
+    action_rec_weight: float = 1.0     # inverse_mdl.py:56
     free_nats: float = 0.0
     hierarchy_levels: int = field(default=-1)
 

@@ -90,6 +90,9 @@ class Outputs(dict):
 class GCPTreeModel:
     """TreeModel(params, logger) counterpart.  `model(inputs, phase)` -> Outputs."""
 
+    _has_aux_training = True      # sampled inverse-model / cost-model training pairs (base_gcp.py:249-260)
+    _has_pred_length = True       # val_mode(pred_length=True) draws the sequence length (base_gcp.py:219-226)
+
     def __init__(self, hp: GCPHParams, params=None, device="cuda", seed=0, materialize_distr=False):
         self._hp = hp
         self.device = torch.device(device)
@@ -178,7 +181,12 @@ class GCPTreeModel:
             elif strict:
                 raise KeyError(k)
         self._pack_all()
+        self._clear_plans()
+
+    def _clear_plans(self):
         self._plans.clear()
+        for cb in getattr(self, "_plan_listeners", ()):
+            cb()
 
     def __call__(self, inputs, phase="train", noise=None):
         return self.forward(inputs, phase, noise)
@@ -319,7 +327,7 @@ class GCPTreeModel:
         self._arena_idx0, self._arena_idx1 = idx0, idx1
         self._psd = self.sd
         self.pk = P0
-        self._plans.clear()
+        self._clear_plans()
         self.repack()
         return X0
 
@@ -653,6 +661,8 @@ class GCPTreeModel:
     def _build_plan(self, key, tin):
         hp, P, lib = self._hp, self.pk, self.lib
         B, has_traj, has_z, sample_prior, phase = key[0], key[1], key[2], key[3], key[4]
+        pred_len = key[9]
+        train_aux = has_traj and phase == "train" and not sample_prior    # the posterior path of a training / validation-loss forward
         L, T, N = hp.hierarchy_levels, hp.max_seq_len, hp.n_nodes
         nz, nv, H, SD = hp.nz_enc, hp.nz_vae, hp.nz_mid_lstm, hp.lstm_state_dim
         PS = 2 ** L + 1                                     # slots per batch element
@@ -691,7 +701,8 @@ class GCPTreeModel:
         plan.lane = 1
         skips = self._plan_encoder(plan, "I0", tin["I_0"].data_ptr(), B, _addr(E), PS * nz, 0, 1)
         plan.lane = 2
-        plan_bookkeeping()
+        if not pred_len:
+            plan_bookkeeping()
         self._plan_encoder(plan, "Ig", tin["I_g"].data_ptr(), B, _addr(E, 2 ** L * nz), PS * nz, 0, 1)
         plan.lane = 0
         if has_traj:
@@ -727,6 +738,11 @@ class GCPTreeModel:
             logits = self._buf("seq_len_logits", (B, T))
             self._mlp(plan, "length_pred", P["length_pred"], [e0(), eg()], B, 1, out=logits.data_ptr(), ob=T, orow=0)
             outs["seq_len_logits"] = logits
+            if pred_len:
+                # get_end_ind under val_mode(pred_length=True) (base_gcp.py:219-226): the fed end_ind is REPLACED by a draw from the
+                # length predictor, clamped to >= 2; the integer bookkeeping therefore follows the draw instead of riding on a side lane
+                plan.add("sample_length", lib.gcpx_sample_length, logits.data_ptr(), tin["len_u"].data_ptr(), B, T, 2, tin["end_ind"].data_ptr())
+                plan_bookkeeping()
 
         # ---- predict_sequence: level-serial tree (tree_utils.py:21-44, tree_module.py:67-114) ----
         for l in range(L):
@@ -817,8 +833,8 @@ class GCPTreeModel:
                 self._mlp(plan, "state_regressor", P["state_regressor"], [self._rowsrc(mes.data_ptr(), Wd * nz, nz, nz)],
                           B * Wd, Wd, out=rs.data_ptr(), ob=Wd * hp.state_dim, orow=hp.state_dim)
                 outs["regressed_state_padded"] = rs
-            if hp.attach_inv_mdl and phase == "train":
-                # InverseModel.full_seq_forward (inverse_mdl.py:110-134)
+            if hp.attach_inv_mdl and phase == "train" and (sample_prior or hp.train_inv_mdl_full_seq or not has_traj):
+                # InverseModel.full_seq_forward (inverse_mdl.py:110-134): val_mode sets _inv_mdl_full_seq (base_gcp.py:44-53,250)
                 act = self._buf("actions", (B, Wd - 1, hp.n_actions))
                 first = enc_traj if has_traj else mes
                 s0 = self._rowsrc(first.data_ptr(), (T if has_traj else Wd) * nz, nz, nz)
@@ -826,6 +842,29 @@ class GCPTreeModel:
                 self._mlp(plan, "inv_mdl", P["inv_mdl"], [s0, s1], B * (Wd - 1), Wd - 1, out=act.data_ptr(),
                           ob=(Wd - 1) * hp.n_actions, orow=hp.n_actions)
                 outs["actions_padded"] = act
+            aux_rows = None
+            if train_aux and ((hp.attach_inv_mdl and not hp.train_inv_mdl_full_seq) or (hp.attach_cost_mdl and hp.run_cost_mdl)):
+                aux_rows = self._buf("aux_rows", (4, B), torch.int32)
+                plan.add("aux_index_rows", lib.gcpx_aux_index_rows, tin["inv_t0"].data_ptr(), tin["inv_t1"].data_ptr(),
+                         tin["cost_start_idx"].data_ptr(), tin["cost_end_idx"].data_ptr(), B, T, Wd, aux_rows.data_ptr())
+                gather = lambda t, i: self._rowsrc(t.data_ptr(), 0, nz, nz, rowidx=aux_rows[i])
+            if hp.attach_inv_mdl and train_aux and not hp.train_inv_mdl_full_seq:
+                # InverseModel.forward on ONE sampled frame pair per sequence (inverse_mdl.py:136-178): first frame from the encoder
+                # (train_im0_enc), second from the model's matched latents; both detached, so only action_pred is trained
+                act = self._buf("actions_sampled", (B, hp.n_actions))
+                self._mlp(plan, "inv_mdl", P["inv_mdl"], [gather(enc_traj, 0), gather(mes, 1)], B, B, out=act.data_ptr(), ob=0,
+                          orow=hp.n_actions)
+                outs["actions_sampled"] = act
+            if hp.attach_cost_mdl and hp.run_cost_mdl and train_aux:
+                # CostModel.forward (cost_mdl.py:42-57): cost_pred on a sampled (start, end) pair of the matched latents against the
+                # ground-truth path cost of the same segment of traj_seq (_general_cost with EuclideanPathLength, conf.py:35-37)
+                cost = self._buf("cost_pred", (B, 1))
+                self._mlp(plan, "cost_mdl", P["cost_mdl"], [gather(mes, 2), gather(mes, 3)], B, B, out=cost.data_ptr(), ob=0, orow=1)
+                gt = self._buf("cost_target", (B,))
+                rows = hp.input_nc * hp.img_sz
+                plan.add("path_cost", lib.gcpx_path_cost, tin["traj_seq"].data_ptr(), tin["cost_start_idx"].data_ptr(),
+                         tin["cost_end_idx"].data_ptr(), B, T, rows, hp.img_sz, self._buf("cost_partial", (B, rows)).data_ptr(), gt.data_ptr())
+                outs["cost_pred"], outs["cost_target"] = cost, gt
 
         # The latent-space heads are ~60 us of small launches.  Beside the decoder blocks (persistent grids, two workgroups per
         # CU) they cost more than that in interference (pyramid-2: 317 us beside them, 200 us alone), so they run in front.
@@ -972,7 +1011,12 @@ class GCPTreeModel:
             if "regressed_state_padded" in outs and "traj_seq_states" in tin:
                 la.regressed_state, la.state_target = outs["regressed_state_padded"].data_ptr(), tin["traj_seq_states"].data_ptr()
             la.seq_len = seq_len.data_ptr()
-            loss_out = self._buf("losses", (8,), zero=True)
+            if "actions_sampled" in outs and "actions" in tin:          # inverse_mdl.py:181-191
+                la.action_pred, la.action_seq, la.inv_t0 = outs["actions_sampled"].data_ptr(), tin["actions"].data_ptr(), tin["inv_t0"].data_ptr()
+                la.n_actions, la.w_action = hp.n_actions, hp.action_rec_weight
+            if "cost_pred" in outs:                                     # cost_mdl.py:59-62
+                la.cost_pred, la.cost_target, la.w_cost = outs["cost_pred"].data_ptr(), outs["cost_target"].data_ptr(), 1.0
+            loss_out = self._buf("losses", (16,), zero=True)
             la.out, la.B, la.T, la.N, la.state_dim = loss_out.data_ptr(), B, T, (N - 1 if adaptive else N), hp.state_dim
             la.w_rec, la.w_kl, la.w_len, la.w_exist, la.w_state = hp.dense_img_rec_weight, hp.kl_weight, hp.length_pred_weight, 1.0, 1.0
             la.total_div = float(T * hp.input_nc * S * S)
@@ -1005,11 +1049,21 @@ class GCPTreeModel:
         has_z = "z" in inputs
         if not has_traj and not has_z and not self._sample_prior:
             raise ValueError("posterior path needs traj_seq (or use val_mode() / feed z)")
-        if "end_ind" not in inputs:
-            raise ValueError("end_ind must be fed (sampled lengths are not part of the hot path, SURVEY D3)")
-        tin = {}
+        # get_end_ind (base_gcp.py:215-229): under val_mode(pred_length=True) the length is drawn from the length predictor whenever
+        # its loss is trained (or no end_ind is fed); otherwise the fed end_ind is used
+        pred_len = bool(self._has_pred_length and self._use_pred_length and hp.regress_length and
+                        (hp.length_pred_weight > 0 or "end_ind" not in inputs))
+        if "end_ind" not in inputs and not pred_len:
+            raise ValueError("end_ind must be fed unless val_mode(pred_length=True) draws it from the length predictor")
         with_loss = has_traj and phase == "train" and "pad_mask" in inputs
-        opt = tuple(k for k in ("pad_mask", "traj_seq_states", "w0") if with_loss and k in inputs)
+        train_aux = has_traj and phase == "train"
+        need_idx = self._has_aux_training and train_aux and ((hp.attach_inv_mdl and not hp.train_inv_mdl_full_seq) or
+                                                             (hp.attach_cost_mdl and hp.run_cost_mdl))
+        AUX = ("inv_t0", "inv_t1", "cost_start_idx", "cost_end_idx")
+        fed_idx = need_idx and all(k in inputs for k in AUX)
+        opt = tuple(k for k in ("pad_mask", "traj_seq_states", "w0", "actions") if with_loss and k in inputs)
+        if not self._decode and (with_loss or has_traj):
+            raise ValueError("decode=False is the planner's prior / given-z path: no ground-truth sequence, no losses")
         # inputs are copied into persistent buffers (one D2D copy; 63 MB for traj_seq at c2 = ~25 us) so that the
         # captured graph — which bakes in device pointers — stays valid whatever tensors the caller passes
         # The copies are enqueued on the MODEL's stream (ordered behind the caller's stream by one event), so the launch that
@@ -1017,14 +1071,36 @@ class GCPTreeModel:
         caller = torch.cuda.current_stream(self.device)
         self._stream.wait_stream(caller)
         tin = {}
+        names = ("I_0", "I_g") + (("end_ind",) if "end_ind" in inputs else ()) + (("traj_seq",) if has_traj else ()) + \
+            (("z",) if has_z else ()) + opt + (AUX if fed_idx else ())
         with torch.cuda.stream(self._stream):
-            for k in ("I_0", "I_g", "end_ind") + (("traj_seq",) if has_traj else ()) + (("z",) if has_z else ()) + opt:
+            for k in names:
                 t = inputs[k]
-                want = torch.int64 if k == "end_ind" else torch.float32
+                want = torch.int64 if (k == "end_ind" or k in AUX) else torch.float32
                 buf = self._buf("in." + k, tuple(t.shape), want)
                 buf.copy_(t, non_blocking=True)
-                t.record_stream(self._stream)
+                if t.is_cuda:
+                    t.record_stream(self._stream)
                 tin[k] = buf
+            if "end_ind" not in tin:
+                tin["end_ind"] = self._buf("in.end_ind", (B,), torch.int64)       # written by the length draw inside the plan
+            if pred_len:
+                # the OneHotCategorical draw of the sequence length (misc.py:49) as one uniform number per sequence
+                lu = self._buf("in.len_u", (B,))
+                if "len_u" in inputs:
+                    lu.copy_(inputs["len_u"], non_blocking=True)
+                else:
+                    lu.uniform_()
+                tin["len_u"] = lu
+            if need_idx and not fed_idx:
+                # InverseModel.sample_offsets / CostModel._general_cost draw their frame indices with np.random on the host
+                # (inverse_mdl.py:84-104, cost_mdl.py:105-107); here: four uniform numbers per sequence, one launch
+                au = self._buf("in.aux_u", (4, B))
+                au.uniform_()
+                for k in AUX:
+                    tin[k] = self._buf("in." + k, (B,), torch.int64)
+                rt.check(self.lib.gcpx_aux_sample_indices(tin["end_ind"].data_ptr(), au.data_ptr(), B, hp.inv_mdl_temp_dist,
+                                                          *[tin[k].data_ptr() for k in AUX], self._stream.cuda_stream), "aux_sample_indices")
             if not has_z:
                 # the draws of Gaussian.sample() live in a persistent buffer as well
                 eps = self._buf("eps", (B, self._n_latents(), hp.nz_vae))
@@ -1032,11 +1108,13 @@ class GCPTreeModel:
                     eps.normal_()
                 else:
                     eps.copy_(noise)
-                    noise.record_stream(self._stream)
+                    if noise.is_cuda:
+                        noise.record_stream(self._stream)
                 tin["eps"] = eps
-        if not self._decode and (with_loss or has_traj):
-            raise ValueError("decode=False is the planner's prior / given-z path: no ground-truth sequence, no losses")
-        key = (B, has_traj, has_z, self._sample_prior, phase, self.training, self.materialize_distr, with_loss, self._decode)
+        # the plan (and its captured graph) bakes in buffer addresses and sizes: everything that selects buffers is part of the key
+        shapes = tuple((k, tuple(tin[k].shape)) for k in sorted(tin))
+        key = (B, has_traj, has_z, self._sample_prior, phase, self.training, self.materialize_distr, with_loss, self._decode, pred_len,
+               shapes)
         if key not in self._plans:
             plan = self._build_plan(key, tin)
             plan.keep.append(tin)
@@ -1192,6 +1270,10 @@ class GCPTreeModel:
             res[name] = Outputs(value=lv[i], weight=w[name])
         if hp.adaptive:                                             # tree_module.py:128 (entropy_weight = 0: logged only)
             res["entropy"] = Outputs(value=raw["entropy_sum"][0] / raw["entropy_df"].numel(), weight=hp.entropy_weight)
+        if raw.get("actions_sampled") is not None and "actions" in inputs:      # base_gcp.py:275-276, inverse_mdl.py:181-191
+            res["action_reconst"] = Outputs(value=lv[7], weight=hp.action_rec_weight)
+        if raw.get("cost_pred") is not None:                        # base_gcp.py:279-280, cost_mdl.py:59-62
+            res["cost_estimation"] = Outputs(value=lv[8], weight=1.0)
         res["nll"] = Outputs(value=lv[6], weight=0.0)               # base_gcp.py:289-290
         res["_total"] = lv[5]
         return res
@@ -1226,6 +1308,10 @@ class GCPTreeModel:
             res.regressed_state = o["regressed_state_padded"][:, :m]
         if "actions_padded" in o:
             res.actions = o["actions_padded"][:, :m - 1]
+        elif "actions_sampled" in o:                                # one sampled frame pair per sequence (inverse_mdl.py:136-178)
+            res.actions = o["actions_sampled"]
+        if "cost_pred" in o:
+            res.cost, res.cost_target = o["cost_pred"], o["cost_target"][:, None]
         return res
 
 

@@ -3,7 +3,7 @@
 All hot kernels put output channels / GEMM columns on the MFMA i side, so the A operand of
 v_mfma_f32_16x16x4_f32 is a weight tile:  lane l holds W[n = 16*nt + (l & 15)][k] for the 4 k-values
 k = 16*kg + 4*(l >> 4) + s, s = 0..3 (one float4).  A packed tensor is therefore [steps][tiles][64 lanes][4]:
-each (step, tile) is one coalesced 1 KiB wavefront load.  See csrc/common.cuh for the operand maps.
+each (step, tile) is one coalesced 1 KiB wavefront load.  See csrc/common.h for the operand maps.
 """
 import torch
 

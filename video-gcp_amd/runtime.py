@@ -34,7 +34,9 @@ class LossArgs(C.Structure):
     _fields_ = [("nll_bt", vp), ("pad_mask", vp), ("kl_b", vp), ("len_logits", vp), ("end_ind", vp), ("existence", vp),
                 ("leave", vp), ("regressed_state", vp), ("state_target", vp), ("seq_len", vp), ("out", vp),
                 ("B", i32), ("T", i32), ("N", i32), ("state_dim", i32), ("w_rec", C.c_float), ("w_kl", C.c_float),
-                ("w_len", C.c_float), ("w_exist", C.c_float), ("w_state", C.c_float), ("total_div", C.c_float)]
+                ("w_len", C.c_float), ("w_exist", C.c_float), ("w_state", C.c_float), ("total_div", C.c_float),
+                ("action_pred", vp), ("action_seq", vp), ("inv_t0", vp), ("cost_pred", vp), ("cost_target", vp),
+                ("n_actions", i32), ("w_action", C.c_float), ("w_cost", C.c_float)]
 
 
 class RowSrc(C.Structure):
@@ -159,6 +161,11 @@ SYMBOLS = [
     ("gcpx_im2col_image", C.c_int, [vp, vp, i32, i32, i32, vp]),
     ("gcpx_dlm_nll_bwd", C.c_int, [vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, vp]),
     ("gcpx_loss_heads_bwd", C.c_int, [C.POINTER(LossArgs), vp, vp, vp, vp]),
+    ("gcpx_loss_aux_heads_bwd", C.c_int, [C.POINTER(LossArgs), vp, vp, vp]),
+    ("gcpx_aux_sample_indices", C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    ("gcpx_aux_index_rows", C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    ("gcpx_path_cost", C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    ("gcpx_sample_length", C.c_int, [vp, vp, i32, i32, i32, vp, vp]),
     ("gcpx_repack", C.c_int, [vp, vp, vp, vp, i64, vp]),
     ("gcpx_radam_step", C.c_int, [vp, vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     ("gcpx_attention", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -17,6 +17,10 @@ from .params import init_params_sequential
 
 
 class GCPSequentialModel(GCPTreeModel):
+    # the flat baseline is trained without the sampled inverse-model / cost-model pairs and always rolls out to the fed end_ind
+    _has_aux_training = False
+    _has_pred_length = False
+
     def _check_hp(self, hp):
         assert hp.lstm_init in ("zero", "mlp")          # the cell state always starts at zero (hyperparameters.py:96)
 
@@ -185,7 +189,7 @@ class GCPSequentialModel(GCPTreeModel):
             la.nll_bt, la.pad_mask, la.kl_b = nll_bt.data_ptr(), tin["w0"].data_ptr(), kl_b.data_ptr()   # frame 0 weighs 0
             la.len_logits = outs["seq_len_logits"].data_ptr() if "seq_len_logits" in outs else None
             la.end_ind, la.seq_len = tin["end_ind"].data_ptr(), seq_len.data_ptr()
-            loss_out = self._buf("losses", (8,), zero=True)
+            loss_out = self._buf("losses", (16,), zero=True)
             la.out, la.B, la.T, la.N, la.state_dim = loss_out.data_ptr(), B, T, T - 1, hp.state_dim
             la.w_rec, la.w_kl, la.w_len, la.w_exist, la.w_state = hp.dense_img_rec_weight, hp.kl_weight, hp.length_pred_weight, 0.0, 0.0
             la.total_div = float(T * hp.input_nc * S * S)

@@ -24,9 +24,25 @@ def make_inputs(hp, seed=0, variant="B", device="cpu"):
                   actions=torch.randn(B, T - 1, hp.n_actions, generator=g))
     noise = torch.randn(B, hp.n_nodes, hp.nz_vae, generator=g)
     z = torch.randn(B, hp.n_nodes, hp.nz_vae, generator=g)
+    inputs.update(aux_indices(end_ind, torch.rand(4, B, generator=g), hp.inv_mdl_temp_dist))
     if device != "cpu":
         inputs = {k: v.to(device) for k, v in inputs.items()}
     return inputs, noise, z
+
+
+def aux_indices(end_ind, u, temp_dist=1):
+    """Index inputs of the auxiliary models' training paths from four uniform draws per sequence (u [4, B] in [0, 1)):
+    inv_t0 ~ U{0 .. end_ind - temp_dist}, inv_t1 = inv_t0 + U{1 .. temp_dist} (inverse_mdl.py:84-104);
+    cost_start_idx ~ U{0 .. end_ind - 1}, cost_end_idx ~ U{start + 1 .. end_ind} (cost_mdl.py:105-107).
+    Same distributions as the reference's np.random draws (a different random stream)."""
+    e = end_ind.to(torch.float64)
+    u = u.to(torch.float64)
+    fl = lambda x: torch.floor(x).long()
+    t0 = torch.minimum(fl(u[0] * (e - temp_dist + 1)), end_ind - temp_dist)
+    t1 = t0 + 1 + torch.clamp(fl(u[1] * temp_dist), max=temp_dist - 1)
+    s = torch.minimum(fl(u[2] * e), end_ind - 1)
+    en = s + 1 + torch.minimum(fl(u[3] * (e - s.to(torch.float64))), end_ind - s - 1)
+    return dict(inv_t0=t0, inv_t1=t1, cost_start_idx=s, cost_end_idx=en)
 
 
 def make_inputs_device(hp, seed, variant, device):
@@ -45,7 +61,9 @@ def make_inputs_device(hp, seed, variant, device):
             end_ind[1] = 2
     pad_mask = (torch.arange(T, device=device)[None] <= end_ind[:, None]).float()
     traj = traj * pad_mask[:, :, None, None, None]
-    return dict(traj_seq=traj, pad_mask=pad_mask, I_0=traj[:, 0].clone(), I_g=traj[torch.arange(B, device=device), end_ind].clone(),
-                end_ind=end_ind, start_ind=torch.zeros(B, dtype=torch.long, device=device),
-                traj_seq_states=torch.randn(B, T, hp.state_dim, generator=g, device=device),
-                actions=torch.randn(B, T - 1, hp.n_actions, generator=g, device=device))
+    inputs = dict(traj_seq=traj, pad_mask=pad_mask, I_0=traj[:, 0].clone(), I_g=traj[torch.arange(B, device=device), end_ind].clone(),
+                  end_ind=end_ind, start_ind=torch.zeros(B, dtype=torch.long, device=device),
+                  traj_seq_states=torch.randn(B, T, hp.state_dim, generator=g, device=device),
+                  actions=torch.randn(B, T - 1, hp.n_actions, generator=g, device=device))
+    inputs.update(aux_indices(end_ind, torch.rand(4, B, generator=g, device=device), hp.inv_mdl_temp_dist))
+    return inputs

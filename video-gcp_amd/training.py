@@ -50,6 +50,8 @@ class GCPTrainStep:
         self.opt_state = torch.zeros(4, device=model.device)
         self.bk = model.build_arena(self._pack_backward)
         self._bplans = {}
+        # backward plans are built from forward plans: drop them whenever the model drops those (load_state_dict, build_arena)
+        model._plan_listeners = getattr(model, "_plan_listeners", []) + [self._bplans.clear]
         self.wgroup_min_blocks = int(os.environ.get("GCPX_WGROUP_MIN", "256"))
         self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
         self.fused_mlp_bwd = os.environ.get("GCPX_NO_FUSED_MLP_BWD") is None
@@ -120,6 +122,10 @@ class GCPTrainStep:
             X["length_pred"] = self._pack_predictor_T(sd, "length_pred.p", [(0, 2 * nz)])
         if hp.attach_state_regressor:
             X["state_regressor"] = self._pack_predictor_T(sd, "state_regressor", [])
+        if hp.attach_inv_mdl:
+            X["inv_mdl"] = self._pack_predictor_T(sd, "inv_mdl.action_pred", [])
+        if hp.attach_cost_mdl:
+            X["cost_mdl"] = self._pack_predictor_T(sd, "cost_mdl.cost_pred", [])
         if hp.adaptive:
             X["distance"] = self._pack_predictor_T(sd, "tree_module.tree_modules.0.binding.distance_predictor", [(0, nz), (nz, nz)])
         else:
@@ -505,6 +511,17 @@ class GCPTrainStep:
         if has_state:   # input detached (base_gcp.py:253-256): parameter gradients only
             self._mlp_bwd(plan, "state_regressor", "state_regressor", rec["mlp:state_regressor"], self.bk["state_regressor"],
                           dstate.data_ptr(), 16, [])
+
+        # inverse model / cost model: inputs detached (inverse_mdl.py:160-162, cost_mdl.py:108-109): parameter gradients only
+        has_inv, has_cost = bool(la.action_pred), bool(la.cost_pred)
+        if has_inv or has_cost:
+            daction = buf("bw.daction", (B, 16)) if has_inv else None
+            dcost = buf("bw.dcost", (B, 16)) if has_cost else None
+            plan.add("bw.aux_heads", lib.gcpx_loss_aux_heads_bwd, C.byref(la), rt.ptr(daction), rt.ptr(dcost))
+            if has_inv:
+                self._mlp_bwd(plan, "inv_mdl", "inv_mdl.action_pred", rec["mlp:inv_mdl"], self.bk["inv_mdl"], daction.data_ptr(), 16, [])
+            if has_cost:
+                self._mlp_bwd(plan, "cost_mdl", "cost_mdl.cost_pred", rec["mlp:cost_mdl"], self.bk["cost_mdl"], dcost.data_ptr(), 16, [])
 
         self._flush(plan)
         # ---- decoder (tree_dense_rec.py:42 backward) ----
