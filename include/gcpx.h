@@ -167,6 +167,12 @@ typedef struct gcpx_gemm_args {
 } gcpx_gemm_args;
 
 int gcpx_gemm(const gcpx_gemm_args* a, void* stream);
+/* Several independent small-M problems (those gcpx_gemm runs as split-K 16 x 16 tiles) in ONE launch: the same layer of the
+   prior / inference / generator nets of a VRNN step (sequential.py:49-54), or independent GEMMs of a tree level.
+   gcpx_gemm_group_dims validates a HOST table of n (<= 16) problems (GCPX_ERR_UNSUPPORTED when one is not in that regime) and
+   fills dims [n][4] + the grid size; the caller uploads table and dims once and replays gcpx_gemm_group. */
+int gcpx_gemm_group_dims(const gcpx_gemm_args* host_table, int32_t n, int32_t* dims, int32_t* total_blocks);
+int gcpx_gemm_group(const gcpx_gemm_args* dev_table, const int32_t* dev_dims, int32_t n, int32_t total_blocks, void* stream);
 /* number of row blocks gcpx_gemm uses for an M x N problem (first dim of stats_partial) */
 int gcpx_gemm_row_blocks(int32_t M, int32_t N);
 
@@ -211,6 +217,13 @@ typedef struct gcpx_mlp_args {
 } gcpx_mlp_args;
 
 int gcpx_mlp(const gcpx_mlp_args* a, void* stream);
+/* Several independent Predictors of the same hidden width in ONE launch: the prior next to the posterior of a tree level
+   (tree_module.py:77 + inference.py:27-35), the latent-space heads of run_auxilliary_models (base_gcp.py:234-262).
+   gcpx_mlp_group_dims validates a HOST table of n (<= 16) problems and fills dims [n][4] = {first block, row blocks, head
+   splits, 0} + the grid size; the caller uploads table and dims once (plan build) and replays gcpx_mlp_group. */
+int gcpx_mlp_group_dims(const gcpx_mlp_args* host_table, int32_t n, int32_t* dims, int32_t* total_blocks);
+int gcpx_mlp_group(const gcpx_mlp_args* dev_table, const int32_t* dev_dims, int32_t n, int32_t total_blocks, int32_t mid,
+                   void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Balanced frame binding — integer bookkeeping, bit-exact with
@@ -330,6 +343,17 @@ int gcpx_path_cost(const float* x, const int64_t* start_idx, const int64_t* end_
 /* get_end_ind under val_mode(pred_length=True) (base_gcp.py:219-226): end_ind[b] = max(min_len, inverse CDF of
    softmax(logits[b]) at u[b]) — the OneHotCategorical draw (misc.py:49) with the uniform number fed in */
 int gcpx_sample_length(const float* logits, const float* u, int32_t B, int32_t T, int32_t min_len, int64_t* end_ind, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------------
+ * Evaluation metrics (csrc/metrics.hip): mse / psnr / ssim of generated against ground-truth sequences —
+ * Evaluator.compute_metrics (gcp/evaluation/compute_metrics.py:123-130; blox.torch.evaluation is absent, spec in
+ * video-gcp_amd/evaluation.py).  tgt [B][T][C][H][W] in [-1,1]; est: a pool of frames [R][C][H][W]; frame_map [B*T] = pool
+ * frame compared with target frame (b, t) (negative: skipped; NULL: identity); per sequence the frames t in [first[b], last[b])
+ * are averaged (the harness crops the two conditioning frames).  scratch: 2*B*T*C doubles.  out [B][3] = mse, psnr, ssim.
+ * ------------------------------------------------------------------------------------------------- */
+int gcpx_image_metrics(const float* est, const float* tgt, const int32_t* frame_map, const int32_t* first, const int32_t* last,
+                       int32_t B, int32_t T, int32_t C, int32_t H, int32_t W, double* scratch, float* out, void* stream);
 
 
 /* ===================================================================================================

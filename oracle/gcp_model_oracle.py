@@ -253,7 +253,8 @@ def _balanced_matching_and_pruning(sd, hp, inp, out, bf, df_lat, img_df, end_ind
     # balanced: pruned_prediction overwritten by BalancedEvalBinding.get_all_samples (tree.py:62-65)
     leave_df = _bf_to_df(match_dist.bool().any(-1)[:, :, None], L)[:, :, 0]
     out["leave_df"] = leave_df
-    out["pruned_prediction"] = [img_df[i][leave_df[i]] for i in range(B)]
+    if img_df is not None:
+        out["pruned_prediction"] = [img_df[i][leave_df[i]] for i in range(B)]
     out["model_enc_seq_list"] = [df_lat[i][leave_df[i]] for i in range(B)]        # base_gcp.py:366-368 ('e_g_prime')
 
     # ---- matched sequence for the loss (frame_binding.py:28-34, 88-99) ---------------------------------
@@ -302,7 +303,8 @@ def _adaptive_matching_and_pruning(sd, hp, inp, out, bf, df_lat, img_df, end_ind
 # ---------------------------------------------------------------------------------------------------
 # forward
 # ---------------------------------------------------------------------------------------------------
-def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, phase="train", taps=None, use_pred_length=False):
+def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, phase="train", taps=None, use_pred_length=False,
+            decode=True):
     """BaseGCPModel.forward for TreeModel (base_gcp.py:140-161).
 
     inputs: dict with I_0, I_g [B,3,H,W]; end_ind int64 [B]; optional start_ind, traj_seq [B,T,3,H,W], pad_mask,
@@ -310,6 +312,8 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     noise:  eps [B,N,nz_vae] in breadth-first node order for the reparametrised samples (replaces torch RNG so
             the HIP path can be fed identical numbers).
     sample_prior: val_mode() switch (base_gcp.py:44-53).
+    decode: False skips TreeDenseRec (no images / pruned_prediction): the latent tree, pruning and latent-space heads only — what the
+            planner's learned cost reads (cost_fcn.py:84-97); used to check all 512 candidates of a CEM iteration.
     use_pred_length: val_mode(pred_length=True): the sequence length is drawn from the length predictor (base_gcp.py:219-226);
             needs inputs["len_u"] (one uniform draw per sequence).
     Optional index inputs for the auxiliary models' training paths: inv_t0 / inv_t1 (inverse_mdl.py:84-104),
@@ -432,12 +436,13 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     bf = {k: torch.cat([lay[k] for lay in layers], 1) for k in layers[0].keys()}          # get_attr_bf
     # dense_rec = TreeDenseRec.forward (tree_dense_rec.py:41-44)
     tap("bf_e_g_prime", bf["e_g_prime"])
-    dec = decode_seq(sd, hp, inp, bf["e_g_prime"], training_bn)
-    bf.update(dec)
+    if decode:
+        dec = decode_seq(sd, hp, inp, bf["e_g_prime"], training_bn)
+        bf.update(dec)
     out["tree_bf"] = bf
 
     df_lat = _bf_to_df(bf["e_g_prime"], L)
-    img_df = _bf_to_df(bf["images"], L)
+    img_df = _bf_to_df(bf["images"], L) if decode else None
     if hp.adaptive:
         _adaptive_matching_and_pruning(sd, hp, inp, out, bf, df_lat, img_df, end_ind, phase)
     else:

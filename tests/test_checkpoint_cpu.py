@@ -39,3 +39,27 @@ def test_roundtrip_and_prefix_filter(tmp_path):
     ck.load_weights(latest, c, submodule_name="cost_mdl")
     assert torch.equal(c.sd["cost_mdl.cost_pred.head.linear.bias"], a.sd["cost_mdl.cost_pred.head.linear.bias"])
     assert torch.equal(c.sd["encoder.net.input.conv.weight"], before)
+
+
+def test_resume_semantics_follow_the_reference(tmp_path):
+    """checkpoint_handler.py:31-42 + train.py:56-62: 'latest' on an empty folder raises NoCheckpointsException (resume -> epoch 0);
+    names are joined with the weights folder and get '.pth' appended; a strict sub-module load checks that sub-module's keys"""
+    import pytest
+    with pytest.raises(ck.NoCheckpointsException):
+        ck.get_resume_ckpt_file("latest", str(tmp_path))
+    assert ck.get_resume_ckpt_file("best_model", str(tmp_path)) == os.path.join(str(tmp_path), "best_model.pth")
+    assert ck.get_resume_ckpt_file("other.pth", str(tmp_path)) == os.path.join(str(tmp_path), "other.pth")
+    assert ck.get_resume_ckpt_file("7", str(tmp_path)) == os.path.join(str(tmp_path), "weights_ep7.pth")
+    with pytest.raises(ValueError):
+        ck.load_weights(os.path.join(str(tmp_path), "weights_ep7.pth"), _M())
+    a = _M()
+    path = ck.save_checkpoint(a, str(tmp_path), 1)
+    raw = torch.load(path)
+    del raw["state_dict"]["cost_mdl.cost_pred.head.linear.bias"]
+    raw["state_dict"]["cost_mdl.cost_pred.head.linear.bias_typo"] = torch.zeros(1)
+    torch.save(raw, path)
+    with pytest.raises(KeyError):
+        ck.load_weights(path, _M(), submodule_name="cost_mdl")           # a misspelled key inside the sub-module is an error
+    ck.load_weights(path, _M(), submodule_name="cost_mdl", strict=False)
+    with pytest.raises(ValueError):
+        ck.load_weights(path, _M(), submodule_name="inv_mdl")

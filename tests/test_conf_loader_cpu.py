@@ -1,0 +1,73 @@
+"""Experiment configuration in the reference's format (gcp_builder.py:112-147): a conf.py with `configuration` / `model_config`
+that imports blox / gcp / experiments names, loaded without those packages."""
+import os
+import textwrap
+
+import pytest
+
+from video_gcp_amd import conf_loader as CL
+
+CONF = textwrap.dedent('''
+    import os
+    from blox import AttrDict
+    from gcp.datasets.data_loader import MazeTopRenderedGlobalSplitVarLenVideoDataset
+    from gcp.planning.cem.cost_fcn import EuclideanPathLength
+    current_dir = os.path.dirname(os.path.realpath(__file__))
+    from experiments.prediction.base_configs import gcp_tree as base_conf
+
+    configuration = AttrDict(base_conf.configuration)
+    configuration.update({'dataset_name': 'nav_25rooms', 'batch_size': 16, 'lr': 2e-4, 'epoch_cycles_train': 2, 'n_rooms': 25})
+    model_config = AttrDict(base_conf.model_config)
+    model_config.update({'untied_layers': True, 'hierarchy_levels': 8, 'ngf': 16, 'nz_mid_lstm': 512, 'n_lstm_layers': 3,
+                         'nz_mid': 128, 'nz_enc': 128, 'nz_vae': 256, 'regress_length': True, 'attach_state_regressor': True,
+                         'attach_cost_mdl': True, 'cost_mdl_params': AttrDict(cost_fcn=EuclideanPathLength),
+                         'attach_inv_mdl': True, 'inv_mdl_params': AttrDict(n_actions=2, use_convs=False, build_encoder=False),
+                         'decoder_distribution': 'discrete_logistic_mixture'})
+    model_config.pop("add_weighted_pixel_copy")
+''')
+
+
+def test_reference_style_conf_py(tmp_path):
+    (tmp_path / "conf.py").write_text(CONF)
+    hp, trainer, ignored = CL.load_conf(str(tmp_path), max_seq_len=200)
+    assert trainer["lr"] == 2e-4 and trainer["batch_size"] == 16 and trainer["metric_pruning_scheme"] == "pruned_dtw"
+    assert hp.batch_size == 16 and hp.hierarchy_levels == 8 and hp.n_nodes == 255 and hp.matching_type == "balanced"
+    assert hp.nz_vae == 256 and hp.attach_cost_mdl and hp.attach_inv_mdl and hp.n_actions == 2
+    assert hp.decoder_distribution == "discrete_logistic_mixture" and hp.untied_layers
+    assert "dataset_name" in ignored and "model" in ignored
+    # nothing leaks into the interpreter's module table
+    import sys
+    assert "blox" not in sys.modules and "experiments" not in sys.modules
+
+
+def test_adaptive_base_config_and_errors(tmp_path):
+    (tmp_path / "conf.py").write_text(textwrap.dedent('''
+        from blox import AttrDict
+        from experiments.prediction.base_configs import gcp_adaptive as base_conf
+        configuration = AttrDict(base_conf.configuration)
+        configuration.update({'batch_size': 8, 'lr': 1e-3})
+        model_config = AttrDict(base_conf.model_config)
+        model_config.update({'hierarchy_levels': 8})
+    '''))
+    hp, trainer, _ = CL.load_conf(str(tmp_path), max_seq_len=200)
+    assert hp.adaptive and hp.attentive_inference and hp.batch_size == 8
+    (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'tree_lstm': 'sum'}\n")
+    with pytest.raises(ValueError):
+        CL.load_conf(str(tmp_path))
+    (tmp_path / "conf.py").write_text("x = 1\n")
+    with pytest.raises(ValueError):
+        CL.load_conf(str(tmp_path))
+
+
+def test_conf_json_and_default(tmp_path):
+    (tmp_path / "conf.json").write_text('{"config": "c1", "overrides": {"batch_size": 3}, "lr": 0.01}')
+    hp, trainer, _ = CL.load_conf(str(tmp_path))
+    assert hp.batch_size == 3 and hp.img_sz == 32 and trainer["lr"] == 0.01
+    hp, trainer, _ = CL.load_conf(None, default="c2")
+    assert hp.max_seq_len == 80 and trainer == {}
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/experiments/prediction/25room/gcp_tree"), reason="reference tree not present")
+def test_the_reference_25room_conf_itself():
+    hp, trainer, ignored = CL.load_conf("/root/reference/experiments/prediction/25room/gcp_tree", max_seq_len=200)
+    assert trainer["lr"] == 2e-4 and hp.batch_size == 16 and hp.hierarchy_levels == 8 and hp.attach_cost_mdl

@@ -98,3 +98,89 @@ def test_two_rank_gradient_all_reduce_keeps_replicas_identical():
         gs = [torch.randn(1000, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(2)]
         opt.step(theta, {"p": (gs[0] + gs[1]) * 0.5})
     assert torch.allclose(res[0], theta["p"], atol=1e-6)
+
+
+def test_gradient_bucket_ranges_tile_the_flat_gradient():
+    """bucket layout of the data-parallel exchange for the c2 model: one ~41 MB bucket per tree level 6..1 in the order the
+    backward finishes them, then the rest (conv stacks, heads, level 0)"""
+    sys.path.insert(0, ROOT)
+    import video_gcp_amd as V
+    from video_gcp_amd.dist import gradient_bucket_ranges
+    hp = V.config("c2")
+    off, poff = 0, {}
+    for k, v in V.init_params(hp, seed=0).items():
+        poff[k] = (off, tuple(v.shape))
+        off += (v.numel() + 3) // 4 * 4
+    r = gradient_bucket_ranges(poff, hp.hierarchy_levels, True)
+    assert [n for n, _, _ in r] == ["tree6", "tree5", "tree4", "tree3", "tree2", "tree1", "rest"]
+    assert r[-1][1] == 0 and r[0][2] == off
+    assert sum(hi - lo for _, lo, hi in r) == off
+    lo, hi = [(a, b) for n, a, b in r if n == "tree3"][0]
+    inside = [k for k, (o, _) in poff.items() if lo <= o < hi]
+    assert inside and all(k.startswith("tree_module.tree_modules.3.") for k in inside)
+    assert gradient_bucket_ranges(poff, hp.hierarchy_levels, False) == [("all", 0, off)]
+
+
+def _bucket_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from video_gcp_amd import dist as D
+    D.init_from_env("gloo")
+    n = 1000
+    ranges = [("tree2", 700, 1000), ("tree1", 300, 700), ("rest", 0, 300)]
+    outs = []
+    for step in range(2):
+        flat = torch.zeros(n)
+        b = D.GradBuckets(flat, ranges)
+        g = torch.randn(n, generator=torch.Generator().manual_seed(10 * step + rank))
+        # the "backward": leaves first; a bucket is handed to the exchange as soon as its slice is written, and the slices of the
+        # levels above are written WHILE that all-reduce is in flight
+        for i, (_, lo, hi) in enumerate(ranges[:-1]):
+            flat[lo:hi] = g[lo:hi]
+            b.reduce_async(i)
+        flat[0:300] = g[0:300]
+        scale = b.finish()
+        assert scale == 0.5 and not b.works
+        outs.append(flat.clone())
+    q.put((rank, outs))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_bucketed_gradient_exchange():
+    """the bucket scheduler GCPTrainStep drives (dist.GradBuckets): buckets started out of order while later slices are still
+    being produced give the plain sum on every rank, bit-identical across ranks"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for step in range(2):
+        want = sum(torch.randn(1000, generator=torch.Generator().manual_seed(10 * step + r)) for r in range(2))
+        assert torch.equal(res[0][step], res[1][step])
+        assert torch.allclose(res[0][step], want, atol=1e-6)
+
+
+def test_bench_self_launches_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns one child per rank BEFORE touching a GPU, wires
+    RANK / WORLD_SIZE / MASTER_*, relays rank 0's single JSON line and returns the children's status.  --launch-check runs the
+    rendezvous + barrier + max-over-ranks plumbing only (no GPU work), here over gloo."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["launch_check"] is True and d["n_gpus"] == 2 and d["ranks"] == [0, 1] and d["slowest_rank_s"] == 2.0
+    # a failing rank fails the whole launch instead of hanging it
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", "--backend", "gloo",
+                        "--fail-rank", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0

@@ -1,0 +1,284 @@
+"""-m gpu: every BASELINE.json config at its OWN size (item counts, grid sizing and BatchNorm partial counts differ from the
+small parity cases):
+
+  configs[1]  c2  64x64, T=80, B=16, 1 GPU            forward vs the oracle, batch-stat BatchNorm over the full batch, and
+                                                      running-stat BatchNorm against the oracle on a slice of the sequences
+  configs[2]  c3  training shard, B=16                gradient vs central differences of the HIP loss itself along random parameter
+                                                      directions (size-independent property), losses vs the oracle, loss decreases
+  configs[3]  c4  64 and 512 candidates x horizon 80  rollout vs the oracle on sampled candidates; costs of ALL candidates vs the
+                                                      oracle (latent tree only); elites identical
+  configs[4]  c5  adaptive binding, T=200, B=8        binding properties + forward / losses vs the oracle on a slice (running-stat BN)
+
+Oracle legs are sized for the GPU box's host cores (tens of seconds each).  Tolerances as in test_gpu_model.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_inputs, assert_close
+
+pytestmark = pytest.mark.gpu
+
+LAT_ATOL, LAT_RTOL = 5e-5, 1e-4
+PIX_ATOL = 2e-5
+
+
+def _build(cfg, materialize=False, **over):
+    import video_gcp_amd as V
+    from video_gcp_amd.model import GCPTreeModel
+    hp = V.config(cfg, **over)
+    sd = V.init_params(hp, seed=1, randomize_affine=True)
+    return hp, sd, GCPTreeModel(hp, params=sd, device="cuda", materialize_distr=materialize)
+
+
+def _slice(inputs, idx):
+    return {k: v[idx] for k, v in inputs.items()}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# configs[1]
+# ------------------------------------------------------------------------------------------------------------------------
+def test_c2_forward_batch16_batchstat_vs_oracle():
+    """BASELINE configs[1] exactly: B=16, batch-statistics BatchNorm over all 16*80 encoder frames / 16*127 decoded nodes."""
+    from oracle import gcp_model_oracle as O
+    hp, sd, model = _build("c2")
+    assert hp.batch_size == 16
+    model.train(True)
+    inputs, noise, _ = make_inputs(hp, seed=5, variant="B")
+    with torch.no_grad():
+        ref = O.forward(sd, hp, inputs, noise=noise, training_bn=True)
+        ref_losses, ref_total = O.losses(sd, hp, inputs, ref)
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    out = model(dev_in, "train", noise=noise.cuda())
+    losses = model.loss(dev_in, out)
+    torch.cuda.synchronize()
+    bf = ref["tree_bf"]
+    assert_close(out.tree.bf.e_g_prime, bf["e_g_prime"], LAT_ATOL, LAT_RTOL, "e_g_prime")
+    assert_close(out.tree.bf.q_z_mu, bf["q_z_mu"], LAT_ATOL, LAT_RTOL, "q_z.mu")
+    assert_close(out.tree.bf.images, bf["images"], PIX_ATOL, 0, "images")
+    assert float(((out.tree.bf.images.cpu() - bf["images"]) ** 2).mean()) < 1e-9
+    assert torch.equal(out.raw["seq_len"].cpu().long(), inputs["end_ind"] + 1)
+    assert np.array_equal(out.raw["leave"].cpu().numpy().astype(bool), ref["leave_df"].numpy())
+    for a, b in zip(model.pruned_prediction(out), ref["pruned_prediction"]):
+        assert_close(a, b, PIX_ATOL, 0, "pruned_prediction")
+    aux = model.aux_outputs(out)
+    assert_close(aux.actions, ref["actions"], LAT_ATOL, LAT_RTOL, "actions")
+    assert_close(aux.cost, ref["cost"], LAT_ATOL, LAT_RTOL, "cost")
+    assert_close(aux.cost_target, ref["cost_target"], 0, 5e-6, "cost_target")
+    for name, (val, w) in ref_losses.items():
+        got = float(losses[name].value)
+        assert abs(got - float(val)) <= 3e-5 * abs(float(val)) + 1e-6, (name, got, float(val))
+    assert abs(float(losses["_total"]) - float(ref_total)) <= 3e-5 * abs(float(ref_total))
+
+
+def test_c2_forward_batch16_running_stats_vs_oracle_slice():
+    """planner-mode BatchNorm (model.eval(), planner_policy.py:51) at B=16: sequences are independent, so the oracle is run on
+    4 of the 16 and must match those rows of the full-size launch."""
+    from oracle import gcp_model_oracle as O
+    hp, sd, model = _build("c2")
+    model.eval()
+    inputs, noise, _ = make_inputs(hp, seed=6, variant="B")
+    out = model({k: v.cuda() for k, v in inputs.items()}, "train", noise=noise.cuda())
+    torch.cuda.synchronize()
+    idx = torch.tensor([0, 1, 7, 15])
+    with torch.no_grad():
+        ref = O.forward(sd, hp, _slice(inputs, idx), noise=noise[idx], training_bn=False)
+    assert_close(out.tree.bf.images[idx.cuda()], ref["tree_bf"]["images"], PIX_ATOL, 0, "images")
+    assert_close(out.tree.bf.hidden_state[idx.cuda()], ref["tree_bf"]["hidden"], LAT_ATOL, LAT_RTOL, "hidden")
+    assert_close(out.seq_len_logits[idx.cuda()], ref["seq_len_logits"], LAT_ATOL, LAT_RTOL, "seq_len_logits")
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# configs[2]: one rank's shard of the 128-sequence minibatch
+# ------------------------------------------------------------------------------------------------------------------------
+def test_c3_training_shard_batch16_gradient_is_the_derivative_of_the_loss():
+    """At B=16 autograd over the oracle would need ~100 GB of saved activations, so the gradient is checked against the function
+    it differentiates: for random parameter directions d, <grad, d> must equal the central difference of the HIP total loss
+    (base_gcp.py:294-304) along d.  Directions are restricted to one parameter group at a time so that every part of the
+    backward (decoder, tree levels, encoders, heads, inverse / cost model) is exercised separately.  Tolerance 2 % + fp32 noise
+    floor of the loss difference."""
+    from video_gcp_amd.training import GCPTrainStep
+    hp, sd, model = _build("c3")
+    assert hp.batch_size == 16
+    tr = GCPTrainStep(model, lr=1e-3)
+    inputs, noise, _ = make_inputs(hp, seed=9, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    dnoise = noise.cuda()
+    out = tr.backward(dev_in, dnoise)
+    torch.cuda.synchronize()
+    base = float(out.raw["losses"][5])
+    assert math.isfinite(base) and bool(torch.isfinite(tr.grad).all())
+    grad = tr.grad.clone()
+    theta0 = model.theta.clone()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    groups = ["decoder.", "encoder.", "inf_encoder.", "tree_module.tree_modules.6.", "tree_module.tree_modules.3.subgoal_pred",
+              "tree_module.tree_modules.0.subgoal_pred", "cost_mdl.", "inv_mdl.", "length_pred."]
+
+    div = float(hp.max_seq_len * hp.input_nc * hp.img_sz ** 2)
+    # inverse model, cost model and state regressor read DETACHED latents (inverse_mdl.py:160-162, cost_mdl.py:108-109,
+    # base_gcp.py:253-256): their loss terms move with the tree's parameters but send no gradient there.  The differentiated
+    # function is therefore: the ELBO terms + length CE + existence BCE for every group, plus a head's own L2 term for that head.
+    elbo = {0: hp.dense_img_rec_weight, 1: hp.kl_weight, 2: hp.length_pred_weight, 3: 1.0}
+    own = {"cost_mdl.": {8: 1.0}, "inv_mdl.": {7: hp.action_rec_weight}, "state_regressor.": {4: 1.0}}
+
+    pm = dev_in["pad_mask"].double()
+
+    def terms_at(theta):
+        """the nine loss terms in float64; the two large sums (NLL over B*T frames, KL over B) are re-added on the host from the
+        per-frame / per-sequence partials, which removes most of the fp32 summation noise from the difference quotient"""
+        model.theta.copy_(theta)
+        model.repack()
+        o = model(dev_in, "train", noise=dnoise)
+        torch.cuda.synchronize()
+        t = o.raw["losses"].double().cpu().clone()
+        t[0] = float((o.raw["nll_bt"].double() * pm).sum() / hp.batch_size)
+        t[1] = float(o.raw["kl_b"].double().sum() / hp.batch_size)
+        return t
+
+    t0 = terms_at(theta0)
+    assert abs(float(t0[0]) - float(out.raw["losses"][0])) <= 1e-5 * abs(float(t0[0]))
+    for pre in groups + ["state_regressor."]:
+        mask = torch.zeros_like(theta0)
+        for k, (o, shp) in model._poff.items():
+            if k.startswith(pre) and not k.endswith(("running_mean", "running_var")):
+                mask[o:o + int(np.prod(shp))] = 1.0
+        assert float(mask.sum()) > 0, pre
+        g = grad * mask
+        d = g / g.norm().clamp_min(1e-30)                 # the group's own gradient direction: the largest directional derivative
+        analytic = float((grad.double() * d.double()).sum())
+        wts = own.get(pre, elbo)
+        # step: 1e-3 of the mean parameter magnitude on the most-moved parameter (measured: the loss is linear to ~2 % up to there,
+        # tools/fd_check.py), the fp32 noise of the per-frame sums still well below the signal
+        eps = 1e-3 * float(theta0[mask > 0].abs().mean()) / max(float(d.abs().max()), 1e-12)
+        tp, tm = terms_at(theta0 + eps * d), terms_at(theta0 - eps * d)
+        fd = sum(w * float(tp[i] - tm[i]) for i, w in wts.items()) / div / (2 * eps)
+        noise_floor = sum(w * 1e-7 * abs(float(t0[i])) for i, w in wts.items()) / div / eps
+        assert abs(fd - analytic) <= 0.04 * abs(analytic) + noise_floor, (pre, fd, analytic, noise_floor)
+        assert abs(analytic) > 2 * noise_floor, (pre, analytic, noise_floor)      # the check has teeth
+    model.theta.copy_(theta0)
+    model.repack()
+
+
+def test_c3_training_shard_batch16_steps_reduce_loss():
+    from video_gcp_amd.training import GCPTrainStep
+    hp, sd, model = _build("c3")
+    tr = GCPTrainStep(model, lr=2e-3)
+    inputs, noise, _ = make_inputs(hp, seed=5, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    vals = []
+    for _ in range(6):
+        out = tr.step(dev_in, noise.cuda())
+        lv = out.raw["losses"].clone()
+        vals.append([float(x) for x in lv[:9]])
+    torch.cuda.synchronize()
+    assert all(math.isfinite(x) for v in vals for x in v)
+    assert vals[-1][5] < vals[0][5], vals                      # total
+    assert vals[-1][0] < vals[0][0]                            # reconstruction NLL
+    assert vals[-1][8] < vals[0][8] and vals[-1][7] < vals[0][7]     # cost model and inverse model are being trained
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# configs[3]: CEM planning, 512 candidates x horizon 80 (64 per GPU when sharded over 8)
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_cand", [64, 512])
+def test_c4_cem_iteration_full_population(n_cand):
+    from oracle import gcp_model_oracle as O
+    from video_gcp_amd.planning import GCPImageSimulator, LearnedCostEstimate, SimpleTreeCEMSampler, CEMPlanner, env2planner, \
+        select_elites
+    hp, sd, model = _build("c4")
+    assert hp.max_seq_len == 80 and hp.img_sz == 64
+    model.eval()
+    rng = np.random.RandomState(3)
+    state = rng.randint(0, 256, size=(1, 64, 64, 3)).astype(np.uint8)
+    goal = rng.randint(0, 256, size=(1, 64, 64, 3)).astype(np.uint8)
+    sampler = SimpleTreeCEMSampler(float("inf"), None, hp.nz_vae, 1.0, n_level_hierarchy=hp.hierarchy_levels, device="cuda", seed=4)
+    planner = CEMPlanner(GCPImageSimulator(model), LearnedCostEstimate(model), sampler, n_iters=1, batch_size=n_cand, elite_frac=0.1,
+                         max_seq_len=hp.max_seq_len, decode_candidates=True)
+    z = sampler.sample(n_cand)
+    scores, r = planner.evaluate(state, goal, z)
+    torch.cuda.synchronize()
+    T = hp.max_seq_len
+    assert scores.shape == (n_cand,) and bool(torch.isfinite(scores).all())
+    assert torch.equal(r.lengths.cpu(), torch.full((n_cand,), T, dtype=torch.int32))          # bit-exact lengths: full horizon
+    # (a) decoded rollouts of sampled candidates against the oracle (running-stat BatchNorm: candidates are independent)
+    idx = torch.tensor(sorted(set([0, 1, n_cand // 2, n_cand - 1])))
+    n = len(idx)
+    zc = z.cpu()
+    inp = lambda zz, m: dict(I_0=env2planner(np.repeat(state, m, 0)), I_g=env2planner(np.repeat(goal, m, 0)), z=zz,
+                             end_ind=torch.full((m,), T - 1, dtype=torch.long), start_ind=torch.zeros(m, dtype=torch.long))
+    with torch.no_grad():
+        ref = O.forward(sd, hp, inp(zc[idx], n), sample_prior=True, training_bn=False)
+    for j, i in enumerate(idx.tolist()):
+        assert_close(r.images[i], ref["pruned_prediction"][j], PIX_ATOL, 0, "rollout images")
+        assert_close(r.latents[i], ref["model_enc_seq"][j], LAT_ATOL, LAT_RTOL, "rollout latents")
+        assert_close(r.actions[i], ref["actions"][j], LAT_ATOL, LAT_RTOL, "rollout actions")
+    # (b) the learned cost of EVERY candidate against the oracle (latent tree only) and the elite set
+    costs = []
+    with torch.no_grad():
+        for c0 in range(0, n_cand, 64):
+            m = min(64, n_cand - c0)
+            o = O.forward(sd, hp, inp(zc[c0:c0 + m], m), sample_prior=True, training_bn=False, decode=False)
+            lat = o["model_enc_seq"]                                          # [m, T, nz]
+            nxt = torch.cat([lat[:, 1:], o["inputs"]["e_g"][:, None]], 1)     # cost_fcn.py:91-94: pairs of cat(seq, goal)
+            c = O.predictor(sd, "cost_mdl.cost_pred", hp, lat.reshape(m * T, -1), nxt.reshape(m * T, -1)).reshape(m, T).sum(1)
+            costs.append(c)
+    want = torch.cat(costs)
+    assert_close(scores, want, 2e-4, 2e-5, "candidate costs")
+    n_elite = max(int(n_cand * 0.1), 1)
+    got_e, want_e = select_elites(scores, n_elite).cpu(), select_elites(want, n_elite)
+    if not torch.equal(got_e, want_e):
+        # a swap is only acceptable between candidates whose oracle costs are closer than the stated cost tolerance
+        for a, b in zip(got_e.tolist(), want_e.tolist()):
+            assert a == b or abs(float(want[a] - want[b])) <= 4e-4 + 4e-5 * abs(float(want[b])), (a, b)
+    # (c) latent-only scoring (planner default) gives the same bits as decoding every candidate
+    planner.decode_candidates = False
+    scores2, r2 = planner.evaluate(state, goal, z)
+    torch.cuda.synchronize()
+    assert torch.equal(scores2, scores) and r2.images is None
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# configs[4]: adaptive binding, one GPU's shard (B=8, T=200, L=8)
+# ------------------------------------------------------------------------------------------------------------------------
+def test_c5_adaptive_batch8_properties_and_oracle_slice():
+    from oracle import gcp_model_oracle as O
+    hp, sd, model = _build("c5")
+    assert hp.batch_size == 8 and hp.max_seq_len == 200
+    model.eval()                                         # running-stat BatchNorm: sequences independent -> oracle on a slice
+    inputs, noise, _ = make_inputs(hp, seed=13, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    out = model(dev_in, "train", noise=noise.cuda())
+    losses = model.loss(dev_in, out)
+    torch.cuda.synchronize()
+    w = out.raw["match_dist_df"]
+    assert torch.isfinite(w).all() and torch.isfinite(out.images_df).all()
+    for b in range(hp.batch_size):
+        e = int(inputs["end_ind"][b])
+        assert torch.allclose(w[b, :, :e + 1].sum(0).cpu(), torch.ones(e + 1), atol=1e-4)
+        if e + 1 < hp.max_seq_len:
+            assert float(w[b, :, e + 1:].abs().max()) == 0.0
+        assert int(out.raw["frame2node"][b, 0]) == 0 and int(out.raw["frame2node"][b, e]) == hp.n_nodes - 1
+    assert all(math.isfinite(float(v.value)) for k, v in losses.items() if k != "_total")
+    idx = torch.tensor([1, 6])
+    with torch.no_grad():
+        ref = O.forward(sd, hp, _slice(inputs, idx), noise=noise[idx], training_bn=False)
+    assert_close(out.tree.bf.images[idx.cuda()], ref["tree_bf"]["images"], PIX_ATOL, 0, "images")
+    assert_close(out.tree.bf.e_g_prime[idx.cuda()], ref["tree_bf"]["e_g_prime"], LAT_ATOL, LAT_RTOL, "e_g_prime")
+    assert_close(out.raw["match_dist_df"][idx.cuda()], ref["match_dist_df"], 2e-5, 1e-4, "match_dist")
+    from oracle import tree_index_oracle as TI
+    assert np.array_equal(out.raw["frame2node"][idx.cuda()].cpu().numpy(), TI.bf2df_perm(hp.hierarchy_levels)[ref["matched_idx"].numpy()])
+
+
+def test_c5_adaptive_batch8_training_step_reduces_loss():
+    from video_gcp_amd.training import GCPTrainStep
+    hp, sd, model = _build("c5")
+    tr = GCPTrainStep(model, lr=2e-3)
+    inputs, noise, _ = make_inputs(hp, seed=32, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    vals = []
+    for _ in range(5):
+        out = tr.step(dev_in, noise.cuda())
+        vals.append(float(out.raw["losses"][5]))
+    assert all(math.isfinite(x) for x in vals) and bool(torch.isfinite(tr.grad).all())
+    assert vals[-1] < vals[0], vals

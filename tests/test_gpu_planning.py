@@ -36,7 +36,7 @@ def test_simulator_rollout_matches_oracle(setup):
     got = sim.rollout(state, goal, z.numpy(), T)
     inp = dict(I_0=env2planner(np.repeat(state, n, 0)), I_g=env2planner(np.repeat(goal, n, 0)), z=z,
                end_ind=torch.full((n,), T - 1, dtype=torch.long), start_ind=torch.zeros(n, dtype=torch.long))
-    ref = O.forward(sd, hp, inp, training_bn=False)
+    ref = O.forward(sd, hp, inp, sample_prior=True, training_bn=False)      # the rollout runs under val_mode (cem_simulator.py:29)
     assert len(got.predictions) == n
     for i in range(n):
         want = torch.cat((ref["pruned_prediction"][i].reshape(T, -1), ref["model_enc_seq_list"][i]), -1)   # cem_simulator.py:54-59
@@ -114,20 +114,34 @@ def test_cem_scoring_without_decoder_is_identical(setup):
 
 
 def test_hierarchical_cem_planner(setup):
-    """HierarchicalImageCEMPlanner flow (cem_planner.py:166-218) on the HIP model: one tree level fixed per iteration."""
+    """HierarchicalImageCEMPlanner flow (cem_planner.py:166-218) on the HIP model: one tree level fixed per iteration.  The
+    device-resident search (rollouts stay on the GPU, costs and selections computed there) against the reference's data flow
+    (every rollout to numpy, the optimizer class that is pinned bit-exactly to the reference's, tests/test_tree_latent_search.py)
+    on identical np.random draws: same selections, same optimised latents, same costs, same final plan."""
     from video_gcp_amd.planning import GCPImageSimulator, LearnedCostEstimate, HierarchicalCEMPlanner
     hp, sd, model = setup
     state, goal = _env_images(hp, 3)
-    np.random.seed(0)
-    planner = HierarchicalCEMPlanner(GCPImageSimulator(model), LearnedCostEstimate(model), hp.hierarchy_levels, [3, 2],
-                                     n_ll_samples=2, action_dim=hp.nz_vae, max_seq_len=hp.max_seq_len)
-    plan, actions, latents, score = planner(state, goal)
-    assert planner.fully_optimized
-    assert plan.shape == (hp.max_seq_len, 3 * hp.img_sz ** 2 + hp.nz_enc) and latents.shape == (hp.max_seq_len, hp.nz_enc)
-    assert np.isfinite(score) and len(planner.logs) == 3
-    # per-iteration plans grow: start/subgoal/goal, then 5 frames, then the dense sequence (+ appended goal)
-    lens = [l.elite_rollouts[0].shape[0] for l in planner.logs]
-    assert lens[0] <= lens[1] <= lens[2]
+    res = {}
+    for dev in (False, True):
+        np.random.seed(0)
+        planner = HierarchicalCEMPlanner(GCPImageSimulator(model), LearnedCostEstimate(model), hp.hierarchy_levels, [3, 2],
+                                         n_ll_samples=2, action_dim=hp.nz_vae, max_seq_len=hp.max_seq_len, device_resident=dev)
+        assert planner.device_resident == dev
+        plan, actions, latents, score = planner(state, goal)
+        assert planner.fully_optimized
+        assert plan.shape == (hp.max_seq_len, 3 * hp.img_sz ** 2 + hp.nz_enc) and latents.shape == (hp.max_seq_len, hp.nz_enc)
+        assert np.isfinite(score) and len(planner.logs) == 3
+        res[dev] = (plan, latents, score, [np.asarray(l.elite_scores, dtype=np.float64).reshape(-1) for l in planner.logs],
+                    planner._sampler.sample(), planner.logs)
+    for a, b in zip(res[False][3], res[True][3]):                  # per-iteration best costs
+        assert np.array_equal(a.astype(np.float32), b.astype(np.float32)), (a, b)
+    assert np.array_equal(res[False][4], res[True][4])              # the fully optimised latent tree
+    assert np.array_equal(res[False][0], res[True][0]) and np.array_equal(res[False][1], res[True][1]) and res[False][2] == res[True][2]
+    # per-iteration plans grow: start / subgoal / goal, then 5 frames, then the dense sequence (+ appended goal)
+    lens_np = [l.elite_rollouts[0].shape[0] for l in res[False][5]]
+    lens_dev = [len(l.elite_rollouts[0]) for l in res[True][5]]
+    assert lens_np[0] <= lens_np[1] <= lens_np[2]
+    assert lens_dev[:2] == lens_np[:2]
 
 
 def test_plan_entry_point_cem_and_hierarchical(tmp_path):

@@ -27,27 +27,48 @@ def save_checkpoint(model, folder, epoch, global_step=0, optimizer_state=None):
     return path
 
 
+class NoCheckpointsException(Exception):
+    """checkpoint_handler.py:10-11: the folder holds no checkpoint (ModelTrainer.resume then starts from epoch 0)"""
+
+
 def get_resume_ckpt_file(ckpt, path):
-    """'latest' -> highest epoch in `path`; int / digit string -> that epoch; otherwise a file path."""
+    """checkpoint_handler.py:31-42: 'latest' -> highest epoch in `path` (NoCheckpointsException when there is none); an epoch
+    number -> weights_ep{N}.pth; any other name gets '.pth' appended when missing; the result is always joined with `path`."""
     if ckpt == "latest":
-        files = glob.glob(os.path.join(path, "weights_ep*.pth"))
-        if not files:
-            raise FileNotFoundError(f"no checkpoints in {path}")
-        return max(files, key=lambda f: int(re.search(r"weights_ep(\d+)\.pth", f).group(1)))
-    if isinstance(ckpt, int) or str(ckpt).isdigit():
-        return os.path.join(path, checkpoint_name(int(ckpt)))
-    return ckpt
+        files = glob.glob(os.path.join(os.path.abspath(path), "*.pth"))
+        epochs = [int(m.group(1)) for m in (re.fullmatch(r"weights_ep(\d+)\.pth", os.path.basename(f)) for f in files) if m]
+        if not epochs:
+            print(f"Warning: No checkpoints found at {path}!")
+            raise NoCheckpointsException
+        name = checkpoint_name(max(epochs))
+    elif isinstance(ckpt, int) or str(ckpt).isdigit():
+        name = checkpoint_name(int(ckpt))
+    elif ".pth" not in str(ckpt):
+        name = str(ckpt) + ".pth"
+    else:
+        name = str(ckpt)
+    return os.path.join(path, name)
 
 
 def load_weights(weights_file, model, submodule_name=None, strict=True):
-    """Returns (global_step, epoch, optimizer_state).  With `submodule_name` only keys under that prefix are loaded
-    (prefix kept, since the model holds the sub-module under the same name)."""
+    """Returns (global_step, epoch, optimizer_state).  checkpoint_handler.py:45-74,133-143: with `submodule_name` only keys under
+    that prefix are loaded.  (The reference strips the prefix because it loads INTO the sub-module; this model holds the
+    sub-module under the same name, so the prefix stays.)  strict: every parameter of the model — of that sub-module, when one is
+    named — must be in the checkpoint, and no key of the (filtered) checkpoint may be unknown to the model."""
+    if not os.path.isfile(weights_file):
+        raise ValueError("Could not find checkpoint file in {}!".format(weights_file))
     ckpt = torch.load(weights_file, map_location="cpu")
     sd = ckpt["state_dict"]
+    own = set(model.state_dict())
     if submodule_name is not None:
         sd = {k: v for k, v in sd.items() if k.startswith(submodule_name + ".")}
         if not sd:
-            raise ValueError(f"No variable with scope '{submodule_name}' found in checkpoint '{weights_file}'!")
-        strict = False
-    model.load_state_dict(sd, strict=strict)
+            raise ValueError("Did not find submodule {} in checkpoint!".format(submodule_name))
+        own = {k for k in own if k.startswith(submodule_name + ".")}
+    if strict:
+        missing, unexpected = sorted(own - set(sd)), sorted(set(sd) - set(model.state_dict()))
+        if missing or unexpected:
+            raise KeyError(f"checkpoint {weights_file}: missing keys {missing[:5]}{'...' if len(missing) > 5 else ''}, "
+                           f"unexpected keys {unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")
+    model.load_state_dict(sd, strict=False)
     return ckpt.get("global_step", 0), ckpt.get("epoch", 0), ckpt.get("optimizer")

@@ -1,0 +1,176 @@
+"""Experiment configuration in the reference's own format.
+
+The reference's trainer loads `<exp_dir>/conf.py` with `imp.load_source` and reads two module-level dicts, `configuration`
+(trainer: batch_size, lr, num_epochs, dataset ...) and `model_config` (model hyper-parameters)
+(/root/reference/gcp/prediction/training/gcp_builder.py:112-147; e.g. experiments/prediction/25room/gcp_tree/conf.py).  Those files
+import `blox.AttrDict`, dataset / logger / cost-function classes and `experiments.prediction.base_configs.*` — none of which is
+importable here — but only use them as VALUES of the two dicts.  `load_conf` therefore executes the file with
+
+  * `blox.AttrDict` provided (a dict with attribute access),
+  * `experiments.prediction.base_configs.{base_tree, gcp_tree, gcp_adaptive, gcp_sequential}` provided with the same entries the
+    reference's base configs hold (restated below as data: base_configs/*.py),
+  * every other `blox.*` / `gcp.*` / `experiments.*` name resolved to an inert named placeholder,
+
+and maps what it finds onto this build's `GCPHParams` / trainer settings.  Keys without a counterpart on the device path (loggers,
+dataset classes, visualisation switches) are returned in `ignored` rather than silently dropped.  A `conf.json`
+({"config": "c2", "overrides": {...}, "lr": ...}) is accepted as well."""
+import glob
+import importlib
+import importlib.abc
+import importlib.machinery
+import json
+import os
+import sys
+import types
+
+from .hparams import GCPHParams, config as named_config
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class _Named(type):
+    """placeholder class: `repr` is the dotted name it was imported under; any attribute is another placeholder"""
+
+    def __getattr__(cls, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Named(f"{cls.__name__}.{name}", (), {})
+
+    def __repr__(cls):
+        return f"<ref {cls.__name__}>"
+
+
+# experiments/prediction/base_configs/*.py of the reference, as data
+_BASE_TREE = dict(one_step_planner="sh_pred", hierarchy_levels=7, binding="loss", seq_enc="conv", tree_lstm="split_linear",
+                  lstm_init="mlp", add_weighted_pixel_copy=True, dense_rec_type="node_prob")
+_BASE_CONFIGS = {
+    "base_tree": (dict(model="TreeModel", logger="HierarchyLogger"), dict(_BASE_TREE)),
+    "gcp_tree": (dict(model="TreeModel", logger="HierarchyLogger", metric_pruning_scheme="pruned_dtw"),
+                 dict(_BASE_TREE, matching_type="balanced")),
+    "gcp_adaptive": (dict(model="TreeModel", logger="HierarchyLogger"),
+                     dict(_BASE_TREE, matching_type="dtw_image", learn_matching_temp=False, attentive_inference=True)),
+    "gcp_sequential": (dict(model="SequentialModel", logger="Logger"), dict(dense_rec_type="svg", lstm_init="zero")),
+}
+
+
+class _Module(types.ModuleType):
+    __path__ = []
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        if name == "AttrDict":
+            return AttrDict
+        if self.__name__ == "experiments.prediction.base_configs" and name in _BASE_CONFIGS:
+            return importlib.import_module(f"{self.__name__}.{name}")     # `from ...base_configs import gcp_tree as base_conf`
+        v = _Named(name, (), {})
+        setattr(self, name, v)
+        return v
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    ROOTS = ("blox", "gcp", "experiments")
+
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split(".")[0] in self.ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _Module(spec.name)
+        parts = spec.name.split(".")
+        if parts[:3] == ["experiments", "prediction", "base_configs"] and len(parts) == 4 and parts[3] in _BASE_CONFIGS:
+            c, mc = _BASE_CONFIGS[parts[3]]
+            m.configuration, m.model_config = AttrDict(c), AttrDict(mc)
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def exec_conf_py(path):
+    """Run a reference-style conf.py; returns (configuration, model_config) as plain dicts."""
+    finder = _Finder()
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in _Finder.ROOTS}
+    for k in saved:
+        del sys.modules[k]
+    sys.meta_path.insert(0, finder)
+    try:
+        ns = {"__file__": os.path.abspath(path), "__name__": "conf"}
+        with open(path) as f:
+            exec(compile(f.read(), path, "exec"), ns)
+    finally:
+        sys.meta_path.remove(finder)
+        for k in [k for k in sys.modules if k.split(".")[0] in _Finder.ROOTS]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    if "configuration" not in ns or "model_config" not in ns:
+        raise ValueError(f"{path}: a configuration file defines `configuration` and `model_config` (gcp_builder.py:136-143)")
+    return dict(ns["configuration"]), dict(ns["model_config"])
+
+
+# trainer keys (gcp_builder.py:_default_hparams) that the device trainer reads
+_TRAINER_KEYS = ("batch_size", "lr", "num_epochs", "adam_beta", "epoch_cycles_train", "seed", "gradient_clip", "top_of_100_eval",
+                 "metric_pruning_scheme")
+# model_config keys that are settled by what this build implements (checked, not mapped)
+_FIXED = {"one_step_planner": ("sh_pred", "continuous"), "binding": ("loss",), "seq_enc": ("conv",), "tree_lstm": ("split_linear",),
+          "dense_rec_type": ("node_prob", "svg", "none", None)}
+
+
+def hparams_from_conf(configuration, model_config, **over):
+    """(GCPHParams, trainer settings, ignored keys).  max_seq_len / img_sz come from the dataset spec in the reference
+    (data_loader.py); here they are overrides or the c2 defaults (T=80, 64x64)."""
+    fields = set(GCPHParams.__dataclass_fields__)
+    kw, ignored = {}, []
+    mc = dict(model_config)
+    for k, allowed in _FIXED.items():
+        if k in mc and mc[k] not in allowed:
+            raise ValueError(f"model_config[{k!r}] = {mc[k]!r}: only {allowed} is built")
+        mc.pop(k, None)
+    if mc.pop("add_weighted_pixel_copy", False):
+        ignored.append("add_weighted_pixel_copy")        # 25room/gcp_tree/conf.py:43 pops it as well
+    inv = mc.pop("inv_mdl_params", None) or {}
+    if "n_actions" in inv:
+        kw["n_actions"] = int(inv["n_actions"])
+    if "temp_dist" in inv:
+        kw["inv_mdl_temp_dist"] = int(inv["temp_dist"])
+    cost = mc.pop("cost_mdl_params", None) or {}
+    if cost.get("use_path_dist_cost"):
+        raise ValueError("cost_mdl_params.use_path_dist_cost: the fast path needs state sequences; image trajectories use the "
+                         "generic cost (cost_mdl.py:81-117)")
+    for k, v in mc.items():
+        if k in fields:
+            kw[k] = v
+        else:
+            ignored.append(k)
+    if "batch_size" in configuration:
+        kw["batch_size"] = int(configuration["batch_size"])
+    kw.update(over)
+    if "hierarchy_levels" in kw and "max_seq_len" in kw and 2 ** int(kw["hierarchy_levels"]) - 1 < int(kw["max_seq_len"]):
+        kw.pop("hierarchy_levels")        # a tree too small for the sequence length: fall back to ceil(log2(T)) (train.py:80-81)
+    hp = GCPHParams(**kw)
+    trainer = {k: configuration[k] for k in _TRAINER_KEYS if k in configuration}
+    ignored += [k for k in configuration if k not in _TRAINER_KEYS]
+    return hp, trainer, ignored
+
+
+def load_conf(exp_dir, default="c2", **over):
+    """`<exp_dir>/*.py` (the reference's rule, gcp_builder.py:112-118: the one configuration file in the directory) or
+    `<exp_dir>/conf.json`.  Returns (GCPHParams, trainer settings dict, ignored keys)."""
+    if exp_dir and os.path.isdir(exp_dir):
+        py = sorted(glob.glob(os.path.join(os.path.abspath(exp_dir), "*.py")))
+        if len(py) > 1:
+            raise ValueError(f"Multiple configuration files found at {exp_dir}!")
+        if py:
+            c, mc = exec_conf_py(py[0])
+            return hparams_from_conf(c, mc, **over)
+        js = os.path.join(exp_dir, "conf.json")
+        if os.path.exists(js):
+            conf = json.load(open(js))
+            ov = dict(conf.get("overrides", {}), **over)
+            hp = named_config(conf.get("config", default), **ov)
+            return hp, {k: conf[k] for k in conf if k not in ("config", "overrides")}, []
+    return named_config(default, **over), {}, []

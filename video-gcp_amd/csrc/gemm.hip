@@ -16,6 +16,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -24,13 +25,13 @@ namespace {
 // wavefronts of a workgroup share one 16 x 16 output tile, take every 4th batch of k-groups and are summed through LDS in a
 // fixed order — 4x the bytes in flight, a quarter of the dependent round trips.
 template <int PR, int CR, bool LSTM, bool KS = false>
-__global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
+__device__ __forceinline__ void gemm_tile(const gcpx_gemm_args& a, const int bx, const int by, const int bz) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int NT = a.N / 16;
-    const int nt0 = KS ? blockIdx.y * CR : (blockIdx.y * 4 + wave) * CR;
+    const int nt0 = KS ? by * CR : (by * 4 + wave) * CR;
     if (!KS && nt0 >= NT) return;
-    const int rowblk = blockIdx.x;
+    const int rowblk = bx;
     const int M = a.M, rpb = a.rpb;
 
     int rr[PR], rb[PR], rj[PR];
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
 #pragma unroll
         for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
 
-    const int zb = blockIdx.z;
+    const int zb = bz;
     const float4* wbase = reinterpret_cast<const float4*>(a.wpk + (size_t)zb * a.z_w_off) + (size_t)nt0 * 64 + lane;
     int kg0 = 0;
     for (int s = 0; s < a.nsrc; ++s) {
@@ -74,9 +75,14 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
         }
         const int nkg = src.width / 16;
         const bool xf = src.scale || src.act;
-        constexpr int UK = (PR * CR >= 8) ? 2 : (PR * CR >= 4) ? 4 : 8;   // k-groups whose loads are issued together
-        for (int kg = KS ? wave * UK : 0; kg < nkg; kg += (KS ? 4 : 1) * UK) {
-            float4 b[UK][PR], w[UK][CR];
+        // k-groups whose loads are issued together = one register set.  Two sets in ping-pong (explicit, no register copies: a
+        // `set = next` after the MFMA block would let the scheduler sink the NEXT batch's wait in front of THIS batch's MFMAs): the
+        // loads of one set are in flight during the MFMAs of the other.  A set's MFMAs last UK * PR * CR * 4 * 32 cycles — sized to
+        // about one L2 / HBM round trip, because with 1024+ wave tiles there is ONE wavefront per SIMD and nothing else hides it.
+        constexpr int UK = KS ? ((PR * CR >= 8) ? 2 : (PR * CR >= 4) ? 4 : 8)
+                              : ((PR * CR >= 16) ? 2 : (PR * CR >= 8) ? 4 : (PR * CR >= 2) ? 4 : 8);
+        const int kstep = (KS ? 4 : 1) * UK;
+        auto load_set = [&](const int kg, float4 (&b)[UK][PR], float4 (&w)[UK][CR]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < UK; ++u) {
                 const int k = (kg + u < nkg) ? kg + u : nkg - 1;
@@ -86,15 +92,23 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
 #pragma unroll
                 for (int ct = 0; ct < CR; ++ct) w[u][ct] = wp[ct * 64];
             }
+        };
+        // XF: affine + activation of the producer on load; MK: some row of this wavefront is masked (tail rows, conv1d edge taps).
+        // Both are wave-uniform and constant over the source: they select one of four loop bodies up front, so that the steady
+        // state is loads + MFMAs only — the per-row uniform branches used to cost ~200 cycles per k-group next to 1024 of MFMA.
+        auto mfma_set = [&](const int kg, float4 (&b)[UK][PR], float4 (&w)[UK][CR], auto xf_tag, auto mk_tag) __attribute__((always_inline)) {
+            constexpr bool XF = decltype(xf_tag)::value, MK = decltype(mk_tag)::value;
 #pragma unroll
             for (int u = 0; u < UK; ++u) {
                 if (kg + u < nkg) {
+                    if constexpr (XF || MK) {
 #pragma unroll
-                    for (int pt = 0; pt < PR; ++pt) {
-                        float4 bb = b[u][pt];
-                        if (xf) bb = affine_act4(bb, src.scale, src.shiftv, ((kg + u) * 16 + q * 4) & (src.cmod - 1), src.act);
-                        bb.x *= mask[pt]; bb.y *= mask[pt]; bb.z *= mask[pt]; bb.w *= mask[pt];
-                        b[u][pt] = bb;
+                        for (int pt = 0; pt < PR; ++pt) {
+                            float4 bb = b[u][pt];
+                            if constexpr (XF) bb = affine_act4(bb, src.scale, src.shiftv, ((kg + u) * 16 + q * 4) & (src.cmod - 1), src.act);
+                            if constexpr (MK) { bb.x *= mask[pt]; bb.y *= mask[pt]; bb.z *= mask[pt]; bb.w *= mask[pt]; }
+                            b[u][pt] = bb;
+                        }
                     }
 #pragma unroll
                     for (int ct = 0; ct < CR; ++ct) {
@@ -108,6 +122,30 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
                     }
                 }
             }
+        };
+        float4 b0[UK][PR], w0[UK][CR], b1[UK][PR], w1[UK][CR];
+        // loads are issued unconditionally (load_set clamps its k index: a redundant re-read of the last k-group at the end):
+        // the number of loads in flight at every wait is then static, and the compiler's s_waitcnt keeps the next set in flight
+        auto run = [&](auto xf_tag, auto mk_tag) __attribute__((always_inline)) {
+            int kg = KS ? wave * UK : 0;
+            if (kg >= nkg) return;
+            load_set(kg, b0, w0);
+            for (; kg < nkg; kg += 2 * kstep) {
+                load_set(kg + kstep, b1, w1);
+                mfma_set(kg, b0, w0, xf_tag, mk_tag);
+                if (kg + kstep >= nkg) break;
+                load_set(kg + 2 * kstep, b0, w0);
+                mfma_set(kg + kstep, b1, w1, xf_tag, mk_tag);
+            }
+        };
+        bool anymask = false;
+#pragma unroll
+        for (int pt = 0; pt < PR; ++pt) anymask = anymask || (mask[pt] == 0.f);
+        const bool mk = __any(anymask);
+        if (xf) {
+            if (mk) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{});
+        } else {
+            if (mk) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{});
         }
         kg0 += nkg;
     }
@@ -189,6 +227,25 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
     }
 }
 
+template <int PR, int CR, bool LSTM, bool KS = false>
+__global__ void __launch_bounds__(256) gemm_kernel(const gcpx_gemm_args a) {
+    gemm_tile<PR, CR, LSTM, KS>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent small-M problems (the split-K <1,1> regime) in ONE launch: the same layer of the three recurrent nets of a
+// VRNN step, or two GEMMs of a tree level that do not depend on each other.  A dependent chain of ~5 us launches is bound by the
+// number of launches, not by their work.  dims[p] = {first block, row blocks, column tiles, batches}.
+__global__ void __launch_bounds__(256) gemm_group_kernel(const gcpx_gemm_args* __restrict__ tab, const int4* __restrict__ dims, const int n) {
+    int p = 0;
+    while (p + 1 < n && (int)blockIdx.x >= dims[p + 1].x) ++p;
+    const int4 d = dims[p];
+    const int local = blockIdx.x - d.x;
+    const int bx = local % d.y, by = (local / d.y) % d.z, bz = local / (d.y * d.z);
+    const gcpx_gemm_args& a = tab[p];
+    if (a.epi == GCPX_EPI_LSTM) gemm_tile<1, 1, true, true>(a, bx, by, bz);
+    else gemm_tile<1, 1, false, true>(a, bx, by, bz);
+}
+
 struct TileChoice { int pr, cr; };
 
 TileChoice choose_tile(int M, int N, int nb = 1) {
@@ -196,25 +253,41 @@ TileChoice choose_tile(int M, int N, int nb = 1) {
         int pr = 0, cr = 0, mm = 0;
         if (sscanf(ov, "%d,%d,%d", &pr, &cr, &mm) == 3 && M >= mm && N % (16 * cr) == 0) return TileChoice{pr, cr};
     }
+    // Every wavefront owns a PR x CR block of 16 x 16 tiles and walks all of K alone.  Cost model fitted to measurements on MI355X
+    // (tools/run_gemm_tiles.sh, K = 1024; microseconds per launch, up to a common constant):
+    //   compute = rounds x block area x e(area),  rounds = ceil(wavefronts / SIMDs): one wavefront per SIMD is the sweet spot
+    //             (M = 512, N = 2048: <2,2> = 1024 wavefronts 26 us; <4,2> = half the SIMDs idle 45 us); a second round costs more
+    //             than twice the first (co-resident wavefronts share the MFMA pipe AND thrash L1): x1.35;
+    //             e = 4.2 / 4.9 / 5.0 / 6.0 / 8.0 us per tile for areas 16 / 8 / 4 / 2 / 1 (bigger blocks: fewer loads per MFMA);
+    //   L2      = tiles x 256 MFMAs x bytes per MFMA / ~10 TB/s, bytes per MFMA = 256 (PR + CR) / (PR CR): <4,1> blocks of the batched
+    //             merge at M = 1024 ran 114 us against 74 us for <4,4>, L2-bound.
+    // The launch is priced at max(compute, L2); ties go to the block with fewer bytes per MFMA.
+    static const long simds = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 4L * (cus > 0 ? cus : 256);
+    }();
     const int prs[3] = {4, 2, 1}, crs[3] = {4, 2, 1};
     TileChoice best{1, 1};
-    long best_wg = -1;
-    static const long wg_min = getenv("GCPX_GEMM_WGMIN") ? atol(getenv("GCPX_GEMM_WGMIN")) : 200;
-    // candidates by decreasing tile area; take the first that fills the chip, else the one with most workgroups
-    for (int area = 16; area >= 1; area /= 2) {
-        for (int pi = 0; pi < 3; ++pi)
-            for (int ci = 0; ci < 3; ++ci) {
-                const int pr = prs[pi], cr = crs[ci];
-                if (pr * cr != area) continue;
-                if (N % (16 * cr)) continue;
-                if (pr > 1 && 16 * pr > ((M + 15) & ~15)) continue;      // row tiles that would be entirely masked
-                const long rbk = (M + 16 * pr - 1) / (16 * pr);
-                const long cbk = (N / 16 + 4 * cr - 1) / (4 * cr);
-                const long wg = rbk * cbk * nb;
-                if (wg >= wg_min) return TileChoice{pr, cr};
-                if (wg > best_wg) { best_wg = wg; best = TileChoice{pr, cr}; }
+    double best_cost = -1.0, best_bytes = 0.0;
+    const long NT = N / 16, RT = (M + 15) / 16;
+    for (int pi = 0; pi < 3; ++pi)
+        for (int ci = 0; ci < 3; ++ci) {
+            const int pr = prs[pi], cr = crs[ci];
+            if (N % (16 * cr)) continue;
+            if (pr > 1 && 16 * pr > ((M + 15) & ~15)) continue;      // row tiles that would be entirely masked
+            const long waves = ((RT + pr - 1) / pr) * ((NT + cr - 1) / cr) * nb;
+            const long rounds = (waves + simds - 1) / simds;
+            const int area = pr * cr;
+            const double e = area >= 16 ? 4.2 : area >= 8 ? 4.9 : area >= 4 ? 5.0 : area >= 2 ? 6.0 : 8.0;
+            const double compute = (double)rounds * area * e * (rounds > 1 ? 1.35 : 1.0);
+            const double bytes = 256.0 * (pr + cr) / area;
+            const double l2 = (double)RT * NT * nb * 256.0 * bytes / 1.0e7;
+            const double cost = compute > l2 ? compute : l2;
+            if (best_cost < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && bytes < best_bytes)) {
+                best_cost = cost; best_bytes = bytes; best = TileChoice{pr, cr};
             }
-    }
+        }
     return best;
 }
 
@@ -236,8 +309,46 @@ extern "C" int gcpx_gemm_row_blocks(int32_t M, int32_t N) {
     return (M + 16 * t.pr - 1) / (16 * t.pr);
 }
 
-extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
+static int gemm_check(const gcpx_gemm_args* a);
+
+// true when gcpx_gemm would run the problem as split-K <1,1> tiles (what gcpx_gemm_group launches)
+static bool gemm_is_small(const gcpx_gemm_args* a) {
+    const int nb = a->nbatch > 1 ? a->nbatch : 1;
+    const TileChoice t = choose_tile(a->M, a->N, nb);
+    const long rbk = (a->M + 15) / 16, nt = a->N / 16;
+    return t.pr == 1 && t.cr == 1 && a->K >= 256 && rbk * nt * nb <= 1024 && !a->stats_partial;
+}
+
+extern "C" int gcpx_gemm_group_dims(const gcpx_gemm_args* host_table, int32_t n, int32_t* dims, int32_t* total_blocks) {
+    GCPX_CHECK_ARG(host_table && dims && total_blocks && n >= 1 && n <= 16, "bad arguments");
+    int start = 0;
+    for (int p = 0; p < n; ++p) {
+        const int st = gemm_check(host_table + p);
+        if (st != GCPX_OK) return st;
+        if (!gemm_is_small(host_table + p)) {
+            gcpx_set_error("gcpx_gemm_group_dims: problem %d (M=%d N=%d K=%d) is not in the small-M split-K regime", p, host_table[p].M,
+                           host_table[p].N, host_table[p].K);
+            return GCPX_ERR_UNSUPPORTED;
+        }
+        const int nb = host_table[p].nbatch > 1 ? host_table[p].nbatch : 1;
+        const int rbk = (host_table[p].M + 15) / 16, nt = host_table[p].N / 16;
+        dims[4 * p] = start; dims[4 * p + 1] = rbk; dims[4 * p + 2] = nt; dims[4 * p + 3] = nb;
+        start += rbk * nt * nb;
+    }
+    *total_blocks = start;
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_gemm_group(const gcpx_gemm_args* dev_table, const int32_t* dev_dims, int32_t n, int32_t total_blocks, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(dev_table && dev_dims && n >= 1 && n <= 16 && total_blocks > 0, "bad arguments");
+    GCPX_CHECK_ARG((((uintptr_t)dev_dims) & 15) == 0, "dims must be 16-byte aligned");
+    hipLaunchKernelGGL(gemm_group_kernel, dim3(total_blocks), dim3(256), 0, stream, dev_table, reinterpret_cast<const int4*>(dev_dims), n);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+static int gemm_check(const gcpx_gemm_args* a) {
     GCPX_CHECK_ARG(a != nullptr, "null args");
     GCPX_CHECK_ARG(a->nsrc >= 1 && a->nsrc <= 6, "nsrc out of range");
     GCPX_CHECK_ARG(a->M > 0 && a->N > 0 && a->N % 16 == 0 && a->rpb > 0, "bad M/N/rpb");
@@ -258,6 +369,13 @@ extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
         GCPX_CHECK_ARG(a->out != nullptr, "out is NULL");
     }
     GCPX_CHECK_ARG(a->nbatch <= 1 || (a->epi != GCPX_EPI_LSTM && !a->stats_partial), "nbatch > 1 only for plain epilogues");
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int st = gemm_check(a);
+    if (st != GCPX_OK) return st;
     const TileChoice t = choose_tile(a->M, a->N, a->nbatch > 1 ? a->nbatch : 1);
     if (t.pr == 1 && t.cr == 1 && a->K >= 256 && !getenv("GCPX_GEMM_NOKS")) {
         // few rows: split K over the wavefronts of a workgroup when that still leaves the launch small

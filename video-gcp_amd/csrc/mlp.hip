@@ -14,20 +14,19 @@
 
 namespace {
 
+// one workgroup = 16 rows (block bx) of one Predictor; by / ny: this workgroup's share of the head's column tiles
 template <int MID>
-__global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
+__device__ __forceinline__ void mlp_rows(const gcpx_mlp_args& a, const int bx, const int by, const int ny, float* hid) {
     constexpr int NTM = MID / 16;                    // column tiles of a hidden layer
     constexpr int NW = NTM >= 4 ? 4 : NTM;           // wavefronts that own hidden-layer tiles
     constexpr int TPW = NTM / NW;                    // tiles per wavefront
     constexpr int PITCH = MID + 4;
     constexpr int CPG = MID / 8;                     // channels per GroupNorm group (gn_groups = 8)
     static_assert(CPG == 4 || CPG == 16, "GroupNorm group must be one lane (4) or one 16-channel tile");
-    __shared__ float4 hid4[2 * 16 * PITCH / 4];
-    float* hid = reinterpret_cast<float*>(hid4);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int r = blockIdx.x * 16 + j;
+    const int r = bx * 16 + j;
     const bool rv = r < a.M;
     const int rs = rv ? r : 0;
     const int rb = rs / a.rpb, rj = rs % a.rpb;
@@ -38,6 +37,17 @@ __global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
     f32x4 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0, 0, 0, 0};
+
+    // weights of the first hidden layer: requested before anything else, they arrive during the input layer
+    auto load_hidden = [&](const int l, float4 (&w)[NTM][TPW]) {
+        const float4* wbase = reinterpret_cast<const float4*>(a.w_mid) + ((size_t)l * NTM * NTM + nt0) * 64 + lane;
+#pragma unroll
+        for (int kg = 0; kg < NTM; ++kg)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) w[kg][t] = wbase[(kg * NTM + t) * 64];
+    };
+    float4 wA[NTM][TPW], wB[NTM][TPW];
+    if (owner && a.n_mid > 0) load_hidden(0, wA);
 
     // ---- input layer: gathered global sources ----
     if (owner) {
@@ -58,18 +68,22 @@ __global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
             const float mask = ok ? 1.f : 0.f;
             const int nkg = src.width / 16;
             const bool xf = src.scale || src.act;
-            for (int kg = 0; kg < nkg; kg += 4) {
-                // issue the whole batch of loads first (independent), then the MFMAs
-                float4 b[4], w[4][TPW];
+            // Every load of this layer is independent of the MFMAs, and one workgroup is all there is on its CU: what bounds the
+            // layer is the number of DEPENDENT global round trips.  Sets of UKI k-groups in ping-pong (explicit register sets): the
+            // loads of one set are in flight during the MFMAs of the other (in_dim = 384: 3 sets instead of 6 serial batches).
+            constexpr int UKI = 8;
+            auto load_set = [&](const int kg, float4 (&b)[UKI], float4 (&w)[UKI][TPW]) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < UKI; ++u) {
                     const int k = (kg + u < nkg) ? kg + u : nkg - 1;
                     b[u] = *reinterpret_cast<const float4*>(bp + k * 16);
 #pragma unroll
                     for (int t = 0; t < TPW; ++t) w[u][t] = wbase[((size_t)(kg0 + k) * NTM + t) * 64];
                 }
+            };
+            auto mfma_set = [&](const int kg, float4 (&b)[UKI], float4 (&w)[UKI][TPW]) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < UKI; ++u) {
                     if (kg + u < nkg) {
                         float4 bb = b[u];
                         if (xf) bb = affine_act4(bb, src.scale, src.shiftv, ((kg + u) * 16 + q * 4) & (src.cmod - 1), src.act);
@@ -83,6 +97,19 @@ __global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
                         }
                     }
                 }
+            };
+            float4 b0[UKI], w0[UKI][TPW], b1[UKI], w1[UKI][TPW];
+            int kg = 0;
+            load_set(0, b0, w0);
+            while (true) {
+                const int kn = kg + UKI;
+                if (kn < nkg) load_set(kn, b1, w1);
+                mfma_set(kg, b0, w0);
+                if (kn >= nkg) break;
+                kg = kn + UKI;
+                if (kg < nkg) load_set(kg, b0, w0);
+                mfma_set(kn, b1, w1);
+                if (kg >= nkg) break;
             }
             kg0 += nkg;
         }
@@ -93,25 +120,23 @@ __global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
             float4 v = make_float4(lrelu(acc[t][0] + bv.x, slope), lrelu(acc[t][1] + bv.y, slope),
                                    lrelu(acc[t][2] + bv.z, slope), lrelu(acc[t][3] + bv.w, slope));
             *reinterpret_cast<float4*>(hid + j * PITCH + c) = v;
-            if (a.save && rv && blockIdx.y == 0) *reinterpret_cast<float4*>(a.save + (size_t)r * MID + c) = v;
+            if (a.save && rv && by == 0) *reinterpret_cast<float4*>(a.save + (size_t)r * MID + c) = v;
         }
     }
     __syncthreads();
 
     // ---- hidden layers: mid -> mid, GroupNorm, LReLU ----
+    // The weights of layer l + 1 are requested while layer l is still being computed (two explicit register sets), so a hidden
+    // layer costs its MFMAs + GroupNorm + one barrier instead of a global round trip on top.
     int cur = 0;
-    for (int l = 0; l < a.n_mid; ++l) {
+    auto hidden = [&](const int l, float4 (&w)[NTM][TPW], float4 (&wnext)[NTM][TPW]) {
         const float* hin = hid + cur * 16 * PITCH;
         float* hout = hid + (cur ^ 1) * 16 * PITCH;
         if (owner) {
-            const float4* wbase = reinterpret_cast<const float4*>(a.w_mid) + ((size_t)l * NTM * NTM + nt0) * 64 + lane;
-            float4 w[NTM][TPW], b[NTM];
+            float4 b[NTM];
 #pragma unroll
-            for (int kg = 0; kg < NTM; ++kg) {
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) w[kg][t] = wbase[(kg * NTM + t) * 64];
-                b[kg] = *reinterpret_cast<const float4*>(hin + j * PITCH + kg * 16 + q * 4);
-            }
+            for (int kg = 0; kg < NTM; ++kg) b[kg] = *reinterpret_cast<const float4*>(hin + j * PITCH + kg * 16 + q * 4);
+            if (l + 1 < a.n_mid) load_hidden(l + 1, wnext);
 #pragma unroll
             for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -141,7 +166,7 @@ __global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
                 float4 o = make_float4(lrelu(d0 * rstd * gv.x + be.x, slope), lrelu(d1 * rstd * gv.y + be.y, slope),
                                        lrelu(d2 * rstd * gv.z + be.z, slope), lrelu(d3 * rstd * gv.w + be.w, slope));
                 *reinterpret_cast<float4*>(hout + j * PITCH + c) = o;
-                if (a.save && rv && blockIdx.y == 0) {
+                if (a.save && rv && by == 0) {
                     float* sv = a.save + (size_t)(1 + 2 * l) * a.M * MID + (size_t)r * MID + c;
                     *reinterpret_cast<float4*>(sv) = make_float4(v0, v1, v2, v3);
                     *reinterpret_cast<float4*>(sv + (size_t)a.M * MID) = o;
@@ -150,6 +175,10 @@ __global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
         }
         cur ^= 1;
         __syncthreads();
+    };
+    for (int l = 0; l < a.n_mid; l += 2) {
+        hidden(l, wA, wB);
+        if (l + 1 < a.n_mid) hidden(l + 1, wB, wA);
     }
 
     // ---- head: mid -> out; column tiles are dealt round-robin to (blockIdx.y, wave) ----
@@ -162,7 +191,7 @@ __global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
     const float4* wbase = reinterpret_cast<const float4*>(a.w_out) + lane;
     const int split = a.out_split > 0 ? a.out_split : a.out_dim;
     float* orow = a.out ? a.out + (size_t)rb * a.ob + (size_t)rj * a.orow : nullptr;
-    const int tstart = blockIdx.y * 4 + wave, tstride = gridDim.y * 4;
+    const int tstart = by * 4 + wave, tstride = ny * 4;
 
     if (a.epi == GCPX_MLP_GAUSS) {
         const int nz = a.out_dim / 2;
@@ -236,10 +265,26 @@ __global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
     }
 }
 
-}  // namespace
+template <int MID>
+__global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
+    __shared__ float4 hid4[2 * 16 * (MID + 4) / 4];
+    mlp_rows<MID>(a, blockIdx.x, blockIdx.y, gridDim.y, reinterpret_cast<float*>(hid4));
+}
 
-extern "C" int gcpx_mlp(const gcpx_mlp_args* a, void* stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+// several Predictors in ONE launch (the prior next to the posterior of a tree level; the latent-space heads): independent
+// problems, so what used to be parallel graph branches or a chain of ~20 us launches is one kernel boundary.
+// dims[p] = {first block, row blocks gx, head splits gy}; blocks of problem p are (bx, by) = (local % gx, local / gx).
+template <int MID>
+__global__ void __launch_bounds__(256) mlp_group_kernel(const gcpx_mlp_args* __restrict__ tab, const int4* __restrict__ dims, const int n) {
+    __shared__ float4 hid4[2 * 16 * (MID + 4) / 4];
+    int p = 0;
+    while (p + 1 < n && (int)blockIdx.x >= dims[p + 1].x) ++p;
+    const int4 d = dims[p];
+    const int local = blockIdx.x - d.x;
+    mlp_rows<MID>(tab[p], local % d.y, local / d.y, d.z, reinterpret_cast<float*>(hid4));
+}
+
+int mlp_check(const gcpx_mlp_args* a) {
     GCPX_CHECK_ARG(a != nullptr, "null args");
     GCPX_CHECK_ARG(a->nsrc >= 1 && a->nsrc <= 4, "nsrc out of range");
     GCPX_CHECK_ARG(a->M > 0 && a->rpb > 0, "bad M/rpb");
@@ -257,11 +302,57 @@ extern "C" int gcpx_mlp(const gcpx_mlp_args* a, void* stream_) {
     } else {
         GCPX_CHECK_ARG(a->out != nullptr, "out is NULL");
     }
-    const int gx = (a->M + 15) / 16;
-    // split a wide head over blockIdx.y when there are few row blocks (the LSTM initialiser: 16 rows x 6144 cols)
+    return GCPX_OK;
+}
+
+// split a wide head over blockIdx.y when there are few row blocks (the LSTM initialiser: 16 rows x 6144 cols)
+void mlp_grid(const gcpx_mlp_args* a, int* gx, int* gy) {
+    *gx = (a->M + 15) / 16;
     const int head_tiles = ((a->epi == GCPX_MLP_GAUSS ? a->out_dim / 2 : a->out_dim) + 15) / 16;
-    int gy = 1;
-    while (gy < 32 && gx * gy < 256 && head_tiles / (4 * gy) >= 2) gy *= 2;
+    int y = 1;
+    while (y < 32 && *gx * y < 256 && head_tiles / (4 * y) >= 2) y *= 2;
+    *gy = y;
+}
+
+}  // namespace
+
+extern "C" int gcpx_mlp_group_dims(const gcpx_mlp_args* host_table, int32_t n, int32_t* dims, int32_t* total_blocks) {
+    GCPX_CHECK_ARG(host_table && dims && total_blocks && n >= 1 && n <= 16, "bad arguments");
+    int start = 0;
+    for (int p = 0; p < n; ++p) {
+        const int st = mlp_check(host_table + p);
+        if (st != GCPX_OK) return st;
+        GCPX_CHECK_ARG(host_table[p].mid == host_table[0].mid, "all problems of a group share the hidden width");
+        int gx, gy;
+        mlp_grid(host_table + p, &gx, &gy);
+        dims[4 * p] = start; dims[4 * p + 1] = gx; dims[4 * p + 2] = gy; dims[4 * p + 3] = 0;
+        start += gx * gy;
+    }
+    *total_blocks = start;
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_mlp_group(const gcpx_mlp_args* dev_table, const int32_t* dev_dims, int32_t n, int32_t total_blocks, int32_t mid,
+                              void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(dev_table && dev_dims && n >= 1 && n <= 16 && total_blocks > 0, "bad arguments");
+    GCPX_CHECK_ARG((((uintptr_t)dev_dims) & 15) == 0, "dims must be 16-byte aligned");
+    if (mid == 128) hipLaunchKernelGGL(mlp_group_kernel<128>, dim3(total_blocks), dim3(256), 0, stream, dev_table, reinterpret_cast<const int4*>(dev_dims), n);
+    else if (mid == 32) hipLaunchKernelGGL(mlp_group_kernel<32>, dim3(total_blocks), dim3(256), 0, stream, dev_table, reinterpret_cast<const int4*>(dev_dims), n);
+    else {
+        gcpx_set_error("gcpx_mlp_group: unsupported mid=%d (128 or 32)", mid);
+        return GCPX_ERR_UNSUPPORTED;
+    }
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_mlp(const gcpx_mlp_args* a, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int st = mlp_check(a);
+    if (st != GCPX_OK) return st;
+    int gx, gy;
+    mlp_grid(a, &gx, &gy);
     if (a->mid == 128) hipLaunchKernelGGL(mlp_kernel<128>, dim3(gx, gy), dim3(256), 0, stream, *a);
     else if (a->mid == 32) hipLaunchKernelGGL(mlp_kernel<32>, dim3(gx, gy), dim3(256), 0, stream, *a);
     else {

@@ -68,3 +68,74 @@ def all_reduce_sum_(flat, group=None):
         return 1.0
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / dist.get_world_size(group)
+
+
+def gradient_bucket_ranges(poff, hierarchy_levels, untied_layers):
+    """Contiguous [lo, hi) ranges of the flat gradient in the order they become FINAL during the backward pass
+    (training.py walks the tree leaves-first): one bucket per untied tree level L-1 .. 1 (about 41 MB each at c2), then ONE bucket
+    with everything below `tree_modules.1` — conv encoder (shared by the three encoder passes, final last), decoder, temporal
+    encoder, latent-space heads and tree level 0 (which also owns the existence / distance predictor).  `poff` is the model's
+    {name: (offset, shape)} table; offsets are in floats.  Tied levels accumulate into one weight set: a single bucket."""
+    end = 0
+    starts = {}
+    for k, (o, shp) in poff.items():
+        n = 1
+        for d in shp:
+            n *= d
+        end = max(end, o + (n + 3) // 4 * 4)
+        if k.startswith("tree_module.tree_modules."):
+            l = int(k.split(".")[2])
+            starts[l] = min(starts.get(l, o), o)
+    if not untied_layers or hierarchy_levels < 2 or len(starts) < hierarchy_levels:
+        return [("all", 0, end)]
+    out = []
+    for l in reversed(range(1, hierarchy_levels)):
+        hi = starts[l + 1] if l + 1 in starts else end
+        out.append((f"tree{l}", starts[l], hi))
+    out.append(("rest", 0, starts[1]))
+    # the table is laid out in parameter order: the ranges must tile [0, end) exactly
+    cover = sorted((lo, hi) for _, lo, hi in out)
+    assert cover[0][0] == 0 and cover[-1][1] == end and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), cover
+    return out
+
+
+class GradBuckets:
+    """Bucketed data-parallel gradient exchange overlapped with the rest of the backward pass: bucket i is
+    all-reduced (sum, in place on its slice of the flat gradient) as soon as the backward reports it final, on a communication
+    stream of its own, while the remaining levels are still being differentiated; `finish()` reduces whatever is left, waits for
+    everything and returns the 1 / world factor the optimizer kernel folds into its update.  xGMI is point-to-point, so a ring
+    all-reduce is per-link bound: a handful of ~40 MB buckets (not hundreds of small ones) keeps each at its bandwidth plateau.
+    Works on CPU tensors with gloo (tests) exactly as on the device with RCCL."""
+
+    def __init__(self, flat, ranges, group=None):
+        self.flat, self.ranges, self.group = flat, list(ranges), group
+        self.works = {}
+        self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
+
+    def reduce_async(self, i, after_streams=()):
+        """Start the all-reduce of bucket i.  after_streams: the device streams whose enqueued work produces this bucket."""
+        if not dist.is_initialized() or i in self.works:
+            return
+        _, lo, hi = self.ranges[i]
+        view = self.flat[lo:hi]
+        if self.comm_stream is not None:
+            for s in after_streams:
+                self.comm_stream.wait_stream(s)
+            with torch.cuda.stream(self.comm_stream):
+                self.works[i] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self.works[i] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """All buckets reduced and visible to the current stream; returns 1 / world."""
+        if not dist.is_initialized():
+            return 1.0
+        if self.comm_stream is not None:
+            # whatever was not started during the backward waits for the caller's stream (the backward has been joined onto it)
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+        for i in range(len(self.ranges)):
+            self.reduce_async(i)
+        for w in self.works.values():
+            w.wait()                      # device tensors: the current stream waits for the collective; gloo: blocks
+        self.works = {}
+        return 1.0 / dist.get_world_size(self.group)

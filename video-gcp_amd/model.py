@@ -62,14 +62,30 @@ class _Plan:
     def join(self, lanes):
         self.ops.append(("@join", None, (tuple(lanes), self._events(len(lanes))), 0))
 
-    def run(self, streams, ops=None):
+    def wait(self, waiter, signaler):
+        """lane `waiter` continues only after everything issued so far on lane `signaler` (one directional edge: a chain running
+        ahead on a side lane hands over chunk by chunk instead of being joined at every step)"""
+        self.ops.append(("@wait", None, (waiter, signaler, self._events(1)[0]), 0))
+
+    def mark(self, tag, payload):
+        """a host-side callback point in the launch sequence (eager replay only): `run(..., on_mark=f)` calls f(tag, payload)"""
+        self.ops.append(("@mark", None, (tag, payload), 0))
+
+    def run(self, streams, ops=None, on_mark=None):
         lib = self.lib
         for name, fn, args, lane in (self.ops if ops is None else ops):
-            if name == "@fork":
+            if name == "@mark":
+                if on_mark is not None:
+                    on_mark(*args)
+            elif name == "@fork":
                 lanes, evs = args
                 rt.check(lib.gcpx_event_record(evs[0], streams[0]), "fork")
                 for l in lanes:
                     rt.check(lib.gcpx_stream_wait_event(streams[l], evs[0]), "fork")
+            elif name == "@wait":
+                waiter, signaler, ev = args
+                rt.check(lib.gcpx_event_record(ev, streams[signaler]), "wait")
+                rt.check(lib.gcpx_stream_wait_event(streams[waiter], ev), "wait")
             elif name == "@join":
                 lanes, evs = args
                 for l, e in zip(lanes, evs):
@@ -85,6 +101,29 @@ class Outputs(dict):
     """AttrDict-like container (the reference returns blox.AttrDict)."""
     __getattr__ = dict.__getitem__
     __setattr__ = dict.__setitem__
+
+
+class ModelOutputs(Outputs):
+    """what `model(inputs)` returns.  The ragged views the reference's callers read as plain attributes — `pruned_prediction`
+    (tree.py:62-65), `actions`, `regressed_state`, `model_enc_seq` (base_gcp.py:234-262) — need the sequence lengths on the host,
+    so they are built on first access (one device-to-host copy of B integers) instead of inside every forward."""
+
+    _LAZY = ("pruned_prediction", "actions", "regressed_state", "model_enc_seq", "cost", "cost_target")
+
+    def __getattr__(self, name):
+        if name in self:
+            return self[name]
+        if name in ModelOutputs._LAZY and "_model" in self:
+            m = self["_model"]
+            if name == "pruned_prediction":
+                self[name] = m.pruned_prediction(self)
+            else:
+                aux = m.aux_outputs(self)
+                for k in aux:
+                    self.setdefault(k, aux[k])
+            if name in self:
+                return self[name]
+        raise AttributeError(name)
 
 
 class GCPTreeModel:
@@ -120,6 +159,13 @@ class GCPTreeModel:
         self._timed_op = None                 # name of one plan op bracketed by HIP events (bench.py roofline)
         self._timed_events = []
         self._pack_all()
+        # sub-module handles under the reference's attribute names (planner_policy.py:225-227, tree_dense_rec.py:13-40)
+        from . import handles as Hd
+        self.encoder, self.decoder, self.dense_rec = Hd.EncoderHandle(self), Hd.DecoderHandle(self), Hd.DenseRecHandle(self)
+        if hp.attach_inv_mdl:
+            self.inv_mdl = Hd.InverseModelHandle(self)
+        if hp.attach_cost_mdl:
+            self.cost_mdl = Hd.CostModelHandle(self)
 
     def _flatten_params(self, params):
         """All parameters live in ONE flat fp32 vector `theta` (canonical torch layouts, 16-byte aligned segments);
@@ -174,6 +220,12 @@ class GCPTreeModel:
     def state_dict(self):
         return dict(self.sd)
 
+    def step(self):
+        """BaseModel.step (base_model.py:24-25, called once per optimisation step, train.py:163): advances the `Updater` children.
+        The only one the reference builds is the KL-weight burn-in (base_gcp.py:125-131, kl_weight_burn_in=None by default), which
+        this build does not have, so this counts steps."""
+        self.n_steps = getattr(self, "n_steps", 0) + 1
+
     def load_state_dict(self, sd, strict=True):
         for k, v in sd.items():
             if k in self.sd:
@@ -190,6 +242,14 @@ class GCPTreeModel:
 
     def __call__(self, inputs, phase="train", noise=None):
         return self.forward(inputs, phase, noise)
+
+    def input_buffer(self, name, shape, dtype=None):
+        """The persistent device buffer the launch plans read input `name` from.  A data loader that writes its batch straight into
+        these buffers (and passes them as the inputs) hands the batch over without the per-call staging copy — 63 MB for traj_seq at
+        c2; any other tensor is copied in as before."""
+        if dtype is None:
+            dtype = torch.int64 if name in ("end_ind", "inv_t0", "inv_t1", "cost_start_idx", "cost_end_idx") else torch.float32
+        return self._buf("in." + name, tuple(shape), dtype)
 
     # ------------------------------------------------------------------------------------------------
     # weight packing
@@ -220,6 +280,24 @@ class GCPTreeModel:
             self.repack()
             return
         self.pk = self._pack_tree(self.sd)
+        self._pack_fused_embed()
+
+    def _pack_fused_embed(self):
+        """Inference only: the input embedding Linear and LSTM layer 0's input projection are two Linears with nothing in between
+        (tree_lstm.py:43-49 -> HiddenStatePredictorModel: embed, then LSTMCell(embed(x), h)), so gates_0 = (W_ih W_e) [e_l, e_r, z, e_0,
+        e_g] + W_hh h + (W_ih b_e + b_ih + b_hh): one launch less on every level's dependent chain.  The product is formed in
+        float64 once per weight load.  The training step keeps the two layers apart (its backward needs the embedding) and so does
+        any model whose packed weights live in the trainer's arena (a gather of theta cannot express a product)."""
+        hp = self._hp
+        for l in range(hp.hierarchy_levels if hp.untied_layers else 1):
+            p = f"tree_module.tree_modules.{l}.subgoal_pred"
+            sd = self.sd
+            We, be = sd[f"{p}.embed.weight"].double(), sd[f"{p}.embed.bias"].double()
+            Wih = sd[f"{p}.lstm.0.weight_ih"].double()
+            Wf = (Wih @ We).float()
+            bf = (Wih @ be).float() + sd[f"{p}.lstm.0.bias_ih"]
+            w, b = pk.lstm_gate_interleave(Wf, sd[f"{p}.lstm.0.weight_hh"], bf, sd[f"{p}.lstm.0.bias_hh"])
+            self.pk[f"tree{l}"]["lstm0f.w"], self.pk[f"tree{l}"]["lstm0f.b"] = pk.pack_gemm(w), b
 
     def _pack_tree(self, sd):
         """Pure index shuffling of `sd` (any dtype) into the kernels' layouts: {name: tensor | nested dict}."""
@@ -398,8 +476,10 @@ class GCPTreeModel:
     # ------------------------------------------------------------------------------------------------
     # buffers and plan-building helpers
     # ------------------------------------------------------------------------------------------------
+    _buf_prefix = ""          # handle plans (model.encoder / model.decoder) keep their activations apart from the forward's
+
     def _buf(self, name, shape, dtype=torch.float32, zero=False):
-        key = (name, tuple(shape), dtype)
+        key = (self._buf_prefix + name, tuple(shape), dtype)
         t = self._bufs.get(key)
         if t is None:
             t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
@@ -431,8 +511,24 @@ class GCPTreeModel:
             out.append(t)
         return out, M, True
 
+    def _gemm_group(self, plan, name, group):
+        """independent small-M GEMMs as one launch (gcpx_gemm_group); problems outside the split-K regime are launched one by one"""
+        if len(group) > 1:
+            n = len(group)
+            tab = (rt.GemmArgs * n)(*[a for _, a in group])
+            dims = (C.c_int32 * (4 * n))()
+            total = C.c_int32()
+            if self.lib.gcpx_gemm_group_dims(tab, n, dims, C.byref(total)) == 0:
+                raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
+                dd = torch.tensor(list(dims), dtype=torch.int32, device=self.device)
+                plan.keep += [raw, dd, tab]
+                plan.add(name, self.lib.gcpx_gemm_group, raw.data_ptr(), dd.data_ptr(), n, total.value)
+                return
+        for nm, a in group:
+            plan.add(nm, self.lib.gcpx_gemm, C.byref(a))
+
     def _gemm(self, plan, name, srcs, M, N, rpb, wpk, bias, out=None, ob=0, orow=0, epi=rt.EPI_NONE,
-              stats=None, lstm=None, batch=None):
+              stats=None, lstm=None, batch=None, group=None):
         srcs, rpb, dense = self._dense_rows(srcs, rpb, M)
         if dense:
             ob, orow = 0, ob
@@ -455,9 +551,14 @@ class GCPTreeModel:
         if batch is not None:
             a.nbatch, a.z_src_off, a.z_w_off, a.z_bias_off, a.z_out_off = batch
         plan.keep.append(a)
+        if group is not None:
+            group.append((name, a))
+            return
         plan.add(name, self.lib.gcpx_gemm, C.byref(a))
 
-    def _mlp(self, plan, name, W, srcs, M, rpb, out=None, ob=0, orow=0, oblk=0, out_split=0, gauss=None):
+    def _mlp(self, plan, name, W, srcs, M, rpb, out=None, ob=0, orow=0, oblk=0, out_split=0, gauss=None, group=None):
+        """One Predictor launch — or, with `group` (a list), only its argument struct: `_mlp_group` then issues the whole list as
+        ONE launch."""
         hp = self._hp
         rec_srcs, rec_rpb = srcs, rpb            # the backward plan addresses rows the way the caller does
         srcs, rpb, dense = self._dense_rows(srcs, rpb, M)
@@ -488,7 +589,25 @@ class GCPTreeModel:
             a.save = sv.data_ptr()
             plan.rec[f"mlp:{name}"] = dict(W=W, srcs=rec_srcs, M=M, rpb=rec_rpb, save=sv)
         plan.keep.append(a)
+        if group is not None:
+            group.append((name, a))
+            return
         plan.add(name, self.lib.gcpx_mlp, C.byref(a))
+
+    def _mlp_group(self, plan, name, group):
+        """independent Predictors of one hidden width as one launch (descriptor table uploaded once, when the plan is built)"""
+        if len(group) == 1:
+            plan.add(group[0][0], self.lib.gcpx_mlp, C.byref(group[0][1]))
+            return
+        n = len(group)
+        tab = (rt.MlpArgs * n)(*[a for _, a in group])
+        dims = (C.c_int32 * (4 * n))()
+        total = C.c_int32()
+        rt.check(self.lib.gcpx_mlp_group_dims(tab, n, dims, C.byref(total)), name)
+        raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
+        dd = torch.tensor(list(dims), dtype=torch.int32, device=self.device)
+        plan.keep += [raw, dd, tab]
+        plan.add(name, self.lib.gcpx_mlp_group, raw.data_ptr(), dd.data_ptr(), n, total.value, group[0][1].mid)
 
     def _bn(self, plan, tag, prefix, C_, stats, n_partial, pitch, count):
         """(scale, shift) of a BatchNorm: batch statistics when training, running statistics otherwise."""
@@ -703,6 +822,13 @@ class GCPTreeModel:
         plan.lane = 2
         if not pred_len:
             plan_bookkeeping()
+        if hp.attach_cost_mdl and hp.run_cost_mdl and train_aux and self._has_aux_training:
+            # ground-truth cost of the cost model's sampled segment (cost_mdl.py:101-117, EuclideanPathLength): reads traj_seq and
+            # two index vectors only, so it rides on this side lane instead of sitting in front of the decoder
+            gt = self._buf("cost_target", (B,))
+            rows = hp.input_nc * hp.img_sz
+            plan.add("path_cost", lib.gcpx_path_cost, tin["traj_seq"].data_ptr(), tin["cost_start_idx"].data_ptr(),
+                     tin["cost_end_idx"].data_ptr(), B, T, rows, hp.img_sz, self._buf("cost_partial", (B, rows)).data_ptr(), gt.data_ptr())
         self._plan_encoder(plan, "Ig", tin["I_g"].data_ptr(), B, _addr(E, 2 ** L * nz), PS * nz, 0, 1)
         plan.lane = 0
         if has_traj:
@@ -766,15 +892,12 @@ class GCPTreeModel:
                 self._gemm(plan, f"merge{l}", [h1, h2], M, H, n, W["proj.w"], W["proj.b"], out=_addr(merged),
                            ob=n * 2 * nl * H, orow=2 * nl * H, batch=(2 * nl, H, W["proj.w"][0].numel(), H, H))
 
-            # lanes: 0 = the chain that produces z and the embedding, 1 = parent-state merge (needs only the
-            # previous level), 2 = the prior when it is off the critical path (posterior mode)
-            side = ([1] if l > 0 else []) + ([2] if not (has_z or sample_prior) else [])
-            if side:
-                plan.fork(side)
+            # One lane for the whole level.  Measured (tools/fwd_tree_phase.py, c2): the parent-state merge on a side lane (parallel
+            # graph branch) made EVERY level slower than issuing it in line — level 1: 93 vs 73 us, level 6: 323 vs 229 us, the
+            # tree phase 1103 vs 853 us — a cross-queue join costs ~10 us and the big levels are throughput-bound anyway.
+            side = []
             if l > 0:
-                plan.lane = 1
                 plan_merge()
-                plan.lane = 0
             if has_z:
                 # given latents in depth-first order (tree.py:38); reparametrised with the learned prior (:79-82)
                 g = (_addr(tin["z"], (s - 1) * nv), N * nv, 2 * s * nv) + z_map
@@ -783,9 +906,9 @@ class GCPTreeModel:
                 g = (_addr(tin["eps"], (n - 1) * nv), N * nv, nv) + z_map
                 self._mlp(plan, f"prior{l}", W["prior"], [el(), er()], M, n, out=pz_out[0], ob=pz_out[1], orow=pz_out[2], gauss=g)
             else:
-                plan.lane = 2
-                self._mlp(plan, f"prior{l}", W["prior"], [el(), er()], M, n, out=pz_out[0], ob=pz_out[1], orow=pz_out[2])
-                plan.lane = 0
+                # the prior only feeds the KL term here: it shares the posterior's launch instead of a side lane of its own
+                pq = []
+                self._mlp(plan, f"prior{l}", W["prior"], [el(), er()], M, n, out=pz_out[0], ob=pz_out[1], orow=pz_out[2], group=pq)
                 if attentive:
                     # AttentiveInference (attentive_inference.py:16-32): e_tilde = attention over the encoded sequence
                     et = self._plan_attention(plan, l, W, el(), er(), M, n, B, Kp, Vp, tin)
@@ -794,27 +917,31 @@ class GCPTreeModel:
                     et = self._rowsrc(inf_enc.data_ptr(), 0, nz, nz, rowidx=etrow[B * (n - 1):])
                 g = (_addr(tin["eps"], (n - 1) * nv), N * nv, nv) + z_map
                 self._mlp(plan, f"posterior{l}", W["q"], [el(), er(), et], M, n, out=_addr(QZ, nodeoff(2 * nv)),
-                          ob=PS * 2 * nv, orow=2 * s * 2 * nv, gauss=g)
+                          ob=PS * 2 * nv, orow=2 * s * 2 * nv, gauss=g, group=pq)
+                self._mlp_group(plan, f"prior+posterior{l}", pq)
             zs = lambda: self._rowsrc(z_map[0], z_map[1], z_map[2], nv)
             if l == 0:
                 # MLPLSTMCellInitializer (tree_module.py:104-105): (h_left, h_right) -> slots 0 and 2^L
                 self._mlp(plan, "lstm_init", W["init"], [el(), er(), zs()], M, n, out=_addr(Hid), ob=PS * SD, orow=0,
                           oblk=2 ** L * SD, out_split=SD)
                 plan_merge()
-            # input embedding of [e_l, e_r, z, e_0, e_g] (tree_module.py:97-101)
+            # input embedding of [e_l, e_r, z, e_0, e_g] (tree_module.py:97-101); inference plans fold it into LSTM layer 0
             x = self._buf(f"x{l}.0", (M, H))
             srcs = [el(), er(), zs()] + ([e0(), eg()] if hp.context_every_step else [])
-            self._gemm(plan, f"embed{l}", srcs, M, H, n, W["embed.w"], W["embed.b"], out=x.data_ptr(), ob=n * H, orow=H)
-            if side:
-                plan.join(side)
+            fused = "lstm0f.w" in W and not self.save_for_backward
+            if not fused:
+                self._gemm(plan, f"embed{l}", srcs, M, H, n, W["embed.w"], W["embed.b"], out=x.data_ptr(), ob=n * H, orow=H)
             for i in range(nl):
                 xn = self._buf(f"x{l}.{i + 1}", (M, H))
                 xs = self._rowsrc(x.data_ptr(), n * H, H, H)
                 hs = self._rowsrc(_addr(merged, 2 * i * H), n * 2 * nl * H, 2 * nl * H, H)
                 lstm = (_addr(merged, (2 * i + 1) * H), 2 * nl * H, _addr(Hid, nodeoff(SD) + 2 * i * H),
                         _addr(Hid, nodeoff(SD) + (2 * i + 1) * H), PS * SD, 2 * s * SD, xn.data_ptr())
-                self._gemm(plan, f"lstm{l}.{i}", [xs, hs], M, 4 * H, n, W[f"lstm{i}.w"], W[f"lstm{i}.b"],
-                           epi=rt.EPI_LSTM, lstm=lstm)
+                if i == 0 and fused:
+                    self._gemm(plan, f"lstm{l}.0", srcs + [hs], M, 4 * H, n, W["lstm0f.w"], W["lstm0f.b"], epi=rt.EPI_LSTM, lstm=lstm)
+                else:
+                    self._gemm(plan, f"lstm{l}.{i}", [xs, hs], M, 4 * H, n, W[f"lstm{i}.w"], W[f"lstm{i}.b"],
+                               epi=rt.EPI_LSTM, lstm=lstm)
                 x = xn
             self._gemm(plan, f"out{l}", [self._rowsrc(x.data_ptr(), n * H, H, H)], M, nz, n, W["out.w"], W["out.b"],
                        out=_addr(E, nodeoff(nz)), ob=PS * nz, orow=2 * s * nz)
@@ -822,6 +949,8 @@ class GCPTreeModel:
         # ---- latent-space heads: independent of the decoder, run next to it on lane 1 ----
         F = B * N
         matching = adaptive and has_traj and phase == "train"        # soft-DTW binding is computed (tree.py:54-56)
+
+        heads = []            # the latent-space heads are independent Predictors of one width: ONE grouped launch
 
         def plan_aux(idx, Wd):
             """run_auxilliary_models (base_gcp.py:234-262) on the pruned / matched latent sequence given by idx [B, Wd]"""
@@ -831,7 +960,7 @@ class GCPTreeModel:
             if hp.attach_state_regressor:
                 rs = self._buf("regressed_state", (B, Wd, hp.state_dim))
                 self._mlp(plan, "state_regressor", P["state_regressor"], [self._rowsrc(mes.data_ptr(), Wd * nz, nz, nz)],
-                          B * Wd, Wd, out=rs.data_ptr(), ob=Wd * hp.state_dim, orow=hp.state_dim)
+                          B * Wd, Wd, out=rs.data_ptr(), ob=Wd * hp.state_dim, orow=hp.state_dim, group=heads)
                 outs["regressed_state_padded"] = rs
             if hp.attach_inv_mdl and phase == "train" and (sample_prior or hp.train_inv_mdl_full_seq or not has_traj):
                 # InverseModel.full_seq_forward (inverse_mdl.py:110-134): val_mode sets _inv_mdl_full_seq (base_gcp.py:44-53,250)
@@ -840,7 +969,7 @@ class GCPTreeModel:
                 s0 = self._rowsrc(first.data_ptr(), (T if has_traj else Wd) * nz, nz, nz)
                 s1 = self._rowsrc(_addr(mes, nz), Wd * nz, nz, nz)
                 self._mlp(plan, "inv_mdl", P["inv_mdl"], [s0, s1], B * (Wd - 1), Wd - 1, out=act.data_ptr(),
-                          ob=(Wd - 1) * hp.n_actions, orow=hp.n_actions)
+                          ob=(Wd - 1) * hp.n_actions, orow=hp.n_actions, group=heads)
                 outs["actions_padded"] = act
             aux_rows = None
             if train_aux and ((hp.attach_inv_mdl and not hp.train_inv_mdl_full_seq) or (hp.attach_cost_mdl and hp.run_cost_mdl)):
@@ -853,18 +982,15 @@ class GCPTreeModel:
                 # (train_im0_enc), second from the model's matched latents; both detached, so only action_pred is trained
                 act = self._buf("actions_sampled", (B, hp.n_actions))
                 self._mlp(plan, "inv_mdl", P["inv_mdl"], [gather(enc_traj, 0), gather(mes, 1)], B, B, out=act.data_ptr(), ob=0,
-                          orow=hp.n_actions)
+                          orow=hp.n_actions, group=heads)
                 outs["actions_sampled"] = act
             if hp.attach_cost_mdl and hp.run_cost_mdl and train_aux:
                 # CostModel.forward (cost_mdl.py:42-57): cost_pred on a sampled (start, end) pair of the matched latents against the
                 # ground-truth path cost of the same segment of traj_seq (_general_cost with EuclideanPathLength, conf.py:35-37)
                 cost = self._buf("cost_pred", (B, 1))
-                self._mlp(plan, "cost_mdl", P["cost_mdl"], [gather(mes, 2), gather(mes, 3)], B, B, out=cost.data_ptr(), ob=0, orow=1)
-                gt = self._buf("cost_target", (B,))
-                rows = hp.input_nc * hp.img_sz
-                plan.add("path_cost", lib.gcpx_path_cost, tin["traj_seq"].data_ptr(), tin["cost_start_idx"].data_ptr(),
-                         tin["cost_end_idx"].data_ptr(), B, T, rows, hp.img_sz, self._buf("cost_partial", (B, rows)).data_ptr(), gt.data_ptr())
-                outs["cost_pred"], outs["cost_target"] = cost, gt
+                self._mlp(plan, "cost_mdl", P["cost_mdl"], [gather(mes, 2), gather(mes, 3)], B, B, out=cost.data_ptr(), ob=0, orow=1,
+                          group=heads)
+                outs["cost_pred"], outs["cost_target"] = cost, self._buf("cost_target", (B,))     # filled on lane 2 (see above)
 
         # The latent-space heads are ~60 us of small launches.  Beside the decoder blocks (persistent grids, two workgroups per
         # CU) they cost more than that in interference (pyramid-2: 317 us beside them, 200 us alone), so they run in front.
@@ -890,8 +1016,11 @@ class GCPTreeModel:
             # existence predictor over depth-first latents (frame_binding.py:67-78)
             exist = self._buf("existence", (B, N))
             self._mlp(plan, "existence", P["existence"], [self._rowsrc(_addr(E, nz), PS * nz, nz, nz)], F, N,
-                      out=exist.data_ptr(), ob=N, orow=1)
+                      out=exist.data_ptr(), ob=N, orow=1, group=heads)
             outs["existence"] = exist
+        if heads:
+            self._mlp_group(plan, "heads", heads)
+            heads.clear()
         plan.lane = 0
 
         decode, with_loss = key[8], key[7]
@@ -952,6 +1081,8 @@ class GCPTreeModel:
                 plan.add("seq_len", lib.gcpx_seq_index, tin["end_ind"].data_ptr(), B, T, self._buf("seq_idx", (B, T), torch.int32).data_ptr(),
                          seq_len.data_ptr())
                 plan_aux(matched_idx, T)                     # get_matched_pruned_seqs for 'dtw' (base_gcp.py:358-366)
+                self._mlp_group(plan, "heads", heads)
+                heads.clear()
                 ent_sum = self._buf("entropy_sum", (1,))
                 plan.add("entropy_sum", lib.gcpx_reduce_partials, entropy.data_ptr(), B * N, 1, 1, ent_sum.data_ptr(), 0)
                 outs["entropy_sum"] = ent_sum
@@ -1078,9 +1209,11 @@ class GCPTreeModel:
                 t = inputs[k]
                 want = torch.int64 if (k == "end_ind" or k in AUX) else torch.float32
                 buf = self._buf("in." + k, tuple(t.shape), want)
-                buf.copy_(t, non_blocking=True)
-                if t.is_cuda:
-                    t.record_stream(self._stream)
+                if not (t.is_cuda and t.data_ptr() == buf.data_ptr() and t.dtype == want):
+                    # (a caller that fills `input_buffer(k, shape)` directly — a loader writing its batch in place — skips the copy)
+                    buf.copy_(t, non_blocking=True)
+                    if t.is_cuda:
+                        t.record_stream(self._stream)
                 tin[k] = buf
             if "end_ind" not in tin:
                 tin["end_ind"] = self._buf("in.end_ind", (B,), torch.int64)       # written by the length draw inside the plan
@@ -1106,7 +1239,7 @@ class GCPTreeModel:
                 eps = self._buf("eps", (B, self._n_latents(), hp.nz_vae))
                 if noise is None:
                     eps.normal_()
-                else:
+                elif not (noise.is_cuda and noise.data_ptr() == eps.data_ptr()):
                     eps.copy_(noise)
                     if noise.is_cuda:
                         noise.record_stream(self._stream)
@@ -1198,7 +1331,8 @@ class GCPTreeModel:
 
     def _wrap_outputs(self, o, tin, phase):
         hp = self._hp
-        out = Outputs()
+        out = ModelOutputs()
+        out["_model"] = self
         out.end_ind = tin["end_ind"]
         out.raw = o
         out.images_df = o.get("images_df")            # None after val_mode(decode=False)
@@ -1237,15 +1371,59 @@ class GCPTreeModel:
 
     def encode(self, images):
         """encoder(img)[0][:, :, 0, 0] (planner_policy.py:225): NCHW images in [-1, 1] -> latents [F, nz_enc]."""
-        x = images.to(device=self.device, dtype=torch.float32).contiguous()
+        return self._encode(images)[0]
+
+    def _encode(self, images, keep_skips=False):
+        from .handles import Skips
+        x = torch.as_tensor(images).to(device=self.device, dtype=torch.float32).contiguous()
         Fr = x.shape[0]
         out = torch.empty(Fr, self._hp.nz_enc, device=self.device)
         plan = _Plan(self.lib)
-        self._plan_encoder(plan, f"encode{Fr}", x.data_ptr(), Fr, out.data_ptr(), self._hp.nz_enc, 0, 1)
+        old, self._buf_prefix = self._buf_prefix, f"handle.enc{Fr}."
+        try:
+            skips = self._plan_encoder(plan, "x", x.data_ptr(), Fr, out.data_ptr(), self._hp.nz_enc, 0, 1)
+        finally:
+            self._buf_prefix = old
         caller = torch.cuda.current_stream(self.device)
         plan.run([caller.cuda_stream] * N_LANES)
         caller.synchronize()      # the plan's argument structs (and x) must outlive the launches
-        return out
+        if keep_skips:
+            # private copies: the encoder's activation buffers are reused by the next call of the same size
+            skips = {k: (t.clone(), C_, None if sc is None else sc.clone(), None if sh is None else sh.clone(), act)
+                     for k, (t, C_, sc, sh, act) in skips.items()}
+        return out, (Skips(skips, Fr) if keep_skips else None)
+
+    def _decode_seq(self, inputs, enc):
+        """DecoderModule.decode_seq (tree_dense_rec.py:42): enc [B, N, nz_enc(,1,1)] -> Outputs(images [B, N, 3, H, W])"""
+        from .handles import Skips, _rows
+        hp = self._hp
+        enc = torch.as_tensor(enc).to(device=self.device, dtype=torch.float32)
+        while enc.dim() > 3:
+            enc = enc[..., 0]
+        B, N = enc.shape[:2]
+        enc = enc.contiguous()
+        sk = inputs.get("skips") if isinstance(inputs, dict) else None
+        if not isinstance(sk, Skips):
+            _, sk = self._encode(inputs["I_0"], keep_skips=True)
+        assert sk.n_frames == B, "one set of skip activations per sequence (base_gcp.py:190: only the start image's)"
+        S = hp.img_sz
+        images = torch.empty(B, N, hp.input_nc, S, S, device=self.device)
+        plan = _Plan(self.lib)
+        old, self._buf_prefix = self._buf_prefix, f"handle.dec{B}x{N}."
+        train_was = self.training
+        try:
+            prev = self._plan_decoder_features(plan, self._rowsrc(enc.data_ptr(), N * hp.nz_enc, hp.nz_enc, hp.nz_enc), B * N, N, sk.srcs)
+            dlm = hp.decoder_distribution == "discrete_logistic_mixture"
+            a = self._conv_args([prev], B * N, S, S, S, S, hp.head_channels, self._head_pitch, self.pk["dec.head.w"], self.pk["dec.head.b"],
+                                None, upsample=0, head_mode=(rt.HEAD_DLM_MEAN if dlm else rt.HEAD_TANH_NCHW), images=images)
+            plan.keep.append(a)
+            plan.add("dec.head", self.lib.gcpx_conv3x3, C.byref(a))
+        finally:
+            self._buf_prefix = old
+        caller = torch.cuda.current_stream(self.device)
+        plan.run([caller.cuda_stream] * N_LANES)
+        caller.synchronize()
+        return Outputs(images=images)
 
     # ---- losses: computed inside the forward graph when traj_seq + pad_mask are fed in phase 'train' ----
     LOSS_NAMES = ("dense_img_rec", "kl", "len_pred", "existence_predictor", "state_regression")

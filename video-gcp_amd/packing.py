@@ -149,8 +149,9 @@ def pack_dlm_head(w, perm):
 
 def lstm_gate_interleave(w_ih, w_hh, b_ih, b_hh):
     """[4H, H] x2 (torch gate order i, f, g, o) -> W [4H, 2H] with row n = 4u + gate, bias [4H] likewise."""
-    H = w_ih.shape[1]
-    w = torch.cat([w_ih, w_hh], dim=1)                      # [4H, 2H], K = [x | h]
-    w = w.view(4, H, 2 * H).permute(1, 0, 2).reshape(4 * H, 2 * H)
+    H = w_hh.shape[1]                                       # (w_ih may be wider than H: embedding folded into layer 0)
+    w = torch.cat([w_ih, w_hh], dim=1)                      # [4H, K], K = [x | h]
+    K = w.shape[1]
+    w = w.view(4, H, K).permute(1, 0, 2).reshape(4 * H, K)
     b = (b_ih + b_hh).view(4, H).t().reshape(4 * H)
     return w.contiguous(), b.contiguous()

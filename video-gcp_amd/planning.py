@@ -228,9 +228,10 @@ class ImageHierarchicalTreeCEMSampler:
     """sampler.py:79-143: draws come from the hierarchical latent optimizer, one tree level is fixed per iteration."""
 
     def __init__(self, clip_val, n_steps, action_dim, initial_std, n_level_hierarchy, sampling_rates_per_layer,
-                 subgoal_cost_fcn, ll_cost_fcn, n_ll_samples):
-        from .tree_latent_search import ImageHierarchicalTreeLatentOptimizer
-        self._cls = ImageHierarchicalTreeLatentOptimizer
+                 subgoal_cost_fcn, ll_cost_fcn, n_ll_samples, device_resident=False):
+        from .tree_latent_search import ImageHierarchicalTreeLatentOptimizer, DeviceHierarchicalTreeLatentOptimizer
+        self._cls = DeviceHierarchicalTreeLatentOptimizer if device_resident else ImageHierarchicalTreeLatentOptimizer
+        self.device_resident = device_resident
         self._clip_val, self._action_dim, self._n_levels = clip_val, action_dim, n_level_hierarchy
         self._rates, self._sub_cost, self._ll_cost, self._n_ll = list(sampling_rates_per_layer), subgoal_cost_fcn, ll_cost_fcn, n_ll_samples
         assert n_level_hierarchy >= len(self._rates)
@@ -250,6 +251,15 @@ class ImageHierarchicalTreeCEMSampler:
             best_cost = [best_cost]
         return [best_rollout], best_cost
 
+    def optimize_device(self, rollout, goal_image=None):
+        """device-resident variant (tree_latent_search.DeviceHierarchicalTreeLatentOptimizer): `rollout` is what
+        GCPImageSimulator.rollout_device returns; the plan comes back as (row, frame) references + its cost"""
+        plan, best_cost = self._optimizer.optimize(rollout)
+        return [plan], [best_cost]
+
+    def materialize(self, plan, goal_image=None):
+        return self._optimizer.materialize(plan, goal_image)
+
     def fit(self, *args, **kwargs):
         pass
 
@@ -266,11 +276,16 @@ class HierarchicalCEMPlanner:
     replicas; the flat `CEMPlanner` is the sharded one."""
 
     def __init__(self, simulator, cost, n_level_hierarchy, sampling_rates_per_layer, n_ll_samples=5, action_dim=256,
-                 max_seq_len=80, clip_val=float("inf")):
+                 max_seq_len=80, clip_val=float("inf"), device_resident=True):
+        # device_resident: the rollouts of every iteration stay on the device — subgoal pair costs, segment costs and the
+        # selections are computed there and only the final plan crosses to the host.  False = the reference's data flow (every
+        # rollout, image ++ latent, to numpy: cem_simulator.py:68-70), kept as the checker: both give the same search.
         self._sim, self.max_seq_len = simulator, max_seq_len
         self.n_iters = len(sampling_rates_per_layer) + 1
+        self.device_resident = bool(device_resident and hasattr(simulator, "rollout_device") and hasattr(cost, "sequence_cost_device"))
         self._sampler = ImageHierarchicalTreeCEMSampler(clip_val, max_seq_len, action_dim, 1.0, n_level_hierarchy,
-                                                        sampling_rates_per_layer, cost, cost, n_ll_samples)
+                                                        sampling_rates_per_layer, cost, cost, n_ll_samples,
+                                                        device_resident=self.device_resident)
         self.logs = []
 
     def __call__(self, state, goal_state):
@@ -280,8 +295,13 @@ class HierarchicalCEMPlanner:
         best_samples = best_scores = None
         for _ in range(self.n_iters):
             samples = self._sampler.sample()
-            rollouts = self._sim.rollout(state, goal, samples, self.max_seq_len)
-            best_rollouts, best_scores = self._sampler.optimize(rollouts.predictions, goal)     # cem_planner.py:215
+            if self.device_resident:
+                # the learned cost reads latents only (cost_fcn.py:84-97): the scoring rollouts skip the image decoder
+                r = self._sim.rollout_device(state, goal, samples, self.max_seq_len, decode=False)
+                best_rollouts, best_scores = self._sampler.optimize_device(r)
+            else:
+                rollouts = self._sim.rollout(state, goal, samples, self.max_seq_len)
+                best_rollouts, best_scores = self._sampler.optimize(rollouts.predictions, goal)     # cem_planner.py:215
             best_samples = self._sampler.sample()                                               # :216
             self.logs.append(Outputs(elite_rollouts=best_rollouts, elite_scores=best_scores))
         final = self._sim.rollout(state, goal, best_samples, self.max_seq_len)

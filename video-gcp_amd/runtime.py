@@ -161,6 +161,11 @@ SYMBOLS = [
     ("gcpx_im2col_image", C.c_int, [vp, vp, i32, i32, i32, vp]),
     ("gcpx_dlm_nll_bwd", C.c_int, [vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, vp]),
     ("gcpx_loss_heads_bwd", C.c_int, [C.POINTER(LossArgs), vp, vp, vp, vp]),
+    ("gcpx_image_metrics", C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    ("gcpx_gemm_group_dims", C.c_int, [vp, i32, vp, vp]),
+    ("gcpx_gemm_group", C.c_int, [vp, vp, i32, i32, vp]),
+    ("gcpx_mlp_group_dims", C.c_int, [vp, i32, vp, vp]),
+    ("gcpx_mlp_group", C.c_int, [vp, vp, i32, i32, i32, vp]),
     ("gcpx_loss_aux_heads_bwd", C.c_int, [C.POINTER(LossArgs), vp, vp, vp]),
     ("gcpx_aux_sample_indices", C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     ("gcpx_aux_index_rows", C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),

@@ -36,24 +36,53 @@ class GCPSequentialModel(GCPTreeModel):
         for net in ("prior_lstm", "inf_lstm", "gen_lstm"):
             P[net] = self._pack_hsp(f"{p}.{net}", hp.n_lstm_layers)
 
+    def _pack_fused_embed(self):
+        """embed Linear folded into LSTM layer 0's input projection (float64 product, once per weight load): one launch less on
+        every step of the three recurrent chains — see GCPTreeModel._pack_fused_embed"""
+        from . import packing as pk
+        sd = self.sd
+        for net in ("prior_lstm", "inf_lstm", "gen_lstm"):
+            p = f"dense_rec.lstm.cell.{net}"
+            We, be = sd[f"{p}.embed.weight"].double(), sd[f"{p}.embed.bias"].double()
+            Wih = sd[f"{p}.lstm.0.weight_ih"].double()
+            w, b = pk.lstm_gate_interleave((Wih @ We).float(), sd[f"{p}.lstm.0.weight_hh"],
+                                           (Wih @ be).float() + sd[f"{p}.lstm.0.bias_ih"], sd[f"{p}.lstm.0.bias_hh"])
+            self.pk[net]["lstm0f.w"], self.pk[net]["lstm0f.b"] = pk.pack_gemm(w), b
+
     # ------------------------------------------------------------------------------------------------
-    def _plan_hsp(self, plan, name, W, srcs, B, state, par, out_ptr, out_ob, N_out):
-        """One step of a recurrent predictor: embed, n LSTM layers (state ping-pong `par` -> 1-par), out."""
+    def _hsp_stages(self, plan, name, W, srcs, B, state, par, out_ptr, out_ob, N_out):
+        """One step of a recurrent predictor as its dependent stages: [LSTM layer 0 (with the folded embedding), layer 1, ...,
+        out Linear].  Each stage is a function(group) that appends its GEMM to `group` — the same stage of nets that do not
+        depend on each other then shares ONE launch (gcpx_gemm_group)."""
         hp = self._hp
         H, nl = hp.nz_mid_lstm, hp.n_lstm_layers
-        x = self._buf(f"{name}.x0", (B, H))
-        self._gemm(plan, f"{name}.embed", srcs, B, H, 1, W["embed.w"], W["embed.b"], out=x.data_ptr(), ob=H, orow=0)
+        fused = "lstm0f.w" in W and not self.save_for_backward
+        xs_buf = [self._buf(f"{name}.x{i}", (B, H)) for i in range(nl + 1)]
+        stages = []
+        if not fused:
+            stages.append(lambda g: self._gemm(plan, f"{name}.embed", srcs, B, H, 1, W["embed.w"], W["embed.b"],
+                                               out=xs_buf[0].data_ptr(), ob=H, orow=0, group=g))
         for i in range(nl):
-            xn = self._buf(f"{name}.x{i + 1}", (B, H))
-            s_in, s_out = state[par][i], state[1 - par][i]             # [B, 2H] = [h | c]
-            xs = self._rowsrc(x.data_ptr(), H, 0, H)
-            hs = self._rowsrc(s_in.data_ptr(), 2 * H, 0, H)
-            lstm = (_addr(s_in, H), 2 * H, s_out.data_ptr(), _addr(s_out, H), 2 * H, 0, xn.data_ptr())
-            self._gemm(plan, f"{name}.lstm{i}", [xs, hs], B, 4 * H, 1, W[f"lstm{i}.w"], W[f"lstm{i}.b"], epi=rt.EPI_LSTM,
-                       lstm=lstm)
-            x = xn
-        self._gemm(plan, f"{name}.out", [self._rowsrc(x.data_ptr(), H, 0, H)], B, N_out, 1, W["out.w"], W["out.b"],
-                   out=out_ptr, ob=out_ob, orow=0)
+            def layer(g, i=i):
+                s_in, s_out = state[par][i], state[1 - par][i]             # [B, 2H] = [h | c]
+                xs = self._rowsrc(xs_buf[i].data_ptr(), H, 0, H)
+                hs = self._rowsrc(s_in.data_ptr(), 2 * H, 0, H)
+                lstm = (_addr(s_in, H), 2 * H, s_out.data_ptr(), _addr(s_out, H), 2 * H, 0, xs_buf[i + 1].data_ptr())
+                if i == 0 and fused:
+                    self._gemm(plan, f"{name}.lstm0", list(srcs) + [hs], B, 4 * H, 1, W["lstm0f.w"], W["lstm0f.b"], epi=rt.EPI_LSTM,
+                               lstm=lstm, group=g)
+                else:
+                    self._gemm(plan, f"{name}.lstm{i}", [xs, hs], B, 4 * H, 1, W[f"lstm{i}.w"], W[f"lstm{i}.b"], epi=rt.EPI_LSTM,
+                               lstm=lstm, group=g)
+            stages.append(layer)
+        stages.append(lambda g: self._gemm(plan, f"{name}.out", [self._rowsrc(xs_buf[nl].data_ptr(), H, 0, H)], B, N_out, 1,
+                                           W["out.w"], W["out.b"], out=out_ptr, ob=out_ob, orow=0, group=g))
+        return stages
+
+    def _plan_hsp(self, plan, name, W, srcs, B, state, par, out_ptr, out_ob, N_out):
+        """One step of a recurrent predictor on its own: embed, n LSTM layers (state ping-pong `par` -> 1-par), out."""
+        for st in self._hsp_stages(plan, name, W, srcs, B, state, par, out_ptr, out_ob, N_out):
+            st(None)
 
     def _build_plan(self, key, tin):
         hp, P, lib = self._hp, self.pk, self.lib
@@ -98,29 +127,55 @@ class GCPSequentialModel(GCPTreeModel):
                 plan.add(f"zero.{net}.{i}", lib.gcpx_fill_zero, state[net][0][i].data_ptr(), B * 2 * H * 4)
         ctx = (lambda: [e0(), eg()]) if hp.context_every_step else (lambda: [])
         posterior = has_traj and not sample_prior and not has_z
-        for t in range(T - 1):
-            par = t & 1
-            xt = lambda: self._rowsrc(_addr(X, t * nz), T * nz, 0, nz)
-            plan.fork([1])
-            plan.lane = 1
-            self._plan_hsp(plan, f"prior{t}", P["prior_lstm"], [xt()] + ctx(), B, state["prior_lstm"], par,
-                           _addr(PZ, t * 2 * nv), (T - 1) * 2 * nv, 2 * nv)
-            plan.lane = 0
-            if has_traj:
-                xp = self._rowsrc(_addr(enc_traj, (t + 1) * nz), T * nz, 0, nz)
-                self._plan_hsp(plan, f"inf{t}", P["inf_lstm"], [xp] + ctx(), B, state["inf_lstm"], par,
-                               _addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 2 * nv)
-            plan.join([1])
+        # Three recurrent nets, ONE lane.  The inference net reads the ENCODED ground truth only (sequential.py:51-54): it does not
+        # wait for the generator, so its step t + 1 is computed NEXT TO the generator's step t — stage by stage in the same
+        # launches (gcpx_gemm_group), together with the prior net's step t (needs x_t, feeds only the KL term).  A step of the
+        # posterior rollout is then 4 grouped launches + the sample instead of 13 launches on three lanes: the first version's
+        # 1300-node multi-lane graph cost the host 9.5 ms per replay, more than the device needed.
+        xt_of = lambda t: self._rowsrc(_addr(X, t * nz), T * nz, 0, nz)
+
+        def prior_stages(t):
+            return self._hsp_stages(plan, f"prior{t}", P["prior_lstm"], [xt_of(t)] + ctx(), B, state["prior_lstm"], t & 1,
+                                    _addr(PZ, t * 2 * nv), (T - 1) * 2 * nv, 2 * nv)
+
+        def inf_stages(t):
+            xp = self._rowsrc(_addr(enc_traj, (t + 1) * nz), T * nz, 0, nz)
+            return self._hsp_stages(plan, f"inf{t}", P["inf_lstm"], [xp] + ctx(), B, state["inf_lstm"], t & 1,
+                                    _addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 2 * nv)
+
+        def z_source(t):
             zt = (_addr(Z, t * nv), (T - 1) * nv, 0)
             if has_z:
-                zsrc = self._rowsrc(_addr(tin["z"], t * nv), (T - 1) * nv, 0, nv)
+                return self._rowsrc(_addr(tin["z"], t * nv), (T - 1) * nv, 0, nv)
+            muls = QZ if posterior else PZ
+            plan.add(f"sample{t}", lib.gcpx_gauss_sample, _addr(muls, t * 2 * nv), (T - 1) * 2 * nv, 0,
+                     _addr(tin["eps"], t * nv), tin["eps"].shape[1] * nv, 0, zt[0], zt[1], zt[2], B, 1, nv)
+            return self._rowsrc(zt[0], zt[1], zt[2], nv)
+
+        def gen_stages(t, zsrc):
+            return self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [xt_of(t), zsrc] + ctx(), B, state["gen_lstm"], t & 1,
+                                    _addr(X, (t + 1) * nz), T * nz, nz)
+
+        def run(*chains):
+            """stage i of every chain in one launch"""
+            chains = [c for c in chains if c]
+            for i in range(max(len(c) for c in chains)):
+                g = []
+                for c in chains:
+                    if i < len(c):
+                        c[i](g)
+                self._gemm_group(plan, f"step.{g[0][0]}", g)
+
+        z_from_prior = not has_z and not posterior          # prior sampling: z_t needs prior(t), which needs x_t: one serial chain
+        if has_traj:
+            run(inf_stages(0))
+        for t in range(T - 1):
+            if z_from_prior:
+                run(prior_stages(t))
+                run(gen_stages(t, z_source(t)))
             else:
-                muls = QZ if posterior else PZ
-                plan.add(f"sample{t}", lib.gcpx_gauss_sample, _addr(muls, t * 2 * nv), (T - 1) * 2 * nv, 0,
-                         _addr(tin["eps"], t * nv), tin["eps"].shape[1] * nv, 0, zt[0], zt[1], zt[2], B, 1, nv)
-                zsrc = self._rowsrc(zt[0], zt[1], zt[2], nv)
-            self._plan_hsp(plan, f"gen{t}", P["gen_lstm"], [xt(), zsrc] + ctx(), B, state["gen_lstm"], par,
-                           _addr(X, (t + 1) * nz), T * nz, nz)
+                zsrc = z_source(t)                            # q(z_t) was produced one step ahead
+                run(gen_stages(t, zsrc), inf_stages(t + 1) if (has_traj and t + 1 < T - 1) else None, prior_stages(t))
 
         # ---- latent-space heads next to the decoder ----
         plan.fork([1])

@@ -66,24 +66,28 @@ class ModelTrainer:
         from .params import init_params
         from .training import GCPTrainStep
         self.cmd_args = args = args if args is not None else get_cmd_args()
-        conf = {}
-        if args.path and os.path.exists(os.path.join(args.path, "conf.json")):
-            conf = json.load(open(os.path.join(args.path, "conf.json")))
-        name = args.config or conf.get("config", "c2")
+        from .conf_loader import load_conf
+        # <path>/conf.py in the reference's format (`configuration` + `model_config`, gcp_builder.py:129-147) or <path>/conf.json
+        name = args.config or "c2"
+        self.hp, conf, self.ignored_conf_keys = load_conf(args.path, default=name)
+        hp = self.hp
         self.exp_path = args.path or os.path.join("experiments", name)
         self.rank, self.local_rank, self.world = D.init_from_env()
         if args.gpu >= 0:
             self.local_rank = args.gpu
         torch.cuda.set_device(self.local_rank)
         self.device = torch.device("cuda", self.local_rank)
-        self.hp = hp = config(name, **conf.get("overrides", {}))
         self.num_epochs = args.num_epochs if args.num_epochs is not None else conf.get("num_epochs", 1)
         nb = args.batches_per_epoch if args.batches_per_epoch is not None else conf.get("batches_per_epoch", 10)
         seed = 0 if args.deterministic else conf.get("seed", 0)
-        # same initial weights on every rank (same seed) = the broadcast of DataParallel replicas
+        # same initial weights on every rank (same seed) = the broadcast of DataParallel replicas ...
         self.model = GCPTreeModel(hp, params=init_params(hp, seed=seed), device=self.device)
+        # ... but a DIFFERENT stream of latent noise / auxiliary-model index draws per rank, as nn.DataParallel's replicas drew
+        # different numbers for their different shards (gcp_builder.py:71-78); reproducible through `seed` / --deterministic
+        torch.cuda.manual_seed(seed * max(self.world, 1) + self.rank + 1)
         pg = torch.distributed.group.WORLD if self.world > 1 else None
-        self.trainer = GCPTrainStep(self.model, lr=conf.get("lr", 1e-3), betas=(conf.get("adam_beta", 0.9), 0.999), process_group=pg)
+        lr = conf.get("lr") if conf.get("lr") is not None else 1e-3
+        self.trainer = GCPTrainStep(self.model, lr=lr, betas=(conf.get("adam_beta", 0.9), 0.999), process_group=pg)
         if not args.feed_random_data and train_loader is None:
             raise ValueError("no dataset reader ships with this build: pass --feed_random_data 1 or give ModelTrainer a loader")
         self.train_loader = train_loader or SyntheticLoader(hp, nb, 1000 + 100000 * self.rank, self.device)
@@ -105,7 +109,10 @@ class ModelTrainer:
     def resume(self, ckpt, path=None):
         from . import checkpoint as CK
         folder = os.path.join(self.exp_path if path is None else path, "weights")
-        f = CK.get_resume_ckpt_file(ckpt, folder)
+        try:
+            f = CK.get_resume_ckpt_file(ckpt, folder)
+        except CK.NoCheckpointsException:               # train.py:59-62: `--resume latest` on a fresh experiment starts at epoch 0
+            return 0
         self.global_step, epoch, opt = CK.load_weights(f, self.model, strict=bool(self.cmd_args.strict_weight_loading))
         if opt is not None:
             self.trainer.load_optimizer_state(opt)
@@ -134,6 +141,7 @@ class ModelTrainer:
         end = time.time()
         for batch_idx, inputs in enumerate(self.train_loader):
             out = self.trainer.step(inputs)            # zero_grad, forward, loss, backward, (all-reduce), optimizer.step
+            self.model.step()                          # train.py:163
             if self.global_step % self.cmd_args.log_outputs_interval == 0:
                 total = float(out.raw["losses"][5])    # the only host sync of the loop, on logging steps
                 self.log.append((self.global_step, total))

@@ -48,6 +48,10 @@ class GCPTrainStep:
         self.exp_avg = torch.zeros_like(model.theta)
         self.exp_avg_sq = torch.zeros_like(model.theta)
         self.opt_state = torch.zeros(4, device=model.device)
+        from .dist import GradBuckets, gradient_bucket_ranges
+        ranges = gradient_bucket_ranges(model._poff, hp.hierarchy_levels, hp.untied_layers)
+        self._bucket_index = {name: i for i, (name, _, _) in enumerate(ranges)} if process_group is not None else {}
+        self.buckets = GradBuckets(self.grad, ranges, process_group) if process_group is not None else None
         self.bk = model.build_arena(self._pack_backward)
         self._bplans = {}
         # backward plans are built from forward plans: drop them whenever the model drops those (load_state_dict, build_arena)
@@ -71,6 +75,7 @@ class GCPTrainStep:
         self.n_side = int(__import__("os").environ.get("GCPX_NSIDE", N_LANES - 1))   # side lanes of the backward plan
         self.side_priority = 0                # middle priority; lowest (> 0) starves the side lanes: 40.9 ms / step
         self._lanes = None
+        self._lane_streams = None
         self._zeros = torch.zeros(256, device=model.device)
 
     # ------------------------------------------------------------------------------------------------
@@ -662,6 +667,10 @@ class GCPTrainStep:
                 srcs.append((dXa.data_ptr(), 2 * nz, 0, nz, -1, -1, 0))
             self._tree_accum(plan, f"E{l}", dE, PS * nz, 2 * s * nz, B, n, nz, srcs)
             self._flush(plan)
+            if f"tree{l}" in self._bucket_index:
+                # every gradient of this level's module has been issued (main lane + the side lanes just flushed): its bucket of the
+                # data-parallel exchange can start while the levels above are differentiated
+                plan.mark("bucket", self._bucket_index[f"tree{l}"])
 
         # ---- temporal inference encoder + image encoders (base_gcp.py:184-213 backward) ----
         d_inf = buf("bw.d_inf", (B * T, nz))
@@ -954,10 +963,17 @@ class GCPTrainStep:
                 bplan.graph = m._capture(bplan, bplan.ops, stream)
             rt.check(m.lib.gcpx_graph_launch(bplan.graph, stream), "graph_launch")
         else:
-            bplan.run(self._backward_streams())
+            bplan.run(self._backward_streams(), on_mark=self._on_mark)
         caller.wait_stream(m._stream)
         self.last_bplan = bplan
         return out
+
+    def _on_mark(self, tag, payload):
+        if tag == "bucket" and self.buckets is not None:
+            if self._lane_streams is None:
+                self._lane_streams = [torch.cuda.ExternalStream(int(s.value if hasattr(s, "value") else s), device=self.m.device)
+                                      for s in self._backward_streams()]
+            self.buckets.reduce_async(payload, after_streams=self._lane_streams)
 
     def _backward_streams(self):
         """lane 0 = the model's stream, side lanes = the model's own side streams: the process then uses four streams in all
@@ -978,9 +994,9 @@ class GCPTrainStep:
         m = self.m
         st = torch.cuda.current_stream(m.device).cuda_stream
         scale = 1.0
-        if self.pg is not None:
-            from .dist import all_reduce_sum_
-            scale = all_reduce_sum_(self.grad, self.pg)              # one RCCL all-reduce over the flat gradient (sum)
+        if self.buckets is not None:
+            # the tree-level buckets were started during the backward; the last one (conv stacks, heads, level 0) goes now
+            scale = self.buckets.finish()
         rt.check(m.lib.gcpx_radam_step(m.theta.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                        self.opt_state.data_ptr(), m.theta.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
                                        scale, st), "radam")

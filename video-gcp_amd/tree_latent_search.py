@@ -182,3 +182,108 @@ class ImageHierarchicalTreeLatentOptimizer(HierarchicalTreeLatentOptimizer):
     def __init__(self, *args, **kw):
         kw.setdefault("image_states", True)
         super().__init__(*args, **kw)
+
+
+class DeviceHierarchicalTreeLatentOptimizer(ImageHierarchicalTreeLatentOptimizer):
+    """The same search with the rollouts left on the device.
+
+    The reference moves every rollout (image ++ latent, tens of MB per CEM iteration) to numpy and slices it on the host
+    (tree_optimizer.py:86-180 via cem_simulator.py:68-70).  Only LATENTS enter the costs (subgoal pair cost :100-110, dense
+    segment cost :70-84), so here a rollout is a (row, first frame, end frame) view into the simulator's device tensors:
+    pair costs are one batched Predictor launch per branch (`cost.pair_cost`), segment costs one `cost.sequence_cost_device`
+    call, and the host sees the sequence lengths and one argmin index per decision.  Plans are lists of (row, frame) references
+    that are gathered into images only when somebody asks (`materialize`).  Draws, selections, costs and `best_z` are identical
+    to the numpy class on identical np.random state: it stays in the tests as the checker."""
+
+    RAW = ("raw",)                                   # goal given as the raw environment image: score against own last latent
+
+    def sample(self):
+        return super().sample()                      # np.random on the host: the search state is a few hundred KB
+
+    def optimize(self, rollout, goal=None):
+        """rollout: Outputs(latents [n, T, nz] device, lengths (device int32 or list), images [n, T, ...] or None)"""
+        import torch
+        self._lat = rollout.latents
+        lens = rollout.lengths.tolist() if torch.is_tensor(rollout.lengths) else list(rollout.lengths)
+        self._rollout = rollout
+        views = [(i, 0, l) for i, l in enumerate(lens)]
+        plan, cost = self._dopt(self._root, views, self.RAW)
+        return plan, cost
+
+    def materialize(self, plan, goal_image=None):
+        """plan references -> [len, 3, H, W] images on the device (the raw goal, when the plan ends in it, is `goal_image`)"""
+        import torch
+        img = self._rollout.images
+        frames = [img[i, t] if i >= 0 else goal_image for i, t in plan]
+        return torch.stack(frames)
+
+    # ---- device mirrors of _opt / _opt_subgoal / _opt_children / _best_segment ----
+    def _rows(self, refs):
+        import torch
+        idx = torch.tensor([[i, t] for i, t in refs], device=self._lat.device)
+        return self._lat[idx[:, 0], idx[:, 1]]
+
+    def _goal_rows(self, views, goal):
+        if goal is self.RAW:
+            return self._rows([(i, b - 1) for i, a, b in views])          # l[-1] of every rollout
+        return self._rows([goal] * len(views))
+
+    def _dbest_segment(self, views, goal):
+        import torch
+        n = len(views)
+        tmax = max(b - a for _, a, b in views)
+        lat = torch.zeros(n, tmax, self._lat.shape[-1], device=self._lat.device)
+        for r, (i, a, b) in enumerate(views):
+            lat[r, :b - a] = self._lat[i, a:b]
+        lens = torch.tensor([b - a for _, a, b in views], dtype=torch.int32, device=self._lat.device)
+        cost = self._seq_cost.sequence_cost_device(lat, lens, self._goal_rows(views, goal))
+        k = int(torch.argmin(cost))
+        i, a, b = views[k]
+        return [(i, t) for t in range(a, b)], np.float32(cost[k].item()), k        # float32 like the numpy class: sums of costs stay bit-equal
+
+    def _dopt(self, lv, views, goal):
+        if lv.left is None:
+            plan, cost, k = self._dbest_segment(views, goal)
+            lv.best_z, lv.done = lv.last_draw[k], True
+            return plan, cost
+        if not lv.done:
+            return self._dopt_subgoal(lv, views, goal)
+        return self._dopt_children(lv, views, goal)
+
+    def _dopt_subgoal(self, lv, views, goal):
+        import torch
+        mids = [(b - a) // 2 for _, a, b in views]
+        start = self._rows([(i, a) for i, a, b in views])
+        sub = self._rows([(i, a + m) for (i, a, b), m in zip(views, mids)])
+        gl = self._goal_rows(views, goal)
+        n = len(views)
+        # both pair costs of all candidates in ONE Predictor launch
+        c = self._pair_cost.pair_cost(torch.cat([start, sub]), torch.cat([sub, gl]))
+        total = c[:n] + c[n:]
+        k = int(torch.argmin(total.reshape(-1)))
+        lv.best_z = lv.last_draw[k]
+        i, a, b = views[k]
+        plan = [(i, a)]
+        if mids[k] != 0:
+            plan.append((i, a + mids[k]))
+        if goal is self.RAW:
+            plan.append((-1, -1))                                 # the raw goal image closes the plan (tree_optimizer.py:127-129)
+        lv.left, lv.right = lv.left[:1], lv.right[:1]
+        lv.n_samples, lv.done = 1, True
+        return plan, np.float32(total.reshape(-1)[k].item())
+
+    def _dopt_children(self, lv, views, goal):
+        results = []
+        for cl, cr, group in zip(lv.left, lv.right, np.array_split(np.arange(len(views)), lv.n_samples)):
+            group = [views[j] for j in group]
+            short = [v for v in group if v[2] - v[1] < 3]
+            if short:
+                raise NotImplementedError("rollouts shorter than 3 frames inside the hierarchy: use the numpy optimizer")
+            cut = [(b - a) // 2 for _, a, b in group]
+            i0, a0, _ = group[0]
+            subgoal = (i0, a0 + cut[0])
+            lr, lc = self._dopt(cl, [(i, a, a + c) for (i, a, b), c in zip(group, cut)], subgoal)
+            rr, rc = self._dopt(cr, [(i, a + c, b) for (i, a, b), c in zip(group, cut)], goal)
+            results.append((lr + rr, lc + rc))
+        k = int(np.argmin(np.array([c for _, c in results])))
+        return results[k]
