@@ -195,7 +195,7 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
         goal = rng.randint(0, 256, size=(1, hp4.img_sz, hp4.img_sz, 3)).astype(np.uint8)
         n = 512
         sampler = SimpleTreeCEMSampler(float("inf"), None, hp4.nz_vae, 1.0, n_level_hierarchy=hp4.hierarchy_levels, device=dev, seed=1)
-        planner = CEMPlanner(GCPImageSimulator(m4), LearnedCostEstimate(m4), sampler, n_iters=1, batch_size=n, elite_frac=0.1,
+        planner = CEMPlanner(GCPImageSimulator(m4, pred_length=False), LearnedCostEstimate(m4), sampler, n_iters=1, batch_size=n, elite_frac=0.1,
                              max_seq_len=hp4.max_seq_len)
 
         def it():

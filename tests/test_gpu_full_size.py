@@ -120,7 +120,8 @@ def test_c3_training_shard_batch16_gradient_is_the_derivative_of_the_loss():
     # base_gcp.py:253-256): their loss terms move with the tree's parameters but send no gradient there.  The differentiated
     # function is therefore: the ELBO terms + length CE + existence BCE for every group, plus a head's own L2 term for that head.
     elbo = {0: hp.dense_img_rec_weight, 1: hp.kl_weight, 2: hp.length_pred_weight, 3: 1.0}
-    own = {"cost_mdl.": {8: 1.0}, "inv_mdl.": {7: hp.action_rec_weight}, "state_regressor.": {4: 1.0}}
+    own = {"cost_mdl.": {8: 1.0}, "inv_mdl.": {7: hp.action_rec_weight}, "state_regressor.": {4: 1.0},
+           "length_pred.": {2: hp.length_pred_weight}}       # (the length head only enters its own cross-entropy)
 
     pm = dev_in["pad_mask"].double()
 
@@ -193,7 +194,7 @@ def test_c4_cem_iteration_full_population(n_cand):
     state = rng.randint(0, 256, size=(1, 64, 64, 3)).astype(np.uint8)
     goal = rng.randint(0, 256, size=(1, 64, 64, 3)).astype(np.uint8)
     sampler = SimpleTreeCEMSampler(float("inf"), None, hp.nz_vae, 1.0, n_level_hierarchy=hp.hierarchy_levels, device="cuda", seed=4)
-    planner = CEMPlanner(GCPImageSimulator(model), LearnedCostEstimate(model), sampler, n_iters=1, batch_size=n_cand, elite_frac=0.1,
+    planner = CEMPlanner(GCPImageSimulator(model, pred_length=False), LearnedCostEstimate(model), sampler, n_iters=1, batch_size=n_cand, elite_frac=0.1,
                          max_seq_len=hp.max_seq_len, decode_candidates=True)
     z = sampler.sample(n_cand)
     scores, r = planner.evaluate(state, goal, z)

@@ -32,7 +32,7 @@ def test_simulator_rollout_matches_oracle(setup):
     state, goal = _env_images(hp, 0)
     n, T = 3, hp.max_seq_len
     z = torch.randn(n, hp.n_nodes, hp.nz_vae, generator=torch.Generator().manual_seed(0))
-    sim = GCPImageSimulator(model, append_latent=True)
+    sim = GCPImageSimulator(model, append_latent=True, pred_length=False)
     got = sim.rollout(state, goal, z.numpy(), T)
     inp = dict(I_0=env2planner(np.repeat(state, n, 0)), I_g=env2planner(np.repeat(goal, n, 0)), z=z,
                end_ind=torch.full((n,), T - 1, dtype=torch.long), start_ind=torch.zeros(n, dtype=torch.long))
@@ -78,8 +78,10 @@ def test_cem_planner_runs_and_is_deterministic(setup):
                              elite_frac=0.25, max_seq_len=hp.max_seq_len)
         plan, actions, latents, score = planner(state, goal)
         res.append((plan, actions, latents, score, [l.elite_scores.cpu().numpy() for l in planner.logs]))
-    assert res[0][0].shape == (hp.max_seq_len, 3 * hp.img_sz ** 2 + hp.nz_enc)
-    assert res[0][1].shape == (hp.max_seq_len - 1, hp.n_actions)
+    # the plan's length is a draw from the length predictor (val_mode(pred_length=True), cem_simulator.py:29): 3 .. T frames
+    n = res[0][0].shape[0]
+    assert 3 <= n <= hp.max_seq_len and res[0][0].shape == (n, 3 * hp.img_sz ** 2 + hp.nz_enc)
+    assert res[0][1].shape == (n - 1, hp.n_actions) and res[0][2].shape == (n, hp.nz_enc)
     assert np.array_equal(res[0][0], res[1][0]) and res[0][3] == res[1][3]
     for a, b in zip(res[0][4], res[1][4]):
         assert np.array_equal(a, b)
@@ -124,7 +126,7 @@ def test_hierarchical_cem_planner(setup):
     res = {}
     for dev in (False, True):
         np.random.seed(0)
-        planner = HierarchicalCEMPlanner(GCPImageSimulator(model), LearnedCostEstimate(model), hp.hierarchy_levels, [3, 2],
+        planner = HierarchicalCEMPlanner(GCPImageSimulator(model, pred_length=False), LearnedCostEstimate(model), hp.hierarchy_levels, [3, 2],
                                          n_ll_samples=2, action_dim=hp.nz_vae, max_seq_len=hp.max_seq_len, device_resident=dev)
         assert planner.device_resident == dev
         plan, actions, latents, score = planner(state, goal)
@@ -155,3 +157,35 @@ def test_plan_entry_point_cem_and_hierarchical(tmp_path):
     assert z["image_plan"].shape[0] == res[0]["plan_len"] and z["latents"].shape[0] == res[0]["plan_len"]
     res = main(["--config", "c1", "--nstart_goal_pairs", "1", "--planner", "hierarchical"])
     assert len(res) == 1 and np.isfinite(res[0]["cost"])
+
+
+def test_rollout_with_predicted_lengths_matches_oracle(setup):
+    """the reference's rollout runs under val_mode() = pred_length=True (cem_simulator.py:29, base_gcp.py:219-226): every
+    candidate's length is a draw from the length predictor; fed draws -> bit-exact lengths, pruned rollouts vs the oracle"""
+    from oracle import gcp_model_oracle as O
+    from video_gcp_amd.planning import GCPImageSimulator, env2planner
+    hp, sd, model = setup
+    state, goal = _env_images(hp, 5)
+    n, T = 5, hp.max_seq_len
+    z = torch.randn(n, hp.n_nodes, hp.nz_vae, generator=torch.Generator().manual_seed(2))
+    len_u = torch.tensor([0.05, 0.3, 0.55, 0.8, 0.97])
+    sim = GCPImageSimulator(model, append_latent=True)            # pred_length=True is the default, as in the reference
+    r = sim.rollout_device(state, goal, z, T, len_u=len_u)
+    inp = dict(I_0=env2planner(np.repeat(state, n, 0)), I_g=env2planner(np.repeat(goal, n, 0)), z=z, len_u=len_u,
+               end_ind=torch.full((n,), T - 1, dtype=torch.long), start_ind=torch.zeros(n, dtype=torch.long))
+    ref = O.forward(sd, hp, inp, sample_prior=True, training_bn=False, use_pred_length=True)
+    lens = r.lengths.cpu().long()
+    assert torch.equal(lens, ref["end_ind"] + 1) and len(set(lens.tolist())) > 1
+    for i in range(n):
+        assert_close(r.images[i, :lens[i]], ref["pruned_prediction"][i], 2e-5, 0, "pruned rollout")
+        assert_close(r.latents[i, :lens[i]], ref["model_enc_seq_list"][i], 5e-5, 1e-4, "latents")
+    # the CEM planner on variable-length rollouts: deterministic (shared length draws), finite scores
+    from video_gcp_amd.planning import LearnedCostEstimate, SimpleTreeCEMSampler, CEMPlanner
+    res = []
+    for _ in range(2):
+        sampler = SimpleTreeCEMSampler(float("inf"), None, hp.nz_vae, 1.0, n_level_hierarchy=hp.hierarchy_levels, device="cuda", seed=3)
+        planner = CEMPlanner(GCPImageSimulator(model), LearnedCostEstimate(model), sampler, n_iters=2, batch_size=16, elite_frac=0.25,
+                             max_seq_len=hp.max_seq_len)
+        plan, actions, latents, score = planner(state, goal)
+        res.append((plan, score))
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and np.isfinite(res[0][1])

@@ -24,7 +24,7 @@ rng = np.random.RandomState(0)
 state = rng.randint(0, 256, size=(1, hp.img_sz, hp.img_sz, 3)).astype(np.uint8)
 goal = rng.randint(0, 256, size=(1, hp.img_sz, hp.img_sz, 3)).astype(np.uint8)
 sampler = SimpleTreeCEMSampler(float("inf"), None, hp.nz_vae, 1.0, n_level_hierarchy=hp.hierarchy_levels, device="cuda", seed=1)
-planner = CEMPlanner(GCPImageSimulator(model), LearnedCostEstimate(model), sampler, n_iters=1, batch_size=args.candidates,
+planner = CEMPlanner(GCPImageSimulator(model, pred_length=False), LearnedCostEstimate(model), sampler, n_iters=1, batch_size=args.candidates,
                      elite_frac=0.1, max_seq_len=hp.max_seq_len)
 for _ in range(2):
     s = sampler.sample(args.candidates)

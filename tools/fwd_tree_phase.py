@@ -22,7 +22,7 @@ L = hp.hierarchy_levels
 def lvl_start(l):
     for cand in (f"prior+posterior{l}", f"prior{l}", f"merge{l}"):
         if cand in names:
-            return min(names.index(c) for c in (f"prior+posterior{l}", f"prior{l}", f"merge{l}", f"posterior{l}") if c in names)
+            return min(names.index(c) for c in (f"prior+posterior{l}", f"prior{l}", f"posterior{l}") + ((f"merge{l}",) if l == 0 else ()) if c in names)
     raise KeyError(l)
 
 
@@ -62,7 +62,7 @@ for l in range(L):
     s = lvl_start(l)
     while s > 0 and names[s - 1].startswith("@"):
         s -= 1
-    e = names.index(f"out{l}") + 1
+    e = [i for i, nm in enumerate(names) if nm == f"out{l}" or nm.startswith(f"out{l}+")][0] + 1
     timed(plan.ops[s:e], f"level {l}")
     timed([o for o in plan.ops[s:e] if not o[0].startswith("@")], f"level {l}, one lane, no events")
 print("---- standalone per-op device time (5 back-to-back launches each)")

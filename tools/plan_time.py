@@ -10,7 +10,7 @@ rng = np.random.RandomState(0)
 state = rng.randint(0, 256, size=(1, 64, 64, 3)).astype(np.uint8); goal = rng.randint(0, 256, size=(1, 64, 64, 3)).astype(np.uint8)
 n = 512
 sampler = SimpleTreeCEMSampler(float("inf"), None, hp4.nz_vae, 1.0, n_level_hierarchy=hp4.hierarchy_levels, device="cuda", seed=1)
-sim, cost = GCPImageSimulator(m4), LearnedCostEstimate(m4)
+sim, cost = GCPImageSimulator(m4, pred_length=False), LearnedCostEstimate(m4)
 planner = CEMPlanner(sim, cost, sampler, n_iters=1, batch_size=n, elite_frac=0.1, max_seq_len=80)
 def T(tag, fn, k=3):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -9,7 +9,7 @@ hp4 = V.config("c4")
 m4 = GCPTreeModel(hp4, params=V.init_params(hp4, seed=0), device="cuda"); m4.eval()
 rng = np.random.RandomState(0)
 state = rng.randint(0, 256, size=(1, 64, 64, 3)).astype(np.uint8); goal = rng.randint(0, 256, size=(1, 64, 64, 3)).astype(np.uint8)
-sim = GCPImageSimulator(m4)
+sim = GCPImageSimulator(m4, pred_length=False)
 for n in (64, 512):
     s = np.random.RandomState(1).randn(n, hp4.n_nodes, hp4.nz_vae).astype(np.float32)
     sim.rollout(state, goal, s, 80); torch.cuda.synchronize()

@@ -271,6 +271,10 @@ TileChoice choose_tile(int M, int N, int nb = 1) {
     TileChoice best{1, 1};
     double best_cost = -1.0, best_bytes = 0.0;
     const long NT = N / 16, RT = (M + 15) / 16;
+    // a problem whose largest blocks already give every SIMD a wavefront is throughput-bound: largest blocks, fewest operand bytes
+    // (the batched merge data gradient, 24576 tiles: <2,2> in six rounds 250 us — the fitted model below underrates how badly small
+    // blocks do once several rounds queue up behind L2)
+    if (M >= 64 && N % 64 == 0 && ((RT + 3) / 4) * (NT / 4) * nb >= simds) return TileChoice{4, 4};
     for (int pi = 0; pi < 3; ++pi)
         for (int ci = 0; ci < 3; ++ci) {
             const int pr = prs[pi], cr = crs[ci];

@@ -884,20 +884,22 @@ class GCPTreeModel:
             nl = hp.n_lstm_layers
             merged = self._buf(f"merged{l}", (M, 2 * nl * H))
 
-            def plan_merge():
-                # split_linear merge of the parents' hidden states (tree_lstm.py:43-48): all 2*n_lstm_layers
+            def plan_merge(lv=l, group=None):
+                # split_linear merge of the parents' hidden states of level lv (tree_lstm.py:43-48): all 2*n_lstm_layers
                 # projections in one launch, blockIdx.z = projection index
-                h1 = self._rowsrc(_addr(Hid), PS * SD, 2 * s * SD, H)
-                h2 = self._rowsrc(_addr(Hid, 2 * s * SD), PS * SD, 2 * s * SD, H)
-                self._gemm(plan, f"merge{l}", [h1, h2], M, H, n, W["proj.w"], W["proj.b"], out=_addr(merged),
-                           ob=n * 2 * nl * H, orow=2 * nl * H, batch=(2 * nl, H, W["proj.w"][0].numel(), H, H))
+                s_, n_ = 2 ** (L - 1 - lv), 2 ** lv
+                Wl = P[f"tree{lv if hp.untied_layers else 0}"]
+                mg = self._buf(f"merged{lv}", (B * n_, 2 * nl * H))
+                h1 = self._rowsrc(_addr(Hid), PS * SD, 2 * s_ * SD, H)
+                h2 = self._rowsrc(_addr(Hid, 2 * s_ * SD), PS * SD, 2 * s_ * SD, H)
+                self._gemm(plan, f"merge{lv}", [h1, h2], B * n_, H, n_, Wl["proj.w"], Wl["proj.b"], out=_addr(mg),
+                           ob=n_ * 2 * nl * H, orow=2 * nl * H, batch=(2 * nl, H, Wl["proj.w"][0].numel(), H, H), group=group)
 
-            # One lane for the whole level.  Measured (tools/fwd_tree_phase.py, c2): the parent-state merge on a side lane (parallel
-            # graph branch) made EVERY level slower than issuing it in line — level 1: 93 vs 73 us, level 6: 323 vs 229 us, the
-            # tree phase 1103 vs 853 us — a cross-queue join costs ~10 us and the big levels are throughput-bound anyway.
+            # One lane for the whole level: the parent-state merge on a side lane (a parallel graph branch) bought nothing — a
+            # cross-queue join costs ~10 us and the big levels are throughput-bound anyway (tools/fwd_tree_phase.py: level 6 323 us
+            # with the side lane, 329 us in line).  Instead the merge of level l + 1, which needs nothing but the hidden states of
+            # level l, shares the launch of level l's `out` Linear while both are in the small-M regime (gcpx_gemm_group).
             side = []
-            if l > 0:
-                plan_merge()
             if has_z:
                 # given latents in depth-first order (tree.py:38); reparametrised with the learned prior (:79-82)
                 g = (_addr(tin["z"], (s - 1) * nv), N * nv, 2 * s * nv) + z_map
@@ -943,8 +945,12 @@ class GCPTreeModel:
                     self._gemm(plan, f"lstm{l}.{i}", [xs, hs], M, 4 * H, n, W[f"lstm{i}.w"], W[f"lstm{i}.b"],
                                epi=rt.EPI_LSTM, lstm=lstm)
                 x = xn
+            g = []
             self._gemm(plan, f"out{l}", [self._rowsrc(x.data_ptr(), n * H, H, H)], M, nz, n, W["out.w"], W["out.b"],
-                       out=_addr(E, nodeoff(nz)), ob=PS * nz, orow=2 * s * nz)
+                       out=_addr(E, nodeoff(nz)), ob=PS * nz, orow=2 * s * nz, group=g)
+            if l + 1 < L:
+                plan_merge(l + 1, group=g)
+            self._gemm_group(plan, f"out{l}+merge{l + 1}" if l + 1 < L else f"out{l}", g)
 
         # ---- latent-space heads: independent of the decoder, run next to it on lane 1 ----
         F = B * N

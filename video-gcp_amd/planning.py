@@ -10,7 +10,10 @@ Reference (paths relative to /root/reference):
 
 Deviations, on purpose:
   * D2 (cem_planner.py:115-122 drops the remainder of `batch_size // max_rollout_bs`): every candidate is evaluated.
-  * D3 (val_mode(pred_length=True) samples a length although end_ind is fed): the rollout length is `rollout_len`.
+  * D3: the reference's rollout runs under `val_mode()` = pred_length=True (cem_simulator.py:29), so the length of every candidate
+    is a DRAW from the length predictor (base_gcp.py:219-226).  `GCPImageSimulator(pred_length=True)` (the default) does the same,
+    with the categorical draw fed as one uniform number per candidate so that sharded ranks agree; `pred_length=False` pins every
+    rollout to `rollout_len` (the fixed-work setting bench.py and the configs[3] tests use).
   * The reference moves every rollout to numpy (~2 GB per 512-candidate call, cem_simulator.py:68-70).  `rollout()` keeps
     that contract; the planner itself uses `rollout_device()` and only the final plan crosses to the host.
   * Multi-GPU: candidates are sharded over ranks; every rank draws the SAME population from a shared
@@ -41,11 +44,12 @@ class GCPImageSimulator:
 
     supports_latent_only = True      # rollout_device(..., decode=False) skips the image decoder
 
-    def __init__(self, model, append_latent=True):
+    def __init__(self, model, append_latent=True, pred_length=True):
         self._model = model
         self._append_latent = append_latent
+        self.pred_length = pred_length
 
-    def rollout_device(self, state, goal_state, samples, rollout_len, decode=True):
+    def rollout_device(self, state, goal_state, samples, rollout_len, decode=True, len_u=None):
         """Device-resident rollout.  state/goal_state: env images [1,H,W,3]; samples [n, N, nz_vae] (depth-first node
         order, tree.py:38).  Returns padded device tensors + lengths.  decode=False: latents only (images = None) — what the
         CEM scoring loop needs; the decoder is 3/4 of the rollout's FLOPs."""
@@ -61,16 +65,18 @@ class GCPImageSimulator:
         z = torch.as_tensor(samples, dtype=torch.float32, device=m.device)
         inp = dict(I_0=I0, I_g=Ig, z=z,
                    end_ind=torch.full((n,), rollout_len - 1, dtype=torch.long, device=m.device))
-        with m.val_mode(pred_length=False, decode=decode):
+        if self.pred_length and len_u is not None:
+            inp["len_u"] = torch.as_tensor(len_u, dtype=torch.float32, device=m.device)
+        with m.val_mode(pred_length=self.pred_length, decode=decode):
             out = m(inp, "train")                    # cem_simulator.py:29-31 (phase defaults to 'train')
         raw = out.raw
         return Outputs(images=raw.get("pruned_padded"), latents=raw["model_enc_seq_padded"], lengths=raw["seq_len"],
                        actions=raw.get("actions_padded"), states=raw.get("regressed_state_padded"),
                        e_goal=raw["E"][:, -1], out=out)
 
-    def rollout(self, state, goal_state, samples, rollout_len, prune=False):
+    def rollout(self, state, goal_state, samples, rollout_len, prune=False, len_u=None):
         """Reference contract (cem_simulator.py:14-43): lists of numpy arrays, one per candidate."""
-        r = self.rollout_device(state, goal_state, samples, rollout_len)
+        r = self.rollout_device(state, goal_state, samples, rollout_len, len_u=len_u)
         lens = r.lengths.tolist()
         n = len(lens)
         img = r.images.reshape(n, r.images.shape[1], -1)
@@ -155,6 +161,10 @@ class FlatCEMSampler:
         raw = self.mean[None] + self.std[None] * eps
         return raw.clamp(-self._clip_val, self._clip_val) if np.isfinite(self._clip_val) else raw
 
+    def sample_uniform(self, n_samples):
+        """one uniform number per candidate from the sampler's own (rank-shared) stream: the length draw of a rollout"""
+        return torch.rand(n_samples, device=self.device, generator=self._gen)
+
     def fit(self, data, scores=None):
         self.mean = data.mean(0)                                    # np.mean / np.std(axis=0), sampler.py:44-46
         self.std = data.std(0, unbiased=False)
@@ -200,7 +210,11 @@ class CEMPlanner:
         """costs [n] of all candidates: this rank rolls out its slice, one all-gather assembles the vector."""
         lo, per = self._shard(samples.shape[0])
         if getattr(self._sim, "supports_latent_only", False):
-            r = self._sim.rollout_device(state, goal_state, samples[lo:lo + per], self.max_seq_len, decode=self.decode_candidates)
+            kw = {}
+            if getattr(self._sim, "pred_length", False) and hasattr(self._sampler, "sample_uniform"):
+                # every rank draws the population's length numbers from the shared stream and keeps its slice
+                kw["len_u"] = self._sampler.sample_uniform(samples.shape[0])[lo:lo + per]
+            r = self._sim.rollout_device(state, goal_state, samples[lo:lo + per], self.max_seq_len, decode=self.decode_candidates, **kw)
         else:                                            # any simulator with the reference's interface
             r = self._sim.rollout_device(state, goal_state, samples[lo:lo + per], self.max_seq_len)
         local = self._cost.sequence_cost_device(r.latents, r.lengths, r.e_goal if self.goal_in_cost else None)
@@ -219,7 +233,10 @@ class CEMPlanner:
             self._sampler.fit(best_samples, best_scores)
             self.logs.append(Outputs(elite_scores=best_scores.clone(), mean_score=scores.mean()))
         # final rollout of the best candidate (cem_planner.py:81-96); every rank computes it (tiny batch)
-        final = self._sim.rollout(state, goal_state, best_samples[:1].cpu().numpy(), self.max_seq_len)
+        kw = {}
+        if getattr(self._sim, "pred_length", False) and hasattr(self._sampler, "sample_uniform"):
+            kw["len_u"] = self._sampler.sample_uniform(1)             # the plan's own length draw, from the rank-shared stream
+        final = self._sim.rollout(state, goal_state, best_samples[:1].cpu().numpy(), self.max_seq_len, **kw)
         actions = final.actions[0] if final.actions is not None else None
         return final.predictions[0], actions, final.latents[0], float(best_scores[0])
 

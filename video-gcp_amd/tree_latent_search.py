@@ -203,7 +203,14 @@ class DeviceHierarchicalTreeLatentOptimizer(ImageHierarchicalTreeLatentOptimizer
     def optimize(self, rollout, goal=None):
         """rollout: Outputs(latents [n, T, nz] device, lengths (device int32 or list), images [n, T, ...] or None)"""
         import torch
-        self._lat = rollout.latents
+        lat = rollout.latents
+        # one extra row holds the reference's stand-in for a rollout too short to split, [inf, 0, inf] (tree_optimizer.py:151-156)
+        dummy = torch.zeros(1, lat.shape[1], lat.shape[2], device=lat.device)
+        dummy[0, 0] = float("inf")
+        if lat.shape[1] > 2:
+            dummy[0, 2] = float("inf")
+        self._lat = torch.cat([lat, dummy])
+        self._dummy = lat.shape[0]
         lens = rollout.lengths.tolist() if torch.is_tensor(rollout.lengths) else list(rollout.lengths)
         self._rollout = rollout
         views = [(i, 0, l) for i, l in enumerate(lens)]
@@ -276,14 +283,18 @@ class DeviceHierarchicalTreeLatentOptimizer(ImageHierarchicalTreeLatentOptimizer
         results = []
         for cl, cr, group in zip(lv.left, lv.right, np.array_split(np.arange(len(views)), lv.n_samples)):
             group = [views[j] for j in group]
-            short = [v for v in group if v[2] - v[1] < 3]
-            if short:
-                raise NotImplementedError("rollouts shorter than 3 frames inside the hierarchy: use the numpy optimizer")
+            short = [v for v in group if v[2] - v[1] < 3]                # nothing left to expand hierarchically
+            group = [v if v[2] - v[1] >= 3 else (self._dummy, 0, 3) for v in group]
             cut = [(b - a) // 2 for _, a, b in group]
             i0, a0, _ = group[0]
             subgoal = (i0, a0 + cut[0])
             lr, lc = self._dopt(cl, [(i, a, a + c) for (i, a, b), c in zip(group, cut)], subgoal)
             rr, rc = self._dopt(cr, [(i, a + c, b) for (i, a, b), c in zip(group, cut)], goal)
-            results.append((lr + rr, lc + rc))
+            best, cost = lr + rr, lc + rc
+            if short:
+                sb, sc, _ = self._dbest_segment(short, goal)
+                if sc < cost or np.isnan(cost):
+                    best, cost = sb, sc
+            results.append((best, cost))
         k = int(np.argmin(np.array([c for _, c in results])))
         return results[k]
