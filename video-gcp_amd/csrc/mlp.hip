@@ -15,7 +15,10 @@
 namespace {
 
 // one workgroup = 16 rows (block bx) of one Predictor; by / ny: this workgroup's share of the head's column tiles
-template <int MID>
+// LEAN: the launch brings more workgroups than CUs, so it is throughput-bound: smaller load sets and no cross-layer weight prefetch
+// keep the kernel at <= 128 registers (two workgroups per CU) instead of 256 (one) — prior + posterior at 1024 rows ran 49 us with
+// the deep pipeline (512 workgroups, two rounds) against 20 us at 16 rows.
+template <int MID, bool LEAN>
 __device__ __forceinline__ void mlp_rows(const gcpx_mlp_args& a, const int bx, const int by, const int ny, float* hid) {
     constexpr int NTM = MID / 16;                    // column tiles of a hidden layer
     constexpr int NW = NTM >= 4 ? 4 : NTM;           // wavefronts that own hidden-layer tiles
@@ -47,7 +50,7 @@ __device__ __forceinline__ void mlp_rows(const gcpx_mlp_args& a, const int bx, c
             for (int t = 0; t < TPW; ++t) w[kg][t] = wbase[(kg * NTM + t) * 64];
     };
     float4 wA[NTM][TPW], wB[NTM][TPW];
-    if (owner && a.n_mid > 0) load_hidden(0, wA);
+    if (!LEAN && owner && a.n_mid > 0) load_hidden(0, wA);
 
     // ---- input layer: gathered global sources ----
     if (owner) {
@@ -71,7 +74,7 @@ __device__ __forceinline__ void mlp_rows(const gcpx_mlp_args& a, const int bx, c
             // Every load of this layer is independent of the MFMAs, and one workgroup is all there is on its CU: what bounds the
             // layer is the number of DEPENDENT global round trips.  Sets of UKI k-groups in ping-pong (explicit register sets): the
             // loads of one set are in flight during the MFMAs of the other (in_dim = 384: 3 sets instead of 6 serial batches).
-            constexpr int UKI = 8;
+            constexpr int UKI = LEAN ? 4 : 8;
             auto load_set = [&](const int kg, float4 (&b)[UKI], float4 (&w)[UKI][TPW]) {
 #pragma unroll
                 for (int u = 0; u < UKI; ++u) {
@@ -136,7 +139,8 @@ __device__ __forceinline__ void mlp_rows(const gcpx_mlp_args& a, const int bx, c
             float4 b[NTM];
 #pragma unroll
             for (int kg = 0; kg < NTM; ++kg) b[kg] = *reinterpret_cast<const float4*>(hin + j * PITCH + kg * 16 + q * 4);
-            if (l + 1 < a.n_mid) load_hidden(l + 1, wnext);
+            if constexpr (LEAN) load_hidden(l, w);
+            else if (l + 1 < a.n_mid) load_hidden(l + 1, wnext);
 #pragma unroll
             for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -176,9 +180,13 @@ __device__ __forceinline__ void mlp_rows(const gcpx_mlp_args& a, const int bx, c
         cur ^= 1;
         __syncthreads();
     };
-    for (int l = 0; l < a.n_mid; l += 2) {
-        hidden(l, wA, wB);
-        if (l + 1 < a.n_mid) hidden(l + 1, wB, wA);
+    if constexpr (LEAN) {
+        for (int l = 0; l < a.n_mid; ++l) hidden(l, wA, wA);
+    } else {
+        for (int l = 0; l < a.n_mid; l += 2) {
+            hidden(l, wA, wB);
+            if (l + 1 < a.n_mid) hidden(l + 1, wB, wA);
+        }
     }
 
     // ---- head: mid -> out; column tiles are dealt round-robin to (blockIdx.y, wave) ----
@@ -265,23 +273,23 @@ __device__ __forceinline__ void mlp_rows(const gcpx_mlp_args& a, const int bx, c
     }
 }
 
-template <int MID>
-__global__ void __launch_bounds__(256) mlp_kernel(const gcpx_mlp_args a) {
+template <int MID, bool LEAN>
+__global__ void __launch_bounds__(256, LEAN ? 2 : 1) mlp_kernel(const gcpx_mlp_args a) {
     __shared__ float4 hid4[2 * 16 * (MID + 4) / 4];
-    mlp_rows<MID>(a, blockIdx.x, blockIdx.y, gridDim.y, reinterpret_cast<float*>(hid4));
+    mlp_rows<MID, LEAN>(a, blockIdx.x, blockIdx.y, gridDim.y, reinterpret_cast<float*>(hid4));
 }
 
 // several Predictors in ONE launch (the prior next to the posterior of a tree level; the latent-space heads): independent
 // problems, so what used to be parallel graph branches or a chain of ~20 us launches is one kernel boundary.
 // dims[p] = {first block, row blocks gx, head splits gy}; blocks of problem p are (bx, by) = (local % gx, local / gx).
-template <int MID>
-__global__ void __launch_bounds__(256) mlp_group_kernel(const gcpx_mlp_args* __restrict__ tab, const int4* __restrict__ dims, const int n) {
+template <int MID, bool LEAN>
+__global__ void __launch_bounds__(256, LEAN ? 2 : 1) mlp_group_kernel(const gcpx_mlp_args* __restrict__ tab, const int4* __restrict__ dims, const int n) {
     __shared__ float4 hid4[2 * 16 * (MID + 4) / 4];
     int p = 0;
     while (p + 1 < n && (int)blockIdx.x >= dims[p + 1].x) ++p;
     const int4 d = dims[p];
     const int local = blockIdx.x - d.x;
-    mlp_rows<MID>(tab[p], local % d.y, local / d.y, d.z, reinterpret_cast<float*>(hid4));
+    mlp_rows<MID, LEAN>(tab[p], local % d.y, local / d.y, d.z, reinterpret_cast<float*>(hid4));
 }
 
 int mlp_check(const gcpx_mlp_args* a) {
@@ -337,8 +345,12 @@ extern "C" int gcpx_mlp_group(const gcpx_mlp_args* dev_table, const int32_t* dev
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(dev_table && dev_dims && n >= 1 && n <= 16 && total_blocks > 0, "bad arguments");
     GCPX_CHECK_ARG((((uintptr_t)dev_dims) & 15) == 0, "dims must be 16-byte aligned");
-    if (mid == 128) hipLaunchKernelGGL(mlp_group_kernel<128>, dim3(total_blocks), dim3(256), 0, stream, dev_table, reinterpret_cast<const int4*>(dev_dims), n);
-    else if (mid == 32) hipLaunchKernelGGL(mlp_group_kernel<32>, dim3(total_blocks), dim3(256), 0, stream, dev_table, reinterpret_cast<const int4*>(dev_dims), n);
+    const bool lean = total_blocks > gcpx_conv_grid() / 2;          // more workgroups than CUs
+    const int4* dd = reinterpret_cast<const int4*>(dev_dims);
+    if (mid == 128 && lean) hipLaunchKernelGGL((mlp_group_kernel<128, true>), dim3(total_blocks), dim3(256), 0, stream, dev_table, dd, n);
+    else if (mid == 128) hipLaunchKernelGGL((mlp_group_kernel<128, false>), dim3(total_blocks), dim3(256), 0, stream, dev_table, dd, n);
+    else if (mid == 32 && lean) hipLaunchKernelGGL((mlp_group_kernel<32, true>), dim3(total_blocks), dim3(256), 0, stream, dev_table, dd, n);
+    else if (mid == 32) hipLaunchKernelGGL((mlp_group_kernel<32, false>), dim3(total_blocks), dim3(256), 0, stream, dev_table, dd, n);
     else {
         gcpx_set_error("gcpx_mlp_group: unsupported mid=%d (128 or 32)", mid);
         return GCPX_ERR_UNSUPPORTED;
@@ -353,8 +365,11 @@ extern "C" int gcpx_mlp(const gcpx_mlp_args* a, void* stream_) {
     if (st != GCPX_OK) return st;
     int gx, gy;
     mlp_grid(a, &gx, &gy);
-    if (a->mid == 128) hipLaunchKernelGGL(mlp_kernel<128>, dim3(gx, gy), dim3(256), 0, stream, *a);
-    else if (a->mid == 32) hipLaunchKernelGGL(mlp_kernel<32>, dim3(gx, gy), dim3(256), 0, stream, *a);
+    const bool lean = gx * gy > gcpx_conv_grid() / 2;               // more workgroups than CUs
+    if (a->mid == 128 && lean) hipLaunchKernelGGL((mlp_kernel<128, true>), dim3(gx, gy), dim3(256), 0, stream, *a);
+    else if (a->mid == 128) hipLaunchKernelGGL((mlp_kernel<128, false>), dim3(gx, gy), dim3(256), 0, stream, *a);
+    else if (a->mid == 32 && lean) hipLaunchKernelGGL((mlp_kernel<32, true>), dim3(gx, gy), dim3(256), 0, stream, *a);
+    else if (a->mid == 32) hipLaunchKernelGGL((mlp_kernel<32, false>), dim3(gx, gy), dim3(256), 0, stream, *a);
     else {
         gcpx_set_error("gcpx_mlp: unsupported mid=%d (128 or 32)", a->mid);
         return GCPX_ERR_UNSUPPORTED;

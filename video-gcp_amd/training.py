@@ -207,11 +207,15 @@ class GCPTrainStep:
         lib, m = self.m.lib, self.m
         groups, rest, cand = {}, [], []
         v, nb = C.c_int32(), C.c_int32()
+        produced = set()          # tags that already have a non-wgrad op queued: a weight gradient of that tag reads its output
+        tag_of = lambda nm: nm.split(":", 1)[1] if ":" in nm else nm
         for op in deferred:
             name, fn, args = op
             a = args[0]._obj if fn is lib.gcpx_wgrad else None
-            if a is None:
+            if a is None or tag_of(name) in produced:
                 rest.append(op)
+                if name.startswith(("bw.act:", "bw.im2col:", "bw.stage:")):
+                    produced.add(tag_of(name))
             else:
                 cand.append((name, a))
         # the in-workgroup row split exists to fill the chip from ONE small problem; a group that already brings >= 1 workgroup
@@ -933,9 +937,12 @@ class GCPTrainStep:
         a.add = dskip[0].data_ptr() if 0 in dskip else None
         a.ldc, a.c_off, a.up, a.fsum, a.act, a.F, a.H, a.W, a.C = ngf, 0, 0, 1, rt.ACT_LRELU, F, res, res, ngf
         plan.keep.append(a)
-        plan.add(f"bw.act:{tag}.input", lib.gcpx_act_bwd, C.byref(a))
+        # the first layer has no data gradient to pass on (its input is the image): its activation backward and the im2col of the
+        # image only feed the weight / bias gradient, so they leave the critical lane together with them (same tag = same side lane,
+        # in order)
+        self._side(plan, f"bw.act:enc.input:{tag}", lib.gcpx_act_bwd, C.byref(a))
         col = buf(f"bw.{tag}.col", (F * res * res, 48))
-        plan.add(f"bw.im2col:{tag}", lib.gcpx_im2col_image, er["x_ptr"], col.data_ptr(), F, S, S)
+        self._side(plan, f"bw.im2col:enc.input:{tag}", lib.gcpx_im2col_image, er["x_ptr"], col.data_ptr(), F, S, S)
         R = F * res * res
         self._wgrad(plan, f"enc.input:{tag}", du0.data_ptr(), ngf, R, ngf, col.data_ptr(), 48, self.g("encoder.net.input.conv.weight"),
                     ldw=48, sr=48, sb=R * 48, rpb=R)
