@@ -173,10 +173,29 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
     res = {}
     k = max(3, min(args.steps, 10))
     model.set_timed_op(None)
+
+    def agree(ok):
+        """Every block first builds its model / trainer and runs one un-timed call WITHOUT collectives; the ranks then agree
+        (all-reduce MIN of a flag) whether to enter the timed region, which contains collectives: a rank that failed in set-up
+        (out of memory, a status error) must not leave the others waiting in an all-reduce."""
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def setup(fn):
+        try:
+            return fn(), None
+        except Exception as e:  # noqa: BLE001
+            return None, repr(e)[:300]
+
     try:
         from video_gcp_amd.training import GCPTrainStep
-        tr = GCPTrainStep(model, process_group=(dist.group.WORLD if world > 1 else None))
         full = {k_: v.to(dev) for k_, v in inputs.items()}
+        tr, err = setup(lambda: GCPTrainStep(model, process_group=(dist.group.WORLD if world > 1 else None)))
+        if not agree(err is None):
+            raise RuntimeError(err or "set-up failed on another rank")
         dt = _timed(lambda: tr.step(full, dnoise), k, 2, world, dev)
         res["train_step"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
                              "ms_per_step": round(1e3 * dt, 3), "workload": "configs[2] shard: forward + ELBO losses + backward + "
@@ -197,6 +216,9 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
         sampler = SimpleTreeCEMSampler(float("inf"), None, hp4.nz_vae, 1.0, n_level_hierarchy=hp4.hierarchy_levels, device=dev, seed=1)
         planner = CEMPlanner(GCPImageSimulator(m4, pred_length=False), LearnedCostEstimate(m4), sampler, n_iters=1, batch_size=n, elite_frac=0.1,
                              max_seq_len=hp4.max_seq_len)
+        _, err = setup(lambda: m4.encode(torch.zeros(1, 3, hp4.img_sz, hp4.img_sz, device=dev)))
+        if not agree(err is None):
+            raise RuntimeError(err or "set-up failed on another rank")
 
         def it():
             s = sampler.sample(n)
@@ -227,12 +249,17 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
         i5, n5, _ = make_inputs(hp5, seed=200 + rank, variant="A")
         d5 = {k_: v.to(dev) for k_, v in i5.items()}
         n5 = n5.to(dev)
+        _, err = setup(lambda: m5(d5, "train", noise=n5))
+        if not agree(err is None):
+            raise RuntimeError(err or "set-up failed on another rank")
         dt = _timed(lambda: m5(d5, "train", noise=n5), k, 2, world, dev)
         res["adaptive_forward"] = {"value": round(world * hp5.batch_size * hp5.max_seq_len / dt, 1), "unit": "frames/s",
                                    "ms_per_step": round(1e3 * dt, 3), "workload": "configs[4] shard: adaptive (soft-DTW) binding + "
                                    "attentive inference forward with losses, 64x64, seq_len 200, L=8 (255 nodes), batch 8/GPU"}
         from video_gcp_amd.training import GCPTrainStep
-        tr5 = GCPTrainStep(m5, process_group=(dist.group.WORLD if world > 1 else None))
+        tr5, err = setup(lambda: GCPTrainStep(m5, process_group=(dist.group.WORLD if world > 1 else None)))
+        if not agree(err is None):
+            raise RuntimeError(err or "set-up failed on another rank")
         dt = _timed(lambda: tr5.step(d5, n5), max(3, k // 2), 2, world, dev)
         res["adaptive_train_step"] = {"value": round(world * hp5.batch_size * hp5.max_seq_len / dt, 1), "unit": "frames/s",
                                       "ms_per_step": round(1e3 * dt, 3), "workload": "configs[4] shard: forward + losses + backward "
@@ -334,7 +361,7 @@ def main():
     from video_gcp_amd import dist as D
     if args.gpus > 1:
         assert int(os.environ["WORLD_SIZE"]) == args.gpus, f"WORLD_SIZE={os.environ['WORLD_SIZE']} but --gpus {args.gpus}"
-        rank, local_rank, world = D.init_from_env(args.backend)      # "nccl" is RCCL on ROCm
+        rank, local_rank, world = D.init_from_env(args.backend, timeout_s=300)      # "nccl" is RCCL on ROCm
     else:
         rank, local_rank, world = 0, 0, 1
         torch.cuda.set_device(0)

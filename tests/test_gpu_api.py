@@ -165,3 +165,23 @@ def test_top_of_n_evaluation_matches_oracle(setup):
     assert np.array_equal(res["best"], np.argmin(want[..., 0], 1))
     summary = ev.dump_metrics()
     assert set(summary) == {"mse", "psnr", "ssim"} and all(len(v) == 3 for v in summary.values())
+
+
+def test_decoder_nll_and_binding_handles(setup):
+    """`self.decoder.nll(estimates, targets, weights)` as BalancedBinding.reconstruction_loss calls it (frame_binding.py:88-99) and the
+    binding's integer helpers (frame_binding.py:52-65)"""
+    hp, sd, model = setup
+    model.train(True)
+    inputs, noise, _ = make_inputs(hp, seed=12, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    out = model(dev_in, "train", noise=noise.cuda())
+    losses = model.loss(dev_in, out)
+    got = model.decoder.nll(out.raw["matched_distr_kernel_order"], dev_in["traj_seq"], dev_in["pad_mask"], log_error_arr=True)
+    torch.cuda.synchronize()
+    assert abs(float(got.dense_img_rec.value) - float(losses.dense_img_rec.value)) <= 1e-6 * abs(float(losses.dense_img_rec.value))
+    assert got.dense_img_rec.error_mat.shape == (hp.batch_size, hp.max_seq_len)
+    model.eval()
+    lo, hi = model.tree_module.binding.get_init_inds(out)
+    assert torch.equal(lo.cpu(), torch.full((hp.batch_size, 1), -1)) and torch.equal(hi.cpu(), inputs["end_ind"][:, None] + 1)
+    t = model.tree_module.binding.comp_timestep(torch.tensor([-1, -1, 3]), torch.tensor([0, 4, 8]))
+    assert t.tolist() == [0, 1, 5]                                  # (-1 + 0) / 2 truncates to 0 under torch 1.3, not to -1

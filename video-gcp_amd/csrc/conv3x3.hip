@@ -241,11 +241,7 @@ conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty, const int n
                     const float wx1 = (cx & 1) ? 0.75f : 0.25f, wx0 = 1.f - wx1;
                     const float wy1 = (ry & 1) ? 0.75f : 0.25f, wy0 = 1.f - wy1;
                     const float* r = raw + ((fl * LH + (ry >> 1)) * LW + (cx >> 1)) * CC + c4 * 4;
-#ifdef GCPX_ABLATE_NOUPSAMPLE
-                    float4 v = *reinterpret_cast<const float4*>(r);
-#else
                     float4 v = lerp4(r, wx1, wx0, wy1, wy0);
-#endif
                     const bool zero = (top && ry == 0) || (bot && ry == RH - 1);
                     if (zero) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     *reinterpret_cast<float4*>(hi + ((fl * RH + ry) * RW + cx) * CCP + c4 * 4) = v;
@@ -275,9 +271,6 @@ conv3x3_kernel(const gcpx_conv_args a, const int ntx, const int nty, const int n
             // chunks and the packed buffer carries one zero step of padding, so the prefetch never branches.
             const float4* wp = wbase + (size_t)chunk * NSTEP * CT * 64;
             __builtin_amdgcn_s_setprio(1);      // MFMA phase outranks the staging VALU of co-resident workgroups
-#ifdef GCPX_ABLATE_NOMFMA
-            if (a.F < 0)
-#endif
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 const int tapoff = ((tap / 3) * RW + (tap % 3)) * CCP;
@@ -1114,11 +1107,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_up16_kernel(const gcpx_conv_ar
                     if (zero) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     *reinterpret_cast<float4*>(hi + (ry * RW + cx) * CCP + c4 * 4) = v;
                 };
-#ifndef GCPX_ABLATE_NOUPSAMPLE
 #pragma unroll
                 for (int ry = 0; ry < RH; ++ry)
                     lerp_store(ry, p + 1, (top && ry == 0) || (bot && ry == RH - 1));
-#endif
                 if (p < 12) {                                               // the two halo columns: 6 rows x 2 sides
                     const int ry = p >> 1, side = p & 1;
                     lerp_store(ry, side ? RW - 1 : 0,
@@ -1128,9 +1119,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_up16_kernel(const gcpx_conv_ar
             // ---- MFMAs: 9 taps x 4 pixel groups x 4 k-steps ----
             const float4* wp = wl + chunk * 9 * 64 + lane;
             __builtin_amdgcn_s_setprio(1);
-#ifdef GCPX_ABLATE_NOMFMA
-            if (a.F < 0)
-#endif
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int tapoff = ((tap / 3) * RW + (tap % 3)) * CCP;

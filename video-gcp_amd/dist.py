@@ -10,8 +10,9 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Returns (rank, local_rank, world).  Initialises the default process group when WORLD_SIZE > 1."""
+def init_from_env(backend=None, timeout_s=None):
+    """Returns (rank, local_rank, world).  Initialises the default process group when WORLD_SIZE > 1.  timeout_s: collective
+    timeout (a rank that dies mid-collective then fails the others after that long instead of after the 10-minute default)."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -24,6 +25,9 @@ def init_from_env(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=timeout_s)
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 

@@ -35,10 +35,53 @@ class DecoderHandle:
     def __init__(self, model):
         self.m = model
 
+    def nll(self, estimates, targets, weights=1, log_error_arr=False):
+        """DecoderModule.nll(estimates, targets, weights) as BalancedBinding.reconstruction_loss calls it (frame_binding.py:88-99):
+        `estimates` = the matched distribution parameters in the head kernel's slot order ([B, T, H, W, 112] — what the training
+        forward keeps as `out.raw['matched_distr_kernel_order']`), `targets` [B, T, 3, H, W], `weights` broadcastable [B, T].
+        Returns Outputs(dense_img_rec=Outputs(value, weight)) with value = sum over frames and pixels / B (+ `error_mat` [B, T])."""
+        from .model import Outputs
+        m, hp = self.m, self.m._hp
+        est = torch.as_tensor(estimates).to(m.device, torch.float32).contiguous()
+        tgt = torch.as_tensor(targets).to(m.device, torch.float32).contiguous()
+        B, T = tgt.shape[:2]
+        S = hp.img_sz
+        w = torch.ones(B, T, device=m.device) * torch.as_tensor(weights, dtype=torch.float32, device=m.device)
+        nll_bt = torch.empty(B, T, device=m.device)
+        st = torch.cuda.current_stream(m.device).cuda_stream
+        rt.check(m.lib.gcpx_dlm_nll(est.data_ptr(), tgt.data_ptr(), w.contiguous().data_ptr(), nll_bt.data_ptr(), B * T, S * S, m._head_pitch,
+                                    hp.n_mixtures, st), "dlm_nll")
+        res = Outputs(dense_img_rec=Outputs(value=(nll_bt * w).sum() / B, weight=hp.dense_img_rec_weight))
+        if log_error_arr:
+            res.dense_img_rec.error_mat = nll_bt
+        return res
+
     def decode_seq(self, inputs, enc):
         """DecoderModule.decode_seq(inputs, enc [B, N, nz_enc(,1,1)]): the skips of inputs['I_0'] (or inputs['skips'] from
         `model.encoder`) are broadcast over the N latents of a sequence.  Returns Outputs(images [B, N, 3, H, W])."""
         return self.m._decode_seq(inputs, enc)
+
+
+class BindingHandle:
+    """`model.tree_module.binding` (BalancedBinding, frame_binding.py:37-65) as far as callers outside the forward use it"""
+
+    def __init__(self, model):
+        self.m = model
+
+    def get_init_inds(self, outputs):
+        """frame_binding.py:62-65: the timesteps of the two virtual root parents, (-1, end_ind + 1), int64 [B, 1]"""
+        e = outputs.end_ind if hasattr(outputs, "end_ind") else outputs["end_ind"]
+        return torch.zeros_like(e[:, None]) - 1, e[:, None] + 1
+
+    @staticmethod
+    def comp_timestep(t_l, t_r):
+        """frame_binding.py:52-54 under the torch 1.3 the reference pins: Long / Long truncates toward zero"""
+        return torch.div(t_l + t_r, 2, rounding_mode="trunc")
+
+
+class TreeModuleHandle:
+    def __init__(self, model):
+        self.binding = BindingHandle(model)
 
 
 class InverseModelHandle:

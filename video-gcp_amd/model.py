@@ -162,6 +162,7 @@ class GCPTreeModel:
         # sub-module handles under the reference's attribute names (planner_policy.py:225-227, tree_dense_rec.py:13-40)
         from . import handles as Hd
         self.encoder, self.decoder, self.dense_rec = Hd.EncoderHandle(self), Hd.DecoderHandle(self), Hd.DenseRecHandle(self)
+        self.tree_module = Hd.TreeModuleHandle(self)
         if hp.attach_inv_mdl:
             self.inv_mdl = Hd.InverseModelHandle(self)
         if hp.attach_cost_mdl:
