@@ -189,3 +189,30 @@ def test_rollout_with_predicted_lengths_matches_oracle(setup):
         plan, actions, latents, score = planner(state, goal)
         res.append((plan, score))
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and np.isfinite(res[0][1])
+
+
+def test_image_cem_policy_closed_loop(setup):
+    """ImageCEMPolicy.act (planner_policy.py:89-113,216-227): plans on the first call, re-plans on the interval, and in closed-loop
+    execution re-infers every action with the inverse model from the current image and the next planned latent"""
+    from oracle import gcp_model_oracle as O
+    from video_gcp_amd.planning import GCPImageSimulator, LearnedCostEstimate, SimpleTreeCEMSampler, CEMPlanner, ImageCEMPolicy, env2planner
+    hp, sd, model = setup
+    rng = np.random.RandomState(9)
+    frames = rng.randint(0, 256, size=(4, 1, hp.img_sz, hp.img_sz, 3)).astype(np.uint8)
+    goal = rng.randint(0, 256, size=(1, hp.img_sz, hp.img_sz, 3)).astype(np.uint8)
+    sampler = SimpleTreeCEMSampler(float("inf"), None, hp.nz_vae, 1.0, n_level_hierarchy=hp.hierarchy_levels, device="cuda", seed=5)
+    planner = CEMPlanner(GCPImageSimulator(model, pred_length=False), LearnedCostEstimate(model), sampler, n_iters=1, batch_size=8,
+                         elite_frac=0.25, max_seq_len=hp.max_seq_len)
+    policy = ImageCEMPolicy(model, planner, replan_interval=2, num_max_replans=10, closed_loop_execution=True)
+    acts = []
+    for t in range(3):
+        acts.append(policy.act(t=t, i_tr=0, images=frames[:t + 1], goal_image=goal).actions)
+    assert policy.num_replans == 2 and policy.current_exec_step == 1       # planned at t = 0 and t = 2
+    assert all(a.shape == (hp.n_actions,) for a in acts)
+    # the last action against the oracle: inverse model on (encoder(current frame), planned latent 1)
+    e0, _ = O.encoder(sd, hp, env2planner(frames[2]), training=False)
+    want = O.predictor(sd, "inv_mdl.action_pred", hp, e0[:, :, 0, 0], torch.as_tensor(policy.latent_plan[1][None]))
+    assert_close(acts[2], want[0], 5e-5, 1e-4, "closed-loop action")
+    policy.closed_loop_execution = False
+    a = policy.act(t=3, i_tr=0, images=frames, goal_image=goal).actions
+    assert np.array_equal(a, policy.action_plan[1])

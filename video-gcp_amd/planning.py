@@ -328,3 +328,53 @@ class HierarchicalCEMPlanner:
     @property
     def fully_optimized(self):
         return self._sampler.fully_optimized
+
+
+class ImageCEMPolicy:
+    """ImageCEMPolicy / CEMPolicy / PlannerPolicy (planner_policy.py:13-241) without the agent infrastructure: plan with the CEM
+    planner when there is no plan, the plan is used up, or the re-planning interval comes round (`act`, :89-113); follow the plan
+    open loop through its inverse-model actions or closed loop by re-inferring each action from the current image and the next
+    planned latent (`_infer_action`, :222-227: `model.encoder(img)[0][:, :, 0, 0]` -> `model.inv_mdl.run_single`)."""
+
+    def __init__(self, model, planner, replan_interval=1, num_max_replans=10, closed_loop_execution=False):
+        self.planner_model, self._cem_planner = model, planner
+        self.replan_interval, self.num_max_replans, self.closed_loop_execution = replan_interval, num_max_replans, closed_loop_execution
+        self.reset()
+
+    def reset(self):
+        self.current_exec_step = None
+        self.image_plan = self.action_plan = self.latent_plan = None
+        self.plan_cost = None
+        self.num_replans = 0
+
+    def act(self, t=None, i_tr=None, state=None, images=None, goal_image=None):
+        """images: the frames executed so far [t+1, 1, H, W, 3] or [t+1, H, W, 3] (env format); goal_image [1, H, W, 3]"""
+        imgs = np.asarray(images)
+        if imgs.ndim == 5:
+            imgs = imgs[:, 0]
+        if self.image_plan is None or self.image_plan.shape[0] - 1 <= self.current_exec_step \
+                or (t % self.replan_interval == 0 and self.num_replans < self.num_max_replans):
+            self._plan(imgs[t][None], goal_image, t)
+            self.num_replans += 1
+        out = Outputs(actions=self.get_action(imgs[t]))
+        self.current_exec_step += 1
+        return out
+
+    def _plan(self, state, goal, step):
+        self.image_plan, self.action_plan, self.latent_plan, self.plan_cost = self._cem_planner(state, goal)
+        self.current_exec_step = 0
+
+    def get_action(self, current_image):
+        if self.closed_loop_execution:
+            return self._infer_action(current_image, self.latent_plan[self.current_exec_step + 1])
+        assert self.action_plan is not None          # need to attach inverse model to planner to get actions!
+        if self.action_plan.size < 1:
+            return 0.05 * np.random.rand(2, )
+        return self.action_plan[self.current_exec_step]
+
+    def _infer_action(self, current_img, target_latent):
+        m = self.planner_model
+        img = env2planner(np.asarray(current_img)[None]).to(m.device)
+        enc_img0 = m.encoder(img)[0][:, :, 0, 0]
+        tl = torch.as_tensor(np.asarray(target_latent)[None], dtype=torch.float32, device=m.device)
+        return m.inv_mdl.run_single(enc_img0, tl)[0].cpu().numpy()
