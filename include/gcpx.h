@@ -89,7 +89,11 @@ typedef struct gcpx_conv_args {
                                Optional accelerator for the plain 3x3 conv: the kernel then walks the rows that exist instead of
                                testing every frame, and zero-fills the frames whose src_row_map entry is negative up front */
     int32_t n_src_rows;
-    int32_t _pad0;
+    int32_t w_split_log2;   /* with wpk_split: the power of two the packed weights were scaled by (the kernel undoes it) */
+    const void* wpk_split;  /* dev or NULL: the same weights as two f16 pieces in 16x16x32 fragment order
+                               (packing.pack_dlm_head_split / pack_conv3x3_split).  When set, kernels that have a split-f16 form run
+                               it: f32-equivalent results (error of the order of one f32 rounding per product) on the f16 matrix
+                               pipes, see csrc/conv3x3_split.hip.  NULL selects the exact f32 MFMA kernels */
 } gcpx_conv_args;
 
 /* decoder block: (bilinear x2 upsample +) 3x3 conv, pad 1.  gcpx_conv3x3_grid(a) = number of workgroups that launch

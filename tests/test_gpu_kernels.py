@@ -214,9 +214,11 @@ def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes):
     assert_close(s[1], (want ** 2).sum((0, 2, 3)), atol=2e-2, rtol=1e-4, name="stats sumsq")
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("S,Fr", [(32, 3), (64, 2)])
-def test_conv3x3_head_dlm(env, S, Fr):
-    """output head: 16 -> 100 channels; raw parameters (kernel order) + fused mixture mean vs the oracle's formulas."""
+def test_conv3x3_head_dlm(env, S, Fr, split):
+    """output head: 16 -> 100 channels; raw parameters (kernel order) + fused mixture mean vs the oracle's formulas.
+    split: the split-f16 kernel (csrc/conv3x3_split.hip) in place of the exact f32 MFMA kernel, same tolerances."""
     rt, pk, lib, dev = env
     from oracle import gcp_model_oracle as O
     from video_gcp_amd import config
@@ -238,6 +240,10 @@ def test_conv3x3_head_dlm(env, S, Fr):
     img = torch.full((Fr, 3, S, S), float("nan"), device=dev)
     a = _conv_args(rt, [(xd, 16, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=S, Win=S, Hout=S, Wout=S, Cout=100,
                    out_pitch=len(perm), upsample=0, head_mode=rt.HEAD_DLM_BOTH, wpk=wp, bias=bk.to(dev), out=raw, images=img)
+    if split:
+        ws, e = pk.pack_conv3x3_split(w, perm)
+        ws = ws.to(dev)
+        a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
     rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head")
     torch.cuda.synchronize()
     slots = torch.nonzero(permt >= 0)[:, 0]
@@ -252,6 +258,60 @@ def test_conv3x3_head_dlm(env, S, Fr):
     rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head mean")
     torch.cuda.synchronize()
     assert torch.equal(img2, img)
+
+
+@pytest.mark.parametrize("case", ["unit", "tiny", "large", "outlier", "zero", "matched_rows"])
+def test_conv3x3_head_split_error_vs_float64(env, case):
+    """The split-f16 head against a float64 conv of the same f32 inputs, next to the exact f32 MFMA kernel: its error is of the same
+    size (three exact f16 x f16 partial products per f32 product, a per-item power-of-two scale) whatever the magnitude of the
+    activations — 1e-3, 300, one 3e4 outlier pixel, all zero — and with the matched-rows map of the training forward."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(11)
+    S, Fr = 64, 3
+    amp = {"unit": 1.0, "tiny": 1e-3, "large": 300.0, "outlier": 1.0, "zero": 0.0, "matched_rows": 1.0}[case]
+    x = torch.randn(Fr, 16, S, S) * amp
+    if case == "outlier":
+        x[1, 3, 17, 40] = 3e4
+    sc, sh = torch.rand(16) + 0.5, torch.randn(16) * 0.2 * amp
+    w, b = torch.randn(100, 16, 3, 3) / 12.0, torch.randn(100) * 0.1
+    xin = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
+    perm = pk.dlm_channel_perm(10)
+    permt = torch.tensor(perm)
+    wp = pk.pack_dlm_head(w, perm).to(dev)
+    ws, e = pk.pack_conv3x3_split(w, perm)
+    ws = ws.to(dev)
+    bk = torch.zeros(len(perm))
+    bk[permt >= 0] = b[permt[permt >= 0]]
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    slots = torch.nonzero(permt >= 0)[:, 0]
+    inv = torch.empty(100, dtype=torch.long)
+    inv[permt[slots]] = slots
+    rows = torch.tensor([1, -1, 0], dtype=torch.int32, device=dev) if case == "matched_rows" else None
+    n_rows = 2 if rows is not None else Fr
+    err, imgs = {}, {}
+    for name in ("f32", "split"):
+        raw = torch.full((n_rows, S, S, len(perm)), float("nan"), device=dev)
+        img = torch.full((Fr, 3, S, S), float("nan"), device=dev)
+        a = _conv_args(rt, [(xd, 16, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=S, Win=S, Hout=S, Wout=S, Cout=100,
+                       out_pitch=len(perm), upsample=0, head_mode=rt.HEAD_DLM_BOTH, wpk=wp, bias=bk.to(dev), out=raw, images=img)
+        if rows is not None:
+            a.raw_row_map = rows.data_ptr()
+        if name == "split":
+            a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+        rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), name)
+        torch.cuda.synchronize()
+        got = raw.cpu().index_select(-1, inv).permute(0, 3, 1, 2).double()
+        want = ref if rows is None else ref[[2, 0]]                  # row 0 <- frame 2, row 1 <- frame 0, frame 1 not stored
+        assert torch.isfinite(got).all() and torch.isfinite(img).all()
+        err[name] = (got - want).abs()
+        imgs[name] = img.cpu()
+    scale = float(ref.abs().max()) + 1e-30
+    # same order as the exact kernel (measured: 0.7x its rms error on unit data), never more than a few f32 roundings of the result
+    assert float(err["split"].pow(2).mean().sqrt()) <= 1.5 * float(err["f32"].pow(2).mean().sqrt()) + 1e-12 * scale
+    assert float(err["split"].max()) <= 2.0 * float(err["f32"].max()) + 4e-7 * scale
+    if case in ("unit", "tiny", "zero", "matched_rows"):
+        assert_close(imgs["split"], imgs["f32"], atol=5e-6, name="mixture mean, split vs exact")
 
 
 @pytest.mark.parametrize("Hin,cin,cout,Fr", [(32, 16, 32, 5), (16, 32, 64, 3), (8, 64, 128, 9), (16, 16, 32, 2)])

@@ -80,3 +80,34 @@ def test_pack_conv4x4_and_image():
     assert q.shape == (12, 1, 64)
     ci, ky, lane = 2, 3, 50
     assert q[ci * 4 + ky, 0, lane] == wi[lane % 16, ci, ky, lane // 16]
+
+
+def test_split_f16_pieces_reconstruct_the_weight():
+    """split_f16: w 2^e = w1 + w2 up to one f32 rounding, the largest magnitude just below the f16 maximum"""
+    torch.manual_seed(3)
+    for amp in (1.0, 1e-4, 50.0):
+        w = torch.randn(64, 16, 3, 3) * amp
+        w1, w2, e = pk.split_f16(w)
+        assert w1.dtype == torch.float16 and w2.dtype == torch.float16
+        ws = w.double() * 2.0 ** e
+        assert 2.0 ** 14 <= float(ws.abs().max()) < 2.0 ** 15
+        rel = ((ws - w1.double() - w2.double()).abs() / ws.abs().clamp_min(1e-300)).max()
+        assert float(rel) <= 2.0 ** -22                       # two 11-bit pieces: 2^-22 worst case, ~2^-24 typical
+        assert torch.isfinite(w1).all() and torch.isfinite(w2).all()
+    w1, w2, e = pk.split_f16(torch.zeros(4, 16, 3, 3))
+    assert e == 0 and not w1.any() and not w2.any()
+
+
+def test_pack_conv3x3_split_layout():
+    """[chunk][5 k-steps][CT][2 pieces][64 lanes][8]: lane (i, q) element el = W[16 ct + i][16 chunk + 8 (q & 1) + el][tap 2 s + (q >> 1)]"""
+    torch.manual_seed(4)
+    w = torch.randn(40, 32, 3, 3)
+    p, e = pk.pack_conv3x3_split(w)
+    assert p.shape == (2, 5, 3, 2, 64, 8) and p.dtype == torch.int16
+    h = p.view(torch.float16).double()
+    rec = (h[:, :, :, 0] + h[:, :, :, 1]) * 2.0 ** -e          # [chunk, s, ct, lane, el]
+    for chunk, s, ct, lane, el in [(0, 0, 0, 0, 0), (1, 2, 1, 37, 5), (0, 4, 2, 17, 3), (1, 4, 0, 40, 1), (0, 3, 2, 63, 7)]:
+        i, q = lane % 16, lane // 16
+        co, ci, tap = 16 * ct + i, 16 * chunk + 8 * (q & 1) + el, 2 * s + (q >> 1)
+        want = float(w[co, ci, tap // 3, tap % 3]) if co < 40 and tap < 9 else 0.0
+        assert abs(float(rec[chunk, s, ct, lane, el]) - want) <= 2.0 ** -22 * abs(want)

@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNELS = {"head": "conv3x3_head_kernel", "up16": "conv3x3_up16_kernel", "conv3x3_tiled": "conv3x3_kernel<", "gemm": "gemm_kernel<",
+KERNELS = {"head": "conv3x3_head", "up16": "conv3x3_up16_kernel", "conv3x3_tiled": "conv3x3_kernel<", "gemm": "gemm_kernel<",
            "mlp": "mlp_kernel<", "enc_lds": "conv4x4s2_lds_kernel", "enc_image": "conv4x4s2_image_kernel"}
 
 

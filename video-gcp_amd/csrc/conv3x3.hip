@@ -1238,6 +1238,8 @@ extern "C" int gcpx_conv_grid(void) {
     return g_conv_grid;
 }
 
+int gcpx_launch_head_split(const gcpx_conv_args* a, hipStream_t stream);      // conv3x3_split.hip
+
 static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool query_only) {
     GCPX_CHECK_ARG(a != nullptr, "null args");
     GCPX_CHECK_ARG(a->nsrc == 1 || a->nsrc == 2, "nsrc must be 1 or 2");
@@ -1259,6 +1261,7 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
             // 100-channel mixture head: 6 full tiles + the 4-channel remainder (weights packed by packing.pack_dlm_head)
             if (a->Cout == 100) {
                 GCPX_CHECK_ARG(!need_out || a->out_pitch >= 100, "mixture head: out_pitch < 100");
+                if (a->wpk_split) return query_only ? gcpx_conv_grid() / 2 : gcpx_launch_head_split(a, stream);
                 return query_only ? gcpx_conv_grid() / 2 : launch_head<6, true>(a, stream);
             }
             if (CT == 1) return query_only ? gcpx_conv_grid() / 2 : launch_head<1, false>(a, stream);

@@ -1,0 +1,343 @@
+// Output head of the decoder on the f16 matrix pipes of gfx950 with f32-equivalent arithmetic ("split-f16").
+//
+// gfx950 has no tf32 / xf32 matrix instruction and runs v_mfma_f32_16x16x4_f32 at 1/16 of the f16 / bf16 MFMA rate.  The exact f32
+// head (conv3x3.hip: conv3x3_head_kernel) is bound by that rate (0.76 of the f32 MFMA peak).  This kernel computes the same 3x3 conv
+// (DecoderModule.decode_seq -> gen_head, /root/reference/gcp/prediction/models/tree/tree_dense_rec.py:42) with both operands
+// split into two f16 pieces and three f16 MFMAs per f32 product:
+//
+//     x = (x1 + x2) / 2^Ex,  x1 = rn16(x 2^Ex),  x2 = rn16(x 2^Ex - x1)        |x 2^Ex - x1 - x2| <= 2^-24 |x 2^Ex|
+//     w = (w1 + w2) / 2^Ew,  likewise (packed on the host, packing.pack_dlm_head_split)
+//     x w 2^(Ex+Ew) ~= x1 w1 + x1 w2 + x2 w1                                     (x2 w2 <= 2^-24 |x w| is dropped)
+//
+// every partial product is exact in the f32 accumulator, so the result differs from the exact product by <= ~3 * 2^-24 |x w| —
+// the size of one f32 rounding.  Ex is chosen PER ITEM from the largest staged activation (a power of two: scaling and unscaling
+// are exact), which pins the pieces in the normal f16 range whatever the magnitude of the data: no overflow, no reliance on f16
+// subnormals.  The error against a float64 conv is measured next to the exact-f32 kernel's in tests/test_gpu_kernels.py.
+//
+// Work decomposition = the wave-autonomous scheme of conv3x3_head_kernel: one 512-thread workgroup per CU keeps all packed weights
+// (5 k-steps x 7 channel tiles x 2 pieces x 1 KiB) in LDS; every wavefront owns items of 4 rows x 16 pixels, stages its haloed
+// 6 x 18 x 16ch region as two f16 planes (32 B per pixel and plane: the ds_read_b128 operand reads are conflict-free without padding)
+// and runs 5 k-steps (two taps x 16 channels = K 32 each; the 10th tap has zero weights) x 7 x 4 tiles x 3 MFMAs.
+#include "common.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+// D[16x16] += A[16x32] * B[32x16]: lane l holds A[i = l & 15][k = 8 (l >> 4) .. + 7], B[k = 8 (l >> 4) .. + 7][j = l & 15];
+// D as in mfma16 (lane l, reg r: i = 4 (l >> 4) + r, j = l & 15).
+__device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float fast_tanh_s(float x) {
+    const float e = __expf(2.f * x);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct SplitHeadCfg {
+    static constexpr int CT = 7, KS = 5;
+    static constexpr int RW = 18, RH = 6;
+    static constexpr int PLANE_BYTES = RH * RW * 32;                       // one f16 piece of the region: 16 channels x 2 B per pixel
+    static constexpr int REGION_BYTES = 2 * PLANE_BYTES;                   // 6912 B per wavefront
+    static constexpr int W_BYTES = KS * CT * 2 * 1024;                     // 71680 B
+    static constexpr int BIAS_BYTES = CT * 16 * 4;                          // bias of the 112 channel slots
+    static constexpr int LDS_BYTES = W_BYTES + 8 * REGION_BYTES + BIAS_BYTES;
+    static constexpr int NS = (RH * RW * 4 + 63) / 64;                     // float4 staging slots per lane
+};
+
+// One pass of the MFMA phase over channel tiles C0 .. C0 + NC - 1: KS x NC blocks (k-step s, tile) of 12 MFMAs.  The two weight
+// pieces of the next block and, during the last four tiles of a k-step, the activation pieces of k-step s + 1 are fetched from LDS
+// while a block computes (12 x 16 cycles of the matrix pipe cover the LDS round trip): a wavefront alone keeps the pipe busy.
+template <int C0, int NC>
+__device__ __forceinline__ void mfma_tiles(const char* wl, const char* reg, const int (&tapoff)[SplitHeadCfg::KS], const int lane,
+                                           f32x4 (&acc)[NC][4]) {
+    using Cfg = SplitHeadCfg;
+    constexpr int KS = Cfg::KS, CT = Cfg::CT, RW = Cfg::RW;
+    constexpr int PB = NC < 4 ? NC : 4;                      // blocks of a k-step that carry the next k-step's activation loads
+    constexpr int PPB = 4 / PB;                              // pixel groups fetched per such block
+    h8 wq[2][2], bq[2][4][2];
+    auto load_w = [&](const int s, const int ct, h8 (&w)[2]) __attribute__((always_inline)) {
+        const char* wp = wl + ((s * CT + ct) * 2 * 64 + lane) * 16;                      // [KS][CT][2][64] x 16 B
+        w[0] = *reinterpret_cast<const h8*>(wp);
+        w[1] = *reinterpret_cast<const h8*>(wp + 1024);
+    };
+    auto load_b = [&](const int s, const int pt, h8 (&b)[2]) __attribute__((always_inline)) {
+        b[0] = *reinterpret_cast<const h8*>(reg + tapoff[s] + pt * RW * 32);
+        b[1] = *reinterpret_cast<const h8*>(reg + tapoff[s] + pt * RW * 32 + Cfg::PLANE_BYTES);
+    };
+    load_w(0, C0, wq[0]);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) load_b(0, pt, bq[0][pt]);
+#ifndef GCPX_SPLIT_NOPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+    static_for<0, KS * NC>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value, s = t / NC, c = t % NC;
+        constexpr bool more = t + 1 < KS * NC;
+        constexpr bool pre_b = c >= NC - PB && s + 1 < KS;
+        if constexpr (more) load_w((t + 1) / NC, C0 + (t + 1) % NC, wq[(t + 1) & 1]);
+        if constexpr (pre_b) {
+#pragma unroll
+            for (int k = 0; k < PPB; ++k) load_b(s + 1, (c - (NC - PB)) * PPB + k, bq[(s + 1) & 1][(c - (NC - PB)) * PPB + k]);
+        }
+        const h8 w1 = wq[t & 1][0], w2 = wq[t & 1][1];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            // small terms first: they are added to the accumulator while it is still small
+            if constexpr (s == 0) acc[c][pt] = mfma32h(w2, bq[0][pt][0], f32x4{0, 0, 0, 0});
+            else acc[c][pt] = mfma32h(w2, bq[s & 1][pt][0], acc[c][pt]);
+        }
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) acc[c][pt] = mfma32h(w1, bq[s & 1][pt][1], acc[c][pt]);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) acc[c][pt] = mfma32h(w1, bq[s & 1][pt][0], acc[c][pt]);
+        __builtin_amdgcn_sched_group_barrier(0x100, (more ? 2 : 0) + (pre_b ? 2 * PPB : 0), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    });
+#ifndef GCPX_SPLIT_NOPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
+// scale back + bias, and the raw NHWC store of channel tiles C0 .. C0 + NC - 1
+template <int C0, int NC>
+__device__ __forceinline__ void finish_tiles(const gcpx_conv_args& a, const float* bias_l, f32x4 (&acc)[NC][4], const float inv, const bool store_raw,
+                                             const int orow, const int y0, const int x0, const int j, const int q) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias_l + (C0 + c) * 16 + q * 4);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            acc[c][pt][0] = fmaf(acc[c][pt][0], inv, bv.x); acc[c][pt][1] = fmaf(acc[c][pt][1], inv, bv.y);
+            acc[c][pt][2] = fmaf(acc[c][pt][2], inv, bv.z); acc[c][pt][3] = fmaf(acc[c][pt][3], inv, bv.w);
+        }
+    }
+    if (store_raw) {
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            float* op = a.out + (((size_t)orow * a.Hout + (y0 + pt)) * a.Wout + (x0 + j)) * a.out_pitch;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int ch = (C0 + c) * 16 + q * 4;
+                if (ch < a.out_pitch) {
+                    const f32x4 v = acc[c][pt];
+                    *reinterpret_cast<float4*>(op + ch) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_conv_args a, const int items_per_wave,
+                                                                    const int nitems) {
+    using Cfg = SplitHeadCfg;
+    constexpr int RW = Cfg::RW, RH = Cfg::RH, NS = Cfg::NS, CT = Cfg::CT, KS = Cfg::KS;
+    extern __shared__ float4 smem4[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const char* wl = reinterpret_cast<const char*>(smem4);                          // [KS][CT][2][64] x 16 B
+    char* reg = reinterpret_cast<char*>(smem4) + Cfg::W_BYTES + wave * Cfg::REGION_BYTES;
+    const int j = lane & 15, q = lane >> 4;
+    const int H = a.Hout, W = a.Wout;
+    const int ncb = W / 16, nrp = H / 4;
+
+    for (int i = tid; i < Cfg::W_BYTES / 16; i += 512) smem4[i] = reinterpret_cast<const float4*>(a.wpk_split)[i];
+    float* bias_l = reinterpret_cast<float*>(reinterpret_cast<char*>(smem4) + Cfg::W_BYTES + 8 * Cfg::REGION_BYTES);
+    if (tid < CT * 16) bias_l[tid] = tid < a.out_pitch ? a.bias[tid] : 0.f;
+    __syncthreads();
+
+    // operand address of k-step s: tap 2 s + (q >> 1), channels 8 (q & 1) .. + 7 of pixel (row + ty, j + tx).  The 10th tap (s = 4,
+    // q >= 2) has zero weights; it re-reads tap 8 so that the multiplicand is a staged (finite) value.
+    int tapoff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int tap = min(2 * s + (q >> 1), 8);
+        tapoff[s] = ((tap / 3) * RW + (tap % 3) + j) * 32 + (q & 1) * 16;
+    }
+    const gcpx_conv_src sr = a.src[0];
+    const int ew = a.w_split_log2;
+    // every staging slot of a lane carries the same 4 channels: their BatchNorm affine is loaded once
+    float4 bn_s = make_float4(1.f, 1.f, 1.f, 1.f), bn_t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sr.scale) {
+        bn_s = *reinterpret_cast<const float4*>(sr.scale + (lane & 3) * 4);
+        bn_t = *reinterpret_cast<const float4*>(sr.shift + (lane & 3) * 4);
+    }
+    const float slope = sr.act == GCPX_ACT_LRELU ? 0.2f : 1.f;
+
+    const int gw = blockIdx.x * 8 + wave;
+    int item = gw * items_per_wave;
+    const int item_end = min(item + items_per_wave, nitems);
+
+    float4 pre[NS];
+    unsigned pre_ok = 0;
+    int pre_orow = 0;                                      // raw_row_map entry of the prefetched item's frame
+    auto origin = [&](int it, int& f, int& y0, int& x0) {
+        const int strip = it % nrp;
+        const int t = it / nrp;
+        y0 = strip * 4; f = t / ncb; x0 = (t % ncb) * 16;
+    };
+    int s_rc[NS];                                          // staging slot -> (row << 8 | col) of the region, item independent
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int t = (lane + 64 * k) >> 2;
+        s_rc[k] = ((t / RW) << 8) | (t % RW);
+    }
+    auto issue_loads = [&](int it) {
+        int f, y0, x0;
+        origin(it, f, y0, x0);
+        pre_ok = 0;
+        const float* base = sr.ptr + (size_t)f * H * W * 16;
+        pre_orow = a.raw_row_map ? a.raw_row_map[f] : f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int idx = lane + 64 * k;
+            const int sy = y0 - 1 + (s_rc[k] >> 8), sx = x0 - 1 + (s_rc[k] & 255);
+            if (idx < RH * RW * 4 && sy >= 0 && sy < H && sx >= 0 && sx < W) {
+                pre[k] = *reinterpret_cast<const float4*>(base + (unsigned)((__umul24(sy, W) + sx) * 16 + (idx & 3) * 4));
+                pre_ok |= 1u << k;
+            }
+        }
+    };
+    if (item < item_end) issue_loads(item);
+
+    for (; item < item_end; ++item) {
+        int f, y0, x0;
+        origin(item, f, y0, x0);
+        const int orow = __builtin_amdgcn_readfirstlane(pre_orow);
+        // ---- staging: BatchNorm affine + LeakyReLU of the producer, the item's power-of-two scale, the two f16 pieces ----
+        float amax = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (pre_ok & (1u << k)) {          // (the zero padding of the conv stays exactly zero)
+                float4 v = pre[k];
+                v.x = fmaf(v.x, bn_s.x, bn_t.x); v.y = fmaf(v.y, bn_s.y, bn_t.y); v.z = fmaf(v.z, bn_s.z, bn_t.z); v.w = fmaf(v.w, bn_s.w, bn_t.w);
+                v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+                v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+                pre[k] = v;
+            }
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(pre[k].x), fabsf(pre[k].y)), fmaxf(fabsf(pre[k].z), fabsf(pre[k].w))));
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+        // amax 2^ex in [2^14, 2^15): below the f16 maximum, and every piece that matters is a normal f16
+        int ex = 14 + 127 - (int)((__float_as_uint(amax) >> 23) & 0xff);
+        ex = __builtin_amdgcn_readfirstlane(amax > 0.f ? max(-100, min(100, ex)) : 0);
+        const float sx2 = __uint_as_float((unsigned)(127 + ex) << 23);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int idx = lane + 64 * k;
+            if (idx < RH * RW * 4) {
+                const float4 v = make_float4(pre[k].x * sx2, pre[k].y * sx2, pre[k].z * sx2, pre[k].w * sx2);
+                h4 p1, p2;
+                p1[0] = (_Float16)v.x; p1[1] = (_Float16)v.y; p1[2] = (_Float16)v.z; p1[3] = (_Float16)v.w;
+                p2[0] = (_Float16)(v.x - (float)p1[0]); p2[1] = (_Float16)(v.y - (float)p1[1]);
+                p2[2] = (_Float16)(v.z - (float)p1[2]); p2[3] = (_Float16)(v.w - (float)p1[3]);
+                char* dst = reg + (idx >> 2) * 32 + (idx & 3) * 8;
+                *reinterpret_cast<h4*>(dst) = p1;
+                *reinterpret_cast<h4*>(dst + Cfg::PLANE_BYTES) = p2;
+            }
+        }
+        if (item + 1 < item_end) issue_loads(item + 1);        // in flight during this item's MFMAs
+
+        const int mode = a.head_mode;
+        const size_t plane = (size_t)H * W;
+        const bool store_raw = (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) && orow >= 0;
+        const float inv = __uint_as_float((unsigned)(127 - ex - ew) << 23);      // undoes the two power-of-two scales (exact)
+
+        // ---- pass A: channel tiles 0..4 = the 80 slots the mixture mean reads ----
+        {
+            f32x4 acc[5][4];
+            mfma_tiles<0, 5>(wl, reg, tapoff, lane, acc);
+            finish_tiles<0, 5>(a, bias_l, acc, inv, store_raw, orow, y0, x0, j, q);
+            if (mode == GCPX_HEAD_DLM_MEAN || mode == GCPX_HEAD_DLM_BOTH) {
+                // kernel channel order and the lane exchange: see conv3x3_head_kernel (conv3x3.hip)
+#pragma unroll
+                for (int ct = 0; ct < 5; ++ct)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ct][s2][r]),
+                                                                             __float_as_uint(acc[ct][s2 + 2][r]), false, false);
+                            acc[ct][s2][r] = __uint_as_float(sw[0]);
+                            acc[ct][s2 + 2][r] = __uint_as_float(sw[1]);
+                        }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float lg[5], mr[5], mg[5], mb[5];
+#pragma unroll
+                    for (int ct = 0; ct < 5; ++ct) {
+                        const f32x4 e = acc[ct][s2], o = acc[ct][s2 + 2];
+                        const float c0 = fast_tanh_s(o[0]), c1 = fast_tanh_s(o[1]), c2 = fast_tanh_s(o[2]);
+                        lg[ct] = e[0];
+                        mr[ct] = e[1];
+                        mg[ct] = e[2] + c0 * mr[ct];
+                        mb[ct] = e[3] + c1 * mr[ct] + c2 * mg[ct];
+                    }
+                    float m = lg[0];
+#pragma unroll
+                    for (int ct = 1; ct < 5; ++ct) m = fmaxf(m, lg[ct]);
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                    float S = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
+#pragma unroll
+                    for (int ct = 0; ct < 5; ++ct) {
+                        const float w = __expf(lg[ct] - m);
+                        S += w; Sr += w * mr[ct]; Sg += w * mg[ct]; Sb += w * mb[ct];
+                    }
+                    S += __shfl_xor(S, 32); Sr += __shfl_xor(Sr, 32); Sg += __shfl_xor(Sg, 32); Sb += __shfl_xor(Sb, 32);
+                    if (q < 2) {
+                        const int pt = s2 + 2 * q;
+                        const float invS = __builtin_amdgcn_rcpf(S);
+                        float* ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + pt) * W + (x0 + j);
+                        ip[0] = fminf(fmaxf(Sr * invS, -1.f), 1.f);
+                        ip[plane] = fminf(fmaxf(Sg * invS, -1.f), 1.f);
+                        ip[2 * plane] = fminf(fmaxf(Sb * invS, -1.f), 1.f);
+                    }
+                }
+            }
+        }
+        // ---- pass B: channel tiles 5, 6 = slots 80..99 (+ 12 empty): only ever stored raw, so only computed when that is asked for ----
+        if (store_raw) {
+            f32x4 acc[2][4];
+            mfma_tiles<5, 2>(wl, reg, tapoff, lane, acc);
+            finish_tiles<5, 2>(a, bias_l, acc, inv, true, orow, y0, x0, j, q);
+        }
+    }
+}
+
+}  // namespace
+
+// Called by conv3x3_dispatch (conv3x3.hip) for the 100-channel mixture head when the caller supplies split-f16 weights.
+int gcpx_launch_head_split(const gcpx_conv_args* a, hipStream_t stream) {
+    using Cfg = SplitHeadCfg;
+    auto kern = conv3x3_head_split_kernel;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) {
+            gcpx_set_error("conv3x3 split head: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const int nitems = a->F * (a->Hout / 4) * (a->Wout / 16);
+    int grid = gcpx_conv_grid() / 2;
+    if (grid * 8 > nitems) grid = (nitems + 7) / 8;
+    const int ipw = (nitems + grid * 8 - 1) / (grid * 8);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, stream, *a, ipw, nitems);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}

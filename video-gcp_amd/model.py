@@ -14,6 +14,7 @@ Data layout in HBM (fp32):
   * decoded images are [B, N, 3, H, W] in depth-first node order (the reference's `tree.df.images`).
 """
 import ctypes as C
+import os
 from contextlib import contextmanager
 
 import torch
@@ -156,6 +157,9 @@ class GCPTreeModel:
                 rt.check(self.lib.gcpx_stream_create(C.byref(sp)), "stream_create")
             self._streams.append(sp)
         self.save_for_backward = False        # training step: forward plans keep what the backward pass needs
+        # split-f16 convs (csrc/conv3x3_split.hip): f32-equivalent results on the f16 matrix pipes.  GCPX_EXACT_F32=1 keeps every
+        # conv on the exact f32 MFMA kernels
+        self.split_f16 = os.environ.get("GCPX_EXACT_F32") is None
         self._timed_op = None                 # name of one plan op bracketed by HIP events (bench.py roofline)
         self._timed_events = []
         self._pack_all()
@@ -282,6 +286,21 @@ class GCPTreeModel:
             return
         self.pk = self._pack_tree(self.sd)
         self._pack_fused_embed()
+        self._pack_split()
+
+    def _pack_split(self):
+        """Inference only (as _pack_fused_embed: not a gather of theta, so not for weights that live in the trainer's arena): the two
+        f16 pieces of the conv weights that have a split-f16 kernel -> self.pk_split[name] = (int16 pack, log2 of its scale)."""
+        self.pk_split = {}
+        if self._hp.decoder_distribution == "discrete_logistic_mixture":
+            w, e = pk.pack_conv3x3_split(self.sd["decoder.gen_head.conv.weight"], pk.dlm_channel_perm(self._hp.n_mixtures))
+            self.pk_split["dec.head"] = (w.to(self.device), e)
+
+    def _set_split(self, a, name):
+        """Hand conv `name`'s split-f16 weights to the launch if this model runs split-f16 and holds them."""
+        ws = getattr(self, "pk_split", {}).get(name)
+        if self.split_f16 and ws is not None and not self.save_for_backward and getattr(self, "_arena", None) is None:
+            a.wpk_split, a.w_split_log2 = ws[0].data_ptr(), ws[1]
 
     def _pack_fused_embed(self):
         """Inference only: the input embedding Linear and LSTM layer 0's input projection are two Linears with nothing in between
@@ -1057,6 +1076,7 @@ class GCPTreeModel:
             a = self._conv_args([prev], F, S, S, S, S, hp.head_channels, self._head_pitch, P["dec.head.w"], P["dec.head.b"],
                                 head_out, upsample=0, head_mode=mode, images=images)
             a.raw_row_map = row_map.data_ptr() if row_map is not None else None
+            self._set_split(a, "dec.head")
             plan.keep.append(a)
             if heads_lane:
                 plan.join([1])       # the latent-space heads overlapped the decoder blocks; the head runs alone
@@ -1423,6 +1443,7 @@ class GCPTreeModel:
             dlm = hp.decoder_distribution == "discrete_logistic_mixture"
             a = self._conv_args([prev], B * N, S, S, S, S, hp.head_channels, self._head_pitch, self.pk["dec.head.w"], self.pk["dec.head.b"],
                                 None, upsample=0, head_mode=(rt.HEAD_DLM_MEAN if dlm else rt.HEAD_TANH_NCHW), images=images)
+            self._set_split(a, "dec.head")
             plan.keep.append(a)
             plan.add("dec.head", self.lib.gcpx_conv3x3, C.byref(a))
         finally:

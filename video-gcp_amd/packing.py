@@ -147,6 +147,46 @@ def pack_dlm_head(w, perm):
     return out.contiguous()
 
 
+def split_f16(w):
+    """w (f32, any shape) -> (w1, w2, e): w 2^e ~= w1 + w2 with f16 pieces, |w 2^e - w1 - w2| <= 2^-24 |w 2^e|.  e puts the largest
+    |w| in [2^14, 2^15): below the f16 maximum, and the second piece of every weight within 2^-12 of the largest is a normal f16."""
+    amax = float(w.abs().max())
+    e = 0 if amax == 0.0 else 14 - int(torch.floor(torch.log2(torch.tensor(amax, dtype=torch.float64))))
+    ws = w.double() * (2.0 ** e)
+    w1 = ws.float().half()                                  # round to nearest even (the scaling is exact)
+    w2 = (ws - w1.double()).float().half()
+    return w1, w2, e
+
+
+def pack_conv3x3_split(w, perm=None):
+    """w [Cout, 16 n, 3, 3] -> (int16 [n][5][CT][2][64][8], e): the two f16 pieces of the weights in v_mfma_f32_16x16x32_f16
+    A-fragment order for csrc/conv3x3_split.hip.  Per 16-channel input chunk, k-step s holds taps 2 s and 2 s + 1 (the 10th tap is
+    zero): lane (i = lane & 15, q = lane >> 4) element e = W[16 ct + i][chunk 16 + 8 (q & 1) + e][tap 2 s + (q >> 1)]."""
+    Cout, Cin = w.shape[:2]
+    assert Cin % 16 == 0
+    dev = w.device
+    if perm is not None:
+        perm_t = torch.as_tensor(perm, device=dev)
+        wk = torch.zeros((len(perm), Cin, 3, 3), dtype=w.dtype, device=dev)
+        valid = perm_t >= 0
+        wk[valid] = w[perm_t[valid]]
+        w = wk
+    CT = (w.shape[0] + 15) // 16
+    w = _pad_rows(w, CT * 16).reshape(CT * 16, Cin, 9)
+    w = torch.cat([w, torch.zeros((CT * 16, Cin, 1), dtype=w.dtype, device=dev)], 2)      # tap 9 = 0
+    w1, w2, e = split_f16(w)
+    pieces = torch.stack([w1, w2], 0)                                                       # [2, CT*16, Cin, 10]
+    ch = torch.arange(Cin // 16, device=dev)[:, None, None, None, None, None]
+    s = torch.arange(5, device=dev)[None, :, None, None, None, None]
+    ct = torch.arange(CT, device=dev)[None, None, :, None, None, None]
+    p = torch.arange(2, device=dev)[None, None, None, :, None, None]
+    li = _LI.to(dev)[None, None, None, None, :, None]
+    lq = _LQ.to(dev)[None, None, None, None, :, None]
+    el = torch.arange(8, device=dev)[None, None, None, None, None, :]
+    out = pieces[p, ct * 16 + li, ch * 16 + (lq % 2) * 8 + el, 2 * s + lq // 2]             # [n, 5, CT, 2, 64, 8]
+    return out.contiguous().view(torch.int16), e
+
+
 def lstm_gate_interleave(w_ih, w_hh, b_ih, b_hh):
     """[4H, H] x2 (torch gate order i, f, g, o) -> W [4H, 2H] with row n = 4u + gate, bias [4H] likewise."""
     H = w_hh.shape[1]                                       # (w_ih may be wider than H: embedding folded into layer 0)

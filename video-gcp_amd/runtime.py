@@ -27,7 +27,7 @@ class ConvArgs(C.Structure):
     _fields_ = [("src", ConvSrc * 2), ("nsrc", i32), ("F", i32), ("Hin", i32), ("Win", i32), ("Hout", i32),
                 ("Wout", i32), ("Cin", i32), ("Cout", i32), ("out_pitch", i32), ("upsample", i32), ("out_act", i32),
                 ("head_mode", i32), ("wpk", vp), ("bias", vp), ("out", vp), ("images", vp), ("stats_partial", vp),
-                ("raw_row_map", vp), ("src_row_map", vp), ("src_row_frames", vp), ("n_src_rows", i32), ("_pad0", i32)]
+                ("raw_row_map", vp), ("src_row_map", vp), ("src_row_frames", vp), ("n_src_rows", i32), ("w_split_log2", i32), ("wpk_split", vp)]
 
 
 class LossArgs(C.Structure):

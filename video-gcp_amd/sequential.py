@@ -219,6 +219,7 @@ class GCPSequentialModel(GCPTreeModel):
         a.raw_row_map = row_map.data_ptr() if row_map is not None else None
         plan.keep.append(a)
         plan.join([1])
+        self._set_split(a, "dec.head")
         plan.add("dec.head", lib.gcpx_conv3x3, C.byref(a))
         # images = cat(I_0, decoded) (sequential.py:57)
         row = hp.input_nc * S * S
