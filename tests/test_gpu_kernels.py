@@ -180,9 +180,13 @@ def _conv_args(rt, srcs, **kw):
 
 @pytest.mark.parametrize("Hin,c_prev,c_skip,cout,Fr,nodes", [(32, 16, 16, 16, 6, 3), (16, 32, 0, 16, 5, 1), (8, 64, 64, 32, 6, 2),
                                                              (4, 128, 0, 64, 7, 1), (4, 64, 64, 32, 6, 3), (8, 32, 0, 16, 4, 1)])
-def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes):
-    """decoder block: concat(prev, skip broadcast over nodes) -> affine+LReLU -> bilinear x2 -> conv3x3 (+ stats)."""
+@pytest.mark.parametrize("split", [False, True])
+def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes, split):
+    """decoder block: concat(prev, skip broadcast over nodes) -> affine+LReLU -> bilinear x2 -> conv3x3 (+ stats).
+    split: the split-f16 form of the 16-output-channel blocks (csrc/conv3x3_split.hip), same tolerances."""
     rt, pk, lib, dev = env
+    if split and cout != 16:
+        pytest.skip("split-f16 form exists for the 16-channel blocks")
     torch.manual_seed(Hin + cout)
     x = torch.randn(Fr, c_prev, Hin, Hin)
     sc, sh = torch.rand(c_prev) + 0.5, torch.randn(c_prev) * 0.2
@@ -202,6 +206,10 @@ def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes):
     out = torch.full((Fr, 2 * Hin, 2 * Hin, cout), float("nan"), device=dev)
     a = _conv_args(rt, srcs, F=Fr, Hin=Hin, Win=Hin, Hout=2 * Hin, Wout=2 * Hin, Cout=cout, out_pitch=cout, upsample=1,
                    head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out, stats_partial=out)
+    if split:
+        ws, e = pk.pack_conv3x3_split(w)
+        ws = ws.to(dev)
+        a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
     G = lib.gcpx_conv3x3_grid(C.byref(a))
     assert G > 0
     st = torch.full((G, 2, cout), float("nan"), device=dev)
@@ -312,6 +320,49 @@ def test_conv3x3_head_split_error_vs_float64(env, case):
     assert float(err["split"].max()) <= 2.0 * float(err["f32"].max()) + 4e-7 * scale
     if case in ("unit", "tiny", "zero", "matched_rows"):
         assert_close(imgs["split"], imgs["f32"], atol=5e-6, name="mixture mean, split vs exact")
+
+
+@pytest.mark.parametrize("case", ["unit", "chunk_scales", "outlier", "zero_chunk"])
+def test_conv3x3_up16_split_error_vs_float64(env, case):
+    """The split-f16 16-channel decoder block against float64, next to the exact f32 kernel; the two 16-channel chunks of the input
+    differ in magnitude by 1e4 either way (the running power-of-two scale), carry an outlier, or are all zero."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(5)
+    Hin, Fr, nodes = 32, 4, 2
+    amp_prev, amp_skip = {"unit": (1, 1), "chunk_scales": (1e-2, 1e2), "outlier": (1, 1), "zero_chunk": (0, 1)}[case]
+    res = {}
+    for order in (0, 1):                                   # small chunk first / large chunk first
+        a_p, a_s = (amp_prev, amp_skip) if order == 0 else (amp_skip, amp_prev)
+        x = torch.randn(Fr, 16, Hin, Hin) * a_p
+        sk = torch.randn(Fr // nodes, 16, Hin, Hin) * a_s
+        if case == "outlier":
+            sk[0, 5, 9, 9] = 2e4
+        sc, sh = torch.rand(16) + 0.5, torch.randn(16) * 0.2 * a_p
+        xin = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)
+        w, b = torch.randn(16, 32, 3, 3) / (9 * 32) ** 0.5, torch.randn(16) * 0.1
+        up = F.interpolate(torch.cat([xin, sk.repeat_interleave(nodes, 0)], 1).double(), scale_factor=2, mode="bilinear", align_corners=False)
+        ref = F.conv2d(up, w.double(), b.double(), padding=1)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+        skd = sk.permute(0, 2, 3, 1).contiguous().to(dev)
+        srcs = [(xd, 16, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU), (skd, 16, nodes, None, None, rt.ACT_NONE)]
+        wp, bd = pk.pack_conv3x3(w, 16).to(dev), pk.pad_vec(b, 16).to(dev)
+        ws, e = pk.pack_conv3x3_split(w)
+        ws = ws.to(dev)
+        err = {}
+        for name in ("f32", "split"):
+            out = torch.full((Fr, 2 * Hin, 2 * Hin, 16), float("nan"), device=dev)
+            a = _conv_args(rt, srcs, F=Fr, Hin=Hin, Win=Hin, Hout=2 * Hin, Wout=2 * Hin, Cout=16, out_pitch=16, upsample=1,
+                           head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out)
+            if name == "split":
+                a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+            rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), name)
+            torch.cuda.synchronize()
+            got = out.cpu().permute(0, 3, 1, 2).double()
+            assert torch.isfinite(got).all()
+            err[name] = (got - ref).abs()
+        scale = float(ref.abs().max())
+        assert float(err["split"].pow(2).mean().sqrt()) <= 1.5 * float(err["f32"].pow(2).mean().sqrt()) + 1e-12 * scale
+        assert float(err["split"].max()) <= 2.0 * float(err["f32"].max()) + 4e-7 * scale
 
 
 @pytest.mark.parametrize("Hin,cin,cout,Fr", [(32, 16, 32, 5), (16, 32, 64, 3), (8, 64, 128, 9), (16, 16, 32, 2)])

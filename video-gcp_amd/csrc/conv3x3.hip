@@ -19,6 +19,8 @@
 
 #include <type_traits>
 
+int gcpx_launch_up16_split(const gcpx_conv_args* a, hipStream_t stream, int grid);      // conv3x3_split.hip
+
 namespace {
 
 template <int TILE> struct TileShape;
@@ -1174,6 +1176,7 @@ int launch_up16(const gcpx_conv_args* a, hipStream_t stream, bool query_only) {
     const int nitems = a->F * (a->Hout / 4) * (a->Wout / 16);
     if (!a->stats_partial && grid * 8 > nitems) grid = (nitems + 7) / 8;
     if (query_only) return grid;
+    if (a->wpk_split) return gcpx_launch_up16_split(a, stream, grid);
     static int lds_set = 0;
     if (lds > lds_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_up16_kernel),

@@ -60,11 +60,12 @@ struct SplitHeadCfg {
 // One pass of the MFMA phase over channel tiles C0 .. C0 + NC - 1: KS x NC blocks (k-step s, tile) of 12 MFMAs.  The two weight
 // pieces of the next block and, during the last four tiles of a k-step, the activation pieces of k-step s + 1 are fetched from LDS
 // while a block computes (12 x 16 cycles of the matrix pipe cover the LDS round trip): a wavefront alone keeps the pipe busy.
-template <int C0, int NC>
+// wl: [KS][CTW][2][64] x 16 B packed pieces (CTW = channel tiles of the pack); INIT: the accumulators start from zero.
+template <int C0, int NC, int CTW = SplitHeadCfg::CT, bool INIT = true>
 __device__ __forceinline__ void mfma_tiles(const char* wl, const char* reg, const int (&tapoff)[SplitHeadCfg::KS], const int lane,
                                            f32x4 (&acc)[NC][4]) {
     using Cfg = SplitHeadCfg;
-    constexpr int KS = Cfg::KS, CT = Cfg::CT, RW = Cfg::RW;
+    constexpr int KS = Cfg::KS, CT = CTW, RW = Cfg::RW;
     constexpr int PB = NC < 4 ? NC : 4;                      // blocks of a k-step that carry the next k-step's activation loads
     constexpr int PPB = 4 / PB;                              // pixel groups fetched per such block
     h8 wq[2][2], bq[2][4][2];
@@ -80,9 +81,7 @@ __device__ __forceinline__ void mfma_tiles(const char* wl, const char* reg, cons
     load_w(0, C0, wq[0]);
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) load_b(0, pt, bq[0][pt]);
-#ifndef GCPX_SPLIT_NOPRIO
     __builtin_amdgcn_s_setprio(1);
-#endif
     static_for<0, KS * NC>([&](auto tc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value, s = t / NC, c = t % NC;
         constexpr bool more = t + 1 < KS * NC;
@@ -96,7 +95,7 @@ __device__ __forceinline__ void mfma_tiles(const char* wl, const char* reg, cons
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
             // small terms first: they are added to the accumulator while it is still small
-            if constexpr (s == 0) acc[c][pt] = mfma32h(w2, bq[0][pt][0], f32x4{0, 0, 0, 0});
+            if constexpr (s == 0 && INIT) acc[c][pt] = mfma32h(w2, bq[0][pt][0], f32x4{0, 0, 0, 0});
             else acc[c][pt] = mfma32h(w2, bq[s & 1][pt][0], acc[c][pt]);
         }
 #pragma unroll
@@ -106,9 +105,7 @@ __device__ __forceinline__ void mfma_tiles(const char* wl, const char* reg, cons
         __builtin_amdgcn_sched_group_barrier(0x100, (more ? 2 : 0) + (pre_b ? 2 * PPB : 0), 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
     });
-#ifndef GCPX_SPLIT_NOPRIO
     __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
 // scale back + bias, and the raw NHWC store of channel tiles C0 .. C0 + NC - 1
@@ -234,7 +231,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
         for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
         // amax 2^ex in [2^14, 2^15): below the f16 maximum, and every piece that matters is a normal f16
         int ex = 14 + 127 - (int)((__float_as_uint(amax) >> 23) & 0xff);
-        ex = __builtin_amdgcn_readfirstlane(amax > 0.f ? max(-100, min(100, ex)) : 0);
+        ex = __builtin_amdgcn_readfirstlane(amax > 0.f ? max(-100, min(min(100, 126 - ew), ex)) : 0);   // (2^-(ex + ew) stays a normal f32)
         const float sx2 = __uint_as_float((unsigned)(127 + ex) << 23);
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
@@ -318,6 +315,209 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
     }
 }
 
+
+// -----------------------------------------------------------------------------------------------------------
+// Decoder blocks with 16 output channels (pyramid-0, additional_conv_layer) in split-f16: the wave-autonomous scheme of
+// conv3x3_up16_kernel (conv3x3.hip) — raw 4 x 10 low-res patch per 16-channel chunk -> BatchNorm affine + LeakyReLU -> bilinear x2
+// into the haloed 6 x 18 region — with the region written as two f16 planes and 5 k-steps x 4 pixel groups x 3 MFMAs per chunk.
+// The power-of-two scale follows the chunks: a chunk with larger values than any before lowers it and the accumulators are
+// rescaled (exact); a chunk with smaller values keeps it (its pieces are then small against the item's largest value, which is all
+// a per-item scale promises).
+// -----------------------------------------------------------------------------------------------------------
+struct SplitUpCfg {
+    static constexpr int RW = 18, RH = 6, LW = 10, LH = 4, CC = 16, KS = 5;
+    static constexpr int RAW_BYTES = LH * LW * CC * 4;                     // 2560: f32 low-res patch
+    static constexpr int PLANE_BYTES = RH * RW * 32;                       // 3456
+    static constexpr int WAVE_BYTES = RAW_BYTES + 2 * PLANE_BYTES;         // 9472
+    static constexpr int NS = (LH * LW * 4 + 63) / 64;                     // raw float4 slots per lane (3)
+    static constexpr int W_CHUNK_BYTES = KS * 2 * 1024;                    // 10240 per 16-channel chunk
+    static int lds_bytes(int nchunk) { return nchunk * W_CHUNK_BYTES + 8 * WAVE_BYTES + 8 * 2 * 16 * 4; }
+};
+
+__global__ void __launch_bounds__(512, 2) conv3x3_up16_split_kernel(const gcpx_conv_args a, const int items_per_wave,
+                                                                    const int nitems) {
+    using Cfg = SplitUpCfg;
+    constexpr int RW = Cfg::RW, RH = Cfg::RH, LW = Cfg::LW, LH = Cfg::LH, CC = Cfg::CC, NS = Cfg::NS, KS = Cfg::KS;
+    extern __shared__ float4 smem4[];
+    const int nchunk = a.Cin / CC;
+    const char* wl = reinterpret_cast<const char*>(smem4);                           // [nchunk][KS][1][2][64] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* wbuf = reinterpret_cast<char*>(smem4) + nchunk * Cfg::W_CHUNK_BYTES + wave * Cfg::WAVE_BYTES;
+    float* raw = reinterpret_cast<float*>(wbuf);
+    char* hi = wbuf + Cfg::RAW_BYTES;
+    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(smem4) + nchunk * Cfg::W_CHUNK_BYTES + 8 * Cfg::WAVE_BYTES);
+    const int j = lane & 15, q = lane >> 4;
+    const int H = a.Hout, W = a.Wout, Hin = a.Hin, Win = a.Win;
+    const int ncb = W / 16, nrq = H / 4;
+
+    for (int i = tid; i < nchunk * Cfg::W_CHUNK_BYTES / 16; i += 512) smem4[i] = reinterpret_cast<const float4*>(a.wpk_split)[i];
+    __syncthreads();
+
+    int tapoff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int tap = min(2 * s + (q >> 1), 8);
+        tapoff[s] = ((tap / 3) * RW + (tap % 3) + j) * 32 + (q & 1) * 16;
+    }
+    const int c0 = a.src[0].C;
+    const int ew = a.w_split_log2;
+    const float4 bv = *reinterpret_cast<const float4*>(a.bias + q * 4);
+
+    const int gw = blockIdx.x * 8 + wave;
+    int item = gw * items_per_wave;
+    const int item_end = min(item + items_per_wave, nitems);
+
+    auto origin = [&](int it, int& f, int& y0, int& x0) {
+        const int strip = it % nrq;
+        const int t = it / nrq;
+        y0 = strip * 4; f = t / ncb; x0 = (t % ncb) * 16;
+    };
+    int s_rc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int t = (lane + 64 * k) >> 2;
+        s_rc[k] = ((t / LW) << 8) | (t % LW);
+    }
+    float4 pre[NS];
+    auto issue_loads = [&](int it, int chunk) {
+        int f, y0, x0;
+        origin(it, f, y0, x0);
+        const int cg = chunk * CC;
+        const bool first = cg < c0;
+        const gcpx_conv_src& sr = first ? a.src[0] : a.src[1];
+        const int cl = first ? cg : cg - c0;
+        const int srcC = sr.C;
+        const float* base = sr.ptr + (size_t)(f / sr.frame_div) * Hin * Win * srcC + cl;
+        const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int idx = lane + 64 * k;
+            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < LH * LW * 4) {
+                const int sy = min(max(ly0 + (s_rc[k] >> 8), 0), Hin - 1);          // replicate clamp (bilinear border rule)
+                const int sx = min(max(lx0 + (s_rc[k] & 255), 0), Win - 1);
+                const unsigned off = __umul24(__umul24(sy, Win) + sx, srcC) + (idx & 3) * 4;
+                pre[k] = *reinterpret_cast<const float4*>(base + off);
+            }
+        }
+    };
+
+    f32x4 st1 = f32x4{0, 0, 0, 0}, st2 = f32x4{0, 0, 0, 0};
+    if (item < item_end) issue_loads(item, 0);
+
+    for (; item < item_end; ++item) {
+        int f, y0, x0;
+        origin(item, f, y0, x0);
+        f32x4 acc[1][4];
+        const bool top = (y0 == 0), bot = (y0 + 4 == H), lft = (x0 == 0), rgt = (x0 + 16 == W);
+        int ex = 0;                                          // the accumulators hold (sum) 2^(ex + ew)
+
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            // ---- registers -> raw patch (BatchNorm affine + LeakyReLU of the producer), largest magnitude of the chunk ----
+            float amax = 0.f;
+            {
+                const int cg = chunk * CC;
+                const bool first = cg < c0;
+                const gcpx_conv_src& sr = first ? a.src[0] : a.src[1];
+                const int cl = first ? cg : cg - c0;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int idx = lane + 64 * k;
+                    if (idx < LH * LW * 4) {
+                        const float4 v = affine_act4(pre[k], sr.scale, sr.shift, cl + (idx & 3) * 4, sr.act);
+                        *reinterpret_cast<float4*>(raw + idx * 4) = v;
+                        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                    }
+                }
+            }
+            if (chunk + 1 < nchunk) issue_loads(item, chunk + 1);
+            else if (item + 1 < item_end) issue_loads(item + 1, 0);
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+            // bilinear values are convex combinations of the patch: |v| <= amax.  amax 2^ec in [2^14, 2^15)
+            int ec = 14 + 127 - (int)((__float_as_uint(amax) >> 23) & 0xff);
+            ec = __builtin_amdgcn_readfirstlane(amax > 0.f ? max(-100, min(min(100, 126 - ew), ec)) : min(100, 126 - ew));
+            if (chunk == 0) ex = ec;
+            else if (ec < ex) {                               // larger values than before: lower the scale, rescale the sums (exact)
+                const float r = __uint_as_float((unsigned)(127 + ec - ex) << 23);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[0][pt] *= r;
+                ex = ec;
+            }
+            const float sx2 = __uint_as_float((unsigned)(127 + ex) << 23);
+            // ---- bilinear x2 into the haloed 6 x 18 region, as two f16 planes ----
+            {
+                const int c4 = lane & 3, p = lane >> 2;
+                auto lerp_store = [&](int ry, int cx, bool zero) {
+                    const float wx1 = (cx & 1) ? 0.75f : 0.25f, wx0 = 1.f - wx1;
+                    const float wy1 = (ry & 1) ? 0.75f : 0.25f, wy0 = 1.f - wy1;
+                    const float* r = raw + (((ry >> 1) * LW + (cx >> 1)) * CC + c4 * 4);
+                    const float4 a00 = *reinterpret_cast<const float4*>(r);
+                    const float4 a01 = *reinterpret_cast<const float4*>(r + CC);
+                    const float4 a10 = *reinterpret_cast<const float4*>(r + LW * CC);
+                    const float4 a11 = *reinterpret_cast<const float4*>(r + LW * CC + CC);
+                    float4 v;
+                    v.x = wy0 * (wx0 * a00.x + wx1 * a01.x) + wy1 * (wx0 * a10.x + wx1 * a11.x);
+                    v.y = wy0 * (wx0 * a00.y + wx1 * a01.y) + wy1 * (wx0 * a10.y + wx1 * a11.y);
+                    v.z = wy0 * (wx0 * a00.z + wx1 * a01.z) + wy1 * (wx0 * a10.z + wx1 * a11.z);
+                    v.w = wy0 * (wx0 * a00.w + wx1 * a01.w) + wy1 * (wx0 * a10.w + wx1 * a11.w);
+                    if (zero) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    v.x *= sx2; v.y *= sx2; v.z *= sx2; v.w *= sx2;
+                    h4 p1, p2;
+                    p1[0] = (_Float16)v.x; p1[1] = (_Float16)v.y; p1[2] = (_Float16)v.z; p1[3] = (_Float16)v.w;
+                    p2[0] = (_Float16)(v.x - (float)p1[0]); p2[1] = (_Float16)(v.y - (float)p1[1]);
+                    p2[2] = (_Float16)(v.z - (float)p1[2]); p2[3] = (_Float16)(v.w - (float)p1[3]);
+                    char* dst = hi + (ry * RW + cx) * 32 + c4 * 8;
+                    *reinterpret_cast<h4*>(dst) = p1;
+                    *reinterpret_cast<h4*>(dst + Cfg::PLANE_BYTES) = p2;
+                };
+#pragma unroll
+                for (int ry = 0; ry < RH; ++ry)
+                    lerp_store(ry, p + 1, (top && ry == 0) || (bot && ry == RH - 1));
+                if (p < 12) {
+                    const int ry = p >> 1, side = p & 1;
+                    lerp_store(ry, side ? RW - 1 : 0,
+                               (top && ry == 0) || (bot && ry == RH - 1) || (lft && side == 0) || (rgt && side == 1));
+                }
+            }
+            // ---- MFMAs: 5 k-steps x 4 pixel groups x 3 ----
+            if (chunk == 0) mfma_tiles<0, 1, 1, true>(wl, hi, tapoff, lane, acc);
+            else mfma_tiles<0, 1, 1, false>(wl + chunk * Cfg::W_CHUNK_BYTES, hi, tapoff, lane, acc);
+        }
+        // ---- epilogue: scale back (exact), bias, raw NHWC store, BatchNorm partial sums ----
+        const float inv = __uint_as_float((unsigned)(127 - ex - ew) << 23);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            f32x4 v = acc[0][pt];
+            v[0] = fmaf(v[0], inv, bv.x); v[1] = fmaf(v[1], inv, bv.y); v[2] = fmaf(v[2], inv, bv.z); v[3] = fmaf(v[3], inv, bv.w);
+            float* obase = a.out + ((size_t)f * H + y0) * W * 16;
+            *reinterpret_cast<float4*>(obase + (unsigned)((pt * W + x0 + j) * 16 + q * 4)) = make_float4(v[0], v[1], v[2], v[3]);
+            st1 += v;
+            st2 += v * v;
+        }
+    }
+    if (a.stats_partial) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s1 = row16_sum(st1[r]);
+            const float s2 = row16_sum(st2[r]);
+            if (j == 0) {
+                red[(wave * 2 + 0) * 16 + q * 4 + r] = s1;
+                red[(wave * 2 + 1) * 16 + q * 4 + r] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int which = tid >> 4, c = tid & 15;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += red[(w * 2 + which) * 16 + c];
+            a.stats_partial[((size_t)blockIdx.x * 2 + which) * 16 + c] = sum;
+        }
+    }
+}
+
 }  // namespace
 
 // Called by conv3x3_dispatch (conv3x3.hip) for the 100-channel mixture head when the caller supplies split-f16 weights.
@@ -338,6 +538,27 @@ int gcpx_launch_head_split(const gcpx_conv_args* a, hipStream_t stream) {
     if (grid * 8 > nitems) grid = (nitems + 7) / 8;
     const int ipw = (nitems + grid * 8 - 1) / (grid * 8);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, stream, *a, ipw, nitems);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+// 16-output-channel upsampling decoder blocks with split-f16 weights (packing.pack_conv3x3_split); grid as launch_up16
+int gcpx_launch_up16_split(const gcpx_conv_args* a, hipStream_t stream, int grid) {
+    const int nchunk = a->Cin / 16;
+    const int lds = SplitUpCfg::lds_bytes(nchunk);
+    const int nitems = a->F * (a->Hout / 4) * (a->Wout / 16);
+    static int lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_up16_split_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            gcpx_set_error("conv3x3 split up16: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
+        lds_set = lds;
+    }
+    const int ipw = (nitems + grid * 8 - 1) / (grid * 8);
+    hipLaunchKernelGGL(conv3x3_up16_split_kernel, dim3(grid), dim3(512), lds, stream, *a, ipw, nitems);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

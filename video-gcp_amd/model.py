@@ -295,6 +295,10 @@ class GCPTreeModel:
         if self._hp.decoder_distribution == "discrete_logistic_mixture":
             w, e = pk.pack_conv3x3_split(self.sd["decoder.gen_head.conv.weight"], pk.dlm_channel_perm(self._hp.n_mixtures))
             self.pk_split["dec.head"] = (w.to(self.device), e)
+        for name, c_prev, c_skip, skip_idx, cout in decoder_layers(self._hp):
+            if cout == 16:                                   # the wave-autonomous 16-channel blocks (conv3x3_up16_split_kernel)
+                w, e = pk.pack_conv3x3_split(self.sd[f"decoder.net.{name}.conv.weight"])
+                self.pk_split[f"dec.{name}"] = (w.to(self.device), e)
 
     def _set_split(self, a, name):
         """Hand conv `name`'s split-f16 weights to the launch if this model runs split-f16 and holds them."""
@@ -785,6 +789,7 @@ class GCPTreeModel:
             st = self._buf(f"dec.st.{name}", (Gl, 2, cpad)) if self.training else None
             a.stats_partial = st.data_ptr() if st is not None else None
             plan.keep.append(a)
+            self._set_split(a, f"dec.{name}")
             plan.add(f"dec.{name}", lib.gcpx_conv3x3, C.byref(a))
             plan.rec["dec"]["blocks"].append(dict(name=name, srcs=srcs, out=o, res_in=res, cout=cout, c_prev=c_prev, c_skip=c_skip,
                                                   skip_idx=skip_idx))

@@ -152,6 +152,7 @@ def split_f16(w):
     |w| in [2^14, 2^15): below the f16 maximum, and the second piece of every weight within 2^-12 of the largest is a normal f16."""
     amax = float(w.abs().max())
     e = 0 if amax == 0.0 else 14 - int(torch.floor(torch.log2(torch.tensor(amax, dtype=torch.float64))))
+    assert -20 <= e <= 100, "split_f16: weight magnitude outside the range the kernels' scale bookkeeping covers"
     ws = w.double() * (2.0 ** e)
     w1 = ws.float().half()                                  # round to nearest even (the scaling is exact)
     w2 = (ws - w1.double()).float().half()
