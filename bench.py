@@ -191,6 +191,21 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
         except Exception as e:  # noqa: BLE001
             return None, repr(e)[:300]
 
+    if model.split_f16 and model.pk_split:
+        # the same forward with every conv on the exact f32 MFMA kernels (GCPX_EXACT_F32=1), for comparison
+        try:
+            model.split_f16 = False
+            model._clear_plans()
+            dt = _timed(lambda: model(dinp, "train", noise=dnoise), k, 2, world, dev)
+            res["forward_exact_f32"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
+                                        "ms_per_step": round(1e3 * dt, 3),
+                                        "workload": "the headline forward with the split-f16 convs switched off (GCPX_EXACT_F32=1): exact f32 "
+                                                    "MFMA kernels throughout"}
+        except Exception as e:  # noqa: BLE001
+            res["forward_exact_f32"] = {"error": repr(e)[:300]}
+        finally:
+            model.split_f16 = True
+            model._clear_plans()
     try:
         from video_gcp_amd.training import GCPTrainStep
         full = {k_: v.to(dev) for k_, v in inputs.items()}

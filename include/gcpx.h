@@ -94,6 +94,8 @@ typedef struct gcpx_conv_args {
                                (packing.pack_dlm_head_split / pack_conv3x3_split).  When set, kernels that have a split-f16 form run
                                it: f32-equivalent results (error of the order of one f32 rounding per product) on the f16 matrix
                                pipes, see csrc/conv3x3_split.hip.  NULL selects the exact f32 MFMA kernels */
+    const int32_t* w_split_log2_dev; /* dev or NULL: when set, the scale exponent is read from here instead of w_split_log2
+                               (weights re-split on the device after every optimizer step, gcpx_split_pack) */
 } gcpx_conv_args;
 
 /* decoder block: (bilinear x2 upsample +) 3x3 conv, pad 1.  gcpx_conv3x3_grid(a) = number of workgroups that launch
@@ -571,6 +573,11 @@ int gcpx_loss_aux_heads_bwd(const gcpx_loss_args* a, float* daction, float* dcos
 /* dst[i] = theta[idx0[i]] (+ theta[idx1[i]]), negative index = 0: every fragment-packed weight arena is a gather of the
    canonical flat parameter vector (video-gcp_amd/packing.py), refreshed once per optimizer step */
 int gcpx_repack(const float* theta, const int32_t* idx0, const int32_t* idx1, float* dst, int64_t n, void* stream);
+/* split-f16 weights from the flat parameter vector (one launch per tensor, after gcpx_repack): v[i] = theta[idx[i]] (negative = 0),
+   e = 14 - floor(log2 max|v|) (0 when all zero), *log2_out = e, and the two f16 pieces of v[i] 2^e in the layout the split kernels
+   read: out[((i / 512) * 2 + p) * 512 + i % 512], p = 0 (rn16(v 2^e)) and 1 (rn16 of the remainder); n % 512 == 0.  Same pieces as
+   packing.split_f16 on the host */
+int gcpx_split_pack(const float* theta, const int32_t* idx, int32_t n, void* out, int32_t* log2_out, void* stream);
 /* RAdam (Liu et al. 2019; blox.torch.radam.RAdam as used by gcp_builder.py:178-179): state[0] = step counter (float),
    incremented by this call; rectified update when the variance is tractable (rho_t > 5), momentum SGD otherwise */
 int gcpx_radam_step(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, float* state, int64_t n, float lr,

@@ -322,6 +322,26 @@ def test_conv3x3_head_split_error_vs_float64(env, case):
         assert_close(imgs["split"], imgs["f32"], atol=5e-6, name="mixture mean, split vs exact")
 
 
+@pytest.mark.parametrize("shape,perm10,amp", [((100, 16, 3, 3), True, 1.0), ((16, 32, 3, 3), False, 1e-3), ((16, 32, 3, 3), False, 0.0)])
+def test_split_pack_on_device_equals_host_pack(env, shape, perm10, amp):
+    """gcpx_split_pack (gather from the flat parameter vector + power-of-two scale + two f16 pieces, one launch) writes the f16 values
+    packing.pack_conv3x3_split computes on the host in float64 (compared as numbers: the sign of a zero piece is not kept)."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(2)
+    w = torch.randn(*shape) * amp
+    perm = pk.dlm_channel_perm(10) if perm10 else None
+    off = 24
+    theta = torch.cat([torch.randn(off) * 100, w.reshape(-1), torch.randn(8) * 100]).to(dev)
+    idx = pk.conv3x3_split_index(shape, off, perm).to(dev)
+    out = torch.full((2 * idx.numel(),), -1, dtype=torch.int16, device=dev)
+    e = torch.full((1,), 99, dtype=torch.int32, device=dev)
+    rt.check(lib.gcpx_split_pack(theta.data_ptr(), idx.data_ptr(), idx.numel(), out.data_ptr(), e.data_ptr(), _stream()), "split_pack")
+    torch.cuda.synchronize()
+    want, we = pk.pack_conv3x3_split(w, perm)
+    assert int(e) == we
+    assert torch.equal(out.cpu().view(torch.float16).view(want.shape), want.view(torch.float16))
+
+
 @pytest.mark.parametrize("case", ["unit", "chunk_scales", "outlier", "zero_chunk"])
 def test_conv3x3_up16_split_error_vs_float64(env, case):
     """The split-f16 16-channel decoder block against float64, next to the exact f32 kernel; the two 16-channel chunks of the input

@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
         tapoff[s] = ((tap / 3) * RW + (tap % 3) + j) * 32 + (q & 1) * 16;
     }
     const gcpx_conv_src sr = a.src[0];
-    const int ew = a.w_split_log2;
+    const int ew = a.w_split_log2_dev ? __builtin_amdgcn_readfirstlane(*a.w_split_log2_dev) : a.w_split_log2;
     // every staging slot of a lane carries the same 4 channels: their BatchNorm affine is loaded once
     float4 bn_s = make_float4(1.f, 1.f, 1.f, 1.f), bn_t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (sr.scale) {
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_up16_split_kernel(const gcpx_c
         tapoff[s] = ((tap / 3) * RW + (tap % 3) + j) * 32 + (q & 1) * 16;
     }
     const int c0 = a.src[0].C;
-    const int ew = a.w_split_log2;
+    const int ew = a.w_split_log2_dev ? __builtin_amdgcn_readfirstlane(*a.w_split_log2_dev) : a.w_split_log2;
     const float4 bv = *reinterpret_cast<const float4*>(a.bias + q * 4);
 
     const int gw = blockIdx.x * 8 + wave;
@@ -559,6 +559,50 @@ int gcpx_launch_up16_split(const gcpx_conv_args* a, hipStream_t stream, int grid
     }
     const int ipw = (nitems + grid * 8 - 1) / (grid * 8);
     hipLaunchKernelGGL(conv3x3_up16_split_kernel, dim3(grid), dim3(512), lds, stream, *a, ipw, nitems);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+namespace {
+// One 1024-thread workgroup per tensor: largest magnitude of the gathered weights -> exponent -> the two f16 pieces.
+__global__ void __launch_bounds__(1024) split_pack_kernel(const float* __restrict__ theta, const int* __restrict__ idx, const int n,
+                                                           _Float16* __restrict__ out, int* __restrict__ log2_out) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    float m = 0.f;
+    for (int i = tid; i < n; i += 1024) {
+        const int k = idx[i];
+        m = fmaxf(m, k >= 0 ? fabsf(theta[k]) : 0.f);
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    // largest magnitude times 2^e in [2^14, 2^15); the range the kernels' exponent bookkeeping covers (packing.split_f16 asserts it)
+    int e = m > 0.f ? 14 + 127 - (int)((__float_as_uint(m) >> 23) & 0xff) : 0;
+    e = max(-20, min(100, e));
+    if (tid == 0) *log2_out = e;
+    const float sc = __uint_as_float((unsigned)(127 + e) << 23);
+    for (int i = tid; i < n; i += 1024) {
+        const int k = idx[i];
+        const float v = (k >= 0 ? theta[k] : 0.f) * sc;
+        const _Float16 h1 = (_Float16)v;
+        const _Float16 h2 = (_Float16)(v - (float)h1);
+        const int o = (i >> 9) * 1024 + (i & 511);
+        out[o] = h1;
+        out[o + 512] = h2;
+    }
+}
+}  // namespace
+
+extern "C" int gcpx_split_pack(const float* theta, const int32_t* idx, int32_t n, void* out, int32_t* log2_out, void* stream_) {
+    GCPX_CHECK_ARG(theta && idx && out && log2_out, "null pointer");
+    GCPX_CHECK_ARG(n > 0 && n % 512 == 0, "n must be a positive multiple of 512");
+    hipLaunchKernelGGL(split_pack_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream_), theta, idx, n,
+                       reinterpret_cast<_Float16*>(out), log2_out);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

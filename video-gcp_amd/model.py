@@ -289,22 +289,35 @@ class GCPTreeModel:
         self._pack_split()
 
     def _pack_split(self):
-        """Inference only (as _pack_fused_embed: not a gather of theta, so not for weights that live in the trainer's arena): the two
-        f16 pieces of the conv weights that have a split-f16 kernel -> self.pk_split[name] = (int16 pack, log2 of its scale)."""
+        """The two f16 pieces of the conv weights that have a split-f16 kernel (csrc/conv3x3_split.hip).  They are gathered and split
+        on the device from the flat parameter vector (gcpx_split_pack: one small launch per tensor), at weight load and — in
+        training — after every optimizer step, right behind the fragment re-pack.  self.pk_split[name] = dict(idx, out, log2)."""
         self.pk_split = {}
-        if self._hp.decoder_distribution == "discrete_logistic_mixture":
-            w, e = pk.pack_conv3x3_split(self.sd["decoder.gen_head.conv.weight"], pk.dlm_channel_perm(self._hp.n_mixtures))
-            self.pk_split["dec.head"] = (w.to(self.device), e)
-        for name, c_prev, c_skip, skip_idx, cout in decoder_layers(self._hp):
+        hp = self._hp
+        todo = []
+        if hp.decoder_distribution == "discrete_logistic_mixture":
+            todo.append(("dec.head", "decoder.gen_head.conv.weight", pk.dlm_channel_perm(hp.n_mixtures)))
+        for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
             if cout == 16:                                   # the wave-autonomous 16-channel blocks (conv3x3_up16_split_kernel)
-                w, e = pk.pack_conv3x3_split(self.sd[f"decoder.net.{name}.conv.weight"])
-                self.pk_split[f"dec.{name}"] = (w.to(self.device), e)
+                todo.append((f"dec.{name}", f"decoder.net.{name}.conv.weight", None))
+        for name, key, perm in todo:
+            off, shp = self._poff[key]
+            idx = pk.conv3x3_split_index(shp, off, perm).to(self.device)
+            self.pk_split[name] = dict(idx=idx, out=torch.zeros(2 * idx.numel(), dtype=torch.int16, device=self.device),
+                                       log2=torch.zeros(1, dtype=torch.int32, device=self.device))
+        self.repack_split()
+
+    def repack_split(self, stream=None):
+        st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        for name, d in self.pk_split.items():
+            rt.check(self.lib.gcpx_split_pack(self.theta.data_ptr(), d["idx"].data_ptr(), d["idx"].numel(), d["out"].data_ptr(),
+                                              d["log2"].data_ptr(), st), "split_pack")
 
     def _set_split(self, a, name):
         """Hand conv `name`'s split-f16 weights to the launch if this model runs split-f16 and holds them."""
-        ws = getattr(self, "pk_split", {}).get(name)
-        if self.split_f16 and ws is not None and not self.save_for_backward and getattr(self, "_arena", None) is None:
-            a.wpk_split, a.w_split_log2 = ws[0].data_ptr(), ws[1]
+        d = getattr(self, "pk_split", {}).get(name)
+        if self.split_f16 and d is not None:
+            a.wpk_split, a.w_split_log2_dev = d["out"].data_ptr(), d["log2"].data_ptr()
 
     def _pack_fused_embed(self):
         """Inference only: the input embedding Linear and LSTM layer 0's input projection are two Linears with nothing in between
@@ -442,6 +455,7 @@ class GCPTreeModel:
         if sp < n:
             rt.check(self.lib.gcpx_repack(self.theta.data_ptr(), self._arena_idx0.data_ptr() + 4 * sp, self._arena_idx1.data_ptr() + 4 * sp,
                                           self._arena.data_ptr() + 4 * sp, n - sp, st), "repack")
+        self.repack_split(st)
 
     def _pack_hsp(self, prefix, n_layers):
         """embed Linear + n gate-interleaved LSTM layers + out Linear of one recurrent predictor."""

@@ -159,10 +159,10 @@ def split_f16(w):
     return w1, w2, e
 
 
-def pack_conv3x3_split(w, perm=None):
-    """w [Cout, 16 n, 3, 3] -> (int16 [n][5][CT][2][64][8], e): the two f16 pieces of the weights in v_mfma_f32_16x16x32_f16
-    A-fragment order for csrc/conv3x3_split.hip.  Per 16-channel input chunk, k-step s holds taps 2 s and 2 s + 1 (the 10th tap is
-    zero): lane (i = lane & 15, q = lane >> 4) element e = W[16 ct + i][chunk 16 + 8 (q & 1) + e][tap 2 s + (q >> 1)]."""
+def conv3x3_split_gather(w, perm=None):
+    """w [Cout, 16 n, 3, 3] (any dtype) -> [n][5][CT][64][8] in v_mfma_f32_16x16x32_f16 A-fragment order (pure index shuffling, zeros
+    for the 10th tap and the padded channel slots).  Per 16-channel input chunk, k-step s holds taps 2 s and 2 s + 1: lane
+    (i = lane & 15, q = lane >> 4) element el = W[16 ct + i][chunk 16 + 8 (q & 1) + el][tap 2 s + (q >> 1)]."""
     Cout, Cin = w.shape[:2]
     assert Cin % 16 == 0
     dev = w.device
@@ -175,17 +175,31 @@ def pack_conv3x3_split(w, perm=None):
     CT = (w.shape[0] + 15) // 16
     w = _pad_rows(w, CT * 16).reshape(CT * 16, Cin, 9)
     w = torch.cat([w, torch.zeros((CT * 16, Cin, 1), dtype=w.dtype, device=dev)], 2)      # tap 9 = 0
-    w1, w2, e = split_f16(w)
-    pieces = torch.stack([w1, w2], 0)                                                       # [2, CT*16, Cin, 10]
-    ch = torch.arange(Cin // 16, device=dev)[:, None, None, None, None, None]
-    s = torch.arange(5, device=dev)[None, :, None, None, None, None]
-    ct = torch.arange(CT, device=dev)[None, None, :, None, None, None]
-    p = torch.arange(2, device=dev)[None, None, None, :, None, None]
-    li = _LI.to(dev)[None, None, None, None, :, None]
-    lq = _LQ.to(dev)[None, None, None, None, :, None]
-    el = torch.arange(8, device=dev)[None, None, None, None, None, :]
-    out = pieces[p, ct * 16 + li, ch * 16 + (lq % 2) * 8 + el, 2 * s + lq // 2]             # [n, 5, CT, 2, 64, 8]
-    return out.contiguous().view(torch.int16), e
+    ch = torch.arange(Cin // 16, device=dev)[:, None, None, None, None]
+    s = torch.arange(5, device=dev)[None, :, None, None, None]
+    ct = torch.arange(CT, device=dev)[None, None, :, None, None]
+    li = _LI.to(dev)[None, None, None, :, None]
+    lq = _LQ.to(dev)[None, None, None, :, None]
+    el = torch.arange(8, device=dev)[None, None, None, None, :]
+    return w[ct * 16 + li, ch * 16 + (lq % 2) * 8 + el, 2 * s + lq // 2].contiguous()        # [n, 5, CT, 64, 8]
+
+
+def pack_conv3x3_split(w, perm=None):
+    """w [Cout, 16 n, 3, 3] -> (int16 [n][5][CT][2][64][8], e): the two f16 pieces of the weights (split_f16) in the layout of
+    conv3x3_split_gather, for csrc/conv3x3_split.hip.  The device-side equivalent is gcpx_split_pack over conv3x3_split_index."""
+    g = conv3x3_split_gather(w, perm)
+    w1, w2, e = split_f16(g)
+    return torch.stack([w1, w2], 3).contiguous().view(torch.int16), e
+
+
+def conv3x3_split_index(shape, offset, perm=None):
+    """int32 [n * 5 * CT * 512]: index into the flat parameter vector of every element of conv3x3_split_gather for a weight of
+    `shape` stored at `offset` (-1 = zero)."""
+    n = 1
+    for d in shape:
+        n *= d
+    ids = (torch.arange(n, dtype=torch.float64) + (offset + 1)).view(shape)
+    return (conv3x3_split_gather(ids, perm).reshape(-1) - 1).to(torch.int32)
 
 
 def lstm_gate_interleave(w_ih, w_hh, b_ih, b_hh):
