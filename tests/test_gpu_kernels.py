@@ -183,10 +183,9 @@ def _conv_args(rt, srcs, **kw):
 @pytest.mark.parametrize("split", [False, True])
 def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes, split):
     """decoder block: concat(prev, skip broadcast over nodes) -> affine+LReLU -> bilinear x2 -> conv3x3 (+ stats).
-    split: the split-f16 form of the 16-output-channel blocks (csrc/conv3x3_split.hip), same tolerances."""
+    split: the split-f16 forms (csrc/conv3x3_split.hip: wave-autonomous for 16 output channels, workgroup-tiled for 32 / 64), same
+    tolerances."""
     rt, pk, lib, dev = env
-    if split and cout != 16:
-        pytest.skip("split-f16 form exists for the 16-channel blocks")
     torch.manual_seed(Hin + cout)
     x = torch.randn(Fr, c_prev, Hin, Hin)
     sc, sh = torch.rand(c_prev) + 0.5, torch.randn(c_prev) * 0.2
@@ -207,7 +206,7 @@ def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes, spli
     a = _conv_args(rt, srcs, F=Fr, Hin=Hin, Win=Hin, Hout=2 * Hin, Wout=2 * Hin, Cout=cout, out_pitch=cout, upsample=1,
                    head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out, stats_partial=out)
     if split:
-        ws, e = pk.pack_conv3x3_split(w)
+        ws, e = pk.pack_conv3x3_split(w) if cout == 16 else pk.pack_conv3x3_split32(w)
         ws = ws.to(dev)
         a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
     G = lib.gcpx_conv3x3_grid(C.byref(a))
@@ -372,6 +371,54 @@ def test_conv3x3_up16_split_error_vs_float64(env, case):
         for name in ("f32", "split"):
             out = torch.full((Fr, 2 * Hin, 2 * Hin, 16), float("nan"), device=dev)
             a = _conv_args(rt, srcs, F=Fr, Hin=Hin, Win=Hin, Hout=2 * Hin, Wout=2 * Hin, Cout=16, out_pitch=16, upsample=1,
+                           head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out)
+            if name == "split":
+                a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+            rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), name)
+            torch.cuda.synchronize()
+            got = out.cpu().permute(0, 3, 1, 2).double()
+            assert torch.isfinite(got).all()
+            err[name] = (got - ref).abs()
+        scale = float(ref.abs().max())
+        assert float(err["split"].pow(2).mean().sqrt()) <= 1.5 * float(err["f32"].pow(2).mean().sqrt()) + 1e-12 * scale
+        assert float(err["split"].max()) <= 2.0 * float(err["f32"].max()) + 4e-7 * scale
+
+
+@pytest.mark.parametrize("case", ["unit", "chunk_scales", "outlier", "zero_chunk"])
+@pytest.mark.parametrize("Hin,c_prev,c_skip,cout", [(8, 64, 64, 32), (4, 128, 0, 64), (4, 64, 64, 32)])
+def test_conv3x3_up32_split_error_vs_float64(env, case, Hin, c_prev, c_skip, cout):
+    """The split-f16 32 / 64-channel decoder blocks (pyramid-1 / pyramid-2 shapes and the 8x8x4-frame tile with two channel tiles)
+    against float64, next to the exact f32 kernel; the 32-channel chunks of the input differ in magnitude by 1e4 either way (the running
+    power-of-two scale is per (tile, chunk)), carry an outlier, or are all zero."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(7)
+    Fr, nodes = 6, 3
+    cin = c_prev + c_skip
+    amp_a, amp_b = {"unit": (1, 1), "chunk_scales": (1e-2, 1e2), "outlier": (1, 1), "zero_chunk": (0, 1)}[case]
+    for order in (0, 1):
+        a_lo, a_hi = (amp_a, amp_b) if order == 0 else (amp_b, amp_a)
+        camp = torch.where(torch.arange(cin) < cin // 2, torch.tensor(float(a_lo)), torch.tensor(float(a_hi)))
+        x = torch.randn(Fr, c_prev, Hin, Hin) * camp[None, :c_prev, None, None]
+        if case == "outlier":
+            x[2, 7, 1, 2] = 2e4
+        sc, sh = torch.rand(c_prev) + 0.5, torch.randn(c_prev) * 0.2 * camp[:c_prev]
+        srcs_ref = [F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)]
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+        srcs = [(xd, c_prev, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)]
+        if c_skip:
+            sk = torch.randn(Fr // nodes, c_skip, Hin, Hin) * camp[None, c_prev:, None, None]
+            srcs_ref.append(sk.repeat_interleave(nodes, 0))
+            srcs.append((sk.permute(0, 2, 3, 1).contiguous().to(dev), c_skip, nodes, None, None, rt.ACT_NONE))
+        w, b = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.randn(cout) * 0.1
+        up = F.interpolate(torch.cat(srcs_ref, 1).double(), scale_factor=2, mode="bilinear", align_corners=False)
+        ref = F.conv2d(up, w.double(), b.double(), padding=1)
+        wp, bd = pk.pack_conv3x3(w, 32).to(dev), pk.pad_vec(b, cout).to(dev)
+        ws, e = pk.pack_conv3x3_split32(w)
+        ws = ws.to(dev)
+        err = {}
+        for name in ("f32", "split"):
+            out = torch.full((Fr, 2 * Hin, 2 * Hin, cout), float("nan"), device=dev)
+            a = _conv_args(rt, srcs, F=Fr, Hin=Hin, Win=Hin, Hout=2 * Hin, Wout=2 * Hin, Cout=cout, out_pitch=cout, upsample=1,
                            head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out)
             if name == "split":
                 a.wpk_split, a.w_split_log2 = ws.data_ptr(), e

@@ -5,7 +5,7 @@ import torch
 from video_gcp_amd import runtime as rt, packing as pk
 lib = rt.load_library(os.environ.get("GCPX_LIB"))
 dev = torch.device("cuda")
-def run(name, Fr, Hin, c_prev, c_skip, cout, nodes):
+def run(name, Fr, Hin, c_prev, c_skip, cout, nodes, split=False):
     x = torch.randn(Fr, Hin, Hin, c_prev, device=dev)
     sc, sh = torch.rand(c_prev, device=dev) + 0.5, torch.randn(c_prev, device=dev) * 0.2
     a = rt.ConvArgs()
@@ -21,6 +21,10 @@ def run(name, Fr, Hin, c_prev, c_skip, cout, nodes):
     out = torch.empty(Fr, 2 * Hin, 2 * Hin, cout, device=dev)
     a.nsrc, a.F, a.Hin, a.Win, a.Hout, a.Wout, a.Cin, a.Cout, a.out_pitch, a.upsample = n, Fr, Hin, Hin, 2 * Hin, 2 * Hin, cin, cout, cout, 1
     a.wpk, a.bias, a.out, a.stats_partial = wp.data_ptr(), b.data_ptr(), out.data_ptr(), out.data_ptr()
+    if split:
+        ws, e = pk.pack_conv3x3_split(w) if cout == 16 else pk.pack_conv3x3_split32(w)
+        ws = ws.to(dev)
+        a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
     G = lib.gcpx_conv3x3_grid(C.byref(a))
     st = torch.zeros(G, 2, (cout + 15) // 16 * 16, device=dev)
     a.stats_partial = st.data_ptr()
@@ -36,8 +40,10 @@ def run(name, Fr, Hin, c_prev, c_skip, cout, nodes):
         stq.synchronize()
     ms = e0.elapsed_time(e1) / 10
     fl = 2.0 * (2 * Hin) ** 2 * cout * cin * 9 * Fr
-    print(f"{name:8s} {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TF")
-run("addl", 2032, 32, 16, 16, 16, 127)
-run("pyr0", 2032, 16, 32, 0, 16, 1)
-run("pyr1", 2032, 8, 64, 64, 32, 127)
-run("pyr2", 2032, 4, 128, 0, 64, 1)
+    print(f"{name:12s} {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TF")
+for split in (False, True):
+    tag = " split" if split else ""
+    run("addl" + tag, 2032, 32, 16, 16, 16, 127, split)
+    run("pyr0" + tag, 2032, 16, 32, 0, 16, 1, split)
+    run("pyr1" + tag, 2032, 8, 64, 64, 32, 127, split)
+    run("pyr2" + tag, 2032, 4, 128, 0, 64, 1, split)

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 int gcpx_launch_up16_split(const gcpx_conv_args* a, hipStream_t stream, int grid);      // conv3x3_split.hip
+int gcpx_launch_up32_split(const gcpx_conv_args* a, hipStream_t stream, int which, int grid);
 
 namespace {
 
@@ -1306,6 +1307,12 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
         if (a->Cout == 16) {
             GCPX_CHECK_ARG(W % 16 == 0 && a->Hout % 4 == 0 && a->out_pitch == 16 && a->Cin <= 64, "16-channel block shape");
             return launch_up16(a, stream, query_only);
+        }
+        if (a->wpk_split && !query_only && a->Cout == CT * 16 && a->out_pitch == a->Cout && a->out_act == GCPX_ACT_NONE) {
+            // same grid as the exact kernel (launch<> in query mode): the statistics rows are the same
+            if (W == 16 && CT == 2) return gcpx_launch_up32_split(a, stream, 0, launch<true, 32, 2, 1>(a, stream, true));
+            if (W == 8 && CT == 2) return gcpx_launch_up32_split(a, stream, 1, launch<true, 32, 2, 2>(a, stream, true));
+            if (W == 8 && CT == 4) return gcpx_launch_up32_split(a, stream, 2, launch<true, 32, 4, 2>(a, stream, true));
         }
         if (W == 16 && CT == 2) return launch<true, 32, 2, 1>(a, stream, query_only);
         if (W == 8 && CT == 2) return launch<true, 32, 2, 2>(a, stream, query_only);

@@ -518,6 +518,318 @@ __global__ void __launch_bounds__(512, 2) conv3x3_up16_split_kernel(const gcpx_c
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------
+// Decoder blocks with 32 / 64 output channels at low resolution (pyramid-1: 128 -> 32 @16x16, pyramid-2: 128 -> 64 @8x8) in split-f16:
+// the workgroup-tiled scheme of conv3x3_kernel<true, 32, CT, TILE> (conv3x3.hip) — 256 output pixels per 256-thread workgroup, the
+// low-res patch of a 32-channel chunk staged f32 (BatchNorm affine + LeakyReLU applied), bilinear x2 LDS -> LDS into the haloed
+// region — with the region written as two f16 planes (64 B per pixel and plane) and one k-step = (tap, 32 channels): 9 k-steps x
+// CT x 4 pixel groups x 3 MFMAs per chunk, weights streamed from L2 one k-step ahead.  The power-of-two scale is per (tile, chunk)
+// (largest staged magnitude over the workgroup) and follows the chunks as in conv3x3_up16_split_kernel.
+// -----------------------------------------------------------------------------------------------------------
+template <int TILE> struct SplitTileShape;
+template <> struct SplitTileShape<1> { static constexpr int TH = 16, TW = 16, TF = 1; };
+template <> struct SplitTileShape<2> { static constexpr int TH = 8, TW = 8, TF = 4; };
+
+template <int CT, int TILE>
+struct SplitTileCfg {
+    using TS = SplitTileShape<TILE>;
+    static constexpr int TH = TS::TH, TW = TS::TW, TF = TS::TF, CC = 32, C4 = 8;
+    static constexpr int RH = TH + 2, RW = TW + 2, LH = TH / 2 + 2, LW = TW / 2 + 2;
+    static constexpr int PLANE_BYTES = TF * RH * RW * 64;
+    static constexpr int RAW_BYTES = TF * LH * LW * CC * 4;
+    static constexpr int LDS_BYTES = 2 * PLANE_BYTES + RAW_BYTES + 64;          // + the 4 per-wavefront maxima
+    static constexpr int NSLOT = TF * LH * LW * C4;
+    static constexpr int NS = (NSLOT + 255) / 256;
+    static constexpr int PR = TH * TW * TF / 64;
+};
+
+template <int CT, int TILE>
+__global__ void __launch_bounds__(256, 2) conv3x3_up32_split_kernel(const gcpx_conv_args a, const int ntx, const int nty, const int ntiles) {
+    using Cfg = SplitTileCfg<CT, TILE>;
+    constexpr int PR = Cfg::PR, TH = Cfg::TH, TW = Cfg::TW, TF = Cfg::TF, RH = Cfg::RH, RW = Cfg::RW;
+    constexpr int LH = Cfg::LH, LW = Cfg::LW, CC = Cfg::CC, C4 = Cfg::C4, NS = Cfg::NS, NSLOT = Cfg::NSLOT;
+    static_assert(PR == 4, "256 output pixels per workgroup");
+    extern __shared__ float4 smem4[];
+    char* hi = reinterpret_cast<char*>(smem4);
+    float* raw = reinterpret_cast<float*>(hi + 2 * Cfg::PLANE_BYTES);
+    float* wmax = reinterpret_cast<float*>(hi + 2 * Cfg::PLANE_BYTES + Cfg::RAW_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int nchunk = a.Cin / CC;
+    const int Hout = a.Hout, Wout = a.Wout, F = a.F;
+    const int ew = a.w_split_log2_dev ? __builtin_amdgcn_readfirstlane(*a.w_split_log2_dev) : a.w_split_log2;
+
+    int pixoff[PR], pfl[PR], py[PR], px[PR];
+#pragma unroll
+    for (int pt = 0; pt < PR; ++pt) {
+        const int p = (wave * PR + pt) * 16 + j;
+        pfl[pt] = p / (TH * TW);
+        const int rem = p % (TH * TW);
+        py[pt] = rem / TW;
+        px[pt] = rem % TW;
+        pixoff[pt] = ((pfl[pt] * RH + py[pt]) * RW + px[pt]) * 64 + q * 16;          // bytes: channels 8 q .. 8 q + 7
+    }
+    auto slot = [&](int k, int& c4, int& rx, int& ry, int& fl, int& lds) {
+        const int idx = tid + 256 * k;
+        c4 = idx % C4;
+        int t = idx / C4;
+        rx = t % LW; t /= LW;
+        ry = t % LH;
+        fl = (idx < NSLOT) ? t / LH : -1;
+        lds = ((fl * LH + ry) * LW + rx) * CC + c4 * 4;
+    };
+    // packed pieces: [chunk][tap][CT][2][64] x 16 B
+    const char* wbase = reinterpret_cast<const char*>(a.wpk_split) + lane * 16;
+    const int nstep = nchunk * 9;
+
+    f32x4 st1[CT], st2[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { st1[ct] = f32x4{0, 0, 0, 0}; st2[ct] = f32x4{0, 0, 0, 0}; }
+
+    float4 pre[NS];
+    unsigned pre_ok = 0;
+    auto tile_origin = [&](int tile, int& f0, int& y0, int& x0) {
+        const int tx = tile % ntx;
+        const int t2 = tile / ntx;
+        f0 = (t2 / nty) * TF; y0 = (t2 % nty) * TH; x0 = tx * TW;
+    };
+    auto issue_loads = [&](int tile, int chunk) {
+        int f0, y0, x0;
+        tile_origin(tile, f0, y0, x0);
+        pre_ok = 0;
+        const int c0 = a.src[0].C;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int s_c4, s_rx, s_ry, s_fl, s_lds;
+            slot(k, s_c4, s_rx, s_ry, s_fl, s_lds);
+            if (s_fl < 0) continue;
+            const int f = f0 + s_fl;
+            if (f < F) {
+                const int sy = min(max(y0 / 2 - 1 + s_ry, 0), a.Hin - 1);
+                const int sx = min(max(x0 / 2 - 1 + s_rx, 0), a.Win - 1);
+                const int cg = chunk * CC + s_c4 * 4;
+                const bool first = cg < c0;
+                const gcpx_conv_src& sr = first ? a.src[0] : a.src[1];
+                const int cl = first ? cg : cg - c0;
+                pre[k] = *reinterpret_cast<const float4*>(sr.ptr + (((size_t)(f / sr.frame_div) * a.Hin + sy) * a.Win + sx) * sr.C + cl);
+                pre_ok |= 1u << k;
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue_loads(tile, 0);
+    for (; tile < ntiles; tile += gridDim.x) {
+        int f0, y0, x0;
+        tile_origin(tile, f0, y0, x0);
+        f32x4 acc[CT][PR];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
+        int ex = 0;                                                   // the accumulators hold (sum) 2^(ex + ew)
+        const bool top = (y0 == 0), bot = (y0 + TH == Hout), lft = (x0 == 0), rgt = (x0 + TW == Wout);
+
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            // ---- registers -> low-res patch (affine + LeakyReLU), largest magnitude of the chunk over the workgroup ----
+            float amax = 0.f;
+            {
+                const int c0 = a.src[0].C;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    int s_c4, s_rx, s_ry, s_fl, s_lds;
+                    slot(k, s_c4, s_rx, s_ry, s_fl, s_lds);
+                    if (s_fl < 0) continue;
+                    float4 v = pre[k];
+                    if (pre_ok & (1u << k)) {
+                        const int cg = chunk * CC + s_c4 * 4;
+                        const bool first = cg < c0;
+                        const gcpx_conv_src& sr = first ? a.src[0] : a.src[1];
+                        v = affine_act4(v, sr.scale, sr.shift, first ? cg : cg - c0, sr.act);
+                    }
+                    *reinterpret_cast<float4*>(raw + s_lds) = v;
+                    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+            if (lane == 0) wmax[wave] = amax;
+            __syncthreads();                       // patch complete, previous chunk's reads of the region done, maxima visible
+            amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            int ec = 14 + 127 - (int)((__float_as_uint(amax) >> 23) & 0xff);
+            ec = __builtin_amdgcn_readfirstlane(amax > 0.f ? max(-100, min(min(100, 126 - ew), ec)) : min(100, 126 - ew));
+            if (chunk == 0) ex = ec;
+            else if (ec < ex) {
+                const float r = __uint_as_float((unsigned)(127 + ec - ex) << 23);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PR; ++pt) acc[ct][pt] *= r;
+                ex = ec;
+            }
+            const float sx2 = __uint_as_float((unsigned)(127 + ex) << 23);
+            // ---- bilinear x2 (align_corners=False) LDS -> LDS, written as two f16 planes (index algebra: conv3x3_kernel) ----
+            {
+                const int c4 = tid & (C4 - 1);
+                const int p = tid >> 3;                                   // 0..31
+                constexpr int RPP = 32 / (TW * TF);                       // region rows per pass (2 for 16x16, 1 for 8x8x4)
+                const int fl = (TF > 1) ? p / TW : 0;
+                const int rx = p % TW;
+                const int rsub = (RPP == 2) ? (p / TW) : 0;
+                auto lerp_store = [&](int f2, int ry, int cx, bool zero) {
+                    const float wx1 = (cx & 1) ? 0.75f : 0.25f, wx0 = 1.f - wx1;
+                    const float wy1 = ((ry & 1) ? 0.75f : 0.25f), wy0 = 1.f - wy1;
+                    const float* r = raw + ((f2 * LH + (ry >> 1)) * LW + (cx >> 1)) * CC + c4 * 4;
+                    const float4 a00 = *reinterpret_cast<const float4*>(r);
+                    const float4 a01 = *reinterpret_cast<const float4*>(r + CC);
+                    const float4 a10 = *reinterpret_cast<const float4*>(r + LW * CC);
+                    const float4 a11 = *reinterpret_cast<const float4*>(r + LW * CC + CC);
+                    float4 v;
+                    v.x = wy0 * (wx0 * a00.x + wx1 * a01.x) + wy1 * (wx0 * a10.x + wx1 * a11.x);
+                    v.y = wy0 * (wx0 * a00.y + wx1 * a01.y) + wy1 * (wx0 * a10.y + wx1 * a11.y);
+                    v.z = wy0 * (wx0 * a00.z + wx1 * a01.z) + wy1 * (wx0 * a10.z + wx1 * a11.z);
+                    v.w = wy0 * (wx0 * a00.w + wx1 * a01.w) + wy1 * (wx0 * a10.w + wx1 * a11.w);
+                    const float sc = zero ? 0.f : sx2;
+                    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                    h4 p1, p2;
+                    p1[0] = (_Float16)v.x; p1[1] = (_Float16)v.y; p1[2] = (_Float16)v.z; p1[3] = (_Float16)v.w;
+                    p2[0] = (_Float16)(v.x - (float)p1[0]); p2[1] = (_Float16)(v.y - (float)p1[1]);
+                    p2[2] = (_Float16)(v.z - (float)p1[2]); p2[3] = (_Float16)(v.w - (float)p1[3]);
+                    char* dst = hi + ((f2 * RH + ry) * RW + cx) * 64 + c4 * 8;
+                    *reinterpret_cast<h4*>(dst) = p1;
+                    *reinterpret_cast<h4*>(dst + Cfg::PLANE_BYTES) = p2;
+                };
+#pragma unroll 2
+                for (int k = 0; k < RH / RPP; ++k) {
+                    const int ry = k * RPP + rsub;
+                    lerp_store(fl, ry, rx + 1, (top && ry == 0) || (bot && ry == RH - 1));
+                }
+                for (int e = p; e < TF * RH * 2; e += 32) {
+                    const int side = e & 1;
+                    const int ry = (e >> 1) % RH, f2 = (e >> 1) / RH;
+                    lerp_store(f2, ry, side ? RW - 1 : 0,
+                               (top && ry == 0) || (bot && ry == RH - 1) || (lft && side == 0) || (rgt && side == 1));
+                }
+            }
+            __syncthreads();
+            if (chunk + 1 < nchunk) issue_loads(tile, chunk + 1);
+            else if (tile + (int)gridDim.x < ntiles) issue_loads(tile + gridDim.x, 0);
+
+            // ---- MFMAs: 9 k-steps (tap, 32 channels) x CT x 4 pixel groups x 3 ----
+            h8 wn[CT][2];
+            {
+                const char* wp = wbase + (size_t)(chunk * 9) * CT * 2048;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    wn[ct][0] = *reinterpret_cast<const h8*>(wp + ct * 2048);
+                    wn[ct][1] = *reinterpret_cast<const h8*>(wp + ct * 2048 + 1024);
+                }
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int tapoff = ((tap / 3) * RW + (tap % 3)) * 64;
+                h8 wc[CT][2];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) { wc[ct][0] = wn[ct][0]; wc[ct][1] = wn[ct][1]; }
+                {
+                    const int stn = min(chunk * 9 + tap + 1, nstep - 1);        // one k-step ahead (the last one re-reads itself)
+                    const char* wp = wbase + (size_t)stn * CT * 2048;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        wn[ct][0] = *reinterpret_cast<const h8*>(wp + ct * 2048);
+                        wn[ct][1] = *reinterpret_cast<const h8*>(wp + ct * 2048 + 1024);
+                    }
+                }
+                h8 b1[PR], b2[PR];
+#pragma unroll
+                for (int pt = 0; pt < PR; ++pt) {
+                    b1[pt] = *reinterpret_cast<const h8*>(hi + pixoff[pt] + tapoff);
+                    b2[pt] = *reinterpret_cast<const h8*>(hi + pixoff[pt] + tapoff + Cfg::PLANE_BYTES);
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                    for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma32h(wc[ct][1], b1[pt], acc[ct][pt]);
+#pragma unroll
+                    for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma32h(wc[ct][0], b2[pt], acc[ct][pt]);
+#pragma unroll
+                    for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma32h(wc[ct][0], b1[pt], acc[ct][pt]);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+
+        // ---- epilogue: scale back (exact), bias, raw NHWC store, BatchNorm partial sums ----
+        const float inv = __uint_as_float((unsigned)(127 - ex - ew) << 23);
+#pragma unroll
+        for (int pt = 0; pt < PR; ++pt) {
+            const int f = f0 + pfl[pt];
+            if (f >= F) continue;
+            float* op = a.out + (((size_t)f * Hout + (y0 + py[pt])) * Wout + (x0 + px[pt])) * a.out_pitch;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + ct * 16 + q * 4);
+                f32x4 v = acc[ct][pt];
+                v[0] = fmaf(v[0], inv, bv.x); v[1] = fmaf(v[1], inv, bv.y); v[2] = fmaf(v[2], inv, bv.z); v[3] = fmaf(v[3], inv, bv.w);
+                *reinterpret_cast<float4*>(op + ct * 16 + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                if (a.stats_partial) {
+                    st1[ct] += v;
+                    st2[ct] += v * v;
+                }
+            }
+        }
+    }
+
+    if (a.stats_partial) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(hi);   // [4 waves][2][CT*16]
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = row16_sum(st1[ct][r]);
+                const float s2 = row16_sum(st2[ct][r]);
+                if (j == 0) {
+                    red[(wave * 2 + 0) * CT * 16 + ct * 16 + q * 4 + r] = s1;
+                    red[(wave * 2 + 1) * CT * 16 + ct * 16 + q * 4 + r] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * CT * 16) {
+            const int which = tid / (CT * 16), c = tid % (CT * 16);
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) sum += red[(w * 2 + which) * CT * 16 + c];
+            a.stats_partial[((size_t)blockIdx.x * 2 + which) * CT * 16 + c] = sum;
+        }
+    }
+}
+
+template <int CT, int TILE>
+int launch_up32_split(const gcpx_conv_args* a, hipStream_t stream, int grid) {
+    using Cfg = SplitTileCfg<CT, TILE>;
+    const int ntx = a->Wout / Cfg::TW, nty = a->Hout / Cfg::TH;
+    const int nfg = (a->F + Cfg::TF - 1) / Cfg::TF;
+    auto kern = conv3x3_up32_split_kernel<CT, TILE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) {
+            gcpx_set_error("conv3x3 split up32: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, *a, ntx, nty, ntx * nty * nfg);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
 }  // namespace
 
 // Called by conv3x3_dispatch (conv3x3.hip) for the 100-channel mixture head when the caller supplies split-f16 weights.
@@ -605,4 +917,12 @@ extern "C" int gcpx_split_pack(const float* theta, const int32_t* idx, int32_t n
                        reinterpret_cast<_Float16*>(out), log2_out);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
+}
+
+// 32 / 64-output-channel upsampling blocks (Cin % 32 == 0) with split-f16 weights (packing.pack_conv3x3_split32): which = 0 for the
+// 16x16 tile with 2 channel tiles, 1 for 8x8x4 with 2, 2 for 8x8x4 with 4; grid as conv3x3.hip's launch<> computes it
+int gcpx_launch_up32_split(const gcpx_conv_args* a, hipStream_t stream, int which, int grid) {
+    if (which == 0) return launch_up32_split<2, 1>(a, stream, grid);
+    if (which == 1) return launch_up32_split<2, 2>(a, stream, grid);
+    return launch_up32_split<4, 2>(a, stream, grid);
 }

@@ -300,9 +300,11 @@ class GCPTreeModel:
         for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
             if cout == 16:                                   # the wave-autonomous 16-channel blocks (conv3x3_up16_split_kernel)
                 todo.append((f"dec.{name}", f"decoder.net.{name}.conv.weight", None))
+            elif cout in (32, 64) and (c_prev + c_skip) % 32 == 0:     # the workgroup-tiled blocks (conv3x3_up32_split_kernel)
+                todo.append((f"dec.{name}", f"decoder.net.{name}.conv.weight", "tiled32"))
         for name, key, perm in todo:
             off, shp = self._poff[key]
-            idx = pk.conv3x3_split_index(shp, off, perm).to(self.device)
+            idx = (pk.conv3x3_split32_index(shp, off) if perm == "tiled32" else pk.conv3x3_split_index(shp, off, perm)).to(self.device)
             self.pk_split[name] = dict(idx=idx, out=torch.zeros(2 * idx.numel(), dtype=torch.int16, device=self.device),
                                        log2=torch.zeros(1, dtype=torch.int32, device=self.device))
         self.repack_split()

@@ -202,6 +202,37 @@ def conv3x3_split_index(shape, offset, perm=None):
     return (conv3x3_split_gather(ids, perm).reshape(-1) - 1).to(torch.int32)
 
 
+def conv3x3_split32_gather(w):
+    """w [16 CT, 32 n, 3, 3] -> [n][9 taps][CT][64][8] for conv3x3_up32_split_kernel: one k-step = (tap, 32-channel chunk);
+    lane (i = lane & 15, q = lane >> 4) element el = W[16 ct + i][32 chunk + 8 q + el][tap]."""
+    Cout, Cin = w.shape[:2]
+    assert Cin % 32 == 0 and Cout % 16 == 0
+    dev = w.device
+    CT = Cout // 16
+    w = w.reshape(Cout, Cin, 9)
+    ch = torch.arange(Cin // 32, device=dev)[:, None, None, None, None]
+    tap = torch.arange(9, device=dev)[None, :, None, None, None]
+    ct = torch.arange(CT, device=dev)[None, None, :, None, None]
+    li = _LI.to(dev)[None, None, None, :, None]
+    lq = _LQ.to(dev)[None, None, None, :, None]
+    el = torch.arange(8, device=dev)[None, None, None, None, :]
+    return w[ct * 16 + li, ch * 32 + lq * 8 + el, tap].contiguous()
+
+
+def pack_conv3x3_split32(w):
+    """-> (int16 [n][9][CT][2][64][8], e): the two f16 pieces in the layout of conv3x3_split32_gather"""
+    w1, w2, e = split_f16(conv3x3_split32_gather(w))
+    return torch.stack([w1, w2], 3).contiguous().view(torch.int16), e
+
+
+def conv3x3_split32_index(shape, offset):
+    n = 1
+    for d in shape:
+        n *= d
+    ids = (torch.arange(n, dtype=torch.float64) + (offset + 1)).view(shape)
+    return (conv3x3_split32_gather(ids).reshape(-1) - 1).to(torch.int32)
+
+
 def lstm_gate_interleave(w_ih, w_hh, b_ih, b_hh):
     """[4H, H] x2 (torch gate order i, f, g, o) -> W [4H, 2H] with row n = 4u + gate, bias [4H] likewise."""
     H = w_hh.shape[1]                                       # (w_ih may be wider than H: embedding folded into layer 0)
