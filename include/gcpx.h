@@ -96,7 +96,13 @@ typedef struct gcpx_conv_args {
                                pipes, see csrc/conv3x3_split.hip.  NULL selects the exact f32 MFMA kernels */
     const int32_t* w_split_log2_dev; /* dev or NULL: when set, the scale exponent is read from here instead of w_split_log2
                                (weights re-split on the device after every optimizer step, gcpx_split_pack) */
+    int32_t split_layout;   /* layout of wpk_split: GCPX_SPLIT_PLAIN (the conv's own 3x3 taps) or GCPX_SPLIT_ROWFOLD (upsampling blocks
+                               with 32 -> 16 channels: the vertical half of the bilinear x2 folded into the weights, see
+                               gcpx_fold_upsample_weights) */
+    int32_t _pad2;
 } gcpx_conv_args;
+
+typedef enum gcpx_split_layout { GCPX_SPLIT_PLAIN = 0, GCPX_SPLIT_ROWFOLD = 1 } gcpx_split_layout;
 
 /* decoder block: (bilinear x2 upsample +) 3x3 conv, pad 1.  gcpx_conv3x3_grid(a) = number of workgroups that launch
    will use = rows of a->stats_partial (a->stats_partial must already be non-NULL in the query if it will be). */
@@ -578,6 +584,16 @@ int gcpx_repack(const float* theta, const int32_t* idx0, const int32_t* idx1, fl
    read: out[((i / 512) * 2 + p) * 512 + i % 512], p = 0 (rn16(v 2^e)) and 1 (rn16 of the remainder); n % 512 == 0.  Same pieces as
    packing.split_f16 on the host */
 int gcpx_split_pack(const float* theta, const int32_t* idx, int32_t n, void* out, int32_t* log2_out, void* stream);
+/* Row-folded weights of an upsampling decoder block (bilinear x2, align_corners=False, then 3x3 conv, pad 1 — DecoderModule's
+   pyramid / additional_conv_layer blocks, blox; called through gcp/prediction/models/tree/tree_dense_rec.py:42).  Output row
+   2 y + py of the block reads the three low-resolution rows y - 1, y, y + 1 (clamped) of the horizontally interpolated input with
+   weights that are fixed linear combinations of the conv's three tap rows:
+       py = 0:  [0.75 W0 + 0.25 W1,  0.25 W0 + 0.75 W1 + 0.75 W2,  0.25 W2]
+       py = 1:  [0.25 W0,  0.75 W0 + 0.75 W1 + 0.25 W2,  0.25 W1 + 0.75 W2]
+   and the conv's zero padding above row 0 / below the last row is restored by the correction sets -W0 (on the clamped row above)
+   and -W2 (on the clamped row below).  w: dev [Cout][Cin][3][3]; out: dev f32 [24][Cout][Cin], set t = py 9 + dyl 3 + tx for
+   t < 18, 18 + tx = -W0[tx], 21 + tx = -W2[tx]; sums formed in float64 in tap-row order (bit-identical to packing.fold_up_weights). */
+int gcpx_fold_upsample_weights(const float* w, int32_t Cout, int32_t Cin, float* out, void* stream);
 /* RAdam (Liu et al. 2019; blox.torch.radam.RAdam as used by gcp_builder.py:178-179): state[0] = step counter (float),
    incremented by this call; rectified update when the variance is tractable (rho_t > 5), momentum SGD otherwise */
 int gcpx_radam_step(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, float* state, int64_t n, float lr,

@@ -180,12 +180,14 @@ def _conv_args(rt, srcs, **kw):
 
 @pytest.mark.parametrize("Hin,c_prev,c_skip,cout,Fr,nodes", [(32, 16, 16, 16, 6, 3), (16, 32, 0, 16, 5, 1), (8, 64, 64, 32, 6, 2),
                                                              (4, 128, 0, 64, 7, 1), (4, 64, 64, 32, 6, 3), (8, 32, 0, 16, 4, 1)])
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [False, True, "fold"])
 def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes, split):
     """decoder block: concat(prev, skip broadcast over nodes) -> affine+LReLU -> bilinear x2 -> conv3x3 (+ stats).
     split: the split-f16 forms (csrc/conv3x3_split.hip: wave-autonomous for 16 output channels, workgroup-tiled for 32 / 64), same
-    tolerances."""
+    tolerances.  fold: the row-folded form of the 32 -> 16 channel blocks (GCPX_SPLIT_ROWFOLD)."""
     rt, pk, lib, dev = env
+    if split == "fold" and not (cout == 16 and c_prev + c_skip == 32 and Hin % 4 == 0):
+        pytest.skip("row-folded form: 32 -> 16 channels")
     torch.manual_seed(Hin + cout)
     x = torch.randn(Fr, c_prev, Hin, Hin)
     sc, sh = torch.rand(c_prev) + 0.5, torch.randn(c_prev) * 0.2
@@ -205,7 +207,11 @@ def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes, spli
     out = torch.full((Fr, 2 * Hin, 2 * Hin, cout), float("nan"), device=dev)
     a = _conv_args(rt, srcs, F=Fr, Hin=Hin, Win=Hin, Hout=2 * Hin, Wout=2 * Hin, Cout=cout, out_pitch=cout, upsample=1,
                    head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out, stats_partial=out)
-    if split:
+    if split == "fold":
+        ws, e = pk.pack_conv3x3_fold(w)
+        ws = ws.to(dev)
+        a.wpk_split, a.w_split_log2, a.split_layout = ws.data_ptr(), e, rt.SPLIT_ROWFOLD
+    elif split:
         ws, e = pk.pack_conv3x3_split(w) if cout == 16 else pk.pack_conv3x3_split32(w)
         ws = ws.to(dev)
         a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
@@ -382,6 +388,71 @@ def test_conv3x3_up16_split_error_vs_float64(env, case):
         scale = float(ref.abs().max())
         assert float(err["split"].pow(2).mean().sqrt()) <= 1.5 * float(err["f32"].pow(2).mean().sqrt()) + 1e-12 * scale
         assert float(err["split"].max()) <= 2.0 * float(err["f32"].max()) + 4e-7 * scale
+
+
+@pytest.mark.parametrize("case", ["unit", "tiny", "large", "outlier", "zero", "zero_skip"])
+@pytest.mark.parametrize("Hin,c_prev,c_skip", [(32, 16, 16), (16, 32, 0), (8, 16, 16)])
+def test_conv3x3_up16_fold_error_vs_float64(env, case, Hin, c_prev, c_skip):
+    """The row-folded split-f16 32 -> 16 channel decoder blocks (additional_conv_layer / pyramid-0 shapes, and the smallest
+    image the kernel takes: every item carries a border correction) against float64, next to the exact f32 kernel: the folded weights are f32
+    roundings of float64 sums, the border rows subtract the -W0 / -W2 correction — the error stays of the size of the exact
+    kernel's whatever the magnitude of the data."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(13)
+    Fr, nodes = 6, 3
+    amp = {"unit": 1.0, "tiny": 1e-3, "large": 300.0, "outlier": 1.0, "zero": 0.0, "zero_skip": 1.0}[case]
+    x = torch.randn(Fr, c_prev, Hin, Hin) * amp
+    if case == "outlier":
+        x[1, 3, Hin // 2, 1] = 2e4
+    sc, sh = torch.rand(c_prev) + 0.5, torch.randn(c_prev) * 0.2 * amp
+    srcs_ref = [F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)]
+    srcs = [(x.permute(0, 2, 3, 1).contiguous().to(dev), c_prev, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)]
+    if c_skip:
+        sk = torch.randn(Fr // nodes, c_skip, Hin, Hin) * (0.0 if case == "zero_skip" else amp)
+        srcs_ref.append(sk.repeat_interleave(nodes, 0))
+        srcs.append((sk.permute(0, 2, 3, 1).contiguous().to(dev), c_skip, nodes, None, None, rt.ACT_NONE))
+    w, b = torch.randn(16, 32, 3, 3) / (9 * 32) ** 0.5, torch.randn(16) * 0.1
+    up = F.interpolate(torch.cat(srcs_ref, 1).double(), scale_factor=2, mode="bilinear", align_corners=False)
+    ref = F.conv2d(up, w.double(), b.double(), padding=1)
+    wp, bd = pk.pack_conv3x3(w, 16).to(dev), pk.pad_vec(b, 16).to(dev)
+    ws, e = pk.pack_conv3x3_fold(w)
+    ws = ws.to(dev)
+    err = {}
+    for name in ("f32", "fold"):
+        out = torch.full((Fr, 2 * Hin, 2 * Hin, 16), float("nan"), device=dev)
+        a = _conv_args(rt, srcs, F=Fr, Hin=Hin, Win=Hin, Hout=2 * Hin, Wout=2 * Hin, Cout=16, out_pitch=16, upsample=1,
+                       head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out)
+        if name == "fold":
+            a.wpk_split, a.w_split_log2, a.split_layout = ws.data_ptr(), e, rt.SPLIT_ROWFOLD
+        rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), name)
+        torch.cuda.synchronize()
+        got = out.cpu().permute(0, 3, 1, 2).double()
+        assert torch.isfinite(got).all()
+        err[name] = (got - ref).abs()
+    scale = float(ref.abs().max())
+    # the fold adds one f32 rounding per folded weight and the border correction one more: 2x the exact kernel's rms, 3x its max
+    assert float(err["fold"].pow(2).mean().sqrt()) <= 2.0 * float(err["f32"].pow(2).mean().sqrt()) + 1e-12 * scale
+    assert float(err["fold"].max()) <= 3.0 * float(err["f32"].max()) + 6e-7 * scale
+
+
+def test_fold_pack_on_device_equals_host_pack(env):
+    """gcpx_fold_upsample_weights + gcpx_split_pack over packing.conv3x3_fold_index write the pieces packing.pack_conv3x3_fold computes"""
+    rt, pk, lib, dev = env
+    torch.manual_seed(4)
+    w = torch.randn(16, 32, 3, 3) * 0.3
+    wd = w.to(dev)
+    scratch = torch.full((24, 16, 32), float("nan"), device=dev)
+    rt.check(lib.gcpx_fold_upsample_weights(wd.data_ptr(), 16, 32, scratch.data_ptr(), _stream()), "fold")
+    torch.cuda.synchronize()
+    assert torch.equal(scratch.cpu(), pk.fold_up_weights(w))
+    idx = pk.conv3x3_fold_index().to(dev)
+    out = torch.full((2 * idx.numel(),), -1, dtype=torch.int16, device=dev)
+    e = torch.full((1,), 99, dtype=torch.int32, device=dev)
+    rt.check(lib.gcpx_split_pack(scratch.data_ptr(), idx.data_ptr(), idx.numel(), out.data_ptr(), e.data_ptr(), _stream()), "split_pack")
+    torch.cuda.synchronize()
+    want, we = pk.pack_conv3x3_fold(w)
+    assert int(e) == we
+    assert torch.equal(out.cpu().view(torch.float16).view(want.shape), want.view(torch.float16))
 
 
 @pytest.mark.parametrize("case", ["unit", "chunk_scales", "outlier", "zero_chunk"])

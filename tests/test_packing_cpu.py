@@ -111,3 +111,33 @@ def test_pack_conv3x3_split_layout():
         co, ci, tap = 16 * ct + i, 16 * chunk + 8 * (q & 1) + el, 2 * s + (q >> 1)
         want = float(w[co, ci, tap // 3, tap % 3]) if co < 40 and tap < 9 else 0.0
         assert abs(float(rec[chunk, s, ct, lane, el]) - want) <= 2.0 ** -22 * abs(want)
+
+
+def test_fold_up_weights_reproduces_upsample_conv():
+    """packing.fold_up_weights: bilinear x2 (align_corners=False) + 3x3 conv (pad 1) == per output-row parity a 3x3 conv over the
+    horizontally interpolated low-resolution rows (replicate rows, zero columns) with the folded weights, plus the -W0 / -W2
+    corrections on the first / last output row (what conv3x3_up16_fold_kernel computes)."""
+    import torch.nn.functional as F
+    from video_gcp_amd import packing as pk
+    torch.manual_seed(3)
+    Fr, Cin, Cout, Hin, Win = 2, 32, 16, 4, 8
+    x = torch.randn(Fr, Cin, Hin, Win, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, 3, 3)
+    want = F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False), w.double(), padding=1)
+    fw = pk.fold_up_weights(w).double()                                     # [24, Cout, Cin]
+    hx = F.interpolate(x, scale_factor=(1, 2), mode="bilinear", align_corners=False)        # horizontal half only
+    hxp = F.pad(F.pad(hx, (1, 1, 0, 0)), (0, 0, 1, 1), mode="replicate")    # zero columns, replicate rows
+    got = torch.zeros_like(want)
+    for py in range(2):
+        k = fw[py * 9:(py + 1) * 9].reshape(3, 3, Cout, Cin).permute(2, 3, 0, 1)             # [Cout, Cin, dyl, tx]
+        got[:, :, py::2] = F.conv2d(hxp, k)
+    ktop = fw[18:21].permute(1, 2, 0)[:, :, None, :]                        # [Cout, Cin, 1, tx]
+    kbot = fw[21:24].permute(1, 2, 0)[:, :, None, :]
+    got[:, :, 0:1] += F.conv2d(hxp[:, :, 0:1], ktop)
+    got[:, :, -1:] += F.conv2d(hxp[:, :, -1:], kbot)
+    assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
+    # fragment order: lane (i, q) element el = fw[t][i][8 q + el]; the index form addresses the same elements
+    g = pk.conv3x3_fold_gather(pk.fold_up_weights(w))
+    assert float(g[5, 16 * 2 + 3, 4]) == float(pk.fold_up_weights(w)[5, 3, 20])
+    idx = pk.conv3x3_fold_index()
+    assert torch.equal(pk.fold_up_weights(w).reshape(-1)[idx.long()].view(24, 64, 8), g)

@@ -3,7 +3,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-heads = [i for i, r in enumerate(rows) if 'conv3x3_head_kernel' in r['Kernel_Name']]
+heads = [i for i, r in enumerate(rows) if 'conv3x3_head' in r['Kernel_Name']]
 # one forward = from the end of the previous head kernel to the end of the last one
 a, b = heads[-2], heads[-1]
 seg = rows[a + 1:b + 1]

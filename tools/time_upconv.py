@@ -21,7 +21,13 @@ def run(name, Fr, Hin, c_prev, c_skip, cout, nodes, split=False):
     out = torch.empty(Fr, 2 * Hin, 2 * Hin, cout, device=dev)
     a.nsrc, a.F, a.Hin, a.Win, a.Hout, a.Wout, a.Cin, a.Cout, a.out_pitch, a.upsample = n, Fr, Hin, Hin, 2 * Hin, 2 * Hin, cin, cout, cout, 1
     a.wpk, a.bias, a.out, a.stats_partial = wp.data_ptr(), b.data_ptr(), out.data_ptr(), out.data_ptr()
-    if split:
+    if split == "fold":
+        if not (cout == 16 and cin == 32):
+            return
+        ws, e = pk.pack_conv3x3_fold(w)
+        ws = ws.to(dev)
+        a.wpk_split, a.w_split_log2, a.split_layout = ws.data_ptr(), e, rt.SPLIT_ROWFOLD
+    elif split:
         ws, e = pk.pack_conv3x3_split(w) if cout == 16 else pk.pack_conv3x3_split32(w)
         ws = ws.to(dev)
         a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
@@ -41,8 +47,13 @@ def run(name, Fr, Hin, c_prev, c_skip, cout, nodes, split=False):
     ms = e0.elapsed_time(e1) / 10
     fl = 2.0 * (2 * Hin) ** 2 * cout * cin * 9 * Fr
     print(f"{name:12s} {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TF")
-for split in (False, True):
-    tag = " split" if split else ""
+only = sys.argv[1:]            # e.g. "addl fold" "pyr0 fold": run just these
+_run = run
+def run(name, *args):
+    if not only or name in only:
+        _run(name, *args)
+for split in (False, True, "fold"):
+    tag = " fold" if split == "fold" else " split" if split else ""
     run("addl" + tag, 2032, 32, 16, 16, 16, 127, split)
     run("pyr0" + tag, 2032, 16, 32, 0, 16, 1, split)
     run("pyr1" + tag, 2032, 8, 64, 64, 32, 127, split)

@@ -21,6 +21,7 @@
 
 int gcpx_launch_up16_split(const gcpx_conv_args* a, hipStream_t stream, int grid);      // conv3x3_split.hip
 int gcpx_launch_up32_split(const gcpx_conv_args* a, hipStream_t stream, int which, int grid);
+int gcpx_launch_up16_fold(const gcpx_conv_args* a, hipStream_t stream, int grid);
 
 namespace {
 
@@ -1177,6 +1178,7 @@ int launch_up16(const gcpx_conv_args* a, hipStream_t stream, bool query_only) {
     const int nitems = a->F * (a->Hout / 4) * (a->Wout / 16);
     if (!a->stats_partial && grid * 8 > nitems) grid = (nitems + 7) / 8;
     if (query_only) return grid;
+    if (a->wpk_split && a->split_layout == GCPX_SPLIT_ROWFOLD) return gcpx_launch_up16_fold(a, stream, grid);
     if (a->wpk_split) return gcpx_launch_up16_split(a, stream, grid);
     static int lds_set = 0;
     if (lds > lds_set) {

@@ -20,6 +20,7 @@
 // and runs 5 k-steps (two taps x 16 channels = K 32 each; the 10th tap has zero weights) x 7 x 4 tiles x 3 MFMAs.
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -830,6 +831,328 @@ int launch_up32_split(const gcpx_conv_args* a, hipStream_t stream, int grid) {
     return GCPX_OK;
 }
 
+
+// -----------------------------------------------------------------------------------------------------------
+// Decoder blocks with 32 input and 16 output channels (pyramid-0, additional_conv_layer) with the VERTICAL half of the bilinear x2
+// folded into the weights (gcpx_fold_upsample_weights).  conv3x3_up16_split_kernel is bound by its LDS traffic and staging VALU: every
+// 16-pixel B fragment serves only three MFMAs, and the region is interpolated from four corners per element at full resolution.
+// Folding the rows turns output rows 2 y and 2 y + 1 into two 3x3 convs over the SAME three horizontally-interpolated low-resolution
+// rows y - 1 .. y + 1:
+//   * the staged region has R + 2 low-resolution rows for 2 R output rows (two corners per element, half as many rows);
+//   * a B fragment (row, tx) is read once per item and serves up to 3 rows x 2 parities x 3 MFMAs;
+//   * one k-step = one (row tap, tx) x 32 channels: 9 k-steps per output group, no padded tenth tap.
+// The conv's zero padding in x is exact (the out-of-image region columns are zero); in y the fold implies replicate padding, and the
+// conv's zero row above row 0 / below row H - 1 is restored by three extra k-steps with -W0 / -W2 on the clamped border row (its
+// horizontally interpolated values are exactly what the folded weights multiplied W0 / W2 with).
+// One power-of-two scale per item (largest staged magnitude of the raw patch: the interpolated values are convex combinations).
+// -----------------------------------------------------------------------------------------------------------
+struct FoldCfg {
+    static constexpr int R = 4;                                    // low-resolution rows per item: 8 output rows x 16 columns
+    static constexpr int PR = R + 2, PW = 10, RW = 18;             // raw patch rows / columns (low-res), region columns (hi-res)
+    static constexpr int RAW_BYTES = PR * PW * 32 * 4;             // 7680: f32 patch, aliases the start of the planes
+    static constexpr int PLANE_BYTES = PR * RW * 64;               // 6912: one f16 piece, 32 channels x 2 B per pixel
+    static constexpr int WAVE_BYTES = 2 * PLANE_BYTES;             // 13824
+    static constexpr int NT = 24;                                  // fragment sets: 2 parities x 9 taps + 2 x 3 corrections
+    static constexpr int W_BYTES = NT * 2048;                      // 49152
+    static constexpr int LDS_BYTES = W_BYTES + 8 * WAVE_BYTES + 8 * 2 * 16 * 4;      // 160768 of 163840
+    static constexpr int NS = (PR * PW * 8 + 63) / 64;             // raw float4 slots per lane (8)
+    static constexpr int NO = (PR * RW * 8 + 63) / 64;             // region float4 outputs per lane (14)
+};
+
+// largest value over the wavefront without the LDS crossbar: DPP inside the 16-lane rows, v_readlane across them (wave-uniform result)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    auto dpp = [](float x, auto ctrl) __attribute__((always_inline)) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0xB1>{}));          // quad_perm [1, 0, 3, 2]
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x4E>{}));          // quad_perm [2, 3, 0, 1]
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x141>{}));         // row_half_mirror
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x140>{}));         // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+template <bool PRIO>
+__global__ void __launch_bounds__(512, 2) conv3x3_up16_fold_kernel(const gcpx_conv_args a, const int items_per_wave, const int nitems) {
+    using Cfg = FoldCfg;
+    constexpr int R = Cfg::R, PR = Cfg::PR, PW = Cfg::PW, RW = Cfg::RW, NS = Cfg::NS, NO = Cfg::NO;
+    extern __shared__ float4 smem4[];
+    const char* wl = reinterpret_cast<const char*>(smem4);                           // [24][2][64] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* wbuf = reinterpret_cast<char*>(smem4) + Cfg::W_BYTES + wave * Cfg::WAVE_BYTES;
+    float* raw = reinterpret_cast<float*>(wbuf);
+    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(smem4) + Cfg::W_BYTES + 8 * Cfg::WAVE_BYTES);
+    const int j = lane & 15, q = lane >> 4;
+    const int H = a.Hout, W = a.Wout, Hin = a.Hin, Win = a.Win;
+    const int ncb = W / 16, nrb = Hin / R;
+
+    for (int i = tid; i < Cfg::W_BYTES / 16; i += 512) smem4[i] = reinterpret_cast<const float4*>(a.wpk_split)[i];
+    __syncthreads();
+
+    // a lane stages the same channel quad in every slot: its source, BatchNorm affine and activation are fixed
+    const int c4 = lane & 7;
+    const int c0 = a.src[0].C;
+    const bool first = c4 * 4 < c0;
+    const int cl = first ? c4 * 4 : c4 * 4 - c0;
+    const float* sptr = first ? a.src[0].ptr : a.src[1].ptr;
+    const int srcC = first ? a.src[0].C : a.src[1].C;
+    const float* scp = first ? a.src[0].scale : a.src[1].scale;
+    const float* shp = first ? a.src[0].shift : a.src[1].shift;
+    const int sact = first ? a.src[0].act : a.src[1].act;
+    float4 bn_s = make_float4(1.f, 1.f, 1.f, 1.f), bn_t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scp) {
+        bn_s = *reinterpret_cast<const float4*>(scp + cl);
+        bn_t = *reinterpret_cast<const float4*>(shp + cl);
+    }
+    const float slope = sact == GCPX_ACT_LRELU ? 0.2f : 1.f;
+    const int fdiv0 = a.src[0].frame_div, fdiv1 = a.nsrc > 1 ? a.src[1].frame_div : 1;
+    const int ew = a.w_split_log2_dev ? __builtin_amdgcn_readfirstlane(*a.w_split_log2_dev) : a.w_split_log2;
+    const float4 bv = *reinterpret_cast<const float4*>(a.bias + q * 4);
+
+    const int gw = blockIdx.x * 8 + wave;
+    int item = gw * items_per_wave;
+    const int item_end = min(item + items_per_wave, nitems);
+
+    auto origin = [&](int it, int& f, int& y0, int& x0) {           // y0: first low-resolution row, x0: first output column
+        const int rb = it % nrb;
+        const int t = it / nrb;
+        y0 = rb * R; f = t / ncb; x0 = (t % ncb) * 16;
+    };
+    // Slot maps with compile-time rows: a patch row is 10 pixels x 8 channel quads = 64 + 16 slots, a region row 18 x 8 = 2 x 64 + 16.
+    // Steps 0 .. 5 (patch) / 0 .. 11 (region) take the first 8 (16) pixels of one row — the lane-dependent part of every address is
+    // the same in all of them — and the leftover columns of all rows share the last two steps.
+    const int ps = lane >> 3;                                        // pixel inside a step
+    const int WinC = Win * srcC;
+    const int rowA = lane >> 4, colA = 8 + (ps & 1);                 // leftover patch slots: rows 0..3 (step 6), 4..5 (step 7; lanes < 32)
+    float4 pre[NS];
+    auto issue_loads = [&](int it) {
+        int f, y0, x0;
+        origin(it, f, y0, x0);
+        const int fs = first ? f / fdiv0 : f / fdiv1;
+        const float* base = sptr + (size_t)fs * Hin * WinC + cl;
+        const int ly0 = y0 - 1, lx0 = x0 / 2 - 1;
+        const int sxm = min(max(lx0 + ps, 0), Win - 1) * srcC;                      // replicate clamp (bilinear border rule)
+        const int sxl = min(max(lx0 + colA, 0), Win - 1) * srcC;
+#pragma unroll
+        for (int k = 0; k < PR; ++k) {
+            const int sy = min(max(ly0 + k, 0), Hin - 1);
+            pre[k] = *reinterpret_cast<const float4*>(base + (unsigned)(sy * WinC + sxm));
+        }
+        pre[PR] = *reinterpret_cast<const float4*>(base + (unsigned)(min(max(ly0 + rowA, 0), Hin - 1) * WinC + sxl));
+        pre[PR + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < 32) pre[PR + 1] = *reinterpret_cast<const float4*>(base + (unsigned)(min(max(ly0 + 4 + rowA, 0), Hin - 1) * WinC + sxl));
+    };
+    // LDS offsets (bytes): patch [row][10][32] f32, region planes [row][18][32] f16
+    const int raw_wr_m = ps * 128 + c4 * 16;                          // + row * 1280
+    const int raw_wr_l = (rowA * 10 + colA) * 128 + c4 * 16;          // step 6; step 7: + 4 * 1280
+    const int raw_rd_m = (ps >> 1) * 128 + c4 * 16;                   // + (row * 10 + 4 h) * 128: patch columns col / 2, col / 2 + 1
+    const int raw_rd_l = ((ps >> 1) * 10 + 8) * 128 + c4 * 16;        // leftover region columns 16, 17 of row ps / 2 (+ 4 rows in the last step)
+    const int reg_wr_m = ps * 64 + c4 * 8;                            // + (row * 18 + 8 h) * 64
+    const int reg_wr_l = ((ps >> 1) * 18 + 16 + (ps & 1)) * 64 + c4 * 8;
+    const float wa_m = (ps & 1) ? 0.25f : 0.75f;                      // region column c: 0.75 / 0.25 (c even) or 0.25 / 0.75 (c odd); 16 + (ps & 1) likewise
+
+    f32x4 st1 = f32x4{0, 0, 0, 0}, st2 = f32x4{0, 0, 0, 0};
+    // An item's output is stored one iteration late, behind the NEXT item's staging.  The memory counter is in order: stores issued
+    // right before the loop's back-edge would have to complete before the staging may touch the prefetched patch (the store round
+    // trip, every item); issued behind the staging they are older than the next prefetch and long complete when it is waited for.
+    f32x4 outv[R][2];
+    float* optr = nullptr;
+    auto store_out = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int yi = 0; yi < R; ++yi)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const f32x4 v = outv[yi][py];
+                *reinterpret_cast<float4*>(optr + (unsigned)((2 * yi + py) * W * 16)) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    };
+    if (item < item_end) issue_loads(item);
+
+    for (; item < item_end; ++item) {
+        int f, y0, x0;
+        origin(item, f, y0, x0);
+        const bool top = (y0 == 0), bot = (y0 + R == Hin), lft = (x0 == 0), rgt = (x0 + 16 == W);
+
+        // ---- registers -> raw patch (BatchNorm affine + LeakyReLU of the producer), the item's largest magnitude ----
+        float amax = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            float4 v = pre[k];
+            v.x = fmaf(v.x, bn_s.x, bn_t.x); v.y = fmaf(v.y, bn_s.y, bn_t.y); v.z = fmaf(v.z, bn_s.z, bn_t.z); v.w = fmaf(v.w, bn_s.w, bn_t.w);
+            v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope); v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+            char* dst = wbuf + (k < PR ? raw_wr_m + k * 1280 : raw_wr_l + (k - PR) * 4 * 1280);
+            if (k < NS - 1 || lane < 32) *reinterpret_cast<float4*>(dst) = v;
+            else v = make_float4(0.f, 0.f, 0.f, 0.f);
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        if (optr) store_out();
+        amax = wave_max_nonneg(amax);
+        int ex = 14 + 127 - (int)((__float_as_uint(amax) >> 23) & 0xff);            // amax 2^ex in [2^14, 2^15)
+        ex = __builtin_amdgcn_readfirstlane(amax > 0.f ? max(-100, min(min(100, 126 - ew), ex)) : min(100, 126 - ew));
+        const float sx2 = __uint_as_float((unsigned)(127 + ex) << 23);
+
+        // ---- horizontal half of the bilinear x2: patch (PR x 10) -> region (PR x 18) as two f16 planes.  Region column c is output
+        //      column x0 - 1 + c = 0.75 / 0.25 (c even) or 0.25 / 0.75 (c odd) of patch columns c / 2 and c / 2 + 1.  The planes
+        //      overwrite the patch: every value is formed first (the wavefront's LDS operations execute in order) ----
+        h4 o1[NO], o2[NO];
+        const float sc_first = (lft && ps == 0) ? 0.f : sx2;                        // region column 0 / 17: the conv's zero padding in x
+        const float sc_last = (rgt && (ps & 1)) ? 0.f : sx2;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) {
+            const bool main_step = k < 2 * PR;
+            const int r = k >> 1, h = k & 1;
+            const char* rp = wbuf + (main_step ? raw_rd_m + (r * 10 + 4 * h) * 128 : raw_rd_l + (k - 2 * PR) * 4 * 1280);
+            const float4 A = *reinterpret_cast<const float4*>(rp);
+            const float4 B = *reinterpret_cast<const float4*>(rp + 128);
+            const float sc = main_step ? (h == 0 ? sc_first : sx2) : sc_last;
+            const float wa = wa_m * sc, wb = (1.f - wa_m) * sc;
+            float4 v;
+            v.x = fmaf(wa, A.x, wb * B.x); v.y = fmaf(wa, A.y, wb * B.y); v.z = fmaf(wa, A.z, wb * B.z); v.w = fmaf(wa, A.w, wb * B.w);
+            h4 p1, p2;
+            p1[0] = (_Float16)v.x; p1[1] = (_Float16)v.y; p1[2] = (_Float16)v.z; p1[3] = (_Float16)v.w;
+            p2[0] = (_Float16)fmaf((float)p1[0], -1.f, v.x); p2[1] = (_Float16)fmaf((float)p1[1], -1.f, v.y);
+            p2[2] = (_Float16)fmaf((float)p1[2], -1.f, v.z); p2[3] = (_Float16)fmaf((float)p1[3], -1.f, v.w);
+            o1[k] = p1;
+            o2[k] = p2;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < NO; ++k) {
+            const bool main_step = k < 2 * PR;
+            const int r = k >> 1, h = k & 1;
+            char* dst = wbuf + (main_step ? reg_wr_m + (r * RW + 8 * h) * 64 : reg_wr_l + (k - 2 * PR) * 4 * RW * 64);
+            if (k < NO - 1 || lane < 32) {
+                *reinterpret_cast<h4*>(dst) = o1[k];
+                *reinterpret_cast<h4*>(dst + Cfg::PLANE_BYTES) = o2[k];
+            }
+        }
+
+        // ---- MFMAs: 18 blocks (tx, row tap, parity) of R x 3.  Every block's two weight pieces are read while the block before it
+        //      computes (12 x 16 cycles of the matrix pipe cover an LDS round trip).  Row taps ascend inside a tx, so rows 0, 1 of the
+        //      row fragments die early: rows 0..3 of tx + 1 are read during blocks 2..5 of tx, rows 4, 5 during its own first two
+        //      blocks — at most 8 row fragments are live.  The border corrections ride at the end of their tx ----
+        f32x4 acc[R][2];
+#pragma unroll
+        for (int yi = 0; yi < R; ++yi) { acc[yi][0] = f32x4{0, 0, 0, 0}; acc[yi][1] = f32x4{0, 0, 0, 0}; }
+        auto load_w = [&](const int t, h8 (&w)[2]) __attribute__((always_inline)) {
+            const char* wp = wl + t * 2048 + lane * 16;
+            w[0] = *reinterpret_cast<const h8*>(wp);
+            w[1] = *reinterpret_cast<const h8*>(wp + 1024);
+        };
+        auto load_b = [&](const int tx, const int r, h8 (&b)[2]) __attribute__((always_inline)) {
+            const char* bp = wbuf + ((r * RW + j + tx) * 64 + q * 16);
+            b[0] = *reinterpret_cast<const h8*>(bp);
+            b[1] = *reinterpret_cast<const h8*>(bp + Cfg::PLANE_BYTES);
+        };
+        if (item + 1 < item_end) issue_loads(item + 1);              // in flight during this item's MFMAs (issued here, not before the
+                                                                     // interpolation: there its 32 registers meant spills, and a
+                                                                     // scratch reload waits for every load in flight)
+        h8 wq[2][2], bq[2][PR][2], wt[2], wb[2];
+        load_w(0, wq[0]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) load_b(0, r, bq[0][r]);
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+        static_for<0, 18>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value, tx = t / 6, blk = t % 6, dyl = blk / 2, py = blk % 2;
+            constexpr bool more = t + 1 < 18;
+            constexpr bool pre_next = blk >= 2 && tx + 1 < 3;                    // rows 0..3 of tx + 1
+            constexpr bool pre_own = blk < 2;                                    // rows 4, 5 of this tx
+            constexpr bool pre_c = blk == 4;                                     // correction weights of this tx
+            if constexpr (more) {
+                constexpr int t1 = t + 1, tx1 = t1 / 6, blk1 = t1 % 6;
+                load_w((blk1 % 2) * 9 + (blk1 / 2) * 3 + tx1, wq[t1 & 1]);
+            }
+            if constexpr (pre_next) load_b(tx + 1, blk - 2, bq[(tx + 1) & 1][blk - 2]);
+            if constexpr (pre_own) load_b(tx, 4 + blk, bq[tx & 1][4 + blk]);
+            if constexpr (pre_c) { load_w(18 + tx, wt); load_w(21 + tx, wb); }
+            const h8 w1 = wq[t & 1][0], w2 = wq[t & 1][1];
+            // small terms first: they are added to the accumulator while it is still small
+#pragma unroll
+            for (int yi = 0; yi < R; ++yi) acc[yi][py] = mfma32h(w2, bq[tx & 1][yi + dyl][0], acc[yi][py]);
+#pragma unroll
+            for (int yi = 0; yi < R; ++yi) acc[yi][py] = mfma32h(w1, bq[tx & 1][yi + dyl][1], acc[yi][py]);
+#pragma unroll
+            for (int yi = 0; yi < R; ++yi) acc[yi][py] = mfma32h(w1, bq[tx & 1][yi + dyl][0], acc[yi][py]);
+            __builtin_amdgcn_sched_group_barrier(0x100, (more ? 2 : 0) + ((pre_next || pre_own) ? 2 : 0) + (pre_c ? 4 : 0), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            if constexpr (blk == 5) {
+                if (top) {                                           // output row 0: the tap row above the image is zero, not row 0 again
+                    acc[0][0] = mfma32h(wt[1], bq[tx & 1][0][0], acc[0][0]);
+                    acc[0][0] = mfma32h(wt[0], bq[tx & 1][0][1], acc[0][0]);
+                    acc[0][0] = mfma32h(wt[0], bq[tx & 1][0][0], acc[0][0]);
+                }
+                if (bot) {                                           // output row H - 1 likewise
+                    acc[R - 1][1] = mfma32h(wb[1], bq[tx & 1][PR - 1][0], acc[R - 1][1]);
+                    acc[R - 1][1] = mfma32h(wb[0], bq[tx & 1][PR - 1][1], acc[R - 1][1]);
+                    acc[R - 1][1] = mfma32h(wb[0], bq[tx & 1][PR - 1][0], acc[R - 1][1]);
+                }
+            }
+        });
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+
+        // ---- epilogue: scale back (exact), bias, BatchNorm partial sums; the raw NHWC store follows the next item's staging ----
+        const float inv = __uint_as_float((unsigned)(127 - ex - ew) << 23);
+        optr = a.out + (((size_t)f * H + 2 * y0) * W + x0 + j) * 16 + q * 4;
+#pragma unroll
+        for (int yi = 0; yi < R; ++yi)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                f32x4 v = acc[yi][py];
+                v[0] = fmaf(v[0], inv, bv.x); v[1] = fmaf(v[1], inv, bv.y); v[2] = fmaf(v[2], inv, bv.z); v[3] = fmaf(v[3], inv, bv.w);
+                outv[yi][py] = v;
+                st1 += v;
+                st2 += v * v;
+            }
+    }
+    if (optr) store_out();
+    if (a.stats_partial) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s1 = row16_sum(st1[r]);
+            const float s2 = row16_sum(st2[r]);
+            if (j == 0) {
+                red[(wave * 2 + 0) * 16 + q * 4 + r] = s1;
+                red[(wave * 2 + 1) * 16 + q * 4 + r] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int which = tid >> 4, c = tid & 15;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += red[(w * 2 + which) * 16 + c];
+            a.stats_partial[((size_t)blockIdx.x * 2 + which) * 16 + c] = sum;
+        }
+    }
+}
+
+// out[t][co][ci] of gcpx_fold_upsample_weights (float64 sums in tap-row order; every product is exact)
+__global__ void __launch_bounds__(256) fold_up_weights_kernel(const float* __restrict__ w, const int Cout, const int Cin, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = Cout * Cin;
+    if (i >= 24 * n) return;
+    const int t = i / n, e = i - t * n;
+    const float* wp = w + (size_t)e * 9;
+    double s;
+    if (t < 18) {
+        const int py = t / 9, dyl = (t % 9) / 3, tx = t % 3;
+        const double cf[2][3][3] = {{{0.75, 0.25, 0.0}, {0.25, 0.75, 0.75}, {0.0, 0.0, 0.25}},
+                                    {{0.25, 0.0, 0.0}, {0.75, 0.75, 0.25}, {0.0, 0.25, 0.75}}};
+        s = cf[py][dyl][0] * (double)wp[tx];
+        s = s + cf[py][dyl][1] * (double)wp[3 + tx];
+        s = s + cf[py][dyl][2] * (double)wp[6 + tx];
+    } else if (t < 21) {
+        s = -(double)wp[t - 18];
+    } else {
+        s = -(double)wp[6 + t - 21];
+    }
+    out[i] = (float)s;
+}
+
 }  // namespace
 
 // Called by conv3x3_dispatch (conv3x3.hip) for the 100-channel mixture head when the caller supplies split-f16 weights.
@@ -925,4 +1248,38 @@ int gcpx_launch_up32_split(const gcpx_conv_args* a, hipStream_t stream, int whic
     if (which == 0) return launch_up32_split<2, 1>(a, stream, grid);
     if (which == 1) return launch_up32_split<2, 2>(a, stream, grid);
     return launch_up32_split<4, 2>(a, stream, grid);
+}
+
+// 32 -> 16 channel upsampling blocks with row-folded split-f16 weights (GCPX_SPLIT_ROWFOLD; packing.pack_conv3x3_fold); grid as launch_up16
+int gcpx_launch_up16_fold(const gcpx_conv_args* a, hipStream_t stream, int grid) {
+    using Cfg = FoldCfg;
+    GCPX_CHECK_ARG(a->Cin == 32 && a->Cout == 16 && a->Hin % Cfg::R == 0 && a->Hout == 2 * a->Hin && a->Wout == 2 * a->Win && a->Wout % 16 == 0,
+                   "row-folded block: 32 -> 16 channels, Hin a multiple of 4, output width a multiple of 16");
+    GCPX_CHECK_ARG(a->src[0].C % 4 == 0 && (a->nsrc == 1 ? a->src[0].C == 32 : a->src[0].C + a->src[1].C == 32), "source channels");
+    static const bool prio = getenv("GCPX_FOLD_NOPRIO") == nullptr;
+    auto kern = prio ? conv3x3_up16_fold_kernel<true> : conv3x3_up16_fold_kernel<false>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        for (auto k : {conv3x3_up16_fold_kernel<true>, conv3x3_up16_fold_kernel<false>}) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+            if (e != hipSuccess) {
+                gcpx_set_error("conv3x3 row-folded up16: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
+                return GCPX_ERR_HIP;
+            }
+        }
+        attr_set = true;
+    }
+    const int nitems = a->F * (a->Hin / Cfg::R) * (a->Wout / 16);
+    const int ipw = (nitems + grid * 8 - 1) / (grid * 8);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, stream, *a, ipw, nitems);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_fold_upsample_weights(const float* w, int32_t Cout, int32_t Cin, float* out, void* stream_) {
+    GCPX_CHECK_ARG(w && out && Cout > 0 && Cin > 0, "bad arguments");
+    const int n = 24 * Cout * Cin;
+    hipLaunchKernelGGL(fold_up_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), w, Cout, Cin, out);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
 }

@@ -298,21 +298,37 @@ class GCPTreeModel:
         if hp.decoder_distribution == "discrete_logistic_mixture":
             todo.append(("dec.head", "decoder.gen_head.conv.weight", pk.dlm_channel_perm(hp.n_mixtures)))
         for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
-            if cout == 16:                                   # the wave-autonomous 16-channel blocks (conv3x3_up16_split_kernel)
+            if cout == 16 and c_prev + c_skip == 32:         # bilinear rows folded into the weights (conv3x3_up16_fold_kernel)
+                todo.append((f"dec.{name}", f"decoder.net.{name}.conv.weight", "rowfold"))
+            elif cout == 16:                                 # the wave-autonomous 16-channel blocks (conv3x3_up16_split_kernel)
                 todo.append((f"dec.{name}", f"decoder.net.{name}.conv.weight", None))
             elif cout in (32, 64) and (c_prev + c_skip) % 32 == 0:     # the workgroup-tiled blocks (conv3x3_up32_split_kernel)
                 todo.append((f"dec.{name}", f"decoder.net.{name}.conv.weight", "tiled32"))
         for name, key, perm in todo:
             off, shp = self._poff[key]
-            idx = (pk.conv3x3_split32_index(shp, off) if perm == "tiled32" else pk.conv3x3_split_index(shp, off, perm)).to(self.device)
-            self.pk_split[name] = dict(idx=idx, out=torch.zeros(2 * idx.numel(), dtype=torch.int16, device=self.device),
-                                       log2=torch.zeros(1, dtype=torch.int32, device=self.device))
+            d = {}
+            if perm == "rowfold":                            # gcpx_fold_upsample_weights(theta + off) -> scratch, split from there
+                d["fold"] = torch.zeros(24 * shp[0] * shp[1], dtype=torch.float32, device=self.device)
+                d["fold_src"] = (off, shp[0], shp[1])
+                idx = pk.conv3x3_fold_index().to(self.device)
+            elif perm == "tiled32":
+                idx = pk.conv3x3_split32_index(shp, off).to(self.device)
+            else:
+                idx = pk.conv3x3_split_index(shp, off, perm).to(self.device)
+            d.update(idx=idx, out=torch.zeros(2 * idx.numel(), dtype=torch.int16, device=self.device),
+                     log2=torch.zeros(1, dtype=torch.int32, device=self.device))
+            self.pk_split[name] = d
         self.repack_split()
 
     def repack_split(self, stream=None):
         st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
         for name, d in self.pk_split.items():
-            rt.check(self.lib.gcpx_split_pack(self.theta.data_ptr(), d["idx"].data_ptr(), d["idx"].numel(), d["out"].data_ptr(),
+            src = self.theta
+            if "fold" in d:
+                off, cout, cin = d["fold_src"]
+                rt.check(self.lib.gcpx_fold_upsample_weights(self.theta.data_ptr() + 4 * off, cout, cin, d["fold"].data_ptr(), st), "fold_upsample_weights")
+                src = d["fold"]
+            rt.check(self.lib.gcpx_split_pack(src.data_ptr(), d["idx"].data_ptr(), d["idx"].numel(), d["out"].data_ptr(),
                                               d["log2"].data_ptr(), st), "split_pack")
 
     def _set_split(self, a, name):
@@ -320,6 +336,7 @@ class GCPTreeModel:
         d = getattr(self, "pk_split", {}).get(name)
         if self.split_f16 and d is not None:
             a.wpk_split, a.w_split_log2_dev = d["out"].data_ptr(), d["log2"].data_ptr()
+            a.split_layout = rt.SPLIT_ROWFOLD if "fold" in d else rt.SPLIT_PLAIN
 
     def _pack_fused_embed(self):
         """Inference only: the input embedding Linear and LSTM layer 0's input projection are two Linears with nothing in between

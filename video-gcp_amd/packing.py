@@ -233,6 +233,54 @@ def conv3x3_split32_index(shape, offset):
     return (conv3x3_split32_gather(ids).reshape(-1) - 1).to(torch.int32)
 
 
+_FOLD_CF = (((0.75, 0.25, 0.0), (0.25, 0.75, 0.75), (0.0, 0.0, 0.25)),
+            ((0.25, 0.0, 0.0), (0.75, 0.75, 0.25), (0.0, 0.25, 0.75)))
+
+
+def fold_up_weights(w):
+    """w [Cout, Cin, 3, 3] -> f32 [24, Cout, Cin]: the row-folded weights of an upsampling block (bilinear x2, align_corners=False, then
+    the 3x3 conv): set py 9 + dyl 3 + tx = sum_ty cf[py][dyl][ty] W[:, :, ty, tx] (output row 2 y + py reads low-resolution row
+    y - 1 + dyl), sets 18 + tx = -W[:, :, 0, tx] and 21 + tx = -W[:, :, 2, tx] (the conv's zero rows above / below the image).  Sums in
+    float64 in tap-row order, as gcpx_fold_upsample_weights forms them (bit-identical)."""
+    wd = w.double()
+    out = []
+    for py in range(2):
+        for dyl in range(3):
+            for tx in range(3):
+                c = _FOLD_CF[py][dyl]
+                s = c[0] * wd[:, :, 0, tx]
+                s = s + c[1] * wd[:, :, 1, tx]
+                s = s + c[2] * wd[:, :, 2, tx]
+                out.append(s)
+    out += [-wd[:, :, 0, tx] for tx in range(3)] + [-wd[:, :, 2, tx] for tx in range(3)]
+    return torch.stack(out, 0).float()
+
+
+def conv3x3_fold_gather(fw):
+    """fw [24, 16, 32] (fold_up_weights of a 32 -> 16 channel block, any dtype) -> [24][64][8] in v_mfma_f32_16x16x32_f16 A-fragment
+    order: lane (i = lane & 15, q = lane >> 4) element el = fw[t][i][8 q + el]."""
+    assert fw.shape == (24, 16, 32)
+    dev = fw.device
+    t = torch.arange(24, device=dev)[:, None, None]
+    li = _LI.to(dev)[None, :, None]
+    lq = _LQ.to(dev)[None, :, None]
+    el = torch.arange(8, device=dev)[None, None, :]
+    return fw[t, li, lq * 8 + el].contiguous()
+
+
+def pack_conv3x3_fold(w):
+    """w [16, 32, 3, 3] -> (int16 [24][2][64][8], e): the two f16 pieces of the row-folded weights for conv3x3_up16_fold_kernel
+    (csrc/conv3x3_split.hip, GCPX_SPLIT_ROWFOLD).  Device-side: gcpx_fold_upsample_weights + gcpx_split_pack over conv3x3_fold_index."""
+    w1, w2, e = split_f16(conv3x3_fold_gather(fold_up_weights(w)))
+    return torch.stack([w1, w2], 1).contiguous().view(torch.int16), e
+
+
+def conv3x3_fold_index():
+    """int32 [24 * 512]: index into the flat [24, 16, 32] folded-weight scratch of every element of conv3x3_fold_gather"""
+    ids = torch.arange(24 * 16 * 32, dtype=torch.float64).view(24, 16, 32)
+    return conv3x3_fold_gather(ids).reshape(-1).to(torch.int32)
+
+
 def lstm_gate_interleave(w_ih, w_hh, b_ih, b_hh):
     """[4H, H] x2 (torch gate order i, f, g, o) -> W [4H, 2H] with row n = 4u + gate, bias [4H] likewise."""
     H = w_hh.shape[1]                                       # (w_ih may be wider than H: embedding folded into layer 0)

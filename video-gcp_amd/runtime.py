@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgcpx.so")
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 HEAD_RAW, HEAD_DLM_MEAN, HEAD_DLM_BOTH, HEAD_TANH_NCHW = 0, 1, 2, 3
+SPLIT_PLAIN, SPLIT_ROWFOLD = 0, 1
 EPI_NONE, EPI_LRELU, EPI_LSTM = 0, 1, 2
 MLP_PLAIN, MLP_GAUSS = 0, 1
 
@@ -27,7 +28,8 @@ class ConvArgs(C.Structure):
     _fields_ = [("src", ConvSrc * 2), ("nsrc", i32), ("F", i32), ("Hin", i32), ("Win", i32), ("Hout", i32),
                 ("Wout", i32), ("Cin", i32), ("Cout", i32), ("out_pitch", i32), ("upsample", i32), ("out_act", i32),
                 ("head_mode", i32), ("wpk", vp), ("bias", vp), ("out", vp), ("images", vp), ("stats_partial", vp),
-                ("raw_row_map", vp), ("src_row_map", vp), ("src_row_frames", vp), ("n_src_rows", i32), ("w_split_log2", i32), ("wpk_split", vp), ("w_split_log2_dev", vp)]
+                ("raw_row_map", vp), ("src_row_map", vp), ("src_row_frames", vp), ("n_src_rows", i32), ("w_split_log2", i32), ("wpk_split", vp), ("w_split_log2_dev", vp),
+                ("split_layout", i32), ("_pad2", i32)]
 
 
 class LossArgs(C.Structure):
@@ -173,6 +175,7 @@ SYMBOLS = [
     ("gcpx_sample_length", C.c_int, [vp, vp, i32, i32, i32, vp, vp]),
     ("gcpx_repack", C.c_int, [vp, vp, vp, vp, i64, vp]),
     ("gcpx_split_pack", C.c_int, [vp, vp, i32, vp, vp, vp]),
+    ("gcpx_fold_upsample_weights", C.c_int, [vp, i32, i32, vp, vp]),
     ("gcpx_radam_step", C.c_int, [vp, vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     ("gcpx_attention", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     ("gcpx_cdist_splits", C.c_int, [i64]),
