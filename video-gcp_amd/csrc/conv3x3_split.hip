@@ -211,6 +211,24 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
     };
     if (item < item_end) issue_loads(item);
 
+    // The image pixels of an item are stored one iteration late, behind the NEXT item's staging: the memory counter is in order, so
+    // stores issued right before the loop's back-edge would have to complete before the staging may touch the prefetched region
+    // (the store round trip, every item); behind the staging they are older than the next prefetch and long complete by its wait.
+    float pend[2][3];
+    float* pend_ip = nullptr;
+    const size_t plane_sz = (size_t)H * W;
+    auto flush_images = [&]() __attribute__((always_inline)) {
+        if (pend_ip) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float* ip = pend_ip + s2 * W;
+                ip[0] = pend[s2][0];
+                ip[plane_sz] = pend[s2][1];
+                ip[2 * plane_sz] = pend[s2][2];
+            }
+        }
+    };
+
     for (; item < item_end; ++item) {
         int f, y0, x0;
         origin(item, f, y0, x0);
@@ -248,6 +266,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                 *reinterpret_cast<h4*>(dst + Cfg::PLANE_BYTES) = p2;
             }
         }
+        flush_images();
+        pend_ip = nullptr;
         if (item + 1 < item_end) issue_loads(item + 1);        // in flight during this item's MFMAs
 
         const int mode = a.head_mode;
@@ -296,14 +316,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                         S += w; Sr += w * mr[ct]; Sg += w * mg[ct]; Sb += w * mb[ct];
                     }
                     S += __shfl_xor(S, 32); Sr += __shfl_xor(Sr, 32); Sg += __shfl_xor(Sg, 32); Sb += __shfl_xor(Sb, 32);
-                    if (q < 2) {
-                        const int pt = s2 + 2 * q;
-                        const float invS = __builtin_amdgcn_rcpf(S);
-                        float* ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + pt) * W + (x0 + j);
-                        ip[0] = fminf(fmaxf(Sr * invS, -1.f), 1.f);
-                        ip[plane] = fminf(fmaxf(Sg * invS, -1.f), 1.f);
-                        ip[2 * plane] = fminf(fmaxf(Sb * invS, -1.f), 1.f);
-                    }
+                    const float invS = __builtin_amdgcn_rcpf(S);
+                    pend[s2][0] = fminf(fmaxf(Sr * invS, -1.f), 1.f);
+                    pend[s2][1] = fminf(fmaxf(Sg * invS, -1.f), 1.f);
+                    pend[s2][2] = fminf(fmaxf(Sb * invS, -1.f), 1.f);
+                    if (s2 == 0 && q < 2) pend_ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + 2 * q) * W + (x0 + j);   // row pt = s2 + 2 q
                 }
             }
         }
@@ -314,6 +331,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
             finish_tiles<5, 2>(a, bias_l, acc, inv, true, orow, y0, x0, j, q);
         }
     }
+    flush_images();
 }
 
 
