@@ -176,6 +176,12 @@ typedef struct gcpx_gemm_args {
     float* h_copy;          /* optional dense copy of h: row r at h_copy + r*H (input of the next layer) */
     int64_t z_src_off, z_w_off, z_bias_off, z_out_off;
     float* gates_out;       /* LSTM epilogue, optional: activated gates [M][H][4] = (i, f, g, o) kept for the backward pass */
+    const void* wpk_split;  /* dev or NULL: the same weights as two f16 pieces, [K/32][N/16][2][64][8] (packing.pack_gemm_split; batch b at
+                               byte offset b * z_w_off * 4).  When set, problems with enough rows to be bound by the f32 MFMA rate run
+                               the split-f16 kernel (csrc/gemm_split.hip): f32-equivalent results, see conv3x3_split.hip */
+    const int32_t* w_split_log2_dev; /* dev or NULL: [nbatch] powers of two the packed pieces were scaled by; NULL = w_split_log2 */
+    int32_t w_split_log2;
+    int32_t _pad_split;
 } gcpx_gemm_args;
 
 int gcpx_gemm(const gcpx_gemm_args* a, void* stream);

@@ -116,6 +116,126 @@ def test_gemm_lstm_epilogue(env):
     assert_close(hc, h1, atol=1e-5, name="h_copy")
 
 
+@pytest.mark.parametrize("case", ["unit", "tiny", "row_scales", "k_growth", "outlier", "zero_rows"])
+@pytest.mark.parametrize("M,N,K", [(200, 2048, 1024), (130, 192, 128), (512, 512, 1024)])
+def test_gemm_split_error_vs_float64(env, case, M, N, K):
+    """The split-f16 row GEMM (csrc/gemm_split.hip: two f16 pieces per operand, three f16 MFMAs per product, a per-row power-of-two
+    scale that follows the row along K) against float64, next to the exact f32 MFMA kernel: rows of magnitude 1e-6 (gradients) next
+    to rows of order 1e3, magnitudes growing 1e4-fold along K (the running scale drops and the sums are rescaled), an outlier, and
+    all-zero rows.  Both tile widths (128 / 64 columns) and the masked last row block are covered by the shapes."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(M + K)
+    x = torch.randn(M, K)
+    if case == "tiny":
+        x *= 1e-6
+    elif case == "row_scales":
+        x *= torch.logspace(-6, 3, M)[:, None]
+    elif case == "k_growth":
+        x *= torch.logspace(-2, 2, K)[None, :]
+    elif case == "outlier":
+        x[3, K // 2] = 3e4
+    elif case == "zero_rows":
+        x[::3] = 0.0
+    w, b = torch.randn(N, K) / K ** 0.5, torch.randn(N)
+    ref = F.linear(x.double(), w.double(), b.double())
+    xd, wp, bd = x.to(dev), pk.pack_gemm(w).to(dev), b.to(dev)
+    ws, e = pk.pack_gemm_split(w)
+    ws = ws.to(dev)
+    err = {}
+    for name in ("f32", "split"):
+        out = torch.full((M, N), float("nan"), device=dev)
+        a = rt.GemmArgs()
+        a.src[0] = _rowsrc(rt, xd, 0, K, K)
+        a.nsrc, a.M, a.N, a.K, a.rpb = 1, M, N, K, M
+        a.wpk, a.bias, a.out, a.ob, a.orow = wp.data_ptr(), bd.data_ptr(), out.data_ptr(), 0, N
+        if name == "split":
+            a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+        rt.check(lib.gcpx_gemm(C.byref(a), _stream()), name)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        err[name] = (out.cpu().double() - ref).abs()
+    # row by row (rows differ by nine orders of magnitude): rms error within 1.5x the exact kernel's, max within 2x (+ one f32 rounding
+    # of the row's largest result)
+    rs = ref.abs().amax(1) + 1e-30
+    rms = {k: v.pow(2).mean(1).sqrt() for k, v in err.items()}
+    assert bool((rms["split"] <= 1.5 * rms["f32"] + 1e-7 * rs).all()), float((rms["split"] / (rms["f32"] + 1e-7 * rs)).max())
+    assert bool((err["split"].amax(1) <= 2.0 * err["f32"].amax(1) + 4e-7 * rs).all())
+
+
+def test_gemm_split_lstm_sources_and_batches(env):
+    """split-f16 GEMM with what the tree levels use: several concatenated sources with a row gather and a masked shift, the LSTM-cell
+    epilogue (h, c, dense h copy), and the batched form (blockIdx.z problems with their own weights, bias and weight exponent)."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(9)
+    M, H = 300, 128
+    pool = torch.randn(500, H)
+    ridx = torch.randint(0, 500, (M,), dtype=torch.int32)
+    x, h, c = pool[ridx.long()], torch.randn(M, H), torch.randn(M, H)
+    cell = torch.nn.LSTMCell(H, H)
+    with torch.no_grad():
+        h1, c1 = cell(x, (h, c))
+    w, b = pk.lstm_gate_interleave(cell.weight_ih.detach(), cell.weight_hh.detach(), cell.bias_ih.detach(), cell.bias_hh.detach())
+    wp, bd = pk.pack_gemm(w).to(dev), b.to(dev)
+    ws, e = pk.pack_gemm_split(w)
+    ws = ws.to(dev)
+    pd, rd, hd, cd = pool.to(dev), ridx.to(dev), h.to(dev), c.to(dev)
+    ho, co, hc = (torch.full((M, H), float("nan"), device=dev) for _ in range(3))
+    a = rt.GemmArgs()
+    a.src[0] = _rowsrc(rt, pd, 0, H, H, rowidx=rd)
+    a.src[1] = _rowsrc(rt, hd, 0, H, H)
+    a.nsrc, a.M, a.N, a.K, a.rpb = 2, M, 4 * H, 2 * H, M
+    a.wpk, a.bias, a.epi = wp.data_ptr(), bd.data_ptr(), rt.EPI_LSTM
+    a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+    a.c_prev, a.c_prev_stride, a.h_out, a.c_out, a.hb, a.hrow, a.h_copy = cd.data_ptr(), H, ho.data_ptr(), co.data_ptr(), 0, H, hc.data_ptr()
+    rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm split lstm")
+    torch.cuda.synchronize()
+    assert_close(ho, h1, atol=1e-5, name="h")
+    assert_close(co, c1, atol=1e-5, name="c")
+    assert_close(hc, h1, atol=1e-5, name="h_copy")
+    # conv1d-over-time form (three shifted sources with an affine + LReLU on load, rows masked at the sequence ends), LReLU epilogue
+    B, T, Cc, N = 4, 40, 64, 128
+    xs = torch.randn(B, T, Cc)
+    sc, sh = torch.rand(Cc) + 0.5, torch.randn(Cc) * 0.1
+    wc, bc = torch.randn(N, Cc, 3) / (3 * Cc) ** 0.5, torch.randn(N)
+    want = F.leaky_relu(F.conv1d(F.leaky_relu(xs * sc + sh, 0.2).transpose(1, 2), wc, bc, padding=1).transpose(1, 2), 0.2)
+    w2 = wc.permute(0, 2, 1).reshape(N, 3 * Cc)
+    xd, scd, shd, bcd = xs.to(dev), sc.to(dev), sh.to(dev), bc.to(dev)
+    wp2 = pk.pack_gemm(w2).to(dev)
+    ws2, e2 = pk.pack_gemm_split(w2)
+    ws2 = ws2.to(dev)
+    out = torch.full((B * T, N), float("nan"), device=dev)
+    a = rt.GemmArgs()
+    for i, d in enumerate((-1, 0, 1)):
+        a.src[i] = _rowsrc(rt, xd, T * Cc, Cc, Cc, shift=d, scale=scd, shiftv=shd, act=rt.ACT_LRELU, cmod=Cc)
+    a.nsrc, a.M, a.N, a.K, a.rpb = 3, B * T, N, 3 * Cc, T
+    a.wpk, a.bias, a.out, a.ob, a.orow, a.epi = wp2.data_ptr(), bcd.data_ptr(), out.data_ptr(), T * N, N, rt.EPI_LRELU
+    a.wpk_split, a.w_split_log2 = ws2.data_ptr(), e2
+    rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm split conv1d")
+    torch.cuda.synchronize()
+    assert_close(out.view(B, T, N), want, atol=2e-5, rtol=1e-5, name="conv1d-gemm split")
+    # batched: 3 problems, weights of different magnitude (their own exponents)
+    nb, M2, N2, K2 = 3, 256, 128, 256
+    xb = torch.randn(nb, M2, K2)
+    wb = torch.randn(nb, N2, K2) / K2 ** 0.5 * torch.tensor([1.0, 1e-3, 50.0])[:, None, None]
+    bb = torch.randn(nb, N2)
+    wantb = torch.einsum("bmk,bnk->bmn", xb, wb) + bb[:, None, :]
+    packs = [pk.pack_gemm_split(wb[i]) for i in range(nb)]
+    wsb = torch.stack([p_[0] for p_ in packs]).contiguous().to(dev)
+    eb = torch.tensor([p_[1] for p_ in packs], dtype=torch.int32, device=dev)
+    wpb = torch.stack([pk.pack_gemm(wb[i]) for i in range(nb)]).contiguous().to(dev)
+    xbd, bbd = xb.to(dev), bb.to(dev)
+    outb = torch.full((nb, M2, N2), float("nan"), device=dev)
+    a = rt.GemmArgs()
+    a.src[0] = _rowsrc(rt, xbd, 0, K2, K2)
+    a.nsrc, a.M, a.N, a.K, a.rpb = 1, M2, N2, K2, M2
+    a.wpk, a.bias, a.out, a.ob, a.orow = wpb.data_ptr(), bbd.data_ptr(), outb.data_ptr(), 0, N2
+    a.nbatch, a.z_src_off, a.z_w_off, a.z_bias_off, a.z_out_off = nb, M2 * K2, N2 * K2, N2, M2 * N2
+    a.wpk_split, a.w_split_log2_dev = wsb.data_ptr(), eb.data_ptr()
+    rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm split batched")
+    torch.cuda.synchronize()
+    assert_close(outb, wantb, atol=3e-5, rtol=2e-5, name="batched split")
+
+
 def _predictor_ref(x, Ws, n_mid, groups=8):
     h = F.leaky_relu(F.linear(x, Ws["w_in"], Ws["b_in"]), 0.2)
     for i in range(n_mid):

@@ -18,6 +18,9 @@
 #include <cstdlib>
 #include <type_traits>
 
+bool gcpx_gemm_split_applies(const gcpx_gemm_args* a);                  // gemm_split.hip
+int gcpx_launch_gemm_split(const gcpx_gemm_args* a, hipStream_t stream);
+
 namespace {
 
 // KS (K split inside the workgroup): with few rows a wavefront streams its whole weight column alone and the launch is bound by
@@ -380,6 +383,7 @@ extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int st = gemm_check(a);
     if (st != GCPX_OK) return st;
+    if (gcpx_gemm_split_applies(a)) return gcpx_launch_gemm_split(a, stream);
     const TileChoice t = choose_tile(a->M, a->N, a->nbatch > 1 ? a->nbatch : 1);
     if (t.pr == 1 && t.cr == 1 && a->K >= 256 && !getenv("GCPX_GEMM_NOKS")) {
         // few rows: split K over the wavefronts of a workgroup when that still leaves the launch small

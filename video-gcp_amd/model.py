@@ -287,6 +287,7 @@ class GCPTreeModel:
         self.pk = self._pack_tree(self.sd)
         self._pack_fused_embed()
         self._pack_split()
+        self._pack_gemm_split()
 
     def _pack_split(self):
         """The two f16 pieces of the conv weights that have a split-f16 kernel (csrc/conv3x3_split.hip).  They are gathered and split
@@ -330,6 +331,28 @@ class GCPTreeModel:
                 src = d["fold"]
             rt.check(self.lib.gcpx_split_pack(src.data_ptr(), d["idx"].data_ptr(), d["idx"].numel(), d["out"].data_ptr(),
                                               d["log2"].data_ptr(), st), "split_pack")
+
+    def _pack_gemm_split(self):
+        """Inference only (like the fused embedding: a re-split of every GEMM weight after each optimizer step is not worth its
+        launches): the two f16 pieces of the tree levels' LSTM and split_linear weights for csrc/gemm_split.hip, keyed by the
+        address of the f32 pack they mirror.  gcpx_gemm takes the split kernel from GCPX_GEMM_SPLIT_MIN_ROWS rows on (default 512:
+        below that the launch is bound by the per-CU load rate, not by the f32 MFMA rate — DESIGN.md section 6c)."""
+        self._gsplit = {}
+        if not self.split_f16:
+            return
+        for name, W in self.pk.items():
+            if not (isinstance(W, dict) and name.startswith("tree")):
+                continue
+            for key, wpk in W.items():
+                if not (key.endswith(".w") and (key.startswith("lstm") or key == "proj.w")):
+                    continue
+                stack = wpk if wpk.dim() == 5 else wpk[None]
+                if (stack.shape[2] * 16) % 64 or (stack.shape[1] * 16) % 64:
+                    continue
+                packs = [pk.pack_gemm_split(pk.unpack_gemm(w, w.shape[1] * 16)) for w in stack]
+                ws = torch.stack([p_[0] for p_ in packs]).contiguous().to(self.device)
+                es = torch.tensor([p_[1] for p_ in packs], dtype=torch.int32, device=self.device)
+                self._gsplit[wpk.data_ptr()] = (ws, es)
 
     def _set_split(self, a, name):
         """Hand conv `name`'s split-f16 weights to the launch if this model runs split-f16 and holds them."""
@@ -597,6 +620,9 @@ class GCPTreeModel:
             a.src[i] = s
         a.nsrc, a.M, a.N, a.K, a.rpb = len(srcs), M, N, sum(s.width for s in srcs), rpb
         a.wpk, a.bias = wpk.data_ptr(), (bias.data_ptr() if bias is not None else None)
+        gs = getattr(self, "_gsplit", {}).get(wpk.data_ptr())
+        if gs is not None and self.split_f16 and getattr(self, "_arena", None) is None:
+            a.wpk_split, a.w_split_log2_dev = gs[0].data_ptr(), gs[1].data_ptr()
         a.out, a.ob, a.orow, a.epi = out, ob, orow, epi
         a.stats_partial = stats.data_ptr() if stats is not None else None
         if lstm is not None:

@@ -34,6 +34,41 @@ def pack_gemm(w):
     return w[nt * 16 + li, kg * 16 + lq * 4 + s].contiguous()
 
 
+def unpack_gemm(wpk, N):
+    """inverse of pack_gemm: [K/16][NT][64][4] -> w [N, K]"""
+    KG, NT = wpk.shape[:2]
+    dev = wpk.device
+    w = torch.zeros((NT * 16, KG * 16), dtype=wpk.dtype, device=dev)
+    kg = torch.arange(KG, device=dev)[:, None, None, None]
+    nt = torch.arange(NT, device=dev)[None, :, None, None]
+    li = _LI.to(dev)[None, None, :, None]
+    lq = _LQ.to(dev)[None, None, :, None]
+    s = torch.arange(4, device=dev)[None, None, None, :]
+    w[(nt * 16 + li).expand_as(wpk), (kg * 16 + lq * 4 + s).expand_as(wpk)] = wpk
+    return w[:N]
+
+
+def gemm_split_gather(w):
+    """w [N, K] (N % 16 == 0, K % 32 == 0, any dtype) -> [K/32][N/16][64][8] in v_mfma_f32_16x16x32_f16 A-fragment order:
+    lane (i = lane & 15, q = lane >> 4) element el = w[16 nt + i][32 ks + 8 q + el]."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0, (N, K)
+    dev = w.device
+    ks = torch.arange(K // 32, device=dev)[:, None, None, None]
+    nt = torch.arange(N // 16, device=dev)[None, :, None, None]
+    li = _LI.to(dev)[None, None, :, None]
+    lq = _LQ.to(dev)[None, None, :, None]
+    el = torch.arange(8, device=dev)[None, None, None, :]
+    return w[nt * 16 + li, ks * 32 + lq * 8 + el].contiguous()
+
+
+def pack_gemm_split(w):
+    """w [N, K] -> (int16 [K/32][N/16][2][64][8], e): the two f16 pieces of the weights (split_f16) for csrc/gemm_split.hip; the same
+    number of bytes as pack_gemm(w)"""
+    w1, w2, e = split_f16(gemm_split_gather(w))
+    return torch.stack([w1, w2], 2).contiguous().view(torch.int16), e
+
+
 def pack_conv3x3(w, cc, perm=None):
     """w [Cout, Cin, 3, 3] -> [Cin/cc * 9 * cc/16 + 1][CT][64][4]; the trailing zero step pads the prefetch.
     perm: optional list mapping kernel channel slot -> canonical output channel (or -1 for an empty slot)."""

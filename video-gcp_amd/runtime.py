@@ -51,7 +51,8 @@ class GemmArgs(C.Structure):
                 ("wpk", vp), ("bias", vp), ("out", vp), ("ob", i64), ("orow", i64), ("epi", i32), ("nbatch", i32),
                 ("stats_partial", vp), ("c_prev", vp), ("c_prev_stride", i64), ("h_out", vp), ("c_out", vp),
                 ("hb", i64), ("hrow", i64), ("h_copy", vp), ("z_src_off", i64), ("z_w_off", i64),
-                ("z_bias_off", i64), ("z_out_off", i64), ("gates_out", vp)]
+                ("z_bias_off", i64), ("z_out_off", i64), ("gates_out", vp),
+                ("wpk_split", vp), ("w_split_log2_dev", vp), ("w_split_log2", i32), ("_pad_split", i32)]
 
 
 class MlpArgs(C.Structure):
