@@ -623,8 +623,11 @@ def test_conv3x3_up32_split_error_vs_float64(env, case, Hin, c_prev, c_skip, cou
         assert float(err["split"].max()) <= 2.0 * float(err["f32"].max()) + 4e-7 * scale
 
 
-@pytest.mark.parametrize("Hin,cin,cout,Fr", [(32, 16, 32, 5), (16, 32, 64, 3), (8, 64, 128, 9), (16, 16, 32, 2)])
-def test_conv4x4s2(env, Hin, cin, cout, Fr):
+@pytest.mark.parametrize("Hin,cin,cout,Fr", [(32, 16, 32, 5), (16, 32, 64, 3), (8, 64, 128, 9), (16, 16, 32, 2), (8, 32, 64, 7), (8, 32, 64, 60),
+                                             (16, 16, 32, 63)])
+@pytest.mark.parametrize("split", [False, True])
+def test_conv4x4s2(env, Hin, cin, cout, Fr, split):
+    """encoder block vs torch; split: the split-f16 form (csrc/conv_enc_split.hip), same tolerances"""
     rt, pk, lib, dev = env
     torch.manual_seed(Hin + cin)
     x = torch.randn(Fr, cin, Hin, Hin)
@@ -637,10 +640,50 @@ def test_conv4x4s2(env, Hin, cin, cout, Fr):
     st = torch.full((G, 2, cout), float("nan"), device=dev)
     a = _conv_args(rt, [(xd, cin, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=Hin, Win=Hin, Hout=Hin // 2, Wout=Hin // 2,
                    Cout=cout, out_pitch=cout, wpk=pk.pack_conv4x4(w).to(dev), bias=b.to(dev), out=out, stats_partial=st)
+    if split:
+        ws, e = pk.pack_conv4x4_split(w)
+        ws = ws.to(dev)
+        a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
     rt.check(lib.gcpx_conv4x4s2(C.byref(a), _stream()), "conv4x4s2")
     torch.cuda.synchronize()
     assert_close(out.permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5, name="conv4x4s2")
     assert_close(st.sum(0)[0], want.sum((0, 2, 3)), atol=1e-2, rtol=1e-4, name="stats")
+    assert_close(st.sum(0)[1], (want ** 2).sum((0, 2, 3)), atol=1e-2, rtol=1e-4, name="stats sumsq")
+
+
+@pytest.mark.parametrize("case", ["unit", "tiny", "large", "outlier", "zero"])
+@pytest.mark.parametrize("Hin,cin,cout,Fr", [(32, 16, 32, 3), (16, 32, 64, 9), (8, 64, 128, 19)])
+def test_conv4x4s2_split_error_vs_float64(env, case, Hin, cin, cout, Fr):
+    """The split-f16 encoder blocks against float64, next to the exact f32 kernel (one power-of-two scale per staged block of
+    frames): data of magnitude 1e-3, 300, with an outlier, all zero; frame counts that leave the last block partly empty."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(17)
+    amp = {"unit": 1.0, "tiny": 1e-3, "large": 300.0, "outlier": 1.0, "zero": 0.0}[case]
+    x = torch.randn(Fr, cin, Hin, Hin) * amp
+    if case == "outlier":
+        x[1, 3, 2, 5] = 3e4
+    sc, sh = torch.rand(cin) + 0.5, torch.randn(cin) * 0.2 * amp
+    w, b = torch.randn(cout, cin, 4, 4) / (16 * cin) ** 0.5, torch.randn(cout) * 0.1
+    ref = F.conv2d(F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2).double(), w.double(), b.double(), stride=2, padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wp, bd = pk.pack_conv4x4(w).to(dev), b.to(dev)
+    ws, e = pk.pack_conv4x4_split(w)
+    ws = ws.to(dev)
+    err = {}
+    for name in ("f32", "split"):
+        out = torch.full((Fr, Hin // 2, Hin // 2, cout), float("nan"), device=dev)
+        a = _conv_args(rt, [(xd, cin, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=Hin, Win=Hin, Hout=Hin // 2, Wout=Hin // 2,
+                       Cout=cout, out_pitch=cout, wpk=wp, bias=bd, out=out)
+        if name == "split":
+            a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+        rt.check(lib.gcpx_conv4x4s2(C.byref(a), _stream()), name)
+        torch.cuda.synchronize()
+        got = out.cpu().permute(0, 3, 1, 2).double()
+        assert torch.isfinite(got).all()
+        err[name] = (got - ref).abs()
+    scale = float(ref.abs().max())
+    assert float(err["split"].pow(2).mean().sqrt()) <= 1.5 * float(err["f32"].pow(2).mean().sqrt()) + 1e-12 * scale
+    assert float(err["split"].max()) <= 2.0 * float(err["f32"].max()) + 4e-7 * scale
 
 
 @pytest.mark.parametrize("S,Fr", [(32, 5), (64, 3)])

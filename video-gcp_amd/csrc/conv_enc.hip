@@ -11,6 +11,8 @@
 
 #include <cstdlib>
 
+int gcpx_launch_enc_split(const gcpx_conv_args* a, hipStream_t stream, int nrows, int cus);     // conv_enc_split.hip
+
 namespace {
 
 // generic NHWC layer: Cin % 16 == 0.
@@ -468,6 +470,14 @@ extern "C" int gcpx_conv4x4s2(const gcpx_conv_args* a, void* stream_) {
     const int nblk = (ngroups + per_blk - 1) / per_blk;
     // stats_partial has gcpx_conv4x4s2_grid() rows: all of them must be written
     if (!a->stats_partial && grid > nblk) grid = nblk;
+    if (a->wpk_split && a->split_layout == GCPX_SPLIT_PLAIN && !getenv("GCPX_ENC_NOSPLIT")) {
+        const int st = gcpx_launch_enc_split(a, stream, gcpx_conv4x4s2_grid(), gcpx_conv_grid() / 2);
+        if (st < 0) return st;
+        if (st == 0) {
+            GCPX_CHECK_LAUNCH();
+            return GCPX_OK;
+        }
+    }
     if (a->Hin == a->Win && !getenv("GCPX_ENC_DIRECT")) {
         int st = 1;
         if (a->Cin == 16 && a->Cout == 32 && a->Hin == 32) st = launch_enc_lds<16, 32, 32, 1, 4, 1, false>(a, stream);

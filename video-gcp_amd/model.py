@@ -305,10 +305,15 @@ class GCPTreeModel:
                 todo.append((f"dec.{name}", f"decoder.net.{name}.conv.weight", None))
             elif cout in (32, 64) and (c_prev + c_skip) % 32 == 0:     # the workgroup-tiled blocks (conv3x3_up32_split_kernel)
                 todo.append((f"dec.{name}", f"decoder.net.{name}.conv.weight", "tiled32"))
+        for name, cin, cout, norm in self._enc_layers[1:]:   # encoder 4x4 stride-2 blocks (conv4x4s2_split_kernel)
+            if cin == 16 or cin % 32 == 0:
+                todo.append((f"enc.{name}", f"encoder.net.{name}.conv.weight", "enc4x4"))
         for name, key, perm in todo:
             off, shp = self._poff[key]
             d = {}
-            if perm == "rowfold":                            # gcpx_fold_upsample_weights(theta + off) -> scratch, split from there
+            if perm == "enc4x4":
+                idx = pk.conv4x4_split_index(shp, off).to(self.device)
+            elif perm == "rowfold":                            # gcpx_fold_upsample_weights(theta + off) -> scratch, split from there
                 d["fold"] = torch.zeros(24 * shp[0] * shp[1], dtype=torch.float32, device=self.device)
                 d["fold_src"] = (off, shp[0], shp[1])
                 idx = pk.conv3x3_fold_index().to(self.device)
@@ -755,6 +760,7 @@ class GCPTreeModel:
             stats = self._buf(f"{tag}.st{li}", (G, 2, cout)) if self.training else None
             a = self._conv_args([prev], F, res, res, res // 2, res // 2, cout, cout, P[f"enc.{name}.w"],
                                 P[f"enc.{name}.b"], r, stats=stats)
+            self._set_split(a, f"enc.{name}")
             plan.keep.append(a)
             plan.add(f"enc.{name}:{tag}", lib.gcpx_conv4x4s2, C.byref(a))
             res //= 2

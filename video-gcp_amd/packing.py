@@ -113,6 +113,45 @@ def pack_conv4x4(w):
     return w[ct * 16 + li, cg * 16 + lq * 4 + s, tap].contiguous()
 
 
+def conv4x4_split_gather(w):
+    """w [Cout, Cin, 4, 4] (Cin = 16 or a multiple of 32, Cout % 16 == 0, any dtype) -> [NSTEP][CT][64][8] in
+    v_mfma_f32_16x16x32_f16 A-fragment order for conv4x4s2_split_kernel (csrc/conv_enc_split.hip): k-step s of lane
+    (i = lane & 15, q = lane >> 4) holds tap / 8-channel group
+        Cin = 16: 2 s + (q >> 1) / q & 1       Cin = 32: s / q       Cin = 64: s >> 1 / 4 (s & 1) + q     (Cin = 32 m: s // m / 4 (s % m) + q)
+    element el = w[16 ct + i][8 group + el][tap]."""
+    Cout, Cin = w.shape[:2]
+    assert (Cin == 16 or Cin % 32 == 0) and Cout % 16 == 0
+    dev = w.device
+    CT = Cout // 16
+    w = w.reshape(Cout, Cin, 16)
+    nstep = 8 if Cin == 16 else 16 * (Cin // 32)
+    st = torch.arange(nstep, device=dev)[:, None, None, None]
+    ct = torch.arange(CT, device=dev)[None, :, None, None]
+    li = _LI.to(dev)[None, None, :, None]
+    lq = _LQ.to(dev)[None, None, :, None]
+    el = torch.arange(8, device=dev)[None, None, None, :]
+    if Cin == 16:
+        tap, grp = 2 * st + lq // 2, lq % 2
+    else:
+        m = Cin // 32
+        tap, grp = st // m, 4 * (st % m) + lq
+    return w[ct * 16 + li, grp * 8 + el, tap].contiguous()
+
+
+def pack_conv4x4_split(w):
+    """-> (int16 [NSTEP][CT][2][64][8], e): the two f16 pieces in the layout of conv4x4_split_gather"""
+    w1, w2, e = split_f16(conv4x4_split_gather(w))
+    return torch.stack([w1, w2], 2).contiguous().view(torch.int16), e
+
+
+def conv4x4_split_index(shape, offset):
+    n = 1
+    for d in shape:
+        n *= d
+    ids = (torch.arange(n, dtype=torch.float64) + (offset + 1)).view(shape)
+    return (conv4x4_split_gather(ids).reshape(-1) - 1).to(torch.int32)
+
+
 def pack_conv4x4_image(w):
     """First encoder layer, w [16, 3, 4, 4] -> [3*4 (ci, ky)][CT=1][64]: lane (i, kk) holds w[i][ci][ky][kx = kk]."""
     Cout, Cin = w.shape[:2]
