@@ -14,8 +14,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNELS = {"head": "conv3x3_head", "up16": "conv3x3_up16_kernel", "conv3x3_tiled": "conv3x3_kernel<", "gemm": "gemm_kernel<",
-           "mlp": "mlp_kernel<", "enc_lds": "conv4x4s2_lds_kernel", "enc_image": "conv4x4s2_image_kernel"}
+KERNELS = {"head": "conv3x3_head", "up16": "conv3x3_up16", "up32": "conv3x3_up32", "conv3x3_tiled": "conv3x3_kernel<", "gemm": "gemm_kernel<",
+           "gemm_split": "gemm_split_kernel", "mlp": "mlp_kernel<", "mlp_group": "mlp_group_kernel", "enc_lds": "conv4x4s2_lds_kernel",
+           "enc_split": "conv4x4s2_split_kernel", "enc_image": "conv4x4s2_image_kernel"}
 
 
 def main():
