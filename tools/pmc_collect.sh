@@ -21,4 +21,5 @@ done
 # only gpurun_out/ travels back from the GPU box: leave copies of what belongs under profiles/ there
 cp profiles/${ROUND}_pmc_kernels.json profiles/pmc_head_kernel.json "$OUT"/ 2>/dev/null
 cp "$OUT"/prof_stats/*kernel_stats.csv "$OUT/${ROUND}_kernel_stats.csv" 2>/dev/null
-rm -rf "$OUT"/pmc_*/*.db "$OUT"/prof_stats/*.db
+# gpurun_out/ is capped at 64 MiB: the raw counter tables (20 MB per SQ pass) stay on the GPU box, the summaries travel
+rm -rf "$OUT"/pmc_[0-9]* "$OUT"/prof_stats
