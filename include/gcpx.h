@@ -150,7 +150,10 @@ typedef struct gcpx_row_src {
 typedef enum gcpx_gemm_epi {
     GCPX_EPI_NONE = 0,
     GCPX_EPI_LRELU = 1,
-    GCPX_EPI_LSTM = 2    /* N = 4H gate-interleaved (n = 4u+g, g in i,f,g,o): writes h, c; see below */
+    GCPX_EPI_LSTM = 2,   /* N = 4H gate-interleaved (n = 4u+g, g in i,f,g,o): writes h, c; see below */
+    GCPX_EPI_GAUSS_SAMPLE = 3 /* gcpx_gemm_group only — not a GEMM: out[r, n] = mu + exp(log_sigma) * eps with [mu | log_sigma] = the 2N-wide
+                            rows of src[0] and eps = the N-wide rows of src[1] (Gaussian.sample / reparametrize, sequential.py:52): lets
+                            the draw of the next VRNN step ride in a launch of this step instead of being a launch of its own */
 } gcpx_gemm_epi;
 
 typedef struct gcpx_gemm_args {

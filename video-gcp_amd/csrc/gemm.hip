@@ -245,6 +245,16 @@ __global__ void __launch_bounds__(256) gemm_group_kernel(const gcpx_gemm_args* _
     const int local = blockIdx.x - d.x;
     const int bx = local % d.y, by = (local / d.y) % d.z, bz = local / (d.y * d.z);
     const gcpx_gemm_args& a = tab[p];
+    if (a.epi == GCPX_EPI_GAUSS_SAMPLE) {                      // 16 rows x 16 latent dimensions per block (formula of gauss_sample_kernel)
+        const int r = bx * 16 + ((int)threadIdx.x >> 4), d = by * 16 + ((int)threadIdx.x & 15);
+        if (r < a.M) {
+            const int b = r / a.rpb, j = r % a.rpb;
+            const float* m = a.src[0].ptr + (size_t)b * a.src[0].sb + (size_t)j * a.src[0].sr;
+            const float e = a.src[1].ptr[(size_t)b * a.src[1].sb + (size_t)j * a.src[1].sr + d];
+            a.out[(size_t)b * a.ob + (size_t)j * a.orow + d] = m[d] + expf(m[a.N + d]) * e;
+        }
+        return;
+    }
     if (a.epi == GCPX_EPI_LSTM) gemm_tile<1, 1, true, true>(a, bx, by, bz);
     else gemm_tile<1, 1, false, true>(a, bx, by, bz);
 }
@@ -330,6 +340,14 @@ extern "C" int gcpx_gemm_group_dims(const gcpx_gemm_args* host_table, int32_t n,
     GCPX_CHECK_ARG(host_table && dims && total_blocks && n >= 1 && n <= 16, "bad arguments");
     int start = 0;
     for (int p = 0; p < n; ++p) {
+        if (host_table[p].epi == GCPX_EPI_GAUSS_SAMPLE) {      // the reparametrised draw: 16 x 16 elements per block
+            const gcpx_gemm_args& a = host_table[p];
+            GCPX_CHECK_ARG(a.nsrc == 2 && a.src[0].ptr && a.src[1].ptr && a.out && a.M > 0 && a.N > 0 && a.N % 16 == 0 && a.rpb > 0 &&
+                               a.src[0].width == 2 * a.N && a.src[1].width == a.N, "gauss sample: [mu | log_sigma] rows, eps rows, out");
+            dims[4 * p] = start; dims[4 * p + 1] = (a.M + 15) / 16; dims[4 * p + 2] = a.N / 16; dims[4 * p + 3] = 1;
+            start += dims[4 * p + 1] * dims[4 * p + 2];
+            continue;
+        }
         const int st = gemm_check(host_table + p);
         if (st != GCPX_OK) return st;
         if (!gemm_is_small(host_table + p)) {
@@ -357,6 +375,7 @@ extern "C" int gcpx_gemm_group(const gcpx_gemm_args* dev_table, const int32_t* d
 
 static int gemm_check(const gcpx_gemm_args* a) {
     GCPX_CHECK_ARG(a != nullptr, "null args");
+    GCPX_CHECK_ARG(a->epi != GCPX_EPI_GAUSS_SAMPLE, "GCPX_EPI_GAUSS_SAMPLE is a gcpx_gemm_group problem");
     GCPX_CHECK_ARG(a->nsrc >= 1 && a->nsrc <= 6, "nsrc out of range");
     GCPX_CHECK_ARG(a->M > 0 && a->N > 0 && a->N % 16 == 0 && a->rpb > 0, "bad M/N/rpb");
     int ksum = 0;

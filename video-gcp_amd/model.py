@@ -610,7 +610,11 @@ class GCPTreeModel:
                 plan.add(name, self.lib.gcpx_gemm_group, raw.data_ptr(), dd.data_ptr(), n, total.value)
                 return
         for nm, a in group:
-            plan.add(nm, self.lib.gcpx_gemm, C.byref(a))
+            if a.epi == rt.EPI_GAUSS_SAMPLE:                 # the reparametrised draw that rides in grouped launches (sequential.py)
+                m, e = a.src[0], a.src[1]
+                plan.add(nm, self.lib.gcpx_gauss_sample, m.ptr, m.sb, m.sr, e.ptr, e.sb, e.sr, a.out, a.ob, a.orow, a.M, a.rpb, a.N)
+            else:
+                plan.add(nm, self.lib.gcpx_gemm, C.byref(a))
 
     def _gemm(self, plan, name, srcs, M, N, rpb, wpk, bias, out=None, ob=0, orow=0, epi=rt.EPI_NONE,
               stats=None, lstm=None, batch=None, group=None):

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgcpx.so")
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 HEAD_RAW, HEAD_DLM_MEAN, HEAD_DLM_BOTH, HEAD_TANH_NCHW = 0, 1, 2, 3
 SPLIT_PLAIN, SPLIT_ROWFOLD = 0, 1
-EPI_NONE, EPI_LRELU, EPI_LSTM = 0, 1, 2
+EPI_NONE, EPI_LRELU, EPI_LSTM, EPI_GAUSS_SAMPLE = 0, 1, 2, 3
 MLP_PLAIN, MLP_GAUSS = 0, 1
 
 vp = C.c_void_p

@@ -48,9 +48,19 @@ class GCPSequentialModel(GCPTreeModel):
             w, b = pk.lstm_gate_interleave((Wih @ We).float(), sd[f"{p}.lstm.0.weight_hh"],
                                            (Wih @ be).float() + sd[f"{p}.lstm.0.bias_ih"], sd[f"{p}.lstm.0.bias_hh"])
             self.pk[net]["lstm0f.w"], self.pk[net]["lstm0f.b"] = pk.pack_gemm(w), b
+            if net == "gen_lstm":
+                # the generator's own output projection folded in as well: x_{t+1} = W_out h_top(t) + b_out only enters step t + 1
+                # through layer 0, so layer 0 of step t + 1 reads h_top(t) with (W_ih W_e)[:, x] W_out — the out Linear leaves the
+                # dependent chain (3 launches per step instead of 4; x_{t+1} itself is still computed, beside the chain)
+                nz = self._hp.nz_enc
+                Wf, Wo, bo = Wih @ We, sd[f"{p}.out.weight"].double(), sd[f"{p}.out.bias"].double()
+                W2 = torch.cat([Wf[:, :nz] @ Wo, Wf[:, nz:]], 1).float()
+                b2 = (Wih @ be + Wf[:, :nz] @ bo).float() + sd[f"{p}.lstm.0.bias_ih"]
+                w, b = pk.lstm_gate_interleave(W2, sd[f"{p}.lstm.0.weight_hh"], b2, sd[f"{p}.lstm.0.bias_hh"])
+                self.pk[net]["lstm0ff.w"], self.pk[net]["lstm0ff.b"] = pk.pack_gemm(w), b
 
     # ------------------------------------------------------------------------------------------------
-    def _hsp_stages(self, plan, name, W, srcs, B, state, par, out_ptr, out_ob, N_out):
+    def _hsp_stages(self, plan, name, W, srcs, B, state, par, out_ptr, out_ob, N_out, w0="lstm0f"):
         """One step of a recurrent predictor as its dependent stages: [LSTM layer 0 (with the folded embedding), layer 1, ...,
         out Linear].  Each stage is a function(group) that appends its GEMM to `group` — the same stage of nets that do not
         depend on each other then shares ONE launch (gcpx_gemm_group)."""
@@ -69,7 +79,7 @@ class GCPSequentialModel(GCPTreeModel):
                 hs = self._rowsrc(s_in.data_ptr(), 2 * H, 0, H)
                 lstm = (_addr(s_in, H), 2 * H, s_out.data_ptr(), _addr(s_out, H), 2 * H, 0, xs_buf[i + 1].data_ptr())
                 if i == 0 and fused:
-                    self._gemm(plan, f"{name}.lstm0", list(srcs) + [hs], B, 4 * H, 1, W["lstm0f.w"], W["lstm0f.b"], epi=rt.EPI_LSTM,
+                    self._gemm(plan, f"{name}.lstm0", list(srcs) + [hs], B, 4 * H, 1, W[w0 + ".w"], W[w0 + ".b"], epi=rt.EPI_LSTM,
                                lstm=lstm, group=g)
                 else:
                     self._gemm(plan, f"{name}.lstm{i}", [xs, hs], B, 4 * H, 1, W[f"lstm{i}.w"], W[f"lstm{i}.b"], epi=rt.EPI_LSTM,
@@ -166,15 +176,71 @@ class GCPSequentialModel(GCPTreeModel):
                         c[i](g)
                 self._gemm_group(plan, f"step.{g[0][0]}", g)
 
+        def sample_stage(t):
+            """z_t = mu + exp(log_sigma) eps of q(z_t) as a one-stage chain: the draw rides in a grouped launch (GCPX_EPI_GAUSS_SAMPLE)"""
+            def st(g):
+                a = rt.GemmArgs()
+                a.src[0] = self._rowsrc(_addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 0, 2 * nv)
+                a.src[1] = self._rowsrc(_addr(tin["eps"], t * nv), tin["eps"].shape[1] * nv, 0, nv)
+                a.nsrc, a.M, a.N, a.K, a.rpb, a.epi = 2, B, nv, 3 * nv, 1, rt.EPI_GAUSS_SAMPLE
+                a.out, a.ob, a.orow = _addr(Z, t * nv), (T - 1) * nv, 0
+                plan.keep.append(a)
+                g.append((f"sample{t}", a))
+            return [st]
+
         z_from_prior = not has_z and not posterior          # prior sampling: z_t needs prior(t), which needs x_t: one serial chain
-        if has_traj:
+        if has_traj and not (posterior and "lstm0ff.w" in P["gen_lstm"] and not self.save_for_backward):
             run(inf_stages(0))
+        fold_out = posterior and "lstm0ff.w" in P["gen_lstm"] and not self.save_for_backward
+        if posterior and fold_out:
+            # Launch schedule of the posterior rollout.  A generator step is THREE dependent launches (layer 0 reads the previous
+            # step's top hidden state through the folded output projection); everything else rides in those launches:
+            #   inf(t)      stages at 3 t .. 3 t + 3        (reads encoded ground truth only: 2 steps ahead of the generator)
+            #   sample(t)   at 3 t + 5                       (q(z_t) is complete after 3 t + 3)
+            #   gen(t)      layers at 3 t + 6 .. 3 t + 8
+            #   out(t)      = x_{t+1}, at 3 t + 9            (beside layer 0 of gen(t + 1))
+            #   prior(t)    stages at 3 t + 7 .. 3 t + 10    (needs x_t = out(t - 1) from 3 t + 6; feeds only the KL term)
+            sched = {}
+
+            def place(chain, start):
+                for i, st in enumerate(chain):
+                    sched.setdefault(start + i, []).append(st)
+            top = lambda t: self._rowsrc(self._buf(f"gen{t}.x{nl}", (B, H)).data_ptr(), H, 0, H)
+            for t in range(T - 1):
+                place(inf_stages(t), 3 * t)
+                place(sample_stage(t), 3 * t + 5)
+                zsrc = self._rowsrc(_addr(Z, t * nv), (T - 1) * nv, 0, nv)
+                if t == 0:
+                    g_st = gen_stages(0, zsrc)
+                else:
+                    g_st = self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [top(t - 1), zsrc] + ctx(), B, state["gen_lstm"], t & 1,
+                                            _addr(X, (t + 1) * nz), T * nz, nz, w0="lstm0ff")
+                place(g_st[:-1], 3 * t + 6)
+                place(g_st[-1:], 3 * t + 9)
+                place(prior_stages(t), 3 * t + 7)
+            for L in sorted(sched):
+                g = []
+                for st in sched[L]:
+                    st(g)
+                self._gemm_group(plan, f"launch{L}.{g[0][0]}", g)
+        elif posterior:
+            # The inference net runs TWO steps ahead of the generator: q(z_{t+1}) is complete when step t starts, so its draw shares
+            # a launch of step t (79 launches of ~5 us off the dependent chain); only the first draw is a launch of its own.
+            if T - 1 > 1:
+                run(inf_stages(1))
+            z_source(0)
         for t in range(T - 1):
+            if posterior and fold_out:
+                break
             if z_from_prior:
                 run(prior_stages(t))
                 run(gen_stages(t, z_source(t)))
+            elif posterior:
+                zsrc = self._rowsrc(_addr(Z, t * nv), (T - 1) * nv, 0, nv)
+                run(gen_stages(t, zsrc), inf_stages(t + 2) if t + 2 < T - 1 else None, prior_stages(t),
+                    sample_stage(t + 1) if t + 1 < T - 1 else None)
             else:
-                zsrc = z_source(t)                            # q(z_t) was produced one step ahead
+                zsrc = z_source(t)                            # z is fed; q(z_t) (for the KL term) was produced one step ahead
                 run(gen_stages(t, zsrc), inf_stages(t + 1) if (has_traj and t + 1 < T - 1) else None, prior_stages(t))
 
         # ---- latent-space heads next to the decoder ----
