@@ -62,6 +62,12 @@ class GCPTrainStep:
         # the decoder's weight gradients (5 ms of throughput-bound kernels) are forked after the decoder's data-gradient chain: they then
         # fill the chip during the latency-bound tree phase instead of competing with the data gradients (23.2 -> 22.8 ms / step)
         self.defer_decoder_side = os.environ.get("GCPX_NO_DEFER_DEC_SIDE") is None
+        # ... and held back further, until the tree backward has passed its large levels: issued right behind the decoder's data
+        # gradients they ran beside the level L-1 / L-2 GEMMs of the tree (1024 / 512 rows, throughput-bound) and stretched two of them
+        # from ~0.1 to 1.5 ms each on the critical lane (profiles/r02f_train_lanes.txt); below those levels the tree backward is a
+        # chain of small launches that leaves the chip to the weight gradients.  GCPX_DEC_SIDE_LEVEL = level after which they go out
+        # (default L - 2; >= L: right after the decoder, the old behaviour).
+        self.dec_side_level = int(os.environ.get("GCPX_DEC_SIDE_LEVEL", str(hp.hierarchy_levels - 2)))
         self.group_wgrads = os.environ.get("GCPX_NO_WGROUP") is None   # one grouped launch per level and kernel variant
         self.side_lanes = bool(hp.untied_layers)   # tied levels accumulate into the same weights: keep them on one lane
         self.wgrad_waves = 8192               # wavefronts a split weight-gradient launch aims for (latency hiding)
@@ -535,7 +541,11 @@ class GCPTrainStep:
         self._flush(plan)
         # ---- decoder (tree_dense_rec.py:42 backward) ----
         dE_dec, dskip = self._decoder_backward(plan, fplan, dMD, B)
-        self._flush(plan)
+        held = []
+        if self.side_lanes and 0 <= self.dec_side_level < L:
+            held, plan.deferred = plan.deferred, []
+        else:
+            self._flush(plan)
         if adaptive:
             plan.add("bw.addrows", lib.gcpx_add_rows, _addr(dE, nz), PS * nz, nz, dE_dec.data_ptr(), None, B, N, nz)
             # distance predictor inputs were (node p, node p + 1), p < N - 1 (adaptive.py:66-67)
@@ -670,6 +680,8 @@ class GCPTrainStep:
             if dXa is not None:
                 srcs.append((dXa.data_ptr(), 2 * nz, 0, nz, -1, -1, 0))
             self._tree_accum(plan, f"E{l}", dE, PS * nz, 2 * s * nz, B, n, nz, srcs)
+            if held and l <= self.dec_side_level:
+                plan.deferred, held = held + plan.deferred, []
             self._flush(plan)
             if f"tree{l}" in self._bucket_index:
                 # every gradient of this level's module has been issued (main lane + the side lanes just flushed): its bucket of the
