@@ -883,11 +883,16 @@ def test_wgrad_group_matches_single_launches(env):
 
 @pytest.mark.parametrize("S,cin,cout,Fr,use_frames", [(32, 112, 16, 9, True), (32, 112, 16, 9, False), (64, 48, 16, 5, True),
                                                       (32, 16, 32, 6, None), (64, 16, 32, 3, None)])
-def test_conv3x3_plain_row_maps(env, S, cin, cout, Fr, use_frames):
+@pytest.mark.parametrize("split", [False, True, "tiny"])
+def test_conv3x3_plain_row_maps(env, S, cin, cout, Fr, use_frames, split):
     """Plain 3x3 conv (the data gradients of the training step): frames read source rows through src_row_map (negative: zeros);
     with the inverse map from gcpx_index_inverse the wave-autonomous kernel walks the rows, without it the tiled kernel runs —
-    both against F.conv2d on the gathered rows.  A padded row that no frame reads must not leak into any frame."""
+    both against F.conv2d on the gathered rows.  A padded row that no frame reads must not leak into any frame.
+    split: the split-f16 form of the wave-autonomous kernel (conv3x3_wave_split_kernel); "tiny": on data of magnitude 1e-6 with
+    chunks that differ 100-fold (loss gradients: the per-item scale has to follow the chunks), error relative to the result."""
     rt, pk, lib, dev = env
+    if split and use_frames is False:
+        pytest.skip("without the inverse map the tiled exact kernel runs")
     torch.manual_seed(S + cin + Fr)
     w = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5
     wp, bd = pk.pack_conv3x3(w, 16).to(dev), torch.zeros(64, device=dev)
@@ -901,10 +906,16 @@ def test_conv3x3_plain_row_maps(env, S, cin, cout, Fr, use_frames):
         for f, r in zip(rows, free):
             fmap[f] = r
     x = torch.randn(R, cin, S, S)
+    if split == "tiny":
+        x *= 1e-6 * torch.logspace(0, 2, cin)[None, :, None, None]
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
     out = torch.full((Fr, S, S, cout), float("nan"), device=dev)
     a = _conv_args(rt, [(xd, cin, 1, None, None, rt.ACT_NONE)], F=Fr, Hin=S, Win=S, Hout=S, Wout=S, Cout=cout, out_pitch=cout,
                    upsample=0, head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out)
+    if split:
+        ws, e = pk.pack_conv3x3_split(w)
+        ws = ws.to(dev)
+        a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
     if fmap is not None:
         fd = fmap.to(dev)
         a.src_row_map = fd.data_ptr()
@@ -926,4 +937,5 @@ def test_conv3x3_plain_row_maps(env, S, cin, cout, Fr, use_frames):
         r = f if fmap is None else int(fmap[f])
         if r >= 0:
             want[f] = full[r]
-    assert_close(out.permute(0, 3, 1, 2), want, atol=3e-5, rtol=1e-5, name="plain conv3x3")
+    scale = float(want.abs().max())
+    assert_close(out.permute(0, 3, 1, 2), want, atol=3e-5 * min(1.0, scale), rtol=1e-5, name="plain conv3x3")

@@ -22,6 +22,7 @@
 int gcpx_launch_up16_split(const gcpx_conv_args* a, hipStream_t stream, int grid);      // conv3x3_split.hip
 int gcpx_launch_up32_split(const gcpx_conv_args* a, hipStream_t stream, int which, int grid);
 int gcpx_launch_up16_fold(const gcpx_conv_args* a, hipStream_t stream, int grid);
+int gcpx_launch_wave_split(const gcpx_conv_args* a, hipStream_t stream, int ct, int depth);
 
 namespace {
 
@@ -1282,12 +1283,20 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
         if (!tiled_only && W % 16 == 0 && a->Hout % 4 == 0 && a->Cout == 16 && a->out_pitch % 4 == 0 && CT == 1 && a->Cin >= 32 &&
             (!a->src_row_map || a->src_row_frames) && WaveCfg<1>::lds_bytes(a->Cin / 16) <= 152 * 1024) {
             if (query_only) return gcpx_conv_grid() / 2;
+            if (a->wpk_split && a->split_layout == GCPX_SPLIT_PLAIN) {
+                const int st = gcpx_launch_wave_split(a, stream, 1, depth);
+                if (st != -1) return st;
+            }
             return depth == 2 ? launch_wave<1, 2>(a, stream) : launch_wave<1, 1>(a, stream);
         }
         static const bool wave32 = getenv("GCPX_DGRAD_NOWAVE32") == nullptr;     // 32 output channels (16-channel decoder blocks): 874 vs 912 us tiled
         if (wave32 && !tiled_only && W % 16 == 0 && a->Hout % 4 == 0 && a->Cout == 32 && a->out_pitch % 4 == 0 && a->Cin % 16 == 0 &&
             (!a->src_row_map || a->src_row_frames) && WaveCfg<2>::lds_bytes(a->Cin / 16) <= 152 * 1024) {
             if (query_only) return gcpx_conv_grid() / 2;
+            if (a->wpk_split && a->split_layout == GCPX_SPLIT_PLAIN) {
+                const int st = gcpx_launch_wave_split(a, stream, 2, 1);
+                if (st != -1) return st;
+            }
             return launch_wave<2, 1>(a, stream);
         }
         const int tile = W >= 32 ? 0 : (W == 16 ? 1 : (W == 8 ? 2 : -1));

@@ -1148,6 +1148,239 @@ __global__ void __launch_bounds__(512, 2) conv3x3_up16_fold_kernel(const gcpx_co
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------
+// Plain 3x3 conv at full resolution with several 16-channel input chunks in split-f16: the data gradients of the output head
+// (112 -> 16) and of the 16-channel decoder blocks (16 -> 32).  Control flow of conv3x3_wave_kernel (conv3x3.hip): items dealt
+// round-robin over the grid's wavefronts, buffer loads with hardware bounds-check zeros, a prefetch cursor DEPTH (item, chunk) steps
+// ahead, rows that no frame reads skipped, frames without a source row zero-filled up front.  Arithmetic of
+// conv3x3_up16_split_kernel: a chunk's 6 x 18 x 16ch region as two f16 planes, 5 k-steps x CT x 4 tiles x 3 MFMAs, the
+// power-of-two scale following the chunks (loss gradients of 1e-6 need it: unscaled they would sit in the f16 subnormals).
+// -----------------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+
+template <int CT>
+struct WaveSplitCfg {
+    static constexpr int RW = 18, RH = 6, KS = 5;
+    static constexpr int PLANE_BYTES = RH * RW * 32;
+    static constexpr int REGION_BYTES = 2 * PLANE_BYTES;
+    static constexpr int W_CHUNK_BYTES = KS * CT * 2 * 1024;
+    static constexpr int NS = (RH * RW * 4 + 63) / 64;
+    static int lds_bytes(int nchunk) { return nchunk * W_CHUNK_BYTES + 8 * REGION_BYTES; }
+};
+
+template <int CT, int DEPTH>
+__global__ void __launch_bounds__(512, 2) conv3x3_wave_split_kernel(const gcpx_conv_args a, const int nitems) {
+    using Cfg = WaveSplitCfg<CT>;
+    constexpr int RW = Cfg::RW, RH = Cfg::RH, NS = Cfg::NS, KS = Cfg::KS;
+    extern __shared__ float4 smem4[];
+    const int nchunk = a.Cin / 16;
+    const char* wl = reinterpret_cast<const char*>(smem4);                  // [nchunk][KS][CT][2][64] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* reg = reinterpret_cast<char*>(smem4) + nchunk * Cfg::W_CHUNK_BYTES + wave * Cfg::REGION_BYTES;
+    const int j = lane & 15, q = lane >> 4;
+    const int H = a.Hout, W = a.Wout;
+    const int ncb = W / 16, nrp = H / 4, ipf = ncb * nrp;
+    const gcpx_conv_src sr = a.src[0];
+    const int Cs = sr.C;
+
+    for (int i = tid; i < nchunk * Cfg::W_CHUNK_BYTES / 16; i += 512) smem4[i] = reinterpret_cast<const float4*>(a.wpk_split)[i];
+    if (a.src_row_frames) {                                 // frames without a source row get zeros
+        const int f4_per_frame = H * W * a.out_pitch / 4;
+        for (int f = blockIdx.x; f < a.F; f += gridDim.x) {
+            if (a.src_row_map[f] >= 0) continue;
+            float4* op = reinterpret_cast<float4*>(a.out + (size_t)f * H * W * a.out_pitch);
+            for (int i = tid; i < f4_per_frame; i += 512) op[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+
+    int tapoff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int tap = min(2 * s + (q >> 1), 8);
+        tapoff[s] = ((tap / 3) * RW + (tap % 3) + j) * 32 + (q & 1) * 16;
+    }
+    const int ew = a.w_split_log2_dev ? __builtin_amdgcn_readfirstlane(*a.w_split_log2_dev) : a.w_split_log2;
+    const int ex_cap = min(100, 126 - ew);
+
+    const int stride = gridDim.x * 8;
+    const int lb = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int first = lb * 8 + wave;
+    const int nmine = first < nitems ? (nitems - first + stride - 1) / stride : 0;
+    const int nsteps = nmine * nchunk;
+
+    int s_ry[NS], s_rx[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int t = (lane + 64 * k) >> 2;
+        s_rx[k] = t % RW;
+        s_ry[k] = t / RW;
+    }
+    auto geom = [&](int k, int& srow, int& y0, int& x0) {
+        const int it = first + k * stride;
+        srow = it / ipf;
+        const int rem = it - srow * ipf;
+        y0 = (rem / ncb) * 4; x0 = (rem % ncb) * 16;
+    };
+
+    // ---- prefetch cursor (conv3x3_wave_kernel) ----
+    int pk = 0, pchunk = 0;
+    unsigned poff[NS];
+    unsigned pmask = 0;
+    const float* pbase = sr.ptr;
+    const unsigned frame_bytes = (unsigned)H * W * Cs * 4;
+    int pf_next_v = 0;
+    auto frame_of_item = [&](int k) { return a.src_row_frames[(first + k * stride) / ipf]; };
+    if (a.src_row_frames && nmine > 0) pf_next_v = frame_of_item(0);
+    auto enter_item = [&]() {
+        int srow, y0, x0;
+        geom(pk, srow, y0, x0);
+        pbase = sr.ptr + (size_t)srow * H * W * Cs;
+        bool live = true;
+        if (a.src_row_frames) {
+            live = __builtin_amdgcn_readfirstlane(pf_next_v) >= 0;
+            if (pk + 1 < nmine) pf_next_v = frame_of_item(pk + 1);
+        }
+        pmask = 0;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int idx = lane + 64 * k;
+            const int sy = y0 - 1 + s_ry[k], sx = x0 - 1 + s_rx[k];
+            const bool ok = live && idx < RH * RW * 4 && sy >= 0 && sy < H && sx >= 0 && sx < W;
+            poff[k] = ok ? (unsigned)((__umul24(sy, W) + sx) * Cs + (idx & 3) * 4) * 4u : 0x80000000u;
+            pmask |= ok ? 1u << k : 0u;
+        }
+    };
+    auto issue = [&](float4 (&pre)[NS], unsigned& ok) {
+        if (pk >= nmine) return;
+        if (pchunk == 0) enter_item();
+        const unsigned long long pb = reinterpret_cast<unsigned long long>(pbase);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pb), hi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, frame_bytes, 0x00020000);
+        const int soff = pchunk * 64;
+        ok = pmask;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const u32x4s v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, poff[k], soff, 0);
+            pre[k] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+        if (++pchunk == nchunk) { pchunk = 0; ++pk; }
+    };
+
+    f32x4 acc[CT][4];
+    int ck = 0, cchunk = 0;
+    int f_v = 0;
+    int ex = 0;                                             // the accumulators hold (sum) 2^(ex + ew)
+    auto step = [&](float4 (&pre)[NS], unsigned& ok) {
+        if (__builtin_amdgcn_readfirstlane(ok) == 0) {      // skipped item
+            issue(pre, ok);
+            if (++cchunk == nchunk) { cchunk = 0; ++ck; }
+            return;
+        }
+        // registers -> (producer's affine + activation) -> the chunk's largest magnitude -> two f16 planes
+        float amax = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            float4 v = pre[k];
+            if (ok & (1u << k)) v = affine_act4(v, sr.scale, sr.shift, cchunk * 16 + ((lane + 64 * k) & 3) * 4, sr.act);
+            pre[k] = v;
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        amax = wave_max_nonneg(amax);
+        int ec = 14 + 127 - (int)((__float_as_uint(amax) >> 23) & 0xff);
+        ec = __builtin_amdgcn_readfirstlane(amax > 0.f ? max(-100, min(ex_cap, ec)) : ex_cap);
+        if (cchunk == 0) ex = ec;
+        else if (ec < ex) {                                 // larger values than before: lower the scale, rescale the sums (exact)
+            const float r = __uint_as_float((unsigned)(127 + ec - ex) << 23);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ct][pt] *= r;
+            ex = ec;
+        }
+        const float sx2 = __uint_as_float((unsigned)(127 + ex) << 23);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int idx = lane + 64 * k;
+            if (idx < RH * RW * 4) {
+                const float4 v = make_float4(pre[k].x * sx2, pre[k].y * sx2, pre[k].z * sx2, pre[k].w * sx2);
+                h4 p1, p2;
+                p1[0] = (_Float16)v.x; p1[1] = (_Float16)v.y; p1[2] = (_Float16)v.z; p1[3] = (_Float16)v.w;
+                p2[0] = (_Float16)fmaf((float)p1[0], -1.f, v.x); p2[1] = (_Float16)fmaf((float)p1[1], -1.f, v.y);
+                p2[2] = (_Float16)fmaf((float)p1[2], -1.f, v.z); p2[3] = (_Float16)fmaf((float)p1[3], -1.f, v.w);
+                char* dst = reg + (idx >> 2) * 32 + (idx & 3) * 8;
+                *reinterpret_cast<h4*>(dst) = p1;
+                *reinterpret_cast<h4*>(dst + Cfg::PLANE_BYTES) = p2;
+            }
+        }
+        issue(pre, ok);                                     // this register set is free again: load the step DEPTH ahead
+        if (cchunk == 0 && a.src_row_frames) f_v = a.src_row_frames[(first + ck * stride) / ipf];
+        if (cchunk == 0) mfma_tiles<0, CT, CT, true>(wl, reg, tapoff, lane, acc);
+        else mfma_tiles<0, CT, CT, false>(wl + cchunk * Cfg::W_CHUNK_BYTES, reg, tapoff, lane, acc);
+
+        if (++cchunk == nchunk) {
+            int srow, y0, x0;
+            geom(ck, srow, y0, x0);
+            const int f = a.src_row_frames ? __builtin_amdgcn_readfirstlane(f_v) : srow;
+            const float inv = __uint_as_float((unsigned)(127 - ex - ew) << 23);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                float* op = a.out + (((size_t)f * H + (y0 + pt)) * W + (x0 + j)) * a.out_pitch;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float4 bs = *reinterpret_cast<const float4*>(a.bias + ct * 16 + q * 4);
+                    const f32x4 v = acc[ct][pt];
+                    *reinterpret_cast<float4*>(op + ct * 16 + q * 4) =
+                        make_float4(fmaf(v[0], inv, bs.x), fmaf(v[1], inv, bs.y), fmaf(v[2], inv, bs.z), fmaf(v[3], inv, bs.w));
+                }
+            }
+            cchunk = 0; ++ck;
+        }
+    };
+
+    float4 preA[NS];
+    unsigned okA = 0;
+    issue(preA, okA);
+    if constexpr (DEPTH == 2) {
+        float4 preB[NS];
+        unsigned okB = 0;
+        issue(preB, okB);
+        for (int s = 0; s < nsteps; s += 2) {
+            step(preA, okA);
+            if (s + 1 < nsteps) step(preB, okB);
+        }
+    } else {
+        for (int s = 0; s < nsteps; ++s) step(preA, okA);
+    }
+}
+
+template <int CT, int DEPTH>
+int launch_wave_split_t(const gcpx_conv_args* a, hipStream_t stream) {
+    using Cfg = WaveSplitCfg<CT>;
+    auto kern = conv3x3_wave_split_kernel<CT, DEPTH>;
+    const int lds = Cfg::lds_bytes(a->Cin / 16);
+    static int attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            gcpx_set_error("conv3x3 wave split: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
+        attr_lds = lds;
+    }
+    const int frames = a->src_row_frames ? a->n_src_rows : a->F;
+    const int nitems = frames * (a->Hout / 4) * (a->Wout / 16);
+    int grid = gcpx_conv_grid() / 2;
+    if (nitems == 0) grid = a->src_row_frames ? grid : 0;
+    else if (grid * 8 > nitems && !a->src_row_frames) grid = (nitems + 7) / 8;
+    if (grid == 0) return GCPX_OK;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, nitems);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
 // out[t][co][ci] of gcpx_fold_upsample_weights (float64 sums in tap-row order; every product is exact)
 __global__ void __launch_bounds__(256) fold_up_weights_kernel(const float* __restrict__ w, const int Cout, const int Cin, float* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1300,4 +1533,16 @@ extern "C" int gcpx_fold_upsample_weights(const float* w, int32_t Cout, int32_t 
     hipLaunchKernelGGL(fold_up_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), w, Cout, Cin, out);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
+}
+
+// plain 3x3 conv, 16 (ct = 1) or 32 (ct = 2) output channels, 16-channel input chunks, split-f16 weights (packing.pack_conv3x3_split):
+// -1 when the shape has no split form (too many chunks for the LDS)
+int gcpx_launch_wave_split(const gcpx_conv_args* a, hipStream_t stream, int ct, int depth) {
+    const int nchunk = a->Cin / 16;
+    if (ct == 1) {
+        if (WaveSplitCfg<1>::lds_bytes(nchunk) > 160 * 1024) return -1;
+        return depth == 2 ? launch_wave_split_t<1, 2>(a, stream) : launch_wave_split_t<1, 1>(a, stream);
+    }
+    if (WaveSplitCfg<2>::lds_bytes(nchunk) > 160 * 1024) return -1;
+    return launch_wave_split_t<2, 1>(a, stream);
 }

@@ -53,6 +53,7 @@ class GCPTrainStep:
         self._bucket_index = {name: i for i, (name, _, _) in enumerate(ranges)} if process_group is not None else {}
         self.buckets = GradBuckets(self.grad, ranges, process_group) if process_group is not None else None
         self.bk = model.build_arena(self._pack_backward)
+        self._pack_backward_split()
         self._bplans = {}
         # backward plans are built from forward plans: drop them whenever the model drops those (load_state_dict, build_arena)
         model._plan_listeners = getattr(model, "_plan_listeners", []) + [self._bplans.clear]
@@ -102,6 +103,38 @@ class GCPTrainStep:
         for i, (c0, w) in enumerate(splits):
             T[f"wT_in{i}"] = pk.pack_gemm(w_in[:, c0:c0 + w].t().contiguous())   # [N = w][K = mid]
         return T
+
+    def _pack_backward_split(self):
+        """Split-f16 pieces of the transposed, flipped weights of the data-gradient convs that run the wave-autonomous kernel
+        (conv3x3_wave_split_kernel): the output head's (112 kernel slots -> 16) and the 16-channel decoder blocks' (16 -> 32).  Like
+        the forward's split weights they are index gathers of the flat parameter vector (model.pk_split), re-split by
+        gcpx_split_pack behind every optimizer step."""
+        m, hp = self.m, self.m._hp
+        if not m.split_f16:
+            return
+
+        def ids_of(key):
+            off, shp = m._poff[key]
+            n = 1
+            for d in shp:
+                n *= d
+            return (torch.arange(n, dtype=torch.float64) + (off + 1)).view(shp)
+
+        todo = {}
+        if hp.decoder_distribution == "discrete_logistic_mixture":
+            hw = ids_of("decoder.gen_head.conv.weight")                      # [100, 16, 3, 3]; inputs of the dgrad = kernel slots
+            perm = torch.as_tensor(pk.dlm_channel_perm(hp.n_mixtures))
+            wk = torch.zeros((len(perm),) + tuple(hw.shape[1:]), dtype=hw.dtype)
+            wk[perm >= 0] = hw[perm[perm >= 0]]
+            todo["bw.dec.head"] = wk.flip(2, 3).transpose(0, 1).contiguous()
+        for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
+            if cout == 16 and c_prev + c_skip == 32:
+                todo[f"bw.dec.{name}"] = ids_of(f"decoder.net.{name}.conv.weight").flip(2, 3).transpose(0, 1).contiguous()
+        for name, wT in todo.items():
+            idx = (pk.conv3x3_split_gather(wT).reshape(-1) - 1).to(torch.int32).to(m.device)
+            m.pk_split[name] = dict(idx=idx, out=torch.zeros(2 * idx.numel(), dtype=torch.int16, device=m.device),
+                                    log2=torch.zeros(1, dtype=torch.int32, device=m.device))
+        m.repack_split()
 
     def _pack_backward(self, sd):
         m, hp = self.m, self.m._hp
@@ -778,6 +811,7 @@ class GCPTrainStep:
             row2frame = buf("bw.row2frame", (B * T,), torch.int32)
             plan.add("bw.row2frame", lib.gcpx_index_inverse, o["node2row"].data_ptr(), F, row2frame.data_ptr(), B * T)
             a.src_row_frames, a.n_src_rows = row2frame.data_ptr(), B * T
+        m._set_split(a, "bw.dec.head")
         plan.keep.append(a)
         plan.add("bw.dgrad:dec.head", lib.gcpx_conv3x3, C.byref(a))
 
@@ -803,6 +837,8 @@ class GCPTrainStep:
                 a = m._conv_args([(dy.data_ptr(), cout, 1, None, None, rt.ACT_NONE)], F, res, res, res, res, ch, cin,
                                  self.bk[f"dec.{name}.wT{h}"], self._zeros, dU)
                 a.out = dU.data_ptr() + 4 * 64 * h
+                if h == 0 and cin <= 64:
+                    m._set_split(a, f"bw.dec.{name}")
                 plan.keep.append(a)
                 plan.add(f"bw.dgrad:dec.{name}.{h}", lib.gcpx_conv3x3, C.byref(a))
             if c_skip:
