@@ -451,7 +451,7 @@ def main():
             "metric": "predicted frames/sec, 64x64x3 seq_len=80 gcp_tree (train-mode posterior forward with batch-stat BatchNorm, no loss kernels)",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" + (" (decoder convs: split-f16 MFMA with f32 accumulate, f32-equivalent; everything else exact f32)" if split else ""),
+            "vs_baseline": None, "dtype": "f32" + (" (encoder / decoder convs and the tree GEMMs from 512 rows: split-f16 MFMA with f32 accumulate, f32-equivalent; everything else exact f32 MFMA)" if split else ""),
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 25-room gcp_tree forward, 64x64x3, seq_len 80, batch 16/GPU, "
                                    "L=7 (127 nodes/seq decoded), discrete-logistic-mixture head, "
