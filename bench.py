@@ -196,7 +196,7 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
         try:
             model.split_f16 = False
             model._clear_plans()
-            dt = _timed(lambda: model(dinp, "train", noise=dnoise), k, 2, world, dev)
+            dt = _timed(lambda: model(dinp, "train"), k, 2, world, dev)
             res["forward_exact_f32"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
                                         "ms_per_step": round(1e3 * dt, 3),
                                         "workload": "the headline forward with the split-f16 convs switched off (GCPX_EXACT_F32=1): exact f32 "
@@ -212,7 +212,7 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
         tr, err = setup(lambda: GCPTrainStep(model, process_group=(dist.group.WORLD if world > 1 else None)))
         if not agree(err is None):
             raise RuntimeError(err or "set-up failed on another rank")
-        dt = _timed(lambda: tr.step(full, dnoise), k, 2, world, dev)
+        dt = _timed(lambda: tr.step(full), k, 2, world, dev)
         res["train_step"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
                              "ms_per_step": round(1e3 * dt, 3), "workload": "configs[2] shard: forward + ELBO losses + backward + "
                              "RAdam, batch 16/GPU" + (", one RCCL all-reduce of the flat fp32 gradient per step" if world > 1 else ""),
@@ -399,12 +399,13 @@ def main():
         dinp[k] = buf
     dnoise = noise.to(dev)
 
+    # the latent noise is DRAWN inside every timed step (noise=None: Gaussian.sample() of the reference draws per forward), not fed
     for _ in range(max(args.warmup, 1)):
-        model(dinp, "train", noise=dnoise)
+        model(dinp, "train")
     torch.cuda.synchronize()
 
     model.set_timed_op("dec.head")
-    model(dinp, "train", noise=dnoise)          # builds the split graphs
+    model(dinp, "train")          # builds the split graphs
     torch.cuda.synchronize()
     model.timed_op_ms()
 
@@ -413,7 +414,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model(dinp, "train", noise=dnoise)
+        model(dinp, "train")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

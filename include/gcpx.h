@@ -351,6 +351,10 @@ int gcpx_loss_combine(const gcpx_loss_args* a, void* stream);
    want its exact stream feed the indices instead.) */
 int gcpx_aux_sample_indices(const int64_t* end_ind, const float* u, int32_t B, int32_t temp_dist, int64_t* inv_t0, int64_t* inv_t1,
                             int64_t* cost_start, int64_t* cost_end, void* stream);
+/* the same from four STANDARD-NORMAL numbers per sequence, n [4][B] (u = Phi(n) is uniform on (0, 1)): the draws then come out of the
+   one generator launch that also fills the latent noise of Gaussian.sample(), and this launch sits inside the forward's graph */
+int gcpx_aux_sample_indices_gauss(const int64_t* end_ind, const float* n, int32_t B, int32_t temp_dist, int64_t* inv_t0, int64_t* inv_t1,
+                                  int64_t* cost_start, int64_t* cost_end, void* stream);
 /* rows [4][B] (int32): absolute rows b*T + inv_t0, b*Wd + inv_t1, b*Wd + cost_start, b*Wd + cost_end — the gather-on-load
    sources of `inv_mdl.action_pred(enc_traj_seq[b,t0], model_enc_seq[b,t1])` (inverse_mdl.py:149-169) and
    `cost_mdl.cost_pred(model_enc_seq[b,start], model_enc_seq[b,end])` (cost_mdl.py:108-109, :50) */

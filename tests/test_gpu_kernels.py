@@ -939,3 +939,28 @@ def test_conv3x3_plain_row_maps(env, S, cin, cout, Fr, use_frames, split):
             want[f] = full[r]
     scale = float(want.abs().max())
     assert_close(out.permute(0, 3, 1, 2), want, atol=3e-5 * min(1.0, scale), rtol=1e-5, name="plain conv3x3")
+
+
+def test_aux_sample_indices_uniform_and_gauss(env):
+    """gcpx_aux_sample_indices (four uniform numbers per sequence) and its _gauss twin (four standard-normal numbers, u = Phi(n): they
+    share the generator launch of the latent noise and the kernel sits inside the forward's graph) against the host formulas of
+    synthetic.aux_indices (InverseModel.sample_offsets / CostModel._general_cost index ranges, inverse_mdl.py:84-104, cost_mdl.py:105-107)."""
+    rt, pk, lib, dev = env
+    from video_gcp_amd.synthetic import aux_indices
+    torch.manual_seed(21)
+    B, T = 257, 80
+    end = torch.randint(2, T, (B,), dtype=torch.int64)
+    n = torch.randn(4, B)
+    n[0, :4] = torch.tensor([-9.0, 9.0, 0.0, 5.5])                 # Phi at the ends of the float range
+    u_from_n = (0.5 * torch.erfc(-n.double() * 0.70710678118654752440))
+    u = torch.rand(4, B)
+    outs = {}
+    for name, fn, src, uu in (("uniform", lib.gcpx_aux_sample_indices, u, u.double()), ("gauss", lib.gcpx_aux_sample_indices_gauss, n, u_from_n)):
+        want = aux_indices(end, uu, 1)
+        d = [torch.full((B,), -7, dtype=torch.int64, device=dev) for _ in range(4)]
+        rt.check(fn(end.to(dev).data_ptr(), src.to(dev).data_ptr(), B, 1, *[t.data_ptr() for t in d], _stream()), name)
+        torch.cuda.synchronize()
+        for t, k in zip(d, ("inv_t0", "inv_t1", "cost_start_idx", "cost_end_idx")):
+            assert torch.equal(t.cpu(), want[k]), (name, k)
+        t0, t1, cs, ce = [t.cpu() for t in d]
+        assert bool(((t0 >= 0) & (t1 > t0) & (t1 <= end) & (cs >= 0) & (ce > cs) & (ce <= end)).all())

@@ -16,6 +16,9 @@ for k in ("traj_seq", "I_0", "I_g", "end_ind"):
     buf.copy_(inputs[k])
     dinp[k] = buf
 dnoise = noise.cuda()
+import contextlib
+ctx = torch.cuda.stream(model._stream) if os.environ.get("ON_MODEL_STREAM") else contextlib.nullcontext()
+ctx.__enter__()
 for _ in range(5):
     model(dinp, "train", noise=dnoise)
 torch.cuda.synchronize()

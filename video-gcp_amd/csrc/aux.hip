@@ -7,7 +7,10 @@
 
 namespace {
 
-// u [4][B] uniform draws -> the four index vectors (float64 arithmetic; same formulas as video-gcp_amd/synthetic.py:aux_indices)
+// u [4][B] uniform draws -> the four index vectors (float64 arithmetic; same formulas as video-gcp_amd/synthetic.py:aux_indices).
+// GAUSS: the draws are standard-normal numbers instead (they come out of the same generator launch as the latent noise): their
+// normal CDF is uniform on (0, 1)
+template <bool GAUSS>
 __global__ void aux_sample_indices_kernel(const long long* __restrict__ end_ind, const float* __restrict__ u, const int B,
                                           const int temp_dist, long long* __restrict__ t0, long long* __restrict__ t1,
                                           long long* __restrict__ cs, long long* __restrict__ ce) {
@@ -15,13 +18,14 @@ __global__ void aux_sample_indices_kernel(const long long* __restrict__ end_ind,
     if (b >= B) return;
     const long long e = end_ind[b];
     const double ed = (double)e;
-    long long a = (long long)floor((double)u[b] * (ed - temp_dist + 1));
+    auto uni = [&](int k) { const double v = (double)u[k * B + b]; return GAUSS ? 0.5 * erfc(-v * 0.70710678118654752440) : v; };
+    long long a = (long long)floor(uni(0) * (ed - temp_dist + 1));
     a = min(a, e - temp_dist);
-    long long d = (long long)floor((double)u[B + b] * temp_dist);
+    long long d = (long long)floor(uni(1) * temp_dist);
     d = min(d, (long long)temp_dist - 1);
-    long long s = (long long)floor((double)u[2 * B + b] * ed);
+    long long s = (long long)floor(uni(2) * ed);
     s = min(s, e - 1);
-    long long w = (long long)floor((double)u[3 * B + b] * (ed - (double)s));
+    long long w = (long long)floor(uni(3) * (ed - (double)s));
     w = min(w, e - s - 1);
     t0[b] = a;
     t1[b] = a + 1 + d;
@@ -122,7 +126,17 @@ extern "C" int gcpx_aux_sample_indices(const int64_t* end_ind, const float* u, i
                                        int64_t* inv_t1, int64_t* cost_start, int64_t* cost_end, void* stream_) {
     STREAM();
     GCPX_CHECK_ARG(end_ind && u && inv_t0 && inv_t1 && cost_start && cost_end && B > 0 && temp_dist >= 1, "bad arguments");
-    hipLaunchKernelGGL(aux_sample_indices_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, (const long long*)end_ind, u, B, temp_dist,
+    hipLaunchKernelGGL(aux_sample_indices_kernel<false>, dim3((B + 63) / 64), dim3(64), 0, stream, (const long long*)end_ind, u, B, temp_dist,
+                       (long long*)inv_t0, (long long*)inv_t1, (long long*)cost_start, (long long*)cost_end);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_aux_sample_indices_gauss(const int64_t* end_ind, const float* n, int32_t B, int32_t temp_dist, int64_t* inv_t0,
+                                             int64_t* inv_t1, int64_t* cost_start, int64_t* cost_end, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(end_ind && n && inv_t0 && inv_t1 && cost_start && cost_end && B > 0 && temp_dist >= 1, "bad arguments");
+    hipLaunchKernelGGL(aux_sample_indices_kernel<true>, dim3((B + 63) / 64), dim3(64), 0, stream, (const long long*)end_ind, n, B, temp_dist,
                        (long long*)inv_t0, (long long*)inv_t1, (long long*)cost_start, (long long*)cost_end);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;

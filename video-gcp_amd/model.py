@@ -881,6 +881,10 @@ class GCPTreeModel:
         PS = 2 ** L + 1                                     # slots per batch element
         plan = _Plan(lib)
         G = lib.gcpx_conv_grid()
+        if "aux_n" in tin:
+            AUXK = ("inv_t0", "inv_t1", "cost_start_idx", "cost_end_idx")
+            plan.add("aux_sample_indices", lib.gcpx_aux_sample_indices_gauss, tin["end_ind"].data_ptr(), tin["aux_n"].data_ptr(), B,
+                     hp.inv_mdl_temp_dist, *[tin[k].data_ptr() for k in AUXK])
 
         E = self._buf("E", (B, PS, nz))
         Hid = self._buf("Hid", (B, PS, SD))
@@ -1326,25 +1330,32 @@ class GCPTreeModel:
                 else:
                     lu.uniform_()
                 tin["len_u"] = lu
-            if need_idx and not fed_idx:
-                # InverseModel.sample_offsets / CostModel._general_cost draw their frame indices with np.random on the host
-                # (inverse_mdl.py:84-104, cost_mdl.py:105-107); here: four uniform numbers per sequence, one launch
-                au = self._buf("in.aux_u", (4, B))
-                au.uniform_()
+            # One generator launch per call: the latent noise of Gaussian.sample() and the four numbers per sequence behind the
+            # inverse / cost model index draws (InverseModel.sample_offsets / CostModel._general_cost draw with np.random on the host,
+            # inverse_mdl.py:84-104, cost_mdl.py:105-107) share one buffer [noise | 4 B numbers]; the index kernel reads the
+            # latter as standard-normal draws (u = Phi(n)) and is an op of the plan, i.e. inside the graph.
+            n_eps = 0 if has_z else B * self._n_latents() * hp.nz_vae
+            draw_idx = need_idx and not fed_idx
+            rng = self._buf("rng", (n_eps + (4 * B if draw_idx else 0),)) if (n_eps or draw_idx) else None
+            if draw_idx:
+                tin["aux_n"] = rng[n_eps:].view(4, B)
                 for k in AUX:
                     tin[k] = self._buf("in." + k, (B,), torch.int64)
-                rt.check(self.lib.gcpx_aux_sample_indices(tin["end_ind"].data_ptr(), au.data_ptr(), B, hp.inv_mdl_temp_dist,
-                                                          *[tin[k].data_ptr() for k in AUX], self._stream.cuda_stream), "aux_sample_indices")
             if not has_z:
                 # the draws of Gaussian.sample() live in a persistent buffer as well
-                eps = self._buf("eps", (B, self._n_latents(), hp.nz_vae))
+                eps = rng[:n_eps].view(B, self._n_latents(), hp.nz_vae)
                 if noise is None:
-                    eps.normal_()
-                elif not (noise.is_cuda and noise.data_ptr() == eps.data_ptr()):
-                    eps.copy_(noise)
-                    if noise.is_cuda:
-                        noise.record_stream(self._stream)
+                    rng.normal_()
+                else:
+                    if not (noise.is_cuda and noise.data_ptr() == eps.data_ptr()):
+                        eps.copy_(noise)
+                        if noise.is_cuda:
+                            noise.record_stream(self._stream)
+                    if draw_idx:
+                        tin["aux_n"].normal_()
                 tin["eps"] = eps
+            elif draw_idx:
+                rng.normal_()
         # the plan (and its captured graph) bakes in buffer addresses and sizes: everything that selects buffers is part of the key
         shapes = tuple((k, tuple(tin[k].shape)) for k in sorted(tin))
         key = (B, has_traj, has_z, self._sample_prior, phase, self.training, self.materialize_distr, with_loss, self._decode, pred_len,

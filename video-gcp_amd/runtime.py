@@ -171,6 +171,7 @@ SYMBOLS = [
     ("gcpx_mlp_group", C.c_int, [vp, vp, i32, i32, i32, vp]),
     ("gcpx_loss_aux_heads_bwd", C.c_int, [C.POINTER(LossArgs), vp, vp, vp]),
     ("gcpx_aux_sample_indices", C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    ("gcpx_aux_sample_indices_gauss", C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     ("gcpx_aux_index_rows", C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     ("gcpx_path_cost", C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     ("gcpx_sample_length", C.c_int, [vp, vp, i32, i32, i32, vp, vp]),
