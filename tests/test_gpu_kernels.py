@@ -958,7 +958,8 @@ def test_aux_sample_indices_uniform_and_gauss(env):
     for name, fn, src, uu in (("uniform", lib.gcpx_aux_sample_indices, u, u.double()), ("gauss", lib.gcpx_aux_sample_indices_gauss, n, u_from_n)):
         want = aux_indices(end, uu, 1)
         d = [torch.full((B,), -7, dtype=torch.int64, device=dev) for _ in range(4)]
-        rt.check(fn(end.to(dev).data_ptr(), src.to(dev).data_ptr(), B, 1, *[t.data_ptr() for t in d], _stream()), name)
+        end_d, src_d = end.to(dev), src.to(dev)
+        rt.check(fn(end_d.data_ptr(), src_d.data_ptr(), B, 1, *[t.data_ptr() for t in d], _stream()), name)
         torch.cuda.synchronize()
         for t, k in zip(d, ("inv_t0", "inv_t1", "cost_start_idx", "cost_end_idx")):
             assert torch.equal(t.cpu(), want[k]), (name, k)
