@@ -37,14 +37,14 @@ __device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <int TN>
+template <int TN, int NSUB>
 struct GsCfg {
-    static constexpr int TM = 64, KS = 64;
+    static constexpr int TM = 64, KS = 32 * NSUB;               // a stage = NSUB sub-steps of 32 k
     static constexpr int NCT = TN / 16;                         // column tiles of the workgroup
     static constexpr int W_SUB = NCT * 2048;                    // one 32-k sub-step: [NCT][2 pieces][64 lanes] x 16 B
-    static constexpr int W_BYTES = 2 * W_SUB;
+    static constexpr int W_BYTES = NSUB * W_SUB;
     static constexpr int X_SUB = 4 * 2048;                      // [4 row tiles][2 pieces][64 lanes] x 16 B
-    static constexpr int X_BYTES = 2 * X_SUB;
+    static constexpr int X_BYTES = NSUB * X_SUB;
     static constexpr int STAGE = W_BYTES + X_BYTES + 256;       // + the 64 row exponents
     static constexpr int LDS_BYTES = 2 * STAGE;
     static constexpr int WLD = W_BYTES / (256 * 16);            // 16-byte weight loads per thread and stage (8 / 4)
@@ -52,9 +52,10 @@ struct GsCfg {
 
 // XF: some source carries an affine / activation on load (its per-channel loads are conditional: the memory counter is then drained
 // at every conversion; the plain variant keeps the newer register set in flight)
-template <int TN, bool LSTM, bool XF>
+template <int TN, int NSUB, bool LSTM, bool XF>
 __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a) {
-    using Cfg = GsCfg<TN>;
+    using Cfg = GsCfg<TN, NSUB>;
+    constexpr int KS = Cfg::KS;
     constexpr int NCT = Cfg::NCT, WLD = Cfg::WLD, CPW = NCT / 2;          // column tiles per wavefront
     extern __shared__ float4 smem4[];
     char* smem = reinterpret_cast<char*>(smem4);
@@ -65,7 +66,7 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
     const int NT = a.N / 16;
     const int ct0 = blockIdx.y * NCT;
     const int M = a.M, rpb = a.rpb;
-    const int NK = a.K / 64;
+    const int NK = a.K / KS;
 
     // ---- staging role: thread t stages k = 8 kq .. + 7 and 32 + 8 kq .. + 7 of row 16 (t >> 6) + (t & 15), kq = (t & 63) >> 4, of every
     //      stage: its two 16-byte pieces are lane t & 63 of row tile t >> 6 (a wavefront writes 1 KiB contiguous: no bank conflicts) ----
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
     for (int i = 0; i < 6; ++i) {
         sp[i] = a.src[0].ptr; sm[i] = 0.f; sw[i] = 0;
         if (i < a.nsrc) {
-            sw[i] = a.src[i].width / 64;
+            sw[i] = a.src[i].width / KS;
             const gcpx_row_src& src = a.src[i];
             bool ok = srv;
             size_t off;
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
     const char* wsrc = reinterpret_cast<const char*>(a.wpk_split) + (size_t)zb * a.z_w_off * 4 + (size_t)ct0 * 2048 + tid * 16;
 
     struct RegSet {
-        float4 x[4], w[WLD];
+        float4 x[2 * NSUB], w[WLD];
         float mask;
         int src, k0;
     };
@@ -132,25 +133,25 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
             last_x = xp + kloc;
             last_s = s;
             r.mask = xmask; r.src = cur_s; r.k0 = kloc;
-            kloc += 64;
+            kloc += KS;
             --krem;
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NSUB; ++h) {
             r.x[2 * h] = gload4(last_x + 32 * h);
             r.x[2 * h + 1] = gload4(last_x + 32 * h + 4);
         }
 #pragma unroll
         for (int i = 0; i < WLD; ++i) {
-            const int sub = i / (WLD / 2), c = i % (WLD / 2);
-            r.w[i] = *reinterpret_cast<const float4*>(wsrc + ((size_t)(2 * last_s + sub) * NT) * 2048 + c * 4096);
+            const int sub = i / (WLD / NSUB), c = i % (WLD / NSUB);
+            r.w[i] = *reinterpret_cast<const float4*>(wsrc + ((size_t)(NSUB * last_s + sub) * NT) * 2048 + c * 4096);
         }
     };
     auto commit = [&](const int st, RegSet& r) __attribute__((always_inline)) {    // registers -> LDS stage st (affine, scale, split)
         char* base = smem + st * Cfg::STAGE;
 #pragma unroll
         for (int i = 0; i < WLD; ++i) {
-            const int sub = i / (WLD / 2), c = i % (WLD / 2);
+            const int sub = i / (WLD / NSUB), c = i % (WLD / NSUB);
             *reinterpret_cast<float4*>(base + sub * Cfg::W_SUB + c * 4096 + tid * 16) = r.w[i];
         }
         if constexpr (XF) {
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
             for (int si = 0; si < 6; ++si) {
                 if (r.src == si && (a.src[si].scale || a.src[si].act)) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 2 * NSUB; ++i)
                         r.x[i] = affine_act4(r.x[i], a.src[si].scale, a.src[si].shiftv,
                                              (r.k0 + 32 * (i >> 1) + 4 * (i & 1) + kq * 8) & (a.src[si].cmod - 1), a.src[si].act);
                 }
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
         }
         float amax = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2 * NSUB; ++i) {
             float4 v = r.x[i];
             v.x *= r.mask; v.y *= r.mask; v.z *= r.mask; v.w *= r.mask;
             r.x[i] = v;
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
         const float sc = __uint_as_float((unsigned)(127 + ex_run) << 23);
         char* xb = base + Cfg::W_BYTES + (wave * 2) * 1024 + lane * 16;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NSUB; ++h) {
             const float4 v0 = r.x[2 * h], v1 = r.x[2 * h + 1];
             const float f[8] = {v0.x * sc, v0.y * sc, v0.z * sc, v0.w * sc, v1.x * sc, v1.y * sc, v1.z * sc, v1.w * sc};
             h8 p1, p2;
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
             }
         }
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < NSUB; ++sub) {
             h8 b[2][2], w[CPW][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -312,13 +313,13 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
     }
 }
 
-template <int TN>
+template <int TN, int NSUB>
 int launch_split(const gcpx_gemm_args* a, hipStream_t stream) {
-    using Cfg = GsCfg<TN>;
+    using Cfg = GsCfg<TN, NSUB>;
     static bool attr_set = false;
     if (!attr_set) {
-        for (const void* k : {reinterpret_cast<const void*>(gemm_split_kernel<TN, false, false>), reinterpret_cast<const void*>(gemm_split_kernel<TN, true, false>),
-                              reinterpret_cast<const void*>(gemm_split_kernel<TN, false, true>), reinterpret_cast<const void*>(gemm_split_kernel<TN, true, true>)}) {
+        for (const void* k : {reinterpret_cast<const void*>(gemm_split_kernel<TN, NSUB, false, false>), reinterpret_cast<const void*>(gemm_split_kernel<TN, NSUB, true, false>),
+                              reinterpret_cast<const void*>(gemm_split_kernel<TN, NSUB, false, true>), reinterpret_cast<const void*>(gemm_split_kernel<TN, NSUB, true, true>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
             if (e != hipSuccess) {
                 gcpx_set_error("gemm split: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
@@ -332,8 +333,8 @@ int launch_split(const gcpx_gemm_args* a, hipStream_t stream) {
     bool xf = false;
     for (int s = 0; s < a->nsrc; ++s) xf = xf || a->src[s].scale || a->src[s].act;
     const bool lstm = a->epi == GCPX_EPI_LSTM;
-    auto kern = lstm ? (xf ? gemm_split_kernel<TN, true, true> : gemm_split_kernel<TN, true, false>)
-                     : (xf ? gemm_split_kernel<TN, false, true> : gemm_split_kernel<TN, false, false>);
+    auto kern = lstm ? (xf ? gemm_split_kernel<TN, NSUB, true, true> : gemm_split_kernel<TN, NSUB, true, false>)
+                     : (xf ? gemm_split_kernel<TN, NSUB, false, true> : gemm_split_kernel<TN, NSUB, false, false>);
     hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, stream, *a);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
@@ -356,6 +357,14 @@ int gcpx_launch_gemm_split(const gcpx_gemm_args* a, hipStream_t stream) {
     const long nb = a->nbatch > 1 ? a->nbatch : 1;
     const long rbk = (a->M + 63) / 64;
     // 128-column tiles read fewer operand bytes per MFMA; 64-column tiles when those would leave most of the chip without a workgroup
-    if (a->N % 128 == 0 && rbk * (a->N / 128) * nb >= 192) return launch_split<128>(a, stream);
-    return launch_split<64>(a, stream);
+    static const int force = [] { const char* e = getenv("GCPX_GEMM_SPLIT_CFG"); return e ? atoi(e) : 0; }();     // tuning aid: TN * 10 + NSUB
+    if (force == 1282) return launch_split<128, 2>(a, stream);
+    if (force == 642) return launch_split<64, 2>(a, stream);
+    if (force == 641) return launch_split<64, 1>(a, stream);
+    if (force == 1281) return launch_split<128, 1>(a, stream);
+    // Stages of 32 k: 24 / 16 KB of LDS per stage, so 3 - 4 workgroups share a CU and one's barrier and conversion hide behind the
+    // others' loads (64-k stages, one or two workgroups per CU: 1024 x 2048 x 1024 38 us, 32768 rows 1082 us; 32-k stages 35 / 754).
+    // 128-column tiles (fewer operand bytes per MFMA) once they still give every CU three workgroups, 64-column tiles below.
+    if (a->N % 128 == 0 && rbk * (a->N / 128) * nb >= 768) return launch_split<128, 1>(a, stream);
+    return launch_split<64, 1>(a, stream);
 }
