@@ -449,6 +449,91 @@ __global__ void __launch_bounds__(256) conv4x4s2_image_kernel(const float* __res
     }
 }
 
+// First layer with the frame resident in LDS.  conv4x4s2_image_kernel fetches every tap of every pixel from global memory with 4-byte
+// loads: each input element travels through the vector memory path four times (16 taps, stride 2 x 2) and the launch runs at 2 TB/s
+// of traffic (68 us for the 63 MB trajectory batch).  Here a workgroup stages one whole frame — coalesced 16-byte loads, three planes of
+// (HIN + 2) rows x PITCH floats with the conv's zero border stored as zeros (no bounds checks on the operand reads) — and its four
+// wavefronts compute the frame's HOUT x WOUT x 16 outputs from LDS: lane (j, q) of k-step (ci, ky) reads x[ci][2 oy - 1 + ky][2 ox_j - 1 + q].
+// Same products in the same order as conv4x4s2_image_kernel: bit-identical results.
+template <int HIN>
+struct ImgLdsCfg {
+    static constexpr int PITCH = HIN + 8;                      // floats per staged row: data at columns 4 .. HIN + 3 (16-byte aligned), zero at 3 and HIN + 4
+    static constexpr int ROWS = HIN + 2;
+    static constexpr int PLANE = ROWS * PITCH;
+    static constexpr int LDS_BYTES = 3 * PLANE * 4;
+};
+
+template <int HIN>
+__global__ void __launch_bounds__(256) conv4x4s2_image_lds_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                                  const float* __restrict__ bias, float* __restrict__ out, const int F,
+                                                                  const int out_act) {
+    using Cfg = ImgLdsCfg<HIN>;
+    constexpr int PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, HOUT = HIN / 2, NG = HOUT * HOUT / 16;
+    extern __shared__ float4 img_smem4[];
+    float* lds = reinterpret_cast<float*>(img_smem4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    // zero border: rows 0 and HIN + 1 of every plane, columns 3 and HIN + 4 of every row (written once: staging never touches them)
+    for (int i = tid; i < 3 * 2 * PITCH; i += 256) {
+        const int pl = i / (2 * PITCH), r = (i / PITCH) % 2, c = i % PITCH;
+        lds[pl * PLANE + (r ? HIN + 1 : 0) * PITCH + c] = 0.f;
+    }
+    for (int i = tid; i < 3 * Cfg::ROWS * 2; i += 256) {
+        const int pl = i / (Cfg::ROWS * 2), r = (i / 2) % Cfg::ROWS, c = (i & 1) ? HIN + 4 : 3;
+        lds[pl * PLANE + r * PITCH + c] = 0.f;
+    }
+    float w[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) w[t] = wpk[t * 64 + lane];
+    const float4 bv = *reinterpret_cast<const float4*>(bias + q * 4);
+    constexpr int F4 = 3 * HIN * HIN / 4;                       // float4 of a frame
+    for (int f = blockIdx.x; f < F; f += gridDim.x) {
+        __syncthreads();                                        // the previous frame's operand reads are done
+        const float4* src = reinterpret_cast<const float4*>(x) + (size_t)f * F4;
+        for (int i = tid; i < F4; i += 256) {
+            const int pl = i / (HIN * HIN / 4), rem = i % (HIN * HIN / 4);
+            const int y = rem / (HIN / 4), x4 = rem % (HIN / 4);
+            *reinterpret_cast<float4*>(lds + pl * PLANE + (y + 1) * PITCH + 4 + 4 * x4) = src[i];
+        }
+        __syncthreads();
+        for (int g = wave; g < NG; g += 4) {
+            const int p = g * 16 + j;
+            const int oy = p / HOUT, ox = p % HOUT;
+            const float* bp = lds + (2 * oy) * PITCH + 3 + 2 * ox + q;      // x[.][2 oy - 1 + ky][2 ox - 1 + q] = row 2 oy + ky, column 3 + 2 ox + q
+            f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) acc = mfma16(w[ci * 4 + ky], bp[ci * PLANE + ky * PITCH], acc);
+            f32x4 v = acc;
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            if (out_act == GCPX_ACT_LRELU) {
+                v[0] = lrelu(v[0], 0.2f); v[1] = lrelu(v[1], 0.2f); v[2] = lrelu(v[2], 0.2f); v[3] = lrelu(v[3], 0.2f);
+            }
+            *reinterpret_cast<float4*>(out + ((size_t)f * HOUT * HOUT + p) * 16 + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <int HIN>
+int launch_image_lds(const float* x, const float* wpk, const float* bias, float* out, int F, int out_act, hipStream_t stream) {
+    using Cfg = ImgLdsCfg<HIN>;
+    auto kern = conv4x4s2_image_lds_kernel<HIN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) {
+            gcpx_set_error("conv4x4s2 image (LDS): hipFuncSetAttribute(%d B): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    int grid = gcpx_conv_grid() / 2 * (160 * 1024 / Cfg::LDS_BYTES);      // as many workgroups as fit the CUs' LDS at once
+    if (grid > F) grid = F;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, x, wpk, bias, out, F, out_act);
+    return GCPX_OK;
+}
+
 }  // namespace
 
 extern "C" int gcpx_conv4x4s2_grid(void) { return gcpx_conv_grid() * 4; }
@@ -512,6 +597,13 @@ extern "C" int gcpx_conv4x4s2_image(const float* x, const float* wpk, const floa
     GCPX_CHECK_ARG(Cout == 16, "first encoder layer: Cout must be 16 (ngf)");
     GCPX_CHECK_ARG(Hin % 2 == 0 && Win % 2 == 0, "even input size");
     GCPX_CHECK_ARG((long long)F * 3 * Hin * Win * 4 < (1LL << 31), "image tensor must stay below 2 GiB (32-bit buffer offsets)");
+    if (Hin == Win && (Hin == 64 || Hin == 32) && !getenv("GCPX_ENC_IMAGE_DIRECT")) {
+        const int st = Hin == 64 ? launch_image_lds<64>(x, wpk, bias, out, F, out_act, stream)
+                                 : launch_image_lds<32>(x, wpk, bias, out, F, out_act, stream);
+        if (st != GCPX_OK) return st;
+        GCPX_CHECK_LAUNCH();
+        return GCPX_OK;
+    }
     const int npix = F * (Hin / 2) * (Win / 2);
     const int nblk = ((npix + 15) / 16 + 7) / 8;
     int grid = gcpx_conv_grid() * 2;
