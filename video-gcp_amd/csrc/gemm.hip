@@ -328,8 +328,39 @@ extern "C" int gcpx_gemm_row_blocks(int32_t M, int32_t N) {
 
 static int gemm_check(const gcpx_gemm_args* a);
 
+// 64 .. 256 rows: a split-K workgroup (four wavefronts share a PR x CR block of tiles and split K) sized by the bytes a CU pulls.
+// These launches are bound by operand delivery (~10 B / cycle and CU): a workgroup pulls (PR + CR) x 16 x K x 4 bytes, so the
+// cost of a block shape is rounds x (PR + CR), rounds = workgroups / CUs rounded up.  Measured (K = 1024, us): cost 3: 9.3, 4:
+// 10.5 - 12.4, 6: 16.3 - 18.8, 8: 21.5, 12: 29 - 36 — against 20.8 / 24.6 for the 128 / 256-row LSTM GEMM on one-wavefront blocks
+// (cost model of choose_tile).  A multi-tile block is taken when the best shape costs <= 6; the single-tile split-K path keeps cost <= 2.
+static bool ks_block_choice(const gcpx_gemm_args* a, int* pr_out, int* cr_out) {
+    if (!(a->M >= 64 && a->M <= 256 && a->K >= 256 && !a->stats_partial) || getenv("GCPX_GEMM_NO_KS_BLOCKS")) return false;
+    static const long cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return (long)(n > 0 ? n : 256);
+    }();
+    const long nb = a->nbatch > 1 ? a->nbatch : 1;
+    const int shapes[5][2] = {{1, 1}, {1, 2}, {2, 2}, {4, 2}, {2, 4}};
+    int best = 0;
+    long best_cost = -1;
+    for (int i = 0; i < 5; ++i) {
+        const int pr = shapes[i][0], cr = shapes[i][1];
+        if (a->N % (16 * cr)) continue;
+        const long wgs = (long)((a->M + 16 * pr - 1) / (16 * pr)) * (a->N / (16 * cr)) * nb;
+        const long cost = ((wgs + cus - 1) / cus) * (pr + cr);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = i; }
+    }
+    if (best == 0 || best_cost > 6) return false;
+    *pr_out = shapes[best][0];
+    *cr_out = shapes[best][1];
+    return true;
+}
+
 // true when gcpx_gemm would run the problem as split-K <1,1> tiles (what gcpx_gemm_group launches)
 static bool gemm_is_small(const gcpx_gemm_args* a) {
+    int pr_ = 1, cr_ = 1;
+    if (ks_block_choice(a, &pr_, &cr_)) return false;          // a multi-tile split-K block beats sharing a launch
     const int nb = a->nbatch > 1 ? a->nbatch : 1;
     const TileChoice t = choose_tile(a->M, a->N, nb);
     const long rbk = (a->M + 15) / 16, nt = a->N / 16;
@@ -404,6 +435,26 @@ extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
     if (st != GCPX_OK) return st;
     if (gcpx_gemm_split_applies(a)) return gcpx_launch_gemm_split(a, stream);
     const TileChoice t = choose_tile(a->M, a->N, a->nbatch > 1 ? a->nbatch : 1);
+    {
+        int pr = 1, cr = 1;
+        if (ks_block_choice(a, &pr, &cr)) {
+            const long nb = a->nbatch > 1 ? a->nbatch : 1;
+            const dim3 grid((a->M + 16 * pr - 1) / (16 * pr), a->N / (16 * cr), nb);
+            const bool lstm = a->epi == GCPX_EPI_LSTM;
+#define GCPX_KS_LAUNCH(PR_, CR_)                                                                                              \
+            do {                                                                                                              \
+                if (lstm) hipLaunchKernelGGL((gemm_kernel<PR_, CR_, true, true>), grid, dim3(256), 0, stream, *a);            \
+                else hipLaunchKernelGGL((gemm_kernel<PR_, CR_, false, true>), grid, dim3(256), 0, stream, *a);                \
+            } while (0)
+            if (pr == 1 && cr == 2) GCPX_KS_LAUNCH(1, 2);
+            else if (pr == 2 && cr == 2) GCPX_KS_LAUNCH(2, 2);
+            else if (pr == 4 && cr == 2) GCPX_KS_LAUNCH(4, 2);
+            else GCPX_KS_LAUNCH(2, 4);
+#undef GCPX_KS_LAUNCH
+            GCPX_CHECK_LAUNCH();
+            return GCPX_OK;
+        }
+    }
     if (t.pr == 1 && t.cr == 1 && a->K >= 256 && !getenv("GCPX_GEMM_NOKS")) {
         // few rows: split K over the wavefronts of a workgroup when that still leaves the launch small
         const long nb = a->nbatch > 1 ? a->nbatch : 1;
