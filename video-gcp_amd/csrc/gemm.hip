@@ -334,13 +334,16 @@ static int gemm_check(const gcpx_gemm_args* a);
 // 10.5 - 12.4, 6: 16.3 - 18.8, 8: 21.5, 12: 29 - 36 — against 20.8 / 24.6 for the 128 / 256-row LSTM GEMM on one-wavefront blocks
 // (cost model of choose_tile).  A multi-tile block is taken when the best shape costs <= 6; the single-tile split-K path keeps cost <= 2.
 static bool ks_block_choice(const gcpx_gemm_args* a, int* pr_out, int* cr_out) {
-    if (!(a->M >= 64 && a->M <= 256 && a->K >= 256 && !a->stats_partial) || getenv("GCPX_GEMM_NO_KS_BLOCKS")) return false;
+    static const int max_rows = [] { const char* e = getenv("GCPX_GEMM_KS_MAX_ROWS"); return e ? atoi(e) : 256; }();
+    static const int max_cost = [] { const char* e = getenv("GCPX_GEMM_KS_MAX_COST"); return e ? atoi(e) : 6; }();
+    if (!(a->M >= 64 && a->M <= max_rows && a->K >= 256 && !a->stats_partial) || getenv("GCPX_GEMM_NO_KS_BLOCKS")) return false;
     static const long cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return (long)(n > 0 ? n : 256);
     }();
     const long nb = a->nbatch > 1 ? a->nbatch : 1;
+    // (a 4 x 4 block is MFMA-bound, not delivery-bound: 512 x 2048 x 1024 at cost 8 ran 31 us against 26 on one-wavefront blocks)
     const int shapes[5][2] = {{1, 1}, {1, 2}, {2, 2}, {4, 2}, {2, 4}};
     int best = 0;
     long best_cost = -1;
@@ -351,7 +354,7 @@ static bool ks_block_choice(const gcpx_gemm_args* a, int* pr_out, int* cr_out) {
         const long cost = ((wgs + cus - 1) / cus) * (pr + cr);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = i; }
     }
-    if (best == 0 || best_cost > 6) return false;
+    if (best == 0 || best_cost > max_cost) return false;
     *pr_out = shapes[best][0];
     *cr_out = shapes[best][1];
     return true;
@@ -433,7 +436,10 @@ extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int st = gemm_check(a);
     if (st != GCPX_OK) return st;
-    if (gcpx_gemm_split_applies(a)) return gcpx_launch_gemm_split(a, stream);
+    {
+        int pr_ = 1, cr_ = 1;
+        if (!ks_block_choice(a, &pr_, &cr_) && gcpx_gemm_split_applies(a)) return gcpx_launch_gemm_split(a, stream);
+    }
     const TileChoice t = choose_tile(a->M, a->N, a->nbatch > 1 ? a->nbatch : 1);
     {
         int pr = 1, cr = 1;
