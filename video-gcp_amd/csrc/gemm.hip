@@ -328,13 +328,15 @@ extern "C" int gcpx_gemm_row_blocks(int32_t M, int32_t N) {
 
 static int gemm_check(const gcpx_gemm_args* a);
 
-// 64 .. 256 rows: a split-K workgroup (four wavefronts share a PR x CR block of tiles and split K) sized by the bytes a CU pulls.
+// From 64 rows: a split-K workgroup (four wavefronts share a PR x CR block of tiles and split K) sized by the bytes a CU pulls.
 // These launches are bound by operand delivery (~10 B / cycle and CU): a workgroup pulls (PR + CR) x 16 x K x 4 bytes, so the
 // cost of a block shape is rounds x (PR + CR), rounds = workgroups / CUs rounded up.  Measured (K = 1024, us): cost 3: 9.3, 4:
 // 10.5 - 12.4, 6: 16.3 - 18.8, 8: 21.5, 12: 29 - 36 — against 20.8 / 24.6 for the 128 / 256-row LSTM GEMM on one-wavefront blocks
-// (cost model of choose_tile).  A multi-tile block is taken when the best shape costs <= 6; the single-tile split-K path keeps cost <= 2.
+// (cost model of choose_tile).  A multi-tile block is taken when the best shape costs <= 6 — the mid levels of the tree, and the
+// narrow GEMMs at any row count (encoder head 1280 x 128 x 2048: 19.8 -> 14.4 us; embedding 1024 x 512 x 768: 18.8 -> 13.0); the
+// single-tile split-K path keeps cost <= 2.
 static bool ks_block_choice(const gcpx_gemm_args* a, int* pr_out, int* cr_out) {
-    static const int max_rows = [] { const char* e = getenv("GCPX_GEMM_KS_MAX_ROWS"); return e ? atoi(e) : 256; }();
+    static const int max_rows = [] { const char* e = getenv("GCPX_GEMM_KS_MAX_ROWS"); return e ? atoi(e) : 4096; }();
     static const int max_cost = [] { const char* e = getenv("GCPX_GEMM_KS_MAX_COST"); return e ? atoi(e) : 6; }();
     if (!(a->M >= 64 && a->M <= max_rows && a->K >= 256 && !a->stats_partial) || getenv("GCPX_GEMM_NO_KS_BLOCKS")) return false;
     static const long cus = [] {
