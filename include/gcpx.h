@@ -438,6 +438,11 @@ int gcpx_wgrad_reduce(const float* partial, int32_t nsplit, int32_t N, int32_t K
    to be combined by gcpx_wgrad_reduce(map CONV).  H, W powers of two, W in {8, 16, 32k}. */
 int gcpx_wgrad_conv3x3(const float* dy, int32_t ldy, const float* u, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                        float* partial, int32_t grid, void* stream);
+/* The same contract on the f16 matrix pipes with f32-equivalent arithmetic (csrc/wgrad_conv_split.hip: both operands split into two
+   f16 pieces in the kernel, three MFMAs per product, f32 accumulate, running power-of-two scales per workgroup).  Shapes it does not
+   cover run on gcpx_wgrad_conv3x3. */
+int gcpx_wgrad_conv3x3_split(const float* dy, int32_t ldy, const float* u, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                             float* partial, int32_t grid, void* stream);
 /* bias gradient: dst[n] (+)= sum_r dy[r][n] (rows addressed like gcpx_wgrad_args.dy); dst2 = optional second destination
    (LSTM b_ih and b_hh); with nsplit > 1 the row range is split and partial [nsplit][N] is written instead of dst */
 int gcpx_colsum(const float* dy, int64_t ldy, int32_t R, int32_t N, int32_t dy_rpb, int64_t dy_sb, int32_t nsplit, float* partial,

@@ -965,3 +965,44 @@ def test_aux_sample_indices_uniform_and_gauss(env):
             assert torch.equal(t.cpu(), want[k]), (name, k)
         t0, t1, cs, ce = [t.cpu() for t in d]
         assert bool(((t0 >= 0) & (t1 > t0) & (t1 <= end) & (cs >= 0) & (ce > cs) & (ce <= end)).all())
+
+
+@pytest.mark.parametrize("Cout,Cin,S,Fr", [(100, 16, 64, 5), (16, 32, 64, 5), (16, 64, 64, 3), (32, 64, 32, 7), (64, 128, 16, 9),
+                                           (64, 128, 8, 12), (32, 64, 8, 10)])
+@pytest.mark.parametrize("case", ["plain", "frame_scales", "tiny", "zero_frames"])
+def test_wgrad_conv3x3_split_error_vs_float64(env, Cout, Cin, S, Fr, case):
+    """Weight gradient of the decoder's 3x3 convs on the split-f16 kernel (csrc/wgrad_conv_split.hip: both operands split in the
+    kernel, quad transposes on the way into LDS, running power-of-two scales per workgroup) against float64, next to the exact f32
+    MFMA kernel.  Frames whose magnitudes differ by six orders (the running scale drops, the sums are rescaled), gradients of
+    order 1e-6, all-zero frames; every tile shape (W = 64 / 32 / 16 / 8) and channel configuration of the decoder."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(Cout + Cin + S)
+    N16 = (Cout + 15) // 16 * 16
+    dy = torch.randn(Fr, S, S, N16, device=dev)
+    dy[..., Cout:] = 0.0
+    u = torch.randn(Fr, S, S, Cin, device=dev)
+    if case == "frame_scales":
+        dy *= torch.logspace(-3, 3, Fr, device=dev)[:, None, None, None]
+        u *= torch.logspace(2, -2, Fr, device=dev)[:, None, None, None]
+    elif case == "tiny":
+        dy *= 1e-6
+    elif case == "zero_frames":
+        dy[::2] = 0.0
+        u[1::3] = 0.0
+    up = F.pad(u.double(), (0, 0, 1, 1, 1, 1))
+    ref = torch.stack([torch.einsum("fhwn,fhwc->nc", dy.double(), up[:, ky:ky + S, kx:kx + S, :]) for ky in range(3) for kx in range(3)], 1)
+    ref = ref.reshape(N16, 9 * Cin)                    # [n][tap*Cin + ci]
+    ych = Cin // 32 if (Cin % 32 == 0 and N16 != 112) else Cin // 16
+    grid = max(1, min(96 // ych, Fr * max(1, S * S // 64)))
+    err = {}
+    for name, fn in (("f32", lib.gcpx_wgrad_conv3x3), ("split", lib.gcpx_wgrad_conv3x3_split)):
+        part = torch.full((grid, N16, 9 * Cin), float("nan"), device=dev)
+        rt.check(fn(dy.data_ptr(), N16, u.data_ptr(), Fr, S, S, Cin, Cout, part.data_ptr(), grid, _stream()), name)
+        torch.cuda.synchronize()
+        assert torch.isfinite(part).all()
+        err[name] = (part.double().sum(0) - ref).abs()
+    scale = float(ref.abs().max()) + 1e-300
+    e32, esp = float(err["f32"].max()) / scale, float(err["split"].max()) / scale
+    r32, rsp = float(err["f32"].pow(2).mean().sqrt()) / scale, float(err["split"].pow(2).mean().sqrt()) / scale
+    assert esp <= 2.0 * e32 + 4e-7, (esp, e32)
+    assert rsp <= 1.5 * r32 + 1e-7, (rsp, r32)

@@ -1,0 +1,419 @@
+// Weight gradient of the decoder's 3x3 convs on the f16 matrix pipes of gfx950 with f32-equivalent arithmetic ("split-f16"):
+//     dW[n][tap][ci] = sum over pixels p of dY[p][n] * U[p + tap][ci]
+// (backward of the blox ConvDecoder blocks / gen_head called through /root/reference/gcp/prediction/models/tree/
+//  tree_dense_rec.py:42; same contract, grid and partial layout as gcpx_wgrad_conv3x3 in wgrad_conv.hip, which is bound by
+//  the f32 MFMA rate: 0.54 - 0.62 of 157 TFLOP/s).
+//
+// Both operands are data here, so both are split in the kernel: x = (x1 + x2) / 2^E, x1 = rn16(x 2^E), x2 = rn16(x 2^E - x1), and
+// a product costs three v_mfma_f32_16x16x32_f16 (x2 y1 + x1 y2 + x1 y1, small terms first, f32 accumulate).  The MFMA k index
+// walks PIXELS, so a lane's operand is 8 pixels of one channel, while the tensors are pixel-major (channels fastest).  The staged
+// tiles stay pixel-major in LDS ([piece][16-channel tile][pixel][16] f16 planes, 8-byte writes of 4 channels) and the operand
+// reads transpose: ds_read_b64_tr_b16 hands lane i channel i of four pixels whose addresses the 16-lane group supplies, so a tap
+// is an address offset of whole pixels (no alignment cases, no shuffles).  A first version transposed 4 x 4 blocks in registers
+// (DPP quad permutes) on the way into LDS: 2.3x the VALU instructions, 59 % of the LDS cycles lost to bank conflicts.
+//
+// Scales: the sum runs over every pixel of every frame, so what matters is the error relative to the largest terms.  Each
+// workgroup keeps a running power-of-two scale per operand (from the largest value staged so far) and rescales its accumulators
+// exactly when a larger value turns up; pieces of smaller tiles lose nothing that the f32 sum would keep.
+#include "common.h"
+
+#include <type_traits>
+
+extern "C" int gcpx_wgrad_conv3x3(const float* dy, int32_t ldy, const float* u, int32_t F, int32_t H, int32_t W, int32_t Cin,
+                                  int32_t Cout, float* partial, int32_t grid, void* stream_);
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1)))* gptr4;
+
+// explicitly global (a flat load would tie up both memory counters), uniform base + 32-bit lane offset (one address register per slot)
+__device__ __forceinline__ float4 gload4(const char* base, const unsigned off_bytes) {
+    const f32x4 t = *(gptr4)(base + off_bytes);
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+
+__device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// ds_read_b64_tr_b16 (measured with tools/tr_probe.hip): inside a 16-lane group, lane s supplies the address of an 8-byte chunk
+// (4 halfs) and lane i receives half (i & 3) of the chunks supplied by lanes 4 j + (i >> 2), j = 0 .. 3.  With lane s pointing at
+// [pixel s >> 2][channels 4 (s & 3) .. + 3] of a [pixel][16 channel] plane, lane i gets channel i of four pixels: the MFMA operand
+// (k = pixels) straight from the pixel-major image.
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ h4 ds_tr(const _Float16* p) {
+    return __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p));
+}
+__device__ __forceinline__ h8 ds_tr8(const _Float16* p, const int second_off) {
+    const h4 lo = ds_tr(p), hi = ds_tr(p + second_off);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dppf(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+
+// largest value over the wavefront: DPP inside the 16-lane rows, v_readlane across them (wave-uniform result)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    v = fmaxf(v, dppf<0xB1>(v));          // quad_perm [1, 0, 3, 2]
+    v = fmaxf(v, dppf<0x4E>(v));          // quad_perm [2, 3, 0, 1]
+    v = fmaxf(v, dppf<0x141>(v));         // row_half_mirror
+    v = fmaxf(v, dppf<0x140>(v));         // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+__device__ __forceinline__ void split4(const float4 v, const float sc, h4& p1, h4& p2) {
+    const float4 s = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+    p1[0] = (_Float16)s.x; p1[1] = (_Float16)s.y; p1[2] = (_Float16)s.z; p1[3] = (_Float16)s.w;
+    p2[0] = (_Float16)fmaf((float)p1[0], -1.f, s.x); p2[1] = (_Float16)fmaf((float)p1[1], -1.f, s.y);
+    p2[2] = (_Float16)fmaf((float)p1[2], -1.f, s.z); p2[3] = (_Float16)fmaf((float)p1[3], -1.f, s.w);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int NT, int CIT, int TW>
+struct WSCfg {
+    static constexpr int NW = 4, NTH = 256;
+    static constexpr int N = NT * 16, CC = CIT * 16;
+    static constexpr int TH = 64 / TW, RH = TH + 2, RW = TW + 2, RPX = RH * RW;
+    static constexpr int PA = 64 * 16 + 16;                    // halfs per (piece, n-tile) plane of dY: [64 pixels][16 channels] + 32 B (the planes start 8 banks apart)
+    static constexpr int PB = RPX * 16 + 16;                   // halfs per (piece, ci-tile) plane of U: [RH x RW pixels][16 channels] + 32 B
+    static constexpr int A_HALFS = 2 * NT * PA, B_HALFS = 2 * CIT * PB;
+    static constexpr int G = 9 * CIT, GPW = (G + NW - 1) / NW;
+    static constexpr int NDS = NT;                             // dY staging slots per thread: slot s = n-tile s, 64 pixels x 4 float4
+    static constexpr int UPS = (RPX + 63) / 64;                // U staging slots per ci-tile: 64 region pixels x 4 float4 each
+    static constexpr int NUS = UPS * CIT;
+    static constexpr int NS = NDS + NUS;
+    static constexpr int LDS_BYTES = (A_HALFS + B_HALFS) * 2 + 64;
+};
+
+template <int NT, int CIT, int TW>
+__global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_kernel(const float* __restrict__ dy, const float* __restrict__ u,
+                                                                     float* __restrict__ partial, const int F, const int H, const int W,
+                                                                     const int Cin, const int ldy) {
+    using Cfg = WSCfg<NT, CIT, TW>;
+    constexpr int NW = Cfg::NW, N = Cfg::N, CC = Cfg::CC, TH = Cfg::TH, RH = Cfg::RH, RW = Cfg::RW, RPX = Cfg::RPX;
+    constexpr int PA = Cfg::PA, PB = Cfg::PB, G = Cfg::G, GPW = Cfg::GPW, NDS = Cfg::NDS, UPS = Cfg::UPS, NUS = Cfg::NUS;
+    extern __shared__ float4 smem4[];
+    _Float16* sA = reinterpret_cast<_Float16*>(smem4);                     // [2][NT][PA]
+    _Float16* sB = sA + Cfg::A_HALFS;                                      // [2][CIT][PB]
+    float* red = reinterpret_cast<float*>(sB + Cfg::B_HALFS);              // [NW][2] tile maxima
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ij = lane & 15, kq = lane >> 4;
+    // the (tap, ci-tile) groups are dealt round-robin over the wavefronts; the deal is rotated per workgroup so that the wavefronts with one
+    // group more land on different SIMDs of a CU that holds two workgroups
+    const int wrot = __builtin_amdgcn_readfirstlane((wave + (int)blockIdx.x) & 3);
+    const int ci0 = blockIdx.y * CC;
+    const int ntx = W / TW, nty = H / TH;
+    const int ntiles = F * nty * ntx;
+
+    // BAL (output head: 7 n-tiles, 9 taps): the 63 (tap, n-tile) accumulator tiles are dealt 16 / 16 / 16 / 15 as in wgrad_conv.hip —
+    //   rotated wavefront w < 3: taps 3w .. 3w+2 x n-tiles 0 .. 4, plus (tap 3w, n-tile 5);   3: n-tile 6 x 9 taps + n-tile 5 x taps {1,2,4,5,7,8}
+    // (64 accumulator registers instead of 84: the generic deal spilled, and a scratch reload waits for every load in flight)
+    constexpr bool BAL = (NT == 7 && CIT == 1);
+    constexpr int NACC = BAL ? 16 : GPW * NT;
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0, 0, 0, 0};
+
+    // ---- staging slots (the same for every tile; per-slot data is one register: anything spilled is reloaded with a wait for every
+    //      load in flight).  A thread moves float4 (tid & 3) of pixel (tid >> 2) of a 16-channel tile: 64 contiguous bytes per pixel in
+    //      global memory, 512 contiguous bytes per wavefront and piece in LDS ----
+    const int sp = tid >> 2, sc4 = tid & 3;
+    const unsigned dgoff0 = (unsigned)((((sp / TW) * W + (sp % TW)) * ldy + 4 * sc4) * 4);       // dY slot s = n-tile s: + 64 s bytes
+    const int dloff0 = sp * 16 + 4 * sc4;                                                          //                       + s PA halfs
+    // U slot (cit, k): region pixel r = sp + 64 k of ci-tile cit; row / column of r packed (r >= RPX: no such pixel)
+    unsigned umeta[Cfg::UPS];
+#pragma unroll
+    for (int k = 0; k < UPS; ++k) {
+        const int r = sp + 64 * k;
+        umeta[k] = r < RPX ? (1u << 16) | ((unsigned)(r / RW) << 8) | (unsigned)(r % RW) : 0u;
+    }
+    float4 pre[Cfg::NS];
+    unsigned okbits = 0;
+    // loads of one tile: uniform tile data first, then one slot at a time (a slot's register is reloaded for the next tile as soon as its
+    // values have been split, before the LDS writes, the barrier and the MFMA phase: the phase alone is shorter than a trip to HBM)
+    const char *dyb = nullptr, *ub = nullptr;
+    int ty0 = 0, tx0 = 0;
+    auto tile_base = [&](const int tile) __attribute__((always_inline)) {
+        const int tx = tile % ntx;
+        const int t2 = tile / ntx;
+        const int f = t2 / nty;
+        ty0 = (t2 % nty) * TH; tx0 = tx * TW;
+        dyb = reinterpret_cast<const char*>(dy + (((size_t)f * H + ty0) * W + tx0) * ldy);
+        ub = reinterpret_cast<const char*>(u + (size_t)f * H * W * Cin + ci0);
+    };
+    auto load_d = [&](const int s) __attribute__((always_inline)) { pre[s] = gload4(dyb, dgoff0 + 64u * s); };
+    auto load_u = [&](const int s) __attribute__((always_inline)) {
+        // out-of-image positions (the conv's zero padding) are loaded from the clamped position and zeroed before use: the loads stay
+        // unconditional
+        const int cit = s / UPS, k = s % UPS;
+        const int row = (umeta[k] >> 8) & 255, col = umeta[k] & 255;
+        const int y = ty0 - 1 + row, x = tx0 - 1 + col;
+        const bool ok = (umeta[k] >> 16) != 0 && y >= 0 && y < H && x >= 0 && x < W;
+        const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+        pre[NDS + s] = gload4(ub, (unsigned)(((yc * W + xc) * Cin + 16 * cit + 4 * sc4) * 4));
+        okbits = (okbits & ~(1u << s)) | (ok ? (1u << s) : 0u);
+    };
+
+    int ea = 0, eb = 0;                 // running scales of dY / U: staged values are multiplied by 2^ea / 2^eb
+    bool have_a = false, have_b = false;
+    const int my_first = wrot;          // first group of this wavefront
+
+    // operand addresses of the transposing reads: lane (s = lane & 15, group kq) points at pixel 4 kq + (s >> 2) (first read; + 16: second)
+    // of a 32-pixel k-step, channels 4 (s & 3) .. + 3.  Groups 0 / 1 (2 / 3) read 256 contiguous bytes: every bank once.
+    const int rpix = 4 * kq + (ij >> 2), rch = 4 * (ij & 3);
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        tile_base(tile);
+#pragma unroll
+        for (int s = 0; s < NDS; ++s) load_d(s);
+#pragma unroll
+        for (int s = 0; s < NUS; ++s) load_u(s);
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        // ---- largest |value| of the tile, per operand ----
+        float ma = 0.f, mb = 0.f;
+#pragma unroll
+        for (int s = 0; s < NDS; ++s)
+            ma = fmaxf(ma, fmaxf(fmaxf(fabsf(pre[s].x), fabsf(pre[s].y)), fmaxf(fabsf(pre[s].z), fabsf(pre[s].w))));
+#pragma unroll
+        for (int s = 0; s < NUS; ++s) {
+            if (!((okbits >> s) & 1u)) pre[NDS + s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = pre[NDS + s];
+            mb = fmaxf(mb, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        ma = wave_max_nonneg(ma);
+        mb = wave_max_nonneg(mb);
+        if (lane == 0) { red[2 * wave] = ma; red[2 * wave + 1] = mb; }
+        __syncthreads();                                      // maxima visible; the previous tile's operand reads are done
+        ma = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
+        mb = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+        ma = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ma)));
+        mb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mb)));
+        float resc = 1.f;
+        if (ma > 0.f) {
+            const int e = max(-100, min(100, 14 + 127 - (int)((__float_as_uint(ma) >> 23) & 0xff)));      // ma 2^e in [2^14, 2^15)
+            if (!have_a) { ea = e; have_a = true; }
+            else if (e < ea) { resc *= __uint_as_float((unsigned)(127 + max(e - ea, -126)) << 23); ea = e; }
+        }
+        if (mb > 0.f) {
+            const int e = max(-100, min(100, 14 + 127 - (int)((__float_as_uint(mb) >> 23) & 0xff)));
+            if (!have_b) { eb = e; have_b = true; }
+            else if (e < eb) { resc *= __uint_as_float((unsigned)(127 + max(e - eb, -126)) << 23); eb = e; }
+        }
+        if (resc != 1.f) {                                    // larger values than before: lower the scale, rescale the sums (exact)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] *= resc;
+        }
+        const float sa = __uint_as_float((unsigned)(127 + ea) << 23), sb = __uint_as_float((unsigned)(127 + eb) << 23);
+
+        // ---- registers -> LDS: split, 8-byte stores into the pixel-major planes; the slot's register takes the next tile's load (the last
+        //      tile loads itself again: the loads stay unconditional) ----
+        tile_base(min(tile + (int)gridDim.x, ntiles - 1));
+#pragma unroll
+        for (int s = 0; s < NDS; ++s) {
+            h4 p1, p2;
+            split4(pre[s], sa, p1, p2);
+            load_d(s);
+            *reinterpret_cast<h4*>(sA + s * PA + dloff0) = p1;
+            *reinterpret_cast<h4*>(sA + (NT + s) * PA + dloff0) = p2;
+        }
+#pragma unroll
+        for (int s = 0; s < NUS; ++s) {
+            const int cit = s / UPS, k = s % UPS;
+            h4 p1, p2;
+            split4(pre[NDS + s], sb, p1, p2);
+            load_u(s);
+            if (umeta[k] >> 16) {
+                *reinterpret_cast<h4*>(sB + cit * PB + 64 * 16 * k + dloff0) = p1;
+                *reinterpret_cast<h4*>(sB + (CIT + cit) * PB + 64 * 16 * k + dloff0) = p2;
+            }
+        }
+        __syncthreads();
+
+        // ---- MFMA phase: two k-steps of 32 pixels.  The deal of groups is compile-time per rotated wavefront index ----
+        auto mm3 = [&](f32x4& c, const h8 a1, const h8 a2, const h8 b1, const h8 b2) __attribute__((always_inline)) {
+            c = mfma32h(a2, b1, c);        // small terms first
+            c = mfma32h(a1, b2, c);
+            c = mfma32h(a1, b1, c);
+        };
+        auto phase = [&](auto wv_c) __attribute__((always_inline)) {
+            constexpr int WV = decltype(wv_c)::value;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+            for (int step = 0; step < 2; ++step) {
+                // k slot (read r, group kq, j) = pixel pi = 4 kq + j + 16 r of the step's 32 pixels; the step covers tile rows 32 / TW * step ..
+                const _Float16* ap = sA + (32 * step + rpix) * 16 + rch;
+                auto lda = [&](const int nt, h8& a1, h8& a2) __attribute__((always_inline)) {
+                    a1 = ds_tr8(ap + nt * PA, 16 * 16);
+                    a2 = ds_tr8(ap + (NT + nt) * PA, 16 * 16);
+                };
+                // region pixel of k slot (r, kq, j) for tap (tdy, tdx): row (32 step + pi) / TW + tdy, column (32 step + pi) % TW + tdx
+                const int p0 = 32 * step + rpix, p1 = p0 + 16;
+                const int rb0 = ((p0 / TW) * RW + (p0 % TW)) * 16 + rch, rb1 = ((p1 / TW) * RW + (p1 % TW)) * 16 + rch;
+                auto ldb = [&](const int cit, const int tdy, const int tdx, h8& b1, h8& b2) __attribute__((always_inline)) {
+                    const _Float16* bp = sB + cit * PB + (tdy * RW + tdx) * 16;
+                    const h4 l1 = ds_tr(bp + rb0), u1 = ds_tr(bp + rb1);
+                    const h4 l2 = ds_tr(bp + CIT * PB + rb0), u2 = ds_tr(bp + CIT * PB + rb1);
+                    b1 = __builtin_shufflevector(l1, u1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    b2 = __builtin_shufflevector(l2, u2, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
+                if constexpr (BAL) {
+                    if constexpr (WV < 3) {
+                        h8 b1[3], b2[3];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) ldb(0, WV, t, b1[t], b2[t]);
+#pragma unroll
+                        for (int nt = 0; nt < 6; ++nt) {
+                            h8 a1, a2;
+                            lda(nt, a1, a2);
+                            if (nt < 5) {
+#pragma unroll
+                                for (int t = 0; t < 3; ++t) mm3(acc[t * 5 + nt], a1, a2, b1[t], b2[t]);
+                            } else {
+                                mm3(acc[15], a1, a2, b1[0], b2[0]);
+                            }
+                        }
+                    } else {
+                        h8 a51, a52, a61, a62;
+                        lda(5, a51, a52);
+                        lda(6, a61, a62);
+#pragma unroll
+                        for (int tdy = 0; tdy < 3; ++tdy) {
+                            h8 b1[3], b2[3];
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) ldb(0, tdy, t, b1[t], b2[t]);
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) {
+                                mm3(acc[tdy * 3 + t], a61, a62, b1[t], b2[t]);
+                                if (t != 0) mm3(acc[9 + tdy * 2 + t - 1], a51, a52, b1[t], b2[t]);
+                            }
+                        }
+                    }
+                } else {
+                    // groups in chunks of three: their fragments stay in registers while the n-tiles pass by
+                    static_for<0, (GPW + 2) / 3>([&](auto cc) __attribute__((always_inline)) {
+                        constexpr int c0 = decltype(cc)::value * 3;
+                        h8 b1[3], b2[3];
+                        static_for<0, 3>([&](auto gc) __attribute__((always_inline)) {
+                            constexpr int g = c0 + decltype(gc)::value, gi = WV + g * NW;
+                            if constexpr (g < GPW && gi < G) ldb(gi % CIT, (gi / CIT) / 3, (gi / CIT) % 3, b1[g - c0], b2[g - c0]);
+                        });
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            h8 a1, a2;
+                            lda(nt, a1, a2);
+                            static_for<0, 3>([&](auto gc) __attribute__((always_inline)) {
+                                constexpr int g = c0 + decltype(gc)::value;
+                                if constexpr (g < GPW && WV + g * NW < G) mm3(acc[g * NT + nt], a1, a2, b1[g - c0], b2[g - c0]);
+                            });
+                        }
+                        if constexpr (GPW * NT >= 20) __builtin_amdgcn_sched_barrier(0);     // keep the next chunk's fragment reads behind this chunk (registers)
+                    });
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        if (my_first == 0) phase(std::integral_constant<int, 0>{});
+        else if (my_first == 1) phase(std::integral_constant<int, 1>{});
+        else if (my_first == 2) phase(std::integral_constant<int, 2>{});
+        else phase(std::integral_constant<int, 3>{});
+    }
+
+    // partial [blockIdx.x][n][K = 9*Cin]: lane holds n = nt*16 + 4*kq + reg, k = tap*Cin + ci0 + cit*16 + ij
+    const int K = 9 * Cin;
+    float* out = partial + (size_t)blockIdx.x * N * K;
+    const float ia = __uint_as_float((unsigned)(127 - ea) << 23), ib = __uint_as_float((unsigned)(127 - eb) << 23);
+    if constexpr (BAL) {
+        auto store = [&](const f32x4& v, int nt, int tap) {
+            const int k = tap * Cin + ci0 + ij;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(nt * 16 + 4 * kq + r) * K + k] = v[r] * ia * ib;
+        };
+        if (wrot < 3) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) store(acc[t * 5 + nt], nt, 3 * wrot + t);
+            store(acc[15], 5, 3 * wrot);
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                store(acc[tap], 6, tap);
+                if (tap % 3 != 0) store(acc[9 + (tap / 3) * 2 + (tap % 3) - 1], 5, tap);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) {
+            const int gi = wrot + g * NW;
+            if (gi >= G) continue;
+            const int tap = gi / CIT, cit = gi % CIT;
+            const int k = tap * Cin + ci0 + cit * 16 + ij;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(size_t)(nt * 16 + 4 * kq + r) * K + k] = acc[g * NT + nt][r] * ia * ib;
+        }
+    }
+}
+
+template <int NT, int CIT, int TW>
+int launch_ws2(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream) {
+    using Cfg = WSCfg<NT, CIT, TW>;
+    if (W % TW || H % Cfg::TH) return GCPX_ERR_UNSUPPORTED;
+    auto kern = wgrad_conv3x3_split_kernel<NT, CIT, TW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    static_assert(Cfg::LDS_BYTES <= 64 * 1024, "operand planes of one tile must fit 64 KiB");
+    hipLaunchKernelGGL(kern, dim3(grid, Cin / Cfg::CC), dim3(256), Cfg::LDS_BYTES, stream, dy, u, partial, F, H, W, Cin, ldy);
+    return GCPX_OK;
+}
+
+template <int NT, int CIT>
+int launch_ws(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream) {
+    if (W >= 32 && W % 32 == 0) return launch_ws2<NT, CIT, 32>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    if (W == 16) return launch_ws2<NT, CIT, 16>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    if (W == 8) return launch_ws2<NT, CIT, 8>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    return GCPX_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// Same arguments, grid and partial layout as gcpx_wgrad_conv3x3 (the exact f32 kernel, which also takes the shapes this one does not
+// cover): grid.y must be Cin / 32 when Cin % 32 == 0 and Cout > 16 ... see gcpx_wgrad_conv3x3_split_chunk.
+extern "C" int gcpx_wgrad_conv3x3_split(const float* dy, int32_t ldy, const float* u, int32_t F, int32_t H, int32_t W, int32_t Cin,
+                                        int32_t Cout, float* partial, int32_t grid, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(dy && u && partial && F > 0 && grid > 0, "bad arguments");
+    GCPX_CHECK_ARG(ldy % 4 == 0 && Cin % 16 == 0, "ldy % 4, Cin % 16");
+    const int NT = (Cout + 15) / 16;
+    GCPX_CHECK_ARG(ldy >= NT * 16, "dy rows must hold Cout rounded up to 16 columns");
+    int st = GCPX_ERR_UNSUPPORTED;
+    if (NT == 7 && Cin == 16) st = launch_ws<7, 1>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    else if (NT == 1 && Cin % 32 == 0) st = launch_ws<1, 2>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    else if (NT == 2 && Cin % 32 == 0) st = launch_ws<2, 2>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    else if (NT == 4 && Cin % 32 == 0) st = launch_ws<4, 2>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+    if (st == GCPX_ERR_UNSUPPORTED) return gcpx_wgrad_conv3x3(dy, ldy, u, F, H, W, Cin, Cout, partial, grid, stream_);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}

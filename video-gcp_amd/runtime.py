@@ -139,6 +139,7 @@ SYMBOLS = [
     ("gcpx_wgrad_classify", C.c_int, [C.POINTER(WgradArgs), i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("gcpx_wgrad_group", C.c_int, [vp, vp, i32, i32, i32, vp]),
     ("gcpx_wgrad_conv3x3", C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    ("gcpx_wgrad_conv3x3_split", C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     ("gcpx_wgrad_reduce", C.c_int, [vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, i64, i32, i32, vp]),
     ("gcpx_colsum", C.c_int, [vp, i64, i32, i32, i32, i64, i32, vp, vp, vp, i32, vp]),
     ("gcpx_reduce_partials", C.c_int, [vp, i32, i64, i32, vp, i32, vp]),
