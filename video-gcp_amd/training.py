@@ -58,6 +58,7 @@ class GCPTrainStep:
         # backward plans are built from forward plans: drop them whenever the model drops those (load_state_dict, build_arena)
         model._plan_listeners = getattr(model, "_plan_listeners", []) + [self._bplans.clear]
         self.wgroup_min_blocks = int(os.environ.get("GCPX_WGROUP_MIN", "256"))
+        self.split_wgrad = os.environ.get("GCPX_WGRAD_NOSPLIT") is None     # decoder conv weight gradients on the split-f16 kernel
         self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
         self.fused_mlp_bwd = os.environ.get("GCPX_NO_FUSED_MLP_BWD") is None
         # the decoder's weight gradients (5 ms of throughput-bound kernels) are forked after the decoder's data-gradient chain: they then
@@ -342,7 +343,9 @@ class GCPTrainStep:
         per_cu = 2 if N16 in (112, 64) else 3
         grid = max(1, min((lib.gcpx_conv_grid() // 2) * per_cu // ych, ntiles))
         part = m._buf(f"bw.part:{tag}", (grid, N16, 9 * Cin))
-        self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad_conv3x3, dy, ldy, u, F, Hh, Ww, Cin, Cout, part.data_ptr(), grid)
+        # split-f16 kernel (f32-equivalent, csrc/wgrad_conv_split.hip) unless the model runs on the exact f32 kernels (GCPX_EXACT_F32)
+        fn = lib.gcpx_wgrad_conv3x3_split if (m.split_f16 and self.split_wgrad) else lib.gcpx_wgrad_conv3x3
+        self._side(plan, f"bw.wgrad:{tag}", fn, dy, ldy, u, F, Hh, Ww, Cin, Cout, part.data_ptr(), grid)
         self._side(plan, f"bw.wreduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), grid, N16, 9 * Cin, dst, rt.WMAP_CONV, Cin, 9, 0,
                    (n_map.data_ptr() if n_map is not None else None), 0, 0, 1)
 
