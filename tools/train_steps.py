@@ -8,7 +8,7 @@ from video_gcp_amd.model import GCPTreeModel
 from video_gcp_amd.training import GCPTrainStep
 from helpers import make_inputs
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-hp = V.config("c2")
+hp = V.config(os.environ.get("CONFIG", "c2"))
 model = GCPTreeModel(hp, device="cuda")
 tr = GCPTrainStep(model)
 model.use_graph = os.environ.get('NOGRAPH') is None
