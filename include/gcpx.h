@@ -579,6 +579,12 @@ int gcpx_conv_stage(const gcpx_conv_args* a, void* stream);
 int gcpx_col2im4x4s2(const float* dcol, float* dx, int32_t F, int32_t H, int32_t W, int32_t Cin, void* stream);
 /* im2col of the NCHW 3-channel image for the first encoder conv's weight gradient: col [F*H/2*W/2][48], k = (ci, ky, kx) */
 int gcpx_im2col_image(const float* x, float* col, int32_t F, int32_t H, int32_t W, void* stream);
+/* Weight + bias gradient of the encoder's first layer (4x4 stride-2 pad-1 conv on the NCHW image, LeakyReLU, no norm) in one launch:
+   (da + add) * slope(r) against the image patches (csrc/wgrad_image.hip; replaces gcpx_act_bwd + gcpx_im2col_image + gcpx_wgrad +
+   gcpx_colsum for that layer).  da / add (or NULL) / r: NHWC [F][S/2][S/2][16]; image [F][3][S][S]; partial [grid][16*48 + 16]
+   (weights [co][ci*16 + ky*4 + kx], then the bias), to be summed by gcpx_reduce_partials(stride 784). */
+int gcpx_wgrad_image4x4s2(const float* da, const float* add, const float* r, const float* image, int32_t F, int32_t S, float* partial,
+                          int32_t grid, void* stream);
 
 /* ---- loss gradients ---- */
 /* d NLL / d params of the discretised logistic mixture (same layouts as gcpx_dlm_nll); row gradient scaled by

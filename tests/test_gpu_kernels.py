@@ -1006,3 +1006,30 @@ def test_wgrad_conv3x3_split_error_vs_float64(env, Cout, Cin, S, Fr, case):
     r32, rsp = float(err["f32"].pow(2).mean().sqrt()) / scale, float(err["split"].pow(2).mean().sqrt()) / scale
     assert esp <= 2.0 * e32 + 4e-7, (esp, e32)
     assert rsp <= 1.5 * r32 + 1e-7, (rsp, r32)
+
+
+@pytest.mark.parametrize("S,Fr,with_add", [(64, 5, False), (64, 3, True), (32, 7, True), (128, 2, False)])
+def test_wgrad_image4x4s2(env, S, Fr, with_add):
+    """First encoder layer's weight + bias gradient in one launch (csrc/wgrad_image.hip: LeakyReLU backward, image patches, both
+    sums) against torch's conv2d weight gradient in float64; image borders (zero padding), every band of output rows, the optional
+    skip-gradient addend, fewer workgroups than items (several items per persistent workgroup) and more (idle workgroups write zeros)."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(S + Fr)
+    x = torch.randn(Fr, 3, S, S, device=dev)
+    H2 = S // 2
+    da, r = torch.randn(Fr, H2, H2, 16, device=dev), torch.randn(Fr, H2, H2, 16, device=dev)
+    add = torch.randn(Fr, H2, H2, 16, device=dev) if with_add else None
+    g = (da + (add if with_add else 0.0)).double() * torch.where(r > 0, 1.0, 0.2).double()
+    gn = g.permute(0, 3, 1, 2).contiguous()
+    dW = torch.nn.grad.conv2d_weight(x.double(), (16, 3, 4, 4), gn, stride=2, padding=1).reshape(16, 48)
+    db = gn.sum((0, 2, 3))
+    nitems = Fr * (H2 // 8)
+    for grid in (max(1, nitems // 3), nitems + 5):
+        part = torch.full((grid, 16 * 48 + 16), float("nan"), device=dev)
+        rt.check(lib.gcpx_wgrad_image4x4s2(da.data_ptr(), add.data_ptr() if with_add else None, r.data_ptr(), x.data_ptr(), Fr, S,
+                                           part.data_ptr(), grid, _stream()), "wgrad_image")
+        torch.cuda.synchronize()
+        assert torch.isfinite(part).all()
+        tot = part.double().sum(0)
+        assert float((tot[:768].view(16, 48) - dW).abs().max()) <= 2e-5 * float(dW.abs().max())
+        assert float((tot[768:] - db).abs().max()) <= 2e-5 * float(db.abs().max()) + 1e-4

@@ -58,6 +58,7 @@ class GCPTrainStep:
         # backward plans are built from forward plans: drop them whenever the model drops those (load_state_dict, build_arena)
         model._plan_listeners = getattr(model, "_plan_listeners", []) + [self._bplans.clear]
         self.wgroup_min_blocks = int(os.environ.get("GCPX_WGROUP_MIN", "256"))
+        self.fused_image_wgrad = os.environ.get("GCPX_IMAGE_WGRAD_UNFUSED") is None
         self.split_wgrad = os.environ.get("GCPX_WGRAD_NOSPLIT") is None     # decoder conv weight gradients on the split-f16 kernel
         self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
         self.fused_mlp_bwd = os.environ.get("GCPX_NO_FUSED_MLP_BWD") is None
@@ -991,6 +992,17 @@ class GCPTrainStep:
         # the first layer has no data gradient to pass on (its input is the image): its activation backward and the im2col of the
         # image only feed the weight / bias gradient, so they leave the critical lane together with them (same tag = same side lane,
         # in order)
+        if ngf == 16 and S in (32, 64, 128) and self.fused_image_wgrad:
+            # one launch for the layer's whole backward (csrc/wgrad_image.hip): LeakyReLU slope, image patches and both sums
+            grid = max(1, min(F * (res // 8), 3 * (lib.gcpx_conv_grid() // 2)))
+            part = buf(f"bw.{tag}.wimg", (grid, 16 * 48 + 16))
+            self._side(plan, f"bw.wgrad:enc.input:{tag}", lib.gcpx_wgrad_image4x4s2, dA.data_ptr(), a.add, er["a0"].data_ptr(), er["x_ptr"],
+                       F, S, part.data_ptr(), grid)
+            self._side(plan, f"bw.wreduce:enc.input:{tag}", lib.gcpx_reduce_partials, part.data_ptr(), grid, 16 * 48 + 16, 16 * 48,
+                       self.g("encoder.net.input.conv.weight"), 1)
+            self._side(plan, f"bw.creduce:enc.input:{tag}", lib.gcpx_reduce_partials, part.data_ptr() + 4 * 16 * 48, grid, 16 * 48 + 16, 16,
+                       self.g("encoder.net.input.conv.bias"), 1)
+            return
         self._side(plan, f"bw.act:enc.input:{tag}", lib.gcpx_act_bwd, C.byref(a))
         col = buf(f"bw.{tag}.col", (F * res * res, 48))
         self._side(plan, f"bw.im2col:enc.input:{tag}", lib.gcpx_im2col_image, er["x_ptr"], col.data_ptr(), F, S, S)
