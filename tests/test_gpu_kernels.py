@@ -1033,3 +1033,42 @@ def test_wgrad_image4x4s2(env, S, Fr, with_add):
         tot = part.double().sum(0)
         assert float((tot[:768].view(16, 48) - dW).abs().max()) <= 2e-5 * float(dW.abs().max())
         assert float((tot[768:] - db).abs().max()) <= 2e-5 * float(db.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("Hin,c_prev,c_skip,Fr,nodes,up", [(32, 16, 16, 6, 3, 1), (8, 64, 64, 6, 2, 1), (4, 128, 0, 5, 1, 1), (16, 16, 0, 4, 1, 0)])
+def test_conv_stage(env, Hin, c_prev, c_skip, Fr, nodes, up):
+    """gcpx_conv_stage: the (bilinear x2, align_corners=False) concat of the normalised + activated sources that the decoder's weight
+    gradients read — 2 x 2 output pixels per low-resolution pixel, clamped borders — against torch; with a frame map (skipped frames
+    are written as zeros)."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(Hin + c_prev)
+    x = torch.randn(Fr, c_prev, Hin, Hin)
+    sc, sh = torch.rand(c_prev) + 0.5, torch.randn(c_prev) * 0.2
+    ref = [F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)]
+    srcs = [(x.permute(0, 2, 3, 1).contiguous().to(dev), c_prev, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)]
+    if c_skip:
+        sk = torch.randn(Fr // nodes, c_skip, Hin, Hin)
+        ref.append(sk.repeat_interleave(nodes, 0))
+        srcs.append((sk.permute(0, 2, 3, 1).contiguous().to(dev), c_skip, nodes, None, None, rt.ACT_NONE))
+    cin = c_prev + c_skip
+    want = torch.cat(ref, 1)
+    if up:
+        want = F.interpolate(want, scale_factor=2, mode="bilinear", align_corners=False)
+    Ho = Hin * (2 if up else 1)
+    out = torch.full((Fr, Ho, Ho, cin), float("nan"), device=dev)
+    a = _conv_args(rt, srcs, F=Fr, Hin=Hin, Win=Hin, Hout=Ho, Wout=Ho, Cout=cin, out_pitch=cin, upsample=up, out=out)
+    rt.check(lib.gcpx_conv_stage(C.byref(a), _stream()), "conv_stage")
+    torch.cuda.synchronize()
+    assert_close(out.permute(0, 3, 1, 2), want, atol=2e-6, rtol=1e-6, name="conv_stage")
+    if not c_skip:
+        fmap = torch.arange(Fr, dtype=torch.int32)
+        fmap[1] = -1
+        fmap[Fr - 1] = 0
+        fm = fmap.to(dev)
+        out.fill_(float("nan"))
+        a.src_row_map = fm.data_ptr()
+        rt.check(lib.gcpx_conv_stage(C.byref(a), _stream()), "conv_stage")
+        torch.cuda.synchronize()
+        w2 = want[fmap.clamp(min=0).long()].clone()
+        w2[1] = 0.0
+        assert_close(out.permute(0, 3, 1, 2), w2, atol=2e-6, rtol=1e-6, name="conv_stage mapped")

@@ -5,6 +5,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import video_gcp_amd as V
 from video_gcp_amd.model import GCPTreeModel
+from video_gcp_amd import runtime as _rt
+if os.environ.get('GCPX_LIB'):          # same-box A/B against another build of the library
+    _rt.LIB_PATH = os.environ['GCPX_LIB']
 from video_gcp_amd.training import GCPTrainStep
 from helpers import make_inputs
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
