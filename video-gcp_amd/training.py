@@ -69,8 +69,10 @@ class GCPTrainStep:
         # gradients they ran beside the level L-1 / L-2 GEMMs of the tree (1024 / 512 rows, throughput-bound) and stretched two of them
         # from ~0.1 to 1.5 ms each on the critical lane (profiles/r02f_train_lanes.txt); below those levels the tree backward is a
         # chain of small launches that leaves the chip to the weight gradients.  GCPX_DEC_SIDE_LEVEL = level after which they go out
-        # (default L - 2; >= L: right after the decoder, the old behaviour).
-        self.dec_side_level = int(os.environ.get("GCPX_DEC_SIDE_LEVEL", str(hp.hierarchy_levels - 2)))
+        # (>= L: right after the decoder, the old behaviour).  Default L - 1: with the split-f16 weight gradients (3.4 instead of 7 ms of
+        # side-lane kernels) holding them past the largest level only is best — same-box, c2: 16.8-17.2 ms / step against 17.3-17.4 (L - 2)
+        # and 17.2-17.5 (L); c5: 22.0 against 22.4 / 22.3.
+        self.dec_side_level = int(os.environ.get("GCPX_DEC_SIDE_LEVEL", str(hp.hierarchy_levels - 1)))
         self.group_wgrads = os.environ.get("GCPX_NO_WGROUP") is None   # one grouped launch per level and kernel variant
         self.side_lanes = bool(hp.untied_layers)   # tied levels accumulate into the same weights: keep them on one lane
         self.wgrad_waves = 8192               # wavefronts a split weight-gradient launch aims for (latency hiding)
