@@ -219,7 +219,10 @@ class GCPTrainStep:
     def _side(self, plan, name, fn, *args):
         plan.deferred.append((name, fn, args))
 
-    def _flush(self, plan):
+    def _flush(self, plan, one_lane=False):
+        """one_lane: everything of this flush goes to ONE side lane, behind all work issued so far on the others — for gradients that
+        ACCUMULATE into parameters an earlier flush (or another op of this one) also accumulates into: the three encoder passes (trajectory
+        frames, I_0, I_g) share their weights, and two lanes adding to one address at the same time lose an update."""
         if not plan.deferred:
             return
         if not self.side_lanes:
@@ -229,6 +232,10 @@ class GCPTrainStep:
             return
         lanes = list(range(1, 1 + self.n_side))
         plan.fork(lanes)
+        if one_lane:
+            for other in lanes[1:]:
+                plan.wait(lanes[0], other)
+            lanes = lanes[:1]
         if self.group_wgrads:
             plan.deferred = self._group_wgrads(plan, plan.deferred)
         # ops of one tag (wgrad + its reduce) stay on one lane, in order
@@ -237,7 +244,9 @@ class GCPTrainStep:
         for name, fn, args in plan.deferred:
             tag = name.split(":", 1)[1] if ":" in name else name
             tag = alias.get(tag, tag)
-            if tag not in lane_of:
+            if one_lane:
+                lane_of[tag] = lanes[0]
+            elif tag not in lane_of:
                 lane_of[tag] = lanes[len(lane_of) % len(lanes)]
             plan.lane = lane_of[tag]
             plan.add(name, fn, *args)
@@ -759,7 +768,7 @@ class GCPTrainStep:
         self._flush(plan)
         self._encoder_backward(plan, fplan, "I0", _addr(dE), nz, 1, PS * nz, dskip)
         self._encoder_backward(plan, fplan, "Ig", _addr(dE, 2 ** L * nz), nz, 1, PS * nz, {})
-        self._flush(plan)
+        self._flush(plan, one_lane=True)      # same parameters as the trajectory pass: one lane, behind it
         if self.side_lanes:
             plan.join(list(range(1, 1 + self.n_side)))
         plan.outs = dict(dE=dE, dHid=dHid, dET=dET, dQZ=dQZ, dPZ=dPZ, dMD=dMD, d_inf=d_inf, d_enc_traj=d_enc_traj, dE_dec=dE_dec,
