@@ -608,6 +608,15 @@ int gcpx_repack(const float* theta, const int32_t* idx0, const int32_t* idx1, fl
    read: out[((i / 512) * 2 + p) * 512 + i % 512], p = 0 (rn16(v 2^e)) and 1 (rn16 of the remainder); n % 512 == 0.  Same pieces as
    packing.split_f16 on the host */
 int gcpx_split_pack(const float* theta, const int32_t* idx, int32_t n, void* out, int32_t* log2_out, void* stream);
+/* The same for several tensors in one launch (one workgroup per tensor; csrc/split_pack.hip): tab = DEVICE array of descriptors */
+typedef struct gcpx_split_pack_desc {
+    const float* src;        /* flat parameter vector (or the folded weights of a row-folded block) */
+    const int32_t* idx;      /* [n] gather indices into src, -1 = zero */
+    void* out;               /* [n / 512][2][512] f16 */
+    int32_t* log2_out;       /* exponent of the tensor */
+    int32_t n, _pad;
+} gcpx_split_pack_desc;
+int gcpx_split_pack_group(const gcpx_split_pack_desc* tab, int32_t nprob, void* stream);
 /* Row-folded weights of an upsampling decoder block (bilinear x2, align_corners=False, then 3x3 conv, pad 1 — DecoderModule's
    pyramid / additional_conv_layer blocks, blox; called through gcp/prediction/models/tree/tree_dense_rec.py:42).  Output row
    2 y + py of the block reads the three low-resolution rows y - 1, y, y + 1 (clamped) of the horizontally interpolated input with

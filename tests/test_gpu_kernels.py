@@ -1072,3 +1072,35 @@ def test_conv_stage(env, Hin, c_prev, c_skip, Fr, nodes, up):
         w2 = want[fmap.clamp(min=0).long()].clone()
         w2[1] = 0.0
         assert_close(out.permute(0, 3, 1, 2), w2, atol=2e-6, rtol=1e-6, name="conv_stage mapped")
+
+
+def test_split_pack_group_equals_single_launches(env):
+    """gcpx_split_pack_group (all split-f16 weight tensors re-split in one launch, one workgroup per tensor) writes bit for bit what one
+    gcpx_split_pack launch per tensor writes: tensors of different sizes and magnitudes, one of them all zero."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(4)
+    shapes = [((100, 16, 3, 3), 1.0), ((16, 32, 3, 3), 1e-3), ((32, 64, 3, 3), 30.0), ((16, 32, 3, 3), 0.0)]
+    off, parts, idxs = 8, [torch.randn(8) * 100], []
+    for shp, amp in shapes:
+        w = torch.randn(*shp) * amp
+        idxs.append(pk.conv3x3_split_index(shp, off, None).to(dev))
+        parts.append(w.reshape(-1))
+        off += w.numel()
+    theta = torch.cat(parts).to(dev)
+    outs_a = [torch.full((2 * i.numel(),), -1, dtype=torch.int16, device=dev) for i in idxs]
+    outs_b = [torch.full((2 * i.numel(),), -2, dtype=torch.int16, device=dev) for i in idxs]
+    ea, eb = torch.full((len(idxs),), 99, dtype=torch.int32, device=dev), torch.full((len(idxs),), 98, dtype=torch.int32, device=dev)
+    for k, i in enumerate(idxs):
+        rt.check(lib.gcpx_split_pack(theta.data_ptr(), i.data_ptr(), i.numel(), outs_a[k].data_ptr(), ea.data_ptr() + 4 * k, _stream()), "split_pack")
+    descs = []
+    for k, i in enumerate(idxs):
+        d = rt.SplitPackDesc()
+        d.src, d.idx, d.out, d.log2_out, d.n = theta.data_ptr(), i.data_ptr(), outs_b[k].data_ptr(), eb.data_ptr() + 4 * k, i.numel()
+        descs.append(d)
+    arr = (rt.SplitPackDesc * len(descs))(*descs)
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    rt.check(lib.gcpx_split_pack_group(tab.data_ptr(), len(descs), _stream()), "split_pack_group")
+    torch.cuda.synchronize()
+    assert torch.equal(ea, eb)
+    for a_, b_ in zip(outs_a, outs_b):
+        assert torch.equal(a_, b_)

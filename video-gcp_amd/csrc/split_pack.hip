@@ -1,0 +1,50 @@
+// Re-split of every split-f16 weight tensor after an optimizer step in ONE launch: workgroup p does what gcpx_split_pack
+// (conv3x3_split.hip) does for tensor p — largest gathered magnitude -> power-of-two exponent -> the two f16 pieces in
+// [..][2][512]-element blocks.  Eleven one-workgroup launches in a row took 0.45 ms of every training step (each is bound by what one
+// CU pulls); side by side they take as long as the largest.
+#include "common.h"
+
+namespace {
+__global__ void __launch_bounds__(1024) split_pack_group_kernel(const gcpx_split_pack_desc* __restrict__ tab) {
+    __shared__ float red[16];
+    const gcpx_split_pack_desc d = tab[blockIdx.x];
+    const float* __restrict__ theta = d.src;
+    const int* __restrict__ idx = d.idx;
+    _Float16* __restrict__ out = reinterpret_cast<_Float16*>(d.out);
+    const int n = d.n, tid = threadIdx.x;
+    float m = 0.f;
+    for (int i = tid; i < n; i += 1024) {
+        const int k = idx[i];
+        m = fmaxf(m, k >= 0 ? fabsf(theta[k]) : 0.f);
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    // largest magnitude times 2^e in [2^14, 2^15): the range the kernels' exponent bookkeeping covers (as gcpx_split_pack)
+    int e = m > 0.f ? 14 + 127 - (int)((__float_as_uint(m) >> 23) & 0xff) : 0;
+    e = max(-20, min(100, e));
+    if (tid == 0) *d.log2_out = e;
+    const float sc = __uint_as_float((unsigned)(127 + e) << 23);
+    for (int i = tid; i < n; i += 1024) {
+        const int k = idx[i];
+        const float v = (k >= 0 ? theta[k] : 0.f) * sc;
+        const _Float16 h1 = (_Float16)v;
+        const _Float16 h2 = (_Float16)(v - (float)h1);
+        const int o = (i >> 9) * 1024 + (i & 511);
+        out[o] = h1;
+        out[o + 512] = h2;
+    }
+}
+}  // namespace
+
+// tab: DEVICE array of nprob descriptors (n a positive multiple of 512 each)
+extern "C" int gcpx_split_pack_group(const gcpx_split_pack_desc* tab, int32_t nprob, void* stream_) {
+    GCPX_CHECK_ARG(tab && nprob > 0, "bad arguments");
+    hipLaunchKernelGGL(split_pack_group_kernel, dim3(nprob), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream_), tab);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}

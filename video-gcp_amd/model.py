@@ -327,15 +327,28 @@ class GCPTreeModel:
         self.repack_split()
 
     def repack_split(self, stream=None):
+        """re-split every split-f16 weight tensor from the flat parameter vector: the row-folded blocks' weights are folded first, then ONE
+        grouped launch splits all tensors side by side (one workgroup each; as separate launches they were 0.45 ms of a training step)"""
         st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        if not self.pk_split:
+            return
+        tab = getattr(self, "_split_tab", None)
+        key = (self.theta.data_ptr(),) + tuple((d["out"].data_ptr(), d["idx"].data_ptr()) for d in self.pk_split.values())
+        if tab is None or tab[2] != key:
+            descs = []
+            for name, d in self.pk_split.items():
+                src = d["fold"] if "fold" in d else self.theta
+                e = rt.SplitPackDesc()
+                e.src, e.idx, e.out, e.log2_out, e.n = src.data_ptr(), d["idx"].data_ptr(), d["out"].data_ptr(), d["log2"].data_ptr(), d["idx"].numel()
+                descs.append(e)
+            arr = (rt.SplitPackDesc * len(descs))(*descs)
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            tab = self._split_tab = (dev, len(descs), key)
         for name, d in self.pk_split.items():
-            src = self.theta
             if "fold" in d:
                 off, cout, cin = d["fold_src"]
                 rt.check(self.lib.gcpx_fold_upsample_weights(self.theta.data_ptr() + 4 * off, cout, cin, d["fold"].data_ptr(), st), "fold_upsample_weights")
-                src = d["fold"]
-            rt.check(self.lib.gcpx_split_pack(src.data_ptr(), d["idx"].data_ptr(), d["idx"].numel(), d["out"].data_ptr(),
-                                              d["log2"].data_ptr(), st), "split_pack")
+        rt.check(self.lib.gcpx_split_pack_group(tab[0].data_ptr(), tab[1], st), "split_pack_group")
 
     def _pack_gemm_split(self):
         """Inference only (like the fused embedding: a re-split of every GEMM weight after each optimizer step is not worth its

@@ -73,6 +73,10 @@ class MlpBwdArgs(C.Structure):
                 ("mid", i32), ("n_mid", i32), ("out_pad", i32), ("ndx", i32), ("gn_eps", C.c_float), ("lrelu_slope", C.c_float)]
 
 
+class SplitPackDesc(C.Structure):
+    _fields_ = [("src", vp), ("idx", vp), ("out", vp), ("log2_out", vp), ("n", i32), ("_pad", i32)]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [("dy", vp), ("x", vp), ("rowidx", vp), ("frame_map", vp), ("scale", vp), ("shiftv", vp), ("out", vp),
                 ("ldy", i64), ("sb", i64), ("sr", i64), ("ldw", i64), ("dy_sb", i64), ("R", i32), ("N", i32), ("n_valid", i32),
@@ -141,6 +145,7 @@ SYMBOLS = [
     ("gcpx_wgrad_conv3x3", C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     ("gcpx_wgrad_conv3x3_split", C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     ("gcpx_wgrad_image4x4s2", C.c_int, [vp, vp, vp, vp, i32, i32, vp, i32, vp]),
+    ("gcpx_split_pack_group", C.c_int, [vp, i32, vp]),
     ("gcpx_wgrad_reduce", C.c_int, [vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, i64, i32, i32, vp]),
     ("gcpx_colsum", C.c_int, [vp, i64, i32, i32, i32, i64, i32, vp, vp, vp, i32, vp]),
     ("gcpx_reduce_partials", C.c_int, [vp, i32, i64, i32, vp, i32, vp]),
