@@ -1,5 +1,6 @@
+"""Device time of the optimizer step alone (RAdam + re-pack + re-split of the split-f16 weights), c2: python tools/opt_time.py"""
 import os, sys, time
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import video_gcp_amd as V

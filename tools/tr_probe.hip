@@ -1,3 +1,5 @@
+// What ds_read_b64_tr_b16 returns: every lane supplies the address of an 8-byte chunk, the output names (source lane, half) of the four
+// halfs each lane receives, for three address patterns.  hipcc --offload-arch=gfx950 -O2 tools/tr_probe.hip -o tools/tr_probe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));

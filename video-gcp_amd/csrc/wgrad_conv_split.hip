@@ -400,7 +400,7 @@ int launch_ws(const float* dy, const float* u, float* partial, int F, int H, int
 }  // namespace
 
 // Same arguments, grid and partial layout as gcpx_wgrad_conv3x3 (the exact f32 kernel, which also takes the shapes this one does not
-// cover): grid.y must be Cin / 32 when Cin % 32 == 0 and Cout > 16 ... see gcpx_wgrad_conv3x3_split_chunk.
+// cover; the input-channel chunk per workgroup row — 16 for the 112-slot head, 32 otherwise — is the same in both).
 extern "C" int gcpx_wgrad_conv3x3_split(const float* dy, int32_t ldy, const float* u, int32_t F, int32_t H, int32_t W, int32_t Cin,
                                         int32_t Cout, float* partial, int32_t grid, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
