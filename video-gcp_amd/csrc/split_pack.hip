@@ -12,10 +12,19 @@ __global__ void __launch_bounds__(1024) split_pack_group_kernel(const gcpx_split
     const int* __restrict__ idx = d.idx;
     _Float16* __restrict__ out = reinterpret_cast<_Float16*>(d.out);
     const int n = d.n, tid = threadIdx.x;
+    // (eight gathers in flight per thread: one workgroup owns a tensor of up to 10^5 elements, and a dependent index -> value load per
+    //  loop iteration made the launch 0.2 ms)
+    constexpr int U = 8;
     float m = 0.f;
-    for (int i = tid; i < n; i += 1024) {
-        const int k = idx[i];
-        m = fmaxf(m, k >= 0 ? fabsf(theta[k]) : 0.f);
+    for (int i0 = tid; i0 < n; i0 += 1024 * U) {
+        int k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) k[u] = i0 + 1024 * u < n ? idx[i0 + 1024 * u] : -1;
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = k[u] >= 0 ? theta[k[u]] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) m = fmaxf(m, fabsf(v[u]));
     }
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s));
@@ -29,14 +38,25 @@ __global__ void __launch_bounds__(1024) split_pack_group_kernel(const gcpx_split
     e = max(-20, min(100, e));
     if (tid == 0) *d.log2_out = e;
     const float sc = __uint_as_float((unsigned)(127 + e) << 23);
-    for (int i = tid; i < n; i += 1024) {
-        const int k = idx[i];
-        const float v = (k >= 0 ? theta[k] : 0.f) * sc;
-        const _Float16 h1 = (_Float16)v;
-        const _Float16 h2 = (_Float16)(v - (float)h1);
-        const int o = (i >> 9) * 1024 + (i & 511);
-        out[o] = h1;
-        out[o + 512] = h2;
+    for (int i0 = tid; i0 < n; i0 += 1024 * U) {
+        int k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) k[u] = i0 + 1024 * u < n ? idx[i0 + 1024 * u] : -1;
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = k[u] >= 0 ? theta[k[u]] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 1024 * u;
+            if (i < n) {
+                const float v = w[u] * sc;
+                const _Float16 h1 = (_Float16)v;
+                const _Float16 h2 = (_Float16)(v - (float)h1);
+                const int o = (i >> 9) * 1024 + (i & 511);
+                out[o] = h1;
+                out[o + 512] = h2;
+            }
+        }
     }
 }
 }  // namespace
