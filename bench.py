@@ -113,29 +113,48 @@ def cpu_baseline(budget_s=24.0, full=False, schedule=None):
         sched = [(cfg, b, k, r, 3, 10, 10, 1e9) for cfg, b in (("c1", 2), ("c2", 16)) for k in (1, all_threads)
                  for r in ("forward", "planning_rollout", "train_step")]
     else:
-        q = budget_s / 8.0
-        sched = [("c2", 2, all_threads, "forward", 1, 3, 10, 3 * q), ("c2", 2, all_threads, "train_step", 0, 1, 3, 3 * q),
-                 ("c1", 2, all_threads, "forward", 1, 3, 10, q / 2), ("c1", 2, all_threads, "train_step", 1, 2, 5, q / 2),
-                 ("c1", 2, 1, "forward", 1, 2, 5, q / 2), ("c1", 2, 1, "train_step", 0, 1, 3, q / 2)]
+        # bounded default (about 30 s): the headline region (c2 shapes, batch 2, inference forward) at 1 / 16 / all threads with
+        # 1 warm-up + 10 timed iterations at the two small thread counts (the all-thread run is oversubscribed on this oracle and
+        # slower: 3 iterations), then one training step and the c1 plumbing config at the thread count that came out best
+        mid = min(16, all_threads)
+        sched = [("c2", 2, 1, "forward", 1, 10, 10, 1e9), ("c2", 2, mid, "forward", 1, 10, 10, 1e9),
+                 ("c2", 2, all_threads, "forward", 1, 3, 3, 1e9)]
+        tail = lambda k: [("c2", 2, k, "train_step", 0, 2, 2, 1e9), ("c1", 2, k, "forward", 1, 10, 10, 1e9),
+                          ("c1", 2, k, "train_step", 1, 3, 3, 1e9)]
     cache = {}
+
+    def run(item):
+        cfg, b, k, region, warm, mn, mx, bud = item
+        if (cfg, b) not in cache:
+            cache[(cfg, b)] = regions(cfg, b)
+        hp, fns = cache[(cfg, b)]
+        torch.set_num_threads(k)
+        st = _stats(_time_region(fns[region], bud, warm, mn, mx))
+        st.update(config=cfg, batch=b, threads=k, region=region,
+                  frames_per_s=round(hp.batch_size * hp.max_seq_len / st["median_s"], 2))
+        out["runs"].append(st)
+
+    def best_forward():
+        return max((r for r in out["runs"] if r["config"] == "c2" and r["region"] == "forward"), key=lambda r: r["frames_per_s"])
+
     try:
-        for cfg, b, k, region, warm, mn, mx, bud in sched:
-            if (cfg, b) not in cache:
-                cache[(cfg, b)] = regions(cfg, b)
-            hp, fns = cache[(cfg, b)]
-            torch.set_num_threads(k)
-            ts = _time_region(fns[region], bud, warm, mn, mx)
-            st = _stats(ts)
-            st.update(config=cfg, batch=b, threads=k, region=region,
-                      frames_per_s=round(hp.batch_size * hp.max_seq_len / st["median_s"], 2))
-            out["runs"].append(st)
+        for item in sched:
+            run(item)
+        if schedule is None and not full:
+            for item in tail(best_forward()["threads"]):
+                run(item)
     finally:
         torch.set_num_threads(all_threads)
-    head = [r for r in out["runs"] if r["config"] == "c2" and r["region"] == "forward" and r["threads"] == all_threads][-1]
+    # `value` = the BEST CPU configuration timed for the headline region (more threads are not faster on this oracle: its tree
+    # levels are small GEMMs), `cores` = the threads that run used
+    head = best_forward()
     out["value"] = head["frames_per_s"]
+    out["cores"] = head["threads"]
+    out["host_threads"] = all_threads
     out["sample"] = (f"oracle/gcp_model_oracle.py (torch {torch.__version__} CPU fp32) at c2 shapes (64x64, T=80, 127 nodes/seq) with batch "
-                     f"{head['batch']}: median of {head['iters']} forward passes on {all_threads} threads; `runs` lists every timed "
-                     "region (config, batch, threads, forward / training step, median and min seconds)"
+                     f"{head['batch']}: median of {head['iters']} forward passes on {head['threads']} of {all_threads} hardware threads "
+                     "(the fastest of the thread counts in `runs`, which lists every timed region: config, batch, threads, forward / "
+                     "training step, median and min seconds)"
                      + ("" if (full or schedule) else "; bounded sample — the full BASELINE.md section-2 protocol is profiles/r02_cpu_baseline_full.json"))
     return out
 

@@ -157,20 +157,26 @@ def hparams_from_conf(configuration, model_config, **over):
     return hp, trainer, ignored
 
 
-def load_conf(exp_dir, default="c2", **over):
+def load_conf(exp_dir, default="c2", name=None, **over):
     """`<exp_dir>/*.py` (the reference's rule, gcp_builder.py:112-118: the one configuration file in the directory) or
-    `<exp_dir>/conf.json`.  Returns (GCPHParams, trainer settings dict, ignored keys)."""
+    `<exp_dir>/conf.json`.  Returns (GCPHParams, trainer settings dict, ignored keys).  `name`: a named configuration given
+    explicitly (the --config flag): it wins over conf.json's "config" entry; `default` is used only when neither names one.
+    A reference-style conf.py carries no dataset spec: `max_seq_len` / `img_sz` not given as overrides fall back to the dataclass
+    defaults and are reported among the ignored keys as "defaulted:<key>"."""
     if exp_dir and os.path.isdir(exp_dir):
         py = sorted(glob.glob(os.path.join(os.path.abspath(exp_dir), "*.py")))
         if len(py) > 1:
             raise ValueError(f"Multiple configuration files found at {exp_dir}!")
         if py:
             c, mc = exec_conf_py(py[0])
-            return hparams_from_conf(c, mc, **over)
+            hp, trainer, ignored = hparams_from_conf(c, mc, **over)
+            # the reference takes these from the dataset spec (data_loader.py), which a conf.py does not hold
+            ignored += [f"defaulted:{k}" for k in ("max_seq_len", "img_sz") if k not in over and k not in mc]
+            return hp, trainer, ignored
         js = os.path.join(exp_dir, "conf.json")
         if os.path.exists(js):
             conf = json.load(open(js))
             ov = dict(conf.get("overrides", {}), **over)
-            hp = named_config(conf.get("config", default), **ov)
+            hp = named_config(name or conf.get("config", default), **ov)
             return hp, {k: conf[k] for k in conf if k not in ("config", "overrides")}, []
-    return named_config(default, **over), {}, []
+    return named_config(name or default, **over), {}, []

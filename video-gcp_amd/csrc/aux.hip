@@ -19,8 +19,10 @@ __global__ void aux_sample_indices_kernel(const long long* __restrict__ end_ind,
     const long long e = end_ind[b];
     const double ed = (double)e;
     auto uni = [&](int k) { const double v = (double)u[k * B + b]; return GAUSS ? 0.5 * erfc(-v * 0.70710678118654752440) : v; };
+    // the reference asserts end_ind >= temp_dist (inverse_mdl.py:93); a shorter sequence must not turn into a negative frame index
+    // (the gather rows and action_seq[b, t0] are addressed with it): t0 is clamped to >= 0, t1 to <= end_ind
     long long a = (long long)floor(uni(0) * (ed - temp_dist + 1));
-    a = min(a, e - temp_dist);
+    a = max(min(a, e - temp_dist), 0ll);
     long long d = (long long)floor(uni(1) * temp_dist);
     d = min(d, (long long)temp_dist - 1);
     long long s = (long long)floor(uni(2) * ed);
@@ -28,7 +30,7 @@ __global__ void aux_sample_indices_kernel(const long long* __restrict__ end_ind,
     long long w = (long long)floor(uni(3) * (ed - (double)s));
     w = min(w, e - s - 1);
     t0[b] = a;
-    t1[b] = a + 1 + d;
+    t1[b] = min(a + 1 + d, max(e, 0ll));
     cs[b] = s;
     ce[b] = s + 1 + w;
 }

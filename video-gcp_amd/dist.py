@@ -116,6 +116,15 @@ class GradBuckets:
         self.works = {}
         self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
 
+    def begin(self):
+        """Start of a backward pass: nothing of a previous pass may still be pending.  A backward that was not followed by
+        `finish()` (gradient inspection, an exception between backward and step, a manual accumulate loop) leaves its works
+        behind; the next pass re-computes the gradient and must re-reduce every bucket, so those works are waited for and
+        dropped here instead of making `reduce_async` skip the bucket."""
+        for w in self.works.values():
+            w.wait()
+        self.works = {}
+
     def reduce_async(self, i, after_streams=()):
         """Start the all-reduce of bucket i.  after_streams: the device streams whose enqueued work produces this bucket."""
         if not dist.is_initialized() or i in self.works:

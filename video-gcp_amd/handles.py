@@ -112,13 +112,21 @@ class DenseRecHandle:
 
     def __init__(self, model):
         self.m = model
-        self.eval_binding = None
+        self._bindings = {}
 
     def _binding(self, pruning_scheme):
-        if self.eval_binding is None:
+        """one evaluation binding per pruning scheme (tree_dense_rec.py:8-11 builds the one its hyper-parameter names; callers
+        here may ask for several)"""
+        b = self._bindings.get(pruning_scheme)
+        if b is None:
             from .evaluation import get_eval_binding
-            self.eval_binding = get_eval_binding(self.m, pruning_scheme)
-        return self.eval_binding
+            b = self._bindings[pruning_scheme] = get_eval_binding(self.m, pruning_scheme)
+        return b
+
+    @property
+    def eval_binding(self):
+        """the most recently used binding (the reference's attribute name)"""
+        return next(reversed(self._bindings.values()), None)
 
     def get_sample_with_len(self, i_ex, length, outputs, inputs, pruning_scheme, name=None):
         b = self._binding(pruning_scheme)

@@ -1320,7 +1320,9 @@ class GCPTreeModel:
         caller = torch.cuda.current_stream(self.device)
         self._stream.wait_stream(caller)
         tin = {}
-        names = ("I_0", "I_g") + (("end_ind",) if "end_ind" in inputs else ()) + (("traj_seq",) if has_traj else ()) + \
+        # under pred_len the fed end_ind is replaced by the draw (base_gcp.py:219-226): it is not read, and the draw goes to a buffer
+        # of its own so that a caller who filled input_buffer('end_ind') in place keeps its ground-truth lengths
+        names = ("I_0", "I_g") + (("end_ind",) if ("end_ind" in inputs and not pred_len) else ()) + (("traj_seq",) if has_traj else ()) + \
             (("z",) if has_z else ()) + opt + (AUX if fed_idx else ())
         with torch.cuda.stream(self._stream):
             for k in names:
@@ -1334,7 +1336,7 @@ class GCPTreeModel:
                         t.record_stream(self._stream)
                 tin[k] = buf
             if "end_ind" not in tin:
-                tin["end_ind"] = self._buf("in.end_ind", (B,), torch.int64)       # written by the length draw inside the plan
+                tin["end_ind"] = self._buf("out.end_ind", (B,), torch.int64)      # written by the length draw inside the plan
             if pred_len:
                 # the OneHotCategorical draw of the sequence length (misc.py:49) as one uniform number per sequence
                 lu = self._buf("in.len_u", (B,))

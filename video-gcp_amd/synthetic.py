@@ -38,8 +38,9 @@ def aux_indices(end_ind, u, temp_dist=1):
     e = end_ind.to(torch.float64)
     u = u.to(torch.float64)
     fl = lambda x: torch.floor(x).long()
-    t0 = torch.minimum(fl(u[0] * (e - temp_dist + 1)), end_ind - temp_dist)
-    t1 = t0 + 1 + torch.clamp(fl(u[1] * temp_dist), max=temp_dist - 1)
+    # (the reference asserts end_ind >= temp_dist, inverse_mdl.py:93; shorter sequences are clamped into [0, end_ind] like the kernel does)
+    t0 = torch.clamp(torch.minimum(fl(u[0] * (e - temp_dist + 1)), end_ind - temp_dist), min=0)
+    t1 = torch.minimum(t0 + 1 + torch.clamp(fl(u[1] * temp_dist), max=temp_dist - 1), torch.clamp(end_ind, min=0))
     s = torch.minimum(fl(u[2] * e), end_ind - 1)
     en = s + 1 + torch.minimum(fl(u[3] * (e - s.to(torch.float64))), end_ind - s - 1)
     return dict(inv_t0=t0, inv_t1=t1, cost_start_idx=s, cost_end_idx=en)

@@ -69,7 +69,12 @@ class ModelTrainer:
         from .conf_loader import load_conf
         # <path>/conf.py in the reference's format (`configuration` + `model_config`, gcp_builder.py:129-147) or <path>/conf.json
         name = args.config or "c2"
-        self.hp, conf, self.ignored_conf_keys = load_conf(args.path, default=name)
+        # an explicit --config wins over conf.json's "config" entry (and names the default experiment directory below)
+        self.hp, conf, self.ignored_conf_keys = load_conf(args.path, default="c2", name=args.config)
+        for k in self.ignored_conf_keys:
+            if k.startswith("defaulted:"):
+                print(f"[train] {k[10:]} is not in the configuration file (the reference reads it from the dataset spec): "
+                      f"using {getattr(self.hp, k[10:])}", flush=True)
         hp = self.hp
         self.exp_path = args.path or os.path.join("experiments", name)
         self.rank, self.local_rank, self.world = D.init_from_env()

@@ -712,6 +712,14 @@ class GCPTrainStep:
             dXa = None
             if attentive:
                 dXa = self._attention_backward(plan, fplan, l, Wt, dEt_l, dKp, dVp, B)
+                # this level's column block of dKp / dVp is final now: its k_proj / v_proj weight gradients belong to the level's
+                # module (and to its bucket of the data-parallel exchange), so they go out with this level's flush, in front of
+                # the bucket mark — issued after the tree loop they were written into a slice whose all-reduce had already started
+                a_ = f"tree_module.tree_modules.{li}.inference.attention.attention_layers.0"
+                self._wgrad(plan, f"attn.k_proj{l}", _addr(dKp, li * dk), n_mod * dk, B * T, dk, kv["keys"].data_ptr(), dk,
+                            self.g(f"{a_}.k_proj.weight"), ldw=dk, sr=dk, sb=B * T * dk, rpb=B * T, dbias=self.g(f"{a_}.k_proj.bias"))
+                self._wgrad(plan, f"attn.v_proj{l}", _addr(dVp, li * nz), n_mod * nz, B * T, nz, o["inf_enc_seq"].data_ptr(), nz,
+                            self.g(f"{a_}.v_proj.weight"), ldw=nz, sr=nz, sb=B * T * nz, rpb=B * T, dbias=self.g(f"{a_}.v_proj.bias"))
             if split:
                 plan.lane = 2
             self._mlp_bwd(plan, f"prior{l}", f"{p}.prior", rec[f"mlp:prior{l}"], Wt["prior"], dp.data_ptr(), 2 * nv,
@@ -745,12 +753,6 @@ class GCPTrainStep:
             self._dgemm(plan, "attn.v_proj", [dense(dVp, n_mod * nz)], B * T, nz, B * T, self.bk["attn.v_proj.wT"], d_inf.data_ptr(), 0, nz)
             dkeys = buf("bw.dkeys", (B * T, dk))
             self._dgemm(plan, "attn.k_proj", [dense(dKp, n_mod * dk)], B * T, dk, B * T, self.bk["attn.k_proj.wT"], dkeys.data_ptr(), 0, dk)
-            for l in range(n_mod):
-                a_ = f"tree_module.tree_modules.{l}.inference.attention.attention_layers.0"
-                self._wgrad(plan, f"attn.k_proj{l}", _addr(dKp, l * dk), n_mod * dk, B * T, dk, kv["keys"].data_ptr(), dk,
-                            self.g(f"{a_}.k_proj.weight"), ldw=dk, sr=dk, sb=B * T * dk, rpb=B * T, dbias=self.g(f"{a_}.k_proj.bias"))
-                self._wgrad(plan, f"attn.v_proj{l}", _addr(dVp, l * nz), n_mod * nz, B * T, nz, o["inf_enc_seq"].data_ptr(), nz,
-                            self.g(f"{a_}.v_proj.weight"), ldw=nz, sr=nz, sb=B * T * nz, rpb=B * T, dbias=self.g(f"{a_}.v_proj.bias"))
             self._wgrad(plan, "kseq.key", dkeys.data_ptr(), dk, B * T, dk, kv["kenc"].data_ptr(), nz,
                         self.g("inf_key_encoder.1.linear.weight"), ldw=nz, sr=nz, sb=B * T * nz, rpb=B * T,
                         dbias=self.g("inf_key_encoder.1.linear.bias"))
@@ -1028,6 +1030,8 @@ class GCPTrainStep:
     def backward(self, inputs, noise=None):
         """forward (phase 'train', losses on device) + backward; gradients in self.grad.  Returns the forward outputs."""
         m = self.m
+        if self.buckets is not None:
+            self.buckets.begin()          # a backward without an optimizer step in between must exchange its buckets again
         out = m.forward(inputs, "train", noise)
         if "losses" not in out.raw:
             raise ValueError("the training step needs traj_seq and pad_mask")
