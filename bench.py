@@ -41,6 +41,8 @@ def measured_head_traffic(batch, eval_bn):
             d = json.load(f)
         if d.get("kernel_src_sha") != kernel_source_sha() or d.get("batch") != batch or bool(d.get("eval_bn")) != bool(eval_bn):
             return None
+        if not d.get("with_loss"):          # the headline forward keeps the matched frames' raw parameters (a round-2 pass did not)
+            return None
         return int(d["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
@@ -180,7 +182,7 @@ def _timed(fn, steps, warmup, world, dev):
     return D.max_over_ranks(time.perf_counter() - t0, device=dev) / steps
 
 
-def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
+def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev, dinp_noloss):
     """Secondary measurements of SURVEY.md §8(d): (iii) training step (forward + backward + RAdam, RCCL all-reduce of the
     flat gradient when N > 1), (ii) one CEM planning iteration over 512 candidates sharded over the ranks, and the
     adaptive-binding forward of configs[4].  Each is whole-job predicted frames/s; failures are reported, not hidden."""
@@ -210,6 +212,30 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
         except Exception as e:  # noqa: BLE001
             return None, repr(e)[:300]
 
+    try:
+        # round-2 headline for continuity: the same forward WITHOUT loss inputs (mean-only head: 80 of the 100 mixture channels)
+        dt = _timed(lambda: model(dinp_noloss, "train"), k, 2, world, dev)
+        res["forward_no_loss"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
+                                  "ms_per_step": round(1e3 * dt, 3),
+                                  "workload": "posterior forward without pad_mask: no loss kernels, head computes the 80 channels the mixture "
+                                              "mean reads (the round-2 headline; an inference forward no reference entry point runs)"}
+        # the planner's rollout (cem_simulator.py:29-31): eval-mode (running-stat BatchNorm) prior path with given latents z
+        was = model.training
+        model.eval()
+        zin = dict(I_0=dinp["I_0"], I_g=dinp["I_g"], end_ind=dinp["end_ind"], start_ind=dinp["start_ind"],
+                   z=torch.randn(hp.batch_size, hp.n_nodes, hp.nz_vae, device=dev))
+
+        def rollout():
+            with model.val_mode(pred_length=False):
+                model(zin, "train")
+        dt = _timed(rollout, k, 2, world, dev)
+        model.train(was)
+        res["planning_rollout"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
+                                   "ms_per_step": round(1e3 * dt, 3),
+                                   "workload": "eval-mode planner rollout at the headline batch: prior path with given z, running-stat "
+                                               "BatchNorm, every node decoded (mean-only head), no trajectory encoder"}
+    except Exception as e:  # noqa: BLE001
+        res["forward_no_loss"] = {"error": repr(e)[:300]}
     if model.split_f16 and model.pk_split:
         # the same forward with every conv on the exact f32 MFMA kernels (GCPX_EXACT_F32=1), for comparison
         try:
@@ -218,8 +244,8 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
             dt = _timed(lambda: model(dinp, "train"), k, 2, world, dev)
             res["forward_exact_f32"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
                                         "ms_per_step": round(1e3 * dt, 3),
-                                        "workload": "the headline forward with the split-f16 convs switched off (GCPX_EXACT_F32=1): exact f32 "
-                                                    "MFMA kernels throughout"}
+                                        "workload": "the headline forward (with losses) with the split-f16 convs switched off (GCPX_EXACT_F32=1): "
+                                                    "exact f32 MFMA kernels throughout"}
         except Exception as e:  # noqa: BLE001
             res["forward_exact_f32"] = {"error": repr(e)[:300]}
         finally:
@@ -302,6 +328,59 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev):
         del tr5, m5
     except Exception as e:  # noqa: BLE001
         res["adaptive_forward"] = {"error": repr(e)[:300]}
+    try:
+        from video_gcp_amd.sequential import GCPSequentialModel
+        ms_ = GCPSequentialModel(hp, device=dev)
+        dseq = {k_: dinp[k_] for k_ in ("traj_seq", "I_0", "I_g", "end_ind", "start_ind", "pad_mask")}
+        _, err = setup(lambda: ms_(dseq, "train"))
+        if not agree(err is None):
+            raise RuntimeError(err or "set-up failed on another rank")
+        dt = _timed(lambda: ms_(dseq, "train"), k, 2, world, dev)
+        res["sequential_forward"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
+                                     "ms_per_step": round(1e3 * dt, 3),
+                                     "workload": "flat VRNN baseline gcp_sequential (sequential.py:13-131) at the headline shapes: posterior "
+                                                 "rollout over 79 steps + decoder + losses"}
+        if hasattr(ms_, "_has_training") and ms_._has_training:
+            from video_gcp_amd.training_sequential import SequentialTrainStep
+            trs, err = setup(lambda: SequentialTrainStep(ms_, process_group=(dist.group.WORLD if world > 1 else None)))
+            if not agree(err is None):
+                raise RuntimeError(err or "set-up failed on another rank")
+            fulls = {k_: v.to(dev) for k_, v in inputs.items()}
+            dt = _timed(lambda: trs.step(fulls), max(3, k // 2), 2, world, dev)
+            res["sequential_train_step"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
+                                            "ms_per_step": round(1e3 * dt, 3),
+                                            "workload": "gcp_sequential: forward + losses + backward through the 79-step recurrence + RAdam"}
+            del trs
+        del ms_
+    except Exception as e:  # noqa: BLE001
+        res["sequential_forward"] = {"error": repr(e)[:300]}
+    try:
+        from video_gcp_amd.planning import GCPImageSimulator, LearnedCostEstimate, HierarchicalCEMPlanner
+        hp4 = V.config("c4")
+        m4 = GCPTreeModel(hp4, params=V.init_params(hp4, seed=0), device=dev)
+        m4.eval()
+        rng = np.random.RandomState(0)
+        state = rng.randint(0, 256, size=(1, hp4.img_sz, hp4.img_sz, 3)).astype(np.uint8)
+        goal = rng.randint(0, 256, size=(1, hp4.img_sz, hp4.img_sz, 3)).astype(np.uint8)
+        hplanner = HierarchicalCEMPlanner(GCPImageSimulator(m4, pred_length=False), LearnedCostEstimate(m4), hp4.hierarchy_levels, [10, 10],
+                                          action_dim=hp4.nz_vae, max_seq_len=hp4.max_seq_len)
+        _, err = setup(lambda: hplanner(state, goal))
+        if err is not None:
+            raise RuntimeError(err)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            hplanner(state, goal)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res["hierarchical_planner_call"] = {"ms_per_call": round(1e3 * dt, 2), "unit": "ms",
+                                            "workload": "HierarchicalCEMPlanner (tree_optimizer.py:7-260; sampling rates [10, 10], the 25-room "
+                                                        "control setting) for one (start, goal) pair at 64x64, horizon 80: device-resident, "
+                                                        "per-rank (not sharded)"}
+        del hplanner, m4
+    except Exception as e:  # noqa: BLE001
+        res["hierarchical_planner_call"] = {"error": repr(e)[:300]}
     torch.cuda.empty_cache()
     return res
 
@@ -408,15 +487,18 @@ def main():
     # the path shards by sequence: every rank predicts its own batch of independent sequences (weak scaling), no
     # data-path collective in the forward
     inputs, noise, _ = make_inputs(hp, seed=D.shard_seed(100, rank), variant="A")
-    # headline = pure prediction forward: without pad_mask the model does not run its loss kernels
+    # headline = the reference's posterior forward WITH its loss (train.py:157-159 / :205-214: every caller of the posterior path
+    # also calls model.loss): pad_mask, states and actions are fed, so the head computes all 100 mixture channels for the matched
+    # frames and the ELBO / auxiliary loss kernels run inside the timed graph.
     # the synthetic batch is written ONCE, before the timed region, into the model's own input buffers (what a device-side
     # loader does): the forward then reads it in place instead of staging a 63 MB copy per call
     dinp = {}
-    for k in ("traj_seq", "I_0", "I_g", "end_ind", "start_ind"):
+    for k in ("traj_seq", "I_0", "I_g", "end_ind", "start_ind", "pad_mask", "traj_seq_states", "actions"):
         buf = model.input_buffer(k, inputs[k].shape) if k != "start_ind" else inputs[k].to(dev)
         buf.copy_(inputs[k])
         dinp[k] = buf
     dnoise = noise.to(dev)
+    dinp_noloss = {k: dinp[k] for k in ("traj_seq", "I_0", "I_g", "end_ind", "start_ind")}
 
     # the latent noise is DRAWN inside every timed step (noise=None: Gaussian.sample() of the reference draws per forward), not fed
     for _ in range(max(args.warmup, 1)):
@@ -433,7 +515,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model(dinp, "train")
+        out = model(dinp, "train")
+        losses = model.loss(dinp, out)                 # device scalars computed inside the graph: no kernel, no sync
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -441,43 +524,50 @@ def main():
     elapsed = time.perf_counter() - t0
     head_ms = model.timed_op_ms()
     elapsed = D.max_over_ranks(elapsed, device=dev)
+    total_loss = float(model.get_total_loss(dinp, losses).value)
 
     also = None
     if not args.no_extras:
-        also = extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev)
+        also = extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev, dinp_noloss)
 
     if rank == 0:
         frames = world * hp.batch_size * hp.max_seq_len * args.steps
         value = frames / elapsed
         F = hp.batch_size * hp.n_nodes
         split = model.split_f16 and "dec.head" in model.pk_split
-        # algorithmic f32 FLOP per launch.  The mean-only head (no loss in this forward) of the split-f16 kernel computes the 80
-        # channel slots the mixture mean reads (logits, means, colour coefficients; the 20 remaining log-scale channels only exist
-        # when the raw parameters are stored); the exact-f32 kernel computes all 100
-        head_ch = 80 if split else hp.head_channels
-        head_flops = 2.0 * hp.img_sz * hp.img_sz * head_ch * hp.ngf * 9 * F
+        # algorithmic f32 FLOP per launch.  The forward with losses keeps the raw parameters of the frames matched to a ground-truth
+        # frame (B * T of the B * N node frames): all 100 channels for those, the 80 channel slots the mixture mean reads (logits,
+        # means, colour coefficients, red log-scales) for the other node frames, whose distribution nobody reads (frame_binding.py:91-92)
+        n_matched = hp.batch_size * hp.max_seq_len
+        per_ch = 2.0 * hp.img_sz * hp.img_sz * hp.ngf * 9
+        if split:
+            head_flops = per_ch * (80 * F + 20 * n_matched)
+        else:
+            head_flops = per_ch * hp.head_channels * F
         avg_ms = sum(head_ms) / len(head_ms)
         achieved = head_flops / (avg_ms * 1e-3) / 1e12
         if split:
             # every f32 product = 3 f16 MFMA products: the matrix-pipe bound for f32-equivalent FLOP is the dense f16 peak / 3
             peak = F16_MFMA_PEAK_TFLOPS / 3.0
-            kern = ("conv3x3_head_split_kernel (decoder output head, 3x3 conv 16->100 ch @64x64, mean-only: 5 of 7 channel tiles; "
+            kern = ("conv3x3_head_split_kernel (decoder output head, 3x3 conv 16->100 ch @64x64 over 2032 node frames: 100 channels + raw "
+                    "parameters for the 1280 matched frames, the 80 channels of the mixture mean for the rest; "
                     "split-f16: 3 v_mfma_f32_16x16x32_f16 per f32 product, f32 accumulate, per-item power-of-two scale; fused mixture mean)")
         else:
             peak = F32_MFMA_PEAK_TFLOPS
             kern = ("conv3x3_head_kernel<6, true> (decoder output head, 3x3 conv 16->100 ch @64x64 = 6 MFMA tiles + 4-channel 4x4x1 "
                     "remainder, fused mixture mean)")
         line = {
-            "metric": "predicted frames/sec, 64x64x3 seq_len=80 gcp_tree (train-mode posterior forward with batch-stat BatchNorm, no loss kernels)",
+            "metric": "predicted frames/sec, 64x64x3 seq_len=80 gcp_tree (posterior forward + all loss terms, model(inputs) and model.loss() of train.py:157-159, batch-stat BatchNorm)",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" + (" (encoder / decoder convs and the tree GEMMs from 512 rows: split-f16 MFMA with f32 accumulate, f32-equivalent; everything else exact f32 MFMA)" if split else ""),
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 25-room gcp_tree forward, 64x64x3, seq_len 80, batch 16/GPU, "
-                                   "L=7 (127 nodes/seq decoded), discrete-logistic-mixture head, "
+                                   "L=7 (127 nodes/seq decoded), discrete-logistic-mixture head, ELBO + auxiliary losses, "
                                    + ("running-stat" if args.eval_bn else "batch-stat") + " BatchNorm",
                        "batch_per_gpu": hp.batch_size, "seq_len": hp.max_seq_len, "img": hp.img_sz,
-                       "nodes_per_seq": hp.n_nodes, "parallelism": f"dp{world} (independent sequences, no collective)"},
+                       "nodes_per_seq": hp.n_nodes, "parallelism": f"dp{world} (independent sequences, no collective)",
+                       "total_loss_last_step": total_loss},
             "roofline": {"kernel": kern,
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),

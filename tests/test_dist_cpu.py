@@ -166,6 +166,75 @@ def test_two_rank_bucketed_gradient_exchange():
         assert torch.allclose(res[0][step], want, atol=1e-6)
 
 
+def _rebackward_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from video_gcp_amd import dist as D
+    from video_gcp_amd.model import _Plan
+    from video_gcp_amd.training import GCPTrainStep
+    D.init_from_env("gloo")
+    n = 1000
+    ranges = [("tree2", 700, 1000), ("tree1", 300, 700), ("rest", 0, 300)]
+    # GCPTrainStep's own exchange hooks (begin at the start of a backward, _on_mark at the plan's bucket marks, finish in front of the
+    # optimizer) around a stub backward: a launch plan whose "kernels" are host functions writing this rank's gradient slices in the
+    # order the real plan finishes them, with the real plan's marks in between
+    tr = GCPTrainStep.__new__(GCPTrainStep)
+    tr.grad = torch.zeros(n)
+    tr.buckets = D.GradBuckets(tr.grad, ranges, None)
+    tr._lane_streams = []                           # CPU tensors: no device streams to order the collective against
+    state = {}
+
+    def write(lo, hi, _stream):
+        tr.grad[lo:hi] = state["g"][lo:hi]
+        return 0
+    plan = _Plan.__new__(_Plan)
+    plan.lib, plan.ops, plan.keep, plan.lane = None, [], [], 0
+    plan.add("bw.zero", lambda _s: (tr.grad.zero_(), 0)[1])
+    for i, (_, lo, hi) in enumerate(ranges[:-1]):
+        plan.add(f"bw.level{i}", write, lo, hi)
+        plan.mark("bucket", i)
+    plan.add("bw.rest", write, 0, 300)
+    outs = []
+
+    def backward(seed):
+        tr.buckets.begin()                          # GCPTrainStep.backward's first action
+        state["g"] = torch.randn(n, generator=torch.Generator().manual_seed(seed))
+        plan.run([None], on_mark=tr._on_mark)
+    # a backward that is NOT followed by an optimizer step (gradient inspection), then a second one: the second pass's gradient must be
+    # exchanged in full — without begin() its marks found the first pass's works and skipped the tree buckets
+    backward(100 + rank)
+    backward(200 + rank)
+    scale = tr.buckets.finish()
+    outs.append((scale, tr.grad.clone()))
+    backward(300 + rank)
+    scale = tr.buckets.finish()
+    outs.append((scale, tr.grad.clone()))
+    q.put((rank, outs))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_exchange_rearms_every_backward():
+    """GCPTrainStep's exchange hooks (GradBuckets.begin / _on_mark / finish) around a stub backward plan, two gloo ranks: after two
+    backward passes with no optimizer step in between, the gradient handed to the optimizer is the cross-rank sum of the SECOND pass
+    for every bucket (round-2 advisor finding: stale works made the second pass skip the tree buckets)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rebackward_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for k, base in enumerate((200, 300)):
+        want = sum(torch.randn(1000, generator=torch.Generator().manual_seed(base + r)) for r in range(2))
+        assert res[0][k][0] == 0.5
+        assert torch.equal(res[0][k][1], res[1][k][1])
+        assert torch.allclose(res[0][k][1], want, atol=1e-6), k
+
+
 def test_bench_self_launches_ranks():
     """`python bench.py --gpus 2` with no launcher around it: the parent spawns one child per rank BEFORE touching a GPU, wires
     RANK / WORLD_SIZE / MASTER_*, relays rank 0's single JSON line and returns the children's status.  --launch-check runs the

@@ -135,6 +135,15 @@ def test_sampled_sequence_length_c1(feed_end_ind):
     torch.cuda.synchronize()
     e = out.end_ind.cpu()
     assert int(e.min()) >= 2 and int(e.max()) <= hp.max_seq_len - 1
+    # a loader that filled input_buffer('end_ind') in place (the zero-copy hand-over) keeps its ground-truth lengths: the draw goes
+    # to a buffer of its own (the reference's outputs.end_ind), it does not overwrite the input
+    gt = model.input_buffer("end_ind", (hp.batch_size,))
+    gt.copy_(inputs["end_ind"])
+    with model.val_mode():
+        out = model(dict({k: v.cuda() for k, v in plan_in.items()}, end_ind=gt, len_u=len_u.cuda()), "train")
+    torch.cuda.synchronize()
+    assert torch.equal(out.end_ind.cpu(), ref["end_ind"]) and out.end_ind.data_ptr() != gt.data_ptr()
+    assert torch.equal(gt.cpu(), inputs["end_ind"])
 
 
 def test_gaussian_decoder_c1():

@@ -216,3 +216,35 @@ def test_image_cem_policy_closed_loop(setup):
     policy.closed_loop_execution = False
     a = policy.act(t=3, i_tr=0, images=frames, goal_image=goal).actions
     assert np.array_equal(a, policy.action_plan[1])
+
+
+def test_hierarchical_planner_at_the_reference_control_shape():
+    """The reference's own control configuration (experiments/control/25room/gcp_tree/mod_hyper.py:34-71): 32 x 32 images,
+    max_seq_len 200, hierarchy_levels 8 (255 nodes), balanced binding, HierarchicalImageCEMPlanner with sampling rates [10, 10],
+    n_iters 3, batch_size 10, learned cost.  The device-resident search against the reference's data flow (numpy rollouts + the
+    optimizer class pinned to the reference's) on identical np.random draws: same per-iteration best costs, same optimised latent
+    tree, same plan; sample shapes per iteration as the reference produces them ([10, 255, D], [10, 255, D], [5, 255, D])."""
+    import video_gcp_amd as V
+    from video_gcp_amd.model import GCPTreeModel
+    from video_gcp_amd.planning import GCPImageSimulator, LearnedCostEstimate, HierarchicalCEMPlanner
+    hp = V.config("c1", max_seq_len=200, hierarchy_levels=8, batch_size=10)
+    assert hp.img_sz == 32 and hp.n_nodes == 255 and hp.nz_vae == 256 and hp.matching_type == "balanced"
+    model = GCPTreeModel(hp, params=V.init_params(hp, seed=3, randomize_affine=True), device="cuda")
+    model.eval()                                                         # planner_policy.py:51
+    state, goal = _env_images(hp, 5)
+    res = {}
+    for dev in (False, True):
+        np.random.seed(1)
+        planner = HierarchicalCEMPlanner(GCPImageSimulator(model, pred_length=False), LearnedCostEstimate(model), hp.hierarchy_levels, [10, 10],
+                                         action_dim=hp.nz_vae, max_seq_len=hp.max_seq_len, device_resident=dev)
+        shapes = []
+        sample0 = planner._sampler.sample
+        planner._sampler.sample = lambda *a, **k: (lambda s: (shapes.append(tuple(s.shape)), s)[1])(sample0(*a, **k))
+        plan, actions, latents, score = planner(state, goal)
+        assert planner.fully_optimized and np.isfinite(score)
+        assert shapes[:3] == [(10, 255, 256), (10, 255, 256), (5, 255, 256)], shapes[:4]
+        assert plan.shape[1] == 3 * 32 * 32 + hp.nz_enc and 3 <= plan.shape[0] <= hp.max_seq_len + 1
+        res[dev] = (plan, latents, score, [np.asarray(l.elite_scores, dtype=np.float32).reshape(-1) for l in planner.logs])
+    for a, b in zip(res[False][3], res[True][3]):
+        assert np.array_equal(a, b), (a, b)
+    assert np.array_equal(res[False][0], res[True][0]) and np.array_equal(res[False][1], res[True][1]) and res[False][2] == res[True][2]

@@ -136,3 +136,38 @@ def test_training_step_c2_shapes_runs_and_decreases_loss():
     assert all(torch.isfinite(torch.tensor(losses)))
     assert torch.isfinite(tr.grad).all()
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("name", ["c1", "c5s"])
+def test_bucket_marks_follow_every_write_of_their_slice(name):
+    """The data-parallel exchange starts a bucket's all-reduce at its `mark` in the backward plan (training.py: plan.mark("bucket", i)
+    behind the level's flush).  That is only right if NOTHING writes into the bucket's slice of the flat gradient after the mark: a late
+    write either races the collective or leaves a rank-local gradient that RAdam still scales by 1 / world.  The real backward plan of
+    GCPTrainStep is replayed eagerly with the mark hook taking a snapshot of the bucket's slice (after waiting for every lane); the
+    final gradient must equal the snapshots bit for bit.  c5s covers the attentive posterior, whose k_proj / v_proj weight gradients
+    were once issued after the tree loop, i.e. after their level's mark (round-2 advisor finding)."""
+    from video_gcp_amd.dist import gradient_bucket_ranges
+    hp, sd, model, tr = _setup(name, False)
+    ranges = gradient_bucket_ranges(model._poff, hp.hierarchy_levels, hp.untied_layers)
+    assert len(ranges) == hp.hierarchy_levels                   # one bucket per level L-1 .. 1, then the rest
+    tr._bucket_index = {n: i for i, (n, _, _) in enumerate(ranges)}      # what a process group switches on (training.py:53)
+    snaps = {}
+
+    def hook(tag, i):
+        assert tag == "bucket" and i not in snaps
+        torch.cuda.synchronize()
+        _, lo, hi = ranges[i]
+        snaps[i] = tr.grad[lo:hi].clone()
+    tr._on_mark = hook
+    inputs, noise, _ = make_inputs(hp, seed=11, variant="B")
+    tr.backward({k: v.cuda() for k, v in inputs.items()}, noise.cuda())
+    torch.cuda.synchronize()
+    assert sorted(snaps) == list(range(len(ranges) - 1)), sorted(snaps)      # every tree level's bucket was marked, in plan order
+    names = tr.named_grads()
+    for i, snap in snaps.items():
+        n, lo, hi = ranges[i]
+        assert float(snap.abs().max()) > 0, n
+        if not torch.equal(tr.grad[lo:hi], snap):
+            late = [k for k, (o, shp) in model._poff.items() if lo <= o < hi and
+                    not torch.equal(names[k].reshape(-1), snap[o - lo:o - lo + names[k].numel()])]
+            raise AssertionError(f"bucket {n}: written after its mark: {late[:8]}")

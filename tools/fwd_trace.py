@@ -3,8 +3,10 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-heads = [i for i, r in enumerate(rows) if 'conv3x3_head' in r['Kernel_Name']]
-# one forward = from the end of the previous head kernel to the end of the last one
+# one forward = from the end of the previous forward's last kernel (the loss combination when the forward computes its losses, else
+# the output head) to the end of the last one
+last = 'loss_combine' if any('loss_combine' in r['Kernel_Name'] for r in rows) else 'conv3x3_head'
+heads = [i for i, r in enumerate(rows) if last in r['Kernel_Name']]
 a, b = heads[-2], heads[-1]
 seg = rows[a + 1:b + 1]
 t0 = int(rows[a]['End_Timestamp'])

@@ -5,7 +5,7 @@
 # then tools/pmc_summary.py writes profiles/<round>_pmc_kernels.json and profiles/pmc_head_kernel.json.
 # Counters are collected with --kernel-trace only (never with --sys-trace / hip / hsa domains), the program sits right after `--`.
 set -u
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out
 export TMPDIR=/tmp
 PY=$(command -v python3)

@@ -53,7 +53,7 @@ def main():
         p = head[0]["pmc_mean_per_dispatch"]
         if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
             import bench
-            d = {"kernel_src_sha": bench.kernel_source_sha(), "sources": list(bench.HEAD_KERNEL_SOURCES), "batch": a.batch, "eval_bn": False,
+            d = {"kernel_src_sha": bench.kernel_source_sha(), "sources": list(bench.HEAD_KERNEL_SOURCES), "batch": a.batch, "eval_bn": False, "with_loss": True,
                  "FETCH_SIZE_KB": p["FETCH_SIZE"], "WRITE_SIZE_KB": p["WRITE_SIZE"],
                  "traffic_bytes_per_launch": int((2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024),
                  "rule": "FETCH_SIZE x 2 (gfx950 counts a wide coalesced read at half its bytes) + WRITE_SIZE, KB -> bytes",
