@@ -59,7 +59,12 @@ typedef enum gcpx_head_mode {
     GCPX_HEAD_RAW = 0,      /* store conv output NHWC [F][H][W][CT*16] (kernel channel order), + bias, + out_act */
     GCPX_HEAD_DLM_MEAN = 1, /* discrete-logistic-mixture mean -> images NCHW [F][3][H][W]; nothing else written */
     GCPX_HEAD_DLM_BOTH = 2, /* both of the above */
-    GCPX_HEAD_TANH_NCHW = 3 /* gaussian head: tanh(first 3 channels) -> images NCHW */
+    GCPX_HEAD_TANH_NCHW = 3, /* gaussian head: tanh(first 3 channels) -> images NCHW */
+    GCPX_HEAD_DLM_NLL = 4   /* mixture mean -> images, and for every frame f with raw_row_map[f] >= 0 the discretised-logistic-mixture
+                               negative log-likelihood of target row raw_row_map[f] (decoder.nll on the matched frames,
+                               frame_binding.py:88-99), evaluated in the epilogue: nll_partial[i][row] = sum over the pixels of item i
+                               (4 rows x 16 columns; (H / 4) * (W / 16) items per frame) — reduce over i with gcpx_reduce_partials.
+                               No raw parameters are stored.  Split-f16 head only (wpk_split set) */
 } gcpx_head_mode;
 
 typedef struct gcpx_conv_args {
@@ -99,7 +104,9 @@ typedef struct gcpx_conv_args {
     int32_t split_layout;   /* layout of wpk_split: GCPX_SPLIT_PLAIN (the conv's own 3x3 taps) or GCPX_SPLIT_ROWFOLD (upsampling blocks
                                with 32 -> 16 channels: the vertical half of the bilinear x2 folded into the weights, see
                                gcpx_fold_upsample_weights) */
-    int32_t _pad2;
+    int32_t nll_rows;       /* GCPX_HEAD_DLM_NLL: rows of nll_target / row pitch of nll_partial */
+    const float* nll_target; /* dev: NCHW [nll_rows][3][H][W] ground-truth frames in [-1, 1] (traj_seq) */
+    float* nll_partial;     /* dev: [(H / 4) * (W / 16)][nll_rows]; rows no frame maps to are not written */
 } gcpx_conv_args;
 
 typedef enum gcpx_split_layout { GCPX_SPLIT_PLAIN = 0, GCPX_SPLIT_ROWFOLD = 1 } gcpx_split_layout;
@@ -506,6 +513,10 @@ int gcpx_lrelu_bwd(const float* a, const float* dy, float* dx, int64_t n, float 
 /* d KL(q||p) (inference.py:38-43): writes d q / d p rows ([mu | log_sigma]) at the same addresses as qz / pz rows */
 int gcpx_kl_bwd(const float* qz, const float* pz, float* dqz, float* dpz, int32_t B, int32_t N, int32_t nz, int64_t batch_stride,
                 int64_t node_stride, float free_nats, float coef, void* stream);
+/* the same with a per-node weight (the flat VRNN's KL term carries pad_mask[:, 1:], sequential.py:63-66):
+   gradient rows scaled by node_weight[b * weight_bstride + n] */
+int gcpx_kl_bwd_weighted(const float* qz, const float* pz, float* dqz, float* dpz, int32_t B, int32_t N, int32_t nz, int64_t batch_stride,
+                         int64_t node_stride, float free_nats, float coef, const float* node_weight, int64_t weight_bstride, void* stream);
 /* one tree level: dq_out[r] = dqz_pos[r] + [dz, dz * exp(log_sigma_q) * eps] (reparametrised sample backward,
    tree_module.py:86-94), dp_out[r] = dpz_pos[r]; rows r = (b, j) of the level; *_pos at base + b*pb + j*prow;
    dz = dz0[r*ldz0 ..] (+ dz1[r*ldz1 ..]); eps at eps + b*eb + j*erow */
@@ -538,6 +549,11 @@ int gcpx_timestep_scatter(const float* det, int64_t db, int64_t dp, const int32_
 /* dst row (b, j) at dst + b*dst_sb + j*dst_sr  +=  src1[r] (+ src2[r]), dense sources [B*rpb][width] */
 int gcpx_add_rows(float* dst, int64_t dst_sb, int64_t dst_sr, const float* src1, const float* src2, int32_t B, int32_t rpb,
                   int32_t width, void* stream);
+/* rows (b, j), j < rpb, of `width` floats between two strided layouts (row at base + b*sb + j*sr): mode 0 dst = src, 1 dst += src,
+   2 dst[b] += sum over j of src[b][j] (dst_sr unused; fixed summation order).  Gradient bookkeeping of the recurrent rollout
+   (sequential.py:49-54 backward): x_t / context slices of the per-step embedding gradients */
+int gcpx_rows_strided(float* dst, int64_t dst_sb, int64_t dst_sr, const float* src, int64_t src_sb, int64_t src_sr, int32_t B, int32_t rpb,
+                      int32_t width, int32_t mode, void* stream);
 /* out[b][t] = idx[b][t] + b*stride (per-sequence node index -> absolute frame index) */
 int gcpx_index_offset(const int32_t* idx, int32_t* out, int32_t B, int32_t T, int32_t stride, void* stream);
 /* inv[r] = i for every i < n with fwd[i] = r >= 0 (fwd injective on its non-negative entries), -1 for rows nobody maps to:

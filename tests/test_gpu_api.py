@@ -175,10 +175,20 @@ def test_decoder_nll_and_binding_handles(setup):
     inputs, noise, _ = make_inputs(hp, seed=12, variant="B")
     dev_in = {k: v.cuda() for k, v in inputs.items()}
     out = model(dev_in, "train", noise=noise.cuda())
-    losses = model.loss(dev_in, out)
-    got = model.decoder.nll(out.raw["matched_distr_kernel_order"], dev_in["traj_seq"], dev_in["pad_mask"], log_error_arr=True)
-    torch.cuda.synchronize()
+    fused = float(model.loss(dev_in, out).dense_img_rec.value)          # likelihood evaluated inside the head kernel
+    assert out.raw["matched_distr_kernel_order"] is None                 # ... so the matched parameters are not kept
+    model.fused_head_nll = False                                          # the stored-parameters forward (what the trainer runs)
+    model._clear_plans()
+    try:
+        out = model(dev_in, "train", noise=noise.cuda())
+        losses = model.loss(dev_in, out)
+        got = model.decoder.nll(out.raw["matched_distr_kernel_order"], dev_in["traj_seq"], dev_in["pad_mask"], log_error_arr=True)
+        torch.cuda.synchronize()
+    finally:
+        model.fused_head_nll = True
+        model._clear_plans()
     assert abs(float(got.dense_img_rec.value) - float(losses.dense_img_rec.value)) <= 1e-6 * abs(float(losses.dense_img_rec.value))
+    assert abs(fused - float(losses.dense_img_rec.value)) <= 1e-5 * abs(fused)
     assert got.dense_img_rec.error_mat.shape == (hp.batch_size, hp.max_seq_len)
     model.eval()
     lo, hi = model.tree_module.binding.get_init_inds(out)

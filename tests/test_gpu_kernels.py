@@ -393,6 +393,69 @@ def test_conv3x3_head_dlm(env, S, Fr, split):
     assert torch.equal(img2, img)
 
 
+@pytest.mark.parametrize("case", ["plain", "edges"])
+def test_conv3x3_head_fused_likelihood(env, case):
+    """GCPX_HEAD_DLM_NLL: the split-f16 head evaluates decoder.nll of the frames matched to a ground-truth frame in its epilogue
+    (frame_binding.py:88-99) instead of storing their 100 parameters per pixel for gcpx_dlm_nll.  Checked per frame against (1) the
+    stored-parameters path (GCPX_HEAD_DLM_BOTH + gcpx_dlm_nll: same formulas, same fast-math helpers) and (2) the oracle's likelihood
+    of a float64 conv.  `edges`: saturated target pixels (x = -1 / +1 take the one-sided branches), log-scales below the -7 clamp and
+    bins whose probability vanishes (the log-pdf branch); frame 1 has no matched row and must not be written."""
+    rt, pk, lib, dev = env
+    from oracle import gcp_model_oracle as O
+    from video_gcp_amd import config
+    hp = config("c1")
+    torch.manual_seed(5)
+    S, Fr = 64, 3
+    x = torch.randn(Fr, 16, S, S)
+    sc, sh = torch.rand(16) + 0.5, torch.randn(16) * 0.2
+    xin = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)
+    w, b = torch.randn(100, 16, 3, 3) / 12.0, torch.randn(100) * 0.1
+    tgt = torch.rand(2, 3, S, S) * 2 - 1                          # rows of the target tensor: row 0 <- frame 2, row 1 <- frame 0
+    if case == "edges":
+        b[20:30] -= 4.0                                           # log_scale_r around -4: narrow bins, some vanish
+        b[50:60] -= 9.0                                           # log_scale_g below the clamp
+        tgt[0, :, :8] = -1.0
+        tgt[1, :, 8:16] = 1.0
+        tgt[0, 1, 30:34] = 0.9995
+    head = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
+    want = torch.stack([O.dlm_nll(head[[2]], tgt[[0]].double(), hp)[0].sum(), O.dlm_nll(head[[0]], tgt[[1]].double(), hp)[0].sum()])
+    perm = pk.dlm_channel_perm(10)
+    permt = torch.tensor(perm)
+    wp = pk.pack_dlm_head(w, perm).to(dev)
+    ws, e = pk.pack_conv3x3_split(w, perm)
+    ws = ws.to(dev)
+    bk = torch.zeros(len(perm))
+    bk[permt >= 0] = b[permt[permt >= 0]]
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    rows = torch.tensor([1, -1, 0], dtype=torch.int32, device=dev)
+    td = tgt.to(dev)
+    nit = (S // 4) * (S // 16)
+    part = torch.full((nit, 2), float("nan"), device=dev)
+    img = torch.full((Fr, 3, S, S), float("nan"), device=dev)
+    a = _conv_args(rt, [(xd, 16, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=S, Win=S, Hout=S, Wout=S, Cout=100,
+                   out_pitch=len(perm), upsample=0, head_mode=rt.HEAD_DLM_NLL, wpk=wp, bias=bk.to(dev), out=None, images=img)
+    a.raw_row_map, a.wpk_split, a.w_split_log2 = rows.data_ptr(), ws.data_ptr(), e
+    a.nll_target, a.nll_partial, a.nll_rows = td.data_ptr(), part.data_ptr(), 2
+    rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head nll")
+    got = torch.empty(2, device=dev)
+    rt.check(lib.gcpx_reduce_partials(part.data_ptr(), nit, 2, 2, got.data_ptr(), 0, _stream()), "reduce")
+    # the stored-parameters path
+    raw = torch.full((2, S, S, len(perm)), float("nan"), device=dev)
+    img2 = torch.full((Fr, 3, S, S), float("nan"), device=dev)
+    a.head_mode, a.out, a.images = rt.HEAD_DLM_BOTH, raw.data_ptr(), img2.data_ptr()
+    rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head both")
+    ref = torch.empty(2, device=dev)
+    rt.check(lib.gcpx_dlm_nll(raw.data_ptr(), td.data_ptr(), None, ref.data_ptr(), 2, S * S, len(perm), 10, _stream()), "dlm_nll")
+    torch.cuda.synchronize()
+    assert torch.isfinite(part).all()
+    assert_close(img, img2, atol=2e-6, name="mixture mean, likelihood variant vs stored-parameters variant")   # (two instantiations: the compiler contracts them differently)
+    assert_close(got, ref, atol=0, rtol=1e-5, name="fused vs stored-parameters likelihood")
+    assert_close(got.double().cpu(), want, atol=0, rtol=(1e-4 if case == "edges" else 2e-5), name="fused likelihood vs float64 oracle")
+    # without wpk_split the mode is refused (the exact-f32 head keeps the stored-parameters path)
+    a.head_mode, a.out, a.wpk_split = rt.HEAD_DLM_NLL, None, None
+    assert lib.gcpx_conv3x3(C.byref(a), _stream()) != 0
+
+
 @pytest.mark.parametrize("case", ["unit", "tiny", "large", "outlier", "zero", "matched_rows"])
 def test_conv3x3_head_split_error_vs_float64(env, case):
     """The split-f16 head against a float64 conv of the same f32 inputs, next to the exact f32 MFMA kernel: its error is of the same

@@ -42,9 +42,14 @@ def test_dlm_perm_is_a_partial_permutation():
     # slot 8k..8k+7 = logit_k, mean_{r,g,b}, coeff_{0,1,2}, log_scale_r; then log_scale_g, log_scale_b; 12 empty slots
     k = 3
     assert perm[8 * k:8 * k + 8] == [k, 10 + k, 40 + k, 70 + k, 30 + k, 60 + k, 90 + k, 20 + k]
-    assert perm[80 + k] == 50 + k and perm[90 + k] == 80 + k and perm[100:] == [-1] * 12
-    for c in range(3):
-        assert perm[pk.dlm_log_scale_slot(c, k)] == 10 + 30 * c + 10 + k
+    assert perm[100:] == [-1] * 12
+    for kk in range(10):
+        for c in range(3):
+            assert perm[pk.dlm_log_scale_slot(c, kk)] == 10 + 30 * c + 10 + kk
+    # green / blue log-scales of mixture 2 ct + h: channel tile 5, lane group 2 h + (ct >> 1), register pair ct & 1 (the lane that
+    # evaluates the mixture in the head kernel's fused likelihood finds them after one row swap); mixtures 8, 9 = the 4-slot remainder
+    assert [pk.dlm_log_scale_slot(1, kk) for kk in range(10)] == [80, 88, 82, 90, 84, 92, 86, 94, 96, 98]
+    assert [pk.dlm_log_scale_slot(2, kk) for kk in range(10)] == [81, 89, 83, 91, 85, 93, 87, 95, 97, 99]
 
 
 def test_pack_dlm_head_remainder_tile():

@@ -140,7 +140,8 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
 __global__ void __launch_bounds__(256) kl_bwd_kernel(const float* __restrict__ qz, const float* __restrict__ pz,
                                                      float* __restrict__ dqz, float* __restrict__ dpz, const int N, const int nz,
                                                      const long long batch_stride, const long long node_stride,
-                                                     const float free_nats, const float coef, const int total) {
+                                                     const float free_nats, const float coef, const int total,
+                                                     const float* __restrict__ node_weight, const long long weight_bstride) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int d = idx % nz, n = (idx / nz) % N, b = idx / (nz * N);
@@ -149,7 +150,8 @@ __global__ void __launch_bounds__(256) kl_bwd_kernel(const float* __restrict__ q
     const float diff = mq - mp;
     const float e2q = expf(2.f * lq), ie2p = expf(-2.f * lp);
     const float kl = lp - lq + (e2q + diff * diff) * 0.5f * ie2p - 0.5f;
-    const float g = kl > free_nats ? coef : 0.f;        // clamp(min=free_nats): no gradient below the floor
+    const float wgt = node_weight ? node_weight[(size_t)b * weight_bstride + n] : 1.f;
+    const float g = kl > free_nats ? coef * wgt : 0.f;  // clamp(min=free_nats): no gradient below the floor
     dqz[o + d] = g * diff * ie2p;
     dpz[o + d] = -g * diff * ie2p;
     dqz[o + nz + d] = g * (e2q * ie2p - 1.f);
@@ -219,6 +221,27 @@ __global__ void __launch_bounds__(256) add_rows_kernel(float* __restrict__ dst, 
     float v = src1[idx];
     if (src2) v += src2[idx];
     dst[(size_t)b * dst_sb + (size_t)j * dst_sr + c] += v;
+}
+
+// rows (b, j) of `width` floats between two strided layouts.  mode 0: dst = src; 1: dst += src; 2: dst[b] += sum over j of src[b][j]
+// (dst_sr unused; the sum runs over j in order: deterministic)
+__global__ void __launch_bounds__(256) rows_strided_kernel(float* __restrict__ dst, const long long dst_sb, const long long dst_sr,
+                                                           const float* __restrict__ src, const long long src_sb, const long long src_sr,
+                                                           const int rpb, const int width, const int mode, const int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % width, r = idx / width;
+    if (mode == 2) {
+        const float* sp = src + (size_t)r * src_sb + c;
+        float v = 0.f;
+        for (int j = 0; j < rpb; ++j) v += sp[(size_t)j * src_sr];
+        dst[(size_t)r * dst_sb + c] += v;
+        return;
+    }
+    const int b = r / rpb, j = r % rpb;
+    const float v = src[(size_t)b * src_sb + (size_t)j * src_sr + c];
+    float* d = dst + (size_t)b * dst_sb + (size_t)j * dst_sr + c;
+    *d = mode == 1 ? *d + v : v;
 }
 
 __global__ void __launch_bounds__(256) index_offset_kernel(const int* __restrict__ idx, int* __restrict__ out, const int T,
@@ -570,7 +593,7 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
             float s = m[0] - lse_logits;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float raw = pp[c == 0 ? 8 * k + 7 : 70 + 10 * c + k];     // packing.dlm_log_scale_slot
+                const float raw = pp[dlm_ls_slot(c, k)];     // packing.dlm_log_scale_slot
                 const float ls = fmaxf(raw, -7.f);
                 const float xc = x[c] - mean[c];
                 const float inv = __expf(-ls);
@@ -631,7 +654,7 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
             m[5] = gw * gm[nk][2] * xr * (1.f - cf[nk][1] * cf[nk][1]);
             m[6] = gw * gm[nk][2] * xg * (1.f - cf[nk][2] * cf[nk][2]);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) pp[c == 0 ? 8 * k + 7 : 70 + 10 * c + k] = gw * gs[nk][c];
+            for (int c = 0; c < 3; ++c) pp[dlm_ls_slot(c, k)] = gw * gs[nk][c];
         }
         if (q == 0)
             for (int s = 80 + 2 * NMIX; s < PITCH; ++s) pp[s] = 0.f;
@@ -846,7 +869,30 @@ extern "C" int gcpx_kl_bwd(const float* qz, const float* pz, float* dqz, float* 
     GCPX_CHECK_ARG(qz && pz && dqz && dpz && B > 0 && N > 0 && nz > 0, "bad arguments");
     const int total = B * N * nz;
     hipLaunchKernelGGL(kl_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, qz, pz, dqz, dpz, N, nz,
-                       (long long)batch_stride, (long long)node_stride, free_nats, coef, total);
+                       (long long)batch_stride, (long long)node_stride, free_nats, coef, total, (const float*)nullptr, 0ll);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_kl_bwd_weighted(const float* qz, const float* pz, float* dqz, float* dpz, int32_t B, int32_t N, int32_t nz,
+                                    int64_t batch_stride, int64_t node_stride, float free_nats, float coef, const float* node_weight,
+                                    int64_t weight_bstride, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(qz && pz && dqz && dpz && node_weight && B > 0 && N > 0 && nz > 0, "bad arguments");
+    const int total = B * N * nz;
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, qz, pz, dqz, dpz, N, nz,
+                       (long long)batch_stride, (long long)node_stride, free_nats, coef, total, node_weight, (long long)weight_bstride);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_rows_strided(float* dst, int64_t dst_sb, int64_t dst_sr, const float* src, int64_t src_sb, int64_t src_sr, int32_t B,
+                                 int32_t rpb, int32_t width, int32_t mode, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(dst && src && B > 0 && rpb > 0 && width > 0 && mode >= 0 && mode <= 2, "bad arguments");
+    const int total = (mode == 2 ? B : B * rpb) * width;
+    hipLaunchKernelGGL(rows_strided_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, dst, (long long)dst_sb, (long long)dst_sr, src,
+                       (long long)src_sb, (long long)src_sr, rpb, width, mode, total);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -49,6 +49,13 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// slot of log_scale_{c,k} in the 112-slot layout of the discrete-logistic-mixture head (video-gcp_amd/packing.py:dlm_log_scale_slot;
+// c = 0: red, inside mixture k's 8-slot group; c = 1, 2: green / blue, slots 80..99 arranged for the head kernel's fused likelihood)
+__host__ __device__ __forceinline__ constexpr int dlm_ls_slot(const int c, const int k) {
+    return c == 0 ? 8 * k + 7
+                  : (k >= 8 ? 96 + 2 * (k - 8) + (c - 1) : 80 + 4 * (2 * (k & 1) + (k >> 2)) + 2 * ((k >> 1) & 1) + (c - 1));
+}
+
 void gcpx_set_error(const char* fmt, ...);
 #define GCPX_CHECK_ARG(cond, msg)                         \
     do {                                                  \

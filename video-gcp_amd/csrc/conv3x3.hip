@@ -1268,6 +1268,7 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
             // 100-channel mixture head: 6 full tiles + the 4-channel remainder (weights packed by packing.pack_dlm_head)
             if (a->Cout == 100) {
                 GCPX_CHECK_ARG(!need_out || a->out_pitch >= 100, "mixture head: out_pitch < 100");
+                GCPX_CHECK_ARG(a->head_mode != GCPX_HEAD_DLM_NLL || a->wpk_split, "GCPX_HEAD_DLM_NLL is built for the split-f16 head (wpk_split)");
                 if (a->wpk_split) return query_only ? gcpx_conv_grid() / 2 : gcpx_launch_head_split(a, stream);
                 return query_only ? gcpx_conv_grid() / 2 : launch_head<6, true>(a, stream);
             }

@@ -55,6 +55,8 @@ struct SplitHeadCfg {
     static constexpr int W_BYTES = KS * CT * 2 * 1024;                     // 71680 B
     static constexpr int BIAS_BYTES = CT * 16 * 4;                          // bias of the 112 channel slots
     static constexpr int LDS_BYTES = W_BYTES + 8 * REGION_BYTES + BIAS_BYTES;
+    static constexpr int STASH_BYTES = 16 * 64 * 4;                        // fused likelihood: 16 floats per lane parked during pass A
+    static constexpr int LDS_BYTES_NLL = LDS_BYTES + 8 * STASH_BYTES;     // 160192 of the 163840 B of a CU
     static constexpr int NS = (RH * RW * 4 + 63) / 64;                     // float4 staging slots per lane
 };
 
@@ -138,6 +140,14 @@ __device__ __forceinline__ void finish_tiles(const gcpx_conv_args& a, const floa
     }
 }
 
+// hardware exp / log / reciprocal forms for the fused mixture likelihood (same helpers as csrc/loss.hip)
+__device__ __forceinline__ float sigmoid_fast_s(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float softplus_s(float x) { return x > 20.f ? x : __logf(1.f + __expf(x)); }
+
+// NLL: head mode GCPX_HEAD_DLM_NLL — frames matched to a ground-truth frame (raw_row_map entry >= 0) additionally evaluate the
+// discretised-logistic-mixture likelihood of that frame in the epilogue and write one partial sum per item
+// (nll_partial[item of the frame][row]); their raw parameters are never stored (frame_binding.py:88-99 -> decoder.nll).
+template <bool NLL>
 __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_conv_args a, const int items_per_wave,
                                                                     const int nitems) {
     using Cfg = SplitHeadCfg;
@@ -175,8 +185,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
     const float slope = sr.act == GCPX_ACT_LRELU ? 0.2f : 1.f;
 
     const int gw = blockIdx.x * 8 + wave;
-    int item = gw * items_per_wave;
-    const int item_end = min(item + items_per_wave, nitems);
+    // NLL: matched frames cost ~1.6x an unmatched one (two more channel tiles + the likelihood), and a contiguous range of items is
+    // about ONE frame — so the items are dealt round-robin over the wavefronts (every wavefront sees the same mix; the eight
+    // wavefronts of a workgroup still work on eight neighbouring items at a time)
+    const int istep = NLL ? (int)gridDim.x * 8 : 1;
+    int item = NLL ? gw : gw * items_per_wave;
+    const int item_end = NLL ? nitems : min(item + items_per_wave, nitems);
 
     float4 pre[NS];
     unsigned pre_ok = 0;
@@ -202,7 +216,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
         for (int k = 0; k < NS; ++k) {
             pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int idx = lane + 64 * k;
-            const int sy = y0 - 1 + (s_rc[k] >> 8), sx = x0 - 1 + (s_rc[k] & 255);
+            // (NLL variant: the seven slot constants are recomputed — six VALU operations each — instead of held in registers: at the
+            // 256-register limit they were the values the compiler spilled, and a scratch reload inside this batch of loads waits for
+            // every load issued before it)
+            int t_ = idx >> 2;
+            if constexpr (NLL) asm volatile("" : "+v"(t_));      // (opaque to the optimiser: otherwise the quotients are hoisted out of the item loop and spilled again)
+            const int rc = NLL ? (((t_ / RW) << 8) | (t_ % RW)) : s_rc[k];
+            const int sy = y0 - 1 + (rc >> 8), sx = x0 - 1 + (rc & 255);
             if (idx < RH * RW * 4 && sy >= 0 && sy < H && sx >= 0 && sx < W) {
                 pre[k] = *reinterpret_cast<const float4*>(base + (unsigned)((__umul24(sy, W) + sx) * 16 + (idx & 3) * 4));
                 pre_ok |= 1u << k;
@@ -229,7 +249,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
         }
     };
 
-    for (; item < item_end; ++item) {
+    for (; item < item_end; item += istep) {
         int f, y0, x0;
         origin(item, f, y0, x0);
         const int orow = __builtin_amdgcn_readfirstlane(pre_orow);
@@ -268,19 +288,57 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
         }
         flush_images();
         pend_ip = nullptr;
-        if (item + 1 < item_end) issue_loads(item + 1);        // in flight during this item's MFMAs
+        if (item + istep < item_end) issue_loads(item + istep);        // in flight during this item's MFMAs
 
         const int mode = a.head_mode;
         const size_t plane = (size_t)H * W;
         const bool store_raw = (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) && orow >= 0;
         const float inv = __uint_as_float((unsigned)(127 - ex - ew) << 23);      // undoes the two power-of-two scales (exact)
 
+        // ---- fused likelihood, first half: the target pixels and the green / blue log-scales (channel tiles 5, 6) ----
+        // A lane of the epilogue below owns pixel (row s2 + 2 (q & 1), column j) and mixtures 2 ct + (q >> 1), ct = 0..4.
+        const bool want_nll = NLL && orow >= 0;
+        // (the kernel sits at the 256-register limit of two wavefronts per SIMD: of the 20 log-scales a lane needs after pass A, 16
+        // wait in a wave-private LDS stash and 4 in registers — 22 spilled registers otherwise, and every scratch reload waits for all
+        // loads in flight, the next item's prefetch included)
+        float4* stash = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem4) + Cfg::LDS_BYTES + wave * Cfg::STASH_BYTES) + lane;
+        float ls4[2][2];
+        if (want_nll) {
+            f32x4 accb[2][4];
+            mfma_tiles<5, 2>(wl, reg, tapoff, lane, accb);
+            finish_tiles<5, 2>(a, bias_l, accb, inv, false, orow, y0, x0, j, q);
+            // the same row swap as for tiles 0..4 below: afterwards accb[c][s2] holds lane group q' = 2 (q >> 1) and accb[c][s2 + 2]
+            // lane group q' + 1 of THIS lane's pixel.  Slot layout of tiles 5, 6: packing.dlm_log_scale_slot
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(accb[c][s2][r]), __float_as_uint(accb[c][s2 + 2][r]), false, false);
+                        accb[c][s2][r] = __uint_as_float(sw[0]);
+                        accb[c][s2 + 2][r] = __uint_as_float(sw[1]);
+                    }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const f32x4 e5 = accb[0][s2], o5 = accb[0][s2 + 2], e6 = accb[1][s2];
+                // {ls_g, ls_b} of ct = 0, 1 (e5) and ct = 2, 3 (o5) of this lane's mixtures: to the stash
+                stash[(2 * s2) * 64] = make_float4(e5[0], e5[1], e5[2], e5[3]);
+                stash[(2 * s2 + 1) * 64] = make_float4(o5[0], o5[1], o5[2], o5[3]);
+                // mixtures 8, 9 sit in lane group 0 of tile 6 (slots 96..99): the odd half (q >= 2) takes registers 2, 3 of its partner lane
+                const float g9 = __shfl_xor(e6[2], 32), b9 = __shfl_xor(e6[3], 32);
+                ls4[s2][0] = q < 2 ? e6[0] : g9;
+                ls4[s2][1] = q < 2 ? e6[1] : b9;
+            }
+        }
+
+        float nll_item = 0.f;
         // ---- pass A: channel tiles 0..4 = the 80 slots the mixture mean reads ----
         {
             f32x4 acc[5][4];
             mfma_tiles<0, 5>(wl, reg, tapoff, lane, acc);
             finish_tiles<0, 5>(a, bias_l, acc, inv, store_raw, orow, y0, x0, j, q);
-            if (mode == GCPX_HEAD_DLM_MEAN || mode == GCPX_HEAD_DLM_BOTH) {
+            if (mode == GCPX_HEAD_DLM_MEAN || mode == GCPX_HEAD_DLM_BOTH || mode == GCPX_HEAD_DLM_NLL) {
                 // kernel channel order and the lane exchange: see conv3x3_head_kernel (conv3x3.hip)
 #pragma unroll
                 for (int ct = 0; ct < 5; ++ct)
@@ -321,7 +379,59 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                     pend[s2][1] = fminf(fmaxf(Sg * invS, -1.f), 1.f);
                     pend[s2][2] = fminf(fmaxf(Sb * invS, -1.f), 1.f);
                     if (s2 == 0 && q < 2) pend_ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + 2 * q) * W + (x0 + j);   // row pt = s2 + 2 q
+                    if (want_nll) {
+                        // ---- fused likelihood, second half (the formulas of dlm_nll_kernel, csrc/loss.hip): this lane's five mixtures of
+                        // its pixel, the other five in lane ^ 32; m / S above are the max / sum of exp over all ten logits
+                        const float lse_logits = m + __logf(S);
+                        const float* tp = a.nll_target + (size_t)orow * 3 * plane + (size_t)(y0 + s2 + 2 * (q & 1)) * W + (x0 + j);
+                        const float xr = tp[0], xg = tp[plane], xb = tp[2 * plane];
+                        const float4 st0 = stash[(2 * s2) * 64], st1 = stash[(2 * s2 + 1) * 64];
+                        const float lsg[5] = {st0.x, st0.z, st1.x, st1.z, ls4[s2][0]}, lsb[5] = {st0.y, st0.w, st1.y, st1.w, ls4[s2][1]};
+                        float lp[5];
+#pragma unroll
+                        for (int ct = 0; ct < 5; ++ct) {
+                            const f32x4 e = acc[ct][s2], o = acc[ct][s2 + 2];
+                            const float c0 = fast_tanh_s(o[0]), c1 = fast_tanh_s(o[1]), c2 = fast_tanh_s(o[2]);
+                            const float mean[3] = {e[1], e[2] + c0 * xr, e[3] + c1 * xr + c2 * xg};
+                            const float x[3] = {xr, xg, xb};
+                            const float lsr[3] = {o[3], lsg[ct], lsb[ct]};
+                            float sacc = e[0] - lse_logits;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const float ls = fmaxf(lsr[c], -7.f);
+                                const float xc = x[c] - mean[c];
+                                const float is = __expf(-ls);
+                                const float plus_in = is * (xc + 1.f / 255.f), min_in = is * (xc - 1.f / 255.f);
+                                const float cdf_delta = sigmoid_fast_s(plus_in) - sigmoid_fast_s(min_in);
+                                float v = __logf(fmaxf(cdf_delta, 1e-12f));
+                                const bool edge = x[c] < -0.999f || x[c] > 0.999f || !(cdf_delta > 1e-5f);
+                                if (__any(edge)) {              // saturated pixels / vanishing bins: rare, evaluated only when some lane needs them
+                                    const float mid_in = is * xc;
+                                    if (x[c] < -0.999f) v = plus_in - softplus_s(plus_in);
+                                    else if (x[c] > 0.999f) v = -softplus_s(min_in);
+                                    else if (!(cdf_delta > 1e-5f)) v = mid_in - ls - 2.f * softplus_s(mid_in) - 4.8481163864f;   // log(127.5)
+                                }
+                                sacc += v;
+                            }
+                            lp[ct] = sacc;
+                        }
+                        float mx = fmaxf(fmaxf(fmaxf(lp[0], lp[1]), fmaxf(lp[2], lp[3])), lp[4]);
+                        mx = fmaxf(mx, __shfl_xor(mx, 32));
+                        float se = 0.f;
+#pragma unroll
+                        for (int ct = 0; ct < 5; ++ct) se += __expf(lp[ct] - mx);
+                        se += __shfl_xor(se, 32);
+                        nll_item -= mx + __logf(se);          // (both lanes of a pixel hold it; only q < 2 is summed below)
+                    }
                 }
+            }
+            if (want_nll) {
+                // the item's 64 pixels: lanes q = 0, 1 (16 columns each), two rows s2 per lane -> one value per item
+                float v = q < 2 ? nll_item : 0.f;
+                v = row16_sum(v);
+                v += __shfl_xor(v, 16);
+                const int it_in_f = (y0 >> 2) * ncb + (x0 >> 4);
+                if (lane == 0) a.nll_partial[(size_t)it_in_f * a.nll_rows + orow] = v;
             }
         }
         // ---- pass B: channel tiles 5, 6 = slots 80..99 (+ 12 empty): only ever stored raw, so only computed when that is asked for ----
@@ -1409,13 +1519,22 @@ __global__ void __launch_bounds__(256) fold_up_weights_kernel(const float* __res
 // Called by conv3x3_dispatch (conv3x3.hip) for the 100-channel mixture head when the caller supplies split-f16 weights.
 int gcpx_launch_head_split(const gcpx_conv_args* a, hipStream_t stream) {
     using Cfg = SplitHeadCfg;
-    auto kern = conv3x3_head_split_kernel;
+    const bool nll = a->head_mode == GCPX_HEAD_DLM_NLL;
+    if (nll) {
+        GCPX_CHECK_ARG(a->nll_target && a->nll_partial && a->nll_rows > 0 && a->raw_row_map, "GCPX_HEAD_DLM_NLL needs nll_target, nll_partial, nll_rows and raw_row_map");
+        GCPX_CHECK_ARG(a->out_pitch == 112, "the fused likelihood is written for the 112-slot layout of the 10-mixture head");
+    }
+    auto kern = nll ? conv3x3_head_split_kernel<true> : conv3x3_head_split_kernel<false>;
+    const int lds = nll ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) {
-            gcpx_set_error("conv3x3 split head: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
-            return GCPX_ERR_HIP;
+        const void* ks[2] = {reinterpret_cast<const void*>(conv3x3_head_split_kernel<false>), reinterpret_cast<const void*>(conv3x3_head_split_kernel<true>)};
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, i ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES);
+            if (e != hipSuccess) {
+                gcpx_set_error("conv3x3 split head: hipFuncSetAttribute(%d B LDS): %s", i ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES, hipGetErrorString(e));
+                return GCPX_ERR_HIP;
+            }
         }
         attr_set = true;
     }
@@ -1423,7 +1542,7 @@ int gcpx_launch_head_split(const gcpx_conv_args* a, hipStream_t stream) {
     int grid = gcpx_conv_grid() / 2;
     if (grid * 8 > nitems) grid = (nitems + 7) / 8;
     const int ipw = (nitems + grid * 8 - 1) / (grid * 8);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, stream, *a, ipw, nitems);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, ipw, nitems);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -21,7 +21,7 @@ __device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __frcp_
 // ---------------------------------------------------------------------------------------------------
 // discretised-logistic-mixture NLL of one frame per workgroup.
 // params: [rows][H*W][pitch] in the head kernel's channel order (packing.dlm_channel_perm):
-//   slot 8k..8k+7 = logit_k, mean_r, mean_g, mean_b, coeff0, coeff1, coeff2, log_scale_{r,k} ; slot 70 + 10c + k = log_scale_{c,k}, c = 1, 2
+//   slot 8k..8k+7 = logit_k, mean_r, mean_g, mean_b, coeff0, coeff1, coeff2, log_scale_{r,k} ; slot dlm_ls_slot(c, k) (80..99, common.h) = log_scale_{c,k}, c = 1, 2
 // A wavefront stages 16 pixels x pitch floats in LDS with coalesced 16-byte loads; lane (j = pixel, q) evaluates
 // mixtures q, q+4, q+8 and the 4-lane column combines them with a logsumexp.
 // ---------------------------------------------------------------------------------------------------
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) dlm_nll_kernel(const float* __restrict__ 
                 float s = m[0] - lse_logits;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float ls = fmaxf(pp[c == 0 ? 8 * k + 7 : 70 + 10 * c + k], -7.f);
+                    const float ls = fmaxf(pp[dlm_ls_slot(c, k)], -7.f);
                     const float xc = x[c] - mean[c];
                     const float inv = __expf(-ls);
                     const float plus_in = inv * (xc + 1.f / 255.f), min_in = inv * (xc - 1.f / 255.f);

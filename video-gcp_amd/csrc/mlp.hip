@@ -12,6 +12,8 @@
 //   misc.py:48, frame_binding.py:71, base_gcp.py:256, inverse_mdl.py:126, cost_mdl.py:63 (heads).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 // one workgroup = 16 rows (block bx) of one Predictor; by / ny: this workgroup's share of the head's column tiles
@@ -273,18 +275,54 @@ __device__ __forceinline__ void mlp_rows(const gcpx_mlp_args& a, const int bx, c
     }
 }
 
+// Helper workgroups of a small launch.  A Predictor at 16 rows is ONE workgroup pulling its 0.65 MB of weights through one CU at the
+// ~10 B / cycle a CU gets from HBM / MALL (29 us) while 240 CUs idle.  The L2 is shared by the 32 CUs of an
+// XCD, and an L2 hit is served several times faster than that: so the launch brings one extra workgroup for every idle CU, and those
+// do nothing but LOAD the weights of the launch's problems — each XCD's helpers share the byte range between them (helper h is
+// assumed to sit on XCD h % 8, the observed dispatch order; when that does not hold some lines are fetched twice and others by the
+// compute workgroup itself: slower, never wrong) — in the order the compute workgroups consume them.  Nothing is stored.
+__device__ __forceinline__ void prefetch_range(const float* base, const size_t n_floats, const int slot, const int nslots) {
+    const size_t n4 = n_floats / 4;                                        // 16-byte units
+    const float4* p = reinterpret_cast<const float4*>(base);
+    for (size_t i = (size_t)slot * 256 + threadIdx.x; i < n4; i += (size_t)nslots * 256) {
+        const float4 v = p[i];
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));            // keeps the load; its value is not needed
+    }
+}
+
+__device__ __forceinline__ void prefetch_weights(const gcpx_mlp_args& a, const int helper, const int nhelpers) {
+    const int nslots = nhelpers >= 8 ? nhelpers / 8 : 1;
+    const int slot = nhelpers >= 8 ? helper / 8 : helper;
+    if (slot >= nslots) return;
+    const int out_pad = (a.out_dim + 15) & ~15;
+    prefetch_range(a.w_in, (size_t)a.in_dim * a.mid, slot, nslots);
+    if (a.n_mid) prefetch_range(a.w_mid, (size_t)a.n_mid * a.mid * a.mid, slot, nslots);
+    prefetch_range(a.w_out, (size_t)a.mid * out_pad, slot, nslots);
+}
+
+// blocks (bx, by) with bx < gx compute; bx >= gx (launched only with gy == 1 ... see gcpx_mlp) are helpers
 template <int MID, bool LEAN>
-__global__ void __launch_bounds__(256, LEAN ? 2 : 1) mlp_kernel(const gcpx_mlp_args a) {
+__global__ void __launch_bounds__(256, LEAN ? 2 : 1) mlp_kernel(const gcpx_mlp_args a, const int nblocks) {
     __shared__ float4 hid4[2 * 16 * (MID + 4) / 4];
-    mlp_rows<MID, LEAN>(a, blockIdx.x, blockIdx.y, gridDim.y, reinterpret_cast<float*>(hid4));
+    const int gx = (a.M + 15) / 16;
+    if ((int)blockIdx.x >= nblocks) {
+        prefetch_weights(a, blockIdx.x - nblocks, gridDim.x - nblocks);
+        return;
+    }
+    mlp_rows<MID, LEAN>(a, blockIdx.x % gx, blockIdx.x / gx, nblocks / gx, reinterpret_cast<float*>(hid4));
 }
 
 // several Predictors in ONE launch (the prior next to the posterior of a tree level; the latent-space heads): independent
 // problems, so what used to be parallel graph branches or a chain of ~20 us launches is one kernel boundary.
 // dims[p] = {first block, row blocks gx, head splits gy}; blocks of problem p are (bx, by) = (local % gx, local / gx).
 template <int MID, bool LEAN>
-__global__ void __launch_bounds__(256, LEAN ? 2 : 1) mlp_group_kernel(const gcpx_mlp_args* __restrict__ tab, const int4* __restrict__ dims, const int n) {
+__global__ void __launch_bounds__(256, LEAN ? 2 : 1) mlp_group_kernel(const gcpx_mlp_args* __restrict__ tab, const int4* __restrict__ dims, const int n,
+                                                                      const int nblocks) {
     __shared__ float4 hid4[2 * 16 * (MID + 4) / 4];
+    if ((int)blockIdx.x >= nblocks) {                     // helper workgroups: pull every problem's weights into this XCD's L2
+        for (int p = 0; p < n; ++p) prefetch_weights(tab[p], blockIdx.x - nblocks, gridDim.x - nblocks);
+        return;
+    }
     int p = 0;
     while (p + 1 < n && (int)blockIdx.x >= dims[p + 1].x) ++p;
     const int4 d = dims[p];
@@ -322,6 +360,15 @@ void mlp_grid(const gcpx_mlp_args* a, int* gx, int* gy) {
     *gy = y;
 }
 
+// helper workgroups (prefetch_weights) a launch of nb compute workgroups brings along: one per CU the launch leaves idle, while the
+// launch is small enough to be bound by what ONE CU pulls (GCPX_MLP_HELPERS=0 switches them off, =n caps them)
+int mlp_helpers(const int nb, const int cus) {
+    static const int cap = [] { const char* e = getenv("GCPX_MLP_HELPERS"); return e ? atoi(e) : 1 << 30; }();
+    if (nb > cus / 4) return 0;
+    const int h = ((cus - nb) / 8) * 8;
+    return h < cap ? (h > 0 ? h : 0) : cap;
+}
+
 }  // namespace
 
 extern "C" int gcpx_mlp_group_dims(const gcpx_mlp_args* host_table, int32_t n, int32_t* dims, int32_t* total_blocks) {
@@ -345,12 +392,14 @@ extern "C" int gcpx_mlp_group(const gcpx_mlp_args* dev_table, const int32_t* dev
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(dev_table && dev_dims && n >= 1 && n <= 16 && total_blocks > 0, "bad arguments");
     GCPX_CHECK_ARG((((uintptr_t)dev_dims) & 15) == 0, "dims must be 16-byte aligned");
-    const bool lean = total_blocks > gcpx_conv_grid() / 2;          // more workgroups than CUs
+    const int cus = gcpx_conv_grid() / 2;
+    const bool lean = total_blocks > cus;                            // more workgroups than CUs
+    const int grid = total_blocks + mlp_helpers(total_blocks, cus);
     const int4* dd = reinterpret_cast<const int4*>(dev_dims);
-    if (mid == 128 && lean) hipLaunchKernelGGL((mlp_group_kernel<128, true>), dim3(total_blocks), dim3(256), 0, stream, dev_table, dd, n);
-    else if (mid == 128) hipLaunchKernelGGL((mlp_group_kernel<128, false>), dim3(total_blocks), dim3(256), 0, stream, dev_table, dd, n);
-    else if (mid == 32 && lean) hipLaunchKernelGGL((mlp_group_kernel<32, true>), dim3(total_blocks), dim3(256), 0, stream, dev_table, dd, n);
-    else if (mid == 32) hipLaunchKernelGGL((mlp_group_kernel<32, false>), dim3(total_blocks), dim3(256), 0, stream, dev_table, dd, n);
+    if (mid == 128 && lean) hipLaunchKernelGGL((mlp_group_kernel<128, true>), dim3(grid), dim3(256), 0, stream, dev_table, dd, n, total_blocks);
+    else if (mid == 128) hipLaunchKernelGGL((mlp_group_kernel<128, false>), dim3(grid), dim3(256), 0, stream, dev_table, dd, n, total_blocks);
+    else if (mid == 32 && lean) hipLaunchKernelGGL((mlp_group_kernel<32, true>), dim3(grid), dim3(256), 0, stream, dev_table, dd, n, total_blocks);
+    else if (mid == 32) hipLaunchKernelGGL((mlp_group_kernel<32, false>), dim3(grid), dim3(256), 0, stream, dev_table, dd, n, total_blocks);
     else {
         gcpx_set_error("gcpx_mlp_group: unsupported mid=%d (128 or 32)", mid);
         return GCPX_ERR_UNSUPPORTED;
@@ -365,11 +414,13 @@ extern "C" int gcpx_mlp(const gcpx_mlp_args* a, void* stream_) {
     if (st != GCPX_OK) return st;
     int gx, gy;
     mlp_grid(a, &gx, &gy);
-    const bool lean = gx * gy > gcpx_conv_grid() / 2;               // more workgroups than CUs
-    if (a->mid == 128 && lean) hipLaunchKernelGGL((mlp_kernel<128, true>), dim3(gx, gy), dim3(256), 0, stream, *a);
-    else if (a->mid == 128) hipLaunchKernelGGL((mlp_kernel<128, false>), dim3(gx, gy), dim3(256), 0, stream, *a);
-    else if (a->mid == 32 && lean) hipLaunchKernelGGL((mlp_kernel<32, true>), dim3(gx, gy), dim3(256), 0, stream, *a);
-    else if (a->mid == 32) hipLaunchKernelGGL((mlp_kernel<32, false>), dim3(gx, gy), dim3(256), 0, stream, *a);
+    const int cus = gcpx_conv_grid() / 2;
+    const bool lean = gx * gy > cus;                                 // more workgroups than CUs
+    const int nb = gx * gy, grid = nb + mlp_helpers(nb, cus);
+    if (a->mid == 128 && lean) hipLaunchKernelGGL((mlp_kernel<128, true>), dim3(grid), dim3(256), 0, stream, *a, nb);
+    else if (a->mid == 128) hipLaunchKernelGGL((mlp_kernel<128, false>), dim3(grid), dim3(256), 0, stream, *a, nb);
+    else if (a->mid == 32 && lean) hipLaunchKernelGGL((mlp_kernel<32, true>), dim3(grid), dim3(256), 0, stream, *a, nb);
+    else if (a->mid == 32) hipLaunchKernelGGL((mlp_kernel<32, false>), dim3(grid), dim3(256), 0, stream, *a, nb);
     else {
         gcpx_set_error("gcpx_mlp: unsupported mid=%d (128 or 32)", a->mid);
         return GCPX_ERR_UNSUPPORTED;

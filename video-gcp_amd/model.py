@@ -160,6 +160,9 @@ class GCPTreeModel:
         # split-f16 convs (csrc/conv3x3_split.hip): f32-equivalent results on the f16 matrix pipes.  GCPX_EXACT_F32=1 keeps every
         # conv on the exact f32 MFMA kernels
         self.split_f16 = os.environ.get("GCPX_EXACT_F32") is None
+        # forward with losses: likelihood of the matched frames inside the head kernel (GCPX_HEAD_DLM_NLL); GCPX_UNFUSED_NLL=1 keeps
+        # the stored-parameters + gcpx_dlm_nll path (what the exact-f32 build and the training forward run)
+        self.fused_head_nll = os.environ.get("GCPX_UNFUSED_NLL") is None
         self._timed_op = None                 # name of one plan op bracketed by HIP events (bench.py roofline)
         self._timed_events = []
         self._pack_all()
@@ -1151,12 +1154,19 @@ class GCPTreeModel:
             with_loss = key[7]
             dlm = hp.decoder_distribution == "discrete_logistic_mixture"
             head_out, row_map = None, None
+            fused_nll = None
             if dlm:
                 mode = rt.HEAD_DLM_MEAN
                 if self.materialize_distr or (adaptive and self.save_for_backward and with_loss):
                     # (adaptive training: the backward of the mixture mean needs the raw parameters of every node)
                     mode, distr = rt.HEAD_DLM_BOTH, self._buf("distr_df", (B, N, S, S, self._head_pitch))
                     head_out = distr
+                elif with_loss and not adaptive and not self.save_for_backward and self.fused_head_nll and self.split_f16 \
+                        and "dec.head" in self.pk_split and S % 16 == 0:
+                    # forward with losses, no backward to follow: the likelihood of the matched frames is evaluated in the head's
+                    # epilogue (GCPX_HEAD_DLM_NLL) — their 2.35 GB of raw parameters (c2) are neither written nor read back
+                    mode, row_map = rt.HEAD_DLM_NLL, node2row
+                    fused_nll = self._buf("nll_partial", ((S // 4) * (S // 16), B * T), zero=True)
                 elif with_loss and not adaptive:
                     # only the nodes matched to a ground-truth frame keep their distribution parameters
                     # (frame_binding.py:91-92): row b*T+t of matched_distr <- node matched to frame t
@@ -1167,6 +1177,8 @@ class GCPTreeModel:
             a = self._conv_args([prev], F, S, S, S, S, hp.head_channels, self._head_pitch, P["dec.head.w"], P["dec.head.b"],
                                 head_out, upsample=0, head_mode=mode, images=images)
             a.raw_row_map = row_map.data_ptr() if row_map is not None else None
+            if fused_nll is not None:
+                a.nll_target, a.nll_partial, a.nll_rows = tin["traj_seq"].data_ptr(), fused_nll.data_ptr(), B * T
             self._set_split(a, "dec.head")
             plan.keep.append(a)
             if heads_lane:
@@ -1224,6 +1236,11 @@ class GCPTreeModel:
                 # LossAveragingCriterion.loss (binding_loss.py:19-42)
                 plan.add("loss.averaging_nll", lib.gcpx_averaging_nll, dsum.data_ptr(), wdf.data_ptr(),
                          self.sd["decoder.log_sigma"].data_ptr(), C.c_float(float(row)), B, N, T, nll_bt.data_ptr())
+            elif dlm and fused_nll is not None:
+                # rows of padded frames (t > end_ind) are written by no node: they keep whatever an earlier call left (finite) and
+                # carry pad_mask 0 in the combination below
+                plan.add("loss.nll_reduce", lib.gcpx_reduce_partials, fused_nll.data_ptr(), fused_nll.shape[0], B * T, B * T,
+                         nll_bt.data_ptr(), 0)
             elif dlm:
                 if matched_distr is None:       # materialize_distr: gather the matched rows out of the full tensor
                     matched_distr = self._buf("matched_distr", (B, T, S, S, self._head_pitch))

@@ -179,9 +179,13 @@ def dlm_channel_perm(n_mix=10):
     """Kernel slot -> canonical head channel (PixelCNN++ order: [logits(nm) | per colour c: means(nm),
     log_scales(nm), coeffs(nm)]), -1 for an empty slot.  100 real channels in slots 0..99, memory pitch 112:
       slots 8k..8k+7 = {logit_k, mean_r, mean_g, mean_b, coeff0, coeff1, coeff2, log_scale_r} of mixture k (k < 10),
-      slots 80+k / 90+k = log_scale_g / log_scale_b of mixture k, slots 100..111 empty.
+      slots 80..99 = log_scale_g / log_scale_b of every mixture (dlm_log_scale_slot), slots 100..111 empty.
     Everything the mixture MEAN needs for mixture k sits in lanes (q, q+1) of one 16-channel MFMA tile (csrc/conv3x3.hip
-    epilogue); the channels fill 6 full MFMA tiles + a 4-channel remainder (slots 96..99) with no padding inside."""
+    epilogue); the channels fill 6 full MFMA tiles + a 4-channel remainder (slots 96..99) with no padding inside.
+    The g / b log-scales of mixture k = 2 ct + h are placed so that the lane that evaluates mixture k of a pixel in the head
+    kernel's epilogue (lane group q with q >> 1 = h) finds them in ITS registers of channel tile 5 after the same row swap as the
+    other parameters (csrc/conv3x3_split.hip, fused likelihood): tile 5 lane group q' = 2 h + (ct >> 1) holds
+    {ls_g, ls_b} of ct & 1 = 0 in registers 0, 1 and of ct & 1 = 1 in registers 2, 3; mixtures 8, 9 are slots 96..99."""
     nm = n_mix
     assert nm == 10, "kernel epilogue is written for 10 mixtures (5 MFMA tiles x 2 mixtures)"
     base = lambda c: nm + c * 3 * nm
@@ -189,17 +193,25 @@ def dlm_channel_perm(n_mix=10):
     for k in range(nm):
         perm += [k, base(0) + k, base(1) + k, base(2) + k, base(0) + 2 * nm + k, base(1) + 2 * nm + k, base(2) + 2 * nm + k,
                  base(0) + nm + k]
+    tail = [-1] * 20
     for c in (1, 2):
         for k in range(nm):
-            perm.append(base(c) + nm + k)
+            tail[dlm_log_scale_slot(c, k) - 80] = base(c) + nm + k
+    perm += tail
+    assert sorted(perm) == list(range(100))
     while len(perm) % 16:
         perm.append(-1)
     return perm
 
 
 def dlm_log_scale_slot(c, k, n_mix=10):
-    """slot of log_scale_{c,k} (the same rule is compiled into csrc/loss.hip and csrc/backward.hip)"""
-    return 8 * k + 7 if c == 0 else 80 + 10 * (c - 1) + k
+    """slot of log_scale_{c,k} (the same rule is compiled into csrc/common.h: dlm_ls_slot)"""
+    if c == 0:
+        return 8 * k + 7
+    if k >= 8:
+        return 96 + 2 * (k - 8) + (c - 1)
+    h, ct = k & 1, k >> 1
+    return 80 + 4 * (2 * h + (ct >> 1)) + 2 * (ct & 1) + (c - 1)
 
 
 def pack_dlm_head(w, perm):

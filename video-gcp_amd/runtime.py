@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgcpx.so")
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
-HEAD_RAW, HEAD_DLM_MEAN, HEAD_DLM_BOTH, HEAD_TANH_NCHW = 0, 1, 2, 3
+HEAD_RAW, HEAD_DLM_MEAN, HEAD_DLM_BOTH, HEAD_TANH_NCHW, HEAD_DLM_NLL = 0, 1, 2, 3, 4
 SPLIT_PLAIN, SPLIT_ROWFOLD = 0, 1
 EPI_NONE, EPI_LRELU, EPI_LSTM, EPI_GAUSS_SAMPLE = 0, 1, 2, 3
 MLP_PLAIN, MLP_GAUSS = 0, 1
@@ -29,7 +29,7 @@ class ConvArgs(C.Structure):
                 ("Wout", i32), ("Cin", i32), ("Cout", i32), ("out_pitch", i32), ("upsample", i32), ("out_act", i32),
                 ("head_mode", i32), ("wpk", vp), ("bias", vp), ("out", vp), ("images", vp), ("stats_partial", vp),
                 ("raw_row_map", vp), ("src_row_map", vp), ("src_row_frames", vp), ("n_src_rows", i32), ("w_split_log2", i32), ("wpk_split", vp), ("w_split_log2_dev", vp),
-                ("split_layout", i32), ("_pad2", i32)]
+                ("split_layout", i32), ("nll_rows", i32), ("nll_target", vp), ("nll_partial", vp)]
 
 
 class LossArgs(C.Structure):
@@ -156,6 +156,8 @@ SYMBOLS = [
     ("gcpx_gn_bwd_blocks", C.c_int, [i32]),
     ("gcpx_lrelu_bwd", C.c_int, [vp, vp, vp, i64, C.c_float, vp]),
     ("gcpx_kl_bwd", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i64, i64, C.c_float, C.c_float, vp]),
+    ("gcpx_kl_bwd_weighted", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i64, i64, C.c_float, C.c_float, vp, i64, vp]),
+    ("gcpx_rows_strided", C.c_int, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
     ("gcpx_latent_bwd", C.c_int, [vp, vp, vp, i64, i64, vp, i64, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp]),
     ("gcpx_tree_accum", C.c_int, [C.POINTER(TreeAccumArgs), vp]),
     ("gcpx_timestep_scatter", C.c_int, [vp, i64, i64, vp, vp, i32, i32, i32, i32, vp]),

@@ -60,14 +60,17 @@ class GCPSequentialModel(GCPTreeModel):
                 self.pk[net]["lstm0ff.w"], self.pk[net]["lstm0ff.b"] = pk.pack_gemm(w), b
 
     # ------------------------------------------------------------------------------------------------
-    def _hsp_stages(self, plan, name, W, srcs, B, state, par, out_ptr, out_ob, N_out, w0="lstm0f"):
+    def _hsp_stages(self, plan, name, W, srcs, B, state, par, out_ptr, out_ob, N_out, w0="lstm0f", xs_buf=None):
         """One step of a recurrent predictor as its dependent stages: [LSTM layer 0 (with the folded embedding), layer 1, ...,
         out Linear].  Each stage is a function(group) that appends its GEMM to `group` — the same stage of nets that do not
-        depend on each other then shares ONE launch (gcpx_gemm_group)."""
+        depend on each other then shares ONE launch (gcpx_gemm_group).  state[par][i] / state[1 - par][i]: the [h | c] rows the
+        step reads / writes (two buffers in ping-pong for inference; the training forward hands in two consecutive slices of a
+        buffer that keeps every step's state, and `xs_buf`, the step's slice of the stacked layer inputs)."""
         hp = self._hp
         H, nl = hp.nz_mid_lstm, hp.n_lstm_layers
         fused = "lstm0f.w" in W and not self.save_for_backward
-        xs_buf = [self._buf(f"{name}.x{i}", (B, H)) for i in range(nl + 1)]
+        if xs_buf is None:
+            xs_buf = [self._buf(f"{name}.x{i}", (B, H)) for i in range(nl + 1)]
         stages = []
         if not fused:
             stages.append(lambda g: self._gemm(plan, f"{name}.embed", srcs, B, H, 1, W["embed.w"], W["embed.b"],
@@ -130,11 +133,34 @@ class GCPSequentialModel(GCPTreeModel):
             outs["seq_len_logits"] = logits
 
         # ---- VRNN rollout (sequential.py:49-54) ----
-        state = {net: [[self._buf(f"{net}.s{par}.{i}", (B, 2 * H)) for i in range(nl)] for par in range(2)]
-                 for net in ("prior_lstm", "inf_lstm", "gen_lstm")}
-        for net in state:
-            for i in range(nl):
-                plan.add(f"zero.{net}.{i}", lib.gcpx_fill_zero, state[net][0][i].data_ptr(), B * 2 * H * 4)
+        NETS = ("prior_lstm", "inf_lstm", "gen_lstm")
+        keep = self.save_for_backward
+        if keep:
+            # training forward: the backward pass through the recurrence needs every step's states and layer inputs.  S[net][t, i] =
+            # [h | c] of layer i BEFORE step t (S[net][0] = 0), XS[net][t, i] = input of layer i at step t (i = 0: the embedding,
+            # i = nl: the top hidden state) — stacked, so the weight gradients of all T - 1 steps are ONE GEMM per weight
+            Sall = {net: self._buf(f"{net}.S", (T, nl, B, 2 * H)) for net in NETS}
+            XSall = {net: self._buf(f"{net}.XS", (T - 1, nl + 1, B, H)) for net in NETS}
+            plan.rec["seq"] = dict(S=Sall, XS=XSall, X=X, EG=EG, PZ=PZ, QZ=QZ, Z=Z)
+            for net in NETS:
+                plan.add(f"zero.{net}", lib.gcpx_fill_zero, Sall[net].data_ptr(), nl * B * 2 * H * 4)
+
+            class _StepState:           # state[t & 1] -> S[t], state[1 - (t & 1)] -> S[t + 1]: what _hsp_stages indexes with `par`
+                def __init__(self, S, t):
+                    self.S, self.t = S, t
+
+                def __getitem__(self, par):
+                    tt = self.t if par == (self.t & 1) else self.t + 1
+                    return [self.S[tt, i] for i in range(nl)]
+            state_of = lambda net, t: _StepState(Sall[net], t)
+            xs_of = lambda net, t: [XSall[net][t, i] for i in range(nl + 1)]
+        else:
+            state = {net: [[self._buf(f"{net}.s{par}.{i}", (B, 2 * H)) for i in range(nl)] for par in range(2)] for net in NETS}
+            for net in state:
+                for i in range(nl):
+                    plan.add(f"zero.{net}.{i}", lib.gcpx_fill_zero, state[net][0][i].data_ptr(), B * 2 * H * 4)
+            state_of = lambda net, t: state[net]
+            xs_of = lambda net, t: None
         ctx = (lambda: [e0(), eg()]) if hp.context_every_step else (lambda: [])
         posterior = has_traj and not sample_prior and not has_z
         # Three recurrent nets, ONE lane.  The inference net reads the ENCODED ground truth only (sequential.py:51-54): it does not
@@ -145,13 +171,13 @@ class GCPSequentialModel(GCPTreeModel):
         xt_of = lambda t: self._rowsrc(_addr(X, t * nz), T * nz, 0, nz)
 
         def prior_stages(t):
-            return self._hsp_stages(plan, f"prior{t}", P["prior_lstm"], [xt_of(t)] + ctx(), B, state["prior_lstm"], t & 1,
-                                    _addr(PZ, t * 2 * nv), (T - 1) * 2 * nv, 2 * nv)
+            return self._hsp_stages(plan, f"prior{t}", P["prior_lstm"], [xt_of(t)] + ctx(), B, state_of("prior_lstm", t), t & 1,
+                                    _addr(PZ, t * 2 * nv), (T - 1) * 2 * nv, 2 * nv, xs_buf=xs_of("prior_lstm", t))
 
         def inf_stages(t):
             xp = self._rowsrc(_addr(enc_traj, (t + 1) * nz), T * nz, 0, nz)
-            return self._hsp_stages(plan, f"inf{t}", P["inf_lstm"], [xp] + ctx(), B, state["inf_lstm"], t & 1,
-                                    _addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 2 * nv)
+            return self._hsp_stages(plan, f"inf{t}", P["inf_lstm"], [xp] + ctx(), B, state_of("inf_lstm", t), t & 1,
+                                    _addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 2 * nv, xs_buf=xs_of("inf_lstm", t))
 
         def z_source(t):
             zt = (_addr(Z, t * nv), (T - 1) * nv, 0)
@@ -163,8 +189,8 @@ class GCPSequentialModel(GCPTreeModel):
             return self._rowsrc(zt[0], zt[1], zt[2], nv)
 
         def gen_stages(t, zsrc):
-            return self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [xt_of(t), zsrc] + ctx(), B, state["gen_lstm"], t & 1,
-                                    _addr(X, (t + 1) * nz), T * nz, nz)
+            return self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [xt_of(t), zsrc] + ctx(), B, state_of("gen_lstm", t), t & 1,
+                                    _addr(X, (t + 1) * nz), T * nz, nz, xs_buf=xs_of("gen_lstm", t))
 
         def run(*chains):
             """stage i of every chain in one launch"""
@@ -213,7 +239,7 @@ class GCPSequentialModel(GCPTreeModel):
                 if t == 0:
                     g_st = gen_stages(0, zsrc)
                 else:
-                    g_st = self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [top(t - 1), zsrc] + ctx(), B, state["gen_lstm"], t & 1,
+                    g_st = self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [top(t - 1), zsrc] + ctx(), B, state_of("gen_lstm", t), t & 1,
                                             _addr(X, (t + 1) * nz), T * nz, nz, w0="lstm0ff")
                 place(g_st[:-1], 3 * t + 6)
                 place(g_st[-1:], 3 * t + 9)
@@ -297,7 +323,16 @@ class GCPSequentialModel(GCPTreeModel):
         # ---- losses (sequential.py:60-68) ----
         if with_loss:
             nll_bt = self._buf("nll_bt", (B, T))
-            if dlm:
+            if dlm and self.save_for_backward:
+                # training step: loss and its gradient w.r.t. the stored parameters in one pass (see GCPTreeModel._build_plan);
+                # d total / d nll_bt = w_rec * w0 / (B * prod(traj_seq.shape[1:]))
+                dMD = self._buf("bw.dMD", (B * T, S, S, self._head_pitch))
+                plan.add("loss.dlm_nll+bwd", lib.gcpx_dlm_nll_bwd, matched.data_ptr(), tin["traj_seq"].data_ptr(), tin["w0"].data_ptr(),
+                         C.c_float(hp.dense_img_rec_weight / (B * float(T * hp.input_nc * S * S))), dMD.data_ptr(),
+                         self._buf("bw.dMD.colsum", (B * T, self._head_pitch)).data_ptr(), nll_bt.data_ptr(), B * T, S * S,
+                         self._head_pitch, hp.n_mixtures)
+                plan.rec["nll_bwd_fused"] = True
+            elif dlm:
                 plan.add("loss.dlm_nll", lib.gcpx_dlm_nll, matched.data_ptr(), tin["traj_seq"].data_ptr(), tin["w0"].data_ptr(),
                          nll_bt.data_ptr(), B * T, S * S, self._head_pitch, hp.n_mixtures)
             else:
@@ -318,7 +353,9 @@ class GCPSequentialModel(GCPTreeModel):
             plan.keep.append(la)
             plan.add("loss.combine", lib.gcpx_loss_combine, C.byref(la))
             outs["losses"], outs["nll_bt"], outs["kl_b"] = loss_out, nll_bt, kl_b
+            plan.rec["loss_args"] = la
         outs["enc_traj_seq"] = enc_traj
+        plan.rec.update(head_src=prev, tin=tin, key=key, seq_row_map=row_map)
         plan.outs = outs
         return plan
 

@@ -1,0 +1,247 @@
+"""Training step of the flat VRNN baseline `gcp_sequential` on MI355X: forward + explicit backward through the T - 1 recurrent
+steps + RAdam, all in HIP.
+
+The reference trains `SequentialModel` through the same loop as the tree model (/root/reference/gcp/prediction/train.py:155-163 with
+`configuration['model'] = SequentialModel`, experiments/prediction/base_configs/gcp_sequential.py; model:
+gcp/prediction/models/sequential.py:13-131) and gets the backward pass from torch autograd.  Here it is a second launch plan built
+from the records of the training forward (`GCPSequentialModel._build_plan` with save_for_backward: every step's LSTM states, layer
+inputs and gates are kept), like `GCPTrainStep`'s for the tree model, whose decoder / encoder / Predictor backward it reuses:
+
+  loss gradients (NLL on frames 1 .. T-1, KL weighted by pad_mask[:, 1:], length CE; sequential.py:60-68, base_gcp.py:264-304)
+  -> decoder backward                                              (gradient of every x_{t+1})
+  -> prior chain   t = T-2 .. 0   (needs only the KL gradient: runs on a side lane next to the decoder backward)
+  -> generator chain t = T-2 .. 0 (x_{t+1} = gen([x_t, z_t, ctx]): the gradient of x_t collects decoder, prior and generator terms)
+  -> reparametrised sample backward for all steps in one launch, inference chain t = T-2 .. 0
+  -> weight gradients of the three recurrent nets: ONE GEMM per weight over the stacked (step, sequence) rows
+  -> encoders (trajectory frames through the inference net's inputs, I_0 through x_0 / context, I_g through the context).
+
+A step of a chain is: out^T, n x (LSTM-cell backward, [W_ih | W_hh]^T in one GEMM), embed^T — eight dependent small launches at
+16 rows.  The three nets' chains are each T - 1 steps long; they are latency-bound (weights stream from L2 / MALL), not MFMA-bound.
+"""
+import ctypes as C
+
+import torch
+
+from . import packing as pk
+from . import runtime as rt
+from .model import _Plan, _addr
+from .params import decoder_layers
+from .training import GCPTrainStep, _c16
+
+NETS = ("prior_lstm", "inf_lstm", "gen_lstm")
+
+
+class SequentialTrainStep(GCPTrainStep):
+    """`step(inputs)` = one optimisation step of a GCPSequentialModel on one minibatch (same interface as GCPTrainStep)."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+        assert model._hp.context_every_step, "the recurrent nets are built with the (e_0, e_g) context at every step (hyperparameters.py default)"
+        super().__init__(model, lr=lr, betas=betas, eps=eps, process_group=process_group)
+        self.side_lanes = True
+
+    # ------------------------------------------------------------------------------------------------
+    def _pack_backward(self, sd):
+        m, hp = self.m, self.m._hp
+        nz = hp.nz_enc
+        X = {}
+        layers, ctop = m._enc_layers, m._c_top
+        for name, cin, cout, norm in layers[1:]:
+            w = sd[f"encoder.net.{name}.conv.weight"]
+            X[f"enc.{name}.wT"] = pk.pack_gemm(w.permute(2, 3, 1, 0).reshape(16 * cin, cout))
+        wh = sd["encoder.net.head.weight"]
+        X["enc.head.wT"] = pk.pack_gemm(wh.permute(2, 3, 1, 0).reshape(16 * ctop, nz))
+        wt = sd["decoder.net.input.conv.weight"]
+        X["dec.input.wT"] = pk.pack_gemm(wt.permute(0, 2, 3, 1).reshape(nz, 16 * ctop))
+        for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
+            wT = sd[f"decoder.net.{name}.conv.weight"].flip(2, 3).transpose(0, 1).contiguous()
+            for h in range((wT.shape[0] + 63) // 64):
+                X[f"dec.{name}.wT{h}"] = pk.pack_conv3x3(wT[64 * h:64 * (h + 1)], 16)
+        hw = sd["decoder.gen_head.conv.weight"]
+        perm = torch.as_tensor(pk.dlm_channel_perm(hp.n_mixtures), device=hw.device)
+        wk = torch.zeros((len(perm),) + tuple(hw.shape[1:]), dtype=hw.dtype, device=hw.device)
+        wk[perm >= 0] = hw[perm[perm >= 0]]
+        X["dec.head.wT"] = pk.pack_conv3x3(wk.flip(2, 3).transpose(0, 1).contiguous(), 16)
+        if hp.regress_length:
+            X["length_pred"] = self._pack_predictor_T(sd, "length_pred.p", [(0, 2 * nz)])
+        for net in NETS:
+            p = f"dense_rec.lstm.cell.{net}"
+            T_ = {"embed.wT": pk.pack_gemm(sd[f"{p}.embed.weight"].t().contiguous()),          # [n = in_dim][k = H]
+                  "out.wT": pk.pack_gemm(sd[f"{p}.out.weight"].t().contiguous())}               # [n = H][k = out]
+            for i in range(hp.n_lstm_layers):
+                # d [x | h] = d gates @ [W_ih | W_hh]: both data gradients of a cell in one GEMM
+                w = torch.cat([sd[f"{p}.lstm.{i}.weight_ih"], sd[f"{p}.lstm.{i}.weight_hh"]], 1)          # [4H, 2H]
+                T_[f"lstm{i}.wxhT"] = pk.pack_gemm(w.t().contiguous())                                    # [n = 2H][k = 4H]
+            X[net] = T_
+        return X
+
+    # ------------------------------------------------------------------------------------------------
+    def _rows(self, plan, name, dst, dst_sb, dst_sr, src, src_sb, src_sr, B, rpb, width, mode):
+        plan.add(name, self.m.lib.gcpx_rows_strided, dst, dst_sb, dst_sr, src, src_sb, src_sr, B, rpb, width, mode)
+
+    def _chain(self, plan, net, dout_of, B, T, dIn, nrec):
+        """Backward of one recurrent net through all T - 1 steps, last step first.  dout_of(t) -> row source of the gradient of the
+        step's output.  Writes dIn [B, T-1, in_dim] (gradient of every step's embedding input), the stacked gate gradients dG[i]
+        [(T-1) B, 4H] and embedding-output gradients DX0 [(T-1) B, 2H] (columns < H) for the weight gradients."""
+        m, hp, lib = self.m, self.m._hp, self.m.lib
+        H, nl = hp.nz_mid_lstm, hp.n_lstm_layers
+        rec, Wt = nrec["rec"], self.bk[net]
+        S, in_dim = nrec["S"][net], nrec["in_dim"][net]
+        buf = m._buf
+        dG = [buf(f"bw.{net}.dG{i}", (T - 1, B, 4 * H)) for i in range(nl)]
+        dxh = [buf(f"bw.{net}.dxh{i}", (B, 2 * H)) for i in range(1, nl)]              # layers 1..: [dx | dh], reused every step
+        DX0 = buf(f"bw.{net}.dxh0", (T - 1, B, 2 * H))                                 # layer 0: kept per step (embedding weight gradient)
+        dtop = buf(f"bw.{net}.dtop", (B, H))
+        dcrec = [buf(f"bw.{net}.dc{i}", (B, H)) for i in range(nl)]
+        for t in reversed(range(T - 1)):
+            last = t == T - 2
+            self._dgemm(plan, f"{net}{t}.out", [dout_of(t)], B, H, 1, Wt["out.wT"], dtop.data_ptr(), H, 0)
+            for i in reversed(range(nl)):
+                out_i = DX0[t] if i == 0 else dxh[i - 1]
+                above = dtop if i == nl - 1 else dxh[i]                                 # d h_i from the layer above (its dx columns)
+                a = rt.LstmBwdArgs()
+                a.gates = rec[f"gates:{nrec['tag'][net]}{t}.lstm{i}"].data_ptr()
+                a.c_prev, a.c_prev_stride = _addr(S[t, i], H), 2 * H
+                a.c_new, a.pb, a.prow = _addr(S[t + 1, i], H), 2 * H, 0
+                a.dh_dense, a.dh_stride = above.data_ptr(), (H if i == nl - 1 else 2 * H)
+                # recurrent terms from step t + 1: d h through W_hh (the dh columns of that step's [dx | dh]), d c through the forget gate
+                prev_out = (DX0[t + 1] if i == 0 else dxh[i - 1]) if not last else None
+                a.dh_pos = _addr(prev_out, H) if prev_out is not None else None
+                a.dc_pos = dcrec[i].data_ptr() if not last else None
+                a.dgates, a.dc_prev, a.dcp_stride = dG[i][t].data_ptr(), dcrec[i].data_ptr(), H
+                a.M, a.H, a.rpb = B, H, 1
+                if a.dh_pos is not None:
+                    # dh_pos / dc_pos are addressed b * pb + j * prow with the strides of c_new (2H per row): the dh columns of [dx | dh]
+                    # have the same pitch; the dense dc buffer does not, so it gets its own pitch-2H twin below
+                    pass
+                plan.keep.append(a)
+                plan.add(f"bw.lstm:{net}{t}.{i}", lib.gcpx_lstm_bwd, C.byref(a))
+                self._dgemm(plan, f"{net}{t}.lstm{i}", [self._dense(dG[i][t].data_ptr(), 4 * H, 4 * H, B)], B, 2 * H, B, Wt[f"lstm{i}.wxhT"],
+                            out_i.data_ptr(), 0, 2 * H)
+            self._dgemm(plan, f"{net}{t}.embed", [self._dense(DX0[t].data_ptr(), 2 * H, H, B)], B, in_dim, 1, Wt["embed.wT"],
+                        _addr(dIn, t * in_dim), (T - 1) * in_dim, 0)
+            yield t
+        nrec.setdefault("dG", {})[net] = dG
+        nrec.setdefault("DX0", {})[net] = DX0
+
+    def _build_backward(self, fplan):
+        m, hp, lib = self.m, self.m._hp, self.m.lib
+        rec, o = fplan.rec, fplan.outs
+        key, tin = rec["key"], rec["tin"]
+        B = key[0]
+        T, nz, nv, H, nl = hp.max_seq_len, hp.nz_enc, hp.nz_vae, hp.nz_mid_lstm, hp.n_lstm_layers
+        S_ = hp.img_sz
+        div = float(T * hp.input_nc * S_ * S_)
+        plan = _Plan(lib)
+        buf = m._buf
+        sq = rec["seq"]
+        X, EG, PZ, QZ, Z = sq["X"], sq["EG"], sq["PZ"], sq["QZ"], sq["Z"]
+        enc_traj = o["enc_traj_seq"]
+        zero = lambda t: plan.add("bw.zero", lib.gcpx_fill_zero, t.data_ptr(), t.numel() * 4)
+        in_dim = {"prior_lstm": 3 * nz, "inf_lstm": 3 * nz, "gen_lstm": 3 * nz + nv}
+        nrec = dict(rec=rec, S=sq["S"], XS=sq["XS"], in_dim=in_dim, tag={"prior_lstm": "prior", "inf_lstm": "inf", "gen_lstm": "gen"})
+
+        DX = buf("bw.seq.DX", (B, T, nz))                    # gradient of X[b, t] = x_t (x_0 = e_0)
+        dEG = buf("bw.seq.dEG", (B, nz))
+        dQZ, dPZ = buf("bw.seq.dQZ", (B, T - 1, 2 * nv)), buf("bw.seq.dPZ", (B, T - 1, 2 * nv))
+        dIn = {net: buf(f"bw.{net}.dIn", (B, T - 1, in_dim[net])) for net in NETS}
+        zero(self.grad); zero(DX); zero(dEG)
+
+        # ---- loss gradients ----
+        la = rec["loss_args"]
+        assert rec.get("nll_bwd_fused"), "the training forward produces d NLL / d parameters together with the loss"
+        dMD = buf("bw.dMD", (B * T, S_, S_, m._head_pitch))
+        plan.add("bw.kl", lib.gcpx_kl_bwd_weighted, QZ.data_ptr(), PZ.data_ptr(), dQZ.data_ptr(), dPZ.data_ptr(), B, T - 1, nv,
+                 (T - 1) * 2 * nv, 2 * nv, C.c_float(hp.free_nats), C.c_float(hp.kl_weight / (B * div)), _addr(tin["pad_mask"], 1), T)
+        ldl = _c16(T)
+        if hp.regress_length:
+            dlen = buf("bw.dlen", (B, ldl))
+            plan.add("bw.heads", lib.gcpx_loss_heads_bwd, C.byref(la), dlen.data_ptr(), None, None)
+            dXl = buf("bw.dX.len", (B, 2 * nz))
+            self._mlp_bwd(plan, "length_pred", "length_pred.p", rec["mlp:length_pred"], self.bk["length_pred"], dlen.data_ptr(), ldl,
+                          [(dXl.data_ptr(), 2 * nz, 0)])
+            self._rows(plan, "bw.len.e0", DX.data_ptr(), T * nz, 0, dXl.data_ptr(), 2 * nz, 0, B, 1, nz, 1)
+            self._rows(plan, "bw.len.eg", dEG.data_ptr(), nz, 0, _addr(dXl, nz), 2 * nz, 0, B, 1, nz, 1)
+
+        # ---- prior chain on a side lane (needs the KL gradient only), decoder backward on the main lane ----
+        plan.fork([1])
+        plan.lane = 1
+        for _ in self._chain(plan, "prior_lstm", lambda t: m._rowsrc(_addr(dPZ, t * 2 * nv), (T - 1) * 2 * nv, 0, 2 * nv), B, T, dIn["prior_lstm"], nrec):
+            pass
+        plan.lane = 0
+        F = B * (T - 1)
+        row2frame = buf("bw.seq.row2frame", (B * T,), torch.int32)       # row (b, t) of the matched arrays <- decoded frame (b, t - 1); (b, 0): none
+        r2f = torch.arange(B * T, dtype=torch.int64).view(B, T)
+        row2frame.copy_(torch.where(r2f % T == 0, r2f // T * (T - 1), r2f // T * (T - 1) + r2f % T - 1).reshape(-1).to(torch.int32))
+        inv = torch.arange(B * T, dtype=torch.int64).view(B, T) // T * (T - 1) + torch.arange(T)[None] - 1
+        inv[:, 0] = -1
+        row2frame_inv = buf("bw.seq.row2frame_inv", (B * T,), torch.int32)
+        row2frame_inv.copy_(inv.reshape(-1).to(torch.int32))
+        dE_dec, dskip = self._decoder_backward(plan, fplan, dMD, B, maps=dict(R=B * T, row2src=row2frame, frame2row=rec["seq_row_map"],
+                                                                               row2frame=row2frame_inv))
+        plan.join([1])
+        self._flush(plan)                                     # decoder weight gradients: beside the generator / inference chains
+        # gradient of x_{t+1}, t = 0 .. T-2: decoder + the prior's input at step t + 1
+        plan.add("bw.addrows.dec", lib.gcpx_add_rows, _addr(DX, nz), T * nz, nz, dE_dec.data_ptr(), None, B, T - 1, nz)
+        self._rows(plan, "bw.prior.dx", DX.data_ptr(), T * nz, nz, dIn["prior_lstm"].data_ptr(), (T - 1) * 3 * nz, 3 * nz, B, T - 1, nz, 1)
+
+        # ---- generator chain: the gradient of x_t is complete once step t has added its input gradient ----
+        for t in self._chain(plan, "gen_lstm", lambda t: m._rowsrc(_addr(DX, (t + 1) * nz), T * nz, 0, nz), B, T, dIn["gen_lstm"], nrec):
+            self._rows(plan, f"bw.gen.dx{t}", _addr(DX, t * nz), T * nz, 0, _addr(dIn["gen_lstm"], t * in_dim["gen_lstm"]),
+                       (T - 1) * in_dim["gen_lstm"], 0, B, 1, nz, 1)
+
+        # ---- z_t = mu_q + exp(log_sigma_q) eps (sequential.py:51-54): d q for every step in one launch, then the inference chain ----
+        DQ, DPd = buf("bw.seq.DQ", (B * (T - 1), 2 * nv)), buf("bw.seq.DPd", (B * (T - 1), 2 * nv))
+        plan.add("bw.latent", lib.gcpx_latent_bwd, dQZ.data_ptr(), dPZ.data_ptr(), QZ.data_ptr(), (T - 1) * 2 * nv, 2 * nv,
+                 tin["eps"].data_ptr(), tin["eps"].shape[1] * nv, nv, _addr(dIn["gen_lstm"], nz), in_dim["gen_lstm"], None, 0,
+                 DQ.data_ptr(), DPd.data_ptr(), B * (T - 1), T - 1, nv)
+        for _ in self._chain(plan, "inf_lstm", lambda t: m._rowsrc(_addr(DQ, t * 2 * nv), (T - 1) * 2 * nv, 0, 2 * nv), B, T, dIn["inf_lstm"], nrec):
+            pass
+
+        # ---- weight gradients of the three nets: stacked rows r = (t, b) ----
+        def stacked(t_stride, b_stride):
+            return dict(rpb=B, sb=t_stride, sr=b_stride)
+        e0s = dict(ptr=_addr(X), **stacked(0, T * nz))
+        egs = dict(ptr=_addr(EG), **stacked(0, nz))
+        srcs = {"prior_lstm": [dict(ptr=_addr(X), w=nz, **stacked(nz, T * nz)), dict(w=nz, **e0s), dict(w=nz, **egs)],
+                "inf_lstm": [dict(ptr=_addr(enc_traj, nz), w=nz, **stacked(nz, T * nz)), dict(w=nz, **e0s), dict(w=nz, **egs)],
+                "gen_lstm": [dict(ptr=_addr(X), w=nz, **stacked(nz, T * nz)), dict(ptr=_addr(Z), w=nv, **stacked(nv, (T - 1) * nv)),
+                             dict(w=nz, **e0s), dict(w=nz, **egs)]}
+        douts = {"prior_lstm": (dPZ.data_ptr(), (T - 1) * 2 * nv, 2 * nv, 2 * nv), "inf_lstm": (DQ.data_ptr(), (T - 1) * 2 * nv, 2 * nv, 2 * nv),
+                 "gen_lstm": (_addr(DX, nz), T * nz, nz, nz)}
+        R = (T - 1) * B
+        for net in NETS:
+            p = f"dense_rec.lstm.cell.{net}"
+            XS, S = sq["XS"][net], sq["S"][net]
+            dG, DX0 = nrec["dG"][net], nrec["DX0"][net]
+            dy, ldy, dy_sb, N_out = douts[net]
+            self._wgrad(plan, f"{net}.out", dy, ldy, R, N_out, XS[0, nl].data_ptr(), H, self.g(f"{p}.out.weight"), ldw=H, rpb=B,
+                        sb=(nl + 1) * B * H, sr=H, dy_rpb=B, dy_sb=dy_sb, dbias=self.g(f"{p}.out.bias"))
+            for i in range(nl):
+                self._wgrad(plan, f"{net}.lstm{i}.ih", dG[i].data_ptr(), 4 * H, R, 4 * H, XS[0, i].data_ptr(), H, self.g(f"{p}.lstm.{i}.weight_ih"),
+                            ldw=H, rpb=B, sb=(nl + 1) * B * H, sr=H, dbias=self.g(f"{p}.lstm.{i}.bias_ih"), dbias2=self.g(f"{p}.lstm.{i}.bias_hh"))
+                self._wgrad(plan, f"{net}.lstm{i}.hh", dG[i].data_ptr(), 4 * H, R, 4 * H, S[0, i].data_ptr(), H, self.g(f"{p}.lstm.{i}.weight_hh"),
+                            ldw=H, rpb=B, sb=nl * B * 2 * H, sr=2 * H)
+            koff = 0
+            for k, sc in enumerate(srcs[net]):
+                self._wgrad(plan, f"{net}.embed{k}", DX0.data_ptr(), 2 * H, R, H, sc["ptr"], sc["w"], self.g(f"{p}.embed.weight"),
+                            ldw=in_dim[net], k_off=koff, rpb=sc["rpb"], sb=sc["sb"], sr=sc["sr"],
+                            dbias=(self.g(f"{p}.embed.bias") if k == 0 else None))
+                koff += sc["w"]
+        self._flush(plan)
+
+        # ---- context and x_0 gradients -> the I_0 / I_g encoder outputs; inference inputs -> the trajectory encoder ----
+        d_enc_traj = buf("bw.d_enc_traj", (B, T, nz))
+        zero(d_enc_traj)
+        self._rows(plan, "bw.inf.dx", _addr(d_enc_traj, nz), T * nz, nz, dIn["inf_lstm"].data_ptr(), (T - 1) * 3 * nz, 3 * nz, B, T - 1, nz, 0)
+        for net in NETS:
+            c0 = in_dim[net] - 2 * nz                         # columns of e_0 / e_g in the embedding input
+            self._rows(plan, f"bw.{net}.de0", DX.data_ptr(), T * nz, 0, _addr(dIn[net], c0), (T - 1) * in_dim[net], in_dim[net], B, T - 1, nz, 2)
+            self._rows(plan, f"bw.{net}.deg", dEG.data_ptr(), nz, 0, _addr(dIn[net], c0 + nz), (T - 1) * in_dim[net], in_dim[net], B, T - 1, nz, 2)
+        self._encoder_backward(plan, fplan, "traj", d_enc_traj.data_ptr(), nz, 0, 0, {})
+        self._flush(plan)
+        self._encoder_backward(plan, fplan, "I0", _addr(DX), nz, 1, T * nz, dskip)
+        self._encoder_backward(plan, fplan, "Ig", _addr(dEG), nz, 1, nz, {})
+        self._flush(plan, one_lane=True)
+        plan.join(list(range(1, 1 + self.n_side)))
+        plan.outs = dict(DX=DX, dEG=dEG, dQZ=dQZ, dPZ=dPZ, DQ=DQ, dIn=dIn, dE_dec=dE_dec, d_enc_traj=d_enc_traj)
+        return plan
