@@ -113,3 +113,15 @@ def losses(sd, hp, inputs, out):
         res["len_pred"] = (F.cross_entropy(out["seq_len_logits"], inputs["end_ind"]), hp.length_pred_weight)
     total = sum(v * w for v, w in res.values() if w > 0) / float(torch.tensor(inputs["traj_seq"].shape[1:]).prod())
     return res, total
+
+
+def gradients(sd, hp, inputs, noise):
+    """d total_loss / d parameter by torch autograd over this oracle's forward + losses (what `losses.total.value.backward()` of
+    train.py:159-161 produces for configuration['model'] = SequentialModel).  Returns ({name: grad}, loss dict, total, out)."""
+    names = [k for k in sd if not (k.endswith("running_mean") or k.endswith("running_var"))]
+    leaf = {k: (sd[k].detach().clone().requires_grad_(True) if k in names else sd[k]) for k in sd}
+    out = forward(leaf, hp, inputs, noise=noise, training_bn=True, phase="train")
+    res, total = losses(leaf, hp, inputs, out)
+    grads = torch.autograd.grad(total, [leaf[k] for k in names], allow_unused=True)
+    g = {k: (torch.zeros_like(leaf[k]) if gr is None else gr) for k, gr in zip(names, grads)}
+    return g, res, total, out

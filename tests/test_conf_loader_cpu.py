@@ -34,10 +34,31 @@ def test_reference_style_conf_py(tmp_path):
     assert hp.batch_size == 16 and hp.hierarchy_levels == 8 and hp.n_nodes == 255 and hp.matching_type == "balanced"
     assert hp.nz_vae == 256 and hp.attach_cost_mdl and hp.attach_inv_mdl and hp.n_actions == 2
     assert hp.decoder_distribution == "discrete_logistic_mixture" and hp.untied_layers
-    assert "dataset_name" in ignored and "model" in ignored
+    assert "dataset_name" in ignored and trainer["model"] == "tree"          # configuration['model'] = TreeModel (gcp_builder.py:75)
     # nothing leaks into the interpreter's module table
     import sys
     assert "blox" not in sys.modules and "experiments" not in sys.modules
+
+
+def test_sequential_conf_selects_the_flat_model(tmp_path):
+    """experiments/prediction/25room/gcp_sequential/conf.py: base config gcp_sequential (configuration['model'] = SequentialModel,
+    hierarchy_levels 0, add_weighted_pixel_copy popped), 1024-wide LSTMs, free_nats 1, KL burn-in (not built: reported)"""
+    (tmp_path / "conf.py").write_text(textwrap.dedent('''
+        from blox import AttrDict
+        from gcp.planning.cem.cost_fcn import EuclideanPathLength
+        from experiments.prediction.base_configs import gcp_sequential as base_conf
+        configuration = AttrDict(base_conf.configuration)
+        configuration.update({'dataset_name': 'nav_25rooms', 'batch_size': 16, 'lr': 2e-4, 'metric_pruning_scheme': 'basic'})
+        model_config = AttrDict(base_conf.model_config)
+        model_config.update({'kl_weight_burn_in': 1e4, 'free_nats': 1, 'ngf': 16, 'nz_mid_lstm': 1024, 'n_lstm_layers': 3, 'nz_mid': 128,
+                             'nz_enc': 128, 'nz_vae': 256, 'regress_length': True, 'attach_state_regressor': True,
+                             'decoder_distribution': 'discrete_logistic_mixture'})
+        model_config.pop("add_weighted_pixel_copy")
+    '''))
+    hp, trainer, ignored = CL.load_conf(str(tmp_path), max_seq_len=80, img_sz=64)
+    assert trainer["model"] == "sequential" and trainer["lr"] == 2e-4
+    assert hp.nz_mid_lstm == 1024 and hp.free_nats == 1 and hp.hierarchy_levels == 7 and hp.max_seq_len == 80
+    assert "kl_weight_burn_in" in ignored
 
 
 def test_adaptive_base_config_and_errors(tmp_path):

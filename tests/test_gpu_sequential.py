@@ -57,3 +57,83 @@ def test_sequential_prior_sampling():
     hp, sd, model, inputs, dev_in, ref, out = _run("discrete_logistic_mixture", False, sample_prior=True)
     assert_close(out.dense_rec.encodings, ref["encodings"], 1e-4, 1e-3, "encodings")
     assert_close(out.dense_rec.images, ref["images"], 5e-5, 0, "images")
+
+
+def _train_setup(graph=True, **over):
+    import video_gcp_amd as V
+    from video_gcp_amd.sequential import GCPSequentialModel
+    from video_gcp_amd.training_sequential import SequentialTrainStep
+    hp = V.config("c1", nz_mid_lstm=128, lstm_init="zero", **over)
+    sd = V.init_params_sequential(hp, seed=1, randomize_affine=True)
+    model = GCPSequentialModel(hp, params=sd, device="cuda")
+    model.use_graph = graph
+    return hp, sd, model, SequentialTrainStep(model, lr=1e-3)
+
+
+@pytest.mark.parametrize("variant", ["B", "A"])
+def test_sequential_gradients_match_autograd(variant):
+    """Training step of the flat VRNN baseline (train.py:155-163 with configuration['model'] = SequentialModel,
+    sequential.py:13-131): every parameter gradient of the explicit backward pass through the T - 1 recurrent steps against torch
+    autograd over the oracle (stated tolerance as for the tree model: 1e-3 of the gradient's max-abs + 5e-7)."""
+    from oracle import gcp_sequential_oracle as S
+    hp, sd, model, tr = _train_setup()
+    inputs, noise, _ = make_inputs(hp, seed=7, variant=variant)
+    noise = noise[:, :hp.max_seq_len - 1].contiguous()
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    for _ in range(2):                                   # the second call replays the captured forward graph
+        out = tr.backward(dev_in, noise.cuda())
+    torch.cuda.synchronize()
+    gref, res, total, _ = S.gradients(sd, hp, inputs, noise)
+    assert abs(float(out.raw["losses"][5]) - float(total)) <= 1e-4 * abs(float(total))
+    got = tr.named_grads()
+    bad, trained = [], 0
+    for k, g in gref.items():
+        err, scale = float((got[k].cpu() - g).abs().max()), float(g.abs().max())
+        trained += scale > 0
+        if err > 1e-3 * scale + 5e-7:
+            bad.append((k, err, scale))
+    assert not bad, bad[:10]
+    # everything the three loss terms reach is trained: encoder, decoder, the three recurrent nets, the length predictor
+    for pre in ("encoder.", "decoder.", "dense_rec.lstm.cell.prior_lstm.", "dense_rec.lstm.cell.inf_lstm.", "dense_rec.lstm.cell.gen_lstm.",
+                "length_pred."):
+        ks = [k for k in gref if k.startswith(pre)]
+        assert ks and any(float(got[k].abs().max()) > 0 for k in ks), pre
+
+
+def test_sequential_two_training_steps():
+    """losses of two consecutive optimisation steps and the updated parameters against the oracle loop (RAdam)"""
+    from oracle import gcp_sequential_oracle as S
+    from oracle.radam_oracle import RAdamOracle
+    hp, sd, model, tr = _train_setup()
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    opt = RAdamOracle(lr=1e-3)
+    for step in range(2):
+        inputs, noise, _ = make_inputs(hp, seed=20 + step, variant="B")
+        noise = noise[:, :hp.max_seq_len - 1].contiguous()
+        out = tr.step({k: v.cuda() for k, v in inputs.items()}, noise.cuda())
+        torch.cuda.synchronize()
+        gref, res, total, _ = S.gradients(ref_sd, hp, inputs, noise)
+        assert abs(float(out.raw["losses"][5]) - float(total)) <= 1e-4 * abs(float(total)), step
+        opt.step(ref_sd, gref)
+        worst = max(float((model.sd[k].cpu() - ref_sd[k]).abs().max()) for k in gref)
+        assert worst <= 2e-3 * 1e-3 * (step + 1) + 1e-7, (step, worst)
+
+
+def test_sequential_training_c2_shapes_decreases_loss():
+    """full-size shapes of the 25-room gcp_sequential configuration (64x64, T=80; batch 4, nz_mid_lstm 512): finite gradients and a
+    falling loss on a fixed batch"""
+    import video_gcp_amd as V
+    from video_gcp_amd.sequential import GCPSequentialModel
+    from video_gcp_amd.training_sequential import SequentialTrainStep
+    hp = V.config("c2", batch_size=4, lstm_init="zero")
+    model = GCPSequentialModel(hp, params=V.init_params_sequential(hp, seed=2), device="cuda")
+    tr = SequentialTrainStep(model, lr=2e-3)
+    inputs, noise, _ = make_inputs(hp, seed=5, variant="B")
+    noise = noise[:, :hp.max_seq_len - 1].contiguous().cuda()
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    losses = []
+    for _ in range(6):
+        out = tr.step(dev_in, noise)
+        losses.append(float(out.raw["losses"][5]))
+    assert all(torch.isfinite(torch.tensor(losses))) and torch.isfinite(tr.grad).all()
+    assert losses[-1] < losses[0], losses

@@ -26,3 +26,25 @@ def test_trainer_epochs_checkpoint_and_resume(tmp_path):
     assert torch.equal(tr2.model.theta, theta_end)
     assert torch.equal(tr2.trainer.exp_avg, tr.trainer.exp_avg) and float(tr2.trainer.opt_state[0]) == 6.0
     assert abs(tr2.val() - val_end) <= 5e-3 * abs(val_end)      # same weights, fresh Gaussian draws for the latents
+
+
+def test_trainer_runs_the_flat_vrnn_baseline(tmp_path):
+    """configuration['model'] = SequentialModel (gcp_builder.py:75, experiments/prediction/base_configs/gcp_sequential.py): the same
+    entry point trains gcp_sequential — model class and training step are chosen from the configuration, checkpoints round-trip"""
+    import json
+    from video_gcp_amd.sequential import GCPSequentialModel
+    from video_gcp_amd.train import ModelTrainer, get_cmd_args
+    from video_gcp_amd.training_sequential import SequentialTrainStep
+    exp = tmp_path / "seq"
+    exp.mkdir()
+    (exp / "conf.json").write_text(json.dumps({"config": "c1", "model": "SequentialModel", "lr": 1e-3,
+                                               "overrides": {"nz_mid_lstm": 128, "lstm_init": "zero"}}))
+    argv = ["--path", str(exp), "--num_epochs", "1", "--batches_per_epoch", "4", "--log_outputs_interval", "1"]
+    tr = ModelTrainer(get_cmd_args(argv))
+    assert isinstance(tr.model, GCPSequentialModel) and isinstance(tr.trainer, SequentialTrainStep)
+    tr.run()
+    losses = [l for _, l in tr.log]
+    assert tr.global_step == 4 and all(torch.isfinite(torch.tensor(losses)))
+    assert os.path.exists(os.path.join(str(exp), "weights", "weights_ep0.pth"))
+    tr2 = ModelTrainer(get_cmd_args(argv + ["--resume", "latest", "--train", "0"]))
+    assert tr2.resume("latest") == 1 and torch.equal(tr2.model.theta, tr.model.theta)

@@ -52,7 +52,8 @@ _BASE_CONFIGS = {
                  dict(_BASE_TREE, matching_type="balanced")),
     "gcp_adaptive": (dict(model="TreeModel", logger="HierarchyLogger"),
                      dict(_BASE_TREE, matching_type="dtw_image", learn_matching_temp=False, attentive_inference=True)),
-    "gcp_sequential": (dict(model="SequentialModel", logger="Logger"), dict(dense_rec_type="svg", lstm_init="zero")),
+    "gcp_sequential": (dict(model="SequentialModel", logger="HierarchyLogger"),
+                       dict(one_step_planner="continuous", dense_rec_type="svg", hierarchy_levels=0, add_weighted_pixel_copy=True)),
 }
 
 
@@ -114,7 +115,15 @@ def exec_conf_py(path):
 
 # trainer keys (gcp_builder.py:_default_hparams) that the device trainer reads
 _TRAINER_KEYS = ("batch_size", "lr", "num_epochs", "adam_beta", "epoch_cycles_train", "seed", "gradient_clip", "top_of_100_eval",
-                 "metric_pruning_scheme")
+                 "metric_pruning_scheme", "optimizer", "momentum")
+
+
+def model_kind(configuration):
+    """configuration['model'] (gcp_builder.py:75: the class the trainer instantiates) -> 'sequential' (SequentialModel, the flat
+    VRNN baseline) or 'tree' (TreeModel).  The class arrives as a placeholder named like the reference's class, or as a string."""
+    v = configuration.get("model", "TreeModel")
+    name = v if isinstance(v, str) else getattr(v, "__name__", repr(v))
+    return "sequential" if "sequential" in name.lower() else "tree"
 # model_config keys that are settled by what this build implements (checked, not mapped)
 _FIXED = {"one_step_planner": ("sh_pred", "continuous"), "binding": ("loss",), "seq_enc": ("conv",), "tree_lstm": ("split_linear",),
           "dense_rec_type": ("node_prob", "svg", "none", None)}
@@ -151,9 +160,12 @@ def hparams_from_conf(configuration, model_config, **over):
     kw.update(over)
     if "hierarchy_levels" in kw and "max_seq_len" in kw and 2 ** int(kw["hierarchy_levels"]) - 1 < int(kw["max_seq_len"]):
         kw.pop("hierarchy_levels")        # a tree too small for the sequence length: fall back to ceil(log2(T)) (train.py:80-81)
+    if kw.get("hierarchy_levels", 1) == 0:
+        kw.pop("hierarchy_levels")        # the flat model's base config (base_configs/gcp_sequential.py) has no tree
     hp = GCPHParams(**kw)
     trainer = {k: configuration[k] for k in _TRAINER_KEYS if k in configuration}
-    ignored += [k for k in configuration if k not in _TRAINER_KEYS]
+    trainer["model"] = model_kind(configuration)
+    ignored += [k for k in configuration if k not in _TRAINER_KEYS and k != "model"]
     return hp, trainer, ignored
 
 
@@ -178,5 +190,7 @@ def load_conf(exp_dir, default="c2", name=None, **over):
             conf = json.load(open(js))
             ov = dict(conf.get("overrides", {}), **over)
             hp = named_config(name or conf.get("config", default), **ov)
-            return hp, {k: conf[k] for k in conf if k not in ("config", "overrides")}, []
+            tr = {k: conf[k] for k in conf if k not in ("config", "overrides")}
+            tr["model"] = model_kind(tr)
+            return hp, tr, []
     return named_config(name or default, **over), {}, []

@@ -2,7 +2,7 @@
 
 Mirrors /root/reference/gcp/prediction/models/sequential.py:13-131 (SequentialRecModule / SequentialModel) on top of the
 same encoder / decoder / head kernels as the tree model.  The VRNN cell (blox.torch.models.vrnn.VRNNCell, absent) follows
-this build's spec (oracle/gcp_sequential_oracle.py): three recurrent nets (embed Linear -> n LSTMCells -> out
+this build's spec (oracle/gcp_sequential_oracle.py; training: training_sequential.py): three recurrent nets (embed Linear -> n LSTMCells -> out
 Linear) with zero initial state, run T-1 steps from x_0 = e_0.  Each step is 16 small launches (batch rows = B); the prior
 chain runs on a side lane next to the posterior chain.  Weight streaming dominates (3 nets x 3 layers x 4H x 2H floats per
 step), so this path is HBM/L2 bound, not MFMA bound.
@@ -20,6 +20,7 @@ class GCPSequentialModel(GCPTreeModel):
     # the flat baseline is trained without the sampled inverse-model / cost-model pairs and always rolls out to the fed end_ind
     _has_aux_training = False
     _has_pred_length = False
+    _has_training = True              # training_sequential.SequentialTrainStep
 
     def _check_hp(self, hp):
         assert hp.lstm_init in ("zero", "mlp")          # the cell state always starts at zero (hyperparameters.py:96)

@@ -86,13 +86,23 @@ class ModelTrainer:
         nb = args.batches_per_epoch if args.batches_per_epoch is not None else conf.get("batches_per_epoch", 10)
         seed = 0 if args.deterministic else conf.get("seed", 0)
         # same initial weights on every rank (same seed) = the broadcast of DataParallel replicas ...
-        self.model = GCPTreeModel(hp, params=init_params(hp, seed=seed), device=self.device)
+        # configuration['model'] (gcp_builder.py:75) chooses the class: TreeModel or the flat VRNN baseline SequentialModel
+        # (experiments/prediction/base_configs/gcp_sequential.py)
+        self.model_kind = conf.get("model", "tree")
+        if self.model_kind == "sequential":
+            from .params import init_params_sequential
+            from .sequential import GCPSequentialModel
+            from .training_sequential import SequentialTrainStep
+            model_cls, init_fn, step_cls = GCPSequentialModel, init_params_sequential, SequentialTrainStep
+        else:
+            model_cls, init_fn, step_cls = GCPTreeModel, init_params, GCPTrainStep
+        self.model = model_cls(hp, params=init_fn(hp, seed=seed), device=self.device)
         # ... but a DIFFERENT stream of latent noise / auxiliary-model index draws per rank, as nn.DataParallel's replicas drew
         # different numbers for their different shards (gcp_builder.py:71-78); reproducible through `seed` / --deterministic
         torch.cuda.manual_seed(seed * max(self.world, 1) + self.rank + 1)
         pg = torch.distributed.group.WORLD if self.world > 1 else None
         lr = conf.get("lr") if conf.get("lr") is not None else 1e-3
-        self.trainer = GCPTrainStep(self.model, lr=lr, betas=(conf.get("adam_beta", 0.9), 0.999), process_group=pg)
+        self.trainer = step_cls(self.model, lr=lr, betas=(conf.get("adam_beta", 0.9), 0.999), process_group=pg)
         if not args.feed_random_data and train_loader is None:
             raise ValueError("no dataset reader ships with this build: pass --feed_random_data 1 or give ModelTrainer a loader")
         self.train_loader = train_loader or SyntheticLoader(hp, nb, 1000 + 100000 * self.rank, self.device)

@@ -787,11 +787,13 @@ class GCPTrainStep:
         plan.add(f"bw.accum:{tag}", self.m.lib.gcpx_tree_accum, C.byref(a))
 
     # ---- decoder ----
-    def _decoder_backward(self, plan, fplan, dMD, B):
+    def _decoder_backward(self, plan, fplan, dMD, B, maps=None):
+        """maps (models whose decoded frames are not tree nodes — the flat VRNN): dict(R = rows of dMD, row2src [R] int32 = the
+        decoded frame whose features row r of the head's weight gradient reads, frame2row [F] = row of frame f (-1: none),
+        row2frame [R] = its inverse (-1 for rows no frame maps to))."""
         m, hp, lib = self.m, self.m._hp, self.m.lib
         rec, o = fplan.rec, fplan.outs
         T, N, nz, L = hp.max_seq_len, hp.n_nodes, hp.nz_enc, hp.hierarchy_levels
-        PS = 2 ** L + 1
         S, pitch = hp.img_sz, m._head_pitch
         buf = m._buf
         dec = rec["dec"]
@@ -801,11 +803,13 @@ class GCPTrainStep:
         perm32.copy_(m._dlm_perm.to(torch.int32))
         # output head: weight gradient over the frames that carry a loss gradient, data gradient to every node frame.
         # balanced: the matched frames (row b*T+t of dMD <- node matched to frame t); adaptive: every node frame
-        all_frames = hp.adaptive
-        R = F if all_frames else B * T
+        all_frames = hp.adaptive and maps is None
+        R = maps["R"] if maps is not None else (F if all_frames else B * T)
         featA = buf("bw.featA", (R, S, S, ngf))
         a = m._conv_args([rec["head_src"]], R, S, S, S, S, ngf, ngf, self._zeros, self._zeros, featA)
-        if not all_frames:
+        if maps is not None:
+            a.src_row_map = maps["row2src"].data_ptr()
+        elif not all_frames:
             f2n_abs = buf("bw.f2n_abs", (B, T), torch.int32)
             plan.add("bw.f2n_abs", lib.gcpx_index_offset, o["frame2node"].data_ptr(), f2n_abs.data_ptr(), B, T, N)
             a.src_row_map = f2n_abs.data_ptr()
@@ -822,7 +826,10 @@ class GCPTrainStep:
         dA = buf("bw.dA.head", (F, S, S, ngf))
         a = m._conv_args([(dMD.data_ptr(), pitch, 1, None, None, rt.ACT_NONE)], F, S, S, S, S, ngf, ngf, self.bk["dec.head.wT"],
                          self._zeros, dA)
-        if not all_frames:
+        if maps is not None:
+            a.src_row_map = maps["frame2row"].data_ptr()
+            a.src_row_frames, a.n_src_rows = maps["row2frame"].data_ptr(), R
+        elif not all_frames:
             a.src_row_map = o["node2row"].data_ptr()
             # inverse map: the kernel walks the B*T matched rows (padded rows, which no node maps to, are -1)
             row2frame = buf("bw.row2frame", (B * T,), torch.int32)
@@ -873,8 +880,9 @@ class GCPTrainStep:
         ctop = m._c_top
         bn0 = rec["bn:dec.bn0"]
         dy0 = self._bn_bwd(plan, "dec.input", bn0, gin[0], gin[1], 0, gin[2], dec["d0"], F, 4, 4)
-        self._wgrad(plan, "dec.input", dy0.data_ptr(), 16 * ctop, F, 16 * ctop, _addr(fplan.outs["E"], nz), nz,
-                    self.g("decoder.net.input.conv.weight"), rpb=rpb, sb=PS * nz, sr=nz, wmap=rt.WMAP_CONVT, ntap=16, Cout=ctop)
+        es = dec["e_src"]                                  # row source of the decoded latents (tree: E slots 1 .. N; flat VRNN: x_1 .. x_{T-1})
+        self._wgrad(plan, "dec.input", dy0.data_ptr(), 16 * ctop, F, 16 * ctop, es.ptr, nz,
+                    self.g("decoder.net.input.conv.weight"), rpb=rpb, sb=es.sb, sr=es.sr, wmap=rt.WMAP_CONVT, ntap=16, Cout=ctop)
         dE_dec = buf("bw.dE_dec", (F, nz))
         self._dgemm(plan, "dec.input", [self._dense(dy0.data_ptr(), 16 * ctop, 16 * ctop, F)], F, nz, F, self.bk["dec.input.wT"],
                     dE_dec.data_ptr(), 0, nz)

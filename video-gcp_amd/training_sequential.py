@@ -91,7 +91,7 @@ class SequentialTrainStep(GCPTrainStep):
         dxh = [buf(f"bw.{net}.dxh{i}", (B, 2 * H)) for i in range(1, nl)]              # layers 1..: [dx | dh], reused every step
         DX0 = buf(f"bw.{net}.dxh0", (T - 1, B, 2 * H))                                 # layer 0: kept per step (embedding weight gradient)
         dtop = buf(f"bw.{net}.dtop", (B, H))
-        dcrec = [buf(f"bw.{net}.dc{i}", (B, H)) for i in range(nl)]
+        dcrec = [buf(f"bw.{net}.dc{i}", (B, 2 * H)) for i in range(nl)]                 # (pitch 2H: addressed with the strides of [h | c])
         for t in reversed(range(T - 1)):
             last = t == T - 2
             self._dgemm(plan, f"{net}{t}.out", [dout_of(t)], B, H, 1, Wt["out.wT"], dtop.data_ptr(), H, 0)
@@ -107,17 +107,15 @@ class SequentialTrainStep(GCPTrainStep):
                 prev_out = (DX0[t + 1] if i == 0 else dxh[i - 1]) if not last else None
                 a.dh_pos = _addr(prev_out, H) if prev_out is not None else None
                 a.dc_pos = dcrec[i].data_ptr() if not last else None
-                a.dgates, a.dc_prev, a.dcp_stride = dG[i][t].data_ptr(), dcrec[i].data_ptr(), H
+                # (dh_pos / dc_pos are addressed with the strides of c_new, 2H per row: the dh columns of [dx | dh] and the dc buffer
+                # have that pitch; a thread reads its dc_pos element before it overwrites it with dc_prev)
+                a.dgates, a.dc_prev, a.dcp_stride = dG[i][t].data_ptr(), dcrec[i].data_ptr(), 2 * H
                 a.M, a.H, a.rpb = B, H, 1
-                if a.dh_pos is not None:
-                    # dh_pos / dc_pos are addressed b * pb + j * prow with the strides of c_new (2H per row): the dh columns of [dx | dh]
-                    # have the same pitch; the dense dc buffer does not, so it gets its own pitch-2H twin below
-                    pass
                 plan.keep.append(a)
                 plan.add(f"bw.lstm:{net}{t}.{i}", lib.gcpx_lstm_bwd, C.byref(a))
                 self._dgemm(plan, f"{net}{t}.lstm{i}", [self._dense(dG[i][t].data_ptr(), 4 * H, 4 * H, B)], B, 2 * H, B, Wt[f"lstm{i}.wxhT"],
                             out_i.data_ptr(), 0, 2 * H)
-            self._dgemm(plan, f"{net}{t}.embed", [self._dense(DX0[t].data_ptr(), 2 * H, H, B)], B, in_dim, 1, Wt["embed.wT"],
+            self._dgemm(plan, f"{net}{t}.embed", [m._rowsrc(DX0[t].data_ptr(), 2 * H, 0, H)], B, in_dim, 1, Wt["embed.wT"],
                         _addr(dIn, t * in_dim), (T - 1) * in_dim, 0)
             yield t
         nrec.setdefault("dG", {})[net] = dG
