@@ -60,11 +60,14 @@ typedef enum gcpx_head_mode {
     GCPX_HEAD_DLM_MEAN = 1, /* discrete-logistic-mixture mean -> images NCHW [F][3][H][W]; nothing else written */
     GCPX_HEAD_DLM_BOTH = 2, /* both of the above */
     GCPX_HEAD_TANH_NCHW = 3, /* gaussian head: tanh(first 3 channels) -> images NCHW */
-    GCPX_HEAD_DLM_NLL = 4   /* mixture mean -> images, and for every frame f with raw_row_map[f] >= 0 the discretised-logistic-mixture
+    GCPX_HEAD_DLM_NLL = 4,  /* mixture mean -> images, and for every frame f with raw_row_map[f] >= 0 the discretised-logistic-mixture
                                negative log-likelihood of target row raw_row_map[f] (decoder.nll on the matched frames,
                                frame_binding.py:88-99), evaluated in the epilogue: nll_partial[i][row] = sum over the pixels of item i
                                (4 rows x 16 columns; (H / 4) * (W / 16) items per frame) — reduce over i with gcpx_reduce_partials.
                                No raw parameters are stored.  Split-f16 head only (wpk_split set) */
+    GCPX_HEAD_DLM_NLL_GRAD = 5 /* training forward: as GCPX_HEAD_DLM_NLL, and row raw_row_map[f] of `out` ([rows][H][W][112]) receives
+                               d (nll_scale * nll_row_weight[row] * NLL) / d parameters — what gcpx_dlm_nll_bwd computes from stored
+                               parameters.  Rows no frame maps to are not written (zero them: gcpx_zero_unmapped_rows) */
 } gcpx_head_mode;
 
 typedef struct gcpx_conv_args {
@@ -107,6 +110,9 @@ typedef struct gcpx_conv_args {
     int32_t nll_rows;       /* GCPX_HEAD_DLM_NLL: rows of nll_target / row pitch of nll_partial */
     const float* nll_target; /* dev: NCHW [nll_rows][3][H][W] ground-truth frames in [-1, 1] (traj_seq) */
     float* nll_partial;     /* dev: [(H / 4) * (W / 16)][nll_rows]; rows no frame maps to are not written */
+    const float* nll_row_weight; /* dev: [nll_rows] or NULL (GCPX_HEAD_DLM_NLL_GRAD): per-row factor of the gradient (pad_mask) */
+    float nll_scale;        /* GCPX_HEAD_DLM_NLL_GRAD: d total / d nll_bt = w_rec / (B * prod(traj_seq.shape[1:])) (base_gcp.py:299-301) */
+    int32_t _pad3;
 } gcpx_conv_args;
 
 typedef enum gcpx_split_layout { GCPX_SPLIT_PLAIN = 0, GCPX_SPLIT_ROWFOLD = 1 } gcpx_split_layout;
@@ -554,6 +560,9 @@ int gcpx_add_rows(float* dst, int64_t dst_sb, int64_t dst_sr, const float* src1,
    (sequential.py:49-54 backward): x_t / context slices of the per-step embedding gradients */
 int gcpx_rows_strided(float* dst, int64_t dst_sb, int64_t dst_sr, const float* src, int64_t src_sb, int64_t src_sr, int32_t B, int32_t rpb,
                       int32_t width, int32_t mode, void* stream);
+/* rows r of `row_floats` floats with row2frame[r] < 0 are set to zero (rows of the matched-frame gradient no decoded frame maps to:
+   padded frames t > end_ind; the head kernel in GCPX_HEAD_DLM_NLL_GRAD mode writes only mapped rows) */
+int gcpx_zero_unmapped_rows(float* ptr, int64_t row_floats, const int32_t* row2frame, int32_t rows, void* stream);
 /* out[b][t] = idx[b][t] + b*stride (per-sequence node index -> absolute frame index) */
 int gcpx_index_offset(const int32_t* idx, int32_t* out, int32_t B, int32_t T, int32_t stride, void* stream);
 /* inv[r] = i for every i < n with fwd[i] = r >= 0 (fwd injective on its non-negative entries), -1 for rows nobody maps to:

@@ -223,6 +223,13 @@ __global__ void __launch_bounds__(256) add_rows_kernel(float* __restrict__ dst, 
     dst[(size_t)b * dst_sb + (size_t)j * dst_sr + c] += v;
 }
 
+__global__ void __launch_bounds__(256) zero_unmapped_rows_kernel(float4* __restrict__ p, const long long row_f4, const int* __restrict__ row2frame) {
+    const int r = blockIdx.y;
+    if (row2frame[r] >= 0) return;
+    float4* row = p + (size_t)r * row_f4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < row_f4; i += (long long)gridDim.x * 256) row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // rows (b, j) of `width` floats between two strided layouts.  mode 0: dst = src; 1: dst += src; 2: dst[b] += sum over j of src[b][j]
 // (dst_sr unused; the sum runs over j in order: deterministic)
 __global__ void __launch_bounds__(256) rows_strided_kernel(float* __restrict__ dst, const long long dst_sb, const long long dst_sr,
@@ -882,6 +889,15 @@ extern "C" int gcpx_kl_bwd_weighted(const float* qz, const float* pz, float* dqz
     const int total = B * N * nz;
     hipLaunchKernelGGL(kl_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, qz, pz, dqz, dpz, N, nz,
                        (long long)batch_stride, (long long)node_stride, free_nats, coef, total, node_weight, (long long)weight_bstride);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_zero_unmapped_rows(float* ptr, int64_t row_floats, const int32_t* row2frame, int32_t rows, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(ptr && row2frame && rows > 0 && row_floats > 0 && row_floats % 4 == 0, "bad arguments");
+    hipLaunchKernelGGL(zero_unmapped_rows_kernel, dim3(64, rows), dim3(256), 0, stream, reinterpret_cast<float4*>(ptr), (long long)(row_floats / 4),
+                       row2frame);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -144,10 +144,13 @@ __device__ __forceinline__ void finish_tiles(const gcpx_conv_args& a, const floa
 __device__ __forceinline__ float sigmoid_fast_s(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float softplus_s(float x) { return x > 20.f ? x : __logf(1.f + __expf(x)); }
 
-// NLL: head mode GCPX_HEAD_DLM_NLL — frames matched to a ground-truth frame (raw_row_map entry >= 0) additionally evaluate the
+// NLL = 1: head mode GCPX_HEAD_DLM_NLL — frames matched to a ground-truth frame (raw_row_map entry >= 0) additionally evaluate the
 // discretised-logistic-mixture likelihood of that frame in the epilogue and write one partial sum per item
 // (nll_partial[item of the frame][row]); their raw parameters are never stored (frame_binding.py:88-99 -> decoder.nll).
-template <bool NLL>
+// NLL = 2: GCPX_HEAD_DLM_NLL_GRAD (training forward) — the same, and the gradient of (nll_scale x row weight x) that likelihood
+// w.r.t. the 100 parameters of every pixel goes to row raw_row_map[f] of `out` (112-slot layout): what gcpx_dlm_nll_bwd computes from
+// the stored parameters, without storing them.
+template <int NLL>
 __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_conv_args a, const int items_per_wave,
                                                                     const int nitems) {
     using Cfg = SplitHeadCfg;
@@ -338,7 +341,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
             f32x4 acc[5][4];
             mfma_tiles<0, 5>(wl, reg, tapoff, lane, acc);
             finish_tiles<0, 5>(a, bias_l, acc, inv, store_raw, orow, y0, x0, j, q);
-            if (mode == GCPX_HEAD_DLM_MEAN || mode == GCPX_HEAD_DLM_BOTH || mode == GCPX_HEAD_DLM_NLL) {
+            if (mode == GCPX_HEAD_DLM_MEAN || mode == GCPX_HEAD_DLM_BOTH || mode == GCPX_HEAD_DLM_NLL || mode == GCPX_HEAD_DLM_NLL_GRAD) {
                 // kernel channel order and the lane exchange: see conv3x3_head_kernel (conv3x3.hip)
 #pragma unroll
                 for (int ct = 0; ct < 5; ++ct)
@@ -388,6 +391,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                         const float4 st0 = stash[(2 * s2) * 64], st1 = stash[(2 * s2 + 1) * 64];
                         const float lsg[5] = {st0.x, st0.z, st1.x, st1.z, ls4[s2][0]}, lsb[5] = {st0.y, st0.w, st1.y, st1.w, ls4[s2][1]};
                         float lp[5];
+                        constexpr int NG = NLL == 2 ? 5 : 1;       // gradient bookkeeping only in the training variant
+                        float gm[NG][3], gs[NG][3], cf[NG][3], lgk[NG];
 #pragma unroll
                         for (int ct = 0; ct < 5; ++ct) {
                             const f32x4 e = acc[ct][s2], o = acc[ct][s2 + 2];
@@ -396,20 +401,45 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                             const float x[3] = {xr, xg, xb};
                             const float lsr[3] = {o[3], lsg[ct], lsb[ct]};
                             float sacc = e[0] - lse_logits;
+                            if constexpr (NLL == 2) { cf[ct][0] = c0; cf[ct][1] = c1; cf[ct][2] = c2; lgk[ct] = e[0]; }
 #pragma unroll
                             for (int c = 0; c < 3; ++c) {
                                 const float ls = fmaxf(lsr[c], -7.f);
                                 const float xc = x[c] - mean[c];
                                 const float is = __expf(-ls);
                                 const float plus_in = is * (xc + 1.f / 255.f), min_in = is * (xc - 1.f / 255.f);
-                                const float cdf_delta = sigmoid_fast_s(plus_in) - sigmoid_fast_s(min_in);
+                                const float sp = sigmoid_fast_s(plus_in), sm = sigmoid_fast_s(min_in);
+                                const float cdf_delta = sp - sm;
                                 float v = __logf(fmaxf(cdf_delta, 1e-12f));
+                                float dm = 0.f, ds = 0.f;          // d v / d mean, d v / d log_scale (dlm_nll_bwd_kernel, csrc/backward.hip)
+                                if constexpr (NLL == 2) {
+                                    const float pp_ = sp * (1.f - sp), pm_ = sm * (1.f - sm);
+                                    const float rcd = __builtin_amdgcn_rcpf(cdf_delta);
+                                    dm = -is * (pp_ - pm_) * rcd;
+                                    ds = -(plus_in * pp_ - min_in * pm_) * rcd;
+                                }
                                 const bool edge = x[c] < -0.999f || x[c] > 0.999f || !(cdf_delta > 1e-5f);
                                 if (__any(edge)) {              // saturated pixels / vanishing bins: rare, evaluated only when some lane needs them
                                     const float mid_in = is * xc;
-                                    if (x[c] < -0.999f) v = plus_in - softplus_s(plus_in);
-                                    else if (x[c] > 0.999f) v = -softplus_s(min_in);
-                                    else if (!(cdf_delta > 1e-5f)) v = mid_in - ls - 2.f * softplus_s(mid_in) - 4.8481163864f;   // log(127.5)
+                                    if (x[c] < -0.999f) {
+                                        v = plus_in - softplus_s(plus_in);
+                                        if constexpr (NLL == 2) { dm = -is * (1.f - sp); ds = -plus_in * (1.f - sp); }
+                                    } else if (x[c] > 0.999f) {
+                                        v = -softplus_s(min_in);
+                                        if constexpr (NLL == 2) { dm = is * sm; ds = min_in * sm; }
+                                    } else if (!(cdf_delta > 1e-5f)) {
+                                        v = mid_in - ls - 2.f * softplus_s(mid_in) - 4.8481163864f;   // log(127.5)
+                                        if constexpr (NLL == 2) {
+                                            const float smid = sigmoid_fast_s(mid_in);
+                                            dm = -is * (1.f - 2.f * smid);
+                                            ds = -mid_in * (1.f - 2.f * smid) - 1.f;
+                                        }
+                                    }
+                                }
+                                if constexpr (NLL == 2) {
+                                    if (lsr[c] < -7.f) ds = 0.f;   // clamp(min=-7) blocks the gradient
+                                    gm[ct][c] = dm;
+                                    gs[ct][c] = ds;
                                 }
                                 sacc += v;
                             }
@@ -422,6 +452,35 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                         for (int ct = 0; ct < 5; ++ct) se += __expf(lp[ct] - mx);
                         se += __shfl_xor(se, 32);
                         nll_item -= mx + __logf(se);          // (both lanes of a pixel hold it; only q < 2 is summed below)
+                        if constexpr (NLL == 2) {
+                            // ---- gradient rows: slots 8k .. 8k+7 of this lane's mixtures k = 2 ct + (q >> 1), then its g / b log-scales ----
+                            const float coef = a.nll_scale * (a.nll_row_weight ? a.nll_row_weight[orow] : 1.f);
+                            const float inv_se = __builtin_amdgcn_rcpf(se);
+                            float* drow = a.out + ((size_t)orow * plane + (size_t)(y0 + s2 + 2 * (q & 1)) * W + (x0 + j)) * a.out_pitch;
+                            const int h = q >> 1;
+                            float glg[5], glb[5];
+#pragma unroll
+                            for (int ct = 0; ct < 5; ++ct) {
+                                const float w = __expf(lp[ct] - mx) * inv_se;                 // responsibility of the mixture
+                                const float pik = __expf(lgk[ct] - lse_logits);
+                                const float gw = -coef * w;                                   // d (-logsumexp) / d s_k
+                                const float g1 = gw * gm[ct][1], g2 = gw * gm[ct][2];
+                                float* dk = drow + 8 * (2 * ct + h);
+                                *reinterpret_cast<float4*>(dk) = make_float4(coef * (pik - w), gw * gm[ct][0], g1, g2);
+                                *reinterpret_cast<float4*>(dk + 4) = make_float4(g1 * xr * (1.f - cf[ct][0] * cf[ct][0]), g2 * xr * (1.f - cf[ct][1] * cf[ct][1]),
+                                                                                 g2 * xg * (1.f - cf[ct][2] * cf[ct][2]), gw * gs[ct][0]);
+                                glg[ct] = gw * gs[ct][1];
+                                glb[ct] = gw * gs[ct][2];
+                            }
+                            // packing.dlm_log_scale_slot: ct = 0, 1 -> lane group 2 h of tile 5, ct = 2, 3 -> 2 h + 1, ct = 4 -> slots 96 + 2 h
+                            *reinterpret_cast<float4*>(drow + 80 + 8 * h) = make_float4(glg[0], glb[0], glg[1], glb[1]);
+                            *reinterpret_cast<float4*>(drow + 84 + 8 * h) = make_float4(glg[2], glb[2], glg[3], glb[3]);
+                            *reinterpret_cast<float2*>(drow + 96 + 2 * h) = make_float2(glg[4], glb[4]);
+                            if (h == 0) {
+#pragma unroll
+                                for (int z = 100; z < 112; z += 4) *reinterpret_cast<float4*>(drow + z) = make_float4(0.f, 0.f, 0.f, 0.f);
+                            }
+                        }
                     }
                 }
             }
@@ -1519,17 +1578,19 @@ __global__ void __launch_bounds__(256) fold_up_weights_kernel(const float* __res
 // Called by conv3x3_dispatch (conv3x3.hip) for the 100-channel mixture head when the caller supplies split-f16 weights.
 int gcpx_launch_head_split(const gcpx_conv_args* a, hipStream_t stream) {
     using Cfg = SplitHeadCfg;
-    const bool nll = a->head_mode == GCPX_HEAD_DLM_NLL;
+    const int nll = a->head_mode == GCPX_HEAD_DLM_NLL ? 1 : (a->head_mode == GCPX_HEAD_DLM_NLL_GRAD ? 2 : 0);
     if (nll) {
         GCPX_CHECK_ARG(a->nll_target && a->nll_partial && a->nll_rows > 0 && a->raw_row_map, "GCPX_HEAD_DLM_NLL needs nll_target, nll_partial, nll_rows and raw_row_map");
         GCPX_CHECK_ARG(a->out_pitch == 112, "the fused likelihood is written for the 112-slot layout of the 10-mixture head");
+        GCPX_CHECK_ARG(nll == 1 || a->out, "GCPX_HEAD_DLM_NLL_GRAD writes the parameter gradient to `out`");
     }
-    auto kern = nll ? conv3x3_head_split_kernel<true> : conv3x3_head_split_kernel<false>;
+    auto kern = nll == 2 ? conv3x3_head_split_kernel<2> : (nll == 1 ? conv3x3_head_split_kernel<1> : conv3x3_head_split_kernel<0>);
     const int lds = nll ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* ks[2] = {reinterpret_cast<const void*>(conv3x3_head_split_kernel<false>), reinterpret_cast<const void*>(conv3x3_head_split_kernel<true>)};
-        for (int i = 0; i < 2; ++i) {
+        const void* ks[3] = {reinterpret_cast<const void*>(conv3x3_head_split_kernel<0>), reinterpret_cast<const void*>(conv3x3_head_split_kernel<1>),
+                             reinterpret_cast<const void*>(conv3x3_head_split_kernel<2>)};
+        for (int i = 0; i < 3; ++i) {
             hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, i ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES);
             if (e != hipSuccess) {
                 gcpx_set_error("conv3x3 split head: hipFuncSetAttribute(%d B LDS): %s", i ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES, hipGetErrorString(e));

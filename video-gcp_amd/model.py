@@ -201,6 +201,18 @@ class GCPTreeModel:
     def _n_latents(self):
         return self._hp.n_nodes
 
+    def _head_nll_fusable(self):
+        hp = self._hp
+        return (self.fused_head_nll and self.split_f16 and "dec.head" in getattr(self, "pk_split", {}) and hp.img_sz % 16 == 0 and
+                hp.decoder_distribution == "discrete_logistic_mixture" and not self.materialize_distr)
+
+    def _head_grad_fused(self, key):
+        """training forward (posterior path with losses, backward to follow) of the balanced model: the head kernel writes the
+        likelihood gradient itself"""
+        has_traj, sample_prior, phase, with_loss = key[1], key[3], key[4], key[7]
+        return bool(self.save_for_backward and with_loss and has_traj and not sample_prior and phase == "train" and
+                    not self._hp.adaptive and self._head_nll_fusable() and type(self)._build_plan is GCPTreeModel._build_plan)
+
     def _default_params(self, hp, seed):
         return init_params(hp, seed)
 
@@ -926,6 +938,14 @@ class GCPTreeModel:
                 plan.add("balanced_binding", lib.gcpx_balanced_binding, tin["end_ind"].data_ptr(), B, L, T, node_t.data_ptr(),
                          leave.data_ptr(), f2n.data_ptr(), etrow.data_ptr(), seq_len.data_ptr(), node2row.data_ptr())
                 plan.add("compact_index", lib.gcpx_compact_index, leave.data_ptr(), B, N, T, kept_idx.data_ptr())
+                if self._head_grad_fused(key):
+                    # training forward with the likelihood gradient written by the head kernel (GCPX_HEAD_DLM_NLL_GRAD): the rows of
+                    # the matched-frame gradient that no node maps to (padded frames) are zeroed here, early and on this side lane
+                    S_ = hp.img_sz
+                    dMD = self._buf("bw.dMD", (B * T, S_, S_, self._head_pitch))
+                    r2f = self._buf("row2frame", (B * T,), torch.int32)
+                    plan.add("row2frame", lib.gcpx_index_inverse, node2row.data_ptr(), B * N, r2f.data_ptr(), B * T)
+                    plan.add("zero_unmapped", lib.gcpx_zero_unmapped_rows, dMD.data_ptr(), S_ * S_ * self._head_pitch, r2f.data_ptr(), B * T)
 
         # ---- run_encoder (base_gcp.py:184-213) ----
         enc_traj = inf_enc = None
@@ -1161,8 +1181,14 @@ class GCPTreeModel:
                     # (adaptive training: the backward of the mixture mean needs the raw parameters of every node)
                     mode, distr = rt.HEAD_DLM_BOTH, self._buf("distr_df", (B, N, S, S, self._head_pitch))
                     head_out = distr
-                elif with_loss and not adaptive and not self.save_for_backward and self.fused_head_nll and self.split_f16 \
-                        and "dec.head" in self.pk_split and S % 16 == 0:
+                elif self._head_grad_fused(key):
+                    # training forward: likelihood AND its gradient w.r.t. the parameters in the head's epilogue
+                    # (GCPX_HEAD_DLM_NLL_GRAD): the parameters themselves are never stored, gcpx_dlm_nll_bwd's pass over them is gone
+                    mode, row_map = rt.HEAD_DLM_NLL_GRAD, node2row
+                    head_out = self._buf("bw.dMD", (B * T, S, S, self._head_pitch))
+                    fused_nll = self._buf("nll_partial", ((S // 4) * (S // 16), B * T), zero=True)
+                    plan.rec["nll_bwd_fused"] = plan.rec["head_grad_fused"] = True
+                elif with_loss and not adaptive and not self.save_for_backward and self._head_nll_fusable():
                     # forward with losses, no backward to follow: the likelihood of the matched frames is evaluated in the head's
                     # epilogue (GCPX_HEAD_DLM_NLL) — their 2.35 GB of raw parameters (c2) are neither written nor read back
                     mode, row_map = rt.HEAD_DLM_NLL, node2row
@@ -1179,6 +1205,10 @@ class GCPTreeModel:
             a.raw_row_map = row_map.data_ptr() if row_map is not None else None
             if fused_nll is not None:
                 a.nll_target, a.nll_partial, a.nll_rows = tin["traj_seq"].data_ptr(), fused_nll.data_ptr(), B * T
+                if mode == rt.HEAD_DLM_NLL_GRAD:
+                    # d total / d nll_bt = w_rec * pad_mask / (B * prod(traj_seq.shape[1:])) (base_gcp.py:299-301)
+                    a.nll_row_weight = tin["pad_mask"].data_ptr()
+                    a.nll_scale = hp.dense_img_rec_weight / (B * float(T * hp.input_nc * S * S))
             self._set_split(a, "dec.head")
             plan.keep.append(a)
             if heads_lane:

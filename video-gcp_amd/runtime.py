@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgcpx.so")
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
-HEAD_RAW, HEAD_DLM_MEAN, HEAD_DLM_BOTH, HEAD_TANH_NCHW, HEAD_DLM_NLL = 0, 1, 2, 3, 4
+HEAD_RAW, HEAD_DLM_MEAN, HEAD_DLM_BOTH, HEAD_TANH_NCHW, HEAD_DLM_NLL, HEAD_DLM_NLL_GRAD = 0, 1, 2, 3, 4, 5
 SPLIT_PLAIN, SPLIT_ROWFOLD = 0, 1
 EPI_NONE, EPI_LRELU, EPI_LSTM, EPI_GAUSS_SAMPLE = 0, 1, 2, 3
 MLP_PLAIN, MLP_GAUSS = 0, 1
@@ -29,7 +29,8 @@ class ConvArgs(C.Structure):
                 ("Wout", i32), ("Cin", i32), ("Cout", i32), ("out_pitch", i32), ("upsample", i32), ("out_act", i32),
                 ("head_mode", i32), ("wpk", vp), ("bias", vp), ("out", vp), ("images", vp), ("stats_partial", vp),
                 ("raw_row_map", vp), ("src_row_map", vp), ("src_row_frames", vp), ("n_src_rows", i32), ("w_split_log2", i32), ("wpk_split", vp), ("w_split_log2_dev", vp),
-                ("split_layout", i32), ("nll_rows", i32), ("nll_target", vp), ("nll_partial", vp)]
+                ("split_layout", i32), ("nll_rows", i32), ("nll_target", vp), ("nll_partial", vp), ("nll_row_weight", vp),
+                ("nll_scale", C.c_float), ("_pad3", i32)]
 
 
 class LossArgs(C.Structure):
@@ -162,6 +163,7 @@ SYMBOLS = [
     ("gcpx_tree_accum", C.c_int, [C.POINTER(TreeAccumArgs), vp]),
     ("gcpx_timestep_scatter", C.c_int, [vp, i64, i64, vp, vp, i32, i32, i32, i32, vp]),
     ("gcpx_add_rows", C.c_int, [vp, i64, i64, vp, vp, i32, i32, i32, vp]),
+    ("gcpx_zero_unmapped_rows", C.c_int, [vp, i64, vp, i32, vp]),
     ("gcpx_index_offset", C.c_int, [vp, vp, i32, i32, i32, vp]),
     ("gcpx_index_inverse", C.c_int, [vp, i32, vp, i32, vp]),
     ("gcpx_act_bwd", C.c_int, [C.POINTER(ActBwdArgs), vp]),

@@ -818,9 +818,14 @@ class GCPTrainStep:
         self._side(plan, "bw.stage:dec.head", lib.gcpx_conv_stage, C.byref(a))
         self._wgrad_conv3(plan, "dec.head", dMD.data_ptr(), pitch, featA.data_ptr(), R, S, S, ngf, pitch,
                           self.g("decoder.gen_head.conv.weight"), n_map=perm32)
-        # bias: per-frame column sums come out of the loss-gradient kernel
-        self._colsum(plan, "dec.head", buf("bw.dMD.colsum", (R, pitch)).data_ptr(), pitch, R, pitch,
-                     self.g("decoder.gen_head.conv.bias"), n_map=perm32)
+        if rec.get("head_grad_fused"):
+            # the head kernel wrote the gradient rows itself: the bias gradient is their column sum over every pixel (a side-lane pass
+            # over dMD next to the weight gradient, which reads the same rows)
+            self._colsum(plan, "dec.head", dMD.data_ptr(), pitch, R * S * S, pitch, self.g("decoder.gen_head.conv.bias"), n_map=perm32)
+        else:
+            # bias: per-frame column sums come out of the loss-gradient kernel
+            self._colsum(plan, "dec.head", buf("bw.dMD.colsum", (R, pitch)).data_ptr(), pitch, R, pitch,
+                         self.g("decoder.gen_head.conv.bias"), n_map=perm32)
         if self.early_fork:
             self._flush(plan)
         dA = buf("bw.dA.head", (F, S, S, ngf))
