@@ -34,8 +34,28 @@ from . import aux_models_oracle as AX
 # ---------------------------------------------------------------------------------------------------
 # building blocks (this build's spec of the absent blox modules)
 # ---------------------------------------------------------------------------------------------------
+# Kink probe for the gradient-parity tests.  The loss is only piecewise smooth in the parameters: a LeakyReLU unit whose
+# pre-activation lies within two implementations' rounding difference of zero may be differentiated on either side.  With
+# KINKS = {"tol": t} every _lrelu call records the units with |pre-activation| < t as (call number, flat index, value) in
+# KINKS["found"]; KINKS["force"] = {(call, index): +1 | -1} evaluates exactly those units on the chosen side (value AND slope), so
+# a test can ask whether a gradient equals the oracle's for SOME assignment of the ambiguous units.  None (default): plain LeakyReLU.
+KINKS = None
+
+
 def _lrelu(x, hp):
-    return F.leaky_relu(x, hp.leaky_slope)
+    if KINKS is None:
+        return F.leaky_relu(x, hp.leaky_slope)
+    call = KINKS["calls"] = KINKS.get("calls", -1) + 1
+    flat = x.detach().reshape(-1)
+    for i in torch.nonzero(flat.abs() < KINKS["tol"]).reshape(-1).tolist():
+        KINKS.setdefault("found", []).append((call, i, float(flat[i])))
+    y = F.leaky_relu(x, hp.leaky_slope)
+    forced = [(i, sgn) for (c, i), sgn in KINKS.get("force", {}).items() if c == call]
+    if forced:
+        idx = torch.tensor([i for i, _ in forced])
+        slope = torch.tensor([1.0 if sgn > 0 else hp.leaky_slope for _, sgn in forced], dtype=x.dtype)
+        y = y.reshape(-1).index_copy(0, idx, x.reshape(-1)[idx] * slope).reshape(x.shape)
+    return y
 
 
 def _bn(x, sd, prefix, hp, training):

@@ -89,6 +89,44 @@ def test_c2_forward_batch16_running_stats_vs_oracle_slice():
     assert_close(out.seq_len_logits[idx.cuda()], ref["seq_len_logits"], LAT_ATOL, LAT_RTOL, "seq_len_logits")
 
 
+def test_c2_split_f16_costs_nothing_against_a_float64_oracle():
+    """What the split-f16 kernels cost at MODEL level (the kernel tests bound each kernel against float64 next to its exact-f32 twin):
+    the c2 forward (64x64, T=80, L=7; two sequences, running-stat BatchNorm so that the slice is the model) on the split build and on
+    the exact-f32 build (GCPX_EXACT_F32) against the oracle evaluated in FLOAT64.  Pixel error of the split build: rms <= 1.5x and
+    max <= 2x the exact build's (+1e-7); ELBO terms (dense_img_rec, kl): both builds within 2e-5 relative of float64, the split build
+    no further off than 2x the exact build + 5e-6."""
+    from oracle import gcp_model_oracle as O
+    hp, sd, model = _build("c2", batch_size=2)
+    model.eval()
+    inputs, noise, _ = make_inputs(hp, seed=9, variant="B")
+    d = lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t
+    with torch.no_grad():
+        sd64 = {k: d(v) for k, v in sd.items()}
+        in64 = {k: d(v) for k, v in inputs.items()}
+        ref = O.forward(sd64, hp, in64, noise=d(noise), training_bn=False)
+        ref_losses, _ = O.losses(sd64, hp, in64, ref)
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    res = {}
+    assert model.split_f16
+    for name in ("split", "exact"):
+        model.split_f16 = name == "split"
+        model._clear_plans()
+        out = model(dev_in, "train", noise=noise.cuda())
+        losses = model.loss(dev_in, out)
+        torch.cuda.synchronize()
+        res[name] = ((out.tree.bf.images.double().cpu() - ref["tree_bf"]["images"]).abs(),
+                     {k: abs(float(losses[k].value) - float(ref_losses[k][0])) / abs(float(ref_losses[k][0])) for k in ("dense_img_rec", "kl")})
+    model.split_f16 = True
+    model._clear_plans()
+    es, ee = res["split"][0], res["exact"][0]
+    assert float(es.max()) <= PIX_ATOL and float(ee.max()) <= PIX_ATOL
+    assert float(es.pow(2).mean().sqrt()) <= 1.5 * float(ee.pow(2).mean().sqrt()) + 1e-8, (float(es.pow(2).mean().sqrt()), float(ee.pow(2).mean().sqrt()))
+    assert float(es.max()) <= 2.0 * float(ee.max()) + 1e-7, (float(es.max()), float(ee.max()))
+    for k in ("dense_img_rec", "kl"):
+        assert res["split"][1][k] <= 2e-5 and res["exact"][1][k] <= 2e-5, (k, res["split"][1], res["exact"][1])
+        assert res["split"][1][k] <= 2.0 * res["exact"][1][k] + 5e-6, (k, res["split"][1], res["exact"][1])
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # configs[2]: one rank's shard of the 128-sequence minibatch
 # ------------------------------------------------------------------------------------------------------------------------

@@ -59,29 +59,58 @@ def _grad_errors(gref, got):
     return {k: float((got[k].cpu() - g).abs().max()) / float(g.abs().max()) for k, g in gref.items() if float(g.abs().max()) > 1e-6}
 
 
-def test_gradients_full_length_sequences_c1():
-    """variant A: every sequence uses all T frames (the planner's shape, cem_simulator.py:22).
-
-    Three input seeds.  The loss is only piecewise smooth (LeakyReLU in every Predictor and conv block): when some unit's
-    pre-activation lies within the two implementations' rounding difference (~1e-6) of zero, HIP and the CPU oracle differentiate on
-    different sides of the kink and the gradients of that unit's layer and of everything upstream differ by a percent or two while
-    every forward value agrees to 1e-6.  Measured over seeds 3..9 (tools/grad_split_probe.py): 1e-5..5e-5 on most seeds, 1e-3 on
-    seed 6 and 6e-3 on seed 8 with the exact-f32 encoder kernels, 2e-2 on seed 3 with the split-f16 ones — same phenomenon, different
-    unlucky seed.  So: every seed within 5e-2 (a wrong kernel or a missing term is off by O(1)), and at least two of the three within
-    the 1e-3 stated at the top of this file."""
+def _oracle_gradients_f64(sd, hp, inputs, noise, tol=None, force=None):
+    """the oracle's gradients in float64 with the LeakyReLU kink probe (oracle.gcp_model_oracle.KINKS): returns (gradients, units with
+    |pre-activation| < tol)"""
     from oracle import gcp_model_oracle as O
-    tight = 0
+    d = lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t
+    O.KINKS = {"tol": tol if tol is not None else 0.0, "force": force or {}}
+    try:
+        g, _, _, _ = O.gradients({k: d(v) for k, v in sd.items()}, hp, {k: d(v) for k, v in inputs.items()}, d(noise))
+        found = list(O.KINKS.get("found", []))
+    finally:
+        O.KINKS = None
+    return {k: v.float() for k, v in g.items()}, found
+
+
+def test_gradients_full_length_sequences_c1():
+    """variant A: every sequence uses all T frames (the planner's shape, cem_simulator.py:22), three input seeds, every parameter
+    gradient within the 1e-3 stated at the top of this file — with the one exception the loss itself has: it is only piecewise smooth
+    (LeakyReLU in every Predictor and conv block), and a unit whose pre-activation lies within the implementations' rounding
+    difference of zero is differentiated on one side by the HIP kernels and possibly on the other by the oracle.  That is not
+    asserted away with a loose bound but checked.  The oracle runs in float64 with a kink probe that lists the units with
+    |pre-activation| < 5e-6 (a few f32 roundings of O(1) activations).  When the plain comparison misses 1e-3, each listed unit is
+    flipped alone (one oracle run each; flips act additively on the gradient to first order), the flips that explain the residual are
+    selected by projection, and ONE more oracle run with exactly those units on the other side must match the HIP gradient to 1e-3 in
+    every parameter; the failure message names the units.  A seed without such units has no excuse."""
+    flat = lambda g, keys: torch.cat([g[k].reshape(-1).double().cpu() / (float(gref[k].abs().max()) + 1e-30) for k in keys])
     for seed in (3, 5, 7):
         hp, sd, model, tr = _setup("c1", False, batch_size=3)
         inputs, noise, _ = make_inputs(hp, seed=seed, variant="A")
         tr.backward({k: v.cuda() for k, v in inputs.items()}, noise.cuda())
         torch.cuda.synchronize()
-        gref, _, _, _ = O.gradients(sd, hp, inputs, noise)
-        err = _grad_errors(gref, tr.named_grads())
+        got = tr.named_grads()
+        gref, kinks = _oracle_gradients_f64(sd, hp, inputs, noise, tol=5e-6)
+        err = _grad_errors(gref, got)
         worst = max(err, key=err.get)
-        assert err[worst] <= 5e-2, (seed, worst, err[worst])
-        tight += err[worst] <= 1e-3
-    assert tight >= 2, tight
+        if err[worst] <= 1e-3:
+            continue
+        assert kinks, (seed, worst, err[worst], "no LeakyReLU unit near its kink: nothing explains the difference")
+        kinks = sorted(kinks, key=lambda k: abs(k[2]))[:24]
+        keys = [k for k in gref if float(gref[k].abs().max()) > 1e-6]
+        resid = flat(got, keys) - flat(gref, keys)
+        chosen = {}
+        for c, i, v in kinks:
+            side = -1 if v > 0 else 1
+            g1, _ = _oracle_gradients_f64(sd, hp, inputs, noise, force={(c, i): side})
+            delta = flat(g1, keys) - flat(gref, keys)
+            if float(delta.abs().max()) > 1e-4 and float(resid @ delta) > 0.5 * float(delta @ delta):
+                chosen[(c, i)] = side
+        assert chosen, (seed, worst, err[worst], "no single flip of a near-kink unit explains the difference", kinks)
+        g2, _ = _oracle_gradients_f64(sd, hp, inputs, noise, force=chosen)
+        e2 = _grad_errors(g2, got)
+        w2 = max(e2, key=e2.get)
+        assert e2[w2] <= 1e-3, (seed, "plain:", worst, err[worst], "with units", chosen, "on the other side:", w2, e2[w2])
 
 
 def test_radam_kernel_matches_oracle():
