@@ -282,9 +282,7 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev, dinp_noloss)
             raise RuntimeError(err or "set-up failed on another rank")
 
         def it():
-            s = sampler.sample(n)
-            scores, _ = planner.evaluate(state, goal, s)
-            sampler.fit(s[torch.argsort(scores)[: n // 10]])
+            planner.iterate(state, goal)       # draw (each rank its own shard), roll out, score, all-gather, elites, refit
         # reference-equivalent work first: every candidate's 80 frames are decoded while scoring (cem_simulator.py:29-59) ...
         planner.decode_candidates = True
         dt_all = _timed(it, 3, 1, world, dev)

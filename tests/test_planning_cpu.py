@@ -29,6 +29,10 @@ def test_kat8_elites_and_refit():
     a = FlatCEMSampler(2.0, 7, 4, 0.3, device="cpu", seed=5).sample(16)
     b = FlatCEMSampler(2.0, 7, 4, 0.3, device="cpu", seed=5).sample(16)
     assert torch.equal(a, b) and float(a.abs().max()) <= 2.0
+    # a sharded population is the concatenation of its shards' own streams: a rank that draws only shard k gets rows k of it
+    full = FlatCEMSampler(2.0, 7, 4, 0.3, device="cpu", seed=5, n_shards=4).sample(16)
+    part = FlatCEMSampler(2.0, 7, 4, 0.3, device="cpu", seed=5, n_shards=4).sample_shard(16, 2)
+    assert full.shape[0] == 16 and torch.equal(part, full[8:12]) and not torch.equal(full[:4], full[4:8])
 
 
 def test_env2planner():
@@ -70,7 +74,8 @@ def _worker(rank, world, port, q):
     from video_gcp_amd.planning import CEMPlanner, FlatCEMSampler
     if world > 1:
         D.init_from_env("gloo")
-    sampler = FlatCEMSampler(float("inf"), 7, 4, 1.0, device="cpu", seed=3)
+    # the population = two independently seeded shards: a 2-rank group draws one each, the single process draws both
+    sampler = FlatCEMSampler(float("inf"), 7, 4, 1.0, device="cpu", seed=3, n_shards=2)
     planner = CEMPlanner(_StubSim(), _StubCost(), sampler, n_iters=3, batch_size=32, elite_frac=0.25, max_seq_len=7)
     _, _, lat, best = planner(None, None)
     q.put((rank, best, [float(l.elite_scores[0]) for l in planner.logs], float(np.abs(lat).sum())))
@@ -93,6 +98,8 @@ def _run(world):
 
 
 def test_sharded_cem_matches_single_rank():
+    """every rank draws and rolls out ONLY its shard of the population (sampler shard = rank), costs all-gathered, the elite rows —
+    drawn on whichever rank — assembled by one all-reduce: same elites, same refit, same plan as one process that draws both shards"""
     one = _run(1)[0]
     two = _run(2)
     # both ranks agree with each other and with the unsharded planner (same population, same elites, same refit)

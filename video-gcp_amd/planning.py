@@ -145,21 +145,51 @@ class FlatCEMSampler:
     """Gaussian sampler over [n_steps, dim] (sampler.py:33-48), on the device, seedable so that all ranks of a
     sharded planner draw the same population."""
 
-    def __init__(self, clip_val, n_steps, action_dim, initial_std, device="cuda", seed=0):
+    def __init__(self, clip_val, n_steps, action_dim, initial_std, device="cuda", seed=0, n_shards=None):
+        """n_shards: the population is the concatenation of n_shards independently seeded sub-streams (seed, shard); default = the
+        number of ranks, so that under a process group every rank draws ONLY its own 1/world of the candidates ("each GPU
+        samples its slice (seed = base + rank)").  A single process asked for n_shards = k draws the same population a k-rank
+        group does, which is how the sharded planner is checked against the unsharded one."""
         self._clip_val, self._n_steps, self._action_dim, self._initial_std = clip_val, n_steps, action_dim, initial_std
         self.device = torch.device(device)
-        self._gen = torch.Generator(device=self.device)
+        self._seed, self._n_shards = seed, n_shards
+        self._gen = torch.Generator(device=self.device)             # rank-shared stream (length draws, one-shard populations)
         self._gen.manual_seed(seed)
+        self._shard_gens = {}
         self.init()
 
     def init(self):
         self.mean = torch.zeros(self._n_steps, self._action_dim, device=self.device)
         self.std = self._initial_std * torch.ones(self._n_steps, self._action_dim, device=self.device)
 
-    def sample(self, n_samples):
-        eps = torch.randn(n_samples, self._n_steps, self._action_dim, device=self.device, generator=self._gen)
+    def n_shards(self):
+        if self._n_shards is not None:
+            return self._n_shards
+        return D.dist.get_world_size() if D.dist.is_initialized() else 1
+
+    def _draw(self, n, gen):
+        eps = torch.randn(n, self._n_steps, self._action_dim, device=self.device, generator=gen)
         raw = self.mean[None] + self.std[None] * eps
         return raw.clamp(-self._clip_val, self._clip_val) if np.isfinite(self._clip_val) else raw
+
+    def sample_shard(self, n_samples, shard):
+        """rows [shard * n / n_shards, (shard + 1) * n / n_shards) of the population of n_samples candidates"""
+        ns = self.n_shards()
+        assert n_samples % ns == 0, "candidate population must divide evenly over the shards"
+        if ns == 1:
+            return self._draw(n_samples, self._gen)
+        g = self._shard_gens.get(shard)
+        if g is None:
+            g = self._shard_gens[shard] = torch.Generator(device=self.device)
+            g.manual_seed(self._seed * 1000003 + 7919 * (shard + 1))
+        return self._draw(n_samples // ns, g)
+
+    def sample(self, n_samples):
+        """the whole population (every shard, in order)"""
+        ns = self.n_shards()
+        if ns == 1:
+            return self._draw(n_samples, self._gen)
+        return torch.cat([self.sample_shard(n_samples, s_) for s_ in range(ns)], 0)
 
     def sample_uniform(self, n_samples):
         """one uniform number per candidate from the sampler's own (rank-shared) stream: the length draw of a rollout"""
@@ -207,18 +237,50 @@ class CEMPlanner:
         return rank * per, per
 
     def evaluate(self, state, goal_state, samples):
-        """costs [n] of all candidates: this rank rolls out its slice, one all-gather assembles the vector."""
+        """costs [n] of all candidates given the WHOLE population: this rank rolls out its slice, one all-gather assembles the vector."""
         lo, per = self._shard(samples.shape[0])
+        return self._evaluate_local(state, goal_state, samples[lo:lo + per], lo, samples.shape[0])
+
+    def _evaluate_local(self, state, goal_state, local, lo, n_total):
+        per = local.shape[0]
         if getattr(self._sim, "supports_latent_only", False):
             kw = {}
             if getattr(self._sim, "pred_length", False) and hasattr(self._sampler, "sample_uniform"):
-                # every rank draws the population's length numbers from the shared stream and keeps its slice
-                kw["len_u"] = self._sampler.sample_uniform(samples.shape[0])[lo:lo + per]
-            r = self._sim.rollout_device(state, goal_state, samples[lo:lo + per], self.max_seq_len, decode=self.decode_candidates, **kw)
+                # every rank draws the population's length numbers (n floats) from the shared stream and keeps its slice
+                kw["len_u"] = self._sampler.sample_uniform(n_total)[lo:lo + per]
+            r = self._sim.rollout_device(state, goal_state, local, self.max_seq_len, decode=self.decode_candidates, **kw)
         else:                                            # any simulator with the reference's interface
-            r = self._sim.rollout_device(state, goal_state, samples[lo:lo + per], self.max_seq_len)
-        local = self._cost.sequence_cost_device(r.latents, r.lengths, r.e_goal if self.goal_in_cost else None)
-        return D.all_gather_costs(local), r
+            r = self._sim.rollout_device(state, goal_state, local, self.max_seq_len)
+        cost = self._cost.sequence_cost_device(r.latents, r.lengths, r.e_goal if self.goal_in_cost else None)
+        return D.all_gather_costs(cost), r
+
+    def iterate(self, state, goal_state):
+        """One CEM iteration (cem_planner.py:68-79): draw, roll out, score, pick elites, refit.  Under a process group every rank
+        draws and rolls out ONLY its own shard of the population (1 / world of the work), the costs are all-gathered, every rank
+        picks the same elites from the full cost vector, and the elite latents — rows of whichever rank drew them — are assembled by
+        one all-reduce of the rank's masked contribution (exactly one non-zero contributor per row: x + 0 + ... = x bit-exactly;
+        n_elite x N x nz floats, 6.6 MB at 51 x 127 x 256).  Returns (elite samples, elite scores, all scores)."""
+        n = self.batch_size
+        n_elite = max(int(n * self.elite_frac), 1)
+        world = D.dist.get_world_size() if D.dist.is_initialized() else 1
+        if world == 1:
+            samples = self._sampler.sample(n)
+            scores, _ = self._evaluate_local(state, goal_state, samples, 0, n)
+            idx = select_elites(scores, n_elite)
+            best = samples[idx]
+        else:
+            assert self._sampler.n_shards() == world, "one shard of the population per rank"
+            lo, per = self._shard(n)
+            local = self._sampler.sample_shard(n, D.dist.get_rank())
+            scores, _ = self._evaluate_local(state, goal_state, local, lo, n)
+            idx = select_elites(scores, n_elite)
+            mine = (idx >= lo) & (idx < lo + per)
+            best = torch.zeros((n_elite,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+            best[mine] = local[idx[mine] - lo]
+            D.dist.all_reduce(best)
+        best_scores = scores[idx]
+        self._sampler.fit(best, best_scores)
+        return best, best_scores, scores
 
     def __call__(self, state, goal_state):
         self._sampler.init()
@@ -226,11 +288,7 @@ class CEMPlanner:
         best_samples = best_scores = None
         self.logs = []
         for _ in range(self.n_iters):
-            samples = self._sampler.sample(self.batch_size)          # identical on every rank (shared seed)
-            scores, _ = self.evaluate(state, goal_state, samples)
-            idx = select_elites(scores, n_elite)
-            best_samples, best_scores = samples[idx], scores[idx]
-            self._sampler.fit(best_samples, best_scores)
+            best_samples, best_scores, scores = self.iterate(state, goal_state)
             self.logs.append(Outputs(elite_scores=best_scores.clone(), mean_score=scores.mean()))
         # final rollout of the best candidate (cem_planner.py:81-96); every rank computes it (tiny batch)
         kw = {}
