@@ -289,6 +289,12 @@ int gcpx_gather_rows(const float* src, const int32_t* idx, float* out, int32_t B
 int gcpx_seq_pairs(const float* lat, const int32_t* lengths, const float* goal, float* nxt, int32_t n, int32_t T,
                    int32_t nz, void* stream);
 int gcpx_masked_row_sum(const float* vals, const int32_t* lengths, float* out, int32_t n, int32_t T, void* stream);
+/* Hand-written planner costs over padded device rollouts (CostFcn subclasses, gcp/planning/cem/cost_fcn.py:10-77): x [n][T][ld]
+   (the first D columns of a row are used), lengths [n], goal row of candidate i at goal + i*goal_stride (0: one goal for all) -> out [n].
+   kind 0 EuclideanDistance, 1 EuclideanPathLength (dense only), 2 StepPathLength, 3 L2ImageCost (D = the image columns);
+   final_step_weight multiplies the last step, dense = sum over steps instead of the last step's value (cost_fcn.py:16-23). */
+int gcpx_rollout_cost(const float* x, int64_t ld, const int32_t* lengths, const float* goal, int64_t goal_stride, float* out, int32_t n,
+                      int32_t T, int32_t D, int32_t kind, int32_t dense, float final_step_weight, void* stream);
 /* dst[b][r] = src[b][r] for r < rows, rows of row_floats floats, independent batch strides (in rows): assembling
    images = cat(I_0, decoded) of the sequential model (sequential.py:57) without a torch.cat */
 int gcpx_copy_rows(const float* src, float* dst, int32_t B, int32_t rows, int64_t row_floats, int64_t src_batch_rows,
@@ -656,6 +662,17 @@ int gcpx_fold_upsample_weights(const float* w, int32_t Cout, int32_t Cin, float*
    incremented by this call; rectified update when the variance is tractable (rho_t > 5), momentum SGD otherwise */
 int gcpx_radam_step(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, float* state, int64_t n, float lr,
                     float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* The trainer's other optimizers (gcp_builder.py:174-186; torch.optim.Adam / RMSprop / SGD formulas): kind 1 = adam (p1, p2 = betas),
+   2 = rmsprop (p1 = momentum, p2 = alpha), 3 = sgd (p1 = momentum).  m / v: the optimizer's two state vectors; state[0] = step
+   counter (incremented), state[1] = gradient-clipping coefficient applied to the (scaled) gradient (0 = unset = 1; set per step by
+   gcpx_grad_clip_coef; gcpx_radam_step applies it too). */
+int gcpx_optim_step(float* theta, const float* grad, float* m, float* v, float* state, int64_t n, int32_t kind, float lr, float p1,
+                    float p2, float eps, float grad_scale, void* stream);
+/* gradient_clip (gcp_builder.py:186 -> blox get_clipped_optimizer; spec here: torch.nn.utils.clip_grad_norm_ over all parameters):
+   state[2] = || grad_scale * grad ||_2, state[1] = min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0).  partial: [n_partial]
+   scratch (deterministic two-stage sum). */
+int gcpx_grad_clip_coef(const float* grad, int64_t n, float grad_scale, float max_norm, float* partial, int32_t n_partial, float* state,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * hipGraph helpers: capture a launch sequence once, replay it per step.

@@ -249,3 +249,50 @@ def test_hierarchical_planner_at_the_reference_control_shape():
     for a, b in zip(res[False][3], res[True][3]):
         assert np.array_equal(a, b), (a, b)
     assert np.array_equal(res[False][0], res[True][0]) and np.array_equal(res[False][1], res[True][1]) and res[False][2] == res[True][2]
+
+
+@pytest.mark.parametrize("cost_name,dense", [("EuclideanDistance", True), ("EuclideanDistance", False), ("EuclideanPathLength", True),
+                                             ("StepPathLength", False), ("L2ImageCost", True)])
+def test_hand_written_costs_on_device_rollouts(setup, cost_name, dense):
+    """the hand-written planner costs (cost_fcn.py:42-77) over the padded device rollout (gcpx_rollout_cost, one launch) equal the
+    reference's host computation over the per-candidate numpy lists the simulator returns (cem_simulator.py:14-43); and a CEM planner
+    built with such a cost (the reference's default is EuclideanPathLength, cem_planner.py:36) picks its elites from those scores"""
+    from video_gcp_amd import planning as P
+    hp, sd, model = setup
+    state, goal = _env_images(hp, 11)
+    sim = P.GCPImageSimulator(model, append_latent=True, pred_length=False)
+    n, T = 6, hp.max_seq_len
+    z = torch.randn(n, hp.n_nodes, hp.nz_vae, generator=torch.Generator().manual_seed(2))
+    cost = getattr(P, cost_name)(dense, 1.5)
+    host = sim.rollout(state, goal, z.numpy(), T)
+    if cost_name == "L2ImageCost":
+        g = goal.astype(np.float32) / 255.0
+    else:
+        g = np.random.RandomState(3).randn(host.predictions[0].shape[1]).astype(np.float32)
+    want = cost([p.copy() for p in host.predictions], g)
+    r = sim.rollout_device(state, goal, z, T)
+    got = cost.rollout_cost_device(sim.predictions_device(r), r.lengths, g)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-5)
+    if cost_name == "L2ImageCost":
+        sampler = P.SimpleTreeCEMSampler(float("inf"), None, hp.nz_vae, 1.0, n_level_hierarchy=hp.hierarchy_levels, device="cuda", seed=4)
+        planner = P.CEMPlanner(sim, cost, sampler, n_iters=2, batch_size=8, elite_frac=0.25, max_seq_len=T)
+        plan, actions, latents, score = planner(state, g[None] if g.ndim == 3 else g)
+        assert planner.decode_candidates and np.isfinite(score) and plan.shape[1] == 3 * hp.img_sz ** 2 + hp.nz_enc
+        assert float(planner.logs[-1].elite_scores[0]) <= float(planner.logs[0].mean_score)
+
+
+def test_pddm_sampler_in_the_planner(setup):
+    """PDDMSampler (sampler.py:52-71) as the planner's sampler: correlated draws on the device, exp(-score)-weighted refit"""
+    from video_gcp_amd import planning as P
+    hp, sd, model = setup
+    state, goal = _env_images(hp, 12)
+
+    class TreePDDM(P.PDDMSampler):
+        def __init__(self, *a, n_level_hierarchy, **kw):
+            super().__init__(a[0], 2 ** n_level_hierarchy - 1, *a[2:], **kw)
+    sampler = TreePDDM(float("inf"), None, hp.nz_vae, 1.0, n_level_hierarchy=hp.hierarchy_levels, device="cuda", seed=5)
+    planner = P.CEMPlanner(P.GCPImageSimulator(model, pred_length=False), P.LearnedCostEstimate(model), sampler, n_iters=2, batch_size=16,
+                           elite_frac=0.25, max_seq_len=hp.max_seq_len)
+    plan, actions, latents, score = planner(state, goal)
+    assert np.isfinite(score) and float(sampler.mean.abs().max()) > 0 and torch.equal(sampler.std, torch.ones_like(sampler.std))

@@ -200,3 +200,70 @@ def test_bucket_marks_follow_every_write_of_their_slice(name):
             late = [k for k, (o, shp) in model._poff.items() if lo <= o < hi and
                     not torch.equal(names[k].reshape(-1), snap[o - lo:o - lo + names[k].numel()])]
             raise AssertionError(f"bucket {n}: written after its mark: {late[:8]}")
+
+
+@pytest.mark.parametrize("kind,momentum", [("adam", 0.0), ("rmsprop", 0.0), ("rmsprop", 0.9), ("sgd", 0.0), ("sgd", 0.9)])
+@pytest.mark.parametrize("clip", [None, 0.5])
+def test_other_optimizers_and_gradient_clip_match_torch(kind, momentum, clip):
+    """the trainer's `optimizer` / `momentum` / `gradient_clip` options (gcp_builder.py:174-186,255-263): Adam, RMSprop and SGD as
+    torch.optim defines them (the classes the reference instantiates), gradient clipping = torch.nn.utils.clip_grad_norm_ over all
+    parameters (spec of blox' get_clipped_optimizer, absent), on a flat vector through the kernels GCPTrainStep.optimizer_step calls"""
+    from video_gcp_amd import runtime as rt
+    lib = rt.load_library()
+    g = torch.Generator().manual_seed(3)
+    n = 10007
+    p_ref = torch.nn.Parameter(torch.randn(n, generator=g))
+    opt = {"adam": lambda: torch.optim.Adam([p_ref], lr=1e-2, betas=(0.9, 0.999), eps=1e-8),
+           "rmsprop": lambda: torch.optim.RMSprop([p_ref], lr=1e-2, alpha=0.99, eps=1e-8, momentum=momentum),
+           "sgd": lambda: torch.optim.SGD([p_ref], lr=1e-2, momentum=momentum)}[kind]()
+    th, m, v, st = p_ref.detach().clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda(), torch.zeros(4).cuda()
+    part = torch.empty(256).cuda()
+    code = {"adam": 1, "rmsprop": 2, "sgd": 3}[kind]
+    p1, p2 = (0.9, 0.999) if kind == "adam" else ((momentum, 0.99) if kind == "rmsprop" else (momentum, 0.0))
+    s = torch.cuda.current_stream().cuda_stream
+    for step in range(6):
+        grad = torch.randn(n, generator=g) * (10.0 ** (step % 3 - 1))
+        p_ref.grad = grad.clone()
+        if clip:
+            torch.nn.utils.clip_grad_norm_([p_ref], clip)
+        opt.step()
+        gd = (2.0 * grad).cuda()                       # two ranks' summed gradient, averaged through grad_scale = 0.5
+        if clip:
+            rt.check(lib.gcpx_grad_clip_coef(gd.data_ptr(), n, 0.5, clip, part.data_ptr(), 256, st.data_ptr(), s), "clip")
+        rt.check(lib.gcpx_optim_step(th.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), st.data_ptr(), n, code, 1e-2, p1, p2, 1e-8,
+                                     0.5, s), "optim")
+        torch.cuda.synchronize()
+        if clip:
+            assert abs(float(st[2]) - float(grad.norm())) <= 1e-5 * float(grad.norm())
+        assert float((th.cpu() - p_ref.detach()).abs().max()) < 5e-6, (kind, step)
+    assert float(st[0]) == 6.0
+
+
+def test_training_step_with_adam_and_clipping_c1():
+    """GCPTrainStep(optimizer='adam', gradient_clip=...) end to end against the oracle's gradients pushed through torch.optim.Adam"""
+    import video_gcp_amd as V
+    from oracle import gcp_model_oracle as O
+    from video_gcp_amd.model import GCPTreeModel
+    from video_gcp_amd.training import GCPTrainStep
+    hp = V.config("c1")
+    sd = V.init_params(hp, seed=1, randomize_affine=True)
+    model = GCPTreeModel(hp, params=sd, device="cuda")
+    tr = GCPTrainStep(model, lr=1e-3, optimizer="adam", gradient_clip=0.05)
+    names = [k for k in sd if not k.endswith(("running_mean", "running_var"))]
+    ref = {k: torch.nn.Parameter(sd[k].clone()) for k in names}
+    opt = torch.optim.Adam(list(ref.values()), lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    for step in range(2):
+        inputs, noise, _ = make_inputs(hp, seed=40 + step, variant="B")
+        tr.step({k: v.cuda() for k, v in inputs.items()}, noise.cuda())
+        torch.cuda.synchronize()
+        cur = dict(sd, **{k: p.detach() for k, p in ref.items()})
+        gref, _, _, _ = O.gradients(cur, hp, inputs, noise)
+        for k, p in ref.items():
+            p.grad = gref[k].clone()
+        total = torch.nn.utils.clip_grad_norm_(list(ref.values()), 0.05)
+        assert abs(float(tr.opt_state[2]) - float(total)) <= 2e-3 * float(total)     # the clipped quantity: the global gradient norm
+        opt.step()
+        worst = max(float((model.sd[k].cpu() - ref[k].detach()).abs().max()) for k in names)
+        assert worst <= 2e-3 * 1e-3 * (step + 1) + 1e-7, (step, worst)
+    with pytest.raises(ValueError):
+        GCPTrainStep(model, optimizer="lbfgs")

@@ -105,3 +105,37 @@ def test_sharded_cem_matches_single_rank():
     # both ranks agree with each other and with the unsharded planner (same population, same elites, same refit)
     assert two[0][1:] == two[1][1:] == one[1:]
     assert one[2][-1] <= one[2][0]            # CEM on a convex cost improves its best elite
+
+
+def test_hand_written_costs_and_pddm_sampler():
+    """CostFcn subclasses (cost_fcn.py:10-77) and PDDMSampler (sampler.py:52-71) against their definitions written out with numpy:
+    final-step weight, dense vs last-step cost, path length with the goal appended, step count, image L2 on the image columns of an
+    (image ++ latent) rollout; correlated noise n_i = BETA u_i + (1 - BETA) n_{i-1} and the exp(-score)-weighted mean refit."""
+    from video_gcp_amd import planning as P
+    rng = np.random.RandomState(0)
+    outs = [rng.randn(l, 5) for l in (3, 6, 1)]
+    goal = rng.randn(5)
+    per = [np.linalg.norm(o - goal[None], axis=-1) for o in outs]
+    assert np.allclose(P.EuclideanDistance(True, 2.0)(outs, goal), [p[:-1].sum() + 2 * p[-1] for p in per])
+    assert np.allclose(P.EuclideanDistance(False, 2.0)(outs, goal), [2 * p[-1] for p in per])
+    pl = [np.linalg.norm(np.concatenate([o[1:], goal[None]]) - o, axis=-1).sum() for o in outs]
+    assert np.allclose(P.EuclideanPathLength(True)(outs, goal), pl)
+    assert np.allclose(P.StepPathLength(False, 3.0)(outs, goal), [9.0, 18.0, 3.0]) and np.allclose(P.StepPathLength(True)(outs, goal), [3, 6, 1])
+    S, nz = 4, P.L2ImageCost.LATENT_SIZE
+    rolls = [rng.rand(l, 3 * S * S + nz) for l in (2, 5)]
+    goal_img = rng.rand(1, S, S, 3)
+    want = [np.sqrt((((r[:, :3 * S * S].reshape(-1, 3, S, S) - (goal_img.transpose(0, 3, 1, 2) * 2 - 1)) ** 2).sum((1, 2, 3))))[-1] for r in rolls]
+    assert np.allclose(P.L2ImageCost(False)(rolls, goal_img), want)
+    s = P.PDDMSampler(float("inf"), 6, 3, 0.5, device="cpu", seed=1)
+    x = s.sample(4)
+    u = 0.5 * torch.randn(4, 6, 3, generator=torch.Generator().manual_seed(1))
+    n_i, cor = torch.zeros(4, 3), []
+    for i in range(6):
+        n_i = s.BETA * u[:, i] + (1 - s.BETA) * n_i
+        cor.append(n_i)
+    assert torch.allclose(x, torch.stack(cor, 1), atol=1e-6)
+    scores = torch.tensor([0.3, 1.2, 0.1, 2.0])
+    std0 = s.std.clone()
+    s.fit(x, scores)
+    w = np.exp(-scores.numpy())
+    assert np.allclose(s.mean.numpy(), (x.numpy() * w[:, None, None]).sum(0) / w.sum(), atol=1e-6) and torch.equal(s.std, std0)

@@ -806,8 +806,9 @@ __global__ void __launch_bounds__(256) radam_kernel(float* __restrict__ theta, c
     float step;
     if (rect) step = sqrtf((1.f - b2t) * (sma - 4.f) / (sma_max - 4.f) * (sma - 2.f) / sma * sma_max / (sma_max - 2.f)) / (1.f - b1t);
     else step = 1.f / (1.f - b1t);
+    const float gsc = grad_scale * (state[1] > 0.f ? state[1] : 1.f);     // state[1]: this step's clipping coefficient (gcpx_grad_clip_coef), 0 = unset
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float g = grad[i] * grad_scale;
+        const float g = grad[i] * gsc;
         const float mi = beta1 * m[i] + (1.f - beta1) * g;
         const float vi = beta2 * v[i] + (1.f - beta2) * g * g;
         m[i] = mi;
@@ -817,6 +818,71 @@ __global__ void __launch_bounds__(256) radam_kernel(float* __restrict__ theta, c
 }
 
 __global__ void radam_tick_kernel(float* state) { state[0] += 1.f; }
+
+// The trainer's other optimizers (gcp_builder.py:174-186: 'adam', 'rmsprop', 'sgd' as torch.optim defines them) and the optional
+// gradient clipping by global norm.  state[0] = step counter, state[1] = clip coefficient of this step (1 when clipping is off).
+//   adam:    m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  theta -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+//   rmsprop: v = alpha v + (1 - alpha) g^2;  d = g / (sqrt(v) + eps);  momentum > 0: m = momentum m + d, theta -= lr m;  else theta -= lr d
+//   sgd:     momentum > 0: m = momentum m + g (m = g at the first step), theta -= lr m;  else theta -= lr g
+__global__ void __launch_bounds__(256) optim_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                                                    float* __restrict__ v, const float* __restrict__ state, const long long n,
+                                                    const int kind, const float lr, const float p1, const float p2, const float eps,
+                                                    const float grad_scale) {
+    const float t = state[0] + 1.f;
+    const float gs = grad_scale * (state[1] > 0.f ? state[1] : 1.f);
+    const float bc1 = 1.f - powf(p1, t), bc2s = sqrtf(1.f - powf(p2, t));
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float g = grad[i] * gs;
+        if (kind == 1) {
+            const float mi = p1 * m[i] + (1.f - p1) * g;
+            const float vi = p2 * v[i] + (1.f - p2) * g * g;
+            m[i] = mi; v[i] = vi;
+            theta[i] -= lr / bc1 * mi / (sqrtf(vi) / bc2s + eps);
+        } else if (kind == 2) {
+            const float vi = p2 * v[i] + (1.f - p2) * g * g;
+            v[i] = vi;
+            const float d = g / (sqrtf(vi) + eps);
+            if (p1 > 0.f) { const float mi = p1 * m[i] + d; m[i] = mi; theta[i] -= lr * mi; }
+            else theta[i] -= lr * d;
+        } else {
+            if (p1 > 0.f) { const float mi = t == 1.f ? g : p1 * m[i] + g; m[i] = mi; theta[i] -= lr * mi; }
+            else theta[i] -= lr * g;
+        }
+    }
+}
+
+// sum of squares of the gradient in a fixed order: [blocks] partials, then one workgroup
+__global__ void __launch_bounds__(256) sqnorm_partial_kernel(const float* __restrict__ g, const long long n, float* __restrict__ part) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += g[i] * g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// clip_grad_norm_: coefficient = min(1, max_norm / (||grad_scale * g|| + 1e-6)) -> state[1]; the norm itself -> state[2]
+__global__ void __launch_bounds__(256) clip_coef_kernel(const float* __restrict__ part, const int nb, const float grad_scale,
+                                                        const float max_norm, float* __restrict__ state) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = fabsf(grad_scale) * sqrtf(red[0]);
+        state[2] = norm;
+        state[1] = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+    }
+}
 
 int blocks_for(long long items, int cap = 4096) {
     long long b = (items + 255) / 256;
@@ -1068,6 +1134,27 @@ extern "C" int gcpx_repack(const float* theta, const int32_t* idx0, const int32_
     GCPX_CHECK_ARG(theta && idx0 && dst && n > 0, "bad arguments");
     GCPX_CHECK_ARG((((uintptr_t)idx0 | (uintptr_t)idx1 | (uintptr_t)dst) & 15) == 0, "idx0 / idx1 / dst must be 16-byte aligned");
     hipLaunchKernelGGL(repack_kernel, dim3(blocks_for((n + 3) / 4, 16384)), dim3(256), 0, stream, theta, idx0, idx1, dst, (long long)n);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_grad_clip_coef(const float* grad, int64_t n, float grad_scale, float max_norm, float* partial, int32_t n_partial,
+                                   float* state, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(grad && partial && state && n > 0 && n_partial > 0 && n_partial <= 4096, "bad arguments");
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(n_partial), dim3(256), 0, stream, grad, (long long)n, partial);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, partial, n_partial, grad_scale, max_norm, state);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_optim_step(float* theta, const float* grad, float* m, float* v, float* state, int64_t n, int32_t kind, float lr,
+                               float p1, float p2, float eps, float grad_scale, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(theta && grad && m && v && state && n > 0 && kind >= 1 && kind <= 3, "bad arguments");
+    hipLaunchKernelGGL(optim_kernel, dim3(blocks_for(n, 16384)), dim3(256), 0, stream, theta, grad, m, v, state, (long long)n, kind, lr,
+                       p1, p2, eps, grad_scale);
+    hipLaunchKernelGGL(radam_tick_kernel, dim3(1), dim3(1), 0, stream, state);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -213,7 +213,56 @@ __global__ void masked_row_sum_kernel(const float* __restrict__ vals, const int3
     out[i] = s;
 }
 
+// Hand-written planner costs over padded rollouts (gcp/planning/cem/cost_fcn.py:10-77): one workgroup per candidate, a wavefront per
+// step computes that step's value over the D columns, then the steps are combined in order (final_step_weight on the last step;
+// dense: sum over steps, else the last step's value).
+//   kind 0 EuclideanDistance   || x_t - goal ||          1 EuclideanPathLength  || next_t - x_t ||, next = x_{t+1}, goal after the last
+//   kind 2 StepPathLength      0, ..., 0, len            3 L2ImageCost          || x_t[:D] - goal || on the image columns only
+__global__ void __launch_bounds__(256) rollout_cost_kernel(const float* __restrict__ x, const long long ld, const int32_t* __restrict__ lengths,
+                                                           const float* __restrict__ goal, const long long goal_stride, float* __restrict__ out,
+                                                           const int T, const int D, const int kind, const int dense, const float final_w) {
+    extern __shared__ float steps[];
+    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int len = min(lengths[i], T);
+    const float* xi = x + (size_t)i * T * ld;
+    const float* g = goal + (size_t)i * goal_stride;
+    for (int t = wave; t < len; t += 4) {
+        float s = 0.f;
+        if (kind == 2) {
+            s = t == len - 1 ? (float)len : 0.f;
+        } else {
+            const float* a = xi + (size_t)t * ld;
+            const float* b = (kind == 1 && t + 1 < len) ? a + ld : g;
+            for (int d = lane; d < D; d += 64) { const float e = (kind == 1 ? b[d] - a[d] : a[d] - b[d]); s += e * e; }
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            s = sqrtf(s);
+        }
+        if (lane == 0) steps[t] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = 0.f;
+        if (len > 0) {
+            if (dense) { for (int t = 0; t + 1 < len; ++t) r += steps[t]; r += steps[len - 1] * final_w; }
+            else r = steps[len - 1] * final_w;
+        }
+        out[i] = r;
+    }
+}
+
 }  // namespace
+
+extern "C" int gcpx_rollout_cost(const float* x, int64_t ld, const int32_t* lengths, const float* goal, int64_t goal_stride, float* out,
+                                 int32_t n, int32_t T, int32_t D, int32_t kind, int32_t dense, float final_step_weight, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(x && lengths && out && n > 0 && T > 0 && D > 0 && ld >= D && kind >= 0 && kind <= 3, "null pointer / bad sizes");
+    GCPX_CHECK_ARG(kind == 2 || goal, "goal is NULL");
+    GCPX_CHECK_ARG(dense || kind != 1, "the path length needs dense_cost (cost_fcn.py:52)");
+    hipLaunchKernelGGL(rollout_cost_kernel, dim3(n), dim3(256), T * sizeof(float), stream, x, (long long)ld, lengths, goal, (long long)goal_stride,
+                       out, T, D, kind, dense, final_step_weight);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
 
 extern "C" int gcpx_seq_pairs(const float* lat, const int32_t* lengths, const float* goal, float* nxt, int32_t n,
                               int32_t T, int32_t nz, void* stream_) {

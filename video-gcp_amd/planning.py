@@ -74,6 +74,14 @@ class GCPImageSimulator:
                        actions=raw.get("actions_padded"), states=raw.get("regressed_state_padded"),
                        e_goal=raw["E"][:, -1], out=out)
 
+    def predictions_device(self, r):
+        """GCPSimulator._get_state_rollouts (cem_simulator.py:48-61) on the padded device rollout: [n, T, 3 H W (+ nz_enc)] — the flat
+        image of every step, with the latent appended when the simulator was built with append_latent"""
+        assert r.images is not None, "hand-written costs read the decoded rollouts: the planner must decode its candidates"
+        n, T = r.images.shape[:2]
+        img = r.images.reshape(n, T, -1)
+        return torch.cat((img, r.latents), dim=-1) if self._append_latent else img
+
     def rollout(self, state, goal_state, samples, rollout_len, prune=False, len_u=None):
         """Reference contract (cem_simulator.py:14-43): lists of numpy arrays, one per candidate."""
         r = self.rollout_device(state, goal_state, samples, rollout_len, len_u=len_u)
@@ -141,6 +149,111 @@ class LearnedCostEstimate:
         return out
 
 
+class CostFcn:
+    """Hand-written CEM cost functions (cost_fcn.py:10-77).  `__call__(cem_outputs, goal)` is the reference's host contract — a list
+    of per-candidate numpy arrays [len_i, D] and the goal — restated in numpy; `rollout_cost_device` scores a padded device rollout
+    ([n, T, D] + lengths) with one HIP launch (gcpx_rollout_cost) for the device-resident planner."""
+    KIND = None
+
+    def __init__(self, dense_cost, final_step_weight=1.0, *unused_args):
+        self._dense_cost = dense_cost
+        self._final_step_weight = final_step_weight
+
+    def __call__(self, cem_outputs, goal):
+        cost_per_step = self._compute(cem_outputs, goal)
+        for c in cost_per_step:
+            c[-1] *= self._final_step_weight
+        if self._dense_cost:
+            return np.array([np.sum(c) for c in cost_per_step])
+        return np.array([c[-1] for c in cost_per_step])
+
+    def _compute(self, cem_outputs, goal):
+        raise NotImplementedError
+
+    def _device_goal(self, goal, D, device):
+        return torch.as_tensor(np.asarray(goal, dtype=np.float32).reshape(-1)[:D].copy(), device=device)
+
+    def rollout_cost_device(self, x, lengths, goal):
+        """x [n, T, ld] device rollouts (predictions), lengths int32 [n], goal: what the host contract takes -> costs [n]"""
+        from . import runtime as rt_
+        n, T, ld = x.shape
+        D = self._device_columns(ld)
+        g = self._device_goal(goal, D, x.device)
+        out = torch.empty(n, device=x.device)
+        x = x.contiguous()
+        rt_.check(rt_.load_library().gcpx_rollout_cost(x.data_ptr(), ld, lengths.data_ptr(), g.data_ptr(), 0, out.data_ptr(), n, T, D, self.KIND,
+                                                       int(bool(self._dense_cost)), float(self._final_step_weight),
+                                                       torch.cuda.current_stream(x.device).cuda_stream), "rollout_cost")
+        return out
+
+    def _device_columns(self, ld):
+        return ld
+
+
+class ImageCost:
+    """cost_fcn.py:26-39: split an (image ++ latent) rollout [len, 3 H W + input_dim] into its image and latent parts"""
+
+    def _split_state_rollout(self, rollouts):
+        imgs, lats = [], []
+        for r in rollouts:
+            flat = r[..., :-self.input_dim]
+            assert flat.ndim == 2
+            res = int(np.sqrt(flat.shape[1] / 3))                 # assumes a 3-channel image
+            imgs.append(flat.reshape(flat.shape[0], 3, res, res))
+            lats.append(r[..., -self.input_dim:])
+        return Outputs(image_rollout=imgs, latent_rollout=lats)
+
+
+class EuclideanDistance(CostFcn):
+    """Euclidean distance between every step and the goal (cost_fcn.py:42-46)"""
+    KIND = 0
+
+    def _compute(self, cem_outputs, goal):
+        return [np.linalg.norm(o - goal[None], axis=-1) for o in cem_outputs]
+
+
+class EuclideanPathLength(CostFcn):
+    """Euclidean length of the whole path to the goal (cost_fcn.py:49-54)"""
+    KIND = 1
+
+    def _compute(self, cem_outputs, goal):
+        assert self._dense_cost                                   # need dense cost for path length computation
+        return [np.linalg.norm(np.concatenate([o[1:], goal[None]]) - o, axis=-1) for o in cem_outputs]
+
+
+class StepPathLength(CostFcn):
+    """number of steps of the path (cost_fcn.py:57-62)"""
+    KIND = 2
+
+    def _compute(self, cem_outputs, goal):
+        return [np.concatenate((np.zeros(o.shape[0] - 1), np.array([float(o.shape[0])]))) for o in cem_outputs]
+
+    def _device_goal(self, goal, D, device):
+        return torch.zeros(1, device=device)
+
+
+class L2ImageCost(CostFcn, ImageCost):
+    """L2 distance to the goal image in pixel space (cost_fcn.py:65-77); goal_raw: env image [1, H, W, 3] in [0, 1]"""
+    KIND = 3
+    LATENT_SIZE = 128
+
+    def _compute(self, cem_outputs, goal_raw):
+        image_sequences = self._split_state_rollout(cem_outputs).image_rollout
+        goal = np.asarray(goal_raw).transpose(0, 3, 1, 2) * 2 - 1.0
+        return [np.sqrt(np.sum((seq - goal) ** 2, axis=(1, 2, 3))) for seq in image_sequences]
+
+    @property
+    def input_dim(self):
+        return self.LATENT_SIZE
+
+    def _device_columns(self, ld):
+        return ld - self.input_dim
+
+    def _device_goal(self, goal_raw, D, device):
+        g = np.asarray(goal_raw, dtype=np.float32).transpose(0, 3, 1, 2) * 2 - 1.0
+        return torch.as_tensor(g.reshape(-1)[:D].copy(), device=device)
+
+
 class FlatCEMSampler:
     """Gaussian sampler over [n_steps, dim] (sampler.py:33-48), on the device, seedable so that all ranks of a
     sharded planner draw the same population."""
@@ -203,6 +316,25 @@ class FlatCEMSampler:
         return Outputs(mean=self.mean, std=self.std)
 
 
+class PDDMSampler(FlatCEMSampler):
+    """Correlated noise + path-integral refit (sampler.py:52-71): n_i = BETA u_i + (1 - BETA) n_{i-1} along the steps, the mean refit
+    as the exp(-GAMMA score)-weighted average of the candidates (scores: lower is better); the std is never refit."""
+    BETA = 0.5      # noise correlation factor
+    GAMMA = 1.0     # reward weighting factor
+
+    def _draw(self, n, gen):
+        noise = self.std[None] * torch.randn(n, self._n_steps, self._action_dim, device=self.device, generator=gen)
+        # the recurrence unrolled: n_i = BETA sum_{k <= i} (1 - BETA)^(i - k) u_k — one lower-triangular mixing of the step axis
+        i = torch.arange(self._n_steps, device=self.device)
+        w = self.BETA * (1.0 - self.BETA) ** (i[:, None] - i[None]).clamp(min=0).to(torch.float32) * (i[:, None] >= i[None])
+        raw = torch.einsum("ik,nkd->nid", w, noise) + self.mean[None]
+        return raw.clamp(-self._clip_val, self._clip_val) if np.isfinite(self._clip_val) else raw
+
+    def fit(self, actions, scores):
+        wgt = torch.exp(-self.GAMMA * torch.as_tensor(scores, dtype=actions.dtype, device=actions.device))
+        self.mean = (actions * wgt[:, None, None]).sum(0) / wgt.sum()
+
+
 class SimpleTreeCEMSampler(FlatCEMSampler):
     """All 2^L - 1 tree latents optimised at once (sampler.py:68-76)."""
 
@@ -223,7 +355,7 @@ class CEMPlanner:
         # decode_candidates: also decode the images of every candidate while scoring (what the reference's simulator does,
         # cem_simulator.py:29-59).  The learned cost reads latents only, so by default the images are decoded once, for the
         # plan that is returned; scores, elites and the returned plan are the same either way.
-        self.decode_candidates = decode_candidates
+        self.decode_candidates = decode_candidates or not hasattr(cost, "sequence_cost_device")     # hand-written costs read the images
         self._sim, self._cost, self._sampler = simulator, cost, sampler
         self.n_iters, self.batch_size, self.elite_frac, self.max_seq_len = n_iters, batch_size, elite_frac, max_seq_len
         self.goal_in_cost = goal_in_cost
@@ -251,7 +383,12 @@ class CEMPlanner:
             r = self._sim.rollout_device(state, goal_state, local, self.max_seq_len, decode=self.decode_candidates, **kw)
         else:                                            # any simulator with the reference's interface
             r = self._sim.rollout_device(state, goal_state, local, self.max_seq_len)
-        cost = self._cost.sequence_cost_device(r.latents, r.lengths, r.e_goal if self.goal_in_cost else None)
+        if hasattr(self._cost, "sequence_cost_device"):
+            cost = self._cost.sequence_cost_device(r.latents, r.lengths, r.e_goal if self.goal_in_cost else None)
+        else:
+            # a hand-written CostFcn scores the rollouts' `predictions` against the goal state (cem_planner.py:126): image ++ latent
+            # rows of the padded device rollout, one launch
+            cost = self._cost.rollout_cost_device(self._sim.predictions_device(r), r.lengths, goal_state)
         return D.all_gather_costs(cost), r
 
     def iterate(self, state, goal_state):

@@ -139,6 +139,7 @@ SYMBOLS = [
     ("gcpx_gather_rows", C.c_int, [vp, vp, vp, i32, i32, i32, i32, i64, vp]),
     ("gcpx_compact_index", C.c_int, [vp, i32, i32, i32, vp, vp]),
     ("gcpx_seq_pairs", C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    ("gcpx_rollout_cost", C.c_int, [vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, i32, C.c_float, vp]),
     ("gcpx_masked_row_sum", C.c_int, [vp, vp, vp, i32, i32, vp]),
     ("gcpx_wgrad", C.c_int, [C.POINTER(WgradArgs), vp]),
     ("gcpx_wgrad_classify", C.c_int, [C.POINTER(WgradArgs), i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -189,6 +190,8 @@ SYMBOLS = [
     ("gcpx_repack", C.c_int, [vp, vp, vp, vp, i64, vp]),
     ("gcpx_split_pack", C.c_int, [vp, vp, i32, vp, vp, vp]),
     ("gcpx_fold_upsample_weights", C.c_int, [vp, i32, i32, vp, vp]),
+    ("gcpx_optim_step", C.c_int, [vp, vp, vp, vp, vp, i64, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
+    ("gcpx_grad_clip_coef", C.c_int, [vp, i64, C.c_float, C.c_float, vp, i32, vp, vp]),
     ("gcpx_radam_step", C.c_int, [vp, vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     ("gcpx_attention", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     ("gcpx_cdist_splits", C.c_int, [i64]),

@@ -102,7 +102,9 @@ class ModelTrainer:
         torch.cuda.manual_seed(seed * max(self.world, 1) + self.rank + 1)
         pg = torch.distributed.group.WORLD if self.world > 1 else None
         lr = conf.get("lr") if conf.get("lr") is not None else 1e-3
-        self.trainer = step_cls(self.model, lr=lr, betas=(conf.get("adam_beta", 0.9), 0.999), process_group=pg)
+        self.trainer = step_cls(self.model, lr=lr, betas=(conf.get("adam_beta", 0.9), 0.999), process_group=pg,
+                                optimizer=conf.get("optimizer", "radam"), momentum=conf.get("momentum", 0),
+                                gradient_clip=conf.get("gradient_clip"))                   # gcp_builder.py:174-186,255-263
         if not args.feed_random_data and train_loader is None:
             raise ValueError("no dataset reader ships with this build: pass --feed_random_data 1 or give ModelTrainer a loader")
         self.train_loader = train_loader or SyntheticLoader(hp, nb, 1000 + 100000 * self.rank, self.device)

@@ -34,7 +34,15 @@ class GCPTrainStep:
     """`step(inputs)` = one optimisation step of `model` (GCPTreeModel) on one minibatch; `backward(inputs)` stops
     after the gradients (tests)."""
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+    OPTIMIZERS = {"radam": 0, "adam": 1, "rmsprop": 2, "sgd": 3}
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, optimizer="radam", momentum=0.0,
+                 gradient_clip=None):
+        """optimizer / momentum / gradient_clip: the trainer's `optimizer` ('radam' default, 'adam', 'rmsprop', 'sgd'), `momentum`
+        (RMSprop / SGD) and `gradient_clip` settings (gcp_builder.py:174-186,255-263)."""
+        if optimizer not in self.OPTIMIZERS:
+            raise ValueError("Optimizer '{}' not supported!".format(optimizer))          # gcp_builder.py:185
+        self.optimizer, self.momentum, self.gradient_clip = optimizer, float(momentum), gradient_clip
         hp = model._hp
         assert hp.decoder_distribution == "discrete_logistic_mixture", "training path implements the DLM head"
         if hp.attentive_inference:
@@ -1095,9 +1103,22 @@ class GCPTrainStep:
         if self.buckets is not None:
             # the tree-level buckets were started during the backward; the last one (conv stacks, heads, level 0) goes now
             scale = self.buckets.finish()
-        rt.check(m.lib.gcpx_radam_step(m.theta.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                       self.opt_state.data_ptr(), m.theta.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
-                                       scale, st), "radam")
+        n = m.theta.numel()
+        if self.gradient_clip:
+            # clip_grad_norm_ over all parameters of the (averaged) gradient: its coefficient lands in opt_state[1], which the step reads
+            if getattr(self, "_clip_part", None) is None:
+                self._clip_part = torch.empty(1024, device=m.device)
+            rt.check(m.lib.gcpx_grad_clip_coef(self.grad.data_ptr(), n, scale, float(self.gradient_clip), self._clip_part.data_ptr(), 1024,
+                                               self.opt_state.data_ptr(), st), "grad_clip")
+        kind = self.OPTIMIZERS[self.optimizer]
+        if kind == 0:
+            rt.check(m.lib.gcpx_radam_step(m.theta.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                           self.opt_state.data_ptr(), n, self.lr, self.betas[0], self.betas[1], self.eps, scale, st), "radam")
+        else:
+            # torch.optim defaults of the reference's get_optimizer_class: Adam betas (adam_beta, 0.999); RMSprop alpha 0.99; eps 1e-8
+            p1, p2 = (self.betas[0], self.betas[1]) if kind == 1 else ((self.momentum, 0.99) if kind == 2 else (self.momentum, 0.0))
+            rt.check(m.lib.gcpx_optim_step(m.theta.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                           self.opt_state.data_ptr(), n, kind, self.lr, p1, p2, self.eps, scale, st), "optim_step")
         m.repack(st)
 
     def step(self, inputs, noise=None):
@@ -1108,13 +1129,16 @@ class GCPTrainStep:
     def optimizer_state(self):
         """optimizer.state_dict() counterpart (train.py:111): flat first / second moments + step counter"""
         return {"exp_avg": self.exp_avg.detach().cpu(), "exp_avg_sq": self.exp_avg_sq.detach().cpu(),
-                "state": self.opt_state.detach().cpu(), "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps}
+                "state": self.opt_state.detach().cpu(), "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
+                "optimizer": self.optimizer, "momentum": self.momentum, "gradient_clip": self.gradient_clip}
 
     def load_optimizer_state(self, st):
         self.exp_avg.copy_(st["exp_avg"])
         self.exp_avg_sq.copy_(st["exp_avg_sq"])
         self.opt_state.copy_(st["state"])
         self.lr, self.betas, self.eps = st["lr"], tuple(st["betas"]), st["eps"]
+        if st.get("optimizer", self.optimizer) != self.optimizer:
+            raise ValueError(f"checkpoint holds the state of optimizer '{st['optimizer']}', this trainer runs '{self.optimizer}'")
 
     def named_grads(self):
         return {k: self.grad[o:o + int(torch.tensor(shp).prod())].view(shp) for k, (o, shp) in self.m._poff.items()}

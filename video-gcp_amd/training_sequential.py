@@ -34,9 +34,9 @@ NETS = ("prior_lstm", "inf_lstm", "gen_lstm")
 class SequentialTrainStep(GCPTrainStep):
     """`step(inputs)` = one optimisation step of a GCPSequentialModel on one minibatch (same interface as GCPTrainStep)."""
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, **optim):
         assert model._hp.context_every_step, "the recurrent nets are built with the (e_0, e_g) context at every step (hyperparameters.py default)"
-        super().__init__(model, lr=lr, betas=betas, eps=eps, process_group=process_group)
+        super().__init__(model, lr=lr, betas=betas, eps=eps, process_group=process_group, **optim)
         self.side_lanes = True
 
     # ------------------------------------------------------------------------------------------------
