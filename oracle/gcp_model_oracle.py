@@ -192,13 +192,18 @@ def seq_encoder(sd, hp, enc_seq, training, prefix="inf_encoder"):
 
 
 def tree_lstm_step(sd, p, hp, hidden1, hidden2, pred_input):
-    """SplitLinTreeHiddenStatePredictorModel.forward (tree_lstm.py:43-49) + HiddenStatePredictorModel (spec)."""
+    """{SplitLin, Lin, Sum}TreeHiddenStatePredictorModel.forward (tree_lstm.py:11-49) + HiddenStatePredictorModel (spec)."""
     nl, H = hp.n_lstm_layers, hp.nz_mid_lstm
-    ch1 = [c for h in torch.chunk(hidden1, nl, 1) for c in torch.chunk(h, 2, 1)]
-    ch2 = [c for h in torch.chunk(hidden2, nl, 1) for c in torch.chunk(h, 2, 1)]
-    proj = [F.linear(torch.cat([a, b], 1), sd[f"{p}.subgoal_pred.projections.{j}.weight"],
-                     sd[f"{p}.subgoal_pred.projections.{j}.bias"]) for j, (a, b) in enumerate(zip(ch1, ch2))]
-    hidden = torch.cat(proj, dim=1)
+    if hp.tree_lstm == "sum":                                     # tree_lstm.py:14-16
+        hidden = hidden1 + hidden2
+    elif hp.tree_lstm == "linear":                                # tree_lstm.py:25-27
+        hidden = F.linear(torch.cat([hidden1, hidden2], 1), sd[f"{p}.subgoal_pred.projection.weight"], sd[f"{p}.subgoal_pred.projection.bias"])
+    else:                                                         # tree_lstm.py:43-49
+        ch1 = [c for h in torch.chunk(hidden1, nl, 1) for c in torch.chunk(h, 2, 1)]
+        ch2 = [c for h in torch.chunk(hidden2, nl, 1) for c in torch.chunk(h, 2, 1)]
+        proj = [F.linear(torch.cat([a, b], 1), sd[f"{p}.subgoal_pred.projections.{j}.weight"],
+                         sd[f"{p}.subgoal_pred.projections.{j}.bias"]) for j, (a, b) in enumerate(zip(ch1, ch2))]
+        hidden = torch.cat(proj, dim=1)
     x = F.linear(torch.cat(pred_input, 1), sd[f"{p}.subgoal_pred.embed.weight"], sd[f"{p}.subgoal_pred.embed.bias"])
     new_hidden = []
     for i, hl in enumerate(torch.chunk(hidden, nl, 1)):
@@ -431,7 +436,10 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
         if hp.context_every_step:                                               # :97-101
             pred_input += [inp["e_0"].repeat_interleave(n, 0), inp["e_g"].repeat_interleave(n, 0)]
         if left["hidden"] is None and right["hidden"] is None:                  # :104-105
-            init = predictor(sd, f"{p}.lstm_initializer.net", hp, e_l, e_r, z)
+            if hp.lstm_init == "zero":                                          # ZeroLSTMCellInitializer (tree_lstm.py:68-70)
+                init = torch.zeros(e_l.shape[0], 2 * hp.lstm_state_dim, dtype=e_l.dtype)
+            else:
+                init = predictor(sd, f"{p}.lstm_initializer.net", hp, e_l, e_r, z)
             hl, hr = torch.chunk(init, 2, 1)
             left["hidden"], right["hidden"] = hl.reshape(B, n, -1), hr.reshape(B, n, -1)
         hidden, e_g_prime = tree_lstm_step(sd, p, hp, flat(left["hidden"]), flat(right["hidden"]), pred_input)   # :107-108

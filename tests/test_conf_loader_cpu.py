@@ -72,7 +72,10 @@ def test_adaptive_base_config_and_errors(tmp_path):
     '''))
     hp, trainer, _ = CL.load_conf(str(tmp_path), max_seq_len=200)
     assert hp.adaptive and hp.attentive_inference and hp.batch_size == 8
-    (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'tree_lstm': 'sum'}\n")
+    (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'tree_lstm': 'sum', 'lstm_init': 'zero'}\n")
+    hp, _, _ = CL.load_conf(str(tmp_path))
+    assert hp.tree_lstm == "sum" and hp.lstm_init == "zero"             # tree_lstm.py:52-74: sum / linear / split_linear, zero / mlp
+    (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'tree_lstm': ''}\n")     # the non-LSTM predictor: not built
     with pytest.raises(ValueError):
         CL.load_conf(str(tmp_path))
     (tmp_path / "conf.py").write_text("x = 1\n")

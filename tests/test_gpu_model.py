@@ -224,3 +224,24 @@ def test_edge_shapes(cfg):
     _check_common(hp, model, out, ref, posterior=True)
     total = float(model.get_total_loss(dev_in, model.loss(dev_in, out)).value)
     assert abs(total - float(ref_total)) <= 2e-5 * abs(float(ref_total)) + 1e-6
+
+
+@pytest.mark.parametrize("tree_lstm,lstm_init", [("sum", "mlp"), ("linear", "mlp"), ("split_linear", "zero"), ("sum", "zero")])
+def test_tree_lstm_variants_c1(tree_lstm, lstm_init):
+    """the other TreeLSTM morphologies and the parameter-free initialiser (tree_lstm.py:11-27,52-74): SumTree adds the parents' hidden
+    states, LinTree projects their concatenation with one Linear, ZeroLSTMCellInitializer starts the root's parents from zero states —
+    forward and losses against the oracle"""
+    from oracle import gcp_model_oracle as O
+    hp, sd, model = _build("c1", tree_lstm=tree_lstm, lstm_init=lstm_init)
+    assert (f"tree_module.tree_modules.0.lstm_initializer.net.input.linear.weight" in sd) == (lstm_init == "mlp")
+    assert ("tree_module.tree_modules.1.subgoal_pred.projection.weight" in sd) == (tree_lstm == "linear")
+    model.train(True)
+    inputs, noise, _ = make_inputs(hp, seed=8, variant="B")
+    ref = O.forward(sd, hp, inputs, noise=noise, training_bn=True)
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    out = model(dev_in, "train", noise=noise.cuda())
+    torch.cuda.synchronize()
+    _check_common(hp, model, out, ref, posterior=True)
+    ref_losses, ref_total = O.losses(sd, hp, inputs, ref)
+    losses = model.loss(dev_in, out)
+    assert abs(float(losses["_total"]) - float(ref_total)) <= 3e-5 * abs(float(ref_total))

@@ -281,3 +281,16 @@ def test_training_step_with_adam_and_clipping_c1():
         assert worst <= 2e-2 * 1e-3, (step, worst)
     with pytest.raises(ValueError):
         GCPTrainStep(model, optimizer="lbfgs")
+
+
+@pytest.mark.parametrize("tree_lstm,lstm_init", [("sum", "zero"), ("linear", "mlp")])
+def test_gradients_tree_lstm_variants_c1(tree_lstm, lstm_init):
+    """training step with the Sum / Lin TreeLSTM merge and the zero initialiser (tree_lstm.py:11-27,68-70): every parameter gradient
+    against autograd over the oracle"""
+    from oracle import gcp_model_oracle as O
+    hp, sd, model, tr = _setup("c1", False, tree_lstm=tree_lstm, lstm_init=lstm_init)
+    inputs, noise, _ = make_inputs(hp, seed=9, variant="B")
+    tr.backward({k: v.cuda() for k, v in inputs.items()}, noise.cuda())
+    torch.cuda.synchronize()
+    gref, _, _, _ = O.gradients(sd, hp, inputs, noise)
+    _compare_grads(gref, tr.named_grads())

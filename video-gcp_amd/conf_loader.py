@@ -125,7 +125,7 @@ def model_kind(configuration):
     name = v if isinstance(v, str) else getattr(v, "__name__", repr(v))
     return "sequential" if "sequential" in name.lower() else "tree"
 # model_config keys that are settled by what this build implements (checked, not mapped)
-_FIXED = {"one_step_planner": ("sh_pred", "continuous"), "binding": ("loss",), "seq_enc": ("conv",), "tree_lstm": ("split_linear",),
+_FIXED = {"one_step_planner": ("sh_pred", "continuous"), "binding": ("loss",), "seq_enc": ("conv",),
           "dense_rec_type": ("node_prob", "svg", "none", None)}
 
 
@@ -139,6 +139,8 @@ def hparams_from_conf(configuration, model_config, **over):
         if k in mc and mc[k] not in allowed:
             raise ValueError(f"model_config[{k!r}] = {mc[k]!r}: only {allowed} is built")
         mc.pop(k, None)
+    if mc.get("tree_lstm", "split_linear") not in ("split_linear", "linear", "sum"):       # tree_lstm.py:52-60; '' / None = the non-LSTM
+        raise ValueError(f"model_config['tree_lstm'] = {mc['tree_lstm']!r}: split_linear, linear and sum are built")   # predictor (not built)
     if mc.pop("add_weighted_pixel_copy", False):
         ignored.append("add_weighted_pixel_copy")        # 25room/gcp_tree/conf.py:43 pops it as well
     inv = mc.pop("inv_mdl_params", None) or {}

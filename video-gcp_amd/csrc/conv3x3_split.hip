@@ -150,7 +150,7 @@ __device__ __forceinline__ float softplus_s(float x) { return x > 20.f ? x : __l
 // NLL = 2: GCPX_HEAD_DLM_NLL_GRAD (training forward) — the same, and the gradient of (nll_scale x row weight x) that likelihood
 // w.r.t. the 100 parameters of every pixel goes to row raw_row_map[f] of `out` (112-slot layout): what gcpx_dlm_nll_bwd computes from
 // the stored parameters, without storing them.
-template <int NLL>
+template <int NLL, bool PP>
 __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_conv_args a, const int items_per_wave,
                                                                     const int nitems) {
     using Cfg = SplitHeadCfg;
@@ -203,12 +203,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
         const int t = it / nrp;
         y0 = strip * 4; f = t / ncb; x0 = (t % ncb) * 16;
     };
-    int s_rc[NS];                                          // staging slot -> (row << 8 | col) of the region, item independent
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        const int t = (lane + 64 * k) >> 2;
-        s_rc[k] = ((t / RW) << 8) | (t % RW);
-    }
     auto issue_loads = [&](int it) {
         int f, y0, x0;
         origin(it, f, y0, x0);
@@ -219,15 +213,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
         for (int k = 0; k < NS; ++k) {
             pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int idx = lane + 64 * k;
-            // (NLL variant: the seven slot constants are recomputed — six VALU operations each — instead of held in registers: at the
-            // 256-register limit they were the values the compiler spilled, and a scratch reload inside this batch of loads waits for
-            // every load issued before it)
+            // (the seven slot -> (row, column) constants are recomputed — six VALU operations each — instead of held in registers: at
+            // the 256-register limit they were the values the compiler spilled, and a scratch reload inside this batch of loads waits
+            // for every load issued before it)
             int t_ = idx >> 2;
-            if constexpr (NLL) asm volatile("" : "+v"(t_));      // (opaque to the optimiser: otherwise the quotients are hoisted out of the item loop and spilled again)
-            const int rc = NLL ? (((t_ / RW) << 8) | (t_ % RW)) : s_rc[k];
+            asm volatile("" : "+v"(t_));      // (opaque to the optimiser: otherwise the quotients are hoisted out of the item loop and spilled again)
+            const int rc = ((t_ / RW) << 8) | (t_ % RW);
             const int sy = y0 - 1 + (rc >> 8), sx = x0 - 1 + (rc & 255);
             if (idx < RH * RW * 4 && sy >= 0 && sy < H && sx >= 0 && sx < W) {
-                pre[k] = *reinterpret_cast<const float4*>(base + (unsigned)((__umul24(sy, W) + sx) * 16 + (idx & 3) * 4));
+                int l4 = lane;
+                asm volatile("" : "+v"(l4));                   // (the lane's channel offset recomputed, not reloaded from scratch in front of every load)
+                pre[k] = *reinterpret_cast<const float4*>(base + (unsigned)((__umul24(sy, W) + sx) * 16 + (l4 & 3) * 4));
                 pre_ok |= 1u << k;
             }
         }
@@ -252,94 +248,30 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
         }
     };
 
-    for (; item < item_end; item += istep) {
-        int f, y0, x0;
-        origin(item, f, y0, x0);
-        const int orow = __builtin_amdgcn_readfirstlane(pre_orow);
-        // ---- staging: BatchNorm affine + LeakyReLU of the producer, the item's power-of-two scale, the two f16 pieces ----
-        float amax = 0.f;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            if (pre_ok & (1u << k)) {          // (the zero padding of the conv stays exactly zero)
-                float4 v = pre[k];
-                v.x = fmaf(v.x, bn_s.x, bn_t.x); v.y = fmaf(v.y, bn_s.y, bn_t.y); v.z = fmaf(v.z, bn_s.z, bn_t.z); v.w = fmaf(v.w, bn_s.w, bn_t.w);
-                v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
-                v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
-                pre[k] = v;
-            }
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(pre[k].x), fabsf(pre[k].y)), fmaxf(fabsf(pre[k].z), fabsf(pre[k].w))));
-        }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
-        // amax 2^ex in [2^14, 2^15): below the f16 maximum, and every piece that matters is a normal f16
-        int ex = 14 + 127 - (int)((__float_as_uint(amax) >> 23) & 0xff);
-        ex = __builtin_amdgcn_readfirstlane(amax > 0.f ? max(-100, min(min(100, 126 - ew), ex)) : 0);   // (2^-(ex + ew) stays a normal f32)
-        const float sx2 = __uint_as_float((unsigned)(127 + ex) << 23);
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const int idx = lane + 64 * k;
-            if (idx < RH * RW * 4) {
-                const float4 v = make_float4(pre[k].x * sx2, pre[k].y * sx2, pre[k].z * sx2, pre[k].w * sx2);
-                h4 p1, p2;
-                p1[0] = (_Float16)v.x; p1[1] = (_Float16)v.y; p1[2] = (_Float16)v.z; p1[3] = (_Float16)v.w;
-                p2[0] = (_Float16)(v.x - (float)p1[0]); p2[1] = (_Float16)(v.y - (float)p1[1]);
-                p2[2] = (_Float16)(v.z - (float)p1[2]); p2[3] = (_Float16)(v.w - (float)p1[3]);
-                char* dst = reg + (idx >> 2) * 32 + (idx & 3) * 8;
-                *reinterpret_cast<h4*>(dst) = p1;
-                *reinterpret_cast<h4*>(dst + Cfg::PLANE_BYTES) = p2;
-            }
-        }
-        flush_images();
-        pend_ip = nullptr;
-        if (item + istep < item_end) issue_loads(item + istep);        // in flight during this item's MFMAs
-
-        const int mode = a.head_mode;
-        const size_t plane = (size_t)H * W;
-        const bool store_raw = (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) && orow >= 0;
-        const float inv = __uint_as_float((unsigned)(127 - ex - ew) << 23);      // undoes the two power-of-two scales (exact)
-
-        // ---- fused likelihood, first half: the target pixels and the green / blue log-scales (channel tiles 5, 6) ----
-        // A lane of the epilogue below owns pixel (row s2 + 2 (q & 1), column j) and mixtures 2 ct + (q >> 1), ct = 0..4.
+    // ---- the item loop: per item a VALU half (the deferred epilogue of the PREVIOUS item — scale-back, mixture mean, likelihood — then
+    // the staging of this one) and an MFMA half.  PP (experiment, off by default): two workgroup barriers per item put waves 0-3 in
+    // their MFMA half while waves 4-7 (their SIMD partners) are in their VALU half and vice versa.  The idea: PMC shows the matrix pipe
+    // 36 % busy and the VALU 58 % with their sum at ~ 94 % — the two wavefronts of a SIMD drift through their phases unsynchronised and
+    // whenever both are in the same kind of phase they halve each other.  Measured: lock step is 10-17 % SLOWER in every mode (the halves
+    // do not balance; a barrier waits for the slowest of eight wavefronts), so the wavefronts run free.
+    const int n_iter = NLL ? (nitems + istep - 1) / istep : items_per_wave;
+    const int grp = wave >> 2;
+    f32x4 acc[5][4];
+    float4* stash = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem4) + Cfg::LDS_BYTES + wave * Cfg::STASH_BYTES) + lane;
+    float ls4[2][2];
+    float tx[2][3];                                             // fused likelihood: this lane's target pixels of the item in flight
+    const int mode = a.head_mode;
+    const size_t plane = (size_t)H * W;
+    // the item whose accumulators wait for their epilogue (wave-uniform)
+    int p_valid = 0, p_f = 0, p_y0 = 0, p_x0 = 0, p_orow = -1;
+    float p_inv = 1.f;
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        const int f = p_f, y0 = p_y0, x0 = p_x0, orow = p_orow;
+        const float inv = p_inv;
+        const bool store_raw = NLL == 0 && (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) && orow >= 0;
         const bool want_nll = NLL && orow >= 0;
-        // (the kernel sits at the 256-register limit of two wavefronts per SIMD: of the 20 log-scales a lane needs after pass A, 16
-        // wait in a wave-private LDS stash and 4 in registers — 22 spilled registers otherwise, and every scratch reload waits for all
-        // loads in flight, the next item's prefetch included)
-        float4* stash = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem4) + Cfg::LDS_BYTES + wave * Cfg::STASH_BYTES) + lane;
-        float ls4[2][2];
-        if (want_nll) {
-            f32x4 accb[2][4];
-            mfma_tiles<5, 2>(wl, reg, tapoff, lane, accb);
-            finish_tiles<5, 2>(a, bias_l, accb, inv, false, orow, y0, x0, j, q);
-            // the same row swap as for tiles 0..4 below: afterwards accb[c][s2] holds lane group q' = 2 (q >> 1) and accb[c][s2 + 2]
-            // lane group q' + 1 of THIS lane's pixel.  Slot layout of tiles 5, 6: packing.dlm_log_scale_slot
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(accb[c][s2][r]), __float_as_uint(accb[c][s2 + 2][r]), false, false);
-                        accb[c][s2][r] = __uint_as_float(sw[0]);
-                        accb[c][s2 + 2][r] = __uint_as_float(sw[1]);
-                    }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const f32x4 e5 = accb[0][s2], o5 = accb[0][s2 + 2], e6 = accb[1][s2];
-                // {ls_g, ls_b} of ct = 0, 1 (e5) and ct = 2, 3 (o5) of this lane's mixtures: to the stash
-                stash[(2 * s2) * 64] = make_float4(e5[0], e5[1], e5[2], e5[3]);
-                stash[(2 * s2 + 1) * 64] = make_float4(o5[0], o5[1], o5[2], o5[3]);
-                // mixtures 8, 9 sit in lane group 0 of tile 6 (slots 96..99): the odd half (q >= 2) takes registers 2, 3 of its partner lane
-                const float g9 = __shfl_xor(e6[2], 32), b9 = __shfl_xor(e6[3], 32);
-                ls4[s2][0] = q < 2 ? e6[0] : g9;
-                ls4[s2][1] = q < 2 ? e6[1] : b9;
-            }
-        }
-
         float nll_item = 0.f;
-        // ---- pass A: channel tiles 0..4 = the 80 slots the mixture mean reads ----
         {
-            f32x4 acc[5][4];
-            mfma_tiles<0, 5>(wl, reg, tapoff, lane, acc);
             finish_tiles<0, 5>(a, bias_l, acc, inv, store_raw, orow, y0, x0, j, q);
             if (mode == GCPX_HEAD_DLM_MEAN || mode == GCPX_HEAD_DLM_BOTH || mode == GCPX_HEAD_DLM_NLL || mode == GCPX_HEAD_DLM_NLL_GRAD) {
                 // kernel channel order and the lane exchange: see conv3x3_head_kernel (conv3x3.hip)
@@ -386,8 +318,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                         // ---- fused likelihood, second half (the formulas of dlm_nll_kernel, csrc/loss.hip): this lane's five mixtures of
                         // its pixel, the other five in lane ^ 32; m / S above are the max / sum of exp over all ten logits
                         const float lse_logits = m + __logf(S);
-                        const float* tp = a.nll_target + (size_t)orow * 3 * plane + (size_t)(y0 + s2 + 2 * (q & 1)) * W + (x0 + j);
-                        const float xr = tp[0], xg = tp[plane], xb = tp[2 * plane];
+                        const float xr = tx[s2][0], xg = tx[s2][1], xb = tx[s2][2];      // (requested one half-phase earlier, beside the staging)
                         const float4 st0 = stash[(2 * s2) * 64], st1 = stash[(2 * s2 + 1) * 64];
                         const float lsg[5] = {st0.x, st0.z, st1.x, st1.z, ls4[s2][0]}, lsb[5] = {st0.y, st0.w, st1.y, st1.w, ls4[s2][1]};
                         float lp[5];
@@ -493,14 +424,129 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                 if (lane == 0) a.nll_partial[(size_t)it_in_f * a.nll_rows + orow] = v;
             }
         }
-        // ---- pass B: channel tiles 5, 6 = slots 80..99 (+ 12 empty): only ever stored raw, so only computed when that is asked for ----
-        if (store_raw) {
-            f32x4 acc[2][4];
-            mfma_tiles<5, 2>(wl, reg, tapoff, lane, acc);
-            finish_tiles<5, 2>(a, bias_l, acc, inv, true, orow, y0, x0, j, q);
+    };
+    if (PP && grp == 1) __syncthreads();                       // the second half of the workgroup runs one half-phase behind
+    for (int it = 0; it <= n_iter; ++it, item += istep) {           // (one extra trip: the last item's epilogue — ONE copy of that code)
+        const bool valid = it < n_iter && item < item_end;
+        // ======== VALU half-phase: epilogue of the previous item, staging of this one ========
+        if (p_valid) epilogue();
+        int f = 0, y0 = 0, x0 = 0, orow = -1;
+        float inv = 1.f;
+        if (valid) {
+            origin(item, f, y0, x0);
+            orow = __builtin_amdgcn_readfirstlane(pre_orow);
+            // ---- staging: BatchNorm affine + LeakyReLU of the producer, the item's power-of-two scale, the two f16 pieces ----
+            float amax = 0.f;
+    #pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                if (pre_ok & (1u << k)) {          // (the zero padding of the conv stays exactly zero)
+                    float4 v = pre[k];
+                    v.x = fmaf(v.x, bn_s.x, bn_t.x); v.y = fmaf(v.y, bn_s.y, bn_t.y); v.z = fmaf(v.z, bn_s.z, bn_t.z); v.w = fmaf(v.w, bn_s.w, bn_t.w);
+                    v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+                    v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+                    pre[k] = v;
+                }
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(pre[k].x), fabsf(pre[k].y)), fmaxf(fabsf(pre[k].z), fabsf(pre[k].w))));
+            }
+    #pragma unroll
+            for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+            // amax 2^ex in [2^14, 2^15): below the f16 maximum, and every piece that matters is a normal f16
+            int ex = 14 + 127 - (int)((__float_as_uint(amax) >> 23) & 0xff);
+            ex = __builtin_amdgcn_readfirstlane(amax > 0.f ? max(-100, min(min(100, 126 - ew), ex)) : 0);   // (2^-(ex + ew) stays a normal f32)
+            const float sx2 = __uint_as_float((unsigned)(127 + ex) << 23);
+    #pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int idx = lane + 64 * k;
+                if (idx < RH * RW * 4) {
+                    const float4 v = make_float4(pre[k].x * sx2, pre[k].y * sx2, pre[k].z * sx2, pre[k].w * sx2);
+                    h4 p1, p2;
+                    p1[0] = (_Float16)v.x; p1[1] = (_Float16)v.y; p1[2] = (_Float16)v.z; p1[3] = (_Float16)v.w;
+                    p2[0] = (_Float16)(v.x - (float)p1[0]); p2[1] = (_Float16)(v.y - (float)p1[1]);
+                    p2[2] = (_Float16)(v.z - (float)p1[2]); p2[3] = (_Float16)(v.w - (float)p1[3]);
+                    char* dst = reg + (idx >> 2) * 32 + (idx & 3) * 8;
+                    *reinterpret_cast<h4*>(dst) = p1;
+                    *reinterpret_cast<h4*>(dst + Cfg::PLANE_BYTES) = p2;
+                }
+            }
+
+            inv = __uint_as_float((unsigned)(127 - ex - ew) << 23);      // undoes the two power-of-two scales (exact)
         }
+        if (NLL && valid && orow >= 0) {
+            // the target pixels of this item's likelihood: requested now, read in the epilogue one full MFMA half-phase later
+            const float* tp = a.nll_target + (size_t)orow * 3 * plane + (size_t)(y0 + 2 * (q & 1)) * W + (x0 + j);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tx[s2][c] = tp[c * plane + (size_t)s2 * W];
+        } else if (NLL) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tx[s2][c] = 0.f;
+        }
+        flush_images();
+        pend_ip = nullptr;
+        if (it + 1 < n_iter && item + istep < item_end) issue_loads(item + istep);        // in flight during this item's MFMAs
+        if (PP) __syncthreads();
+        // ======== MFMA half-phase ========
+        if (valid) {
+            const bool want_nll = NLL && orow >= 0;
+            // fused likelihood, first half: the green / blue log-scales (channel tiles 5, 6).  A lane of the epilogue owns pixel
+            // (row s2 + 2 (q & 1), column j) and mixtures 2 ct + (q >> 1), ct = 0..4.  (The kernel sits at the 256-register limit of
+            // two wavefronts per SIMD: of the 20 log-scales a lane needs in the epilogue, 16 wait in a wave-private LDS stash and 4 in
+            // registers — 22 spilled registers otherwise, and every scratch reload waits for all loads in flight.)
+            if (want_nll) {
+                f32x4 accb[2][4];
+                mfma_tiles<5, 2>(wl, reg, tapoff, lane, accb);
+                finish_tiles<5, 2>(a, bias_l, accb, inv, false, orow, y0, x0, j, q);
+                // the same row swap as for tiles 0..4 below: afterwards accb[c][s2] holds lane group q' = 2 (q >> 1) and accb[c][s2 + 2]
+                // lane group q' + 1 of THIS lane's pixel.  Slot layout of tiles 5, 6: packing.dlm_log_scale_slot
+    #pragma unroll
+                for (int c = 0; c < 2; ++c)
+    #pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(accb[c][s2][r]), __float_as_uint(accb[c][s2 + 2][r]), false, false);
+                            accb[c][s2][r] = __uint_as_float(sw[0]);
+                            accb[c][s2 + 2][r] = __uint_as_float(sw[1]);
+                        }
+    #pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const f32x4 e5 = accb[0][s2], o5 = accb[0][s2 + 2], e6 = accb[1][s2];
+                    // {ls_g, ls_b} of ct = 0, 1 (e5) and ct = 2, 3 (o5) of this lane's mixtures: to the stash
+                    stash[(2 * s2) * 64] = make_float4(e5[0], e5[1], e5[2], e5[3]);
+                    stash[(2 * s2 + 1) * 64] = make_float4(o5[0], o5[1], o5[2], o5[3]);
+                    // mixtures 8, 9 sit in lane group 0 of tile 6 (slots 96..99): the odd half (q >= 2) takes registers 2, 3 of its partner lane
+                    const float g9 = __shfl_xor(e6[2], 32), b9 = __shfl_xor(e6[3], 32);
+                    ls4[s2][0] = q < 2 ? e6[0] : g9;
+                    ls4[s2][1] = q < 2 ? e6[1] : b9;
+                }
+            }
+
+            // pass A: channel tiles 0..4 = the 80 slots the mixture mean reads; their epilogue runs in the next VALU half-phase
+            mfma_tiles<0, 5>(wl, reg, tapoff, lane, acc);
+            // pass B for the stored-parameters modes: channel tiles 5, 6 = slots 80..99 (+ 12 empty), only ever stored raw
+            if (NLL == 0 && (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) && orow >= 0) {
+                f32x4 accr[2][4];
+                mfma_tiles<5, 2>(wl, reg, tapoff, lane, accr);
+                finish_tiles<5, 2>(a, bias_l, accr, inv, true, orow, y0, x0, j, q);
+            }
+        }
+        else {
+            // (every path through this half-phase defines the accumulators: otherwise they count as live across the staging and the
+            // prefetch of the next item — 80 registers — and the prefetch addresses get spilled instead)
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[c][pt] = f32x4{0, 0, 0, 0};
+            ls4[0][0] = ls4[0][1] = ls4[1][0] = ls4[1][1] = 0.f;
+        }
+        p_valid = valid; p_f = f; p_y0 = y0; p_x0 = x0; p_orow = orow; p_inv = inv;
+        if (PP) __syncthreads();
     }
     flush_images();
+    if (PP && grp == 0) __syncthreads();                       // every wavefront passes the same number of barriers
 }
 
 
@@ -1584,16 +1630,23 @@ int gcpx_launch_head_split(const gcpx_conv_args* a, hipStream_t stream) {
         GCPX_CHECK_ARG(a->out_pitch == 112, "the fused likelihood is written for the 112-slot layout of the 10-mixture head");
         GCPX_CHECK_ARG(nll == 1 || a->out, "GCPX_HEAD_DLM_NLL_GRAD writes the parameter gradient to `out`");
     }
-    auto kern = nll == 2 ? conv3x3_head_split_kernel<2> : (nll == 1 ? conv3x3_head_split_kernel<1> : conv3x3_head_split_kernel<0>);
+    // GCPX_HEAD_PINGPONG=1: the loop WITH two workgroup barriers per item, so that waves 0-3 issue MFMAs while waves 4-7 do their
+    // epilogue / staging VALU work and vice versa (the two wavefronts of a SIMD in explicit alternation).  Measured SLOWER in every mode
+    // (standalone, c2 shapes: mean only 0.81 vs 0.69 ms, fused likelihood 1.29 vs 1.08, + gradient 1.73 vs 1.50; in the forward 1.11 vs
+    // 0.95): the half-phases do not balance and every barrier waits for the slowest of eight wavefronts — kept as an experiment switch.
+    static const bool pp = getenv("GCPX_HEAD_PINGPONG") != nullptr;
+    typedef void (*kern_t)(const gcpx_conv_args, const int, const int);
+    static const kern_t kerns[6] = {conv3x3_head_split_kernel<0, false>, conv3x3_head_split_kernel<1, false>, conv3x3_head_split_kernel<2, false>,
+                                    conv3x3_head_split_kernel<0, true>, conv3x3_head_split_kernel<1, true>, conv3x3_head_split_kernel<2, true>};
+    kern_t kern = kerns[(pp ? 3 : 0) + nll];
     const int lds = nll ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* ks[3] = {reinterpret_cast<const void*>(conv3x3_head_split_kernel<0>), reinterpret_cast<const void*>(conv3x3_head_split_kernel<1>),
-                             reinterpret_cast<const void*>(conv3x3_head_split_kernel<2>)};
-        for (int i = 0; i < 3; ++i) {
-            hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, i ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES);
+        for (int i = 0; i < 6; ++i) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (i % 3) ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES);
             if (e != hipSuccess) {
-                gcpx_set_error("conv3x3 split head: hipFuncSetAttribute(%d B LDS): %s", i ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES, hipGetErrorString(e));
+                gcpx_set_error("conv3x3 split head: hipFuncSetAttribute(%d B LDS): %s", (i % 3) ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES, hipGetErrorString(e));
                 return GCPX_ERR_HIP;
             }
         }

@@ -191,7 +191,11 @@ class GCPTreeModel:
             self.sd[k] = view
 
     def _check_hp(self, hp):
-        assert hp.matching_type in ("balanced", "dtw_image") and hp.tree_lstm == "split_linear" and hp.lstm_init == "mlp"
+        assert hp.matching_type in ("balanced", "dtw_image")
+        if hp.tree_lstm not in ("split_linear", "linear", "sum"):                  # tree_lstm.py:52-60 (the non-LSTM
+            raise ValueError("don't know this TreeLSTM type")                      # GeneralizedPredictorModel, tree_module.py:45-46, is not built)
+        if hp.lstm_init not in ("mlp", "zero"):
+            raise ValueError("dont know lstm init type {}!".format(hp.lstm_init))  # tree_lstm.py:74
         if hp.attentive_inference:
             assert hp.n_attention_layers == 1, "one attention layer is built (hyperparameters.py:25 default)"
         if hp.adaptive:
@@ -200,6 +204,9 @@ class GCPTreeModel:
 
     def _n_latents(self):
         return self._hp.n_nodes
+
+    def _zero_row(self, n):
+        return self._buf("zero_row", (n,), zero=True)
 
     def _head_nll_fusable(self):
         hp = self._hp
@@ -573,9 +580,13 @@ class GCPTreeModel:
             T["out.w"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.out.weight"])
             T["out.b"] = sd[f"{p}.subgoal_pred.out.bias"].contiguous()
             nproj = 2 * hp.n_lstm_layers
-            T["proj.w"] = torch.stack([pk.pack_gemm(sd[f"{p}.subgoal_pred.projections.{j}.weight"]) for j in range(nproj)]).contiguous()
-            T["proj.b"] = torch.stack([sd[f"{p}.subgoal_pred.projections.{j}.bias"] for j in range(nproj)]).contiguous()
-            if l == 0:
+            if hp.tree_lstm == "split_linear":
+                T["proj.w"] = torch.stack([pk.pack_gemm(sd[f"{p}.subgoal_pred.projections.{j}.weight"]) for j in range(nproj)]).contiguous()
+                T["proj.b"] = torch.stack([sd[f"{p}.subgoal_pred.projections.{j}.bias"] for j in range(nproj)]).contiguous()
+            elif hp.tree_lstm == "linear":
+                T["proj.w"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.projection.weight"])
+                T["proj.b"] = sd[f"{p}.subgoal_pred.projection.bias"].contiguous()
+            if l == 0 and hp.lstm_init == "mlp":
                 T["init"] = self._pack_predictor(f"{p}.lstm_initializer.net", 2 * hp.lstm_state_dim)
             if hp.attentive_inference:
                 a = f"{p}.inference.attention"
@@ -1024,6 +1035,19 @@ class GCPTreeModel:
                 s_, n_ = 2 ** (L - 1 - lv), 2 ** lv
                 Wl = P[f"tree{lv if hp.untied_layers else 0}"]
                 mg = self._buf(f"merged{lv}", (B * n_, 2 * nl * H))
+                if hp.tree_lstm == "sum":
+                    # SumTree (tree_lstm.py:14-16): the parents' states added, no parameters
+                    for side, mode in ((0, 0), (2 * s_ * SD, 1)):
+                        plan.add(f"merge{lv}.{mode}", lib.gcpx_rows_strided, _addr(mg), n_ * SD, SD, _addr(Hid, side), PS * SD, 2 * s_ * SD,
+                                 B, n_, SD, mode)
+                    return
+                if hp.tree_lstm == "linear":
+                    # LinTree (tree_lstm.py:25-27): ONE Linear(2 SD -> SD) over both parents' whole states
+                    h1 = self._rowsrc(_addr(Hid), PS * SD, 2 * s_ * SD, SD)
+                    h2 = self._rowsrc(_addr(Hid, 2 * s_ * SD), PS * SD, 2 * s_ * SD, SD)
+                    self._gemm(plan, f"merge{lv}", [h1, h2], B * n_, SD, n_, Wl["proj.w"], Wl["proj.b"], out=_addr(mg), ob=n_ * SD, orow=SD,
+                               group=group)
+                    return
                 h1 = self._rowsrc(_addr(Hid), PS * SD, 2 * s_ * SD, H)
                 h2 = self._rowsrc(_addr(Hid, 2 * s_ * SD), PS * SD, 2 * s_ * SD, H)
                 self._gemm(plan, f"merge{lv}", [h1, h2], B * n_, H, n_, Wl["proj.w"], Wl["proj.b"], out=_addr(mg),
@@ -1057,9 +1081,15 @@ class GCPTreeModel:
                 self._mlp_group(plan, f"prior+posterior{l}", pq)
             zs = lambda: self._rowsrc(z_map[0], z_map[1], z_map[2], nv)
             if l == 0:
-                # MLPLSTMCellInitializer (tree_module.py:104-105): (h_left, h_right) -> slots 0 and 2^L
-                self._mlp(plan, "lstm_init", W["init"], [el(), er(), zs()], M, n, out=_addr(Hid), ob=PS * SD, orow=0,
-                          oblk=2 ** L * SD, out_split=SD)
+                if hp.lstm_init == "zero":
+                    # ZeroLSTMCellInitializer (tree_lstm.py:68-70): both root parents start from zero states
+                    for slot in (0, 2 ** L):
+                        plan.add(f"lstm_init.zero{slot}", lib.gcpx_rows_strided, _addr(Hid, slot * SD), PS * SD, 0, self._zero_row(SD).data_ptr(),
+                                 0, 0, B, 1, SD, 0)
+                else:
+                    # MLPLSTMCellInitializer (tree_module.py:104-105): (h_left, h_right) -> slots 0 and 2^L
+                    self._mlp(plan, "lstm_init", W["init"], [el(), er(), zs()], M, n, out=_addr(Hid), ob=PS * SD, orow=0,
+                              oblk=2 ** L * SD, out_split=SD)
                 plan_merge()
             # input embedding of [e_l, e_r, z, e_0, e_g] (tree_module.py:97-101); inference plans fold it into LSTM layer 0
             x = self._buf(f"x{l}.0", (M, H))

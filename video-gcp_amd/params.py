@@ -147,9 +147,13 @@ def param_table(hp):
             tab[f"{p}.subgoal_pred.lstm.{i}.bias_hh"] = ((4 * H,), "lstm")
         tab[f"{p}.subgoal_pred.out.weight"] = ((hp.nz_enc, H), "xavier")
         tab[f"{p}.subgoal_pred.out.bias"] = ((hp.nz_enc,), "zeros")
-        for j in range(2 * hp.n_lstm_layers):
-            tab[f"{p}.subgoal_pred.projections.{j}.weight"] = ((H, 2 * H), "xavier")
-            tab[f"{p}.subgoal_pred.projections.{j}.bias"] = ((H,), "zeros")
+        if hp.tree_lstm == "split_linear":                       # tree_lstm.py:30-41: one Linear(2H -> H) per (layer, h / c) chunk
+            for j in range(2 * hp.n_lstm_layers):
+                tab[f"{p}.subgoal_pred.projections.{j}.weight"] = ((H, 2 * H), "xavier")
+                tab[f"{p}.subgoal_pred.projections.{j}.bias"] = ((H,), "zeros")
+        elif hp.tree_lstm == "linear":                           # tree_lstm.py:19-27: one Linear over both parents' whole states
+            tab[f"{p}.subgoal_pred.projection.weight"] = ((hp.lstm_state_dim, 2 * hp.lstm_state_dim), "xavier")
+            tab[f"{p}.subgoal_pred.projection.bias"] = ((hp.lstm_state_dim,), "zeros")
         if hp.attentive_inference:
             # AttentiveInference.attention (attentive_inference.py:38-45)
             a = f"{p}.inference.attention"
@@ -166,8 +170,9 @@ def param_table(hp):
             tab[f"{a}.out.weight"] = ((hp.nz_enc, hp.nz_enc), "xavier")
             tab[f"{a}.out.bias"] = ((hp.nz_enc,), "zeros")
         if l == 0:
-            _predictor(tab, f"{p}.lstm_initializer.net", 2 * hp.nz_enc + hp.nz_vae, 2 * hp.lstm_state_dim,
-                       hp.init_mlp_mid_sz, hp.init_mlp_layers)
+            if hp.lstm_init == "mlp":                            # 'zero' (ZeroLSTMCellInitializer, tree_lstm.py:68-70) has no parameters
+                _predictor(tab, f"{p}.lstm_initializer.net", 2 * hp.nz_enc + hp.nz_vae, 2 * hp.lstm_state_dim,
+                           hp.init_mlp_mid_sz, hp.init_mlp_layers)
             if hp.adaptive:
                 # AdaptiveBinding.build_network (adaptive.py:18-30)
                 _predictor(tab, f"{p}.binding.distance_predictor", 2 * hp.nz_enc, 1, hp.nz_mid, npl)

@@ -206,9 +206,12 @@ class GCPTrainStep:
                 T[f"lstm{i}.wxT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.lstm.{i}.weight_ih"].t().contiguous())   # [H][4H]
                 T[f"lstm{i}.whT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.lstm.{i}.weight_hh"].t().contiguous())
             T["out.wT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.out.weight"].t().contiguous())                     # [H][nz]
-            T["proj.wT"] = torch.stack([pk.pack_gemm(sd[f"{p}.subgoal_pred.projections.{j}.weight"].t().contiguous())
-                                        for j in range(2 * hp.n_lstm_layers)]).contiguous()                     # [2H][H] each
-            if l == 0:
+            if hp.tree_lstm == "split_linear":
+                T["proj.wT"] = torch.stack([pk.pack_gemm(sd[f"{p}.subgoal_pred.projections.{j}.weight"].t().contiguous())
+                                            for j in range(2 * hp.n_lstm_layers)]).contiguous()                 # [2H][H] each
+            elif hp.tree_lstm == "linear":
+                T["proj.wT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.projection.weight"].t().contiguous())         # [n = 2 SD][k = SD]
+            if l == 0 and hp.lstm_init == "mlp":
                 T["init"] = self._pack_predictor_T(sd, f"{p}.lstm_initializer.net", [(0, 2 * nz + nv)])
             if hp.attentive_inference:
                 a = f"{p}.inference.attention"
@@ -674,6 +677,20 @@ class GCPTrainStep:
             dpi = buf(f"bw.dpi{l}", (M, pid))
             self._dgemm(plan, f"embed{l}", [self._dense(dx0.data_ptr(), H, H, M)], M, pid, M, Wt["embed.wT"], dpi.data_ptr(), 0, pid)
             def merge_backward():
+                if hp.tree_lstm == "sum":
+                    # SumTree (tree_lstm.py:14-16): the gradient of the merged state goes to both parents unchanged
+                    self._tree_accum(plan, f"hid{l}", dHid, PS * SD, 2 * s * SD, B, n, SD, [(dmerged.data_ptr(), SD, 0, 0, -1, -1, 0)])
+                    return
+                if hp.tree_lstm == "linear":
+                    # LinTree (tree_lstm.py:25-27): one Linear over [hidden_left | hidden_right]
+                    for side, base in ((0, 0), (1, 2 * s * SD)):
+                        self._wgrad(plan, f"proj{l}.{side}", dmerged.data_ptr(), SD, M, SD, _addr(Hid, base), SD,
+                                    self.g(f"{sp}.projection.weight"), ldw=2 * SD, k_off=side * SD, rpb=n, sb=PS * SD, sr=2 * s * SD,
+                                    dbias=(self.g(f"{sp}.projection.bias") if side == 0 else None))
+                    dpar = buf(f"bw.dpar{l}", (M, 2 * SD))
+                    self._dgemm(plan, f"merge{l}", [self._dense(dmerged.data_ptr(), SD, SD, M)], M, 2 * SD, M, Wt["proj.wT"], dpar.data_ptr(), 0, 2 * SD)
+                    self._tree_accum(plan, f"hid{l}", dHid, PS * SD, 2 * s * SD, B, n, SD, [(dpar.data_ptr(), 2 * SD, 0, SD, -1, -1, 0)])
+                    return
                 # split_linear merge of the parents' hidden states
                 # all 2*n_lstm_layers projections in one launch per parent side (blockIdx.z = projection)
                 po = [m._poff[f"{sp}.projections.{j}.weight"][0] for j in range(2 * nl)]
@@ -696,7 +713,7 @@ class GCPTrainStep:
             dXi = None
             if not split:
                 merge_backward()
-            if l == 0:
+            if l == 0 and hp.lstm_init == "mlp":
                 # MLP LSTM initialiser (tree_module.py:104-105): outputs live in Hid slots 0 and 2^L
                 dinit = buf("bw.dinit", (B, 2 * SD))
                 plan.add("bw.dinit.l", lib.gcpx_copy_rows, _addr(dHid), dinit.data_ptr(), B, 1, SD, PS, 2)
