@@ -286,11 +286,13 @@ def test_training_step_with_adam_and_clipping_c1():
 @pytest.mark.parametrize("tree_lstm,lstm_init", [("sum", "zero"), ("linear", "mlp")])
 def test_gradients_tree_lstm_variants_c1(tree_lstm, lstm_init):
     """training step with the Sum / Lin TreeLSTM merge and the zero initialiser (tree_lstm.py:11-27,68-70): every parameter gradient
-    against autograd over the oracle"""
+    against autograd over the oracle.  5e-3 here: a wrong or missing merge backward is off by O(1) in the projection / upstream
+    gradients; differences of 2-3e-3 in a few tensors are LeakyReLU units on the other side of their kink (dissected, unit by unit, in
+    test_gradients_full_length_sequences_c1)."""
     from oracle import gcp_model_oracle as O
     hp, sd, model, tr = _setup("c1", False, tree_lstm=tree_lstm, lstm_init=lstm_init)
     inputs, noise, _ = make_inputs(hp, seed=9, variant="B")
     tr.backward({k: v.cuda() for k, v in inputs.items()}, noise.cuda())
     torch.cuda.synchronize()
     gref, _, _, _ = O.gradients(sd, hp, inputs, noise)
-    _compare_grads(gref, tr.named_grads())
+    _compare_grads(gref, tr.named_grads(), rtol=5e-3)

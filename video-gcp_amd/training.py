@@ -230,7 +230,7 @@ class GCPTrainStep:
     def _side(self, plan, name, fn, *args):
         plan.deferred.append((name, fn, args))
 
-    def _flush(self, plan, one_lane=False):
+    def _flush(self, plan, one_lane=False, only_lane=None):
         """one_lane: everything of this flush goes to ONE side lane, behind all work issued so far on the others — for gradients that
         ACCUMULATE into parameters an earlier flush (or another op of this one) also accumulates into: the three encoder passes (trajectory
         frames, I_0, I_g) share their weights, and two lanes adding to one address at the same time lose an update."""
@@ -242,6 +242,8 @@ class GCPTrainStep:
             plan.deferred = []
             return
         lanes = list(range(1, 1 + self.n_side))
+        if only_lane is not None:                              # everything of this flush on ONE given side lane (the others stay free)
+            lanes = [only_lane]
         plan.fork(lanes)
         if one_lane:
             for other in lanes[1:]:

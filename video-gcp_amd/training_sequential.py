@@ -177,23 +177,30 @@ class SequentialTrainStep(GCPTrainStep):
         dE_dec, dskip = self._decoder_backward(plan, fplan, dMD, B, maps=dict(R=B * T, row2src=row2frame, frame2row=rec["seq_row_map"],
                                                                                row2frame=row2frame_inv))
         plan.join([1])
-        self._flush(plan)                                     # decoder weight gradients: beside the generator / inference chains
+        self._flush(plan, only_lane=2)                        # decoder weight gradients: on lane 2, beside the generator / inference chains
         # gradient of x_{t+1}, t = 0 .. T-2: decoder + the prior's input at step t + 1
         plan.add("bw.addrows.dec", lib.gcpx_add_rows, _addr(DX, nz), T * nz, nz, dE_dec.data_ptr(), None, B, T - 1, nz)
         self._rows(plan, "bw.prior.dx", DX.data_ptr(), T * nz, nz, dIn["prior_lstm"].data_ptr(), (T - 1) * 3 * nz, 3 * nz, B, T - 1, nz, 1)
 
-        # ---- generator chain: the gradient of x_t is complete once step t has added its input gradient ----
+        # ---- generator chain on the main lane, inference chain one step behind it on lane 1 ----
+        # gen(t): the gradient of x_t is complete once step t has added its input gradient.  z_t = mu_q + exp(log_sigma_q) eps
+        # (sequential.py:51-54): step t's d z_t turns into d q_t right away (one tiny launch), lane 1 waits for exactly that and runs the
+        # inference net's step t while the generator goes on to step t - 1 — the two 79-step chains overlap instead of queueing.
+        DQ, DPd = buf("bw.seq.DQ", (T - 1, B, 2 * nv)), buf("bw.seq.DPd", (B, 2 * nv))
+        gd = in_dim["gen_lstm"]
+        inf_chain = self._chain(plan, "inf_lstm", lambda t: m._rowsrc(DQ[t].data_ptr(), 2 * nv, 0, 2 * nv), B, T, dIn["inf_lstm"], nrec)
         for t in self._chain(plan, "gen_lstm", lambda t: m._rowsrc(_addr(DX, (t + 1) * nz), T * nz, 0, nz), B, T, dIn["gen_lstm"], nrec):
-            self._rows(plan, f"bw.gen.dx{t}", _addr(DX, t * nz), T * nz, 0, _addr(dIn["gen_lstm"], t * in_dim["gen_lstm"]),
-                       (T - 1) * in_dim["gen_lstm"], 0, B, 1, nz, 1)
-
-        # ---- z_t = mu_q + exp(log_sigma_q) eps (sequential.py:51-54): d q for every step in one launch, then the inference chain ----
-        DQ, DPd = buf("bw.seq.DQ", (B * (T - 1), 2 * nv)), buf("bw.seq.DPd", (B * (T - 1), 2 * nv))
-        plan.add("bw.latent", lib.gcpx_latent_bwd, dQZ.data_ptr(), dPZ.data_ptr(), QZ.data_ptr(), (T - 1) * 2 * nv, 2 * nv,
-                 tin["eps"].data_ptr(), tin["eps"].shape[1] * nv, nv, _addr(dIn["gen_lstm"], nz), in_dim["gen_lstm"], None, 0,
-                 DQ.data_ptr(), DPd.data_ptr(), B * (T - 1), T - 1, nv)
-        for _ in self._chain(plan, "inf_lstm", lambda t: m._rowsrc(_addr(DQ, t * 2 * nv), (T - 1) * 2 * nv, 0, 2 * nv), B, T, dIn["inf_lstm"], nrec):
+            self._rows(plan, f"bw.gen.dx{t}", _addr(DX, t * nz), T * nz, 0, _addr(dIn["gen_lstm"], t * gd), (T - 1) * gd, 0, B, 1, nz, 1)
+            plan.add(f"bw.latent{t}", lib.gcpx_latent_bwd, _addr(dQZ, t * 2 * nv), _addr(dPZ, t * 2 * nv), _addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 0,
+                     _addr(tin["eps"], t * nv), tin["eps"].shape[1] * nv, 0, _addr(dIn["gen_lstm"], t * gd + nz), (T - 1) * gd, None, 0,
+                     DQ[t].data_ptr(), DPd.data_ptr(), B, 1, nv)
+            plan.wait(1, 0)
+            plan.lane = 1
+            next(inf_chain)
+            plan.lane = 0
+        for _ in inf_chain:                                   # (exhausts the generator: it records its stacked buffers on the way out)
             pass
+        plan.join([1])
 
         # ---- weight gradients of the three nets: stacked rows r = (t, b) ----
         def stacked(t_stride, b_stride):
@@ -204,7 +211,8 @@ class SequentialTrainStep(GCPTrainStep):
                 "inf_lstm": [dict(ptr=_addr(enc_traj, nz), w=nz, **stacked(nz, T * nz)), dict(w=nz, **e0s), dict(w=nz, **egs)],
                 "gen_lstm": [dict(ptr=_addr(X), w=nz, **stacked(nz, T * nz)), dict(ptr=_addr(Z), w=nv, **stacked(nv, (T - 1) * nv)),
                              dict(w=nz, **e0s), dict(w=nz, **egs)]}
-        douts = {"prior_lstm": (dPZ.data_ptr(), (T - 1) * 2 * nv, 2 * nv, 2 * nv), "inf_lstm": (DQ.data_ptr(), (T - 1) * 2 * nv, 2 * nv, 2 * nv),
+        # (gradient of a net's output, rows (t, b): pointer, pitch of b, stride of t — 0 = dense t-major rows —, width)
+        douts = {"prior_lstm": (dPZ.data_ptr(), (T - 1) * 2 * nv, 2 * nv, 2 * nv), "inf_lstm": (DQ.data_ptr(), 2 * nv, 0, 2 * nv),
                  "gen_lstm": (_addr(DX, nz), T * nz, nz, nz)}
         R = (T - 1) * B
         for net in NETS:
@@ -213,7 +221,7 @@ class SequentialTrainStep(GCPTrainStep):
             dG, DX0 = nrec["dG"][net], nrec["DX0"][net]
             dy, ldy, dy_sb, N_out = douts[net]
             self._wgrad(plan, f"{net}.out", dy, ldy, R, N_out, XS[0, nl].data_ptr(), H, self.g(f"{p}.out.weight"), ldw=H, rpb=B,
-                        sb=(nl + 1) * B * H, sr=H, dy_rpb=B, dy_sb=dy_sb, dbias=self.g(f"{p}.out.bias"))
+                        sb=(nl + 1) * B * H, sr=H, dy_rpb=(B if dy_sb else 0), dy_sb=dy_sb, dbias=self.g(f"{p}.out.bias"))
             for i in range(nl):
                 self._wgrad(plan, f"{net}.lstm{i}.ih", dG[i].data_ptr(), 4 * H, R, 4 * H, XS[0, i].data_ptr(), H, self.g(f"{p}.lstm.{i}.weight_ih"),
                             ldw=H, rpb=B, sb=(nl + 1) * B * H, sr=H, dbias=self.g(f"{p}.lstm.{i}.bias_ih"), dbias2=self.g(f"{p}.lstm.{i}.bias_hh"))
