@@ -34,8 +34,15 @@ __device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// exp / log straight on the hardware instructions (v_exp_f32 / v_log_f32 are base 2).  __expf / __logf wrap them in a range fix-up for
+// denormal results / inputs — two compares, two selects and a multiply per call: 531 selects and 558 compares in the likelihood variant of
+// the head kernel, whose time IS its VALU count (PMC: VALU 58 % busy, matrix pipe 36 %, no overlap).  Every use here has a result that
+// may flush to zero (softmax / mixture weights, sigmoids) or an argument >= 1e-12 (logs).
+__device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float log_hw(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+
 __device__ __forceinline__ float fast_tanh_s(float x) {
-    const float e = __expf(2.f * x);
+    const float e = exp_hw(2.f * x);
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
@@ -141,8 +148,8 @@ __device__ __forceinline__ void finish_tiles(const gcpx_conv_args& a, const floa
 }
 
 // hardware exp / log / reciprocal forms for the fused mixture likelihood (same helpers as csrc/loss.hip)
-__device__ __forceinline__ float sigmoid_fast_s(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float softplus_s(float x) { return x > 20.f ? x : __logf(1.f + __expf(x)); }
+__device__ __forceinline__ float sigmoid_fast_s(float x) { return __builtin_amdgcn_rcpf(1.f + exp_hw(-x)); }
+__device__ __forceinline__ float softplus_s(float x) { return x > 20.f ? x : log_hw(1.f + exp_hw(x)); }
 
 // NLL = 1: head mode GCPX_HEAD_DLM_NLL — frames matched to a ground-truth frame (raw_row_map entry >= 0) additionally evaluate the
 // discretised-logistic-mixture likelihood of that frame in the epilogue and write one partial sum per item
@@ -305,7 +312,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                     float S = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
 #pragma unroll
                     for (int ct = 0; ct < 5; ++ct) {
-                        const float w = __expf(lg[ct] - m);
+                        const float w = exp_hw(lg[ct] - m);
                         S += w; Sr += w * mr[ct]; Sg += w * mg[ct]; Sb += w * mb[ct];
                     }
                     S += __shfl_xor(S, 32); Sr += __shfl_xor(Sr, 32); Sg += __shfl_xor(Sg, 32); Sb += __shfl_xor(Sb, 32);
@@ -317,7 +324,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                     if (want_nll) {
                         // ---- fused likelihood, second half (the formulas of dlm_nll_kernel, csrc/loss.hip): this lane's five mixtures of
                         // its pixel, the other five in lane ^ 32; m / S above are the max / sum of exp over all ten logits
-                        const float lse_logits = m + __logf(S);
+                        const float lse_logits = m + log_hw(S);
                         const float xr = tx[s2][0], xg = tx[s2][1], xb = tx[s2][2];      // (requested one half-phase earlier, beside the staging)
                         const float4 st0 = stash[(2 * s2) * 64], st1 = stash[(2 * s2 + 1) * 64];
                         const float lsg[5] = {st0.x, st0.z, st1.x, st1.z, ls4[s2][0]}, lsb[5] = {st0.y, st0.w, st1.y, st1.w, ls4[s2][1]};
@@ -337,11 +344,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                             for (int c = 0; c < 3; ++c) {
                                 const float ls = fmaxf(lsr[c], -7.f);
                                 const float xc = x[c] - mean[c];
-                                const float is = __expf(-ls);
+                                const float is = exp_hw(-ls);
                                 const float plus_in = is * (xc + 1.f / 255.f), min_in = is * (xc - 1.f / 255.f);
                                 const float sp = sigmoid_fast_s(plus_in), sm = sigmoid_fast_s(min_in);
                                 const float cdf_delta = sp - sm;
-                                float v = __logf(fmaxf(cdf_delta, 1e-12f));
+                                float v = log_hw(fmaxf(cdf_delta, 1e-12f));
                                 float dm = 0.f, ds = 0.f;          // d v / d mean, d v / d log_scale (dlm_nll_bwd_kernel, csrc/backward.hip)
                                 if constexpr (NLL == 2) {
                                     const float pp_ = sp * (1.f - sp), pm_ = sm * (1.f - sm);
@@ -380,9 +387,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                         mx = fmaxf(mx, __shfl_xor(mx, 32));
                         float se = 0.f;
 #pragma unroll
-                        for (int ct = 0; ct < 5; ++ct) se += __expf(lp[ct] - mx);
+                        for (int ct = 0; ct < 5; ++ct) se += exp_hw(lp[ct] - mx);
                         se += __shfl_xor(se, 32);
-                        nll_item -= mx + __logf(se);          // (both lanes of a pixel hold it; only q < 2 is summed below)
+                        nll_item -= mx + log_hw(se);          // (both lanes of a pixel hold it; only q < 2 is summed below)
                         if constexpr (NLL == 2) {
                             // ---- gradient rows: slots 8k .. 8k+7 of this lane's mixtures k = 2 ct + (q >> 1), then its g / b log-scales ----
                             const float coef = a.nll_scale * (a.nll_row_weight ? a.nll_row_weight[orow] : 1.f);
@@ -392,8 +399,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                             float glg[5], glb[5];
 #pragma unroll
                             for (int ct = 0; ct < 5; ++ct) {
-                                const float w = __expf(lp[ct] - mx) * inv_se;                 // responsibility of the mixture
-                                const float pik = __expf(lgk[ct] - lse_logits);
+                                const float w = exp_hw(lp[ct] - mx) * inv_se;                 // responsibility of the mixture
+                                const float pik = exp_hw(lgk[ct] - lse_logits);
                                 const float gw = -coef * w;                                   // d (-logsumexp) / d s_k
                                 const float g1 = gw * gm[ct][1], g2 = gw * gm[ct][2];
                                 float* dk = drow + 8 * (2 * ct + h);
