@@ -349,6 +349,9 @@ typedef struct gcpx_loss_args {
     const float* cost_target;     /* [B] */
     int32_t n_actions;
     float w_action, w_cost;
+    /* weights of the state regression when they differ from pad_mask (gcp_sequential: pad_mask above is the reconstruction
+       weight with frame 0 zeroed, sequential.py:63-66, while the regressor still sees frame 0, base_gcp.py:281-286); NULL = pad_mask */
+    const float* state_mask;      /* [B*T] or NULL */
 } gcpx_loss_args;
 
 int gcpx_dlm_nll(const float* params, const float* target, const float* row_weight, float* nll_out, int32_t rows,

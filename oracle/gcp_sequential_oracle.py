@@ -82,7 +82,8 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     mes = torch.nn.utils.rnn.pad_sequence(out["model_enc_seq_list"], batch_first=True)
     out["model_enc_seq"] = mes
     if hp.attach_state_regressor:
-        out["regressed_state"] = O.predictor(sd, "state_regressor", hp, mes.reshape(-1, mes.shape[-1])).reshape(B, mes.shape[1], -1)
+        reg_in = mes.detach()                                         # base_gcp.py:253-255 (supervised_decoder=False)
+        out["regressed_state"] = O.predictor(sd, "state_regressor", hp, reg_in.reshape(-1, mes.shape[-1])).reshape(B, mes.shape[1], -1)
     if hp.attach_inv_mdl and phase == "train":
         e1 = mes[:, 1:]
         e0s = inp["enc_traj_seq"][:, :-1][:, :e1.shape[1]] if "enc_traj_seq" in inp else mes[:, :-1]
@@ -111,6 +112,10 @@ def losses(sd, hp, inputs, out):
     res = {"dense_img_rec": (nll, hp.dense_img_rec_weight), "kl": (kl.sum() / B, hp.kl_weight)}
     if hp.regress_length:
         res["len_pred"] = (F.cross_entropy(out["seq_len_logits"], inputs["end_ind"]), hp.length_pred_weight)
+    if "regressed_state" in out and "traj_seq_states" in inputs:      # base_gcp.py:281-286
+        rl = out["regressed_state"].shape[1]
+        e = (out["regressed_state"] - inputs["traj_seq_states"][:, :rl]) ** 2 * pm[:, :rl, None]
+        res["state_regression"] = (e.mean(), 1.0)
     total = sum(v * w for v, w in res.values() if w > 0) / float(torch.tensor(inputs["traj_seq"].shape[1:]).prod())
     return res, total
 

@@ -93,9 +93,9 @@ def test_sequential_gradients_match_autograd(variant):
         if err > 1e-3 * scale + 5e-7:
             bad.append((k, err, scale))
     assert not bad, bad[:10]
-    # everything the three loss terms reach is trained: encoder, decoder, the three recurrent nets, the length predictor
+    # everything the loss terms reach is trained: encoder, decoder, the three recurrent nets, the length predictor, the state regressor
     for pre in ("encoder.", "decoder.", "dense_rec.lstm.cell.prior_lstm.", "dense_rec.lstm.cell.inf_lstm.", "dense_rec.lstm.cell.gen_lstm.",
-                "length_pred."):
+                "length_pred.", "state_regressor."):
         ks = [k for k in gref if k.startswith(pre)]
         assert ks and any(float(got[k].abs().max()) > 0 for k in ks), pre
 

@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(256) loss_heads_bwd_kernel(const gcpx_loss_arg
             const int t = r % T;
             float v = 0.f;
             if (c < a.state_dim && t < rl) {
-                const float pm = a.pad_mask[r];
+                const float pm = (a.state_mask ? a.state_mask : a.pad_mask)[r];
                 v = k * pm * (a.regressed_state[(size_t)r * a.state_dim + c] - a.state_target[(size_t)r * a.state_dim + c]);
             }
             dstate[i] = v;

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256) loss_combine_kernel(const gcpx_loss_args 
         for (int i = tid; i < B * maxlen * sd; i += 256) {
             const int d = i % sd, t = (i / sd) % maxlen, b = i / (sd * maxlen);
             const float e = a.regressed_state[((size_t)b * T + t) * sd + d] - a.state_target[((size_t)b * T + t) * sd + d];
-            v += a.pad_mask[b * T + t] * e * e;
+            v += (a.state_mask ? a.state_mask : a.pad_mask)[b * T + t] * e * e;
         }
         sreg = block_sum(v, red) / (B * maxlen * sd);
     }

@@ -39,7 +39,7 @@ class LossArgs(C.Structure):
                 ("B", i32), ("T", i32), ("N", i32), ("state_dim", i32), ("w_rec", C.c_float), ("w_kl", C.c_float),
                 ("w_len", C.c_float), ("w_exist", C.c_float), ("w_state", C.c_float), ("total_div", C.c_float),
                 ("action_pred", vp), ("action_seq", vp), ("inv_t0", vp), ("cost_pred", vp), ("cost_target", vp),
-                ("n_actions", i32), ("w_action", C.c_float), ("w_cost", C.c_float)]
+                ("n_actions", i32), ("w_action", C.c_float), ("w_cost", C.c_float), ("state_mask", vp)]
 
 
 class RowSrc(C.Structure):

@@ -296,20 +296,41 @@ class GCPSequentialModel(GCPTreeModel):
         prev = self._plan_decoder_features(plan, self._rowsrc(_addr(X, nz), T * nz, nz, nz), F, T - 1, skips)
         dec_images = self._buf("seq.dec_images", (B, T - 1, hp.input_nc, S, S))
         dlm = hp.decoder_distribution == "discrete_logistic_mixture"
-        head_out = row_map = matched = None
+        head_out = row_map = matched = fused_nll = None
         if dlm:
             mode = rt.HEAD_DLM_MEAN
             if with_loss or self.materialize_distr:
                 # parameters of frame (b, t) land in row b*T + t + 1: aligned with the target frame traj_seq[b, t+1]
-                mode, matched = rt.HEAD_DLM_BOTH, self._buf("matched_distr", (B, T, S, S, self._head_pitch))
-                head_out = matched
                 row_map = self._buf("seq.row_map", (F,), torch.int32)
                 row_map.copy_((torch.arange(B)[:, None] * T + torch.arange(1, T)[None]).reshape(-1).to(torch.int32))
+                if with_loss and self._head_nll_fusable():
+                    # likelihood (and, in a training forward, its gradient) in the head's epilogue, as GCPTreeModel._build_plan
+                    fused_nll = self._buf("nll_partial", ((S // 4) * (S // 16), B * T), zero=True)
+                    mode = rt.HEAD_DLM_NLL
+                    if self.save_for_backward:
+                        mode, head_out = rt.HEAD_DLM_NLL_GRAD, self._buf("bw.dMD", (B * T, S, S, self._head_pitch))
+                        # rows (b, 0) of the gradient belong to no decoded frame
+                        r2f = self._buf("seq.row2frame", (B * T,), torch.int32)
+                        inv = torch.arange(B * T, dtype=torch.int64).view(B, T) // T * (T - 1) + torch.arange(T)[None] - 1
+                        inv[:, 0] = -1
+                        r2f.copy_(inv.reshape(-1).to(torch.int32))
+                        plan.add("zero_unmapped", lib.gcpx_zero_unmapped_rows, head_out.data_ptr(), S * S * self._head_pitch,
+                                 r2f.data_ptr(), B * T)
+                        plan.rec["nll_bwd_fused"] = plan.rec["head_grad_fused"] = True
+                else:
+                    mode, matched = rt.HEAD_DLM_BOTH, self._buf("matched_distr", (B, T, S, S, self._head_pitch))
+                    head_out = matched
         else:
             mode = rt.HEAD_TANH_NCHW
         a = self._conv_args([prev], F, S, S, S, S, hp.head_channels, self._head_pitch, P["dec.head.w"], P["dec.head.b"],
                             head_out, upsample=0, head_mode=mode, images=dec_images)
         a.raw_row_map = row_map.data_ptr() if row_map is not None else None
+        if fused_nll is not None:
+            a.nll_target, a.nll_partial, a.nll_rows = tin["traj_seq"].data_ptr(), fused_nll.data_ptr(), B * T
+            if mode == rt.HEAD_DLM_NLL_GRAD:
+                # d total / d nll_bt = w_rec * w0 / (B * prod(traj_seq.shape[1:]))
+                a.nll_row_weight = tin["w0"].data_ptr()
+                a.nll_scale = hp.dense_img_rec_weight / (B * float(T * hp.input_nc * S * S))
         plan.keep.append(a)
         plan.join([1])
         self._set_split(a, "dec.head")
@@ -324,7 +345,11 @@ class GCPSequentialModel(GCPTreeModel):
         # ---- losses (sequential.py:60-68) ----
         if with_loss:
             nll_bt = self._buf("nll_bt", (B, T))
-            if dlm and self.save_for_backward:
+            if dlm and fused_nll is not None:
+                # rows (b, 0) are written by no frame: they stay zero and weigh 0 in the combination below
+                plan.add("loss.nll_reduce", lib.gcpx_reduce_partials, fused_nll.data_ptr(), fused_nll.shape[0], B * T, B * T,
+                         nll_bt.data_ptr(), 0)
+            elif dlm and self.save_for_backward:
                 # training step: loss and its gradient w.r.t. the stored parameters in one pass (see GCPTreeModel._build_plan);
                 # d total / d nll_bt = w_rec * w0 / (B * prod(traj_seq.shape[1:]))
                 dMD = self._buf("bw.dMD", (B * T, S, S, self._head_pitch))
@@ -350,6 +375,10 @@ class GCPSequentialModel(GCPTreeModel):
             loss_out = self._buf("losses", (16,), zero=True)
             la.out, la.B, la.T, la.N, la.state_dim = loss_out.data_ptr(), B, T, T - 1, hp.state_dim
             la.w_rec, la.w_kl, la.w_len, la.w_exist, la.w_state = hp.dense_img_rec_weight, hp.kl_weight, hp.length_pred_weight, 0.0, 0.0
+            if "regressed_state_padded" in outs and "traj_seq_states" in tin:
+                # state regression over the frames of the sequence, frame 0 included (base_gcp.py:281-286)
+                la.regressed_state, la.state_target = outs["regressed_state_padded"].data_ptr(), tin["traj_seq_states"].data_ptr()
+                la.state_mask, la.w_state = tin["pad_mask"].data_ptr(), 1.0
             la.total_div = float(T * hp.input_nc * S * S)
             plan.keep.append(la)
             plan.add("loss.combine", lib.gcpx_loss_combine, C.byref(la))
@@ -383,7 +412,7 @@ class GCPSequentialModel(GCPTreeModel):
         lens = out.raw["seq_len"].tolist()
         return [out.raw["images"][b, :lens[b]] for b in range(len(lens))]
 
-    LOSS_NAMES = ("dense_img_rec", "kl", "len_pred")
+    LOSS_NAMES = ("dense_img_rec", "kl", "len_pred", "state_regression")
 
     def loss(self, inputs, outputs, log_error_arr=False):
         raw = outputs.raw
@@ -395,5 +424,7 @@ class GCPSequentialModel(GCPTreeModel):
         res["kl"] = Outputs(value=lv[1], weight=hp.kl_weight)
         if hp.regress_length:
             res["len_pred"] = Outputs(value=lv[2], weight=hp.length_pred_weight)
+        if "regressed_state_padded" in raw and "traj_seq_states" in inputs:
+            res["state_regression"] = Outputs(value=lv[4], weight=1.0)
         res["_total"] = lv[5]
         return res

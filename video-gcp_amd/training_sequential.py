@@ -63,6 +63,8 @@ class SequentialTrainStep(GCPTrainStep):
         X["dec.head.wT"] = pk.pack_conv3x3(wk.flip(2, 3).transpose(0, 1).contiguous(), 16)
         if hp.regress_length:
             X["length_pred"] = self._pack_predictor_T(sd, "length_pred.p", [(0, 2 * nz)])
+        if hp.attach_state_regressor:
+            X["state_regressor"] = self._pack_predictor_T(sd, "state_regressor", [])
         for net in NETS:
             p = f"dense_rec.lstm.cell.{net}"
             T_ = {"embed.wT": pk.pack_gemm(sd[f"{p}.embed.weight"].t().contiguous()),          # [n = in_dim][k = H]
@@ -151,9 +153,15 @@ class SequentialTrainStep(GCPTrainStep):
         plan.add("bw.kl", lib.gcpx_kl_bwd_weighted, QZ.data_ptr(), PZ.data_ptr(), dQZ.data_ptr(), dPZ.data_ptr(), B, T - 1, nv,
                  (T - 1) * 2 * nv, 2 * nv, C.c_float(hp.free_nats), C.c_float(hp.kl_weight / (B * div)), _addr(tin["pad_mask"], 1), T)
         ldl = _c16(T)
+        has_state = bool(la.regressed_state)
+        dlen = buf("bw.dlen", (B, ldl)) if hp.regress_length else None
+        dstate = buf("bw.dstate", (B * T, 16)) if has_state else None
+        if hp.regress_length or has_state:
+            plan.add("bw.heads", lib.gcpx_loss_heads_bwd, C.byref(la), rt.ptr(dlen), None, rt.ptr(dstate))
+        if has_state:   # input detached (base_gcp.py:253-256): parameter gradients only
+            self._mlp_bwd(plan, "state_regressor", "state_regressor", rec["mlp:state_regressor"], self.bk["state_regressor"],
+                          dstate.data_ptr(), 16, [])
         if hp.regress_length:
-            dlen = buf("bw.dlen", (B, ldl))
-            plan.add("bw.heads", lib.gcpx_loss_heads_bwd, C.byref(la), dlen.data_ptr(), None, None)
             dXl = buf("bw.dX.len", (B, 2 * nz))
             self._mlp_bwd(plan, "length_pred", "length_pred.p", rec["mlp:length_pred"], self.bk["length_pred"], dlen.data_ptr(), ldl,
                           [(dXl.data_ptr(), 2 * nz, 0)])
