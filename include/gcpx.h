@@ -362,6 +362,13 @@ int gcpx_kl_gauss(const float* qz, const float* pz, int32_t B, int32_t N, int32_
                   int64_t node_stride, float free_nats, const float* node_weight /* b*weight_bstride + n, or NULL */,
                   int64_t weight_bstride, float* kl_out, void* stream);
 int gcpx_loss_combine(const gcpx_loss_args* a, void* stream);
+/* The same in two launches for a forward whose serial tail matters: gcpx_loss_pre = gcpx_kl_gauss (same arguments) + the five terms
+   that need no decoded frame (length cross entropy, existence BCE, state / action / cost regression -> out[2], [3], [4], [7], [8]),
+   one launch that can be issued before the decoder; gcpx_loss_final = reconstruction + KL sums and the weighted total
+   (base_gcp.py:264-304) from nll_bt, kl_b and those five values. */
+int gcpx_loss_pre(const gcpx_loss_args* a, const float* qz, const float* pz, int32_t N, int32_t nz, int64_t batch_stride,
+                  int64_t node_stride, float free_nats, const float* node_weight, int64_t weight_bstride, float* kl_out, void* stream);
+int gcpx_loss_final(const gcpx_loss_args* a, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------------

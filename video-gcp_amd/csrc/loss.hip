@@ -121,14 +121,12 @@ __global__ void __launch_bounds__(256) gauss_nll_kernel(const float* __restrict_
 }
 
 // analytic KL(q || p) of diagonal Gaussians, clamped below at free_nats per dimension, summed per batch element
-__global__ void __launch_bounds__(1024) kl_kernel(const float* __restrict__ qz, const float* __restrict__ pz, const int N,
-                                                  const int nz, const long long batch_stride, const long long node_stride,
-                                                  const float free_nats, const float* __restrict__ node_weight,
-                                                  const long long weight_bstride, float* __restrict__ kl_out) {
-    // one 1024-thread workgroup per sequence (deterministic sum), four dimensions per thread and trip: the 256-thread scalar
-    // version took 39 - 76 us at the serial tail of the forward with B workgroups on the chip
-    __shared__ float red[1024];
-    const int b = blockIdx.x;
+// one 1024-thread workgroup per sequence (deterministic sum), four dimensions per thread and trip: the 256-thread scalar
+// version took 39 - 76 us at the serial tail of the forward with B workgroups on the chip
+__device__ __forceinline__ void kl_sequence(const int b, const float* __restrict__ qz, const float* __restrict__ pz, const int N, const int nz,
+                                            const long long batch_stride, const long long node_stride, const float free_nats,
+                                            const float* __restrict__ node_weight, const long long weight_bstride,
+                                            float* __restrict__ kl_out, float* red) {
     const int nz4 = nz / 4;
     float acc = 0.f;
     for (int i = threadIdx.x; i < N * nz4; i += 1024) {
@@ -158,10 +156,18 @@ __global__ void __launch_bounds__(1024) kl_kernel(const float* __restrict__ qz, 
     if (threadIdx.x == 0) kl_out[b] = red[0];
 }
 
+__global__ void __launch_bounds__(1024) kl_kernel(const float* __restrict__ qz, const float* __restrict__ pz, const int N,
+                                                  const int nz, const long long batch_stride, const long long node_stride,
+                                                  const float free_nats, const float* __restrict__ node_weight,
+                                                  const long long weight_bstride, float* __restrict__ kl_out) {
+    __shared__ float red[1024];
+    kl_sequence(blockIdx.x, qz, pz, N, nz, batch_stride, node_stride, free_nats, node_weight, weight_bstride, kl_out, red);
+}
+
 __device__ float block_sum(float v, float* red) {
     red[threadIdx.x] = v;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
@@ -170,80 +176,97 @@ __device__ float block_sum(float v, float* red) {
     return r;
 }
 
-// one workgroup: the small losses and the weighted total
+// ---- the small loss terms, each a block-wide reduction over blockDim.x threads (red: blockDim.x floats) ----
+// length prediction: cross entropy of seq_len_logits [B,T] against end_ind (misc.py:53-56)
+__device__ float term_len_ce(const gcpx_loss_args& a, float* red) {
+    if (!a.len_logits) return 0.f;
+    const int B = a.B, T = a.T, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    float v = 0.f;
+    for (int b = tid >> 6; b < B; b += nw) {            // one wavefront per sequence, lanes over the T logits
+        const float* l = a.len_logits + (size_t)b * T;
+        float m = -INFINITY;
+        for (int t = lane; t < T; t += 64) m = fmaxf(m, l[t]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float s = 0.f;
+        for (int t = lane; t < T; t += 64) s += expf(l[t] - m);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) v += m + logf(s) - l[a.end_ind[b]];
+    }
+    return block_sum(v, red) / B;
+}
+// existence: BCE with logits against the keep mask in depth-first order (frame_binding.py:80-86)
+__device__ float term_exist_bce(const gcpx_loss_args& a, float* red) {
+    if (!a.existence) return 0.f;
+    const int B = a.B, N = a.N;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < B * N; i += blockDim.x) {
+        const float x = a.existence[i], y = a.leave[i] ? 1.f : 0.f;
+        v += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+    }
+    return block_sum(v, red) / (B * N);
+}
+// state regression: mean over [B, max_len, state_dim] of pad_mask * (pred - target)^2 (base_gcp.py:281-286)
+__device__ float term_state_reg(const gcpx_loss_args& a, float* red) {
+    if (!(a.regressed_state && a.state_target)) return 0.f;
+    const int B = a.B, T = a.T;
+    int maxlen = 0;
+    for (int b = 0; b < B; ++b) maxlen = max(maxlen, a.seq_len[b]);
+    float v = 0.f;
+    const int sd = a.state_dim;
+    const float* mask = a.state_mask ? a.state_mask : a.pad_mask;
+    for (int i = threadIdx.x; i < B * maxlen * sd; i += blockDim.x) {
+        const int d = i % sd, t = (i / sd) % maxlen, b = i / (sd * maxlen);
+        const float e = a.regressed_state[((size_t)b * T + t) * sd + d] - a.state_target[((size_t)b * T + t) * sd + d];
+        v += mask[b * T + t] * e * e;
+    }
+    return block_sum(v, red) / (B * maxlen * sd);
+}
+// inverse model, sampled pair: mean over [B, n_actions] of (pred - actions[b, t0[b]])^2 (inverse_mdl.py:181-191, weights = 1)
+__device__ float term_action_reg(const gcpx_loss_args& a, float* red) {
+    if (!a.action_pred) return 0.f;
+    const int B = a.B, T = a.T, na = a.n_actions;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < B * na; i += blockDim.x) {
+        const int b = i / na, d = i % na;
+        const float e = a.action_pred[i] - a.action_seq[((size_t)b * (T - 1) + (int)a.inv_t0[b]) * na + d];
+        v += e * e;
+    }
+    return block_sum(v, red) / (B * na);
+}
+// cost model: mean over [B, 1] of (cost - gt_cost)^2 (cost_mdl.py:59-62)
+__device__ float term_cost_reg(const gcpx_loss_args& a, float* red) {
+    if (!a.cost_pred) return 0.f;
+    const int B = a.B;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const float e = a.cost_pred[i] - a.cost_target[i];
+        v += e * e;
+    }
+    return block_sum(v, red) / B;
+}
+
+// PRE = false: one workgroup, every term and the weighted total.  PRE = true: the reconstruction / KL sums and the total only; the
+// five latent-side terms were left in out[2], [3], [4], [7], [8] by loss_pre_kernel (they do not depend on the decoder, so they are
+// off the serial tail of the forward)
+template <bool PRE>
 __global__ void __launch_bounds__(256) loss_combine_kernel(const gcpx_loss_args a) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
-    const int B = a.B, T = a.T, N = a.N;
+    const int B = a.B, T = a.T;
     // dense_img_rec: sum_bt pad_mask * nll / B
     float v = 0.f;
     for (int i = tid; i < B * T; i += 256) v += a.nll_bt[i] * a.pad_mask[i];
     const float rec = block_sum(v, red) / B;
     v = 0.f;
-    for (int i = tid; i < B; i += 256) v += a.kl_b[i];
+    if (a.kl_b)
+        for (int i = tid; i < B; i += 256) v += a.kl_b[i];
     const float kl = a.kl_b ? block_sum(v, red) / B : 0.f;
-    // length prediction: cross entropy of seq_len_logits [B,T] against end_ind (misc.py:53-56)
-    float ce = 0.f;
-    if (a.len_logits) {
-        v = 0.f;
-        const int lane = tid & 63;
-        for (int b = tid >> 6; b < B; b += 4) {            // one wavefront per sequence, lanes over the T logits
-            const float* l = a.len_logits + (size_t)b * T;
-            float m = -INFINITY;
-            for (int t = lane; t < T; t += 64) m = fmaxf(m, l[t]);
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            float s = 0.f;
-            for (int t = lane; t < T; t += 64) s += expf(l[t] - m);
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) v += m + logf(s) - l[a.end_ind[b]];
-        }
-        ce = block_sum(v, red) / B;
-    }
-    // existence: BCE with logits against the keep mask in depth-first order (frame_binding.py:80-86)
-    float bce = 0.f;
-    if (a.existence) {
-        v = 0.f;
-        for (int i = tid; i < B * N; i += 256) {
-            const float x = a.existence[i], y = a.leave[i] ? 1.f : 0.f;
-            v += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
-        }
-        bce = block_sum(v, red) / (B * N);
-    }
-    // state regression: mean over [B, max_len, state_dim] of pad_mask * (pred - target)^2 (base_gcp.py:281-286)
-    float sreg = 0.f;
-    if (a.regressed_state && a.state_target) {
-        int maxlen = 0;
-        for (int b = 0; b < B; ++b) maxlen = max(maxlen, a.seq_len[b]);
-        v = 0.f;
-        const int sd = a.state_dim;
-        for (int i = tid; i < B * maxlen * sd; i += 256) {
-            const int d = i % sd, t = (i / sd) % maxlen, b = i / (sd * maxlen);
-            const float e = a.regressed_state[((size_t)b * T + t) * sd + d] - a.state_target[((size_t)b * T + t) * sd + d];
-            v += (a.state_mask ? a.state_mask : a.pad_mask)[b * T + t] * e * e;
-        }
-        sreg = block_sum(v, red) / (B * maxlen * sd);
-    }
-    // inverse model, sampled pair: mean over [B, n_actions] of (pred - actions[b, t0[b]])^2 (inverse_mdl.py:181-191, weights = 1)
-    float areg = 0.f;
-    if (a.action_pred) {
-        v = 0.f;
-        const int na = a.n_actions;
-        for (int i = tid; i < B * na; i += 256) {
-            const int b = i / na, d = i % na;
-            const float e = a.action_pred[i] - a.action_seq[((size_t)b * (T - 1) + (int)a.inv_t0[b]) * na + d];
-            v += e * e;
-        }
-        areg = block_sum(v, red) / (B * na);
-    }
-    // cost model: mean over [B, 1] of (cost - gt_cost)^2 (cost_mdl.py:59-62)
-    float creg = 0.f;
-    if (a.cost_pred) {
-        v = 0.f;
-        for (int i = tid; i < B; i += 256) {
-            const float e = a.cost_pred[i] - a.cost_target[i];
-            v += e * e;
-        }
-        creg = block_sum(v, red) / B;
+    float ce, bce, sreg, areg, creg;
+    if constexpr (PRE) {
+        ce = a.out[2]; bce = a.out[3]; sreg = a.out[4]; areg = a.out[7]; creg = a.out[8];
+    } else {
+        ce = term_len_ce(a, red); bce = term_exist_bce(a, red); sreg = term_state_reg(a, red);
+        areg = term_action_reg(a, red); creg = term_cost_reg(a, red);
     }
     if (tid == 0) {
         a.out[7] = areg; a.out[8] = creg;
@@ -259,6 +282,30 @@ __global__ void __launch_bounds__(256) loss_combine_kernel(const gcpx_loss_args 
         a.out[5] = total / a.total_div;      // base_gcp.py:299-301: / prod(traj_seq.shape[1:])
         a.out[6] = rec + kl;                 // nll upper bound (base_gcp.py:289-290)
     }
+}
+
+// Everything of the loss that needs no decoded frame, in ONE launch in front of the decoder: workgroups 0 .. B-1 the KL of one
+// sequence each (kl_kernel), workgroups B .. B+4 one latent-side term each
+__global__ void __launch_bounds__(1024) loss_pre_kernel(const gcpx_loss_args a, const float* __restrict__ qz, const float* __restrict__ pz,
+                                                        const int N, const int nz, const long long batch_stride, const long long node_stride,
+                                                        const float free_nats, const float* __restrict__ node_weight,
+                                                        const long long weight_bstride, float* __restrict__ kl_out) {
+    __shared__ float red[1024];
+    const int blk = blockIdx.x;
+    if (blk < a.B) {
+        kl_sequence(blk, qz, pz, N, nz, batch_stride, node_stride, free_nats, node_weight, weight_bstride, kl_out, red);
+        return;
+    }
+    float r;
+    int slot;
+    switch (blk - a.B) {
+        case 0: r = term_len_ce(a, red); slot = 2; break;
+        case 1: r = term_exist_bce(a, red); slot = 3; break;
+        case 2: r = term_state_reg(a, red); slot = 4; break;
+        case 3: r = term_action_reg(a, red); slot = 7; break;
+        default: r = term_cost_reg(a, red); slot = 8; break;
+    }
+    if (threadIdx.x == 0) a.out[slot] = r;
 }
 
 }  // namespace
@@ -302,7 +349,29 @@ extern "C" int gcpx_loss_combine(const gcpx_loss_args* a, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(a && a->nll_bt && a->pad_mask && a->out, "null pointer");
     GCPX_CHECK_ARG(a->B > 0 && a->T > 0 && a->total_div > 0, "bad sizes");
-    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(256), 0, stream, *a);
+    hipLaunchKernelGGL(loss_combine_kernel<false>, dim3(1), dim3(256), 0, stream, *a);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_loss_pre(const gcpx_loss_args* a, const float* qz, const float* pz, int32_t N, int32_t nz, int64_t batch_stride,
+                             int64_t node_stride, float free_nats, const float* node_weight, int64_t weight_bstride, float* kl_out,
+                             void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(a && a->out && a->B > 0 && a->T > 0, "null pointer / bad sizes");
+    GCPX_CHECK_ARG(qz && pz && kl_out && N > 0 && nz > 0, "null pointer / bad sizes");
+    GCPX_CHECK_ARG(nz % 4 == 0 && batch_stride % 4 == 0 && node_stride % 4 == 0, "nz and the strides must be multiples of 4");
+    hipLaunchKernelGGL(loss_pre_kernel, dim3(a->B + 5), dim3(1024), 0, stream, *a, qz, pz, N, nz, (long long)batch_stride,
+                       (long long)node_stride, free_nats, node_weight, (long long)weight_bstride, kl_out);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_loss_final(const gcpx_loss_args* a, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(a && a->nll_bt && a->pad_mask && a->out, "null pointer");
+    GCPX_CHECK_ARG(a->B > 0 && a->T > 0 && a->total_div > 0, "bad sizes");
+    hipLaunchKernelGGL(loss_combine_kernel<true>, dim3(1), dim3(256), 0, stream, *a);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -975,6 +975,16 @@ class GCPTreeModel:
             plan.add("path_cost", lib.gcpx_path_cost, tin["traj_seq"].data_ptr(), tin["cost_start_idx"].data_ptr(),
                      tin["cost_end_idx"].data_ptr(), B, T, rows, hp.img_sz, self._buf("cost_partial", (B, rows)).data_ptr(), gt.data_ptr())
         self._plan_encoder(plan, "Ig", tin["I_g"].data_ptr(), B, _addr(E, 2 ** L * nz), PS * nz, 0, 1)
+        outs = {}
+        e0 = lambda: self._rowsrc(_addr(E), PS * nz, 0, nz)
+        eg = lambda: self._rowsrc(_addr(E, 2 ** L * nz), PS * nz, 0, nz)
+        if hp.regress_length and not pred_len:
+            # get_end_ind's length predictor (misc.py:45-51) feeds only the loss and the outputs: it runs here, behind the two image
+            # encoders and beside the trajectory encoder, instead of in front of the tree (20 us of the serial chain)
+            plan.wait(2, 1)
+            logits = self._buf("seq_len_logits", (B, T))
+            self._mlp(plan, "length_pred", P["length_pred"], [e0(), eg()], B, 1, out=logits.data_ptr(), ob=T, orow=0)
+            outs["seq_len_logits"] = logits
         plan.lane = 0
         if has_traj:
             enc_traj = self._buf("enc_traj", (B * T, nz))
@@ -1000,20 +1010,16 @@ class GCPTreeModel:
                            out=Vp.data_ptr(), ob=0, orow=nz, batch=(n_mod, 0, P["attn.v_proj.w"][0].numel(), nz, B * T * nz))
                 plan.rec["attn_kv"] = dict(Kp=Kp, Vp=Vp, keys=keys, kenc=kenc, n_mod=n_mod)
         plan.join([1, 2])
-        e0 = lambda: self._rowsrc(_addr(E), PS * nz, 0, nz)
-        eg = lambda: self._rowsrc(_addr(E, 2 ** L * nz), PS * nz, 0, nz)
 
         # ---- get_end_ind: length predictor (misc.py:45-51) ----
-        outs = {}
-        if hp.regress_length:
+        if hp.regress_length and pred_len:
             logits = self._buf("seq_len_logits", (B, T))
             self._mlp(plan, "length_pred", P["length_pred"], [e0(), eg()], B, 1, out=logits.data_ptr(), ob=T, orow=0)
             outs["seq_len_logits"] = logits
-            if pred_len:
-                # get_end_ind under val_mode(pred_length=True) (base_gcp.py:219-226): the fed end_ind is REPLACED by a draw from the
-                # length predictor, clamped to >= 2; the integer bookkeeping therefore follows the draw instead of riding on a side lane
-                plan.add("sample_length", lib.gcpx_sample_length, logits.data_ptr(), tin["len_u"].data_ptr(), B, T, 2, tin["end_ind"].data_ptr())
-                plan_bookkeeping()
+            # get_end_ind under val_mode(pred_length=True) (base_gcp.py:219-226): the fed end_ind is REPLACED by a draw from the
+            # length predictor, clamped to >= 2; the integer bookkeeping therefore follows the draw instead of riding on a side lane
+            plan.add("sample_length", lib.gcpx_sample_length, logits.data_ptr(), tin["len_u"].data_ptr(), B, T, 2, tin["end_ind"].data_ptr())
+            plan_bookkeeping()
 
         # ---- predict_sequence: level-serial tree (tree_utils.py:21-44, tree_module.py:67-114) ----
         for l in range(L):
@@ -1193,7 +1199,43 @@ class GCPTreeModel:
             heads.clear()
         plan.lane = 0
 
+        def kl_args(kl_b, batch=()):
+            return (_addr(QZ, 2 * nv), _addr(PZ, 2 * nv)) + batch + (N, nv, PS * 2 * nv, 2 * nv, C.c_float(hp.free_nats), None, 0, kl_b.data_ptr())
+
+        def loss_args():
+            """gcpx_loss_args of this forward (base_gcp.py:264-304, tree_module.py:116-157)"""
+            kl_b = self._buf("kl_b", (B,))
+            la = rt.LossArgs()
+            la.nll_bt, la.pad_mask, la.kl_b = self._buf("nll_bt", (B, T)).data_ptr(), tin["pad_mask"].data_ptr(), kl_b.data_ptr()
+            la.len_logits = outs["seq_len_logits"].data_ptr() if "seq_len_logits" in outs else None
+            la.end_ind = tin["end_ind"].data_ptr()
+            if adaptive:     # BCE of the learned-pruning logits against "same best frame" (adaptive.py:118-122), N - 1 pairs
+                la.existence, la.leave = outs["distances"].data_ptr(), outs["distance_target"].data_ptr()
+            else:
+                la.existence, la.leave = outs["existence"].data_ptr(), leave.data_ptr()
+            if "regressed_state_padded" in outs and "traj_seq_states" in tin:
+                la.regressed_state, la.state_target = outs["regressed_state_padded"].data_ptr(), tin["traj_seq_states"].data_ptr()
+            la.seq_len = seq_len.data_ptr()
+            if "actions_sampled" in outs and "actions" in tin:          # inverse_mdl.py:181-191
+                la.action_pred, la.action_seq, la.inv_t0 = outs["actions_sampled"].data_ptr(), tin["actions"].data_ptr(), tin["inv_t0"].data_ptr()
+                la.n_actions, la.w_action = hp.n_actions, hp.action_rec_weight
+            if "cost_pred" in outs:                                     # cost_mdl.py:59-62
+                la.cost_pred, la.cost_target, la.w_cost = outs["cost_pred"].data_ptr(), outs["cost_target"].data_ptr(), 1.0
+            loss_out = self._buf("losses", (16,), zero=True)
+            la.out, la.B, la.T, la.N, la.state_dim = loss_out.data_ptr(), B, T, (N - 1 if adaptive else N), hp.state_dim
+            la.w_rec, la.w_kl, la.w_len, la.w_exist, la.w_state = hp.dense_img_rec_weight, hp.kl_weight, hp.length_pred_weight, 1.0, 1.0
+            la.total_div = float(T * hp.input_nc * hp.img_sz * hp.img_sz)
+            plan.keep.append(la)
+            return la, kl_b
+
         decode, with_loss = key[8], key[7]
+        # Everything of the loss that needs no decoded frame — the KL and the latent-side terms — goes in front of the decoder in one
+        # launch (gcpx_loss_pre); behind the head only the reconstruction sum and the total remain (gcpx_loss_final).  (The adaptive
+        # model's pruning target comes out of the soft-DTW matching of decoded frames: it keeps the single combine at the end.)
+        loss_pre = None
+        if with_loss and not adaptive:
+            loss_pre = loss_args()
+            plan.add("loss.pre", lib.gcpx_loss_pre, C.byref(loss_pre[0]), *kl_args(loss_pre[1]))
         if decode:
             # ---- dense_rec: decode every node (tree_dense_rec.py:41-44) ----
             F = B * N
@@ -1323,31 +1365,14 @@ class GCPTreeModel:
                 plan.add("loss.gauss_nll", lib.gcpx_gauss_nll, outs["soft_matched_estimates"].data_ptr(),
                          tin["traj_seq"].data_ptr(), self.sd["decoder.log_sigma"].data_ptr(), nll_bt.data_ptr(), B * T,
                          hp.input_nc * S * S)
-            kl_b = self._buf("kl_b", (B,))
-            plan.add("loss.kl", lib.gcpx_kl_gauss, _addr(QZ, 2 * nv), _addr(PZ, 2 * nv), B, N, nv, PS * 2 * nv, 2 * nv,
-                     C.c_float(hp.free_nats), None, 0, kl_b.data_ptr())
-            la = rt.LossArgs()
-            la.nll_bt, la.pad_mask, la.kl_b = nll_bt.data_ptr(), tin["pad_mask"].data_ptr(), kl_b.data_ptr()
-            la.len_logits = outs["seq_len_logits"].data_ptr() if "seq_len_logits" in outs else None
-            la.end_ind = tin["end_ind"].data_ptr()
-            if adaptive:     # BCE of the learned-pruning logits against "same best frame" (adaptive.py:118-122), N - 1 pairs
-                la.existence, la.leave = outs["distances"].data_ptr(), dist_tgt.data_ptr()
+            if loss_pre is None:
+                la, kl_b = loss_args()
+                plan.add("loss.kl", lib.gcpx_kl_gauss, *kl_args(kl_b, (B,)))
+                plan.add("loss.combine", lib.gcpx_loss_combine, C.byref(la))
             else:
-                la.existence, la.leave = outs["existence"].data_ptr(), leave.data_ptr()
-            if "regressed_state_padded" in outs and "traj_seq_states" in tin:
-                la.regressed_state, la.state_target = outs["regressed_state_padded"].data_ptr(), tin["traj_seq_states"].data_ptr()
-            la.seq_len = seq_len.data_ptr()
-            if "actions_sampled" in outs and "actions" in tin:          # inverse_mdl.py:181-191
-                la.action_pred, la.action_seq, la.inv_t0 = outs["actions_sampled"].data_ptr(), tin["actions"].data_ptr(), tin["inv_t0"].data_ptr()
-                la.n_actions, la.w_action = hp.n_actions, hp.action_rec_weight
-            if "cost_pred" in outs:                                     # cost_mdl.py:59-62
-                la.cost_pred, la.cost_target, la.w_cost = outs["cost_pred"].data_ptr(), outs["cost_target"].data_ptr(), 1.0
+                la, kl_b = loss_pre
+                plan.add("loss.final", lib.gcpx_loss_final, C.byref(la))
             loss_out = self._buf("losses", (16,), zero=True)
-            la.out, la.B, la.T, la.N, la.state_dim = loss_out.data_ptr(), B, T, (N - 1 if adaptive else N), hp.state_dim
-            la.w_rec, la.w_kl, la.w_len, la.w_exist, la.w_state = hp.dense_img_rec_weight, hp.kl_weight, hp.length_pred_weight, 1.0, 1.0
-            la.total_div = float(T * hp.input_nc * S * S)
-            plan.keep.append(la)
-            plan.add("loss.combine", lib.gcpx_loss_combine, C.byref(la))
             outs["losses"], outs["nll_bt"], outs["kl_b"] = loss_out, nll_bt, kl_b
             outs["matched_distr_kernel_order"] = matched_distr
 

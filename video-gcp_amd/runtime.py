@@ -136,6 +136,8 @@ SYMBOLS = [
     ("gcpx_fill_zero", C.c_int, [vp, i64, vp]),
     ("gcpx_copy_rows", C.c_int, [vp, vp, i32, i32, i64, i64, i64, vp]),
     ("gcpx_loss_combine", C.c_int, [C.POINTER(LossArgs), vp]),
+    ("gcpx_loss_pre", C.c_int, [C.POINTER(LossArgs), vp, vp, i32, i32, i64, i64, C.c_float, vp, i64, vp, vp]),
+    ("gcpx_loss_final", C.c_int, [C.POINTER(LossArgs), vp]),
     ("gcpx_gather_rows", C.c_int, [vp, vp, vp, i32, i32, i32, i32, i64, vp]),
     ("gcpx_compact_index", C.c_int, [vp, i32, i32, i32, vp, vp]),
     ("gcpx_seq_pairs", C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
