@@ -113,6 +113,10 @@ typedef struct gcpx_conv_args {
     const float* nll_row_weight; /* dev: [nll_rows] or NULL (GCPX_HEAD_DLM_NLL_GRAD): per-row factor of the gradient (pad_mask) */
     float nll_scale;        /* GCPX_HEAD_DLM_NLL_GRAD: d total / d nll_bt = w_rec / (B * prod(traj_seq.shape[1:])) (base_gcp.py:299-301) */
     int32_t _pad3;
+    float* images_rows;     /* dev or NULL (split-f16 mixture heads): NCHW [rows][3][H][W]; every frame f with raw_row_map[f] >= 0 stores its
+                               image at that row as well — the matched / kept frames in sequence order (tree_dense_rec.py:56-60,
+                               tree.py:62-65) without a gather pass behind the head.  Rows no frame maps to are not written */
+    int64_t images_rows_dup; /* != 0: a second copy of those rows at images_rows + images_rows_dup (floats) */
 } gcpx_conv_args;
 
 typedef enum gcpx_split_layout { GCPX_SPLIT_PLAIN = 0, GCPX_SPLIT_ROWFOLD = 1 } gcpx_split_layout;
@@ -282,6 +286,10 @@ int gcpx_balanced_binding(const int64_t* end_ind, int32_t B, int32_t L, int32_t 
    src has N rows per batch element; rows with idx < 0 are zero-filled (pad_sequence, base_gcp.py:242). */
 int gcpx_gather_rows(const float* src, const int32_t* idx, float* out, int32_t B, int32_t T, int32_t N,
                      int32_t idx_offset, int64_t row_floats, void* stream);
+/* gcpx_gather_rows for the rows its producer has NOT written: rows r with written[r] >= 0 are left untouched (the output head stores
+   the frames matched to a row itself, gcpx_conv_args.images_rows; what remains are the padded rows: zeros, or the frame idx names) */
+int gcpx_gather_rows_rest(const float* src, const int32_t* idx, float* out, int32_t B, int32_t T, int32_t N, int32_t idx_offset,
+                          int64_t row_floats, const int32_t* written, void* stream);
 /* Learned pairwise cost over a rollout (LearnedCostEstimate, gcp/planning/cem/cost_fcn.py:88-95):
    gcpx_seq_pairs builds the "next" operand nxt[i][t] = lat[i][t+1] (t+1 < len_i) else goal[i] (goal == NULL: the
    sequence's own last latent); the cost MLP runs on (lat, nxt) rows; gcpx_masked_row_sum adds the first len_i

@@ -1261,6 +1261,10 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
     GCPX_CHECK_ARG(!need_out || a->out, "out is NULL");
     GCPX_CHECK_ARG(need_out || a->images, "images is NULL");
     GCPX_CHECK_ARG(!need_out || a->out_pitch % 4 == 0, "out_pitch % 4");
+    GCPX_CHECK_ARG(!a->images_rows || (a->wpk_split && a->raw_row_map && a->images && a->Cout == 100 && !a->upsample &&
+                                       (a->head_mode == GCPX_HEAD_DLM_MEAN || a->head_mode == GCPX_HEAD_DLM_BOTH ||
+                                        a->head_mode == GCPX_HEAD_DLM_NLL || a->head_mode == GCPX_HEAD_DLM_NLL_GRAD)),
+                   "images_rows: split-f16 mixture head with raw_row_map and images only");
     const int W = a->Wout;
     if (!a->upsample) {
         GCPX_CHECK_ARG(a->nsrc == 1 && a->src[0].frame_div == 1, "non-upsampling 3x3 conv takes one per-frame source");

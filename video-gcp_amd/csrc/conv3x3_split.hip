@@ -242,6 +242,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
     // (the store round trip, every item); behind the staging they are older than the next prefetch and long complete by its wait.
     float pend[2][3];
     float* pend_ip = nullptr;
+    // images_rows: the frames with a raw_row_map entry are stored a second (and third) time, at that row of a [rows][3][H][W] array —
+    // the gathers of the matched / kept frames behind the head (tree_dense_rec.py:56-60, tree.py:62-65) without their 2 x 63 MB round
+    // trip.  The second address differs from the first by a wave-uniform offset: it lives in scalar registers.
+    long long pend_d2 = 0;
+    bool pend_has2 = false;
     const size_t plane_sz = (size_t)H * W;
     auto flush_images = [&]() __attribute__((always_inline)) {
         if (pend_ip) {
@@ -251,6 +256,19 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                 ip[0] = pend[s2][0];
                 ip[plane_sz] = pend[s2][1];
                 ip[2 * plane_sz] = pend[s2][2];
+            }
+            if (pend_has2) {
+#pragma unroll
+                for (int cpy = 0; cpy < 2; ++cpy) {
+                    if (cpy == 1 && a.images_rows_dup == 0) break;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        float* ip = pend_ip + pend_d2 + cpy * a.images_rows_dup + s2 * W;
+                        ip[0] = pend[s2][0];
+                        ip[plane_sz] = pend[s2][1];
+                        ip[2 * plane_sz] = pend[s2][2];
+                    }
+                }
             }
         }
     };
@@ -321,6 +339,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                     pend[s2][1] = fminf(fmaxf(Sg * invS, -1.f), 1.f);
                     pend[s2][2] = fminf(fmaxf(Sb * invS, -1.f), 1.f);
                     if (s2 == 0 && q < 2) pend_ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + 2 * q) * W + (x0 + j);   // row pt = s2 + 2 q
+                    if (s2 == 0) {
+                        pend_has2 = a.images_rows != nullptr && orow >= 0;
+                        const long long d2 = pend_has2 ? (a.images_rows - a.images) + ((long long)orow - f) * 3 * (long long)plane : 0;
+                        pend_d2 = ((long long)__builtin_amdgcn_readfirstlane((int)(d2 >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(d2 & 0xffffffffll));
+                    }
                     if (want_nll) {
                         // ---- fused likelihood, second half (the formulas of dlm_nll_kernel, csrc/loss.hip): this lane's five mixtures of
                         // its pixel, the other five in lane ^ 32; m / S above are the max / sum of exp over all ten logits

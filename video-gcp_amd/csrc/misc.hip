@@ -142,9 +142,10 @@ __global__ void compact_index_kernel(const int32_t* __restrict__ leave, const in
 
 __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
                                                           float* __restrict__ out, const int T, const int N,
-                                                          const int idx_offset, const long long row4) {
+                                                          const int idx_offset, const long long row4, const int32_t* __restrict__ skip) {
     const int bt = blockIdx.x;
     const int b = bt / T;
+    if (skip && skip[bt] >= 0) return;                     // (the row was written by its producer already)
     const int i = idx[bt];
     float4* o = reinterpret_cast<float4*>(out) + (size_t)bt * row4;
     if (i < 0) {
@@ -371,7 +372,18 @@ extern "C" int gcpx_gather_rows(const float* src, const int32_t* idx, float* out
     GCPX_CHECK_ARG(src && idx && out && B > 0 && T > 0 && N > 0, "null pointer / bad sizes");
     GCPX_CHECK_ARG(row_floats > 0 && row_floats % 4 == 0, "row_floats must be a positive multiple of 4");
     hipLaunchKernelGGL(gather_rows_kernel, dim3(B * T), dim3(256), 0, stream, src, idx, out, T, N,
-                       idx_offset, (long long)(row_floats / 4));
+                       idx_offset, (long long)(row_floats / 4), static_cast<const int32_t*>(nullptr));
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_gather_rows_rest(const float* src, const int32_t* idx, float* out, int32_t B, int32_t T, int32_t N, int32_t idx_offset,
+                                     int64_t row_floats, const int32_t* written, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(src && idx && out && written && B > 0 && T > 0 && N > 0, "null pointer / bad sizes");
+    GCPX_CHECK_ARG(row_floats > 0 && row_floats % 4 == 0, "row_floats must be a positive multiple of 4");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(B * T), dim3(256), 0, stream, src, idx, out, T, N,
+                       idx_offset, (long long)(row_floats / 4), written);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

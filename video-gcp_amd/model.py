@@ -213,6 +213,14 @@ class GCPTreeModel:
         return (self.fused_head_nll and self.split_f16 and "dec.head" in getattr(self, "pk_split", {}) and hp.img_sz % 16 == 0 and
                 hp.decoder_distribution == "discrete_logistic_mixture" and not self.materialize_distr)
 
+    def _rows_direct(self, key):
+        """the output head stores the frames of the balanced tree that belong to a row of the sequence there itself
+        (gcpx_conv_args.images_rows): split-f16 mixture head, decoded frames wanted"""
+        hp = self._hp
+        return bool(key[8] and not hp.adaptive and self.split_f16 and "dec.head" in getattr(self, "pk_split", {}) and hp.img_sz % 16 == 0 and
+                    hp.decoder_distribution == "discrete_logistic_mixture" and not self.materialize_distr and
+                    os.environ.get("GCPX_HEAD_NO_ROWS") is None and type(self)._build_plan is GCPTreeModel._build_plan)
+
     def _head_grad_fused(self, key):
         """training forward (posterior path with losses, backward to follow) of the balanced model: the head kernel writes the
         likelihood gradient itself"""
@@ -949,13 +957,14 @@ class GCPTreeModel:
                 plan.add("balanced_binding", lib.gcpx_balanced_binding, tin["end_ind"].data_ptr(), B, L, T, node_t.data_ptr(),
                          leave.data_ptr(), f2n.data_ptr(), etrow.data_ptr(), seq_len.data_ptr(), node2row.data_ptr())
                 plan.add("compact_index", lib.gcpx_compact_index, leave.data_ptr(), B, N, T, kept_idx.data_ptr())
+                r2f = self._buf("row2frame", (B * T,), torch.int32)
+                if self._head_grad_fused(key) or self._rows_direct(key):
+                    plan.add("row2frame", lib.gcpx_index_inverse, node2row.data_ptr(), B * N, r2f.data_ptr(), B * T)
                 if self._head_grad_fused(key):
                     # training forward with the likelihood gradient written by the head kernel (GCPX_HEAD_DLM_NLL_GRAD): the rows of
                     # the matched-frame gradient that no node maps to (padded frames) are zeroed here, early and on this side lane
                     S_ = hp.img_sz
                     dMD = self._buf("bw.dMD", (B * T, S_, S_, self._head_pitch))
-                    r2f = self._buf("row2frame", (B * T,), torch.int32)
-                    plan.add("row2frame", lib.gcpx_index_inverse, node2row.data_ptr(), B * N, r2f.data_ptr(), B * T)
                     plan.add("zero_unmapped", lib.gcpx_zero_unmapped_rows, dMD.data_ptr(), S_ * S_ * self._head_pitch, r2f.data_ptr(), B * T)
 
         # ---- run_encoder (base_gcp.py:184-213) ----
@@ -1274,6 +1283,16 @@ class GCPTreeModel:
                 mode = rt.HEAD_TANH_NCHW
             a = self._conv_args([prev], F, S, S, S, S, hp.head_channels, self._head_pitch, P["dec.head.w"], P["dec.head.b"],
                                 head_out, upsample=0, head_mode=mode, images=images)
+            # the split-f16 mixture head stores the frames node2row maps to a row a second time, in sequence order: the matched /
+            # kept frames (tree_dense_rec.py:56-60, tree.py:62-65) need no gather pass over the decoded frames afterwards
+            rows_direct = self._rows_direct(key) and (row_map is not None or mode == rt.HEAD_DLM_MEAN)
+            rows_images = None
+            if rows_direct:
+                row_map = node2row
+                want_matched = has_traj and phase == "train"
+                rows_images = self._buf("rows_images", (2 if want_matched else 1, B, T, hp.input_nc, S, S))
+                a.images_rows = rows_images.data_ptr()
+                a.images_rows_dup = rows_images[0].numel() if want_matched else 0
             a.raw_row_map = row_map.data_ptr() if row_map is not None else None
             if fused_nll is not None:
                 a.nll_target, a.nll_partial, a.nll_rows = tin["traj_seq"].data_ptr(), fused_nll.data_ptr(), B * T
@@ -1321,14 +1340,25 @@ class GCPTreeModel:
                 outs.update(cdist_sum=dsum, match_dist_df=wdf, matched_idx=matched_idx, best_t=best_t, entropy_df=entropy, p_n_df=p_n,
                             distance_target=dist_tgt, aux_len=seq_len)
             elif has_traj and phase == "train":
-                matched = self._buf("matched_images", (B, T, hp.input_nc, S, S))
-                plan.add("gather.matched", lib.gcpx_gather_rows, images.data_ptr(), f2n.data_ptr(), matched.data_ptr(), B, T, N,
-                         0, row)
+                if rows_images is not None:
+                    # (what the head has not written: the padded frames, which argmax over an all-zero column matches to the root)
+                    matched = rows_images[1]
+                    plan.add("gather.matched.rest", lib.gcpx_gather_rows_rest, images.data_ptr(), f2n.data_ptr(), matched.data_ptr(), B, T, N,
+                             0, row, self._buf("row2frame", (B * T,), torch.int32).data_ptr())
+                else:
+                    matched = self._buf("matched_images", (B, T, hp.input_nc, S, S))
+                    plan.add("gather.matched", lib.gcpx_gather_rows, images.data_ptr(), f2n.data_ptr(), matched.data_ptr(), B, T, N,
+                             0, row)
                 outs["soft_matched_estimates"] = matched
             Wp = N if adaptive else T
-            pruned = self._buf("pruned_images", (B, Wp, hp.input_nc, S, S))
-            plan.add("gather.pruned", lib.gcpx_gather_rows, images.data_ptr(), kept_idx.data_ptr(), pruned.data_ptr(), B, Wp, N, 0,
-                     row)
+            if rows_images is not None:
+                pruned = rows_images[0]                      # (rows beyond the sequence: zeros)
+                plan.add("gather.pruned.rest", lib.gcpx_gather_rows_rest, images.data_ptr(), kept_idx.data_ptr(), pruned.data_ptr(), B, Wp, N,
+                         0, row, self._buf("row2frame", (B * T,), torch.int32).data_ptr())
+            else:
+                pruned = self._buf("pruned_images", (B, Wp, hp.input_nc, S, S))
+                plan.add("gather.pruned", lib.gcpx_gather_rows, images.data_ptr(), kept_idx.data_ptr(), pruned.data_ptr(), B, Wp, N, 0,
+                         row)
             outs["pruned_padded"] = pruned
 
         # ---- losses (base_gcp.py:264-304, tree_module.py:116-157) ----

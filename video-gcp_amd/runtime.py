@@ -30,7 +30,7 @@ class ConvArgs(C.Structure):
                 ("head_mode", i32), ("wpk", vp), ("bias", vp), ("out", vp), ("images", vp), ("stats_partial", vp),
                 ("raw_row_map", vp), ("src_row_map", vp), ("src_row_frames", vp), ("n_src_rows", i32), ("w_split_log2", i32), ("wpk_split", vp), ("w_split_log2_dev", vp),
                 ("split_layout", i32), ("nll_rows", i32), ("nll_target", vp), ("nll_partial", vp), ("nll_row_weight", vp),
-                ("nll_scale", C.c_float), ("_pad3", i32)]
+                ("nll_scale", C.c_float), ("_pad3", i32), ("images_rows", vp), ("images_rows_dup", i64)]
 
 
 class LossArgs(C.Structure):
@@ -139,6 +139,7 @@ SYMBOLS = [
     ("gcpx_loss_pre", C.c_int, [C.POINTER(LossArgs), vp, vp, i32, i32, i64, i64, C.c_float, vp, i64, vp, vp]),
     ("gcpx_loss_final", C.c_int, [C.POINTER(LossArgs), vp]),
     ("gcpx_gather_rows", C.c_int, [vp, vp, vp, i32, i32, i32, i32, i64, vp]),
+    ("gcpx_gather_rows_rest", C.c_int, [vp, vp, vp, i32, i32, i32, i32, i64, vp, vp]),
     ("gcpx_compact_index", C.c_int, [vp, i32, i32, i32, vp, vp]),
     ("gcpx_seq_pairs", C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     ("gcpx_rollout_cost", C.c_int, [vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, i32, C.c_float, vp]),
