@@ -117,6 +117,13 @@ typedef struct gcpx_conv_args {
                                image at that row as well — the matched / kept frames in sequence order (tree_dense_rec.py:56-60,
                                tree.py:62-65) without a gather pass behind the head.  Rows no frame maps to are not written */
     int64_t images_rows_dup; /* != 0: a second copy of those rows at images_rows + images_rows_dup (floats) */
+    /* Data gradient of a 16-channel layer with the NEXT step of the backward pass in its epilogue (split-f16 plain 3x3 conv with 16
+       output channels, out_pitch 16): the layer whose output gradient this conv produces is BatchNorm + LeakyReLU(0.2) of the raw
+       tensor bwd_r [F][H][W][16], so the kernel stores  g = conv * (bwd_scale * r + bwd_shift > 0 ? 1 : 0.2)  and leaves the
+       per-workgroup sums of g and of g * (r - bwd_mean) * bwd_rstd in stats_partial [gcpx_conv3x3_grid(a)][2][16] — what gcpx_act_bwd
+       (up = 0, no add) computes in a pass of its own over the same tensors.  NULL: plain data gradient */
+    const float* bwd_r;
+    const float *bwd_scale, *bwd_shift, *bwd_mean, *bwd_rstd;
 } gcpx_conv_args;
 
 typedef enum gcpx_split_layout { GCPX_SPLIT_PLAIN = 0, GCPX_SPLIT_ROWFOLD = 1 } gcpx_split_layout;
@@ -262,6 +269,14 @@ int gcpx_mlp(const gcpx_mlp_args* a, void* stream);
 int gcpx_mlp_group_dims(const gcpx_mlp_args* host_table, int32_t n, int32_t* dims, int32_t* total_blocks);
 int gcpx_mlp_group(const gcpx_mlp_args* dev_table, const int32_t* dev_dims, int32_t n, int32_t total_blocks, int32_t mid,
                    void* stream);
+/* The same launch carrying one row GEMM (a HOST gcpx_gemm_args, plain epilogue) as additional workgroups: a level of the tree in front
+   of its recurrent cell — prior + posterior Predictors (tree_module.py:77, inference.py:27-35) and the split_linear merge of the
+   parents' hidden states (tree_lstm.py:43-48) depend on the previous level only, not on each other.  Results are those of
+   gcpx_mlp_group + gcpx_gemm.  gcpx_mlp_group_gemm_supported: 1 when the GEMM's tiling and the group's size have a combined kernel
+   (hidden width 128, at most one workgroup per CU, GEMM not on the split-f16 kernel); otherwise launch the two separately. */
+int gcpx_mlp_group_gemm_supported(const gcpx_gemm_args* g, int32_t total_blocks, int32_t mid);
+int gcpx_mlp_group_gemm(const gcpx_mlp_args* dev_table, const int32_t* dev_dims, int32_t n, int32_t total_blocks, int32_t mid,
+                        const gcpx_gemm_args* g, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Balanced frame binding — integer bookkeeping, bit-exact with
@@ -457,6 +472,10 @@ typedef struct gcpx_wgrad_args {
     float* dbias;           /* optional (direct mode): dbias[n] (+)= sum_r dy[r][n], fused bias gradient */
     float* dbias2;          /* optional second destination of the same sums (LSTM b_ih / b_hh; not batched) */
     int64_t z_dy_off, z_x_off, z_out_off, z_bias_off;
+    int32_t split_f16;      /* != 0: a direct-mode ROWS problem of whole 128 x 128 blocks of dW with >= 256 plain rows runs on the f16 matrix
+                               pipes with f32-equivalent arithmetic (csrc/wgrad_rows_split.hip: both operands split into two f16 pieces in
+                               the kernel, three MFMAs per product, f32 accumulate); everything else, and 0, runs the exact f32 kernel */
+    int32_t _pad_split;
 } gcpx_wgrad_args;
 
 int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream);
@@ -707,6 +726,9 @@ int gcpx_graph_destroy(void* graph_exec);
 int gcpx_stream_create(void** stream);
 /* level < 0: highest priority of the device, 0: middle, > 0: lowest (side lanes that must not delay the critical chain) */
 int gcpx_stream_create_priority(void** stream, int level);
+/* a stream restricted to the CUs whose bit is set in mask (nwords x 32 bits): side lanes that must leave CUs free for a dependent
+   chain on another stream */
+int gcpx_stream_create_cumask(void** stream, const uint32_t* mask, int32_t nwords);
 int gcpx_stream_destroy(void* stream);
 int gcpx_stream_wait_event(void* stream, void* ev);
 

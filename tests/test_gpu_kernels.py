@@ -944,6 +944,79 @@ def test_wgrad_group_matches_single_launches(env):
             assert_close(got, one, atol=2e-4, rtol=1e-5, name="grouped vs single")
 
 
+@pytest.mark.parametrize("R,N,K", [(1024, 256, 128), (300, 128, 256), (512, 512, 384)])
+@pytest.mark.parametrize("case", ["plain", "row_scales", "tiny", "strided_batch", "grouped"])
+def test_wgrad_rows_split_error_vs_float64(env, R, N, K, case):
+    """Weight gradients of the tree's Linear / LSTM layers on the split-f16 kernel (csrc/wgrad_rows_split.hip: gcpx_wgrad_args.split_f16,
+    whole 128 x 128 blocks of dW, >= 256 plain rows) against float64, next to the exact f32 kernel on the same descriptor: dW, the
+    fused bias gradient into two destinations, accumulation into existing gradients.  Row blocks whose magnitudes differ by six
+    orders (the running scale drops, the sums are rescaled), gradients of order 1e-6, a row count that is no multiple of 64;
+    'strided_batch': rows addressed as (batch element, node) with strides for both operands and three batched problems (the
+    split_linear projections); 'grouped': through gcpx_wgrad_classify (variant 4) + gcpx_wgrad_group."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(R + N + K)
+    nb = 3 if case == "strided_batch" else 1
+    rpb = 4 if case == "strided_batch" else R
+    B = R // rpb
+    ldy, sr = nb * N + 32, nb * K + 16                          # row pitches wider than the problem (other columns belong to other problems)
+    dy_sb, sb = rpb * ldy + 64, rpb * sr + 128                  # batch elements further apart than their rows
+    dyb = torch.randn(B, dy_sb // ldy + 1, ldy, device=dev)
+    xb = torch.randn(B, sb // sr + 1, sr, device=dev)
+    dyf, xf = dyb.reshape(B, -1)[:, :dy_sb].contiguous(), xb.reshape(B, -1)[:, :sb].contiguous()      # [B][dy_sb], [B][sb] flat batch slabs
+    if case == "row_scales":
+        dyf *= torch.logspace(-3, 3, B, device=dev)[:, None]
+        xf *= torch.logspace(2, -2, B, device=dev)[:, None]
+    elif case == "tiny":
+        dyf *= 1e-6
+
+    def rows(flat, pitch, bstride, width, z):                   # [R][width] view of batch problem z
+        idx = (torch.arange(B, device=dev)[:, None] * bstride + torch.arange(rpb, device=dev)[None] * pitch).reshape(-1)
+        return flat.reshape(-1)[(idx[:, None] + z * width + torch.arange(width, device=dev)[None])]
+
+    ref = [rows(dyf, ldy, dy_sb, N, z).double().t() @ rows(xf, sr, sb, K, z).double() for z in range(nb)]
+    refb = [rows(dyf, ldy, dy_sb, N, z).double().sum(0) for z in range(nb)]
+    ldw, k_off = K + 64, 32
+    err, berr = {}, {}
+    init = 0.0 if case == "tiny" else 1.0                       # existing gradient the launch accumulates onto
+    for name, split in (("f32", 0), ("split", 1)):
+        out = torch.full((nb, N, ldw), init, device=dev)
+        db, db2 = torch.full((nb, N), init, device=dev), torch.full((N,), init, device=dev)
+        a = rt.WgradArgs()
+        a.dy, a.x, a.ldy, a.R, a.N, a.n_valid, a.K, a.mode = dyf.data_ptr(), xf.data_ptr(), ldy, R, N, N, K, rt.WG_ROWS
+        a.sb, a.sr, a.rpb, a.dy_sb, a.dy_rpb = sb, sr, rpb, dy_sb, rpb
+        a.out, a.ldw, a.k_off, a.accumulate, a.partial, a.nsplit = out.data_ptr(), ldw, k_off, 1, 0, 1
+        a.dbias, a.dbias2 = db.data_ptr(), (db2.data_ptr() if nb == 1 else None)
+        if nb > 1:
+            a.nbatch, a.z_dy_off, a.z_x_off, a.z_out_off, a.z_bias_off = nb, N, K, N * ldw, N
+        a.split_f16 = split
+        if case == "grouped" and split:
+            v, nblk = C.c_int32(), C.c_int32()
+            rt.check(lib.gcpx_wgrad_classify(C.byref(a), 0, C.byref(v), C.byref(nblk)), "classify")
+            assert v.value == 4 and nblk.value == (N // 128) * (K // 128) * nb
+            tab = (rt.WgradArgs * 1)(a)
+            raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
+            bst = torch.zeros(1, dtype=torch.int32, device=dev)
+            rt.check(lib.gcpx_wgrad_group(raw.data_ptr(), bst.data_ptr(), 1, nblk.value, 4, _stream()), "wgrad_group")
+        else:
+            rt.check(lib.gcpx_wgrad(C.byref(a), _stream()), name)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        assert bool((out[:, :, :k_off] == init).all()) and bool((out[:, :, k_off + K:] == init).all())       # neighbours untouched
+        err[name] = torch.stack([(out[z, :, k_off:k_off + K].double() - init - ref[z]).abs() for z in range(nb)])
+        berr[name] = torch.stack([(db[z].double() - init - refb[z]).abs() for z in range(nb)])
+        if nb == 1:
+            assert torch.equal(db2, db[0])
+    scale = max(float(r.abs().max()) for r in ref) + 1e-300
+    e32, esp = float(err["f32"].max()) / scale, float(err["split"].max()) / scale
+    r32, rsp = float(err["f32"].pow(2).mean().sqrt()) / scale, float(err["split"].pow(2).mean().sqrt()) / scale
+    # (the outputs accumulate onto `init`: one more f32 rounding of max(init, |dW|) in both kernels)
+    floor = 1.2e-7 * max(init, scale) / scale
+    assert esp <= 2.0 * e32 + 4e-7 + floor, (esp, e32)
+    assert rsp <= 1.5 * r32 + 1e-7 + floor, (rsp, r32)
+    bscale = max(float(r.abs().max()) for r in refb) + 1e-300
+    assert float(berr["split"].max()) / bscale <= 2.0 * float(berr["f32"].max()) / bscale + 4e-7 + 1.2e-7 * max(init, bscale) / bscale
+
+
 @pytest.mark.parametrize("S,cin,cout,Fr,use_frames", [(32, 112, 16, 9, True), (32, 112, 16, 9, False), (64, 48, 16, 5, True),
                                                       (32, 16, 32, 6, None), (64, 16, 32, 3, None)])
 @pytest.mark.parametrize("split", [False, True, "tiny"])
@@ -1002,6 +1075,71 @@ def test_conv3x3_plain_row_maps(env, S, cin, cout, Fr, use_frames, split):
             want[f] = full[r]
     scale = float(want.abs().max())
     assert_close(out.permute(0, 3, 1, 2), want, atol=3e-5 * min(1.0, scale), rtol=1e-5, name="plain conv3x3")
+
+
+@pytest.mark.parametrize("with_rows", [True, False])
+def test_conv3x3_data_gradient_with_activation_backward(env, with_rows):
+    """gcpx_conv_args.bwd_r: the head's data gradient (112 -> 16 channels, split-f16 wave-autonomous kernel) with the next step of the
+    backward pass in its epilogue — g = conv * LeakyReLU'(scale r + shift) stored, per-workgroup sums of g and g * x_hat left for
+    gcpx_bn_bwd_finalize — against the plain conv followed by gcpx_act_bwd (what the training step ran before); with and without
+    the matched-row maps (frames without a row: zeros, no contribution)."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(5)
+    S, cin, cout, Fr = 32, 112, 16, 7
+    w = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5
+    wp, bd = pk.pack_conv3x3(w, 16).to(dev), torch.zeros(64, device=dev)
+    ws, e = pk.pack_conv3x3_split(w)
+    ws = ws.to(dev)
+    if with_rows:
+        rows = [r for r in range(Fr) if r % 3 != 1]
+        fmap = torch.full((Fr,), -1, dtype=torch.int32)
+        for i, f in enumerate(rows):
+            fmap[f] = i
+        R = len(rows) + 1                                        # one row nobody reads
+    else:
+        fmap, R = None, Fr
+    x = (torch.randn(R, S, S, cin) * 1e-4).to(dev)               # loss gradients: small
+    r = torch.randn(Fr, S, S, cout, device=dev) * 2 + 0.5
+    scale, shift = torch.randn(cout, device=dev), torch.randn(cout, device=dev) * 0.3
+    mean, rstd = torch.randn(cout, device=dev) * 0.2 + 0.5, torch.rand(cout, device=dev) + 0.3
+
+    def run(fused):
+        out = torch.full((Fr, S, S, cout), float("nan"), device=dev)
+        a = _conv_args(rt, [(x, cin, 1, None, None, rt.ACT_NONE)], F=Fr, Hin=S, Win=S, Hout=S, Wout=S, Cout=cout, out_pitch=cout,
+                       upsample=0, head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out)
+        a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+        keep = []
+        if fmap is not None:
+            fd = fmap.to(dev)
+            inv = torch.full((R,), -1, dtype=torch.int32, device=dev)
+            rt.check(lib.gcpx_index_inverse(fd.data_ptr(), Fr, inv.data_ptr(), R, _stream()), "index_inverse")
+            a.src_row_map, a.src_row_frames, a.n_src_rows = fd.data_ptr(), inv.data_ptr(), R
+            keep += [fd, inv]
+        st = None
+        if fused:
+            nb = lib.gcpx_conv3x3_grid(C.byref(a))
+            st = torch.full((nb, 2, cout), float("nan"), device=dev)
+            a.bwd_r, a.bwd_scale, a.bwd_shift, a.bwd_mean, a.bwd_rstd = r.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+            a.stats_partial = st.data_ptr()
+        rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "conv3x3 plain")
+        torch.cuda.synchronize()
+        return out, st
+
+    plain, _ = run(False)
+    dy = torch.empty_like(plain)
+    nb = lib.gcpx_act_bwd_blocks()
+    st_ref = torch.zeros(nb, 2, cout, device=dev)
+    b = rt.ActBwdArgs()
+    b.da, b.r, b.scale, b.shift, b.mean, b.rstd = plain.data_ptr(), r.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    b.dy, b.stats_partial, b.ldc, b.c_off, b.up, b.fsum, b.act = dy.data_ptr(), st_ref.data_ptr(), cout, 0, 0, 1, rt.ACT_LRELU
+    b.F, b.H, b.W, b.C = Fr, S, S, cout
+    rt.check(lib.gcpx_act_bwd(C.byref(b), _stream()), "act_bwd")
+    torch.cuda.synchronize()
+    got, st = run(True)
+    assert torch.isfinite(st).all()
+    assert torch.equal(got, dy)                                  # same products, same mask
+    want, have = st_ref.double().sum(0), st.double().sum(0)
+    assert_close(have, want, atol=2e-6 * float(want.abs().max()), rtol=1e-5, name="BatchNorm backward sums")
 
 
 def test_aux_sample_indices_uniform_and_gauss(env):

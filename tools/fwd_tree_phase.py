@@ -20,13 +20,14 @@ plan = [v[1] for v in model._plans.values()][-1]
 names = [o[0] for o in plan.ops]
 L = hp.hierarchy_levels
 def lvl_start(l):
-    for cand in (f"prior+posterior{l}", f"prior{l}", f"merge{l}"):
-        if cand in names:
-            return min(names.index(c) for c in (f"prior+posterior{l}", f"prior{l}", f"posterior{l}") + ((f"merge{l}",) if l == 0 else ()) if c in names)
-    raise KeyError(l)
+    hits = [i for i, nm in enumerate(names) if nm in (f"prior{l}", f"posterior{l}", f"merge{l}") or nm.startswith(f"prior+posterior{l}")
+            or nm.endswith(f"+merge{l}")]
+    if not hits:
+        raise KeyError(l)
+    return min(hits)
 
 
-first = names.index("length_pred") if "length_pred" in names else lvl_start(0)
+first = lvl_start(0)
 # start at the fork that precedes the first tree op
 a = first
 while a > 0 and names[a - 1].startswith("@"):

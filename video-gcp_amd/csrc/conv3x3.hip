@@ -1279,7 +1279,14 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
             if (CT == 1) return query_only ? gcpx_conv_grid() / 2 : launch_head<1, false>(a, stream);
         }
         // data gradients of the decoder blocks (3x3 conv with the transposed, flipped weights): workgroup-tiled kernel
-        GCPX_CHECK_ARG(a->head_mode == GCPX_HEAD_RAW && !a->stats_partial, "plain 3x3 conv stores raw output, no statistics");
+        GCPX_CHECK_ARG(a->head_mode == GCPX_HEAD_RAW && (!a->stats_partial || a->bwd_r), "plain 3x3 conv stores raw output, no statistics");
+        if (a->bwd_r) {
+            // activation backward in the epilogue: only the split-f16 wave-autonomous kernel with 16 output channels has it
+            const bool fits = a->wpk_split && a->split_layout == GCPX_SPLIT_PLAIN && W % 16 == 0 && a->Hout % 4 == 0 && a->Cout == 16 &&
+                              a->out_pitch == 16 && a->Cin >= 32 && a->Cin % 16 == 0 && (!a->src_row_map || a->src_row_frames) &&
+                              a->stats_partial && a->bwd_scale && a->bwd_shift && a->bwd_mean && a->bwd_rstd && !getenv("GCPX_DGRAD_TILED");
+            GCPX_CHECK_ARG(fits, "bwd_r: split-f16 plain 3x3 conv, 16 output channels at pitch 16, Cin >= 32, stats_partial and the four BatchNorm vectors");
+        }
         static const bool tiled_only = getenv("GCPX_DGRAD_TILED") != nullptr;
         static const int depth = getenv("GCPX_DGRAD_DEPTH") ? atoi(getenv("GCPX_DGRAD_DEPTH")) : 2;
         GCPX_CHECK_ARG(!a->src_row_frames || (a->src_row_map && a->n_src_rows >= 0), "src_row_frames needs src_row_map and n_src_rows");

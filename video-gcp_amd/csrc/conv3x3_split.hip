@@ -1411,10 +1411,11 @@ struct WaveSplitCfg {
     static constexpr int REGION_BYTES = 2 * PLANE_BYTES;
     static constexpr int W_CHUNK_BYTES = KS * CT * 2 * 1024;
     static constexpr int NS = (RH * RW * 4 + 63) / 64;
-    static int lds_bytes(int nchunk) { return nchunk * W_CHUNK_BYTES + 8 * REGION_BYTES; }
+    static int lds_bytes(int nchunk) { return nchunk * W_CHUNK_BYTES + 8 * REGION_BYTES + 256 + 1024; }      // + ACTB: four 16-channel vectors, [8 wavefronts][2][16] sums
 };
 
-template <int CT, int DEPTH>
+// ACTB (CT = 1): the activation + BatchNorm-statistics step of the backward pass in the epilogue (gcpx_conv_args.bwd_r)
+template <int CT, int DEPTH, bool ACTB = false>
 __global__ void __launch_bounds__(512, 2) conv3x3_wave_split_kernel(const gcpx_conv_args a, const int nitems) {
     using Cfg = WaveSplitCfg<CT>;
     constexpr int RW = Cfg::RW, RH = Cfg::RH, NS = Cfg::NS, KS = Cfg::KS;
@@ -1438,6 +1439,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_split_kernel(const gcpx_c
             float4* op = reinterpret_cast<float4*>(a.out + (size_t)f * H * W * a.out_pitch);
             for (int i = tid; i < f4_per_frame; i += 512) op[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    }
+    if constexpr (ACTB) {
+        float* bx0 = reinterpret_cast<float*>(reinterpret_cast<char*>(smem4) + nchunk * Cfg::W_CHUNK_BYTES + 8 * Cfg::REGION_BYTES);
+        if (tid < 64) {
+            const float* src = tid < 16 ? a.bwd_scale : tid < 32 ? a.bwd_shift : tid < 48 ? a.bwd_mean : a.bwd_rstd;
+            bx0[tid] = src[tid & 15];
+        }
+        if (tid < 256) bx0[64 + tid] = 0.f;
     }
     __syncthreads();
 
@@ -1519,6 +1528,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_split_kernel(const gcpx_c
     int ck = 0, cchunk = 0;
     int f_v = 0;
     int ex = 0;                                             // the accumulators hold (sum) 2^(ex + ew)
+    // ACTB: this lane's four channels of the layer behind the gradient (BatchNorm affine, batch statistics) and its running sums
+    // (vectors and running sums live in LDS: held in registers across the prefetch pipeline they spill, and a scratch reload waits
+    // for every load in flight)
+    const int bx_off = nchunk * Cfg::W_CHUNK_BYTES + 8 * Cfg::REGION_BYTES;   // (uniform; the lane addresses are rebuilt in every epilogue)
     auto step = [&](float4 (&pre)[NS], unsigned& ok) {
         if (__builtin_amdgcn_readfirstlane(ok) == 0) {      // skipped item
             issue(pre, ok);
@@ -1571,6 +1584,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_split_kernel(const gcpx_c
             geom(ck, srow, y0, x0);
             const int f = a.src_row_frames ? __builtin_amdgcn_readfirstlane(f_v) : srow;
             const float inv = __uint_as_float((unsigned)(127 - ex - ew) << 23);
+            float bs1[4] = {0.f, 0.f, 0.f, 0.f}, bs2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
                 float* op = a.out + (((size_t)f * H + (y0 + pt)) * W + (x0 + j)) * a.out_pitch;
@@ -1578,8 +1592,36 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_split_kernel(const gcpx_c
                 for (int ct = 0; ct < CT; ++ct) {
                     const float4 bs = *reinterpret_cast<const float4*>(a.bias + ct * 16 + q * 4);
                     const f32x4 v = acc[ct][pt];
-                    *reinterpret_cast<float4*>(op + ct * 16 + q * 4) =
-                        make_float4(fmaf(v[0], inv, bs.x), fmaf(v[1], inv, bs.y), fmaf(v[2], inv, bs.z), fmaf(v[3], inv, bs.w));
+                    float4 o = make_float4(fmaf(v[0], inv, bs.x), fmaf(v[1], inv, bs.y), fmaf(v[2], inv, bs.z), fmaf(v[3], inv, bs.w));
+                    if constexpr (ACTB) {
+                        int q2 = q;
+                        asm volatile("" : "+v"(q2));       // (opaque: otherwise the address is hoisted out of the item loop and spilled)
+                        const float4* bvec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(smem4) + bx_off) + q2;
+                        const float4 b_sc = bvec[0], b_sh = bvec[4], b_mu = bvec[8], b_rs = bvec[12];
+                        const float4 rv = *reinterpret_cast<const float4*>(a.bwd_r + (op - a.out) + q2 * 4);      // (out_pitch == 16: the same offsets)
+                        o.x *= fmaf(rv.x, b_sc.x, b_sh.x) > 0.f ? 1.f : 0.2f; o.y *= fmaf(rv.y, b_sc.y, b_sh.y) > 0.f ? 1.f : 0.2f;
+                        o.z *= fmaf(rv.z, b_sc.z, b_sh.z) > 0.f ? 1.f : 0.2f; o.w *= fmaf(rv.w, b_sc.w, b_sh.w) > 0.f ? 1.f : 0.2f;
+                        bs1[0] += o.x; bs1[1] += o.y; bs1[2] += o.z; bs1[3] += o.w;
+                        bs2[0] += o.x * (rv.x - b_mu.x) * b_rs.x; bs2[1] += o.y * (rv.y - b_mu.y) * b_rs.y;
+                        bs2[2] += o.z * (rv.z - b_mu.z) * b_rs.z; bs2[3] += o.w * (rv.w - b_mu.w) * b_rs.w;
+                    }
+                    *reinterpret_cast<float4*>(op + ct * 16 + q * 4) = o;
+                }
+            }
+            if constexpr (ACTB) {
+                // the item's sums over its 16 pixel lanes, added to the wavefront's LDS sums by one lane per channel group (same
+                // order in every run: deterministic)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { bs1[k] = row16_sum(bs1[k]); bs2[k] = row16_sum(bs2[k]); }
+                if (j == 0) {
+                    int q2 = q;
+                    asm volatile("" : "+v"(q2));
+                    float* bsum = reinterpret_cast<float*>(reinterpret_cast<char*>(smem4) + bx_off + 256) + wave * 32 + q2 * 4;   // this wavefront's [2][16] sums
+                    float4 t1 = *reinterpret_cast<float4*>(bsum), t2 = *reinterpret_cast<float4*>(bsum + 16);
+                    t1.x += bs1[0]; t1.y += bs1[1]; t1.z += bs1[2]; t1.w += bs1[3];
+                    t2.x += bs2[0]; t2.y += bs2[1]; t2.z += bs2[2]; t2.w += bs2[3];
+                    *reinterpret_cast<float4*>(bsum) = t1;
+                    *reinterpret_cast<float4*>(bsum + 16) = t2;
                 }
             }
             cchunk = 0; ++ck;
@@ -1600,12 +1642,24 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_split_kernel(const gcpx_c
     } else {
         for (int s = 0; s < nsteps; ++s) step(preA, okA);
     }
+    if constexpr (ACTB) {
+        // per-workgroup sums: the 8 wavefronts' LDS sums in a fixed order
+        __syncthreads();
+        const float* red = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem4) + nchunk * Cfg::W_CHUNK_BYTES + 8 * Cfg::REGION_BYTES + 256);
+        if (tid < 32) {
+            const int which = tid >> 4, c = tid & 15;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += red[(w * 2 + which) * 16 + c];
+            a.stats_partial[((size_t)blockIdx.x * 2 + which) * 16 + c] = sum;
+        }
+    }
 }
 
-template <int CT, int DEPTH>
+template <int CT, int DEPTH, bool ACTB = false>
 int launch_wave_split_t(const gcpx_conv_args* a, hipStream_t stream) {
     using Cfg = WaveSplitCfg<CT>;
-    auto kern = conv3x3_wave_split_kernel<CT, DEPTH>;
+    auto kern = conv3x3_wave_split_kernel<CT, DEPTH, ACTB>;
     const int lds = Cfg::lds_bytes(a->Cin / 16);
     static int attr_lds = 0;
     if (lds > attr_lds) {
@@ -1619,8 +1673,8 @@ int launch_wave_split_t(const gcpx_conv_args* a, hipStream_t stream) {
     const int frames = a->src_row_frames ? a->n_src_rows : a->F;
     const int nitems = frames * (a->Hout / 4) * (a->Wout / 16);
     int grid = gcpx_conv_grid() / 2;
-    if (nitems == 0) grid = a->src_row_frames ? grid : 0;
-    else if (grid * 8 > nitems && !a->src_row_frames) grid = (nitems + 7) / 8;
+    if (nitems == 0) grid = (a->src_row_frames || ACTB) ? grid : 0;
+    else if (grid * 8 > nitems && !a->src_row_frames && !ACTB) grid = (nitems + 7) / 8;      // (ACTB: every row of stats_partial is written)
     if (grid == 0) return GCPX_OK;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, nitems);
     GCPX_CHECK_LAUNCH();
@@ -1805,6 +1859,7 @@ int gcpx_launch_wave_split(const gcpx_conv_args* a, hipStream_t stream, int ct, 
     const int nchunk = a->Cin / 16;
     if (ct == 1) {
         if (WaveSplitCfg<1>::lds_bytes(nchunk) > 160 * 1024) return -1;
+        if (a->bwd_r) return depth == 2 ? launch_wave_split_t<1, 2, true>(a, stream) : launch_wave_split_t<1, 1, true>(a, stream);
         return depth == 2 ? launch_wave_split_t<1, 2>(a, stream) : launch_wave_split_t<1, 1>(a, stream);
     }
     if (WaveSplitCfg<2>::lds_bytes(nchunk) > 160 * 1024) return -1;

@@ -362,6 +362,7 @@ int gcpx_launch_gemm_split(const gcpx_gemm_args* a, hipStream_t stream) {
     if (force == 642) return launch_split<64, 2>(a, stream);
     if (force == 641) return launch_split<64, 1>(a, stream);
     if (force == 1281) return launch_split<128, 1>(a, stream);
+    if (force == 2561 && a->N % 256 == 0) return launch_split<256, 1>(a, stream);
     // Stages of 32 k: 24 / 16 KB of LDS per stage, so 3 - 4 workgroups share a CU and one's barrier and conversion hide behind the
     // others' loads (64-k stages, one or two workgroups per CU: 1024 x 2048 x 1024 38 us, 32768 rows 1082 us; 32-k stages 35 / 754).
     // 128-column tiles (fewer operand bytes per MFMA) once they still give every CU three workgroups, 64-column tiles below.

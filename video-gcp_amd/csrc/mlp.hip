@@ -11,8 +11,11 @@
 //   /root/reference/gcp/prediction/models/tree/tree_module.py:105  (MLP LSTM initialiser)
 //   misc.py:48, frame_binding.py:71, base_gcp.py:256, inverse_mdl.py:126, cost_mdl.py:63 (heads).
 #include "common.h"
+#include "gemm_tile.h"
 
 #include <cstdlib>
+
+bool gcpx_gemm_tile_plan(const gcpx_gemm_args* a, int* pr, int* cr, int* ks, int* gx, int* gy, int* gz);      // gemm.hip
 
 namespace {
 
@@ -330,6 +333,46 @@ __global__ void __launch_bounds__(256, LEAN ? 2 : 1) mlp_group_kernel(const gcpx
     mlp_rows<MID, LEAN>(tab[p], local % d.y, local / d.y, d.z, reinterpret_cast<float*>(hid4));
 }
 
+// A level of the tree in front of its recurrent cell: the prior and posterior Predictors of level l AND the merge of the parents'
+// hidden states (tree_lstm.py:43-48) need nothing but level l - 1's results and not each other — one launch.  Workgroups
+// [0, nblocks) are the Predictors' (as mlp_group_kernel), the next gx * gy * gz carry the GEMM's blocks as gemm_kernel<PR, CR, false, KS>
+// would (the merge GEMM was a launch of its own on the dependent chain: 14 - 35 us per level at c2), the rest are helpers.
+template <int MID, int PR, int CR, bool KS>
+__global__ void __launch_bounds__(256, 1) level_pre_kernel(const gcpx_mlp_args* __restrict__ tab, const int4* __restrict__ dims, const int n,
+                                                           const int nblocks, const gcpx_gemm_args g, const int gx, const int gy, const int gz) {
+    __shared__ float4 hid4[2 * 16 * (MID + 4) / 4];
+    const int blk = blockIdx.x;
+    if (blk >= nblocks) {
+        const int local = blk - nblocks, ng = gx * gy * gz;
+        if (local < ng) {
+            gemm_tile<PR, CR, false, KS>(g, local % gx, (local / gx) % gy, local / (gx * gy));
+        } else {
+            for (int p = 0; p < n; ++p) prefetch_weights(tab[p], local - ng, gridDim.x - nblocks - ng);
+        }
+        return;
+    }
+    int p = 0;
+    while (p + 1 < n && blk >= dims[p + 1].x) ++p;
+    const int4 d = dims[p];
+    const int local = blk - d.x;
+    mlp_rows<MID, false>(tab[p], local % d.y, local / d.y, d.z, reinterpret_cast<float*>(hid4));
+}
+
+typedef void (*level_pre_fn)(const gcpx_mlp_args*, const int4*, int, int, const gcpx_gemm_args, int, int, int);
+level_pre_fn level_pre_variant(const int pr, const int cr, const int ks) {
+    if (ks) {
+        if (pr == 1 && cr == 1) return level_pre_kernel<128, 1, 1, true>;
+        if (pr == 1 && cr == 2) return level_pre_kernel<128, 1, 2, true>;
+        if (pr == 2 && cr == 2) return level_pre_kernel<128, 2, 2, true>;
+        if (pr == 4 && cr == 2) return level_pre_kernel<128, 4, 2, true>;
+        if (pr == 2 && cr == 4) return level_pre_kernel<128, 2, 4, true>;
+        return nullptr;
+    }
+    if (pr == 2 && cr == 2) return level_pre_kernel<128, 2, 2, false>;
+    if (pr == 4 && cr == 2) return level_pre_kernel<128, 4, 2, false>;
+    return nullptr;
+}
+
 int mlp_check(const gcpx_mlp_args* a) {
     GCPX_CHECK_ARG(a != nullptr, "null args");
     GCPX_CHECK_ARG(a->nsrc >= 1 && a->nsrc <= 4, "nsrc out of range");
@@ -355,8 +398,9 @@ int mlp_check(const gcpx_mlp_args* a) {
 void mlp_grid(const gcpx_mlp_args* a, int* gx, int* gy) {
     *gx = (a->M + 15) / 16;
     const int head_tiles = ((a->epi == GCPX_MLP_GAUSS ? a->out_dim / 2 : a->out_dim) + 15) / 16;
+    static const int ymax = [] { const char* e = getenv("GCPX_MLP_GY_MAX"); return e ? atoi(e) : 32; }();     // tuning aid
     int y = 1;
-    while (y < 32 && *gx * y < 256 && head_tiles / (4 * y) >= 2) y *= 2;
+    while (y < ymax && *gx * y < 256 && head_tiles / (4 * y) >= 2) y *= 2;
     *gy = y;
 }
 
@@ -404,6 +448,37 @@ extern "C" int gcpx_mlp_group(const gcpx_mlp_args* dev_table, const int32_t* dev
         gcpx_set_error("gcpx_mlp_group: unsupported mid=%d (128 or 32)", mid);
         return GCPX_ERR_UNSUPPORTED;
     }
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+// 1 when gcpx_mlp_group_gemm can carry this GEMM next to a group of total_blocks Predictor workgroups of hidden width mid
+extern "C" int gcpx_mlp_group_gemm_supported(const gcpx_gemm_args* g, int32_t total_blocks, int32_t mid) {
+    if (!g || mid != 128 || g->epi == GCPX_EPI_LSTM || g->epi == GCPX_EPI_GAUSS_SAMPLE) return 0;
+    const int cus = gcpx_conv_grid() / 2;
+    if (total_blocks > cus) return 0;                                // (the throughput-bound Predictor launches run the lean kernel)
+    int pr, cr, ks, gx, gy, gz;
+    if (!gcpx_gemm_tile_plan(g, &pr, &cr, &ks, &gx, &gy, &gz)) return 0;
+    return level_pre_variant(pr, cr, ks) != nullptr;
+}
+
+extern "C" int gcpx_mlp_group_gemm(const gcpx_mlp_args* dev_table, const int32_t* dev_dims, int32_t n, int32_t total_blocks, int32_t mid,
+                                   const gcpx_gemm_args* g, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(dev_table && dev_dims && g && n >= 1 && n <= 16 && total_blocks > 0, "bad arguments");
+    GCPX_CHECK_ARG((((uintptr_t)dev_dims) & 15) == 0, "dims must be 16-byte aligned");
+    int pr, cr, ks, gx, gy, gz;
+    level_pre_fn kern = nullptr;
+    if (mid == 128 && g->epi != GCPX_EPI_LSTM && g->epi != GCPX_EPI_GAUSS_SAMPLE && gcpx_gemm_tile_plan(g, &pr, &cr, &ks, &gx, &gy, &gz))
+        kern = level_pre_variant(pr, cr, ks);
+    if (!kern) {
+        gcpx_set_error("gcpx_mlp_group_gemm: this GEMM / hidden width has no combined launch (ask gcpx_mlp_group_gemm_supported)");
+        return GCPX_ERR_UNSUPPORTED;
+    }
+    const int cus = gcpx_conv_grid() / 2;
+    const int work = total_blocks + gx * gy * gz;
+    const int grid = work + mlp_helpers(work, cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, stream, dev_table, reinterpret_cast<const int4*>(dev_dims), n, total_blocks, *g, gx, gy, gz);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -14,6 +14,14 @@
 // (deterministic), which also maps (n, k) to the canonical torch parameter layout.
 #include "common.h"
 
+#include <cstdlib>
+
+// split-f16 form of the direct-mode row problems with whole 128 x 128 blocks (wgrad_rows_split.hip)
+bool gcpx_wgrad_rows_split_applies(const gcpx_wgrad_args* a);
+int gcpx_wgrad_rows_split_blocks(const gcpx_wgrad_args* a);
+int gcpx_launch_wgrad_rows_split(const gcpx_wgrad_args* a, hipStream_t stream);
+int gcpx_launch_wgrad_rows_split_group(const gcpx_wgrad_args* tab, const int32_t* block_start, int nprob, int total_blocks, hipStream_t stream);
+
 namespace {
 
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
@@ -378,6 +386,12 @@ extern "C" int gcpx_wgrad(const gcpx_wgrad_args* a, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int st = wgrad_check(a);
     if (st != GCPX_OK) return st;
+    if (a->split_f16 && gcpx_wgrad_rows_split_applies(a)) {
+        const int s2 = gcpx_launch_wgrad_rows_split(a, stream);
+        if (s2 != GCPX_OK) return s2;
+        GCPX_CHECK_LAUNCH();
+        return GCPX_OK;
+    }
     const int v = wgrad_variant(a);
     int gx, gy, gz;
     wgrad_grid(*a, (v & 2) != 0, gx, gy, gz);
@@ -394,6 +408,11 @@ extern "C" int gcpx_wgrad_classify(const gcpx_wgrad_args* a, int32_t row_split, 
     const int st = wgrad_check(a);
     if (st != GCPX_OK) return st;
     GCPX_CHECK_ARG(variant && nblocks, "null output");
+    if (a->split_f16 && gcpx_wgrad_rows_split_applies(a)) {          // variant 4: the split-f16 kernel, one workgroup per 128 x 128 block
+        *variant = 4;
+        *nblocks = gcpx_wgrad_rows_split_blocks(a);
+        return GCPX_OK;
+    }
     int v = wgrad_variant(a);
     if (row_split == 0) v &= 1;          // the caller fills the chip with the group: one wavefront per 64 x 64 tile
     else if (row_split == 1) v |= 2;
@@ -407,7 +426,13 @@ extern "C" int gcpx_wgrad_classify(const gcpx_wgrad_args* a, int32_t row_split, 
 extern "C" int gcpx_wgrad_group(const gcpx_wgrad_args* tab, const int32_t* block_start, int32_t nprob, int32_t total_blocks,
                                 int32_t variant, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    GCPX_CHECK_ARG(tab && block_start && nprob > 0 && nprob <= 64 && total_blocks > 0 && variant >= 0 && variant < 4, "bad arguments");
+    GCPX_CHECK_ARG(tab && block_start && nprob > 0 && nprob <= 64 && total_blocks > 0 && variant >= 0 && variant <= 4, "bad arguments");
+    if (variant == 4) {
+        const int s2 = gcpx_launch_wgrad_rows_split_group(tab, block_start, nprob, total_blocks, stream);
+        if (s2 != GCPX_OK) return s2;
+        GCPX_CHECK_LAUNCH();
+        return GCPX_OK;
+    }
     const dim3 grid(total_blocks);
     if (variant == 3) hipLaunchKernelGGL((wgrad_group_kernel<4, true>), grid, dim3(256), 0, stream, tab, block_start, nprob);
     else if (variant == 2) hipLaunchKernelGGL((wgrad_group_kernel<1, true>), grid, dim3(256), 0, stream, tab, block_start, nprob);

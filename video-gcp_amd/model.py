@@ -151,10 +151,17 @@ class GCPTreeModel:
         # and orders it against the caller's current stream with events (wait_stream), never a host sync
         self._stream = torch.cuda.Stream(device=self.device)
         self._streams = [self._stream.cuda_stream]
+        # GCPX_SIDE_CU_MASK="k/n" (experiment): side lanes run on CUs i with i % n < k only
+        cu_mask = os.environ.get("GCPX_SIDE_CU_MASK")
         for _ in range(N_LANES - 1):
             sp = C.c_void_p()
             with torch.cuda.device(self.device):
-                rt.check(self.lib.gcpx_stream_create(C.byref(sp)), "stream_create")
+                if cu_mask:
+                    k_, n_ = (int(v) for v in cu_mask.split("/"))
+                    words = (C.c_uint32 * 10)(*[sum(1 << b for b in range(32) if (32 * w + b) % n_ < k_) for w in range(10)])
+                    rt.check(self.lib.gcpx_stream_create_cumask(C.byref(sp), words, 10), "stream_create_cumask")
+                else:
+                    rt.check(self.lib.gcpx_stream_create(C.byref(sp)), "stream_create")
             self._streams.append(sp)
         self.save_for_backward = False        # training step: forward plans keep what the backward pass needs
         # split-f16 convs (csrc/conv3x3_split.hip): f32-equivalent results on the f16 matrix pipes.  GCPX_EXACT_F32=1 keeps every
@@ -733,9 +740,13 @@ class GCPTreeModel:
             return
         plan.add(name, self.lib.gcpx_mlp, C.byref(a))
 
-    def _mlp_group(self, plan, name, group):
-        """independent Predictors of one hidden width as one launch (descriptor table uploaded once, when the plan is built)"""
+    def _mlp_group(self, plan, name, group, gemm=None):
+        """independent Predictors of one hidden width as one launch (descriptor table uploaded once, when the plan is built).
+        gemm: a (name, GemmArgs) that depends on none of them and rides in the same launch when there is a combined kernel for its
+        tiling (gcpx_mlp_group_gemm), else it is launched first."""
         if len(group) == 1:
+            if gemm is not None:
+                plan.add(gemm[0], self.lib.gcpx_gemm, C.byref(gemm[1]))
             plan.add(group[0][0], self.lib.gcpx_mlp, C.byref(group[0][1]))
             return
         n = len(group)
@@ -746,7 +757,13 @@ class GCPTreeModel:
         raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
         dd = torch.tensor(list(dims), dtype=torch.int32, device=self.device)
         plan.keep += [raw, dd, tab]
-        plan.add(name, self.lib.gcpx_mlp_group, raw.data_ptr(), dd.data_ptr(), n, total.value, group[0][1].mid)
+        mid = group[0][1].mid
+        if gemm is not None:
+            if os.environ.get("GCPX_NO_LEVEL_PRE") is None and self.lib.gcpx_mlp_group_gemm_supported(C.byref(gemm[1]), total.value, mid):
+                plan.add(f"{name}+{gemm[0]}", self.lib.gcpx_mlp_group_gemm, raw.data_ptr(), dd.data_ptr(), n, total.value, mid, C.byref(gemm[1]))
+                return
+            plan.add(gemm[0], self.lib.gcpx_gemm, C.byref(gemm[1]))
+        plan.add(name, self.lib.gcpx_mlp_group, raw.data_ptr(), dd.data_ptr(), n, total.value, mid)
 
     def _bn(self, plan, tag, prefix, C_, stats, n_partial, pitch, count):
         """(scale, shift) of a BatchNorm: batch statistics when training, running statistics otherwise."""
@@ -1072,7 +1089,7 @@ class GCPTreeModel:
             # cross-queue join costs ~10 us and the big levels are throughput-bound anyway (tools/fwd_tree_phase.py: level 6 323 us
             # with the side lane, 329 us in line).  Instead the merge of level l + 1, which needs nothing but the hidden states of
             # level l, shares the launch of level l's `out` Linear while both are in the small-M regime (gcpx_gemm_group).
-            side = []
+            merge_with_predictors = not has_z and not sample_prior and hp.tree_lstm != "sum"
             if has_z:
                 # given latents in depth-first order (tree.py:38); reparametrised with the learned prior (:79-82)
                 g = (_addr(tin["z"], (s - 1) * nv), N * nv, 2 * s * nv) + z_map
@@ -1093,7 +1110,11 @@ class GCPTreeModel:
                 g = (_addr(tin["eps"], (n - 1) * nv), N * nv, nv) + z_map
                 self._mlp(plan, f"posterior{l}", W["q"], [el(), er(), et], M, n, out=_addr(QZ, nodeoff(2 * nv)),
                           ob=PS * 2 * nv, orow=2 * s * 2 * nv, gauss=g, group=pq)
-                self._mlp_group(plan, f"prior+posterior{l}", pq)
+                # the merge of this level's parent states needs level l - 1 only, like the two Predictors: same launch
+                mg = []
+                if l > 0 and merge_with_predictors:
+                    plan_merge(l, group=mg)
+                self._mlp_group(plan, f"prior+posterior{l}", pq, gemm=(mg[0] if mg else None))
             zs = lambda: self._rowsrc(z_map[0], z_map[1], z_map[2], nv)
             if l == 0:
                 if hp.lstm_init == "zero":
@@ -1127,9 +1148,9 @@ class GCPTreeModel:
             g = []
             self._gemm(plan, f"out{l}", [self._rowsrc(x.data_ptr(), n * H, H, H)], M, nz, n, W["out.w"], W["out.b"],
                        out=_addr(E, nodeoff(nz)), ob=PS * nz, orow=2 * s * nz, group=g)
-            if l + 1 < L:
+            if l + 1 < L and not merge_with_predictors:
                 plan_merge(l + 1, group=g)
-            self._gemm_group(plan, f"out{l}+merge{l + 1}" if l + 1 < L else f"out{l}", g)
+            self._gemm_group(plan, f"out{l}+merge{l + 1}" if len(g) > 1 else f"out{l}", g)
 
         # ---- latent-space heads: independent of the decoder, run next to it on lane 1 ----
         F = B * N

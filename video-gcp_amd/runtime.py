@@ -30,7 +30,8 @@ class ConvArgs(C.Structure):
                 ("head_mode", i32), ("wpk", vp), ("bias", vp), ("out", vp), ("images", vp), ("stats_partial", vp),
                 ("raw_row_map", vp), ("src_row_map", vp), ("src_row_frames", vp), ("n_src_rows", i32), ("w_split_log2", i32), ("wpk_split", vp), ("w_split_log2_dev", vp),
                 ("split_layout", i32), ("nll_rows", i32), ("nll_target", vp), ("nll_partial", vp), ("nll_row_weight", vp),
-                ("nll_scale", C.c_float), ("_pad3", i32), ("images_rows", vp), ("images_rows_dup", i64)]
+                ("nll_scale", C.c_float), ("_pad3", i32), ("images_rows", vp), ("images_rows_dup", i64), ("bwd_r", vp), ("bwd_scale", vp), ("bwd_shift", vp), ("bwd_mean", vp),
+                ("bwd_rstd", vp)]
 
 
 class LossArgs(C.Structure):
@@ -84,7 +85,7 @@ class WgradArgs(C.Structure):
                 ("K", i32), ("mode", i32), ("Cin", i32), ("H", i32), ("W", i32), ("rpb", i32), ("shift", i32),
                 ("act", i32), ("cmod", i32), ("k_off", i32), ("accumulate", i32), ("partial", i32), ("nsplit", i32),
                 ("dy_rpb", i32), ("nbatch", i32), ("dbias", vp), ("dbias2", vp), ("z_dy_off", i64), ("z_x_off", i64),
-                ("z_out_off", i64), ("z_bias_off", i64)]
+                ("z_out_off", i64), ("z_bias_off", i64), ("split_f16", i32), ("_pad_split", i32)]
 
 
 class LstmBwdArgs(C.Structure):
@@ -184,6 +185,8 @@ SYMBOLS = [
     ("gcpx_gemm_group", C.c_int, [vp, vp, i32, i32, vp]),
     ("gcpx_mlp_group_dims", C.c_int, [vp, i32, vp, vp]),
     ("gcpx_mlp_group", C.c_int, [vp, vp, i32, i32, i32, vp]),
+    ("gcpx_mlp_group_gemm_supported", C.c_int, [C.POINTER(GemmArgs), i32, i32]),
+    ("gcpx_mlp_group_gemm", C.c_int, [vp, vp, i32, i32, i32, C.POINTER(GemmArgs), vp]),
     ("gcpx_loss_aux_heads_bwd", C.c_int, [C.POINTER(LossArgs), vp, vp, vp]),
     ("gcpx_aux_sample_indices", C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     ("gcpx_aux_sample_indices_gauss", C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
@@ -214,6 +217,7 @@ SYMBOLS = [
     ("gcpx_graph_destroy", C.c_int, [vp]),
     ("gcpx_stream_create", C.c_int, [C.POINTER(vp)]),
     ("gcpx_stream_create_priority", C.c_int, [C.POINTER(vp), C.c_int]),
+    ("gcpx_stream_create_cumask", C.c_int, [C.POINTER(vp), vp, i32]),
     ("gcpx_stream_destroy", C.c_int, [vp]),
     ("gcpx_stream_wait_event", C.c_int, [vp, vp]),
     ("gcpx_event_create", C.c_int, [C.POINTER(vp)]),

@@ -68,6 +68,8 @@ class GCPTrainStep:
         self.wgroup_min_blocks = int(os.environ.get("GCPX_WGROUP_MIN", "256"))
         self.fused_image_wgrad = os.environ.get("GCPX_IMAGE_WGRAD_UNFUSED") is None
         self.split_wgrad = os.environ.get("GCPX_WGRAD_NOSPLIT") is None     # decoder conv weight gradients on the split-f16 kernel
+        self.fuse_head_act = os.environ.get("GCPX_NO_HEAD_ACT_FUSION") is None     # activation backward of the last decoder block in the head's data gradient
+        self.split_wgrad_rows = os.environ.get("GCPX_WGRAD_ROWS_NOSPLIT") is None   # the tree's Linear / LSTM weight gradients (>= 256 rows) likewise
         self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
         self.fused_mlp_bwd = os.environ.get("GCPX_NO_FUSED_MLP_BWD") is None
         # the decoder's weight gradients (5 ms of throughput-bound kernels) are forked after the decoder's data-gradient chain: they then
@@ -80,7 +82,9 @@ class GCPTrainStep:
         # (>= L: right after the decoder, the old behaviour).  Default L - 1: with the split-f16 weight gradients (3.4 instead of 7 ms of
         # side-lane kernels) holding them past the largest level only is best — same-box, c2: 16.8-17.2 ms / step against 17.3-17.4 (L - 2)
         # and 17.2-17.5 (L); c5: 22.0 against 22.4 / 22.3.
-        self.dec_side_level = int(os.environ.get("GCPX_DEC_SIDE_LEVEL", str(hp.hierarchy_levels - 1)))
+        # Round 3 (the tree's own weight gradients on the split-f16 kernel, 1.6 -> 1.2 ms of side-lane kernels per step): three runs each
+        # on one box, c2: 15.36 ms (L - 1), 15.14 (L - 3), 15.12 (L - 4) — L - 3.
+        self.dec_side_level = int(os.environ.get("GCPX_DEC_SIDE_LEVEL", str(max(0, hp.hierarchy_levels - 3))))
         self.group_wgrads = os.environ.get("GCPX_NO_WGROUP") is None   # one grouped launch per level and kernel variant
         self.side_lanes = bool(hp.untied_layers)   # tied levels accumulate into the same weights: keep them on one lane
         self.wgrad_waves = 8192               # wavefronts a split weight-gradient launch aims for (latency hiding)
@@ -339,6 +343,11 @@ class GCPTrainStep:
         a.Cin, a.H, a.W, a.dy_rpb, a.dy_sb = Cin, H, W, dy_rpb, dy_sb
         waves = ((K + 63) // 64) * ((N + 63) // 64 if N > 16 else 1)
         nsplit = max(1, min(self.wgrad_waves // waves, R // 256, 512))
+        # plain row problems of whole 128 x 128 blocks with enough rows: the split-f16 kernel (csrc/wgrad_rows_split.hip; one workgroup per
+        # block walks all rows, no row split, direct output) unless the model runs on the exact f32 kernels
+        if (m.split_f16 and self.split_wgrad_rows and mode == rt.WG_ROWS and rowidx is None and scale is None and not act and shift == 0 and
+                R >= 256 and N % 128 == 0 and K % 128 == 0 and n_valid == N and wmap == rt.WMAP_LINEAR and ldw % 4 == 0 and k_off % 4 == 0):
+            a.split_f16, nsplit = 1, 1
         if batch is not None:
             nsplit = 1
             a.nbatch, a.z_dy_off, a.z_x_off, a.z_out_off, a.z_bias_off = batch
@@ -403,20 +412,25 @@ class GCPTrainStep:
     def _dense(self, ptr, ld, width, M):
         return self.m._rowsrc(ptr, M * ld, ld, width)
 
-    def _bn_bwd(self, plan, tag, bn, da, ldc, c_off, up, r, F, Hh, Ww, add=None):
-        """activation + BatchNorm backward of one conv block: returns the buffer holding d(raw conv output)."""
+    def _bn_bwd(self, plan, tag, bn, da, ldc, c_off, up, r, F, Hh, Ww, add=None, fused=None):
+        """activation + BatchNorm backward of one conv block: returns the buffer holding d(raw conv output).
+        fused = (dy, partial sums [nb][2][C], nb): the data-gradient conv that produced `da` already applied the activation's derivative
+        and left the statistics (gcpx_conv_args.bwd_r): only the BatchNorm half remains, in place."""
         m, lib, hp = self.m, self.m.lib, self.m._hp
         Cc = bn["C"]
-        dy = m._buf(f"bw.dy:{tag}", (F, Hh, Ww, Cc))
-        nb = lib.gcpx_act_bwd_blocks()
-        st = m._buf(f"bw.st:{tag}", (nb, 2, Cc))
-        a = rt.ActBwdArgs()
-        a.da, a.add, a.r = da, (add.data_ptr() if add is not None else None), r.data_ptr()
-        a.scale, a.shift, a.mean, a.rstd = bn["scale"].data_ptr(), bn["shift"].data_ptr(), bn["mean"].data_ptr(), bn["rstd"].data_ptr()
-        a.dy, a.stats_partial, a.ldc, a.c_off, a.up, a.fsum, a.act = dy.data_ptr(), st.data_ptr(), ldc, c_off, up, 1, rt.ACT_LRELU
-        a.F, a.H, a.W, a.C = F, Hh, Ww, Cc
-        plan.keep.append(a)
-        plan.add(f"bw.act:{tag}", lib.gcpx_act_bwd, C.byref(a))
+        if fused is not None:
+            dy, st, nb = fused
+        else:
+            dy = m._buf(f"bw.dy:{tag}", (F, Hh, Ww, Cc))
+            nb = lib.gcpx_act_bwd_blocks()
+            st = m._buf(f"bw.st:{tag}", (nb, 2, Cc))
+            a = rt.ActBwdArgs()
+            a.da, a.add, a.r = da, (add.data_ptr() if add is not None else None), r.data_ptr()
+            a.scale, a.shift, a.mean, a.rstd = bn["scale"].data_ptr(), bn["shift"].data_ptr(), bn["mean"].data_ptr(), bn["rstd"].data_ptr()
+            a.dy, a.stats_partial, a.ldc, a.c_off, a.up, a.fsum, a.act = dy.data_ptr(), st.data_ptr(), ldc, c_off, up, 1, rt.ACT_LRELU
+            a.F, a.H, a.W, a.C = F, Hh, Ww, Cc
+            plan.keep.append(a)
+            plan.add(f"bw.act:{tag}", lib.gcpx_act_bwd, C.byref(a))
         coef = m._buf(f"bw.coef:{tag}", (3, Cc))
         pre = bn["prefix"]
         plan.add(f"bw.bnfin:{tag}", lib.gcpx_bn_bwd_finalize, st.data_ptr(), nb, Cc, C.c_double(float(F * Hh * Ww)),
@@ -868,6 +882,20 @@ class GCPTrainStep:
             plan.add("bw.row2frame", lib.gcpx_index_inverse, o["node2row"].data_ptr(), F, row2frame.data_ptr(), B * T)
             a.src_row_frames, a.n_src_rows = row2frame.data_ptr(), B * T
         m._set_split(a, "bw.dec.head")
+        # the head's data gradient is the gradient of the last block's BatchNorm + LeakyReLU output: the split-f16 kernel applies the
+        # activation's derivative and sums the BatchNorm statistics in its epilogue (gcpx_conv_args.bwd_r) — gcpx_act_bwd's pass over
+        # 2 x 533 MB (c2) on the critical lane is gone
+        head_fused = None
+        last = dec["blocks"][-1]
+        if self.fuse_head_act and bool(a.wpk_split) and ngf == 16 and last["cout"] == 16 and pitch // 16 >= 2:
+            bn_l = rec[f"bn:dec.bn.{last['name']}"]
+            nb_h = lib.gcpx_conv_grid() // 2
+            st_h = buf("bw.st:dec.head_fused", (nb_h, 2, 16))
+            a.bwd_r = last["out"].data_ptr()
+            a.bwd_scale, a.bwd_shift = bn_l["scale"].data_ptr(), bn_l["shift"].data_ptr()
+            a.bwd_mean, a.bwd_rstd = bn_l["mean"].data_ptr(), bn_l["rstd"].data_ptr()
+            a.stats_partial = st_h.data_ptr()
+            head_fused = (dA, st_h, nb_h)
         plan.keep.append(a)
         plan.add("bw.dgrad:dec.head", lib.gcpx_conv3x3, C.byref(a))
 
@@ -878,7 +906,8 @@ class GCPTrainStep:
             res = 2 * res_in
             cin = c_prev + c_skip
             bn = rec[f"bn:dec.bn.{name}"]
-            dy = self._bn_bwd(plan, f"dec.{name}", bn, gin[0], gin[1], 0, gin[2], blk["out"], F, res, res)
+            dy = self._bn_bwd(plan, f"dec.{name}", bn, gin[0], gin[1], 0, gin[2], blk["out"], F, res, res,
+                              fused=(head_fused if blk is last else None))
             U = buf(f"bw.U.{name}", (F, res, res, cin))
             a = m._conv_args(blk["srcs"], F, res_in, res_in, res, res, cin, cin, self._zeros, self._zeros, U, upsample=1)
             plan.keep.append(a)
