@@ -282,6 +282,122 @@ def test_mlp(env, mid, in_dims, out_dim, M, gauss):
         assert_close(z, want[:, :nz] + torch.exp(want[:, nz:]) * eps, atol=5e-5, rtol=1e-5, name="z")
 
 
+@pytest.mark.parametrize("Mg,Ng,nb", [(32, 512, 6), (64, 512, 6), (128, 512, 6), (256, 512, 2), (64, 128, 1)])
+def test_mlp_group_with_gemm(env, Mg, Ng, nb):
+    """gcpx_mlp_group_gemm (level_pre_kernel): two Predictors and one batched row GEMM as ONE launch — prior + posterior + the
+    split_linear merge of a tree level — equals gcpx_mlp_group followed by gcpx_gemm bit for bit (same workgroup bodies), for every
+    GEMM tiling the tree levels use (split-K single tiles, split-K blocks, one-wavefront blocks)."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(Mg + Ng)
+    mid, n_mid, M = 128, 3, Mg
+    keep = []
+
+    def predictor(in_dims, out_dim, gauss):
+        K = sum(in_dims)
+        Ws = dict(w_in=torch.randn(mid, K) / K ** 0.5, b_in=torch.randn(mid) * 0.1, w_mid=torch.randn(n_mid, mid, mid) / mid ** 0.5,
+                  b_mid=torch.randn(n_mid, mid) * 0.1, g=torch.rand(n_mid, mid) + 0.5, be=torch.randn(n_mid, mid) * 0.1,
+                  w_out=torch.randn(out_dim, mid) / mid ** 0.5, b_out=torch.randn(out_dim) * 0.1)
+        d = {k: v.to(dev) for k, v in dict(
+            w_in=pk.pack_gemm(Ws["w_in"]), b_in=Ws["b_in"], w_mid=torch.stack([pk.pack_gemm(Ws["w_mid"][i]) for i in range(n_mid)]),
+            b_mid=Ws["b_mid"], g=Ws["g"], be=Ws["be"], w_out=pk.pack_gemm(Ws["w_out"]), b_out=Ws["b_out"]).items()}
+        xd = [torch.randn(M, dd, device=dev) for dd in in_dims]
+        outs = [torch.full((M, out_dim), float("nan"), device=dev) for _ in range(2)]
+        zs = [torch.zeros(M, out_dim // 2, device=dev) for _ in range(2)]
+        eps = torch.randn(M, out_dim // 2, device=dev)
+        args = []
+        for o, z in zip(outs, zs):
+            a = rt.MlpArgs()
+            for i, x in enumerate(xd):
+                a.src[i] = _rowsrc(rt, x, 0, in_dims[i], in_dims[i])
+            a.nsrc, a.M, a.rpb, a.in_dim, a.mid, a.n_mid, a.out_dim = len(xd), M, M, K, mid, n_mid, out_dim
+            a.w_in, a.b_in, a.w_mid, a.b_mid = d["w_in"].data_ptr(), d["b_in"].data_ptr(), d["w_mid"].data_ptr(), d["b_mid"].data_ptr()
+            a.gn_gamma, a.gn_beta, a.w_out, a.b_out = d["g"].data_ptr(), d["be"].data_ptr(), d["w_out"].data_ptr(), d["b_out"].data_ptr()
+            a.gn_eps, a.lrelu_slope = 1e-5, 0.2
+            a.out, a.ob, a.orow = o.data_ptr(), 0, out_dim
+            if gauss:
+                a.epi, a.eps, a.eb, a.erow, a.z, a.zb, a.zrow = rt.MLP_GAUSS, eps.data_ptr(), 0, out_dim // 2, z.data_ptr(), 0, out_dim // 2
+            args.append(a)
+        keep.extend([d, xd, eps])
+        return args, outs, zs
+
+    pa, pouts, _ = predictor((128, 128), 512, False)
+    qa, qouts, qz = predictor((128, 128, 128), 512, True)
+    Kg = 1024
+    xg = torch.randn(nb, Mg, Kg, device=dev)
+    wg = torch.randn(nb, Ng, Kg) / Kg ** 0.5
+    wpg = torch.stack([pk.pack_gemm(wg[i]) for i in range(nb)]).contiguous().to(dev)
+    bg = torch.randn(nb, Ng, device=dev)
+    gouts = [torch.full((nb, Mg, Ng), float("nan"), device=dev) for _ in range(2)]
+    gargs = []
+    for o in gouts:
+        g = rt.GemmArgs()
+        g.src[0] = _rowsrc(rt, xg, 0, Kg, Kg)
+        g.nsrc, g.M, g.N, g.K, g.rpb = 1, Mg, Ng, Kg, Mg
+        g.wpk, g.bias, g.out, g.ob, g.orow = wpg.data_ptr(), bg.data_ptr(), o.data_ptr(), 0, Ng
+        if nb > 1:
+            g.nbatch, g.z_src_off, g.z_w_off, g.z_bias_off, g.z_out_off = nb, Mg * Kg, Ng * Kg, Ng, Mg * Ng
+        gargs.append(g)
+
+    def group(i):
+        tab = (rt.MlpArgs * 2)(pa[i], qa[i])
+        dims = (C.c_int32 * 8)()
+        total = C.c_int32()
+        rt.check(lib.gcpx_mlp_group_dims(tab, 2, dims, C.byref(total)), "dims")
+        raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
+        dd = torch.tensor(list(dims), dtype=torch.int32, device=dev)
+        keep.extend([raw, dd, tab])
+        return raw, dd, total.value
+
+    raw, dd, total = group(0)
+    rt.check(lib.gcpx_mlp_group(raw.data_ptr(), dd.data_ptr(), 2, total, mid, _stream()), "mlp_group")
+    rt.check(lib.gcpx_gemm(C.byref(gargs[0]), _stream()), "gemm")
+    raw, dd, total = group(1)
+    assert lib.gcpx_mlp_group_gemm_supported(C.byref(gargs[1]), total, mid) == 1
+    rt.check(lib.gcpx_mlp_group_gemm(raw.data_ptr(), dd.data_ptr(), 2, total, mid, C.byref(gargs[1]), _stream()), "mlp_group_gemm")
+    torch.cuda.synchronize()
+    want = torch.einsum("bmk,bnk->bmn", xg.cpu().double(), wg.double()) + bg.cpu().double()[:, None]
+    assert_close(gouts[1], want.float(), atol=3e-5, rtol=2e-5, name="merge GEMM")
+    assert torch.equal(gouts[0], gouts[1]) and torch.equal(pouts[0], pouts[1]) and torch.equal(qouts[0], qouts[1]) and torch.equal(qz[0], qz[1])
+
+
+def test_loss_pre_and_final_equal_the_single_combine(env):
+    """gcpx_loss_pre (KL per sequence + the five terms that need no decoded frame, one launch in front of the decoder) followed by
+    gcpx_loss_final == gcpx_kl_gauss + gcpx_loss_combine (base_gcp.py:264-304): every loss value and the total, bit for bit (the same
+    device functions, the same reduction orders)."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(3)
+    B, T, N, nz, sd_, na = 5, 20, 31, 32, 2, 2
+    q, p_ = torch.randn(B, N, 2 * nz, device=dev) * 0.5, torch.randn(B, N, 2 * nz, device=dev) * 0.5
+    end = torch.randint(2, T, (B,), dtype=torch.int64, device=dev)
+    seq_len = (end + 1).to(torch.int32)
+    pad = (torch.arange(T, device=dev)[None] <= end[:, None]).float()
+    t = dict(nll=torch.rand(B, T, device=dev) * 100, len_logits=torch.randn(B, T, device=dev), exist=torch.randn(B, N, device=dev),
+             leave=torch.randint(0, 2, (B, N), dtype=torch.int32, device=dev), reg=torch.randn(B, T, sd_, device=dev),
+             tgt=torch.randn(B, T, sd_, device=dev), act=torch.randn(B, na, device=dev), acts=torch.randn(B, T - 1, na, device=dev),
+             t0=torch.randint(0, T - 1, (B,), dtype=torch.int64, device=dev), cost=torch.randn(B, device=dev), ctgt=torch.randn(B, device=dev))
+    outs, kls = [], []
+    for mode in ("combine", "pre+final"):
+        out, kl = torch.full((16,), float("nan"), device=dev), torch.full((B,), float("nan"), device=dev)
+        la = rt.LossArgs()
+        la.nll_bt, la.pad_mask, la.kl_b, la.len_logits, la.end_ind = t["nll"].data_ptr(), pad.data_ptr(), kl.data_ptr(), t["len_logits"].data_ptr(), end.data_ptr()
+        la.existence, la.leave, la.regressed_state, la.state_target, la.seq_len = t["exist"].data_ptr(), t["leave"].data_ptr(), t["reg"].data_ptr(), t["tgt"].data_ptr(), seq_len.data_ptr()
+        la.action_pred, la.action_seq, la.inv_t0, la.cost_pred, la.cost_target = t["act"].data_ptr(), t["acts"].data_ptr(), t["t0"].data_ptr(), t["cost"].data_ptr(), t["ctgt"].data_ptr()
+        la.out, la.B, la.T, la.N, la.state_dim, la.n_actions = out.data_ptr(), B, T, N, sd_, na
+        la.w_rec, la.w_kl, la.w_len, la.w_exist, la.w_state, la.w_action, la.w_cost, la.total_div = 1.0, 0.5, 1.0, 1.0, 1.0, 2.0, 1.0, 960.0
+        klargs = (N, nz, N * 2 * nz, 2 * nz, C.c_float(0.1), None, 0, kl.data_ptr())
+        if mode == "combine":
+            rt.check(lib.gcpx_kl_gauss(q.data_ptr(), p_.data_ptr(), B, *klargs, _stream()), "kl")
+            rt.check(lib.gcpx_loss_combine(C.byref(la), _stream()), "combine")
+        else:
+            rt.check(lib.gcpx_loss_pre(C.byref(la), q.data_ptr(), p_.data_ptr(), *klargs, _stream()), "pre")
+            rt.check(lib.gcpx_loss_final(C.byref(la), _stream()), "final")
+        torch.cuda.synchronize()
+        outs.append(out[:9].clone()); kls.append(kl)
+    assert torch.isfinite(outs[0]).all() and bool((outs[0][[0, 1, 2, 3, 4, 7, 8]] != 0).all())
+    assert torch.equal(kls[0], kls[1])
+    assert_close(outs[1], outs[0], atol=0, rtol=2e-6, name="loss values")     # (block sums over 256 vs 1024 threads: a different tree)
+
+
 def _conv_args(rt, srcs, **kw):
     a = rt.ConvArgs()
     a._keep = (srcs, kw)          # device tensors must outlive the launch (the struct only holds raw pointers)
@@ -391,6 +507,26 @@ def test_conv3x3_head_dlm(env, S, Fr, split):
     rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head mean")
     torch.cuda.synchronize()
     assert torch.equal(img2, img)
+    if split:
+        # images_rows: frames with a row-map entry are stored at that row of a second array (and of a copy of it) as well; rows no
+        # frame maps to stay as they were
+        rmap = torch.full((Fr,), -1, dtype=torch.int32)
+        rows = [f for f in range(Fr) if f % 2 == 0]
+        for i, f in enumerate(reversed(rows)):
+            rmap[f] = i
+        R = len(rows) + 2
+        rows_img = torch.full((2, R, 3, S, S), 7.0, device=dev)
+        rmd = rmap.to(dev)
+        a.raw_row_map, a.images_rows, a.images_rows_dup = rmd.data_ptr(), rows_img.data_ptr(), rows_img[0].numel()
+        img3 = torch.full((Fr, 3, S, S), float("nan"), device=dev)
+        a.images = img3.data_ptr()
+        rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head mean + rows")
+        torch.cuda.synchronize()
+        assert torch.equal(img3, img)
+        for f in range(Fr):
+            if rmap[f] >= 0:
+                assert torch.equal(rows_img[0, rmap[f]], img[f]) and torch.equal(rows_img[1, rmap[f]], img[f])
+        assert bool((rows_img[:, len(rows):] == 7.0).all())
 
 
 @pytest.mark.parametrize("case", ["plain", "edges"])
