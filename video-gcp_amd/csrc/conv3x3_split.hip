@@ -1859,7 +1859,9 @@ int gcpx_launch_wave_split(const gcpx_conv_args* a, hipStream_t stream, int ct, 
     const int nchunk = a->Cin / 16;
     if (ct == 1) {
         if (WaveSplitCfg<1>::lds_bytes(nchunk) > 160 * 1024) return -1;
-        if (a->bwd_r) return depth == 2 ? launch_wave_split_t<1, 2, true>(a, stream) : launch_wave_split_t<1, 1, true>(a, stream);
+        // (one register set in the prefetch pipeline: with two, the epilogue's extra values spill — 1107 against 1083 us for the head's
+        // data gradient at c2)
+        if (a->bwd_r) return launch_wave_split_t<1, 1, true>(a, stream);
         return depth == 2 ? launch_wave_split_t<1, 2>(a, stream) : launch_wave_split_t<1, 1>(a, stream);
     }
     if (WaveSplitCfg<2>::lds_bytes(nchunk) > 160 * 1024) return -1;
