@@ -68,6 +68,9 @@ class GCPTrainStep:
         self.wgroup_min_blocks = int(os.environ.get("GCPX_WGROUP_MIN", "256"))
         self.fused_image_wgrad = os.environ.get("GCPX_IMAGE_WGRAD_UNFUSED") is None
         self.split_wgrad = os.environ.get("GCPX_WGRAD_NOSPLIT") is None     # decoder conv weight gradients on the split-f16 kernel
+        # the I_0 / I_g encoder backward chains on the side lanes beside the trajectory pass's: the backward's tail gets 0.15 ms shorter in
+        # tools/train_phase_times.py, the step does not (8 same-box pairs, c2: 14.94 ms with, 14.64 without) — off
+        self.parallel_encoder_passes = os.environ.get("GCPX_PARALLEL_ENCODER_BWD") is not None
         self.fuse_head_act = os.environ.get("GCPX_NO_HEAD_ACT_FUSION") is None     # activation backward of the last decoder block in the head's data gradient
         self.split_wgrad_rows = os.environ.get("GCPX_WGRAD_ROWS_NOSPLIT") is None   # the tree's Linear / LSTM weight gradients (>= 256 rows) likewise
         self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
@@ -412,7 +415,7 @@ class GCPTrainStep:
     def _dense(self, ptr, ld, width, M):
         return self.m._rowsrc(ptr, M * ld, ld, width)
 
-    def _bn_bwd(self, plan, tag, bn, da, ldc, c_off, up, r, F, Hh, Ww, add=None, fused=None):
+    def _bn_bwd(self, plan, tag, bn, da, ldc, c_off, up, r, F, Hh, Ww, add=None, fused=None, defer_affine=False):
         """activation + BatchNorm backward of one conv block: returns the buffer holding d(raw conv output).
         fused = (dy, partial sums [nb][2][C], nb): the data-gradient conv that produced `da` already applied the activation's derivative
         and left the statistics (gcpx_conv_args.bwd_r): only the BatchNorm half remains, in place."""
@@ -433,9 +436,18 @@ class GCPTrainStep:
             plan.add(f"bw.act:{tag}", lib.gcpx_act_bwd, C.byref(a))
         coef = m._buf(f"bw.coef:{tag}", (3, Cc))
         pre = bn["prefix"]
-        plan.add(f"bw.bnfin:{tag}", lib.gcpx_bn_bwd_finalize, st.data_ptr(), nb, Cc, C.c_double(float(F * Hh * Ww)),
-                 m.sd[f"{pre}.weight"].data_ptr(), bn["rstd"].data_ptr(), coef.data_ptr(), self.g(f"{pre}.weight"),
-                 self.g(f"{pre}.bias"), 1)
+        if defer_affine:
+            # this chain runs beside other chains that accumulate into the same d gamma / d beta (the three encoder passes): the sums go
+            # to a scratch pair and are added with the pass's weight gradients, in order on one lane
+            dgb = m._buf(f"bw.dgb:{tag}", (2, Cc))
+            plan.add(f"bw.bnfin:{tag}", lib.gcpx_bn_bwd_finalize, st.data_ptr(), nb, Cc, C.c_double(float(F * Hh * Ww)),
+                     m.sd[f"{pre}.weight"].data_ptr(), bn["rstd"].data_ptr(), coef.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), 0)
+            self._side(plan, f"bw.bnacc:{tag}.g", lib.gcpx_reduce_partials, dgb[0].data_ptr(), 1, Cc, Cc, self.g(f"{pre}.weight"), 1)
+            self._side(plan, f"bw.bnacc:{tag}.b", lib.gcpx_reduce_partials, dgb[1].data_ptr(), 1, Cc, Cc, self.g(f"{pre}.bias"), 1)
+        else:
+            plan.add(f"bw.bnfin:{tag}", lib.gcpx_bn_bwd_finalize, st.data_ptr(), nb, Cc, C.c_double(float(F * Hh * Ww)),
+                     m.sd[f"{pre}.weight"].data_ptr(), bn["rstd"].data_ptr(), coef.data_ptr(), self.g(f"{pre}.weight"),
+                     self.g(f"{pre}.bias"), 1)
         plan.add(f"bw.bnapply:{tag}", lib.gcpx_bn_bwd_apply, dy.data_ptr(), r.data_ptr(), bn["mean"].data_ptr(),
                  bn["rstd"].data_ptr(), coef.data_ptr(), F * Hh * Ww * Cc, Cc)
         return dy
@@ -807,16 +819,39 @@ class GCPTrainStep:
         if attentive:
             plan.add("bw.addrows.kenc", lib.gcpx_add_rows, d_enc_traj.data_ptr(), T * nz, nz, d_enc_key.data_ptr(), None, B, T, nz)
         self._flush(plan)
-        self._encoder_backward(plan, fplan, "traj", d_enc_traj.data_ptr(), nz, 0, 0, {})
-        self._flush(plan)
-        self._encoder_backward(plan, fplan, "I0", _addr(dE), nz, 1, PS * nz, dskip)
-        self._encoder_backward(plan, fplan, "Ig", _addr(dE, 2 ** L * nz), nz, 1, PS * nz, {})
-        self._flush(plan, one_lane=True)      # same parameters as the trajectory pass: one lane, behind it
+        self._three_encoder_passes(plan, fplan, lambda: self._encoder_backward(plan, fplan, "traj", d_enc_traj.data_ptr(), nz, 0, 0, {}),
+                                   lambda: self._encoder_backward(plan, fplan, "I0", _addr(dE), nz, 1, PS * nz, dskip),
+                                   lambda: self._encoder_backward(plan, fplan, "Ig", _addr(dE, 2 ** L * nz), nz, 1, PS * nz, {}))
         if self.side_lanes:
             plan.join(list(range(1, 1 + self.n_side)))
         plan.outs = dict(dE=dE, dHid=dHid, dET=dET, dQZ=dQZ, dPZ=dPZ, dMD=dMD, d_inf=d_inf, d_enc_traj=d_enc_traj, dE_dec=dE_dec,
                          dE_ex=(None if adaptive else dE_ex), dlen=dlen, dexist=dexist, dstate=dstate)
         return plan
+
+    def _three_encoder_passes(self, plan, fplan, traj, i0, ig):
+        """The backward chains of the three encoder passes (trajectory frames, I_0, I_g: base_gcp.py:188,208,209) are independent — each a
+        chain of ~15 small launches, 0.7 / 0.3 / 0.3 ms at c2 — so the two image passes run on the side lanes beside the trajectory pass
+        instead of behind it.  Their weight gradients ACCUMULATE into the same parameters: the trajectory pass's go out first (over the
+        lanes, one layer per tag), the image passes' behind them on one lane."""
+        if not (self.side_lanes and self.n_side >= 2 and self.parallel_encoder_passes):
+            traj()
+            self._flush(plan)
+            i0()
+            ig()
+            self._flush(plan, one_lane=True)      # same parameters as the trajectory pass: one lane, behind it
+            return
+        assert not plan.deferred
+        plan.fork([1, 2])
+        plan.lane = 1
+        i0()
+        plan.lane = 2
+        ig()
+        plan.lane = 0
+        late, plan.deferred = plan.deferred, []
+        traj()
+        self._flush(plan)
+        plan.deferred = late
+        self._flush(plan, one_lane=True)
 
     def _tree_accum(self, plan, tag, dst, dst_sb, slot_stride, B, n, width, srcs):
         a = rt.TreeAccumArgs()
@@ -1047,7 +1082,8 @@ class GCPTrainStep:
             name, cin, cout, _ = layers[li]
             r = er["r"][li]
             bn = rec[f"bn:{tag}.bn{li}"]
-            dy = self._bn_bwd(plan, f"{tag}.{name}", bn, dA.data_ptr(), cout, 0, 0, r, F, res, res, add=dskip.get(li))
+            dy = self._bn_bwd(plan, f"{tag}.{name}", bn, dA.data_ptr(), cout, 0, 0, r, F, res, res, add=dskip.get(li),
+                              defer_affine=(self.side_lanes and self.n_side >= 2 and self.parallel_encoder_passes))
             if li == 1:
                 x, sc, sh, act = er["a0"], None, None, rt.ACT_NONE
             else:

@@ -251,11 +251,10 @@ class SequentialTrainStep(GCPTrainStep):
             c0 = in_dim[net] - 2 * nz                         # columns of e_0 / e_g in the embedding input
             self._rows(plan, f"bw.{net}.de0", DX.data_ptr(), T * nz, 0, _addr(dIn[net], c0), (T - 1) * in_dim[net], in_dim[net], B, T - 1, nz, 2)
             self._rows(plan, f"bw.{net}.deg", dEG.data_ptr(), nz, 0, _addr(dIn[net], c0 + nz), (T - 1) * in_dim[net], in_dim[net], B, T - 1, nz, 2)
-        self._encoder_backward(plan, fplan, "traj", d_enc_traj.data_ptr(), nz, 0, 0, {})
         self._flush(plan)
-        self._encoder_backward(plan, fplan, "I0", _addr(DX), nz, 1, T * nz, dskip)
-        self._encoder_backward(plan, fplan, "Ig", _addr(dEG), nz, 1, nz, {})
-        self._flush(plan, one_lane=True)
+        self._three_encoder_passes(plan, fplan, lambda: self._encoder_backward(plan, fplan, "traj", d_enc_traj.data_ptr(), nz, 0, 0, {}),
+                                   lambda: self._encoder_backward(plan, fplan, "I0", _addr(DX), nz, 1, T * nz, dskip),
+                                   lambda: self._encoder_backward(plan, fplan, "Ig", _addr(dEG), nz, 1, nz, {}))
         plan.join(list(range(1, 1 + self.n_side)))
         plan.outs = dict(DX=DX, dEG=dEG, dQZ=dQZ, dPZ=dPZ, DQ=DQ, dIn=dIn, dE_dec=dE_dec, d_enc_traj=d_enc_traj)
         return plan
