@@ -499,6 +499,13 @@ int gcpx_wgrad_conv3x3(const float* dy, int32_t ldy, const float* u, int32_t F, 
    cover run on gcpx_wgrad_conv3x3. */
 int gcpx_wgrad_conv3x3_split(const float* dy, int32_t ldy, const float* u, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                              float* partial, int32_t grid, void* stream);
+/* The same for an UPSAMPLING block with 16 output channels, reading the block's own low-resolution sources: `a` is the block's forward
+   descriptor as gcpx_conv_stage takes it (src / nsrc / F / Hin / Win / Hout / Wout / Cin, upsample = 1, no src_row_map); the kernel forms
+   the bilinear x2 of the concatenated, normalised + activated sources per tile, so the operand tensor gcpx_conv_stage would write
+   (additional_conv_layer at c2: 1.07 GB per step, read back by the weight gradient) never exists.  GCPX_ERR_UNSUPPORTED (nothing
+   launched) when the shape has no fused form: Cout <= 16, Cin % 32 == 0, source widths % 16 == 0, W in {8, 16, 32 k}. */
+int gcpx_wgrad_conv3x3_split_up(const float* dy, int32_t ldy, const gcpx_conv_args* a, int32_t Cout, float* partial, int32_t grid,
+                                void* stream);
 /* bias gradient: dst[n] (+)= sum_r dy[r][n] (rows addressed like gcpx_wgrad_args.dy); dst2 = optional second destination
    (LSTM b_ih and b_hh); with nsplit > 1 the row range is split and partial [nsplit][N] is written instead of dst */
 int gcpx_colsum(const float* dy, int64_t ldy, int32_t R, int32_t N, int32_t dy_rpb, int64_t dy_sb, int32_t nsplit, float* partial,

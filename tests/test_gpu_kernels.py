@@ -1411,6 +1411,47 @@ def test_conv_stage(env, Hin, c_prev, c_skip, Fr, nodes, up):
         assert_close(out.permute(0, 3, 1, 2), w2, atol=2e-6, rtol=1e-6, name="conv_stage mapped")
 
 
+@pytest.mark.parametrize("Hin,c_prev,c_skip,Fr,nodes", [(32, 16, 16, 6, 3), (16, 32, 0, 5, 1), (8, 32, 0, 7, 1), (4, 16, 16, 8, 2)])
+@pytest.mark.parametrize("case", ["plain", "tiny"])
+def test_wgrad_conv3x3_split_up_reads_the_blocks_sources(env, Hin, c_prev, c_skip, Fr, nodes, case):
+    """gcpx_wgrad_conv3x3_split_up: weight gradient of a 16-output-channel upsampling block that forms its operand (bilinear x2 of the
+    concatenated, normalised + activated low-resolution sources; skip source shared by `nodes` frames) inside the kernel — against
+    float64 on torch's own interpolation, and against gcpx_conv_stage + gcpx_wgrad_conv3x3_split on the same data (the path it
+    replaces: same operand values, same scales, same sums).  Every tile shape (W = 64 / 32 / 16 / 8)."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(Hin + c_prev + c_skip)
+    Cout, S = 16, 2 * Hin
+    x = torch.randn(Fr, c_prev, Hin, Hin)
+    sc, sh = torch.rand(c_prev) + 0.5, torch.randn(c_prev) * 0.2
+    ref = [F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)]
+    srcs = [(x.permute(0, 2, 3, 1).contiguous().to(dev), c_prev, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)]
+    if c_skip:
+        sk = torch.randn(Fr // nodes, c_skip, Hin, Hin)
+        ref.append(sk.repeat_interleave(nodes, 0))
+        srcs.append((sk.permute(0, 2, 3, 1).contiguous().to(dev), c_skip, nodes, None, None, rt.ACT_NONE))
+    cin = c_prev + c_skip
+    U = F.interpolate(torch.cat(ref, 1).double(), scale_factor=2, mode="bilinear", align_corners=False)      # [Fr][cin][S][S]
+    dy = torch.randn(Fr, S, S, Cout, device=dev) * (1e-6 if case == "tiny" else 1.0)
+    up = F.pad(U.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))
+    want = torch.stack([torch.einsum("fhwn,fhwc->nc", dy.cpu().double(), up[:, ky:ky + S, kx:kx + S, :]) for ky in range(3) for kx in range(3)], 1)
+    want = want.reshape(Cout, 9 * cin)
+    grid = max(1, min(96 // (cin // 32), Fr * max(1, S * S // 64)))
+    staged = torch.full((Fr, S, S, cin), float("nan"), device=dev)
+    a = _conv_args(rt, srcs, F=Fr, Hin=Hin, Win=Hin, Hout=S, Wout=S, Cout=cin, out_pitch=cin, upsample=1, out=staged)
+    rt.check(lib.gcpx_conv_stage(C.byref(a), _stream()), "conv_stage")
+    p_ref = torch.full((grid, Cout, 9 * cin), float("nan"), device=dev)
+    rt.check(lib.gcpx_wgrad_conv3x3_split(dy.data_ptr(), Cout, staged.data_ptr(), Fr, S, S, cin, Cout, p_ref.data_ptr(), grid, _stream()), "staged")
+    p_up = torch.full((grid, Cout, 9 * cin), float("nan"), device=dev)
+    a.out = None
+    rt.check(lib.gcpx_wgrad_conv3x3_split_up(dy.data_ptr(), Cout, C.byref(a), Cout, p_up.data_ptr(), grid, _stream()), "fused")
+    torch.cuda.synchronize()
+    assert torch.isfinite(p_up).all()
+    got, ref_ = p_up.double().sum(0).cpu(), p_ref.double().sum(0).cpu()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2.0 * float((ref_ - want).abs().max()) + 4e-7 * scale
+    assert_close(got.float(), ref_.float(), atol=2e-6 * scale, rtol=0, name="fused vs staged")
+
+
 def test_split_pack_group_equals_single_launches(env):
     """gcpx_split_pack_group (all split-f16 weight tensors re-split in one launch, one workgroup per tensor) writes bit for bit what one
     gcpx_split_pack launch per tensor writes: tensors of different sizes and magnitudes, one of them all zero."""

@@ -316,6 +316,262 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_kernel(const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same weight gradient for an UPSAMPLING block with 16 output channels, reading the block's own sources: U[p][ci] = bilinear x2
+// (align_corners = False) of the concatenated, normalised + activated low-resolution sources, formed in the kernel instead of being
+// materialised by gcpx_conv_stage (additional_conv_layer at c2: 1.07 GB written by the stage kernel and read back here, per step).
+// Per tile the workgroup first stages the LOW-resolution source region (TH/2 + 2 rows x TW/2 + 2 columns x 32 channels, border
+// pixels replicated = the clamped indices of the interpolation; affine + LeakyReLU applied once per source value) as f32 in LDS; every
+// thread then blends its region pixels of the operand from four LDS reads (weights 9/16, 3/16, 3/16, 1/16), and the rest — maxima,
+// scales, split, planes, MFMA phase — is the kernel above with NT = 1, CIT = 2.
+struct WsUpSrc {
+    const float *p0, *sc0, *sh0, *p1, *sc1, *sh1;      // sources [F / fdiv][Hs][Ws][C], per-channel affine (or NULL)
+    int C0, C1, fdiv0, fdiv1, act0, act1;
+};
+
+template <int TW>
+__global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_up_kernel(const float* __restrict__ dy, const WsUpSrc us, float* __restrict__ partial,
+                                                                        const int F, const int H, const int W, const int Cin, const int ldy) {
+    constexpr int NT = 1, CIT = 2;
+    using Cfg = WSCfg<NT, CIT, TW>;
+    constexpr int NW = Cfg::NW, N = Cfg::N, CC = Cfg::CC, TH = Cfg::TH, RH = Cfg::RH, RW = Cfg::RW, RPX = Cfg::RPX;
+    constexpr int PA = Cfg::PA, PB = Cfg::PB, G = Cfg::G, GPW = Cfg::GPW, NDS = Cfg::NDS, UPS = Cfg::UPS, NUS = Cfg::NUS;
+    constexpr int SRH = TH / 2 + 2, SRW = TW / 2 + 2, SPX = SRH * SRW, NSRC = (SPX + 31) / 32;
+    extern __shared__ float4 smem4[];
+    _Float16* sA = reinterpret_cast<_Float16*>(smem4);                     // [2][NT][PA]
+    _Float16* sB = sA + Cfg::A_HALFS;                                      // [2][CIT][PB]
+    float* red = reinterpret_cast<float*>(sB + Cfg::B_HALFS);              // [NW][2] tile maxima
+    float4* sS = reinterpret_cast<float4*>(red + 16);                      // [SPX][8] source region (f32, 32 channels)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ij = lane & 15, kq = lane >> 4;
+    const int wrot = __builtin_amdgcn_readfirstlane((wave + (int)blockIdx.x) & 3);
+    const int ci0 = blockIdx.y * CC;
+    const int ntx = W / TW, nty = H / TH;
+    const int ntiles = F * nty * ntx;
+    const int Hs = H / 2, Ws = W / 2;
+
+    constexpr int NACC = GPW * NT;
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0, 0, 0, 0};
+
+    // dY staging slots as above; source slots: thread (sp_s = tid >> 3, sc8 = tid & 7) moves float4 sc8 (of the 32 channels) of region
+    // pixels sp_s + 32 k
+    const int sp = tid >> 2, sc4 = tid & 3;
+    const unsigned dgoff0 = (unsigned)((((sp / TW) * W + (sp % TW)) * ldy + 4 * sc4) * 4);
+    const int dloff0 = sp * 16 + 4 * sc4;
+    const int sp_s = tid >> 3, sc8 = tid & 7;
+    const int cg = ci0 + 4 * sc8;                                          // this thread's source channels
+    const bool first = cg < us.C0;
+    const float* sbase = first ? us.p0 : us.p1;
+    const int sC = first ? us.C0 : us.C1, cl = first ? cg : cg - us.C0, fdiv = first ? us.fdiv0 : us.fdiv1;
+    const float* scp = first ? us.sc0 : us.sc1;
+    const float* shp = first ? us.sh0 : us.sh1;
+    const bool aff = scp != nullptr, lre = (first ? us.act0 : us.act1) == GCPX_ACT_LRELU;
+    float4 a_sc = make_float4(1.f, 1.f, 1.f, 1.f), a_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (aff) { a_sc = *reinterpret_cast<const float4*>(scp + cl); a_sh = *reinterpret_cast<const float4*>(shp + cl); }
+    unsigned smeta[NSRC];                                                  // region pixel -> (row, column), or no such pixel
+#pragma unroll
+    for (int k = 0; k < NSRC; ++k) {
+        const int r = sp_s + 32 * k;
+        smeta[k] = r < SPX ? (1u << 16) | ((unsigned)(r / SRW) << 8) | (unsigned)(r % SRW) : 0u;
+    }
+    // operand region pixels of this thread (as umeta above)
+    unsigned umeta[Cfg::UPS];
+#pragma unroll
+    for (int k = 0; k < UPS; ++k) {
+        const int r = sp + 64 * k;
+        umeta[k] = r < RPX ? (1u << 16) | ((unsigned)(r / RW) << 8) | (unsigned)(r % RW) : 0u;
+    }
+    float4 pre[NDS + NSRC];
+    const char* dyb = nullptr;
+    const float* sfb = nullptr;
+    int ty0 = 0, tx0 = 0;
+    auto tile_base = [&](const int tile) __attribute__((always_inline)) {
+        const int tx = tile % ntx;
+        const int t2 = tile / ntx;
+        const int f = t2 / nty;
+        ty0 = (t2 % nty) * TH; tx0 = tx * TW;
+        dyb = reinterpret_cast<const char*>(dy + (((size_t)f * H + ty0) * W + tx0) * ldy);
+        sfb = sbase + (size_t)(f / fdiv) * Hs * Ws * sC + cl;
+    };
+    auto load_d = [&](const int s) __attribute__((always_inline)) { pre[s] = gload4(dyb, dgoff0 + 64u * s); };
+    auto load_s = [&](const int k) __attribute__((always_inline)) {
+        // clamped source pixel: the border replication of the interpolation's index clamp (pixels past the region are never read)
+        const int row = (smeta[k] >> 8) & 255, col = smeta[k] & 255;
+        const int ys = min(max(ty0 / 2 - 1 + row, 0), Hs - 1), xs = min(max(tx0 / 2 - 1 + col, 0), Ws - 1);
+        pre[NDS + k] = gload4(reinterpret_cast<const char*>(sfb), (unsigned)((ys * Ws + xs) * sC * 4));
+    };
+
+    int ea = 0, eb = 0;
+    bool have_a = false, have_b = false;
+    const int my_first = wrot;
+    const int rpix = 4 * kq + (ij >> 2), rch = 4 * (ij & 3);
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        tile_base(tile);
+#pragma unroll
+        for (int s = 0; s < NDS; ++s) load_d(s);
+#pragma unroll
+        for (int k = 0; k < NSRC; ++k) load_s(k);
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int cty0 = ty0, ctx0 = tx0;                       // (tile_base below moves on to the next tile)
+        // ---- source region -> LDS (affine + activation once per value); the registers take the next tile's loads at once ----
+        tile_base(min(tile + (int)gridDim.x, ntiles - 1));
+#pragma unroll
+        for (int k = 0; k < NSRC; ++k) {
+            float4 t = pre[NDS + k];
+            if (aff) { t.x = fmaf(t.x, a_sc.x, a_sh.x); t.y = fmaf(t.y, a_sc.y, a_sh.y); t.z = fmaf(t.z, a_sc.z, a_sh.z); t.w = fmaf(t.w, a_sc.w, a_sh.w); }
+            if (lre) { t.x = lrelu(t.x, 0.2f); t.y = lrelu(t.y, 0.2f); t.z = lrelu(t.z, 0.2f); t.w = lrelu(t.w, 0.2f); }
+            load_s(k);
+            if (smeta[k] >> 16) sS[(sp_s + 32 * k) * 8 + sc8] = t;
+        }
+        __syncthreads();                                      // source region complete (and the previous tile's operand reads are done)
+        // ---- this thread's operand pixels: bilinear x2 from the region; positions outside the image are the conv's zero padding ----
+        float4 uv[NUS];
+#pragma unroll
+        for (int s = 0; s < NUS; ++s) {
+            const int cit = s / UPS, k = s % UPS;
+            const int row = (umeta[k] >> 8) & 255, col = umeta[k] & 255;
+            const int y = cty0 - 1 + row, x = ctx0 - 1 + col;
+            uv[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((umeta[k] >> 16) != 0 && y >= 0 && y < H && x >= 0 && x < W) {
+                // rows (ra, ra + 1) / columns (ca, ca + 1) of the region; weights of the FIRST of the pair: 0.75 for odd y (x), 0.25 for even
+                const int ra = ((y + 1) >> 1) - cty0 / 2, ca = ((x + 1) >> 1) - ctx0 / 2;
+                const float wy0 = (y & 1) ? 0.75f : 0.25f, wy1 = 1.f - wy0, wx0 = (x & 1) ? 0.75f : 0.25f, wx1 = 1.f - wx0;
+                const float4* q0 = sS + (ra * SRW + ca) * 8 + cit * 4 + sc4;
+                const float4 v00 = q0[0], v01 = q0[8], v10 = q0[SRW * 8], v11 = q0[SRW * 8 + 8];
+                float4 r_;
+                r_.x = wy0 * (wx0 * v00.x + wx1 * v01.x) + wy1 * (wx0 * v10.x + wx1 * v11.x);
+                r_.y = wy0 * (wx0 * v00.y + wx1 * v01.y) + wy1 * (wx0 * v10.y + wx1 * v11.y);
+                r_.z = wy0 * (wx0 * v00.z + wx1 * v01.z) + wy1 * (wx0 * v10.z + wx1 * v11.z);
+                r_.w = wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
+                uv[s] = r_;
+            }
+        }
+        // ---- largest |value| of the tile, per operand ----
+        float ma = 0.f, mb = 0.f;
+#pragma unroll
+        for (int s = 0; s < NDS; ++s)
+            ma = fmaxf(ma, fmaxf(fmaxf(fabsf(pre[s].x), fabsf(pre[s].y)), fmaxf(fabsf(pre[s].z), fabsf(pre[s].w))));
+#pragma unroll
+        for (int s = 0; s < NUS; ++s)
+            mb = fmaxf(mb, fmaxf(fmaxf(fabsf(uv[s].x), fabsf(uv[s].y)), fmaxf(fabsf(uv[s].z), fabsf(uv[s].w))));
+        ma = wave_max_nonneg(ma);
+        mb = wave_max_nonneg(mb);
+        if (lane == 0) { red[2 * wave] = ma; red[2 * wave + 1] = mb; }
+        __syncthreads();
+        ma = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
+        mb = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+        ma = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ma)));
+        mb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mb)));
+        float resc = 1.f;
+        if (ma > 0.f) {
+            const int e = max(-100, min(100, 14 + 127 - (int)((__float_as_uint(ma) >> 23) & 0xff)));
+            if (!have_a) { ea = e; have_a = true; }
+            else if (e < ea) { resc *= __uint_as_float((unsigned)(127 + max(e - ea, -126)) << 23); ea = e; }
+        }
+        if (mb > 0.f) {
+            const int e = max(-100, min(100, 14 + 127 - (int)((__float_as_uint(mb) >> 23) & 0xff)));
+            if (!have_b) { eb = e; have_b = true; }
+            else if (e < eb) { resc *= __uint_as_float((unsigned)(127 + max(e - eb, -126)) << 23); eb = e; }
+        }
+        if (resc != 1.f) {
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] *= resc;
+        }
+        const float sa = __uint_as_float((unsigned)(127 + ea) << 23), sb = __uint_as_float((unsigned)(127 + eb) << 23);
+#pragma unroll
+        for (int s = 0; s < NDS; ++s) {
+            h4 p1, p2;
+            split4(pre[s], sa, p1, p2);
+            load_d(s);
+            *reinterpret_cast<h4*>(sA + s * PA + dloff0) = p1;
+            *reinterpret_cast<h4*>(sA + (NT + s) * PA + dloff0) = p2;
+        }
+#pragma unroll
+        for (int s = 0; s < NUS; ++s) {
+            const int cit = s / UPS, k = s % UPS;
+            h4 p1, p2;
+            split4(uv[s], sb, p1, p2);
+            if (umeta[k] >> 16) {
+                *reinterpret_cast<h4*>(sB + cit * PB + 64 * 16 * k + dloff0) = p1;
+                *reinterpret_cast<h4*>(sB + (CIT + cit) * PB + 64 * 16 * k + dloff0) = p2;
+            }
+        }
+        __syncthreads();
+
+        // ---- MFMA phase (as above, generic deal with NT = 1) ----
+        auto mm3 = [&](f32x4& c, const h8 a1, const h8 a2, const h8 b1, const h8 b2) __attribute__((always_inline)) {
+            c = mfma32h(a2, b1, c);
+            c = mfma32h(a1, b2, c);
+            c = mfma32h(a1, b1, c);
+        };
+        auto phase = [&](auto wv_c) __attribute__((always_inline)) {
+            constexpr int WV = decltype(wv_c)::value;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+            for (int step = 0; step < 2; ++step) {
+                const _Float16* ap = sA + (32 * step + rpix) * 16 + rch;
+                const h8 a1 = ds_tr8(ap, 16 * 16), a2 = ds_tr8(ap + NT * PA, 16 * 16);
+                const int p0 = 32 * step + rpix, p1 = p0 + 16;
+                const int rb0 = ((p0 / TW) * RW + (p0 % TW)) * 16 + rch, rb1 = ((p1 / TW) * RW + (p1 % TW)) * 16 + rch;
+                static_for<0, GPW>([&](auto gc) __attribute__((always_inline)) {
+                    constexpr int g = decltype(gc)::value, gi = WV + g * NW;
+                    if constexpr (gi < G) {
+                        constexpr int cit = gi % CIT, tdy = (gi / CIT) / 3, tdx = (gi / CIT) % 3;
+                        const _Float16* bp = sB + cit * PB + (tdy * RW + tdx) * 16;
+                        const h4 l1 = ds_tr(bp + rb0), u1 = ds_tr(bp + rb1);
+                        const h4 l2 = ds_tr(bp + CIT * PB + rb0), u2 = ds_tr(bp + CIT * PB + rb1);
+                        const h8 b1 = __builtin_shufflevector(l1, u1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const h8 b2 = __builtin_shufflevector(l2, u2, 0, 1, 2, 3, 4, 5, 6, 7);
+                        mm3(acc[g], a1, a2, b1, b2);
+                    }
+                });
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        if (my_first == 0) phase(std::integral_constant<int, 0>{});
+        else if (my_first == 1) phase(std::integral_constant<int, 1>{});
+        else if (my_first == 2) phase(std::integral_constant<int, 2>{});
+        else phase(std::integral_constant<int, 3>{});
+    }
+
+    const int K = 9 * Cin;
+    float* out = partial + (size_t)blockIdx.x * N * K;
+    const float ia = __uint_as_float((unsigned)(127 - ea) << 23), ib = __uint_as_float((unsigned)(127 - eb) << 23);
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        const int gi = wrot + g * NW;
+        if (gi >= G) continue;
+        const int tap = gi / CIT, cit = gi % CIT;
+        const int k = tap * Cin + ci0 + cit * 16 + ij;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(4 * kq + r) * K + k] = acc[g][r] * ia * ib;
+    }
+}
+
+template <int TW>
+int launch_ws_up(const float* dy, const WsUpSrc& us, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream) {
+    using Cfg = WSCfg<1, 2, TW>;
+    constexpr int SPX = (Cfg::TH / 2 + 2) * (TW / 2 + 2);
+    constexpr int LDS = Cfg::LDS_BYTES + SPX * 128;
+    static_assert(LDS <= 64 * 1024, "operand planes + source region must fit 64 KiB");
+    if (W % TW || H % Cfg::TH) return GCPX_ERR_UNSUPPORTED;
+    auto kern = wgrad_conv3x3_split_up_kernel<TW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid, Cin / Cfg::CC), dim3(256), LDS, stream, dy, us, partial, F, H, W, Cin, ldy);
+    return GCPX_OK;
+}
+
 template <int NT, int CIT, int TW>
 int launch_ws2(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream) {
     using Cfg = WSCfg<NT, CIT, TW>;
@@ -356,6 +612,35 @@ extern "C" int gcpx_wgrad_conv3x3_split(const float* dy, int32_t ldy, const floa
     else if (NT == 2 && Cin % 32 == 0) st = launch_ws<2, 2>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
     else if (NT == 4 && Cin % 32 == 0) st = launch_ws<4, 2>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
     if (st == GCPX_ERR_UNSUPPORTED) return gcpx_wgrad_conv3x3(dy, ldy, u, F, H, W, Cin, Cout, partial, grid, stream_);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+// The same for an upsampling block with 16 output channels, reading the block's own (low-resolution) sources: `a` is the block's forward
+// descriptor as gcpx_conv_stage takes it (src / nsrc / F / Hin / Win / Hout / Wout / Cin, upsample = 1; no src_row_map), the operand
+// tensor of gcpx_wgrad_conv3x3_split is never materialised.  GCPX_ERR_UNSUPPORTED when the shape has no fused form (the caller then
+// runs gcpx_conv_stage + gcpx_wgrad_conv3x3_split): 16 output channels, Cin a multiple of 32, 16-channel groups that do not straddle
+// the two sources, W in {8, 16, 32k}.
+extern "C" int gcpx_wgrad_conv3x3_split_up(const float* dy, int32_t ldy, const gcpx_conv_args* a, int32_t Cout, float* partial, int32_t grid,
+                                           void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(dy && a && partial && grid > 0 && a->F > 0, "bad arguments");
+    GCPX_CHECK_ARG(ldy % 4 == 0 && ldy >= 16, "dy rows must hold 16 columns");
+    const bool fits = a->upsample == 1 && !a->src_row_map && (a->nsrc == 1 || a->nsrc == 2) && Cout <= 16 && a->Cin % 32 == 0 &&
+                      a->src[0].C % 16 == 0 && (a->nsrc == 1 || a->src[1].C % 16 == 0) &&
+                      a->Cin == a->src[0].C + (a->nsrc == 2 ? a->src[1].C : 0) && a->Hout == 2 * a->Hin && a->Wout == 2 * a->Win &&
+                      a->src[0].frame_div >= 1 && (a->nsrc == 1 || a->src[1].frame_div >= 1);
+    if (!fits) return GCPX_ERR_UNSUPPORTED;
+    WsUpSrc us;
+    us.p0 = a->src[0].ptr; us.sc0 = a->src[0].scale; us.sh0 = a->src[0].shift; us.C0 = a->src[0].C; us.fdiv0 = a->src[0].frame_div; us.act0 = a->src[0].act;
+    const gcpx_conv_src& s1 = a->src[a->nsrc == 2 ? 1 : 0];
+    us.p1 = s1.ptr; us.sc1 = s1.scale; us.sh1 = s1.shift; us.C1 = s1.C; us.fdiv1 = s1.frame_div; us.act1 = s1.act;
+    const int H = a->Hout, W = a->Wout;
+    int st = GCPX_ERR_UNSUPPORTED;
+    if (W >= 32 && W % 32 == 0) st = launch_ws_up<32>(dy, us, partial, a->F, H, W, a->Cin, ldy, grid, stream);
+    else if (W == 16) st = launch_ws_up<16>(dy, us, partial, a->F, H, W, a->Cin, ldy, grid, stream);
+    else if (W == 8) st = launch_ws_up<8>(dy, us, partial, a->F, H, W, a->Cin, ldy, grid, stream);
+    if (st != GCPX_OK) return st;
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -71,6 +71,7 @@ class GCPTrainStep:
         # the I_0 / I_g encoder backward chains on the side lanes beside the trajectory pass's: the backward's tail gets 0.15 ms shorter in
         # tools/train_phase_times.py, the step does not (8 same-box pairs, c2: 14.94 ms with, 14.64 without) — off
         self.parallel_encoder_passes = os.environ.get("GCPX_PARALLEL_ENCODER_BWD") is not None
+        self.fuse_stage = os.environ.get("GCPX_NO_STAGE_FUSION") is None     # 16-channel upsampling blocks: weight gradient without gcpx_conv_stage
         self.fuse_head_act = os.environ.get("GCPX_NO_HEAD_ACT_FUSION") is None     # activation backward of the last decoder block in the head's data gradient
         self.split_wgrad_rows = os.environ.get("GCPX_WGRAD_ROWS_NOSPLIT") is None   # the tree's Linear / LSTM weight gradients (>= 256 rows) likewise
         self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
@@ -370,8 +371,10 @@ class GCPTrainStep:
         self._side(plan, f"bw.wreduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, n_valid, K, dst, wmap, Cin, ntap, Cout,
                    (n_map.data_ptr() if n_map is not None else None), ldw, k_off, 1)
 
-    def _wgrad_conv3(self, plan, tag, dy, ldy, u, F, Hh, Ww, Cin, Cout, dst, n_map=None):
-        """LDS-tiled 3x3 conv weight gradient (decoder blocks / output head) + its deterministic reduction"""
+    def _wgrad_conv3(self, plan, tag, dy, ldy, u, F, Hh, Ww, Cin, Cout, dst, n_map=None, up_args=None):
+        """LDS-tiled 3x3 conv weight gradient (decoder blocks / output head) + its deterministic reduction.
+        up_args: the block's forward descriptor — the split-f16 kernel then interpolates its operand from the block's own sources
+        (gcpx_wgrad_conv3x3_split_up) and `u` is not read"""
         lib, m = self.m.lib, self.m
         N16 = _c16(Cout)
         ych = Cin // 32 if (Cin % 32 == 0 and N16 != 112) else Cin // 16
@@ -382,7 +385,10 @@ class GCPTrainStep:
         part = m._buf(f"bw.part:{tag}", (grid, N16, 9 * Cin))
         # split-f16 kernel (f32-equivalent, csrc/wgrad_conv_split.hip) unless the model runs on the exact f32 kernels (GCPX_EXACT_F32)
         fn = lib.gcpx_wgrad_conv3x3_split if (m.split_f16 and self.split_wgrad) else lib.gcpx_wgrad_conv3x3
-        self._side(plan, f"bw.wgrad:{tag}", fn, dy, ldy, u, F, Hh, Ww, Cin, Cout, part.data_ptr(), grid)
+        if up_args is not None:
+            self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad_conv3x3_split_up, dy, ldy, C.byref(up_args), Cout, part.data_ptr(), grid)
+        else:
+            self._side(plan, f"bw.wgrad:{tag}", fn, dy, ldy, u, F, Hh, Ww, Cin, Cout, part.data_ptr(), grid)
         self._side(plan, f"bw.wreduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), grid, N16, 9 * Cin, dst, rt.WMAP_CONV, Cin, 9, 0,
                    (n_map.data_ptr() if n_map is not None else None), 0, 0, 1)
 
@@ -943,12 +949,20 @@ class GCPTrainStep:
             bn = rec[f"bn:dec.bn.{name}"]
             dy = self._bn_bwd(plan, f"dec.{name}", bn, gin[0], gin[1], 0, gin[2], blk["out"], F, res, res,
                               fused=(head_fused if blk is last else None))
-            U = buf(f"bw.U.{name}", (F, res, res, cin))
+            # 16-output-channel blocks: the split-f16 weight gradient interpolates its operand from the block's own sources; the others
+            # materialise it first (gcpx_conv_stage)
+            fused_up = (self.fuse_stage and m.split_f16 and self.split_wgrad and cout == 16 and cin % 32 == 0 and
+                        all(sdesc[1] % 16 == 0 for sdesc in blk["srcs"]) and (res in (8, 16) or res % 32 == 0))
+            U = None if fused_up else buf(f"bw.U.{name}", (F, res, res, cin))
             a = m._conv_args(blk["srcs"], F, res_in, res_in, res, res, cin, cin, self._zeros, self._zeros, U, upsample=1)
             plan.keep.append(a)
-            self._side(plan, f"bw.stage:dec.{name}", lib.gcpx_conv_stage, C.byref(a))
-            self._wgrad_conv3(plan, f"dec.{name}", dy.data_ptr(), cout, U.data_ptr(), F, res, res, cin, cout,
-                              self.g(f"decoder.net.{name}.conv.weight"))
+            if fused_up:
+                self._wgrad_conv3(plan, f"dec.{name}", dy.data_ptr(), cout, None, F, res, res, cin, cout,
+                                  self.g(f"decoder.net.{name}.conv.weight"), up_args=a)
+            else:
+                self._side(plan, f"bw.stage:dec.{name}", lib.gcpx_conv_stage, C.byref(a))
+                self._wgrad_conv3(plan, f"dec.{name}", dy.data_ptr(), cout, U.data_ptr(), F, res, res, cin, cout,
+                                  self.g(f"decoder.net.{name}.conv.weight"))
             if self.early_fork:
                 self._flush(plan)
             dU = buf(f"bw.dU.{name}", (F, res, res, cin))
