@@ -1452,6 +1452,43 @@ def test_wgrad_conv3x3_split_up_reads_the_blocks_sources(env, Hin, c_prev, c_ski
     assert_close(got.float(), ref_.float(), atol=2e-6 * scale, rtol=0, name="fused vs staged")
 
 
+@pytest.mark.parametrize("Cout,Cin,S", [(100, 16, 64), (16, 32, 32), (32, 64, 16)])
+def test_wgrad_conv3x3_split_src_applies_affine_and_frame_map(env, Cout, Cin, S):
+    """gcpx_wgrad_conv3x3_split_src: the operand is LeakyReLU(scale x + shift) of a raw tensor read through a frame map (the output
+    head's weight gradient over the matched rows) — against gcpx_conv_stage (gathered, activated copy) + gcpx_wgrad_conv3x3_split, the
+    path it replaces (same operand values: identical sums), and against float64."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(Cout + S)
+    Fx, R = 9, 6
+    N16 = (Cout + 15) // 16 * 16
+    x = torch.randn(Fx, S, S, Cin, device=dev)
+    sc, sh = (torch.rand(Cin) + 0.5).to(dev), (torch.randn(Cin) * 0.3).to(dev)
+    fmap = torch.tensor([4, 0, 8, 8, 2, 5], dtype=torch.int32, device=dev)
+    dy = torch.randn(R, S, S, N16, device=dev) * 1e-3
+    dy[..., Cout:] = 0.0
+    staged = torch.full((R, S, S, Cin), float("nan"), device=dev)
+    a = _conv_args(rt, [(x, Cin, 1, sc, sh, rt.ACT_LRELU)], F=R, Hin=S, Win=S, Hout=S, Wout=S, Cout=Cin, out_pitch=Cin, upsample=0, out=staged)
+    a.src_row_map = fmap.data_ptr()
+    rt.check(lib.gcpx_conv_stage(C.byref(a), _stream()), "conv_stage")
+    ych = Cin // 32 if (Cin % 32 == 0 and N16 != 112) else Cin // 16
+    grid = max(1, min(96 // ych, R * max(1, S * S // 64)))
+    p_ref = torch.full((grid, N16, 9 * Cin), float("nan"), device=dev)
+    rt.check(lib.gcpx_wgrad_conv3x3_split(dy.data_ptr(), N16, staged.data_ptr(), R, S, S, Cin, Cout, p_ref.data_ptr(), grid, _stream()), "staged")
+    p_src = torch.full((grid, N16, 9 * Cin), float("nan"), device=dev)
+    rt.check(lib.gcpx_wgrad_conv3x3_split_src(dy.data_ptr(), N16, x.data_ptr(), fmap.data_ptr(), sc.data_ptr(), sh.data_ptr(), R, S, S, Cin, Cout,
+                                              p_src.data_ptr(), grid, _stream()), "src")
+    torch.cuda.synchronize()
+    u = F.leaky_relu(x.double() * sc.double() + sh.double(), 0.2)[fmap.long()]
+    up = F.pad(u, (0, 0, 1, 1, 1, 1))
+    want = torch.stack([torch.einsum("fhwn,fhwc->nc", dy.double(), up[:, ky:ky + S, kx:kx + S, :]) for ky in range(3) for kx in range(3)], 1)
+    want = want.reshape(N16, 9 * Cin)
+    assert torch.isfinite(p_src).all()
+    got, ref_ = p_src.double().sum(0), p_ref.double().sum(0)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2.0 * float((ref_ - want).abs().max()) + 4e-7 * scale
+    assert_close(got.float(), ref_.float(), atol=2e-6 * scale, rtol=0, name="src vs staged")
+
+
 def test_split_pack_group_equals_single_launches(env):
     """gcpx_split_pack_group (all split-f16 weight tensors re-split in one launch, one workgroup per tensor) writes bit for bit what one
     gcpx_split_pack launch per tensor writes: tensors of different sizes and magnitudes, one of them all zero."""

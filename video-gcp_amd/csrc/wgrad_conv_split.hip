@@ -38,13 +38,14 @@ struct WSCfg {
     static constexpr int UPS = (RPX + 63) / 64;                // U staging slots per ci-tile: 64 region pixels x 4 float4 each
     static constexpr int NUS = UPS * CIT;
     static constexpr int NS = NDS + NUS;
-    static constexpr int LDS_BYTES = (A_HALFS + B_HALFS) * 2 + 64;
+    static constexpr int LDS_BYTES = (A_HALFS + B_HALFS) * 2 + 64 + 2 * CC * 4;      // planes, tile maxima, optional operand affine
 };
 
 template <int NT, int CIT, int TW>
 __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_kernel(const float* __restrict__ dy, const float* __restrict__ u,
                                                                      float* __restrict__ partial, const int F, const int H, const int W,
-                                                                     const int Cin, const int ldy) {
+                                                                     const int Cin, const int ldy, const int* __restrict__ fmap,
+                                                                     const float* __restrict__ usc, const float* __restrict__ ush) {
     using Cfg = WSCfg<NT, CIT, TW>;
     constexpr int NW = Cfg::NW, N = Cfg::N, CC = Cfg::CC, TH = Cfg::TH, RH = Cfg::RH, RW = Cfg::RW, RPX = Cfg::RPX;
     constexpr int PA = Cfg::PA, PB = Cfg::PB, G = Cfg::G, GPW = Cfg::GPW, NDS = Cfg::NDS, UPS = Cfg::UPS, NUS = Cfg::NUS;
@@ -52,6 +53,14 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_kernel(const float
     _Float16* sA = reinterpret_cast<_Float16*>(smem4);                     // [2][NT][PA]
     _Float16* sB = sA + Cfg::A_HALFS;                                      // [2][CIT][PB]
     float* red = reinterpret_cast<float*>(sB + Cfg::B_HALFS);              // [NW][2] tile maxima
+    // usc / ush (optional): the operand is LeakyReLU(usc * u + ush) of the tensor at `u`, frame f of the operand = frame fmap[f] of that
+    // tensor (the output head's input: the last decoder block's raw output at the matched nodes) — what gcpx_conv_stage would materialise.
+    // The two vectors sit in LDS behind the maxima (in registers they would be the values that spill).
+    float* uaff = red + 8;                                                 // [2][CC]
+    if (usc) {
+        if (threadIdx.x < 2 * CC) uaff[threadIdx.x] = (threadIdx.x < CC ? usc : ush)[blockIdx.y * CC + (threadIdx.x % CC)];
+        __syncthreads();
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,7 +106,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_kernel(const float
         const int f = t2 / nty;
         ty0 = (t2 % nty) * TH; tx0 = tx * TW;
         dyb = reinterpret_cast<const char*>(dy + (((size_t)f * H + ty0) * W + tx0) * ldy);
-        ub = reinterpret_cast<const char*>(u + (size_t)f * H * W * Cin + ci0);
+        const int fu = fmap ? max(fmap[f], 0) : f;                       // (rows without a frame carry a zero gradient: any frame will do)
+        ub = reinterpret_cast<const char*>(u + (size_t)fu * H * W * Cin + ci0);
     };
     auto load_d = [&](const int s) __attribute__((always_inline)) { pre[s] = gload4(dyb, dgoff0 + 64u * s); };
     auto load_u = [&](const int s) __attribute__((always_inline)) {
@@ -136,6 +146,14 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_kernel(const float
             ma = fmaxf(ma, fmaxf(fmaxf(fabsf(pre[s].x), fabsf(pre[s].y)), fmaxf(fabsf(pre[s].z), fabsf(pre[s].w))));
 #pragma unroll
         for (int s = 0; s < NUS; ++s) {
+            if (usc) {
+                const float4 a_sc = *reinterpret_cast<const float4*>(uaff + 16 * (s / UPS) + 4 * sc4);
+                const float4 a_sh = *reinterpret_cast<const float4*>(uaff + CC + 16 * (s / UPS) + 4 * sc4);
+                float4 t = pre[NDS + s];
+                t.x = lrelu(fmaf(t.x, a_sc.x, a_sh.x), 0.2f); t.y = lrelu(fmaf(t.y, a_sc.y, a_sh.y), 0.2f);
+                t.z = lrelu(fmaf(t.z, a_sc.z, a_sh.z), 0.2f); t.w = lrelu(fmaf(t.w, a_sc.w, a_sh.w), 0.2f);
+                pre[NDS + s] = t;
+            }
             if (!((okbits >> s) & 1u)) pre[NDS + s] = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 v = pre[NDS + s];
             mb = fmaxf(mb, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
@@ -341,7 +359,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_up_kernel(const fl
     _Float16* sA = reinterpret_cast<_Float16*>(smem4);                     // [2][NT][PA]
     _Float16* sB = sA + Cfg::A_HALFS;                                      // [2][CIT][PB]
     float* red = reinterpret_cast<float*>(sB + Cfg::B_HALFS);              // [NW][2] tile maxima
-    float4* sS = reinterpret_cast<float4*>(red + 16);                      // [SPX][8] source region (f32, 32 channels)
+    float4* sS = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem4) + Cfg::LDS_BYTES);      // [SPX][8] source region (f32, 32 channels)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -573,7 +591,8 @@ int launch_ws_up(const float* dy, const WsUpSrc& us, float* partial, int F, int 
 }
 
 template <int NT, int CIT, int TW>
-int launch_ws2(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream) {
+int launch_ws2(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream,
+               const int* fmap = nullptr, const float* usc = nullptr, const float* ush = nullptr) {
     using Cfg = WSCfg<NT, CIT, TW>;
     if (W % TW || H % Cfg::TH) return GCPX_ERR_UNSUPPORTED;
     auto kern = wgrad_conv3x3_split_kernel<NT, CIT, TW>;
@@ -583,15 +602,16 @@ int launch_ws2(const float* dy, const float* u, float* partial, int F, int H, in
         attr_set = true;
     }
     static_assert(Cfg::LDS_BYTES <= 64 * 1024, "operand planes of one tile must fit 64 KiB");
-    hipLaunchKernelGGL(kern, dim3(grid, Cin / Cfg::CC), dim3(256), Cfg::LDS_BYTES, stream, dy, u, partial, F, H, W, Cin, ldy);
+    hipLaunchKernelGGL(kern, dim3(grid, Cin / Cfg::CC), dim3(256), Cfg::LDS_BYTES, stream, dy, u, partial, F, H, W, Cin, ldy, fmap, usc, ush);
     return GCPX_OK;
 }
 
 template <int NT, int CIT>
-int launch_ws(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream) {
-    if (W >= 32 && W % 32 == 0) return launch_ws2<NT, CIT, 32>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
-    if (W == 16) return launch_ws2<NT, CIT, 16>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
-    if (W == 8) return launch_ws2<NT, CIT, 8>(dy, u, partial, F, H, W, Cin, ldy, grid, stream);
+int launch_ws(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream,
+              const int* fmap = nullptr, const float* usc = nullptr, const float* ush = nullptr) {
+    if (W >= 32 && W % 32 == 0) return launch_ws2<NT, CIT, 32>(dy, u, partial, F, H, W, Cin, ldy, grid, stream, fmap, usc, ush);
+    if (W == 16) return launch_ws2<NT, CIT, 16>(dy, u, partial, F, H, W, Cin, ldy, grid, stream, fmap, usc, ush);
+    if (W == 8) return launch_ws2<NT, CIT, 8>(dy, u, partial, F, H, W, Cin, ldy, grid, stream, fmap, usc, ush);
     return GCPX_ERR_UNSUPPORTED;
 }
 
@@ -640,6 +660,28 @@ extern "C" int gcpx_wgrad_conv3x3_split_up(const float* dy, int32_t ldy, const g
     if (W >= 32 && W % 32 == 0) st = launch_ws_up<32>(dy, us, partial, a->F, H, W, a->Cin, ldy, grid, stream);
     else if (W == 16) st = launch_ws_up<16>(dy, us, partial, a->F, H, W, a->Cin, ldy, grid, stream);
     else if (W == 8) st = launch_ws_up<8>(dy, us, partial, a->F, H, W, a->Cin, ldy, grid, stream);
+    if (st != GCPX_OK) return st;
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+// The same for a NON-upsampling conv whose operand is LeakyReLU(scale * x + shift) of a raw tensor x [Fx][H][W][Cin] read through a frame
+// map (operand frame f = frame frame_map[f] of x; negative entries must carry a zero dy): the output head's weight gradient reads the
+// last decoder block's raw output at the matched nodes directly — gcpx_conv_stage's gathered copy is never written.  frame_map /
+// scale + shift may be NULL.  GCPX_ERR_UNSUPPORTED (nothing launched) for shapes without a split form.
+extern "C" int gcpx_wgrad_conv3x3_split_src(const float* dy, int32_t ldy, const float* x, const int32_t* frame_map, const float* scale,
+                                            const float* shift, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* partial,
+                                            int32_t grid, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(dy && x && partial && F > 0 && grid > 0, "bad arguments");
+    GCPX_CHECK_ARG(ldy % 4 == 0 && Cin % 16 == 0 && (scale == nullptr) == (shift == nullptr), "ldy % 4, Cin % 16, scale and shift together");
+    const int NT = (Cout + 15) / 16;
+    GCPX_CHECK_ARG(ldy >= NT * 16, "dy rows must hold Cout rounded up to 16 columns");
+    int st = GCPX_ERR_UNSUPPORTED;
+    if (NT == 7 && Cin == 16) st = launch_ws<7, 1>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift);
+    else if (NT == 1 && Cin % 32 == 0) st = launch_ws<1, 2>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift);
+    else if (NT == 2 && Cin % 32 == 0) st = launch_ws<2, 2>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift);
+    else if (NT == 4 && Cin % 32 == 0) st = launch_ws<4, 2>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift);
     if (st != GCPX_OK) return st;
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;

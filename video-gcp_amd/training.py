@@ -371,7 +371,7 @@ class GCPTrainStep:
         self._side(plan, f"bw.wreduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, n_valid, K, dst, wmap, Cin, ntap, Cout,
                    (n_map.data_ptr() if n_map is not None else None), ldw, k_off, 1)
 
-    def _wgrad_conv3(self, plan, tag, dy, ldy, u, F, Hh, Ww, Cin, Cout, dst, n_map=None, up_args=None):
+    def _wgrad_conv3(self, plan, tag, dy, ldy, u, F, Hh, Ww, Cin, Cout, dst, n_map=None, up_args=None, src=None):
         """LDS-tiled 3x3 conv weight gradient (decoder blocks / output head) + its deterministic reduction.
         up_args: the block's forward descriptor — the split-f16 kernel then interpolates its operand from the block's own sources
         (gcpx_wgrad_conv3x3_split_up) and `u` is not read"""
@@ -387,6 +387,8 @@ class GCPTrainStep:
         fn = lib.gcpx_wgrad_conv3x3_split if (m.split_f16 and self.split_wgrad) else lib.gcpx_wgrad_conv3x3
         if up_args is not None:
             self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad_conv3x3_split_up, dy, ldy, C.byref(up_args), Cout, part.data_ptr(), grid)
+        elif src is not None:      # (raw tensor, frame map, scale, shift): operand = LeakyReLU(scale * x + shift) at the mapped frames
+            self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad_conv3x3_split_src, dy, ldy, *src, F, Hh, Ww, Cin, Cout, part.data_ptr(), grid)
         else:
             self._side(plan, f"bw.wgrad:{tag}", fn, dy, ldy, u, F, Hh, Ww, Cin, Cout, part.data_ptr(), grid)
         self._side(plan, f"bw.wreduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), grid, N16, 9 * Cin, dst, rt.WMAP_CONV, Cin, 9, 0,
@@ -887,19 +889,28 @@ class GCPTrainStep:
         # balanced: the matched frames (row b*T+t of dMD <- node matched to frame t); adaptive: every node frame
         all_frames = hp.adaptive and maps is None
         R = maps["R"] if maps is not None else (F if all_frames else B * T)
-        featA = buf("bw.featA", (R, S, S, ngf))
-        a = m._conv_args([rec["head_src"]], R, S, S, S, S, ngf, ngf, self._zeros, self._zeros, featA)
+        row_map = None
         if maps is not None:
-            a.src_row_map = maps["row2src"].data_ptr()
+            row_map = maps["row2src"]
         elif not all_frames:
-            f2n_abs = buf("bw.f2n_abs", (B, T), torch.int32)
-            plan.add("bw.f2n_abs", lib.gcpx_index_offset, o["frame2node"].data_ptr(), f2n_abs.data_ptr(), B, T, N)
-            a.src_row_map = f2n_abs.data_ptr()
-        plan.keep.append(a)
-        # the materialised conv input is only read by the weight gradient: both go to a side lane
-        self._side(plan, "bw.stage:dec.head", lib.gcpx_conv_stage, C.byref(a))
-        self._wgrad_conv3(plan, "dec.head", dMD.data_ptr(), pitch, featA.data_ptr(), R, S, S, ngf, pitch,
-                          self.g("decoder.gen_head.conv.weight"), n_map=perm32)
+            row_map = buf("bw.f2n_abs", (B, T), torch.int32)
+            plan.add("bw.f2n_abs", lib.gcpx_index_offset, o["frame2node"].data_ptr(), row_map.data_ptr(), B, T, N)
+        hs = rec["head_src"]                                   # (pointer, channels, frame divisor, scale, shift, activation)
+        if (self.fuse_stage and m.split_f16 and self.split_wgrad and ngf == 16 and hs[2] == 1 and hs[5] == rt.ACT_LRELU and
+                hs[3] is not None and (S in (8, 16) or S % 32 == 0)):
+            # the split-f16 kernel reads the last block's raw output at the rows' frames and applies BatchNorm affine + LeakyReLU on load
+            self._wgrad_conv3(plan, "dec.head", dMD.data_ptr(), pitch, None, R, S, S, ngf, pitch, self.g("decoder.gen_head.conv.weight"),
+                              n_map=perm32, src=(hs[0], rt.ptr(row_map), rt.ptr(hs[3]), rt.ptr(hs[4])))
+        else:
+            featA = buf("bw.featA", (R, S, S, ngf))
+            a = m._conv_args([hs], R, S, S, S, S, ngf, ngf, self._zeros, self._zeros, featA)
+            if row_map is not None:
+                a.src_row_map = row_map.data_ptr()
+            plan.keep.append(a)
+            # the materialised conv input is only read by the weight gradient: both go to a side lane
+            self._side(plan, "bw.stage:dec.head", lib.gcpx_conv_stage, C.byref(a))
+            self._wgrad_conv3(plan, "dec.head", dMD.data_ptr(), pitch, featA.data_ptr(), R, S, S, ngf, pitch,
+                              self.g("decoder.gen_head.conv.weight"), n_map=perm32)
         if rec.get("head_grad_fused"):
             # the head kernel wrote the gradient rows itself: the bias gradient is their column sum over every pixel (a side-lane pass
             # over dMD next to the weight gradient, which reads the same rows)
