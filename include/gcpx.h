@@ -509,10 +509,12 @@ int gcpx_wgrad_conv3x3_split_up(const float* dy, int32_t ldy, const gcpx_conv_ar
 /* ... and for a NON-upsampling conv whose operand is LeakyReLU(0.2)(scale * x + shift) of a raw tensor x [Fx][H][W][Cin] read through a
    frame map (operand frame f = frame frame_map[f] of x; a negative entry must carry a zero dy): the output head's weight gradient reads
    the last decoder block's raw output at the matched nodes — the gathered, activated copy gcpx_conv_stage would write (335 MB at c2)
-   never exists.  frame_map, or scale + shift, may be NULL. */
+   never exists.  frame_map, or scale + shift, may be NULL.  bias_partial (optional; the 112-column head form only): [grid][112]
+   per-workgroup column sums of dy over every pixel = the bias gradient, from the same staged tiles (sum over the grid with
+   gcpx_wgrad_reduce): no gcpx_colsum pass over dy (2.35 GB at c2). */
 int gcpx_wgrad_conv3x3_split_src(const float* dy, int32_t ldy, const float* x, const int32_t* frame_map, const float* scale,
                                  const float* shift, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* partial,
-                                 int32_t grid, void* stream);
+                                 float* bias_partial, int32_t grid, void* stream);
 /* bias gradient: dst[n] (+)= sum_r dy[r][n] (rows addressed like gcpx_wgrad_args.dy); dst2 = optional second destination
    (LSTM b_ih and b_hh); with nsplit > 1 the row range is split and partial [nsplit][N] is written instead of dst */
 int gcpx_colsum(const float* dy, int64_t ldy, int32_t R, int32_t N, int32_t dy_rpb, int64_t dy_sb, int32_t nsplit, float* partial,

@@ -1475,9 +1475,13 @@ def test_wgrad_conv3x3_split_src_applies_affine_and_frame_map(env, Cout, Cin, S)
     p_ref = torch.full((grid, N16, 9 * Cin), float("nan"), device=dev)
     rt.check(lib.gcpx_wgrad_conv3x3_split(dy.data_ptr(), N16, staged.data_ptr(), R, S, S, Cin, Cout, p_ref.data_ptr(), grid, _stream()), "staged")
     p_src = torch.full((grid, N16, 9 * Cin), float("nan"), device=dev)
+    bpart = torch.full((grid, N16), float("nan"), device=dev) if N16 == 112 else None       # the head form also sums dy's columns
     rt.check(lib.gcpx_wgrad_conv3x3_split_src(dy.data_ptr(), N16, x.data_ptr(), fmap.data_ptr(), sc.data_ptr(), sh.data_ptr(), R, S, S, Cin, Cout,
-                                              p_src.data_ptr(), grid, _stream()), "src")
+                                              p_src.data_ptr(), (bpart.data_ptr() if bpart is not None else None), grid, _stream()), "src")
     torch.cuda.synchronize()
+    if bpart is not None:
+        wantb = dy.double().sum((0, 1, 2))
+        assert_close(bpart.double().sum(0).float(), wantb.float(), atol=3e-6 * float(wantb.abs().max()), rtol=0, name="bias column sums")
     u = F.leaky_relu(x.double() * sc.double() + sh.double(), 0.2)[fmap.long()]
     up = F.pad(u, (0, 0, 1, 1, 1, 1))
     want = torch.stack([torch.einsum("fhwn,fhwc->nc", dy.double(), up[:, ky:ky + S, kx:kx + S, :]) for ky in range(3) for kx in range(3)], 1)

@@ -45,7 +45,8 @@ template <int NT, int CIT, int TW>
 __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_kernel(const float* __restrict__ dy, const float* __restrict__ u,
                                                                      float* __restrict__ partial, const int F, const int H, const int W,
                                                                      const int Cin, const int ldy, const int* __restrict__ fmap,
-                                                                     const float* __restrict__ usc, const float* __restrict__ ush) {
+                                                                     const float* __restrict__ usc, const float* __restrict__ ush,
+                                                                     float* __restrict__ bias_partial) {
     using Cfg = WSCfg<NT, CIT, TW>;
     constexpr int NW = Cfg::NW, N = Cfg::N, CC = Cfg::CC, TH = Cfg::TH, RH = Cfg::RH, RW = Cfg::RW, RPX = Cfg::RPX;
     constexpr int PA = Cfg::PA, PB = Cfg::PB, G = Cfg::G, GPW = Cfg::GPW, NDS = Cfg::NDS, UPS = Cfg::UPS, NUS = Cfg::NUS;
@@ -80,6 +81,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_kernel(const float
     f32x4 acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    // BAL + bias_partial: the bias gradient (column sums of dY over every pixel) comes out of the same staged tiles as two more
+    // accumulator tiles per wavefront — dY against a fragment of ones — instead of a pass of its own over dY (2.35 GB at c2).
+    // Rotated wavefront 0 / 1 / 2 / 3 sums n-tiles {0, 1} / {2, 3} / {4} / {5, 6}.
+    f32x4 bacc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    const bool do_bias = BAL && bias_partial != nullptr;
 
     // ---- staging slots (the same for every tile; per-slot data is one register: anything spilled is reloaded with a wait for every
     //      load in flight).  A thread moves float4 (tid & 3) of pixel (tid >> 2) of a 16-channel tile: 64 contiguous bytes per pixel in
@@ -170,7 +176,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_kernel(const float
         if (ma > 0.f) {
             const int e = max(-100, min(100, 14 + 127 - (int)((__float_as_uint(ma) >> 23) & 0xff)));      // ma 2^e in [2^14, 2^15)
             if (!have_a) { ea = e; have_a = true; }
-            else if (e < ea) { resc *= __uint_as_float((unsigned)(127 + max(e - ea, -126)) << 23); ea = e; }
+            else if (e < ea) {
+                resc *= __uint_as_float((unsigned)(127 + max(e - ea, -126)) << 23); ea = e;
+                if constexpr (BAL) { bacc[0] *= resc; bacc[1] *= resc; }                                  // (the bias sums carry the dY scale only)
+            }
         }
         if (mb > 0.f) {
             const int e = max(-100, min(100, 14 + 127 - (int)((__float_as_uint(mb) >> 23) & 0xff)));
@@ -215,6 +224,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_kernel(const float
         };
         auto phase = [&](auto wv_c) __attribute__((always_inline)) {
             constexpr int WV = decltype(wv_c)::value;
+            const h8 one8 = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
             for (int step = 0; step < 2; ++step) {
@@ -249,11 +259,20 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_kernel(const float
                             } else {
                                 mm3(acc[15], a1, a2, b1[0], b2[0]);
                             }
+                            if (do_bias && nt >= 2 * WV && nt < 2 * WV + 2 && nt < 5) {
+                                f32x4& bc = bacc[nt - 2 * WV];
+                                bc = mfma32h(a2, one8, bc);
+                                bc = mfma32h(a1, one8, bc);
+                            }
                         }
                     } else {
                         h8 a51, a52, a61, a62;
                         lda(5, a51, a52);
                         lda(6, a61, a62);
+                        if (do_bias) {
+                            bacc[0] = mfma32h(a52, one8, bacc[0]); bacc[0] = mfma32h(a51, one8, bacc[0]);
+                            bacc[1] = mfma32h(a62, one8, bacc[1]); bacc[1] = mfma32h(a61, one8, bacc[1]);
+                        }
 #pragma unroll
                         for (int tdy = 0; tdy < 3; ++tdy) {
                             h8 b1[3], b2[3];
@@ -301,6 +320,15 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_kernel(const float
     float* out = partial + (size_t)blockIdx.x * N * K;
     const float ia = __uint_as_float((unsigned)(127 - ea) << 23), ib = __uint_as_float((unsigned)(127 - eb) << 23);
     if constexpr (BAL) {
+        if (do_bias && blockIdx.y == 0 && ij == 0) {          // every column of a bias tile holds the same sums: column 0 writes them
+            const int nt0 = wrot < 3 ? 2 * wrot : 5;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (wrot != 2 || i == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bias_partial[(size_t)blockIdx.x * N + (nt0 + i) * 16 + 4 * kq + r] = bacc[i][r] * ia;
+                }
+        }
         auto store = [&](const f32x4& v, int nt, int tap) {
             const int k = tap * Cin + ci0 + ij;
 #pragma unroll
@@ -592,7 +620,7 @@ int launch_ws_up(const float* dy, const WsUpSrc& us, float* partial, int F, int 
 
 template <int NT, int CIT, int TW>
 int launch_ws2(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream,
-               const int* fmap = nullptr, const float* usc = nullptr, const float* ush = nullptr) {
+               const int* fmap = nullptr, const float* usc = nullptr, const float* ush = nullptr, float* bias_partial = nullptr) {
     using Cfg = WSCfg<NT, CIT, TW>;
     if (W % TW || H % Cfg::TH) return GCPX_ERR_UNSUPPORTED;
     auto kern = wgrad_conv3x3_split_kernel<NT, CIT, TW>;
@@ -602,16 +630,16 @@ int launch_ws2(const float* dy, const float* u, float* partial, int F, int H, in
         attr_set = true;
     }
     static_assert(Cfg::LDS_BYTES <= 64 * 1024, "operand planes of one tile must fit 64 KiB");
-    hipLaunchKernelGGL(kern, dim3(grid, Cin / Cfg::CC), dim3(256), Cfg::LDS_BYTES, stream, dy, u, partial, F, H, W, Cin, ldy, fmap, usc, ush);
+    hipLaunchKernelGGL(kern, dim3(grid, Cin / Cfg::CC), dim3(256), Cfg::LDS_BYTES, stream, dy, u, partial, F, H, W, Cin, ldy, fmap, usc, ush, bias_partial);
     return GCPX_OK;
 }
 
 template <int NT, int CIT>
 int launch_ws(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream,
-              const int* fmap = nullptr, const float* usc = nullptr, const float* ush = nullptr) {
-    if (W >= 32 && W % 32 == 0) return launch_ws2<NT, CIT, 32>(dy, u, partial, F, H, W, Cin, ldy, grid, stream, fmap, usc, ush);
-    if (W == 16) return launch_ws2<NT, CIT, 16>(dy, u, partial, F, H, W, Cin, ldy, grid, stream, fmap, usc, ush);
-    if (W == 8) return launch_ws2<NT, CIT, 8>(dy, u, partial, F, H, W, Cin, ldy, grid, stream, fmap, usc, ush);
+              const int* fmap = nullptr, const float* usc = nullptr, const float* ush = nullptr, float* bias_partial = nullptr) {
+    if (W >= 32 && W % 32 == 0) return launch_ws2<NT, CIT, 32>(dy, u, partial, F, H, W, Cin, ldy, grid, stream, fmap, usc, ush, bias_partial);
+    if (W == 16) return launch_ws2<NT, CIT, 16>(dy, u, partial, F, H, W, Cin, ldy, grid, stream, fmap, usc, ush, bias_partial);
+    if (W == 8) return launch_ws2<NT, CIT, 8>(dy, u, partial, F, H, W, Cin, ldy, grid, stream, fmap, usc, ush, bias_partial);
     return GCPX_ERR_UNSUPPORTED;
 }
 
@@ -668,17 +696,20 @@ extern "C" int gcpx_wgrad_conv3x3_split_up(const float* dy, int32_t ldy, const g
 // The same for a NON-upsampling conv whose operand is LeakyReLU(scale * x + shift) of a raw tensor x [Fx][H][W][Cin] read through a frame
 // map (operand frame f = frame frame_map[f] of x; negative entries must carry a zero dy): the output head's weight gradient reads the
 // last decoder block's raw output at the matched nodes directly — gcpx_conv_stage's gathered copy is never written.  frame_map /
-// scale + shift may be NULL.  GCPX_ERR_UNSUPPORTED (nothing launched) for shapes without a split form.
+// scale + shift may be NULL.  bias_partial (optional, the 112-column head form): [grid][112] per-workgroup column sums of dy — the bias
+// gradient out of the same staged tiles (two more accumulator tiles per wavefront against a fragment of ones) instead of a pass of its
+// own over dy.  GCPX_ERR_UNSUPPORTED (nothing launched) for shapes without a split form.
 extern "C" int gcpx_wgrad_conv3x3_split_src(const float* dy, int32_t ldy, const float* x, const int32_t* frame_map, const float* scale,
                                             const float* shift, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* partial,
-                                            int32_t grid, void* stream_) {
+                                            float* bias_partial, int32_t grid, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(dy && x && partial && F > 0 && grid > 0, "bad arguments");
     GCPX_CHECK_ARG(ldy % 4 == 0 && Cin % 16 == 0 && (scale == nullptr) == (shift == nullptr), "ldy % 4, Cin % 16, scale and shift together");
     const int NT = (Cout + 15) / 16;
     GCPX_CHECK_ARG(ldy >= NT * 16, "dy rows must hold Cout rounded up to 16 columns");
     int st = GCPX_ERR_UNSUPPORTED;
-    if (NT == 7 && Cin == 16) st = launch_ws<7, 1>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift);
+    GCPX_CHECK_ARG(!bias_partial || (NT == 7 && Cin == 16), "bias_partial: the 112-column head form only");
+    if (NT == 7 && Cin == 16) st = launch_ws<7, 1>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift, bias_partial);
     else if (NT == 1 && Cin % 32 == 0) st = launch_ws<1, 2>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift);
     else if (NT == 2 && Cin % 32 == 0) st = launch_ws<2, 2>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift);
     else if (NT == 4 && Cin % 32 == 0) st = launch_ws<4, 2>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift);

@@ -151,7 +151,7 @@ SYMBOLS = [
     ("gcpx_wgrad_conv3x3", C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     ("gcpx_wgrad_conv3x3_split", C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     ("gcpx_wgrad_conv3x3_split_up", C.c_int, [vp, i32, C.POINTER(ConvArgs), i32, vp, i32, vp]),
-    ("gcpx_wgrad_conv3x3_split_src", C.c_int, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    ("gcpx_wgrad_conv3x3_split_src", C.c_int, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
     ("gcpx_wgrad_image4x4s2", C.c_int, [vp, vp, vp, vp, i32, i32, vp, i32, vp]),
     ("gcpx_split_pack_group", C.c_int, [vp, i32, vp]),
     ("gcpx_wgrad_reduce", C.c_int, [vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, i64, i32, i32, vp]),

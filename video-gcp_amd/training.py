@@ -371,7 +371,7 @@ class GCPTrainStep:
         self._side(plan, f"bw.wreduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, n_valid, K, dst, wmap, Cin, ntap, Cout,
                    (n_map.data_ptr() if n_map is not None else None), ldw, k_off, 1)
 
-    def _wgrad_conv3(self, plan, tag, dy, ldy, u, F, Hh, Ww, Cin, Cout, dst, n_map=None, up_args=None, src=None):
+    def _wgrad_conv3(self, plan, tag, dy, ldy, u, F, Hh, Ww, Cin, Cout, dst, n_map=None, up_args=None, src=None, dbias=None):
         """LDS-tiled 3x3 conv weight gradient (decoder blocks / output head) + its deterministic reduction.
         up_args: the block's forward descriptor — the split-f16 kernel then interpolates its operand from the block's own sources
         (gcpx_wgrad_conv3x3_split_up) and `u` is not read"""
@@ -388,7 +388,14 @@ class GCPTrainStep:
         if up_args is not None:
             self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad_conv3x3_split_up, dy, ldy, C.byref(up_args), Cout, part.data_ptr(), grid)
         elif src is not None:      # (raw tensor, frame map, scale, shift): operand = LeakyReLU(scale * x + shift) at the mapped frames
-            self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad_conv3x3_split_src, dy, ldy, *src, F, Hh, Ww, Cin, Cout, part.data_ptr(), grid)
+            bpart = None
+            if dbias is not None:  # the bias gradient (column sums of dy) out of the same launch
+                bpart = m._buf(f"bw.bpart:{tag}", (grid, N16))
+            self._side(plan, f"bw.wgrad:{tag}", lib.gcpx_wgrad_conv3x3_split_src, dy, ldy, *src, F, Hh, Ww, Cin, Cout, part.data_ptr(),
+                       rt.ptr(bpart), grid)
+            if bpart is not None:
+                self._side(plan, f"bw.creduce:{tag}", lib.gcpx_wgrad_reduce, bpart.data_ptr(), grid, N16, 1, dbias, rt.WMAP_CONV, 1, 1, 0,
+                           (n_map.data_ptr() if n_map is not None else None), 0, 0, 1)
         else:
             self._side(plan, f"bw.wgrad:{tag}", fn, dy, ldy, u, F, Hh, Ww, Cin, Cout, part.data_ptr(), grid)
         self._side(plan, f"bw.wreduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), grid, N16, 9 * Cin, dst, rt.WMAP_CONV, Cin, 9, 0,
@@ -899,9 +906,12 @@ class GCPTrainStep:
         if (self.fuse_stage and m.split_f16 and self.split_wgrad and ngf == 16 and hs[2] == 1 and hs[5] == rt.ACT_LRELU and
                 hs[3] is not None and (S in (8, 16) or S % 32 == 0)):
             # the split-f16 kernel reads the last block's raw output at the rows' frames and applies BatchNorm affine + LeakyReLU on load
+            head_bias_fused = bool(rec.get("head_grad_fused")) and pitch == 112
             self._wgrad_conv3(plan, "dec.head", dMD.data_ptr(), pitch, None, R, S, S, ngf, pitch, self.g("decoder.gen_head.conv.weight"),
-                              n_map=perm32, src=(hs[0], rt.ptr(row_map), rt.ptr(hs[3]), rt.ptr(hs[4])))
+                              n_map=perm32, src=(hs[0], rt.ptr(row_map), rt.ptr(hs[3]), rt.ptr(hs[4])),
+                              dbias=(self.g("decoder.gen_head.conv.bias") if head_bias_fused else None))
         else:
+            head_bias_fused = False
             featA = buf("bw.featA", (R, S, S, ngf))
             a = m._conv_args([hs], R, S, S, S, S, ngf, ngf, self._zeros, self._zeros, featA)
             if row_map is not None:
@@ -911,7 +921,9 @@ class GCPTrainStep:
             self._side(plan, "bw.stage:dec.head", lib.gcpx_conv_stage, C.byref(a))
             self._wgrad_conv3(plan, "dec.head", dMD.data_ptr(), pitch, featA.data_ptr(), R, S, S, ngf, pitch,
                               self.g("decoder.gen_head.conv.weight"), n_map=perm32)
-        if rec.get("head_grad_fused"):
+        if head_bias_fused:
+            pass                       # (column sums of dMD came out of the weight-gradient launch)
+        elif rec.get("head_grad_fused"):
             # the head kernel wrote the gradient rows itself: the bias gradient is their column sum over every pixel (a side-lane pass
             # over dMD next to the weight gradient, which reads the same rows)
             self._colsum(plan, "dec.head", dMD.data_ptr(), pitch, R * S * S, pitch, self.g("decoder.gen_head.conv.bias"), n_map=perm32)
