@@ -742,9 +742,6 @@ int gcpx_graph_destroy(void* graph_exec);
 int gcpx_stream_create(void** stream);
 /* level < 0: highest priority of the device, 0: middle, > 0: lowest (side lanes that must not delay the critical chain) */
 int gcpx_stream_create_priority(void** stream, int level);
-/* a stream restricted to the CUs whose bit is set in mask (nwords x 32 bits): side lanes that must leave CUs free for a dependent
-   chain on another stream */
-int gcpx_stream_create_cumask(void** stream, const uint32_t* mask, int32_t nwords);
 int gcpx_stream_destroy(void* stream);
 int gcpx_stream_wait_event(void* stream, void* ev);
 

@@ -449,15 +449,6 @@ extern "C" int gcpx_stream_create_priority(void** stream, int level) {
     return GCPX_OK;
 }
 
-// a stream whose kernels run on a subset of the CUs (bit i of mask = CU i enabled)
-extern "C" int gcpx_stream_create_cumask(void** stream, const uint32_t* mask, int32_t nwords) {
-    GCPX_CHECK_ARG(stream != nullptr && mask != nullptr && nwords > 0, "bad arguments");
-    hipStream_t s;
-    GCPX_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask));
-    *stream = s;
-    return GCPX_OK;
-}
-
 extern "C" int gcpx_stream_destroy(void* stream) {
     GCPX_HIP(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
     return GCPX_OK;

@@ -151,17 +151,10 @@ class GCPTreeModel:
         # and orders it against the caller's current stream with events (wait_stream), never a host sync
         self._stream = torch.cuda.Stream(device=self.device)
         self._streams = [self._stream.cuda_stream]
-        # GCPX_SIDE_CU_MASK="k/n" (experiment): side lanes run on CUs i with i % n < k only
-        cu_mask = os.environ.get("GCPX_SIDE_CU_MASK")
         for _ in range(N_LANES - 1):
             sp = C.c_void_p()
             with torch.cuda.device(self.device):
-                if cu_mask:
-                    k_, n_ = (int(v) for v in cu_mask.split("/"))
-                    words = (C.c_uint32 * 10)(*[sum(1 << b for b in range(32) if (32 * w + b) % n_ < k_) for w in range(10)])
-                    rt.check(self.lib.gcpx_stream_create_cumask(C.byref(sp), words, 10), "stream_create_cumask")
-                else:
-                    rt.check(self.lib.gcpx_stream_create(C.byref(sp)), "stream_create")
+                rt.check(self.lib.gcpx_stream_create(C.byref(sp)), "stream_create")
             self._streams.append(sp)
         self.save_for_backward = False        # training step: forward plans keep what the backward pass needs
         # split-f16 convs (csrc/conv3x3_split.hip): f32-equivalent results on the f16 matrix pipes.  GCPX_EXACT_F32=1 keeps every

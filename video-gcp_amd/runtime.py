@@ -219,7 +219,6 @@ SYMBOLS = [
     ("gcpx_graph_destroy", C.c_int, [vp]),
     ("gcpx_stream_create", C.c_int, [C.POINTER(vp)]),
     ("gcpx_stream_create_priority", C.c_int, [C.POINTER(vp), C.c_int]),
-    ("gcpx_stream_create_cumask", C.c_int, [C.POINTER(vp), vp, i32]),
     ("gcpx_stream_destroy", C.c_int, [vp]),
     ("gcpx_stream_wait_event", C.c_int, [vp, vp]),
     ("gcpx_event_create", C.c_int, [C.POINTER(vp)]),
