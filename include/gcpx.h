@@ -230,10 +230,11 @@ int gcpx_gemm_row_blocks(int32_t M, int32_t N);
  * GCPX_MLP_GAUSS: out = 2*nz, mu = out[:nz], log_sigma = out[nz:]; additionally z = mu + exp(log_sigma) * eps
  * (Gaussian.sample / reparametrize, tree_module.py:79-94).
  * ------------------------------------------------------------------------------------------------- */
-typedef enum gcpx_mlp_epi { GCPX_MLP_PLAIN = 0, GCPX_MLP_GAUSS = 1 } gcpx_mlp_epi;
+typedef enum gcpx_mlp_epi { GCPX_MLP_PLAIN = 0, GCPX_MLP_GAUSS = 1,
+                             GCPX_MLP_TANH = 2 /* out = tanh(head): the non-LSTM subgoal predictor, tree_module.py:109-110 */ } gcpx_mlp_epi;
 
 typedef struct gcpx_mlp_args {
-    gcpx_row_src src[4];
+    gcpx_row_src src[6];
     int32_t nsrc;
     int32_t M, rpb;
     int32_t in_dim, mid, n_mid, out_dim;
@@ -571,6 +572,10 @@ typedef struct gcpx_mlp_bwd_args {
 } gcpx_mlp_bwd_args;
 int gcpx_mlp_bwd(const gcpx_mlp_bwd_args* a, void* stream);
 int gcpx_mlp_bwd_blocks(int32_t M);
+/* dx[r][c] = dy[r][c] * (1 - y[r][c]^2), backward of y = tanh(u) (GCPX_MLP_TANH; tree_module.py:109-110): dy and y rows (b, j) at
+   base + b*sb + j*sr, dx dense [B*rpb][width] */
+int gcpx_tanh_bwd_rows(const float* dy, const float* y, float* dx, int64_t sb, int64_t sr, int32_t B, int32_t rpb, int32_t width,
+                       void* stream);
 /* dx[i] = dy[i] * (a[i] > 0 ? 1 : slope) */
 int gcpx_lrelu_bwd(const float* a, const float* dy, float* dx, int64_t n, float slope, void* stream);
 

@@ -435,15 +435,20 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
         pred_input = [e_l, e_r, z]
         if hp.context_every_step:                                               # :97-101
             pred_input += [inp["e_0"].repeat_interleave(n, 0), inp["e_g"].repeat_interleave(n, 0)]
-        if left["hidden"] is None and right["hidden"] is None:                  # :104-105
-            if hp.lstm_init == "zero":                                          # ZeroLSTMCellInitializer (tree_lstm.py:68-70)
-                init = torch.zeros(e_l.shape[0], 2 * hp.lstm_state_dim, dtype=e_l.dtype)
-            else:
-                init = predictor(sd, f"{p}.lstm_initializer.net", hp, e_l, e_r, z)
-            hl, hr = torch.chunk(init, 2, 1)
-            left["hidden"], right["hidden"] = hl.reshape(B, n, -1), hr.reshape(B, n, -1)
-        hidden, e_g_prime = tree_lstm_step(sd, p, hp, flat(left["hidden"]), flat(right["hidden"]), pred_input)   # :107-108
-        sg["hidden"], sg["e_g_prime"] = hidden, e_g_prime
+        if not hp.tree_lstm:
+            # non-LSTM subgoal predictor (tree_module.py:45-46,109-110; GeneralizedPredictorModel is blox, absent — this build's spec: one
+            # Predictor over the concatenated inputs): no hidden state
+            sg["e_g_prime"] = torch.tanh(predictor(sd, f"{p}.subgoal_pred.net", hp, *pred_input))
+        else:
+            if left["hidden"] is None and right["hidden"] is None:              # :104-105
+                if hp.lstm_init == "zero":                                      # ZeroLSTMCellInitializer (tree_lstm.py:68-70)
+                    init = torch.zeros(e_l.shape[0], 2 * hp.lstm_state_dim, dtype=e_l.dtype)
+                else:
+                    init = predictor(sd, f"{p}.lstm_initializer.net", hp, e_l, e_r, z)
+                hl, hr = torch.chunk(init, 2, 1)
+                left["hidden"], right["hidden"] = hl.reshape(B, n, -1), hr.reshape(B, n, -1)
+            hidden, e_g_prime = tree_lstm_step(sd, p, hp, flat(left["hidden"]), flat(right["hidden"]), pred_input)   # :107-108
+            sg["hidden"], sg["e_g_prime"] = hidden, e_g_prime
         sg["ind"] = (flat(start_inds) + flat(end_inds)) / 2                     # :113
         sg = {k: v.reshape(B, n, *v.shape[1:]) for k, v in sg.items()}
         for k in ("e_g_prime", "hidden", "z", "q_z_mu", "q_z_log_sigma", "p_z_mu", "p_z_log_sigma"):
@@ -451,8 +456,11 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
                 tap(f"{k}.{l}", sg[k])
         layers.append(sg)
         # child layer inputs (tree_utils.py:37-44)
-        new_left = {k: _interleave(left[k], sg[k]) for k in ("e_g_prime", "hidden")}
-        new_right = {k: _interleave(sg[k], right[k]) for k in ("e_g_prime", "hidden")}
+        carried = ("e_g_prime", "hidden") if hp.tree_lstm else ("e_g_prime",)
+        new_left = {k: _interleave(left[k], sg[k]) for k in carried}
+        new_right = {k: _interleave(sg[k], right[k]) for k in carried}
+        if not hp.tree_lstm:
+            new_left["hidden"] = new_right["hidden"] = None
         if "match_timesteps" in sg and left["match_timesteps"] is not None:
             new_left["match_timesteps"] = _interleave(left["match_timesteps"], sg["match_timesteps"])
             new_right["match_timesteps"] = _interleave(sg["match_timesteps"], right["match_timesteps"])

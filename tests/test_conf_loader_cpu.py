@@ -75,7 +75,10 @@ def test_adaptive_base_config_and_errors(tmp_path):
     (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'tree_lstm': 'sum', 'lstm_init': 'zero'}\n")
     hp, _, _ = CL.load_conf(str(tmp_path))
     assert hp.tree_lstm == "sum" and hp.lstm_init == "zero"             # tree_lstm.py:52-74: sum / linear / split_linear, zero / mlp
-    (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'tree_lstm': ''}\n")     # the non-LSTM predictor: not built
+    (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'tree_lstm': ''}\n")     # the non-LSTM subgoal predictor
+    hp, _, _ = CL.load_conf(str(tmp_path))                              # (tree_module.py:45-46)
+    assert hp.tree_lstm == ""
+    (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'tree_lstm': 'gru'}\n")
     with pytest.raises(ValueError):
         CL.load_conf(str(tmp_path))
     (tmp_path / "conf.py").write_text("x = 1\n")

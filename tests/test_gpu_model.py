@@ -27,7 +27,8 @@ def _check_common(hp, model, out, ref, posterior):
     bf = ref["tree_bf"]
     tree = out.tree
     assert_close(tree.bf.e_g_prime, bf["e_g_prime"], LAT_ATOL, LAT_RTOL, "e_g_prime")
-    assert_close(tree.bf.hidden_state, bf["hidden"], LAT_ATOL, LAT_RTOL, "hidden_state")
+    if "hidden" in bf:                                         # (the non-LSTM subgoal predictor carries no hidden state)
+        assert_close(tree.bf.hidden_state, bf["hidden"], LAT_ATOL, LAT_RTOL, "hidden_state")
     assert_close(tree.bf.z, bf["z"], LAT_ATOL, LAT_RTOL, "z")
     assert_close(tree.bf.p_z_mu, bf["p_z_mu"], LAT_ATOL, LAT_RTOL, "p_z.mu")
     assert_close(tree.bf.p_z_log_sigma, bf["p_z_log_sigma"], LAT_ATOL, LAT_RTOL, "p_z.log_sigma")
@@ -226,15 +227,17 @@ def test_edge_shapes(cfg):
     assert abs(total - float(ref_total)) <= 2e-5 * abs(float(ref_total)) + 1e-6
 
 
-@pytest.mark.parametrize("tree_lstm,lstm_init", [("sum", "mlp"), ("linear", "mlp"), ("split_linear", "zero"), ("sum", "zero")])
+@pytest.mark.parametrize("tree_lstm,lstm_init", [("sum", "mlp"), ("linear", "mlp"), ("split_linear", "zero"), ("sum", "zero"), ("", "mlp")])
 def test_tree_lstm_variants_c1(tree_lstm, lstm_init):
     """the other TreeLSTM morphologies and the parameter-free initialiser (tree_lstm.py:11-27,52-74): SumTree adds the parents' hidden
     states, LinTree projects their concatenation with one Linear, ZeroLSTMCellInitializer starts the root's parents from zero states —
     forward and losses against the oracle"""
     from oracle import gcp_model_oracle as O
     hp, sd, model = _build("c1", tree_lstm=tree_lstm, lstm_init=lstm_init)
-    assert (f"tree_module.tree_modules.0.lstm_initializer.net.input.linear.weight" in sd) == (lstm_init == "mlp")
+    # ('' = the non-LSTM subgoal predictor, tree_module.py:45-46,109-110: one Predictor + tanh, no hidden state, no initialiser)
+    assert (f"tree_module.tree_modules.0.lstm_initializer.net.input.linear.weight" in sd) == (lstm_init == "mlp" and tree_lstm != "")
     assert ("tree_module.tree_modules.1.subgoal_pred.projection.weight" in sd) == (tree_lstm == "linear")
+    assert ("tree_module.tree_modules.1.subgoal_pred.net.head.linear.weight" in sd) == (tree_lstm == "")
     model.train(True)
     inputs, noise, _ = make_inputs(hp, seed=8, variant="B")
     ref = O.forward(sd, hp, inputs, noise=noise, training_bn=True)

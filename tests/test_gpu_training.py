@@ -283,7 +283,7 @@ def test_training_step_with_adam_and_clipping_c1():
         GCPTrainStep(model, optimizer="lbfgs")
 
 
-@pytest.mark.parametrize("tree_lstm,lstm_init", [("sum", "zero"), ("linear", "mlp")])
+@pytest.mark.parametrize("tree_lstm,lstm_init", [("sum", "zero"), ("linear", "mlp"), ("", "mlp")])
 def test_gradients_tree_lstm_variants_c1(tree_lstm, lstm_init):
     """training step with the Sum / Lin TreeLSTM merge and the zero initialiser (tree_lstm.py:11-27,68-70): every parameter gradient
     against autograd over the oracle.  5e-3 here: a wrong or missing merge backward is off by O(1) in the projection / upstream

@@ -139,8 +139,8 @@ def hparams_from_conf(configuration, model_config, **over):
         if k in mc and mc[k] not in allowed:
             raise ValueError(f"model_config[{k!r}] = {mc[k]!r}: only {allowed} is built")
         mc.pop(k, None)
-    if mc.get("tree_lstm", "split_linear") not in ("split_linear", "linear", "sum"):       # tree_lstm.py:52-60; '' / None = the non-LSTM
-        raise ValueError(f"model_config['tree_lstm'] = {mc['tree_lstm']!r}: split_linear, linear and sum are built")   # predictor (not built)
+    if (mc.get("tree_lstm", "split_linear") or "") not in ("split_linear", "linear", "sum", ""):      # tree_lstm.py:52-60; '' / None = the
+        raise ValueError(f"model_config['tree_lstm'] = {mc['tree_lstm']!r}: split_linear, linear, sum and '' are built")   # non-LSTM predictor
     if mc.pop("add_weighted_pixel_copy", False):
         ignored.append("add_weighted_pixel_copy")        # 25room/gcp_tree/conf.py:43 pops it as well
     inv = mc.pop("inv_mdl_params", None) or {}

@@ -251,6 +251,20 @@ __global__ void __launch_bounds__(256) rows_strided_kernel(float* __restrict__ d
     *d = mode == 1 ? *d + v : v;
 }
 
+// dx[r][c] = dy[r][c] * (1 - y[r][c]^2): backward of y = tanh(u) (the non-LSTM subgoal predictor's output, tree_module.py:109-110);
+// dy / y rows (b, j) at base + b*sb + j*sr, dx dense [B * rpb][width]
+__global__ void __launch_bounds__(256) tanh_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                                            const long long sb, const long long sr, const int rpb, const int width,
+                                                            const long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % width);
+    const long long r = i / width;
+    const long long o = (r / rpb) * sb + (r % rpb) * sr + c;
+    const float t = y[o];
+    dx[i] = dy[o] * (1.f - t * t);
+}
+
 __global__ void __launch_bounds__(256) index_offset_kernel(const int* __restrict__ idx, int* __restrict__ out, const int T,
                                                            const int stride, const int total) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1045,6 +1059,17 @@ extern "C" int gcpx_act_bwd(const gcpx_actbwd_args* a, void* stream_) {
     GCPX_CHECK_ARG(a->fsum >= 1 && a->ldc % 4 == 0 && a->c_off % 4 == 0, "bad fsum / ldc / c_off");
     GCPX_CHECK_ARG(!a->stats_partial || (a->mean && a->rstd && a->r), "stats need r, mean, rstd");
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ACT_BLOCKS), dim3(256), 0, stream, *a);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_tanh_bwd_rows(const float* dy, const float* y, float* dx, int64_t sb, int64_t sr, int32_t B, int32_t rpb, int32_t width,
+                                  void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(dy && y && dx && B > 0 && rpb > 0 && width > 0, "bad arguments");
+    const long long total = (long long)B * rpb * width;
+    hipLaunchKernelGGL(tanh_bwd_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dy, y, dx, (long long)sb, (long long)sr,
+                       rpb, width, total);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

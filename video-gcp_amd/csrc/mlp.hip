@@ -260,7 +260,8 @@ __device__ __forceinline__ void mlp_rows(const gcpx_mlp_args& a, const int bx, c
                 const int n = nt * 16 + q * 4;
                 if (n < a.out_dim) {
                     const float4 bv = *reinterpret_cast<const float4*>(a.b_out + n);
-                    const float v[4] = {ao[0] + bv.x, ao[1] + bv.y, ao[2] + bv.z, ao[3] + bv.w};
+                    float v[4] = {ao[0] + bv.x, ao[1] + bv.y, ao[2] + bv.z, ao[3] + bv.w};
+                    if (a.epi == GCPX_MLP_TANH) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
                     const int blk = n / split, nn = n % split;
                     float* op = orow + (size_t)blk * a.oblk + nn;
                     if (n + 3 < a.out_dim && nn + 3 < split && (((uintptr_t)op) & 15) == 0) {
@@ -375,7 +376,7 @@ level_pre_fn level_pre_variant(const int pr, const int cr, const int ks) {
 
 int mlp_check(const gcpx_mlp_args* a) {
     GCPX_CHECK_ARG(a != nullptr, "null args");
-    GCPX_CHECK_ARG(a->nsrc >= 1 && a->nsrc <= 4, "nsrc out of range");
+    GCPX_CHECK_ARG(a->nsrc >= 1 && a->nsrc <= 6, "nsrc out of range");
     GCPX_CHECK_ARG(a->M > 0 && a->rpb > 0, "bad M/rpb");
     int ksum = 0;
     for (int s = 0; s < a->nsrc; ++s) {

@@ -192,8 +192,8 @@ class GCPTreeModel:
 
     def _check_hp(self, hp):
         assert hp.matching_type in ("balanced", "dtw_image")
-        if hp.tree_lstm not in ("split_linear", "linear", "sum"):                  # tree_lstm.py:52-60 (the non-LSTM
-            raise ValueError("don't know this TreeLSTM type")                      # GeneralizedPredictorModel, tree_module.py:45-46, is not built)
+        if hp.tree_lstm not in ("split_linear", "linear", "sum", ""):              # tree_lstm.py:52-60; '' = the non-LSTM subgoal
+            raise ValueError("don't know this TreeLSTM type")                      # predictor (tree_module.py:45-46,109-110)
         if hp.lstm_init not in ("mlp", "zero"):
             raise ValueError("dont know lstm init type {}!".format(hp.lstm_init))  # tree_lstm.py:74
         if hp.attentive_inference:
@@ -315,7 +315,8 @@ class GCPTreeModel:
             self.repack()
             return
         self.pk = self._pack_tree(self.sd)
-        self._pack_fused_embed()
+        if self._hp.tree_lstm:
+            self._pack_fused_embed()
         self._pack_split()
         self._pack_gemm_split()
 
@@ -579,6 +580,12 @@ class GCPTreeModel:
             T = {}
             T["prior"] = self._pack_predictor(f"{p}.prior", 2 * hp.nz_vae)
             T["q"] = self._pack_predictor(f"{p}.inference.q", 2 * hp.nz_vae)
+            if not hp.tree_lstm:
+                T["sg"] = self._pack_predictor(f"{p}.subgoal_pred.net", hp.nz_enc)
+                P[f"tree{l}"] = T
+                if hp.attentive_inference:
+                    raise ValueError("attentive inference with the non-LSTM subgoal predictor is not built")
+                continue
             T["embed.w"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.embed.weight"])
             T["embed.b"] = sd[f"{p}.subgoal_pred.embed.bias"].contiguous()
             for i in range(hp.n_lstm_layers):
@@ -695,7 +702,7 @@ class GCPTreeModel:
             return
         plan.add(name, self.lib.gcpx_gemm, C.byref(a))
 
-    def _mlp(self, plan, name, W, srcs, M, rpb, out=None, ob=0, orow=0, oblk=0, out_split=0, gauss=None, group=None):
+    def _mlp(self, plan, name, W, srcs, M, rpb, out=None, ob=0, orow=0, oblk=0, out_split=0, gauss=None, group=None, tanh=False):
         """One Predictor launch — or, with `group` (a list), only its argument struct: `_mlp_group` then issues the whole list as
         ONE launch."""
         hp = self._hp
@@ -719,7 +726,7 @@ class GCPTreeModel:
         a.w_out, a.b_out = W["w_out"].data_ptr(), W["b_out"].data_ptr()
         a.gn_eps, a.lrelu_slope = hp.gn_eps, hp.leaky_slope
         a.out, a.ob, a.orow, a.oblk, a.out_split = out, ob, orow, oblk, out_split
-        a.epi = rt.MLP_PLAIN
+        a.epi = rt.MLP_TANH if tanh else rt.MLP_PLAIN
         if gauss is not None:
             a.epi = rt.MLP_GAUSS
             a.eps, a.eb, a.erow, a.z, a.zb, a.zrow = gauss
@@ -1082,7 +1089,7 @@ class GCPTreeModel:
             # cross-queue join costs ~10 us and the big levels are throughput-bound anyway (tools/fwd_tree_phase.py: level 6 323 us
             # with the side lane, 329 us in line).  Instead the merge of level l + 1, which needs nothing but the hidden states of
             # level l, shares the launch of level l's `out` Linear while both are in the small-M regime (gcpx_gemm_group).
-            merge_with_predictors = not has_z and not sample_prior and hp.tree_lstm != "sum"
+            merge_with_predictors = not has_z and not sample_prior and hp.tree_lstm not in ("sum", "")
             if has_z:
                 # given latents in depth-first order (tree.py:38); reparametrised with the learned prior (:79-82)
                 g = (_addr(tin["z"], (s - 1) * nv), N * nv, 2 * s * nv) + z_map
@@ -1109,6 +1116,11 @@ class GCPTreeModel:
                     plan_merge(l, group=mg)
                 self._mlp_group(plan, f"prior+posterior{l}", pq, gemm=(mg[0] if mg else None))
             zs = lambda: self._rowsrc(z_map[0], z_map[1], z_map[2], nv)
+            if not hp.tree_lstm:
+                # non-LSTM subgoal predictor (tree_module.py:109-110): e = tanh(Predictor([e_l, e_r, z (, e_0, e_g)])), no hidden state
+                srcs = [el(), er(), zs()] + ([e0(), eg()] if hp.context_every_step else [])
+                self._mlp(plan, f"subgoal{l}", W["sg"], srcs, M, n, out=_addr(E, nodeoff(nz)), ob=PS * nz, orow=2 * s * nz, tanh=True)
+                continue
             if l == 0:
                 if hp.lstm_init == "zero":
                     # ZeroLSTMCellInitializer (tree_lstm.py:68-70): both root parents start from zero states

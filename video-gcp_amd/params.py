@@ -138,15 +138,22 @@ def param_table(hp):
         p = f"tree_module.tree_modules.{l}"
         _predictor(tab, f"{p}.prior", 2 * hp.nz_enc, 2 * hp.nz_vae, hp.nz_mid, npl)
         _predictor(tab, f"{p}.inference.q", 3 * hp.nz_enc, 2 * hp.nz_vae, hp.nz_mid, npl)
-        tab[f"{p}.subgoal_pred.embed.weight"] = ((H, hp.pred_inp_dim), "xavier")
-        tab[f"{p}.subgoal_pred.embed.bias"] = ((H,), "zeros")
-        for i in range(hp.n_lstm_layers):
+        if not hp.tree_lstm:
+            # tree_lstm = '' (tree_module.py:45-46,109-110): GeneralizedPredictorModel with one head (blox, absent) — this build's spec:
+            # a Predictor over [e_l, e_r, z (, e_0, e_g)] whose output goes through tanh; no hidden states, no initialiser
+            _predictor(tab, f"{p}.subgoal_pred.net", hp.pred_inp_dim, hp.nz_enc, hp.nz_mid, npl)
+        lstm_layers = hp.n_lstm_layers if hp.tree_lstm else 0
+        if hp.tree_lstm:
+            tab[f"{p}.subgoal_pred.embed.weight"] = ((H, hp.pred_inp_dim), "xavier")
+            tab[f"{p}.subgoal_pred.embed.bias"] = ((H,), "zeros")
+        for i in range(lstm_layers):
             tab[f"{p}.subgoal_pred.lstm.{i}.weight_ih"] = ((4 * H, H), "lstm")
             tab[f"{p}.subgoal_pred.lstm.{i}.weight_hh"] = ((4 * H, H), "lstm")
             tab[f"{p}.subgoal_pred.lstm.{i}.bias_ih"] = ((4 * H,), "lstm")
             tab[f"{p}.subgoal_pred.lstm.{i}.bias_hh"] = ((4 * H,), "lstm")
-        tab[f"{p}.subgoal_pred.out.weight"] = ((hp.nz_enc, H), "xavier")
-        tab[f"{p}.subgoal_pred.out.bias"] = ((hp.nz_enc,), "zeros")
+        if hp.tree_lstm:
+            tab[f"{p}.subgoal_pred.out.weight"] = ((hp.nz_enc, H), "xavier")
+            tab[f"{p}.subgoal_pred.out.bias"] = ((hp.nz_enc,), "zeros")
         if hp.tree_lstm == "split_linear":                       # tree_lstm.py:30-41: one Linear(2H -> H) per (layer, h / c) chunk
             for j in range(2 * hp.n_lstm_layers):
                 tab[f"{p}.subgoal_pred.projections.{j}.weight"] = ((H, 2 * H), "xavier")
@@ -170,7 +177,7 @@ def param_table(hp):
             tab[f"{a}.out.weight"] = ((hp.nz_enc, hp.nz_enc), "xavier")
             tab[f"{a}.out.bias"] = ((hp.nz_enc,), "zeros")
         if l == 0:
-            if hp.lstm_init == "mlp":                            # 'zero' (ZeroLSTMCellInitializer, tree_lstm.py:68-70) has no parameters
+            if hp.tree_lstm and hp.lstm_init == "mlp":           # 'zero' (ZeroLSTMCellInitializer, tree_lstm.py:68-70) has no parameters
                 _predictor(tab, f"{p}.lstm_initializer.net", 2 * hp.nz_enc + hp.nz_vae, 2 * hp.lstm_state_dim,
                            hp.init_mlp_mid_sz, hp.init_mlp_layers)
             if hp.adaptive:

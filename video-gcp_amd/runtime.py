@@ -13,7 +13,7 @@ ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 HEAD_RAW, HEAD_DLM_MEAN, HEAD_DLM_BOTH, HEAD_TANH_NCHW, HEAD_DLM_NLL, HEAD_DLM_NLL_GRAD = 0, 1, 2, 3, 4, 5
 SPLIT_PLAIN, SPLIT_ROWFOLD = 0, 1
 EPI_NONE, EPI_LRELU, EPI_LSTM, EPI_GAUSS_SAMPLE = 0, 1, 2, 3
-MLP_PLAIN, MLP_GAUSS = 0, 1
+MLP_PLAIN, MLP_GAUSS, MLP_TANH = 0, 1, 2
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -58,7 +58,7 @@ class GemmArgs(C.Structure):
 
 
 class MlpArgs(C.Structure):
-    _fields_ = [("src", RowSrc * 4), ("nsrc", i32), ("M", i32), ("rpb", i32), ("in_dim", i32), ("mid", i32),
+    _fields_ = [("src", RowSrc * 6), ("nsrc", i32), ("M", i32), ("rpb", i32), ("in_dim", i32), ("mid", i32),
                 ("n_mid", i32), ("out_dim", i32), ("w_in", vp), ("b_in", vp), ("w_mid", vp), ("b_mid", vp),
                 ("gn_gamma", vp), ("gn_beta", vp), ("w_out", vp), ("b_out", vp), ("gn_eps", C.c_float),
                 ("lrelu_slope", C.c_float), ("epi", i32), ("out_split", i32), ("out", vp), ("ob", i64), ("orow", i64),
@@ -162,6 +162,7 @@ SYMBOLS = [
     ("gcpx_mlp_bwd_blocks", C.c_int, [i32]),
     ("gcpx_gn_lrelu_bwd", C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float, vp]),
     ("gcpx_gn_bwd_blocks", C.c_int, [i32]),
+    ("gcpx_tanh_bwd_rows", C.c_int, [vp, vp, vp, i64, i64, i32, i32, i32, vp]),
     ("gcpx_lrelu_bwd", C.c_int, [vp, vp, vp, i64, C.c_float, vp]),
     ("gcpx_kl_bwd", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i64, i64, C.c_float, C.c_float, vp]),
     ("gcpx_kl_bwd_weighted", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i64, i64, C.c_float, C.c_float, vp, i64, vp]),

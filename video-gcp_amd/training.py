@@ -209,6 +209,10 @@ class GCPTrainStep:
             T = {}
             T["prior"] = self._pack_predictor_T(sd, f"{p}.prior", [(0, 2 * nz)])
             T["q"] = self._pack_predictor_T(sd, f"{p}.inference.q", [(0, 2 * nz), (2 * nz, nz)])
+            if not hp.tree_lstm:                                   # non-LSTM subgoal predictor (tree_module.py:109-110)
+                T["sg"] = self._pack_predictor_T(sd, f"{p}.subgoal_pred.net", [(0, hp.pred_inp_dim)])
+                X[f"tree{l}"] = T
+                continue
             T["embed.wT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.embed.weight"].t().contiguous())
             for i in range(hp.n_lstm_layers):
                 T[f"lstm{i}.wxT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.lstm.{i}.weight_ih"].t().contiguous())   # [H][4H]
@@ -672,54 +676,65 @@ class GCPTrainStep:
             s, n = 2 ** (L - 1 - l), 2 ** l
             M = B * n
             dEn = _addr(dE, s * nz)
-            # out linear
-            x_top = buf(f"x{l}.{nl}", (M, H))
-            self._wgrad(plan, f"out{l}", dEn, 2 * s * nz, M, nz, x_top.data_ptr(), H, self.g(f"{sp}.out.weight"), ldw=H, sr=H,
-                        sb=M * H, rpb=M, dy_rpb=n, dy_sb=PS * nz, dbias=self.g(f"{sp}.out.bias"))
-            dxt = buf(f"bw.dxt{l}", (M, H))
-            self._dgemm(plan, f"out{l}", [m._rowsrc(dEn, PS * nz, 2 * s * nz, nz)], M, H, n, Wt["out.wT"], dxt.data_ptr(), n * H, H)
-            merged = buf(f"merged{l}", (M, 2 * nl * H))
-            dmerged = buf(f"bw.dmerged{l}", (M, 2 * nl * H))
-            dh_src = dxt
-            for i in reversed(range(nl)):
-                dg = buf(f"bw.dgates{l}.{i}", (M, 4 * H))
-                a = rt.LstmBwdArgs()
-                a.gates = rec[f"gates:lstm{l}.{i}"].data_ptr()
-                a.c_prev, a.c_prev_stride = _addr(merged, (2 * i + 1) * H), 2 * nl * H
-                a.c_new, a.pb, a.prow = _addr(Hid, s * SD + (2 * i + 1) * H), PS * SD, 2 * s * SD
-                a.dh_dense, a.dh_stride = dh_src.data_ptr(), H
-                a.dh_pos, a.dc_pos = _addr(dHid, s * SD + 2 * i * H), _addr(dHid, s * SD + (2 * i + 1) * H)
-                a.dgates, a.dc_prev, a.dcp_stride = dg.data_ptr(), _addr(dmerged, (2 * i + 1) * H), 2 * nl * H
-                a.M, a.H, a.rpb = M, H, n
-                plan.keep.append(a)
-                plan.add(f"bw.lstm{l}.{i}", lib.gcpx_lstm_bwd, C.byref(a))
-                x_i = buf(f"x{l}.{i}", (M, H))
-                self._wgrad(plan, f"lstm{l}.{i}.ih", dg.data_ptr(), 4 * H, M, 4 * H, x_i.data_ptr(), H,
-                            self.g(f"{sp}.lstm.{i}.weight_ih"), ldw=H, sr=H, sb=M * H, rpb=M,
-                            dbias=self.g(f"{sp}.lstm.{i}.bias_ih"), dbias2=self.g(f"{sp}.lstm.{i}.bias_hh"))
-                self._wgrad(plan, f"lstm{l}.{i}.hh", dg.data_ptr(), 4 * H, M, 4 * H, _addr(merged, 2 * i * H), H,
-                            self.g(f"{sp}.lstm.{i}.weight_hh"), ldw=H, sr=2 * nl * H, sb=M * 2 * nl * H, rpb=M)
-                dxi = buf(f"bw.dxi{l}.{i}", (M, H))
-                src = [self._dense(dg.data_ptr(), 4 * H, 4 * H, M)]
-                self._dgemm(plan, f"lstm{l}.{i}.x", src, M, H, M, Wt[f"lstm{i}.wxT"], dxi.data_ptr(), 0, H)
-                self._dgemm(plan, f"lstm{l}.{i}.h", src, M, H, M, Wt[f"lstm{i}.whT"], _addr(dmerged, 2 * i * H), 0, 2 * nl * H)
-                dh_src = dxi
-            dx0 = dh_src
-            # embedding of [e_l, e_r, z, e_0, e_g]
-            el = m._rowsrc(_addr(E), PS * nz, 2 * s * nz, nz)
-            er = m._rowsrc(_addr(E, 2 * s * nz), PS * nz, 2 * s * nz, nz)
-            zs = m._rowsrc(_addr(o["Z"], s * nv), PS * nv, 2 * s * nv, nv)
-            esrcs = [el, er, zs]
-            if hp.context_every_step:
-                esrcs += [m._rowsrc(_addr(E), PS * nz, 0, nz), m._rowsrc(_addr(E, 2 ** L * nz), PS * nz, 0, nz)]
-            koff = 0
-            for i, sc in enumerate(esrcs):
-                self._wgrad(plan, f"embed{l}.{i}", dx0.data_ptr(), H, M, H, sc.ptr, sc.width, self.g(f"{sp}.embed.weight"), ldw=pid,
-                            k_off=koff, rpb=n, sb=sc.sb, sr=sc.sr, dbias=(self.g(f"{sp}.embed.bias") if i == 0 else None))
-                koff += sc.width
             dpi = buf(f"bw.dpi{l}", (M, pid))
-            self._dgemm(plan, f"embed{l}", [self._dense(dx0.data_ptr(), H, H, M)], M, pid, M, Wt["embed.wT"], dpi.data_ptr(), 0, pid)
+            if not hp.tree_lstm:
+                # non-LSTM subgoal predictor: e = tanh(net([e_l, e_r, z (, e_0, e_g)])) (tree_module.py:109-110): d pre-activation, then the
+                # Predictor's backward straight into the gradient of the predictor inputs
+                dpre = buf(f"bw.dpre{l}", (M, _c16(nz)))
+                plan.add(f"bw.tanh{l}", lib.gcpx_tanh_bwd_rows, dEn, _addr(E, s * nz), dpre.data_ptr(), PS * nz, 2 * s * nz, B, n, nz)
+                self._mlp_bwd(plan, f"subgoal{l}", f"{sp}.net", rec[f"mlp:subgoal{l}"], Wt["sg"], dpre.data_ptr(), _c16(nz),
+                              [(dpi.data_ptr(), n * pid, pid)])
+            else:
+                # out linear
+                x_top = buf(f"x{l}.{nl}", (M, H))
+                self._wgrad(plan, f"out{l}", dEn, 2 * s * nz, M, nz, x_top.data_ptr(), H, self.g(f"{sp}.out.weight"), ldw=H, sr=H,
+                            sb=M * H, rpb=M, dy_rpb=n, dy_sb=PS * nz, dbias=self.g(f"{sp}.out.bias"))
+                dxt = buf(f"bw.dxt{l}", (M, H))
+                self._dgemm(plan, f"out{l}", [m._rowsrc(dEn, PS * nz, 2 * s * nz, nz)], M, H, n, Wt["out.wT"], dxt.data_ptr(), n * H, H)
+                merged = buf(f"merged{l}", (M, 2 * nl * H))
+                dmerged = buf(f"bw.dmerged{l}", (M, 2 * nl * H))
+                dh_src = dxt
+                for i in reversed(range(nl)):
+                    dg = buf(f"bw.dgates{l}.{i}", (M, 4 * H))
+                    a = rt.LstmBwdArgs()
+                    a.gates = rec[f"gates:lstm{l}.{i}"].data_ptr()
+                    a.c_prev, a.c_prev_stride = _addr(merged, (2 * i + 1) * H), 2 * nl * H
+                    a.c_new, a.pb, a.prow = _addr(Hid, s * SD + (2 * i + 1) * H), PS * SD, 2 * s * SD
+                    a.dh_dense, a.dh_stride = dh_src.data_ptr(), H
+                    a.dh_pos, a.dc_pos = _addr(dHid, s * SD + 2 * i * H), _addr(dHid, s * SD + (2 * i + 1) * H)
+                    a.dgates, a.dc_prev, a.dcp_stride = dg.data_ptr(), _addr(dmerged, (2 * i + 1) * H), 2 * nl * H
+                    a.M, a.H, a.rpb = M, H, n
+                    plan.keep.append(a)
+                    plan.add(f"bw.lstm{l}.{i}", lib.gcpx_lstm_bwd, C.byref(a))
+                    x_i = buf(f"x{l}.{i}", (M, H))
+                    self._wgrad(plan, f"lstm{l}.{i}.ih", dg.data_ptr(), 4 * H, M, 4 * H, x_i.data_ptr(), H,
+                                self.g(f"{sp}.lstm.{i}.weight_ih"), ldw=H, sr=H, sb=M * H, rpb=M,
+                                dbias=self.g(f"{sp}.lstm.{i}.bias_ih"), dbias2=self.g(f"{sp}.lstm.{i}.bias_hh"))
+                    self._wgrad(plan, f"lstm{l}.{i}.hh", dg.data_ptr(), 4 * H, M, 4 * H, _addr(merged, 2 * i * H), H,
+                                self.g(f"{sp}.lstm.{i}.weight_hh"), ldw=H, sr=2 * nl * H, sb=M * 2 * nl * H, rpb=M)
+                    dxi = buf(f"bw.dxi{l}.{i}", (M, H))
+                    src = [self._dense(dg.data_ptr(), 4 * H, 4 * H, M)]
+                    self._dgemm(plan, f"lstm{l}.{i}.x", src, M, H, M, Wt[f"lstm{i}.wxT"], dxi.data_ptr(), 0, H)
+                    self._dgemm(plan, f"lstm{l}.{i}.h", src, M, H, M, Wt[f"lstm{i}.whT"], _addr(dmerged, 2 * i * H), 0, 2 * nl * H)
+                    dh_src = dxi
+                dx0 = dh_src
+                # embedding of [e_l, e_r, z, e_0, e_g]
+                el = m._rowsrc(_addr(E), PS * nz, 2 * s * nz, nz)
+                er = m._rowsrc(_addr(E, 2 * s * nz), PS * nz, 2 * s * nz, nz)
+                zs = m._rowsrc(_addr(o["Z"], s * nv), PS * nv, 2 * s * nv, nv)
+                esrcs = [el, er, zs]
+                if hp.context_every_step:
+                    esrcs += [m._rowsrc(_addr(E), PS * nz, 0, nz), m._rowsrc(_addr(E, 2 ** L * nz), PS * nz, 0, nz)]
+                koff = 0
+                for i, sc in enumerate(esrcs):
+                    self._wgrad(plan, f"embed{l}.{i}", dx0.data_ptr(), H, M, H, sc.ptr, sc.width, self.g(f"{sp}.embed.weight"), ldw=pid,
+                                k_off=koff, rpb=n, sb=sc.sb, sr=sc.sr, dbias=(self.g(f"{sp}.embed.bias") if i == 0 else None))
+                    koff += sc.width
+                dpi = buf(f"bw.dpi{l}", (M, pid))
+                self._dgemm(plan, f"embed{l}", [self._dense(dx0.data_ptr(), H, H, M)], M, pid, M, Wt["embed.wT"], dpi.data_ptr(), 0, pid)
             def merge_backward():
+                if not hp.tree_lstm:
+                    return
                 if hp.tree_lstm == "sum":
                     # SumTree (tree_lstm.py:14-16): the gradient of the merged state goes to both parents unchanged
                     self._tree_accum(plan, f"hid{l}", dHid, PS * SD, 2 * s * SD, B, n, SD, [(dmerged.data_ptr(), SD, 0, 0, -1, -1, 0)])
@@ -756,7 +771,7 @@ class GCPTrainStep:
             dXi = None
             if not split:
                 merge_backward()
-            if l == 0 and hp.lstm_init == "mlp":
+            if l == 0 and hp.tree_lstm and hp.lstm_init == "mlp":
                 # MLP LSTM initialiser (tree_module.py:104-105): outputs live in Hid slots 0 and 2^L
                 dinit = buf("bw.dinit", (B, 2 * SD))
                 plan.add("bw.dinit.l", lib.gcpx_copy_rows, _addr(dHid), dinit.data_ptr(), B, 1, SD, PS, 2)
