@@ -18,6 +18,36 @@ def _free_port():
     return p
 
 
+def _run_ranks(worker, world=2, attempts=2):
+    """start `world` spawned processes of worker(rank, world, port, queue) and return what each put on the queue.  The rendezvous is
+    infrastructure (a port that was free a moment ago, process start-up under load): a run whose workers do not ALL deliver and exit
+    cleanly is repeated once on a fresh port; what the workers deliver is checked by the caller, never retried."""
+    import queue as _q
+    last = None
+    for _ in range(attempts):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = []
+        try:
+            for _ in procs:
+                res.append(q.get(timeout=180))
+        except _q.Empty:
+            last = "a rank delivered nothing within 180 s"
+        for p in procs:
+            p.join(60)
+            if p.exitcode is None:
+                p.kill()                               # (exactly this process: never by pattern)
+                p.join(10)
+        if len(res) == world and all(p.exitcode == 0 for p in procs):
+            return res
+        last = last or f"exit codes {[p.exitcode for p in procs]}"
+    raise AssertionError(f"the {world}-rank run failed twice: {last}")
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -40,16 +70,7 @@ def _worker(rank, world, port, q):
 
 
 def test_two_rank_gloo_path():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=180) for _ in procs)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = sorted(_run_ranks(_worker))
     (r0, s0, e0, c0, el0, v0), (r1, s1, e1, c1, el1, v1) = res
     assert s0 != s1                                  # different data shards
     assert e0 == e1 == 2.0                           # max over ranks
@@ -80,16 +101,7 @@ def _grad_worker(rank, world, port, q):
 def test_two_rank_gradient_all_reduce_keeps_replicas_identical():
     """the training step's only collective: sum all-reduce of the flat gradient, 1/world folded into the update"""
     from oracle.radam_oracle import RAdamOracle
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=180) for _ in procs)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = dict(_run_ranks(_grad_worker))
     assert torch.equal(res[0], res[1])
     g = torch.Generator().manual_seed(0)
     theta = {"p": torch.randn(1000, generator=g)}
@@ -150,16 +162,7 @@ def _bucket_worker(rank, world, port, q):
 def test_two_rank_bucketed_gradient_exchange():
     """the bucket scheduler GCPTrainStep drives (dist.GradBuckets): buckets started out of order while later slices are still
     being produced give the plain sum on every rank, bit-identical across ranks"""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=180) for _ in procs)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = dict(_run_ranks(_bucket_worker))
     for step in range(2):
         want = sum(torch.randn(1000, generator=torch.Generator().manual_seed(10 * step + r)) for r in range(2))
         assert torch.equal(res[0][step], res[1][step])
@@ -218,16 +221,7 @@ def test_two_rank_exchange_rearms_every_backward():
     """GCPTrainStep's exchange hooks (GradBuckets.begin / _on_mark / finish) around a stub backward plan, two gloo ranks: after two
     backward passes with no optimizer step in between, the gradient handed to the optimizer is the cross-rank sum of the SECOND pass
     for every bucket (round-2 advisor finding: stale works made the second pass skip the tree buckets)."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_rebackward_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=180) for _ in procs)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = dict(_run_ranks(_rebackward_worker))
     for k, base in enumerate((200, 300)):
         want = sum(torch.randn(1000, generator=torch.Generator().manual_seed(base + r)) for r in range(2))
         assert res[0][k][0] == 0.5
