@@ -84,10 +84,29 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     if hp.attach_state_regressor:
         reg_in = mes.detach()                                         # base_gcp.py:253-255 (supervised_decoder=False)
         out["regressed_state"] = O.predictor(sd, "state_regressor", hp, reg_in.reshape(-1, mes.shape[-1])).reshape(B, mes.shape[1], -1)
+    # run_auxilliary_models (base_gcp.py:234-262) is BaseGCPModel's: the same branches as in gcp_model_oracle.forward
     if hp.attach_inv_mdl and phase == "train":
-        e1 = mes[:, 1:]
-        e0s = inp["enc_traj_seq"][:, :-1][:, :e1.shape[1]] if "enc_traj_seq" in inp else mes[:, :-1]
-        out["actions"] = O.predictor(sd, "inv_mdl.action_pred", hp, torch.cat([e0s, e1], 2).reshape(-1, 2 * hp.nz_enc)).reshape(B, e1.shape[1], -1)
+        if sample_prior or hp.train_inv_mdl_full_seq or "inv_t0" not in inp:      # base_gcp.py:250 (val_mode sets _inv_mdl_full_seq)
+            e1 = mes[:, 1:]
+            e0s = inp["enc_traj_seq"][:, :-1][:, :e1.shape[1]] if "enc_traj_seq" in inp else mes[:, :-1]
+            a = O.predictor(sd, "inv_mdl.action_pred", hp, torch.cat([e0s, e1], 2).detach().reshape(-1, 2 * hp.nz_enc))
+            out["actions"] = a.reshape(B, e1.shape[1], -1)
+        else:
+            # InverseModel.forward, sampled pair (inverse_mdl.py:136-178); the np.random draws of sample_offsets are inputs
+            ar = torch.arange(B)
+            t0, t1 = inp["inv_t0"], inp["inv_t1"]
+            enc_im0, enc_im1 = inp["enc_traj_seq"][ar, t0].detach(), mes[ar, t1].detach()
+            out["actions_sampled"] = O.predictor(sd, "inv_mdl.action_pred", hp, enc_im0, enc_im1)      # [B, n_actions]
+            if "actions" in inp:
+                out["action_targets"] = inp["actions"][ar, t0]
+    if hp.attach_cost_mdl and hp.run_cost_mdl and phase == "train" and "cost_start_idx" in inp and "traj_seq" in inp:
+        # CostModel.forward (cost_mdl.py:42-57) with _general_cost's np.random draws fed as inputs (:101-117)
+        from . import aux_models_oracle as AX
+        ar = torch.arange(B)
+        s_idx, e_idx = inp["cost_start_idx"], inp["cost_end_idx"]
+        start, end = mes[ar, s_idx].detach(), mes[ar, e_idx].detach()
+        out["cost"] = O.predictor(sd, "cost_mdl.cost_pred", hp, torch.cat([start, end], dim=-1))
+        out["cost_target"] = torch.as_tensor(AX.euclidean_path_cost(inp["traj_seq"].detach().numpy(), s_idx.numpy(), e_idx.numpy()))
     return out
 
 
@@ -116,6 +135,12 @@ def losses(sd, hp, inputs, out):
         rl = out["regressed_state"].shape[1]
         e = (out["regressed_state"] - inputs["traj_seq_states"][:, :rl]) ** 2 * pm[:, :rl, None]
         res["state_regression"] = (e.mean(), 1.0)
+    if hp.attach_inv_mdl and "action_targets" in out:                 # base_gcp.py:275-276, inverse_mdl.py:181-191
+        from . import aux_models_oracle as AX
+        res["action_reconst"] = (AX.l2_loss(out["actions_sampled"], out["action_targets"], 1.0), hp.action_rec_weight)
+    if hp.attach_cost_mdl and hp.run_cost_mdl and "cost" in out:      # base_gcp.py:279-280, cost_mdl.py:59-62
+        from . import aux_models_oracle as AX
+        res["cost_estimation"] = (AX.l2_loss(out["cost"], out["cost_target"]), 1.0)
     total = sum(v * w for v, w in res.values() if w > 0) / float(torch.tensor(inputs["traj_seq"].shape[1:]).prod())
     return res, total
 

@@ -44,7 +44,10 @@ def test_sequential_posterior_forward_and_losses(dist, training_bn):
     aux = model.aux_outputs(out)
     assert_close(aux.model_enc_seq, ref["model_enc_seq"], 1e-4, 1e-3, "model_enc_seq")
     assert_close(aux.regressed_state, ref["regressed_state"], 1e-4, 1e-3, "regressed_state")
-    assert_close(aux.actions, ref["actions"], 1e-4, 1e-3, "actions")
+    # (train phase with the index draws fed: ONE sampled frame pair per sequence, inverse_mdl.py:136-178, and the cost model's segment)
+    assert_close(aux.actions, ref["actions_sampled"], 1e-4, 1e-3, "actions")
+    assert_close(aux.cost, ref["cost"], 1e-4, 1e-3, "cost")
+    assert_close(aux.cost_target.reshape(-1), ref["cost_target"].float().reshape(-1), 1e-3, 1e-4, "cost_target")
     ref_losses, ref_total = S.losses(sd, hp, inputs, ref)
     losses = model.loss(dev_in, out)
     for name, (val, w) in ref_losses.items():
@@ -95,7 +98,7 @@ def test_sequential_gradients_match_autograd(variant):
     assert not bad, bad[:10]
     # everything the loss terms reach is trained: encoder, decoder, the three recurrent nets, the length predictor, the state regressor
     for pre in ("encoder.", "decoder.", "dense_rec.lstm.cell.prior_lstm.", "dense_rec.lstm.cell.inf_lstm.", "dense_rec.lstm.cell.gen_lstm.",
-                "length_pred.", "state_regressor."):
+                "length_pred.", "state_regressor.", "inv_mdl.", "cost_mdl."):
         ks = [k for k in gref if k.startswith(pre)]
         assert ks and any(float(got[k].abs().max()) > 0 for k in ks), pre
 

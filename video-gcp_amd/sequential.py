@@ -18,7 +18,7 @@ from .params import init_params_sequential
 
 class GCPSequentialModel(GCPTreeModel):
     # the flat baseline is trained without the sampled inverse-model / cost-model pairs and always rolls out to the fed end_ind
-    _has_aux_training = False
+    _has_aux_training = True      # sampled inverse-model / cost-model training pairs (base_gcp.py:249-260), as for the tree model
     _has_pred_length = False
     _has_training = True              # training_sequential.SequentialTrainStep
 
@@ -112,6 +112,11 @@ class GCPSequentialModel(GCPTreeModel):
         idx = self._buf("seq.idx", (B, T), torch.int32)
         seq_len = self._buf("seq.len", (B,), torch.int32)
         plan.add("seq_index", lib.gcpx_seq_index, tin["end_ind"].data_ptr(), B, T, idx.data_ptr(), seq_len.data_ptr())
+        train_aux = has_traj and phase == "train" and not sample_prior    # the posterior path of a training / validation-loss forward
+        if "aux_n" in tin:
+            AUXK = ("inv_t0", "inv_t1", "cost_start_idx", "cost_end_idx")
+            plan.add("aux_sample_indices", lib.gcpx_aux_sample_indices_gauss, tin["end_ind"].data_ptr(), tin["aux_n"].data_ptr(), B,
+                     hp.inv_mdl_temp_dist, *[tin[k].data_ptr() for k in AUXK])
 
         # ---- run_encoder (base_gcp.py:184-213) ----
         enc_traj = None
@@ -119,6 +124,12 @@ class GCPSequentialModel(GCPTreeModel):
         plan.lane = 1
         skips = self._plan_encoder(plan, "I0", tin["I_0"].data_ptr(), B, _addr(X), T * nz, 0, 1)
         plan.lane = 2
+        if hp.attach_cost_mdl and hp.run_cost_mdl and train_aux and "cost_start_idx" in tin:
+            # ground-truth cost of the cost model's sampled segment (cost_mdl.py:101-117, EuclideanPathLength), beside the I_g encoder
+            rows = hp.input_nc * hp.img_sz
+            plan.add("path_cost", lib.gcpx_path_cost, tin["traj_seq"].data_ptr(), tin["cost_start_idx"].data_ptr(),
+                     tin["cost_end_idx"].data_ptr(), B, T, rows, hp.img_sz, self._buf("cost_partial", (B, rows)).data_ptr(),
+                     self._buf("cost_target", (B,)).data_ptr())
         self._plan_encoder(plan, "Ig", tin["I_g"].data_ptr(), B, _addr(EG), nz, 0, 1)
         plan.lane = 0
         if has_traj:
@@ -281,7 +292,9 @@ class GCPSequentialModel(GCPTreeModel):
             self._mlp(plan, "state_regressor", P["state_regressor"], [self._rowsrc(mes.data_ptr(), T * nz, nz, nz)],
                       B * T, T, out=rs.data_ptr(), ob=T * hp.state_dim, orow=hp.state_dim)
             outs["regressed_state_padded"] = rs
-        if hp.attach_inv_mdl and phase == "train":
+        aux_ok = train_aux and "inv_t0" in tin
+        if hp.attach_inv_mdl and phase == "train" and (sample_prior or hp.train_inv_mdl_full_seq or not has_traj or not aux_ok):
+            # InverseModel.full_seq_forward (inverse_mdl.py:110-134): val_mode sets _inv_mdl_full_seq (base_gcp.py:44-53,250)
             act = self._buf("actions", (B, T - 1, hp.n_actions))
             first = enc_traj if has_traj else mes
             s0 = self._rowsrc(first.data_ptr(), T * nz, nz, nz)
@@ -289,6 +302,21 @@ class GCPSequentialModel(GCPTreeModel):
             self._mlp(plan, "inv_mdl", P["inv_mdl"], [s0, s1], B * (T - 1), T - 1, out=act.data_ptr(),
                       ob=(T - 1) * hp.n_actions, orow=hp.n_actions)
             outs["actions_padded"] = act
+        if aux_ok and ((hp.attach_inv_mdl and not hp.train_inv_mdl_full_seq) or (hp.attach_cost_mdl and hp.run_cost_mdl)):
+            # run_auxilliary_models on ONE sampled frame pair / segment per sequence, as GCPTreeModel._build_plan (base_gcp.py:249-260)
+            aux_rows = self._buf("aux_rows", (4, B), torch.int32)
+            plan.add("aux_index_rows", lib.gcpx_aux_index_rows, tin["inv_t0"].data_ptr(), tin["inv_t1"].data_ptr(),
+                     tin["cost_start_idx"].data_ptr(), tin["cost_end_idx"].data_ptr(), B, T, T, aux_rows.data_ptr())
+            gather = lambda t, i: self._rowsrc(t.data_ptr(), 0, nz, nz, rowidx=aux_rows[i])
+            if hp.attach_inv_mdl and not hp.train_inv_mdl_full_seq:
+                act = self._buf("actions_sampled", (B, hp.n_actions))
+                self._mlp(plan, "inv_mdl", P["inv_mdl"], [gather(enc_traj, 0), gather(mes, 1)], B, B, out=act.data_ptr(), ob=0,
+                          orow=hp.n_actions)
+                outs["actions_sampled"] = act
+            if hp.attach_cost_mdl and hp.run_cost_mdl:
+                cost = self._buf("cost_pred", (B, 1))
+                self._mlp(plan, "cost_mdl", P["cost_mdl"], [gather(mes, 2), gather(mes, 3)], B, B, out=cost.data_ptr(), ob=0, orow=1)
+                outs["cost_pred"], outs["cost_target"] = cost, self._buf("cost_target", (B,))
         plan.lane = 0
 
         # ---- decoder over the T-1 predicted latents of every sequence (sequential.py:56) ----
@@ -379,6 +407,11 @@ class GCPSequentialModel(GCPTreeModel):
                 # state regression over the frames of the sequence, frame 0 included (base_gcp.py:281-286)
                 la.regressed_state, la.state_target = outs["regressed_state_padded"].data_ptr(), tin["traj_seq_states"].data_ptr()
                 la.state_mask, la.w_state = tin["pad_mask"].data_ptr(), 1.0
+            if "actions_sampled" in outs and "actions" in tin:          # inverse_mdl.py:181-191
+                la.action_pred, la.action_seq, la.inv_t0 = outs["actions_sampled"].data_ptr(), tin["actions"].data_ptr(), tin["inv_t0"].data_ptr()
+                la.n_actions, la.w_action = hp.n_actions, hp.action_rec_weight
+            if "cost_pred" in outs:                                     # cost_mdl.py:59-62
+                la.cost_pred, la.cost_target, la.w_cost = outs["cost_pred"].data_ptr(), outs["cost_target"].data_ptr(), 1.0
             la.total_div = float(T * hp.input_nc * S * S)
             plan.keep.append(la)
             plan.add("loss.combine", lib.gcpx_loss_combine, C.byref(la))
@@ -412,7 +445,7 @@ class GCPSequentialModel(GCPTreeModel):
         lens = out.raw["seq_len"].tolist()
         return [out.raw["images"][b, :lens[b]] for b in range(len(lens))]
 
-    LOSS_NAMES = ("dense_img_rec", "kl", "len_pred", "state_regression")
+    LOSS_NAMES = ("dense_img_rec", "kl", "len_pred", "state_regression", "action_reconst", "cost_estimation")
 
     def loss(self, inputs, outputs, log_error_arr=False):
         raw = outputs.raw
@@ -426,5 +459,9 @@ class GCPSequentialModel(GCPTreeModel):
             res["len_pred"] = Outputs(value=lv[2], weight=hp.length_pred_weight)
         if "regressed_state_padded" in raw and "traj_seq_states" in inputs:
             res["state_regression"] = Outputs(value=lv[4], weight=1.0)
+        if raw.get("actions_sampled") is not None and "actions" in inputs:      # base_gcp.py:275-276, inverse_mdl.py:181-191
+            res["action_reconst"] = Outputs(value=lv[7], weight=hp.action_rec_weight)
+        if raw.get("cost_pred") is not None:                                    # base_gcp.py:279-280, cost_mdl.py:59-62
+            res["cost_estimation"] = Outputs(value=lv[8], weight=1.0)
         res["_total"] = lv[5]
         return res

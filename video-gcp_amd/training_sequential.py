@@ -65,6 +65,10 @@ class SequentialTrainStep(GCPTrainStep):
             X["length_pred"] = self._pack_predictor_T(sd, "length_pred.p", [(0, 2 * nz)])
         if hp.attach_state_regressor:
             X["state_regressor"] = self._pack_predictor_T(sd, "state_regressor", [])
+        if hp.attach_inv_mdl:
+            X["inv_mdl"] = self._pack_predictor_T(sd, "inv_mdl.action_pred", [])
+        if hp.attach_cost_mdl:
+            X["cost_mdl"] = self._pack_predictor_T(sd, "cost_mdl.cost_pred", [])
         for net in NETS:
             p = f"dense_rec.lstm.cell.{net}"
             T_ = {"embed.wT": pk.pack_gemm(sd[f"{p}.embed.weight"].t().contiguous()),          # [n = in_dim][k = H]
@@ -161,6 +165,17 @@ class SequentialTrainStep(GCPTrainStep):
         if has_state:   # input detached (base_gcp.py:253-256): parameter gradients only
             self._mlp_bwd(plan, "state_regressor", "state_regressor", rec["mlp:state_regressor"], self.bk["state_regressor"],
                           dstate.data_ptr(), 16, [])
+        # inverse model / cost model on the sampled pairs: inputs detached (inverse_mdl.py:160-162, cost_mdl.py:108-109) — parameter
+        # gradients only
+        has_inv, has_cost = bool(la.action_pred), bool(la.cost_pred)
+        if has_inv or has_cost:
+            daction = buf("bw.daction", (B, 16)) if has_inv else None
+            dcost = buf("bw.dcost", (B, 16)) if has_cost else None
+            plan.add("bw.aux_heads", lib.gcpx_loss_aux_heads_bwd, C.byref(la), rt.ptr(daction), rt.ptr(dcost))
+            if has_inv:
+                self._mlp_bwd(plan, "inv_mdl", "inv_mdl.action_pred", rec["mlp:inv_mdl"], self.bk["inv_mdl"], daction.data_ptr(), 16, [])
+            if has_cost:
+                self._mlp_bwd(plan, "cost_mdl", "cost_mdl.cost_pred", rec["mlp:cost_mdl"], self.bk["cost_mdl"], dcost.data_ptr(), 16, [])
         if hp.regress_length:
             dXl = buf("bw.dX.len", (B, 2 * nz))
             self._mlp_bwd(plan, "length_pred", "length_pred.p", rec["mlp:length_pred"], self.bk["length_pred"], dlen.data_ptr(), ldl,
