@@ -376,6 +376,9 @@ typedef struct gcpx_loss_args {
     /* weights of the state regression when they differ from pad_mask (gcp_sequential: pad_mask above is the reconstruction
        weight with frame 0 zeroed, sequential.py:63-66, while the regressor still sees frame 0, base_gcp.py:281-286); NULL = pad_mask */
     const float* state_mask;      /* [B*T] or NULL */
+    /* KL weight under a schedule (kl_weight_burn_in, base_gcp.py:121-128: the weight ramps from 0 to its target over the first
+       iterations): when set, the weight is read from this device scalar instead of w_kl, so a captured graph sees the current value */
+    const float* w_kl_dev;
 } gcpx_loss_args;
 
 int gcpx_dlm_nll(const float* params, const float* target, const float* row_weight, float* nll_out, int32_t rows,
@@ -587,6 +590,11 @@ int gcpx_kl_bwd(const float* qz, const float* pz, float* dqz, float* dpz, int32_
    gradient rows scaled by node_weight[b * weight_bstride + n] */
 int gcpx_kl_bwd_weighted(const float* qz, const float* pz, float* dqz, float* dpz, int32_t B, int32_t N, int32_t nz, int64_t batch_stride,
                          int64_t node_stride, float free_nats, float coef, const float* node_weight, int64_t weight_bstride, void* stream);
+/* the general form with the scheduled part of the weight in device memory: gradient rows scaled by coef * (*coef_dev) (* node_weight
+   when given) — the KL weight burn-in (base_gcp.py:121-128) */
+int gcpx_kl_bwd_scheduled(const float* qz, const float* pz, float* dqz, float* dpz, int32_t B, int32_t N, int32_t nz, int64_t batch_stride,
+                          int64_t node_stride, float free_nats, float coef, const float* node_weight, int64_t weight_bstride,
+                          const float* coef_dev, void* stream);
 /* one tree level: dq_out[r] = dqz_pos[r] + [dz, dz * exp(log_sigma_q) * eps] (reparametrised sample backward,
    tree_module.py:86-94), dp_out[r] = dpz_pos[r]; rows r = (b, j) of the level; *_pos at base + b*pb + j*prow;
    dz = dz0[r*ldz0 ..] (+ dz1[r*ldz1 ..]); eps at eps + b*eb + j*erow */

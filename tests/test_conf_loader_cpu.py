@@ -58,7 +58,7 @@ def test_sequential_conf_selects_the_flat_model(tmp_path):
     hp, trainer, ignored = CL.load_conf(str(tmp_path), max_seq_len=80, img_sz=64)
     assert trainer["model"] == "sequential" and trainer["lr"] == 2e-4
     assert hp.nz_mid_lstm == 1024 and hp.free_nats == 1 and hp.hierarchy_levels == 7 and hp.max_seq_len == 80
-    assert "kl_weight_burn_in" in ignored
+    assert hp.kl_weight_burn_in == 1e4 and "kl_weight_burn_in" not in ignored      # base_gcp.py:121-128
 
 
 def test_adaptive_base_config_and_errors(tmp_path):

@@ -296,3 +296,26 @@ def test_gradients_tree_lstm_variants_c1(tree_lstm, lstm_init):
     torch.cuda.synchronize()
     gref, _, _, _ = O.gradients(sd, hp, inputs, noise)
     _compare_grads(gref, tr.named_grads(), rtol=5e-3)
+
+
+def test_kl_weight_burn_in_follows_the_step_counter():
+    """kl_weight_burn_in (hyperparameters.py:42, base_gcp.py:121-128; the 25-room gcp_sequential conf sets 1e4): the KL weight starts at 0
+    and is kl_weight * min(1, steps / burn_in) after `steps` calls of model.step() (LinearUpdater is blox, absent: this build's spec).
+    The weight lives in a device scalar, so the CAPTURED forward graph and the backward plan built at weight 0 must give the loss and
+    every gradient of the oracle at the current weight."""
+    import dataclasses
+    from oracle import gcp_model_oracle as O
+    hp, sd, model, tr = _setup("c1", True, kl_weight_burn_in=4.0)
+    inputs, noise, _ = make_inputs(hp, seed=11, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    for steps, w in ((0, 0.0), (2, 0.5), (9, 1.0)):
+        while getattr(model, "n_steps", 0) < steps:
+            model.step()
+        assert abs(model.kl_weight_now - w * hp.kl_weight) < 1e-12
+        out = tr.backward(dev_in, noise.cuda())
+        torch.cuda.synchronize()
+        hp_w = dataclasses.replace(hp, kl_weight=w * hp.kl_weight, kl_weight_burn_in=None)
+        gref, res, total, _ = O.gradients(sd, hp_w, inputs, noise)
+        assert abs(float(out.raw["losses"][5]) - float(total)) <= 2e-5 * abs(float(total)), (steps, float(out.raw["losses"][5]), float(total))
+        assert abs(float(model.loss(dev_in, out)["kl"].weight) - w * hp.kl_weight) < 1e-12
+        _compare_grads(gref, tr.named_grads(), rtol=2e-3)

@@ -140,10 +140,12 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
 __global__ void __launch_bounds__(256) kl_bwd_kernel(const float* __restrict__ qz, const float* __restrict__ pz,
                                                      float* __restrict__ dqz, float* __restrict__ dpz, const int N, const int nz,
                                                      const long long batch_stride, const long long node_stride,
-                                                     const float free_nats, const float coef, const int total,
-                                                     const float* __restrict__ node_weight, const long long weight_bstride) {
+                                                     const float free_nats, float coef, const int total,
+                                                     const float* __restrict__ node_weight, const long long weight_bstride,
+                                                     const float* __restrict__ coef_dev) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
+    if (coef_dev) coef *= *coef_dev;                         // (the scheduled part of the KL weight lives in device memory)
     const int d = idx % nz, n = (idx / nz) % N, b = idx / (nz * N);
     const size_t o = (size_t)b * batch_stride + (size_t)n * node_stride;
     const float mq = qz[o + d], lq = qz[o + nz + d], mp = pz[o + d], lp = pz[o + nz + d];
@@ -956,7 +958,7 @@ extern "C" int gcpx_kl_bwd(const float* qz, const float* pz, float* dqz, float* 
     GCPX_CHECK_ARG(qz && pz && dqz && dpz && B > 0 && N > 0 && nz > 0, "bad arguments");
     const int total = B * N * nz;
     hipLaunchKernelGGL(kl_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, qz, pz, dqz, dpz, N, nz,
-                       (long long)batch_stride, (long long)node_stride, free_nats, coef, total, (const float*)nullptr, 0ll);
+                       (long long)batch_stride, (long long)node_stride, free_nats, coef, total, (const float*)nullptr, 0ll, (const float*)nullptr);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }
@@ -968,7 +970,20 @@ extern "C" int gcpx_kl_bwd_weighted(const float* qz, const float* pz, float* dqz
     GCPX_CHECK_ARG(qz && pz && dqz && dpz && node_weight && B > 0 && N > 0 && nz > 0, "bad arguments");
     const int total = B * N * nz;
     hipLaunchKernelGGL(kl_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, qz, pz, dqz, dpz, N, nz,
-                       (long long)batch_stride, (long long)node_stride, free_nats, coef, total, node_weight, (long long)weight_bstride);
+                       (long long)batch_stride, (long long)node_stride, free_nats, coef, total, node_weight, (long long)weight_bstride,
+                       (const float*)nullptr);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_kl_bwd_scheduled(const float* qz, const float* pz, float* dqz, float* dpz, int32_t B, int32_t N, int32_t nz,
+                                     int64_t batch_stride, int64_t node_stride, float free_nats, float coef, const float* node_weight,
+                                     int64_t weight_bstride, const float* coef_dev, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(qz && pz && dqz && dpz && coef_dev && B > 0 && N > 0 && nz > 0, "bad arguments");
+    const int total = B * N * nz;
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, qz, pz, dqz, dpz, N, nz,
+                       (long long)batch_stride, (long long)node_stride, free_nats, coef, total, node_weight, (long long)weight_bstride, coef_dev);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

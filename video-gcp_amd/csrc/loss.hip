@@ -273,7 +273,8 @@ __global__ void __launch_bounds__(256) loss_combine_kernel(const gcpx_loss_args 
         a.out[0] = rec; a.out[1] = kl; a.out[2] = ce; a.out[3] = bce; a.out[4] = sreg;
         float total = 0.f;
         if (a.w_rec > 0.f) total += a.w_rec * rec;
-        if (a.w_kl > 0.f) total += a.w_kl * kl;
+        const float w_kl = a.w_kl_dev ? *a.w_kl_dev : a.w_kl;       // (burn-in schedule: the current weight lives in device memory)
+        if (w_kl > 0.f) total += w_kl * kl;
         if (a.w_len > 0.f) total += a.w_len * ce;
         if (a.w_exist > 0.f) total += a.w_exist * bce;
         if (a.w_state > 0.f) total += a.w_state * sreg;

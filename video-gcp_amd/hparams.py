@@ -70,6 +70,7 @@ class GCPHParams:
     gn_eps: float = 1e-5
     # loss weights (hyperparameters.py:38-46)
     kl_weight: float = 1.0
+    kl_weight_burn_in: float = None    # hyperparameters.py:42, base_gcp.py:121-128: iterations over which the KL weight ramps 0 -> kl_weight
     length_pred_weight: float = 1.0
     dense_img_rec_weight: float = 1.0
     entropy_weight: float = 0.0

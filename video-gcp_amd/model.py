@@ -156,6 +156,7 @@ class GCPTreeModel:
             with torch.cuda.device(self.device):
                 rt.check(self.lib.gcpx_stream_create(C.byref(sp)), "stream_create")
             self._streams.append(sp)
+        self._set_kl_weight()
         self.save_for_backward = False        # training step: forward plans keep what the backward pass needs
         # split-f16 convs (csrc/conv3x3_split.hip): f32-equivalent results on the f16 matrix pipes.  GCPX_EXACT_F32=1 keeps every
         # conv on the exact f32 MFMA kernels
@@ -257,9 +258,23 @@ class GCPTreeModel:
 
     def step(self):
         """BaseModel.step (base_model.py:24-25, called once per optimisation step, train.py:163): advances the `Updater` children.
-        The only one the reference builds is the KL-weight burn-in (base_gcp.py:125-131, kl_weight_burn_in=None by default), which
-        this build does not have, so this counts steps."""
+        The only one the reference builds is the KL-weight burn-in (base_gcp.py:121-128, kl_weight_burn_in=None by default):
+        `LinearUpdater(kl_weight, n_iter, target)` is blox (absent) — this build's spec: the weight starts at 0 (the reference
+        initialises the parameter with zeros) and is target * min(1, steps / n_iter) after `steps` calls.  The current value lives in a
+        device scalar that the loss kernels and the KL backward read, so captured graphs need no rebuild."""
         self.n_steps = getattr(self, "n_steps", 0) + 1
+        self._set_kl_weight()
+
+    def _set_kl_weight(self):
+        hp = self._hp
+        if hp.kl_weight_burn_in:
+            w = hp.kl_weight * min(1.0, getattr(self, "n_steps", 0) / float(hp.kl_weight_burn_in))
+            if getattr(self, "_kl_w", None) is None:
+                self._kl_w = torch.zeros(1, device=self.device)
+            self._kl_w.fill_(w)
+            self.kl_weight_now = w
+        else:
+            self._kl_w, self.kl_weight_now = None, hp.kl_weight
 
     def load_state_dict(self, sd, strict=True):
         for k, v in sd.items():
@@ -1259,6 +1274,8 @@ class GCPTreeModel:
             loss_out = self._buf("losses", (16,), zero=True)
             la.out, la.B, la.T, la.N, la.state_dim = loss_out.data_ptr(), B, T, (N - 1 if adaptive else N), hp.state_dim
             la.w_rec, la.w_kl, la.w_len, la.w_exist, la.w_state = hp.dense_img_rec_weight, hp.kl_weight, hp.length_pred_weight, 1.0, 1.0
+            if self._kl_w is not None:                   # burn-in schedule: the current weight is read from device memory
+                la.w_kl_dev = self._kl_w.data_ptr()
             la.total_div = float(T * hp.input_nc * hp.img_sz * hp.img_sz)
             plan.keep.append(la)
             return la, kl_b
@@ -1720,7 +1737,7 @@ class GCPTreeModel:
         if "losses" not in raw:
             raise ValueError("losses need traj_seq and pad_mask in the inputs of a phase='train' forward")
         hp, lv = self._hp, raw["losses"]
-        w = dict(dense_img_rec=hp.dense_img_rec_weight, kl=hp.kl_weight, len_pred=hp.length_pred_weight,
+        w = dict(dense_img_rec=hp.dense_img_rec_weight, kl=self.kl_weight_now, len_pred=hp.length_pred_weight,
                  existence_predictor=1.0, state_regression=1.0)
         res = Outputs()
         for i, name in enumerate(self.LOSS_NAMES):

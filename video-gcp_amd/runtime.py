@@ -40,7 +40,7 @@ class LossArgs(C.Structure):
                 ("B", i32), ("T", i32), ("N", i32), ("state_dim", i32), ("w_rec", C.c_float), ("w_kl", C.c_float),
                 ("w_len", C.c_float), ("w_exist", C.c_float), ("w_state", C.c_float), ("total_div", C.c_float),
                 ("action_pred", vp), ("action_seq", vp), ("inv_t0", vp), ("cost_pred", vp), ("cost_target", vp),
-                ("n_actions", i32), ("w_action", C.c_float), ("w_cost", C.c_float), ("state_mask", vp)]
+                ("n_actions", i32), ("w_action", C.c_float), ("w_cost", C.c_float), ("state_mask", vp), ("w_kl_dev", vp)]
 
 
 class RowSrc(C.Structure):
@@ -166,6 +166,7 @@ SYMBOLS = [
     ("gcpx_lrelu_bwd", C.c_int, [vp, vp, vp, i64, C.c_float, vp]),
     ("gcpx_kl_bwd", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i64, i64, C.c_float, C.c_float, vp]),
     ("gcpx_kl_bwd_weighted", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i64, i64, C.c_float, C.c_float, vp, i64, vp]),
+    ("gcpx_kl_bwd_scheduled", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i64, i64, C.c_float, C.c_float, vp, i64, vp, vp]),
     ("gcpx_rows_strided", C.c_int, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
     ("gcpx_latent_bwd", C.c_int, [vp, vp, vp, i64, i64, vp, i64, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp]),
     ("gcpx_tree_accum", C.c_int, [C.POINTER(TreeAccumArgs), vp]),

@@ -403,6 +403,8 @@ class GCPSequentialModel(GCPTreeModel):
             loss_out = self._buf("losses", (16,), zero=True)
             la.out, la.B, la.T, la.N, la.state_dim = loss_out.data_ptr(), B, T, T - 1, hp.state_dim
             la.w_rec, la.w_kl, la.w_len, la.w_exist, la.w_state = hp.dense_img_rec_weight, hp.kl_weight, hp.length_pred_weight, 0.0, 0.0
+            if self._kl_w is not None:                   # burn-in schedule (the 25-room gcp_sequential conf sets kl_weight_burn_in)
+                la.w_kl_dev = self._kl_w.data_ptr()
             if "regressed_state_padded" in outs and "traj_seq_states" in tin:
                 # state regression over the frames of the sequence, frame 0 included (base_gcp.py:281-286)
                 la.regressed_state, la.state_target = outs["regressed_state_padded"].data_ptr(), tin["traj_seq_states"].data_ptr()
@@ -454,7 +456,7 @@ class GCPSequentialModel(GCPTreeModel):
         hp, lv = self._hp, raw["losses"]
         res = Outputs()
         res["dense_img_rec"] = Outputs(value=lv[0], weight=hp.dense_img_rec_weight)
-        res["kl"] = Outputs(value=lv[1], weight=hp.kl_weight)
+        res["kl"] = Outputs(value=lv[1], weight=self.kl_weight_now)
         if hp.regress_length:
             res["len_pred"] = Outputs(value=lv[2], weight=hp.length_pred_weight)
         if "regressed_state_padded" in raw and "traj_seq_states" in inputs:

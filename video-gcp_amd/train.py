@@ -133,6 +133,9 @@ class ModelTrainer:
         self.global_step, epoch, opt = CK.load_weights(f, self.model, strict=bool(self.cmd_args.strict_weight_loading))
         if opt is not None:
             self.trainer.load_optimizer_state(opt)
+        # schedules follow the step counter (the KL-weight burn-in, base_gcp.py:121-128, counts model.step() calls)
+        self.model.n_steps = int(self.global_step)
+        self.model._set_kl_weight()
         self.model.train()
         return epoch + 1
 

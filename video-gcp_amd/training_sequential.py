@@ -154,8 +154,13 @@ class SequentialTrainStep(GCPTrainStep):
         la = rec["loss_args"]
         assert rec.get("nll_bwd_fused"), "the training forward produces d NLL / d parameters together with the loss"
         dMD = buf("bw.dMD", (B * T, S_, S_, m._head_pitch))
-        plan.add("bw.kl", lib.gcpx_kl_bwd_weighted, QZ.data_ptr(), PZ.data_ptr(), dQZ.data_ptr(), dPZ.data_ptr(), B, T - 1, nv,
-                 (T - 1) * 2 * nv, 2 * nv, C.c_float(hp.free_nats), C.c_float(hp.kl_weight / (B * div)), _addr(tin["pad_mask"], 1), T)
+        if m._kl_w is not None:                               # burn-in schedule: kl_weight(step) is read from device memory
+            plan.add("bw.kl", lib.gcpx_kl_bwd_scheduled, QZ.data_ptr(), PZ.data_ptr(), dQZ.data_ptr(), dPZ.data_ptr(), B, T - 1, nv,
+                     (T - 1) * 2 * nv, 2 * nv, C.c_float(hp.free_nats), C.c_float(1.0 / (B * div)), _addr(tin["pad_mask"], 1), T,
+                     m._kl_w.data_ptr())
+        else:
+            plan.add("bw.kl", lib.gcpx_kl_bwd_weighted, QZ.data_ptr(), PZ.data_ptr(), dQZ.data_ptr(), dPZ.data_ptr(), B, T - 1, nv,
+                     (T - 1) * 2 * nv, 2 * nv, C.c_float(hp.free_nats), C.c_float(hp.kl_weight / (B * div)), _addr(tin["pad_mask"], 1), T)
         ldl = _c16(T)
         has_state = bool(la.regressed_state)
         dlen = buf("bw.dlen", (B, ldl)) if hp.regress_length else None
