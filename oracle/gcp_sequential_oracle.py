@@ -10,6 +10,11 @@ PARITY UNPINNED: `blox.torch.models.vrnn.VRNNCell` is absent (empty submodule). 
     q(z_t | x_{t+1}, ctx)  = inf_lstm([enc(traj_{t+1}), e_0, e_g])
     x_{t+1}                = gen_lstm([x_t, z_t, e_0, e_g])
 run for T-1 steps from x_0 = e_0 (sequential.py:49-54); images = cat(I_0, decode(x_1..x_{T-1})) (:56-57).
+Variants (experiments/prediction/base_configs/vmpc.py:11-16):
+  action_conditioned_pred   a_t = action_encoder(actions[:, t]) (base_gcp.py:211-213) is `more_context` of the cell
+                            (sequential.py:45-49): appended to the input of every net at step t
+  var_inf = 'deterministic' nz_vae = 0: no prior / inference net, x_{t+1} = gen_lstm([x_t, e_0, e_g, a_t]), KL = 0
+  non_goal_conditioned      I_g and the sequence's end frame are zeroed before anything is encoded (base_gcp.py:163-170)
 """
 import torch
 import torch.nn.functional as F
@@ -33,12 +38,24 @@ def _hsp_step(sd, p, hp, state, x):
     return new, F.linear(x, sd[f"{p}.out.weight"], sd[f"{p}.out.bias"])
 
 
+def preprocess(hp, inputs):
+    """optional_preprocessing (base_gcp.py:163-170; the reference edits `inputs` in place, so its losses see the same tensors)."""
+    inp = dict(inputs)
+    if hp.non_goal_conditioned:
+        if "traj_seq" in inp:
+            inp["traj_seq"] = inp["traj_seq"].clone()
+            inp["traj_seq"][torch.arange(inp["traj_seq"].shape[0]), inp["end_ind"]] = 0.0
+        inp["I_g"] = torch.zeros_like(inp["I_g"])
+    return inp
+
+
 def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, phase="train"):
     """noise: eps [B, T-1, nz_vae]; inputs may carry z [B, T-1, nz_vae] (used as the latent directly)."""
     inp = dict(inputs)
     B = inp["I_0"].shape[0]
     T, H, nv = hp.max_seq_len, hp.nz_mid_lstm, hp.nz_vae
     out = {}
+    inp = preprocess(hp, inp)
     if "traj_seq" in inp:
         ts = inp["traj_seq"]
         enc, _ = O.encoder(sd, hp, ts.reshape(B * T, *ts.shape[2:]), training_bn)
@@ -50,12 +67,21 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     if hp.regress_length:
         out["seq_len_logits"] = O.predictor(sd, "length_pred.p", hp, e0, eg)
     ctx = [e0, eg] if hp.context_every_step else []
+    if hp.action_conditioned_pred:                                    # base_gcp.py:211-213: batch_apply(action_encoder, actions)
+        a = inp["actions"]
+        enc_act = O.predictor(sd, "action_encoder", hp, a.reshape(-1, a.shape[-1])).reshape(B, a.shape[1], -1)
     zero = lambda: [(torch.zeros(B, H), torch.zeros(B, H)) for _ in range(hp.n_lstm_layers)]
     sp, sq, sg = zero(), zero(), zero()
     p = "dense_rec.lstm.cell"
     x = e0
     xs, pzs, qzs, zs = [], [], [], []
     for t in range(T - 1):
+        if hp.action_conditioned_pred:
+            ctx = ctx[:2 if hp.context_every_step else 0] + [enc_act[:, t]]
+        if hp.deterministic:
+            sg, x = _hsp_step(sd, f"{p}.gen_lstm", hp, sg, torch.cat([x] + ctx, 1))
+            xs.append(x)
+            continue
         sp, pz = _hsp_step(sd, f"{p}.prior_lstm", hp, sp, torch.cat([x] + ctx, 1))
         if "enc_traj_seq" in inp:
             sq, qz = _hsp_step(sd, f"{p}.inf_lstm", hp, sq, torch.cat([inp["enc_traj_seq"][:, t + 1]] + ctx, 1))
@@ -70,7 +96,9 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
         sg, x = _hsp_step(sd, f"{p}.gen_lstm", hp, sg, torch.cat([x, z] + ctx, 1))
         xs.append(x); pzs.append(pz); qzs.append(qz); zs.append(z)
     enc = torch.stack(xs, 1)                                          # encodings [B, T-1, nz]
-    out["encodings"], out["p_z"], out["q_z"], out["z"] = enc, torch.stack(pzs, 1), torch.stack(qzs, 1), torch.stack(zs, 1)
+    out["encodings"] = enc
+    if not hp.deterministic:
+        out["p_z"], out["q_z"], out["z"] = torch.stack(pzs, 1), torch.stack(qzs, 1), torch.stack(zs, 1)
     dec = O.decode_seq(sd, hp, inp, enc, training_bn)                 # sequential.py:56
     out["distr"] = dec["distr"]
     out["images"] = torch.cat([inp["I_0"][:, None], dec["images"]], 1)   # :57
@@ -112,6 +140,7 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
 
 def losses(sd, hp, inputs, out):
     """decoder.loss on frames 1..T-1 + KL weighted by pad_mask[:, 1:] (sequential.py:60-68)."""
+    inputs = preprocess(hp, inputs)
     B, T = inputs["traj_seq"].shape[:2]
     pm = inputs["pad_mask"]
     tgt = inputs["traj_seq"][:, 1:]
@@ -125,9 +154,12 @@ def losses(sd, hp, inputs, out):
         nllpp = O.dlm_nll(d.reshape(B * (T - 1), *d.shape[2:]), tgt.reshape(B * (T - 1), *tgt.shape[2:]), hp).reshape(B, T - 1, -1)
         nll = (nllpp.sum(2) * pm[:, 1:]).sum() / B
     nv = hp.nz_vae
-    mq, lq, mp, lp = out["q_z"][..., :nv], out["q_z"][..., nv:], out["p_z"][..., :nv], out["p_z"][..., nv:]
-    kl = lp - lq + (torch.exp(2 * lq) + (mq - mp) ** 2) / (2 * torch.exp(2 * lp)) - 0.5
-    kl = torch.clamp(kl, min=hp.free_nats) * pm[:, 1:, None]
+    if hp.deterministic:
+        kl = torch.zeros(B, 1, 1)                                     # no latent: both distributions are empty
+    else:
+        mq, lq, mp, lp = out["q_z"][..., :nv], out["q_z"][..., nv:], out["p_z"][..., :nv], out["p_z"][..., nv:]
+        kl = lp - lq + (torch.exp(2 * lq) + (mq - mp) ** 2) / (2 * torch.exp(2 * lp)) - 0.5
+        kl = torch.clamp(kl, min=hp.free_nats) * pm[:, 1:, None]
     res = {"dense_img_rec": (nll, hp.dense_img_rec_weight), "kl": (kl.sum() / B, hp.kl_weight)}
     if hp.regress_length:
         res["len_pred"] = (F.cross_entropy(out["seq_len_logits"], inputs["end_ind"]), hp.length_pred_weight)

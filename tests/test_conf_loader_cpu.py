@@ -61,6 +61,31 @@ def test_sequential_conf_selects_the_flat_model(tmp_path):
     assert hp.kl_weight_burn_in == 1e4 and "kl_weight_burn_in" not in ignored      # base_gcp.py:121-128
 
 
+def test_vmpc_base_config_selects_the_action_conditioned_flat_model(tmp_path):
+    """experiments/prediction/base_configs/vmpc.py:11-16 on top of gcp_sequential: action-conditioned, not goal-conditioned, no latent"""
+    (tmp_path / "conf.py").write_text(textwrap.dedent('''
+        from blox import AttrDict
+        from experiments.prediction.base_configs import vmpc as base_conf
+        configuration = AttrDict(base_conf.configuration)
+        configuration.update({'batch_size': 16, 'lr': 2e-4})
+        model_config = AttrDict(base_conf.model_config)
+        model_config.update({'nz_mid_lstm': 512, 'inv_mdl_params': AttrDict(n_actions=2)})
+        model_config.pop("add_weighted_pixel_copy")
+    '''))
+    hp, trainer, ignored = CL.load_conf(str(tmp_path), max_seq_len=40, img_sz=32)
+    assert trainer["model"] == "sequential"
+    assert hp.action_conditioned_pred and hp.non_goal_conditioned and hp.deterministic and hp.nz_vae == 0 and hp.n_actions == 2
+    # the sequential parameter table of such a model: one recurrent net and the action encoder
+    from video_gcp_amd.params import param_table_sequential
+    tab = param_table_sequential(hp)
+    assert not any("prior_lstm" in k or "inf_lstm" in k for k in tab)
+    assert tab["action_encoder.input.linear.weight"][0] == (hp.nz_mid, hp.n_actions)
+    assert tab["dense_rec.lstm.cell.gen_lstm.embed.weight"][0] == (hp.nz_mid_lstm, 4 * hp.nz_enc)      # x, e_0, e_g, encoded action
+    import pytest
+    with pytest.raises(AssertionError):
+        CL.GCPHParams(var_inf="deterministic")            # a deterministic predictor has no latent (vmpc.py:14-15)
+
+
 def test_adaptive_base_config_and_errors(tmp_path):
     (tmp_path / "conf.py").write_text(textwrap.dedent('''
         from blox import AttrDict

@@ -296,3 +296,43 @@ def test_pddm_sampler_in_the_planner(setup):
                            elite_frac=0.25, max_seq_len=hp.max_seq_len)
     plan, actions, latents, score = planner(state, goal)
     assert np.isfinite(score) and float(sampler.mean.abs().max()) > 0 and torch.equal(sampler.std, torch.ones_like(sampler.std))
+
+
+def test_action_conditioned_simulator_and_flat_cem():
+    """ActCondGCPImageSimulator (cem_simulator.py:99-104; planner_policy.py:231 with act_cond): the candidates are action sequences
+    rolled out by an action-conditioned flat predictor (base_configs/vmpc.py).  Rollouts against the oracle, then the flat CEM loop
+    (FlatCEMSampler over [T - 1, n_actions]) with the learned cost on the rolled-out latents."""
+    import video_gcp_amd as V
+    from oracle import gcp_sequential_oracle as S
+    from video_gcp_amd.sequential import GCPSequentialModel
+    from video_gcp_amd.planning import ActCondGCPImageSimulator, CEMPlanner, FlatCEMSampler, LearnedCostEstimate, env2planner
+    hp = V.config("c1", nz_mid_lstm=128, lstm_init="zero", action_conditioned_pred=True, non_goal_conditioned=True, nz_vae=0,
+                  var_inf="deterministic")
+    sd = V.init_params_sequential(hp, seed=2, randomize_affine=True)
+    model = GCPSequentialModel(hp, params=sd, device="cuda")
+    model.eval()
+    state, goal = _env_images(hp, 4)
+    n, T = 4, hp.max_seq_len
+    acts = torch.randn(n, T - 1, hp.n_actions, generator=torch.Generator().manual_seed(0))
+    sim = ActCondGCPImageSimulator(model)
+    got = sim.rollout(state, goal, acts.numpy(), T)
+    inp = dict(I_0=env2planner(np.repeat(state, n, 0)), I_g=env2planner(np.repeat(goal, n, 0)), actions=acts,
+               end_ind=torch.full((n,), T - 1, dtype=torch.long))
+    ref = S.forward(sd, hp, inp, training_bn=False, sample_prior=True)
+    for i in range(n):
+        want = torch.cat((ref["pruned_prediction"][i].reshape(T, -1), ref["model_enc_seq_list"][i]), -1)
+        assert_close(got.predictions[i], want, 5e-5, 1e-3, "predictions")
+        assert_close(got.latents[i], ref["model_enc_seq"][i], 1e-4, 1e-3, "latents")
+    # the samples may arrive with the image simulator's two unit axes (cem_simulator.py:78,102)
+    r5 = sim.rollout_device(state, goal, acts[..., None, None], T)
+    assert_close(r5.latents, ref["model_enc_seq"], 1e-4, 1e-3, "latents, 5-d samples")
+
+    def plan(seed):
+        sampler = FlatCEMSampler(clip_val=float("inf"), n_steps=T - 1, action_dim=hp.n_actions, initial_std=1.0, device="cuda", seed=seed)
+        planner = CEMPlanner(sim, LearnedCostEstimate(model), sampler, n_iters=2, batch_size=16, elite_frac=0.25, max_seq_len=T)
+        return planner(state, goal), planner
+    (pred, actions, latents, cost), planner = plan(3)
+    assert pred.shape == (T, 3 * hp.img_sz ** 2 + hp.nz_enc) and latents.shape == (T, hp.nz_enc) and np.isfinite(cost)
+    assert len(planner.logs) == 2 and all(bool(torch.isfinite(l.elite_scores).all()) for l in planner.logs)
+    (pred2, _, _, cost2), _ = plan(3)
+    assert cost2 == cost and np.array_equal(pred2, pred)

@@ -140,3 +140,103 @@ def test_sequential_training_c2_shapes_decreases_loss():
         losses.append(float(out.raw["losses"][5]))
     assert all(torch.isfinite(torch.tensor(losses))) and torch.isfinite(tr.grad).all()
     assert losses[-1] < losses[0], losses
+
+
+# ---- flat-predictor variants of experiments/prediction/base_configs/vmpc.py:11-16 ----
+_VARIANTS = {
+    # the visual-MPC style predictor: action-conditioned, deterministic (no latent), not goal-conditioned
+    "vmpc": dict(action_conditioned_pred=True, non_goal_conditioned=True, nz_vae=0, var_inf="deterministic"),
+    # action conditioning alone: the VRNN keeps its latent, all three nets read the encoded action
+    "act_vrnn": dict(action_conditioned_pred=True),
+    # deterministic but goal-conditioned, no actions
+    "det": dict(nz_vae=0, var_inf="deterministic"),
+}
+
+
+def _variant_setup(name, **over):
+    import video_gcp_amd as V
+    from video_gcp_amd.sequential import GCPSequentialModel
+    hp = V.config("c1", nz_mid_lstm=128, lstm_init="zero", **_VARIANTS[name], **over)
+    sd = V.init_params_sequential(hp, seed=1, randomize_affine=True)
+    model = GCPSequentialModel(hp, params=sd, device="cuda")
+    inputs, noise, _ = make_inputs(hp, seed=5, variant="B")
+    noise = noise[:, :hp.max_seq_len - 1].contiguous() if hp.nz_vae else None
+    return hp, sd, model, inputs, noise
+
+
+@pytest.mark.parametrize("name", sorted(_VARIANTS))
+def test_sequential_variants_forward_and_losses(name):
+    """action_conditioned_pred (sequential.py:24-25,45-49; base_gcp.py:211-213), var_inf='deterministic' and non_goal_conditioned
+    (base_gcp.py:163-170) against the oracle: rollout, images, every loss term"""
+    from oracle import gcp_sequential_oracle as S
+    hp, sd, model, inputs, noise = _variant_setup(name)
+    ref = S.forward(sd, hp, inputs, noise=noise, training_bn=True)
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    keep = {k: v.clone() for k, v in dev_in.items()}
+    out = model(dev_in, "train", noise=(noise.cuda() if noise is not None else None))
+    torch.cuda.synchronize()
+    assert all(torch.equal(dev_in[k], keep[k]) for k in keep), "the caller's tensors are left alone"
+    assert_close(out.dense_rec.encodings, ref["encodings"], 1e-4, 1e-3, "encodings")
+    assert_close(out.dense_rec.images, ref["images"], 5e-5, 0, "images")
+    if hp.nz_vae:
+        assert_close(out.dense_rec.p_z, ref["p_z"], 1e-4, 1e-3, "p_z")
+        assert_close(out.dense_rec.q_z, ref["q_z"], 1e-4, 1e-3, "q_z")
+    ref_losses, ref_total = S.losses(sd, hp, inputs, ref)
+    losses = model.loss(dev_in, out)
+    for key, (val, w) in ref_losses.items():
+        got = float(losses[key].value)
+        assert abs(got - float(val)) <= 1e-4 * abs(float(val)) + 1e-5, (key, got, float(val))
+    assert abs(float(model.get_total_loss(dev_in, losses).value) - float(ref_total)) <= 1e-4 * abs(float(ref_total))
+    if hp.deterministic:
+        assert float(losses["kl"].value) == 0.0
+
+
+@pytest.mark.parametrize("name", ["vmpc", "act_vrnn"])
+def test_sequential_variants_rollout_from_actions(name):
+    """the planner's call (cem_simulator.py:99-104): start / goal image and an action sequence, no ground-truth frames; running-stat
+    BatchNorm, prior samples where the model has a latent"""
+    from oracle import gcp_sequential_oracle as S
+    hp, sd, model, inputs, noise = _variant_setup(name)
+    model.train(False)
+    feed = {k: inputs[k] for k in ("I_0", "I_g", "actions", "end_ind")}
+    ref = S.forward(sd, hp, feed, noise=noise, training_bn=False, sample_prior=True)
+    with model.val_mode():
+        out = model({k: v.cuda() for k, v in feed.items()}, "train", noise=(noise.cuda() if noise is not None else None))
+    torch.cuda.synchronize()
+    assert_close(out.dense_rec.encodings, ref["encodings"], 1e-4, 1e-3, "encodings")
+    assert_close(out.dense_rec.images, ref["images"], 5e-5, 0, "images")
+    # a different action sequence gives a different rollout
+    feed2 = dict(feed, actions=-feed["actions"])
+    with model.val_mode():
+        out2 = model({k: v.cuda() for k, v in feed2.items()}, "train", noise=(noise.cuda() if noise is not None else None))
+    assert float((out2.dense_rec.encodings - torch.as_tensor(ref["encodings"]).cuda()).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("name", sorted(_VARIANTS))
+def test_sequential_variants_gradients_match_autograd(name):
+    """explicit backward of the variants against torch autograd over the oracle: the action encoder is trained through every net that
+    reads the encoded action; a deterministic predictor has neither prior nor inference net (same tolerance as the base model)"""
+    from oracle import gcp_sequential_oracle as S
+    from video_gcp_amd.training_sequential import SequentialTrainStep
+    hp, sd, model, inputs, noise = _variant_setup(name)
+    tr = SequentialTrainStep(model, lr=1e-3)
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    for _ in range(2):
+        out = tr.backward(dev_in, noise.cuda() if noise is not None else None)
+    torch.cuda.synchronize()
+    gref, res, total, _ = S.gradients(sd, hp, inputs, noise)
+    assert abs(float(out.raw["losses"][5]) - float(total)) <= 1e-4 * abs(float(total))
+    got = tr.named_grads()
+    assert set(got) == set(gref)
+    bad = []
+    for k, g in gref.items():
+        err, scale = float((got[k].cpu() - g).abs().max()), float(g.abs().max())
+        if err > 1e-3 * scale + 5e-7:
+            bad.append((k, err, scale))
+    assert not bad, bad[:10]
+    pres = ["encoder.", "decoder.", "dense_rec.lstm.cell.gen_lstm."] + (["action_encoder."] if hp.action_conditioned_pred else []) + \
+        ([] if hp.deterministic else ["dense_rec.lstm.cell.prior_lstm.", "dense_rec.lstm.cell.inf_lstm."])
+    for pre in pres:
+        ks = [k for k in gref if k.startswith(pre)]
+        assert ks and any(float(got[k].abs().max()) > 0 for k in ks), pre
+    assert hp.deterministic == (not any("prior_lstm" in k for k in got))

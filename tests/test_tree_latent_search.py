@@ -43,3 +43,40 @@ def test_sample_layout_is_depth_first():
     assert z.shape == (10, 255, 3)
     # the root latent sits in the middle of the depth-first axis and differs per sample
     assert len({tuple(z[i, 127]) for i in range(10)}) == 10
+
+
+def test_generator_draws_run_the_same_search_on_fewer_gaussians():
+    """rng=np.random.Generator: only the rows the search keeps are drawn (below the level being optimised the reference draws
+    n_samples rows and keeps the first, tree_optimizer.py:76-82).  Same shapes, layout, completion schedule and selection rule as the
+    reference-stream mode; reproducible from the seed; the module-level np.random stream is left untouched."""
+    from planner_stubs import StubCost, stub_rollouts
+    from video_gcp_amd.tree_latent_search import ImageHierarchicalTreeLatentOptimizer
+
+    def search(rng, seed=5):
+        np.random.seed(seed)
+        cost = StubCost()
+        opt = ImageHierarchicalTreeLatentOptimizer(4, [3, 2], 5, cost, cost, 4, rng=rng)
+        goal = np.random.rand(1, 2, 2, 3)
+        trace = []
+        for it in range(3):
+            z = opt.sample()
+            best, c = opt.optimize(stub_rollouts(z), goal)
+            trace.append((z, np.asarray(best), bool(opt.fully_optimized)))
+        return trace, opt.sample()
+    ref_trace, ref_final = search(None)
+    a_trace, a_final = search(np.random.default_rng(11))
+    after = np.random.get_state()[1].copy()
+    np.random.seed(5)
+    np.random.rand(1, 2, 2, 3)                                                   # (the goal image of `search` is the only legacy draw)
+    assert np.array_equal(np.random.get_state()[1], after), "generator mode must not consume the legacy stream"
+    b_trace, b_final = search(np.random.default_rng(11))
+    for (za, ba, fa), (zb, bb, fb), (zr, br, fr) in zip(a_trace, b_trace, ref_trace):
+        assert np.array_equal(za, zb) and np.array_equal(ba, bb)                  # reproducible
+        assert za.shape == zr.shape and za.dtype == np.float32 and fa == fr       # same populations, same completion schedule
+    assert a_final.shape == ref_final.shape == (1, 31, 4) and np.array_equal(a_final, b_final)
+    # what was fixed in iteration 0 (the root latent of the chosen sample) stays in every later population
+    root = a_trace[1][0][:, 15]
+    assert all(np.array_equal(root[0], r) for r in root) and any(np.array_equal(root[0], z15) for z15 in a_trace[0][0][:, 15])
+    # the draws are standard normal
+    big = ImageHierarchicalTreeLatentOptimizer(64, [10, 10], 7, StubCost(), StubCost(), 5, rng=np.random.default_rng(0)).sample()
+    assert big.shape == (10, 127, 64) and abs(float(big.mean())) < 0.02 and abs(float(big.std()) - 1.0) < 0.02

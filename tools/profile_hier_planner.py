@@ -13,8 +13,9 @@ m.eval()
 rng = np.random.RandomState(0)
 state = rng.randint(0, 256, size=(1, hp.img_sz, hp.img_sz, 3)).astype(np.uint8)
 goal = rng.randint(0, 256, size=(1, hp.img_sz, hp.img_sz, 3)).astype(np.uint8)
+# FAST=1: fast_draws (numpy Generator, kept rows only); default: the reference's np.random stream
 pl = HierarchicalCEMPlanner(GCPImageSimulator(m, pred_length=False), LearnedCostEstimate(m), hp.hierarchy_levels, [10, 10], action_dim=hp.nz_vae,
-                            max_seq_len=hp.max_seq_len)
+                            max_seq_len=hp.max_seq_len, fast_draws=bool(os.environ.get("FAST")))
 for _ in range(3):
     pl(state, goal)
 torch.cuda.synchronize()

@@ -7,7 +7,7 @@ import `blox.AttrDict`, dataset / logger / cost-function classes and `experiment
 importable here — but only use them as VALUES of the two dicts.  `load_conf` therefore executes the file with
 
   * `blox.AttrDict` provided (a dict with attribute access),
-  * `experiments.prediction.base_configs.{base_tree, gcp_tree, gcp_adaptive, gcp_sequential}` provided with the same entries the
+  * `experiments.prediction.base_configs.{base_tree, gcp_tree, gcp_adaptive, gcp_sequential, vmpc}` provided with the same entries the
     reference's base configs hold (restated below as data: base_configs/*.py),
   * every other `blox.*` / `gcp.*` / `experiments.*` name resolved to an inert named placeholder,
 
@@ -54,6 +54,10 @@ _BASE_CONFIGS = {
                      dict(_BASE_TREE, matching_type="dtw_image", learn_matching_temp=False, attentive_inference=True)),
     "gcp_sequential": (dict(model="SequentialModel", logger="HierarchyLogger"),
                        dict(one_step_planner="continuous", dense_rec_type="svg", hierarchy_levels=0, add_weighted_pixel_copy=True)),
+    # base_configs/vmpc.py:11-16: gcp_sequential made action-conditioned, deterministic and blind to the goal
+    "vmpc": (dict(model="SequentialModel", logger="HierarchyLogger"),
+             dict(one_step_planner="continuous", dense_rec_type="svg", hierarchy_levels=0, add_weighted_pixel_copy=True,
+                  action_conditioned_pred=True, non_goal_conditioned=True, nz_vae=0, var_inf="deterministic")),
 }
 
 

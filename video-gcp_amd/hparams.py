@@ -63,6 +63,10 @@ class GCPHParams:
     run_cost_mdl: bool = True          # hyperparameters.py:63
     train_inv_mdl_full_seq: bool = False   # hyperparameters.py:108
     inv_mdl_temp_dist: int = 1         # inverse_mdl.py:39 (InverseModel default 'temp_dist')
+    # flat-predictor variants (gcp_sequential only; experiments/prediction/base_configs/vmpc.py:11-16 sets all four)
+    action_conditioned_pred: bool = False    # hyperparameters.py:65: the encoded action of every step feeds the recurrent nets
+    non_goal_conditioned: bool = False       # hyperparameters.py:89: goal image (and the sequence's end frame) zeroed, base_gcp.py:163-175
+    var_inf: str = "standard"                # hyperparameters.py:80; 'deterministic': no latent (nz_vae = 0); '2layer' is not built
     # build spec for what blox would define
     leaky_slope: float = 0.2
     bn_eps: float = 1e-5
@@ -86,7 +90,13 @@ class GCPHParams:
         assert self.nz_mid % self.gn_groups == 0 and self.init_mlp_mid_sz % self.gn_groups == 0
         assert self.decoder_distribution in ("discrete_logistic_mixture", "gaussian")
         assert self.matching_type in ("balanced", "dtw_image")
+        assert self.var_inf in ("standard", "deterministic"), "var_inf '2layer' is not built"
+        assert (self.var_inf == "deterministic") == (self.nz_vae == 0), "a deterministic predictor has no latent: nz_vae = 0 (vmpc.py:14-15)"
         assert self.nz_attn_key % self.n_attention_heads == 0 and self.nz_enc % self.n_attention_heads == 0
+
+    @property
+    def deterministic(self):
+        return self.var_inf == "deterministic"
 
     @property
     def adaptive(self):
@@ -133,6 +143,9 @@ def config(name, **over):
                    matching_type="dtw_image", attentive_inference=True),       # inference (base_configs/gcp_adaptive.py:6-11)
         "c5s": dict(batch_size=2, max_seq_len=12, img_sz=32,       # small adaptive case for parity tests (L=4, N=15)
                     matching_type="dtw_image", attentive_inference=True),
+        # the visual-MPC style flat predictor of base_configs/vmpc.py at the parity-test size (gcp_sequential only)
+        "vmpc_s": dict(batch_size=2, max_seq_len=8, img_sz=32, action_conditioned_pred=True, non_goal_conditioned=True,
+                       nz_vae=0, var_inf="deterministic"),
         "tiny": dict(batch_size=2, max_seq_len=6, img_sz=32, nz_mid_lstm=64, n_lstm_layers=2,
                      nz_vae=32, nz_enc=32, nz_mid=32),
     }[name]

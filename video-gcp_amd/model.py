@@ -199,6 +199,8 @@ class GCPTreeModel:
             raise ValueError("dont know lstm init type {}!".format(hp.lstm_init))  # tree_lstm.py:74
         if hp.attentive_inference:
             assert hp.n_attention_layers == 1, "one attention layer is built (hyperparameters.py:25 default)"
+        assert not (hp.action_conditioned_pred or hp.deterministic or hp.non_goal_conditioned), \
+            "the vmpc.py variants belong to the flat predictor (SequentialModel): GCPSequentialModel"
         if hp.adaptive:
             assert hp.top_bias == 1.0 and hp.leaves_bias == 0.0, "WeightsHacker biases are not built (defaults only)"
             assert hp.entropy_weight == 0.0, "the matching entropy is reported, not optimised (hyperparameters.py default)"
@@ -311,8 +313,14 @@ class GCPTreeModel:
         while f"{prefix}.pyramid-{n_mid}.linear.weight" in sd:
             n_mid += 1
         out_pad = (out_dim + 15) // 16 * 16
-        d = dict(mid=mid, n_mid=n_mid, out_dim=out_dim, in_dim=sd[f"{prefix}.input.linear.weight"].shape[1])
-        d["w_in"] = pk.pack_gemm(sd[f"{prefix}.input.linear.weight"])
+        w_in = sd[f"{prefix}.input.linear.weight"]
+        k_raw = w_in.shape[1]
+        if k_raw % 16:
+            # an input narrower than one MFMA k-group (the action encoder's n_actions columns, sequential.py:108-110): zero columns up
+            # to 16 — the caller feeds rows padded the same way; in_dim_raw is the parameter's own width (its gradient's row pitch)
+            w_in = torch.cat([w_in, torch.zeros((mid, -k_raw % 16), dtype=w_in.dtype, device=w_in.device)], 1)
+        d = dict(mid=mid, n_mid=n_mid, out_dim=out_dim, in_dim=w_in.shape[1], in_dim_raw=k_raw)
+        d["w_in"] = pk.pack_gemm(w_in)
         d["b_in"] = sd[f"{prefix}.input.linear.bias"].contiguous()
         if n_mid:
             d["w_mid"] = torch.stack([pk.pack_gemm(sd[f"{prefix}.pyramid-{i}.linear.weight"]) for i in range(n_mid)]).contiguous()
@@ -1471,7 +1479,7 @@ class GCPTreeModel:
         B = inputs["I_0"].shape[0]
         has_traj = "traj_seq" in inputs and not self._sample_prior
         has_z = "z" in inputs
-        if not has_traj and not has_z and not self._sample_prior:
+        if not has_traj and not has_z and not self._sample_prior and not hp.deterministic:
             raise ValueError("posterior path needs traj_seq (or use val_mode() / feed z)")
         # get_end_ind (base_gcp.py:215-229): under val_mode(pred_length=True) the length is drawn from the length predictor whenever
         # its loss is trained (or no end_ind is fed); otherwise the fed end_ind is used
@@ -1486,6 +1494,8 @@ class GCPTreeModel:
         AUX = ("inv_t0", "inv_t1", "cost_start_idx", "cost_end_idx")
         fed_idx = need_idx and all(k in inputs for k in AUX)
         opt = tuple(k for k in ("pad_mask", "traj_seq_states", "w0", "actions") if with_loss and k in inputs)
+        if hp.action_conditioned_pred and "actions" not in opt:
+            opt += ("actions",)                      # the action-conditioned predictor reads them on every path (sequential.py:45-47)
         if not self._decode and (with_loss or has_traj):
             raise ValueError("decode=False is the planner's prior / given-z path: no ground-truth sequence, no losses")
         # inputs are copied into persistent buffers (one D2D copy; 63 MB for traj_seq at c2 = ~25 us) so that the
@@ -1531,7 +1541,7 @@ class GCPTreeModel:
                 tin["aux_n"] = rng[n_eps:].view(4, B)
                 for k in AUX:
                     tin[k] = self._buf("in." + k, (B,), torch.int64)
-            if not has_z:
+            if not has_z and n_eps:
                 # the draws of Gaussian.sample() live in a persistent buffer as well
                 eps = rng[:n_eps].view(B, self._n_latents(), hp.nz_vae)
                 if noise is None:
@@ -1545,7 +1555,7 @@ class GCPTreeModel:
                         tin["aux_n"].normal_()
                 tin["eps"] = eps
             elif draw_idx:
-                rng.normal_()
+                rng.normal_()                        # (z is fed, or the predictor is deterministic: only the index draws)
         # the plan (and its captured graph) bakes in buffer addresses and sizes: everything that selects buffers is part of the key
         shapes = tuple((k, tuple(tin[k].shape)) for k in sorted(tin))
         key = (B, has_traj, has_z, self._sample_prior, phase, self.training, self.materialize_distr, with_loss, self._decode, pred_len,

@@ -259,13 +259,18 @@ def _hsp(tab, prefix, in_dim, out_dim, H, n_layers):
 
 def param_table_sequential(hp):
     """Same encoder / decoder / heads as the tree model; the tree modules are replaced by the VRNN cell
-    (sequential.py:28: VRNNCell(hp, nz_enc, context = 2*nz_enc, ...))."""
+    (sequential.py:19-28: VRNNCell(hp, nz_enc, context = 2*nz_enc (+ nz_enc of the encoded action when action_conditioned_pred), ...)).
+    var_inf = 'deterministic' (vmpc.py:14-15): no latent, so only the generator net exists.  action_conditioned_pred adds the action
+    encoder (sequential.py:108-110: BaseProcessingNet(n_actions, nz_mid, nz_enc, n_processing_layers))."""
     tab = OrderedDict((k, v) for k, v in param_table(hp).items() if not k.startswith("tree_module."))
-    ctx = 2 * hp.nz_enc if hp.context_every_step else 0
+    ctx = (2 * hp.nz_enc if hp.context_every_step else 0) + (hp.nz_enc if hp.action_conditioned_pred else 0)
     p = "dense_rec.lstm.cell"
-    _hsp(tab, f"{p}.prior_lstm", hp.nz_enc + ctx, 2 * hp.nz_vae, hp.nz_mid_lstm, hp.n_lstm_layers)
-    _hsp(tab, f"{p}.inf_lstm", hp.nz_enc + ctx, 2 * hp.nz_vae, hp.nz_mid_lstm, hp.n_lstm_layers)
+    if not hp.deterministic:
+        _hsp(tab, f"{p}.prior_lstm", hp.nz_enc + ctx, 2 * hp.nz_vae, hp.nz_mid_lstm, hp.n_lstm_layers)
+        _hsp(tab, f"{p}.inf_lstm", hp.nz_enc + ctx, 2 * hp.nz_vae, hp.nz_mid_lstm, hp.n_lstm_layers)
     _hsp(tab, f"{p}.gen_lstm", hp.nz_enc + hp.nz_vae + ctx, hp.nz_enc, hp.nz_mid_lstm, hp.n_lstm_layers)
+    if hp.action_conditioned_pred:
+        _predictor(tab, "action_encoder", hp.n_actions, hp.nz_enc, hp.nz_mid, hp.n_processing_layers)
     return tab
 
 

@@ -49,19 +49,20 @@ class GCPImageSimulator:
         self._append_latent = append_latent
         self.pred_length = pred_length
 
+    def _bcast(self, img, n):
+        """the (single) start / goal image is converted once and broadcast on the device (cem_simulator.py:18 repeats it on the host:
+        512 x 64 x 64 x 3 numpy copies + two 25 MB pageable uploads were 42 ms of a 60 ms scoring rollout)"""
+        t = env2planner(np.asarray(img) if not torch.is_tensor(img) else img).to(self._model.device)
+        assert t.shape[0] in (1, n), "one image for all candidates, or one per candidate"
+        return t.expand(n, *t.shape[1:]) if t.shape[0] == 1 else t
+
     def rollout_device(self, state, goal_state, samples, rollout_len, decode=True, len_u=None):
         """Device-resident rollout.  state/goal_state: env images [1,H,W,3]; samples [n, N, nz_vae] (depth-first node
         order, tree.py:38).  Returns padded device tensors + lengths.  decode=False: latents only (images = None) — what the
         CEM scoring loop needs; the decoder is 3/4 of the rollout's FLOPs."""
         m = self._model
         n = samples.shape[0]
-        # the (single) start / goal image is converted once and broadcast on the device (cem_simulator.py:18 repeats it on the host:
-        # 512 x 64 x 64 x 3 numpy copies + two 25 MB pageable uploads were 42 ms of a 60 ms scoring rollout)
-        def bcast(img):
-            t = env2planner(np.asarray(img) if not torch.is_tensor(img) else img).to(m.device)
-            assert t.shape[0] in (1, n), "one image for all candidates, or one per candidate"
-            return t.expand(n, *t.shape[1:]) if t.shape[0] == 1 else t
-        I0, Ig = bcast(state), bcast(goal_state)
+        I0, Ig = self._bcast(state, n), self._bcast(goal_state, n)
         z = torch.as_tensor(samples, dtype=torch.float32, device=m.device)
         inp = dict(I_0=I0, I_g=Ig, z=z,
                    end_ind=torch.full((n,), rollout_len - 1, dtype=torch.long, device=m.device))
@@ -99,6 +100,36 @@ class GCPImageSimulator:
         cap = lambda t, off=0: [t[i, :max(l - off, 0)].cpu().numpy() for i, l in enumerate(lens)]
         return Outputs(predictions=preds, actions=cap(r.actions, 1) if r.actions is not None else None,
                        states=cap(r.states) if r.states is not None else None, latents=cap(r.latents))
+
+
+class ActCondGCPImageSimulator(GCPImageSimulator):
+    """cem_simulator.py:99-104: the planner's samples are ACTION sequences (they arrive in the `z` slot), rolled out by an
+    action-conditioned flat predictor (`action_conditioned_pred`, sequential.py:24-25,45-49; base_configs/vmpc.py) —
+    `GCPSequentialModel`.  Selected by the policy's `act_cond` flag (planner_policy.py:197,231).  Such a model never draws its length
+    (base_gcp.py:224-226): every rollout has `rollout_len` frames, frame 0 being the start image (sequential.py:57)."""
+
+    supports_latent_only = False     # the flat predictor's plan always decodes
+
+    def __init__(self, model, append_latent=True, pred_length=False):
+        assert model._hp.action_conditioned_pred, "the action-conditioned simulator needs an action-conditioned predictor"
+        super().__init__(model, append_latent=append_latent, pred_length=False)
+
+    def rollout_device(self, state, goal_state, samples, rollout_len, decode=True, len_u=None):
+        """samples [n, max_seq_len - 1, n_actions]: action t leads from frame t to frame t + 1"""
+        m = self._model
+        hp = m._hp
+        a = torch.as_tensor(samples, dtype=torch.float32, device=m.device)
+        if a.dim() == 5:
+            a = a[..., 0, 0]                                      # (cem_simulator.py:102: the image simulator appended two unit axes)
+        n = a.shape[0]
+        assert tuple(a.shape[1:]) == (hp.max_seq_len - 1, hp.n_actions), "one action per predicted frame"
+        inp = dict(I_0=self._bcast(state, n), I_g=self._bcast(goal_state, n), actions=a,
+                   end_ind=torch.full((n,), rollout_len - 1, dtype=torch.long, device=m.device))
+        with m.val_mode(pred_length=False):
+            out = m(inp, "train")
+        raw = out.raw
+        return Outputs(images=raw["images"], latents=raw["model_enc_seq_padded"], lengths=raw["seq_len"],
+                       actions=raw.get("actions_padded"), states=raw.get("regressed_state_padded"), e_goal=raw["e_g"], out=out)
 
 
 class LearnedCostEstimate:
@@ -440,17 +471,19 @@ class ImageHierarchicalTreeCEMSampler:
     """sampler.py:79-143: draws come from the hierarchical latent optimizer, one tree level is fixed per iteration."""
 
     def __init__(self, clip_val, n_steps, action_dim, initial_std, n_level_hierarchy, sampling_rates_per_layer,
-                 subgoal_cost_fcn, ll_cost_fcn, n_ll_samples, device_resident=False):
+                 subgoal_cost_fcn, ll_cost_fcn, n_ll_samples, device_resident=False, rng=None):
         from .tree_latent_search import ImageHierarchicalTreeLatentOptimizer, DeviceHierarchicalTreeLatentOptimizer
         self._cls = DeviceHierarchicalTreeLatentOptimizer if device_resident else ImageHierarchicalTreeLatentOptimizer
         self.device_resident = device_resident
         self._clip_val, self._action_dim, self._n_levels = clip_val, action_dim, n_level_hierarchy
         self._rates, self._sub_cost, self._ll_cost, self._n_ll = list(sampling_rates_per_layer), subgoal_cost_fcn, ll_cost_fcn, n_ll_samples
+        self._rng = rng                  # None: the reference's np.random stream; a np.random.Generator: tree_latent_search._draw
         assert n_level_hierarchy >= len(self._rates)
         self.init()
 
     def init(self):
-        self._optimizer = self._cls(self._action_dim, self._rates.copy(), self._n_levels, self._sub_cost, self._ll_cost, self._n_ll)
+        self._optimizer = self._cls(self._action_dim, self._rates.copy(), self._n_levels, self._sub_cost, self._ll_cost, self._n_ll,
+                                    rng=self._rng)
 
     def sample(self, n_samples=None):
         return np.clip(self._optimizer.sample(), -self._clip_val, self._clip_val)
@@ -488,16 +521,20 @@ class HierarchicalCEMPlanner:
     replicas; the flat `CEMPlanner` is the sharded one."""
 
     def __init__(self, simulator, cost, n_level_hierarchy, sampling_rates_per_layer, n_ll_samples=5, action_dim=256,
-                 max_seq_len=80, clip_val=float("inf"), device_resident=True):
+                 max_seq_len=80, clip_val=float("inf"), device_resident=True, fast_draws=False, seed=0):
         # device_resident: the rollouts of every iteration stay on the device — subgoal pair costs, segment costs and the
         # selections are computed there and only the final plan crosses to the host.  False = the reference's data flow (every
         # rollout, image ++ latent, to numpy: cem_simulator.py:68-70), kept as the checker: both give the same search.
         self._sim, self.max_seq_len = simulator, max_seq_len
         self.n_iters = len(sampling_rates_per_layer) + 1
         self.device_resident = bool(device_resident and hasattr(simulator, "rollout_device") and hasattr(cost, "sequence_cost_device"))
+        # fast_draws: the search draws from np.random.default_rng(seed) and only the rows it keeps (tree_latent_search._draw) instead
+        # of replaying the reference's np.random call sequence — same distribution of searches, a call is no longer bound by the host's
+        # Gaussian generator.  False (default) = the reference's stream, draw for draw.
         self._sampler = ImageHierarchicalTreeCEMSampler(clip_val, max_seq_len, action_dim, 1.0, n_level_hierarchy,
                                                         sampling_rates_per_layer, cost, cost, n_ll_samples,
-                                                        device_resident=self.device_resident)
+                                                        device_resident=self.device_resident,
+                                                        rng=(np.random.default_rng(seed) if fast_draws else None))
         self.logs = []
 
     def __call__(self, state, goal_state):

@@ -24,6 +24,13 @@ class GCPSequentialModel(GCPTreeModel):
 
     def _check_hp(self, hp):
         assert hp.lstm_init in ("zero", "mlp")          # the cell state always starts at zero (hyperparameters.py:96)
+        assert hp.n_actions <= 16 or not hp.action_conditioned_pred, "the action rows are padded to one 16-column k-group"
+
+    @property
+    def _nets(self):
+        """the recurrent nets of the cell: a deterministic predictor (var_inf = 'deterministic', vmpc.py:14-15) has no latent, hence
+        neither prior nor inference net"""
+        return ("gen_lstm",) if self._hp.deterministic else ("prior_lstm", "inf_lstm", "gen_lstm")
 
     def _default_params(self, hp, seed):
         return init_params_sequential(hp, seed)
@@ -34,15 +41,17 @@ class GCPSequentialModel(GCPTreeModel):
     def _pack_latent_model(self, P):
         hp = self._hp
         p = "dense_rec.lstm.cell"
-        for net in ("prior_lstm", "inf_lstm", "gen_lstm"):
+        for net in self._nets:
             P[net] = self._pack_hsp(f"{p}.{net}", hp.n_lstm_layers)
+        if hp.action_conditioned_pred:                  # sequential.py:108-110
+            P["action_encoder"] = self._pack_predictor("action_encoder", hp.nz_enc)
 
     def _pack_fused_embed(self):
         """embed Linear folded into LSTM layer 0's input projection (float64 product, once per weight load): one launch less on
         every step of the three recurrent chains — see GCPTreeModel._pack_fused_embed"""
         from . import packing as pk
         sd = self.sd
-        for net in ("prior_lstm", "inf_lstm", "gen_lstm"):
+        for net in self._nets:
             p = f"dense_rec.lstm.cell.{net}"
             We, be = sd[f"{p}.embed.weight"].double(), sd[f"{p}.embed.bias"].double()
             Wih = sd[f"{p}.lstm.0.weight_ih"].double()
@@ -144,8 +153,20 @@ class GCPSequentialModel(GCPTreeModel):
             self._mlp(plan, "length_pred", P["length_pred"], [e0(), eg()], B, 1, out=logits.data_ptr(), ob=T, orow=0)
             outs["seq_len_logits"] = logits
 
+        # ---- encoded actions (base_gcp.py:211-213): `more_context` of every step of the cell (sequential.py:45-49) ----
+        EA = None
+        if hp.action_conditioned_pred:
+            na = hp.n_actions
+            assert tuple(tin["actions"].shape) == (B, T - 1, na), "actions [B, T-1, n_actions]: action t leads to frame t + 1 (sequential.py:50)"
+            A16 = self._buf("seq.actions16", (B, T - 1, 16), zero=True)       # rows padded to one k-group of the Predictor's input layer
+            plan.add("actions.pad", lib.gcpx_rows_strided, A16.data_ptr(), (T - 1) * 16, 16, tin["actions"].data_ptr(), (T - 1) * na, na,
+                     B, T - 1, na, 0)
+            EA = self._buf("seq.EA", (B, T - 1, nz))
+            self._mlp(plan, "action_encoder", P["action_encoder"], [self._rowsrc(A16.data_ptr(), (T - 1) * 16, 16, 16)], B * (T - 1), T - 1,
+                      out=EA.data_ptr(), ob=(T - 1) * nz, orow=nz)
+
         # ---- VRNN rollout (sequential.py:49-54) ----
-        NETS = ("prior_lstm", "inf_lstm", "gen_lstm")
+        NETS = self._nets
         keep = self.save_for_backward
         if keep:
             # training forward: the backward pass through the recurrence needs every step's states and layer inputs.  S[net][t, i] =
@@ -153,7 +174,7 @@ class GCPSequentialModel(GCPTreeModel):
             # i = nl: the top hidden state) — stacked, so the weight gradients of all T - 1 steps are ONE GEMM per weight
             Sall = {net: self._buf(f"{net}.S", (T, nl, B, 2 * H)) for net in NETS}
             XSall = {net: self._buf(f"{net}.XS", (T - 1, nl + 1, B, H)) for net in NETS}
-            plan.rec["seq"] = dict(S=Sall, XS=XSall, X=X, EG=EG, PZ=PZ, QZ=QZ, Z=Z)
+            plan.rec["seq"] = dict(S=Sall, XS=XSall, X=X, EG=EG, PZ=PZ, QZ=QZ, Z=Z, EA=EA)
             for net in NETS:
                 plan.add(f"zero.{net}", lib.gcpx_fill_zero, Sall[net].data_ptr(), nl * B * 2 * H * 4)
 
@@ -173,8 +194,10 @@ class GCPSequentialModel(GCPTreeModel):
                     plan.add(f"zero.{net}.{i}", lib.gcpx_fill_zero, state[net][0][i].data_ptr(), B * 2 * H * 4)
             state_of = lambda net, t: state[net]
             xs_of = lambda net, t: None
-        ctx = (lambda: [e0(), eg()]) if hp.context_every_step else (lambda: [])
-        posterior = has_traj and not sample_prior and not has_z
+        def ctx(t):
+            c = [e0(), eg()] if hp.context_every_step else []
+            return c + ([self._rowsrc(_addr(EA, t * nz), (T - 1) * nz, 0, nz)] if EA is not None else [])
+        posterior = has_traj and not sample_prior and not has_z and not hp.deterministic
         # Three recurrent nets, ONE lane.  The inference net reads the ENCODED ground truth only (sequential.py:51-54): it does not
         # wait for the generator, so its step t + 1 is computed NEXT TO the generator's step t — stage by stage in the same
         # launches (gcpx_gemm_group), together with the prior net's step t (needs x_t, feeds only the KL term).  A step of the
@@ -183,12 +206,12 @@ class GCPSequentialModel(GCPTreeModel):
         xt_of = lambda t: self._rowsrc(_addr(X, t * nz), T * nz, 0, nz)
 
         def prior_stages(t):
-            return self._hsp_stages(plan, f"prior{t}", P["prior_lstm"], [xt_of(t)] + ctx(), B, state_of("prior_lstm", t), t & 1,
+            return self._hsp_stages(plan, f"prior{t}", P["prior_lstm"], [xt_of(t)] + ctx(t), B, state_of("prior_lstm", t), t & 1,
                                     _addr(PZ, t * 2 * nv), (T - 1) * 2 * nv, 2 * nv, xs_buf=xs_of("prior_lstm", t))
 
         def inf_stages(t):
             xp = self._rowsrc(_addr(enc_traj, (t + 1) * nz), T * nz, 0, nz)
-            return self._hsp_stages(plan, f"inf{t}", P["inf_lstm"], [xp] + ctx(), B, state_of("inf_lstm", t), t & 1,
+            return self._hsp_stages(plan, f"inf{t}", P["inf_lstm"], [xp] + ctx(t), B, state_of("inf_lstm", t), t & 1,
                                     _addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 2 * nv, xs_buf=xs_of("inf_lstm", t))
 
         def z_source(t):
@@ -201,8 +224,8 @@ class GCPSequentialModel(GCPTreeModel):
             return self._rowsrc(zt[0], zt[1], zt[2], nv)
 
         def gen_stages(t, zsrc):
-            return self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [xt_of(t), zsrc] + ctx(), B, state_of("gen_lstm", t), t & 1,
-                                    _addr(X, (t + 1) * nz), T * nz, nz, xs_buf=xs_of("gen_lstm", t))
+            return self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [xt_of(t)] + ([zsrc] if zsrc is not None else []) + ctx(t), B,
+                                    state_of("gen_lstm", t), t & 1, _addr(X, (t + 1) * nz), T * nz, nz, xs_buf=xs_of("gen_lstm", t))
 
         def run(*chains):
             """stage i of every chain in one launch"""
@@ -227,7 +250,28 @@ class GCPSequentialModel(GCPTreeModel):
             return [st]
 
         z_from_prior = not has_z and not posterior          # prior sampling: z_t needs prior(t), which needs x_t: one serial chain
-        if has_traj and not (posterior and "lstm0ff.w" in P["gen_lstm"] and not self.save_for_backward):
+        if hp.deterministic:
+            # x_{t+1} = gen([x_t, e_0, e_g, a_t]): ONE chain of T - 1 steps, nl dependent launches each when layer 0 reads the previous
+            # step's top hidden state through the folded output projection (x_{t+1} itself is then computed beside layer 0 of the next step)
+            fold = "lstm0ff.w" in P["gen_lstm"] and not self.save_for_backward
+            top = lambda t: self._rowsrc(self._buf(f"gen{t}.x{nl}", (B, H)).data_ptr(), H, 0, H)
+            pending = None
+            for t in range(T - 1):
+                if fold and t > 0:
+                    g_st = self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [top(t - 1)] + ctx(t), B, state_of("gen_lstm", t), t & 1,
+                                            _addr(X, (t + 1) * nz), T * nz, nz, w0="lstm0ff")
+                else:
+                    g_st = gen_stages(t, None)
+                if not fold:
+                    run(g_st)
+                    continue
+                run(g_st[:1], pending)
+                if len(g_st) > 2:
+                    run(g_st[1:-1])
+                pending = g_st[-1:]
+            if pending:
+                run(pending)
+        elif has_traj and not (posterior and "lstm0ff.w" in P["gen_lstm"] and not self.save_for_backward):
             run(inf_stages(0))
         fold_out = posterior and "lstm0ff.w" in P["gen_lstm"] and not self.save_for_backward
         if posterior and fold_out:
@@ -251,7 +295,7 @@ class GCPSequentialModel(GCPTreeModel):
                 if t == 0:
                     g_st = gen_stages(0, zsrc)
                 else:
-                    g_st = self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [top(t - 1), zsrc] + ctx(), B, state_of("gen_lstm", t), t & 1,
+                    g_st = self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [top(t - 1), zsrc] + ctx(t), B, state_of("gen_lstm", t), t & 1,
                                             _addr(X, (t + 1) * nz), T * nz, nz, w0="lstm0ff")
                 place(g_st[:-1], 3 * t + 6)
                 place(g_st[-1:], 3 * t + 9)
@@ -268,7 +312,7 @@ class GCPSequentialModel(GCPTreeModel):
                 run(inf_stages(1))
             z_source(0)
         for t in range(T - 1):
-            if posterior and fold_out:
+            if (posterior and fold_out) or hp.deterministic:
                 break
             if z_from_prior:
                 run(prior_stages(t))
@@ -368,7 +412,7 @@ class GCPSequentialModel(GCPTreeModel):
         images = self._buf("seq.images", (B, T, hp.input_nc, S, S))
         plan.add("cat.I0", lib.gcpx_copy_rows, tin["I_0"].data_ptr(), images.data_ptr(), B, 1, row, 1, T)
         plan.add("cat.dec", lib.gcpx_copy_rows, dec_images.data_ptr(), _addr(images, row), B, T - 1, row, T - 1, T)
-        outs.update(images=images, X=X, PZ=PZ, QZ=QZ, Z=Z, seq_len=seq_len, matched_distr_kernel_order=matched)
+        outs.update(images=images, X=X, PZ=PZ, QZ=QZ, Z=Z, seq_len=seq_len, matched_distr_kernel_order=matched, e_g=EG)
 
         # ---- losses (sequential.py:60-68) ----
         if with_loss:
@@ -393,9 +437,10 @@ class GCPSequentialModel(GCPTreeModel):
                 # rows (b, 0) compare I_0 with itself-as-target and carry weight 0 in the combine below
                 plan.add("loss.gauss_nll", lib.gcpx_gauss_nll, images.data_ptr(), tin["traj_seq"].data_ptr(),
                          self.sd["decoder.log_sigma"].data_ptr(), nll_bt.data_ptr(), B * T, row)
-            kl_b = self._buf("kl_b", (B,))
-            plan.add("loss.kl", lib.gcpx_kl_gauss, QZ.data_ptr(), PZ.data_ptr(), B, T - 1, nv, (T - 1) * 2 * nv, 2 * nv,
-                     C.c_float(hp.free_nats), _addr(tin["pad_mask"], 1), T, kl_b.data_ptr())
+            kl_b = self._buf("kl_b", (B,), zero=hp.deterministic)
+            if not hp.deterministic:                     # (no latent: both distributions are empty and the KL term is 0)
+                plan.add("loss.kl", lib.gcpx_kl_gauss, QZ.data_ptr(), PZ.data_ptr(), B, T - 1, nv, (T - 1) * 2 * nv, 2 * nv,
+                         C.c_float(hp.free_nats), _addr(tin["pad_mask"], 1), T, kl_b.data_ptr())
             la = rt.LossArgs()
             la.nll_bt, la.pad_mask, la.kl_b = nll_bt.data_ptr(), tin["w0"].data_ptr(), kl_b.data_ptr()   # frame 0 weighs 0
             la.len_logits = outs["seq_len_logits"].data_ptr() if "seq_len_logits" in outs else None
@@ -427,6 +472,14 @@ class GCPSequentialModel(GCPTreeModel):
     # ------------------------------------------------------------------------------------------------
     def forward(self, inputs, phase="train", noise=None):
         """noise: eps [B, T-1, nz_vae] for the per-step Gaussian samples; inputs['z'] [B, T-1, nz_vae] feeds latents."""
+        if self._hp.non_goal_conditioned:
+            # optional_preprocessing (base_gcp.py:163-170): the goal image and the sequence's end frame are zeroed before anything is
+            # encoded; the reference edits `inputs` in place (so its losses see the zeroed frame too), here the caller's tensors stay
+            inputs = dict(inputs, I_g=torch.zeros_like(torch.as_tensor(inputs["I_g"])))
+            if "traj_seq" in inputs:
+                ts = torch.as_tensor(inputs["traj_seq"]).to(self.device, torch.float32, copy=True)
+                ts[torch.arange(ts.shape[0], device=self.device), torch.as_tensor(inputs["end_ind"]).to(self.device)] = 0.0
+                inputs["traj_seq"] = ts
         if "pad_mask" in inputs and "traj_seq" in inputs and phase == "train":
             # NLL row weights: frame 0 is the conditioning frame, never reconstructed (sequential.py:63-66)
             pm = inputs["pad_mask"].to(self.device, torch.float32)

@@ -76,6 +76,7 @@ class GCPTrainStep:
         self.split_wgrad_rows = os.environ.get("GCPX_WGRAD_ROWS_NOSPLIT") is None   # the tree's Linear / LSTM weight gradients (>= 256 rows) likewise
         self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
         self.fused_mlp_bwd = os.environ.get("GCPX_NO_FUSED_MLP_BWD") is None
+        self._pad_fixups = []                 # (see _mlp_in_dst)
         # the decoder's weight gradients (5 ms of throughput-bound kernels) are forked after the decoder's data-gradient chain: they then
         # fill the chip during the latency-bound tree phase instead of competing with the data gradients (23.2 -> 22.8 ms / step)
         self.defer_decoder_side = os.environ.get("GCPX_NO_DEFER_DEC_SIDE") is None
@@ -509,8 +510,9 @@ class GCPTrainStep:
         du0 = m._buf(f"bw.{tag}.du0", (M, mid))
         plan.add(f"bw.lrelu:{tag}", lib.gcpx_lrelu_bwd, a_ptr[0], da.data_ptr(), du0.data_ptr(), M * mid, C.c_float(hp.leaky_slope))
         koff = 0
+        w_in_dst = self._mlp_in_dst(plan, tag, prefix, W)
         for i, s in enumerate(srcs):
-            self._wgrad(plan, f"{tag}.in{i}", du0.data_ptr(), mid, M, mid, s.ptr, s.width, self.g(f"{prefix}.input.linear.weight"),
+            self._wgrad(plan, f"{tag}.in{i}", du0.data_ptr(), mid, M, mid, s.ptr, s.width, w_in_dst,
                         ldw=in_dim, k_off=koff, rpb=rpb, sb=s.sb, sr=s.sr, shift=s.shift,
                         rowidx=_PtrHolder(s.rowidx) if s.rowidx else None,
                         dbias=(self.g(f"{prefix}.input.linear.bias") if i == 0 else None))
@@ -519,6 +521,23 @@ class GCPTrainStep:
             wT = T[f"wT_in{i}"]
             width = wT.shape[1] * 16
             self._dgemm(plan, f"{tag}.in{i}", [self.m._rowsrc(du0.data_ptr(), rpb * mid, mid, mid)], M, width, rpb, wT, optr, ob, orow)
+
+    def _mlp_in_dst(self, plan, tag, prefix, W):
+        """Where the weight gradient of a Predictor's input layer is accumulated: the parameter's gradient itself — unless the layer's
+        input was padded to a 16-column k-group (model._pack_predictor: the action encoder's n_actions columns): then rows of the padded
+        width in a scratch block, whose first in_dim_raw columns `_unpad_input_grads` copies behind the last side lane."""
+        raw = W.get("in_dim_raw", W["in_dim"])
+        if raw == W["in_dim"]:
+            return self.g(f"{prefix}.input.linear.weight")
+        scratch = self.m._buf(f"bw.{tag}.dW_in", (W["mid"], W["in_dim"]))
+        plan.add("bw.zero", self.m.lib.gcpx_fill_zero, scratch.data_ptr(), scratch.numel() * 4)
+        self._pad_fixups.append((tag, self.g(f"{prefix}.input.linear.weight"), raw, scratch, W["in_dim"], W["mid"]))
+        return scratch.data_ptr()
+
+    def _unpad_input_grads(self, plan):
+        for tag, dst, raw, scratch, pad, mid in self._pad_fixups:
+            plan.add(f"bw.unpad:{tag}", self.m.lib.gcpx_rows_strided, dst, 0, raw, scratch.data_ptr(), 0, pad, 1, mid, raw, 0)
+        self._pad_fixups = []
 
     def _mlp_bwd_fused(self, plan, tag, prefix, rec, T, dout, ldo, dx_outs, a_ptr):
         """The data-gradient chain of one Predictor as ONE launch (gcpx_mlp_bwd); weight gradients and the GroupNorm parameter
@@ -552,8 +571,9 @@ class GCPTrainStep:
             self._wgrad(plan, f"{tag}.mid{l}", du[1 + l].data_ptr(), mid, M, mid, a_ptr[l], mid, self.g(f"{pre}.linear.weight"), ldw=mid,
                         sr=mid, sb=M * mid, rpb=M, dbias=self.g(f"{pre}.linear.bias"))
         koff = 0
+        w_in_dst = self._mlp_in_dst(plan, tag, prefix, W)
         for i, s in enumerate(srcs):
-            self._wgrad(plan, f"{tag}.in{i}", du[0].data_ptr(), mid, M, mid, s.ptr, s.width, self.g(f"{prefix}.input.linear.weight"),
+            self._wgrad(plan, f"{tag}.in{i}", du[0].data_ptr(), mid, M, mid, s.ptr, s.width, w_in_dst,
                         ldw=in_dim, k_off=koff, rpb=rpb, sb=s.sb, sr=s.sr, shift=s.shift,
                         rowidx=_PtrHolder(s.rowidx) if s.rowidx else None,
                         dbias=(self.g(f"{prefix}.input.linear.bias") if i == 0 else None))

@@ -69,7 +69,9 @@ class SequentialTrainStep(GCPTrainStep):
             X["inv_mdl"] = self._pack_predictor_T(sd, "inv_mdl.action_pred", [])
         if hp.attach_cost_mdl:
             X["cost_mdl"] = self._pack_predictor_T(sd, "cost_mdl.cost_pred", [])
-        for net in NETS:
+        if hp.action_conditioned_pred:
+            X["action_encoder"] = self._pack_predictor_T(sd, "action_encoder", [])      # its input, the actions, takes no gradient
+        for net in m._nets:
             p = f"dense_rec.lstm.cell.{net}"
             T_ = {"embed.wT": pk.pack_gemm(sd[f"{p}.embed.weight"].t().contiguous()),          # [n = in_dim][k = H]
                   "out.wT": pk.pack_gemm(sd[f"{p}.out.weight"].t().contiguous())}               # [n = H][k = out]
@@ -141,7 +143,10 @@ class SequentialTrainStep(GCPTrainStep):
         X, EG, PZ, QZ, Z = sq["X"], sq["EG"], sq["PZ"], sq["QZ"], sq["Z"]
         enc_traj = o["enc_traj_seq"]
         zero = lambda t: plan.add("bw.zero", lib.gcpx_fill_zero, t.data_ptr(), t.numel() * 4)
-        in_dim = {"prior_lstm": 3 * nz, "inf_lstm": 3 * nz, "gen_lstm": 3 * nz + nv}
+        NETS = m._nets                                       # ('gen_lstm',) for a deterministic predictor (no latent: no KL, no prior / inference net)
+        det, EA = hp.deterministic, sq.get("EA")
+        na_ = nz if EA is not None else 0                     # the encoded action: last nz columns of every net's input (sequential.py:45-49)
+        in_dim = {"prior_lstm": 3 * nz + na_, "inf_lstm": 3 * nz + na_, "gen_lstm": 3 * nz + nv + na_}
         nrec = dict(rec=rec, S=sq["S"], XS=sq["XS"], in_dim=in_dim, tag={"prior_lstm": "prior", "inf_lstm": "inf", "gen_lstm": "gen"})
 
         DX = buf("bw.seq.DX", (B, T, nz))                    # gradient of X[b, t] = x_t (x_0 = e_0)
@@ -154,7 +159,9 @@ class SequentialTrainStep(GCPTrainStep):
         la = rec["loss_args"]
         assert rec.get("nll_bwd_fused"), "the training forward produces d NLL / d parameters together with the loss"
         dMD = buf("bw.dMD", (B * T, S_, S_, m._head_pitch))
-        if m._kl_w is not None:                               # burn-in schedule: kl_weight(step) is read from device memory
+        if det:
+            pass
+        elif m._kl_w is not None:                               # burn-in schedule: kl_weight(step) is read from device memory
             plan.add("bw.kl", lib.gcpx_kl_bwd_scheduled, QZ.data_ptr(), PZ.data_ptr(), dQZ.data_ptr(), dPZ.data_ptr(), B, T - 1, nv,
                      (T - 1) * 2 * nv, 2 * nv, C.c_float(hp.free_nats), C.c_float(1.0 / (B * div)), _addr(tin["pad_mask"], 1), T,
                      m._kl_w.data_ptr())
@@ -191,8 +198,9 @@ class SequentialTrainStep(GCPTrainStep):
         # ---- prior chain on a side lane (needs the KL gradient only), decoder backward on the main lane ----
         plan.fork([1])
         plan.lane = 1
-        for _ in self._chain(plan, "prior_lstm", lambda t: m._rowsrc(_addr(dPZ, t * 2 * nv), (T - 1) * 2 * nv, 0, 2 * nv), B, T, dIn["prior_lstm"], nrec):
-            pass
+        if not det:
+            for _ in self._chain(plan, "prior_lstm", lambda t: m._rowsrc(_addr(dPZ, t * 2 * nv), (T - 1) * 2 * nv, 0, 2 * nv), B, T, dIn["prior_lstm"], nrec):
+                pass
         plan.lane = 0
         F = B * (T - 1)
         row2frame = buf("bw.seq.row2frame", (B * T,), torch.int32)       # row (b, t) of the matched arrays <- decoded frame (b, t - 1); (b, 0): none
@@ -208,7 +216,9 @@ class SequentialTrainStep(GCPTrainStep):
         self._flush(plan, only_lane=2)                        # decoder weight gradients: on lane 2, beside the generator / inference chains
         # gradient of x_{t+1}, t = 0 .. T-2: decoder + the prior's input at step t + 1
         plan.add("bw.addrows.dec", lib.gcpx_add_rows, _addr(DX, nz), T * nz, nz, dE_dec.data_ptr(), None, B, T - 1, nz)
-        self._rows(plan, "bw.prior.dx", DX.data_ptr(), T * nz, nz, dIn["prior_lstm"].data_ptr(), (T - 1) * 3 * nz, 3 * nz, B, T - 1, nz, 1)
+        if not det:
+            pd = in_dim["prior_lstm"]
+            self._rows(plan, "bw.prior.dx", DX.data_ptr(), T * nz, nz, dIn["prior_lstm"].data_ptr(), (T - 1) * pd, pd, B, T - 1, nz, 1)
 
         # ---- generator chain on the main lane, inference chain one step behind it on lane 1 ----
         # gen(t): the gradient of x_t is complete once step t has added its input gradient.  z_t = mu_q + exp(log_sigma_q) eps
@@ -216,9 +226,12 @@ class SequentialTrainStep(GCPTrainStep):
         # inference net's step t while the generator goes on to step t - 1 — the two 79-step chains overlap instead of queueing.
         DQ, DPd = buf("bw.seq.DQ", (T - 1, B, 2 * nv)), buf("bw.seq.DPd", (B, 2 * nv))
         gd = in_dim["gen_lstm"]
-        inf_chain = self._chain(plan, "inf_lstm", lambda t: m._rowsrc(DQ[t].data_ptr(), 2 * nv, 0, 2 * nv), B, T, dIn["inf_lstm"], nrec)
+        inf_chain = iter(()) if det else \
+            self._chain(plan, "inf_lstm", lambda t: m._rowsrc(DQ[t].data_ptr(), 2 * nv, 0, 2 * nv), B, T, dIn["inf_lstm"], nrec)
         for t in self._chain(plan, "gen_lstm", lambda t: m._rowsrc(_addr(DX, (t + 1) * nz), T * nz, 0, nz), B, T, dIn["gen_lstm"], nrec):
             self._rows(plan, f"bw.gen.dx{t}", _addr(DX, t * nz), T * nz, 0, _addr(dIn["gen_lstm"], t * gd), (T - 1) * gd, 0, B, 1, nz, 1)
+            if det:
+                continue
             plan.add(f"bw.latent{t}", lib.gcpx_latent_bwd, _addr(dQZ, t * 2 * nv), _addr(dPZ, t * 2 * nv), _addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 0,
                      _addr(tin["eps"], t * nv), tin["eps"].shape[1] * nv, 0, _addr(dIn["gen_lstm"], t * gd + nz), (T - 1) * gd, None, 0,
                      DQ[t].data_ptr(), DPd.data_ptr(), B, 1, nv)
@@ -235,10 +248,12 @@ class SequentialTrainStep(GCPTrainStep):
             return dict(rpb=B, sb=t_stride, sr=b_stride)
         e0s = dict(ptr=_addr(X), **stacked(0, T * nz))
         egs = dict(ptr=_addr(EG), **stacked(0, nz))
-        srcs = {"prior_lstm": [dict(ptr=_addr(X), w=nz, **stacked(nz, T * nz)), dict(w=nz, **e0s), dict(w=nz, **egs)],
-                "inf_lstm": [dict(ptr=_addr(enc_traj, nz), w=nz, **stacked(nz, T * nz)), dict(w=nz, **e0s), dict(w=nz, **egs)],
-                "gen_lstm": [dict(ptr=_addr(X), w=nz, **stacked(nz, T * nz)), dict(ptr=_addr(Z), w=nv, **stacked(nv, (T - 1) * nv)),
-                             dict(w=nz, **e0s), dict(w=nz, **egs)]}
+        eas = [dict(ptr=_addr(EA), w=nz, **stacked(nz, (T - 1) * nz))] if EA is not None else []
+        zs_ = [dict(ptr=_addr(Z), w=nv, **stacked(nv, (T - 1) * nv))] if not det else []
+        srcs = {"gen_lstm": [dict(ptr=_addr(X), w=nz, **stacked(nz, T * nz))] + zs_ + [dict(w=nz, **e0s), dict(w=nz, **egs)] + eas}
+        if not det:
+            srcs["prior_lstm"] = [dict(ptr=_addr(X), w=nz, **stacked(nz, T * nz)), dict(w=nz, **e0s), dict(w=nz, **egs)] + eas
+            srcs["inf_lstm"] = [dict(ptr=_addr(enc_traj, nz), w=nz, **stacked(nz, T * nz)), dict(w=nz, **e0s), dict(w=nz, **egs)] + eas
         # (gradient of a net's output, rows (t, b): pointer, pitch of b, stride of t — 0 = dense t-major rows —, width)
         douts = {"prior_lstm": (dPZ.data_ptr(), (T - 1) * 2 * nv, 2 * nv, 2 * nv), "inf_lstm": (DQ.data_ptr(), 2 * nv, 0, 2 * nv),
                  "gen_lstm": (_addr(DX, nz), T * nz, nz, nz)}
@@ -266,9 +281,18 @@ class SequentialTrainStep(GCPTrainStep):
         # ---- context and x_0 gradients -> the I_0 / I_g encoder outputs; inference inputs -> the trajectory encoder ----
         d_enc_traj = buf("bw.d_enc_traj", (B, T, nz))
         zero(d_enc_traj)
-        self._rows(plan, "bw.inf.dx", _addr(d_enc_traj, nz), T * nz, nz, dIn["inf_lstm"].data_ptr(), (T - 1) * 3 * nz, 3 * nz, B, T - 1, nz, 0)
+        if not det:
+            idm = in_dim["inf_lstm"]
+            self._rows(plan, "bw.inf.dx", _addr(d_enc_traj, nz), T * nz, nz, dIn["inf_lstm"].data_ptr(), (T - 1) * idm, idm, B, T - 1, nz, 0)
+        if EA is not None:
+            # gradient of the encoded action a_t: the last nz input columns of every net at step t -> the action encoder's parameters
+            dEA = buf("bw.seq.dEA", (B, T - 1, nz))
+            for k, net in enumerate(NETS):
+                self._rows(plan, f"bw.{net}.dea", dEA.data_ptr(), (T - 1) * nz, nz, _addr(dIn[net], in_dim[net] - nz), (T - 1) * in_dim[net],
+                           in_dim[net], B, T - 1, nz, int(k > 0))
+            self._mlp_bwd(plan, "action_encoder", "action_encoder", rec["mlp:action_encoder"], self.bk["action_encoder"], dEA.data_ptr(), nz, [])
         for net in NETS:
-            c0 = in_dim[net] - 2 * nz                         # columns of e_0 / e_g in the embedding input
+            c0 = in_dim[net] - 2 * nz - na_                   # columns of e_0 / e_g in the embedding input
             self._rows(plan, f"bw.{net}.de0", DX.data_ptr(), T * nz, 0, _addr(dIn[net], c0), (T - 1) * in_dim[net], in_dim[net], B, T - 1, nz, 2)
             self._rows(plan, f"bw.{net}.deg", dEG.data_ptr(), nz, 0, _addr(dIn[net], c0 + nz), (T - 1) * in_dim[net], in_dim[net], B, T - 1, nz, 2)
         self._flush(plan)
@@ -276,5 +300,6 @@ class SequentialTrainStep(GCPTrainStep):
                                    lambda: self._encoder_backward(plan, fplan, "I0", _addr(DX), nz, 1, T * nz, dskip),
                                    lambda: self._encoder_backward(plan, fplan, "Ig", _addr(dEG), nz, 1, nz, {}))
         plan.join(list(range(1, 1 + self.n_side)))
+        self._unpad_input_grads(plan)
         plan.outs = dict(DX=DX, dEG=dEG, dQZ=dQZ, dPZ=dPZ, DQ=DQ, dIn=dIn, dE_dec=dE_dec, d_enc_traj=d_enc_traj)
         return plan

@@ -44,7 +44,11 @@ class HierarchicalTreeLatentOptimizer:
     """Same constructor / methods as the reference class (image variant: states are flattened 3xRxR images)."""
 
     def __init__(self, latent_dim, sampling_rates, depth, subgoal_cost_fcn, ll_cost_fcn, final_layer_samples,
-                 image_states=True):
+                 image_states=True, rng=None):
+        """rng: None = the reference's draws (module-level np.random, the legacy Gaussian stream, every draw the reference makes —
+        bit-exact with its class); a np.random.Generator = the same search on that generator with only the KEPT rows drawn, see
+        _draw"""
+        self._rng = rng
         self._dim = latent_dim
         self._pair_cost = subgoal_cost_fcn
         self._seq_cost = ll_cost_fcn
@@ -63,9 +67,16 @@ class HierarchicalTreeLatentOptimizer:
             # numpy walks the broadcast element by element, 0.0 + 1.0 * gauss — the same legacy Gaussian stream, in the same order, as
             # standard_normal fills in one call (bit-identical draws, pinned by tests/golden/ref_tree_optimizer.npz; 92 of the 97 ms
             # of a planner call were spent in the slow form)
-            z = np.random.standard_normal(size=(lv.n_samples, lv.n_latents, self._dim))
-            if below:                      # below the level being optimised only one latent is decoded
-                z = z[:1]
+            if self._rng is None:
+                z = np.random.standard_normal(size=(lv.n_samples, lv.n_latents, self._dim))
+                if below:                  # below the level being optimised only one latent is decoded
+                    z = z[:1]
+            else:
+                # Below the level being optimised the reference draws n_samples rows and keeps the first (tree_optimizer.py:76-82):
+                # 3.5 M Gaussians per planner call at rates [10, 10], 5 dense samples, 256-d latents, 26 ns each on the legacy
+                # stream = 92 of the 98 ms of a call.  The rows are i.i.d., so drawing only the kept row gives the same
+                # distribution of searches; float32 from the generator's ziggurat (what the model reads anyway).
+                z = self._rng.standard_normal(size=(1 if below else lv.n_samples, lv.n_latents, self._dim), dtype=np.float32)
             lv.last_draw = z.copy()
         child_below = below or not lv.done
         if lv.left is None:
