@@ -146,6 +146,28 @@ def test_hierarchical_cem_planner(setup):
     assert lens_dev[:2] == lens_np[:2]
 
 
+def test_hierarchical_planner_fast_draws(setup):
+    """fast_draws: the same search on a seeded numpy Generator that draws only the rows the search keeps (tree_latent_search._draw):
+    reproducible from the seed, complete after len(rates) + 1 rounds, plan of the model's horizon, np.random untouched"""
+    from video_gcp_amd.planning import GCPImageSimulator, LearnedCostEstimate, HierarchicalCEMPlanner
+    hp, sd, model = setup
+    state, goal = _env_images(hp, 3)
+
+    def run(seed):
+        planner = HierarchicalCEMPlanner(GCPImageSimulator(model, pred_length=False), LearnedCostEstimate(model), hp.hierarchy_levels, [3, 2],
+                                         n_ll_samples=2, action_dim=hp.nz_vae, max_seq_len=hp.max_seq_len, fast_draws=True, seed=seed)
+        plan, actions, latents, score = planner(state, goal)
+        assert planner.fully_optimized and len(planner.logs) == 3 and np.isfinite(score)
+        assert plan.shape == (hp.max_seq_len, 3 * hp.img_sz ** 2 + hp.nz_enc)
+        return plan, score
+    np.random.seed(9)
+    before = np.random.get_state()[1].copy()
+    (p1, s1), (p2, s2), (p3, s3) = run(4), run(4), run(5)
+    assert np.array_equal(np.random.get_state()[1], before)
+    assert np.array_equal(p1, p2) and s1 == s2
+    assert not np.array_equal(p1, p3)
+
+
 def test_plan_entry_point_cem_and_hierarchical(tmp_path):
     """`python -m video_gcp_amd.plan` counterpart of the planner call behind planning/run.py: plans for seeded start / goal pairs"""
     import numpy as np

@@ -30,6 +30,9 @@ def get_args(argv=None):
     p.add_argument("--split", default="candidates", choices=["candidates", "pairs"])
     p.add_argument("--out", default="", help="directory for plan_{i}.npz")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--reference_rng", action="store_true",
+                   help="hierarchical planner: replay the reference's np.random call sequence draw for draw (6x the host time per "
+                        "call) instead of drawing only the kept rows from a seeded numpy Generator")
     return p.parse_args(argv)
 
 
@@ -71,7 +74,8 @@ def main(argv=None):
                                max_seq_len=hp.max_seq_len)
     else:
         planner = P.HierarchicalCEMPlanner(sim, cost, hp.hierarchy_levels, [10, 10], action_dim=hp.nz_vae,       # rates of the
-                                           max_seq_len=hp.max_seq_len)                                       # 25-room control config
+                                           max_seq_len=hp.max_seq_len,                                       # 25-room control config
+                                           fast_draws=not args.reference_rng, seed=args.seed + 1)
     results = []
     for i in idx:
         plan, actions, latents, c = planner(starts[i:i + 1], goals[i:i + 1])
