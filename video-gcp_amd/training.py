@@ -500,9 +500,7 @@ class GCPTrainStep:
             plan.add(f"bw.gn:{tag}.{l}", lib.gcpx_gn_lrelu_bwd, u_ptr[l], da.data_ptr(), m.sd[f"{pre}.norm.weight"].data_ptr(),
                      m.sd[f"{pre}.norm.bias"].data_ptr(), du.data_ptr(), part.data_ptr(), M, mid, hp.gn_groups,
                      C.c_float(hp.gn_eps), C.c_float(hp.leaky_slope))
-            self._side(plan, f"bw.gnred:{tag}.{l}", lib.gcpx_reduce_partials, part.data_ptr(), nb, 2 * mid, mid, self.g(f"{pre}.norm.weight"), 1)
-            self._side(plan, f"bw.gnred2:{tag}.{l}", lib.gcpx_reduce_partials, part.data_ptr() + 4 * mid, nb, 2 * mid, mid,
-                       self.g(f"{pre}.norm.bias"), 1)
+            self._gn_param_grads(plan, f"{tag}.{l}", pre, part, nb, mid)
             self._wgrad(plan, f"{tag}.mid{l}", du.data_ptr(), mid, M, mid, a_ptr[l], mid, self.g(f"{pre}.linear.weight"), ldw=mid,
                         sr=mid, sb=M * mid, rpb=M, dbias=self.g(f"{pre}.linear.bias"))
             da = m._buf(f"bw.{tag}.da{l}", (M, mid))
@@ -521,6 +519,17 @@ class GCPTrainStep:
             wT = T[f"wT_in{i}"]
             width = wT.shape[1] * 16
             self._dgemm(plan, f"{tag}.in{i}", [self.m._rowsrc(du0.data_ptr(), rpb * mid, mid, mid)], M, width, rpb, wT, optr, ob, orow)
+
+    def _gn_param_grads(self, plan, tag, pre, part, nb, mid):
+        """GroupNorm gamma / beta gradients of one Predictor layer from the per-workgroup partials [nb][2][mid].  The two parameters are
+        neighbours in the flat vector (params._predictor lists weight, then bias), so ONE reduction over 2 * mid columns writes both —
+        60 launches of ~4 us less on the side lanes of a c2 step than one reduction each."""
+        lib, off = self.m.lib, self.m._poff
+        if off[f"{pre}.norm.bias"][0] == off[f"{pre}.norm.weight"][0] + mid:
+            self._side(plan, f"bw.gnred:{tag}", lib.gcpx_reduce_partials, part.data_ptr(), nb, 2 * mid, 2 * mid, self.g(f"{pre}.norm.weight"), 1)
+            return
+        self._side(plan, f"bw.gnred:{tag}", lib.gcpx_reduce_partials, part.data_ptr(), nb, 2 * mid, mid, self.g(f"{pre}.norm.weight"), 1)
+        self._side(plan, f"bw.gnred2:{tag}", lib.gcpx_reduce_partials, part.data_ptr() + 4 * mid, nb, 2 * mid, mid, self.g(f"{pre}.norm.bias"), 1)
 
     def _mlp_in_dst(self, plan, tag, prefix, W):
         """Where the weight gradient of a Predictor's input layer is accumulated: the parameter's gradient itself — unless the layer's
@@ -565,9 +574,7 @@ class GCPTrainStep:
         plan.add(f"bw.mlp:{tag}", lib.gcpx_mlp_bwd, C.byref(a))
         for l in reversed(range(n_mid)):
             pre = f"{prefix}.pyramid-{l}"
-            self._side(plan, f"bw.gnred:{tag}.{l}", lib.gcpx_reduce_partials, parts[l].data_ptr(), nb, 2 * mid, mid, self.g(f"{pre}.norm.weight"), 1)
-            self._side(plan, f"bw.gnred2:{tag}.{l}", lib.gcpx_reduce_partials, parts[l].data_ptr() + 4 * mid, nb, 2 * mid, mid,
-                       self.g(f"{pre}.norm.bias"), 1)
+            self._gn_param_grads(plan, f"{tag}.{l}", pre, parts[l], nb, mid)
             self._wgrad(plan, f"{tag}.mid{l}", du[1 + l].data_ptr(), mid, M, mid, a_ptr[l], mid, self.g(f"{pre}.linear.weight"), ldw=mid,
                         sr=mid, sb=M * mid, rpb=M, dbias=self.g(f"{pre}.linear.bias"))
         koff = 0
