@@ -153,3 +153,36 @@ def test_hand_written_costs_and_pddm_sampler():
     s.fit(x, scores)
     w = np.exp(-scores.numpy())
     assert np.allclose(s.mean.numpy(), (x.numpy() * w[:, None, None]).sum(0) / w.sum(), atol=1e-6) and torch.equal(s.std, std0)
+
+
+def test_costs_and_samplers_match_the_executed_reference():
+    """tests/golden/ref_costs_samplers.npz = outputs of the reference's own CostFcn subclasses (cost_fcn.py:8-77) and of its
+    FlatCEMSampler / PDDMSampler (sampler.py:33-71) executed in the build container (make_ref_costs_goldens.py).  The host contract of
+    the cost classes is float64 numpy like the reference's: equal to the last bit.  The samplers here are float32 torch: the population
+    they build from the SAME standard-normal numbers the reference's np.random call consumed, and their refits, to float32 rounding."""
+    from video_gcp_amd import planning as P
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_costs_samplers.npz"))
+    rolls = [g[f"state_roll{i}"] for i in range(len(g["state_lens"]))]
+    for k, case in enumerate(g["state_cases"]):
+        name, dense, w = str(case).split("|")
+        got = getattr(P, name)(bool(int(dense)), float(w))([r.copy() for r in rolls], g["state_goal"])
+        assert np.array_equal(np.asarray(got, dtype=np.float64), g[f"state_cost{k}"]), case
+    img_rolls = [g[f"img_roll{i}"] for i in range(len(g["img_lens"]))]
+    for k, (dense, w) in enumerate(g["img_cases"]):
+        got = P.L2ImageCost(bool(dense), float(w))([r.copy() for r in img_rolls], g["img_goal"])
+        assert np.array_equal(np.asarray(got, dtype=np.float64), g[f"img_cost{k}"]), (dense, w)
+    n, steps, ad = (int(v) for v in g["sampler_shape"])
+    for tag, cls in (("flat", P.FlatCEMSampler), ("pddm", P.PDDMSampler)):
+        for ct, clip in (("inf", float("inf")), ("clip", 0.8)):
+            s = cls(clip, steps, ad, 0.7, device="cpu", seed=0)
+            s.mean, s.std = torch.tensor(g[f"{tag}_{ct}_mean"], dtype=torch.float32), torch.tensor(g[f"{tag}_{ct}_std"], dtype=torch.float32)
+            got = s.from_unit_noise(torch.tensor(g[f"{tag}_{ct}_unit_noise"], dtype=torch.float32))
+            assert np.allclose(got.numpy(), g[f"{tag}_{ct}_samples"], rtol=0, atol=2e-6), (tag, ct)
+            if ct == "clip":
+                assert float(got.abs().max()) == np.float32(0.8) and float(np.abs(g[f"{tag}_{ct}_samples"]).max()) == 0.8      # something was clipped
+        s = cls(float("inf"), steps, ad, 0.7, device="cpu", seed=0)
+        s.fit(torch.tensor(g[f"{tag}_fit_data"], dtype=torch.float32), torch.tensor(g[f"{tag}_fit_scores"], dtype=torch.float32))
+        assert np.allclose(s.mean.numpy(), g[f"{tag}_fit_mean"], atol=2e-6), tag
+        assert np.allclose(s.std.numpy(), g[f"{tag}_fit_std"], atol=2e-6), tag          # (PDDM never refits its std: equals the initial one)
+        if tag == "pddm":
+            assert np.array_equal(g["pddm_fit_std"], g["pddm_fit_std_before"])

@@ -312,7 +312,11 @@ class FlatCEMSampler:
         return D.dist.get_world_size() if D.dist.is_initialized() else 1
 
     def _draw(self, n, gen):
-        eps = torch.randn(n, self._n_steps, self._action_dim, device=self.device, generator=gen)
+        return self.from_unit_noise(torch.randn(n, self._n_steps, self._action_dim, device=self.device, generator=gen))
+
+    def from_unit_noise(self, eps):
+        """the population that standard-normal numbers eps [n, n_steps, action_dim] stand for (sampler.py:40-42: np.random.normal(loc=mean,
+        scale=std) = mean + std * eps, clipped) — the deterministic part of `sample`, pinned to the reference's on its own draws"""
         raw = self.mean[None] + self.std[None] * eps
         return raw.clamp(-self._clip_val, self._clip_val) if np.isfinite(self._clip_val) else raw
 
@@ -353,8 +357,8 @@ class PDDMSampler(FlatCEMSampler):
     BETA = 0.5      # noise correlation factor
     GAMMA = 1.0     # reward weighting factor
 
-    def _draw(self, n, gen):
-        noise = self.std[None] * torch.randn(n, self._n_steps, self._action_dim, device=self.device, generator=gen)
+    def from_unit_noise(self, eps):
+        noise = self.std[None] * eps
         # the recurrence unrolled: n_i = BETA sum_{k <= i} (1 - BETA)^(i - k) u_k — one lower-triangular mixing of the step axis
         i = torch.arange(self._n_steps, device=self.device)
         w = self.BETA * (1.0 - self.BETA) ** (i[:, None] - i[None]).clamp(min=0).to(torch.float32) * (i[:, None] >= i[None])
