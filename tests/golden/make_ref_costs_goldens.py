@@ -1,6 +1,8 @@
 """Golden vectors from the REFERENCE's hand-written planner costs and flat samplers, produced by executing
 /root/reference/gcp/planning/cem/cost_fcn.py (CostFcn / EuclideanDistance / EuclideanPathLength / StepPathLength / L2ImageCost, :8-77)
-and /root/reference/gcp/planning/cem/sampler.py (FlatCEMSampler / PDDMSampler, :33-71) in the build container.
+and /root/reference/gcp/planning/cem/sampler.py (FlatCEMSampler / PDDMSampler, :33-71), plus the input conventions of
+/root/reference/gcp/planning/cem/cem_simulator.py (GCPImageSimulator._env2planner / _postprocess_inputs, ActCondGCPImageSimulator, :72-104),
+in the build container.
 
 Run from the repo root:  python tests/golden/make_ref_costs_goldens.py  ->  tests/golden/ref_costs_samplers.npz   (arrays only)
 
@@ -93,6 +95,22 @@ def main():
         s.fit(data, scores)
         out[f"{tag}_fit_data"], out[f"{tag}_fit_scores"] = data, scores
         out[f"{tag}_fit_mean"], out[f"{tag}_fit_std"], out[f"{tag}_fit_std_before"] = s.mean, s.std, std0
+    # ---- simulator input conventions (cem_simulator.py:72-104) ----
+    import torch
+    SIM = load("ref_cem_simulator", os.path.join(REF, "cem", "cem_simulator.py"))
+    AttrDict = sys.modules["blox"].AttrDict
+    u8 = rng.randint(0, 256, size=(1, 4, 4, 3)).astype(np.uint8)
+    unit = rng.rand(2, 4, 4, 3).astype(np.float32)                 # already in [0, 1]
+    five = rng.randint(0, 256, size=(1, 2, 4, 4, 3)).astype(np.uint8)
+    for tag, img in (("u8", u8), ("unit", unit), ("five", five)):
+        out[f"env_{tag}_in"] = img
+        out[f"env_{tag}_out"] = SIM.GCPImageSimulator._env2planner(torch.tensor(img.astype(np.float32))).numpy()
+    acts = rng.randn(3, 5, 2).astype(np.float32)
+    sim = SIM.ActCondGCPImageSimulator(None, True)
+    inp = sim._postprocess_inputs(AttrDict(z=torch.tensor(acts), I_0=torch.tensor(u8.astype(np.float32)).repeat(3, 1, 1, 1),
+                                           I_g=torch.tensor(u8.astype(np.float32)).repeat(3, 1, 1, 1)))
+    assert "z" not in inp
+    out["act_in"], out["act_actions"], out["act_pad_mask"], out["act_I_0"] = acts, inp.actions.numpy(), inp.pad_mask.numpy(), inp.I_0.numpy()
     np.savez_compressed(os.path.join(HERE, "ref_costs_samplers.npz"), **out)
     print("wrote ref_costs_samplers.npz:", len(out), "arrays")
 

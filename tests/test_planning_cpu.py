@@ -186,3 +186,16 @@ def test_costs_and_samplers_match_the_executed_reference():
         assert np.allclose(s.std.numpy(), g[f"{tag}_fit_std"], atol=2e-6), tag          # (PDDM never refits its std: equals the initial one)
         if tag == "pddm":
             assert np.array_equal(g["pddm_fit_std"], g["pddm_fit_std_before"])
+
+
+def test_simulator_input_conventions_match_the_executed_reference():
+    """GCPImageSimulator._env2planner on uint8 / unit-range / 5-d inputs and ActCondGCPImageSimulator._postprocess_inputs
+    (cem_simulator.py:72-104) executed in the build container: env images -> NCHW in [-1, 1]; the action-conditioned simulator's
+    candidates are the planner's samples themselves ([n, T-1, n_actions]) with a pad mask of ones"""
+    from video_gcp_amd.planning import env2planner
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_costs_samplers.npz"))
+    for tag in ("u8", "unit", "five"):
+        got = env2planner(g[f"env_{tag}_in"])
+        assert got.dtype == torch.float32 and np.array_equal(got.numpy(), g[f"env_{tag}_out"]), tag
+    assert np.array_equal(g["act_actions"], g["act_in"]) and np.array_equal(g["act_pad_mask"], np.ones(g["act_in"].shape[:2], np.float32))
+    assert np.array_equal(env2planner(np.repeat(g["env_u8_in"], 3, 0)).numpy(), g["act_I_0"])
