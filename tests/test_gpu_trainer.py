@@ -48,3 +48,33 @@ def test_trainer_runs_the_flat_vrnn_baseline(tmp_path):
     assert os.path.exists(os.path.join(str(exp), "weights", "weights_ep0.pth"))
     tr2 = ModelTrainer(get_cmd_args(argv + ["--resume", "latest", "--train", "0"]))
     assert tr2.resume("latest") == 1 and torch.equal(tr2.model.theta, tr.model.theta)
+
+
+def test_trainer_runs_the_vmpc_variant_from_a_reference_style_conf(tmp_path):
+    """a conf.py on top of experiments/prediction/base_configs/vmpc.py (action-conditioned, deterministic, not goal-conditioned flat
+    predictor): loaded by conf_loader, trained by the same entry point, loss falls on a fixed batch, checkpoint holds the action encoder"""
+    import textwrap
+    from video_gcp_amd.sequential import GCPSequentialModel
+    from video_gcp_amd.train import ModelTrainer, get_cmd_args
+    exp = tmp_path / "vmpc"
+    exp.mkdir()
+    (exp / "conf.py").write_text(textwrap.dedent('''
+        from blox import AttrDict
+        from experiments.prediction.base_configs import vmpc as base_conf
+        configuration = AttrDict(base_conf.configuration)
+        configuration.update({'batch_size': 2, 'lr': 1e-3})
+        model_config = AttrDict(base_conf.model_config)
+        model_config.update({'nz_mid_lstm': 128, 'max_seq_len': 12, 'img_sz': 32})
+        model_config.pop("add_weighted_pixel_copy")
+    '''))
+    argv = ["--path", str(exp), "--num_epochs", "1", "--batches_per_epoch", "6", "--log_outputs_interval", "1"]
+    tr = ModelTrainer(get_cmd_args(argv))
+    hp = tr.model._hp
+    assert isinstance(tr.model, GCPSequentialModel) and hp.action_conditioned_pred and hp.deterministic and hp.non_goal_conditioned
+    before = tr.model.sd["action_encoder.input.linear.weight"].clone()
+    tr.run()
+    losses = [l for _, l in tr.log]
+    assert tr.global_step == 6 and all(torch.isfinite(torch.tensor(losses)))
+    assert not torch.equal(tr.model.sd["action_encoder.input.linear.weight"], before)       # the action encoder is trained
+    ck = torch.load(os.path.join(str(exp), "weights", "weights_ep0.pth"))
+    assert any(k.startswith("action_encoder.") for k in ck["state_dict"]) and not any("prior_lstm" in k for k in ck["state_dict"])
