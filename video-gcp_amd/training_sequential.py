@@ -17,6 +17,10 @@ inputs and gates are kept), like `GCPTrainStep`'s for the tree model, whose deco
 
 A step of a chain is: out^T, n x (LSTM-cell backward, [W_ih | W_hh]^T in one GEMM), embed^T — eight dependent small launches at
 16 rows.  The three nets' chains are each T - 1 steps long; they are latency-bound (weights stream from L2 / MALL), not MFMA-bound.
+
+Variants of base_configs/vmpc.py (GCPSequentialModel._nets, hparams.action_conditioned_pred / deterministic): a deterministic predictor
+has only the generator chain (no KL, no latent backward, no prior / inference chain); with action conditioning the last nz_enc input
+columns of every net are the encoded action, whose gradient — summed over the nets — goes through the action encoder's Predictor backward.
 """
 import ctypes as C
 
@@ -27,8 +31,6 @@ from . import runtime as rt
 from .model import _Plan, _addr
 from .params import decoder_layers
 from .training import GCPTrainStep, _c16
-
-NETS = ("prior_lstm", "inf_lstm", "gen_lstm")
 
 
 class SequentialTrainStep(GCPTrainStep):
@@ -160,7 +162,7 @@ class SequentialTrainStep(GCPTrainStep):
         assert rec.get("nll_bwd_fused"), "the training forward produces d NLL / d parameters together with the loss"
         dMD = buf("bw.dMD", (B * T, S_, S_, m._head_pitch))
         if det:
-            pass
+            pass                                              # no latent: no KL term, dQZ / dPZ are empty
         elif m._kl_w is not None:                               # burn-in schedule: kl_weight(step) is read from device memory
             plan.add("bw.kl", lib.gcpx_kl_bwd_scheduled, QZ.data_ptr(), PZ.data_ptr(), dQZ.data_ptr(), dPZ.data_ptr(), B, T - 1, nv,
                      (T - 1) * 2 * nv, 2 * nv, C.c_float(hp.free_nats), C.c_float(1.0 / (B * div)), _addr(tin["pad_mask"], 1), T,
