@@ -379,8 +379,8 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev, dinp_noloss)
                                             "unit": "ms",
                                             "workload": "HierarchicalCEMPlanner (tree_optimizer.py:7-260; sampling rates [10, 10], the 25-room "
                                                         "control setting) for one (start, goal) pair at 64x64, horizon 80: device-resident, "
-                                                        "per-rank (not sharded).  ms_per_call: fast_draws=True (numpy Generator, only the rows "
-                                                        "the search keeps are drawn); ms_per_call_reference_rng_stream: the reference's "
+                                                        "per-rank (not sharded).  ms_per_call: fast_draws=True (seeded device generator, only the "
+                                                        "rows the search keeps are drawn); ms_per_call_reference_rng_stream: the reference's "
                                                         "np.random call sequence draw for draw (3.5 M legacy Gaussians per call on the host)"}
         del m4
     except Exception as e:  # noqa: BLE001

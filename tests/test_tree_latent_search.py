@@ -80,3 +80,30 @@ def test_generator_draws_run_the_same_search_on_fewer_gaussians():
     # the draws are standard normal
     big = ImageHierarchicalTreeLatentOptimizer(64, [10, 10], 7, StubCost(), StubCost(), 5, rng=np.random.default_rng(0)).sample()
     assert big.shape == (10, 127, 64) and abs(float(big.mean())) < 0.02 and abs(float(big.std()) - 1.0) < 0.02
+
+
+def test_torch_generator_draws_have_the_same_layout():
+    """rng=torch.Generator (what the device-resident planner uses): `sample()` is built on the generator's device — same shape, same
+    depth-first layout ([left | node | right]: a fixed root latent sits in the middle of every row), reproducible from the seed"""
+    import torch
+    from planner_stubs import StubCost
+    from video_gcp_amd.tree_latent_search import ImageHierarchicalTreeLatentOptimizer
+
+    def make(seed):
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed)
+        return ImageHierarchicalTreeLatentOptimizer(8, [4, 3], 5, StubCost(), StubCost(), 2, rng=g)
+    a, b = make(1), make(1)
+    za, zb = a.sample(), b.sample()
+    assert torch.is_tensor(za) and za.shape == (4, 31, 8) and za.dtype == torch.float32 and torch.equal(za, zb)
+    assert len({tuple(za[i, 15].tolist()) for i in range(4)}) == 4                 # one root latent per sample
+    # fix the root the way _opt_subgoal does and draw again: every row carries it, the level below is now the sampled one
+    root = a._root
+    root.best_z, root.done, root.n_samples = root.last_draw[2], True, 1
+    root.left, root.right = root.left[:1], root.right[:1]
+    z2 = a.sample()
+    assert z2.shape == (3, 31, 8) and all(torch.equal(z2[i, 15], za[2, 15]) for i in range(3))
+    assert len({tuple(z2[i, 7].tolist()) for i in range(3)}) == 3                  # left child's subgoal latent: one per sample
+    big = make(0)
+    big._dim = 64
+    assert abs(float(torch.cat([big.sample() for _ in range(20)]).std()) - 1.0) < 0.02

@@ -490,7 +490,10 @@ class ImageHierarchicalTreeCEMSampler:
                                     rng=self._rng)
 
     def sample(self, n_samples=None):
-        return np.clip(self._optimizer.sample(), -self._clip_val, self._clip_val)
+        z = self._optimizer.sample()
+        if torch.is_tensor(z):                                      # (generator mode on the device)
+            return z.clamp(-self._clip_val, self._clip_val) if np.isfinite(self._clip_val) else z
+        return np.clip(z, -self._clip_val, self._clip_val)
 
     def optimize(self, rollouts, goal):
         best_rollout, best_cost = self._optimizer.optimize(rollouts, goal)
@@ -538,15 +541,27 @@ class HierarchicalCEMPlanner:
         self._sampler = ImageHierarchicalTreeCEMSampler(clip_val, max_seq_len, action_dim, 1.0, n_level_hierarchy,
                                                         sampling_rates_per_layer, cost, cost, n_ll_samples,
                                                         device_resident=self.device_resident,
-                                                        rng=(np.random.default_rng(seed) if fast_draws else None))
+                                                        rng=self._make_rng(fast_draws, seed))
         self.logs = []
+
+    def _make_rng(self, fast_draws, seed):
+        """fast_draws: False -> None (the reference's np.random stream); True -> a seeded generator — on the model's device when the
+        search is device-resident (the population is then drawn where the rollout reads it), numpy's otherwise"""
+        if not fast_draws:
+            return None
+        dev = getattr(getattr(self._sim, "_model", None), "device", None)
+        if self.device_resident and dev is not None and dev.type == "cuda":
+            g = torch.Generator(device=dev)
+            g.manual_seed(int(seed))
+            return g
+        return np.random.default_rng(seed)
 
     def __call__(self, state, goal_state):
         self._sampler.init()
         self.logs = []
         goal = np.asarray(goal_state)
         best_samples = best_scores = None
-        for _ in range(self.n_iters):
+        for it in range(self.n_iters):
             samples = self._sampler.sample()
             if self.device_resident:
                 # the learned cost reads latents only (cost_fcn.py:84-97): the scoring rollouts skip the image decoder
@@ -555,7 +570,10 @@ class HierarchicalCEMPlanner:
             else:
                 rollouts = self._sim.rollout(state, goal, samples, self.max_seq_len)
                 best_rollouts, best_scores = self._sampler.optimize(rollouts.predictions, goal)     # cem_planner.py:215
-            best_samples = self._sampler.sample()                                               # :216
+            # :216 draws the population again after every round; only the last one (everything optimised: no randomness left in it) is
+            # used.  The reference's stream has to consume the others' Gaussians to stay draw-for-draw; the generator mode skips them.
+            if self._sampler._rng is None or it == self.n_iters - 1:
+                best_samples = self._sampler.sample()
             self.logs.append(Outputs(elite_rollouts=best_rollouts, elite_scores=best_scores))
         final = self._sim.rollout(state, goal, best_samples, self.max_seq_len)
         actions = final.actions[0] if final.actions is not None else None

@@ -47,7 +47,8 @@ class HierarchicalTreeLatentOptimizer:
                  image_states=True, rng=None):
         """rng: None = the reference's draws (module-level np.random, the legacy Gaussian stream, every draw the reference makes —
         bit-exact with its class); a np.random.Generator = the same search on that generator with only the KEPT rows drawn, see
-        _draw"""
+        _draw; a torch.Generator (of the device the rollouts run on) = the same, drawn on that device (_draw_device: `sample()` then
+        returns a device tensor)"""
         self._rng = rng
         self._dim = latent_dim
         self._pair_cost = subgoal_cost_fcn
@@ -59,7 +60,35 @@ class HierarchicalTreeLatentOptimizer:
     def sample(self):
         return self._draw(self._root, False)
 
+    def _draw_device(self, lv, below):
+        """`_draw` in generator mode with a torch.Generator: the population is built where the model reads it (a dozen small launches
+        per call instead of ~300 k host Gaussians and an upload); same tree walk, rows i.i.d. N(0, 1)"""
+        import torch
+        g = self._rng
+        if below:
+            assert not lv.done
+            return torch.randn(1, 2 ** lv.depth - 1, self._dim, generator=g, device=g.device)
+        if lv.done:
+            z = lv.best_z[None]
+        else:
+            z = torch.randn(lv.n_samples, lv.n_latents, self._dim, generator=g, device=g.device)
+            lv.last_draw = z
+        if lv.left is None:
+            return z
+        rows = []
+        for cl, cr, zi in zip(lv.left, lv.right, z):
+            zl, zr = self._draw_device(cl, not lv.done), self._draw_device(cr, not lv.done)
+            rows.append(torch.cat([zl, zi[:1].expand(zl.shape[0], 1, self._dim), zr], dim=1))      # depth-first: left | node | right
+        return torch.cat(rows)
+
     def _draw(self, lv, below):
+        if self._rng is not None and not isinstance(self._rng, np.random.Generator):
+            return self._draw_device(lv, below)
+        if below and self._rng is not None:
+            # generator mode, below the level being optimised: nothing in this subtree is fixed yet (a level is optimised only after
+            # its parent) and one row is kept of every draw — the whole subtree is one block of i.i.d. Gaussians, whatever its layout
+            assert not lv.done
+            return self._rng.standard_normal(size=(1, 2 ** lv.depth - 1, self._dim), dtype=np.float32)
         if lv.done:
             z = lv.best_z.copy()[None]
         else:
