@@ -323,6 +323,7 @@ class GCPTrainStep:
                 plan.keep += [raw, bst]
                 gid = plan.rec["_ngroups"] = plan.rec.get("_ngroups", 0) + 1
                 gtag = f"g{gid}.v{v}x{len(chunk)}"
+                plan.rec.setdefault("_groups", {})[gtag] = [(it[0], it[1].R, it[1].N, it[1].K, it[2]) for it in chunk]   # (tools: what a group holds)
                 out.append((f"bw.wgroup:{gtag}", lib.gcpx_wgrad_group, (raw.data_ptr(), bst.data_ptr(), len(chunk), tot, v)))
                 # the reduction of a split problem's partials must follow the group on the same lane
                 alias = plan.rec.setdefault("_lane_alias", {})
