@@ -117,12 +117,13 @@ def test_gemm_lstm_epilogue(env):
 
 
 @pytest.mark.parametrize("case", ["unit", "tiny", "row_scales", "k_growth", "outlier", "zero_rows"])
-@pytest.mark.parametrize("M,N,K", [(200, 2048, 1024), (130, 192, 128), (512, 512, 1024)])
+@pytest.mark.parametrize("M,N,K", [(200, 2048, 1024), (130, 192, 128), (512, 512, 1024), (8200, 1024, 192)])
 def test_gemm_split_error_vs_float64(env, case, M, N, K):
     """The split-f16 row GEMM (csrc/gemm_split.hip: two f16 pieces per operand, three f16 MFMAs per product, a per-row power-of-two
     scale that follows the row along K) against float64, next to the exact f32 MFMA kernel: rows of magnitude 1e-6 (gradients) next
     to rows of order 1e3, magnitudes growing 1e4-fold along K (the running scale drops and the sums are rescaled), an outlier, and
-    all-zero rows.  Both tile widths (128 / 64 columns) and the masked last row block are covered by the shapes."""
+    all-zero rows.  Both tile widths (128 / 64 columns), the 128-row / 512-thread form of problems with thousands of rows (8200 x 1024)
+    and the masked last row block are covered by the shapes."""
     rt, pk, lib, dev = env
     torch.manual_seed(M + K)
     x = torch.randn(M, K)
@@ -192,6 +193,25 @@ def test_gemm_split_lstm_sources_and_batches(env):
     assert_close(ho, h1, atol=1e-5, name="h")
     assert_close(co, c1, atol=1e-5, name="c")
     assert_close(hc, h1, atol=1e-5, name="h_copy")
+    # the same cell over thousands of rows: the 128-row / 512-thread workgroups (gathered source, LSTM epilogue, masked last block)
+    Mb = 16500
+    ridx_b = torch.randint(0, 500, (Mb,), dtype=torch.int32)
+    xb_, hb_, cb_ = pool[ridx_b.long()], torch.randn(Mb, H), torch.randn(Mb, H)
+    with torch.no_grad():
+        h1b, c1b = cell(xb_, (hb_, cb_))
+    rdb, hdb, cdb = ridx_b.to(dev), hb_.to(dev), cb_.to(dev)
+    hob, cob = (torch.full((Mb, H), float("nan"), device=dev) for _ in range(2))
+    a = rt.GemmArgs()
+    a.src[0] = _rowsrc(rt, pd, 0, H, H, rowidx=rdb)
+    a.src[1] = _rowsrc(rt, hdb, 0, H, H)
+    a.nsrc, a.M, a.N, a.K, a.rpb = 2, Mb, 4 * H, 2 * H, Mb
+    a.wpk, a.bias, a.epi = wp.data_ptr(), bd.data_ptr(), rt.EPI_LSTM
+    a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+    a.c_prev, a.c_prev_stride, a.h_out, a.c_out, a.hb, a.hrow = cdb.data_ptr(), H, hob.data_ptr(), cob.data_ptr(), 0, H
+    rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm split lstm, many rows")
+    torch.cuda.synchronize()
+    assert_close(hob, h1b, atol=1e-5, name="h, many rows")
+    assert_close(cob, c1b, atol=1e-5, name="c, many rows")
     # conv1d-over-time form (three shifted sources with an affine + LReLU on load, rows masked at the sequence ends), LReLU epilogue
     B, T, Cc, N = 4, 40, 64, 128
     xs = torch.randn(B, T, Cc)

@@ -13,7 +13,8 @@
 // with every stage, and the wavefronts that accumulate the row rescale their sums (exactly) when it drops.  A row's error is then
 // a few f32 roundings of its largest term whatever the magnitude of the data — gradients of 1e-6 as well as states of order one.
 //
-// Tiling: one 256-thread workgroup computes 64 rows x TN columns (TN = 128 or 64); a stage is 64 k.  Weights travel global -> registers
+// Tiling: one 256-thread workgroup computes 64 rows x TN columns (TN = 128 or 64) — or, for problems with thousands of rows, one
+// 512-thread workgroup 128 rows x 128 columns (template parameter NW) —; a stage is 32 NSUB k.  Weights travel global -> registers
 // -> LDS in fragment order (the packed layout IS the LDS layout), activations global (gathered / shifted / masked rows, producer's
 // affine + activation applied) -> registers -> two f16 planes in fragment order.  Two LDS stages, the next stage's global loads in
 // flight during this stage's 48 MFMAs per wavefront; wavefront (wr, wc) owns row tiles 2 wr, 2 wr + 1 x column tiles of half wc.
@@ -37,24 +38,27 @@ __device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <int TN, int NSUB>
+// NW = wavefronts of the workgroup: 4 (64 rows) or 8 (128 rows, 512 threads: the same roles per wavefront — a wavefront stages the 16
+// rows of "its" row tile and accumulates two row tiles x half the column tiles —, 1.55x the FLOPs per operand byte pulled)
+template <int TN, int NSUB, int NW = 4>
 struct GsCfg {
-    static constexpr int TM = 64, KS = 32 * NSUB;               // a stage = NSUB sub-steps of 32 k
+    static constexpr int TM = 16 * NW, THREADS = 64 * NW, KS = 32 * NSUB;   // a stage = NSUB sub-steps of 32 k
     static constexpr int NCT = TN / 16;                         // column tiles of the workgroup
     static constexpr int W_SUB = NCT * 2048;                    // one 32-k sub-step: [NCT][2 pieces][64 lanes] x 16 B
     static constexpr int W_BYTES = NSUB * W_SUB;
-    static constexpr int X_SUB = 4 * 2048;                      // [4 row tiles][2 pieces][64 lanes] x 16 B
+    static constexpr int X_SUB = NW * 2048;                     // [NW row tiles][2 pieces][64 lanes] x 16 B
     static constexpr int X_BYTES = NSUB * X_SUB;
-    static constexpr int STAGE = W_BYTES + X_BYTES + 256;       // + the 64 row exponents
+    static constexpr int STAGE = W_BYTES + X_BYTES + 4 * TM;    // + the TM row exponents
     static constexpr int LDS_BYTES = 2 * STAGE;
-    static constexpr int WLD = W_BYTES / (256 * 16);            // 16-byte weight loads per thread and stage (8 / 4)
+    static constexpr int WLD = W_BYTES / (THREADS * 16);        // 16-byte weight loads per thread and stage
+    static constexpr int WSTEP = THREADS * 16;                  // bytes the workgroup moves per weight load
 };
 
 // XF: some source carries an affine / activation on load (its per-channel loads are conditional: the memory counter is then drained
 // at every conversion; the plain variant keeps the newer register set in flight)
-template <int TN, int NSUB, bool LSTM, bool XF>
-__global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a) {
-    using Cfg = GsCfg<TN, NSUB>;
+template <int TN, int NSUB, bool LSTM, bool XF, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) gemm_split_kernel(const gcpx_gemm_args a) {
+    using Cfg = GsCfg<TN, NSUB, NW>;
     constexpr int KS = Cfg::KS;
     constexpr int NCT = Cfg::NCT, WLD = Cfg::WLD, CPW = NCT / 2;          // column tiles per wavefront
     extern __shared__ float4 smem4[];
@@ -71,7 +75,7 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
     // ---- staging role: thread t stages k = 8 kq .. + 7 and 32 + 8 kq .. + 7 of row 16 (t >> 6) + (t & 15), kq = (t & 63) >> 4, of every
     //      stage: its two 16-byte pieces are lane t & 63 of row tile t >> 6 (a wavefront writes 1 KiB contiguous: no bank conflicts) ----
     const int srow = (wave << 4) + j, kq = q;
-    const int sr_ = blockIdx.x * 64 + srow;
+    const int sr_ = blockIdx.x * Cfg::TM + srow;
     const bool srv = sr_ < M;
     const int srs = srv ? sr_ : 0;
     const int srb = srs / rpb, srj = srs % rpb;
@@ -144,7 +148,7 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
 #pragma unroll
         for (int i = 0; i < WLD; ++i) {
             const int sub = i / (WLD / NSUB), c = i % (WLD / NSUB);
-            r.w[i] = *reinterpret_cast<const float4*>(wsrc + ((size_t)(NSUB * last_s + sub) * NT) * 2048 + c * 4096);
+            r.w[i] = *reinterpret_cast<const float4*>(wsrc + ((size_t)(NSUB * last_s + sub) * NT) * 2048 + c * Cfg::WSTEP);
         }
     };
     auto commit = [&](const int st, RegSet& r) __attribute__((always_inline)) {    // registers -> LDS stage st (affine, scale, split)
@@ -152,7 +156,7 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
 #pragma unroll
         for (int i = 0; i < WLD; ++i) {
             const int sub = i / (WLD / NSUB), c = i % (WLD / NSUB);
-            *reinterpret_cast<float4*>(base + sub * Cfg::W_SUB + c * 4096 + tid * 16) = r.w[i];
+            *reinterpret_cast<float4*>(base + sub * Cfg::W_SUB + c * Cfg::WSTEP + tid * 16) = r.w[i];
         }
         if constexpr (XF) {
 #pragma unroll
@@ -278,7 +282,7 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
     // ---- epilogue (scale back: exact; then as gemm.hip) ----
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int r = blockIdx.x * 64 + (2 * wr + i) * 16 + j;
+        const int r = blockIdx.x * Cfg::TM + (2 * wr + i) * 16 + j;
         const bool rv = r < M;
         const int rs = rv ? r : 0;
         const int rb = rs / rpb, rj = rs % rpb;
@@ -313,13 +317,13 @@ __global__ void __launch_bounds__(256) gemm_split_kernel(const gcpx_gemm_args a)
     }
 }
 
-template <int TN, int NSUB>
+template <int TN, int NSUB, int NW = 4>
 int launch_split(const gcpx_gemm_args* a, hipStream_t stream) {
-    using Cfg = GsCfg<TN, NSUB>;
+    using Cfg = GsCfg<TN, NSUB, NW>;
     static bool attr_set = false;
     if (!attr_set) {
-        for (const void* k : {reinterpret_cast<const void*>(gemm_split_kernel<TN, NSUB, false, false>), reinterpret_cast<const void*>(gemm_split_kernel<TN, NSUB, true, false>),
-                              reinterpret_cast<const void*>(gemm_split_kernel<TN, NSUB, false, true>), reinterpret_cast<const void*>(gemm_split_kernel<TN, NSUB, true, true>)}) {
+        for (const void* k : {reinterpret_cast<const void*>(gemm_split_kernel<TN, NSUB, false, false, NW>), reinterpret_cast<const void*>(gemm_split_kernel<TN, NSUB, true, false, NW>),
+                              reinterpret_cast<const void*>(gemm_split_kernel<TN, NSUB, false, true, NW>), reinterpret_cast<const void*>(gemm_split_kernel<TN, NSUB, true, true, NW>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
             if (e != hipSuccess) {
                 gcpx_set_error("gemm split: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
@@ -329,13 +333,13 @@ int launch_split(const gcpx_gemm_args* a, hipStream_t stream) {
         attr_set = true;
     }
     const int nb = a->nbatch > 1 ? a->nbatch : 1;
-    const dim3 grid((a->M + 63) / 64, a->N / TN, nb);
+    const dim3 grid((a->M + Cfg::TM - 1) / Cfg::TM, a->N / TN, nb);
     bool xf = false;
     for (int s = 0; s < a->nsrc; ++s) xf = xf || a->src[s].scale || a->src[s].act;
     const bool lstm = a->epi == GCPX_EPI_LSTM;
-    auto kern = lstm ? (xf ? gemm_split_kernel<TN, NSUB, true, true> : gemm_split_kernel<TN, NSUB, true, false>)
-                     : (xf ? gemm_split_kernel<TN, NSUB, false, true> : gemm_split_kernel<TN, NSUB, false, false>);
-    hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, stream, *a);
+    auto kern = lstm ? (xf ? gemm_split_kernel<TN, NSUB, true, true, NW> : gemm_split_kernel<TN, NSUB, true, false, NW>)
+                     : (xf ? gemm_split_kernel<TN, NSUB, false, true, NW> : gemm_split_kernel<TN, NSUB, false, false, NW>);
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, *a);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }
@@ -363,9 +367,14 @@ int gcpx_launch_gemm_split(const gcpx_gemm_args* a, hipStream_t stream) {
     if (force == 641) return launch_split<64, 1>(a, stream);
     if (force == 1281) return launch_split<128, 1>(a, stream);
     if (force == 2561 && a->N % 256 == 0) return launch_split<256, 1>(a, stream);
+    if (force == 1288 && a->N % 128 == 0) return launch_split<128, 1, 8>(a, stream);      // 128 x 128 tiles, 512 threads
     // Stages of 32 k: 24 / 16 KB of LDS per stage, so 3 - 4 workgroups share a CU and one's barrier and conversion hide behind the
     // others' loads (64-k stages, one or two workgroups per CU: 1024 x 2048 x 1024 38 us, 32768 rows 1082 us; 32-k stages 35 / 754).
     // 128-column tiles (fewer operand bytes per MFMA) once they still give every CU three workgroups, 64-column tiles below.
+    // Many rows (the planner's 65 k-node trees): 128 x 128 tiles in 512-thread workgroups once they still give every CU two of them —
+    // 1.55x the FLOPs per operand byte pulled, the same number of wavefronts per CU: 32768 / 8192 / 4096 x 2048 x 1024 802 / 199 / 94 us
+    // against 872 / 214 / 107 (at 1024 rows 44 against 35: half the chip without a workgroup).
+    if (a->N % 128 == 0 && ((a->M + 127) / 128) * (long)(a->N / 128) * nb >= 512) return launch_split<128, 1, 8>(a, stream);
     if (a->N % 128 == 0 && rbk * (a->N / 128) * nb >= 768) return launch_split<128, 1>(a, stream);
     return launch_split<64, 1>(a, stream);
 }
