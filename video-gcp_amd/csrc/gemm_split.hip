@@ -368,8 +368,9 @@ int gcpx_launch_gemm_split(const gcpx_gemm_args* a, hipStream_t stream) {
     if (force == 1281) return launch_split<128, 1>(a, stream);
     if (force == 2561 && a->N % 256 == 0) return launch_split<256, 1>(a, stream);
     if (force == 1288 && a->N % 128 == 0) return launch_split<128, 1, 8>(a, stream);      // 128 x 128 tiles, 512 threads
-    // Stages of 32 k: 24 / 16 KB of LDS per stage, so 3 - 4 workgroups share a CU and one's barrier and conversion hide behind the
-    // others' loads (64-k stages, one or two workgroups per CU: 1024 x 2048 x 1024 38 us, 32768 rows 1082 us; 32-k stages 35 / 754).
+    // Stages of 32 k: 24 / 16 KB of LDS per stage and 208 / 144 registers per thread (128- / 64-column tiles), so two / three workgroups
+    // share a CU — the registers, not the LDS, set that number — and one's barrier and conversion hide behind the others' loads (64-k
+    // stages: 264 / 176 registers, one or two workgroups per CU: 1024 x 2048 x 1024 38 us, 32768 rows 1082 us; 32-k stages 35 / 754).
     // 128-column tiles (fewer operand bytes per MFMA) once they still give every CU three workgroups, 64-column tiles below.
     // Many rows (the planner's 65 k-node trees): 128 x 128 tiles in 512-thread workgroups once they still give every CU two of them —
     // 1.55x the FLOPs per operand byte pulled, the same number of wavefronts per CU: 32768 / 8192 / 4096 x 2048 x 1024 802 / 199 / 94 us
