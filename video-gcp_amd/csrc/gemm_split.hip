@@ -230,32 +230,38 @@ __global__ void __launch_bounds__(64 * NW) gemm_split_kernel(const gcpx_gemm_arg
         }
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
-            h8 b[2][2], w[CPW][2];
+            h8 b[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const char* bp = base + Cfg::W_BYTES + sub * Cfg::X_SUB + ((2 * wr + i) * 2) * 1024 + lane * 16;
                 b[i][0] = *reinterpret_cast<const h8*>(bp);
                 b[i][1] = *reinterpret_cast<const h8*>(bp + 1024);
             }
+            // column tiles four at a time (the 256-column form would hold 64 registers of weight fragments otherwise)
+            constexpr int CH = CPW <= 4 ? CPW : 2;
 #pragma unroll
-            for (int c = 0; c < CPW; ++c) {
-                const char* wp = base + sub * Cfg::W_SUB + ((wc * CPW + c) * 2) * 1024 + lane * 16;
-                w[c][0] = *reinterpret_cast<const h8*>(wp);
-                w[c][1] = *reinterpret_cast<const h8*>(wp + 1024);
+            for (int c0 = 0; c0 < CPW; c0 += CH) {
+                h8 w[CH][2];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const char* wp = base + sub * Cfg::W_SUB + ((wc * CPW + c0 + c) * 2) * 1024 + lane * 16;
+                    w[c][0] = *reinterpret_cast<const h8*>(wp);
+                    w[c][1] = *reinterpret_cast<const h8*>(wp + 1024);
+                }
+                // small terms first: they are added to the accumulator while it is still small
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[c0 + c][i] = mfma32h(w[c][1], b[i][0], acc[c0 + c][i]);
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[c0 + c][i] = mfma32h(w[c][0], b[i][1], acc[c0 + c][i]);
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[c0 + c][i] = mfma32h(w[c][0], b[i][0], acc[c0 + c][i]);
             }
-            // small terms first: they are added to the accumulator while it is still small
-#pragma unroll
-            for (int c = 0; c < CPW; ++c)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[c][i] = mfma32h(w[c][1], b[i][0], acc[c][i]);
-#pragma unroll
-            for (int c = 0; c < CPW; ++c)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[c][i] = mfma32h(w[c][0], b[i][1], acc[c][i]);
-#pragma unroll
-            for (int c = 0; c < CPW; ++c)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[c][i] = mfma32h(w[c][0], b[i][0], acc[c][i]);
         }
     };
 
@@ -368,6 +374,7 @@ int gcpx_launch_gemm_split(const gcpx_gemm_args* a, hipStream_t stream) {
     if (force == 1281) return launch_split<128, 1>(a, stream);
     if (force == 2561 && a->N % 256 == 0) return launch_split<256, 1>(a, stream);
     if (force == 1288 && a->N % 128 == 0) return launch_split<128, 1, 8>(a, stream);      // 128 x 128 tiles, 512 threads
+    if (force == 2568 && a->N % 256 == 0) return launch_split<256, 1, 8>(a, stream);      // 128 x 256 tiles, 512 threads
     // Stages of 32 k: 24 / 16 KB of LDS per stage and 208 / 144 registers per thread (128- / 64-column tiles), so two / three workgroups
     // share a CU — the registers, not the LDS, set that number — and one's barrier and conversion hide behind the others' loads (64-k
     // stages: 264 / 176 registers, one or two workgroups per CU: 1024 x 2048 x 1024 38 us, 32768 rows 1082 us; 32-k stages 35 / 754).
@@ -375,6 +382,9 @@ int gcpx_launch_gemm_split(const gcpx_gemm_args* a, hipStream_t stream) {
     // Many rows (the planner's 65 k-node trees): 128 x 128 tiles in 512-thread workgroups once they still give every CU two of them —
     // 1.55x the FLOPs per operand byte pulled, the same number of wavefronts per CU: 32768 / 8192 / 4096 x 2048 x 1024 802 / 199 / 94 us
     // against 872 / 214 / 107 (at 1024 rows 44 against 35: half the chip without a workgroup).
+    // ... and 128 x 256 tiles (2.1x) once those give every CU a workgroup: 640 / 155 / 77 us, the batched merge 813 against 1 013 us
+    // (one workgroup of eight wavefronts per CU in both forms: 256 / 184 registers per thread).
+    if (a->N % 256 == 0 && ((a->M + 127) / 128) * (long)(a->N / 256) * nb >= 256) return launch_split<256, 1, 8>(a, stream);
     if (a->N % 128 == 0 && ((a->M + 127) / 128) * (long)(a->N / 128) * nb >= 512) return launch_split<128, 1, 8>(a, stream);
     if (a->N % 128 == 0 && rbk * (a->N / 128) * nb >= 768) return launch_split<128, 1>(a, stream);
     return launch_split<64, 1>(a, stream);
