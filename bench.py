@@ -35,17 +35,23 @@ def kernel_source_sha(paths=HEAD_KERNEL_SOURCES):
 def measured_head_traffic(batch, eval_bn):
     """HBM bytes per launch of the head kernel from the rocprofv3 PMC passes of tools/pmc_collect.sh (FETCH_SIZE x 2 for the
     gfx950 wide-load undercount + WRITE_SIZE, MI355X_MICROARCH.md "HBM"), valid only for the kernel sources they were taken on:
-    the summary records a hash of those sources, and a mismatch (kernel edited since) or another workload prints null."""
+    the summary records a hash of those sources, and a mismatch (kernel edited since) or another workload prints null — with the
+    reason on stderr, so a regenerated summary that lost a field does not make `roofline.traffic` disappear silently."""
+    def reject(why):
+        print(f"bench: roofline.traffic = null ({PMC_SUMMARY}: {why})", file=sys.stderr, flush=True)
+        return None
     try:
         with open(PMC_SUMMARY) as f:
             d = json.load(f)
-        if d.get("kernel_src_sha") != kernel_source_sha() or d.get("batch") != batch or bool(d.get("eval_bn")) != bool(eval_bn):
-            return None
+        if d.get("kernel_src_sha") != kernel_source_sha():
+            return reject(f"taken on kernel sources {d.get('kernel_src_sha')}, these are {kernel_source_sha()}")
+        if d.get("batch") != batch or bool(d.get("eval_bn")) != bool(eval_bn):
+            return reject(f"taken at batch {d.get('batch')}, eval_bn {d.get('eval_bn')}")
         if not d.get("with_loss"):          # the headline forward keeps the matched frames' raw parameters (a round-2 pass did not)
-            return None
+            return reject("no `with_loss` field: not a pass over the forward with losses")
         return int(d["traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+    except (OSError, KeyError, ValueError) as e:
+        return reject(repr(e))
 
 
 def _stats(ts):
@@ -212,15 +218,21 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev, dinp_noloss)
         except Exception as e:  # noqa: BLE001
             return None, repr(e)[:300]
 
+    # round-2 headline for continuity: the same forward WITHOUT loss inputs (mean-only head: 80 of the 100 mixture channels)
     try:
-        # round-2 headline for continuity: the same forward WITHOUT loss inputs (mean-only head: 80 of the 100 mixture channels)
+        _, err = setup(lambda: model(dinp_noloss, "train"))
+        if not agree(err is None):
+            raise RuntimeError(err or "set-up failed on another rank")
         dt = _timed(lambda: model(dinp_noloss, "train"), k, 2, world, dev)
         res["forward_no_loss"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
                                   "ms_per_step": round(1e3 * dt, 3),
                                   "workload": "posterior forward without pad_mask: no loss kernels, head computes the 80 channels the mixture "
                                               "mean reads (the round-2 headline; an inference forward no reference entry point runs)"}
-        # the planner's rollout (cem_simulator.py:29-31): eval-mode (running-stat BatchNorm) prior path with given latents z
-        was = model.training
+    except Exception as e:  # noqa: BLE001
+        res["forward_no_loss"] = {"error": repr(e)[:300]}
+    # the planner's rollout (cem_simulator.py:29-31): eval-mode (running-stat BatchNorm) prior path with given latents z
+    was = model.training
+    try:
         model.eval()
         zin = dict(I_0=dinp["I_0"], I_g=dinp["I_g"], end_ind=dinp["end_ind"], start_ind=dinp["start_ind"],
                    z=torch.randn(hp.batch_size, hp.n_nodes, hp.nz_vae, device=dev))
@@ -228,14 +240,18 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev, dinp_noloss)
         def rollout():
             with model.val_mode(pred_length=False):
                 model(zin, "train")
+        _, err = setup(rollout)
+        if not agree(err is None):
+            raise RuntimeError(err or "set-up failed on another rank")
         dt = _timed(rollout, k, 2, world, dev)
-        model.train(was)
         res["planning_rollout"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
                                    "ms_per_step": round(1e3 * dt, 3),
                                    "workload": "eval-mode planner rollout at the headline batch: prior path with given z, running-stat "
                                                "BatchNorm, every node decoded (mean-only head), no trajectory encoder"}
     except Exception as e:  # noqa: BLE001
-        res["forward_no_loss"] = {"error": repr(e)[:300]}
+        res["planning_rollout"] = {"error": repr(e)[:300]}
+    finally:
+        model.train(was)              # the exact-f32 leg below must run with the headline's batch-stat BatchNorm whatever happened here
     if model.split_f16 and model.pk_split:
         # the same forward with every conv on the exact f32 MFMA kernels (GCPX_EXACT_F32=1), for comparison
         try:

@@ -94,6 +94,7 @@ def test_adaptive_base_config_and_errors(tmp_path):
         configuration.update({'batch_size': 8, 'lr': 1e-3})
         model_config = AttrDict(base_conf.model_config)
         model_config.update({'hierarchy_levels': 8})
+        model_config.pop("add_weighted_pixel_copy")
     '''))
     hp, trainer, _ = CL.load_conf(str(tmp_path), max_seq_len=200)
     assert hp.adaptive and hp.attentive_inference and hp.batch_size == 8
@@ -123,3 +124,11 @@ def test_conf_json_and_default(tmp_path):
 def test_the_reference_25room_conf_itself():
     hp, trainer, ignored = CL.load_conf("/root/reference/experiments/prediction/25room/gcp_tree", max_seq_len=200)
     assert trainer["lr"] == 2e-4 and hp.batch_size == 16 and hp.hierarchy_levels == 8 and hp.attach_cost_mdl
+
+
+def test_a_conf_that_keeps_the_pixel_copy_stream_is_refused(tmp_path):
+    """base_configs/base_tree.py sets add_weighted_pixel_copy=True (hyperparameters.py:54) and the room confs pop it; a conf that
+    keeps it asks for a decoder this build does not have and must not train a different one silently"""
+    (tmp_path / "conf.py").write_text(CONF.replace('model_config.pop("add_weighted_pixel_copy")', ''))
+    with pytest.raises(ValueError, match="add_weighted_pixel_copy"):
+        CL.load_conf(str(tmp_path), max_seq_len=200)

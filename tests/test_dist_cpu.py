@@ -212,6 +212,10 @@ def _rebackward_worker(rank, world, port, q):
     outs.append((scale, tr.grad.clone()))
     backward(300 + rank)
     scale = tr.buckets.finish()
+    once = tr.grad.clone()
+    # a caller that inspects the reduced gradient and then runs optimizer_step() calls finish() a second time in the same pass: the
+    # slices must not be summed over the ranks again (round-3 advisor finding)
+    assert tr.buckets.finish() == scale and torch.equal(tr.grad, once)
     outs.append((scale, tr.grad.clone()))
     q.put((rank, outs))
     torch.distributed.destroy_process_group()

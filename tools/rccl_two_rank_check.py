@@ -28,7 +28,8 @@ for step in range(2):
     want = ref.grad.clone()
     dist.all_reduce(want)                                  # plain sum over the ranks
     tr.backward(d, noise.to(dev))
-    scale = tr.buckets.finish()                            # what optimizer_step does first
+    scale = tr.buckets.finish()                            # what optimizer_step does first (idempotent within a backward pass:
+                                                           # optimizer_step's own finish() below does not reduce a second time)
     torch.cuda.synchronize()
     numel = {k: v.numel() for k, v in ref.named_grads().items()}
     bad = [k for k, (o, shp) in tr.m._poff.items() if not torch.equal(tr.grad[o:o + numel[k]], want[o:o + numel[k]])]

@@ -146,7 +146,11 @@ def hparams_from_conf(configuration, model_config, **over):
     if (mc.get("tree_lstm", "split_linear") or "") not in ("split_linear", "linear", "sum", ""):      # tree_lstm.py:52-60; '' / None = the
         raise ValueError(f"model_config['tree_lstm'] = {mc['tree_lstm']!r}: split_linear, linear, sum and '' are built")   # non-LSTM predictor
     if mc.pop("add_weighted_pixel_copy", False):
-        ignored.append("add_weighted_pixel_copy")        # 25room/gcp_tree/conf.py:43 pops it as well
+        # hyperparameters.py:54; base_configs/base_tree.py and gcp_sequential.py set it, every room conf pops it again
+        # (25room/gcp_tree/conf.py:43).  A conf that keeps it asks for a decoder with a pixel-copy stream, which is not built: training
+        # a different decoder silently is worse than stopping
+        raise ValueError("model_config['add_weighted_pixel_copy'] = True: the weighted pixel-copy decoder stream is not built "
+                         "(the 25-room / 9-room confs pop the key: `model_config.pop('add_weighted_pixel_copy')`)")
     inv = mc.pop("inv_mdl_params", None) or {}
     if "n_actions" in inv:
         kw["n_actions"] = int(inv["n_actions"])

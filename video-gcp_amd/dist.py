@@ -114,6 +114,7 @@ class GradBuckets:
     def __init__(self, flat, ranges, group=None):
         self.flat, self.ranges, self.group = flat, list(ranges), group
         self.works = {}
+        self.reduced = set()           # buckets whose all-reduce has been issued in THIS backward pass (reset by begin())
         self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
 
     def begin(self):
@@ -124,11 +125,13 @@ class GradBuckets:
         for w in self.works.values():
             w.wait()
         self.works = {}
+        self.reduced = set()
 
     def reduce_async(self, i, after_streams=()):
         """Start the all-reduce of bucket i.  after_streams: the device streams whose enqueued work produces this bucket."""
-        if not dist.is_initialized() or i in self.works:
-            return
+        if not dist.is_initialized() or i in self.reduced:
+            return                        # once per backward pass: a second finish() must not sum the slice over the ranks again
+        self.reduced.add(i)
         _, lo, hi = self.ranges[i]
         view = self.flat[lo:hi]
         if self.comm_stream is not None:
@@ -140,7 +143,9 @@ class GradBuckets:
             self.works[i] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
-        """All buckets reduced and visible to the current stream; returns 1 / world."""
+        """All buckets reduced and visible to the current stream; returns 1 / world.  Idempotent within one backward pass
+        (`begin()` re-arms it): a caller that inspects the reduced gradient and then runs the optimizer step — which calls
+        `finish()` itself — gets the sum over the ranks once, not world times."""
         if not dist.is_initialized():
             return 1.0
         if self.comm_stream is not None:

@@ -17,7 +17,7 @@ from .params import init_params_sequential
 
 
 class GCPSequentialModel(GCPTreeModel):
-    # the flat baseline is trained without the sampled inverse-model / cost-model pairs and always rolls out to the fed end_ind
+    # the flat baseline always rolls out to the fed end_ind (no length predictor)
     _has_aux_training = True      # sampled inverse-model / cost-model training pairs (base_gcp.py:249-260), as for the tree model
     _has_pred_length = False
     _has_training = True              # training_sequential.SequentialTrainStep

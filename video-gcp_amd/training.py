@@ -1264,7 +1264,8 @@ class GCPTrainStep:
         return self._lanes
 
     def optimizer_step(self):
-        """RAdam on the flat vectors + one re-pack gather (gcp_builder.py:88-89,178-179)."""
+        """The configured optimizer (RAdam / Adam / RMSprop / SGD, optional clip_grad_norm_) on the flat vectors + one re-pack gather
+        (gcp_builder.py:88-89,178-179)."""
         m = self.m
         st = torch.cuda.current_stream(m.device).cuda_stream
         scale = 1.0
@@ -1278,6 +1279,11 @@ class GCPTrainStep:
                 self._clip_part = torch.empty(1024, device=m.device)
             rt.check(m.lib.gcpx_grad_clip_coef(self.grad.data_ptr(), n, scale, float(self.gradient_clip), self._clip_part.data_ptr(), 1024,
                                                self.opt_state.data_ptr(), st), "grad_clip")
+        elif getattr(self, "_clip_state_dirty", True):
+            # opt_state[1] is the clip coefficient the step kernels apply whenever it is > 0: without clipping it must be 0 — also after
+            # resuming a checkpoint that was trained WITH clipping (the whole opt_state is restored)
+            self.opt_state[1:2].zero_()
+            self._clip_state_dirty = False
         kind = self.OPTIMIZERS[self.optimizer]
         if kind == 0:
             rt.check(m.lib.gcpx_radam_step(m.theta.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
@@ -1307,6 +1313,13 @@ class GCPTrainStep:
         self.lr, self.betas, self.eps = st["lr"], tuple(st["betas"]), st["eps"]
         if st.get("optimizer", self.optimizer) != self.optimizer:
             raise ValueError(f"checkpoint holds the state of optimizer '{st['optimizer']}', this trainer runs '{self.optimizer}'")
+        # momentum / gradient_clip are the TRAINER's settings (the conf's), as torch.optim's load_state_dict keeps the param-group
+        # values it is given; a checkpoint trained with other values resumes, but says so
+        for k in ("momentum", "gradient_clip"):
+            if k in st and st[k] != getattr(self, k):
+                import warnings
+                warnings.warn(f"checkpoint was trained with {k}={st[k]!r}, this trainer runs {k}={getattr(self, k)!r}")
+        self._clip_state_dirty = True         # a restored clip coefficient must not outlive a trainer without clipping
 
     def named_grads(self):
         return {k: self.grad[o:o + int(torch.tensor(shp).prod())].view(shp) for k, (o, shp) in self.m._poff.items()}
