@@ -209,9 +209,16 @@ typedef struct gcpx_gemm_args {
     const int32_t* w_split_log2_dev; /* dev or NULL: [nbatch] powers of two the packed pieces were scaled by; NULL = w_split_log2 */
     int32_t w_split_log2;
     int32_t _pad_split;
+    void* x_planes;         /* dev or NULL: workspace for the activations as two f16 pieces in fragment order + x_exp [padded rows] row
+                               exponents (sizes: gcpx_gemm_planes_workspace).  When set (with wpk_split) problems with many rows run as a
+                               conversion pass + an LDS-DMA fed GEMM (csrc/gemm_planes.hip); same results class as the split kernel */
+    int32_t* x_exp;
+    int64_t x_planes_bytes; /* size of the x_planes allocation (checked against the problem) */
 } gcpx_gemm_args;
 
 int gcpx_gemm(const gcpx_gemm_args* a, void* stream);
+/* workspace of gcpx_gemm_args.x_planes / x_exp for an M x K activation matrix (x nbatch): bytes of the planes, number of int32 exponents */
+int gcpx_gemm_planes_workspace(int32_t M, int32_t K, int32_t nbatch, int64_t* planes_bytes, int64_t* n_exp);
 /* Several independent small-M problems (those gcpx_gemm runs as split-K 16 x 16 tiles) in ONE launch: the same layer of the
    prior / inference / generator nets of a VRNN step (sequential.py:49-54), or independent GEMMs of a tree level.
    gcpx_gemm_group_dims validates a HOST table of n (<= 16) problems (GCPX_ERR_UNSUPPORTED when one is not in that regime) and

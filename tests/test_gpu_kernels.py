@@ -1543,3 +1543,302 @@ def test_split_pack_group_equals_single_launches(env):
     assert torch.equal(ea, eb)
     for a_, b_ in zip(outs_a, outs_b):
         assert torch.equal(a_, b_)
+
+
+# ---- the split-f16 bound, stated as it is (norm-wise per scaled unit) and probed where it is weakest -------------------------------
+#
+# A value x of a unit that shares one power-of-two scale 2^E (2^14 <= max|x| 2^E < 2^15: an item of the head, a staged block of frames of
+# an encoder layer, a row of the GEMM from the stage on that holds the row's largest magnitude, a whole weight tensor) is kept as two f16
+# pieces whose sum differs from x by at most
+#         max( 2^-22 |x| ,  2^-39 max|x|_unit )          (the second term: the f16 subnormal quantum 2^-24 / 2^-25 under the scale),
+# and the product x w adds the dropped x2 w2 <= 2^-22 |x w|.  Element-wise the result of a split kernel is therefore off by at most
+#         sum_k [ 3 * 2^-22 |x_k w_k| + 2^-39 ( Xmax |w_k| + |x_k| Wmax ) ]   + the f32 accumulation's own roundings,
+# which is one f32 rounding of the result when the terms near the unit's maximum carry it (everything the decoder sees behind a
+# BatchNorm), and NOT when a large channel meets zero weights beside a small channel that carries the output: values 2^-k of the unit's
+# maximum keep about 39 - k bits.  The cases below build exactly that and report the element-wise relative error next to the exact kernel's.
+_SPLIT_C1, _SPLIT_C2 = 4 * 2.0 ** -22, 2.0 ** -38
+
+
+def _split_bound(absx_dot_absw, xmax, sum_absw, wmax, sum_absx):
+    return _SPLIT_C1 * absx_dot_absw + _SPLIT_C2 * (xmax * sum_absw + wmax * sum_absx)
+
+
+def _report_split_bound(name, err, dot, bound):
+    """element-wise error relative to sum_k |x_k w_k| of the SAME element (not to the largest result: an output that cancels is not the
+    point, one whose terms are all small beside a large neighbour is)"""
+    rel = {k: float((v / dot.clamp_min(1e-300)).max()) for k, v in err.items()}
+    frac = float((err["split"] / bound).max())
+    print(f"SPLIT-BOUND {name}: max over elements of |error| / sum_k |x_k w_k|: split {rel['split']:.3e}, exact f32 {rel['f32']:.3e}; "
+          f"split error / stated bound (max over elements) {frac:.3f}")
+    assert frac <= 1.0, (name, frac)
+    return rel
+
+
+@pytest.mark.parametrize("form", ["split", "planes"])
+@pytest.mark.parametrize("ratio_log2", [20, 31])
+def test_split_bound_gemm_large_column_with_zero_weights(env, ratio_log2, form):
+    """Row GEMM: the first 64 columns of every row hold values 2^ratio_log2 times larger than the rest and meet ZERO weights; the small
+    columns carry the whole output.  The row's scale is pinned by the large values (split kernel: from the first stage on; two-launch
+    planes form: one scale per row), so the small ones keep ~39 - ratio_log2 bits: the result obeys the stated norm-wise bound and is
+    element-wise far from f32-equivalent."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(ratio_log2)
+    M, N, K = 4608, 256, 512                                     # (more than 4096 rows: smaller problems stay on the exact kernel's blocks)
+    small = 2.0 ** -10
+    x = torch.randn(M, K) * small
+    x[:, :64] = small * 2.0 ** ratio_log2 * (1 + torch.rand(M, 64))
+    w, b = torch.randn(N, K) / K ** 0.5, torch.zeros(N)
+    w[:, :64] = 0.0
+    ref = F.linear(x.double(), w.double())
+    xd, wp, bd = x.to(dev), pk.pack_gemm(w).to(dev), b.to(dev)
+    ws, e = pk.pack_gemm_split(w)
+    ws = ws.to(dev)
+    err = {}
+    for name in ("f32", "split"):
+        out = torch.full((M, N), float("nan"), device=dev)
+        a = rt.GemmArgs()
+        a.src[0] = _rowsrc(rt, xd, 0, K, K)
+        a.nsrc, a.M, a.N, a.K, a.rpb = 1, M, N, K, M
+        a.wpk, a.bias, a.out, a.ob, a.orow = wp.data_ptr(), bd.data_ptr(), out.data_ptr(), 0, N
+        if name == "split":
+            a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+            if form == "planes":
+                keep = _planes_workspace(rt, lib, a, dev)
+        rt.check(lib.gcpx_gemm(C.byref(a), _stream()), name)
+        torch.cuda.synchronize()
+        err[name] = (out.cpu().double() - ref).abs()
+    ax, aw = x.double().abs(), w.double().abs()
+    bound = _split_bound(ax @ aw.T, ax.amax(1, keepdim=True), aw.sum(1)[None, :], float(aw.max()), ax.sum(1, keepdim=True)) \
+        + 2.0 ** -22 * (ax @ aw.T)                               # the f32 accumulation itself (K = 512 terms)
+    rel = _report_split_bound(f"gemm ({form}) 4608x256x512, large/small = 2^{ratio_log2}", err, ax @ aw.T, bound)
+    assert rel["f32"] < 1e-5                                    # the exact kernel does not care
+    if ratio_log2 >= 31:
+        assert rel["split"] > 10 * rel["f32"]                   # ... the split kernel does: this is what "norm-wise" means
+
+
+@pytest.mark.parametrize("ratio_log2", [20, 31])
+def test_split_bound_head_large_channel_with_zero_weights(env, ratio_log2):
+    """Output head: channel 0 of the last decoder block is 2^ratio_log2 times larger than the other 15 and has zero weights; every
+    4 x 16-pixel item's scale is pinned by it."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(40 + ratio_log2)
+    S, Fr = 64, 2
+    small = 2.0 ** -10
+    x = torch.randn(Fr, 16, S, S) * small
+    x[:, 0] = small * 2.0 ** ratio_log2 * (1 + torch.rand(Fr, S, S))
+    sc, sh = torch.ones(16), torch.zeros(16)
+    xin = F.leaky_relu(x, 0.2)
+    w, b = torch.randn(100, 16, 3, 3) / 12.0, torch.zeros(100)
+    w[:, 0] = 0.0
+    ref = F.conv2d(xin.double(), w.double(), padding=1)
+    perm = pk.dlm_channel_perm(10)
+    permt = torch.tensor(perm)
+    wp = pk.pack_dlm_head(w, perm).to(dev)
+    ws, e = pk.pack_conv3x3_split(w, perm)
+    ws = ws.to(dev)
+    bk = torch.zeros(len(perm))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    slots = torch.nonzero(permt >= 0)[:, 0]
+    inv = torch.empty(100, dtype=torch.long)
+    inv[permt[slots]] = slots
+    err = {}
+    for name in ("f32", "split"):
+        raw = torch.full((Fr, S, S, len(perm)), float("nan"), device=dev)
+        img = torch.full((Fr, 3, S, S), float("nan"), device=dev)
+        a = _conv_args(rt, [(xd, 16, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=S, Win=S, Hout=S, Wout=S, Cout=100,
+                       out_pitch=len(perm), upsample=0, head_mode=rt.HEAD_DLM_BOTH, wpk=wp, bias=bk.to(dev), out=raw, images=img)
+        if name == "split":
+            a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+        rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), name)
+        torch.cuda.synchronize()
+        err[name] = (raw.cpu().index_select(-1, inv).permute(0, 3, 1, 2).double() - ref).abs()
+    ax, aw = xin.double().abs(), w.double().abs()
+    dot = F.conv2d(ax, aw, padding=1)
+    sum_absx = F.conv2d(ax, torch.ones(1, 16, 3, 3, dtype=torch.float64), padding=1)            # [Fr, 1, S, S]
+    bound = _split_bound(dot, float(ax.max()), aw.sum((1, 2, 3))[None, :, None, None], float(aw.max()), sum_absx) + 2.0 ** -22 * dot
+    rel = _report_split_bound(f"head 16->100 @64x64, large/small = 2^{ratio_log2}", err, dot, bound)
+    assert rel["f32"] < 1e-5
+    if ratio_log2 >= 31:
+        assert rel["split"] > 10 * rel["f32"]
+
+
+@pytest.mark.parametrize("ratio_log2", [20, 31])
+def test_split_bound_encoder_large_channel_with_zero_weights(env, ratio_log2):
+    """First split layer of the encoder (16 -> 32 channels @32x32 -> 16x16, un-normalised inputs): same construction; one scale per
+    staged block of frames."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(80 + ratio_log2)
+    Hin, cin, cout, Fr = 32, 16, 32, 3
+    small = 2.0 ** -10
+    x = torch.randn(Fr, cin, Hin, Hin) * small
+    x[:, 0] = small * 2.0 ** ratio_log2 * (1 + torch.rand(Fr, Hin, Hin))
+    sc, sh = torch.ones(cin), torch.zeros(cin)
+    xin = F.leaky_relu(x, 0.2)
+    w, b = torch.randn(cout, cin, 4, 4) / (16 * cin) ** 0.5, torch.zeros(cout)
+    w[:, 0] = 0.0
+    ref = F.conv2d(xin.double(), w.double(), stride=2, padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wp, bd = pk.pack_conv4x4(w).to(dev), b.to(dev)
+    ws, e = pk.pack_conv4x4_split(w)
+    ws = ws.to(dev)
+    err = {}
+    for name in ("f32", "split"):
+        out = torch.full((Fr, Hin // 2, Hin // 2, cout), float("nan"), device=dev)
+        a = _conv_args(rt, [(xd, cin, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=Hin, Win=Hin, Hout=Hin // 2, Wout=Hin // 2,
+                       Cout=cout, out_pitch=cout, wpk=wp, bias=bd, out=out)
+        if name == "split":
+            a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+        rt.check(lib.gcpx_conv4x4s2(C.byref(a), _stream()), name)
+        torch.cuda.synchronize()
+        err[name] = (out.cpu().permute(0, 3, 1, 2).double() - ref).abs()
+    ax, aw = xin.double().abs(), w.double().abs()
+    dot = F.conv2d(ax, aw, stride=2, padding=1)
+    sum_absx = F.conv2d(ax, torch.ones(1, cin, 4, 4, dtype=torch.float64), stride=2, padding=1)
+    bound = _split_bound(dot, float(ax.max()), aw.sum((1, 2, 3))[None, :, None, None], float(aw.max()), sum_absx) + 2.0 ** -22 * dot
+    rel = _report_split_bound(f"encoder 16->32 @32x32, large/small = 2^{ratio_log2}", err, dot, bound)
+    assert rel["f32"] < 1e-5
+    if ratio_log2 >= 31:
+        assert rel["split"] > 10 * rel["f32"]
+
+
+# ---- the row GEMM as conversion pass + LDS-DMA fed GEMM (csrc/gemm_planes.hip) ---------------------------------------------------------
+def _planes_workspace(rt, lib, a, dev):
+    """hands gcpx_gemm the activation-planes workspace: with it (and wpk_split) problems from 512 rows on take the two-launch form"""
+    nbytes, nexp = C.c_int64(), C.c_int64()
+    rt.check(lib.gcpx_gemm_planes_workspace(a.M, a.K, a.nbatch, C.byref(nbytes), C.byref(nexp)), "workspace")
+    planes = torch.full((nbytes.value // 2,), float("nan"), dtype=torch.float16, device=dev)
+    exps = torch.full((nexp.value,), 77, dtype=torch.int32, device=dev)
+    a.x_planes, a.x_exp, a.x_planes_bytes = planes.data_ptr(), exps.data_ptr(), nbytes.value
+    return planes, exps
+
+
+@pytest.mark.parametrize("case", ["unit", "tiny", "row_scales", "k_growth", "outlier", "zero_rows"])
+@pytest.mark.parametrize("M,N,K", [(1024, 2048, 1024), (8200, 1024, 192), (33000, 2048, 256), (2100, 2048, 128)])
+def test_gemm_planes_error_vs_float64(env, case, M, N, K):
+    """The two-launch form of the split-f16 row GEMM (conversion pass with ONE power-of-two scale per row over all of K, then the GEMM fed by
+    LDS-DMA) against float64 next to the exact f32 MFMA kernel, same cases and bounds as test_gemm_split_error_vs_float64.  The four
+    shapes take the four tile configurations (64 x 128 / 128 x 256 / 256 x 256 / 128 x 128), three of them with a masked last row block
+    (shapes the dispatcher keeps on the exact kernel's split-K blocks — few rows x few columns — never reach this form)."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(M + K)
+    x = torch.randn(M, K)
+    if case == "tiny":
+        x *= 1e-6
+    elif case == "row_scales":
+        x *= torch.logspace(-6, 3, M)[:, None]
+    elif case == "k_growth":
+        x *= torch.logspace(-2, 2, K)[None, :]
+    elif case == "outlier":
+        x[3, K // 2] = 3e4
+    elif case == "zero_rows":
+        x[::3] = 0.0
+    w, b = torch.randn(N, K) / K ** 0.5, torch.randn(N)
+    ref = F.linear(x.double(), w.double(), b.double())
+    xd, wp, bd = x.to(dev), pk.pack_gemm(w).to(dev), b.to(dev)
+    ws, e = pk.pack_gemm_split(w)
+    ws = ws.to(dev)
+    err = {}
+    for name in ("f32", "planes"):
+        out = torch.full((M, N), float("nan"), device=dev)
+        a = rt.GemmArgs()
+        a.src[0] = _rowsrc(rt, xd, 0, K, K)
+        a.nsrc, a.M, a.N, a.K, a.rpb = 1, M, N, K, M
+        a.wpk, a.bias, a.out, a.ob, a.orow = wp.data_ptr(), bd.data_ptr(), out.data_ptr(), 0, N
+        if name == "planes":
+            a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+            keep = _planes_workspace(rt, lib, a, dev)
+        rt.check(lib.gcpx_gemm(C.byref(a), _stream()), name)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        if name == "planes":
+            assert not bool((keep[1][:M] == 77).any())             # the conversion pass ran (every row got its exponent)
+        err[name] = (out.cpu().double() - ref).abs()
+    rs = ref.abs().amax(1) + 1e-30
+    rms = {k: v.pow(2).mean(1).sqrt() for k, v in err.items()}
+    # k_growth: one scale per row over all of K (the early, small columns sit 2^-13 below the row's maximum: still 22 bits) — same bounds
+    assert bool((rms["planes"] <= 1.5 * rms["f32"] + 1e-7 * rs).all()), float((rms["planes"] / (rms["f32"] + 1e-7 * rs)).max())
+    assert bool((err["planes"].amax(1) <= 2.0 * err["f32"].amax(1) + 4e-7 * rs).all())
+
+
+def test_gemm_planes_lstm_sources_and_batches(env):
+    """the two-launch form with what the tree levels use: concatenated sources with a row gather, the LSTM-cell epilogue (h, c, dense h
+    copy), the conv1d-over-time form (shifted, masked sources with affine + LReLU on load) and batched problems with their own weight
+    exponents"""
+    rt, pk, lib, dev = env
+    torch.manual_seed(19)
+    H = 128
+    pool = torch.randn(500, H)
+    cell = torch.nn.LSTMCell(H, H)
+    w, b = pk.lstm_gate_interleave(cell.weight_ih.detach(), cell.weight_hh.detach(), cell.bias_ih.detach(), cell.bias_hh.detach())
+    wp, bd = pk.pack_gemm(w).to(dev), b.to(dev)
+    ws, e = pk.pack_gemm_split(w)
+    ws = ws.to(dev)
+    pd = pool.to(dev)
+    for Mb in (4200, 16500):
+        ridx_b = torch.randint(0, 500, (Mb,), dtype=torch.int32)
+        xb_, hb_, cb_ = pool[ridx_b.long()], torch.randn(Mb, H), torch.randn(Mb, H)
+        with torch.no_grad():
+            h1b, c1b = cell(xb_, (hb_, cb_))
+        rdb, hdb, cdb = ridx_b.to(dev), hb_.to(dev), cb_.to(dev)
+        hob, cob, hcb = (torch.full((Mb, H), float("nan"), device=dev) for _ in range(3))
+        a = rt.GemmArgs()
+        a.src[0] = _rowsrc(rt, pd, 0, H, H, rowidx=rdb)
+        a.src[1] = _rowsrc(rt, hdb, 0, H, H)
+        a.nsrc, a.M, a.N, a.K, a.rpb = 2, Mb, 4 * H, 2 * H, Mb
+        a.wpk, a.bias, a.epi = wp.data_ptr(), bd.data_ptr(), rt.EPI_LSTM
+        a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+        a.c_prev, a.c_prev_stride, a.h_out, a.c_out, a.hb, a.hrow, a.h_copy = cdb.data_ptr(), H, hob.data_ptr(), cob.data_ptr(), 0, H, hcb.data_ptr()
+        keep = _planes_workspace(rt, lib, a, dev)
+        rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm planes lstm")
+        torch.cuda.synchronize()
+        assert not bool((keep[1][:Mb] == 77).any())
+        assert_close(hob, h1b, atol=1e-5, name=f"h, {Mb} rows")
+        assert_close(cob, c1b, atol=1e-5, name=f"c, {Mb} rows")
+        assert_close(hcb, h1b, atol=1e-5, name=f"h_copy, {Mb} rows")
+    # conv1d-over-time form
+    B, T, Cc, N = 16, 40, 64, 128
+    xs = torch.randn(B, T, Cc)
+    sc, sh = torch.rand(Cc) + 0.5, torch.randn(Cc) * 0.1
+    wc, bc = torch.randn(N, Cc, 3) / (3 * Cc) ** 0.5, torch.randn(N)
+    want = F.leaky_relu(F.conv1d(F.leaky_relu(xs * sc + sh, 0.2).transpose(1, 2), wc, bc, padding=1).transpose(1, 2), 0.2)
+    w2 = wc.permute(0, 2, 1).reshape(N, 3 * Cc)
+    xd, scd, shd, bcd = xs.to(dev), sc.to(dev), sh.to(dev), bc.to(dev)
+    wp2 = pk.pack_gemm(w2).to(dev)
+    ws2, e2 = pk.pack_gemm_split(w2)
+    ws2 = ws2.to(dev)
+    out = torch.full((B * T, N), float("nan"), device=dev)
+    a = rt.GemmArgs()
+    for i, d in enumerate((-1, 0, 1)):
+        a.src[i] = _rowsrc(rt, xd, T * Cc, Cc, Cc, shift=d, scale=scd, shiftv=shd, act=rt.ACT_LRELU, cmod=Cc)
+    a.nsrc, a.M, a.N, a.K, a.rpb = 3, B * T, N, 3 * Cc, T
+    a.wpk, a.bias, a.out, a.ob, a.orow, a.epi = wp2.data_ptr(), bcd.data_ptr(), out.data_ptr(), T * N, N, rt.EPI_LRELU
+    a.wpk_split, a.w_split_log2 = ws2.data_ptr(), e2
+    keep = _planes_workspace(rt, lib, a, dev)
+    rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm planes conv1d")
+    torch.cuda.synchronize()
+    assert not bool((keep[1][:B * T] == 77).any())
+    assert_close(out.view(B, T, N), want, atol=2e-5, rtol=1e-5, name="conv1d-gemm planes")
+    # batched: 3 problems, weights of different magnitude (their own exponents), rows not a multiple of the tile
+    nb, M2, N2, K2 = 3, 4200, 128, 256
+    xb = torch.randn(nb, M2, K2)
+    wb = torch.randn(nb, N2, K2) / K2 ** 0.5 * torch.tensor([1.0, 1e-3, 50.0])[:, None, None]
+    bb = torch.randn(nb, N2)
+    wantb = torch.einsum("bmk,bnk->bmn", xb, wb) + bb[:, None, :]
+    packs = [pk.pack_gemm_split(wb[i]) for i in range(nb)]
+    wsb = torch.stack([p_[0] for p_ in packs]).contiguous().to(dev)
+    eb = torch.tensor([p_[1] for p_ in packs], dtype=torch.int32, device=dev)
+    wpb = torch.stack([pk.pack_gemm(wb[i]) for i in range(nb)]).contiguous().to(dev)
+    xbd, bbd = xb.to(dev), bb.to(dev)
+    outb = torch.full((nb, M2, N2), float("nan"), device=dev)
+    a = rt.GemmArgs()
+    a.src[0] = _rowsrc(rt, xbd, 0, K2, K2)
+    a.nsrc, a.M, a.N, a.K, a.rpb = 1, M2, N2, K2, M2
+    a.wpk, a.bias, a.out, a.ob, a.orow = wpb.data_ptr(), bbd.data_ptr(), outb.data_ptr(), 0, N2
+    a.nbatch, a.z_src_off, a.z_w_off, a.z_bias_off, a.z_out_off = nb, M2 * K2, N2 * K2, N2, M2 * N2
+    a.wpk_split, a.w_split_log2_dev = wsb.data_ptr(), eb.data_ptr()
+    keep = _planes_workspace(rt, lib, a, dev)
+    rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm planes batched")
+    torch.cuda.synchronize()
+    wantb = torch.einsum("bmk,bnk->bmn", xb.double(), wb.double()) + bb[:, None, :].double()
+    for i, wscale in enumerate((1.0, 1e-3, 50.0)):                # an f32 rounding of the terms' size, per problem
+        assert_close(outb[i].double().cpu(), wantb[i], atol=3e-5 * max(wscale, 1.0), rtol=2e-5, name=f"batched planes, problem {i}")

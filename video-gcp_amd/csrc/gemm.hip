@@ -21,6 +21,8 @@
 
 bool gcpx_gemm_split_applies(const gcpx_gemm_args* a);                  // gemm_split.hip
 int gcpx_launch_gemm_split(const gcpx_gemm_args* a, hipStream_t stream);
+bool gcpx_gemm_planes_applies(const gcpx_gemm_args* a);                 // gemm_planes.hip
+int gcpx_launch_gemm_planes(const gcpx_gemm_args* a, hipStream_t stream);
 
 namespace {
 
@@ -256,7 +258,10 @@ extern "C" int gcpx_gemm(const gcpx_gemm_args* a, void* stream_) {
     if (st != GCPX_OK) return st;
     {
         int pr_ = 1, cr_ = 1;
-        if (!ks_block_choice(a, &pr_, &cr_) && gcpx_gemm_split_applies(a)) return gcpx_launch_gemm_split(a, stream);
+        if (!ks_block_choice(a, &pr_, &cr_)) {
+            if (gcpx_gemm_planes_applies(a)) return gcpx_launch_gemm_planes(a, stream);
+            if (gcpx_gemm_split_applies(a)) return gcpx_launch_gemm_split(a, stream);
+        }
     }
     const TileChoice t = choose_tile(a->M, a->N, a->nbatch > 1 ? a->nbatch : 1);
     {

@@ -410,6 +410,9 @@ class GCPTreeModel:
         address of the f32 pack they mirror.  gcpx_gemm takes the split kernel from GCPX_GEMM_SPLIT_MIN_ROWS rows on (default 512:
         below that the launch is bound by the per-CU load rate, not by the f32 MFMA rate — DESIGN.md section 6c)."""
         self._gsplit = {}
+        # rows from which a split GEMM with >= 1024 columns takes the two-launch planes form (GCPX_GEMM_PLANES_ROWS; 0 = never)
+        pr = int(os.environ.get("GCPX_GEMM_PLANES_ROWS", "2048"))
+        self._planes_min_rows = pr if pr > 0 else 1 << 60
         if not self.split_f16:
             return
         for name, W in self.pk.items():
@@ -719,6 +722,14 @@ class GCPTreeModel:
                 plan.rec[f"gates:{name}"] = g
         if batch is not None:
             a.nbatch, a.z_src_off, a.z_w_off, a.z_bias_off, a.z_out_off = batch
+        if a.wpk_split and M >= getattr(self, "_planes_min_rows", 1 << 60) and N >= 1024 and group is None and not a.stats_partial and not a.gates_out:
+            # many rows x many columns: conversion pass + LDS-DMA fed GEMM (csrc/gemm_planes.hip).  The workspace is shared by the launches
+            # of one lane that need the same size (a lane is a stream: its launches are ordered)
+            nbytes, nexp = C.c_int64(), C.c_int64()
+            rt.check(self.lib.gcpx_gemm_planes_workspace(M, a.K, a.nbatch, C.byref(nbytes), C.byref(nexp)), "planes workspace")
+            wsb = self._buf(f"xplanes.l{plan.lane}", (nbytes.value,), torch.uint8)
+            wse = self._buf(f"xexp.l{plan.lane}", (nexp.value,), torch.int32)
+            a.x_planes, a.x_exp, a.x_planes_bytes = wsb.data_ptr(), wse.data_ptr(), nbytes.value
         plan.keep.append(a)
         if group is not None:
             group.append((name, a))

@@ -54,7 +54,8 @@ class GemmArgs(C.Structure):
                 ("stats_partial", vp), ("c_prev", vp), ("c_prev_stride", i64), ("h_out", vp), ("c_out", vp),
                 ("hb", i64), ("hrow", i64), ("h_copy", vp), ("z_src_off", i64), ("z_w_off", i64),
                 ("z_bias_off", i64), ("z_out_off", i64), ("gates_out", vp),
-                ("wpk_split", vp), ("w_split_log2_dev", vp), ("w_split_log2", i32), ("_pad_split", i32)]
+                ("wpk_split", vp), ("w_split_log2_dev", vp), ("w_split_log2", i32), ("_pad_split", i32),
+                ("x_planes", vp), ("x_exp", vp), ("x_planes_bytes", i64)]
 
 
 class MlpArgs(C.Structure):
@@ -127,6 +128,7 @@ SYMBOLS = [
     ("gcpx_bn_fold", C.c_int, [vp, vp, vp, vp, C.c_float, i32, vp, vp, vp]),
     ("gcpx_gemm", C.c_int, [C.POINTER(GemmArgs), vp]),
     ("gcpx_gemm_row_blocks", C.c_int, [i32, i32]),
+    ("gcpx_gemm_planes_workspace", C.c_int, [i32, i32, i32, vp, vp]),
     ("gcpx_mlp", C.c_int, [C.POINTER(MlpArgs), vp]),
     ("gcpx_balanced_binding", C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     ("gcpx_dlm_nll", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
