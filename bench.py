@@ -196,6 +196,7 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev, dinp_noloss)
     import torch
     import torch.distributed as dist
     import video_gcp_amd as V
+    from video_gcp_amd import dist as D
     from video_gcp_amd.model import GCPTreeModel
     from helpers import make_inputs
     res = {}
@@ -276,8 +277,31 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev, dinp_noloss)
         dt = _timed(lambda: tr.step(full), k, 2, world, dev)
         res["train_step"] = {"value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s",
                              "ms_per_step": round(1e3 * dt, 3), "workload": "configs[2] shard: forward + ELBO losses + backward + "
-                             "RAdam, batch 16/GPU" + (", one RCCL all-reduce of the flat fp32 gradient per step" if world > 1 else ""),
+                             "RAdam, batch 16/GPU" + (", bucketed RCCL all-reduce of the flat fp32 gradient overlapped with the backward" if world > 1 else ""),
                              "grad_mbytes": round(tr.grad.numel() * 4 / 1e6, 1)}
+        if world > 1 and tr.buckets is not None:
+            # what the scaling curve is made of: the collectives' own time on the communication stream, bucket by bucket (in-region
+            # events of one more step), next to ONE all-reduce of the whole flat gradient with nothing else running
+            tr.buckets.timing = True
+            tr.step(full)
+            torch.cuda.synchronize()
+            per = tr.buckets.comm_ms()
+            tr.buckets.timing = False
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dist.barrier()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                dist.all_reduce(tr.grad)
+            e1.record()
+            torch.cuda.synchronize()
+            flat_ms = D.max_over_ranks(e0.elapsed_time(e1) / 3, device=dev)
+            tr.grad.zero_()
+            res["train_step"]["allreduce"] = {"buckets_ms_in_step": {k_: round(v, 3) for k_, v in per.items()},
+                                              "buckets_ms_sum": round(sum(per.values()), 3), "flat_gradient_alone_ms": round(flat_ms, 3),
+                                              "note": "buckets_ms_in_step: event pairs on the communication stream around every bucket's "
+                                                      "all-reduce inside one training step (rank 0; includes waiting for the slowest rank); "
+                                                      "flat_gradient_alone_ms: one all-reduce of the whole gradient on an idle device, max over ranks"}
         del tr
     except Exception as e:  # noqa: BLE001
         res["train_step"] = {"error": repr(e)[:300]}

@@ -30,6 +30,15 @@ torch.cuda.synchronize()
 err = float((tr.m.theta - ref.m.theta).abs().max())
 print("training step with RCCL all-reduce (1 rank) vs no process group: max |theta diff| =", err)
 assert err == 0.0
+# the per-bucket timing bench.py --gpus N reports (event pairs on the communication stream around every bucket's all-reduce)
+tr.buckets.timing = True
+tr.step(d, noise.to(dev)); ref.step(d, noise.to(dev))
+torch.cuda.synchronize()
+per = tr.buckets.comm_ms()
+tr.buckets.timing = False
+assert len(per) == len(tr.buckets.ranges) and all(v >= 0.0 for v in per.values()), per
+assert float((tr.m.theta - ref.m.theta).abs().max()) == 0.0
+print("bucket all-reduce times (ms):", {k: round(v, 3) for k, v in per.items()})
 from video_gcp_amd.planning import GCPImageSimulator, LearnedCostEstimate, SimpleTreeCEMSampler, CEMPlanner
 m.eval()
 rng = np.random.RandomState(0)

@@ -71,12 +71,13 @@ __device__ __forceinline__ void transpose4_rows(float (&x)[4]) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// activations -> two f16 planes in fragment order + one exponent per row.  One 256-thread workgroup per 16 rows; wavefront w takes the
-// 32-k steps ks = w (mod 4); lane (q, j) holds k = 8 q .. 8 q + 7 of row j of a step.  Two passes over the row (the second one hits L2):
-// largest magnitude, then scale / split / store.
-template <bool XF>
-__global__ void __launch_bounds__(256) split_rows_kernel(const gcpx_gemm_args a) {
-    __shared__ unsigned wmax[4][16];
+// activations -> two f16 planes in fragment order + one exponent per row.  One workgroup of NWV wavefronts per 16 rows; wavefront w takes
+// the 32-k steps ks = w (mod NWV); lane (q, j) holds k = 8 q .. 8 q + 7 of row j of a step.  Two passes over the row (the second one hits
+// L2): largest magnitude, then scale / split / store.  NWV = 4 when the rows alone fill the chip, 16 for a few hundred row tiles (one
+// wavefront then holds two or three steps: the pass is a latency chain, not a stream).
+template <bool XF, int NWV>
+__global__ void __launch_bounds__(64 * NWV) split_rows_kernel(const gcpx_gemm_args a) {
+    __shared__ unsigned wmax[NWV][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int zb = blockIdx.z, rt = blockIdx.x;
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const gcpx_gemm_args a)
                 const float* p = src.ptr + (size_t)zb * a.z_src_off + off + q * 8;
                 const float mask = ok ? 1.f : 0.f;
                 const int n = src.width >> 5;
-                for (int l = (wave - s0) & 3; l < n; l += 4) {
+                for (int l = (wave - s0) & (NWV - 1); l < n; l += NWV) {
                     float4 v0 = gload4(p + 32 * l), v1 = gload4(p + 32 * l + 4);
                     if constexpr (XF) {
                         if (src.scale || src.act) {
@@ -136,7 +137,9 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const gcpx_gemm_args a)
         u = max(s32[0], s32[1]);
         if (q == 0) wmax[wave][j] = u;
         __syncthreads();
-        u = max(max(wmax[0][j], wmax[1][j]), max(wmax[2][j], wmax[3][j]));
+        u = wmax[0][j];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) u = max(u, wmax[w][j]);
         amax = __uint_as_float(u);
     }
     const int ew = a.w_split_log2_dev ? a.w_split_log2_dev[zb] : a.w_split_log2;
@@ -451,8 +454,13 @@ int gcpx_launch_gemm_planes(const gcpx_gemm_args* a, hipStream_t stream) {
     bool xf = false;
     for (int s = 0; s < a->nsrc; ++s) xf = xf || a->src[s].scale || a->src[s].act;
     const dim3 sgrid((a->M + 15) / 16, 1, nb);
-    if (xf) hipLaunchKernelGGL(split_rows_kernel<true>, sgrid, dim3(256), 0, stream, *a);
-    else hipLaunchKernelGGL(split_rows_kernel<false>, sgrid, dim3(256), 0, stream, *a);
+    if ((long)sgrid.x * nb >= 1024) {
+        if (xf) hipLaunchKernelGGL((split_rows_kernel<true, 4>), sgrid, dim3(256), 0, stream, *a);
+        else hipLaunchKernelGGL((split_rows_kernel<false, 4>), sgrid, dim3(256), 0, stream, *a);
+    } else {
+        if (xf) hipLaunchKernelGGL((split_rows_kernel<true, 16>), sgrid, dim3(1024), 0, stream, *a);
+        else hipLaunchKernelGGL((split_rows_kernel<false, 16>), sgrid, dim3(1024), 0, stream, *a);
+    }
     GCPX_CHECK_LAUNCH();
     static const int force = [] { const char* e = getenv("GCPX_GEMM_PLANES_CFG"); return e ? atoi(e) : 0; }();     // tuning aid
     const long tiles_a = (long)((a->M + 255) / 256) * (a->N / 256) * nb, tiles_b = (long)((a->M + 127) / 128) * (a->N / 256) * nb;

@@ -116,6 +116,8 @@ class GradBuckets:
         self.works = {}
         self.reduced = set()           # buckets whose all-reduce has been issued in THIS backward pass (reset by begin())
         self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
+        self.timing = False            # record an event pair on the communication stream around every bucket's collective
+        self._events = {}
 
     def begin(self):
         """Start of a backward pass: nothing of a previous pass may still be pending.  A backward that was not followed by
@@ -138,9 +140,20 @@ class GradBuckets:
             for s in after_streams:
                 self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm_stream)
                 self.works[i] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.timing:
+                    e1.record(self.comm_stream)
+                    self._events[i] = (e0, e1)
         else:
             self.works[i] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def comm_ms(self):
+        """{bucket name: milliseconds its all-reduce occupied the communication stream} for the last pass (timing = True; call after a
+        device synchronisation).  What a scaling run reads next to its step time: the collectives' own duration, bucket by bucket."""
+        return {self.ranges[i][0]: e0.elapsed_time(e1) for i, (e0, e1) in sorted(self._events.items())}
 
     def finish(self):
         """All buckets reduced and visible to the current stream; returns 1 / world.  Idempotent within one backward pass

@@ -411,7 +411,7 @@ class GCPTreeModel:
         below that the launch is bound by the per-CU load rate, not by the f32 MFMA rate — DESIGN.md section 6c)."""
         self._gsplit = {}
         # rows from which a split GEMM with >= 1024 columns takes the two-launch planes form (GCPX_GEMM_PLANES_ROWS; 0 = never)
-        pr = int(os.environ.get("GCPX_GEMM_PLANES_ROWS", "2048"))
+        pr = int(os.environ.get("GCPX_GEMM_PLANES_ROWS", "1024"))
         self._planes_min_rows = pr if pr > 0 else 1 << 60
         if not self.split_f16:
             return
