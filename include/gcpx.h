@@ -668,6 +668,10 @@ typedef struct gcpx_actbwd_args {
 } gcpx_actbwd_args;
 int gcpx_act_bwd(const gcpx_actbwd_args* a, void* stream);
 int gcpx_act_bwd_blocks(void);
+/* gcpx_act_bwd (up = 1, fsum = 1) for the channels a->c_off .. + a->C of an upsampling decoder block's input gradient AND, from the same pass
+   over the tensor, the skip-connection half: ds [F / rpb][H][W][Cs] = sum over the rpb frames of a sequence of the (bilinear-transposed)
+   channels c_off_s .. + Cs (the two gcpx_act_bwd launches of training.py's decoder backward, tree_dense_rec.py:42 / base_gcp.py:190) */
+int gcpx_act_skip_bwd(const gcpx_actbwd_args* a, float* ds, int32_t c_off_s, int32_t Cs, int32_t rpb, void* stream);
 /* BatchNorm backward, second half: coef[0..C) = gamma*rstd, coef[C..2C) = mean(dy), coef[2C..3C) = mean(dy*x_hat);
    d gamma / d beta written (accumulated) to the gradient buffers */
 int gcpx_bn_bwd_finalize(const float* partial, int32_t n_partial, int32_t C, double count, const float* gamma, const float* rstd,

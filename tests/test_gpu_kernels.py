@@ -1842,3 +1842,46 @@ def test_gemm_planes_lstm_sources_and_batches(env):
     wantb = torch.einsum("bmk,bnk->bmn", xb.double(), wb.double()) + bb[:, None, :].double()
     for i, wscale in enumerate((1.0, 1e-3, 50.0)):                # an f32 rounding of the terms' size, per problem
         assert_close(outb[i].double().cpu(), wantb[i], atol=3e-5 * max(wscale, 1.0), rtol=2e-5, name=f"batched planes, problem {i}")
+
+
+@pytest.mark.parametrize("B,nodes,H,Ca,Cs", [(3, 5, 16, 16, 16), (2, 7, 8, 64, 64), (16, 3, 32, 16, 16)])
+def test_act_skip_bwd_equals_the_two_passes(env, B, nodes, H, Ca, Cs):
+    """gcpx_act_skip_bwd (one pass over the upsampling block's input gradient: previous-block half through the transposed bilinear x2,
+    LeakyReLU' and the BatchNorm-backward sums; skip half summed over a sequence's frames) against the two gcpx_act_bwd launches it
+    replaces in the decoder's backward, and the first half against torch's own bilinear backward."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(B * H)
+    Fr, ldc = B * nodes, Ca + Cs
+    dU = torch.randn(Fr, 2 * H, 2 * H, ldc, device=dev)
+    r = torch.randn(Fr, H, H, Ca, device=dev)
+    sc, sh = torch.rand(Ca, device=dev) + 0.5, torch.randn(Ca, device=dev) * 0.2
+    mean, rstd = torch.randn(Ca, device=dev) * 0.1, torch.rand(Ca, device=dev) + 0.5
+    nb = lib.gcpx_act_bwd_blocks()
+
+    def act_args(dy, st):
+        a = rt.ActBwdArgs()
+        a.da, a.r, a.scale, a.shift, a.mean, a.rstd = dU.data_ptr(), r.data_ptr(), sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        a.dy, a.stats_partial, a.ldc, a.c_off, a.up, a.fsum, a.act = dy.data_ptr(), st.data_ptr(), ldc, 0, 1, 1, rt.ACT_LRELU
+        a.F, a.H, a.W, a.C = Fr, H, H, Ca
+        return a
+    dy0, st0 = torch.full((Fr, H, H, Ca), float("nan"), device=dev), torch.full((nb, 2, Ca), float("nan"), device=dev)
+    a0 = act_args(dy0, st0)
+    rt.check(lib.gcpx_act_bwd(C.byref(a0), _stream()), "act")
+    ds0 = torch.full((B, H, H, Cs), float("nan"), device=dev)
+    a1 = rt.ActBwdArgs()
+    a1.da, a1.dy, a1.ldc, a1.c_off, a1.up, a1.fsum, a1.act = dU.data_ptr(), ds0.data_ptr(), ldc, Ca, 1, nodes, rt.ACT_NONE
+    a1.F, a1.H, a1.W, a1.C = B, H, H, Cs
+    rt.check(lib.gcpx_act_bwd(C.byref(a1), _stream()), "skip")
+    dy1, st1 = torch.full((Fr, H, H, Ca), float("nan"), device=dev), torch.full((nb, 2, Ca), float("nan"), device=dev)
+    ds1 = torch.full((B, H, H, Cs), float("nan"), device=dev)
+    a2 = act_args(dy1, st1)
+    rt.check(lib.gcpx_act_skip_bwd(C.byref(a2), ds1.data_ptr(), Ca, Cs, nodes, _stream()), "act+skip")
+    torch.cuda.synchronize()
+    assert torch.equal(dy1, dy0) and torch.equal(ds1, ds0)          # same taps in the same order, frames summed in order
+    assert_close(st1.sum(0).cpu(), st0.sum(0).cpu(), atol=2e-3 * float(st0.sum(0).abs().max()) + 1e-3, name="BatchNorm-backward sums")
+    # the previous-block half against autograd through F.interpolate
+    x = torch.zeros(Fr, Ca, H, H, dtype=torch.float64, requires_grad=True)
+    up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    up.backward(dU[..., :Ca].permute(0, 3, 1, 2).double().cpu())
+    slope = torch.where((r * sc + sh) > 0, 1.0, 0.2).cpu().double()
+    assert_close(dy1.cpu().double(), x.grad.permute(0, 2, 3, 1) * slope, atol=1e-5, name="transposed bilinear x LeakyReLU'")

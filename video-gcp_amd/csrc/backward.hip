@@ -361,6 +361,108 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const gcpx_actbwd_args a) 
     }
 }
 
+// The two passes over the data gradient of an upsampling decoder block's concatenated input [F][2H][2W][ldc] in ONE: the transpose of
+// the bilinear x2 (a 4 x 4 window per low-resolution pixel) for
+//   * the channels that came from the previous block (a.c_off .. + a.C): times the activation's derivative, BatchNorm-backward sums,
+//     stored per frame (what gcpx_act_bwd with up = 1 does), and
+//   * the channels that came from the skip connection of I_0 (c_off_s .. + Cs): summed over the rpb node frames of a sequence, in frame
+//     order (what gcpx_act_bwd with fsum = rpb does) — the skip activations are one per sequence (base_gcp.py:190).
+// Both halves of a pixel sit in the same 128-byte lines, so each pass alone moved the whole tensor (1.07 GB at c2 for the last block).
+// A thread owns one float4 channel group of one low-resolution pixel of one SEQUENCE and walks that sequence's frames.
+__global__ void __launch_bounds__(256) act_skip_bwd_kernel(const gcpx_actbwd_args a, float* __restrict__ ds, const int c_off_s, const int Cs,
+                                                           const int rpb) {
+    const int Ca4 = a.C / 4, G = Ca4 + Cs / 4;
+    const int B = a.F / rpb;
+    const long long total = (long long)B * a.H * a.W * G;
+    const int cg = threadIdx.x % G;                                  // (256 % G == 0: fixed per thread over the grid-stride loop)
+    const bool skip = cg >= Ca4;
+    const int c = skip ? (cg - Ca4) * 4 : cg * 4;
+    const int csrc = skip ? c_off_s + c : a.c_off + c;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 mu = sh, rs = sc;
+    if (!skip) {
+        if (a.scale) { sc = *reinterpret_cast<const float4*>(a.scale + c); sh = *reinterpret_cast<const float4*>(a.shift + c); }
+        if (a.mean) { mu = *reinterpret_cast<const float4*>(a.mean + c); rs = *reinterpret_cast<const float4*>(a.rstd + c); }
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int Hd = 2 * a.H, Wd = 2 * a.W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long p = i / G;
+        const int x = (int)(p % a.W); p /= a.W;
+        const int y = (int)(p % a.H);
+        const int b = (int)(p / a.H);
+        int yy[4], xx[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            yy[t] = min(max(2 * y - 1 + t, 0), Hd - 1);
+            xx[t] = min(max(2 * x - 1 + t, 0), Wd - 1);
+        }
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);                    // skip half: ONE running sum over frames and taps (as gcpx_act_bwd with fsum)
+        // the 16 window loads of the NEXT frame are in flight while this frame's are summed (a thread walks rpb frames: without the
+        // second register set every frame would cost a full memory round trip)
+        float4 v[16], vn[16];
+        auto load_window = [&](const int fs, float4 (&w)[16]) __attribute__((always_inline)) {
+            const float* base = a.da + ((size_t)(b * rpb + min(fs, rpb - 1)) * Hd * Wd) * a.ldc + csrc;
+#pragma unroll
+            for (int ty = 0; ty < 4; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 4; ++tx) w[ty * 4 + tx] = *reinterpret_cast<const float4*>(base + ((size_t)yy[ty] * Wd + xx[tx]) * a.ldc);
+        };
+        load_window(0, vn);
+        for (int fs = 0; fs < rpb; ++fs) {
+            const int f = b * rpb + fs;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = vn[t];
+            load_window(fs + 1, vn);
+            if (!skip) g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ty = 0; ty < 4; ++ty) {
+                const float wy = (ty == 0 || ty == 3) ? 0.25f : 0.75f;
+#pragma unroll
+                for (int tx = 0; tx < 4; ++tx) {
+                    const float w = wy * ((tx == 0 || tx == 3) ? 0.25f : 0.75f);
+                    const float4 u = v[ty * 4 + tx];
+                    g.x += w * u.x; g.y += w * u.y; g.z += w * u.z; g.w += w * u.w;
+                }
+            }
+            if (skip) continue;
+            const size_t o = ((((size_t)f * a.H + y) * a.W + x) * a.C) + c;
+            if (a.add) {
+                const float4 av = *reinterpret_cast<const float4*>(a.add + o);
+                g.x += av.x; g.y += av.y; g.z += av.z; g.w += av.w;
+            }
+            if (a.r) {
+                const float4 rv = *reinterpret_cast<const float4*>(a.r + o);
+                const float yv[4] = {fmaf(rv.x, sc.x, sh.x), fmaf(rv.y, sc.y, sh.y), fmaf(rv.z, sc.z, sh.z), fmaf(rv.w, sc.w, sh.w)};
+                float gv[4] = {g.x, g.y, g.z, g.w};
+                const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+                const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, ss[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (a.act == GCPX_ACT_LRELU) gv[k] *= (yv[k] > 0.f ? 1.f : 0.2f);
+                    s1[k] += gv[k];
+                    s2[k] += gv[k] * (rr[k] - mm[k]) * ss[k];
+                }
+                g = make_float4(gv[0], gv[1], gv[2], gv[3]);
+            }
+            *reinterpret_cast<float4*>(a.dy + o) = g;
+        }
+        if (skip) *reinterpret_cast<float4*>(ds + ((((size_t)b * a.H + y) * a.W + x) * Cs) + c) = g;
+    }
+    if (a.stats_partial) {
+        __shared__ float red[256][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[threadIdx.x][k] = s1[k]; red[threadIdx.x][4 + k] = s2[k]; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * a.C; i += 256) {
+            const int which = i / a.C, ch = i % a.C;
+            float s = 0.f;
+            for (int t = ch / 4; t < 256; t += G) s += red[t][which * 4 + (ch & 3)];      // threads of channel group ch / 4 (previous-block half)
+            a.stats_partial[((size_t)blockIdx.x * 2 + which) * a.C + ch] = s;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ partial, const int n_partial, const int C,
                                                               const double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ rstd, float* __restrict__ coef,
@@ -1074,6 +1176,18 @@ extern "C" int gcpx_act_bwd(const gcpx_actbwd_args* a, void* stream_) {
     GCPX_CHECK_ARG(a->fsum >= 1 && a->ldc % 4 == 0 && a->c_off % 4 == 0, "bad fsum / ldc / c_off");
     GCPX_CHECK_ARG(!a->stats_partial || (a->mean && a->rstd && a->r), "stats need r, mean, rstd");
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ACT_BLOCKS), dim3(256), 0, stream, *a);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_act_skip_bwd(const gcpx_actbwd_args* a, float* ds, int32_t c_off_s, int32_t Cs, int32_t rpb, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(a && a->da && a->dy && ds, "missing pointer");
+    GCPX_CHECK_ARG(a->up == 1 && a->fsum == 1 && rpb >= 1 && a->F % rpb == 0, "the fused form is the upsampled one, one output frame per input frame, whole sequences");
+    GCPX_CHECK_ARG(a->C >= 4 && Cs >= 4 && a->C % 4 == 0 && Cs % 4 == 0 && 256 % ((a->C + Cs) / 4) == 0, "channel groups must divide 256");
+    GCPX_CHECK_ARG(a->ldc % 4 == 0 && a->c_off % 4 == 0 && c_off_s % 4 == 0, "bad ldc / c_off");
+    GCPX_CHECK_ARG(!a->stats_partial || (a->mean && a->rstd && a->r), "stats need r, mean, rstd");
+    hipLaunchKernelGGL(act_skip_bwd_kernel, dim3(ACT_BLOCKS), dim3(256), 0, stream, *a, ds, c_off_s, Cs, rpb);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

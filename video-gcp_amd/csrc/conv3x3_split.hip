@@ -907,6 +907,20 @@ __global__ void __launch_bounds__(256, 2) conv3x3_up32_split_kernel(const gcpx_c
         int ex = 0;                                                   // the accumulators hold (sum) 2^(ex + ew)
         const bool top = (y0 == 0), bot = (y0 + TH == Hout), lft = (x0 == 0), rgt = (x0 + TW == Wout);
 
+        h8 wr[3][CT][2];
+        auto wload = [&](const int stn_, h8 (&w)[CT][2]) __attribute__((always_inline)) {
+            const char* wp = wbase + (size_t)min(stn_, nstep - 1) * CT * 2048;           // (past the end: the last step again, never used)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                w[ct][0] = *reinterpret_cast<const h8*>(wp + ct * 2048);
+                w[ct][1] = *reinterpret_cast<const h8*>(wp + ct * 2048 + 1024);
+            }
+        };
+        if constexpr (CT <= 2) {
+            wload(0, wr[0]);
+            wload(1, wr[1]);
+        }
+
         for (int chunk = 0; chunk < nchunk; ++chunk) {
             // ---- registers -> low-res patch (affine + LeakyReLU), largest magnitude of the chunk over the workgroup ----
             float amax = 0.f;
@@ -992,46 +1006,81 @@ __global__ void __launch_bounds__(256, 2) conv3x3_up32_split_kernel(const gcpx_c
             if (chunk + 1 < nchunk) issue_loads(tile, chunk + 1);
             else if (tile + (int)gridDim.x < ntiles) issue_loads(tile + gridDim.x, 0);
 
-            // ---- MFMAs: 9 k-steps (tap, 32 channels) x CT x 4 pixel groups x 3 ----
-            h8 wn[CT][2];
-            {
-                const char* wp = wbase + (size_t)(chunk * 9) * CT * 2048;
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    wn[ct][0] = *reinterpret_cast<const h8*>(wp + ct * 2048);
-                    wn[ct][1] = *reinterpret_cast<const h8*>(wp + ct * 2048 + 1024);
+            if constexpr (CT <= 2) {
+                // ---- MFMAs: 9 k-steps (tap, 32 channels) x CT x 4 pixel groups x 3 ----
+                // weight fragments TWO k-steps ahead (three register sets in rotation, the tap loop unrolled by three so that the rotation
+                // is a renaming): one step of MFMAs (12 CT x 16 cycles, shared with the partner wavefront) did not cover an L2 round trip
+                // under load — the kernel spent 40-47 % of its wave cycles parked at these waits (PMC)
+                auto tap_mfmas = [&](const int tap, const h8 (&wc)[CT][2]) __attribute__((always_inline)) {
+                    const int tapoff = ((tap / 3) * RW + (tap % 3)) * 64;
+                    h8 b1[PR], b2[PR];
+    #pragma unroll
+                    for (int pt = 0; pt < PR; ++pt) {
+                        b1[pt] = *reinterpret_cast<const h8*>(hi + pixoff[pt] + tapoff);
+                        b2[pt] = *reinterpret_cast<const h8*>(hi + pixoff[pt] + tapoff + Cfg::PLANE_BYTES);
+                    }
+    #pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+    #pragma unroll
+                        for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma32h(wc[ct][1], b1[pt], acc[ct][pt]);
+    #pragma unroll
+                        for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma32h(wc[ct][0], b2[pt], acc[ct][pt]);
+    #pragma unroll
+                        for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma32h(wc[ct][0], b1[pt], acc[ct][pt]);
+                    }
+                };
+                __builtin_amdgcn_s_setprio(1);
+    #pragma unroll 1
+                for (int t3 = 0; t3 < 9; t3 += 3) {      // (the last trip of a chunk requests the first two steps of the next one)
+                    wload(chunk * 9 + t3 + 2, wr[2]);
+                    tap_mfmas(t3, wr[0]);
+                    wload(chunk * 9 + t3 + 3, wr[0]);
+                    tap_mfmas(t3 + 1, wr[1]);
+                    wload(chunk * 9 + t3 + 4, wr[1]);
+                    tap_mfmas(t3 + 2, wr[2]);
                 }
-            }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
-                const int tapoff = ((tap / 3) * RW + (tap % 3)) * 64;
-                h8 wc[CT][2];
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) { wc[ct][0] = wn[ct][0]; wc[ct][1] = wn[ct][1]; }
+            } else {          // (64 output channels: the third register set would spill; one step ahead as before)
+                // ---- MFMAs: 9 k-steps (tap, 32 channels) x CT x 4 pixel groups x 3 ----
+                h8 wn[CT][2];
                 {
-                    const int stn = min(chunk * 9 + tap + 1, nstep - 1);        // one k-step ahead (the last one re-reads itself)
-                    const char* wp = wbase + (size_t)stn * CT * 2048;
-#pragma unroll
+                    const char* wp = wbase + (size_t)(chunk * 9) * CT * 2048;
+    #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
                         wn[ct][0] = *reinterpret_cast<const h8*>(wp + ct * 2048);
                         wn[ct][1] = *reinterpret_cast<const h8*>(wp + ct * 2048 + 1024);
                     }
                 }
-                h8 b1[PR], b2[PR];
-#pragma unroll
-                for (int pt = 0; pt < PR; ++pt) {
-                    b1[pt] = *reinterpret_cast<const h8*>(hi + pixoff[pt] + tapoff);
-                    b2[pt] = *reinterpret_cast<const h8*>(hi + pixoff[pt] + tapoff + Cfg::PLANE_BYTES);
-                }
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-#pragma unroll
-                    for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma32h(wc[ct][1], b1[pt], acc[ct][pt]);
-#pragma unroll
-                    for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma32h(wc[ct][0], b2[pt], acc[ct][pt]);
-#pragma unroll
-                    for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma32h(wc[ct][0], b1[pt], acc[ct][pt]);
+                __builtin_amdgcn_s_setprio(1);
+    #pragma unroll 1
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int tapoff = ((tap / 3) * RW + (tap % 3)) * 64;
+                    h8 wc[CT][2];
+    #pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) { wc[ct][0] = wn[ct][0]; wc[ct][1] = wn[ct][1]; }
+                    {
+                        const int stn = min(chunk * 9 + tap + 1, nstep - 1);        // one k-step ahead (the last one re-reads itself)
+                        const char* wp = wbase + (size_t)stn * CT * 2048;
+    #pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) {
+                            wn[ct][0] = *reinterpret_cast<const h8*>(wp + ct * 2048);
+                            wn[ct][1] = *reinterpret_cast<const h8*>(wp + ct * 2048 + 1024);
+                        }
+                    }
+                    h8 b1[PR], b2[PR];
+    #pragma unroll
+                    for (int pt = 0; pt < PR; ++pt) {
+                        b1[pt] = *reinterpret_cast<const h8*>(hi + pixoff[pt] + tapoff);
+                        b2[pt] = *reinterpret_cast<const h8*>(hi + pixoff[pt] + tapoff + Cfg::PLANE_BYTES);
+                    }
+    #pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+    #pragma unroll
+                        for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma32h(wc[ct][1], b1[pt], acc[ct][pt]);
+    #pragma unroll
+                        for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma32h(wc[ct][0], b2[pt], acc[ct][pt]);
+    #pragma unroll
+                        for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = mfma32h(wc[ct][0], b1[pt], acc[ct][pt]);
+                    }
                 }
             }
             __builtin_amdgcn_s_setprio(0);

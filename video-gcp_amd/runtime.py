@@ -179,6 +179,7 @@ SYMBOLS = [
     ("gcpx_index_inverse", C.c_int, [vp, i32, vp, i32, vp]),
     ("gcpx_act_bwd", C.c_int, [C.POINTER(ActBwdArgs), vp]),
     ("gcpx_act_bwd_blocks", C.c_int, []),
+    ("gcpx_act_skip_bwd", C.c_int, [C.POINTER(ActBwdArgs), vp, i32, i32, i32, vp]),
     ("gcpx_bn_bwd_finalize", C.c_int, [vp, i32, i32, C.c_double, vp, vp, vp, vp, vp, i32, vp]),
     ("gcpx_bn_bwd_apply", C.c_int, [vp, vp, vp, vp, vp, i64, i32, vp]),
     ("gcpx_conv_stage", C.c_int, [C.POINTER(ConvArgs), vp]),
@@ -244,7 +245,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("GCPX_LIB") or LIB_PATH     # GCPX_LIB: another build of the same library (same-box A/B of kernels)
     if not os.path.exists(p):
         raise GcpxError(f"HIP extension not built: {p} is missing (run `python -c 'import __graft_entry__ as g; g.build()'`"
                         " or video-gcp_amd/csrc/build.sh). There is no CPU fallback.")

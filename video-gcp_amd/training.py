@@ -73,6 +73,7 @@ class GCPTrainStep:
         self.parallel_encoder_passes = os.environ.get("GCPX_PARALLEL_ENCODER_BWD") is not None
         self.fuse_stage = os.environ.get("GCPX_NO_STAGE_FUSION") is None     # 16-channel upsampling blocks: weight gradient without gcpx_conv_stage
         self.fuse_head_act = os.environ.get("GCPX_NO_HEAD_ACT_FUSION") is None     # activation backward of the last decoder block in the head's data gradient
+        self.fuse_skip = os.environ.get("GCPX_NO_SKIP_FUSION") is None             # skip-connection sum of a 16 + 16 channel block in the activation pass in front of it
         self.split_wgrad_rows = os.environ.get("GCPX_WGRAD_ROWS_NOSPLIT") is None   # the tree's Linear / LSTM weight gradients (>= 256 rows) likewise
         self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
         self.fused_mlp_bwd = os.environ.get("GCPX_NO_FUSED_MLP_BWD") is None
@@ -436,10 +437,12 @@ class GCPTrainStep:
     def _dense(self, ptr, ld, width, M):
         return self.m._rowsrc(ptr, M * ld, ld, width)
 
-    def _bn_bwd(self, plan, tag, bn, da, ldc, c_off, up, r, F, Hh, Ww, add=None, fused=None, defer_affine=False):
+    def _bn_bwd(self, plan, tag, bn, da, ldc, c_off, up, r, F, Hh, Ww, add=None, fused=None, defer_affine=False, skip=None):
         """activation + BatchNorm backward of one conv block: returns the buffer holding d(raw conv output).
         fused = (dy, partial sums [nb][2][C], nb): the data-gradient conv that produced `da` already applied the activation's derivative
-        and left the statistics (gcpx_conv_args.bwd_r): only the BatchNorm half remains, in place."""
+        and left the statistics (gcpx_conv_args.bwd_r): only the BatchNorm half remains, in place.
+        skip = (ds, channel offset, channels, frames per sequence): `da` also holds the gradient of a skip connection's channels, whose sum
+        over a sequence's frames comes out of the same pass (gcpx_act_skip_bwd)."""
         m, lib, hp = self.m, self.m.lib, self.m._hp
         Cc = bn["C"]
         if fused is not None:
@@ -454,7 +457,11 @@ class GCPTrainStep:
             a.dy, a.stats_partial, a.ldc, a.c_off, a.up, a.fsum, a.act = dy.data_ptr(), st.data_ptr(), ldc, c_off, up, 1, rt.ACT_LRELU
             a.F, a.H, a.W, a.C = F, Hh, Ww, Cc
             plan.keep.append(a)
-            plan.add(f"bw.act:{tag}", lib.gcpx_act_bwd, C.byref(a))
+            if skip is not None:
+                ds, c_off_s, Cs, rpb_s = skip
+                plan.add(f"bw.act+skip:{tag}", lib.gcpx_act_skip_bwd, C.byref(a), ds.data_ptr(), c_off_s, Cs, rpb_s)
+            else:
+                plan.add(f"bw.act:{tag}", lib.gcpx_act_bwd, C.byref(a))
         coef = m._buf(f"bw.coef:{tag}", (3, Cc))
         pre = bn["prefix"]
         if defer_affine:
@@ -1012,13 +1019,15 @@ class GCPTrainStep:
 
         gin = (dA.data_ptr(), ngf, 0)            # (pointer, channel pitch, upsampled?) of the incoming gradient
         dskip = {}
+        pending_skip = None                      # skip half of the block behind this one, summed in this block's activation pass
         for blk in reversed(dec["blocks"]):
             name, res_in, cout, c_prev, c_skip = blk["name"], blk["res_in"], blk["cout"], blk["c_prev"], blk["c_skip"]
             res = 2 * res_in
             cin = c_prev + c_skip
             bn = rec[f"bn:dec.bn.{name}"]
             dy = self._bn_bwd(plan, f"dec.{name}", bn, gin[0], gin[1], 0, gin[2], blk["out"], F, res, res,
-                              fused=(head_fused if blk is last else None))
+                              fused=(head_fused if blk is last else None), skip=pending_skip)
+            pending_skip = None
             # 16-output-channel blocks: the split-f16 weight gradient interpolates its operand from the block's own sources; the others
             # materialise it first (gcpx_conv_stage)
             fused_up = (self.fuse_stage and m.split_f16 and self.split_wgrad and cout == 16 and cin % 32 == 0 and
@@ -1047,11 +1056,21 @@ class GCPTrainStep:
                 plan.add(f"bw.dgrad:dec.{name}.{h}", lib.gcpx_conv3x3, C.byref(a))
             if c_skip:
                 ds = buf(f"bw.dskip.{name}", (B, res_in, res_in, c_skip))
-                a = rt.ActBwdArgs()
-                a.da, a.dy, a.ldc, a.c_off, a.up, a.fsum, a.act = dU.data_ptr(), ds.data_ptr(), cin, c_prev, 1, rpb, rt.ACT_NONE
-                a.F, a.H, a.W, a.C = B, res_in, res_in, c_skip
-                plan.keep.append(a)
-                plan.add(f"bw.skip:{name}", lib.gcpx_act_bwd, C.byref(a))
+                # Both halves of a pixel of dU share its 128-byte lines when the block is 16 + 16 channels wide: the activation pass of the
+                # block in front (which reads the other half) then sums the skip half on the way (one pass over 1.07 GB at c2 instead of
+                # two); wider blocks keep the two launches (their halves are whole lines, and a sequence-major pass has too few threads)
+                nxt_i = dec["blocks"].index(blk) - 1
+                fuse = (self.fuse_skip and nxt_i >= 0 and dec["blocks"][nxt_i]["cout"] == c_prev and F % rpb == 0 and F // rpb == B and
+                        256 % ((c_prev + c_skip) // 4) == 0 and
+                        B * res_in * res_in * ((c_prev + c_skip) // 4) >= int(os.environ.get("GCPX_SKIP_FUSION_MIN_ITEMS", "65536")))
+                if fuse:
+                    pending_skip = (ds, c_prev, c_skip, rpb)
+                else:
+                    a = rt.ActBwdArgs()
+                    a.da, a.dy, a.ldc, a.c_off, a.up, a.fsum, a.act = dU.data_ptr(), ds.data_ptr(), cin, c_prev, 1, rpb, rt.ACT_NONE
+                    a.F, a.H, a.W, a.C = B, res_in, res_in, c_skip
+                    plan.keep.append(a)
+                    plan.add(f"bw.skip:{name}", lib.gcpx_act_bwd, C.byref(a))
                 dskip[blk["skip_idx"]] = ds
             gin = (dU.data_ptr(), cin, 1)
             if not self.defer_decoder_side:
