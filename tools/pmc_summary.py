@@ -15,7 +15,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 KERNELS = {"head": "conv3x3_head", "up16": "conv3x3_up16", "up32": "conv3x3_up32", "conv3x3_tiled": "conv3x3_kernel<", "gemm": "gemm_kernel<",
-           "gemm_split": "gemm_split_kernel", "mlp": "mlp_kernel<", "mlp_group": "mlp_group_kernel", "enc_lds": "conv4x4s2_lds_kernel",
+           "gemm_split": "gemm_split_kernel", "gemm_planes": "gemm_planes_kernel", "split_rows": "split_rows_kernel", "level_pre": "level_pre_kernel",
+           "mlp": "mlp_kernel<", "mlp_group": "mlp_group_kernel", "enc_lds": "conv4x4s2_lds_kernel",
            "enc_split": "conv4x4s2_split_kernel", "enc_image": "conv4x4s2_image_kernel"}
 
 

@@ -411,6 +411,7 @@ class GCPTreeModel:
         below that the launch is bound by the per-CU load rate, not by the f32 MFMA rate — DESIGN.md section 6c)."""
         self._gsplit = {}
         # rows from which a split GEMM with >= 1024 columns takes the two-launch planes form (GCPX_GEMM_PLANES_ROWS; 0 = never)
+        self._merge_side_rows = int(os.environ.get("GCPX_MERGE_SIDE_ROWS", "512")) or (1 << 60)   # rows from which a level's merge takes a side lane (0: never)
         pr = int(os.environ.get("GCPX_GEMM_PLANES_ROWS", "1024"))
         self._planes_min_rows = pr if pr > 0 else 1 << 60
         if not self.split_f16:
@@ -979,10 +980,12 @@ class GCPTreeModel:
         PS = 2 ** L + 1                                     # slots per batch element
         plan = _Plan(lib)
         G = lib.gcpx_conv_grid()
-        if "aux_n" in tin:
+        def plan_aux_indices():
             AUXK = ("inv_t0", "inv_t1", "cost_start_idx", "cost_end_idx")
             plan.add("aux_sample_indices", lib.gcpx_aux_sample_indices_gauss, tin["end_ind"].data_ptr(), tin["aux_n"].data_ptr(), B,
                      hp.inv_mdl_temp_dist, *[tin[k].data_ptr() for k in AUXK])
+        if "aux_n" in tin and pred_len:
+            plan_aux_indices()
 
         E = self._buf("E", (B, PS, nz))
         Hid = self._buf("Hid", (B, PS, SD))
@@ -1026,6 +1029,8 @@ class GCPTreeModel:
         skips = self._plan_encoder(plan, "I0", tin["I_0"].data_ptr(), B, _addr(E), PS * nz, 0, 1)
         plan.lane = 2
         if not pred_len:
+            if "aux_n" in tin:
+                plan_aux_indices()          # read by the ground-truth cost below and by the heads behind the tree: not in front of the encoders
             plan_bookkeeping()
         if hp.attach_cost_mdl and hp.run_cost_mdl and train_aux and self._has_aux_training:
             # ground-truth cost of the cost model's sampled segment (cost_mdl.py:101-117, EuclideanPathLength): reads traj_seq and
@@ -1082,6 +1087,7 @@ class GCPTreeModel:
             plan_bookkeeping()
 
         # ---- predict_sequence: level-serial tree (tree_utils.py:21-44, tree_module.py:67-114) ----
+        side_merge = False                                  # the merge of the level being planned is already running on lane 1
         for l in range(L):
             W = P[f"tree{l if hp.untied_layers else 0}"]
             s = 2 ** (L - 1 - l)
@@ -1144,11 +1150,15 @@ class GCPTreeModel:
                 g = (_addr(tin["eps"], (n - 1) * nv), N * nv, nv) + z_map
                 self._mlp(plan, f"posterior{l}", W["q"], [el(), er(), et], M, n, out=_addr(QZ, nodeoff(2 * nv)),
                           ob=PS * 2 * nv, orow=2 * s * 2 * nv, gauss=g, group=pq)
-                # the merge of this level's parent states needs level l - 1 only, like the two Predictors: same launch
+                # the merge of this level's parent states needs level l - 1 only, like the two Predictors: same launch — or, at the wide
+                # levels (a split-f16 GEMM of its own), a side lane started behind level l - 1's last LSTM layer (below)
                 mg = []
-                if l > 0 and merge_with_predictors:
+                if l > 0 and merge_with_predictors and not side_merge:
                     plan_merge(l, group=mg)
                 self._mlp_group(plan, f"prior+posterior{l}", pq, gemm=(mg[0] if mg else None))
+                if side_merge:
+                    plan.join([1])
+                    side_merge = False
             zs = lambda: self._rowsrc(z_map[0], z_map[1], z_map[2], nv)
             if not hp.tree_lstm:
                 # non-LSTM subgoal predictor (tree_module.py:109-110): e = tanh(Predictor([e_l, e_r, z (, e_0, e_g)])), no hidden state
@@ -1184,6 +1194,14 @@ class GCPTreeModel:
                     self._gemm(plan, f"lstm{l}.{i}", [xs, hs], M, 4 * H, n, W[f"lstm{i}.w"], W[f"lstm{i}.b"],
                                epi=rt.EPI_LSTM, lstm=lstm)
                 x = xn
+            if (l + 1 < L and merge_with_predictors and hp.tree_lstm == "split_linear" and B * 2 ** (l + 1) >= getattr(self, "_merge_side_rows", 1 << 60)):
+                # wide level ahead: its merge (40 us at 1024 rows) needs the hidden states just written and nothing else — it runs on lane 1
+                # beside this level's `out` and the next level's prior + posterior instead of in front of them
+                plan.fork([1])
+                plan.lane = 1
+                plan_merge(l + 1)
+                plan.lane = 0
+                side_merge = True
             g = []
             self._gemm(plan, f"out{l}", [self._rowsrc(x.data_ptr(), n * H, H, H)], M, nz, n, W["out.w"], W["out.b"],
                        out=_addr(E, nodeoff(nz)), ob=PS * nz, orow=2 * s * nz, group=g)
