@@ -390,6 +390,24 @@ def extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev, dinp_noloss)
                                             "workload": "gcp_sequential: forward + losses + backward through the 79-step recurrence + RAdam"}
             del trs
         del ms_
+        if hasattr(GCPSequentialModel, "_has_training"):
+            # the reference's own gcp_sequential conf runs 1024-wide LSTMs (experiments/prediction/25room/gcp_sequential/conf.py)
+            from video_gcp_amd.training_sequential import SequentialTrainStep
+            hpw = V.config("c2", batch_size=hp.batch_size, nz_mid_lstm=1024)
+            msw = GCPSequentialModel(hpw, device=dev)
+            _, err = setup(lambda: msw(dseq, "train"))
+            if not agree(err is None):
+                raise RuntimeError(err or "set-up failed on another rank")
+            dtf = _timed(lambda: msw(dseq, "train"), max(3, k // 2), 2, world, dev)
+            trw, err = setup(lambda: SequentialTrainStep(msw, process_group=(dist.group.WORLD if world > 1 else None)))
+            if not agree(err is None):
+                raise RuntimeError(err or "set-up failed on another rank")
+            fullw = {k_: v.to(dev) for k_, v in inputs.items()}
+            dtt = _timed(lambda: trw.step(fullw), max(3, k // 2), 2, world, dev)
+            res["sequential_1024"] = {"forward_ms": round(1e3 * dtf, 3), "train_step_ms": round(1e3 * dtt, 3),
+                                      "train_frames_per_s": round(world * hp.batch_size * hp.max_seq_len / dtt, 1),
+                                      "workload": "gcp_sequential with nz_mid_lstm = 1024 (the reference conf's width), otherwise the headline shapes"}
+            del trw, msw
     except Exception as e:  # noqa: BLE001
         res["sequential_forward"] = {"error": repr(e)[:300]}
     try:

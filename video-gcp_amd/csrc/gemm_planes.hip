@@ -472,8 +472,11 @@ int gcpx_launch_gemm_planes(const gcpx_gemm_args* a, hipStream_t stream) {
     if (force == 4) return launch_planes<4, 8, 4, 2, 2, 3>(a, stream);
     if (force == 5) return launch_planes<16, 8, 8, 4, 1, 3>(a, stream);                    // 256 x 128, 3 x 48 KB
     if (force == 6) return launch_planes<8, 8, 8, 4, 1, 4>(a, stream);                     // 128 x 128, 32-k stages, 4 x 32 KB
+    if (force == 7) return launch_planes<4, 4, 4, 4, 2, 4>(a, stream);                     // 64 x 64, 64-k stages, 4 x 32 KB
     if (n256 && tiles_a >= 256) return launch_planes<16, 16, 8, 2, 1, 2>(a, stream);       // 256 x 256, 2 x 64 KB
     if (n256 && tiles_b >= 256) return launch_planes<8, 16, 8, 2, 1, 3>(a, stream);        // 128 x 256, 3 x 48 KB
     if (tiles_d >= 256) return launch_planes<8, 8, 8, 4, 2, 2>(a, stream);                 // 128 x 128, 64-k stages, 2 x 64 KB
+    const long tiles_c = (long)((a->M + 63) / 64) * (a->N / 128) * nb;
+    if (tiles_c < 192) return launch_planes<4, 4, 4, 4, 2, 4>(a, stream);                  // 64 x 64, 64-k stages, 4 x 32 KB (a few hundred rows)
     return launch_planes<4, 8, 4, 2, 2, 3>(a, stream);                                     // 64 x 128, 64-k stages, 3 x 48 KB
 }

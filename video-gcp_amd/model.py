@@ -412,7 +412,7 @@ class GCPTreeModel:
         self._gsplit = {}
         # rows from which a split GEMM with >= 1024 columns takes the two-launch planes form (GCPX_GEMM_PLANES_ROWS; 0 = never)
         self._merge_side_rows = int(os.environ.get("GCPX_MERGE_SIDE_ROWS", "512")) or (1 << 60)   # rows from which a level's merge takes a side lane (0: never)
-        pr = int(os.environ.get("GCPX_GEMM_PLANES_ROWS", "1024"))
+        pr = int(os.environ.get("GCPX_GEMM_PLANES_ROWS", "512"))
         self._planes_min_rows = pr if pr > 0 else 1 << 60
         if not self.split_f16:
             return
