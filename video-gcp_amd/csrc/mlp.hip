@@ -280,7 +280,7 @@ __device__ __forceinline__ void mlp_rows(const gcpx_mlp_args& a, const int bx, c
 }
 
 // Helper workgroups of a small launch.  A Predictor at 16 rows is ONE workgroup pulling its 0.65 MB of weights through one CU at the
-// ~10 B / cycle a CU gets from HBM / MALL (29 us) while 240 CUs idle.  The L2 is shared by the 32 CUs of an
+// ~10 B / cycle a CU gets from HBM / MALL (29 us, NOTEBOOK.md section 6c) while 240 CUs idle.  The L2 is shared by the 32 CUs of an
 // XCD, and an L2 hit is served several times faster than that: so the launch brings one extra workgroup for every idle CU, and those
 // do nothing but LOAD the weights of the launch's problems — each XCD's helpers share the byte range between them (helper h is
 // assumed to sit on XCD h % 8, the observed dispatch order; when that does not hold some lines are fetched twice and others by the

@@ -408,7 +408,7 @@ class GCPTreeModel:
         """Inference only (like the fused embedding: a re-split of every GEMM weight after each optimizer step is not worth its
         launches): the two f16 pieces of the tree levels' LSTM and split_linear weights for csrc/gemm_split.hip, keyed by the
         address of the f32 pack they mirror.  gcpx_gemm takes the split kernel from GCPX_GEMM_SPLIT_MIN_ROWS rows on (default 512:
-        below that the launch is bound by the per-CU load rate, not by the f32 MFMA rate — DESIGN.md section 6c)."""
+        below that the launch is bound by the per-CU load rate, not by the f32 MFMA rate — NOTEBOOK.md section 6c)."""
         self._gsplit = {}
         # rows from which a split GEMM with >= 1024 columns takes the two-launch planes form (GCPX_GEMM_PLANES_ROWS; 0 = never)
         self._merge_side_rows = int(os.environ.get("GCPX_MERGE_SIDE_ROWS", "512")) or (1 << 60)   # rows from which a level's merge takes a side lane (0: never)
