@@ -471,7 +471,18 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __res
     __shared__ double r1[256], r2[256];
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int p = threadIdx.x; p < n_partial; p += 256) {
+    int p = threadIdx.x;
+    for (; p + 3 * 256 < n_partial; p += 4 * 256) {                // four rows' loads in flight per thread, summed in row order
+        float a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = partial[((size_t)(p + u * 256) * 2 + 0) * C + c];
+            b[u] = partial[((size_t)(p + u * 256) * 2 + 1) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s1 += a[u]; s2 += b[u]; }
+    }
+    for (; p < n_partial; p += 256) {
         s1 += partial[((size_t)p * 2 + 0) * C + c];
         s2 += partial[((size_t)p * 2 + 1) * C + c];
     }
