@@ -35,7 +35,9 @@ for val in (va, vb):
 torch.cuda.synchronize()
 res = [[], []]
 for r in range(rounds):
-    for i, (m, d) in enumerate(models):
+    order = (0, 1) if r % 2 == 0 else (1, 0)          # A B B A ...: whatever the position inside a round costs, both pay it equally
+    for i in order:
+        m, d = models[i]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):

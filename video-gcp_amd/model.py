@@ -1194,20 +1194,21 @@ class GCPTreeModel:
                     self._gemm(plan, f"lstm{l}.{i}", [xs, hs], M, 4 * H, n, W[f"lstm{i}.w"], W[f"lstm{i}.b"],
                                epi=rt.EPI_LSTM, lstm=lstm)
                 x = xn
-            if (l + 1 < L and merge_with_predictors and hp.tree_lstm == "split_linear" and B * 2 ** (l + 1) >= getattr(self, "_merge_side_rows", 1 << 60)):
-                # wide level ahead: its merge (40 us at 1024 rows) needs the hidden states just written and nothing else — it runs on lane 1
-                # beside this level's `out` and the next level's prior + posterior instead of in front of them
-                plan.fork([1])
-                plan.lane = 1
-                plan_merge(l + 1)
-                plan.lane = 0
-                side_merge = True
             g = []
             self._gemm(plan, f"out{l}", [self._rowsrc(x.data_ptr(), n * H, H, H)], M, nz, n, W["out.w"], W["out.b"],
                        out=_addr(E, nodeoff(nz)), ob=PS * nz, orow=2 * s * nz, group=g)
             if l + 1 < L and not merge_with_predictors:
                 plan_merge(l + 1, group=g)
             self._gemm_group(plan, f"out{l}+merge{l + 1}" if len(g) > 1 else f"out{l}", g)
+            if (l + 1 < L and merge_with_predictors and hp.tree_lstm == "split_linear" and B * 2 ** (l + 1) >= getattr(self, "_merge_side_rows", 1 << 60)):
+                # wide level ahead: its merge (a 33-43 us split GEMM of its own at 512 / 1024 rows) needs the hidden states just written and
+                # nothing else — it runs on lane 1 beside the next level's prior + posterior instead of in front of them.  Forked BEHIND
+                # `out`: started together, the merge's 768 workgroups starved the 5 us `out` GEMM for 36 us (profiles/r04f_fwd_trace.txt)
+                plan.fork([1])
+                plan.lane = 1
+                plan_merge(l + 1)
+                plan.lane = 0
+                side_merge = True
 
         # ---- latent-space heads: independent of the decoder, run next to it on lane 1 ----
         F = B * N
