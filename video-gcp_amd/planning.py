@@ -181,25 +181,35 @@ class LearnedCostEstimate:
 
 
 class CostFcn:
-    """Hand-written CEM cost functions (cost_fcn.py:10-77).  `__call__(cem_outputs, goal)` is the reference's host contract — a list
-    of per-candidate numpy arrays [len_i, D] and the goal — restated in numpy; `rollout_cost_device` scores a padded device rollout
-    ([n, T, D] + lengths) with one HIP launch (gcpx_rollout_cost) for the device-resident planner."""
+    """Hand-written CEM costs (cost_fcn.py:10-77).  Host contract of the reference: `cost(cem_outputs, goal)` with `cem_outputs` a list of
+    per-candidate arrays [len_i, D] -> one score per candidate; a subclass says what ONE rollout costs per step (`per_step`), this class
+    turns the step costs into the score: the last step weighted by `final_step_weight`, then either everything summed (`dense_cost`) or
+    the last step alone.  `rollout_cost_device` scores a padded device rollout ([n, T, D] + lengths) with one HIP launch
+    (gcpx_rollout_cost, same four kinds) for the device-resident planner."""
     KIND = None
 
     def __init__(self, dense_cost, final_step_weight=1.0, *unused_args):
         self._dense_cost = dense_cost
         self._final_step_weight = final_step_weight
 
-    def __call__(self, cem_outputs, goal):
-        cost_per_step = self._compute(cem_outputs, goal)
-        for c in cost_per_step:
-            c[-1] *= self._final_step_weight
-        if self._dense_cost:
-            return np.array([np.sum(c) for c in cost_per_step])
-        return np.array([c[-1] for c in cost_per_step])
-
-    def _compute(self, cem_outputs, goal):
+    def per_step(self, rollout, goal):
+        """[len] step costs of one rollout [len, D]"""
         raise NotImplementedError
+
+    def _prepare_goal(self, goal):
+        return goal
+
+    def __call__(self, cem_outputs, goal):
+        goal = self._prepare_goal(goal)
+        scores = np.empty(len(cem_outputs))
+        for i, rollout in enumerate(self._prepare_rollouts(cem_outputs)):
+            steps = np.array(self.per_step(rollout, goal), dtype=np.float64)
+            steps[-1] = steps[-1] * self._final_step_weight
+            scores[i] = steps.sum() if self._dense_cost else steps[-1]
+        return scores
+
+    def _prepare_rollouts(self, cem_outputs):
+        return cem_outputs
 
     def _device_goal(self, goal, D, device):
         return torch.as_tensor(np.asarray(goal, dtype=np.float32).reshape(-1)[:D].copy(), device=device)
@@ -222,67 +232,83 @@ class CostFcn:
 
 
 class ImageCost:
-    """cost_fcn.py:26-39: split an (image ++ latent) rollout [len, 3 H W + input_dim] into its image and latent parts"""
+    """cost_fcn.py:26-39: a rollout row is an image (3 x S x S, flattened) followed by `input_dim` latent columns"""
 
     def _split_state_rollout(self, rollouts):
-        imgs, lats = [], []
+        images, latents = [], []
         for r in rollouts:
-            flat = r[..., :-self.input_dim]
-            assert flat.ndim == 2
-            res = int(np.sqrt(flat.shape[1] / 3))                 # assumes a 3-channel image
-            imgs.append(flat.reshape(flat.shape[0], 3, res, res))
-            lats.append(r[..., -self.input_dim:])
-        return Outputs(image_rollout=imgs, latent_rollout=lats)
+            r = np.asarray(r)
+            assert r.ndim == 2
+            n_pix = r.shape[1] - self.input_dim
+            side = int(np.sqrt(n_pix / 3))                        # three colour planes of side x side pixels
+            images.append(r[:, :n_pix].reshape(r.shape[0], 3, side, side))
+            latents.append(r[:, n_pix:])
+        return Outputs(image_rollout=images, latent_rollout=latents)
+
+
+def _row_norms(a):
+    return np.sqrt(np.square(a).sum(axis=-1))
 
 
 class EuclideanDistance(CostFcn):
-    """Euclidean distance between every step and the goal (cost_fcn.py:42-46)"""
+    """distance of every step to the goal (cost_fcn.py:42-46)"""
     KIND = 0
 
-    def _compute(self, cem_outputs, goal):
-        return [np.linalg.norm(o - goal[None], axis=-1) for o in cem_outputs]
+    def per_step(self, rollout, goal):
+        return _row_norms(rollout - np.asarray(goal).reshape(1, -1))
 
 
 class EuclideanPathLength(CostFcn):
-    """Euclidean length of the whole path to the goal (cost_fcn.py:49-54)"""
+    """length of the path through the steps and on to the goal (cost_fcn.py:49-54); only meaningful summed over the steps"""
     KIND = 1
 
-    def _compute(self, cem_outputs, goal):
-        assert self._dense_cost                                   # need dense cost for path length computation
-        return [np.linalg.norm(np.concatenate([o[1:], goal[None]]) - o, axis=-1) for o in cem_outputs]
+    def per_step(self, rollout, goal):
+        assert self._dense_cost, "a path length is the sum over its steps: dense_cost must be set"
+        successor = np.vstack([rollout[1:], np.asarray(goal).reshape(1, -1)])
+        return _row_norms(successor - rollout)
 
 
 class StepPathLength(CostFcn):
-    """number of steps of the path (cost_fcn.py:57-62)"""
+    """the number of steps, charged to the last one (cost_fcn.py:57-62)"""
     KIND = 2
 
-    def _compute(self, cem_outputs, goal):
-        return [np.concatenate((np.zeros(o.shape[0] - 1), np.array([float(o.shape[0])]))) for o in cem_outputs]
+    def per_step(self, rollout, goal):
+        steps = np.zeros(len(rollout))
+        steps[-1] = float(len(rollout))
+        return steps
 
     def _device_goal(self, goal, D, device):
         return torch.zeros(1, device=device)
 
 
 class L2ImageCost(CostFcn, ImageCost):
-    """L2 distance to the goal image in pixel space (cost_fcn.py:65-77); goal_raw: env image [1, H, W, 3] in [0, 1]"""
+    """pixel-space distance of every predicted image to the goal image (cost_fcn.py:65-77); goal_raw: env image [1, H, W, 3] in [0, 1]"""
     KIND = 3
     LATENT_SIZE = 128
-
-    def _compute(self, cem_outputs, goal_raw):
-        image_sequences = self._split_state_rollout(cem_outputs).image_rollout
-        goal = np.asarray(goal_raw).transpose(0, 3, 1, 2) * 2 - 1.0
-        return [np.sqrt(np.sum((seq - goal) ** 2, axis=(1, 2, 3))) for seq in image_sequences]
 
     @property
     def input_dim(self):
         return self.LATENT_SIZE
 
+    @staticmethod
+    def _goal_planes(goal_raw, dtype=None):
+        g = np.asarray(goal_raw, dtype=dtype)
+        return np.moveaxis(g, 3, 1) * 2 - 1.0                     # HWC in [0, 1] -> CHW in [-1, 1]
+
+    def _prepare_goal(self, goal_raw):
+        return self._goal_planes(goal_raw)
+
+    def _prepare_rollouts(self, cem_outputs):
+        return self._split_state_rollout(cem_outputs).image_rollout
+
+    def per_step(self, images, goal):
+        return np.sqrt(np.square(images - goal).sum(axis=(1, 2, 3)))
+
     def _device_columns(self, ld):
         return ld - self.input_dim
 
     def _device_goal(self, goal_raw, D, device):
-        g = np.asarray(goal_raw, dtype=np.float32).transpose(0, 3, 1, 2) * 2 - 1.0
-        return torch.as_tensor(g.reshape(-1)[:D].copy(), device=device)
+        return torch.as_tensor(self._goal_planes(goal_raw, np.float32).reshape(-1)[:D].copy(), device=device)
 
 
 class FlatCEMSampler:
