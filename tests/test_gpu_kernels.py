@@ -1885,3 +1885,41 @@ def test_act_skip_bwd_equals_the_two_passes(env, B, nodes, H, Ca, Cs):
     up.backward(dU[..., :Ca].permute(0, 3, 1, 2).double().cpu())
     slope = torch.where((r * sc + sh) > 0, 1.0, 0.2).cpu().double()
     assert_close(dy1.cpu().double(), x.grad.permute(0, 2, 3, 1) * slope, atol=1e-5, name="transposed bilinear x LeakyReLU'")
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 256), (1100, 2048, 1024), (4200, 1024, 512)])
+def test_gemm_planes_same_bits_under_memory_load(env, M, N, K):
+    """Race screen of the LDS-DMA pipeline (hand-counted waits, one barrier per stage): the same problem 24 times while a second stream
+    streams 1 GB copies through the chip — an early fragment read or a stage restaged too soon shows up as a run whose bits differ.
+    Every run must reproduce the first one exactly, and the first one the float64 result."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(M)
+    x = torch.randn(M, K)
+    w, b = torch.randn(N, K) / K ** 0.5, torch.randn(N)
+    ref = F.linear(x.double(), w.double(), b.double())
+    xd, wp, bd = x.to(dev), pk.pack_gemm(w).to(dev), b.to(dev)
+    ws, e = pk.pack_gemm_split(w)
+    ws = ws.to(dev)
+    a = rt.GemmArgs()
+    a.src[0] = _rowsrc(rt, xd, 0, K, K)
+    a.nsrc, a.M, a.N, a.K, a.rpb = 1, M, N, K, M
+    out = torch.empty(M, N, device=dev)
+    a.wpk, a.bias, a.out, a.ob, a.orow = wp.data_ptr(), bd.data_ptr(), out.data_ptr(), 0, N
+    a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
+    keep = _planes_workspace(rt, lib, a, dev)
+    hog_a, hog_b = torch.empty(1 << 28, dtype=torch.float32, device=dev), torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream()
+    first = None
+    for it in range(24):
+        with torch.cuda.stream(side):
+            if it % 3:
+                hog_b.copy_(hog_a)                                 # uneven load: two runs of three beside a 1 GB copy, one alone
+        out.fill_(float("nan"))
+        rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "planes")
+        torch.cuda.synchronize()
+        if first is None:
+            first = out.clone()
+            err = (first.double().cpu() - ref).abs().max()
+            assert float(err) <= 2e-5 * float(ref.abs().max()), float(err)
+        else:
+            assert torch.equal(out, first), (it, int((out != first).sum()))
