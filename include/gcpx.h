@@ -147,6 +147,10 @@ int gcpx_bn_finalize(const float* partial, int32_t n_partial, int32_t pitch, int
                      const float* gamma, const float* beta, float eps, float* scale, float* shift,
                      float* running_mean, float* running_var, float momentum, float* mean_out, float* rstd_out,
                      void* stream);   /* mean_out / rstd_out: [C] batch statistics kept for the backward pass, or NULL */
+/* n standard-normal numbers (Philox4x32-10 + Box-Muller) into out (16-byte aligned); state: dev uint64 [2] = {seed, offset}, the offset
+   advanced by a second launch behind the draw, so a replayed graph draws fresh numbers.  Replaces the torch.randn behind
+   Gaussian.sample() (tree_module.py:79-94) for models that draw their latent noise themselves. */
+int gcpx_randn(float* out, int64_t n, uint64_t* state, void* stream);
 /* eval-mode fold: scale/shift from running statistics */
 int gcpx_bn_fold(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
                  float eps, int32_t C, float* scale, float* shift, void* stream);

@@ -1923,3 +1923,34 @@ def test_gemm_planes_same_bits_under_memory_load(env, M, N, K):
             assert float(err) <= 2e-5 * float(ref.abs().max()), float(err)
         else:
             assert torch.equal(out, first), (it, int((out != first).sum()))
+
+
+def test_randn_in_plan_generator(env):
+    """gcpx_randn (Philox4x32-10 + Box-Muller; the latent noise of a forward that is not fed any): standard-normal moments and tails on
+    4 M numbers, the same numbers for the same {seed, offset}, fresh numbers on every call (the offset advances on the device), other
+    numbers for another seed, and sizes that are not a multiple of four."""
+    rt, pk, lib, dev = env
+    n = 1 << 22
+    st = torch.tensor([1234, 0], dtype=torch.int64, device=dev)
+    a, b, c = (torch.full((n,), float("nan"), device=dev) for _ in range(3))
+    rt.check(lib.gcpx_randn(a.data_ptr(), n, st.data_ptr(), _stream()), "randn")
+    rt.check(lib.gcpx_randn(b.data_ptr(), n, st.data_ptr(), _stream()), "randn")
+    torch.cuda.synchronize()
+    assert int(st[1]) == 2 * (n // 4) and int(st[0]) == 1234
+    st2 = torch.tensor([1234, 0], dtype=torch.int64, device=dev)
+    rt.check(lib.gcpx_randn(c.data_ptr(), n, st2.data_ptr(), _stream()), "randn")
+    torch.cuda.synchronize()
+    assert torch.equal(a, c) and not torch.equal(a, b)
+    x = torch.cat([a, b]).double().cpu()
+    assert torch.isfinite(x).all()
+    assert abs(float(x.mean())) < 2e-3 and abs(float(x.var()) - 1.0) < 3e-3
+    assert abs(float((x ** 3).mean())) < 1e-2 and abs(float((x ** 4).mean()) - 3.0) < 3e-2
+    for thr, p in ((1.0, 0.158655), (2.0, 0.0227501), (3.0, 0.0013499)):
+        frac = float((x > thr).double().mean())
+        assert abs(frac - p) < 4 * (p / x.numel()) ** 0.5 + 1e-5, (thr, frac, p)
+    assert abs(float((a[:-1].double() * a[1:].double()).mean().cpu())) < 3e-3            # neighbours uncorrelated
+    st3 = torch.tensor([99, 0], dtype=torch.int64, device=dev)
+    d = torch.full((1003 + 5,), 7.0, device=dev)
+    rt.check(lib.gcpx_randn(d.data_ptr(), 1003, st3.data_ptr(), _stream()), "randn")
+    torch.cuda.synchronize()
+    assert bool((d[1003:] == 7.0).all()) and not bool((d[:1003] == 7.0).any()) and not torch.equal(d[:1003], a[:1003])

@@ -1,6 +1,6 @@
 """Same-process A/B of the headline forward under two values of one environment setting that the model reads when it is built
 (box-to-box and run-to-run spreads of +-3 % hide effects of 1-2 %; two processes in a row differ by the chip's temperature):
-both models live in one process and take turns, ROUNDS x STEPS forwards each.
+two models per value live in one process (built A B B A) and take turns, ROUNDS x STEPS forwards each.
     python tools/ab_inproc.py VAR valueA valueB [rounds] [steps]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,8 +17,12 @@ dev = torch.device("cuda", 0)
 hp = V.config("c2")
 inputs, noise, _ = make_inputs(hp, seed=100, variant="A")
 models = []
-for val in (va, vb):
-    if val == "-":
+# FOUR instances, built A B B A: a model built earlier in the process runs 0.02-0.08 ms slower than one built later (measured with two
+# identical settings), so each setting gets one early and one late instance
+for val in (va, vb, vb, va):
+    if var == "@stream":                       # not a setting of the model: which stream the CALLER works on ("caller" = the current
+        pass                                   # stream, "model" = the model's own: no cross-stream hand-over per forward)
+    elif val == "-":
         os.environ.pop(var, None)
     else:
         os.environ[var] = val
@@ -33,18 +37,22 @@ for val in (va, vb):
         m(d, "train")
     models.append((m, d))
 torch.cuda.synchronize()
-res = [[], []]
+res = [[], [], [], []]
+vals4 = (va, vb, vb, va)
 for r in range(rounds):
-    order = (0, 1) if r % 2 == 0 else (1, 0)          # A B B A ...: whatever the position inside a round costs, both pay it equally
+    order = (0, 1, 2, 3) if r % 2 == 0 else (3, 2, 1, 0)     # whatever the position inside a round costs, both settings pay it equally
     for i in order:
         m, d = models[i]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            out = m(d, "train")
-            m.loss(d, out)
+        with torch.cuda.stream(m._stream if (var == "@stream" and vals4[i] == "model") else torch.cuda.current_stream(dev)):
+            for _ in range(steps):
+                out = m(d, "train")
+                m.loss(d, out)
         torch.cuda.synchronize()
         res[i].append(1e3 * (time.perf_counter() - t0) / steps)
-for i, val in enumerate((va, vb)):
-    v = sorted(res[i])
-    print(f"{var}={val:8s} median {v[len(v) // 2]:.3f} ms  min {v[0]:.3f}  max {v[-1]:.3f}   rounds: " + " ".join(f"{x:.3f}" for x in res[i]))
+med = lambda t: sorted(t)[len(t) // 2]
+for val, idx in ((va, (0, 3)), (vb, (1, 2))):
+    both = res[idx[0]] + res[idx[1]]
+    print(f"{var}={val:8s} mean of the two instances' medians {(med(res[idx[0]]) + med(res[idx[1]])) / 2:.3f} ms  "
+          f"(instance built {idx[0] + 1}.: {med(res[idx[0]]):.3f}, built {idx[1] + 1}.: {med(res[idx[1]]):.3f})  min {min(both):.3f}  max {max(both):.3f}")

@@ -85,6 +85,45 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Standard-normal draws inside the launch plan (Gaussian.sample() of the reference draws from torch's generator on every forward,
+// tree_module.py:79-94; as a torch kernel in front of the captured graph that draw sat at the head of the forward's dependent chain):
+// Philox4x32-10 counter-based generator (key = seed, counter = offset + thread index) + Box-Muller, four numbers per thread; the
+// offset lives in device memory and is advanced by a second, one-thread launch behind the draw — replaying the graph draws fresh numbers.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, const long long n, const unsigned long long* __restrict__ state) {
+    const unsigned long long seed = state[0], ctr = state[1] + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+    // u in (0, 1] from the top 24 bits; two Box-Muller pairs
+    const float u0 = ((r.x >> 8) + 1u) * 5.9604644775390625e-8f, u1 = (r.y >> 8) * 5.9604644775390625e-8f;
+    const float u2 = ((r.z >> 8) + 1u) * 5.9604644775390625e-8f, u3 = (r.w >> 8) * 5.9604644775390625e-8f;
+    const float ra = sqrtf(-2.f * __logf(u0)), rb = sqrtf(-2.f * __logf(u2));
+    float sa, ca, sb, cb;
+    __sincosf(6.283185307179586f * u1, &sa, &ca);
+    __sincosf(6.283185307179586f * u3, &sb, &cb);
+    const float v[4] = {ra * ca, ra * sa, rb * cb, rb * sb};
+    if (i + 3 < n) {
+        *reinterpret_cast<float4*>(out + i) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        for (int k = 0; k < 4 && i + k < n; ++k) out[i + k] = v[k];
+    }
+}
+
+__global__ void rng_advance_kernel(unsigned long long* state, const unsigned long long inc) { state[1] += inc; }
+
 __global__ void bn_fold_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
                                const float* __restrict__ gamma, const float* __restrict__ beta, const float eps,
                                const int C, float* __restrict__ scale, float* __restrict__ shift) {
@@ -346,6 +385,17 @@ extern "C" int gcpx_bn_finalize(const float* partial, int32_t n_partial, int32_t
     GCPX_CHECK_ARG(n_partial > 0 && C > 0 && pitch >= C && pitch % C == 0 && count > 0, "bad sizes");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, partial, n_partial, pitch, C, count, gamma,
                        beta, eps, scale, shift, running_mean, running_var, momentum, mean_out, rstd_out);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_randn(float* out, int64_t n, uint64_t* state, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(out && state && n > 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "null pointer / n <= 0 / out not 16-byte aligned");
+    const long long threads = (n + 3) / 4;
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    hipLaunchKernelGGL(randn_kernel, dim3(blocks), dim3(256), 0, stream, out, (long long)n, reinterpret_cast<const unsigned long long*>(state));
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, stream, reinterpret_cast<unsigned long long*>(state), (unsigned long long)blocks * 256);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -132,6 +132,7 @@ class GCPTreeModel:
 
     _has_aux_training = True      # sampled inverse-model / cost-model training pairs (base_gcp.py:249-260)
     _has_pred_length = True       # val_mode(pred_length=True) draws the sequence length (base_gcp.py:219-226)
+    _rng_in_plan = True           # the latent noise / index draws of a forward without fed noise are an op of the plan (gcpx_randn)
 
     def __init__(self, hp: GCPHParams, params=None, device="cuda", seed=0, materialize_distr=False):
         self._hp = hp
@@ -1026,6 +1027,11 @@ class GCPTreeModel:
         # three independent encoder passes (separate BatchNorm statistics, base_gcp.py:188,208,209) on three lanes
         plan.fork([1, 2])
         plan.lane = 1
+        if "rng_all" in tin:
+            # Gaussian.sample()'s numbers for this forward (+ the index draws' four per sequence): first needed by level 0's posterior
+            plan.add("randn", lib.gcpx_randn, tin["rng_all"].data_ptr(), tin["rng_all"].numel(), self._buf("rng_state", (2,), torch.int64).data_ptr())
+            if "aux_n" in tin and not pred_len:
+                plan.wait(2, 1)             # lane 2's index draw reads them
         skips = self._plan_encoder(plan, "I0", tin["I_0"].data_ptr(), B, _addr(E), PS * nz, 0, 1)
         plan.lane = 2
         if not pred_len:
@@ -1497,6 +1503,15 @@ class GCPTreeModel:
 
     # ------------------------------------------------------------------------------------------------
     # forward
+    def _sync_rng_state(self):
+        """{seed, offset} of the plan's generator on the device.  The seed follows torch's CUDA generator (what the torch draw used:
+        `torch.cuda.manual_seed` — per rank in train.py — keeps its meaning); re-seeding torch restarts the stream."""
+        seed = int(torch.cuda.initial_seed()) & ((1 << 63) - 1)
+        if getattr(self, "_rng_seed", None) != seed:
+            self._rng_seed = seed
+            st = self._buf("rng_state", (2,), torch.int64)
+            st.copy_(torch.tensor([seed, 0], dtype=torch.int64), non_blocking=True)
+
     # ------------------------------------------------------------------------------------------------
     def forward(self, inputs, phase="train", noise=None):
         """BaseGCPModel.forward (base_gcp.py:140-161).
@@ -1567,6 +1582,9 @@ class GCPTreeModel:
             n_eps = 0 if has_z else B * self._n_latents() * hp.nz_vae
             draw_idx = need_idx and not fed_idx
             rng = self._buf("rng", (n_eps + (4 * B if draw_idx else 0),)) if (n_eps or draw_idx) else None
+            # drawn by the plan itself (a side-lane op of the graph, off the encoder chain) when nothing is fed
+            in_plan = bool(self._rng_in_plan and rng is not None and noise is None and os.environ.get("GCPX_TORCH_RNG") is None and
+                           not (pred_len and draw_idx))       # (there the index draw sits in front of the fork: keep the torch draw)
             if draw_idx:
                 tin["aux_n"] = rng[n_eps:].view(4, B)
                 for k in AUX:
@@ -1575,7 +1593,8 @@ class GCPTreeModel:
                 # the draws of Gaussian.sample() live in a persistent buffer as well
                 eps = rng[:n_eps].view(B, self._n_latents(), hp.nz_vae)
                 if noise is None:
-                    rng.normal_()
+                    if not in_plan:
+                        rng.normal_()
                 else:
                     if not (noise.is_cuda and noise.data_ptr() == eps.data_ptr()):
                         eps.copy_(noise)
@@ -1584,12 +1603,15 @@ class GCPTreeModel:
                     if draw_idx:
                         tin["aux_n"].normal_()
                 tin["eps"] = eps
-            elif draw_idx:
+            elif draw_idx and not in_plan:
                 rng.normal_()                        # (z is fed, or the predictor is deterministic: only the index draws)
+            if in_plan:
+                tin["rng_all"] = rng
+                self._sync_rng_state()
         # the plan (and its captured graph) bakes in buffer addresses and sizes: everything that selects buffers is part of the key
         shapes = tuple((k, tuple(tin[k].shape)) for k in sorted(tin))
         key = (B, has_traj, has_z, self._sample_prior, phase, self.training, self.materialize_distr, with_loss, self._decode, pred_len,
-               shapes)
+               shapes)             # (a plan that draws its own noise has "rng_all" among its inputs: part of `shapes`)
         if key not in self._plans:
             plan = self._build_plan(key, tin)
             plan.keep.append(tin)

@@ -126,6 +126,7 @@ SYMBOLS = [
     ("gcpx_conv4x4s2_image", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     ("gcpx_bn_finalize", C.c_int, [vp, i32, i32, i32, C.c_double, vp, vp, C.c_float, vp, vp, vp, vp, C.c_float, vp, vp, vp]),
     ("gcpx_bn_fold", C.c_int, [vp, vp, vp, vp, C.c_float, i32, vp, vp, vp]),
+    ("gcpx_randn", C.c_int, [vp, i64, vp, vp]),
     ("gcpx_gemm", C.c_int, [C.POINTER(GemmArgs), vp]),
     ("gcpx_gemm_row_blocks", C.c_int, [i32, i32]),
     ("gcpx_gemm_planes_workspace", C.c_int, [i32, i32, i32, vp, vp]),

@@ -20,6 +20,7 @@ class GCPSequentialModel(GCPTreeModel):
     # the flat baseline always rolls out to the fed end_ind (no length predictor)
     _has_aux_training = True      # sampled inverse-model / cost-model training pairs (base_gcp.py:249-260), as for the tree model
     _has_pred_length = False
+    _rng_in_plan = False              # (the flat model's plan keeps the torch draw in front of it)
     _has_training = True              # training_sequential.SequentialTrainStep
 
     def _check_hp(self, hp):
