@@ -20,14 +20,16 @@ models = []
 # FOUR instances, built A B B A: a model built earlier in the process runs 0.02-0.08 ms slower than one built later (measured with two
 # identical settings), so each setting gets one early and one late instance
 for val in (va, vb, vb, va):
-    if var == "@stream":                       # not a setting of the model: which stream the CALLER works on ("caller" = the current
-        pass                                   # stream, "model" = the model's own: no cross-stream hand-over per forward)
+    if var in ("@stream", "@graph"):           # not environment settings: which stream the CALLER works on ("caller" = the current stream,
+        pass                                   # "model" = the model's own); hipGraph replay ("1") or eager launches of the plan ("0")
     elif val == "-":
         os.environ.pop(var, None)
     else:
         os.environ[var] = val
     m = GCPTreeModel(hp, params=V.init_params(hp, seed=0), device=dev)
     m.train(True)
+    if var == "@graph":
+        m.use_graph = {"1": True, "0": False}.get(val, "auto")
     d = {}
     for k in ("traj_seq", "I_0", "I_g", "end_ind", "start_ind", "pad_mask", "traj_seq_states", "actions"):
         buf = m.input_buffer(k, inputs[k].shape) if k != "start_ind" else inputs[k].to(dev)
@@ -37,6 +39,7 @@ for val in (va, vb, vb, va):
         m(d, "train")
     models.append((m, d))
 torch.cuda.synchronize()
+print("plans replayed eagerly:", [[p.eager for _, p in m._plans.values()] for m, _ in models], " use_graph:", [m.use_graph for m, _ in models])
 res = [[], [], [], []]
 vals4 = (va, vb, vb, va)
 for r in range(rounds):

@@ -42,6 +42,7 @@ class _Plan:
         self.ops = []        # (name, fn, args, lane) | ("@fork"/"@join", None, (lanes, events), 0)
         self.keep = []       # keeps argument structs / tensors alive
         self.graph = None
+        self.eager = False   # replay by eager launches although a graph exists (GCPTreeModel._eager_replays_faster)
         self.lane = 0
         self.rec = {}        # buffers / records the backward plan is built from (training step)
         self.deferred = []   # ops waiting to be issued on a side lane (training.py)
@@ -147,7 +148,11 @@ class GCPTreeModel:
         self.materialize_distr = materialize_distr
         self._bufs = {}
         self._plans = {}
-        self.use_graph = True
+        # how a built plan is replayed: True = hipGraph, False = eager launches over the three lanes, "auto" (default) = whichever
+        # replays faster back to back, timed once per plan (GCPX_FORWARD_REPLAY=graph|eager|auto).  At c2 the graph loses 0.19 ms of
+        # 2.9 to the eager plan (a ~30 us gap in front of every replay plus its cross-branch edges; the host needs ~0.4 ms to enqueue a
+        # 2.8 ms forward); at c1 (a 0.3 ms forward) the eager plan is host-bound and the graph wins
+        self.use_graph = {"graph": True, "eager": False}.get(os.environ.get("GCPX_FORWARD_REPLAY", "auto"), "auto")
         # hipGraph capture is not allowed on the legacy default stream: the model launches on its own stream
         # and orders it against the caller's current stream with events (wait_stream), never a host sync
         self._stream = torch.cuda.Stream(device=self.device)
@@ -1624,11 +1629,35 @@ class GCPTreeModel:
             if plan.graph is None:
                 plan.run(self._streams)               # warm-up (sets kernel attributes) outside capture
                 plan.graph = self._capture(plan, plan.ops, stream)
-            rt.check(self.lib.gcpx_graph_launch(plan.graph, stream), "graph_launch")
+                plan.eager = self.use_graph == "auto" and self._eager_replays_faster(plan, stream)
+            if plan.eager:
+                plan.run(self._streams)
+            else:
+                rt.check(self.lib.gcpx_graph_launch(plan.graph, stream), "graph_launch")
         else:
             plan.run(self._streams)
         caller.wait_stream(self._stream)
         return self._wrap_outputs(plan.outs, tin, phase)
+
+    def _eager_replays_faster(self, plan, stream, reps=4, trials=3):
+        """time `reps` back-to-back replays of the plan as a hipGraph and as eager launches (host enqueue included: that is what a
+        caller's loop pays), `trials` times in turn, and say whether the best eager time beats the best graph time by more than 2 %.
+        One-time cost per plan: 2 x trials x (reps + 1) forwards."""
+        import time
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(self.device)
+            return time.perf_counter() - t0
+        tg = te = float("inf")
+        for _ in range(trials):
+            tg = min(tg, timed(lambda: rt.check(self.lib.gcpx_graph_launch(plan.graph, stream), "graph_launch")))
+            te = min(te, timed(lambda: plan.run(self._streams)))
+        return te < 0.98 * tg
 
     def _capture(self, plan, ops, stream):
         rt.check(self.lib.gcpx_graph_begin(stream), "graph_begin")
@@ -1645,13 +1674,27 @@ class GCPTreeModel:
     def _run_timed(self, plan, stream):
         names = [op[0] for op in plan.ops]
         i = names.index(self._timed_op)
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        rt.check(self.lib.gcpx_event_create(C.byref(e0)), "event_create")
+        rt.check(self.lib.gcpx_event_create(C.byref(e1)), "event_create")
+        if self.use_graph == "auto" and plan.graph is None:
+            plan.run(self._streams)
+            plan.graph = self._capture(plan, plan.ops, stream)
+            plan.eager = self._eager_replays_faster(plan, stream)
+        if plan.eager or not self.use_graph:
+            # the plan as it is replayed (eager launches over the lanes), with an event on the main lane in front of and behind the op
+            if getattr(plan, "timed_ops", None) is None or plan.timed_ops[0] != self._timed_op:
+                assert plan.ops[i][3] == 0, "the timed op must be on the main lane"
+                plan.timed_ops = (self._timed_op, plan.ops[:i] + [("@mark", None, ("timed", 0), 0), plan.ops[i], ("@mark", None, ("timed", 1), 0)] +
+                                  plan.ops[i + 1:])
+            plan.run(self._streams, ops=plan.timed_ops[1],
+                     on_mark=lambda tag, k: rt.check(self.lib.gcpx_event_record(e1 if k else e0, stream), "event_record") if tag == "timed" else None)
+            self._timed_events.append((e0, e1))
+            return
         if getattr(plan, "split", None) is None:
             plan.run(self._streams)
             assert plan.ops[i][3] == 0, "the timed op must be on the main lane"
             plan.split = (self._capture(plan, plan.ops[:i], stream), self._capture(plan, plan.ops[i + 1:], stream))
-        e0, e1 = C.c_void_p(), C.c_void_p()
-        rt.check(self.lib.gcpx_event_create(C.byref(e0)), "event_create")
-        rt.check(self.lib.gcpx_event_create(C.byref(e1)), "event_create")
         rt.check(self.lib.gcpx_graph_launch(plan.split[0], stream), "graph_launch")
         rt.check(self.lib.gcpx_event_record(e0, stream), "event_record")
         name, fn, args, _ = plan.ops[i]
