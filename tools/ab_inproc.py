@@ -39,7 +39,8 @@ for val in (va, vb, vb, va):
         m(d, "train")
     models.append((m, d))
 torch.cuda.synchronize()
-print("plans replayed eagerly:", [[p.eager for _, p in m._plans.values()] for m, _ in models], " use_graph:", [m.use_graph for m, _ in models])
+print("plans replayed eagerly:", [[p.eager for _, p in m._plans.values()] for m, _ in models], " use_graph:", [m.use_graph for m, _ in models],
+      " tuned (graph, eager) ms:", [[tuple(round(1e3 * t, 3) for t in getattr(p, "tuned", (0, 0))) for _, p in m._plans.values()] for m, _ in models])
 res = [[], [], [], []]
 vals4 = (va, vb, vb, va)
 for r in range(rounds):
