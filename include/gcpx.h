@@ -715,6 +715,8 @@ int gcpx_loss_aux_heads_bwd(const gcpx_loss_args* a, float* daction, float* dcos
 /* dst[i] = theta[idx0[i]] (+ theta[idx1[i]]), negative index = 0: every fragment-packed weight arena is a gather of the
    canonical flat parameter vector (video-gcp_amd/packing.py), refreshed once per optimizer step */
 int gcpx_repack(const float* theta, const int32_t* idx0, const int32_t* idx1, float* dst, int64_t n, void* stream);
+/* the same, held to max_blocks 256-thread workgroups (0 = no limit): see gcpx_optim_range */
+int gcpx_repack_blocks(const float* theta, const int32_t* idx0, const int32_t* idx1, float* dst, int64_t n, int32_t max_blocks, void* stream);
 /* split-f16 weights from the flat parameter vector (one launch per tensor, after gcpx_repack): v[i] = theta[idx[i]] (negative = 0),
    e = 14 - floor(log2 max|v|) (0 when all zero), *log2_out = e, and the two f16 pieces of v[i] 2^e in the layout the split kernels
    read: out[((i / 512) * 2 + p) * 512 + i % 512], p = 0 (rn16(v 2^e)) and 1 (rn16 of the remainder); n % 512 == 0.  Same pieces as
@@ -729,6 +731,9 @@ typedef struct gcpx_split_pack_desc {
     int32_t n, _pad;
 } gcpx_split_pack_desc;
 int gcpx_split_pack_group(const gcpx_split_pack_desc* tab, int32_t nprob, void* stream);
+/* The same result, bit for bit, from two launches with 32 workgroups per tensor (largest magnitudes first, then the pieces): the form
+   the trainer runs behind every optimizer step.  scratch: DEVICE [nprob] uint32, overwritten */
+int gcpx_split_pack_group2(const gcpx_split_pack_desc* tab, int32_t nprob, uint32_t* scratch, void* stream);
 /* Row-folded weights of an upsampling decoder block (bilinear x2, align_corners=False, then 3x3 conv, pad 1 — DecoderModule's
    pyramid / additional_conv_layer blocks, blox; called through gcp/prediction/models/tree/tree_dense_rec.py:42).  Output row
    2 y + py of the block reads the three low-resolution rows y - 1, y, y + 1 (clamped) of the horizontally interpolated input with
@@ -749,6 +754,15 @@ int gcpx_radam_step(float* theta, const float* grad, float* exp_avg, float* exp_
    gcpx_grad_clip_coef; gcpx_radam_step applies it too). */
 int gcpx_optim_step(float* theta, const float* grad, float* m, float* v, float* state, int64_t n, int32_t kind, float lr, float p1,
                     float p2, float eps, float grad_scale, void* stream);
+/* One slice of an optimizer step: kind 0 = RAdam (p1, p2 = betas), 1 .. 3 as gcpx_optim_step, over n elements of the four vectors;
+   state[0] is incremented only when tick != 0.  A trainer whose gradient becomes final slice by slice (the tree levels of the backward
+   pass, leaves first) applies each slice while the rest is still being differentiated and ticks with the last one: every slice of a
+   step must read the same counter, so all tick == 0 calls of a step are ordered before its tick != 0 call.  The same arithmetic per
+   element as gcpx_radam_step / gcpx_optim_step (a step cut into slices gives the same bits as one call).  max_blocks > 0 holds the
+   launch to that many 256-thread workgroups: a slice applied beside the backward's critical chain must leave it the chip (a full
+   grid's wavefronts fill every CU and stretched the chain's 40 us GEMMs to 100 us). */
+int gcpx_optim_range(float* theta, const float* grad, float* m, float* v, float* state, int64_t n, int32_t kind, float lr, float p1,
+                     float p2, float eps, float grad_scale, int32_t tick, int32_t max_blocks, void* stream);
 /* gradient_clip (gcp_builder.py:186 -> blox get_clipped_optimizer; spec here: torch.nn.utils.clip_grad_norm_ over all parameters):
    state[2] = || grad_scale * grad ||_2, state[1] = min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0).  partial: [n_partial]
    scratch (deterministic two-stage sum). */

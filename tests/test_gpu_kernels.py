@@ -1543,6 +1543,22 @@ def test_split_pack_group_equals_single_launches(env):
     assert torch.equal(ea, eb)
     for a_, b_ in zip(outs_a, outs_b):
         assert torch.equal(a_, b_)
+    # ... and so does the two-launch form with 32 workgroups per tensor (the one the trainer runs behind every optimizer step); twice,
+    # the second time over different parameters: its scratch must not carry the first call's maxima over
+    for rep in range(2):
+        if rep:
+            theta.mul_(0.25)
+            for k, i in enumerate(idxs):
+                rt.check(lib.gcpx_split_pack(theta.data_ptr(), i.data_ptr(), i.numel(), outs_a[k].data_ptr(), ea.data_ptr() + 4 * k, _stream()), "split_pack")
+        for o in outs_b:
+            o.fill_(-3)
+        eb.fill_(97)
+        scratch = torch.full((len(descs),), 0x7f7fffff, dtype=torch.int32, device=dev)
+        rt.check(lib.gcpx_split_pack_group2(tab.data_ptr(), len(descs), scratch.data_ptr(), _stream()), "split_pack_group2")
+        torch.cuda.synchronize()
+        assert torch.equal(ea, eb), rep
+        for a_, b_ in zip(outs_a, outs_b):
+            assert torch.equal(a_, b_), rep
 
 
 # ---- the split-f16 bound, stated as it is (norm-wise per scaled unit) and probed where it is weakest -------------------------------

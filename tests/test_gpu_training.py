@@ -134,6 +134,62 @@ def test_radam_kernel_matches_oracle():
     assert float(st[0]) == 8.0
 
 
+def test_optimizer_slices_equal_one_call():
+    """gcpx_optim_range over the slices of a step (tick with the last) leaves the bits of one gcpx_radam_step / gcpx_optim_step call"""
+    from video_gcp_amd import runtime as rt
+    lib = rt.load_library()
+    g = torch.Generator().manual_seed(3)
+    n, cuts = 20011, [0, 4096, 4101, 12000, 20011]        # (4101: a slice the 16-byte path cannot take)
+    st_ = torch.cuda.current_stream().cuda_stream
+    for kind, p1, p2 in [(0, 0.9, 0.999), (1, 0.9, 0.999), (2, 0.9, 0.99), (3, 0.9, 0.0)]:
+        a = [torch.randn(n, generator=g).cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda(), torch.zeros(4).cuda()]
+        b = [t.clone() for t in a]
+        for step in range(7):
+            gd = (torch.randn(n, generator=g) * 0.1).cuda()
+            if kind == 0:
+                rt.check(lib.gcpx_radam_step(a[0].data_ptr(), gd.data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), n, 1e-2, p1, p2,
+                                             1e-8, 0.5, st_), "radam")
+            else:
+                rt.check(lib.gcpx_optim_step(a[0].data_ptr(), gd.data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), n, kind, 1e-2, p1,
+                                             p2, 1e-8, 0.5, st_), "optim")
+            order = list(zip(cuts[:-1], cuts[1:]))
+            order = order[::-1] if step % 2 else order
+            for j, (lo, hi) in enumerate(order):
+                rt.check(lib.gcpx_optim_range(b[0].data_ptr() + 4 * lo, gd.data_ptr() + 4 * lo, b[1].data_ptr() + 4 * lo, b[2].data_ptr() + 4 * lo,
+                                              b[3].data_ptr(), hi - lo, kind, 1e-2, p1, p2, 1e-8, 0.5, int(j == len(order) - 1), (0, 3, 64)[j % 3], st_), "range")
+            torch.cuda.synchronize()
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), (kind, step)
+        assert float(b[3][0]) == 7.0
+
+
+@pytest.mark.parametrize("name", ["c1", "c5s"])
+def test_step_with_slices_applied_during_the_backward_equals_the_late_step(name):
+    """step() updates a tree level's slice of the parameters (and re-packs its weights) on the caller's stream as soon as the backward
+    marks it final; with GCPX_NO_EARLY_OPTIMIZER (early_optimizer = False) everything happens behind the backward.  Same bits in the
+    parameters, both moment vectors, the counter and every packed weight after three steps — an update that ran before a late reader
+    of its weights, or a pack left stale, shows up here."""
+    hp, sd, ma, ta = _setup(name, True)
+    _, _, mb, tb = _setup(name, True)
+    tb.early_optimizer = False
+    assert len(ta._ranges) == hp.hierarchy_levels
+    for step in range(3):
+        inputs, noise, _ = make_inputs(hp, seed=30 + step, variant="B")
+        dev_in = {k: v.cuda() for k, v in inputs.items()}
+        oa = ta.step(dev_in, noise.cuda())
+        if step == 0:
+            assert ta._applied == set() and ta._early_on is False         # consumed by the optimizer step
+        ob = tb.step(dev_in, noise.cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(oa.raw["losses"], ob.raw["losses"]), step
+        for x, y, what in [(ma.theta, mb.theta, "theta"), (ta.exp_avg, tb.exp_avg, "exp_avg"), (ta.exp_avg_sq, tb.exp_avg_sq, "exp_avg_sq"),
+                           (ta.opt_state, tb.opt_state, "state"), (ma._arena, mb._arena, "packed weights")]:
+            assert torch.equal(x, y), (step, what)
+        for k in ma.pk_split:
+            assert torch.equal(ma.pk_split[k]["out"], mb.pk_split[k]["out"]), (step, k)
+    assert float(ta.opt_state[0]) == 3.0
+
+
 def test_two_training_steps_c1():
     """losses of two consecutive optimisation steps and the updated parameters against the oracle loop"""
     from oracle import gcp_model_oracle as O

@@ -3,10 +3,10 @@ import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'radam_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'radam_tick_kernel' in r['Kernel_Name']]      # one per optimizer step (its last launch but the re-pack)
 seg = rows[idx[-2]:idx[-1] + 1]
 t0 = int(seg[0]['Start_Timestamp'])
-print("step wall (radam to radam): %.2f ms; kernels: %d" % ((int(seg[-1]['End_Timestamp']) - t0) / 1e6, len(seg)))
+print("step wall (tick to tick): %.2f ms; kernels: %d" % ((int(seg[-1]['End_Timestamp']) - t0) / 1e6, len(seg)))
 q = collections.defaultdict(int)
 k = collections.defaultdict(lambda: [0, 0])
 for r in seg:

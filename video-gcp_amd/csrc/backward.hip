@@ -4,6 +4,7 @@
 // transposed packs for data gradients, gcpx_wgrad for weight gradients).  All reductions are deterministic
 // (per-workgroup partial sums combined in a fixed order; no atomics).
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -901,8 +902,21 @@ __global__ void __launch_bounds__(256) loss_aux_heads_bwd_kernel(const gcpx_loss
 // four consecutive destination elements per thread (arena leaves are padded to multiples of 4): 16-byte index loads and stores
 __global__ void __launch_bounds__(256) repack_kernel(const float* __restrict__ theta, const int* __restrict__ idx0,
                                                      const int* __restrict__ idx1, float* __restrict__ dst, const long long n) {
-    const long long n4 = n >> 2;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long n4 = n >> 2, stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (!idx1) {
+        // (two index -> value chains in flight: a launch held to a few workgroups — gcpx_repack_blocks — is bound by their latency)
+        for (; i + stride < n4; i += 2 * stride) {
+            const int4 a = reinterpret_cast<const int4*>(idx0)[i], b = reinterpret_cast<const int4*>(idx0)[i + stride];
+            const float4 va = make_float4(a.x >= 0 ? theta[a.x] : 0.f, a.y >= 0 ? theta[a.y] : 0.f, a.z >= 0 ? theta[a.z] : 0.f,
+                                          a.w >= 0 ? theta[a.w] : 0.f);
+            const float4 vb = make_float4(b.x >= 0 ? theta[b.x] : 0.f, b.y >= 0 ? theta[b.y] : 0.f, b.z >= 0 ? theta[b.z] : 0.f,
+                                          b.w >= 0 ? theta[b.w] : 0.f);
+            reinterpret_cast<float4*>(dst)[i] = va;
+            reinterpret_cast<float4*>(dst)[i + stride] = vb;
+        }
+    }
+    for (; i < n4; i += stride) {
         const int4 a = reinterpret_cast<const int4*>(idx0)[i];
         float4 v = make_float4(a.x >= 0 ? theta[a.x] : 0.f, a.y >= 0 ? theta[a.y] : 0.f, a.z >= 0 ? theta[a.z] : 0.f,
                                a.w >= 0 ? theta[a.w] : 0.f);
@@ -923,27 +937,70 @@ __global__ void __launch_bounds__(256) repack_kernel(const float* __restrict__ t
     }
 }
 
-__global__ void __launch_bounds__(256) radam_kernel(float* __restrict__ theta, const float* __restrict__ grad,
-                                                    float* __restrict__ m, float* __restrict__ v, const float* __restrict__ state,
-                                                    const long long n, const float lr, const float beta1, const float beta2,
-                                                    const float eps, const float grad_scale) {
+struct RadamCoef { float step, gsc; bool rect; };
+__device__ __forceinline__ RadamCoef radam_coef(const float* __restrict__ state, const float beta1, const float beta2, const float grad_scale) {
     const float t = state[0] + 1.f;
     const float b2t = powf(beta2, t), b1t = powf(beta1, t);
     const float sma_max = 2.f / (1.f - beta2) - 1.f;
     const float sma = sma_max - 2.f * t * b2t / (1.f - b2t);
-    const bool rect = sma >= 5.f;
-    float step;
-    if (rect) step = sqrtf((1.f - b2t) * (sma - 4.f) / (sma_max - 4.f) * (sma - 2.f) / sma * sma_max / (sma_max - 2.f)) / (1.f - b1t);
-    else step = 1.f / (1.f - b1t);
-    const float gsc = grad_scale * (state[1] > 0.f ? state[1] : 1.f);     // state[1]: this step's clipping coefficient (gcpx_grad_clip_coef), 0 = unset
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float g = grad[i] * gsc;
-        const float mi = beta1 * m[i] + (1.f - beta1) * g;
-        const float vi = beta2 * v[i] + (1.f - beta2) * g * g;
-        m[i] = mi;
-        v[i] = vi;
-        theta[i] -= rect ? lr * step * mi / (sqrtf(vi) + eps) : lr * step * mi;
+    RadamCoef c;
+    c.rect = sma >= 5.f;
+    if (c.rect) c.step = sqrtf((1.f - b2t) * (sma - 4.f) / (sma_max - 4.f) * (sma - 2.f) / sma * sma_max / (sma_max - 2.f)) / (1.f - b1t);
+    else c.step = 1.f / (1.f - b1t);
+    c.gsc = grad_scale * (state[1] > 0.f ? state[1] : 1.f);     // state[1]: this step's clipping coefficient (gcpx_grad_clip_coef), 0 = unset
+    return c;
+}
+__device__ __forceinline__ void radam_one(float& th, const float gr, float& m, float& v, const RadamCoef& c, const float lr, const float beta1,
+                                          const float beta2, const float eps) {
+    // (no contraction: the 16-byte and the scalar loop must round alike — the compiler fused different products in the two)
+#pragma clang fp contract(off)
+    const float g = gr * c.gsc;
+    const float mi = beta1 * m + (1.f - beta1) * g;
+    const float vi = beta2 * v + (1.f - beta2) * g * g;
+    m = mi;
+    v = vi;
+    th -= c.rect ? lr * c.step * mi / (sqrtf(vi) + eps) : lr * c.step * mi;
+}
+
+// VEC: the four vectors are 16-byte aligned — four elements per thread and access, two accesses in flight (a launch held to a few
+// workgroups, gcpx_optim_range's max_blocks, still pulls ~10 GB/s per wavefront); the remainder and unaligned slices take the scalar loop.
+// The arithmetic per element is the same function either way: a step cut into slices leaves the bits of one call.
+template <bool VEC>
+__global__ void __launch_bounds__(256) radam_kernel(float* __restrict__ theta, const float* __restrict__ grad,
+                                                    float* __restrict__ m, float* __restrict__ v, const float* __restrict__ state,
+                                                    const long long n, const float lr, const float beta1, const float beta2,
+                                                    const float eps, const float grad_scale) {
+    const RadamCoef c = radam_coef(state, beta1, beta2, grad_scale);
+    const long long stride = (long long)gridDim.x * 256, first = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long done = 0;
+    if (VEC) {
+        const long long n4 = n >> 2;
+        float4* __restrict__ t4 = reinterpret_cast<float4*>(theta);
+        const float4* __restrict__ g4 = reinterpret_cast<const float4*>(grad);
+        float4* __restrict__ m4 = reinterpret_cast<float4*>(m);
+        float4* __restrict__ v4 = reinterpret_cast<float4*>(v);
+        for (long long i = first; i < n4; i += 2 * stride) {
+            const long long j = i + stride;
+            const bool two = j < n4;
+            float4 ta = t4[i], ga = g4[i], ma = m4[i], va = v4[i];
+            float4 tb = ta, gb = ga, mb = ma, vb = va;
+            if (two) { tb = t4[j]; gb = g4[j]; mb = m4[j]; vb = v4[j]; }
+            radam_one(ta.x, ga.x, ma.x, va.x, c, lr, beta1, beta2, eps);
+            radam_one(ta.y, ga.y, ma.y, va.y, c, lr, beta1, beta2, eps);
+            radam_one(ta.z, ga.z, ma.z, va.z, c, lr, beta1, beta2, eps);
+            radam_one(ta.w, ga.w, ma.w, va.w, c, lr, beta1, beta2, eps);
+            t4[i] = ta; m4[i] = ma; v4[i] = va;
+            if (two) {
+                radam_one(tb.x, gb.x, mb.x, vb.x, c, lr, beta1, beta2, eps);
+                radam_one(tb.y, gb.y, mb.y, vb.y, c, lr, beta1, beta2, eps);
+                radam_one(tb.z, gb.z, mb.z, vb.z, c, lr, beta1, beta2, eps);
+                radam_one(tb.w, gb.w, mb.w, vb.w, c, lr, beta1, beta2, eps);
+                t4[j] = tb; m4[j] = mb; v4[j] = vb;
+            }
+        }
+        done = n4 << 2;
     }
+    for (long long i = done + first; i < n; i += stride) radam_one(theta[i], grad[i], m[i], v[i], c, lr, beta1, beta2, eps);
 }
 
 __global__ void radam_tick_kernel(float* state) { state[0] += 1.f; }
@@ -1294,13 +1351,20 @@ extern "C" int gcpx_loss_aux_heads_bwd(const gcpx_loss_args* a, float* daction, 
     return GCPX_OK;
 }
 
-extern "C" int gcpx_repack(const float* theta, const int32_t* idx0, const int32_t* idx1, float* dst, int64_t n, void* stream_) {
+extern "C" int gcpx_repack_blocks(const float* theta, const int32_t* idx0, const int32_t* idx1, float* dst, int64_t n, int32_t max_blocks,
+                                  void* stream_) {
     STREAM();
-    GCPX_CHECK_ARG(theta && idx0 && dst && n > 0, "bad arguments");
+    GCPX_CHECK_ARG(theta && idx0 && dst && n > 0 && max_blocks >= 0, "bad arguments");
     GCPX_CHECK_ARG((((uintptr_t)idx0 | (uintptr_t)idx1 | (uintptr_t)dst) & 15) == 0, "idx0 / idx1 / dst must be 16-byte aligned");
-    hipLaunchKernelGGL(repack_kernel, dim3(blocks_for((n + 3) / 4, 16384)), dim3(256), 0, stream, theta, idx0, idx1, dst, (long long)n);
+    int nb = blocks_for((n + 3) / 4, 16384);
+    if (max_blocks > 0) nb = std::min(nb, max_blocks);
+    hipLaunchKernelGGL(repack_kernel, dim3(nb), dim3(256), 0, stream, theta, idx0, idx1, dst, (long long)n);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
+}
+
+extern "C" int gcpx_repack(const float* theta, const int32_t* idx0, const int32_t* idx1, float* dst, int64_t n, void* stream_) {
+    return gcpx_repack_blocks(theta, idx0, idx1, dst, n, 0, stream_);
 }
 
 extern "C" int gcpx_grad_clip_coef(const float* grad, int64_t n, float grad_scale, float max_norm, float* partial, int32_t n_partial,
@@ -1324,12 +1388,39 @@ extern "C" int gcpx_optim_step(float* theta, const float* grad, float* m, float*
     return GCPX_OK;
 }
 
+namespace {
+void launch_radam(float* theta, const float* grad, float* m, float* v, float* state, int64_t n, float lr, float b1, float b2, float eps,
+                  float grad_scale, int max_blocks, hipStream_t stream) {
+    const bool vec = ((((uintptr_t)theta | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && n >= 4;
+    int nb = blocks_for(vec ? (n + 7) / 8 : n, 16384);
+    if (max_blocks > 0) nb = std::min(nb, max_blocks);
+    if (vec)
+        hipLaunchKernelGGL(radam_kernel<true>, dim3(nb), dim3(256), 0, stream, theta, grad, m, v, state, (long long)n, lr, b1, b2, eps, grad_scale);
+    else
+        hipLaunchKernelGGL(radam_kernel<false>, dim3(nb), dim3(256), 0, stream, theta, grad, m, v, state, (long long)n, lr, b1, b2, eps, grad_scale);
+}
+}  // namespace
+
+extern "C" int gcpx_optim_range(float* theta, const float* grad, float* m, float* v, float* state, int64_t n, int32_t kind, float lr,
+                                float p1, float p2, float eps, float grad_scale, int32_t tick, int32_t max_blocks, void* stream_) {
+    STREAM();
+    GCPX_CHECK_ARG(theta && grad && m && v && state && n > 0 && kind >= 0 && kind <= 3, "bad arguments");
+    GCPX_CHECK_ARG(max_blocks >= 0, "max_blocks: 0 (no limit) or a positive number of workgroups");
+    if (kind == 0)
+        launch_radam(theta, grad, m, v, state, n, lr, p1, p2, eps, grad_scale, max_blocks, stream);
+    else
+        hipLaunchKernelGGL(optim_kernel, dim3(max_blocks > 0 ? std::min(max_blocks, blocks_for(n, 16384)) : blocks_for(n, 16384)), dim3(256), 0,
+                           stream, theta, grad, m, v, state, (long long)n, kind, lr, p1, p2, eps, grad_scale);
+    if (tick) hipLaunchKernelGGL(radam_tick_kernel, dim3(1), dim3(1), 0, stream, state);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
 extern "C" int gcpx_radam_step(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, float* state, int64_t n, float lr,
                                float beta1, float beta2, float eps, float grad_scale, void* stream_) {
     STREAM();
     GCPX_CHECK_ARG(theta && grad && exp_avg && exp_avg_sq && state && n > 0, "bad arguments");
-    hipLaunchKernelGGL(radam_kernel, dim3(blocks_for(n, 16384)), dim3(256), 0, stream, theta, grad, exp_avg, exp_avg_sq, state,
-                       (long long)n, lr, beta1, beta2, eps, grad_scale);
+    launch_radam(theta, grad, exp_avg, exp_avg_sq, state, n, lr, beta1, beta2, eps, grad_scale, 0, stream);
     hipLaunchKernelGGL(radam_tick_kernel, dim3(1), dim3(1), 0, stream, state);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;

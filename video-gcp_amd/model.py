@@ -403,12 +403,12 @@ class GCPTreeModel:
                 descs.append(e)
             arr = (rt.SplitPackDesc * len(descs))(*descs)
             dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-            tab = self._split_tab = (dev, len(descs), key)
+            tab = self._split_tab = (dev, len(descs), key, torch.zeros(len(descs), dtype=torch.int32, device=self.device))
         for name, d in self.pk_split.items():
             if "fold" in d:
                 off, cout, cin = d["fold_src"]
                 rt.check(self.lib.gcpx_fold_upsample_weights(self.theta.data_ptr() + 4 * off, cout, cin, d["fold"].data_ptr(), st), "fold_upsample_weights")
-        rt.check(self.lib.gcpx_split_pack_group(tab[0].data_ptr(), tab[1], st), "split_pack_group")
+        rt.check(self.lib.gcpx_split_pack_group2(tab[0].data_ptr(), tab[1], tab[3].data_ptr(), st), "split_pack_group2")
 
     def _pack_gemm_split(self):
         """Inference only (like the fused embedding: a re-split of every GEMM weight after each optimizer step is not worth its
@@ -548,21 +548,48 @@ class GCPTreeModel:
         walk(X0, X1, ("X",))
         # leaves that sum two parameters (the fused LSTM biases b_ih + b_hh) go last: the bulk of the arena is then re-packed without
         # reading a second index array
-        leaves.sort(key=lambda lf: bool((lf[3] > 0).any()))
-        total = sum((t.numel() + 3) // 4 * 4 for _, _, t, _ in leaves)
+        # ... and inside both halves the leaves are grouped by the slice of the flat vector they gather from (dist.gradient_bucket_ranges:
+        # one per untied tree level, "rest" for everything else and for leaves that stack several levels): a trainer that applies the
+        # optimizer slice by slice during the backward pass re-packs each slice's leaves as ONE contiguous run per half (repack(bucket=))
+        from .dist import gradient_bucket_ranges
+        ranges = gradient_bucket_ranges(self._poff, self._hp.hierarchy_levels, self._hp.untied_layers)
+        rest = len(ranges) - 1
+        def bucket_of(t0, t1):
+            ids = torch.cat([t0.reshape(-1), t1.reshape(-1)])
+            ids = ids[ids > 0] - 1
+            if ids.numel() == 0:
+                return rest
+            lo, hi = int(ids.min()), int(ids.max())
+            for i, (_, a, b) in enumerate(ranges):
+                if a <= lo and hi < b:
+                    return i
+            return rest
+        leaves = [lf + (bucket_of(lf[2], lf[3]),) for lf in leaves]
+        leaves.sort(key=lambda lf: (bool((lf[3] > 0).any()), lf[4]))
+        leaves = [lf[:4] + (lf[4],) for lf in leaves]
+        total = sum((lf[2].numel() + 3) // 4 * 4 for lf in leaves)
         self._arena = torch.zeros(total, dtype=torch.float32, device=dev)
         idx0 = torch.full((total,), -1, dtype=torch.int32, device=dev)
         idx1 = torch.full((total,), -1, dtype=torch.int32, device=dev)
         off = 0
         self._arena_split = None
-        for path, holder, t0, t1 in leaves:
+        runs = {}                                  # (bucket, two-index half?) -> [first element, one past the last]
+        for path, holder, t0, t1, bkt in leaves:
             n = t0.numel()
-            if self._arena_split is None and bool((t1 > 0).any()):
+            two = bool((t1 > 0).any())
+            if self._arena_split is None and two:
                 self._arena_split = off
             idx0[off:off + n] = (t0.reshape(-1) - 1).to(torch.int32)
             idx1[off:off + n] = (t1.reshape(-1) - 1).to(torch.int32)
             holder[path[-1]] = self._arena[off:off + n].view(t0.shape)
+            r = runs.setdefault((bkt, two), [off, off])
+            assert r[1] == off, "leaves of one slice are contiguous inside a half"
             off += (n + 3) // 4 * 4
+            r[1] = off
+        self._arena_runs = {ranges[b][0]: [] for b in range(len(ranges))}
+        for (bkt, two), (a, b) in sorted(runs.items()):
+            self._arena_runs[ranges[bkt][0]].append((a, b - a, two))
+        self._arena_ranges = ranges
         self._arena_idx0, self._arena_idx1 = idx0, idx1
         self._psd = self.sd
         self.pk = P0
@@ -570,8 +597,19 @@ class GCPTreeModel:
         self.repack()
         return X0
 
-    def repack(self, stream=None):
+    def repack(self, stream=None, bucket=None, max_blocks=0):
+        """bucket = None: every packed weight.  bucket = a name of dist.gradient_bucket_ranges: only the leaves that gather from that
+        slice of the flat vector ("rest" also re-splits the split-f16 tensors, which all gather from it), in launches of at most
+        max_blocks workgroups (0: no limit)."""
         st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        if bucket is not None:
+            for off, cnt, two in self._arena_runs[bucket]:
+                rt.check(self.lib.gcpx_repack_blocks(self.theta.data_ptr(), self._arena_idx0.data_ptr() + 4 * off,
+                                                     (self._arena_idx1.data_ptr() + 4 * off) if two else None, self._arena.data_ptr() + 4 * off,
+                                                     cnt, max_blocks, st), "repack")
+            if bucket == self._arena_ranges[-1][0]:
+                self.repack_split(st)
+            return
         n, sp = self._arena.numel(), self._arena_split
         sp = n if sp is None else sp
         if sp > 0:

@@ -157,6 +157,7 @@ SYMBOLS = [
     ("gcpx_wgrad_conv3x3_split_src", C.c_int, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
     ("gcpx_wgrad_image4x4s2", C.c_int, [vp, vp, vp, vp, i32, i32, vp, i32, vp]),
     ("gcpx_split_pack_group", C.c_int, [vp, i32, vp]),
+    ("gcpx_split_pack_group2", C.c_int, [vp, i32, vp, vp]),
     ("gcpx_wgrad_reduce", C.c_int, [vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, i64, i32, i32, vp]),
     ("gcpx_colsum", C.c_int, [vp, i64, i32, i32, i32, i64, i32, vp, vp, vp, i32, vp]),
     ("gcpx_reduce_partials", C.c_int, [vp, i32, i64, i32, vp, i32, vp]),
@@ -206,6 +207,8 @@ SYMBOLS = [
     ("gcpx_fold_upsample_weights", C.c_int, [vp, i32, i32, vp, vp]),
     ("gcpx_optim_step", C.c_int, [vp, vp, vp, vp, vp, i64, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     ("gcpx_grad_clip_coef", C.c_int, [vp, i64, C.c_float, C.c_float, vp, i32, vp, vp]),
+    ("gcpx_optim_range", C.c_int, [vp, vp, vp, vp, vp, i64, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, i32, vp]),
+    ("gcpx_repack_blocks", C.c_int, [vp, vp, vp, vp, i64, i32, vp]),
     ("gcpx_radam_step", C.c_int, [vp, vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     ("gcpx_attention", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     ("gcpx_cdist_splits", C.c_int, [i64]),

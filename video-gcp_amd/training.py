@@ -35,6 +35,7 @@ class GCPTrainStep:
     after the gradients (tests)."""
 
     OPTIMIZERS = {"radam": 0, "adam": 1, "rmsprop": 2, "sgd": 3}
+    _early_on, _caller = False, None          # (see __init__: early_optimizer)
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, optimizer="radam", momentum=0.0,
                  gradient_clip=None):
@@ -58,8 +59,20 @@ class GCPTrainStep:
         self.opt_state = torch.zeros(4, device=model.device)
         from .dist import GradBuckets, gradient_bucket_ranges
         ranges = gradient_bucket_ranges(model._poff, hp.hierarchy_levels, hp.untied_layers)
-        self._bucket_index = {name: i for i, (name, _, _) in enumerate(ranges)} if process_group is not None else {}
+        self._ranges = ranges
+        self._bucket_index = {name: i for i, (name, _, _) in enumerate(ranges)}
         self.buckets = GradBuckets(self.grad, ranges, process_group) if process_group is not None else None
+        # step(): the optimizer update of a tree level's slice (+ the re-pack of its weights) is issued on the CALLER's stream — idle
+        # while the backward plan runs on the model's lanes — as soon as the backward reports the slice final (and, data-parallel, its
+        # all-reduce is done): 6 of the 7 levels' 10.3 M parameters each (c2) are updated under the remaining levels and the encoder
+        # backward, instead of 2.9 GB of optimizer + re-pack traffic behind the last gradient.  Not with gradient_clip (the global norm
+        # needs every slice) and not with a graph-captured backward (no host callbacks).  backward() alone never touches parameters.
+        # Those launches are held to `early_blocks` workgroups: a full grid of the optimizer kernel fills every CU with wavefronts and
+        # stretched the tree chain's GEMMs beside it from 41 to 101 us (profiles/r04n_train_timeline.txt), which took back 0.4 of the
+        # 0.58 ms the early slices save.
+        self.early_optimizer = os.environ.get("GCPX_NO_EARLY_OPTIMIZER") is None
+        self.early_blocks = int(os.environ.get("GCPX_EARLY_BLOCKS", "128"))
+        self._early_on, self._applied, self._caller = False, set(), None
         self.bk = model.build_arena(self._pack_backward)
         self._pack_backward_split()
         self._bplans = {}
@@ -1248,6 +1261,8 @@ class GCPTrainStep:
             self._bplans[key] = self._build_backward(m._plans[key][1])
         bplan = self._bplans[key]
         caller = torch.cuda.current_stream(m.device)
+        self._caller = caller
+        self._applied = set()
         m._stream.wait_stream(caller)
         stream = m._stream.cuda_stream
         if m.use_graph and self.backward_graph:
@@ -1262,11 +1277,40 @@ class GCPTrainStep:
         return out
 
     def _on_mark(self, tag, payload):
-        if tag == "bucket" and self.buckets is not None:
-            if self._lane_streams is None:
-                self._lane_streams = [torch.cuda.ExternalStream(int(s.value if hasattr(s, "value") else s), device=self.m.device)
-                                      for s in self._backward_streams()]
+        if tag != "bucket" or (self.buckets is None and not self._early_on):
+            return
+        if self._lane_streams is None:
+            self._lane_streams = [torch.cuda.ExternalStream(int(s.value if hasattr(s, "value") else s), device=self.m.device)
+                                  for s in self._backward_streams()]
+        if self.buckets is not None:
             self.buckets.reduce_async(payload, after_streams=self._lane_streams)
+        if self._early_on:
+            self._apply_slice(payload, tick=False, after_streams=self._lane_streams, max_blocks=self.early_blocks)
+            self._applied.add(payload)
+
+    def _apply_slice(self, i, tick, after_streams=(), max_blocks=0):
+        """optimizer update of slice i of the flat vectors + re-pack of the weights that gather from it, on the caller's stream (which
+        first waits for `after_streams`, the lanes that produce the slice's gradient, and for the slice's all-reduce)"""
+        m = self.m
+        name, lo, hi = self._ranges[i]
+        caller = self._caller
+        for s in after_streams:
+            caller.wait_stream(s)
+        scale = 1.0
+        if self.buckets is not None and torch.distributed.is_initialized():
+            w = self.buckets.works.get(i)
+            if w is not None:
+                with torch.cuda.stream(caller):
+                    w.wait()                                   # the caller's stream waits for the collective (no host block)
+            scale = 1.0 / torch.distributed.get_world_size(self.buckets.group)
+        kind = self.OPTIMIZERS[self.optimizer]
+        p1, p2 = (self.betas[0], self.betas[1]) if kind <= 1 else ((self.momentum, 0.99) if kind == 2 else (self.momentum, 0.0))
+        st = caller.cuda_stream
+        o = 4 * lo
+        rt.check(m.lib.gcpx_optim_range(m.theta.data_ptr() + o, self.grad.data_ptr() + o, self.exp_avg.data_ptr() + o,
+                                        self.exp_avg_sq.data_ptr() + o, self.opt_state.data_ptr(), hi - lo, kind, self.lr, p1, p2, self.eps,
+                                        scale, 1 if tick else 0, max_blocks, st), "optim_range")
+        m.repack(st, bucket=name, max_blocks=max_blocks)
 
     def _backward_streams(self):
         """lane 0 = the model's stream, side lanes = the model's own side streams: the process then uses four streams in all
@@ -1291,6 +1335,17 @@ class GCPTrainStep:
         if self.buckets is not None:
             # the tree-level buckets were started during the backward; the last one (conv stacks, heads, level 0) goes now
             scale = self.buckets.finish()
+        applied, self._applied = self._applied, set()
+        if applied:
+            # step(): those slices were updated during the backward; the others (at least "rest") follow here, the last one ticks
+            assert self._caller is not None and self._caller.cuda_stream == st, "step() runs on one stream"
+            if getattr(self, "_clip_state_dirty", True):
+                self.opt_state[1:2].zero_()      # (ordered behind the early slices: they already read it — see step())
+                self._clip_state_dirty = False
+            todo = [i for i in range(len(self._ranges)) if i not in applied]
+            for j, i in enumerate(todo):
+                self._apply_slice(i, tick=(j == len(todo) - 1))
+            return
         n = m.theta.numel()
         if self.gradient_clip:
             # clip_grad_norm_ over all parameters of the (averaged) gradient: its coefficient lands in opt_state[1], which the step reads
@@ -1315,7 +1370,15 @@ class GCPTrainStep:
         m.repack(st)
 
     def step(self, inputs, noise=None):
-        out = self.backward(inputs, noise)
+        self._early_on = (self.early_optimizer and not self.gradient_clip and len(self._ranges) > 1 and
+                          not (self.m.use_graph and self.backward_graph))
+        if self._early_on and getattr(self, "_clip_state_dirty", True):
+            self.opt_state[1:2].zero_()          # the early slices read the clip coefficient: it must be 0 (unset) before they run
+            self._clip_state_dirty = False
+        try:
+            out = self.backward(inputs, noise)
+        finally:
+            self._early_on = False
         self.optimizer_step()
         return out
 
