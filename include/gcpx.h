@@ -585,6 +585,11 @@ typedef struct gcpx_mlp_bwd_args {
     float gn_eps, lrelu_slope;
 } gcpx_mlp_bwd_args;
 int gcpx_mlp_bwd(const gcpx_mlp_bwd_args* a, void* stream);
+/* nprob (<= GCPX_MLP_BWD_GROUP_MAX) Predictors of one hidden width whose chains are independent, in ONE launch (blockIdx.y = the
+   Predictor; tab: HOST array, copied into the kernel arguments): a tree level's posterior and prior share the level's latency-bound
+   chain.  Bit for bit what one gcpx_mlp_bwd per Predictor writes. */
+#define GCPX_MLP_BWD_GROUP_MAX 4
+int gcpx_mlp_bwd_group(const gcpx_mlp_bwd_args* tab, int32_t nprob, void* stream);
 int gcpx_mlp_bwd_blocks(int32_t M);
 /* dx[r][c] = dy[r][c] * (1 - y[r][c]^2), backward of y = tanh(u) (GCPX_MLP_TANH; tree_module.py:109-110): dy and y rows (b, j) at
    base + b*sb + j*sr, dx dense [B*rpb][width] */

@@ -190,6 +190,36 @@ def test_step_with_slices_applied_during_the_backward_equals_the_late_step(name)
     assert float(ta.opt_state[0]) == 3.0
 
 
+def test_grouped_level_launches_give_the_gradient_of_single_launches():
+    """A level's posterior + prior Predictor backward as one grouped launch (gcpx_mlp_bwd_group: the same function per workgroup) and the
+    three layers' d h_prev GEMMs as one batched launch (same GEMM, blockIdx.z = layer; the launch heuristics may pick another tile for
+    the larger grid, so sums may be ordered differently): 3 launches per level less on the chain, the same gradient to f32 rounding."""
+    hp, sd, ma, ta = _setup("c1", False)
+    _, _, mb, tb = _setup("c1", False)
+    tb.group_mlp_bwd, tb.batch_dh = False, False
+    inputs, noise, _ = make_inputs(hp, seed=41, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    ta.backward(dev_in, noise.cuda())
+    tb.backward(dev_in, noise.cuda())
+    torch.cuda.synchronize()
+    na = sum(1 for op in ta.last_bplan.ops if not op[0].startswith("@"))
+    nb = sum(1 for op in tb.last_bplan.ops if not op[0].startswith("@"))
+    assert nb - na == 3 * hp.hierarchy_levels, (na, nb)
+    ga, gb = ta.named_grads(), tb.named_grads()
+    for k in ga:
+        scale = float(gb[k].abs().max())
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * scale + 1e-12, k
+    # the grouped Predictor launch itself is bit-identical
+    tb2 = tb
+    tb2.group_mlp_bwd = True
+    tb2._bplans.clear()
+    tb2.backward(dev_in, noise.cuda())
+    torch.cuda.synchronize()
+    gc = tb2.named_grads()
+    for k in gb:
+        assert torch.equal(gb[k], gc[k]), k
+
+
 def test_two_training_steps_c1():
     """losses of two consecutive optimisation steps and the updated parameters against the oracle loop"""
     from oracle import gcp_model_oracle as O

@@ -12,7 +12,7 @@
 namespace {
 
 template <int MID>
-__global__ void __launch_bounds__(256) mlp_bwd_kernel(const gcpx_mlp_bwd_args a) {
+__device__ __forceinline__ void mlp_bwd_body(const gcpx_mlp_bwd_args& a, const int bx) {
     constexpr int NTM = MID / 16;
     constexpr int NW = NTM >= 4 ? 4 : NTM;
     constexpr int TPW = NTM / NW;
@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const gcpx_mlp_bwd_args a)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int r = blockIdx.x * 16 + j;
+    const int r = bx * 16 + j;
     const bool rv = r < a.M;
     const int rs = rv ? r : 0;
     const int rb = rs / a.rpb, rj = rs % a.rpb;
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const gcpx_mlp_bwd_args a)
         if (owner) {
             const float* ul = a.save + (size_t)(1 + 2 * l) * a.M * MID + (size_t)rs * MID;
             float* dul = a.du[1 + l];
-            float* part = a.gn_partial[l] + (size_t)blockIdx.x * 2 * MID;
+            float* part = a.gn_partial[l] + (size_t)bx * 2 * MID;
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int c = (nt0 + t) * 16 + q * 4;
@@ -191,22 +191,73 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const gcpx_mlp_bwd_args a)
     }
 }
 
+template <int MID>
+__global__ void __launch_bounds__(256) mlp_bwd_kernel(const gcpx_mlp_bwd_args a) { mlp_bwd_body<MID>(a, blockIdx.x); }
+
+// several Predictors whose chains are independent (a tree level's posterior and prior) side by side: blockIdx.y = the Predictor.
+// The same function per workgroup: the same bits as one launch each.
+struct MlpBwdGroup { gcpx_mlp_bwd_args p[GCPX_MLP_BWD_GROUP_MAX]; };
+template <int MID>
+__global__ void __launch_bounds__(256) mlp_bwd_group_kernel(const MlpBwdGroup g) {
+    const gcpx_mlp_bwd_args& a = g.p[blockIdx.y];
+    if ((int)blockIdx.x * 16 >= a.M) return;
+    mlp_bwd_body<MID>(a, blockIdx.x);
+}
+
+int check_mlp_bwd(const gcpx_mlp_bwd_args* a, const char* fn) {
+#define CHK(cond, msg)                                     \
+    do {                                                   \
+        if (!(cond)) {                                     \
+            gcpx_set_error("%s: %s", fn, msg);             \
+            return GCPX_ERR_INVALID_ARG;                   \
+        }                                                  \
+    } while (0)
+    CHK(a != nullptr, "null args");
+    CHK(a->M > 0 && a->rpb > 0, "bad M / rpb");
+    CHK(a->dout && a->save && a->wT_out && a->du[0], "missing pointer");
+    CHK(a->out_pad > 0 && a->out_pad % 16 == 0 && a->ldo >= a->out_pad && a->ldo % 4 == 0, "out_pad % 16, ldo");
+    CHK(a->n_mid >= 0 && a->n_mid <= 4 && a->ndx >= 0 && a->ndx <= 4, "n_mid / ndx out of range");
+    for (int l = 0; l < a->n_mid; ++l)
+        CHK(a->wT_mid[l] && a->gn_gamma[l] && a->gn_beta[l] && a->du[1 + l] && a->gn_partial[l], "hidden-layer pointer missing");
+    for (int i = 0; i < a->ndx; ++i)
+        CHK(a->dx[i].wT && a->dx[i].out && a->dx[i].width > 0 && a->dx[i].width % 16 == 0 && a->dx[i].orow % 4 == 0 && a->dx[i].ob % 4 == 0,
+            "input split: pointers, width % 16, 16-byte aligned rows");
+#undef CHK
+    return GCPX_OK;
+}
+
 }  // namespace
+
+extern "C" int gcpx_mlp_bwd_group(const gcpx_mlp_bwd_args* tab, int32_t nprob, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(tab && nprob >= 1 && nprob <= GCPX_MLP_BWD_GROUP_MAX, "1 .. GCPX_MLP_BWD_GROUP_MAX problems");
+    MlpBwdGroup g;
+    int mx = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const int st = check_mlp_bwd(tab + i, __func__);
+        if (st != GCPX_OK) return st;
+        GCPX_CHECK_ARG(tab[i].mid == tab[0].mid, "one hidden width per group");
+        g.p[i] = tab[i];
+        mx = tab[i].M > mx ? tab[i].M : mx;
+    }
+    for (int i = nprob; i < GCPX_MLP_BWD_GROUP_MAX; ++i) g.p[i] = tab[0];
+    const dim3 grid((mx + 15) / 16, nprob);
+    if (tab[0].mid == 128) hipLaunchKernelGGL(mlp_bwd_group_kernel<128>, grid, dim3(256), 0, stream, g);
+    else if (tab[0].mid == 32) hipLaunchKernelGGL(mlp_bwd_group_kernel<32>, grid, dim3(256), 0, stream, g);
+    else {
+        gcpx_set_error("gcpx_mlp_bwd_group: unsupported mid=%d (128 or 32)", tab[0].mid);
+        return GCPX_ERR_UNSUPPORTED;
+    }
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
 
 extern "C" int gcpx_mlp_bwd_blocks(int32_t M) { return (M + 15) / 16; }
 
 extern "C" int gcpx_mlp_bwd(const gcpx_mlp_bwd_args* a, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    GCPX_CHECK_ARG(a != nullptr, "null args");
-    GCPX_CHECK_ARG(a->M > 0 && a->rpb > 0, "bad M / rpb");
-    GCPX_CHECK_ARG(a->dout && a->save && a->wT_out && a->du[0], "missing pointer");
-    GCPX_CHECK_ARG(a->out_pad > 0 && a->out_pad % 16 == 0 && a->ldo >= a->out_pad && a->ldo % 4 == 0, "out_pad % 16, ldo");
-    GCPX_CHECK_ARG(a->n_mid >= 0 && a->n_mid <= 4 && a->ndx >= 0 && a->ndx <= 4, "n_mid / ndx out of range");
-    for (int l = 0; l < a->n_mid; ++l)
-        GCPX_CHECK_ARG(a->wT_mid[l] && a->gn_gamma[l] && a->gn_beta[l] && a->du[1 + l] && a->gn_partial[l], "hidden-layer pointer missing");
-    for (int i = 0; i < a->ndx; ++i)
-        GCPX_CHECK_ARG(a->dx[i].wT && a->dx[i].out && a->dx[i].width > 0 && a->dx[i].width % 16 == 0 && a->dx[i].orow % 4 == 0 &&
-                           a->dx[i].ob % 4 == 0, "input split: pointers, width % 16, 16-byte aligned rows");
+    const int st = check_mlp_bwd(a, __func__);
+    if (st != GCPX_OK) return st;
     const int gx = (a->M + 15) / 16;
     if (a->mid == 128) hipLaunchKernelGGL(mlp_bwd_kernel<128>, dim3(gx), dim3(256), 0, stream, *a);
     else if (a->mid == 32) hipLaunchKernelGGL(mlp_bwd_kernel<32>, dim3(gx), dim3(256), 0, stream, *a);

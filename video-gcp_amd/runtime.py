@@ -163,6 +163,7 @@ SYMBOLS = [
     ("gcpx_reduce_partials", C.c_int, [vp, i32, i64, i32, vp, i32, vp]),
     ("gcpx_lstm_bwd", C.c_int, [C.POINTER(LstmBwdArgs), vp]),
     ("gcpx_mlp_bwd", C.c_int, [C.POINTER(MlpBwdArgs), vp]),
+    ("gcpx_mlp_bwd_group", C.c_int, [C.POINTER(MlpBwdArgs), i32, vp]),
     ("gcpx_mlp_bwd_blocks", C.c_int, [i32]),
     ("gcpx_gn_lrelu_bwd", C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float, vp]),
     ("gcpx_gn_bwd_blocks", C.c_int, [i32]),

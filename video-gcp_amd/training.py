@@ -88,6 +88,8 @@ class GCPTrainStep:
         self.fuse_head_act = os.environ.get("GCPX_NO_HEAD_ACT_FUSION") is None     # activation backward of the last decoder block in the head's data gradient
         self.fuse_skip = os.environ.get("GCPX_NO_SKIP_FUSION") is None             # skip-connection sum of a 16 + 16 channel block in the activation pass in front of it
         self.split_wgrad_rows = os.environ.get("GCPX_WGRAD_ROWS_NOSPLIT") is None   # the tree's Linear / LSTM weight gradients (>= 256 rows) likewise
+        self.batch_dh = os.environ.get("GCPX_NO_BATCH_DH") is None                 # a level's d h_prev GEMMs as one batched launch
+        self.group_mlp_bwd = os.environ.get("GCPX_NO_MLP_BWD_GROUP") is None       # a level's posterior + prior backward as one launch
         self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
         self.fused_mlp_bwd = os.environ.get("GCPX_NO_FUSED_MLP_BWD") is None
         self._pad_fixups = []                 # (see _mlp_in_dst)
@@ -231,7 +233,9 @@ class GCPTrainStep:
             T["embed.wT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.embed.weight"].t().contiguous())
             for i in range(hp.n_lstm_layers):
                 T[f"lstm{i}.wxT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.lstm.{i}.weight_ih"].t().contiguous())   # [H][4H]
-                T[f"lstm{i}.whT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.lstm.{i}.weight_hh"].t().contiguous())
+            # (stacked: the layers' d h_prev GEMMs of a level are ONE batched launch behind the level's d x chain)
+            T["lstm.whT"] = torch.stack([pk.pack_gemm(sd[f"{p}.subgoal_pred.lstm.{i}.weight_hh"].t().contiguous())
+                                         for i in range(hp.n_lstm_layers)]).contiguous()
             T["out.wT"] = pk.pack_gemm(sd[f"{p}.subgoal_pred.out.weight"].t().contiguous())                     # [H][nz]
             if hp.tree_lstm == "split_linear":
                 T["proj.wT"] = torch.stack([pk.pack_gemm(sd[f"{p}.subgoal_pred.projections.{j}.weight"].t().contiguous())
@@ -493,7 +497,20 @@ class GCPTrainStep:
                  bn["rstd"].data_ptr(), coef.data_ptr(), F * Hh * Ww * Cc, Cc)
         return dy
 
-    def _mlp_bwd(self, plan, tag, prefix, rec, T, dout, ldo, dx_outs):
+    def _mlp_bwd_group(self, plan, tag, group):
+        """the launches `_mlp_bwd(..., group=group)` held back: one grouped launch when they share a hidden width, else one each"""
+        if not group:
+            return
+        lib = self.m.lib
+        if len(group) > 1 and len(group) <= 4 and len({a.mid for _, a in group}) == 1:
+            tab = (rt.MlpBwdArgs * len(group))(*[a for _, a in group])
+            plan.keep.append(tab)
+            plan.add(f"bw.mlp:{tag}", lib.gcpx_mlp_bwd_group, tab, len(group))
+        else:
+            for t, a in group:
+                plan.add(f"bw.mlp:{t}", lib.gcpx_mlp_bwd, C.byref(a))
+
+    def _mlp_bwd(self, plan, tag, prefix, rec, T, dout, ldo, dx_outs, group=None):
         """Backward of one Predictor MLP.  dout: dense [M][ldo] gradient of the head output (pad columns zero).
         dx_outs: one (out_ptr, ob, orow) per input split packed in T (wT_in{i}); rows (b, j) with the forward's rpb."""
         m, lib, hp = self.m, self.m.lib, self.m._hp
@@ -509,7 +526,7 @@ class GCPTrainStep:
                     ldw=mid, n_valid=out_dim, sr=mid, sb=M * mid, rpb=M, dbias=self.g(f"{prefix}.head.linear.bias"))
         if self.fused_mlp_bwd and mid in (128, 32) and n_mid <= 4 and len(dx_outs) <= 4 and out_pad <= 1024 and \
                 all(ob % 4 == 0 and orow % 4 == 0 for _, ob, orow in dx_outs):
-            self._mlp_bwd_fused(plan, tag, prefix, rec, T, dout, ldo, dx_outs, a_ptr)
+            self._mlp_bwd_fused(plan, tag, prefix, rec, T, dout, ldo, dx_outs, a_ptr, group=group)
             return
         da = m._buf(f"bw.{tag}.da{n_mid}", (M, mid))
         self._dgemm(plan, f"{tag}.out", [self._dense(dout, ldo, out_pad, M)], M, mid, M, T["wT_out"], da.data_ptr(), 0, mid)
@@ -569,7 +586,7 @@ class GCPTrainStep:
             plan.add(f"bw.unpad:{tag}", self.m.lib.gcpx_rows_strided, dst, 0, raw, scratch.data_ptr(), 0, pad, 1, mid, raw, 0)
         self._pad_fixups = []
 
-    def _mlp_bwd_fused(self, plan, tag, prefix, rec, T, dout, ldo, dx_outs, a_ptr):
+    def _mlp_bwd_fused(self, plan, tag, prefix, rec, T, dout, ldo, dx_outs, a_ptr, group=None):
         """The data-gradient chain of one Predictor as ONE launch (gcpx_mlp_bwd); weight gradients and the GroupNorm parameter
         reductions stay on the side lanes (the head's weight gradient was queued by the caller)."""
         m, lib, hp = self.m, self.m.lib, self.m._hp
@@ -592,7 +609,10 @@ class GCPTrainStep:
             wT = T[f"wT_in{i}"]
             a.dx[i].wT, a.dx[i].out, a.dx[i].ob, a.dx[i].orow, a.dx[i].width = wT.data_ptr(), optr, ob, orow, wT.shape[1] * 16
         plan.keep.append(a)
-        plan.add(f"bw.mlp:{tag}", lib.gcpx_mlp_bwd, C.byref(a))
+        if group is not None:
+            group.append((tag, a))               # issued by _mlp_bwd_group (the queued weight gradients below go out with a later flush)
+        else:
+            plan.add(f"bw.mlp:{tag}", lib.gcpx_mlp_bwd, C.byref(a))
         for l in reversed(range(n_mid)):
             pre = f"{prefix}.pyramid-{l}"
             self._gn_param_grads(plan, f"{tag}.{l}", pre, parts[l], nb, mid)
@@ -746,8 +766,9 @@ class GCPTrainStep:
                 merged = buf(f"merged{l}", (M, 2 * nl * H))
                 dmerged = buf(f"bw.dmerged{l}", (M, 2 * nl * H))
                 dh_src = dxt
+                dgs = buf(f"bw.dgates{l}", (nl, M, 4 * H))
                 for i in reversed(range(nl)):
-                    dg = buf(f"bw.dgates{l}.{i}", (M, 4 * H))
+                    dg = dgs[i]
                     a = rt.LstmBwdArgs()
                     a.gates = rec[f"gates:lstm{l}.{i}"].data_ptr()
                     a.c_prev, a.c_prev_stride = _addr(merged, (2 * i + 1) * H), 2 * nl * H
@@ -767,9 +788,15 @@ class GCPTrainStep:
                     dxi = buf(f"bw.dxi{l}.{i}", (M, H))
                     src = [self._dense(dg.data_ptr(), 4 * H, 4 * H, M)]
                     self._dgemm(plan, f"lstm{l}.{i}.x", src, M, H, M, Wt[f"lstm{i}.wxT"], dxi.data_ptr(), 0, H)
-                    self._dgemm(plan, f"lstm{l}.{i}.h", src, M, H, M, Wt[f"lstm{i}.whT"], _addr(dmerged, 2 * i * H), 0, 2 * nl * H)
+                    if not self.batch_dh:
+                        self._dgemm(plan, f"lstm{l}.{i}.h", src, M, H, M, Wt["lstm.whT"][i], _addr(dmerged, 2 * i * H), 0, 2 * nl * H)
                     dh_src = dxi
                 dx0 = dh_src
+                if self.batch_dh:
+                    # d h_prev of every layer (wanted by the merge only): one launch, blockIdx.z = layer — the level's chain is 2 of its
+                    # 6 LSTM data-gradient GEMMs shorter, and the launch has nl times the workgroups of one (16 .. 256 rows below level 5)
+                    self._dgemm(plan, f"lstm{l}.h", [self._dense(dgs.data_ptr(), 4 * H, 4 * H, M)], M, H, M, Wt["lstm.whT"],
+                                dmerged.data_ptr(), 0, 2 * nl * H, batch=(nl, M * 4 * H, Wt["lstm.whT"][0].numel(), 0, 2 * H))
                 # embedding of [e_l, e_r, z, e_0, e_g]
                 el = m._rowsrc(_addr(E), PS * nz, 2 * s * nz, nz)
                 er = m._rowsrc(_addr(E, 2 * s * nz), PS * nz, 2 * s * nz, nz)
@@ -842,8 +869,11 @@ class GCPTrainStep:
             if split:
                 plan.fork([1, 2])
                 plan.lane = 1
+            # posterior and prior chains are independent: one grouped launch of both (not with attention, whose backward sits between
+            # them and reads the posterior's result; not on three lanes)
+            grp = [] if (self.group_mlp_bwd and not attentive and not split) else None
             self._mlp_bwd(plan, f"posterior{l}", f"{p}.inference.q", rec[f"mlp:posterior{l}"], Wt["q"], dq.data_ptr(), 2 * nv,
-                          [(dXq.data_ptr(), n * 2 * nz, 2 * nz), et_out])
+                          [(dXq.data_ptr(), n * 2 * nz, 2 * nz), et_out], group=grp)
             dXa = None
             if attentive:
                 dXa = self._attention_backward(plan, fplan, l, Wt, dEt_l, dKp, dVp, B)
@@ -858,7 +888,8 @@ class GCPTrainStep:
             if split:
                 plan.lane = 2
             self._mlp_bwd(plan, f"prior{l}", f"{p}.prior", rec[f"mlp:prior{l}"], Wt["prior"], dp.data_ptr(), 2 * nv,
-                          [(dXp.data_ptr(), n * 2 * nz, 2 * nz)])
+                          [(dXp.data_ptr(), n * 2 * nz, 2 * nz)], group=grp)
+            self._mlp_bwd_group(plan, f"level{l}", grp)
             if split:
                 plan.lane = 0
                 merge_backward()
