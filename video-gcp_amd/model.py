@@ -155,7 +155,7 @@ class GCPTreeModel:
         self.use_graph = {"graph": True, "eager": False}.get(os.environ.get("GCPX_FORWARD_REPLAY", "auto"), "auto")
         # hipGraph capture is not allowed on the legacy default stream: the model launches on its own stream
         # and orders it against the caller's current stream with events (wait_stream), never a host sync
-        self._stream = torch.cuda.Stream(device=self.device)
+        self._stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("GCPX_MAIN_PRIORITY", "0")))
         self._streams = [self._stream.cuda_stream]
         for _ in range(N_LANES - 1):
             sp = C.c_void_p()

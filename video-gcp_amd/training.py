@@ -88,6 +88,7 @@ class GCPTrainStep:
         self.fuse_head_act = os.environ.get("GCPX_NO_HEAD_ACT_FUSION") is None     # activation backward of the last decoder block in the head's data gradient
         self.fuse_skip = os.environ.get("GCPX_NO_SKIP_FUSION") is None             # skip-connection sum of a 16 + 16 channel block in the activation pass in front of it
         self.split_wgrad_rows = os.environ.get("GCPX_WGRAD_ROWS_NOSPLIT") is None   # the tree's Linear / LSTM weight gradients (>= 256 rows) likewise
+        self.heads_on_side_lane = os.environ.get("GCPX_NO_HEADS_ASIDE") is None
         self.batch_dh = os.environ.get("GCPX_NO_BATCH_DH") is None                 # a level's d h_prev GEMMs as one batched launch
         self.group_mlp_bwd = os.environ.get("GCPX_NO_MLP_BWD_GROUP") is None       # a level's posterior + prior backward as one launch
         self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
@@ -673,6 +674,13 @@ class GCPTrainStep:
                 plan.add("bw.dlm_nll", lib.gcpx_dlm_nll_bwd, md.data_ptr(), tin["traj_seq"].data_ptr(), tin["pad_mask"].data_ptr(),
                          C.c_float(hp.dense_img_rec_weight / (B * div)), dMD.data_ptr(), buf("bw.dMD.colsum", (B * T, pitch)).data_ptr(),
                          None, B * T, S * S, pitch, hp.n_mixtures)
+        # The latent-space heads (KL, length / existence / state / inverse-model / cost Predictors: ~10 small launches, 0.25 ms on an
+        # otherwise idle chip) run on side lane 1 beside the decoder's data-gradient chain, which needs none of their results; lane 0
+        # picks them up where the decoder's gradient meets dE (bw.addrows below)
+        heads_aside = self.heads_on_side_lane and self.side_lanes and self.n_side >= 1 and not adaptive
+        if heads_aside:
+            plan.fork([1])
+            plan.lane = 1
         if m._kl_w is not None:                               # burn-in schedule: kl_weight(step) is read from device memory
             plan.add("bw.kl", lib.gcpx_kl_bwd_scheduled, _addr(QZ, 2 * nv), _addr(PZ, 2 * nv), _addr(dQZ, 2 * nv), _addr(dPZ, 2 * nv), B, N, nv,
                      PS * 2 * nv, 2 * nv, C.c_float(hp.free_nats), C.c_float(1.0 / (B * div)), None, 0, m._kl_w.data_ptr())
@@ -716,9 +724,15 @@ class GCPTrainStep:
             if has_cost:
                 self._mlp_bwd(plan, "cost_mdl", "cost_mdl.cost_pred", rec["mlp:cost_mdl"], self.bk["cost_mdl"], dcost.data_ptr(), 16, [])
 
-        self._flush(plan)
+        if heads_aside:
+            self._flush(plan, only_lane=1)        # their weight gradients follow them on the same lane (they read the Predictors' du)
+            plan.lane = 0
+        else:
+            self._flush(plan)
         # ---- decoder (tree_dense_rec.py:42 backward) ----
         dE_dec, dskip = self._decoder_backward(plan, fplan, dMD, B)
+        if heads_aside:
+            plan.wait(0, 1)
         held = []
         if self.side_lanes and 0 <= self.dec_side_level < L:
             held, plan.deferred = plan.deferred, []
