@@ -42,7 +42,7 @@ for rep in range(3):
     out = model.forward(dev_in, "train", None)
     torch.cuda.synchronize()
     rt.check(lib.gcpx_event_record(e0, streams[0]), "rec")
-    bplan.run(streams, ops=ops, on_mark=on_mark)
+    bplan.run(streams + [torch.cuda.current_stream().cuda_stream], ops=ops, on_mark=on_mark)
     torch.cuda.synchronize()
 ms = C.c_float()
 print("%-44s %9s %9s %9s   (ms since backward start; lane idle = its earlier work done)" % ("point", "lane0", "lane1", "lane2"))

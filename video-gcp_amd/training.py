@@ -35,7 +35,8 @@ class GCPTrainStep:
     after the gradients (tests)."""
 
     OPTIMIZERS = {"radam": 0, "adam": 1, "rmsprop": 2, "sgd": 3}
-    _early_on, _caller = False, None          # (see __init__: early_optimizer)
+    _early_on, _caller, _slice_stream, last_bplan_caller_lane = False, None, None, False          # (see __init__: early_optimizer)
+    _pending_slices = ()
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, optimizer="radam", momentum=0.0,
                  gradient_clip=None):
@@ -67,11 +68,14 @@ class GCPTrainStep:
         # all-reduce is done): 6 of the 7 levels' 10.3 M parameters each (c2) are updated under the remaining levels and the encoder
         # backward, instead of 2.9 GB of optimizer + re-pack traffic behind the last gradient.  Not with gradient_clip (the global norm
         # needs every slice) and not with a graph-captured backward (no host callbacks).  backward() alone never touches parameters.
-        # Those launches are held to `early_blocks` workgroups: a full grid of the optimizer kernel fills every CU with wavefronts and
-        # stretched the tree chain's GEMMs beside it from 41 to 101 us (profiles/r04n_train_timeline.txt), which took back 0.4 of the
-        # 0.58 ms the early slices save.
+        # Issued at a level's mark, a full grid of the optimizer kernel stretched the tree chain's GEMMs beside it from 41 to 101 us
+        # (profiles/r04n_train_timeline.txt) and took back 0.4 of the 0.58 ms; with the levels' merge chains on the caller's stream
+        # (merge_on_caller_lane) the slices are held until the last chain is out and run under the encoder backward (_on_mark): -0.24 ms
+        # per step (tools/ab_train_attr.py early_optimizer 1 0).  `early_blocks` > 0 holds their launches to that many workgroups
+        # (128: +0.07 ms, 32: +3.5 ms; 0 = full grids).
         self.early_optimizer = os.environ.get("GCPX_NO_EARLY_OPTIMIZER") is None
-        self.early_blocks = int(os.environ.get("GCPX_EARLY_BLOCKS", "128"))
+        self.early_blocks = int(os.environ.get("GCPX_EARLY_BLOCKS", "0"))
+        self.early_on_caller = os.environ.get("GCPX_EARLY_STREAM", "caller") == "caller"     # else: communication stream / last side lane
         self._early_on, self._applied, self._caller = False, set(), None
         self.bk = model.build_arena(self._pack_backward)
         self._pack_backward_split()
@@ -88,6 +92,11 @@ class GCPTrainStep:
         self.fuse_head_act = os.environ.get("GCPX_NO_HEAD_ACT_FUSION") is None     # activation backward of the last decoder block in the head's data gradient
         self.fuse_skip = os.environ.get("GCPX_NO_SKIP_FUSION") is None             # skip-connection sum of a 16 + 16 channel block in the activation pass in front of it
         self.split_wgrad_rows = os.environ.get("GCPX_WGRAD_ROWS_NOSPLIT") is None   # the tree's Linear / LSTM weight gradients (>= 256 rows) likewise
+        # The parent-state merge chain of a level (batched d h_prev GEMM -> merge data gradient -> accumulation into the parents' states:
+        # three dependent launches that only the NEXT level's LSTM backward waits for) runs on the CALLER's stream as a fourth lane — idle
+        # during the backward, with a hardware queue of its own (a fifth stream would share one of the four) — beside the level's
+        # embedding / latent / Predictor chain on lane 0
+        self.merge_on_caller_lane = os.environ.get("GCPX_NO_MERGE_LANE") is None
         self.heads_on_side_lane = os.environ.get("GCPX_NO_HEADS_ASIDE") is None
         self.batch_dh = os.environ.get("GCPX_NO_BATCH_DH") is None                 # a level's d h_prev GEMMs as one batched launch
         self.group_mlp_bwd = os.environ.get("GCPX_NO_MLP_BWD_GROUP") is None       # a level's posterior + prior backward as one launch
@@ -753,6 +762,11 @@ class GCPTrainStep:
                 raise NotImplementedError("attentive training with tied tree layers")
 
         # ---- tree levels, leaves first (tree_utils.py:21-44 backward) ----
+        MERGE_LANE = 1 + self.n_side                    # the caller's stream (backward(): the last entry of the stream list)
+        merge_lane = (self.merge_on_caller_lane and self.side_lanes and bool(hp.tree_lstm) and not self.parallel_level_chains and
+                      not (m.use_graph and self.backward_graph))
+        plan.rec["caller_lane"] = merge_lane
+        merge_pending = False
         pid = hp.pred_inp_dim
         for l in reversed(range(L)):
             li = l if hp.untied_layers else 0
@@ -779,6 +793,9 @@ class GCPTrainStep:
                 self._dgemm(plan, f"out{l}", [m._rowsrc(dEn, PS * nz, 2 * s * nz, nz)], M, H, n, Wt["out.wT"], dxt.data_ptr(), n * H, H)
                 merged = buf(f"merged{l}", (M, 2 * nl * H))
                 dmerged = buf(f"bw.dmerged{l}", (M, 2 * nl * H))
+                if merge_pending:
+                    plan.wait(0, MERGE_LANE)            # the level above wrote this level's d state (dHid) on the merge lane
+                    merge_pending = False
                 dh_src = dxt
                 dgs = buf(f"bw.dgates{l}", (nl, M, 4 * H))
                 for i in reversed(range(nl)):
@@ -806,11 +823,14 @@ class GCPTrainStep:
                         self._dgemm(plan, f"lstm{l}.{i}.h", src, M, H, M, Wt["lstm.whT"][i], _addr(dmerged, 2 * i * H), 0, 2 * nl * H)
                     dh_src = dxi
                 dx0 = dh_src
-                if self.batch_dh:
+                if merge_lane:
+                    plan.fork([MERGE_LANE])            # the merge chain (below) starts here: all gates' gradients are out
+                def dh_batched():
                     # d h_prev of every layer (wanted by the merge only): one launch, blockIdx.z = layer — the level's chain is 2 of its
                     # 6 LSTM data-gradient GEMMs shorter, and the launch has nl times the workgroups of one (16 .. 256 rows below level 5)
-                    self._dgemm(plan, f"lstm{l}.h", [self._dense(dgs.data_ptr(), 4 * H, 4 * H, M)], M, H, M, Wt["lstm.whT"],
-                                dmerged.data_ptr(), 0, 2 * nl * H, batch=(nl, M * 4 * H, Wt["lstm.whT"][0].numel(), 0, 2 * H))
+                    if self.batch_dh:
+                        self._dgemm(plan, f"lstm{l}.h", [self._dense(dgs.data_ptr(), 4 * H, 4 * H, M)], M, H, M, Wt["lstm.whT"],
+                                    dmerged.data_ptr(), 0, 2 * nl * H, batch=(nl, M * 4 * H, Wt["lstm.whT"][0].numel(), 0, 2 * H))
                 # embedding of [e_l, e_r, z, e_0, e_g]
                 el = m._rowsrc(_addr(E), PS * nz, 2 * s * nz, nz)
                 er = m._rowsrc(_addr(E, 2 * s * nz), PS * nz, 2 * s * nz, nz)
@@ -863,7 +883,17 @@ class GCPTrainStep:
             split = self.parallel_level_chains and self.side_lanes and l > 0
             dXi = None
             if not split:
+                if hp.tree_lstm:
+                    if merge_lane:
+                        plan.lane = MERGE_LANE
+                    dh_batched()
                 merge_backward()
+                if hp.tree_lstm and merge_lane:
+                    plan.lane = 0
+                    merge_pending = True
+                    if l == 0:
+                        plan.wait(0, MERGE_LANE)        # (the LSTM initialiser below reads the root states' gradient)
+                        merge_pending = False
             if l == 0 and hp.tree_lstm and hp.lstm_init == "mlp":
                 # MLP LSTM initialiser (tree_module.py:104-105): outputs live in Hid slots 0 and 2^L
                 dinit = buf("bw.dinit", (B, 2 * SD))
@@ -906,6 +936,8 @@ class GCPTrainStep:
             self._mlp_bwd_group(plan, f"level{l}", grp)
             if split:
                 plan.lane = 0
+                if hp.tree_lstm:
+                    dh_batched()
                 merge_backward()
                 plan.join([1, 2])
             ctx = (2 * nz + nv, 3 * nz + nv) if hp.context_every_step else (-1, -1)
@@ -918,12 +950,17 @@ class GCPTrainStep:
             self._tree_accum(plan, f"E{l}", dE, PS * nz, 2 * s * nz, B, n, nz, srcs)
             if held and l <= self.dec_side_level:
                 plan.deferred, held = held + plan.deferred, []
+            if merge_lane and hp.tree_lstm and plan.deferred:
+                for sl in range(1, 1 + self.n_side):    # the projections' weight gradients read the merge lane's d merged
+                    plan.wait(sl, MERGE_LANE)
             self._flush(plan)
             if f"tree{l}" in self._bucket_index:
                 # every gradient of this level's module has been issued (main lane + the side lanes just flushed): its bucket of the
                 # data-parallel exchange can start while the levels above are differentiated
                 plan.mark("bucket", self._bucket_index[f"tree{l}"])
 
+        if merge_lane:
+            plan.mark("slices", None)         # (step(): the early optimizer slices held back for the merge chains go out here)
         # ---- temporal inference encoder + image encoders (base_gcp.py:184-213 backward) ----
         d_inf = buf("bw.d_inf", (B * T, nz))
         if attentive:
@@ -1308,6 +1345,8 @@ class GCPTrainStep:
         caller = torch.cuda.current_stream(m.device)
         self._caller = caller
         self._applied = set()
+        self._pending_slices = []
+        self.last_bplan_caller_lane = bool(bplan.rec.get("caller_lane"))
         m._stream.wait_stream(caller)
         stream = m._stream.cuda_stream
         if m.use_graph and self.backward_graph:
@@ -1316,12 +1355,16 @@ class GCPTrainStep:
                 bplan.graph = m._capture(bplan, bplan.ops, stream)
             rt.check(m.lib.gcpx_graph_launch(bplan.graph, stream), "graph_launch")
         else:
-            bplan.run(self._backward_streams(), on_mark=self._on_mark)
+            # (the caller's stream is the plan's last lane: the levels' merge chains, and step()'s early optimizer slices behind them)
+            bplan.run(self._backward_streams() + [caller.cuda_stream], on_mark=self._on_mark)
         caller.wait_stream(m._stream)
         self.last_bplan = bplan
         return out
 
     def _on_mark(self, tag, payload):
+        if tag == "slices":
+            self._issue_pending_slices()
+            return
         if tag != "bucket" or (self.buckets is None and not self._early_on):
             return
         if self._lane_streams is None:
@@ -1330,23 +1373,55 @@ class GCPTrainStep:
         if self.buckets is not None:
             self.buckets.reduce_async(payload, after_streams=self._lane_streams)
         if self._early_on:
-            self._apply_slice(payload, tick=False, after_streams=self._lane_streams, max_blocks=self.early_blocks)
+            if self.early_on_caller and self.last_bplan_caller_lane:
+                # The caller's stream also carries the levels' merge chains (merge_on_caller_lane): a slice issued here would wait for
+                # the level's weight gradients on the side lanes and hold up the next level's merge chain behind it (measured: 15.0
+                # instead of 13.2 ms / step).  Remember where the lanes stand (events) and issue the slices behind the last merge chain
+                # (the plan's "slices" mark): they then run under the encoder backward.
+                evs = []
+                for s_ in self._lane_streams:
+                    e = torch.cuda.Event()
+                    e.record(s_)
+                    evs.append(e)
+                self._pending_slices.append((payload, evs))
+                return
+            # elsewhere: at once, on the caller's stream or — early_on_caller = False — on the communication stream (data-parallel: the
+            # slice follows its all-reduce there) / the last side lane
+            if self.early_on_caller:
+                on = self._caller
+            elif self.buckets is not None and self.buckets.comm_stream is not None:
+                on = self.buckets.comm_stream
+            else:
+                on = self._lane_streams[-1]
+            self._slice_stream = on
+            self._apply_slice(payload, tick=False, on=on, after=[s_ for s_ in self._lane_streams if s_ is not on],
+                              max_blocks=self.early_blocks)
             self._applied.add(payload)
 
-    def _apply_slice(self, i, tick, after_streams=(), max_blocks=0):
-        """optimizer update of slice i of the flat vectors + re-pack of the weights that gather from it, on the caller's stream (which
-        first waits for `after_streams`, the lanes that produce the slice's gradient, and for the slice's all-reduce)"""
+    def _issue_pending_slices(self):
+        for i, evs in self._pending_slices:
+            self._slice_stream = self._caller
+            self._apply_slice(i, tick=False, on=self._caller, after=evs, max_blocks=self.early_blocks)
+            self._applied.add(i)
+        self._pending_slices = []
+
+    def _apply_slice(self, i, tick, on, after=(), max_blocks=0):
+        """optimizer update of slice i of the flat vectors + re-pack of the weights that gather from it, on stream `on` (which first
+        waits for `after` — streams or events: the lanes that produce the slice's gradient — and for the slice's all-reduce)"""
         m = self.m
         name, lo, hi = self._ranges[i]
-        caller = self._caller
-        for s in after_streams:
-            caller.wait_stream(s)
+        caller = on
+        for s in after:
+            if isinstance(s, torch.cuda.Event):
+                caller.wait_event(s)
+            else:
+                caller.wait_stream(s)
         scale = 1.0
         if self.buckets is not None and torch.distributed.is_initialized():
             w = self.buckets.works.get(i)
             if w is not None:
                 with torch.cuda.stream(caller):
-                    w.wait()                                   # the caller's stream waits for the collective (no host block)
+                    w.wait()                                   # the stream waits for the collective (no host block)
             scale = 1.0 / torch.distributed.get_world_size(self.buckets.group)
         kind = self.OPTIMIZERS[self.optimizer]
         p1, p2 = (self.betas[0], self.betas[1]) if kind <= 1 else ((self.momentum, 0.99) if kind == 2 else (self.momentum, 0.0))
@@ -1387,9 +1462,11 @@ class GCPTrainStep:
             if getattr(self, "_clip_state_dirty", True):
                 self.opt_state[1:2].zero_()      # (ordered behind the early slices: they already read it — see step())
                 self._clip_state_dirty = False
+            if self._slice_stream is not None and self._slice_stream is not self._caller:
+                self._caller.wait_stream(self._slice_stream)
             todo = [i for i in range(len(self._ranges)) if i not in applied]
             for j, i in enumerate(todo):
-                self._apply_slice(i, tick=(j == len(todo) - 1))
+                self._apply_slice(i, tick=(j == len(todo) - 1), on=self._caller)
             return
         n = m.theta.numel()
         if self.gradient_clip:
