@@ -184,6 +184,7 @@ typedef enum gcpx_gemm_epi {
                             the draw of the next VRNN step ride in a launch of this step instead of being a launch of its own */
 } gcpx_gemm_epi;
 
+struct gcpx_lstm_bwd_args;
 typedef struct gcpx_gemm_args {
     gcpx_row_src src[6];
     int32_t nsrc;
@@ -218,6 +219,13 @@ typedef struct gcpx_gemm_args {
                                conversion pass + an LDS-DMA fed GEMM (csrc/gemm_planes.hip); same results class as the split kernel */
     int32_t* x_exp;
     int64_t x_planes_bytes; /* size of the x_planes allocation (checked against the problem) */
+    const struct gcpx_lstm_bwd_args* lstm_bwd;
+                            /* DEVICE copy of a gcpx_lstm_bwd_args, or NULL (GCPX_EPI_NONE, single problem, dense rows r = b*rpb + j of the
+                               M rows the cell backward has too): the epilogue runs the LSTM cell backward of the layer this GEMM feeds —
+                               output column u < H of row r IS that cell's d h from above, so dgates / dc_prev of (r, u) are written next
+                               to out[r, u] and the separate gcpx_lstm_bwd launch (one of two per layer on a latency-bound chain)
+                               disappears.  dh_dense of the struct is ignored; columns >= H (the d h_prev half of a [dx | dh] GEMM) are
+                               plain outputs.  Same arithmetic as gcpx_lstm_bwd. */
 } gcpx_gemm_args;
 
 int gcpx_gemm(const gcpx_gemm_args* a, void* stream);

@@ -48,6 +48,58 @@ def test_gemm_plain(env, M, N, K):
     assert_close(out, want, atol=2e-5, rtol=1e-5, name="gemm")
 
 
+@pytest.mark.parametrize("M,rpb,H,N,K", [(16, 1, 128, 256, 512), (48, 4, 64, 64, 256), (300, 4, 256, 256, 1024), (1024, 64, 128, 128, 512)])
+def test_gemm_lstm_bwd_epilogue_equals_separate_launch(env, M, rpb, H, N, K):
+    """gcpx_gemm_args.lstm_bwd: the cell backward of the layer a data-gradient GEMM feeds, run in the GEMM's epilogue, writes what
+    gcpx_gemm followed by gcpx_lstm_bwd (reading the GEMM's output as dh_dense) writes — dgates and dc_prev bit for bit (the same
+    device function on the same values) — over the one-tile split-K, multi-tile and one-wavefront-per-block launch forms, a [dx | dh]
+    GEMM twice as wide as the cell (columns >= H are plain outputs), rows addressed as (b, j), a dc buffer that is both dc_pos and dc_prev."""
+    rt, pk, lib, dev = env
+    torch.manual_seed(M + N + K)
+    x, w = torch.randn(M, K, device=dev), (torch.randn(N, K) / K ** 0.5)
+    wp = pk.pack_gemm(w).to(dev)
+    nb = M // rpb
+    PB, PR_ = rpb * 2 * H + 32, 2 * H            # stored states: row (b, j) at b*PB + j*PR_ (pitch 2H: [h | c] as in the VRNN)
+    gates = torch.rand(M, H, 4, device=dev) * 0.9 + 0.05
+    gates[:, :, 2] = gates[:, :, 2] * 2 - 1
+    c_prev, c_new = torch.randn(M, 3 * H, device=dev), torch.randn(nb * PB, device=dev)
+    dh_pos = torch.randn(nb * PB, device=dev)
+    outs = []
+    for fused in (False, True):
+        out = torch.full((M, N), float("nan"), device=dev)
+        dgates = torch.full((M, 4 * H), float("nan"), device=dev)
+        dc = torch.arange(nb * PB, device=dev, dtype=torch.float32).sin()           # dc_pos, overwritten in place by dc_prev
+        L = rt.LstmBwdArgs()
+        L.gates, L.c_prev, L.c_prev_stride = gates.data_ptr(), c_prev.data_ptr() + 4 * H, 3 * H
+        L.c_new, L.pb, L.prow = c_new.data_ptr(), PB, PR_
+        L.dh_dense, L.dh_stride = out.data_ptr(), N
+        L.dh_pos, L.dc_pos = dh_pos.data_ptr(), dc.data_ptr()
+        L.dgates, L.dc_prev, L.dcp_stride = dgates.data_ptr(), dc.data_ptr(), 0
+        L.M, L.H, L.rpb = M, H, rpb
+        # dc_prev row r at dc_prev + r*dcp_stride must alias dc_pos of the same (b, j): only possible with rpb == 1 or a dense pitch —
+        # keep the alias for rpb == 1, a separate buffer otherwise
+        if rpb == 1:
+            L.dcp_stride = PB
+        else:
+            dcp = torch.full((M, H), float("nan"), device=dev)
+            L.dc_prev, L.dcp_stride = dcp.data_ptr(), H
+        Ld = torch.frombuffer(bytearray(bytes(L)), dtype=torch.uint8).to(dev)
+        a = rt.GemmArgs()
+        a.src[0] = _rowsrc(rt, x, 0, K, K)
+        a.nsrc, a.M, a.N, a.K, a.rpb = 1, M, N, K, M
+        a.wpk, a.out, a.ob, a.orow = wp.data_ptr(), out.data_ptr(), 0, N
+        if fused:
+            a.lstm_bwd = Ld.data_ptr()
+        rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm")
+        if not fused:
+            rt.check(lib.gcpx_lstm_bwd(C.byref(L), _stream()), "lstm_bwd")
+        torch.cuda.synchronize()
+        outs.append((out, dgates, dc if rpb == 1 else dcp))
+    for (x0, x1), what in zip(zip(*outs), ("out", "dgates", "dc_prev")):
+        assert not torch.isnan(x1).any() or what == "dc_prev", what
+        assert torch.equal(x0, x1), what
+
+
 def test_gemm_sources_shift_affine_stats(env):
     """conv1d-over-time form: three shifted sources, affine+LReLU on load, LReLU epilogue, stats partials."""
     rt, pk, lib, dev = env

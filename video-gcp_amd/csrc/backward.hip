@@ -24,27 +24,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_kernel(const gcpx_lstm_bwd_args 
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.M * a.H) return;
     const int r = idx / a.H, u = idx % a.H;
-    const int b = r / a.rpb, j = r % a.rpb;
-    const size_t pos = (size_t)b * a.pb + (size_t)j * a.prow + u;
-    const float4 g = *reinterpret_cast<const float4*>(a.gates + (size_t)idx * 4);   // i, f, g, o (activated)
-    const float c = a.c_new[pos];
-    const float cp = a.c_prev[(size_t)r * a.c_prev_stride + u];
-    float dh = 0.f, dc = 0.f;
-    if (a.dh_dense) dh += a.dh_dense[(size_t)r * a.dh_stride + u];
-    if (a.dh_pos) dh += a.dh_pos[pos];
-    if (a.dc_pos) dc += a.dc_pos[pos];
-    const float tc = tanhf(c);
-    dc += dh * g.w * (1.f - tc * tc);
-    const float di = dc * g.z * g.x * (1.f - g.x);
-    const float df = dc * cp * g.y * (1.f - g.y);
-    const float dg = dc * g.x * (1.f - g.z * g.z);
-    const float dout = dh * tc * g.w * (1.f - g.w);
-    float* dgr = a.dgates + (size_t)r * 4 * a.H + u;
-    dgr[0] = di;
-    dgr[a.H] = df;
-    dgr[2 * a.H] = dg;
-    dgr[3 * a.H] = dout;
-    a.dc_prev[(size_t)r * a.dcp_stride + u] = dc * g.y;
+    lstm_bwd_cell(a, r, u, a.dh_dense ? a.dh_dense[(size_t)r * a.dh_stride + u] : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------------

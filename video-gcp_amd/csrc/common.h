@@ -40,6 +40,32 @@ __device__ __forceinline__ float4 affine_act4(float4 v, const float* __restrict_
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// LSTM cell backward of (row r, unit u): the body of gcpx_lstm_bwd, also run by the row GEMM's epilogue (gcpx_gemm_args.lstm_bwd) with
+// `dh_above` = the accumulator instead of a.dh_dense
+__device__ __forceinline__ void lstm_bwd_cell(const gcpx_lstm_bwd_args& a, const int r, const int u, const float dh_above) {
+    const int b = r / a.rpb, j = r % a.rpb;
+    const size_t pos = (size_t)b * a.pb + (size_t)j * a.prow + u;
+    const float4 g = *reinterpret_cast<const float4*>(a.gates + ((size_t)r * a.H + u) * 4);   // i, f, g, o (activated)
+    const float c = a.c_new[pos];
+    const float cp = a.c_prev[(size_t)r * a.c_prev_stride + u];
+    float dh = 0.f, dc = 0.f;
+    dh += dh_above;
+    if (a.dh_pos) dh += a.dh_pos[pos];
+    if (a.dc_pos) dc += a.dc_pos[pos];
+    const float tc = tanhf(c);
+    dc += dh * g.w * (1.f - tc * tc);
+    const float di = dc * g.z * g.x * (1.f - g.x);
+    const float df = dc * cp * g.y * (1.f - g.y);
+    const float dg = dc * g.x * (1.f - g.z * g.z);
+    const float dout = dh * tc * g.w * (1.f - g.w);
+    float* dgr = a.dgates + (size_t)r * 4 * a.H + u;
+    dgr[0] = di;
+    dgr[a.H] = df;
+    dgr[2 * a.H] = dg;
+    dgr[3 * a.H] = dout;
+    a.dc_prev[(size_t)r * a.dcp_stride + u] = dc * g.y;
+}
+
 // sum over the 16 lanes that share (lane >> 4): butterflies inside a 16-lane row
 __device__ __forceinline__ float row16_sum(float v) {
     v += __shfl_xor(v, 1);

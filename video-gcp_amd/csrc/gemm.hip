@@ -227,6 +227,8 @@ static int gemm_check(const gcpx_gemm_args* a) {
         GCPX_CHECK_ARG(a->out != nullptr, "out is NULL");
     }
     GCPX_CHECK_ARG(a->nbatch <= 1 || (a->epi != GCPX_EPI_LSTM && !a->stats_partial), "nbatch > 1 only for plain epilogues");
+    GCPX_CHECK_ARG(!a->lstm_bwd || (a->epi == GCPX_EPI_NONE && a->nbatch <= 1 && !a->stats_partial),
+                   "lstm_bwd: plain epilogue, single problem");
     return GCPX_OK;
 }
 

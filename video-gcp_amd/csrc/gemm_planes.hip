@@ -441,7 +441,7 @@ extern "C" int gcpx_gemm_planes_workspace(int32_t M, int32_t K, int32_t nbatch, 
 // gemm.hip asks: planes workspace given, split weights given, enough rows that the conversion pass pays, shapes the tiles cover
 bool gcpx_gemm_planes_applies(const gcpx_gemm_args* a) {
     static const int min_rows = [] { const char* e = getenv("GCPX_GEMM_PLANES_MIN_ROWS"); return e ? atoi(e) : 512; }();
-    if (!a->x_planes || !a->x_exp || !a->wpk_split || a->M < min_rows || a->N % 128 || a->K % 64 || a->stats_partial || a->gates_out) return false;
+    if (!a->x_planes || !a->x_exp || !a->wpk_split || a->M < min_rows || a->N % 128 || a->K % 64 || a->stats_partial || a->gates_out || a->lstm_bwd) return false;
     for (int s = 0; s < a->nsrc; ++s)
         if (a->src[s].width % 32) return false;
     int64_t need = 0;

@@ -357,7 +357,7 @@ int launch_split(const gcpx_gemm_args* a, hipStream_t stream) {
 // by the rate at which a CU pulls its operand bytes, ~10 B / cycle, not by the f32 MFMA rate: measured 24 us at 128 rows against 21 us).
 bool gcpx_gemm_split_applies(const gcpx_gemm_args* a) {
     static const int min_rows = [] { const char* e = getenv("GCPX_GEMM_SPLIT_MIN_ROWS"); return e ? atoi(e) : 512; }();
-    if (!a->wpk_split || a->M < min_rows || a->N % 64 || a->stats_partial || a->gates_out) return false;
+    if (!a->wpk_split || a->M < min_rows || a->N % 64 || a->stats_partial || a->gates_out || a->lstm_bwd) return false;
     for (int s = 0; s < a->nsrc; ++s)
         if (a->src[s].width % 64) return false;
     return true;

@@ -191,6 +191,13 @@ __device__ __forceinline__ void gemm_tile(const gcpx_gemm_args& a, const int bx,
                 if (rv[pt]) {
                     float* op = a.out + (size_t)zb * a.z_out_off + (size_t)rb[pt] * a.ob + (size_t)rj[pt] * a.orow + n;
                     *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (a.lstm_bwd) {                        // the cell backward of the layer this gradient feeds (gcpx_gemm_args.lstm_bwd)
+                        const gcpx_lstm_bwd_args& L = *a.lstm_bwd;
+                        if (n < L.H) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) lstm_bwd_cell(L, rr[pt], n + e, v[e]);
+                        }
+                    }
                     if (a.stats_partial) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }

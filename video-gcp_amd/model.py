@@ -742,7 +742,7 @@ class GCPTreeModel:
                 plan.add(nm, self.lib.gcpx_gemm, C.byref(a))
 
     def _gemm(self, plan, name, srcs, M, N, rpb, wpk, bias, out=None, ob=0, orow=0, epi=rt.EPI_NONE,
-              stats=None, lstm=None, batch=None, group=None):
+              stats=None, lstm=None, batch=None, group=None, lstm_bwd=None):
         srcs, rpb, dense = self._dense_rows(srcs, rpb, M)
         if dense:
             ob, orow = 0, ob
@@ -767,6 +767,8 @@ class GCPTreeModel:
                 plan.rec[f"gates:{name}"] = g
         if batch is not None:
             a.nbatch, a.z_src_off, a.z_w_off, a.z_bias_off, a.z_out_off = batch
+        if lstm_bwd is not None:                 # device copy of the LstmBwdArgs of the layer this gradient feeds (gcpx_gemm_args.lstm_bwd)
+            a.lstm_bwd = lstm_bwd
         if a.wpk_split and M >= getattr(self, "_planes_min_rows", 1 << 60) and N >= 1024 and group is None and not a.stats_partial and not a.gates_out:
             # many rows x many columns: conversion pass + LDS-DMA fed GEMM (csrc/gemm_planes.hip).  The workspace is shared by the launches
             # of one lane that need the same size (a lane is a stream: its launches are ordered)

@@ -55,7 +55,7 @@ class GemmArgs(C.Structure):
                 ("hb", i64), ("hrow", i64), ("h_copy", vp), ("z_src_off", i64), ("z_w_off", i64),
                 ("z_bias_off", i64), ("z_out_off", i64), ("gates_out", vp),
                 ("wpk_split", vp), ("w_split_log2_dev", vp), ("w_split_log2", i32), ("_pad_split", i32),
-                ("x_planes", vp), ("x_exp", vp), ("x_planes_bytes", i64)]
+                ("x_planes", vp), ("x_exp", vp), ("x_planes_bytes", i64), ("lstm_bwd", vp)]
 
 
 class MlpArgs(C.Structure):

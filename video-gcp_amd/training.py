@@ -97,6 +97,10 @@ class GCPTrainStep:
         # during the backward, with a hardware queue of its own (a fifth stream would share one of the four) — beside the level's
         # embedding / latent / Predictor chain on lane 0
         self.merge_on_caller_lane = os.environ.get("GCPX_NO_MERGE_LANE") is None
+        # LSTM cell backward in the epilogue of the GEMM that feeds it (gcpx_gemm_args.lstm_bwd): 3 launches per level off the chain, but
+        # the cell's dependent loads then sit behind the K loop of a launch with 32 .. 64 workgroups: c2 step 13.07 ms with, 12.91 without
+        # (tools/ab_train_attr.py fuse_lstm_bwd 1 0); gcp_sequential 24.3 either way (host issue time 10 -> 7.6 ms).  Off.
+        self.fuse_lstm_bwd = os.environ.get("GCPX_LSTM_BWD_FUSION") is not None
         self.heads_on_side_lane = os.environ.get("GCPX_NO_HEADS_ASIDE") is None
         self.batch_dh = os.environ.get("GCPX_NO_BATCH_DH") is None                 # a level's d h_prev GEMMs as one batched launch
         self.group_mlp_bwd = os.environ.get("GCPX_NO_MLP_BWD_GROUP") is None       # a level's posterior + prior backward as one launch
@@ -457,9 +461,15 @@ class GCPTrainStep:
             self._side(plan, f"bw.creduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, N, 1, dst, rt.WMAP_CONV, 1, 1, 0,
                        n_map.data_ptr(), 0, 0, 1)
 
-    def _dgemm(self, plan, tag, srcs, M, N, rpb, wpk, out, ob, orow, batch=None):
-        """data-gradient GEMM: out = concat(srcs) @ packed(W^T)"""
-        self.m._gemm(plan, f"bw.dgrad:{tag}", srcs, M, N, rpb, wpk, None, out=out, ob=ob, orow=orow, batch=batch)
+    def _dgemm(self, plan, tag, srcs, M, N, rpb, wpk, out, ob, orow, batch=None, lstm_bwd=None):
+        """data-gradient GEMM: out = concat(srcs) @ packed(W^T).  lstm_bwd: LstmBwdArgs of the LSTM layer this gradient is the d h of —
+        its cell backward then runs in the GEMM's epilogue (gcpx_gemm_args.lstm_bwd) instead of a launch of its own."""
+        dev = None
+        if lstm_bwd is not None:
+            t = torch.frombuffer(bytearray(bytes(lstm_bwd)), dtype=torch.uint8).to(self.m.device)
+            plan.keep += [t, lstm_bwd]
+            dev = t.data_ptr()
+        self.m._gemm(plan, f"bw.dgrad:{tag}", srcs, M, N, rpb, wpk, None, out=out, ob=ob, orow=orow, batch=batch, lstm_bwd=dev)
 
     def _dense(self, ptr, ld, width, M):
         return self.m._rowsrc(ptr, M * ld, ld, width)
@@ -790,35 +800,52 @@ class GCPTrainStep:
                 self._wgrad(plan, f"out{l}", dEn, 2 * s * nz, M, nz, x_top.data_ptr(), H, self.g(f"{sp}.out.weight"), ldw=H, sr=H,
                             sb=M * H, rpb=M, dy_rpb=n, dy_sb=PS * nz, dbias=self.g(f"{sp}.out.bias"))
                 dxt = buf(f"bw.dxt{l}", (M, H))
-                self._dgemm(plan, f"out{l}", [m._rowsrc(dEn, PS * nz, 2 * s * nz, nz)], M, H, n, Wt["out.wT"], dxt.data_ptr(), n * H, H)
                 merged = buf(f"merged{l}", (M, 2 * nl * H))
                 dmerged = buf(f"bw.dmerged{l}", (M, 2 * nl * H))
-                if merge_pending:
-                    plan.wait(0, MERGE_LANE)            # the level above wrote this level's d state (dHid) on the merge lane
-                    merge_pending = False
-                dh_src = dxt
                 dgs = buf(f"bw.dgates{l}", (nl, M, 4 * H))
-                for i in reversed(range(nl)):
-                    dg = dgs[i]
+                dxis = [buf(f"bw.dxi{l}.{i}", (M, H)) for i in range(nl)]
+                cells = []
+                for i in range(nl):
+                    dh_src = dxt if i == nl - 1 else dxis[i + 1]
                     a = rt.LstmBwdArgs()
                     a.gates = rec[f"gates:lstm{l}.{i}"].data_ptr()
                     a.c_prev, a.c_prev_stride = _addr(merged, (2 * i + 1) * H), 2 * nl * H
                     a.c_new, a.pb, a.prow = _addr(Hid, s * SD + (2 * i + 1) * H), PS * SD, 2 * s * SD
                     a.dh_dense, a.dh_stride = dh_src.data_ptr(), H
                     a.dh_pos, a.dc_pos = _addr(dHid, s * SD + 2 * i * H), _addr(dHid, s * SD + (2 * i + 1) * H)
-                    a.dgates, a.dc_prev, a.dcp_stride = dg.data_ptr(), _addr(dmerged, (2 * i + 1) * H), 2 * nl * H
+                    a.dgates, a.dc_prev, a.dcp_stride = dgs[i].data_ptr(), _addr(dmerged, (2 * i + 1) * H), 2 * nl * H
                     a.M, a.H, a.rpb = M, H, n
                     plan.keep.append(a)
-                    plan.add(f"bw.lstm{l}.{i}", lib.gcpx_lstm_bwd, C.byref(a))
+                    cells.append(a)
+                # each layer's cell backward rides in the epilogue of the GEMM that produces its d h (fuse_lstm_bwd): 3 launches per level
+                # less on the chain
+                fuse_cell = self.fuse_lstm_bwd
+                if merge_pending:
+                    # the level above wrote this level's d state (dHid) on the merge lane: the first cell backward reads it
+                    if not fuse_cell:
+                        self._dgemm(plan, f"out{l}", [m._rowsrc(dEn, PS * nz, 2 * s * nz, nz)], M, H, n, Wt["out.wT"], dxt.data_ptr(), n * H, H)
+                    plan.wait(0, MERGE_LANE)
+                    merge_pending = False
+                    if fuse_cell:
+                        self._dgemm(plan, f"out{l}", [m._rowsrc(dEn, PS * nz, 2 * s * nz, nz)], M, H, n, Wt["out.wT"], dxt.data_ptr(), n * H, H,
+                                    lstm_bwd=cells[nl - 1])
+                else:
+                    self._dgemm(plan, f"out{l}", [m._rowsrc(dEn, PS * nz, 2 * s * nz, nz)], M, H, n, Wt["out.wT"], dxt.data_ptr(), n * H, H,
+                                lstm_bwd=(cells[nl - 1] if fuse_cell else None))
+                for i in reversed(range(nl)):
+                    dg = dgs[i]
+                    if not fuse_cell:
+                        plan.add(f"bw.lstm{l}.{i}", lib.gcpx_lstm_bwd, C.byref(cells[i]))
                     x_i = buf(f"x{l}.{i}", (M, H))
                     self._wgrad(plan, f"lstm{l}.{i}.ih", dg.data_ptr(), 4 * H, M, 4 * H, x_i.data_ptr(), H,
                                 self.g(f"{sp}.lstm.{i}.weight_ih"), ldw=H, sr=H, sb=M * H, rpb=M,
                                 dbias=self.g(f"{sp}.lstm.{i}.bias_ih"), dbias2=self.g(f"{sp}.lstm.{i}.bias_hh"))
                     self._wgrad(plan, f"lstm{l}.{i}.hh", dg.data_ptr(), 4 * H, M, 4 * H, _addr(merged, 2 * i * H), H,
                                 self.g(f"{sp}.lstm.{i}.weight_hh"), ldw=H, sr=2 * nl * H, sb=M * 2 * nl * H, rpb=M)
-                    dxi = buf(f"bw.dxi{l}.{i}", (M, H))
+                    dxi = dxis[i]
                     src = [self._dense(dg.data_ptr(), 4 * H, 4 * H, M)]
-                    self._dgemm(plan, f"lstm{l}.{i}.x", src, M, H, M, Wt[f"lstm{i}.wxT"], dxi.data_ptr(), 0, H)
+                    self._dgemm(plan, f"lstm{l}.{i}.x", src, M, H, M, Wt[f"lstm{i}.wxT"], dxi.data_ptr(), 0, H,
+                                lstm_bwd=(cells[i - 1] if (fuse_cell and i > 0) else None))
                     if not self.batch_dh:
                         self._dgemm(plan, f"lstm{l}.{i}.h", src, M, H, M, Wt["lstm.whT"][i], _addr(dmerged, 2 * i * H), 0, 2 * nl * H)
                     dh_src = dxi

@@ -102,11 +102,11 @@ class SequentialTrainStep(GCPTrainStep):
         DX0 = buf(f"bw.{net}.dxh0", (T - 1, B, 2 * H))                                 # layer 0: kept per step (embedding weight gradient)
         dtop = buf(f"bw.{net}.dtop", (B, H))
         dcrec = [buf(f"bw.{net}.dc{i}", (B, 2 * H)) for i in range(nl)]                 # (pitch 2H: addressed with the strides of [h | c])
+        fuse_cell = self.fuse_lstm_bwd        # a layer's cell backward in the epilogue of the GEMM that produces its d h (training.py)
         for t in reversed(range(T - 1)):
             last = t == T - 2
-            self._dgemm(plan, f"{net}{t}.out", [dout_of(t)], B, H, 1, Wt["out.wT"], dtop.data_ptr(), H, 0)
-            for i in reversed(range(nl)):
-                out_i = DX0[t] if i == 0 else dxh[i - 1]
+            cells = []
+            for i in range(nl):
                 above = dtop if i == nl - 1 else dxh[i]                                 # d h_i from the layer above (its dx columns)
                 a = rt.LstmBwdArgs()
                 a.gates = rec[f"gates:{nrec['tag'][net]}{t}.lstm{i}"].data_ptr()
@@ -122,9 +122,15 @@ class SequentialTrainStep(GCPTrainStep):
                 a.dgates, a.dc_prev, a.dcp_stride = dG[i][t].data_ptr(), dcrec[i].data_ptr(), 2 * H
                 a.M, a.H, a.rpb = B, H, 1
                 plan.keep.append(a)
-                plan.add(f"bw.lstm:{net}{t}.{i}", lib.gcpx_lstm_bwd, C.byref(a))
+                cells.append(a)
+            self._dgemm(plan, f"{net}{t}.out", [dout_of(t)], B, H, 1, Wt["out.wT"], dtop.data_ptr(), H, 0,
+                        lstm_bwd=(cells[nl - 1] if fuse_cell else None))
+            for i in reversed(range(nl)):
+                out_i = DX0[t] if i == 0 else dxh[i - 1]
+                if not fuse_cell:
+                    plan.add(f"bw.lstm:{net}{t}.{i}", lib.gcpx_lstm_bwd, C.byref(cells[i]))
                 self._dgemm(plan, f"{net}{t}.lstm{i}", [self._dense(dG[i][t].data_ptr(), 4 * H, 4 * H, B)], B, 2 * H, B, Wt[f"lstm{i}.wxhT"],
-                            out_i.data_ptr(), 0, 2 * H)
+                            out_i.data_ptr(), 0, 2 * H, lstm_bwd=(cells[i - 1] if (fuse_cell and i > 0) else None))
             self._dgemm(plan, f"{net}{t}.embed", [m._rowsrc(DX0[t].data_ptr(), 2 * H, 0, H)], B, in_dim, 1, Wt["embed.wT"],
                         _addr(dIn, t * in_dim), (T - 1) * in_dim, 0)
             yield t
