@@ -16,7 +16,7 @@ args = [a for a in sys.argv[1:] if "=" not in a]
 opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
 attr, vals = args[0], [int(v) for v in args[1:]]
 rounds, steps = int(opts.get("rounds", 6)), int(opts.get("steps", 8))
-hp = V.config("c2")
+hp = V.config(opts.get("cfg", "c2"), **({"batch_size": int(opts["batch"])} if "batch" in opts else {}))
 inputs, noise, _ = make_inputs(hp, seed=0, variant="A")
 dev_in = {k: v.cuda() for k, v in inputs.items()}
 tr = GCPTrainStep(GCPTreeModel(hp, device="cuda"))
