@@ -103,6 +103,24 @@ def test_sequential_gradients_match_autograd(variant):
         assert ks and any(float(got[k].abs().max()) > 0 for k in ks), pre
 
 
+def test_sequential_cell_backward_in_the_gemm_epilogue_gives_the_same_gradient():
+    """fuse_lstm_bwd (off by default: it does not pay, NOTEBOOK round 4): every LSTM cell backward of the 79-step chains rides in the
+    epilogue of the data-gradient GEMM that feeds it (gcpx_gemm_args.lstm_bwd) — the same device function on the same values: the
+    gradient of the plain plan, bit for bit."""
+    hp, sd, model, tr = _train_setup(False)
+    _, _, model2, tr2 = _train_setup(False)
+    tr2.fuse_lstm_bwd = True
+    inputs, noise, _ = make_inputs(hp, seed=7, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    tr.backward(dev_in, noise.cuda())
+    tr2.backward(dev_in, noise.cuda())
+    torch.cuda.synchronize()
+    n1 = sum(1 for op in tr.last_bplan.ops if not op[0].startswith("@"))
+    n2 = sum(1 for op in tr2.last_bplan.ops if not op[0].startswith("@"))
+    assert n1 - n2 >= 3 * (hp.max_seq_len - 1), (n1, n2)
+    assert torch.equal(tr.grad, tr2.grad)
+
+
 def test_sequential_two_training_steps():
     """losses of two consecutive optimisation steps and the updated parameters against the oracle loop (RAdam)"""
     from oracle import gcp_sequential_oracle as S

@@ -220,6 +220,22 @@ def test_grouped_level_launches_give_the_gradient_of_single_launches():
         assert torch.equal(gb[k], gc[k]), k
 
 
+def test_cell_backward_in_the_gemm_epilogue_gives_the_same_gradient():
+    """fuse_lstm_bwd (off by default) on the tree: 3 launches per level fewer, the same gradient bit for bit"""
+    hp, sd, ma, ta = _setup("c1", False)
+    _, _, mb, tb = _setup("c1", False)
+    tb.fuse_lstm_bwd = True
+    inputs, noise, _ = make_inputs(hp, seed=43, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    ta.backward(dev_in, noise.cuda())
+    tb.backward(dev_in, noise.cuda())
+    torch.cuda.synchronize()
+    na = sum(1 for op in ta.last_bplan.ops if not op[0].startswith("@"))
+    nb = sum(1 for op in tb.last_bplan.ops if not op[0].startswith("@"))
+    assert na - nb == hp.n_lstm_layers * hp.hierarchy_levels, (na, nb)
+    assert torch.equal(ta.grad, tb.grad)
+
+
 def test_two_training_steps_c1():
     """losses of two consecutive optimisation steps and the updated parameters against the oracle loop"""
     from oracle import gcp_model_oracle as O
