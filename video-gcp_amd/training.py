@@ -77,6 +77,7 @@ class GCPTrainStep:
         self.early_blocks = int(os.environ.get("GCPX_EARLY_BLOCKS", "0"))
         self.early_on_caller = os.environ.get("GCPX_EARLY_STREAM", "caller") == "caller"     # else: communication stream / last side lane
         self._early_on, self._applied, self._caller = False, set(), None
+        self.split_dgrad_wide = os.environ.get("GCPX_NO_SPLIT_DGRAD_WIDE") is None     # data gradients of the 32- / 64-channel decoder blocks on the split-f16 kernel
         self.bk = model.build_arena(self._pack_backward)
         self._pack_backward_split()
         self._bplans = {}
@@ -102,6 +103,7 @@ class GCPTrainStep:
         # (tools/ab_train_attr.py fuse_lstm_bwd 1 0); gcp_sequential 24.3 either way (host issue time 10 -> 7.6 ms).  Off.
         self.fuse_lstm_bwd = os.environ.get("GCPX_LSTM_BWD_FUSION") is not None
         self.heads_on_side_lane = os.environ.get("GCPX_NO_HEADS_ASIDE") is None
+
         self.batch_dh = os.environ.get("GCPX_NO_BATCH_DH") is None                 # a level's d h_prev GEMMs as one batched launch
         self.group_mlp_bwd = os.environ.get("GCPX_NO_MLP_BWD_GROUP") is None       # a level's posterior + prior backward as one launch
         self.early_fork = os.environ.get("GCPX_EARLY_FORK") is not None   # measured: forking the head's weight gradient before its data gradient costs 0.25 ms (contention on the critical lane)
@@ -181,6 +183,12 @@ class GCPTrainStep:
         for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
             if cout == 16 and c_prev + c_skip == 32:
                 todo[f"bw.dec.{name}"] = ids_of(f"decoder.net.{name}.conv.weight").flip(2, 3).transpose(0, 1).contiguous()
+            elif self.split_dgrad_wide and cout % 16 == 0 and (c_prev + c_skip) % 32 == 0:
+                # wider blocks: 32 of the block's input channels per launch on the same kernel (conv3x3_wave_split_kernel<2>: the exact
+                # f32 tiles they ran on take 3x the MFMA time), where the frame is >= 16 wide (_decoder_backward)
+                wT = ids_of(f"decoder.net.{name}.conv.weight").flip(2, 3).transpose(0, 1).contiguous()          # [cin, cout, 3, 3]
+                for h in range((c_prev + c_skip) // 32):
+                    todo[f"bw.dec.{name}.q{h}"] = wT[32 * h:32 * (h + 1)].contiguous()
         for name, wT in todo.items():
             idx = (pk.conv3x3_split_gather(wT).reshape(-1) - 1).to(torch.int32).to(m.device)
             m.pk_split[name] = dict(idx=idx, out=torch.zeros(2 * idx.numel(), dtype=torch.int16, device=m.device),
@@ -205,6 +213,10 @@ class GCPTrainStep:
             cin = wT.shape[0]
             for h in range((cin + 63) // 64):
                 X[f"dec.{name}.wT{h}"] = pk.pack_conv3x3(wT[64 * h:64 * (h + 1)], 16)
+            if self.split_dgrad_wide and m.split_f16 and cin % 32 == 0 and not (cout == 16 and cin == 32):
+                # (the f32 twin of the 32-channel launches of _decoder_backward: what the launch falls back to if its split form does not fit)
+                for h in range(cin // 32):
+                    X[f"dec.{name}.wTq{h}"] = pk.pack_conv3x3(wT[32 * h:32 * (h + 1)], 16)
         hw = sd["decoder.gen_head.conv.weight"]                              # [100, 16, 3, 3]; inputs of the dgrad = kernel slots
         perm = torch.as_tensor(pk.dlm_channel_perm(hp.n_mixtures), device=hw.device)
         wk = torch.zeros((len(perm),) + tuple(hw.shape[1:]), dtype=hw.dtype, device=hw.device)
@@ -1167,7 +1179,18 @@ class GCPTrainStep:
             if self.early_fork:
                 self._flush(plan)
             dU = buf(f"bw.dU.{name}", (F, res, res, cin))
-            for h in range((cin + 63) // 64):
+            quarters = (self.split_dgrad_wide and m.split_f16 and res % 16 == 0 and res >= 16 and cin % 32 == 0 and cout % 16 == 0 and
+                        f"bw.dec.{name}.q0" in getattr(m, "pk_split", {}) and f"dec.{name}.wTq0" in self.bk)
+            for h in range(cin // 32 if quarters else (cin + 63) // 64):
+                if quarters:
+                    # 32 output channels per launch on the split-f16 wave kernel (its f32 pack is not read: any valid pointer)
+                    a = m._conv_args([(dy.data_ptr(), cout, 1, None, None, rt.ACT_NONE)], F, res, res, res, res, 32, cin,
+                                     self.bk[f"dec.{name}.wTq{h}"], self._zeros, dU)
+                    a.out = dU.data_ptr() + 4 * 32 * h
+                    m._set_split(a, f"bw.dec.{name}.q{h}")
+                    plan.keep.append(a)
+                    plan.add(f"bw.dgrad:dec.{name}.q{h}", lib.gcpx_conv3x3, C.byref(a))
+                    continue
                 ch = min(64, cin - 64 * h)
                 a = m._conv_args([(dy.data_ptr(), cout, 1, None, None, rt.ACT_NONE)], F, res, res, res, res, ch, cin,
                                  self.bk[f"dec.{name}.wT{h}"], self._zeros, dU)
