@@ -18,6 +18,24 @@ def _free_port():
     return p
 
 
+def _wire(x):
+    """what a rank puts on the queue: tensors as numpy arrays (a torch tensor travels as a file descriptor the SENDER must keep open until
+    the parent has received it — a rank that exits first leaves the parent with EOFError; seen with a cold bytecode cache)"""
+    if torch.is_tensor(x):
+        return ("__tensor__", x.detach().cpu().numpy())
+    if isinstance(x, (list, tuple)):
+        return type(x)(_wire(v) for v in x)
+    return x
+
+
+def _unwire(x):
+    if isinstance(x, tuple) and len(x) == 2 and isinstance(x[0], str) and x[0] == "__tensor__":
+        return torch.from_numpy(x[1])
+    if isinstance(x, (list, tuple)):
+        return type(x)(_unwire(v) for v in x)
+    return x
+
+
 def _run_ranks(worker, world=2, attempts=3):
     """start `world` spawned processes of worker(rank, world, port, queue) and return what each put on the queue.  The rendezvous is
     infrastructure (a port that was free a moment ago, process start-up under load): a run whose workers do not ALL deliver and exit
@@ -43,7 +61,7 @@ def _run_ranks(worker, world=2, attempts=3):
                 p.kill()                               # (exactly this process: never by pattern)
                 p.join(10)
         if len(res) == world and all(p.exitcode == 0 for p in procs):
-            return res
+            return [_unwire(r) for r in res]
         last = last or f"exit codes {[p.exitcode for p in procs]}"
     raise AssertionError(f"the {world}-rank run failed three times: {last}")
 
@@ -94,7 +112,7 @@ def _grad_worker(rank, world, port, q):
         grad = torch.randn(1000, generator=gl)
         scale = D.all_reduce_sum_(grad)
         opt.step(theta, {"p": grad * scale})
-    q.put((rank, theta["p"].clone()))
+    q.put(_wire((rank, theta["p"].clone())))
     torch.distributed.destroy_process_group()
 
 
@@ -155,7 +173,7 @@ def _bucket_worker(rank, world, port, q):
         scale = b.finish()
         assert scale == 0.5 and not b.works
         outs.append(flat.clone())
-    q.put((rank, outs))
+    q.put(_wire((rank, outs)))
     torch.distributed.destroy_process_group()
 
 
@@ -217,7 +235,7 @@ def _rebackward_worker(rank, world, port, q):
     # slices must not be summed over the ranks again (round-3 advisor finding)
     assert tr.buckets.finish() == scale and torch.equal(tr.grad, once)
     outs.append((scale, tr.grad.clone()))
-    q.put((rank, outs))
+    q.put(_wire((rank, outs)))
     torch.distributed.destroy_process_group()
 
 

@@ -607,6 +607,7 @@ class GCPTreeModel:
                 rt.check(self.lib.gcpx_repack_blocks(self.theta.data_ptr(), self._arena_idx0.data_ptr() + 4 * off,
                                                      (self._arena_idx1.data_ptr() + 4 * off) if two else None, self._arena.data_ptr() + 4 * off,
                                                      cnt, max_blocks, st), "repack")
+            self._repack_gsplit(st, bucket)
             if bucket == self._arena_ranges[-1][0]:
                 self.repack_split(st)
             return
@@ -617,7 +618,15 @@ class GCPTreeModel:
         if sp < n:
             rt.check(self.lib.gcpx_repack(self.theta.data_ptr(), self._arena_idx0.data_ptr() + 4 * sp, self._arena_idx1.data_ptr() + 4 * sp,
                                           self._arena.data_ptr() + 4 * sp, n - sp, st), "repack")
+        self._repack_gsplit(st, None)
         self.repack_split(st)
+
+    def _repack_gsplit(self, st, bucket):
+        """re-split the GEMM weights a trainer keeps in split-f16 form (training.py: _live_gemm_split) that gather from `bucket`'s slice of
+        the flat vector (None: all of them)"""
+        for name, (tab, n, scratch) in getattr(self, "_gsplit_tabs", {}).items():
+            if bucket is None or bucket == name:
+                rt.check(self.lib.gcpx_split_pack_group2(tab.data_ptr(), n, scratch.data_ptr(), st), "split_pack_group2")
 
     def _pack_hsp(self, prefix, n_layers):
         """embed Linear + n gate-interleaved LSTM layers + out Linear of one recurrent predictor."""
@@ -755,7 +764,8 @@ class GCPTreeModel:
         a.nsrc, a.M, a.N, a.K, a.rpb = len(srcs), M, N, sum(s.width for s in srcs), rpb
         a.wpk, a.bias = wpk.data_ptr(), (bias.data_ptr() if bias is not None else None)
         gs = getattr(self, "_gsplit", {}).get(wpk.data_ptr())
-        if gs is not None and self.split_f16 and getattr(self, "_arena", None) is None:
+        # (a trainer's model: only packs the trainer re-splits behind every optimizer step — training.py: _live_gemm_split)
+        if gs is not None and self.split_f16 and (getattr(self, "_arena", None) is None or getattr(self, "_gsplit_live", False)):
             a.wpk_split, a.w_split_log2_dev = gs[0].data_ptr(), gs[1].data_ptr()
         a.out, a.ob, a.orow, a.epi = out, ob, orow, epi
         a.stats_partial = stats.data_ptr() if stats is not None else None

@@ -80,6 +80,7 @@ class GCPTrainStep:
         self.split_dgrad_wide = os.environ.get("GCPX_NO_SPLIT_DGRAD_WIDE") is None     # data gradients of the 32- / 64-channel decoder blocks on the split-f16 kernel
         self.bk = model.build_arena(self._pack_backward)
         self._pack_backward_split()
+        self._live_gemm_split()
         self._bplans = {}
         # backward plans are built from forward plans: drop them whenever the model drops those (load_state_dict, build_arena)
         model._plan_listeners = getattr(model, "_plan_listeners", []) + [self._bplans.clear]
@@ -194,6 +195,59 @@ class GCPTrainStep:
             m.pk_split[name] = dict(idx=idx, out=torch.zeros(2 * idx.numel(), dtype=torch.int16, device=m.device),
                                     log2=torch.zeros(1, dtype=torch.int32, device=m.device))
         m.repack_split()
+
+    def _live_gemm_split(self):
+        """The GEMM weights of the tree levels that run with >= 512 rows at the configured batch size, kept in split-f16 form ALSO in
+        training (the inference model splits them once at weight load, model._pack_gemm_split): their forward merge / output GEMMs and every
+        data-gradient GEMM of those levels then run on the split-f16 kernels (3x the f32 MFMA rate) instead of the exact f32 tiles.  Each
+        pack is an index gather of the flat parameter vector — the arena's index map pushed through packing.unpack_gemm / gemm_split_gather —
+        re-split by gcpx_split_pack_group2 with the slice of the optimizer step it belongs to (model.repack(bucket=): under the encoder
+        backward, like the slice itself)."""
+        m, hp = self.m, self.m._hp
+        m._gsplit, m._gsplit_tabs, m._gsplit_live = {}, {}, False
+        if not (m.split_f16 and hp.tree_lstm and os.environ.get("GCPX_NO_LIVE_GEMM_SPLIT") is None):
+            return
+        min_rows = int(os.environ.get("GCPX_GEMM_SPLIT_MIN_ROWS", "512"))
+        L = hp.hierarchy_levels
+        levels = [l for l in range(L) if hp.batch_size * 2 ** l >= min_rows]
+        if not hp.untied_layers:
+            levels = [0] if levels else []
+        base = m._arena.data_ptr()
+        descs = {}
+        keep = []
+        for l in levels:
+            bucket = f"tree{l}" if (hp.untied_layers and l >= 1 and len(m._arena_ranges) > 1) else m._arena_ranges[-1][0]
+            import re
+            fwd = lambda k: k in ("proj.w", "out.w", "embed.w") or re.fullmatch(r"lstm\d+\.w", k)
+            bwd = lambda k: k in ("proj.wT", "out.wT", "embed.wT", "lstm.whT") or re.fullmatch(r"lstm\d+\.wxT", k)
+            leaves = [(k, v) for k, v in m.pk[f"tree{l}"].items() if torch.is_tensor(v) and fwd(k)]
+            leaves += [(k, v) for k, v in self.bk[f"tree{l}"].items() if torch.is_tensor(v) and bwd(k)]
+            for k, leaf in leaves:
+                stack = leaf if leaf.dim() == 5 else leaf[None]
+                KG, NT = stack.shape[1], stack.shape[2]
+                N, K = NT * 16, KG * 16
+                if K % 64 or N % 64:
+                    continue
+                off = (leaf.data_ptr() - base) // 4
+                idx0 = m._arena_idx0[off:off + leaf.numel()].view(stack.shape).to(torch.int64)
+                n_el = N * K
+                ws = torch.zeros(stack.shape[0], 2 * n_el, dtype=torch.int16, device=m.device)
+                es = torch.zeros(stack.shape[0], dtype=torch.int32, device=m.device)
+                for b in range(stack.shape[0]):
+                    ids = pk.gemm_split_gather(pk.unpack_gemm(idx0[b] + 1, N)).reshape(-1) - 1          # (-1: a zero-padded slot)
+                    ids = ids.to(torch.int32).contiguous()
+                    e = rt.SplitPackDesc()
+                    e.src, e.idx, e.out, e.log2_out, e.n = m.theta.data_ptr(), ids.data_ptr(), ws[b].data_ptr(), es[b:b + 1].data_ptr(), n_el
+                    descs.setdefault(bucket, []).append(e)
+                    keep.append(ids)
+                m._gsplit[leaf.data_ptr()] = (ws, es)
+        self._gsplit_keep = keep
+        for bucket, ds in descs.items():
+            arr = (rt.SplitPackDesc * len(ds))(*ds)
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(m.device)
+            m._gsplit_tabs[bucket] = (dev, len(ds), torch.zeros(len(ds), dtype=torch.int32, device=m.device))
+        m._gsplit_live = bool(descs)
+        m._repack_gsplit(torch.cuda.current_stream(m.device).cuda_stream, None)
 
     def _pack_backward(self, sd):
         m, hp = self.m, self.m._hp
