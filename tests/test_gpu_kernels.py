@@ -1856,6 +1856,12 @@ def test_gemm_planes_lstm_sources_and_batches(env):
         a.wpk, a.bias, a.epi = wp.data_ptr(), bd.data_ptr(), rt.EPI_LSTM
         a.wpk_split, a.w_split_log2 = ws.data_ptr(), e
         a.c_prev, a.c_prev_stride, a.h_out, a.c_out, a.hb, a.hrow, a.h_copy = cdb.data_ptr(), H, hob.data_ptr(), cob.data_ptr(), 0, H, hcb.data_ptr()
+        # gates_out (the training forward keeps the activated gates for the backward pass): written by the planes form's epilogue ...
+        gob = torch.full((Mb, H, 4), float("nan"), device=dev)
+        a.gates_out = gob.data_ptr()
+        with torch.no_grad():
+            pre = (F.linear(xb_, cell.weight_ih, cell.bias_ih) + F.linear(hb_, cell.weight_hh, cell.bias_hh)).view(Mb, 4, H)
+            gates_ref = torch.stack([torch.sigmoid(pre[:, 0]), torch.sigmoid(pre[:, 1]), torch.tanh(pre[:, 2]), torch.sigmoid(pre[:, 3])], 2)
         keep = _planes_workspace(rt, lib, a, dev)
         rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm planes lstm")
         torch.cuda.synchronize()
@@ -1863,6 +1869,14 @@ def test_gemm_planes_lstm_sources_and_batches(env):
         assert_close(hob, h1b, atol=1e-5, name=f"h, {Mb} rows")
         assert_close(cob, c1b, atol=1e-5, name=f"c, {Mb} rows")
         assert_close(hcb, h1b, atol=1e-5, name=f"h_copy, {Mb} rows")
+        assert_close(gob, gates_ref, atol=1e-5, name=f"gates, {Mb} rows")
+        # ... and by the one-launch split form's (no workspace)
+        a.x_planes, a.x_exp, a.x_planes_bytes = None, None, 0
+        gob.fill_(float("nan")); hob.fill_(float("nan"))
+        rt.check(lib.gcpx_gemm(C.byref(a), _stream()), "gemm split lstm")
+        torch.cuda.synchronize()
+        assert_close(hob, h1b, atol=1e-5, name=f"h (split), {Mb} rows")
+        assert_close(gob, gates_ref, atol=1e-5, name=f"gates (split), {Mb} rows")
     # conv1d-over-time form
     B, T, Cc, N = 16, 40, 64, 128
     xs = torch.randn(B, T, Cc)

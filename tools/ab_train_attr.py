@@ -20,11 +20,15 @@ hp = V.config(opts.get("cfg", "c2"), **({"batch_size": int(opts["batch"])} if "b
 inputs, noise, _ = make_inputs(hp, seed=0, variant="A")
 dev_in = {k: v.cuda() for k, v in inputs.items()}
 tr = GCPTrainStep(GCPTreeModel(hp, device="cuda"))
-assert hasattr(tr, attr), attr
+on_model = attr.startswith("m.")              # "m.NAME": an attribute of the model (forward plans are rebuilt too)
+obj, attr_ = (tr.m, attr[2:]) if on_model else (tr, attr)
+assert hasattr(obj, attr_), attr
 res = {v: [] for v in vals}
 for r in range(rounds):
     for v in (vals if r % 2 == 0 else vals[::-1]):
-        setattr(tr, attr, v)
+        setattr(obj, attr_, v)
+        if on_model:
+            tr.m._clear_plans()
         tr._bplans.clear()
         for _ in range(2):
             tr.step(dev_in)

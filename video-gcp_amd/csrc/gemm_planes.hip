@@ -345,6 +345,8 @@ __global__ void __launch_bounds__(64 * NW) gemm_planes_kernel(const gcpx_gemm_ar
                     const float gg = tanh_hw(fmaf(v[2], inv, bv[c].z)), og = sigmoid_hw(fmaf(v[3], inv, bv[c].w));
                     cv[c] = fg * cp[c] + ig * gg;
                     hv[c] = og * tanh_hw(cv[c]);
+                    if (a.gates_out && rv)                        // (training forward: the activated gates of unit 4 (nt0 + c) + q, kept for the backward)
+                        *reinterpret_cast<float4*>(a.gates_out + ((size_t)r * (a.N / 4) + (nt0 + c) * 4 + q) * 4) = make_float4(ig, fg, gg, og);
                 }
                 transpose4_rows(hv);
                 transpose4_rows(cv);
@@ -386,6 +388,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_planes_kernel(const gcpx_gemm_ar
                 const size_t o = (size_t)rb * a.hb + (size_t)rj * a.hrow + u;
                 a.h_out[o] = h;
                 a.c_out[o] = cn;
+                if (a.gates_out) *reinterpret_cast<float4*>(a.gates_out + ((size_t)r * (a.N / 4) + u) * 4) = make_float4(ig, fg, gg, og);
 #ifndef GP_TRACE
                 if (a.h_copy) a.h_copy[(size_t)r * (a.N / 4) + u] = h;
 #endif
@@ -441,7 +444,7 @@ extern "C" int gcpx_gemm_planes_workspace(int32_t M, int32_t K, int32_t nbatch, 
 // gemm.hip asks: planes workspace given, split weights given, enough rows that the conversion pass pays, shapes the tiles cover
 bool gcpx_gemm_planes_applies(const gcpx_gemm_args* a) {
     static const int min_rows = [] { const char* e = getenv("GCPX_GEMM_PLANES_MIN_ROWS"); return e ? atoi(e) : 512; }();
-    if (!a->x_planes || !a->x_exp || !a->wpk_split || a->M < min_rows || a->N % 128 || a->K % 64 || a->stats_partial || a->gates_out || a->lstm_bwd) return false;
+    if (!a->x_planes || !a->x_exp || !a->wpk_split || a->M < min_rows || a->N % 128 || a->K % 64 || a->stats_partial || a->lstm_bwd) return false;
     for (int s = 0; s < a->nsrc; ++s)
         if (a->src[s].width % 32) return false;
     int64_t need = 0;

@@ -312,6 +312,8 @@ __global__ void __launch_bounds__(64 * NW) gemm_split_kernel(const gcpx_gemm_arg
                 a.h_out[o] = h;
                 a.c_out[o] = cn;
                 if (a.h_copy) a.h_copy[(size_t)r * (a.N / 4) + u] = h;
+                if (a.gates_out)                                   // (training forward: the activated gates, kept for the backward pass)
+                    *reinterpret_cast<float4*>(a.gates_out + ((size_t)r * (a.N / 4) + u) * 4) = make_float4(ig, fg, gg, og);
             } else {
                 if (a.epi == GCPX_EPI_LRELU) {
                     v[0] = lrelu(v[0], 0.2f); v[1] = lrelu(v[1], 0.2f); v[2] = lrelu(v[2], 0.2f); v[3] = lrelu(v[3], 0.2f);
@@ -357,7 +359,7 @@ int launch_split(const gcpx_gemm_args* a, hipStream_t stream) {
 // by the rate at which a CU pulls its operand bytes, ~10 B / cycle, not by the f32 MFMA rate: measured 24 us at 128 rows against 21 us).
 bool gcpx_gemm_split_applies(const gcpx_gemm_args* a) {
     static const int min_rows = [] { const char* e = getenv("GCPX_GEMM_SPLIT_MIN_ROWS"); return e ? atoi(e) : 512; }();
-    if (!a->wpk_split || a->M < min_rows || a->N % 64 || a->stats_partial || a->gates_out || a->lstm_bwd) return false;
+    if (!a->wpk_split || a->M < min_rows || a->N % 64 || a->stats_partial || a->lstm_bwd) return false;
     for (int s = 0; s < a->nsrc; ++s)
         if (a->src[s].width % 64) return false;
     return true;

@@ -779,7 +779,7 @@ class GCPTreeModel:
             a.nbatch, a.z_src_off, a.z_w_off, a.z_bias_off, a.z_out_off = batch
         if lstm_bwd is not None:                 # device copy of the LstmBwdArgs of the layer this gradient feeds (gcpx_gemm_args.lstm_bwd)
             a.lstm_bwd = lstm_bwd
-        if a.wpk_split and M >= getattr(self, "_planes_min_rows", 1 << 60) and N >= 1024 and group is None and not a.stats_partial and not a.gates_out:
+        if a.wpk_split and M >= getattr(self, "_planes_min_rows", 1 << 60) and N >= 1024 and group is None and not a.stats_partial:
             # many rows x many columns: conversion pass + LDS-DMA fed GEMM (csrc/gemm_planes.hip).  The workspace is shared by the launches
             # of one lane that need the same size (a lane is a stream: its launches are ordered)
             nbytes, nexp = C.c_int64(), C.c_int64()
