@@ -135,6 +135,8 @@ class GCPTreeModel:
     _has_pred_length = True       # val_mode(pred_length=True) draws the sequence length (base_gcp.py:219-226)
     _rng_in_plan = True           # the latent noise / index draws of a forward without fed noise are an op of the plan (gcpx_randn)
 
+    _stream_pool = {}           # (device index, main-stream priority) -> (torch stream, [lane streams]): shared by all models of the process
+
     def __init__(self, hp: GCPHParams, params=None, device="cuda", seed=0, materialize_distr=False):
         self._hp = hp
         self.device = torch.device(device)
@@ -155,13 +157,25 @@ class GCPTreeModel:
         self.use_graph = {"graph": True, "eager": False}.get(os.environ.get("GCPX_FORWARD_REPLAY", "auto"), "auto")
         # hipGraph capture is not allowed on the legacy default stream: the model launches on its own stream
         # and orders it against the caller's current stream with events (wait_stream), never a host sync
-        self._stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("GCPX_MAIN_PRIORITY", "0")))
-        self._streams = [self._stream.cuda_stream]
-        for _ in range(N_LANES - 1):
-            sp = C.c_void_p()
-            with torch.cuda.device(self.device):
-                rt.check(self.lib.gcpx_stream_create(C.byref(sp)), "stream_create")
-            self._streams.append(sp)
+        # Every model of a process on one device shares ONE set of lanes: the runtime deals streams onto its four hardware queues in
+        # creation order, and a second model's lanes land on other queues than the first one's — its training step then ran 1.5-2.3 ms
+        # slower (13.6 / 15.1 / 13.6 / 15.9 ms for four trainers built in a row, tools/ab_train_inproc.py): lanes that share a queue with
+        # each other or with the caller's stream serialise.  Models of one process are not run concurrently (their launches would be
+        # ordered by the shared streams); GCPX_PRIVATE_STREAMS=1 gives every model its own.
+        pool_key = (self.device.index, os.environ.get("GCPX_MAIN_PRIORITY", "0"))
+        pool = None if os.environ.get("GCPX_PRIVATE_STREAMS") else GCPTreeModel._stream_pool.get(pool_key)
+        if pool is None:
+            main = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("GCPX_MAIN_PRIORITY", "0")))
+            lanes = [main.cuda_stream]
+            for _ in range(N_LANES - 1):
+                sp = C.c_void_p()
+                with torch.cuda.device(self.device):
+                    rt.check(self.lib.gcpx_stream_create(C.byref(sp)), "stream_create")
+                lanes.append(sp)
+            pool = (main, lanes)
+            if not os.environ.get("GCPX_PRIVATE_STREAMS"):
+                GCPTreeModel._stream_pool[pool_key] = pool
+        self._stream, self._streams = pool[0], list(pool[1])
         self._set_kl_weight()
         self.save_for_backward = False        # training step: forward plans keep what the backward pass needs
         # split-f16 convs (csrc/conv3x3_split.hip): f32-equivalent results on the f16 matrix pipes.  GCPX_EXACT_F32=1 keeps every

@@ -209,7 +209,7 @@ class GCPTrainStep:
             return
         min_rows = int(os.environ.get("GCPX_GEMM_SPLIT_MIN_ROWS", "512"))
         L = hp.hierarchy_levels
-        levels = [l for l in range(L) if hp.batch_size * 2 ** l >= min_rows]
+        levels = [l for l in range(L) if hp.batch_size * 2 ** l >= min_rows and f"tree{l}" in m.pk and f"tree{l}" in self.bk]
         if not hp.untied_layers:
             levels = [0] if levels else []
         base = m._arena.data_ptr()
