@@ -735,7 +735,18 @@ class GCPTrainStep:
         dE, dHid = buf("bw.dE", (B, PS, nz)), buf("bw.dHid", (B, PS, SD))
         dET = buf("bw.dET", (B, PS, nz))
         dQZ, dPZ = buf("bw.dQZ", (B, PS, 2 * nv)), buf("bw.dPZ", (B, PS, 2 * nv))
-        zero(self.grad); zero(dE); zero(dHid)
+        zero(dE); zero(dHid)
+        if self.side_lanes and self.n_side >= 2 and not hp.adaptive:
+            # the 293 MB gradient vector is cleared on lane 2 (lane 1 waits for it once; lane 0's first gradient write — the BatchNorm
+            # parameter sums behind the head's data gradient — waits there, _decoder_backward): 54 us less in front of the decoder's chain
+            plan.rec["zero_on_lane2"] = True
+            plan.fork([2])
+            plan.lane = 2
+            zero(self.grad)
+            plan.lane = 0
+            plan.wait(1, 2)
+        else:
+            zero(self.grad)
 
         # ---- loss gradients (base_gcp.py:264-304) ----
         la = rec["loss_args"]
@@ -1204,6 +1215,8 @@ class GCPTrainStep:
             head_fused = (dA, st_h, nb_h)
         plan.keep.append(a)
         plan.add("bw.dgrad:dec.head", lib.gcpx_conv3x3, C.byref(a))
+        if plan.rec.get("zero_on_lane2"):
+            plan.wait(0, 2)                      # (the gradient vector is cleared there: _build_backward)
 
         gin = (dA.data_ptr(), ngf, 0)            # (pointer, channel pitch, upsampled?) of the incoming gradient
         dskip = {}
