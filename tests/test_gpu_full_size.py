@@ -237,6 +237,29 @@ def test_c3_training_shard_batch16_steps_reduce_loss():
     assert vals[-1][5] < vals[0][5], vals                      # total
     assert vals[-1][0] < vals[0][0]                            # reconstruction NLL
     assert vals[-1][8] < vals[0][8] and vals[-1][7] < vals[0][7]     # cost model and inverse model are being trained
+    # The wide levels' GEMM weights are kept in split-f16 form by the trainer and re-split with their optimizer slice (training.py:
+    # _live_gemm_split): after six steps every such pack is the split of the CURRENT weights — the pieces and the exponent that
+    # packing.pack_gemm_split makes of the f32 pack the same launch re-gathered — bit for bit; a stale pack (a slice re-packed but not
+    # re-split, a wrong index map) shows here
+    from video_gcp_amd import packing as pk
+    assert model._gsplit_live and model._gsplit, "levels 5 and 6 run with >= 512 rows at batch 16"
+    leaves = {}
+    for tree in list(model.pk.values()) + list(tr.bk.values()):
+        if isinstance(tree, dict):
+            for k, v in tree.items():
+                if torch.is_tensor(v) and v.data_ptr() in model._gsplit:
+                    leaves[v.data_ptr()] = (k, v)
+    assert len(leaves) == len(model._gsplit)
+    checked = 0
+    for ptr, (k, leaf) in leaves.items():
+        ws, es = model._gsplit[ptr]
+        stack = leaf if leaf.dim() == 5 else leaf[None]
+        for b in range(stack.shape[0]):
+            want, e = pk.pack_gemm_split(pk.unpack_gemm(stack[b].cpu(), stack.shape[2] * 16))
+            assert int(es[b]) == e, (k, b)
+            assert torch.equal(ws[b].cpu().view(-1), want.view(-1)), (k, b)
+            checked += 1
+    assert checked >= 2 * (3 + 6 + 2)             # per level: 3 LSTM layers, 6 projections, embedding / output, and their transposes
 
 
 # ------------------------------------------------------------------------------------------------------------------------
