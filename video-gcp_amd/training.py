@@ -103,6 +103,7 @@ class GCPTrainStep:
         # the cell's dependent loads then sit behind the K loop of a launch with 32 .. 64 workgroups: c2 step 13.07 ms with, 12.91 without
         # (tools/ab_train_attr.py fuse_lstm_bwd 1 0); gcp_sequential 24.3 either way (host issue time 10 -> 7.6 ms).  Off.
         self.fuse_lstm_bwd = os.environ.get("GCPX_LSTM_BWD_FUSION") is not None
+        self.zero_on_side_lane = os.environ.get("GCPX_ZERO_ON_LANE0") is None
         self.heads_on_side_lane = os.environ.get("GCPX_NO_HEADS_ASIDE") is None
 
         self.batch_dh = os.environ.get("GCPX_NO_BATCH_DH") is None                 # a level's d h_prev GEMMs as one batched launch
@@ -736,7 +737,7 @@ class GCPTrainStep:
         dET = buf("bw.dET", (B, PS, nz))
         dQZ, dPZ = buf("bw.dQZ", (B, PS, 2 * nv)), buf("bw.dPZ", (B, PS, 2 * nv))
         zero(dE); zero(dHid)
-        if self.side_lanes and self.n_side >= 2 and not hp.adaptive:
+        if self.zero_on_side_lane and self.side_lanes and self.n_side >= 2 and not hp.adaptive:
             # the 293 MB gradient vector is cleared on lane 2 (lane 1 waits for it once; lane 0's first gradient write — the BatchNorm
             # parameter sums behind the head's data gradient — waits there, _decoder_backward): 54 us less in front of the decoder's chain
             plan.rec["zero_on_lane2"] = True
