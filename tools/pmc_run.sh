@@ -33,4 +33,5 @@ with open(f"{out}/{tag}_pmc.txt", "w") as fh:
 print(open(f"{out}/{tag}_pmc.txt").read())
 PYEOF
 cp "$OUT/${TAG}_stats"/*kernel_stats.csv "$OUT/${TAG}_stats.csv" 2>/dev/null
-rm -rf "$OUT"/${TAG}_pmc_*/*.db "$OUT"/${TAG}_stats/*.db
+# gpurun_out/ is capped at 64 MiB: the raw counter tables stay on the GPU box, the summaries travel
+rm -rf "$OUT"/${TAG}_pmc_[0-9]* "$OUT"/${TAG}_stats
