@@ -17,6 +17,7 @@ call over one buffer) and the optimizer + the re-pack of the MFM
 """
 import ctypes as C
 import os
+import re
 
 import torch
 
@@ -218,7 +219,7 @@ class GCPTrainStep:
         keep = []
         for l in levels:
             bucket = f"tree{l}" if (hp.untied_layers and l >= 1 and len(m._arena_ranges) > 1) else m._arena_ranges[-1][0]
-            import re
+
             fwd = lambda k: k in ("proj.w", "out.w", "embed.w") or re.fullmatch(r"lstm\d+\.w", k)
             bwd = lambda k: k in ("proj.wT", "out.wT", "embed.wT", "lstm.whT") or re.fullmatch(r"lstm\d+\.wxT", k)
             leaves = [(k, v) for k, v in m.pk[f"tree{l}"].items() if torch.is_tensor(v) and fwd(k)]
