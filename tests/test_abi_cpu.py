@@ -95,3 +95,12 @@ def test_invalid_args_are_rejected_without_a_gpu(lib):
     assert lib.gcpx_lstm_bwd(C.byref(rt.LstmBwdArgs()), None) == -1
     assert lib.gcpx_act_bwd(C.byref(rt.ActBwdArgs()), None) == -1
     assert lib.gcpx_radam_step(None, None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 1.0, None) == -1
+    # round-4 entry points: the optimizer slice, the block-limited re-pack, the grouped Predictor backward, the two-launch split re-pack
+    assert lib.gcpx_optim_range(None, None, None, None, None, 0, 0, 0.0, 0.9, 0.999, 1e-8, 1.0, 1, 0, None) == -1
+    assert lib.gcpx_repack_blocks(None, None, None, None, 0, 0, None) == -1
+    assert lib.gcpx_mlp_bwd_group(None, 0, None) == -1
+    assert b"GCPX_MLP_BWD_GROUP_MAX" in lib.gcpx_last_error()
+    tab = (rt.MlpBwdArgs * 5)()
+    assert lib.gcpx_mlp_bwd_group(tab, 5, None) == -1                  # more than GCPX_MLP_BWD_GROUP_MAX problems
+    assert lib.gcpx_mlp_bwd_group(tab, 2, None) == -1                  # empty descriptors: rejected before any launch
+    assert lib.gcpx_split_pack_group2(None, 0, None, None) == -1
