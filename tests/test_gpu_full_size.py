@@ -262,6 +262,29 @@ def test_c3_training_shard_batch16_steps_reduce_loss():
     assert checked >= 2 * (3 + 6 + 2)             # per level: 3 LSTM layers, 6 projections, embedding / output, and their transposes
 
 
+def test_c3_training_step_is_deterministic_at_full_size():
+    """Two trainers, the same data and noise, three steps each: parameters, moments, losses and the likelihood gradient bit-identical.
+    Every kernel sums in a fixed order and the lanes of the step are ordered by events, so any difference is a race — round 4 found one
+    this way: at full size (two wavefronts per SIMD, both busy) the head's training variant stored ~150 of its 587 M gradient values as the
+    register's previous content (a VALU-result -> store-data hazard, fixed by wait states in front of the stores: conv3x3_split.hip);
+    smaller configurations never showed it."""
+    from video_gcp_amd.training import GCPTrainStep
+    hp, sd, ma = _build("c3")
+    _, _, mb = _build("c3")
+    ta, tb = GCPTrainStep(ma, lr=1e-3), GCPTrainStep(mb, lr=1e-3)
+    for step in range(3):
+        inputs, noise, _ = make_inputs(hp, seed=60 + step, variant="B")
+        dev_in = {k: v.cuda() for k, v in inputs.items()}
+        oa = ta.step(dev_in, noise.cuda())
+        dmd_a = ta.last_bplan.outs["dMD"].clone()
+        ob = tb.step(dev_in, noise.cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(dmd_a, tb.last_bplan.outs["dMD"]), step
+        assert torch.equal(oa.raw["losses"], ob.raw["losses"]), step
+        for x, y, what in [(ma.theta, mb.theta, "theta"), (ta.exp_avg, tb.exp_avg, "exp_avg"), (ta.exp_avg_sq, tb.exp_avg_sq, "exp_avg_sq")]:
+            assert torch.equal(x, y), (step, what)
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # configs[3]: CEM planning, 512 candidates x horizon 80 (64 per GPU when sharded over 8)
 # ------------------------------------------------------------------------------------------------------------------------

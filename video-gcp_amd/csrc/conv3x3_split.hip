@@ -437,12 +437,23 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                                 const float gw = -coef * w;                                   // d (-logsumexp) / d s_k
                                 const float g1 = gw * gm[ct][1], g2 = gw * gm[ct][2];
                                 float* dk = drow + 8 * (2 * ct + h);
-                                *reinterpret_cast<float4*>(dk) = make_float4(coef * (pik - w), gw * gm[ct][0], g1, g2);
-                                *reinterpret_cast<float4*>(dk + 4) = make_float4(g1 * xr * (1.f - cf[ct][0] * cf[ct][0]), g2 * xr * (1.f - cf[ct][1] * cf[ct][1]),
-                                                                                 g2 * xg * (1.f - cf[ct][2] * cf[ct][2]), gw * gs[ct][0]);
+                                float4 va = make_float4(coef * (pik - w), gw * gm[ct][0], g1, g2);
+                                float4 vb = make_float4(g1 * xr * (1.f - cf[ct][0] * cf[ct][0]), g2 * xr * (1.f - cf[ct][1] * cf[ct][1]),
+                                                        g2 * xg * (1.f - cf[ct][2] * cf[ct][2]), gw * gs[ct][0]);
+                                // Wait states between the (packed-f32) multiplies that produce the rows and the 16-byte stores that read them.
+                                // Without them ~1e-7 of the stored values came out as the register's previous content (+-0) in lanes 32..63, a
+                                // different handful of items every launch — every intermediate identical, the stored component not
+                                // (tools/soak_early_vs_late.py found it; NOTEBOOK round 4: a VALU-result -> store-data hazard the compiler's
+                                // table for gfx950 does not cover; it shows when the SIMD's other wavefront delays the second pass of the
+                                // producer).  s_nop 7 in front of the stores: deterministic over 6 x 587 M values.
+                                asm volatile("s_nop 7" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w), "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
+                                *reinterpret_cast<float4*>(dk) = va;
+                                *reinterpret_cast<float4*>(dk + 4) = vb;
                                 glg[ct] = gw * gs[ct][1];
                                 glb[ct] = gw * gs[ct][2];
                             }
+                            asm volatile("s_nop 7" : "+v"(glg[0]), "+v"(glb[0]), "+v"(glg[1]), "+v"(glb[1]), "+v"(glg[2]), "+v"(glb[2]), "+v"(glg[3]), "+v"(glb[3]),
+                                         "+v"(glg[4]), "+v"(glb[4]));
                             // packing.dlm_log_scale_slot: ct = 0, 1 -> lane group 2 h of tile 5, ct = 2, 3 -> 2 h + 1, ct = 4 -> slots 96 + 2 h
                             *reinterpret_cast<float4*>(drow + 80 + 8 * h) = make_float4(glg[0], glb[0], glg[1], glb[1]);
                             *reinterpret_cast<float4*>(drow + 84 + 8 * h) = make_float4(glg[2], glb[2], glg[3], glb[3]);
