@@ -131,8 +131,8 @@ def test_two_rank_gradient_all_reduce_keeps_replicas_identical():
 
 
 def test_gradient_bucket_ranges_tile_the_flat_gradient():
-    """bucket layout of the data-parallel exchange for the c2 model: one ~41 MB bucket per tree level 6..1 in the order the
-    backward finishes them, then the rest (conv stacks, heads, level 0)"""
+    """bucket layout of the data-parallel exchange for the c2 model: one ~41 MB bucket per tree level 6..0 in the order the
+    backward finishes them, then the rest (conv stacks, heads: 5 MB)"""
     sys.path.insert(0, ROOT)
     import video_gcp_amd as V
     from video_gcp_amd.dist import gradient_bucket_ranges
@@ -142,7 +142,8 @@ def test_gradient_bucket_ranges_tile_the_flat_gradient():
         poff[k] = (off, tuple(v.shape))
         off += (v.numel() + 3) // 4 * 4
     r = gradient_bucket_ranges(poff, hp.hierarchy_levels, True)
-    assert [n for n, _, _ in r] == ["tree6", "tree5", "tree4", "tree3", "tree2", "tree1", "rest"]
+    assert [n for n, _, _ in r] == ["tree6", "tree5", "tree4", "tree3", "tree2", "tree1", "tree0", "rest"]
+    assert r[-1][2] - r[-1][1] < 2_000_000                       # what is left behind the backward: 1.3 M parameters
     assert r[-1][1] == 0 and r[0][2] == off
     assert sum(hi - lo for _, lo, hi in r) == off
     lo, hi = [(a, b) for n, a, b in r if n == "tree3"][0]

@@ -172,7 +172,7 @@ def test_step_with_slices_applied_during_the_backward_equals_the_late_step(name)
     hp, sd, ma, ta = _setup(name, True)
     _, _, mb, tb = _setup(name, True)
     tb.early_optimizer = False
-    assert len(ta._ranges) == hp.hierarchy_levels
+    assert len(ta._ranges) == hp.hierarchy_levels + 1
     for step in range(3):
         inputs, noise, _ = make_inputs(hp, seed=30 + step, variant="B")
         dev_in = {k: v.cuda() for k, v in inputs.items()}
@@ -280,7 +280,7 @@ def test_bucket_marks_follow_every_write_of_their_slice(name):
     from video_gcp_amd.dist import gradient_bucket_ranges
     hp, sd, model, tr = _setup(name, False)
     ranges = gradient_bucket_ranges(model._poff, hp.hierarchy_levels, hp.untied_layers)
-    assert len(ranges) == hp.hierarchy_levels                   # one bucket per level L-1 .. 1, then the rest
+    assert len(ranges) == hp.hierarchy_levels + 1               # one bucket per level L-1 .. 0, then the rest
     tr._bucket_index = {n: i for i, (n, _, _) in enumerate(ranges)}      # what a process group switches on (training.py:53)
     snaps = {}
 

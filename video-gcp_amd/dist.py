@@ -76,10 +76,12 @@ def all_reduce_sum_(flat, group=None):
 
 def gradient_bucket_ranges(poff, hierarchy_levels, untied_layers):
     """Contiguous [lo, hi) ranges of the flat gradient in the order they become FINAL during the backward pass
-    (training.py walks the tree leaves-first): one bucket per untied tree level L-1 .. 1 (about 41 MB each at c2), then ONE bucket
-    with everything below `tree_modules.1` — conv encoder (shared by the three encoder passes, final last), decoder, temporal
-    encoder, latent-space heads and tree level 0 (which also owns the existence / distance predictor).  `poff` is the model's
-    {name: (offset, shape)} table; offsets are in floats.  Tied levels accumulate into one weight set: a single bucket."""
+    (training.py walks the tree leaves-first): one bucket per untied tree level L-1 .. 0 (about 41 MB each at c2; level 0 also owns
+    the existence / distance predictor and the LSTM initialiser, whose gradients are out before its mark), then ONE bucket with
+    everything below `tree_modules.0` — conv encoder (shared by the three encoder passes, final last), decoder, temporal encoder,
+    latent-space heads: 5 MB at c2, the only part of the exchange (and of the optimizer step) that cannot start before the backward
+    ends.  `poff` is the model's {name: (offset, shape)} table; offsets are in floats.  Tied levels accumulate into one weight set: a
+    single bucket."""
     end = 0
     starts = {}
     for k, (o, shp) in poff.items():
@@ -93,10 +95,11 @@ def gradient_bucket_ranges(poff, hierarchy_levels, untied_layers):
     if not untied_layers or hierarchy_levels < 2 or len(starts) < hierarchy_levels:
         return [("all", 0, end)]
     out = []
-    for l in reversed(range(1, hierarchy_levels)):
+    for l in reversed(range(0, hierarchy_levels)):
         hi = starts[l + 1] if l + 1 in starts else end
         out.append((f"tree{l}", starts[l], hi))
-    out.append(("rest", 0, starts[1]))
+    if starts[0] > 0:
+        out.append(("rest", 0, starts[0]))
     # the table is laid out in parameter order: the ranges must tile [0, end) exactly
     cover = sorted((lo, hi) for _, lo, hi in out)
     assert cover[0][0] == 0 and cover[-1][1] == end and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), cover

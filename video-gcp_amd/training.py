@@ -218,7 +218,7 @@ class GCPTrainStep:
         descs = {}
         keep = []
         for l in levels:
-            bucket = f"tree{l}" if (hp.untied_layers and l >= 1 and len(m._arena_ranges) > 1) else m._arena_ranges[-1][0]
+            bucket = f"tree{l}" if f"tree{l}" in [n_ for n_, _, _ in m._arena_ranges] else m._arena_ranges[-1][0]
 
             fwd = lambda k: k in ("proj.w", "out.w", "embed.w") or re.fullmatch(r"lstm\d+\.w", k)
             bwd = lambda k: k in ("proj.wT", "out.wT", "embed.wT", "lstm.whT") or re.fullmatch(r"lstm\d+\.wxT", k)
