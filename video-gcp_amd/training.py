@@ -66,7 +66,7 @@ class GCPTrainStep:
         self.buckets = GradBuckets(self.grad, ranges, process_group) if process_group is not None else None
         # step(): the optimizer update of a tree level's slice (+ the re-pack of its weights) is issued on the CALLER's stream — idle
         # while the backward plan runs on the model's lanes — as soon as the backward reports the slice final (and, data-parallel, its
-        # all-reduce is done): 6 of the 7 levels' 10.3 M parameters each (c2) are updated under the remaining levels and the encoder
+        # all-reduce is done): the 7 levels' 10.3 M parameters each (c2) are updated under the remaining levels and the encoder
         # backward, instead of 2.9 GB of optimizer + re-pack traffic behind the last gradient.  Not with gradient_clip (the global norm
         # needs every slice) and not with a graph-captured backward (no host callbacks).  backward() alone never touches parameters.
         # Issued at a level's mark, a full grid of the optimizer kernel stretched the tree chain's GEMMs beside it from 41 to 101 us
