@@ -1,605 +1,13 @@
-// Output head of the decoder on the f16 matrix pipes of gfx950 with f32-equivalent arithmetic ("split-f16").
-//
-// gfx950 has no tf32 / xf32 matrix instruction and runs v_mfma_f32_16x16x4_f32 at 1/16 of the f16 / bf16 MFMA rate.  The exact f32
-// head (conv3x3.hip: conv3x3_head_kernel) is bound by that rate (0.76 of the f32 MFMA peak).  This kernel computes the same 3x3 conv
-// (DecoderModule.decode_seq -> gen_head, /root/reference/gcp/prediction/models/tree/tree_dense_rec.py:42) with both operands
-// split into two f16 pieces and three f16 MFMAs per f32 product:
-//
-//     x 2^Ex = x1 + x2 + dx,  x1 = rn16(x 2^Ex),  x2 = rn16(x 2^Ex - x1)
-//     w 2^Ew = w1 + w2 + dw,  likewise (one Ew per tensor; split on the device, gcpx_split_pack)
-//     x w 2^(Ex+Ew) ~= x1 w1 + x1 w2 + x2 w1                                     (x2 w2 <= 2^-22 |x w| is dropped)
-//
-// Every partial product is exact in the f32 accumulator.  The bound is NORM-WISE per scaled unit, not element-wise: Ex is chosen PER
-// ITEM from the largest staged activation (a power of two: scaling and unscaling are exact; max |x| 2^Ex lands in [2^14, 2^15), so
-// nothing overflows), and
-//
-//     |dx| 2^-Ex <= max( 2^-22 |x| , 2^-39 max|x|_item )
-//
-// — two round-to-nearest f16 pieces carry 11 + 11 significant bits (2^-22 |x| worst case, about 2^-24 |x| on average) as long as the
-// second piece is a normal f16, i.e. for |x| >= 2^-17 of the item's maximum; below that the f16 subnormal quantum (2^-24 under the
-// scale) is the floor, and a value 2^-k of the maximum keeps about 39 - k bits.  A result is therefore one f32 rounding of its largest
-// terms — f32-equivalent wherever the terms near the item's maximum carry the output (everything behind a BatchNorm) — and NOT
-// element-wise f32 when a large channel meets zero weights beside a small channel that carries the output
-// (tests/test_gpu_kernels.py::test_split_bound_head_large_channel_with_zero_weights states the bound and reports that case).  The error
-// against a float64 conv is measured next to the exact-f32 kernel's in tests/test_gpu_kernels.py.
-//
-// Work decomposition = the wave-autonomous scheme of conv3x3_head_kernel: one 512-thread workgroup per CU keeps all packed weights
-// (5 k-steps x 7 channel tiles x 2 pieces x 1 KiB) in LDS; every wavefront owns items of 4 rows x 16 pixels, stages its haloed
-// 6 x 18 x 16ch region as two f16 planes (32 B per pixel and plane: the ds_read_b128 operand reads are conflict-free without padding)
-// and runs 5 k-steps (two taps x 16 channels = K 32 each; the 10th tap has zero weights) x 7 x 4 tiles x 3 MFMAs.
+// Decoder convolutions on the f16 matrix pipes of gfx950 with f32-equivalent arithmetic ("split-f16", split_mfma.h): the 16-channel
+// upsampling blocks, the 32 / 64-channel upsampling blocks, the row-folded 32 -> 16 block, plain 3x3 convs of the backward pass and the
+// device-side weight split.  The output head lives in conv3x3_head_split.hip.
 #include "common.h"
+#include "split_mfma.h"
 
 #include <cstdlib>
 #include <type_traits>
 
 namespace {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-
-// D[16x16] += A[16x32] * B[32x16]: lane l holds A[i = l & 15][k = 8 (l >> 4) .. + 7], B[k = 8 (l >> 4) .. + 7][j = l & 15];
-// D as in mfma16 (lane l, reg r: i = 4 (l >> 4) + r, j = l & 15).
-__device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-// exp / log straight on the hardware instructions (v_exp_f32 / v_log_f32 are base 2).  __expf / __logf wrap them in a range fix-up for
-// denormal results / inputs — two compares, two selects and a multiply per call: 531 selects and 558 compares in the likelihood variant of
-// the head kernel, whose time IS its VALU count (PMC: VALU 58 % busy, matrix pipe 36 %, no overlap).  Every use here has a result that
-// may flush to zero (softmax / mixture weights, sigmoids) or an argument >= 1e-12 (logs).
-__device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
-__device__ __forceinline__ float log_hw(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
-
-__device__ __forceinline__ float fast_tanh_s(float x) {
-    const float e = exp_hw(2.f * x);
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-}
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-struct SplitHeadCfg {
-    static constexpr int CT = 7, KS = 5;
-    static constexpr int RW = 18, RH = 6;
-    static constexpr int PLANE_BYTES = RH * RW * 32;                       // one f16 piece of the region: 16 channels x 2 B per pixel
-    static constexpr int REGION_BYTES = 2 * PLANE_BYTES;                   // 6912 B per wavefront
-    static constexpr int W_BYTES = KS * CT * 2 * 1024;                     // 71680 B
-    static constexpr int BIAS_BYTES = CT * 16 * 4;                          // bias of the 112 channel slots
-    static constexpr int LDS_BYTES = W_BYTES + 8 * REGION_BYTES + BIAS_BYTES;
-    static constexpr int STASH_BYTES = 16 * 64 * 4;                        // fused likelihood: 16 floats per lane parked during pass A
-    static constexpr int LDS_BYTES_NLL = LDS_BYTES + 8 * STASH_BYTES;     // 160192 of the 163840 B of a CU
-    static constexpr int NS = (RH * RW * 4 + 63) / 64;                     // float4 staging slots per lane
-};
-
-// One pass of the MFMA phase over channel tiles C0 .. C0 + NC - 1: KS x NC blocks (k-step s, tile) of 12 MFMAs.  The two weight
-// pieces of the next block and, during the last four tiles of a k-step, the activation pieces of k-step s + 1 are fetched from LDS
-// while a block computes (12 x 16 cycles of the matrix pipe cover the LDS round trip): a wavefront alone keeps the pipe busy.
-// wl: [KS][CTW][2][64] x 16 B packed pieces (CTW = channel tiles of the pack); INIT: the accumulators start from zero.
-template <int C0, int NC, int CTW = SplitHeadCfg::CT, bool INIT = true>
-__device__ __forceinline__ void mfma_tiles(const char* wl, const char* reg, const int (&tapoff)[SplitHeadCfg::KS], const int lane,
-                                           f32x4 (&acc)[NC][4]) {
-    using Cfg = SplitHeadCfg;
-    constexpr int KS = Cfg::KS, CT = CTW, RW = Cfg::RW;
-    constexpr int PB = NC < 4 ? NC : 4;                      // blocks of a k-step that carry the next k-step's activation loads
-    constexpr int PPB = 4 / PB;                              // pixel groups fetched per such block
-    h8 wq[2][2], bq[2][4][2];
-    auto load_w = [&](const int s, const int ct, h8 (&w)[2]) __attribute__((always_inline)) {
-        const char* wp = wl + ((s * CT + ct) * 2 * 64 + lane) * 16;                      // [KS][CT][2][64] x 16 B
-        w[0] = *reinterpret_cast<const h8*>(wp);
-        w[1] = *reinterpret_cast<const h8*>(wp + 1024);
-    };
-    auto load_b = [&](const int s, const int pt, h8 (&b)[2]) __attribute__((always_inline)) {
-        b[0] = *reinterpret_cast<const h8*>(reg + tapoff[s] + pt * RW * 32);
-        b[1] = *reinterpret_cast<const h8*>(reg + tapoff[s] + pt * RW * 32 + Cfg::PLANE_BYTES);
-    };
-    load_w(0, C0, wq[0]);
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) load_b(0, pt, bq[0][pt]);
-    __builtin_amdgcn_s_setprio(1);
-    static_for<0, KS * NC>([&](auto tc) __attribute__((always_inline)) {
-        constexpr int t = decltype(tc)::value, s = t / NC, c = t % NC;
-        constexpr bool more = t + 1 < KS * NC;
-        constexpr bool pre_b = c >= NC - PB && s + 1 < KS;
-        if constexpr (more) load_w((t + 1) / NC, C0 + (t + 1) % NC, wq[(t + 1) & 1]);
-        if constexpr (pre_b) {
-#pragma unroll
-            for (int k = 0; k < PPB; ++k) load_b(s + 1, (c - (NC - PB)) * PPB + k, bq[(s + 1) & 1][(c - (NC - PB)) * PPB + k]);
-        }
-        const h8 w1 = wq[t & 1][0], w2 = wq[t & 1][1];
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            // small terms first: they are added to the accumulator while it is still small
-            if constexpr (s == 0 && INIT) acc[c][pt] = mfma32h(w2, bq[0][pt][0], f32x4{0, 0, 0, 0});
-            else acc[c][pt] = mfma32h(w2, bq[s & 1][pt][0], acc[c][pt]);
-        }
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) acc[c][pt] = mfma32h(w1, bq[s & 1][pt][1], acc[c][pt]);
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) acc[c][pt] = mfma32h(w1, bq[s & 1][pt][0], acc[c][pt]);
-        __builtin_amdgcn_sched_group_barrier(0x100, (more ? 2 : 0) + (pre_b ? 2 * PPB : 0), 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-    });
-    __builtin_amdgcn_s_setprio(0);
-}
-
-// scale back + bias, and the raw NHWC store of channel tiles C0 .. C0 + NC - 1
-template <int C0, int NC>
-__device__ __forceinline__ void finish_tiles(const gcpx_conv_args& a, const float* bias_l, f32x4 (&acc)[NC][4], const float inv, const bool store_raw,
-                                             const int orow, const int y0, const int x0, const int j, const int q) {
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias_l + (C0 + c) * 16 + q * 4);
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            acc[c][pt][0] = fmaf(acc[c][pt][0], inv, bv.x); acc[c][pt][1] = fmaf(acc[c][pt][1], inv, bv.y);
-            acc[c][pt][2] = fmaf(acc[c][pt][2], inv, bv.z); acc[c][pt][3] = fmaf(acc[c][pt][3], inv, bv.w);
-        }
-    }
-    if (store_raw) {
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            float* op = a.out + (((size_t)orow * a.Hout + (y0 + pt)) * a.Wout + (x0 + j)) * a.out_pitch;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int ch = (C0 + c) * 16 + q * 4;
-                if (ch < a.out_pitch) {
-                    const f32x4 v = acc[c][pt];
-                    *reinterpret_cast<float4*>(op + ch) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
-    }
-}
-
-// hardware exp / log / reciprocal forms for the fused mixture likelihood (same helpers as csrc/loss.hip)
-__device__ __forceinline__ float sigmoid_fast_s(float x) { return __builtin_amdgcn_rcpf(1.f + exp_hw(-x)); }
-__device__ __forceinline__ float softplus_s(float x) { return x > 20.f ? x : log_hw(1.f + exp_hw(x)); }
-
-// NLL = 1: head mode GCPX_HEAD_DLM_NLL — frames matched to a ground-truth frame (raw_row_map entry >= 0) additionally evaluate the
-// discretised-logistic-mixture likelihood of that frame in the epilogue and write one partial sum per item
-// (nll_partial[item of the frame][row]); their raw parameters are never stored (frame_binding.py:88-99 -> decoder.nll).
-// NLL = 2: GCPX_HEAD_DLM_NLL_GRAD (training forward) — the same, and the gradient of (nll_scale x row weight x) that likelihood
-// w.r.t. the 100 parameters of every pixel goes to row raw_row_map[f] of `out` (112-slot layout): what gcpx_dlm_nll_bwd computes from
-// the stored parameters, without storing them.
-template <int NLL, bool PP>
-__global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_conv_args a, const int items_per_wave,
-                                                                    const int nitems) {
-    using Cfg = SplitHeadCfg;
-    constexpr int RW = Cfg::RW, RH = Cfg::RH, NS = Cfg::NS, CT = Cfg::CT, KS = Cfg::KS;
-    extern __shared__ float4 smem4[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const char* wl = reinterpret_cast<const char*>(smem4);                          // [KS][CT][2][64] x 16 B
-    char* reg = reinterpret_cast<char*>(smem4) + Cfg::W_BYTES + wave * Cfg::REGION_BYTES;
-    const int j = lane & 15, q = lane >> 4;
-    const int H = a.Hout, W = a.Wout;
-    const int ncb = W / 16, nrp = H / 4;
-
-    for (int i = tid; i < Cfg::W_BYTES / 16; i += 512) smem4[i] = reinterpret_cast<const float4*>(a.wpk_split)[i];
-    float* bias_l = reinterpret_cast<float*>(reinterpret_cast<char*>(smem4) + Cfg::W_BYTES + 8 * Cfg::REGION_BYTES);
-    if (tid < CT * 16) bias_l[tid] = tid < a.out_pitch ? a.bias[tid] : 0.f;
-    __syncthreads();
-
-    // operand address of k-step s: tap 2 s + (q >> 1), channels 8 (q & 1) .. + 7 of pixel (row + ty, j + tx).  The 10th tap (s = 4,
-    // q >= 2) has zero weights; it re-reads tap 8 so that the multiplicand is a staged (finite) value.
-    int tapoff[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int tap = min(2 * s + (q >> 1), 8);
-        tapoff[s] = ((tap / 3) * RW + (tap % 3) + j) * 32 + (q & 1) * 16;
-    }
-    const gcpx_conv_src sr = a.src[0];
-    const int ew = a.w_split_log2_dev ? __builtin_amdgcn_readfirstlane(*a.w_split_log2_dev) : a.w_split_log2;
-    // every staging slot of a lane carries the same 4 channels: their BatchNorm affine is loaded once
-    float4 bn_s = make_float4(1.f, 1.f, 1.f, 1.f), bn_t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (sr.scale) {
-        bn_s = *reinterpret_cast<const float4*>(sr.scale + (lane & 3) * 4);
-        bn_t = *reinterpret_cast<const float4*>(sr.shift + (lane & 3) * 4);
-    }
-    const float slope = sr.act == GCPX_ACT_LRELU ? 0.2f : 1.f;
-
-    const int gw = blockIdx.x * 8 + wave;
-    // NLL: matched frames cost ~1.6x an unmatched one (two more channel tiles + the likelihood), and a contiguous range of items is
-    // about ONE frame — so the items are dealt round-robin over the wavefronts (every wavefront sees the same mix; the eight
-    // wavefronts of a workgroup still work on eight neighbouring items at a time)
-    const int istep = NLL ? (int)gridDim.x * 8 : 1;
-    int item = NLL ? gw : gw * items_per_wave;
-    const int item_end = NLL ? nitems : min(item + items_per_wave, nitems);
-
-    float4 pre[NS];
-    unsigned pre_ok = 0;
-    int pre_orow = 0;                                      // raw_row_map entry of the prefetched item's frame
-    auto origin = [&](int it, int& f, int& y0, int& x0) {
-        const int strip = it % nrp;
-        const int t = it / nrp;
-        y0 = strip * 4; f = t / ncb; x0 = (t % ncb) * 16;
-    };
-    auto issue_loads = [&](int it) {
-        int f, y0, x0;
-        origin(it, f, y0, x0);
-        pre_ok = 0;
-        const float* base = sr.ptr + (size_t)f * H * W * 16;
-        pre_orow = a.raw_row_map ? a.raw_row_map[f] : f;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int idx = lane + 64 * k;
-            // (the seven slot -> (row, column) constants are recomputed — six VALU operations each — instead of held in registers: at
-            // the 256-register limit they were the values the compiler spilled, and a scratch reload inside this batch of loads waits
-            // for every load issued before it)
-            int t_ = idx >> 2;
-            asm volatile("" : "+v"(t_));      // (opaque to the optimiser: otherwise the quotients are hoisted out of the item loop and spilled again)
-            const int rc = ((t_ / RW) << 8) | (t_ % RW);
-            const int sy = y0 - 1 + (rc >> 8), sx = x0 - 1 + (rc & 255);
-            if (idx < RH * RW * 4 && sy >= 0 && sy < H && sx >= 0 && sx < W) {
-                int l4 = lane;
-                asm volatile("" : "+v"(l4));                   // (the lane's channel offset recomputed, not reloaded from scratch in front of every load)
-                pre[k] = *reinterpret_cast<const float4*>(base + (unsigned)((__umul24(sy, W) + sx) * 16 + (l4 & 3) * 4));
-                pre_ok |= 1u << k;
-            }
-        }
-    };
-    if (item < item_end) issue_loads(item);
-
-    // The image pixels of an item are stored one iteration late, behind the NEXT item's staging: the memory counter is in order, so
-    // stores issued right before the loop's back-edge would have to complete before the staging may touch the prefetched region
-    // (the store round trip, every item); behind the staging they are older than the next prefetch and long complete by its wait.
-    float pend[2][3];
-    float* pend_ip = nullptr;
-    // images_rows: the frames with a raw_row_map entry are stored a second (and third) time, at that row of a [rows][3][H][W] array —
-    // the gathers of the matched / kept frames behind the head (tree_dense_rec.py:56-60, tree.py:62-65) without their 2 x 63 MB round
-    // trip.  The second address differs from the first by a wave-uniform offset: it lives in scalar registers.
-    long long pend_d2 = 0;
-    bool pend_has2 = false;
-    const size_t plane_sz = (size_t)H * W;
-    auto flush_images = [&]() __attribute__((always_inline)) {
-        if (pend_ip) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                float* ip = pend_ip + s2 * W;
-                ip[0] = pend[s2][0];
-                ip[plane_sz] = pend[s2][1];
-                ip[2 * plane_sz] = pend[s2][2];
-            }
-            if (pend_has2) {
-#pragma unroll
-                for (int cpy = 0; cpy < 2; ++cpy) {
-                    if (cpy == 1 && a.images_rows_dup == 0) break;
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        float* ip = pend_ip + pend_d2 + cpy * a.images_rows_dup + s2 * W;
-                        ip[0] = pend[s2][0];
-                        ip[plane_sz] = pend[s2][1];
-                        ip[2 * plane_sz] = pend[s2][2];
-                    }
-                }
-            }
-        }
-    };
-
-    // ---- the item loop: per item a VALU half (the deferred epilogue of the PREVIOUS item — scale-back, mixture mean, likelihood — then
-    // the staging of this one) and an MFMA half.  PP (experiment, off by default): two workgroup barriers per item put waves 0-3 in
-    // their MFMA half while waves 4-7 (their SIMD partners) are in their VALU half and vice versa.  The idea: PMC shows the matrix pipe
-    // 36 % busy and the VALU 58 % with their sum at ~ 94 % — the two wavefronts of a SIMD drift through their phases unsynchronised and
-    // whenever both are in the same kind of phase they halve each other.  Measured: lock step is 10-17 % SLOWER in every mode (the halves
-    // do not balance; a barrier waits for the slowest of eight wavefronts), so the wavefronts run free.
-    const int n_iter = NLL ? (nitems + istep - 1) / istep : items_per_wave;
-    const int grp = wave >> 2;
-    f32x4 acc[5][4];
-    float4* stash = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem4) + Cfg::LDS_BYTES + wave * Cfg::STASH_BYTES) + lane;
-    float ls4[2][2];
-    float tx[2][3];                                             // fused likelihood: this lane's target pixels of the item in flight
-    const int mode = a.head_mode;
-    const size_t plane = (size_t)H * W;
-    // the item whose accumulators wait for their epilogue (wave-uniform)
-    int p_valid = 0, p_f = 0, p_y0 = 0, p_x0 = 0, p_orow = -1;
-    float p_inv = 1.f;
-    auto epilogue = [&]() __attribute__((always_inline)) {
-        const int f = p_f, y0 = p_y0, x0 = p_x0, orow = p_orow;
-        const float inv = p_inv;
-        const bool store_raw = NLL == 0 && (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) && orow >= 0;
-        const bool want_nll = NLL && orow >= 0;
-        float nll_item = 0.f;
-        {
-            finish_tiles<0, 5>(a, bias_l, acc, inv, store_raw, orow, y0, x0, j, q);
-            if (mode == GCPX_HEAD_DLM_MEAN || mode == GCPX_HEAD_DLM_BOTH || mode == GCPX_HEAD_DLM_NLL || mode == GCPX_HEAD_DLM_NLL_GRAD) {
-                // kernel channel order and the lane exchange: see conv3x3_head_kernel (conv3x3.hip)
-#pragma unroll
-                for (int ct = 0; ct < 5; ++ct)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ct][s2][r]),
-                                                                             __float_as_uint(acc[ct][s2 + 2][r]), false, false);
-                            acc[ct][s2][r] = __uint_as_float(sw[0]);
-                            acc[ct][s2 + 2][r] = __uint_as_float(sw[1]);
-                        }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    float lg[5], mr[5], mg[5], mb[5];
-#pragma unroll
-                    for (int ct = 0; ct < 5; ++ct) {
-                        const f32x4 e = acc[ct][s2], o = acc[ct][s2 + 2];
-                        const float c0 = fast_tanh_s(o[0]), c1 = fast_tanh_s(o[1]), c2 = fast_tanh_s(o[2]);
-                        lg[ct] = e[0];
-                        mr[ct] = e[1];
-                        mg[ct] = e[2] + c0 * mr[ct];
-                        mb[ct] = e[3] + c1 * mr[ct] + c2 * mg[ct];
-                    }
-                    float m = lg[0];
-#pragma unroll
-                    for (int ct = 1; ct < 5; ++ct) m = fmaxf(m, lg[ct]);
-                    m = fmaxf(m, __shfl_xor(m, 32));
-                    float S = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
-#pragma unroll
-                    for (int ct = 0; ct < 5; ++ct) {
-                        const float w = exp_hw(lg[ct] - m);
-                        S += w; Sr += w * mr[ct]; Sg += w * mg[ct]; Sb += w * mb[ct];
-                    }
-                    S += __shfl_xor(S, 32); Sr += __shfl_xor(Sr, 32); Sg += __shfl_xor(Sg, 32); Sb += __shfl_xor(Sb, 32);
-                    const float invS = __builtin_amdgcn_rcpf(S);
-                    pend[s2][0] = fminf(fmaxf(Sr * invS, -1.f), 1.f);
-                    pend[s2][1] = fminf(fmaxf(Sg * invS, -1.f), 1.f);
-                    pend[s2][2] = fminf(fmaxf(Sb * invS, -1.f), 1.f);
-                    if (s2 == 0 && q < 2) pend_ip = a.images + (size_t)f * 3 * plane + (size_t)(y0 + 2 * q) * W + (x0 + j);   // row pt = s2 + 2 q
-                    if (s2 == 0) {
-                        pend_has2 = a.images_rows != nullptr && orow >= 0;
-                        const long long d2 = pend_has2 ? (a.images_rows - a.images) + ((long long)orow - f) * 3 * (long long)plane : 0;
-                        pend_d2 = ((long long)__builtin_amdgcn_readfirstlane((int)(d2 >> 32)) << 32) |
-                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(d2 & 0xffffffffll));
-                    }
-                    if (want_nll) {
-                        // ---- fused likelihood, second half (the formulas of dlm_nll_kernel, csrc/loss.hip): this lane's five mixtures of
-                        // its pixel, the other five in lane ^ 32; m / S above are the max / sum of exp over all ten logits
-                        const float lse_logits = m + log_hw(S);
-                        const float xr = tx[s2][0], xg = tx[s2][1], xb = tx[s2][2];      // (requested one half-phase earlier, beside the staging)
-                        const float4 st0 = stash[(2 * s2) * 64], st1 = stash[(2 * s2 + 1) * 64];
-                        const float lsg[5] = {st0.x, st0.z, st1.x, st1.z, ls4[s2][0]}, lsb[5] = {st0.y, st0.w, st1.y, st1.w, ls4[s2][1]};
-                        float lp[5];
-                        constexpr int NG = NLL == 2 ? 5 : 1;       // gradient bookkeeping only in the training variant
-                        float gm[NG][3], gs[NG][3], cf[NG][3], lgk[NG];
-#pragma unroll
-                        for (int ct = 0; ct < 5; ++ct) {
-                            const f32x4 e = acc[ct][s2], o = acc[ct][s2 + 2];
-                            const float c0 = fast_tanh_s(o[0]), c1 = fast_tanh_s(o[1]), c2 = fast_tanh_s(o[2]);
-                            const float mean[3] = {e[1], e[2] + c0 * xr, e[3] + c1 * xr + c2 * xg};
-                            const float x[3] = {xr, xg, xb};
-                            const float lsr[3] = {o[3], lsg[ct], lsb[ct]};
-                            float sacc = e[0] - lse_logits;
-                            if constexpr (NLL == 2) { cf[ct][0] = c0; cf[ct][1] = c1; cf[ct][2] = c2; lgk[ct] = e[0]; }
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const float ls = fmaxf(lsr[c], -7.f);
-                                const float xc = x[c] - mean[c];
-                                const float is = exp_hw(-ls);
-                                const float plus_in = is * (xc + 1.f / 255.f), min_in = is * (xc - 1.f / 255.f);
-                                const float sp = sigmoid_fast_s(plus_in), sm = sigmoid_fast_s(min_in);
-                                const float cdf_delta = sp - sm;
-                                float v = log_hw(fmaxf(cdf_delta, 1e-12f));
-                                float dm = 0.f, ds = 0.f;          // d v / d mean, d v / d log_scale (dlm_nll_bwd_kernel, csrc/backward.hip)
-                                if constexpr (NLL == 2) {
-                                    const float pp_ = sp * (1.f - sp), pm_ = sm * (1.f - sm);
-                                    const float rcd = __builtin_amdgcn_rcpf(cdf_delta);
-                                    dm = -is * (pp_ - pm_) * rcd;
-                                    ds = -(plus_in * pp_ - min_in * pm_) * rcd;
-                                }
-                                const bool edge = x[c] < -0.999f || x[c] > 0.999f || !(cdf_delta > 1e-5f);
-                                if (__any(edge)) {              // saturated pixels / vanishing bins: rare, evaluated only when some lane needs them
-                                    const float mid_in = is * xc;
-                                    if (x[c] < -0.999f) {
-                                        v = plus_in - softplus_s(plus_in);
-                                        if constexpr (NLL == 2) { dm = -is * (1.f - sp); ds = -plus_in * (1.f - sp); }
-                                    } else if (x[c] > 0.999f) {
-                                        v = -softplus_s(min_in);
-                                        if constexpr (NLL == 2) { dm = is * sm; ds = min_in * sm; }
-                                    } else if (!(cdf_delta > 1e-5f)) {
-                                        v = mid_in - ls - 2.f * softplus_s(mid_in) - 4.8481163864f;   // log(127.5)
-                                        if constexpr (NLL == 2) {
-                                            const float smid = sigmoid_fast_s(mid_in);
-                                            dm = -is * (1.f - 2.f * smid);
-                                            ds = -mid_in * (1.f - 2.f * smid) - 1.f;
-                                        }
-                                    }
-                                }
-                                if constexpr (NLL == 2) {
-                                    if (lsr[c] < -7.f) ds = 0.f;   // clamp(min=-7) blocks the gradient
-                                    gm[ct][c] = dm;
-                                    gs[ct][c] = ds;
-                                }
-                                sacc += v;
-                            }
-                            lp[ct] = sacc;
-                        }
-                        float mx = fmaxf(fmaxf(fmaxf(lp[0], lp[1]), fmaxf(lp[2], lp[3])), lp[4]);
-                        mx = fmaxf(mx, __shfl_xor(mx, 32));
-                        float se = 0.f;
-#pragma unroll
-                        for (int ct = 0; ct < 5; ++ct) se += exp_hw(lp[ct] - mx);
-                        se += __shfl_xor(se, 32);
-                        nll_item -= mx + log_hw(se);          // (both lanes of a pixel hold it; only q < 2 is summed below)
-                        if constexpr (NLL == 2) {
-                            // ---- gradient rows: slots 8k .. 8k+7 of this lane's mixtures k = 2 ct + (q >> 1), then its g / b log-scales ----
-                            const float coef = a.nll_scale * (a.nll_row_weight ? a.nll_row_weight[orow] : 1.f);
-                            const float inv_se = __builtin_amdgcn_rcpf(se);
-                            float* drow = a.out + ((size_t)orow * plane + (size_t)(y0 + s2 + 2 * (q & 1)) * W + (x0 + j)) * a.out_pitch;
-                            const int h = q >> 1;
-                            float glg[5], glb[5];
-#pragma unroll
-                            for (int ct = 0; ct < 5; ++ct) {
-                                const float w = exp_hw(lp[ct] - mx) * inv_se;                 // responsibility of the mixture
-                                const float pik = exp_hw(lgk[ct] - lse_logits);
-                                const float gw = -coef * w;                                   // d (-logsumexp) / d s_k
-                                const float g1 = gw * gm[ct][1], g2 = gw * gm[ct][2];
-                                float* dk = drow + 8 * (2 * ct + h);
-                                float4 va = make_float4(coef * (pik - w), gw * gm[ct][0], g1, g2);
-                                float4 vb = make_float4(g1 * xr * (1.f - cf[ct][0] * cf[ct][0]), g2 * xr * (1.f - cf[ct][1] * cf[ct][1]),
-                                                        g2 * xg * (1.f - cf[ct][2] * cf[ct][2]), gw * gs[ct][0]);
-                                // Wait states between the (packed-f32) multiplies that produce the rows and the 16-byte stores that read them.
-                                // Without them ~1e-7 of the stored values came out as the register's previous content (+-0) in lanes 32..63, a
-                                // different handful of items every launch — every intermediate identical, the stored component not
-                                // (tools/soak_early_vs_late.py found it; NOTEBOOK round 4: a VALU-result -> store-data hazard the compiler's
-                                // table for gfx950 does not cover; it shows when the SIMD's other wavefront delays the second pass of the
-                                // producer).  s_nop 7 in front of the stores: deterministic over 6 x 587 M values.
-                                asm volatile("s_nop 7" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w), "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
-                                *reinterpret_cast<float4*>(dk) = va;
-                                *reinterpret_cast<float4*>(dk + 4) = vb;
-                                glg[ct] = gw * gs[ct][1];
-                                glb[ct] = gw * gs[ct][2];
-                            }
-                            asm volatile("s_nop 7" : "+v"(glg[0]), "+v"(glb[0]), "+v"(glg[1]), "+v"(glb[1]), "+v"(glg[2]), "+v"(glb[2]), "+v"(glg[3]), "+v"(glb[3]),
-                                         "+v"(glg[4]), "+v"(glb[4]));
-                            // packing.dlm_log_scale_slot: ct = 0, 1 -> lane group 2 h of tile 5, ct = 2, 3 -> 2 h + 1, ct = 4 -> slots 96 + 2 h
-                            *reinterpret_cast<float4*>(drow + 80 + 8 * h) = make_float4(glg[0], glb[0], glg[1], glb[1]);
-                            *reinterpret_cast<float4*>(drow + 84 + 8 * h) = make_float4(glg[2], glb[2], glg[3], glb[3]);
-                            *reinterpret_cast<float2*>(drow + 96 + 2 * h) = make_float2(glg[4], glb[4]);
-                            if (h == 0) {
-#pragma unroll
-                                for (int z = 100; z < 112; z += 4) *reinterpret_cast<float4*>(drow + z) = make_float4(0.f, 0.f, 0.f, 0.f);
-                            }
-                        }
-                    }
-                }
-            }
-            if (want_nll) {
-                // the item's 64 pixels: lanes q = 0, 1 (16 columns each), two rows s2 per lane -> one value per item
-                float v = q < 2 ? nll_item : 0.f;
-                v = row16_sum(v);
-                v += __shfl_xor(v, 16);
-                const int it_in_f = (y0 >> 2) * ncb + (x0 >> 4);
-                if (lane == 0) a.nll_partial[(size_t)it_in_f * a.nll_rows + orow] = v;
-            }
-        }
-    };
-    if (PP && grp == 1) __syncthreads();                       // the second half of the workgroup runs one half-phase behind
-    for (int it = 0; it <= n_iter; ++it, item += istep) {           // (one extra trip: the last item's epilogue — ONE copy of that code)
-        const bool valid = it < n_iter && item < item_end;
-        // ======== VALU half-phase: epilogue of the previous item, staging of this one ========
-        if (p_valid) epilogue();
-        int f = 0, y0 = 0, x0 = 0, orow = -1;
-        float inv = 1.f;
-        if (valid) {
-            origin(item, f, y0, x0);
-            orow = __builtin_amdgcn_readfirstlane(pre_orow);
-            // ---- staging: BatchNorm affine + LeakyReLU of the producer, the item's power-of-two scale, the two f16 pieces ----
-            float amax = 0.f;
-    #pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                if (pre_ok & (1u << k)) {          // (the zero padding of the conv stays exactly zero)
-                    float4 v = pre[k];
-                    v.x = fmaf(v.x, bn_s.x, bn_t.x); v.y = fmaf(v.y, bn_s.y, bn_t.y); v.z = fmaf(v.z, bn_s.z, bn_t.z); v.w = fmaf(v.w, bn_s.w, bn_t.w);
-                    v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
-                    v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
-                    pre[k] = v;
-                }
-                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(pre[k].x), fabsf(pre[k].y)), fmaxf(fabsf(pre[k].z), fabsf(pre[k].w))));
-            }
-    #pragma unroll
-            for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
-            // amax 2^ex in [2^14, 2^15): below the f16 maximum, and every piece that matters is a normal f16
-            int ex = 14 + 127 - (int)((__float_as_uint(amax) >> 23) & 0xff);
-            ex = __builtin_amdgcn_readfirstlane(amax > 0.f ? max(-100, min(min(100, 126 - ew), ex)) : 0);   // (2^-(ex + ew) stays a normal f32)
-            const float sx2 = __uint_as_float((unsigned)(127 + ex) << 23);
-    #pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int idx = lane + 64 * k;
-                if (idx < RH * RW * 4) {
-                    const float4 v = make_float4(pre[k].x * sx2, pre[k].y * sx2, pre[k].z * sx2, pre[k].w * sx2);
-                    h4 p1, p2;
-                    p1[0] = (_Float16)v.x; p1[1] = (_Float16)v.y; p1[2] = (_Float16)v.z; p1[3] = (_Float16)v.w;
-                    p2[0] = (_Float16)(v.x - (float)p1[0]); p2[1] = (_Float16)(v.y - (float)p1[1]);
-                    p2[2] = (_Float16)(v.z - (float)p1[2]); p2[3] = (_Float16)(v.w - (float)p1[3]);
-                    char* dst = reg + (idx >> 2) * 32 + (idx & 3) * 8;
-                    *reinterpret_cast<h4*>(dst) = p1;
-                    *reinterpret_cast<h4*>(dst + Cfg::PLANE_BYTES) = p2;
-                }
-            }
-
-            inv = __uint_as_float((unsigned)(127 - ex - ew) << 23);      // undoes the two power-of-two scales (exact)
-        }
-        if (NLL && valid && orow >= 0) {
-            // the target pixels of this item's likelihood: requested now, read in the epilogue one full MFMA half-phase later
-            const float* tp = a.nll_target + (size_t)orow * 3 * plane + (size_t)(y0 + 2 * (q & 1)) * W + (x0 + j);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) tx[s2][c] = tp[c * plane + (size_t)s2 * W];
-        } else if (NLL) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) tx[s2][c] = 0.f;
-        }
-        flush_images();
-        pend_ip = nullptr;
-        if (it + 1 < n_iter && item + istep < item_end) issue_loads(item + istep);        // in flight during this item's MFMAs
-        if (PP) __syncthreads();
-        // ======== MFMA half-phase ========
-        if (valid) {
-            const bool want_nll = NLL && orow >= 0;
-            // fused likelihood, first half: the green / blue log-scales (channel tiles 5, 6).  A lane of the epilogue owns pixel
-            // (row s2 + 2 (q & 1), column j) and mixtures 2 ct + (q >> 1), ct = 0..4.  (The kernel sits at the 256-register limit of
-            // two wavefronts per SIMD: of the 20 log-scales a lane needs in the epilogue, 16 wait in a wave-private LDS stash and 4 in
-            // registers — 22 spilled registers otherwise, and every scratch reload waits for all loads in flight.)
-            if (want_nll) {
-                f32x4 accb[2][4];
-                mfma_tiles<5, 2>(wl, reg, tapoff, lane, accb);
-                finish_tiles<5, 2>(a, bias_l, accb, inv, false, orow, y0, x0, j, q);
-                // the same row swap as for tiles 0..4 below: afterwards accb[c][s2] holds lane group q' = 2 (q >> 1) and accb[c][s2 + 2]
-                // lane group q' + 1 of THIS lane's pixel.  Slot layout of tiles 5, 6: packing.dlm_log_scale_slot
-    #pragma unroll
-                for (int c = 0; c < 2; ++c)
-    #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(accb[c][s2][r]), __float_as_uint(accb[c][s2 + 2][r]), false, false);
-                            accb[c][s2][r] = __uint_as_float(sw[0]);
-                            accb[c][s2 + 2][r] = __uint_as_float(sw[1]);
-                        }
-    #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const f32x4 e5 = accb[0][s2], o5 = accb[0][s2 + 2], e6 = accb[1][s2];
-                    // {ls_g, ls_b} of ct = 0, 1 (e5) and ct = 2, 3 (o5) of this lane's mixtures: to the stash
-                    stash[(2 * s2) * 64] = make_float4(e5[0], e5[1], e5[2], e5[3]);
-                    stash[(2 * s2 + 1) * 64] = make_float4(o5[0], o5[1], o5[2], o5[3]);
-                    // mixtures 8, 9 sit in lane group 0 of tile 6 (slots 96..99): the odd half (q >= 2) takes registers 2, 3 of its partner lane
-                    const float g9 = __shfl_xor(e6[2], 32), b9 = __shfl_xor(e6[3], 32);
-                    ls4[s2][0] = q < 2 ? e6[0] : g9;
-                    ls4[s2][1] = q < 2 ? e6[1] : b9;
-                }
-            }
-
-            // pass A: channel tiles 0..4 = the 80 slots the mixture mean reads; their epilogue runs in the next VALU half-phase
-            mfma_tiles<0, 5>(wl, reg, tapoff, lane, acc);
-            // pass B for the stored-parameters modes: channel tiles 5, 6 = slots 80..99 (+ 12 empty), only ever stored raw
-            if (NLL == 0 && (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) && orow >= 0) {
-                f32x4 accr[2][4];
-                mfma_tiles<5, 2>(wl, reg, tapoff, lane, accr);
-                finish_tiles<5, 2>(a, bias_l, accr, inv, true, orow, y0, x0, j, q);
-            }
-        }
-        else {
-            // (every path through this half-phase defines the accumulators: otherwise they count as live across the staging and the
-            // prefetch of the next item — 80 registers — and the prefetch addresses get spilled instead)
-#pragma unroll
-            for (int c = 0; c < 5; ++c)
-#pragma unroll
-                for (int pt = 0; pt < 4; ++pt) acc[c][pt] = f32x4{0, 0, 0, 0};
-            ls4[0][0] = ls4[0][1] = ls4[1][0] = ls4[1][1] = 0.f;
-        }
-        p_valid = valid; p_f = f; p_y0 = y0; p_x0 = x0; p_orow = orow; p_inv = inv;
-        if (PP) __syncthreads();
-    }
-    flush_images();
-    if (PP && grp == 0) __syncthreads();                       // every wavefront passes the same number of barriers
-}
-
 
 // -----------------------------------------------------------------------------------------------------------
 // Decoder blocks with 16 output channels (pyramid-0, additional_conv_layer) in split-f16: the wave-autonomous scheme of
@@ -1774,46 +1182,6 @@ __global__ void __launch_bounds__(256) fold_up_weights_kernel(const float* __res
 }
 
 }  // namespace
-
-// Called by conv3x3_dispatch (conv3x3.hip) for the 100-channel mixture head when the caller supplies split-f16 weights.
-int gcpx_launch_head_split(const gcpx_conv_args* a, hipStream_t stream) {
-    using Cfg = SplitHeadCfg;
-    const int nll = a->head_mode == GCPX_HEAD_DLM_NLL ? 1 : (a->head_mode == GCPX_HEAD_DLM_NLL_GRAD ? 2 : 0);
-    if (nll) {
-        GCPX_CHECK_ARG(a->nll_target && a->nll_partial && a->nll_rows > 0 && a->raw_row_map, "GCPX_HEAD_DLM_NLL needs nll_target, nll_partial, nll_rows and raw_row_map");
-        GCPX_CHECK_ARG(a->out_pitch == 112, "the fused likelihood is written for the 112-slot layout of the 10-mixture head");
-        GCPX_CHECK_ARG(nll == 1 || a->out, "GCPX_HEAD_DLM_NLL_GRAD writes the parameter gradient to `out`");
-    }
-    // GCPX_HEAD_PINGPONG=1: the loop WITH two workgroup barriers per item, so that waves 0-3 issue MFMAs while waves 4-7 do their
-    // epilogue / staging VALU work and vice versa (the two wavefronts of a SIMD in explicit alternation).  Measured SLOWER in every mode
-    // (standalone, c2 shapes: mean only 0.81 vs 0.69 ms, fused likelihood 1.29 vs 1.08, + gradient 1.73 vs 1.50; in the forward 1.11 vs
-    // 0.95): the half-phases do not balance and every barrier waits for the slowest of eight wavefronts — kept as an experiment switch.
-    static const bool pp = getenv("GCPX_HEAD_PINGPONG") != nullptr;
-    typedef void (*kern_t)(const gcpx_conv_args, const int, const int);
-    static const kern_t kerns[6] = {conv3x3_head_split_kernel<0, false>, conv3x3_head_split_kernel<1, false>, conv3x3_head_split_kernel<2, false>,
-                                    conv3x3_head_split_kernel<0, true>, conv3x3_head_split_kernel<1, true>, conv3x3_head_split_kernel<2, true>};
-    kern_t kern = kerns[(pp ? 3 : 0) + nll];
-    const int lds = nll ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (int i = 0; i < 6; ++i) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (i % 3) ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES);
-            if (e != hipSuccess) {
-                gcpx_set_error("conv3x3 split head: hipFuncSetAttribute(%d B LDS): %s", (i % 3) ? Cfg::LDS_BYTES_NLL : Cfg::LDS_BYTES, hipGetErrorString(e));
-                return GCPX_ERR_HIP;
-            }
-        }
-        attr_set = true;
-    }
-    const int nitems = a->F * (a->Hout / 4) * (a->Wout / 16);
-    int grid = gcpx_conv_grid() / 2;
-    if (grid * 8 > nitems) grid = (nitems + 7) / 8;
-    const int ipw = (nitems + grid * 8 - 1) / (grid * 8);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, ipw, nitems);
-    GCPX_CHECK_LAUNCH();
-    return GCPX_OK;
-}
 
 // 16-output-channel upsampling decoder blocks with split-f16 weights (packing.pack_conv3x3_split); grid as launch_up16
 int gcpx_launch_up16_split(const gcpx_conv_args* a, hipStream_t stream, int grid) {
