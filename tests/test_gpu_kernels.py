@@ -664,6 +664,94 @@ def test_conv3x3_head_fused_likelihood(env, case):
     assert lib.gcpx_conv3x3(C.byref(a), _stream()) != 0
 
 
+@pytest.mark.parametrize("case", ["full", "edges"])
+def test_conv3x3_head_nll_grad_values(env, case):
+    """GCPX_HEAD_DLM_NLL_GRAD (the training forward's head, csrc/conv3x3_head_split.hip, NLL = 2): every stored gradient value of sampled
+    frames against autograd of (nll_scale x row weight x) oracle.dlm_nll over a float64 conv of the same inputs, the per-row likelihood
+    against the same oracle, and the whole gradient tensor bit for bit across 8 launches.
+    `full`: 64 x 64, 2304 frames of which 1408 matched (more than the c2 training forward: both wavefronts of every SIMD busy for the
+    whole launch — the regime in which the round-4 store hazard showed), 72 sampled rows.  `edges`: saturated targets (x = -1 / +1),
+    log-scales below the -7 clamp (no gradient through the clamp) and bins whose probability vanishes (the bin-centre branch)."""
+    rt, pk, lib, dev = env
+    from oracle import gcp_model_oracle as O
+    from video_gcp_amd import config
+    hp = config("c1")
+    torch.manual_seed(23)
+    S = 64
+    Fr, R, n_check = (2304, 1408, 72) if case == "full" else (6, 4, 4)
+    x = torch.randn(Fr, S, S, 16)
+    sc, sh = torch.rand(16) + 0.5, torch.randn(16) * 0.2
+    w, b = torch.randn(100, 16, 3, 3) / 20.0, torch.randn(100) * 0.1
+    tgt = torch.rand(R, 3, S, S) * 2 - 1
+    if case == "edges":
+        b[20:30] -= 4.0                                           # log_scale_r around -4: narrow bins, some vanish
+        b[50:60] -= 9.0                                           # log_scale_g below the clamp
+        tgt[0, :, :8] = -1.0
+        tgt[1, :, 8:16] = 1.0
+        tgt[2, 1, 30:34] = 0.9995
+    rows = torch.full((Fr,), -1, dtype=torch.int32)
+    sel = torch.randperm(Fr)[:R]
+    rows[sel] = torch.arange(R, dtype=torch.int32)
+    wgt = torch.rand(R) * 0.5 + 0.75
+    wgt[R // 2] = 0.0                                             # a padded frame: its row must be written, as zeros
+    scale = 1e-3
+    perm = pk.dlm_channel_perm(10)
+    permt = torch.tensor(perm)
+    wp = pk.pack_dlm_head(w, perm).to(dev)
+    ws, e = pk.pack_conv3x3_split(w, perm)
+    ws = ws.to(dev)
+    bk = torch.zeros(len(perm))
+    bk[permt >= 0] = b[permt[permt >= 0]]
+    xd, rd, td, wd = x.to(dev), rows.to(dev), tgt.to(dev), wgt.to(dev)
+    nit = (S // 4) * (S // 16)
+    part = torch.full((nit, R), float("nan"), device=dev)
+    img = torch.full((Fr, 3, S, S), float("nan"), device=dev)
+    grad = torch.full((R, S, S, len(perm)), float("nan"), device=dev)
+    a = _conv_args(rt, [(xd, 16, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=S, Win=S, Hout=S, Wout=S, Cout=100,
+                   out_pitch=len(perm), upsample=0, head_mode=rt.HEAD_DLM_NLL_GRAD, wpk=wp, bias=bk.to(dev), out=grad, images=img)
+    a.raw_row_map, a.wpk_split, a.w_split_log2 = rd.data_ptr(), ws.data_ptr(), e
+    a.nll_target, a.nll_partial, a.nll_rows, a.nll_row_weight, a.nll_scale = td.data_ptr(), part.data_ptr(), R, wd.data_ptr(), scale
+    rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head nll + gradient")
+    torch.cuda.synchronize()
+    first, first_part = grad.clone(), part.clone()
+    for rep in range(7):                                          # run to run: the same bits in all 8 launches
+        grad.fill_(float("nan"))
+        rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head nll + gradient")
+        torch.cuda.synchronize()
+        assert torch.equal(grad, first), f"launch {rep + 2} differs from the first in {int((grad != first).sum())} values"
+        assert torch.equal(part, first_part)
+    assert torch.isfinite(first).all() and torch.isfinite(img).all()
+    assert bool((first[..., 100:] == 0).all())                    # the 12 empty slots of the 112-slot layout
+    assert bool((first[R // 2] == 0).all())                       # zero row weight
+    # sampled rows against autograd in float64
+    check = torch.randperm(R)[:n_check].tolist() if case == "full" else list(range(R))
+    frame_of = {int(r): f for f, r in enumerate(rows.tolist()) if r >= 0}
+    slots = torch.nonzero(permt >= 0)[:, 0]
+    inv = torch.empty(100, dtype=torch.long)
+    inv[permt[slots]] = slots
+    nll_got = first_part.sum(0).double().cpu()
+    worst = 0.0
+    for r in check:
+        f = frame_of[r]
+        xin = F.leaky_relu(x[f].permute(2, 0, 1)[None].double() * sc[None, :, None, None].double() + sh[None, :, None, None].double(), 0.2)
+        head = F.conv2d(xin, w.double(), b.double(), padding=1).requires_grad_(True)
+        nll = O.dlm_nll(head, tgt[[r]].double(), hp).sum()
+        (g,) = torch.autograd.grad(nll * (scale * float(wgt[r])), head)
+        got = first[r].cpu().index_select(-1, inv).permute(2, 0, 1).double()
+        ref = g[0]
+        # f32 arithmetic on hardware exp / rcp against float64.  The bin probability is a difference of two exponentials ~0.8 % / scale
+        # apart (in the reference: of two sigmoids): one rounding of each is ~1e-5 of the difference, and d / d mean, d / d log_scale
+        # divide by it — measured worst case 1.9e-5 of the row's largest gradient (tools/head_grad_probe.py; the round-4 kernel, which
+        # formed s (1 - s) as s - s^2, carried 1.5e-4).  A stale or dropped register (the round-4 store hazard) is an error of the
+        # size of the value.
+        tol = 5e-5 * float(ref.abs().max()) + 2e-4 * ref.abs()
+        err = (got - ref).abs()
+        worst = max(worst, float((err / (tol + 1e-30)).max()))
+        assert bool((err <= tol).all()), (r, float(err.max()), float(ref.abs().max()), float((err / tol).max()))
+        assert abs(float(nll_got[r]) - float(nll.detach())) <= (1e-4 if case == "edges" else 2e-5) * abs(float(nll.detach())), (r, float(nll_got[r]), float(nll.detach()))
+    print(f"head nll gradient [{case}]: worst error / tolerance over {len(check)} rows = {worst:.3f}")
+
+
 @pytest.mark.parametrize("case", ["unit", "tiny", "large", "outlier", "zero", "matched_rows"])
 def test_conv3x3_head_split_error_vs_float64(env, case):
     """The split-f16 head against a float64 conv of the same f32 inputs, next to the exact f32 MFMA kernel: its error is of the same

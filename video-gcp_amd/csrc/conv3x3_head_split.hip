@@ -30,6 +30,48 @@ namespace {
 
 constexpr float L2E = 1.44269504088896341f, LN2 = 0.69314718055994531f;
 
+// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue like their scalar forms and do two lanes' worth: wherever two values go through the
+// same f32 arithmetic they travel as a pair
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef GCPX_NOPK
+__device__ __forceinline__ f32x2 pk_fma(const f32x2 a, const f32x2 b, const f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#else
+__device__ __forceinline__ f32x2 pk_fma(const f32x2 a, const f32x2 b, const f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+__device__ __forceinline__ f32x2 pk2(const float a, const float b) { return f32x2{a, b}; }
+__device__ __forceinline__ f32x2 pk1(const float a) { return f32x2{a, a}; }
+
+// scale back + bias (two channels per instruction), and the raw NHWC store of channel tiles C0 .. C0 + NC - 1
+template <int C0, int NC>
+__device__ __forceinline__ void finish_tiles(const gcpx_conv_args& a, const float* bias_l, f32x4 (&acc)[NC][4], const float inv, const bool store_raw,
+                                             const int orow, const int y0, const int x0, const int j, const int q) {
+    const f32x2 inv2 = pk1(inv);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias_l + (C0 + c) * 16 + q * 4);
+        const f32x2 b01 = pk2(bv.x, bv.y), b23 = pk2(bv.z, bv.w);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const f32x2 lo = pk_fma(pk2(acc[c][pt][0], acc[c][pt][1]), inv2, b01), hi = pk_fma(pk2(acc[c][pt][2], acc[c][pt][3]), inv2, b23);
+            acc[c][pt][0] = lo.x; acc[c][pt][1] = lo.y; acc[c][pt][2] = hi.x; acc[c][pt][3] = hi.y;
+        }
+    }
+    if (store_raw) {
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            float* op = a.out + (((size_t)orow * a.Hout + (y0 + pt)) * a.Wout + (x0 + j)) * a.out_pitch;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int ch = (C0 + c) * 16 + q * 4;
+                if (ch < a.out_pitch) {
+                    const f32x4 v = acc[c][pt];
+                    *reinterpret_cast<float4*>(op + ch) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
 // v_max_f32 without the canonicalising v_max the compiler puts in front of fmaxf on values that went through a lane swap (bit casts)
 __device__ __forceinline__ float vmax(float a, float b) {
     float r;
@@ -101,6 +143,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
     using Cfg = SplitHeadCfg;
     constexpr int RW = Cfg::RW, RH = Cfg::RH, CT = Cfg::CT, KS = Cfg::KS;
     constexpr int NSL = 7;                                                          // staging slots per lane: six region rows + the halo columns
+    // @phase prologue wave
     extern __shared__ float4 smem4[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,6 +195,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
     // item = (frame * ncb + column block) * nrp + strip, advanced by `istep` in scalar registers
     struct Pos { int f, cb, strip; };
     const int st_strip = istep % nrp, st_cb = (istep / nrp) % ncb, st_f = istep / nrp / ncb;
+    // @phase bookkeeping item
     auto advance = [&](Pos& p) __attribute__((always_inline)) {
         p.strip += st_strip;
         int c = p.strip >= nrp;
@@ -161,14 +205,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
         p.cb -= c ? ncb : 0;
         p.f += st_f + c;
     };
+    // @phase prologue wave
     Pos nxt;                                               // the item whose activations are in flight
     nxt.strip = item0 % nrp; nxt.cb = (item0 / nrp) % ncb; nxt.f = item0 / nrp / ncb;
 
     float4 pre[NSL];
     int pre_orow = 0;                                      // raw_row_map entry of the prefetched item's frame
+    // @phase loads item
     auto halo_ok = [&](const int y0, const int x0) __attribute__((always_inline)) {
         return lane < 48 && (unsigned)(y0 - 1 + hrow) < (unsigned)H && (unsigned)(x0 + (hside ? 16 : -1)) < (unsigned)W;
     };
+    // @phase loads item
     auto issue_loads = [&](const Pos& p) __attribute__((always_inline)) {
         const int y0 = p.strip * 4, x0 = p.cb * 16;
         // (the row above the frame for y0 = 0: formed, never dereferenced)
@@ -196,6 +243,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
     long long pend_d2 = 0;
     bool pend_has2 = false;
     const size_t plane = (size_t)H * W;
+    // @phase image_stores item
     auto flush_images = [&]() __attribute__((always_inline)) {
         if (pend_ip) {
 #pragma unroll
@@ -240,6 +288,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             // ---- softmax weights of this lane's five mixtures (the other five: lane ^ 32) ----
+            // @phase softmax item
             float m = vmax(acc[0][s2][0], acc[1][s2][0]);
             m = vmax(m, acc[2][s2][0]); m = vmax(m, acc[3][s2][0]); m = vmax(m, acc[4][s2][0]);
             m = pair_max(m);
@@ -252,8 +301,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
             }
             S = pair_sum(S);
             // likelihood: targets, their bin edges, the saturated-pixel cases (wave-level masks), the stashed green / blue log-scales
-            float x[3] = {0.f, 0.f, 0.f}, xp[3], xm[3], lsg[5], lsb[5], lp2[5], lse2 = 0.f;
+            // @phase nll_setup item
+            float x[3] = {0.f, 0.f, 0.f}, xp[3], lsg[5], lsb[5], lp2[5], lse2 = 0.f;
             bool lo[3], hi[3];
+            f32x2 xpgb = pk1(0.f);
             constexpr int NG = NLL == 2 ? 5 : 1;           // gradient bookkeeping only in the training variant
             float gm[NG][3], gs[NG][3], cf[NG][3];
             if constexpr (WN) {
@@ -261,97 +312,148 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     x[c] = tx[s2][c];                       // (requested one half-phase earlier, beside the staging)
-                    xp[c] = x[c] + 1.f / 255.f; xm[c] = x[c] - 1.f / 255.f;
+                    xp[c] = x[c] + 1.f / 255.f;
                     lo[c] = x[c] < -0.999f; hi[c] = x[c] > 0.999f;
                 }
+                xpgb = pk2(xp[1], xp[2]);
                 const float4 st0 = stash[(2 * s2) * 64], st1 = stash[(2 * s2 + 1) * 64];
                 lsg[0] = st0.x; lsg[1] = st0.z; lsg[2] = st1.x; lsg[3] = st1.z; lsg[4] = ls4[s2][0];
                 lsb[0] = st0.y; lsb[1] = st0.w; lsb[2] = st1.y; lsb[3] = st1.w; lsb[4] = ls4[s2][1];
             }
+            // @phase mean item
             float Sr = 0.f, Sg = 0.f, Sb = 0.f;
 #pragma unroll
             for (int ct = 0; ct < 5; ++ct) {
                 const f32x4 e = acc[ct][s2], o = acc[ct][s2 + 2];          // {logit, mean r, g, b}, {coefficients 0..2, log-scale r}
-                const float c0 = fast_tanh_s(o[0]), c1 = fast_tanh_s(o[1]), c2 = fast_tanh_s(o[2]);
-                const float mr = e[1], mg = fmaf(c0, mr, e[2]), mb = fmaf(c2, mg, fmaf(c1, mr, e[3]));
+                // tanh of the colour coefficients, 1 - 2 / (exp(2 x) + 1): (c0, c1) as a pair, c2 alone
+                const f32x2 a01 = pk2(o[0], o[1]) * pk1(2.f * L2E);
+                const f32x2 q01 = pk2(exp2_hw(a01.x), exp2_hw(a01.y)) + pk1(1.f);
+                const float q2 = exp2_hw(o[2] * (2.f * L2E)) + 1.f;
+                const f32x2 c01 = pk_fma(pk2(rcp_hw(q01.x), rcp_hw(q01.y)), pk1(-2.f), pk1(1.f));
+                const float c2 = fmaf(rcp_hw(q2), -2.f, 1.f);
+                const float mr = e[1];
+                const f32x2 gb = pk_fma(c01, pk1(mr), pk2(e[2], e[3]));         // (mean g, mean b without its green term)
+                const float mg = gb.x, mb = fmaf(c2, mg, gb.y);
                 Sr = fmaf(w[ct], mr, Sr); Sg = fmaf(w[ct], mg, Sg); Sb = fmaf(w[ct], mb, Sb);
                 if constexpr (WN) {
+                    // @phase likelihood matched
                     // ---- likelihood of mixture 2 ct + (q >> 1) at this lane's pixel.  With e_p = exp(-plus_in), e_m = exp(-min_in):
                     //   cdf_plus - cdf_min = (e_m - e_p) / ((1 + e_p)(1 + e_m));   x < -0.999: cdf_plus = 1 / (1 + e_p);
                     //   x > 0.999: 1 - cdf_min = e_m / (1 + e_m), i.e. e_p := 0.
                     // e_p, e_m come out of v_exp_f32 already scaled by 2^-SC (SC = 10 in the forward variant: the product of three
                     // numerators / denominators stays a normal f32 and the three channels share one v_rcp_f32 and one v_log_f32; the
-                    // training variant needs the per-channel quotients anyway and runs unscaled)
+                    // training variant needs the per-channel quotients anyway and runs unscaled).  Red alone, (green, blue) as a pair.
                     constexpr int SC = NLL == 1 ? 10 : 0;
                     constexpr float S1 = NLL == 1 ? 9.765625e-4f : 1.f, S2 = S1 * S1;       // 2^-SC, 2^-2SC
-                    const float mean[3] = {e[1], fmaf(c0, x[0], e[2]), fmaf(c2, x[1], fmaf(c1, x[0], e[3]))};
+                    constexpr float LIM = 40.f - SC;                            // (e_m <= 2^40: only x > 0.999 lanes get there unharmed)
+                    const f32x2 mgb = pk_fma(c01, pk1(x[0]), pk2(e[2], e[3]));
+                    const float mean[3] = {e[1], mgb.x, fmaf(c2, x[1], mgb.y)};
                     const float lsr[3] = {o[3], lsg[ct], lsb[ct]};
-                    float t[3], num[3], den[3], lsc[3], cdq[3];
+                    float tl[3], num[3], den[3], lsc[3], cdq[3], ap[3], am[3], ep[3], em[3], P[3], M[3];
                     bool bad[3];
-                    if constexpr (NLL == 2) { cf[ct][0] = c0; cf[ct][1] = c1; cf[ct][2] = c2; }
+                    if constexpr (NLL == 2) { cf[ct][0] = c01.x; cf[ct][1] = c01.y; cf[ct][2] = c2; }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) lsc[c] = vmax(lsr[c], -7.f);
+                    // log2(e) / scale straight out of v_exp_f32 (log2 of log2(e) folded into its argument): the factor that turns
+                    // (x - mean) into an exp2 argument
+                    const f32x2 lgb = pk_fma(pk2(lsc[1], lsc[2]), pk1(-L2E), pk1(0.52876637294f));
+                    tl[0] = exp2_hw(fmaf(lsc[0], -L2E, 0.52876637294f)); tl[1] = exp2_hw(lgb.x); tl[2] = exp2_hw(lgb.y);
+                    const f32x2 tgb = pk2(tl[1], tl[2]);
+                    const f32x2 apgb = pk_fma(-tgb, xpgb - pk2(mean[1], mean[2]), pk1(-(float)SC));
+                    const f32x2 amgb = pk_fma(tgb, pk1(2.f / 255.f), apgb);
+                    ap[0] = fmaf(-tl[0], xp[0] - mean[0], -(float)SC); ap[1] = apgb.x; ap[2] = apgb.y;
+                    am[0] = fminf(fmaf(tl[0], 2.f / 255.f, ap[0]), LIM); am[1] = fminf(amgb.x, LIM); am[2] = fminf(amgb.y, LIM);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        lsc[c] = vmax(lsr[c], -7.f);
-                        t[c] = exp2_hw(lsc[c] * -L2E);                          // 1 / scale
-                        const float tl = t[c] * -L2E;
-                        const float ap = fmaf(tl, xp[c] - mean[c], -(float)SC);
-                        const float am = fminf(fmaf(tl, xm[c] - mean[c], -(float)SC), 40.f - SC);   // (e_m <= 2^40: only x > 0.999 lanes get there unharmed)
-                        float ep = exp2_hw(ap);
-                        const float em = exp2_hw(am);
-                        ep = hi[c] ? 0.f : ep;
-                        const float P = ep + S1, M = em + S1;                    // 2^-SC (1 + e_p), 2^-SC (1 + e_m)
-                        den[c] = P * M;
-                        num[c] = lo[c] ? M : em - ep;
+                        ep[c] = exp2_hw(ap[c]);
+                        em[c] = exp2_hw(am[c]);
+                        ep[c] = hi[c] ? 0.f : ep[c];
+                    }
+                    const f32x2 epgb = pk2(ep[1], ep[2]), emgb = pk2(em[1], em[2]);
+                    const f32x2 Pgb = epgb + pk1(S1), Mgb = emgb + pk1(S1);     // 2^-SC (1 + e_p), 2^-SC (1 + e_m)
+                    const f32x2 dgb = Pgb * Mgb, ngb = emgb - epgb, thgb = dgb * pk1(1e-5f / S1);
+                    P[0] = ep[0] + S1; M[0] = em[0] + S1; P[1] = Pgb.x; P[2] = Pgb.y; M[1] = Mgb.x; M[2] = Mgb.y;
+                    den[0] = P[0] * M[0]; den[1] = dgb.x; den[2] = dgb.y;
+                    const float dif[3] = {em[0] - ep[0], ngb.x, ngb.y}, thr[3] = {den[0] * (1e-5f / S1), thgb.x, thgb.y};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        num[c] = lo[c] ? M[c] : dif[c];
                         // bin probability > 1e-5 (as the reference's branch, on num / den instead of the difference of two sigmoids);
                         // false for every non-finite or out-of-range term
-                        bad[c] = !(num[c] > (1e-5f / S1) * den[c]);
+                        bad[c] = !(num[c] > thr[c]);
                         if constexpr (NLL == 2) {
                             // d log(bin) / d mean, d log(bin) / d log_scale (dlm_nll_bwd_kernel, csrc/backward.hip) from cdf_plus = M / den,
                             // cdf_min = P / den; x > 0.999 follows from e_p = 0, x < -0.999 needs cdf_min := 0
                             const float rd = rcp_hw(den[c]);
-                            const float sp = M * rd, sm = lo[c] ? 0.f : P * rd;
-                            const float pp_ = fmaf(-sp, sp, sp), pm_ = fmaf(-sm, sm, sm);
+                            const float sp = M[c] * rd, sm = lo[c] ? 0.f : P[c] * rd;
+                            // s (1 - s) as e s^2 (1 - cdf_plus = e_p cdf_plus, likewise cdf_min): no cancellation where a sigmoid
+                            // saturates — s - s^2 in f32 loses 2e-4 of the value at |mid| = 8 (what the round-4 kernel and an f32
+                            // evaluation of the reference's expression carry)
+                            const float pp_ = ep[c] * sp * sp, pm_ = em[c] * sm * sm;
                             cdq[c] = num[c] * rd;
                             const float rcd = rcp_hw(cdq[c]);
-                            const float plus_in = ap * -LN2, min_in = am * -LN2;
-                            gm[ct][c] = -t[c] * (pp_ - pm_) * rcd;
+                            const float plus_in = ap[c] * -LN2, min_in = am[c] * -LN2;
+                            gm[ct][c] = -(tl[c] * LN2) * (pp_ - pm_) * rcd;
                             gs[ct][c] = -(plus_in * pp_ - min_in * pm_) * rcd;
                         }
                     }
-                    float extra2 = 0.f;                                       // log2 terms of the lanes on the exact path
+                    // @phase likelihood_offpath rare
+                    float extra2 = 0.f;                                       // log2 terms of the lanes off the main path
                     if (__any(bad[0] || bad[1] || bad[2])) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             if (__any(bad[c])) {
-                                // the exact formulas (dlm_nll_kernel, csrc/loss.hip) for the lanes that need them
-                                const float is = t[c], xc = x[c] - mean[c];
-                                const float plus_in = is * (xc + 1.f / 255.f), min_in = is * (xc - 1.f / 255.f), mid_in = is * xc;
-                                float v, dm = 0.f, ds = 0.f;
-                                if (lo[c]) {
-                                    v = plus_in - softplus_s(plus_in);
-                                    if constexpr (NLL == 2) { const float sp = sigmoid_fast_s(plus_in); dm = -is * (1.f - sp); ds = -plus_in * (1.f - sp); }
-                                } else if (hi[c]) {
-                                    v = -softplus_s(min_in);
-                                    if constexpr (NLL == 2) { const float sm = sigmoid_fast_s(min_in); dm = is * sm; ds = min_in * sm; }
-                                } else {
-                                    v = mid_in - lsc[c] - 2.f * softplus_s(mid_in) - 4.8481163864f;   // log(127.5)
-                                    if constexpr (NLL == 2) {
-                                        const float smid = sigmoid_fast_s(mid_in);
-                                        dm = -is * (1.f - 2.f * smid);
-                                        ds = -mid_in * (1.f - 2.f * smid) - 1.f;
-                                    }
-                                }
-                                extra2 += bad[c] ? v * L2E : 0.f;
-                                num[c] = bad[c] ? S1 : num[c];                  // (their quotient is the 2^SC of a channel that took no part)
-                                den[c] = bad[c] ? S2 : den[c];
+                                // The reference's branch for vanishing bins: log(pdf at the bin centre) - log(127.5) = log(2/255 t s'(mid)),
+                                // s'(mid) = g / (1 + g)^2 with g = exp(-|mid|) — as numerator 2/255 t, denominator (1 + g)^2 and -|mid| as a
+                                // log2 term (nothing underflows whatever |mid|): one v_exp_f32 for the lanes that need it
+                                const float xc = x[c] - mean[c], t = tl[c] * LN2;          // t = 1 / scale
+                                const float u = fabsf(tl[c] * xc);
+                                const float g = exp2_hw(-u);
+                                const float A = fmaf(g, S1, S1);
+                                float vn = t * (2.f / 255.f * S1), vd = A * A, ve = -u, dm = 0.f, ds = 0.f;
                                 if constexpr (NLL == 2) {
-                                    cdq[c] = bad[c] ? 1.f : cdq[c];
+                                    const float h = (1.f - g) * rcp_hw(1.f + g);       // |1 - 2 sigmoid(mid)|
+                                    dm = xc < 0.f ? -t * h : t * h;
+                                    ds = fmaf(u * LN2, h, -1.f);
+                                }
+                                // beyond that form's reach — saturated pixels whose terms left the range, scales beyond 1e30: the exact
+                                // formulas of dlm_nll_kernel (csrc/loss.hip)
+                                const bool odd = bad[c] && (lo[c] || hi[c] || !(t > 1e-30f));
+                                if (__any(odd)) {
+                                    const float is = t;
+                                    const float plus_in = is * (xc + 1.f / 255.f), min_in = is * (xc - 1.f / 255.f), mid_in = is * xc;
+                                    float v, dmx = 0.f, dsx = 0.f;
+                                    if (lo[c]) {
+                                        v = plus_in - softplus_s(plus_in);
+                                        if constexpr (NLL == 2) { const float sp = sigmoid_fast_s(plus_in); dmx = -is * (1.f - sp); dsx = -plus_in * (1.f - sp); }
+                                    } else if (hi[c]) {
+                                        v = -softplus_s(min_in);
+                                        if constexpr (NLL == 2) { const float sm = sigmoid_fast_s(min_in); dmx = is * sm; dsx = min_in * sm; }
+                                    } else {
+                                        v = mid_in - lsc[c] - 2.f * softplus_s(mid_in) - 4.8481163864f;   // log(127.5)
+                                        if constexpr (NLL == 2) {
+                                            const float smid = sigmoid_fast_s(mid_in);
+                                            dmx = -is * (1.f - 2.f * smid);
+                                            dsx = -mid_in * (1.f - 2.f * smid) - 1.f;
+                                        }
+                                    }
+                                    vn = odd ? S1 : vn;                       // (their quotient is the 2^SC of a channel that takes no part)
+                                    vd = odd ? S2 : vd;
+                                    ve = odd ? v * L2E : ve;
+                                    if constexpr (NLL == 2) { dm = odd ? dmx : dm; ds = odd ? dsx : ds; }
+                                }
+                                extra2 += bad[c] ? ve : 0.f;
+                                num[c] = bad[c] ? vn : num[c];
+                                den[c] = bad[c] ? vd : den[c];
+                                if constexpr (NLL == 2) {
+                                    cdq[c] = bad[c] ? vn * rcp_hw(vd) : cdq[c];
                                     gm[ct][c] = bad[c] ? dm : gm[ct][c];
                                     gs[ct][c] = bad[c] ? ds : gs[ct][c];
                                 }
                             }
                         }
                     }
+                    // @phase likelihood matched
                     if constexpr (NLL == 2) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c)
@@ -364,6 +466,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                     lp2[ct] = fmaf(e[0], L2E, log2_hw(prod)) + (extra2 - lse2 - 3.f * SC);
                 }
             }
+            // @phase pixels item
             Sr = pair_sum(Sr); Sg = pair_sum(Sg); Sb = pair_sum(Sb);
             const float invS = rcp_hw(S);
             pend[s2][0] = fminf(fmaxf(Sr * invS, -1.f), 1.f);
@@ -377,6 +480,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                           (unsigned)__builtin_amdgcn_readfirstlane((int)(d2 & 0xffffffffll));
             }
             if constexpr (WN) {
+                // @phase logsumexp matched
                 float mx = fmaxf(fmaxf(fmaxf(lp2[0], lp2[1]), fmaxf(lp2[2], lp2[3])), lp2[4]);
                 mx = pair_max(mx);
                 float r[5], se = 0.f;
@@ -385,6 +489,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                 se = pair_sum(se);
                 nll_item -= (mx + log2_hw(se)) * LN2;          // (both lanes of a pixel hold it; only q < 2 is summed below)
                 if constexpr (NLL == 2) {
+                    // @phase gradient_rows matched
                     // ---- gradient rows: slots 8k .. 8k+7 of this lane's mixtures k = 2 ct + (q >> 1), then its g / b log-scales ----
                     const float coef = a.nll_scale * (a.nll_row_weight ? a.nll_row_weight[orow] : 1.f);
                     const float inv_se = rcp_hw(se);
@@ -425,6 +530,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
             }
         }
         if constexpr (WN) {
+            // @phase nll_reduce matched
             // the item's 64 pixels: lanes q = 0, 1 (16 columns each), two rows s2 per lane -> one value per item
             float v = q < 2 ? nll_item : 0.f;
             v = row16_sum(v);
@@ -433,6 +539,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
             if (lane == 0) a.nll_partial[(size_t)it_in_f * a.nll_rows + orow] = v;
         }
     };
+    // @phase finish_swap item
     auto epilogue = [&]() __attribute__((always_inline)) {
         const int f = p_f, y0 = p_y0, x0 = p_x0, orow = p_orow;
         const bool store_raw = NLL == 0 && (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) && orow >= 0;
@@ -450,10 +557,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                     acc[ct][s2][r] = __uint_as_float(sw[0]);
                     acc[ct][s2 + 2][r] = __uint_as_float(sw[1]);
                 }
-        if (NLL && orow >= 0) mixtures(std::true_type{}, f, y0, x0, orow);
-        else mixtures(std::false_type{}, f, y0, x0, orow);
+        if (NLL && orow >= 0) mixtures(std::true_type{}, f, y0, x0, orow);      // @callsite matched
+        else mixtures(std::false_type{}, f, y0, x0, orow);                      // @callsite unmatched
     };
 
+    // @phase bookkeeping item
     Pos cur = nxt;
     for (int it = 0; it <= n_iter; ++it) {                         // (one extra trip: the last item's epilogue — ONE copy of that code)
         const int item = item0 + it * istep;
@@ -466,6 +574,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
             cur = nxt;
             f = cur.f; y0 = cur.strip * 4; x0 = cur.cb * 16;
             orow = __builtin_amdgcn_readfirstlane(pre_orow);
+            // @phase staging item
             // ---- staging: BatchNorm affine + LeakyReLU of the producer, the item's power-of-two scale, the two f16 pieces ----
             float amax = 0.f;
 #pragma unroll
@@ -474,8 +583,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                 const bool rv = k == RH ? true : (!(k == 0 && y0 == 0) && !(k == RH - 1 && y0 + 4 == H));
                 if (rv) {
                     float4 v = pre[k];
-                    v.x = fmaf(v.x, bn_s.x, bn_t.x); v.y = fmaf(v.y, bn_s.y, bn_t.y); v.z = fmaf(v.z, bn_s.z, bn_t.z); v.w = fmaf(v.w, bn_s.w, bn_t.w);
-                    v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope); v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+                    const f32x2 v01 = pk_fma(pk2(v.x, v.y), pk2(bn_s.x, bn_s.y), pk2(bn_t.x, bn_t.y));
+                    const f32x2 v23 = pk_fma(pk2(v.z, v.w), pk2(bn_s.z, bn_s.w), pk2(bn_t.z, bn_t.w));
+                    const f32x2 l01 = v01 * pk1(slope), l23 = v23 * pk1(slope);
+                    v.x = fmaxf(v01.x, l01.x); v.y = fmaxf(v01.y, l01.y); v.z = fmaxf(v23.x, l23.x); v.w = fmaxf(v23.y, l23.y);
                     if (k == RH) {
                         const bool ok = halo_ok(y0, x0);
                         v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
@@ -505,6 +616,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
             }
             inv = __uint_as_float((unsigned)(127 - ex - ew) << 23);      // undoes the two power-of-two scales (exact)
         }
+        // @phase targets item
         if (NLL && valid && orow >= 0) {
             // the target pixels of this item's likelihood: requested now, read in the epilogue one full MFMA half-phase later
             const float* tp = a.nll_target + (size_t)orow * 3 * plane + (size_t)(y0 + 2 * (q & 1)) * W + (x0 + j);
@@ -520,10 +632,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
         }
         flush_images();
         pend_ip = nullptr;
+        // @phase bookkeeping item
         if (it + 1 < n_iter && item + istep < item_end) {                               // in flight during this item's MFMAs
             advance(nxt);
             issue_loads(nxt);
         }
+        // @phase mfma_tiles56_stash matched
         // ======== MFMA half-phase ========
         if (valid) {
             const bool want_nll = NLL && orow >= 0;
@@ -562,6 +676,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                 }
             }
 
+            // @phase mfma_passA item
             // pass A: channel tiles 0..4 = the 80 slots the mixture mean reads; their epilogue runs in the next VALU half-phase
             mfma_tiles<0, 5>(wl, reg, tapoff, lane, acc);
             // pass B for the stored-parameters modes: channel tiles 5, 6 = slots 80..99 (+ 12 empty), only ever stored raw
@@ -571,6 +686,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                 finish_tiles<5, 2>(a, bias_l, accr, inv, true, orow, y0, x0, j, q);
             }
         } else {
+            // @phase invalid_item rare
             // (every path through this half-phase defines the accumulators: otherwise they count as live across the staging and the
             // prefetch of the next item — 80 registers — and the prefetch addresses get spilled instead)
 #pragma unroll
@@ -579,6 +695,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                 for (int pt = 0; pt < 4; ++pt) acc[c][pt] = f32x4{0, 0, 0, 0};
             ls4[0][0] = ls4[0][1] = ls4[1][0] = ls4[1][1] = 0.f;
         }
+        // @phase bookkeeping item
         p_valid = valid; p_f = f; p_y0 = y0; p_x0 = x0; p_orow = orow; p_inv = inv;
     }
     flush_images();

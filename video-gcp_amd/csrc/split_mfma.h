@@ -126,33 +126,4 @@ __device__ __forceinline__ void mfma_tiles(const char* wl, const char* reg, cons
     __builtin_amdgcn_s_setprio(0);
 }
 
-// scale back + bias, and the raw NHWC store of channel tiles C0 .. C0 + NC - 1
-template <int C0, int NC>
-__device__ __forceinline__ void finish_tiles(const gcpx_conv_args& a, const float* bias_l, f32x4 (&acc)[NC][4], const float inv, const bool store_raw,
-                                             const int orow, const int y0, const int x0, const int j, const int q) {
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias_l + (C0 + c) * 16 + q * 4);
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            acc[c][pt][0] = fmaf(acc[c][pt][0], inv, bv.x); acc[c][pt][1] = fmaf(acc[c][pt][1], inv, bv.y);
-            acc[c][pt][2] = fmaf(acc[c][pt][2], inv, bv.z); acc[c][pt][3] = fmaf(acc[c][pt][3], inv, bv.w);
-        }
-    }
-    if (store_raw) {
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            float* op = a.out + (((size_t)orow * a.Hout + (y0 + pt)) * a.Wout + (x0 + j)) * a.out_pitch;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int ch = (C0 + c) * 16 + q * 4;
-                if (ch < a.out_pitch) {
-                    const f32x4 v = acc[c][pt];
-                    *reinterpret_cast<float4*>(op + ch) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
-    }
-}
-
 }  // namespace
