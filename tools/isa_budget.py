@@ -57,7 +57,8 @@ def main():
 
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-gline-tables-only", "-S", "--cuda-device-only"] + args.flags.split() + [src, "-o", out]
+        extra = ["-fno-slp-vectorize"] if base in ("conv3x3_head_split.hip", "loss.hip") else []      # per-file flags of csrc/build.sh
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-gline-tables-only", "-S", "--cuda-device-only"] + extra + args.flags.split() + [src, "-o", out]
         subprocess.run(cmd, check=True, cwd=os.path.dirname(src), stderr=subprocess.DEVNULL)
         asm = open(out).read().split("\n")
     start = next(i for i, l in enumerate(asm) if args.kernel in l and re.match(r"^_Z\S+:", l))
@@ -116,10 +117,10 @@ def main():
         t = um * res["unmatched item"]["trans"] + mt * res["matched item"]["trans"]
         m = um * res["unmatched item"]["mfma"] + mt * res["matched item"]["mfma"]
         print(f"\nper launch ({args.items} items, {mt} of matched frames): VALU {v / 1e6:.1f} M wave instructions (of them transcendental {t / 1e6:.1f} M), MFMA {m / 1e6:.1f} M")
-        # 2 cycles per plain VALU, 10.7 per transcendental (both wavefronts of a SIMD busy: tools/mfma_valu_overlap.hip), 16 per MFMA; 1024 SIMDs
-        cyc = ((v - t) * 2 + t * 10.7 + m * 16) / 1024
-        print(f"issue-time model: {cyc / 1e6:.3f} M cycles per SIMD = {cyc / 2.1e9 * 1e3:.3f} ms at 2.1 GHz (MFMA {m * 16 / 1024 / 2.1e9 * 1e3:.3f}, plain VALU {(v - t) * 2 / 1024 / 2.1e9 * 1e3:.3f}, transcendental {t * 10.7 / 1024 / 2.1e9 * 1e3:.3f})")
-
+        # issue cost per wave instruction on a SIMD, from the round-5 ablation builds of the head kernel (profiles/r05_head_isa_budget.txt):
+        # 4 cycles per plain VALU, ~11 per transcendental, 16 per v_mfma_f32_16x16x32_f16; nothing overlaps (two wavefronts per SIMD); 1024 SIMDs
+        cyc = ((v - t) * 4 + t * 11 + m * 16) / 1024
+        print(f"issue-time model: {cyc / 1e6:.3f} M cycles per SIMD = {cyc / 2.1e9 * 1e3:.3f} ms at 2.1 GHz (MFMA {m * 16 / 1024 / 2.1e9 * 1e3:.3f}, plain VALU {(v - t) * 4 / 1024 / 2.1e9 * 1e3:.3f}, transcendental {t * 11 / 1024 / 2.1e9 * 1e3:.3f})")
 
 if __name__ == "__main__":
     main()

@@ -26,22 +26,32 @@
 #include <cstdlib>
 #include <type_traits>
 
+// (ablation switch of the gradient rows' scalar-register statement: profiles/r05_head_store_hazard.txt)
+#ifndef GCPX_STORE_WAIT
+#define GCPX_STORE_WAIT 1
+#endif
+
 namespace {
 
 constexpr float L2E = 1.44269504088896341f, LN2 = 0.69314718055994531f;
 
-// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue like their scalar forms and do two lanes' worth: wherever two values go through the
-// same f32 arithmetic they travel as a pair
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-#ifdef GCPX_NOPK
+// Two values that go through the same f32 arithmetic travel as a pair — of SCALAR instructions.  This file is built with
+// -fno-slp-vectorize (csrc/build.sh) and holds no packed-f32 VALU instruction: v_pk_*_f32 measured no faster here (a packed operation
+// costs its two scalar issues), and every wrong value of the round-4 corruption of the training variant's gradient rows came out of a
+// packed multiply whose low lane read the high half of a register pair (profiles/r05_head_store_hazard.txt; tools/isa_hazard_scan.py
+// keeps this file at zero such instructions).
+struct f32x2 {
+    float x, y;
+};
+__device__ __forceinline__ f32x2 operator+(const f32x2 a, const f32x2 b) { return f32x2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f32x2 operator-(const f32x2 a, const f32x2 b) { return f32x2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f32x2 operator*(const f32x2 a, const f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f32x2 operator-(const f32x2 a) { return f32x2{-a.x, -a.y}; }
 __device__ __forceinline__ f32x2 pk_fma(const f32x2 a, const f32x2 b, const f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
-#else
-__device__ __forceinline__ f32x2 pk_fma(const f32x2 a, const f32x2 b, const f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-#endif
 __device__ __forceinline__ f32x2 pk2(const float a, const float b) { return f32x2{a, b}; }
 __device__ __forceinline__ f32x2 pk1(const float a) { return f32x2{a, a}; }
 
-// scale back + bias (two channels per instruction), and the raw NHWC store of channel tiles C0 .. C0 + NC - 1
+// scale back + bias, and the raw NHWC store of channel tiles C0 .. C0 + NC - 1
 template <int C0, int NC>
 __device__ __forceinline__ void finish_tiles(const gcpx_conv_args& a, const float* bias_l, f32x4 (&acc)[NC][4], const float inv, const bool store_raw,
                                              const int orow, const int y0, const int x0, const int j, const int q) {
@@ -507,17 +517,25 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
                         float4 va = make_float4(coef * (pik - wk), gw_ * gm[ct][0], g1, g2);
                         float4 vb = make_float4(g1 * xr * (1.f - cf[ct][0] * cf[ct][0]), g2 * xr * (1.f - cf[ct][1] * cf[ct][1]),
                                                 g2 * xg * (1.f - cf[ct][2] * cf[ct][2]), gw_ * gs[ct][0]);
-                        // Wait states between the (packed-f32) multiplies that produce the rows and the 16-byte stores that read them
-                        // (round 4: without them ~1e-7 of the stored values came out as the register's previous content in lanes 32..63;
-                        // profiles/r05_head_store_hazard.txt has the instruction pair)
+                        // The row's eight products pass this statement as single registers (round 4 found ~1e-7 of the stored values
+                        // wrong, +-0 in lanes 32..63, run to run; round 5: every one of them the LOW result of a v_pk_mul_f32 that read
+                        // the HIGH half of a register pair; wait states in front of the stores change nothing, scalar multiplies do —
+                        // profiles/r05_head_store_hazard.txt.  The file is built without packed f32 at all; the statement keeps the
+                        // rows scalar under any flags: GCPX_STORE_WAIT=0 + SLP vectorisation is the failing build)
+#if GCPX_STORE_WAIT == 1
+                        asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w), "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
+#elif GCPX_STORE_WAIT == 2
                         asm volatile("s_nop 7" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w), "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
+#endif
                         *reinterpret_cast<float4*>(dk) = va;
                         *reinterpret_cast<float4*>(dk + 4) = vb;
                         glg[ct] = gw_ * gs[ct][1];
                         glb[ct] = gw_ * gs[ct][2];
                     }
-                    asm volatile("s_nop 7" : "+v"(glg[0]), "+v"(glb[0]), "+v"(glg[1]), "+v"(glb[1]), "+v"(glg[2]), "+v"(glb[2]), "+v"(glg[3]), "+v"(glb[3]),
+#if GCPX_STORE_WAIT == 1
+                    asm volatile("" : "+v"(glg[0]), "+v"(glb[0]), "+v"(glg[1]), "+v"(glb[1]), "+v"(glg[2]), "+v"(glb[2]), "+v"(glg[3]), "+v"(glb[3]),
                                  "+v"(glg[4]), "+v"(glb[4]));
+#endif
                     // packing.dlm_log_scale_slot: ct = 0, 1 -> lane group 2 h of tile 5, ct = 2, 3 -> 2 h + 1, ct = 4 -> slots 96 + 2 h
                     *reinterpret_cast<float4*>(drow + 80 + 8 * h) = make_float4(glg[0], glb[0], glg[1], glb[1]);
                     *reinterpret_cast<float4*>(drow + 84 + 8 * h) = make_float4(glg[2], glb[2], glg[3], glb[3]);
