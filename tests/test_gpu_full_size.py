@@ -264,10 +264,10 @@ def test_c3_training_shard_batch16_steps_reduce_loss():
 
 def test_c3_training_step_is_deterministic_at_full_size():
     """Two trainers, the same data and noise, three steps each: parameters, moments, losses and the likelihood gradient bit-identical.
-    Every kernel sums in a fixed order and the lanes of the step are ordered by events, so any difference is a race — round 4 found one
-    this way: at full size (two wavefronts per SIMD, both busy) the head's training variant stored ~150 of its 587 M gradient values as the
-    register's previous content (a VALU-result -> store-data hazard, fixed by wait states in front of the stores: conv3x3_split.hip);
-    smaller configurations never showed it."""
+    Every kernel sums in a fixed order and the lanes of the step are ordered by events, so any difference is a race or a miscompiled /
+    mis-executed instruction — round 4 found one this way: at full size (two wavefronts per SIMD, both busy) ~150 of the head's 587 M
+    likelihood-gradient values came out as +-0, different ones every launch; round 5 traced them to packed-f32 multiplies whose low lane
+    reads the high half of a register pair (profiles/r05_head_store_hazard.txt).  Smaller configurations never showed it."""
     from video_gcp_amd.training import GCPTrainStep
     hp, sd, ma = _build("c3")
     _, _, mb = _build("c3")
@@ -283,6 +283,76 @@ def test_c3_training_step_is_deterministic_at_full_size():
         assert torch.equal(oa.raw["losses"], ob.raw["losses"]), step
         for x, y, what in [(ma.theta, mb.theta, "theta"), (ta.exp_avg, tb.exp_avg, "exp_avg"), (ta.exp_avg_sq, tb.exp_avg_sq, "exp_avg_sq")]:
             assert torch.equal(x, y), (step, what)
+
+
+def _tensors(o, pre=""):
+    out = {}
+    for k, v in (o.items() if hasattr(o, "items") else []):
+        if torch.is_tensor(v):
+            out[pre + k] = v
+        elif isinstance(v, dict):
+            out.update(_tensors(v, pre + k + "."))
+    return out
+
+
+def _same(a, b):
+    return a.shape == b.shape and bool(((a == b) | (torch.isnan(a) & torch.isnan(b)) if a.is_floating_point() else (a == b)).all())
+
+
+@pytest.mark.parametrize("phase", ["train", "inference"])
+def test_c2_forward_is_deterministic_at_full_size(phase):
+    """Every tensor the c2 forward returns (images of all 2032 node frames, latents, matched / pruned sequences, every loss input),
+    bit for bit over four runs on the same inputs and noise — batch-statistics and running-statistics BatchNorm."""
+    hp, sd, model = _build("c2")
+    model.train(phase == "train")
+    inputs, noise, _ = make_inputs(hp, seed=1, variant="A")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    runs = []
+    for _ in range(4):
+        o = model(dev_in, phase, noise=noise.cuda())
+        torch.cuda.synchronize()
+        runs.append({k: v.clone() for k, v in _tensors(o.raw).items()})
+    assert len(runs[0]) >= 20
+    diff = [k for k in runs[0] if not all(_same(runs[0][k], r[k]) for r in runs[1:])]
+    assert not diff, diff
+
+
+def test_c5_adaptive_training_gradient_is_deterministic_at_full_size():
+    """The adaptive (soft-DTW binding, attentive inference) training step of the c5 shard (B = 8, T = 200, 255 nodes): losses and the
+    whole flat gradient bit for bit over three backward passes."""
+    from video_gcp_amd.training import GCPTrainStep
+    hp, sd, model = _build("c5")
+    tr = GCPTrainStep(model)
+    inputs, noise, _ = make_inputs(hp, seed=2, variant="A")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    gs, ls = [], []
+    for _ in range(3):
+        o = tr.backward(dev_in, noise.cuda())
+        torch.cuda.synchronize()
+        gs.append(tr.grad.clone())
+        ls.append(o.raw["losses"].clone())
+    assert torch.equal(gs[0], gs[1]) and torch.equal(gs[0], gs[2])
+    assert torch.equal(ls[0], ls[1]) and torch.equal(ls[0], ls[2])
+    assert torch.isfinite(gs[0]).all() and float(gs[0].abs().max()) > 0
+
+
+def test_sequential_training_gradient_is_deterministic_at_full_size():
+    """gcp_sequential (flat VRNN, 79 dependent steps on three lanes) at the c2 shapes: the flat gradient bit for bit over three backward passes."""
+    from video_gcp_amd.sequential import GCPSequentialModel
+    from video_gcp_amd.training_sequential import SequentialTrainStep
+    from video_gcp_amd import config
+    hp = config("c2")
+    tr = SequentialTrainStep(GCPSequentialModel(hp, device="cuda"))
+    inputs, noise, _ = make_inputs(hp, seed=3, variant="A")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    nz = noise[:, :hp.max_seq_len - 1].contiguous().cuda()
+    gs = []
+    for _ in range(3):
+        tr.backward(dev_in, nz)
+        torch.cuda.synchronize()
+        gs.append(tr.grad.clone())
+    assert torch.equal(gs[0], gs[1]) and torch.equal(gs[0], gs[2])
+    assert torch.isfinite(gs[0]).all() and float(gs[0].abs().max()) > 0
 
 
 # ------------------------------------------------------------------------------------------------------------------------
