@@ -4,6 +4,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -150,6 +151,19 @@ def test_gradient_bucket_ranges_tile_the_flat_gradient():
     inside = [k for k, (o, _) in poff.items() if lo <= o < hi]
     assert inside and all(k.startswith("tree_module.tree_modules.3.") for k in inside)
     assert gradient_bucket_ranges(poff, hp.hierarchy_levels, False) == [("all", 0, off)]
+    # a table in another order (a converted reference state_dict: decoder parameters behind the tree levels) must not hand decoder
+    # parameters to a tree level's slice — the early optimizer would update them before their gradient exists: one bucket instead
+    keys = list(poff)
+    moved = [k for k in keys if not k.startswith("decoder.")] + [k for k in keys if k.startswith("decoder.")]
+    off2, poff2 = 0, {}
+    for k in moved:
+        poff2[k] = (off2, poff[k][1])
+        n = 1
+        for d in poff[k][1]:
+            n *= d
+        off2 += (n + 3) // 4 * 4
+    with pytest.warns(UserWarning, match="outside the range of its slice"):
+        assert gradient_bucket_ranges(poff2, hp.hierarchy_levels, True) == [("all", 0, off2)]
 
 
 def _bucket_worker(rank, world, port, q):

@@ -51,21 +51,24 @@ __device__ __forceinline__ f32x2 pk_fma(const f32x2 a, const f32x2 b, const f32x
 __device__ __forceinline__ f32x2 pk2(const float a, const float b) { return f32x2{a, b}; }
 __device__ __forceinline__ f32x2 pk1(const float a) { return f32x2{a, a}; }
 
-// scale back + bias, and the raw NHWC store of channel tiles C0 .. C0 + NC - 1
-template <int C0, int NC>
-__device__ __forceinline__ void finish_tiles(const gcpx_conv_args& a, const float* bias_l, f32x4 (&acc)[NC][4], const float inv, const bool store_raw,
-                                             const int orow, const int y0, const int x0, const int j, const int q) {
-    const f32x2 inv2 = pk1(inv);
+// scale back + bias, and the raw NHWC store of channel tiles C0 .. C0 + NC - 1.  FOLD (the kernels that never store raw parameters):
+// the lanes that hold colour coefficients (odd lane groups, registers 0..2 of tiles 0..4) scale by `inv3` = inv x 2 log2(e) — the
+// argument of the tanh's v_exp_f32 comes straight out of this fma (their bias slots are scaled alike when the bias is loaded)
+template <int C0, int NC, bool FOLD = false>
+__device__ __forceinline__ void finish_tiles(const gcpx_conv_args& a, const float* bias_l, f32x4 (&acc)[NC][4], const float inv, const float inv3,
+                                             const bool store_raw, const int orow, const int y0, const int x0, const int j, const int q) {
+    const f32x2 inv2 = pk1(inv), inv01 = pk1(FOLD ? inv3 : inv), inv23 = pk2(FOLD ? inv3 : inv, inv);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const float4 bv = *reinterpret_cast<const float4*>(bias_l + (C0 + c) * 16 + q * 4);
         const f32x2 b01 = pk2(bv.x, bv.y), b23 = pk2(bv.z, bv.w);
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-            const f32x2 lo = pk_fma(pk2(acc[c][pt][0], acc[c][pt][1]), inv2, b01), hi = pk_fma(pk2(acc[c][pt][2], acc[c][pt][3]), inv2, b23);
+            const f32x2 lo = pk_fma(pk2(acc[c][pt][0], acc[c][pt][1]), inv01, b01), hi = pk_fma(pk2(acc[c][pt][2], acc[c][pt][3]), inv23, b23);
             acc[c][pt][0] = lo.x; acc[c][pt][1] = lo.y; acc[c][pt][2] = hi.x; acc[c][pt][3] = hi.y;
         }
     }
+    (void)inv2;
     if (store_raw) {
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
@@ -114,6 +117,14 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
     const auto s32 = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
     x = max((int)s32[0], (int)s32[1]);
     return __int_as_float(__builtin_amdgcn_readfirstlane(x));
+}
+// sum over the 16 lanes of a row by DPP row operations (every lane of the row ends with the sum)
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));     // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));     // row_mirror
+    return v;
 }
 // the two f16 pieces of four scaled values: p1 = rn16(v s), p2 = rn16(v s - p1) (v s is exact: s is a power of two), one fused
 // multiply-add with an f16 result per piece and value
@@ -165,7 +176,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
 
     for (int i = tid; i < Cfg::W_BYTES / 16; i += 512) smem4[i] = reinterpret_cast<const float4*>(a.wpk_split)[i];
     float* bias_l = reinterpret_cast<float*>(reinterpret_cast<char*>(smem4) + Cfg::W_BYTES + 8 * Cfg::REGION_BYTES);
-    if (tid < CT * 16) bias_l[tid] = tid < a.out_pitch ? a.bias[tid] : 0.f;
+    // (FOLD: slots 8k+4 .. 8k+6, the colour coefficients of mixture k, carry 2 log2(e) x bias — finish_tiles)
+    constexpr bool FOLD = NLL != 0;
+    if (tid < CT * 16) bias_l[tid] = tid < a.out_pitch ? a.bias[tid] * (FOLD && tid < 80 && (tid & 7) >= 4 && (tid & 7) < 7 ? 2.f * L2E : 1.f) : 0.f;
     __syncthreads();
 
     // operand address of k-step s: tap 2 s + (q >> 1), channels 8 (q & 1) .. + 7 of pixel (row + ty, j + tx).  The 10th tap (s = 4,
@@ -336,9 +349,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
             for (int ct = 0; ct < 5; ++ct) {
                 const f32x4 e = acc[ct][s2], o = acc[ct][s2 + 2];          // {logit, mean r, g, b}, {coefficients 0..2, log-scale r}
                 // tanh of the colour coefficients, 1 - 2 / (exp(2 x) + 1): (c0, c1) as a pair, c2 alone
-                const f32x2 a01 = pk2(o[0], o[1]) * pk1(2.f * L2E);
+                const f32x2 a01 = FOLD ? pk2(o[0], o[1]) : pk2(o[0], o[1]) * pk1(2.f * L2E);      // (FOLD: scaled by finish_tiles)
                 const f32x2 q01 = pk2(exp2_hw(a01.x), exp2_hw(a01.y)) + pk1(1.f);
-                const float q2 = exp2_hw(o[2] * (2.f * L2E)) + 1.f;
+                const float q2 = exp2_hw(FOLD ? o[2] : o[2] * (2.f * L2E)) + 1.f;
                 const f32x2 c01 = pk_fma(pk2(rcp_hw(q01.x), rcp_hw(q01.y)), pk1(-2.f), pk1(1.f));
                 const float c2 = fmaf(rcp_hw(q2), -2.f, 1.f);
                 const float mr = e[1];
@@ -551,8 +564,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
             // @phase nll_reduce matched
             // the item's 64 pixels: lanes q = 0, 1 (16 columns each), two rows s2 per lane -> one value per item
             float v = q < 2 ? nll_item : 0.f;
-            v = row16_sum(v);
-            v += __shfl_xor(v, 16);
+            v = row16_sum_dpp(v);
+            const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+            v = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);      // lane groups 0 + 1 (2, 3 hold zeros)
             const int it_in_f = (y0 >> 2) * ncb + (x0 >> 4);
             if (lane == 0) a.nll_partial[(size_t)it_in_f * a.nll_rows + orow] = v;
         }
@@ -561,7 +575,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
     auto epilogue = [&]() __attribute__((always_inline)) {
         const int f = p_f, y0 = p_y0, x0 = p_x0, orow = p_orow;
         const bool store_raw = NLL == 0 && (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) && orow >= 0;
-        finish_tiles<0, 5>(a, bias_l, acc, p_inv, store_raw, orow, y0, x0, j, q);
+        // (the coefficient lanes: odd lane groups before the row swap)
+        finish_tiles<0, 5, FOLD>(a, bias_l, acc, p_inv, (q & 1) ? p_inv * (2.f * L2E) : p_inv, store_raw, orow, y0, x0, j, q);
         if (mode == GCPX_HEAD_RAW) return;
         // kernel channel order and the lane exchange: see conv3x3_head_kernel (conv3x3.hip)
 #pragma unroll
@@ -666,7 +681,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
             if (want_nll) {
                 f32x4 accb[2][4];
                 mfma_tiles<5, 2>(wl, reg, tapoff, lane, accb);
-                finish_tiles<5, 2>(a, bias_l, accb, inv, false, orow, y0, x0, j, q);
+                finish_tiles<5, 2>(a, bias_l, accb, inv, inv, false, orow, y0, x0, j, q);
                 // the same row swap as for tiles 0..4: afterwards accb[c][s2] holds lane group q' = 2 (q >> 1) and accb[c][s2 + 2]
                 // lane group q' + 1 of THIS lane's pixel.  Slot layout of tiles 5, 6: packing.dlm_log_scale_slot
 #pragma unroll
@@ -701,7 +716,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
             if (NLL == 0 && (mode == GCPX_HEAD_RAW || mode == GCPX_HEAD_DLM_BOTH) && orow >= 0) {
                 f32x4 accr[2][4];
                 mfma_tiles<5, 2>(wl, reg, tapoff, lane, accr);
-                finish_tiles<5, 2>(a, bias_l, accr, inv, true, orow, y0, x0, j, q);
+                finish_tiles<5, 2>(a, bias_l, accr, inv, inv, true, orow, y0, x0, j, q);
             }
         } else {
             // @phase invalid_item rare

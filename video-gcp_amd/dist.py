@@ -83,15 +83,17 @@ def gradient_bucket_ranges(poff, hierarchy_levels, untied_layers):
     ends.  `poff` is the model's {name: (offset, shape)} table; offsets are in floats.  Tied levels accumulate into one weight set: a
     single bucket."""
     end = 0
-    starts = {}
+    starts, spans = {}, []
     for k, (o, shp) in poff.items():
         n = 1
         for d in shp:
             n *= d
-        end = max(end, o + (n + 3) // 4 * 4)
-        if k.startswith("tree_module.tree_modules."):
-            l = int(k.split(".")[2])
-            starts[l] = min(starts.get(l, o), o)
+        hi = o + (n + 3) // 4 * 4
+        end = max(end, hi)
+        lvl = int(k.split(".")[2]) if k.startswith("tree_module.tree_modules.") else -1
+        spans.append((o, hi, lvl, k))
+        if lvl >= 0:
+            starts[lvl] = min(starts.get(lvl, o), o)
     if not untied_layers or hierarchy_levels < 2 or len(starts) < hierarchy_levels:
         return [("all", 0, end)]
     out = []
@@ -100,6 +102,18 @@ def gradient_bucket_ranges(poff, hierarchy_levels, untied_layers):
         out.append((f"tree{l}", starts[l], hi))
     if starts[0] > 0:
         out.append(("rest", 0, starts[0]))
+    # The ranges are also the slices of the early optimizer (training.py marks a slice final at its tree level and updates + re-packs its
+    # parameters before the encoder's gradients exist): that is only right if every parameter of level l lies inside [starts[l],
+    # starts[l + 1]) and nothing else does — true for the model's own table (params.param_table order), not for an arbitrary order of
+    # the `params` dict (a converted reference state_dict).  Anything else gets the single bucket, which is always right.
+    level_range = {int(n[4:]): (lo, hi) for n, lo, hi in out if n.startswith("tree")}
+    for lo, hi, lvl, k in spans:
+        ok = (level_range[lvl][0] <= lo and hi <= level_range[lvl][1]) if lvl >= 0 else hi <= starts[0]
+        if not ok:
+            import warnings
+            warnings.warn(f"gradient buckets: parameter {k} at [{lo}, {hi}) is outside the range of its slice; using one bucket "
+                          "(pass the parameters in params.param_table order to get the per-level exchange)")
+            return [("all", 0, end)]
     # the table is laid out in parameter order: the ranges must tile [0, end) exactly
     cover = sorted((lo, hi) for _, lo, hi in out)
     assert cover[0][0] == 0 and cover[-1][1] == end and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), cover
