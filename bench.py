@@ -20,7 +20,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2500.0     # same table: dense f16 / bf16 MFMA (no sparsity)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_head_kernel.json")
-HEAD_KERNEL_SOURCES = ("video-gcp_amd/csrc/conv3x3.hip", "video-gcp_amd/csrc/conv3x3_split.hip", "video-gcp_amd/csrc/common.h")
+HEAD_KERNEL_SOURCES = ("video-gcp_amd/csrc/conv3x3.hip", "video-gcp_amd/csrc/conv3x3_head_split.hip", "video-gcp_amd/csrc/split_mfma.h",
+                       "video-gcp_amd/csrc/common.h")
 
 
 def kernel_source_sha(paths=HEAD_KERNEL_SOURCES):
@@ -39,7 +40,7 @@ def measured_head_traffic(batch, eval_bn):
     reason on stderr, so a regenerated summary that lost a field does not make `roofline.traffic` disappear silently."""
     def reject(why):
         print(f"bench: roofline.traffic = null ({PMC_SUMMARY}: {why})", file=sys.stderr, flush=True)
-        return None
+        return None, None
     try:
         with open(PMC_SUMMARY) as f:
             d = json.load(f)
@@ -49,7 +50,7 @@ def measured_head_traffic(batch, eval_bn):
             return reject(f"taken at batch {d.get('batch')}, eval_bn {d.get('eval_bn')}")
         if not d.get("with_loss"):          # the headline forward keeps the matched frames' raw parameters (a round-2 pass did not)
             return reject("no `with_loss` field: not a pass over the forward with losses")
-        return int(d["traffic_bytes_per_launch"])
+        return int(d["traffic_bytes_per_launch"]), d.get("round")
     except (OSError, KeyError, ValueError) as e:
         return reject(repr(e))
 
@@ -121,14 +122,14 @@ def cpu_baseline(budget_s=24.0, full=False, schedule=None):
         sched = [(cfg, b, k, r, 3, 10, 10, 1e9) for cfg, b in (("c1", 2), ("c2", 16)) for k in (1, all_threads)
                  for r in ("forward", "planning_rollout", "train_step")]
     else:
-        # bounded default (about 30 s): the headline region (c2 shapes, batch 2, inference forward) at 1 / 16 / all threads with
-        # 1 warm-up + 10 timed iterations at the two small thread counts (the all-thread run is oversubscribed on this oracle and
-        # slower: 3 iterations), then one training step and the c1 plumbing config at the thread count that came out best
+        # bounded default (about 40 s): the headline region (c2 shapes, batch 2, inference forward) at 1 / 16 / all threads with
+        # BASELINE.md section 2's 3 warm-up + 10 timed iterations (the all-thread run is oversubscribed on this oracle and slower: 3 + 4),
+        # then one training step (3 + 3: a step is ~1.5 s) and the c1 plumbing config at the thread count that came out best
         mid = min(16, all_threads)
-        sched = [("c2", 2, 1, "forward", 1, 10, 10, 1e9), ("c2", 2, mid, "forward", 1, 10, 10, 1e9),
-                 ("c2", 2, all_threads, "forward", 1, 3, 3, 1e9)]
-        tail = lambda k: [("c2", 2, k, "train_step", 0, 2, 2, 1e9), ("c1", 2, k, "forward", 1, 10, 10, 1e9),
-                          ("c1", 2, k, "train_step", 1, 3, 3, 1e9)]
+        sched = [("c2", 2, 1, "forward", 3, 10, 10, 1e9), ("c2", 2, mid, "forward", 3, 10, 10, 1e9),
+                 ("c2", 2, all_threads, "forward", 3, 4, 4, 1e9)]
+        tail = lambda k: [("c2", 2, k, "train_step", 3, 3, 3, 1e9), ("c1", 2, k, "forward", 3, 10, 10, 1e9),
+                          ("c1", 2, k, "train_step", 3, 10, 10, 1e9)]
     cache = {}
 
     def run(item):
@@ -163,7 +164,8 @@ def cpu_baseline(budget_s=24.0, full=False, schedule=None):
                      f"{head['batch']}: median of {head['iters']} forward passes on {head['threads']} of {all_threads} hardware threads "
                      "(the fastest of the thread counts in `runs`, which lists every timed region: config, batch, threads, forward / "
                      "training step, median and min seconds)"
-                     + ("" if (full or schedule) else "; bounded sample — the full BASELINE.md section-2 protocol is profiles/r02_cpu_baseline_full.json"))
+                     + ("" if (full or schedule) else "; bounded sample (3 warm-up iterations per region) — BASELINE.md section 2's protocol at "
+                        "c1 and c2, B = 16, on this round's GPU box: profiles/r05_cpu_baseline_full.json"))
     return out
 
 
@@ -587,10 +589,28 @@ def main():
     head_ms = model.timed_op_ms()
     elapsed = D.max_over_ranks(elapsed, device=dev)
     total_loss = float(model.get_total_loss(dinp, losses).value)
+    replay = model.replay_info()
+
+    def replay_leg(mode):
+        """the headline step (forward + loss, no events around the head) with every plan forced onto one way of replaying, same process"""
+        model.set_timed_op(None)
+        model.force_replay(mode)
+
+        def step():
+            o = model(dinp, "train")
+            model.loss(dinp, o)
+        step()
+        dt = _timed(step, args.steps, 2, world, dev)
+        return {"ms_per_step": round(1e3 * dt, 3), "value": round(world * hp.batch_size * hp.max_seq_len / dt, 1), "unit": "frames/s"}
+    replay_legs = None
+    if not args.no_extras:
+        replay_legs = {"forward_graph": replay_leg("graph"), "forward_eager": replay_leg("eager")}
+        model.force_replay("auto")
 
     also = None
     if not args.no_extras:
         also = extras(args, model, hp, dinp, dnoise, inputs, rank, world, dev, dinp_noloss)
+        also = dict(replay_legs, **also)
 
     if rank == 0:
         frames = world * hp.batch_size * hp.max_seq_len * args.steps
@@ -618,6 +638,10 @@ def main():
             peak = F32_MFMA_PEAK_TFLOPS
             kern = ("conv3x3_head_kernel<6, true> (decoder output head, 3x3 conv 16->100 ch @64x64 = 6 MFMA tiles + 4-channel 4x4x1 "
                     "remainder, fused mixture mean)")
+        traffic, pmc_round = measured_head_traffic(hp.batch_size, args.eval_bn)
+        traffic_source = (None if traffic is None else
+                          f"profiles/pmc_head_kernel.json ({pmc_round}): rocprofv3 --pmc passes of this command on these kernel sources "
+                          "(source hash checked), NOT measured in this run")
         line = {
             "metric": "predicted frames/sec, 64x64x3 seq_len=80 gcp_tree (posterior forward + all loss terms, model(inputs) and model.loss() of train.py:157-159, batch-stat BatchNorm)",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -629,7 +653,11 @@ def main():
                                    + ("running-stat" if args.eval_bn else "batch-stat") + " BatchNorm",
                        "batch_per_gpu": hp.batch_size, "seq_len": hp.max_seq_len, "img": hp.img_sz,
                        "nodes_per_seq": hp.n_nodes, "parallelism": f"dp{world} (independent sequences, no collective)",
-                       "total_loss_last_step": total_loss},
+                       "total_loss_last_step": total_loss,
+                       # how the timed steps were replayed: GCPTreeModel times graph against eager replay once per plan (`tuned_ms`,
+                       # 3 x 4 replays each between a forward() call's stream hand-overs) and keeps the faster; also.forward_graph /
+                       # also.forward_eager time the whole step both ways in this process
+                       "replay": replay},
             "roofline": {"kernel": kern,
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
@@ -637,7 +665,7 @@ def main():
                          # HBM bytes per launch: rocprofv3 PMC passes of this command on these kernel sources (profiles/pmc_head_kernel.json,
                          # tools/pmc_collect.sh), null when the head kernel changed since or the workload differs;
                          # algorithmic bytes = 532.7 MB in (16 ch f32 @64x64 x 2032 frames) + 99.9 MB out
-                         "traffic": measured_head_traffic(hp.batch_size, args.eval_bn),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": head_flops},
         }
         if also is not None:

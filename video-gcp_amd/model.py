@@ -1735,6 +1735,24 @@ class GCPTreeModel:
         plan.tuned = (tg / reps, te / reps)
         return te < 0.98 * tg
 
+    def replay_info(self):
+        """How the plan of the latest forward() is replayed and what the one-time comparison measured (bench.py reports it):
+        {"mode": "graph" | "eager", "policy": the GCPX_FORWARD_REPLAY setting, "tuned_ms": {"graph", "eager"} or None}."""
+        plan = [v[1] for v in self._plans.values()][-1]
+        tuned = getattr(plan, "tuned", None)
+        return {"mode": "eager" if (plan.eager or not self.use_graph) else "graph",
+                "policy": {True: "graph", False: "eager"}.get(self.use_graph, "auto"),
+                "tuned_ms": None if tuned is None else {"graph": round(1e3 * tuned[0], 4), "eager": round(1e3 * tuned[1], 4)}}
+
+    def force_replay(self, mode):
+        """Replay every existing plan as a hipGraph ("graph"), by eager launches ("eager") or as the one-time comparison chose ("auto",
+        re-measured on the next call).  Measurement aid (bench.py's also.forward_graph / forward_eager legs)."""
+        self.use_graph = {"graph": True, "eager": False, "auto": "auto"}[mode]
+        for _, plan in self._plans.values():
+            if mode == "auto":
+                plan.graph = None
+            plan.eager = mode == "eager"
+
     def _capture(self, plan, ops, stream):
         rt.check(self.lib.gcpx_graph_begin(stream), "graph_begin")
         plan.run(self._streams, ops)
