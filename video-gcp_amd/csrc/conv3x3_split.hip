@@ -600,21 +600,6 @@ struct FoldCfg {
     static constexpr int NO = (PR * RW * 8 + 63) / 64;             // region float4 outputs per lane (14)
 };
 
-// largest value over the wavefront without the LDS crossbar: DPP inside the 16-lane rows, v_readlane across them (wave-uniform result)
-__device__ __forceinline__ float wave_max_nonneg(float v) {
-    auto dpp = [](float x, auto ctrl) __attribute__((always_inline)) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
-    };
-    v = fmaxf(v, dpp(v, std::integral_constant<int, 0xB1>{}));          // quad_perm [1, 0, 3, 2]
-    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x4E>{}));          // quad_perm [2, 3, 0, 1]
-    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x141>{}));         // row_half_mirror
-    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x140>{}));         // row_mirror
-    const int b = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-}
-
 template <bool PRIO>
 __global__ void __launch_bounds__(512, 2) conv3x3_up16_fold_kernel(const gcpx_conv_args a, const int items_per_wave, const int nitems) {
     using Cfg = FoldCfg;
@@ -1015,18 +1000,19 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_split_kernel(const gcpx_c
             if (++cchunk == nchunk) { cchunk = 0; ++ck; }
             return;
         }
-        // registers -> (producer's affine + activation) -> the chunk's largest magnitude -> two f16 planes
+        // registers -> (producer's affine + activation) -> the chunk's largest magnitude -> two f16 planes (instruction-count notes:
+        // conv3x3_head_split.hip; slot k of a lane is float4 number lane + 64 k of the region: LDS byte 8 (lane + 64 k))
         float amax = 0.f;
+        const bool plain = sr.scale == nullptr && sr.act == GCPX_ACT_NONE;       // (a gradient tensor: nothing to apply)
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            float4 v = pre[k];
-            if (ok & (1u << k)) v = affine_act4(v, sr.scale, sr.shift, cchunk * 16 + ((lane + 64 * k) & 3) * 4, sr.act);
-            pre[k] = v;
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            if (!plain && (ok & (1u << k))) pre[k] = affine_act4(pre[k], sr.scale, sr.shift, cchunk * 16 + (lane & 3) * 4, sr.act);
+            amax = vmax3abs(amax, pre[k].x, pre[k].y);
+            amax = vmax3abs(amax, pre[k].z, pre[k].w);
         }
         amax = wave_max_nonneg(amax);
         int ec = 14 + 127 - (int)((__float_as_uint(amax) >> 23) & 0xff);
-        ec = __builtin_amdgcn_readfirstlane(amax > 0.f ? max(-100, min(ex_cap, ec)) : ex_cap);
+        ec = amax > 0.f ? max(-100, min(ex_cap, ec)) : ex_cap;
         if (cchunk == 0) ex = ec;
         else if (ec < ex) {                                 // larger values than before: lower the scale, rescale the sums (exact)
             const float r = __uint_as_float((unsigned)(127 + ec - ex) << 23);
@@ -1037,18 +1023,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_split_kernel(const gcpx_c
             ex = ec;
         }
         const float sx2 = __uint_as_float((unsigned)(127 + ex) << 23);
+        char* const dst0 = reg + lane * 8;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            const int idx = lane + 64 * k;
-            if (idx < RH * RW * 4) {
-                const float4 v = make_float4(pre[k].x * sx2, pre[k].y * sx2, pre[k].z * sx2, pre[k].w * sx2);
+            if (lane + 64 * k < RH * RW * 4) {
                 h4 p1, p2;
-                p1[0] = (_Float16)v.x; p1[1] = (_Float16)v.y; p1[2] = (_Float16)v.z; p1[3] = (_Float16)v.w;
-                p2[0] = (_Float16)fmaf((float)p1[0], -1.f, v.x); p2[1] = (_Float16)fmaf((float)p1[1], -1.f, v.y);
-                p2[2] = (_Float16)fmaf((float)p1[2], -1.f, v.z); p2[3] = (_Float16)fmaf((float)p1[3], -1.f, v.w);
-                char* dst = reg + (idx >> 2) * 32 + (idx & 3) * 8;
-                *reinterpret_cast<h4*>(dst) = p1;
-                *reinterpret_cast<h4*>(dst + Cfg::PLANE_BYTES) = p2;
+                split4(pre[k], sx2, p1, p2);
+                *reinterpret_cast<h4*>(dst0 + k * 512) = p1;
+                *reinterpret_cast<h4*>(dst0 + k * 512 + Cfg::PLANE_BYTES) = p2;
             }
         }
         issue(pre, ok);                                     // this register set is free again: load the step DEPTH ahead
@@ -1089,7 +1071,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_split_kernel(const gcpx_c
                 // the item's sums over its 16 pixel lanes, added to the wavefront's LDS sums by one lane per channel group (same
                 // order in every run: deterministic)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { bs1[k] = row16_sum(bs1[k]); bs2[k] = row16_sum(bs2[k]); }
+                for (int k = 0; k < 4; ++k) { bs1[k] = row16_sum_dpp(bs1[k]); bs2[k] = row16_sum_dpp(bs2[k]); }
                 if (j == 0) {
                     int q2 = q;
                     asm volatile("" : "+v"(q2));

@@ -126,4 +126,65 @@ __device__ __forceinline__ void mfma_tiles(const char* wl, const char* reg, cons
     __builtin_amdgcn_s_setprio(0);
 }
 
+// v_max_f32 without the canonicalising v_max the compiler puts in front of fmaxf on values that went through a lane swap (bit casts)
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3abs(float a, float x, float y) {
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(x), "v"(y));
+    return r;
+}
+// the value of the other lane of a pixel's lane pair (lane ^ 32) combined with this lane's: one swap instead of a ds_bpermute round trip
+__device__ __forceinline__ float pair_sum(float v) {
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+__device__ __forceinline__ float pair_max(float v) {
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmax(__uint_as_float(s[0]), __uint_as_float(s[1]));
+}
+// largest value of a wavefront (v >= 0 in every lane, all lanes active): non-negative floats order like their bit patterns
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    int x = __float_as_int(v);
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false));     // row_half_mirror
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false));     // row_mirror: every lane of a 16-lane row holds the row's max
+    const auto s16 = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+    x = max((int)s16[0], (int)s16[1]);
+    const auto s32 = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    x = max((int)s32[0], (int)s32[1]);
+    return __int_as_float(__builtin_amdgcn_readfirstlane(x));
+}
+// sum over the 16 lanes of a row by DPP row operations (every lane of the row ends with the sum)
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));     // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));     // row_mirror
+    return v;
+}
+// the two f16 pieces of four scaled values: p1 = rn16(v s), p2 = rn16(v s - p1) (v s is exact: s is a power of two), one fused
+// multiply-add with an f16 result per piece and value
+__device__ __forceinline__ void split4(const float4 v, const float s, h4& p1, h4& p2) {
+    unsigned a0, a1, b0, b1;
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(a0), "=&v"(b0) : "v"(v.x), "v"(v.y), "s"(s));
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(a1), "=&v"(b1) : "v"(v.z), "v"(v.w), "s"(s));
+    const uint2 ua = make_uint2(a0, a1), ub = make_uint2(b0, b1);
+    p1 = *reinterpret_cast<const h4*>(&ua);
+    p2 = *reinterpret_cast<const h4*>(&ub);
+}
+
+
 }  // namespace
