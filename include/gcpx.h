@@ -889,6 +889,22 @@ int gcpx_attention_bwd(const float* q, const float* k, const float* v, const flo
                        const float* temperature, float* dS, float* dq, float* dtemp_row, float* dK, int64_t ldk, float* dV, int64_t ldv,
                        int32_t M, int32_t rpb, int32_t T, int32_t dk, int32_t nz, void* stream);
 
+/* ---- collectives of the data-parallel paths: RCCL over xGMI, one communicator per process (one process
+ *   per GPU), enqueued on the caller's stream, no synchronisation.  Replaces nn.DataParallel's gradient reduce
+ *   (/root/reference/gcp/prediction/training/gcp_builder.py:71-78) and the per-GPU split of planning work (gcp/planning/run.py:108-120:
+ *   here the costs of one sharded CEM population are gathered).  The Python host reaches the same RCCL through torch.distributed
+ *   (video-gcp_amd/dist.py); these entry points serve a binder without torch.  RCCL is resolved at run time (GCPX_ERR_COMM when absent). */
+#define GCPX_COMM_ID_BYTES 128
+/* rank 0: a fresh rendezvous id (GCPX_COMM_ID_BYTES bytes) to hand to every rank by any host channel */
+int gcpx_comm_unique_id(void* id_out);
+/* every rank (its GPU current): *comm = communicator of `world` ranks */
+int gcpx_comm_init(void** comm, int32_t rank, int32_t world, const void* id);
+/* in-place sum of buf[0..n) over the ranks (the flat fp32 gradient or one of its buckets; 1 / world is folded into gcpx_optim_step) */
+int gcpx_comm_allreduce(void* comm, float* buf, int64_t n, void* stream);
+/* recv[r * n .. (r + 1) * n) = rank r's send[0..n)  (the candidates' costs of a sharded CEM population) */
+int gcpx_comm_allgather(void* comm, const float* send, float* recv, int64_t n, void* stream);
+int gcpx_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

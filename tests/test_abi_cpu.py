@@ -104,3 +104,9 @@ def test_invalid_args_are_rejected_without_a_gpu(lib):
     assert lib.gcpx_mlp_bwd_group(tab, 5, None) == -1                  # more than GCPX_MLP_BWD_GROUP_MAX problems
     assert lib.gcpx_mlp_bwd_group(tab, 2, None) == -1                  # empty descriptors: rejected before any launch
     assert lib.gcpx_split_pack_group2(None, 0, None, None) == -1
+    # round-5 entry points: the collectives (argument checks come before RCCL is even looked for)
+    assert lib.gcpx_comm_unique_id(None) == -1
+    comm = C.c_void_p()
+    assert lib.gcpx_comm_init(C.byref(comm), 2, 2, None) == -1 and lib.gcpx_comm_init(C.byref(comm), 2, 2, C.create_string_buffer(128)) == -1
+    assert lib.gcpx_comm_allreduce(None, None, 0, None) == -1 and lib.gcpx_comm_allgather(None, None, None, 0, None) == -1
+    assert lib.gcpx_comm_destroy(None) == -1

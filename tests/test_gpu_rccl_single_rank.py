@@ -18,3 +18,33 @@ def test_rccl_paths_with_one_rank():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = r.stdout.strip().splitlines()               # (RCCL prints its version banner after the script's last line)
     assert "max |theta diff| = 0.0" in r.stdout and "ok" in lines, r.stdout[-2000:]
+
+
+def test_comm_exports_with_one_rank():
+    """gcpx_comm_* (the collectives behind the C boundary, include/gcpx.h): a one-rank communicator on the box's GPU — unique id, init,
+    an in-place all-reduce and an all-gather on a stream of the caller, destroy.  (In a subprocess: RCCL initialises its own state.)"""
+    code = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import torch
+from video_gcp_amd import runtime as rt
+lib = rt.load_library()
+torch.cuda.set_device(0)
+uid = C.create_string_buffer(128)
+rt.check(lib.gcpx_comm_unique_id(uid), "unique_id")
+comm = C.c_void_p()
+rt.check(lib.gcpx_comm_init(C.byref(comm), 0, 1, uid), "comm_init")
+st = torch.cuda.Stream()
+x = torch.arange(1000, dtype=torch.float32, device="cuda")
+want = x.clone()
+y = torch.zeros(1000, device="cuda")
+st.wait_stream(torch.cuda.current_stream())
+rt.check(lib.gcpx_comm_allreduce(comm, x.data_ptr(), x.numel(), st.cuda_stream), "allreduce")
+rt.check(lib.gcpx_comm_allgather(comm, x.data_ptr(), y.data_ptr(), x.numel(), st.cuda_stream), "allgather")
+st.synchronize()
+assert torch.equal(x, want) and torch.equal(y, want)
+rt.check(lib.gcpx_comm_destroy(comm), "destroy")
+print("comm ok")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "comm ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -155,6 +155,26 @@ def test_hand_written_costs_and_pddm_sampler():
     assert np.allclose(s.mean.numpy(), (x.numpy() * w[:, None, None]).sum(0) / w.sum(), atol=1e-6) and torch.equal(s.std, std0)
 
 
+def test_cost_scores_keep_the_rollout_dtype():
+    """cost_fcn.py:15-22: float32 rollouts give float32 step costs, the final-step weight and the sum stay in float32 and so do the
+    scores (the reference never widens them) — equal, bit for bit, to that formula written out."""
+    from video_gcp_amd.planning import EuclideanDistance, EuclideanPathLength
+    rng = np.random.RandomState(4)
+    rollouts = [rng.randn(n, 6).astype(np.float32) for n in (5, 9, 2)]
+    goal = rng.randn(6).astype(np.float32)
+    for cls, dense, w in [(EuclideanDistance, True, 3.0), (EuclideanDistance, False, 0.5), (EuclideanPathLength, True, 1.0)]:
+        fn = cls(dense, w)
+        got = fn(rollouts, goal)
+        assert got.dtype == np.float32, cls.__name__
+        want = []
+        for r in rollouts:
+            c = np.array(fn.per_step(r, fn._prepare_goal(goal)))
+            assert c.dtype == np.float32
+            c[-1] *= w
+            want.append(np.sum(c) if dense else c[-1])
+        assert np.array_equal(got, np.array(want))
+
+
 def test_costs_and_samplers_match_the_executed_reference():
     """tests/golden/ref_costs_samplers.npz = outputs of the reference's own CostFcn subclasses (cost_fcn.py:8-77) and of its
     FlatCEMSampler / PDDMSampler (sampler.py:33-71) executed in the build container (make_ref_costs_goldens.py).  The host contract of

@@ -22,6 +22,10 @@ def save_checkpoint(model, folder, epoch, global_step=0, optimizer_state=None):
     state = {"epoch": epoch, "global_step": global_step,
              "state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
              "optimizer": optimizer_state}
+    # (beyond the reference's four keys: where the model's in-plan noise stream stands, so that a resumed run continues the sequence)
+    rng = model.rng_state() if hasattr(model, "rng_state") else None
+    if rng is not None:
+        state["rng_state"] = rng
     path = os.path.join(folder, checkpoint_name(epoch))
     torch.save(state, path)
     return path
@@ -71,4 +75,6 @@ def load_weights(weights_file, model, submodule_name=None, strict=True):
             raise KeyError(f"checkpoint {weights_file}: missing keys {missing[:5]}{'...' if len(missing) > 5 else ''}, "
                            f"unexpected keys {unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")
     model.load_state_dict(sd, strict=False)
+    if submodule_name is None and ckpt.get("rng_state") is not None and hasattr(model, "set_rng_state"):
+        model.set_rng_state(ckpt["rng_state"])
     return ckpt.get("global_step", 0), ckpt.get("epoch", 0), ckpt.get("optimizer")

@@ -273,7 +273,11 @@ int launch_wc2(const float* dy, const float* u, float* partial, int F, int H, in
     auto kern = wgrad_conv3x3_kernel<NT, CIT, NW, TW, BAL>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) {
+            gcpx_set_error("%s: hipFuncSetAttribute(64 KiB LDS): %s", __func__, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid, Cin / Cfg::CC), dim3(NW * 64), lds, stream, dy, u, partial, F, H, W, Cin, ldy, TH);

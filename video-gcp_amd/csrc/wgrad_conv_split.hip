@@ -611,7 +611,11 @@ int launch_ws_up(const float* dy, const WsUpSrc& us, float* partial, int F, int 
     auto kern = wgrad_conv3x3_split_up_kernel<TW>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) {
+            gcpx_set_error("%s: hipFuncSetAttribute(64 KiB LDS): %s", __func__, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid, Cin / Cfg::CC), dim3(256), LDS, stream, dy, us, partial, F, H, W, Cin, ldy);
@@ -626,7 +630,11 @@ int launch_ws2(const float* dy, const float* u, float* partial, int F, int H, in
     auto kern = wgrad_conv3x3_split_kernel<NT, CIT, TW>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) {
+            gcpx_set_error("%s: hipFuncSetAttribute(64 KiB LDS): %s", __func__, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
+        }
         attr_set = true;
     }
     static_assert(Cfg::LDS_BYTES <= 64 * 1024, "operand planes of one tile must fit 64 KiB");

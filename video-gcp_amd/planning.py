@@ -200,13 +200,15 @@ class CostFcn:
         return goal
 
     def __call__(self, cem_outputs, goal):
+        # (cost_fcn.py:15-22: the step costs keep the rollout's dtype — float32 for model rollouts — through the final-step weight and
+        # the sum, and so do the scores: near-tied candidates rank as in the reference)
         goal = self._prepare_goal(goal)
-        scores = np.empty(len(cem_outputs))
-        for i, rollout in enumerate(self._prepare_rollouts(cem_outputs)):
-            steps = np.array(self.per_step(rollout, goal), dtype=np.float64)
-            steps[-1] = steps[-1] * self._final_step_weight
-            scores[i] = steps.sum() if self._dense_cost else steps[-1]
-        return scores
+        scores = []
+        for rollout in self._prepare_rollouts(cem_outputs):
+            steps = np.array(self.per_step(rollout, goal))
+            steps[-1] *= self._final_step_weight
+            scores.append(np.sum(steps) if self._dense_cost else steps[-1])
+        return np.array(scores)
 
     def _prepare_rollouts(self, cem_outputs):
         return cem_outputs

@@ -236,6 +236,11 @@ SYMBOLS = [
     ("gcpx_event_record", C.c_int, [vp, vp]),
     ("gcpx_event_elapsed_ms", C.c_int, [vp, vp, C.POINTER(C.c_float)]),
     ("gcpx_event_destroy", C.c_int, [vp]),
+    ("gcpx_comm_unique_id", C.c_int, [vp]),
+    ("gcpx_comm_init", C.c_int, [C.POINTER(vp), i32, i32, vp]),
+    ("gcpx_comm_allreduce", C.c_int, [vp, vp, i64, vp]),
+    ("gcpx_comm_allgather", C.c_int, [vp, vp, vp, i64, vp]),
+    ("gcpx_comm_destroy", C.c_int, [vp]),
 ]
 
 _lib = None

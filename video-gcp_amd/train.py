@@ -100,6 +100,7 @@ class ModelTrainer:
         # ... but a DIFFERENT stream of latent noise / auxiliary-model index draws per rank, as nn.DataParallel's replicas drew
         # different numbers for their different shards (gcp_builder.py:71-78); reproducible through `seed` / --deterministic
         torch.cuda.manual_seed(seed * max(self.world, 1) + self.rank + 1)
+        self.model.reseed()                   # (a second trainer of the process seeded with the same value starts the same stream again)
         pg = torch.distributed.group.WORLD if self.world > 1 else None
         lr = conf.get("lr") if conf.get("lr") is not None else 1e-3
         self.trainer = step_cls(self.model, lr=lr, betas=(conf.get("adam_beta", 0.9), 0.999), process_group=pg,
