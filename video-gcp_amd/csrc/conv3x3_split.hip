@@ -1090,7 +1090,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wave_split_kernel(const gcpx_c
     float4 preA[NS];
     unsigned okA = 0;
     issue(preA, okA);
-    if constexpr (DEPTH == 2) {
+    if constexpr (DEPTH == 3) {
+        float4 preB[NS], preC[NS];
+        unsigned okB = 0, okC = 0;
+        issue(preB, okB);
+        issue(preC, okC);
+        for (int s = 0; s < nsteps; s += 3) {
+            step(preA, okA);
+            if (s + 1 < nsteps) step(preB, okB);
+            if (s + 2 < nsteps) step(preC, okC);
+        }
+    } else if constexpr (DEPTH == 2) {
         float4 preB[NS];
         unsigned okB = 0;
         issue(preB, okB);
@@ -1280,7 +1290,10 @@ int gcpx_launch_wave_split(const gcpx_conv_args* a, hipStream_t stream, int ct, 
         if (WaveSplitCfg<1>::lds_bytes(nchunk) > 160 * 1024) return -1;
         // (one register set in the prefetch pipeline: with two, the epilogue's extra values spill — 1107 against 1083 us for the head's
         // data gradient at c2)
-        if (a->bwd_r) return launch_wave_split_t<1, 1, true>(a, stream);
+        if (a->bwd_r) {
+            static const int d = getenv("GCPX_WAVE_DEPTH") ? atoi(getenv("GCPX_WAVE_DEPTH")) : 1;
+            return d == 3 ? launch_wave_split_t<1, 3, true>(a, stream) : d == 2 ? launch_wave_split_t<1, 2, true>(a, stream) : launch_wave_split_t<1, 1, true>(a, stream);
+        }
         return depth == 2 ? launch_wave_split_t<1, 2>(a, stream) : launch_wave_split_t<1, 1>(a, stream);
     }
     if (WaveSplitCfg<2>::lds_bytes(nchunk) > 160 * 1024) return -1;
