@@ -51,11 +51,29 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// the two f16 pieces of four scaled values, p1 = rn16(v sc), p2 = rn16(v sc - p1): one fused multiply-add with an f16 result per piece
+// and value (v sc is exact: sc is a power of two; the same bits as the cvt / fma / cvt chain, 8 instructions instead of ~14)
 __device__ __forceinline__ void split4(const float4 v, const float sc, h4& p1, h4& p2) {
-    const float4 s = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
-    p1[0] = (_Float16)s.x; p1[1] = (_Float16)s.y; p1[2] = (_Float16)s.z; p1[3] = (_Float16)s.w;
-    p2[0] = (_Float16)fmaf((float)p1[0], -1.f, s.x); p2[1] = (_Float16)fmaf((float)p1[1], -1.f, s.y);
-    p2[2] = (_Float16)fmaf((float)p1[2], -1.f, s.z); p2[3] = (_Float16)fmaf((float)p1[3], -1.f, s.w);
+    unsigned a0, a1, b0, b1;
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(a0), "=&v"(b0) : "v"(v.x), "v"(v.y), "s"(sc));
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(a1), "=&v"(b1) : "v"(v.z), "v"(v.w), "s"(sc));
+    const uint2 ua = make_uint2(a0, a1), ub = make_uint2(b0, b1);
+    p1 = *reinterpret_cast<const h4*>(&ua);
+    p2 = *reinterpret_cast<const h4*>(&ub);
+}
+// running maximum of |x|, |y| in one instruction
+__device__ __forceinline__ float vmax3abs(float a, float x, float y) {
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(x), "v"(y));
+    return r;
 }
 
 template <int I, int N, class F>

@@ -431,6 +431,19 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_up_kernel(const fl
         const int r = sp + 64 * k;
         umeta[k] = r < RPX ? (1u << 16) | ((unsigned)(r / RW) << 8) | (unsigned)(r % RW) : 0u;
     }
+    // A tile's origin is even in both directions, so which two region rows / columns an operand pixel interpolates between and with
+    // which weights depends on the slot alone: the LDS offset of its first source value and the four products of the bilinear weights
+    // are formed once (v = w00 a + w01 b + w10 c + w11 d: one multiply + three fma per value; 0.75 goes to the nearer source pixel)
+    int uq[NUS];
+    float uw[Cfg::UPS][4];
+#pragma unroll
+    for (int k = 0; k < UPS; ++k) {
+        const int row = (umeta[k] >> 8) & 255, col = umeta[k] & 255;        // operand pixel (row - 1, col - 1) relative to the tile
+        const float wy0 = (row & 1) ? 0.25f : 0.75f, wx0 = (col & 1) ? 0.25f : 0.75f;     // y = origin - 1 + row is odd for even row
+        uw[k][0] = wy0 * wx0; uw[k][1] = wy0 * (1.f - wx0); uw[k][2] = (1.f - wy0) * wx0; uw[k][3] = (1.f - wy0) * (1.f - wx0);
+#pragma unroll
+        for (int cit = 0; cit < CIT; ++cit) uq[cit * UPS + k] = ((row >> 1) * SRW + (col >> 1)) * 8 + cit * 4 + sc4;
+    }
     float4 pre[NDS + NSRC];
     const char* dyb = nullptr;
     const float* sfb = nullptr;
@@ -481,32 +494,28 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv3x3_split_up_kernel(const fl
         float4 uv[NUS];
 #pragma unroll
         for (int s = 0; s < NUS; ++s) {
-            const int cit = s / UPS, k = s % UPS;
+            const int k = s % UPS;
             const int row = (umeta[k] >> 8) & 255, col = umeta[k] & 255;
             const int y = cty0 - 1 + row, x = ctx0 - 1 + col;
             uv[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((umeta[k] >> 16) != 0 && y >= 0 && y < H && x >= 0 && x < W) {
-                // rows (ra, ra + 1) / columns (ca, ca + 1) of the region; weights of the FIRST of the pair: 0.75 for odd y (x), 0.25 for even
-                const int ra = ((y + 1) >> 1) - cty0 / 2, ca = ((x + 1) >> 1) - ctx0 / 2;
-                const float wy0 = (y & 1) ? 0.75f : 0.25f, wy1 = 1.f - wy0, wx0 = (x & 1) ? 0.75f : 0.25f, wx1 = 1.f - wx0;
-                const float4* q0 = sS + (ra * SRW + ca) * 8 + cit * 4 + sc4;
+                const float4* q0 = sS + uq[s];
                 const float4 v00 = q0[0], v01 = q0[8], v10 = q0[SRW * 8], v11 = q0[SRW * 8 + 8];
+                const float w00 = uw[k][0], w01 = uw[k][1], w10 = uw[k][2], w11 = uw[k][3];
                 float4 r_;
-                r_.x = wy0 * (wx0 * v00.x + wx1 * v01.x) + wy1 * (wx0 * v10.x + wx1 * v11.x);
-                r_.y = wy0 * (wx0 * v00.y + wx1 * v01.y) + wy1 * (wx0 * v10.y + wx1 * v11.y);
-                r_.z = wy0 * (wx0 * v00.z + wx1 * v01.z) + wy1 * (wx0 * v10.z + wx1 * v11.z);
-                r_.w = wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
+                r_.x = fmaf(w11, v11.x, fmaf(w10, v10.x, fmaf(w01, v01.x, w00 * v00.x)));
+                r_.y = fmaf(w11, v11.y, fmaf(w10, v10.y, fmaf(w01, v01.y, w00 * v00.y)));
+                r_.z = fmaf(w11, v11.z, fmaf(w10, v10.z, fmaf(w01, v01.z, w00 * v00.z)));
+                r_.w = fmaf(w11, v11.w, fmaf(w10, v10.w, fmaf(w01, v01.w, w00 * v00.w)));
                 uv[s] = r_;
             }
         }
         // ---- largest |value| of the tile, per operand ----
         float ma = 0.f, mb = 0.f;
 #pragma unroll
-        for (int s = 0; s < NDS; ++s)
-            ma = fmaxf(ma, fmaxf(fmaxf(fabsf(pre[s].x), fabsf(pre[s].y)), fmaxf(fabsf(pre[s].z), fabsf(pre[s].w))));
+        for (int s = 0; s < NDS; ++s) { ma = vmax3abs(ma, pre[s].x, pre[s].y); ma = vmax3abs(ma, pre[s].z, pre[s].w); }
 #pragma unroll
-        for (int s = 0; s < NUS; ++s)
-            mb = fmaxf(mb, fmaxf(fmaxf(fabsf(uv[s].x), fabsf(uv[s].y)), fmaxf(fabsf(uv[s].z), fabsf(uv[s].w))));
+        for (int s = 0; s < NUS; ++s) { mb = vmax3abs(mb, uv[s].x, uv[s].y); mb = vmax3abs(mb, uv[s].z, uv[s].w); }
         ma = wave_max_nonneg(ma);
         mb = wave_max_nonneg(mb);
         if (lane == 0) { red[2 * wave] = ma; red[2 * wave + 1] = mb; }
