@@ -101,7 +101,7 @@ typedef struct gcpx_conv_args {
     const void* wpk_split;  /* dev or NULL: the same weights as two f16 pieces in 16x16x32 fragment order
                                (packing.pack_dlm_head_split / pack_conv3x3_split).  When set, kernels that have a split-f16 form run
                                it: f32-equivalent results (error of the order of one f32 rounding per product) on the f16 matrix
-                               pipes, see csrc/conv3x3_split.hip.  NULL selects the exact f32 MFMA kernels */
+                               pipes, see csrc/split_mfma.h.  NULL selects the exact f32 MFMA kernels */
     const int32_t* w_split_log2_dev; /* dev or NULL: when set, the scale exponent is read from here instead of w_split_log2
                                (weights re-split on the device after every optimizer step, gcpx_split_pack) */
     int32_t split_layout;   /* layout of wpk_split: GCPX_SPLIT_PLAIN (the conv's own 3x3 taps) or GCPX_SPLIT_ROWFOLD (upsampling blocks
@@ -210,7 +210,7 @@ typedef struct gcpx_gemm_args {
     float* gates_out;       /* LSTM epilogue, optional: activated gates [M][H][4] = (i, f, g, o) kept for the backward pass */
     const void* wpk_split;  /* dev or NULL: the same weights as two f16 pieces, [K/32][N/16][2][64][8] (packing.pack_gemm_split; batch b at
                                byte offset b * z_w_off * 4).  When set, problems with enough rows to be bound by the f32 MFMA rate run
-                               the split-f16 kernel (csrc/gemm_split.hip): f32-equivalent results, see conv3x3_split.hip */
+                               the split-f16 kernel (csrc/gemm_split.hip): f32-equivalent results, see split_mfma.h */
     const int32_t* w_split_log2_dev; /* dev or NULL: [nbatch] powers of two the packed pieces were scaled by; NULL = w_split_log2 */
     int32_t w_split_log2;
     int32_t _pad_split;

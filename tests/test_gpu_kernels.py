@@ -539,7 +539,7 @@ def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes, spli
 @pytest.mark.parametrize("S,Fr", [(32, 3), (64, 2)])
 def test_conv3x3_head_dlm(env, S, Fr, split):
     """output head: 16 -> 100 channels; raw parameters (kernel order) + fused mixture mean vs the oracle's formulas.
-    split: the split-f16 kernel (csrc/conv3x3_split.hip) in place of the exact f32 MFMA kernel, same tolerances."""
+    split: the split-f16 kernel (csrc/conv3x3_head_split.hip) in place of the exact f32 MFMA kernel, same tolerances."""
     rt, pk, lib, dev = env
     from oracle import gcp_model_oracle as O
     from video_gcp_amd import config

@@ -94,7 +94,7 @@ class GCPTreeModel(WeightsMixin, PlanOpsMixin, ForwardPlanMixin, ReplayMixin):
         self._stream, self._streams = pool[0], list(pool[1])
         self._set_kl_weight()
         self.save_for_backward = False        # training step: forward plans keep what the backward pass needs
-        # split-f16 convs (csrc/conv3x3_split.hip): f32-equivalent results on the f16 matrix pipes.  GCPX_EXACT_F32=1 keeps every
+        # split-f16 convs (csrc/split_mfma.h, conv3x3_split.hip, conv3x3_head_split.hip): f32-equivalent results on the f16 matrix pipes.  GCPX_EXACT_F32=1 keeps every
         # conv on the exact f32 MFMA kernels
         self.split_f16 = os.environ.get("GCPX_EXACT_F32") is None
         # forward with losses: likelihood of the matched frames inside the head kernel (GCPX_HEAD_DLM_NLL); GCPX_UNFUSED_NLL=1 keeps

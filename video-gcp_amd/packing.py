@@ -184,7 +184,7 @@ def dlm_channel_perm(n_mix=10):
     epilogue); the channels fill 6 full MFMA tiles + a 4-channel remainder (slots 96..99) with no padding inside.
     The g / b log-scales of mixture k = 2 ct + h are placed so that the lane that evaluates mixture k of a pixel in the head
     kernel's epilogue (lane group q with q >> 1 = h) finds them in ITS registers of channel tile 5 after the same row swap as the
-    other parameters (csrc/conv3x3_split.hip, fused likelihood): tile 5 lane group q' = 2 h + (ct >> 1) holds
+    other parameters (csrc/conv3x3_head_split.hip, fused likelihood): tile 5 lane group q' = 2 h + (ct >> 1) holds
     {ls_g, ls_b} of ct & 1 = 0 in registers 0, 1 and of ct & 1 = 1 in registers 2, 3; mixtures 8, 9 are slots 96..99."""
     nm = n_mix
     assert nm == 10, "kernel epilogue is written for 10 mixtures (5 MFMA tiles x 2 mixtures)"
