@@ -29,3 +29,19 @@ def stub_rollouts(z):
     img = np.tanh(z @ A) + t
     lat = z @ Bm + 2.0 * t
     return [np.concatenate((img[i], lat[i]), -1) for i in range(n)]
+
+
+def flat_stub_len(sample, max_seq_len):
+    """rollout length of ONE flat candidate [steps, ad]: a function of its content, so that chunked and whole-population rollouts agree"""
+    return 3 + int(abs(float(sample[0, 0])) * 1000.0) % (max_seq_len - 2)
+
+
+def flat_stub_rollout(samples, max_seq_len, dtype=np.float64):
+    """samples [n, steps, ad] -> (predictions: list of [len_i, ad] paths = half the running sum of the candidate's steps, latents: the
+    steps themselves), ragged lengths — the stub simulator of the flat CEM loop's fixtures (ref_cem_loop.npz)"""
+    preds, lats = [], []
+    for s in np.asarray(samples):
+        n = flat_stub_len(s, max_seq_len)
+        preds.append((0.5 * np.cumsum(s[:n], axis=0)).astype(dtype))
+        lats.append(s[:n].astype(dtype))
+    return preds, lats

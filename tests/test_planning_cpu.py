@@ -219,3 +219,138 @@ def test_simulator_input_conventions_match_the_executed_reference():
         assert got.dtype == torch.float32 and np.array_equal(got.numpy(), g[f"env_{tag}_out"]), tag
     assert np.array_equal(g["act_actions"], g["act_in"]) and np.array_equal(g["act_pad_mask"], np.ones(g["act_in"].shape[:2], np.float32))
     assert np.array_equal(env2planner(np.repeat(g["env_u8_in"], 3, 0)).numpy(), g["act_I_0"])
+
+
+# ---- the CEM loop itself against the EXECUTED reference (tests/golden/make_ref_cem_loop_goldens.py -> ref_cem_loop.npz):
+# cem_planner.py:55-135 (flat) and :166-218 (hierarchical) on a stub simulator, the draws replayed from the recorded unit numbers ----
+def _cem_golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_cem_loop.npz"))
+
+
+class _ReplaySampler:
+    """FlatCEMSampler whose Gaussian numbers are the ones the reference's np.random stream produced (one array per sample() call)"""
+
+    def __new__(cls, eps_list, *args, **kw):
+        from video_gcp_amd.planning import FlatCEMSampler
+
+        class R(FlatCEMSampler):
+            def sample(self, n_samples):
+                e = torch.as_tensor(self._eps.pop(0))
+                assert e.shape[0] == n_samples
+                return self.from_unit_noise(e.to(self.mean.dtype))
+        r = R(*args, **kw)
+        r._eps = list(eps_list)
+        return r
+
+
+class _FlatStubSim:
+    """tests/golden/planner_stubs.flat_stub_rollout behind the planner's simulator interface"""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def _roll(self, samples, rollout_len):
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        from planner_stubs import flat_stub_rollout
+        return flat_stub_rollout(np.asarray(samples), rollout_len, self.dtype)
+
+    def rollout_device(self, state, goal, samples, rollout_len):
+        from video_gcp_amd.model import Outputs
+        preds, _ = self._roll(samples.numpy(), rollout_len)
+        n, D = len(preds), preds[0].shape[1]
+        pad = np.zeros((n, rollout_len, D), self.dtype)
+        for i, p in enumerate(preds):
+            pad[i, :len(p)] = p
+        return Outputs(latents=torch.as_tensor(pad), lengths=torch.tensor([len(p) for p in preds], dtype=torch.int32), e_goal=None)
+
+    def rollout(self, state, goal, samples, rollout_len, prune=False):
+        from video_gcp_amd.model import Outputs
+        preds, lats = self._roll(samples, rollout_len)
+        return Outputs(predictions=preds, actions=[p[1:] - p[:-1] for p in preds], latents=lats)
+
+
+class _HostCostOnPadded:
+    """the package's host-side hand-written cost (cost_fcn.py contract) applied to the rows of a padded rollout"""
+
+    def __init__(self, cost, goal):
+        self.cost, self.goal = cost, goal
+
+    def sequence_cost_device(self, lat, lengths, goal=None):
+        rolls = [lat[i, :int(l)].numpy() for i, l in enumerate(lengths)]
+        return torch.as_tensor(np.asarray(self.cost(rolls, self.goal), dtype=np.float64))
+
+
+def test_flat_cem_loop_matches_executed_reference():
+    from video_gcp_amd.planning import CEMPlanner, EuclideanPathLength
+    g = _cem_golden()
+    steps, ad = (int(v) for v in g["flat_shape"])
+    for ci, (batch, efrac, mrb, nbytes, clip, seed) in enumerate(g["flat_cases"]):
+        batch = int(batch)
+        dt = np.float64 if nbytes == 8 else np.float32
+        goal = g[f"flat{ci}_goal"]
+        sampler = _ReplaySampler([g[f"flat{ci}_it{it}_eps"] for it in range(3)], float(clip), steps, ad, 0.6, device="cpu", dtype=torch.float64)
+        cost = _HostCostOnPadded(EuclideanPathLength(True, 2.0), goal)
+        planner = CEMPlanner(_FlatStubSim(dt), cost, sampler, n_iters=3, batch_size=batch, elite_frac=float(efrac), max_seq_len=steps)
+        # the loop, iteration by iteration, so that every intermediate is compared
+        sampler.init()
+        if mrb < batch:
+            # The reference's chunked rollout (cem_planner.py:114-121, batch_size > max_rollout_bs; no shipped conf gets there: 10 / 5
+            # candidates against 100) PREPENDS every chunk (`_join_dicts(sim_output, output)` = d1 + d2), so its score vector is in
+            # reversed chunk order while `samples[elite_idxs]` indexes the draw order: elites are refit from the wrong candidates.  This
+            # planner scores the population in draw order; the fixture pins what the reference does, as a permutation of the same scores.
+            _, _, scores = planner.iterate(None, goal)
+            mrb = int(mrb)
+            chunks = [scores.numpy()[i * mrb:(i + 1) * mrb] for i in range(batch // mrb)]
+            np.testing.assert_allclose(np.concatenate(chunks[::-1]), g[f"flat{ci}_it0_scores"], rtol=1e-13)
+            assert list(g[f"flat{ci}_rollout_calls"][:batch // mrb]) == [mrb] * (batch // mrb)
+            continue
+        for it in range(3):
+            best, best_scores, scores = planner.iterate(None, goal)
+            want_scores = g[f"flat{ci}_it{it}_scores"]
+            assert scores.shape[0] == want_scores.shape[0] == batch
+            np.testing.assert_allclose(scores.numpy(), want_scores, rtol=1e-13, atol=0)
+            order = torch.argsort(scores, stable=True)[:len(g[f"flat{ci}_it{it}_elite_idx"])].numpy()
+            assert np.array_equal(order, g[f"flat{ci}_it{it}_elite_idx"]), (ci, it)
+            np.testing.assert_allclose(best_scores.numpy(), g[f"flat{ci}_it{it}_elite_scores"], rtol=1e-13)
+            np.testing.assert_allclose(best.numpy(), g[f"flat{ci}_it{it}_elite_samples"], rtol=1e-13, atol=1e-15)
+            np.testing.assert_allclose(sampler.mean.numpy(), g[f"flat{ci}_it{it}_mean"], rtol=1e-13, atol=1e-15)
+            np.testing.assert_allclose(sampler.std.numpy(), g[f"flat{ci}_it{it}_std"], rtol=1e-12, atol=1e-15)
+        # and the whole call: plan = rollout of the best candidate, score = its cost (cem_planner.py:81-100)
+        sampler._eps = [g[f"flat{ci}_it{it}_eps"] for it in range(3)]
+        pred, actions, latents, score = planner(None, goal)
+        np.testing.assert_allclose(pred, g[f"flat{ci}_plan_pred"], rtol=1e-6 if dt is np.float32 else 1e-13, atol=1e-7 if dt is np.float32 else 1e-15)
+        np.testing.assert_allclose(actions, g[f"flat{ci}_plan_actions"], rtol=1e-5 if dt is np.float32 else 1e-12, atol=1e-6 if dt is np.float32 else 1e-14)
+        np.testing.assert_allclose(latents, g[f"flat{ci}_plan_latents"], rtol=1e-6 if dt is np.float32 else 1e-13, atol=1e-7 if dt is np.float32 else 1e-15)
+        assert abs(score - float(g[f"flat{ci}_plan_score"][0])) <= 1e-12 * abs(score)
+
+
+def test_hierarchical_cem_call_matches_executed_reference():
+    """HierarchicalCEMPlanner.__call__ (cem_planner.py:166-218): the host data flow (device_resident=False) on the reference's np.random
+    stream, draw for draw: elite rollouts and scores of every round and the returned plan, bit for bit"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from planner_stubs import StubCost, stub_rollouts, RES
+    from video_gcp_amd.planning import HierarchicalCEMPlanner
+    from video_gcp_amd.model import Outputs
+    g = _cem_golden()
+
+    class TreeStubSim:
+        def rollout(self, state, goal, samples, max_seq_len):
+            r = stub_rollouts(np.asarray(samples))
+            n_img = 3 * RES * RES
+            return Outputs(predictions=r, actions=[x[1:, :2] - x[:-1, :2] for x in r], latents=[x[:, n_img:].copy() for x in r])
+
+    for ci, row in enumerate(g["hier_cases"]):
+        depth, n_ll, ld, seed, nr = (int(v) for v in row[:5])
+        rates = [int(v) for v in row[5:5 + nr]]
+        goal = g[f"hier{ci}_goal"]
+        planner = HierarchicalCEMPlanner(TreeStubSim(), StubCost(), depth, rates, n_ll_samples=n_ll, action_dim=ld, max_seq_len=2 ** depth - 1,
+                                         device_resident=False)
+        np.random.seed(seed + 100)
+        pred, actions, latents, score = planner(None, goal)
+        for it in range(len(rates) + 1):
+            assert np.array_equal(np.asarray(planner.logs[it].elite_rollouts[0]), g[f"hier{ci}_it{it}_elite_rollout"]), (ci, it)
+            assert np.array_equal(np.asarray(planner.logs[it].elite_scores, dtype=np.float64).reshape(-1), g[f"hier{ci}_it{it}_elite_score"]), (ci, it)
+        assert np.array_equal(pred, g[f"hier{ci}_plan_pred"]) and np.array_equal(actions, g[f"hier{ci}_plan_actions"])
+        assert np.array_equal(latents, g[f"hier{ci}_plan_latents"])
+        assert score == float(g[f"hier{ci}_plan_score"][0])
+        assert bool(planner.fully_optimized) == bool(g[f"hier{ci}_fully"][0])

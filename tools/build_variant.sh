@@ -4,10 +4,11 @@
 set -e
 cd "$(dirname "$0")/../video-gcp_amd/csrc"
 name=$1; src=$2; shift 2
-extra=""; if [ $src = conv3x3_head_split ] || [ $src = loss ]; then extra="-fno-slp-vectorize"; fi
+. ./sources.sh
+extra="$(gcpx_flags_for $src)"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-variable $extra "$@" -c $src.hip -o build/variant_${src}_$name.o
 objs=""
-for f in conv3x3 conv3x3_split conv3x3_head_split conv_enc conv_enc_split gemm gemm_split gemm_planes mlp mlp_bwd misc loss wgrad wgrad_conv wgrad_conv_split wgrad_rows_split wgrad_image split_pack backward adaptive aux metrics comm; do
+for f in $GCPX_SOURCES; do
   if [ $f = $src ]; then objs="$objs build/variant_${src}_$name.o"; else objs="$objs build/$f.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC $objs -ldl -o ../libgcpx_$name.so

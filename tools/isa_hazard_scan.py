@@ -10,8 +10,9 @@
 import argparse, collections, concurrent.futures, glob, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NO_SLP = ("conv3x3_head_split.hip", "loss.hip")          # per-file flags of csrc/build.sh
 CSRC = os.path.join(ROOT, "video-gcp_amd", "csrc")
+# per-file flags: the list csrc/build.sh reads (csrc/sources.sh)
+NO_SLP = tuple(n + ".hip" for n in re.search(r'GCPX_NO_SLP="([^"]*)"', open(os.path.join(CSRC, "sources.sh")).read()).group(1).split())
 
 
 def regs(tok):

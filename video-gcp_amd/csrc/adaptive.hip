@@ -10,7 +10,6 @@
 
 namespace {
 
-__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }   // = fast_tanh of the head kernel
 
 __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -596,103 +595,6 @@ __global__ void __launch_bounds__(1024) averaging_dls_kernel(const float* __rest
     if (threadIdx.x == 0) dst[0] += coef * red[0];
 }
 
-// Backward of the mixture MEAN (images of the discrete-logistic-mixture head; oracle dlm_mean): params [F][npix][PITCH] in the
-// head's slot order, dimg NCHW [F][3][npix] -> dparams [F][npix][PITCH] (+ per-frame column sums for the bias gradient).
-// A wavefront stages 16 pixels x PITCH parameters in LDS; lane (j = pixel, q) owns mixtures q, q + 4, q + 8.
-template <int NMIX, int PITCH>
-__global__ void __launch_bounds__(256) dlm_mean_bwd_kernel(const float* __restrict__ params, const float* __restrict__ dimg,
-                                                           float* __restrict__ dparams, float* __restrict__ colsum, const int npix) {
-    __shared__ float4 stage4[4 * 16 * PITCH / 4];
-    __shared__ float csum[4][2][64];
-    float cs0 = 0.f, cs1 = 0.f;
-    const int row = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, q = lane >> 4;
-    constexpr int F4 = 16 * PITCH / 4;
-    float* st = reinterpret_cast<float*>(stage4) + wave * 16 * PITCH;
-    const float* prow = params + (size_t)row * npix * PITCH;
-    const float* grow = dimg + (size_t)row * 3 * npix;
-    float* drow = dparams + (size_t)row * npix * PITCH;
-    for (int p0 = wave * 16; p0 < npix; p0 += 64) {
-        const float4* src = reinterpret_cast<const float4*>(prow + (size_t)p0 * PITCH);
-        for (int i = lane; i < F4; i += 64) reinterpret_cast<float4*>(st)[i] = src[i];
-        __builtin_amdgcn_wave_barrier();
-        float* pp = st + j * PITCH;
-        float lmax = pp[0];
-#pragma unroll
-        for (int k = 1; k < NMIX; ++k) lmax = fmaxf(lmax, pp[8 * k]);
-        float lsum = 0.f;
-#pragma unroll
-        for (int k = 0; k < NMIX; ++k) lsum += __expf(pp[8 * k] - lmax);
-        const float rls = __frcp_rn(lsum);
-        float pi[3], Mr[3], Mg[3], Mb[3], cf[3][3];
-        float Sr = 0.f, Sg = 0.f, Sb = 0.f;
-        int nk = 0;
-        for (int k = q; k < NMIX; k += 4, ++nk) {
-            const float* m = pp + 8 * k;
-            const float c0 = tanh_fast(m[4]), c1 = tanh_fast(m[5]), c2 = tanh_fast(m[6]);   // the head's forward uses the same
-            cf[nk][0] = c0; cf[nk][1] = c1; cf[nk][2] = c2;
-            pi[nk] = __expf(m[0] - lmax) * rls;
-            Mr[nk] = m[1];
-            Mg[nk] = m[2] + c0 * Mr[nk];
-            Mb[nk] = m[3] + c1 * Mr[nk] + c2 * Mg[nk];
-            Sr += pi[nk] * Mr[nk]; Sg += pi[nk] * Mg[nk]; Sb += pi[nk] * Mb[nk];
-        }
-        Sr += __shfl_xor(Sr, 16); Sr += __shfl_xor(Sr, 32);
-        Sg += __shfl_xor(Sg, 16); Sg += __shfl_xor(Sg, 32);
-        Sb += __shfl_xor(Sb, 16); Sb += __shfl_xor(Sb, 32);
-        // clamp(-1, 1) of the forward blocks the gradient outside the interval
-        const float gr = (Sr >= -1.f && Sr <= 1.f) ? grow[p0 + j] : 0.f;
-        const float gg = (Sg >= -1.f && Sg <= 1.f) ? grow[npix + p0 + j] : 0.f;
-        const float gb = (Sb >= -1.f && Sb <= 1.f) ? grow[2 * npix + p0 + j] : 0.f;
-        float dpi[3], dot = 0.f;
-        for (int i = 0; i < nk; ++i) {
-            dpi[i] = gr * Mr[i] + gg * Mg[i] + gb * Mb[i];
-            dot += pi[i] * dpi[i];
-        }
-        dot += __shfl_xor(dot, 16);
-        dot += __shfl_xor(dot, 32);
-        __builtin_amdgcn_wave_barrier();           // every lane has read the logits of its pixel
-        nk = 0;
-        for (int k = q; k < NMIX; k += 4, ++nk) {
-            float* m = pp + 8 * k;
-            const float dMb = gb * pi[nk];
-            const float dMg = gg * pi[nk] + dMb * cf[nk][2];
-            const float dMr = gr * pi[nk] + dMb * cf[nk][1] + dMg * cf[nk][0];
-            m[0] = pi[nk] * (dpi[nk] - dot);
-            m[1] = dMr;
-            m[2] = dMg;
-            m[3] = dMb;
-            m[4] = dMg * Mr[nk] * (1.f - cf[nk][0] * cf[nk][0]);
-            m[5] = dMb * Mr[nk] * (1.f - cf[nk][1] * cf[nk][1]);
-            m[6] = dMb * Mg[nk] * (1.f - cf[nk][2] * cf[nk][2]);
-            m[7] = 0.f;                               // log_scale_r: the mean does not depend on the scales
-        }
-        if (q == 0)
-            for (int s = 8 * NMIX; s < PITCH; ++s) pp[s] = 0.f;
-        __builtin_amdgcn_wave_barrier();
-        float4* dst = reinterpret_cast<float4*>(drow + (size_t)p0 * PITCH);
-        for (int i = lane; i < F4; i += 64) dst[i] = reinterpret_cast<float4*>(st)[i];
-        if (colsum) {
-#pragma unroll
-            for (int px = 0; px < 16; ++px) {
-                cs0 += st[px * PITCH + lane];
-                if (lane + 64 < PITCH) cs1 += st[px * PITCH + lane + 64];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (colsum) {
-        csum[wave][0][lane] = cs0;
-        csum[wave][1][lane] = cs1;
-        __syncthreads();
-        for (int i = tid; i < PITCH; i += 256) {
-            const int h = i >> 6, l = i & 63;
-            colsum[(size_t)row * PITCH + i] = (csum[0][h][l] + csum[1][h][l]) + (csum[2][h][l] + csum[3][h][l]);
-        }
-    }
-}
-
 // attention backward, per query row (one wavefront): dS[r][t] = a_t * (dA_t - sum_t a_t dA_t) with dA_t = dO[r] . V[b][t];
 // dq[r] = sum_t dS_t K[b][t] / (sqrt(dk) temp); dtemp_row[r] = -sum_t dS_t score_t / temp   (one head)
 __global__ void __launch_bounds__(256) attention_bwd_row_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -922,16 +824,6 @@ extern "C" int gcpx_averaging_nll_bwd(const float* w, const float* pad_mask, con
                        (long long)T, (long long)N * T, pad_mask, traj, images, log_sigma, coef, dimg, T, N, (long long)D);
     hipLaunchKernelGGL(averaging_dls_kernel, dim3(1), dim3(1024), 0, stream, dsum, w, pad_mask, log_sigma, (float)D, coef, dlog_sigma, B,
                        N, T);
-    GCPX_CHECK_LAUNCH();
-    return GCPX_OK;
-}
-
-extern "C" int gcpx_dlm_mean_bwd(const float* params, const float* dimg, float* dparams, float* colsum, int32_t rows, int32_t npix,
-                                 int32_t pitch, int32_t n_mix, void* stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    GCPX_CHECK_ARG(params && dimg && dparams && rows > 0, "bad arguments");
-    GCPX_CHECK_ARG(n_mix == 10 && pitch == 112 && npix % 64 == 0, "supports 10 mixtures, pitch 112, npix % 64 == 0");
-    hipLaunchKernelGGL((dlm_mean_bwd_kernel<10, 112>), dim3(rows), dim3(256), 0, stream, params, dimg, dparams, colsum, npix);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -27,20 +27,9 @@
 // This header: the f16 MFMA wrapper, hardware exp / log forms, the LDS layout of the wave-autonomous head / 16-channel kernels and
 // their MFMA pass over channel tiles.
 #pragma once
-#include "common.h"
-
-#include <type_traits>
+#include "split_common.h"
 
 namespace {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-
-// D[16x16] += A[16x32] * B[32x16]: lane l holds A[i = l & 15][k = 8 (l >> 4) .. + 7], B[k = 8 (l >> 4) .. + 7][j = l & 15];
-// D as in mfma16 (lane l, reg r: i = 4 (l >> 4) + r, j = l & 15).
-__device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
 
 // exp / log straight on the hardware instructions (v_exp_f32 / v_log_f32 are base 2).  __expf / __logf wrap them in a range fix-up for
 // denormal results / inputs — two compares, two selects and a multiply per call: 531 selects and 558 compares in the likelihood variant of
@@ -52,14 +41,6 @@ __device__ __forceinline__ float log_hw(float x) { return __builtin_amdgcn_logf(
 __device__ __forceinline__ float fast_tanh_s(float x) {
     const float e = exp_hw(2.f * x);
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-}
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
 }
 
 struct SplitHeadCfg {
@@ -132,11 +113,6 @@ __device__ __forceinline__ float vmax(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ float vmax3abs(float a, float x, float y) {
-    float r;
-    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(x), "v"(y));
-    return r;
-}
 // the value of the other lane of a pixel's lane pair (lane ^ 32) combined with this lane's: one swap instead of a ds_bpermute round trip
 __device__ __forceinline__ float pair_sum(float v) {
     const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -166,24 +142,6 @@ __device__ __forceinline__ float row16_sum_dpp(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));     // row_half_mirror
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));     // row_mirror
     return v;
-}
-// the two f16 pieces of four scaled values: p1 = rn16(v s), p2 = rn16(v s - p1) (v s is exact: s is a power of two), one fused
-// multiply-add with an f16 result per piece and value
-__device__ __forceinline__ void split4(const float4 v, const float s, h4& p1, h4& p2) {
-    unsigned a0, a1, b0, b1;
-    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
-        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
-        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(a0), "=&v"(b0) : "v"(v.x), "v"(v.y), "s"(s));
-    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
-        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
-        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(a1), "=&v"(b1) : "v"(v.z), "v"(v.w), "s"(s));
-    const uint2 ua = make_uint2(a0, a1), ub = make_uint2(b0, b1);
-    p1 = *reinterpret_cast<const h4*>(&ua);
-    p2 = *reinterpret_cast<const h4*>(&ub);
 }
 
 

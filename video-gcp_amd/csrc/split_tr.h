@@ -1,24 +1,16 @@
 // Helpers shared by the split-f16 weight-gradient kernels (wgrad_conv_split.hip, wgrad_rows_split.hip): both operands are data, staged
 // row-major ("pixel-major") into f16 planes in LDS and read back through the transposing LDS read, so that the MFMA k index walks rows.
 #pragma once
-#include "common.h"
-
-#include <type_traits>
+#include "split_common.h"
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef const f32x4 __attribute__((address_space(1)))* gptr4;
 
 // explicitly global (a flat load would tie up both memory counters), uniform base + 32-bit lane offset (one address register per slot)
 __device__ __forceinline__ float4 gload4(const char* base, const unsigned off_bytes) {
     const f32x4 t = *(gptr4)(base + off_bytes);
     return make_float4(t[0], t[1], t[2], t[3]);
-}
-
-__device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
 // ds_read_b64_tr_b16 (measured with tools/tr_probe.hip): inside a 16-lane group, lane s supplies the address of an 8-byte chunk
@@ -49,39 +41,6 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
     const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-}
-
-// the two f16 pieces of four scaled values, p1 = rn16(v sc), p2 = rn16(v sc - p1): one fused multiply-add with an f16 result per piece
-// and value (v sc is exact: sc is a power of two; the same bits as the cvt / fma / cvt chain, 8 instructions instead of ~14)
-__device__ __forceinline__ void split4(const float4 v, const float sc, h4& p1, h4& p2) {
-    unsigned a0, a1, b0, b1;
-    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
-        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
-        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(a0), "=&v"(b0) : "v"(v.x), "v"(v.y), "s"(sc));
-    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
-        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
-        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(a1), "=&v"(b1) : "v"(v.z), "v"(v.w), "s"(sc));
-    const uint2 ua = make_uint2(a0, a1), ub = make_uint2(b0, b1);
-    p1 = *reinterpret_cast<const h4*>(&ua);
-    p2 = *reinterpret_cast<const h4*>(&ub);
-}
-// running maximum of |x|, |y| in one instruction
-__device__ __forceinline__ float vmax3abs(float a, float x, float y) {
-    float r;
-    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(x), "v"(y));
-    return r;
-}
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
 }
 
 }  // namespace

@@ -317,22 +317,23 @@ class FlatCEMSampler:
     """Gaussian sampler over [n_steps, dim] (sampler.py:33-48), on the device, seedable so that all ranks of a
     sharded planner draw the same population."""
 
-    def __init__(self, clip_val, n_steps, action_dim, initial_std, device="cuda", seed=0, n_shards=None):
-        """n_shards: the population is the concatenation of n_shards independently seeded sub-streams (seed, shard); default = the
+    def __init__(self, clip_val, n_steps, action_dim, initial_std, device="cuda", seed=0, n_shards=None, dtype=torch.float32):
+        """dtype: of the distribution and its draws (the reference's sampler is float64 numpy; float32 on the device by default).
+        n_shards: the population is the concatenation of n_shards independently seeded sub-streams (seed, shard); default = the
         number of ranks, so that under a process group every rank draws ONLY its own 1/world of the candidates ("each GPU
         samples its slice (seed = base + rank)").  A single process asked for n_shards = k draws the same population a k-rank
         group does, which is how the sharded planner is checked against the unsharded one."""
         self._clip_val, self._n_steps, self._action_dim, self._initial_std = clip_val, n_steps, action_dim, initial_std
         self.device = torch.device(device)
-        self._seed, self._n_shards = seed, n_shards
+        self._seed, self._n_shards, self._dtype = seed, n_shards, dtype
         self._gen = torch.Generator(device=self.device)             # rank-shared stream (length draws, one-shard populations)
         self._gen.manual_seed(seed)
         self._shard_gens = {}
         self.init()
 
     def init(self):
-        self.mean = torch.zeros(self._n_steps, self._action_dim, device=self.device)
-        self.std = self._initial_std * torch.ones(self._n_steps, self._action_dim, device=self.device)
+        self.mean = torch.zeros(self._n_steps, self._action_dim, device=self.device, dtype=self._dtype)
+        self.std = self._initial_std * torch.ones(self._n_steps, self._action_dim, device=self.device, dtype=self._dtype)
 
     def n_shards(self):
         if self._n_shards is not None:
@@ -340,7 +341,7 @@ class FlatCEMSampler:
         return D.dist.get_world_size() if D.dist.is_initialized() else 1
 
     def _draw(self, n, gen):
-        return self.from_unit_noise(torch.randn(n, self._n_steps, self._action_dim, device=self.device, generator=gen))
+        return self.from_unit_noise(torch.randn(n, self._n_steps, self._action_dim, device=self.device, generator=gen, dtype=self._dtype))
 
     def from_unit_noise(self, eps):
         """the population that standard-normal numbers eps [n, n_steps, action_dim] stand for (sampler.py:40-42: np.random.normal(loc=mean,
