@@ -126,7 +126,9 @@ typedef struct gcpx_conv_args {
     const float *bwd_scale, *bwd_shift, *bwd_mean, *bwd_rstd;
 } gcpx_conv_args;
 
-typedef enum gcpx_split_layout { GCPX_SPLIT_PLAIN = 0, GCPX_SPLIT_ROWFOLD = 1 } gcpx_split_layout;
+/* GCPX_SPLIT_HEAD32: the 100-channel mixture head's weights in 32x32x16 A-fragment order [9 taps][4 tiles][2 pieces][64][8]
+   (packing.pack_head32_split / head32_index) for csrc/conv3x3_head32.hip — modes GCPX_HEAD_DLM_MEAN / _NLL / _NLL_GRAD only */
+typedef enum gcpx_split_layout { GCPX_SPLIT_PLAIN = 0, GCPX_SPLIT_ROWFOLD = 1, GCPX_SPLIT_HEAD32 = 2 } gcpx_split_layout;
 
 /* decoder block: (bilinear x2 upsample +) 3x3 conv, pad 1.  gcpx_conv3x3_grid(a) = number of workgroups that launch
    will use = rows of a->stats_partial (a->stats_partial must already be non-NULL in the query if it will be). */

@@ -63,3 +63,44 @@ def test_resume_semantics_follow_the_reference(tmp_path):
     ck.load_weights(path, _M(), submodule_name="cost_mdl", strict=False)
     with pytest.raises(ValueError):
         ck.load_weights(path, _M(), submodule_name="inv_mdl")
+
+
+def test_resumed_noise_stream_keeps_each_ranks_own_key():
+    """round-5 advisor finding: checkpoints are rank 0's, so restoring the stored (key, offset) on every rank made all ranks draw rank 0's
+    latent noise after --resume.  One process continues the stored stream as it was; under a process group a rank keeps its own key and
+    takes the offset."""
+    stored = (1234567, 4096)
+    assert ck.resumed_rng_state(stored, own_key=999, world=1) == stored
+    assert ck.resumed_rng_state(stored, own_key=999, world=2) == (999, 4096)
+
+
+def _resume_rank(rank, world, port, q):
+    import os as _os
+    _os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the per-rank seeds of train.py:100-103 -> per-rank keys (replay._rng_key is seed + stream id * constant: distinct seeds, distinct keys)
+    seed = 7 * world + rank + 1
+    own_key = (seed + 0 * 0x9E3779B97F4A7C15) & ((1 << 63) - 1)
+    key, offset = ck.resumed_rng_state((7 * world + 0 + 1, 1 << 20), own_key, dist.get_world_size())
+    keys = [None] * world
+    dist.all_gather_object(keys, (key, offset))
+    q.put((rank, keys))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_resume_with_different_keys_and_the_same_offset():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_resume_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for _, keys in res:
+        assert keys[0][0] != keys[1][0], "both ranks would draw the same latent noise after --resume"
+        assert keys[0][1] == keys[1][1] == 1 << 20

@@ -580,6 +580,16 @@ def test_conv3x3_head_dlm(env, S, Fr, split):
     torch.cuda.synchronize()
     assert torch.equal(img2, img)
     if split:
+        # the 32x32-tile head (csrc/conv3x3_head32.hip) runs the mean-only mode from its own weight layout: same images within f32
+        ws32, e32 = pk.pack_head32_split(w, perm)
+        ws32 = ws32.to(dev)
+        img32 = torch.full((Fr, 3, S, S), float("nan"), device=dev)
+        a.images, a.wpk_split, a.w_split_log2, a.split_layout = img32.data_ptr(), ws32.data_ptr(), e32, rt.SPLIT_HEAD32
+        rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head32 mean")
+        torch.cuda.synchronize()
+        assert_close(img32, want_img, atol=1e-5, name="dlm mean, 32x32 head")
+        assert_close(img32, img, atol=4e-6, name="dlm mean, 32x32 head vs 16x16 head")
+        a.images, a.wpk_split, a.w_split_log2, a.split_layout = img2.data_ptr(), ws.data_ptr(), e, rt.SPLIT_PLAIN
         # images_rows: frames with a row-map entry are stored at that row of a second array (and of a copy of it) as well; rows no
         # frame maps to stay as they were
         rmap = torch.full((Fr,), -1, dtype=torch.int32)
@@ -601,8 +611,9 @@ def test_conv3x3_head_dlm(env, S, Fr, split):
         assert bool((rows_img[:, len(rows):] == 7.0).all())
 
 
+@pytest.mark.parametrize("layout", ["plain", "head32"])
 @pytest.mark.parametrize("case", ["plain", "edges"])
-def test_conv3x3_head_fused_likelihood(env, case):
+def test_conv3x3_head_fused_likelihood(env, case, layout):
     """GCPX_HEAD_DLM_NLL: the split-f16 head evaluates decoder.nll of the frames matched to a ground-truth frame in its epilogue
     (frame_binding.py:88-99) instead of storing their 100 parameters per pixel for gcpx_dlm_nll.  Checked per frame against (1) the
     stored-parameters path (GCPX_HEAD_DLM_BOTH + gcpx_dlm_nll: same formulas, same fast-math helpers) and (2) the oracle's likelihood
@@ -644,9 +655,15 @@ def test_conv3x3_head_fused_likelihood(env, case):
                    out_pitch=len(perm), upsample=0, head_mode=rt.HEAD_DLM_NLL, wpk=wp, bias=bk.to(dev), out=None, images=img)
     a.raw_row_map, a.wpk_split, a.w_split_log2 = rows.data_ptr(), ws.data_ptr(), e
     a.nll_target, a.nll_partial, a.nll_rows = td.data_ptr(), part.data_ptr(), 2
+    if layout == "head32":
+        # the 32x32-tile head (csrc/conv3x3_head32.hip): its own weight layout, the same interface and results
+        ws32, e32 = pk.pack_head32_split(w, perm)
+        ws32 = ws32.to(dev)
+        a.wpk_split, a.w_split_log2, a.split_layout = ws32.data_ptr(), e32, rt.SPLIT_HEAD32
     rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head nll")
     got = torch.empty(2, device=dev)
     rt.check(lib.gcpx_reduce_partials(part.data_ptr(), nit, 2, 2, got.data_ptr(), 0, _stream()), "reduce")
+    a.wpk_split, a.w_split_log2, a.split_layout = ws.data_ptr(), e, rt.SPLIT_PLAIN
     # the stored-parameters path
     raw = torch.full((2, S, S, len(perm)), float("nan"), device=dev)
     img2 = torch.full((Fr, 3, S, S), float("nan"), device=dev)
@@ -656,7 +673,7 @@ def test_conv3x3_head_fused_likelihood(env, case):
     rt.check(lib.gcpx_dlm_nll(raw.data_ptr(), td.data_ptr(), None, ref.data_ptr(), 2, S * S, len(perm), 10, _stream()), "dlm_nll")
     torch.cuda.synchronize()
     assert torch.isfinite(part).all()
-    assert_close(img, img2, atol=2e-6, name="mixture mean, likelihood variant vs stored-parameters variant")   # (two instantiations: the compiler contracts them differently)
+    assert_close(img, img2, atol=2e-6 if layout == "plain" else 1e-5, name="mixture mean, likelihood variant vs stored-parameters variant")   # (two instantiations: the compiler contracts them differently)
     assert_close(got, ref, atol=0, rtol=1e-5, name="fused vs stored-parameters likelihood")
     assert_close(got.double().cpu(), want, atol=0, rtol=(1e-4 if case == "edges" else 2e-5), name="fused likelihood vs float64 oracle")
     # without wpk_split the mode is refused (the exact-f32 head keeps the stored-parameters path)
@@ -664,8 +681,9 @@ def test_conv3x3_head_fused_likelihood(env, case):
     assert lib.gcpx_conv3x3(C.byref(a), _stream()) != 0
 
 
+@pytest.mark.parametrize("layout", ["plain", "head32"])
 @pytest.mark.parametrize("case", ["full", "edges"])
-def test_conv3x3_head_nll_grad_values(env, case):
+def test_conv3x3_head_nll_grad_values(env, case, layout):
     """GCPX_HEAD_DLM_NLL_GRAD (the training forward's head, csrc/conv3x3_head_split.hip, NLL = 2): every stored gradient value of sampled
     frames against autograd of (nll_scale x row weight x) oracle.dlm_nll over a float64 conv of the same inputs, the per-row likelihood
     against the same oracle, and the whole gradient tensor bit for bit across 8 launches.
@@ -711,6 +729,10 @@ def test_conv3x3_head_nll_grad_values(env, case):
                    out_pitch=len(perm), upsample=0, head_mode=rt.HEAD_DLM_NLL_GRAD, wpk=wp, bias=bk.to(dev), out=grad, images=img)
     a.raw_row_map, a.wpk_split, a.w_split_log2 = rd.data_ptr(), ws.data_ptr(), e
     a.nll_target, a.nll_partial, a.nll_rows, a.nll_row_weight, a.nll_scale = td.data_ptr(), part.data_ptr(), R, wd.data_ptr(), scale
+    if layout == "head32":
+        ws32, e32 = pk.pack_head32_split(w, perm)
+        ws32 = ws32.to(dev)
+        a.wpk_split, a.w_split_log2, a.split_layout = ws32.data_ptr(), e32, rt.SPLIT_HEAD32
     rt.check(lib.gcpx_conv3x3(C.byref(a), _stream()), "head nll + gradient")
     torch.cuda.synchronize()
     first, first_part = grad.clone(), part.clone()

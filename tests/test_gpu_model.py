@@ -248,3 +248,29 @@ def test_tree_lstm_variants_c1(tree_lstm, lstm_init):
     ref_losses, ref_total = O.losses(sd, hp, inputs, ref)
     losses = model.loss(dev_in, out)
     assert abs(float(losses["_total"]) - float(ref_total)) <= 3e-5 * abs(float(ref_total))
+
+
+def test_head32_opt_in_matches_the_default_head(monkeypatch):
+    """GCPX_HEAD32=1 routes the mean-only / fused-likelihood head modes to the 32x32x16-tile kernel (csrc/conv3x3_head32.hip, opt-in:
+    profiles/r06_head32_study.txt): the same forward, images within f32 rounding, every loss term within 2e-5"""
+    import video_gcp_amd as V
+    from video_gcp_amd.model import GCPTreeModel
+    hp = V.config("c1")
+    sd = V.init_params(hp, seed=3, randomize_affine=True)
+    inputs, noise, _ = make_inputs(hp, seed=1, variant="B")
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GCPX_HEAD32", flag)
+        m = GCPTreeModel(hp, params=sd, device="cuda")
+        assert m.head32 == (flag == "1") and ("dec.head32" in m.pk_split) == (flag == "1")
+        m.train(True)
+        dev_in = {k: v.cuda() for k, v in inputs.items()}
+        out = m(dev_in, "train", noise=noise.cuda())
+        losses = m.loss(dev_in, out)
+        total = m.get_total_loss(dev_in, losses)
+        torch.cuda.synchronize()
+        res[flag] = (out.tree.bf.images.float().cpu().clone(), {k: float(losses[k].value) for k in ("dense_img_rec", "kl")}, float(total.value))
+    assert_close(res["1"][0], res["0"][0], atol=1e-5, name="images, 32x32 head vs default head")
+    for k, v in res["0"][1].items():
+        assert abs(res["1"][1][k] - v) <= 2e-5 * max(1.0, abs(v)), (k, res["1"][1][k], v)
+    assert abs(res["1"][2] - res["0"][2]) <= 2e-5 * max(1.0, abs(res["0"][2]))

@@ -23,7 +23,7 @@ def test_head_and_loss_kernels_carry_no_packed_f32():
         assert line and ": 0 packed-f32 VALU instructions, 0 with a low lane reading a high half" in line[0], r.stdout[-2000:]
     # the per-file flag has ONE home (csrc/sources.sh) that the build, the variant builds and the scan all read
     src = open(os.path.join(ROOT, "video-gcp_amd", "csrc", "sources.sh")).read()
-    assert 'GCPX_NO_SLP="conv3x3_head_split loss scalar_f32"' in src and "-fno-slp-vectorize" in src
+    assert 'GCPX_NO_SLP="conv3x3_head_split conv3x3_head32 loss scalar_f32"' in src and "-fno-slp-vectorize" in src
     for p in ("video-gcp_amd/csrc/build.sh", "tools/build_variant.sh"):
         assert "sources.sh" in open(os.path.join(ROOT, p)).read(), p
     assert "sources.sh" in open(os.path.join(ROOT, "tools", "isa_hazard_scan.py")).read()

@@ -10,6 +10,13 @@
 #define MF32 "v_mfma_f32_32x32x16_f16 a[0:15], v[64:67], v[68:71], a[0:15]\n v_mfma_f32_32x32x16_f16 a[16:31], v[64:67], v[68:71], a[16:31]\n"
 #define FMA8 "v_fma_f32 v80, v80, v72, v73\n v_fma_f32 v81, v81, v72, v73\n v_fma_f32 v82, v82, v72, v73\n v_fma_f32 v83, v83, v72, v73\n" \
              "v_fma_f32 v84, v84, v72, v73\n v_fma_f32 v85, v85, v72, v73\n v_fma_f32 v86, v86, v72, v73\n v_fma_f32 v87, v87, v72, v73\n"
+// a dependent chain with transcendentals, as an epilogue has them: 8 instructions, 2 of them v_exp_f32, every one reading the previous result
+#define CHAIN8 "v_fma_f32 v80, v80, v72, v73\n v_exp_f32 v80, v80\n v_fma_f32 v80, v80, v72, v73\n v_add_f32 v80, v80, v73\n" \
+               "v_mul_f32 v80, v80, v72\n v_exp_f32 v80, v80\n v_fma_f32 v80, v80, v72, v73\n v_min_f32 v80, v80, v73\n"
+#ifdef USE_CHAIN
+#undef FMA8
+#define FMA8 CHAIN8
+#endif
 
 // mode: bit 0 = MFMA waves run, bit 1 = VALU waves run; form: 0 = 16x16x32 (8 per iteration), 1 = 32x32x16 (4 per iteration: same FLOPs)
 template <int FORM, int PRIO_M, int PRIO_V>

@@ -54,6 +54,14 @@ def get_resume_ckpt_file(ckpt, path):
     return os.path.join(path, name)
 
 
+def resumed_rng_state(stored, own_key, world):
+    """(key, offset) a model continues its in-plan noise stream from after loading a checkpoint that stored `stored` = (key, offset).
+    One process: the stored stream, as it was.  A process group: the checkpoint is rank 0's (train.py saves on rank 0 only), so every
+    rank keeps its own key — per-rank seeds give per-rank keys — and takes the offset, the position in the sequence."""
+    key, offset = int(stored[0]), int(stored[1])
+    return (key, offset) if world <= 1 else (int(own_key), offset)
+
+
 def load_weights(weights_file, model, submodule_name=None, strict=True):
     """Returns (global_step, epoch, optimizer_state).  checkpoint_handler.py:45-74,133-143: with `submodule_name` only keys under
     that prefix are loaded.  (The reference strips the prefix because it loads INTO the sub-module; this model holds the

@@ -8,6 +8,7 @@
 #include "common.h"
 
 #include <cstring>
+#include <string>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -23,27 +24,56 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
-Rccl* rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+// Resolved once, thread-safely (function-local static initialised by a lambda).  A copy of RCCL the process already holds — torch's
+// bundled one, under whatever path or soname — is found first through the global symbol scope (dlsym(RTLD_DEFAULT)) and through
+// RTLD_NOLOAD, so that two copies never serve one process; only then is a new one loaded.
+struct RcclLoad {
+    Rccl r;
+    bool ok = false;
+    std::string why;
+};
+
+const RcclLoad& rccl_load() {
+    static const RcclLoad load = []() {
+        RcclLoad l;
+        Rccl& r = l.r;
+        auto bind = [&](void* h) {
+            r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+            r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+            r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+            r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+            r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+            r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+            return r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.AllGather;
+        };
+        if (dlsym(RTLD_DEFAULT, "ncclAllReduce") && bind(RTLD_DEFAULT)) {           // already in the process (e.g. torch's copy)
+            l.ok = true;
+            return l;
+        }
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const int flags : {RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD, RTLD_NOW | RTLD_GLOBAL}) {
+            for (const char* name : names) {
+                r.handle = dlopen(name, flags);
+                if (r.handle) break;
+            }
             if (r.handle) break;
         }
-        if (r.handle) {
-            r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
-            r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
-            r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
-            r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.handle, "ncclAllReduce"));
-            r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
-            r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
+        if (!r.handle) {
+            const char* e = dlerror();                   // (NULL when the last failure was already reported)
+            l.why = e ? e : "unknown dlopen error";
+            return l;
         }
-    }
-    const bool ok = r.handle && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.AllGather;
-    if (!ok) gcpx_set_error("gcpx_comm: librccl.so not found or incomplete (%s)", r.handle ? "missing symbol" : dlerror());
-    return ok ? &r : nullptr;
+        l.ok = bind(r.handle);
+        if (!l.ok) l.why = "missing symbol";
+        return l;
+    }();
+    return load;
+}
+
+Rccl* rccl() {
+    const RcclLoad& l = rccl_load();
+    if (!l.ok) gcpx_set_error("gcpx_comm: librccl.so not found or incomplete (%s)", l.why.c_str());
+    return l.ok ? const_cast<Rccl*>(&l.r) : nullptr;
 }
 
 int fail(Rccl* r, const char* what, ncclResult_t st) {

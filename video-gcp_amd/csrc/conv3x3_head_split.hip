@@ -676,9 +676,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_head_split_kernel(const gcpx_c
 
 }  // namespace
 
+int gcpx_launch_head32(const gcpx_conv_args* a, hipStream_t stream);            // conv3x3_head32.hip
+
 // Called by conv3x3_dispatch (conv3x3.hip) for the 100-channel mixture head when the caller supplies split-f16 weights.
 int gcpx_launch_head_split(const gcpx_conv_args* a, hipStream_t stream) {
     using Cfg = SplitHeadCfg;
+    if (a->split_layout == GCPX_SPLIT_HEAD32) return gcpx_launch_head32(a, stream);
     const int nll = a->head_mode == GCPX_HEAD_DLM_NLL ? 1 : (a->head_mode == GCPX_HEAD_DLM_NLL_GRAD ? 2 : 0);
     if (nll) {
         GCPX_CHECK_ARG(a->nll_target && a->nll_partial && a->nll_rows > 0 && a->raw_row_map, "GCPX_HEAD_DLM_NLL needs nll_target, nll_partial, nll_rows and raw_row_map");

@@ -108,7 +108,9 @@ def gradient_bucket_ranges(poff, hierarchy_levels, untied_layers):
     # the `params` dict (a converted reference state_dict).  Anything else gets the single bucket, which is always right.
     level_range = {int(n[4:]): (lo, hi) for n, lo, hi in out if n.startswith("tree")}
     for lo, hi, lvl, k in spans:
-        ok = (level_range[lvl][0] <= lo and hi <= level_range[lvl][1]) if lvl >= 0 else hi <= starts[0]
+        # (a level the model does not have — a converted state_dict of a deeper tree — has no slice: not ok, one bucket)
+        rng = level_range.get(lvl)
+        ok = (rng is not None and rng[0] <= lo and hi <= rng[1]) if lvl >= 0 else hi <= starts[0]
         if not ok:
             import warnings
             warnings.warn(f"gradient buckets: parameter {k} at [{lo}, {hi}) is outside the range of its slice; using one bucket "

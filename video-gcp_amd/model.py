@@ -100,6 +100,9 @@ class GCPTreeModel(WeightsMixin, PlanOpsMixin, ForwardPlanMixin, ReplayMixin):
         # forward with losses: likelihood of the matched frames inside the head kernel (GCPX_HEAD_DLM_NLL); GCPX_UNFUSED_NLL=1 keeps
         # the stored-parameters + gcpx_dlm_nll path (what the exact-f32 build and the training forward run)
         self.fused_head_nll = os.environ.get("GCPX_UNFUSED_NLL") is None
+        # GCPX_HEAD32=1: the mixture head on 32x32x16 MFMA tiles (csrc/conv3x3_head32.hip) for the modes that store no raw parameters.
+        # Parity-green and measured slower than the 16x16x32 kernel (profiles/r06_head32_study.txt): off unless asked for
+        self.head32 = os.environ.get("GCPX_HEAD32", "0") == "1"
         self._timed_op = None                 # name of one plan op bracketed by HIP events (bench.py roofline)
         self._timed_events = []
         self._pack_all()

@@ -319,6 +319,50 @@ def conv3x3_split32_index(shape, offset):
     return (conv3x3_split32_gather(ids).reshape(-1) - 1).to(torch.int32)
 
 
+# ---- output head in 32x32x16 MFMA tiles (csrc/conv3x3_head32.hip) ----------------------------------------------------------------
+def head32_slot(c, i, n_mix=10):
+    """Row i (0..31) of 32-channel tile c (0..3) of the 32x32 head kernel -> slot of the 112-slot layout (dlm_channel_perm), -1 = empty.
+    v_mfma_f32_32x32x16_f16 leaves lane l (half h = l >> 5) with rows i = 8 g + 4 h + r (g, r = 0..3) of every tile, all of ONE pixel: the
+    lane evaluates mixtures k = 2 m + h (m = 0..4) of that pixel and finds mixture m's eight slots {logit, mean r g b, coeff 0 1 2,
+    log_scale_r} in tile m >> 1 at registers 8 (m & 1) + p, and its green / blue log-scales in tile 3 at registers 2 m + (c - 1) —
+    no lane exchange.  The same rule is compiled into the kernel (head32_slot)."""
+    g, h, r = i // 8, (i // 4) % 2, i % 4
+    if c < 3:
+        m, p = 2 * c + g // 2, 4 * (g % 2) + r
+        return 8 * (2 * m + h) + p if m < 5 else -1
+    u = 4 * g + r
+    return dlm_log_scale_slot(1 + u % 2, 2 * (u // 2) + h, n_mix) if u < 10 else -1
+
+
+def head32_gather(w, perm):
+    """w [100, 16, 3, 3] -> [9 taps][4 tiles][64][8] in v_mfma_f32_32x32x16_f16 A-fragment order: lane l (i = l & 31, kh = l >> 5)
+    element el = W[channel of head32_slot(tile, i)][8 kh + el][tap] (zeros for empty slots)"""
+    assert w.shape[1] == 16 and w.shape[0] == 100
+    dev = w.device
+    chan = torch.tensor([[perm[head32_slot(c, i)] if head32_slot(c, i) >= 0 else -1 for i in range(32)] for c in range(4)], device=dev)
+    wz = torch.cat([w.reshape(100, 16, 9), torch.zeros((1, 16, 9), dtype=w.dtype, device=dev)], 0)       # row 100 = zeros
+    chan = torch.where(chan >= 0, chan, torch.full_like(chan, 100))
+    tap = torch.arange(9, device=dev)[:, None, None, None]
+    ct = torch.arange(4, device=dev)[None, :, None, None]
+    lane = torch.arange(64, device=dev)[None, None, :, None]
+    el = torch.arange(8, device=dev)[None, None, None, :]
+    return wz[chan[ct, lane % 32], (lane // 32) * 8 + el, tap].contiguous()                                 # [9, 4, 64, 8]
+
+
+def pack_head32_split(w, perm):
+    """-> (int16 [9][4][2][64][8], e): the two f16 pieces in the layout of head32_gather (host twin of gcpx_split_pack over head32_index)"""
+    w1, w2, e = split_f16(head32_gather(w, perm))
+    return torch.stack([w1, w2], 2).contiguous().view(torch.int16), e
+
+
+def head32_index(shape, offset, perm):
+    n = 1
+    for d in shape:
+        n *= d
+    ids = (torch.arange(n, dtype=torch.float64) + (offset + 1)).view(shape)
+    return (head32_gather(ids, perm).reshape(-1) - 1).to(torch.int32)
+
+
 _FOLD_CF = (((0.75, 0.25, 0.0), (0.25, 0.75, 0.75), (0.0, 0.0, 0.25)),
             ((0.25, 0.0, 0.0), (0.75, 0.75, 0.25), (0.0, 0.25, 0.75)))
 

@@ -14,6 +14,22 @@ from .params import init_params, encoder_layers, encoder_skip_layers, decoder_la
 from .plan_ops import _Plan, _addr, N_LANES
 
 
+# Replay policy "auto".  One process: graph against eager replay timed once per plan (ReplayMixin._eager_replays_faster).  Under a
+# process group no rank times anything inside forward() — 24 extra forwards and 6 device synchronisations on the first call of every
+# plan key, and ranks that could decide differently —: the decision is a rule every rank evaluates alike.  What the timing finds on
+# one device: a plan with ~0.3 ms of GPU work (c1: 2 x 31 frames of 32 x 32) is bound by the host's enqueue cost and replays faster as
+# a graph, a plan with ~2.8 ms (c2: 16 x 127 frames of 64 x 64) loses 0.15-0.2 ms to the graph.
+REPLAY_RULE_PIXELS = 1 << 20        # decoded pixels per forward from which the eager plan is replayed under a process group
+
+
+def choose_replay(decoded_pixels, world, measure):
+    """True = replay by eager launches, False = replay the hipGraph.  `measure()` is the one-time comparison; it is NOT called when
+    world > 1 (tests/test_dist_cpu.py)."""
+    if world > 1:
+        return decoded_pixels >= REPLAY_RULE_PIXELS
+    return bool(measure())
+
+
 class ReplayMixin:
 
     # ------------------------------------------------------------------------------------------------
@@ -49,11 +65,18 @@ class ReplayMixin:
         return tuple(int(v) for v in self._buf("rng_state", (2,), torch.int64).cpu().tolist())
 
     def set_rng_state(self, state):
+        """Continue a checkpointed noise stream.  Checkpoints are written by rank 0 only (train.py), so under a process group the stored
+        KEY is rank 0's: every rank keeps its OWN key (derived from its per-rank seed, train.py:100-103) and takes only the offset —
+        the ranks' streams stay different after --resume (checkpoint.resumed_rng_state)."""
         if state is None:
             return
-        self._rng_seed = int(torch.cuda.initial_seed()) & ((1 << 63) - 1)      # (the restored stream survives until torch is seeded with another value)
+        from .checkpoint import resumed_rng_state
+        seed = int(torch.cuda.initial_seed()) & ((1 << 63) - 1)
+        self._rng_seed = seed                                                  # (the restored stream survives until torch is seeded with another value)
+        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        key, offset = resumed_rng_state(state, self._rng_key(seed), world)
         with torch.cuda.stream(self._stream):
-            self._write_rng_state(int(state[0]), int(state[1]))
+            self._write_rng_state(key, offset)
 
     # ------------------------------------------------------------------------------------------------
     def forward(self, inputs, phase="train", noise=None):
@@ -167,7 +190,7 @@ class ReplayMixin:
             if plan.graph is None:
                 plan.run(self._streams)               # warm-up (sets kernel attributes) outside capture
                 plan.graph = self._capture(plan, plan.ops, stream)
-                plan.eager = self.use_graph == "auto" and self._eager_replays_faster(plan, stream)
+                plan.eager = self.use_graph == "auto" and self._choose_eager(plan, stream, B)
             if plan.eager:
                 plan.run(self._streams)
             else:
@@ -176,6 +199,13 @@ class ReplayMixin:
             plan.run(self._streams)
         caller.wait_stream(self._stream)
         return self._wrap_outputs(plan.outs, tin, phase)
+
+    def _choose_eager(self, plan, stream, B):
+        dist = torch.distributed
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        hp = self._hp
+        frames = (B if B is not None else hp.batch_size) * hp.n_nodes if self._decode else 0
+        return choose_replay(frames * hp.img_sz * hp.img_sz, world, lambda: self._eager_replays_faster(plan, stream))
 
     def _eager_replays_faster(self, plan, stream, reps=4, trials=3):
         """time `reps` consecutive replays of the plan as a hipGraph and as eager launches — each replay between the same two stream
@@ -229,7 +259,10 @@ class ReplayMixin:
 
     def _capture(self, plan, ops, stream):
         rt.check(self.lib.gcpx_graph_begin(stream), "graph_begin")
-        plan.run(self._streams, ops)
+        # GCPX_GRAPH_LINEAR=1: every lane captured on the main stream — the graph is one chain of kernel nodes (no cross-branch edges,
+        # no lane overlap)
+        lanes = [self._streams[0]] * len(self._streams) if os.environ.get("GCPX_GRAPH_LINEAR") == "1" else self._streams
+        plan.run(lanes, ops)
         g = C.c_void_p()
         rt.check(self.lib.gcpx_graph_end(stream, C.byref(g)), "graph_end")
         return g
@@ -248,7 +281,7 @@ class ReplayMixin:
         if self.use_graph == "auto" and plan.graph is None:
             plan.run(self._streams)
             plan.graph = self._capture(plan, plan.ops, stream)
-            plan.eager = self._eager_replays_faster(plan, stream)
+            plan.eager = self._choose_eager(plan, stream, None)
         if plan.eager or not self.use_graph:
             # the plan as it is replayed (eager launches over the lanes), with an event on the main lane in front of and behind the op
             if plan.timed_ops is None or plan.timed_ops[0] != self._timed_op:

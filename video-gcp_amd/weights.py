@@ -80,6 +80,9 @@ class WeightsMixin:
         todo = []
         if hp.decoder_distribution == "discrete_logistic_mixture":
             todo.append(("dec.head", "decoder.gen_head.conv.weight", pk.dlm_channel_perm(hp.n_mixtures)))
+            if self.head32 and hp.n_mixtures == 10 and hp.head_channels == 100:
+                # the same weights in 32x32x16 fragment order for csrc/conv3x3_head32.hip (mean-only and fused-likelihood modes)
+                todo.append(("dec.head32", "decoder.gen_head.conv.weight", ("head32", pk.dlm_channel_perm(hp.n_mixtures))))
         for name, c_prev, c_skip, skip_idx, cout in decoder_layers(hp):
             if cout == 16 and c_prev + c_skip == 32:         # bilinear rows folded into the weights (conv3x3_up16_fold_kernel)
                 todo.append((f"dec.{name}", f"decoder.net.{name}.conv.weight", "rowfold"))
@@ -101,6 +104,8 @@ class WeightsMixin:
                 idx = pk.conv3x3_fold_index().to(self.device)
             elif perm == "tiled32":
                 idx = pk.conv3x3_split32_index(shp, off).to(self.device)
+            elif isinstance(perm, tuple) and perm[0] == "head32":
+                idx = pk.head32_index(shp, off, perm[1]).to(self.device)
             else:
                 idx = pk.conv3x3_split_index(shp, off, perm).to(self.device)
             d.update(idx=idx, out=torch.zeros(2 * idx.numel(), dtype=torch.int16, device=self.device),
@@ -161,9 +166,14 @@ class WeightsMixin:
     def _set_split(self, a, name):
         """Hand conv `name`'s split-f16 weights to the launch if this model runs split-f16 and holds them."""
         d = self.pk_split.get(name)
+        layout = None
+        if name == "dec.head" and self.head32 and a.head_mode in (rt.HEAD_DLM_MEAN, rt.HEAD_DLM_NLL, rt.HEAD_DLM_NLL_GRAD) \
+                and "dec.head32" in self.pk_split:
+            # the modes that store no raw parameters run the 32x32-tile head (csrc/conv3x3_head32.hip)
+            d, layout = self.pk_split["dec.head32"], rt.SPLIT_HEAD32
         if self.split_f16 and d is not None:
             a.wpk_split, a.w_split_log2_dev = d["out"].data_ptr(), d["log2"].data_ptr()
-            a.split_layout = rt.SPLIT_ROWFOLD if "fold" in d else rt.SPLIT_PLAIN
+            a.split_layout = layout if layout is not None else (rt.SPLIT_ROWFOLD if "fold" in d else rt.SPLIT_PLAIN)
 
     def _pack_fused_embed(self):
         """Inference only: the input embedding Linear and LSTM layer 0's input projection are two Linears with nothing in between
