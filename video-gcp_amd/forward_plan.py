@@ -205,6 +205,40 @@ class ForwardPlanMixin:
         enc_traj = inf_enc = None
         # three independent encoder passes (separate BatchNorm statistics, base_gcp.py:188,208,209) on three lanes
         plan.fork([1, 2])
+        # The trajectory encoder (B T frames: ~0.3 ms of the forward) is ENQUEUED FIRST: eager replay issues the ops in plan order at
+        # ~4 us per launch, and two lanes can share a hardware queue — behind the ~25 small launches of the two image encoders and the
+        # index bookkeeping its first kernel started 0.25 ms into the forward (profiles/r05c_fwd_trace.txt: t = 271 us, queue q1 behind
+        # the I_g pass).  GCPX_ENC_ORDER=small_first restores the old order (A/B aid).
+        traj_first = os.environ.get("GCPX_ENC_ORDER") != "small_first"
+        def plan_traj_encoder():
+            nonlocal enc_traj, inf_enc
+            plan.lane = 0
+            if has_traj:
+                enc_traj = self._buf("enc_traj", (B * T, nz))
+                self._plan_encoder(plan, "traj", tin["traj_seq"].data_ptr(), B * T, enc_traj.data_ptr(), T * nz, nz, T)
+                inf_enc = self._buf("inf_enc_seq", (B * T, nz))
+                self._plan_seq_encoder(plan, "seq", "inf_encoder", enc_traj, inf_enc, B)
+                if attentive:
+                    # attention keys: second temporal encoder + per-frame Linear (base_gcp.py:122-123, :200); then the key /
+                    # value projections of every level's attention in one batched launch each
+                    dk = hp.nz_attn_key
+                    n_mod = L if hp.untied_layers else 1
+                    kenc = self._buf("inf_key_enc", (B * T, nz))
+                    self._plan_seq_encoder(plan, "kseq", "inf_key_encoder.0", enc_traj, kenc, B)
+                    keys = self._buf("inf_enc_key_seq", (B * T, dk))
+                    dense = lambda t, w: self._rowsrc(t.data_ptr(), 0, w, w)
+                    self._gemm(plan, "kseq.key", [dense(kenc, nz)], B * T, dk, B * T, P["kseq.key.w"], P["kseq.key.b"],
+                               out=keys.data_ptr(), ob=0, orow=dk)
+                    Kp = self._buf("attn.K", (n_mod, B * T, dk))
+                    Vp = self._buf("attn.V", (n_mod, B * T, nz))
+                    self._gemm(plan, "attn.k_proj", [dense(keys, dk)], B * T, dk, B * T, P["attn.k_proj.w"], P["attn.k_proj.b"],
+                               out=Kp.data_ptr(), ob=0, orow=dk, batch=(n_mod, 0, P["attn.k_proj.w"][0].numel(), dk, B * T * dk))
+                    self._gemm(plan, "attn.v_proj", [dense(inf_enc, nz)], B * T, nz, B * T, P["attn.v_proj.w"], P["attn.v_proj.b"],
+                               out=Vp.data_ptr(), ob=0, orow=nz, batch=(n_mod, 0, P["attn.v_proj.w"][0].numel(), nz, B * T * nz))
+                    plan.rec["attn_kv"] = dict(Kp=Kp, Vp=Vp, keys=keys, kenc=kenc, n_mod=n_mod)
+
+        if traj_first:
+            plan_traj_encoder()
         plan.lane = 1
         if "rng_all" in tin:
             # Gaussian.sample()'s numbers for this forward (+ the index draws' four per sequence): first needed by level 0's posterior
@@ -235,30 +269,9 @@ class ForwardPlanMixin:
             logits = self._buf("seq_len_logits", (B, T))
             self._mlp(plan, "length_pred", P["length_pred"], [e0(), eg()], B, 1, out=logits.data_ptr(), ob=T, orow=0)
             outs["seq_len_logits"] = logits
+        if not traj_first:
+            plan_traj_encoder()
         plan.lane = 0
-        if has_traj:
-            enc_traj = self._buf("enc_traj", (B * T, nz))
-            self._plan_encoder(plan, "traj", tin["traj_seq"].data_ptr(), B * T, enc_traj.data_ptr(), T * nz, nz, T)
-            inf_enc = self._buf("inf_enc_seq", (B * T, nz))
-            self._plan_seq_encoder(plan, "seq", "inf_encoder", enc_traj, inf_enc, B)
-            if attentive:
-                # attention keys: second temporal encoder + per-frame Linear (base_gcp.py:122-123, :200); then the key /
-                # value projections of every level's attention in one batched launch each
-                dk = hp.nz_attn_key
-                n_mod = L if hp.untied_layers else 1
-                kenc = self._buf("inf_key_enc", (B * T, nz))
-                self._plan_seq_encoder(plan, "kseq", "inf_key_encoder.0", enc_traj, kenc, B)
-                keys = self._buf("inf_enc_key_seq", (B * T, dk))
-                dense = lambda t, w: self._rowsrc(t.data_ptr(), 0, w, w)
-                self._gemm(plan, "kseq.key", [dense(kenc, nz)], B * T, dk, B * T, P["kseq.key.w"], P["kseq.key.b"],
-                           out=keys.data_ptr(), ob=0, orow=dk)
-                Kp = self._buf("attn.K", (n_mod, B * T, dk))
-                Vp = self._buf("attn.V", (n_mod, B * T, nz))
-                self._gemm(plan, "attn.k_proj", [dense(keys, dk)], B * T, dk, B * T, P["attn.k_proj.w"], P["attn.k_proj.b"],
-                           out=Kp.data_ptr(), ob=0, orow=dk, batch=(n_mod, 0, P["attn.k_proj.w"][0].numel(), dk, B * T * dk))
-                self._gemm(plan, "attn.v_proj", [dense(inf_enc, nz)], B * T, nz, B * T, P["attn.v_proj.w"], P["attn.v_proj.b"],
-                           out=Vp.data_ptr(), ob=0, orow=nz, batch=(n_mod, 0, P["attn.v_proj.w"][0].numel(), nz, B * T * nz))
-                plan.rec["attn_kv"] = dict(Kp=Kp, Vp=Vp, keys=keys, kenc=kenc, n_mod=n_mod)
         plan.join([1, 2])
 
         # ---- get_end_ind: length predictor (misc.py:45-51) ----
