@@ -21,7 +21,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 F16_MFMA_PEAK_TFLOPS = 2500.0     # same table: dense f16 / bf16 MFMA (no sparsity)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_head_kernel.json")
 HEAD_KERNEL_SOURCES = ("video-gcp_amd/csrc/conv3x3.hip", "video-gcp_amd/csrc/conv3x3_head_split.hip", "video-gcp_amd/csrc/split_mfma.h",
-                       "video-gcp_amd/csrc/common.h")
+                       "video-gcp_amd/csrc/split_common.h", "video-gcp_amd/csrc/common.h")
 
 
 def kernel_source_sha(paths=HEAD_KERNEL_SOURCES):

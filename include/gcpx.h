@@ -124,6 +124,14 @@ typedef struct gcpx_conv_args {
        (up = 0, no add) computes in a pass of its own over the same tensors.  NULL: plain data gradient */
     const float* bwd_r;
     const float *bwd_scale, *bwd_shift, *bwd_mean, *bwd_rstd;
+    /* Upsampling blocks with 32 / 64 output channels in split-f16 (conv3x3_up32_split_kernel): a raw NHWC tensor
+       [F / addend_frame_div][Hout][Wout][out_pitch] added to the conv's result (before the BatchNorm partial sums and the store), frame f
+       reading frame f / addend_frame_div.  The decoder concatenates the skip activations of I_0 — the same for the N nodes of a sequence
+       — to every node's features (tree_dense_rec.py:42 -> blox ConvDecoder with skips); a conv is linear in its input channels, so the
+       skip half is convolved ONCE per sequence and arrives here, and the per-node launch walks the node's own channels only.  NULL: none */
+    const float* addend;
+    int32_t addend_frame_div;
+    int32_t _pad4;
 } gcpx_conv_args;
 
 /* GCPX_SPLIT_HEAD32: the 100-channel mixture head's weights in 32x32x16 A-fragment order [9 taps][4 tiles][2 pieces][64][8]

@@ -289,14 +289,14 @@ def test_bench_self_launches_ranks():
 def _replay_choice_rank(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
-    from video_gcp_amd.replay import choose_replay, REPLAY_RULE_PIXELS
+    from video_gcp_amd.replay import choose_replay
     dist.init_process_group("gloo", rank=rank, world_size=world)
     calls = []
 
     def measure():                      # a per-rank timing would disagree between ranks: rank 0 "measures" eager, rank 1 graph
         calls.append(1)
         return rank == 0
-    picks = [choose_replay(px, dist.get_world_size(), measure) for px in (0, 2 * 31 * 32 * 32, REPLAY_RULE_PIXELS, 16 * 127 * 64 * 64)]
+    picks = [choose_replay(px, dist.get_world_size(), measure) for px in (0, 2 * 31 * 32 * 32, 1 << 20, 16 * 127 * 64 * 64)]
     q.put((rank, picks, len(calls)))
     dist.destroy_process_group()
 
@@ -316,6 +316,6 @@ def test_replay_policy_under_a_process_group_is_a_rule_not_a_measurement():
     res = sorted(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(60)
-    assert res[0][1] == res[1][1] == [False, False, True, True]         # (graph for the small plans, eager from the rule's size on)
+    assert res[0][1] == res[1][1] == [False, False, False, False]       # (every rank replays the graph, whatever the plan's size)
     assert res[0][2] == res[1][2] == 0                                  # nobody timed anything
     assert choose_replay(0, 1, lambda: True) is True and choose_replay(1 << 30, 1, lambda: False) is False

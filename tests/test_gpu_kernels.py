@@ -535,6 +535,63 @@ def test_conv3x3_upsample_blocks(env, Hin, c_prev, c_skip, cout, Fr, nodes, spli
     assert_close(s[1], (want ** 2).sum((0, 2, 3)), atol=2e-2, rtol=1e-4, name="stats sumsq")
 
 
+@pytest.mark.parametrize("Hin,c_prev,c_skip,cout,Fr,nodes", [(8, 64, 64, 32, 6, 3), (4, 64, 64, 32, 8, 4), (4, 64, 64, 64, 6, 2)])
+def test_conv3x3_up32_skip_channels_convolved_once_per_sequence(env, Hin, c_prev, c_skip, cout, Fr, nodes):
+    """gcpx_conv_args.addend: the skip half of a decoder block (the same activations for every node of a sequence) convolved ONCE per
+    sequence (second k-steps of the same weight pack, zero bias) and added in the per-node launch's epilogue = the one-launch block over
+    the concatenated channels, output and BatchNorm partial sums, within f32 rounding; against F.conv2d as the block test"""
+    rt, pk, lib, dev = env
+    torch.manual_seed(Hin + cout + nodes)
+    x = torch.randn(Fr, c_prev, Hin, Hin)
+    sc, sh = torch.rand(c_prev) + 0.5, torch.randn(c_prev) * 0.2
+    sk = torch.randn(Fr // nodes, c_skip, Hin, Hin)
+    ssc, ssh = torch.rand(c_skip) + 0.5, torch.randn(c_skip) * 0.2
+    xin = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)
+    skin = F.leaky_relu(sk * ssc[None, :, None, None] + ssh[None, :, None, None], 0.2)
+    cin = c_prev + c_skip
+    w, b = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.randn(cout) * 0.1
+    want = F.conv2d(F.interpolate(torch.cat([xin, skin.repeat_interleave(nodes, 0)], 1), scale_factor=2, mode="bilinear", align_corners=False),
+                    w, b, padding=1)
+    xd, skd = x.permute(0, 2, 3, 1).contiguous().to(dev), sk.permute(0, 2, 3, 1).contiguous().to(dev)
+    wp, bd = pk.pack_conv3x3(w, 32).to(dev), pk.pad_vec(b, cout).to(dev)
+    ws, e = pk.pack_conv3x3_split32(w)
+    ws = ws.to(dev)
+    H2 = 2 * Hin
+    # one launch over both sources
+    out1 = torch.full((Fr, H2, H2, cout), float("nan"), device=dev)
+    a1 = _conv_args(rt, [(xd, c_prev, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU), (skd, c_skip, nodes, ssc.to(dev), ssh.to(dev), rt.ACT_LRELU)],
+                    F=Fr, Hin=Hin, Win=Hin, Hout=H2, Wout=H2, Cout=cout, out_pitch=cout, upsample=1, head_mode=rt.HEAD_RAW, wpk=wp, bias=bd,
+                    out=out1, stats_partial=out1)
+    a1.wpk_split, a1.w_split_log2 = ws.data_ptr(), e
+    G = lib.gcpx_conv3x3_grid(C.byref(a1))
+    st1 = torch.full((G, 2, cout), float("nan"), device=dev)
+    a1.stats_partial = st1.data_ptr()
+    rt.check(lib.gcpx_conv3x3(C.byref(a1), _stream()), "block, one launch")
+    # the skip half once per sequence, then the nodes' own channels + addend
+    add = torch.full((Fr // nodes, H2, H2, cout), float("nan"), device=dev)
+    zb = torch.zeros(cout, device=dev)
+    a_s = _conv_args(rt, [(skd, c_skip, 1, ssc.to(dev), ssh.to(dev), rt.ACT_LRELU)], F=Fr // nodes, Hin=Hin, Win=Hin, Hout=H2, Wout=H2, Cout=cout,
+                     out_pitch=cout, upsample=1, head_mode=rt.HEAD_RAW, wpk=wp, bias=zb, out=add)
+    a_s.wpk_split, a_s.w_split_log2 = ws.data_ptr() + (c_prev // 32) * 9 * (cout // 16) * 2048, e
+    rt.check(lib.gcpx_conv3x3(C.byref(a_s), _stream()), "skip half")
+    out2 = torch.full((Fr, H2, H2, cout), float("nan"), device=dev)
+    a2 = _conv_args(rt, [(xd, c_prev, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=Hin, Win=Hin, Hout=H2, Wout=H2, Cout=cout,
+                    out_pitch=cout, upsample=1, head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out2, stats_partial=out2)
+    a2.wpk_split, a2.w_split_log2 = ws.data_ptr(), e
+    a2.addend, a2.addend_frame_div = add.data_ptr(), nodes
+    assert lib.gcpx_conv3x3_grid(C.byref(a2)) == G
+    st2 = torch.full((G, 2, cout), float("nan"), device=dev)
+    a2.stats_partial = st2.data_ptr()
+    rt.check(lib.gcpx_conv3x3(C.byref(a2), _stream()), "nodes' half + addend")
+    torch.cuda.synchronize()
+    assert_close(out2.permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5, name="block with the skip half hoisted vs F.conv2d")
+    assert_close(out2, out1, atol=4e-6, rtol=1e-5, name="hoisted vs one launch")
+    assert_close(st2.sum(0), st1.sum(0), atol=2e-2, rtol=1e-4, name="BatchNorm partial sums")
+    # the exact-f32 kernels do not take an addend: refused, not dropped
+    a2.wpk_split = None
+    assert lib.gcpx_conv3x3(C.byref(a2), _stream()) != 0
+
+
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("S,Fr", [(32, 3), (64, 2)])
 def test_conv3x3_head_dlm(env, S, Fr, split):

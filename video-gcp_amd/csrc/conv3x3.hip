@@ -1266,6 +1266,7 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
                                         a->head_mode == GCPX_HEAD_DLM_NLL || a->head_mode == GCPX_HEAD_DLM_NLL_GRAD)),
                    "images_rows: split-f16 mixture head with raw_row_map and images only");
     const int W = a->Wout;
+    GCPX_CHECK_ARG(!a->addend || (a->upsample && a->Cout != 16 && a->addend_frame_div > 0), "addend: upsampling blocks with 32 / 64 output channels, addend_frame_div > 0");
     if (!a->upsample) {
         GCPX_CHECK_ARG(a->nsrc == 1 && a->src[0].frame_div == 1, "non-upsampling 3x3 conv takes one per-frame source");
         if (a->Cin == 16 && !a->src_row_map && W % 16 == 0 && a->Hout % 4 == 0) {
@@ -1337,6 +1338,8 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
             if (W == 8 && CT == 2) return gcpx_launch_up32_split(a, stream, 1, launch<true, 32, 2, 2>(a, stream, true));
             if (W == 8 && CT == 4) return gcpx_launch_up32_split(a, stream, 2, launch<true, 32, 4, 2>(a, stream, true));
         }
+        // (only the split-f16 kernels above add gcpx_conv_args.addend: anything that falls through must not drop it silently)
+        GCPX_CHECK_ARG(query_only || !a->addend, "addend: split-f16 upsampling blocks with 32 / 64 output channels only");
         if (W == 16 && CT == 2) return launch<true, 32, 2, 1>(a, stream, query_only);
         if (W == 8 && CT == 2) return launch<true, 32, 2, 2>(a, stream, query_only);
         if (W == 8 && CT == 4) return launch<true, 32, 4, 2>(a, stream, query_only);

@@ -517,6 +517,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_up32_split_kernel(const gcpx_c
                 const float4 bv = *reinterpret_cast<const float4*>(a.bias + ct * 16 + q * 4);
                 f32x4 v = acc[ct][pt];
                 v[0] = fmaf(v[0], inv, bv.x); v[1] = fmaf(v[1], inv, bv.y); v[2] = fmaf(v[2], inv, bv.z); v[3] = fmaf(v[3], inv, bv.w);
+                if (a.addend) {
+                    // the sequence's share of the conv (its skip channels, convolved once per sequence): gcpx_conv_args.addend
+                    const float4 ad = *reinterpret_cast<const float4*>(a.addend + (((size_t)(f / a.addend_frame_div) * Hout + (y0 + py[pt])) * Wout +
+                                                                                   (x0 + px[pt])) * a.out_pitch + ct * 16 + q * 4);
+                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+                }
                 *reinterpret_cast<float4*>(op + ct * 16 + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 if (a.stats_partial) {
                     st1[ct] += v;

@@ -130,8 +130,32 @@ class ForwardPlanMixin:
                 srcs.append((t.data_ptr(), C_, rpb, ssc, ssh, sact))    # skips of I_0 broadcast over the sequence's frames
             o = self._buf(f"dec.{name}", (F, 2 * res, 2 * res, cout))
             cpad = (cout + 15) // 16 * 16
-            a = self._conv_args(srcs, F, res, res, 2 * res, 2 * res, cout, cout, P[f"dec.{name}.w"], P[f"dec.{name}.b"],
+            # A conv is linear in its input channels and the skip channels are the SAME for the rpb nodes of a sequence: the blocks
+            # whose split-f16 kernel takes an addend (32 / 64 output channels) convolve the skip half once per sequence — F / rpb frames,
+            # on a side lane as soon as the I_0 encoder is done — and the per-node launch walks the node's own channels only: half of
+            # the block's MFMAs (pyramid-1 at c2: 128 -> 32 channels at 16 x 16, 38 of 455 GFLOP).  GCPX_NO_SKIP_HOIST=1: one launch
+            hoist = (skip_idx >= 0 and rpb > 1 and F % rpb == 0 and self.split_f16 and cout in (32, 64) and c_prev % 32 == 0 and
+                     c_skip % 32 == 0 and f"dec.{name}" in self.pk_split and "fold" not in self.pk_split[f"dec.{name}"] and
+                     os.environ.get("GCPX_NO_SKIP_HOIST") is None)
+            addend = None
+            if hoist:
+                addend = self._buf(f"dec.{name}.skip", (F // rpb, 2 * res, 2 * res, cout))
+                t, C_, ssc, ssh, sact = skips[skip_idx]
+                zb = self._buf(f"dec.{name}.zero_bias", (cpad,), zero=True)
+                a_s = self._conv_args([(t.data_ptr(), C_, 1, ssc, ssh, sact)], F // rpb, res, res, 2 * res, 2 * res, cout, cout,
+                                      P[f"dec.{name}.w"], zb, addend, upsample=1)
+                self._set_split(a_s, f"dec.{name}")
+                # the skip channels' k-steps follow the previous block's in the pack: [chunk][tap][CT][2][64] x 16 B, 32 channels per chunk
+                a_s.wpk_split = a_s.wpk_split + (c_prev // 32) * 9 * (cpad // 16) * 2048
+                plan.keep.append(a_s)
+                plan.add(f"dec.{name}.skip", lib.gcpx_conv3x3, C.byref(a_s))
+                srcs_main = [prev]
+            else:
+                srcs_main = srcs
+            a = self._conv_args(srcs_main, F, res, res, 2 * res, 2 * res, cout, cout, P[f"dec.{name}.w"], P[f"dec.{name}.b"],
                                 o, upsample=1, stats=(o if self.training else None))     # placeholder pointer for the query
+            if hoist:
+                a.addend, a.addend_frame_div = addend.data_ptr(), rpb
             Gl = lib.gcpx_conv3x3_grid(C.byref(a))
             assert Gl > 0, rt.lib().gcpx_last_error()
             st = self._buf(f"dec.st.{name}", (Gl, 2, cpad)) if self.training else None
@@ -341,7 +365,7 @@ class ForwardPlanMixin:
                 self._mlp(plan, f"prior{l}", W["prior"], [el(), er()], M, n, out=pz_out[0], ob=pz_out[1], orow=pz_out[2], group=pq)
                 if attentive:
                     # AttentiveInference (attentive_inference.py:16-32): e_tilde = attention over the encoded sequence
-                    et = self._plan_attention(plan, l, W, el(), er(), M, n, B, Kp, Vp, tin)
+                    et = self._plan_attention(plan, l, W, el(), er(), M, n, B, plan.rec["attn_kv"]["Kp"], plan.rec["attn_kv"]["Vp"], tin)
                 else:
                     # posterior: gather inf_enc_seq at the node's matched timestep (inference.py:27-33)
                     et = self._rowsrc(inf_enc.data_ptr(), 0, nz, nz, rowidx=etrow[B * (n - 1):])

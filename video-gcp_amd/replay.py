@@ -16,17 +16,17 @@ from .plan_ops import _Plan, _addr, N_LANES
 
 # Replay policy "auto".  One process: graph against eager replay timed once per plan (ReplayMixin._eager_replays_faster).  Under a
 # process group no rank times anything inside forward() — 24 extra forwards and 6 device synchronisations on the first call of every
-# plan key, and ranks that could decide differently —: the decision is a rule every rank evaluates alike.  What the timing finds on
-# one device: a plan with ~0.3 ms of GPU work (c1: 2 x 31 frames of 32 x 32) is bound by the host's enqueue cost and replays faster as
-# a graph, a plan with ~2.8 ms (c2: 16 x 127 frames of 64 x 64) loses 0.15-0.2 ms to the graph.
-REPLAY_RULE_PIXELS = 1 << 20        # decoded pixels per forward from which the eager plan is replayed under a process group
+# plan key, and ranks that could decide differently —: every rank replays the hipGraph.  With the trajectory encoder captured first
+# (forward_plan.py) the graph is at least as fast as the eager plan at every size measured (c1: host-bound eager plan, graph wins;
+# c2: 2.62-2.72 ms graph against 2.68-2.73 ms eager, profiles/r06_replay_order.txt) and costs the host one launch per forward.
+REPLAY_RULE_PIXELS = None           # decoded pixels per forward from which the eager plan would be replayed under a process group: never
 
 
 def choose_replay(decoded_pixels, world, measure):
     """True = replay by eager launches, False = replay the hipGraph.  `measure()` is the one-time comparison; it is NOT called when
     world > 1 (tests/test_dist_cpu.py)."""
     if world > 1:
-        return decoded_pixels >= REPLAY_RULE_PIXELS
+        return REPLAY_RULE_PIXELS is not None and decoded_pixels >= REPLAY_RULE_PIXELS
     return bool(measure())
 
 

@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
                 ("raw_row_map", vp), ("src_row_map", vp), ("src_row_frames", vp), ("n_src_rows", i32), ("w_split_log2", i32), ("wpk_split", vp), ("w_split_log2_dev", vp),
                 ("split_layout", i32), ("nll_rows", i32), ("nll_target", vp), ("nll_partial", vp), ("nll_row_weight", vp),
                 ("nll_scale", C.c_float), ("_pad3", i32), ("images_rows", vp), ("images_rows_dup", i64), ("bwd_r", vp), ("bwd_scale", vp), ("bwd_shift", vp), ("bwd_mean", vp),
-                ("bwd_rstd", vp)]
+                ("bwd_rstd", vp), ("addend", vp), ("addend_frame_div", i32), ("_pad4", i32)]
 
 
 class LossArgs(C.Structure):
