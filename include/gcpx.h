@@ -136,7 +136,10 @@ typedef struct gcpx_conv_args {
 
 /* GCPX_SPLIT_HEAD32: the 100-channel mixture head's weights in 32x32x16 A-fragment order [9 taps][4 tiles][2 pieces][64][8]
    (packing.pack_head32_split / head32_index) for csrc/conv3x3_head32.hip — modes GCPX_HEAD_DLM_MEAN / _NLL / _NLL_GRAD only */
-typedef enum gcpx_split_layout { GCPX_SPLIT_PLAIN = 0, GCPX_SPLIT_ROWFOLD = 1, GCPX_SPLIT_HEAD32 = 2 } gcpx_split_layout;
+/* GCPX_SPLIT_ROWFOLD16: the row-folded weights of a 16 -> 16 channel upsampling block, two horizontal taps per k-step
+   (packing.pack_conv3x3_fold16 / conv3x3_fold16_index over the [24][16][Cin] scratch of gcpx_fold_upsample_weights): the node half / the
+   skip half of additional_conv_layer once the skip half is hoisted (gcpx_conv_args.addend) */
+typedef enum gcpx_split_layout { GCPX_SPLIT_PLAIN = 0, GCPX_SPLIT_ROWFOLD = 1, GCPX_SPLIT_HEAD32 = 2, GCPX_SPLIT_ROWFOLD16 = 3 } gcpx_split_layout;
 
 /* decoder block: (bilinear x2 upsample +) 3x3 conv, pad 1.  gcpx_conv3x3_grid(a) = number of workgroups that launch
    will use = rows of a->stats_partial (a->stats_partial must already be non-NULL in the query if it will be). */

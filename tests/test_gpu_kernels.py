@@ -592,6 +592,73 @@ def test_conv3x3_up32_skip_channels_convolved_once_per_sequence(env, Hin, c_prev
     assert lib.gcpx_conv3x3(C.byref(a2), _stream()) != 0
 
 
+@pytest.mark.parametrize("Hin,Fr,nodes", [(32, 6, 3), (8, 8, 4), (8, 4, 2)])
+def test_conv3x3_fold16_block_with_the_skip_half_hoisted(env, Hin, Fr, nodes):
+    """GCPX_SPLIT_ROWFOLD16 (conv3x3_up16_fold16_kernel): the 16 + 16 -> 16 channel block as two 16-channel row-folded convs — the skip
+    half once per sequence, the node half with that addend — against F.conv2d over the concatenated, upsampled input and against the
+    32-channel row-folded kernel (GCPX_SPLIT_ROWFOLD), output and BatchNorm partial sums"""
+    rt, pk, lib, dev = env
+    torch.manual_seed(Hin + nodes)
+    cp = cs = cout = 16
+    x = torch.randn(Fr, cp, Hin, Hin)
+    sc, sh = torch.rand(cp) + 0.5, torch.randn(cp) * 0.2
+    sk = torch.randn(Fr // nodes, cs, Hin, Hin)
+    ssc, ssh = torch.rand(cs) + 0.5, torch.randn(cs) * 0.2
+    xin = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)
+    skin = F.leaky_relu(sk * ssc[None, :, None, None] + ssh[None, :, None, None], 0.2)
+    w, b = torch.randn(cout, cp + cs, 3, 3) / (9 * 32) ** 0.5, torch.randn(cout) * 0.1
+    want = F.conv2d(F.interpolate(torch.cat([xin, skin.repeat_interleave(nodes, 0)], 1), scale_factor=2, mode="bilinear", align_corners=False),
+                    w, b, padding=1)
+    xd, skd = x.permute(0, 2, 3, 1).contiguous().to(dev), sk.permute(0, 2, 3, 1).contiguous().to(dev)
+    wp, bd = pk.pack_conv3x3(w, 16).to(dev), pk.pad_vec(b, cout).to(dev)
+    H2 = 2 * Hin
+    # the 32-channel row-folded kernel, one launch
+    wf, ef = pk.pack_conv3x3_fold(w)
+    wf = wf.to(dev)
+    out1 = torch.full((Fr, H2, H2, cout), float("nan"), device=dev)
+    a1 = _conv_args(rt, [(xd, cp, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU), (skd, cs, nodes, ssc.to(dev), ssh.to(dev), rt.ACT_LRELU)],
+                    F=Fr, Hin=Hin, Win=Hin, Hout=H2, Wout=H2, Cout=cout, out_pitch=cout, upsample=1, head_mode=rt.HEAD_RAW, wpk=wp, bias=bd,
+                    out=out1, stats_partial=out1)
+    a1.wpk_split, a1.w_split_log2, a1.split_layout = wf.data_ptr(), ef, rt.SPLIT_ROWFOLD
+    G = lib.gcpx_conv3x3_grid(C.byref(a1))
+    st1 = torch.full((G, 2, cout), float("nan"), device=dev)
+    a1.stats_partial = st1.data_ptr()
+    rt.check(lib.gcpx_conv3x3(C.byref(a1), _stream()), "32-channel row-folded block")
+    # the skip half once per sequence, the node half with the addend
+    wa, ea = pk.pack_conv3x3_fold16(w, 0)
+    wb, eb = pk.pack_conv3x3_fold16(w, 16)
+    wa, wb = wa.to(dev), wb.to(dev)
+    add = torch.full((Fr // nodes, H2, H2, cout), float("nan"), device=dev)
+    a_s = _conv_args(rt, [(skd, cs, 1, ssc.to(dev), ssh.to(dev), rt.ACT_LRELU)], F=Fr // nodes, Hin=Hin, Win=Hin, Hout=H2, Wout=H2, Cout=cout,
+                     out_pitch=cout, upsample=1, head_mode=rt.HEAD_RAW, wpk=wp, bias=torch.zeros(cout, device=dev), out=add)
+    a_s.wpk_split, a_s.w_split_log2, a_s.split_layout = wb.data_ptr(), eb, rt.SPLIT_ROWFOLD16
+    rt.check(lib.gcpx_conv3x3(C.byref(a_s), _stream()), "skip half")
+    out2 = torch.full((Fr, H2, H2, cout), float("nan"), device=dev)
+    a2 = _conv_args(rt, [(xd, cp, 1, sc.to(dev), sh.to(dev), rt.ACT_LRELU)], F=Fr, Hin=Hin, Win=Hin, Hout=H2, Wout=H2, Cout=cout,
+                    out_pitch=cout, upsample=1, head_mode=rt.HEAD_RAW, wpk=wp, bias=bd, out=out2, stats_partial=out2)
+    a2.wpk_split, a2.w_split_log2, a2.split_layout = wa.data_ptr(), ea, rt.SPLIT_ROWFOLD16
+    a2.addend, a2.addend_frame_div = add.data_ptr(), nodes
+    assert lib.gcpx_conv3x3_grid(C.byref(a2)) == G
+    st2 = torch.full((G, 2, cout), float("nan"), device=dev)
+    a2.stats_partial = st2.data_ptr()
+    rt.check(lib.gcpx_conv3x3(C.byref(a2), _stream()), "node half + addend")
+    torch.cuda.synchronize()
+    assert_close(out2.permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5, name="16-channel row-folded block, skip hoisted, vs F.conv2d")
+    assert_close(out2, out1, atol=4e-6, rtol=1e-5, name="hoisted vs the 32-channel row-folded launch")
+    assert_close(st2.sum(0), st1.sum(0), atol=2e-2, rtol=1e-4, name="BatchNorm partial sums")
+    # device-side packs (gcpx_fold_upsample_weights + gcpx_split_pack over conv3x3_fold16_index) = the host packs, bit for bit
+    fold = torch.zeros(24 * 16 * 32, device=dev)
+    wdev = w.to(dev).contiguous()
+    rt.check(lib.gcpx_fold_upsample_weights(wdev.data_ptr(), 16, 32, fold.data_ptr(), _stream()), "fold")
+    for cbase, host, eh in ((0, wa, ea), (16, wb, eb)):
+        idx = pk.conv3x3_fold16_index(32, cbase).to(dev)
+        outp = torch.zeros(2 * idx.numel(), dtype=torch.int16, device=dev)
+        lg = torch.zeros(1, dtype=torch.int32, device=dev)
+        rt.check(lib.gcpx_split_pack(fold.data_ptr(), idx.data_ptr(), idx.numel(), outp.data_ptr(), lg.data_ptr(), _stream()), "split_pack")
+        torch.cuda.synchronize()
+        assert int(lg) == eh and torch.equal(outp.view(-1), host.view(-1))
+
+
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("S,Fr", [(32, 3), (64, 2)])
 def test_conv3x3_head_dlm(env, S, Fr, split):

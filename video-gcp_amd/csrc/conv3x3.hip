@@ -22,6 +22,7 @@
 int gcpx_launch_up16_split(const gcpx_conv_args* a, hipStream_t stream, int grid);      // conv3x3_split.hip
 int gcpx_launch_up32_split(const gcpx_conv_args* a, hipStream_t stream, int which, int grid);
 int gcpx_launch_up16_fold(const gcpx_conv_args* a, hipStream_t stream, int grid);
+int gcpx_launch_up16_fold16(const gcpx_conv_args* a, hipStream_t stream, int grid);
 int gcpx_launch_wave_split(const gcpx_conv_args* a, hipStream_t stream, int ct, int depth);
 
 namespace {
@@ -1180,6 +1181,7 @@ int launch_up16(const gcpx_conv_args* a, hipStream_t stream, bool query_only) {
     if (!a->stats_partial && grid * 8 > nitems) grid = (nitems + 7) / 8;
     if (query_only) return grid;
     if (a->wpk_split && a->split_layout == GCPX_SPLIT_ROWFOLD) return gcpx_launch_up16_fold(a, stream, grid);
+    if (a->wpk_split && a->split_layout == GCPX_SPLIT_ROWFOLD16) return gcpx_launch_up16_fold16(a, stream, grid);
     if (a->wpk_split) return gcpx_launch_up16_split(a, stream, grid);
     static int lds_set = 0;
     if (lds > lds_set) {
@@ -1266,7 +1268,8 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
                                         a->head_mode == GCPX_HEAD_DLM_NLL || a->head_mode == GCPX_HEAD_DLM_NLL_GRAD)),
                    "images_rows: split-f16 mixture head with raw_row_map and images only");
     const int W = a->Wout;
-    GCPX_CHECK_ARG(!a->addend || (a->upsample && a->Cout != 16 && a->addend_frame_div > 0), "addend: upsampling blocks with 32 / 64 output channels, addend_frame_div > 0");
+    GCPX_CHECK_ARG(!a->addend || (a->upsample && a->addend_frame_div > 0 && a->wpk_split && (a->Cout != 16 || a->split_layout == GCPX_SPLIT_ROWFOLD16)),
+                   "addend: split-f16 upsampling blocks (32 / 64 output channels, or the 16-channel row-folded block), addend_frame_div > 0");
     if (!a->upsample) {
         GCPX_CHECK_ARG(a->nsrc == 1 && a->src[0].frame_div == 1, "non-upsampling 3x3 conv takes one per-frame source");
         if (a->Cin == 16 && !a->src_row_map && W % 16 == 0 && a->Hout % 4 == 0) {
@@ -1324,7 +1327,8 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
         if (a->Cin % 16 == 0 && CT == 1) GCPX_PLAIN(16, 1);
 #undef GCPX_PLAIN
     } else {
-        GCPX_CHECK_ARG(a->Cin % 32 == 0, "upsampling 3x3 conv expects Cin % 32 == 0");
+        GCPX_CHECK_ARG(a->Cin % 32 == 0 || (a->Cin == 16 && a->wpk_split && a->split_layout == GCPX_SPLIT_ROWFOLD16),
+                       "upsampling 3x3 conv expects Cin % 32 == 0 (16 channels: the row-folded split-f16 block, GCPX_SPLIT_ROWFOLD16)");
         GCPX_CHECK_ARG(a->head_mode == GCPX_HEAD_RAW, "decoder blocks store raw output");
         // 16-output-channel blocks: wave-autonomous kernel; its weights are packed in 16-channel chunks
         // (packing.pack_conv3x3(w, 16)), every other block in 32-channel chunks

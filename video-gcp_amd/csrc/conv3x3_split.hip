@@ -863,6 +863,274 @@ __global__ void __launch_bounds__(512, 2) conv3x3_up16_fold_kernel(const gcpx_co
 }
 
 // -----------------------------------------------------------------------------------------------------------
+// The row-folded block over SIXTEEN input channels (GCPX_SPLIT_ROWFOLD16): additional_conv_layer (16 + 16 -> 16 channels @64x64) after its
+// skip half has been hoisted out (gcpx_conv_args.addend: the skip activations of I_0 are the same for the N nodes of a sequence, so they
+// are convolved once per sequence — by this same kernel over the sequence's frames — and arrive as an addend).  Same scheme as
+// conv3x3_up16_fold_kernel with half the channels per pixel: a 16x16x32 MFMA k-step now holds TWO horizontal taps x 16 channels
+// (lane groups q >> 1 = 0 / 1 read pixel column tx / tx + 1), so the three taps of a row are a pair (tx 0, 1) and a single (tx 2, the
+// other half of its k-step meets zero weights): 12 blocks of R x 3 MFMAs per item instead of 18, half the staging arithmetic.
+// Fragment sets (packing.conv3x3_fold16_gather): [py][dyl][kind] (12), then the border corrections [top / bottom][kind] (4).
+// -----------------------------------------------------------------------------------------------------------
+struct Fold16Cfg {
+    static constexpr int R = 4;
+    static constexpr int PR = R + 2, PW = 10, RW = 18, CC = 16;
+    static constexpr int RAW_BYTES = PR * PW * CC * 4;             // 3840: f32 patch, aliases the start of the planes
+    static constexpr int PLANE_BYTES = PR * RW * 32;               // 3456: one f16 piece, 16 channels x 2 B per pixel
+    static constexpr int WAVE_BYTES = 2 * PLANE_BYTES;             // 6912
+    static constexpr int NT = 16;
+    static constexpr int W_BYTES = NT * 2048;                      // 32768
+    static constexpr int LDS_BYTES = W_BYTES + 8 * WAVE_BYTES + 8 * 2 * 16 * 4;
+    static constexpr int NS = (PR * PW * 4 + 63) / 64;             // raw float4 slots per lane (4)
+    static constexpr int NO = (PR * RW * 4 + 63) / 64;             // region float4 outputs per lane (7)
+};
+
+__global__ void __launch_bounds__(512, 2) conv3x3_up16_fold16_kernel(const gcpx_conv_args a, const int items_per_wave, const int nitems) {
+    using Cfg = Fold16Cfg;
+    constexpr int R = Cfg::R, PR = Cfg::PR, PW = Cfg::PW, RW = Cfg::RW, NS = Cfg::NS, NO = Cfg::NO;
+    extern __shared__ float4 smem4[];
+    const char* wl = reinterpret_cast<const char*>(smem4);                           // [16][2][64] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* wbuf = reinterpret_cast<char*>(smem4) + Cfg::W_BYTES + wave * Cfg::WAVE_BYTES;
+    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(smem4) + Cfg::W_BYTES + 8 * Cfg::WAVE_BYTES);
+    const int j = lane & 15, q = lane >> 4;
+    const int H = a.Hout, W = a.Wout, Hin = a.Hin, Win = a.Win;
+    const int ncb = W / 16, nrb = Hin / R;
+
+    for (int i = tid; i < Cfg::W_BYTES / 16; i += 512) smem4[i] = reinterpret_cast<const float4*>(a.wpk_split)[i];
+    __syncthreads();
+
+    // a lane stages the same channel quad in every slot
+    const int c4 = lane & 3, ps = lane >> 2;                          // channel quad, pixel inside a step of 16
+    const float* sptr = a.src[0].ptr;
+    const int srcC = a.src[0].C;
+    float4 bn_s = make_float4(1.f, 1.f, 1.f, 1.f), bn_t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.src[0].scale) {
+        bn_s = *reinterpret_cast<const float4*>(a.src[0].scale + c4 * 4);
+        bn_t = *reinterpret_cast<const float4*>(a.src[0].shift + c4 * 4);
+    }
+    const float slope = a.src[0].act == GCPX_ACT_LRELU ? 0.2f : 1.f;
+    const int fdiv0 = a.src[0].frame_div;
+    const int ew = a.w_split_log2_dev ? __builtin_amdgcn_readfirstlane(*a.w_split_log2_dev) : a.w_split_log2;
+    const float4 bv = *reinterpret_cast<const float4*>(a.bias + q * 4);
+
+    const int gw = blockIdx.x * 8 + wave;
+    int item = gw * items_per_wave;
+    const int item_end = min(item + items_per_wave, nitems);
+    auto origin = [&](int it, int& f, int& y0, int& x0) {           // y0: first low-resolution row, x0: first output column
+        const int rb = it % nrb;
+        const int t = it / nrb;
+        y0 = rb * R; f = t / ncb; x0 = (t % ncb) * 16;
+    };
+    // slot maps (lane constants): patch slot k = pixel ps + 16 k of the 6 x 10 patch, region slot k = pixel ps + 16 k of the 6 x 18 region
+    int p_row[NS], p_col[NS], p_lds[NS];
+    bool p_ok[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int pix = ps + 16 * k;
+        p_ok[k] = pix < PR * PW;
+        p_row[k] = min(pix, PR * PW - 1) / PW;
+        p_col[k] = min(pix, PR * PW - 1) % PW;
+        p_lds[k] = (p_row[k] * PW + p_col[k]) * 64 + c4 * 16;
+    }
+    int r_rd[NO], r_wr[NO];
+    float r_wa[NO];
+    bool r_ok[NO], r_c0[NO], r_c17[NO];
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+        const int pix = ps + 16 * k;
+        r_ok[k] = pix < PR * RW;
+        const int r = min(pix, PR * RW - 1) / RW, c = min(pix, PR * RW - 1) % RW;
+        r_rd[k] = (r * PW + (c >> 1)) * 64 + c4 * 16;                 // patch columns c / 2 and c / 2 + 1
+        r_wr[k] = (r * RW + c) * 32 + c4 * 8;
+        r_wa[k] = (c & 1) ? 0.25f : 0.75f;
+        r_c0[k] = c == 0; r_c17[k] = c == RW - 1;
+    }
+    float4 pre[NS];
+    auto issue_loads = [&](int it) {
+        int f, y0, x0;
+        origin(it, f, y0, x0);
+        const float* base = sptr + (size_t)(f / fdiv0) * Hin * Win * srcC + c4 * 4;
+        const int ly0 = y0 - 1, lx0 = x0 / 2 - 1;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int sy = min(max(ly0 + p_row[k], 0), Hin - 1), sx = min(max(lx0 + p_col[k], 0), Win - 1);      // replicate clamp (bilinear border rule)
+            pre[k] = *reinterpret_cast<const float4*>(base + (unsigned)((sy * Win + sx) * srcC));
+        }
+    };
+
+    f32x4 st1 = f32x4{0, 0, 0, 0}, st2 = f32x4{0, 0, 0, 0};
+    f32x4 outv[R][2];
+    float* optr = nullptr;
+    auto store_out = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int yi = 0; yi < R; ++yi)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const f32x4 v = outv[yi][py];
+                *reinterpret_cast<float4*>(optr + (unsigned)((2 * yi + py) * W * 16)) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    };
+    if (item < item_end) issue_loads(item);
+
+    // B fragment of (kind, region row): kind 0 = taps tx 0 | 1 (lane groups q >> 1), kind 1 = tap tx 2 (the other half re-reads it: finite, zero weights)
+    const int boff0 = (j + (q >> 1)) * 32 + (q & 1) * 16, boff1 = (j + 2) * 32 + (q & 1) * 16;
+
+    for (; item < item_end; ++item) {
+        int f, y0, x0;
+        origin(item, f, y0, x0);
+        const bool top = (y0 == 0), bot = (y0 + R == Hin), lft = (x0 == 0), rgt = (x0 + 16 == W);
+
+        // ---- registers -> raw patch (BatchNorm affine + LeakyReLU of the producer), the item's largest magnitude ----
+        float amax = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            float4 v = pre[k];
+            v.x = fmaf(v.x, bn_s.x, bn_t.x); v.y = fmaf(v.y, bn_s.y, bn_t.y); v.z = fmaf(v.z, bn_s.z, bn_t.z); v.w = fmaf(v.w, bn_s.w, bn_t.w);
+            v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope); v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+            if (p_ok[k]) *reinterpret_cast<float4*>(wbuf + p_lds[k]) = v;
+            else v = make_float4(0.f, 0.f, 0.f, 0.f);
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        // the next item's patch: requested as soon as this one's registers are free (16 registers: no spill), AHEAD of the previous
+        // item's stores — with 144 MFMAs an item is too short to cover an HBM round trip from behind the interpolation (PMC: 56 % of the
+        // wave cycles parked in s_waitcnt), and the in-order memory counter then never waits for a store on the way to these loads
+        if (item + 1 < item_end) issue_loads(item + 1);
+        if (optr) store_out();
+        amax = wave_max_nonneg(amax);
+        int ex = 14 + 127 - (int)((__float_as_uint(amax) >> 23) & 0xff);            // amax 2^ex in [2^14, 2^15)
+        ex = __builtin_amdgcn_readfirstlane(amax > 0.f ? max(-100, min(min(100, 126 - ew), ex)) : min(100, 126 - ew));
+        const float sx2 = __uint_as_float((unsigned)(127 + ex) << 23);
+
+        // ---- horizontal half of the bilinear x2: patch (6 x 10) -> region (6 x 18) as two f16 planes (they overwrite the patch: every
+        //      value is formed first, the wavefront's LDS operations execute in order) ----
+        h4 o1[NO], o2[NO];
+#pragma unroll
+        for (int k = 0; k < NO; ++k) {
+            const float4 A = *reinterpret_cast<const float4*>(wbuf + r_rd[k]);
+            const float4 B = *reinterpret_cast<const float4*>(wbuf + r_rd[k] + 64);
+            const float sc = ((lft && r_c0[k]) || (rgt && r_c17[k])) ? 0.f : sx2;    // region column 0 / 17: the conv's zero padding in x
+            const float wa = r_wa[k] * sc, wb = (1.f - r_wa[k]) * sc;
+            float4 v;
+            v.x = fmaf(wa, A.x, wb * B.x); v.y = fmaf(wa, A.y, wb * B.y); v.z = fmaf(wa, A.z, wb * B.z); v.w = fmaf(wa, A.w, wb * B.w);
+            h4 p1, p2;
+            p1[0] = (_Float16)v.x; p1[1] = (_Float16)v.y; p1[2] = (_Float16)v.z; p1[3] = (_Float16)v.w;
+            p2[0] = (_Float16)fmaf((float)p1[0], -1.f, v.x); p2[1] = (_Float16)fmaf((float)p1[1], -1.f, v.y);
+            p2[2] = (_Float16)fmaf((float)p1[2], -1.f, v.z); p2[3] = (_Float16)fmaf((float)p1[3], -1.f, v.w);
+            o1[k] = p1;
+            o2[k] = p2;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < NO; ++k) {
+            if (r_ok[k]) {
+                *reinterpret_cast<h4*>(wbuf + r_wr[k]) = o1[k];
+                *reinterpret_cast<h4*>(wbuf + r_wr[k] + Cfg::PLANE_BYTES) = o2[k];
+            }
+        }
+
+        // ---- MFMAs: 12 blocks (kind, row tap, parity) of R x 3; the weight pieces of the next block and the row fragments of the next
+        //      kind are read while a block computes ----
+        f32x4 acc[R][2];
+#pragma unroll
+        for (int yi = 0; yi < R; ++yi) { acc[yi][0] = f32x4{0, 0, 0, 0}; acc[yi][1] = f32x4{0, 0, 0, 0}; }
+        auto load_w = [&](const int t, h8 (&w)[2]) __attribute__((always_inline)) {
+            const char* wp = wl + t * 2048 + lane * 16;
+            w[0] = *reinterpret_cast<const h8*>(wp);
+            w[1] = *reinterpret_cast<const h8*>(wp + 1024);
+        };
+        auto load_b = [&](const int kind, const int r, h8 (&b)[2]) __attribute__((always_inline)) {
+            const char* bp = wbuf + r * RW * 32 + (kind ? boff1 : boff0);
+            b[0] = *reinterpret_cast<const h8*>(bp);
+            b[1] = *reinterpret_cast<const h8*>(bp + Cfg::PLANE_BYTES);
+        };
+        h8 wq[2][2], bq[2][PR][2], wt[2], wb[2];
+        load_w(0, wq[0]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) load_b(0, r, bq[0][r]);
+        __builtin_amdgcn_s_setprio(1);
+        static_for<0, 12>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value, kind = t / 6, blk = t % 6, dyl = blk / 2, py = blk % 2;
+            constexpr bool more = t + 1 < 12;
+            constexpr bool pre_next = blk >= 2 && kind + 1 < 2;                  // rows 0..3 of the next kind
+            constexpr bool pre_own = blk < 2;                                    // rows 4, 5 of this kind
+            constexpr bool pre_c = blk == 4;                                     // correction weights of this kind
+            if constexpr (more) {
+                constexpr int t1 = t + 1, kind1 = t1 / 6, blk1 = t1 % 6;
+                load_w((blk1 % 2) * 6 + (blk1 / 2) * 2 + kind1, wq[t1 & 1]);
+            }
+            if constexpr (pre_next) load_b(kind + 1, blk - 2, bq[(kind + 1) & 1][blk - 2]);
+            if constexpr (pre_own) load_b(kind, 4 + blk, bq[kind & 1][4 + blk]);
+            if constexpr (pre_c) { load_w(12 + kind, wt); load_w(14 + kind, wb); }
+            const h8 w1 = wq[t & 1][0], w2 = wq[t & 1][1];
+            // small terms first: they are added to the accumulator while it is still small
+#pragma unroll
+            for (int yi = 0; yi < R; ++yi) acc[yi][py] = mfma32h(w2, bq[kind & 1][yi + dyl][0], acc[yi][py]);
+#pragma unroll
+            for (int yi = 0; yi < R; ++yi) acc[yi][py] = mfma32h(w1, bq[kind & 1][yi + dyl][1], acc[yi][py]);
+#pragma unroll
+            for (int yi = 0; yi < R; ++yi) acc[yi][py] = mfma32h(w1, bq[kind & 1][yi + dyl][0], acc[yi][py]);
+            __builtin_amdgcn_sched_group_barrier(0x100, (more ? 2 : 0) + ((pre_next || pre_own) ? 2 : 0) + (pre_c ? 4 : 0), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            if constexpr (blk == 5) {
+                if (top) {                                           // output row 0: the tap row above the image is zero, not row 0 again
+                    acc[0][0] = mfma32h(wt[1], bq[kind & 1][0][0], acc[0][0]);
+                    acc[0][0] = mfma32h(wt[0], bq[kind & 1][0][1], acc[0][0]);
+                    acc[0][0] = mfma32h(wt[0], bq[kind & 1][0][0], acc[0][0]);
+                }
+                if (bot) {                                           // output row H - 1 likewise
+                    acc[R - 1][1] = mfma32h(wb[1], bq[kind & 1][PR - 1][0], acc[R - 1][1]);
+                    acc[R - 1][1] = mfma32h(wb[0], bq[kind & 1][PR - 1][1], acc[R - 1][1]);
+                    acc[R - 1][1] = mfma32h(wb[0], bq[kind & 1][PR - 1][0], acc[R - 1][1]);
+                }
+            }
+        });
+        __builtin_amdgcn_s_setprio(0);
+
+        // ---- epilogue: scale back (exact), bias, the sequence's addend, BatchNorm partial sums; the raw NHWC store follows the next
+        //      item's staging ----
+        const float inv = __uint_as_float((unsigned)(127 - ex - ew) << 23);
+        optr = a.out + (((size_t)f * H + 2 * y0) * W + x0 + j) * 16 + q * 4;
+        const float* adp = a.addend ? a.addend + (((size_t)(f / a.addend_frame_div) * H + 2 * y0) * W + x0 + j) * 16 + q * 4 : nullptr;
+#pragma unroll
+        for (int yi = 0; yi < R; ++yi)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                f32x4 v = acc[yi][py];
+                v[0] = fmaf(v[0], inv, bv.x); v[1] = fmaf(v[1], inv, bv.y); v[2] = fmaf(v[2], inv, bv.z); v[3] = fmaf(v[3], inv, bv.w);
+                if (adp) {
+                    const float4 ad = *reinterpret_cast<const float4*>(adp + (unsigned)((2 * yi + py) * W * 16));
+                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+                }
+                outv[yi][py] = v;
+                st1 += v;
+                st2 += v * v;
+            }
+    }
+    if (optr) store_out();
+    if (a.stats_partial) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s1 = row16_sum(st1[r]);
+            const float s2 = row16_sum(st2[r]);
+            if (j == 0) {
+                red[(wave * 2 + 0) * 16 + q * 4 + r] = s1;
+                red[(wave * 2 + 1) * 16 + q * 4 + r] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int which = tid >> 4, c = tid & 15;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += red[(w * 2 + which) * 16 + c];
+            a.stats_partial[((size_t)blockIdx.x * 2 + which) * 16 + c] = sum;
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------------
 // Plain 3x3 conv at full resolution with several 16-channel input chunks in split-f16: the data gradients of the output head
 // (112 -> 16) and of the 16-channel decoder blocks (16 -> 32).  Control flow of conv3x3_wave_kernel (conv3x3.hip): items dealt
 // round-robin over the grid's wavefronts, buffer loads with hardware bounds-check zeros, a prefetch cursor DEPTH (item, chunk) steps
@@ -1270,6 +1538,29 @@ int gcpx_launch_up16_fold(const gcpx_conv_args* a, hipStream_t stream, int grid)
                 gcpx_set_error("conv3x3 row-folded up16: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
                 return GCPX_ERR_HIP;
             }
+        }
+        attr_set = true;
+    }
+    const int nitems = a->F * (a->Hin / Cfg::R) * (a->Wout / 16);
+    const int ipw = (nitems + grid * 8 - 1) / (grid * 8);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, stream, *a, ipw, nitems);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+// 16 -> 16 channel row-folded block (GCPX_SPLIT_ROWFOLD16: packing.pack_conv3x3_fold16); grid as launch_up16
+int gcpx_launch_up16_fold16(const gcpx_conv_args* a, hipStream_t stream, int grid) {
+    using Cfg = Fold16Cfg;
+    GCPX_CHECK_ARG(a->Cin == 16 && a->Cout == 16 && a->nsrc == 1 && a->src[0].C == 16 && a->Hin % Cfg::R == 0 && a->Hout == 2 * a->Hin &&
+                   a->Wout == 2 * a->Win && a->Wout % 16 == 0,
+                   "row-folded 16-channel block: one 16-channel source, 16 output channels, Hin a multiple of 4, output width a multiple of 16");
+    auto kern = conv3x3_up16_fold16_kernel;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) {
+            gcpx_set_error("conv3x3 row-folded up16 (16 channels): hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
+            return GCPX_ERR_HIP;
         }
         attr_set = true;
     }

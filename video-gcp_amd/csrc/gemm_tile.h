@@ -39,6 +39,29 @@ __device__ __forceinline__ void gemm_tile(const gcpx_gemm_args& a, const int bx,
         for (int pt = 0; pt < PR; ++pt) acc[ct][pt] = f32x4{0, 0, 0, 0};
 
     const int zb = bz;
+    // What the epilogue reads — bias, and the LSTM's previous cell state — is requested NOW: a few-row launch is one latency chain
+    // (arguments -> operands -> dependent MFMAs -> combine -> epilogue, profiles/r06_gemm_rows_pmc.txt) and these two loads sat at its end
+    // as a round trip of their own.  (Split K: only the wavefront that runs the epilogue needs them.)
+    float4 bias_pre[CR];
+    float cprev_pre[CR][PR];
+#pragma unroll
+    for (int ct = 0; ct < CR; ++ct) {
+        bias_pre[ct] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int pt = 0; pt < PR; ++pt) cprev_pre[ct][pt] = 0.f;
+    }
+    if (!KS || wave == 0) {
+#pragma unroll
+        for (int ct = 0; ct < CR; ++ct) {
+            const int n = (nt0 + ct) * 16 + q * 4;
+            if (a.bias) bias_pre[ct] = *reinterpret_cast<const float4*>(a.bias + (size_t)zb * a.z_bias_off + n);
+            if constexpr (LSTM) {
+#pragma unroll
+                for (int pt = 0; pt < PR; ++pt)
+                    if (rv[pt]) cprev_pre[ct][pt] = a.c_prev[(size_t)rr[pt] * a.c_prev_stride + (nt0 + ct) * 4 + q];
+            }
+        }
+    }
     const float4* wbase = reinterpret_cast<const float4*>(a.wpk + (size_t)zb * a.z_w_off) + (size_t)nt0 * 64 + lane;
     int kg0 = 0;
     for (int s = 0; s < a.nsrc; ++s) {
@@ -163,8 +186,7 @@ __device__ __forceinline__ void gemm_tile(const gcpx_gemm_args& a, const int bx,
 #pragma unroll
     for (int ct = 0; ct < CR; ++ct) {
         const int n = (nt0 + ct) * 16 + q * 4;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + (size_t)zb * a.z_bias_off + n);
+        const float4 bv = bias_pre[ct];
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int pt = 0; pt < PR; ++pt) {
@@ -173,7 +195,7 @@ __device__ __forceinline__ void gemm_tile(const gcpx_gemm_args& a, const int bx,
             if constexpr (LSTM) {
                 if (rv[pt]) {
                     const int u = (nt0 + ct) * 4 + q;    // hidden unit of this lane; regs = gates i, f, g, o
-                    const float cp = a.c_prev[(size_t)rr[pt] * a.c_prev_stride + u];
+                    const float cp = cprev_pre[ct][pt];
                     const float ig = sigmoidf_(v[0]), fg = sigmoidf_(v[1]), gg = tanhf(v[2]), og = sigmoidf_(v[3]);
                     const float c = fg * cp + ig * gg;
                     const float h = og * tanhf(c);

@@ -137,8 +137,24 @@ class ForwardPlanMixin:
             hoist = (skip_idx >= 0 and rpb > 1 and F % rpb == 0 and self.split_f16 and cout in (32, 64) and c_prev % 32 == 0 and
                      c_skip % 32 == 0 and f"dec.{name}" in self.pk_split and "fold" not in self.pk_split[f"dec.{name}"] and
                      os.environ.get("GCPX_NO_SKIP_HOIST") is None)
+            # ... and the 16 + 16 -> 16 channel block (additional_conv_layer) through the 16-channel row-folded packs
+            # (opt-in, GCPX_SKIP_HOIST16=1: measured SLOWER than the one-launch 32-channel row-folded kernel, 282 against 234 us at c2 — with
+            # 144 MFMAs per item the wavefront's latency chain (patch loads -> LDS -> interpolation -> LDS -> fragments, the addend's loads
+            # in the epilogue) is no longer covered: 57 % of the wave cycles parked in s_waitcnt, profiles/r06_skip_hoist.txt)
+            hoist16 = (skip_idx >= 0 and rpb > 1 and F % rpb == 0 and self.split_f16 and cout == 16 and c_prev == 16 and c_skip == 16 and
+                       f"dec.{name}.f16a" in self.pk_split and res % 4 == 0 and os.environ.get("GCPX_SKIP_HOIST16") == "1")
             addend = None
-            if hoist:
+            if hoist16:
+                addend = self._buf(f"dec.{name}.skip", (F // rpb, 2 * res, 2 * res, cout))
+                t, C_, ssc, ssh, sact = skips[skip_idx]
+                zb = self._buf(f"dec.{name}.zero_bias", (cpad,), zero=True)
+                a_s = self._conv_args([(t.data_ptr(), C_, 1, ssc, ssh, sact)], F // rpb, res, res, 2 * res, 2 * res, cout, cout,
+                                      P[f"dec.{name}.w"], zb, addend, upsample=1)
+                self._set_split(a_s, f"dec.{name}.f16b")
+                plan.keep.append(a_s)
+                plan.add(f"dec.{name}.skip", lib.gcpx_conv3x3, C.byref(a_s))
+                srcs_main = [prev]
+            elif hoist:
                 addend = self._buf(f"dec.{name}.skip", (F // rpb, 2 * res, 2 * res, cout))
                 t, C_, ssc, ssh, sact = skips[skip_idx]
                 zb = self._buf(f"dec.{name}.zero_bias", (cpad,), zero=True)
@@ -148,20 +164,22 @@ class ForwardPlanMixin:
                 # the skip channels' k-steps follow the previous block's in the pack: [chunk][tap][CT][2][64] x 16 B, 32 channels per chunk
                 a_s.wpk_split = a_s.wpk_split + (c_prev // 32) * 9 * (cpad // 16) * 2048
                 plan.keep.append(a_s)
+                # (16 frames: a latency-bound 18 us launch, in line.  On lane 1 beside the previous block it measured SLOWER — 2.62-2.66 ms
+                # against 2.60-2.61 in line, three rounds: a fork / join pair in the middle of the decoder chain costs more than it hides)
                 plan.add(f"dec.{name}.skip", lib.gcpx_conv3x3, C.byref(a_s))
                 srcs_main = [prev]
             else:
                 srcs_main = srcs
             a = self._conv_args(srcs_main, F, res, res, 2 * res, 2 * res, cout, cout, P[f"dec.{name}.w"], P[f"dec.{name}.b"],
                                 o, upsample=1, stats=(o if self.training else None))     # placeholder pointer for the query
-            if hoist:
+            if hoist or hoist16:
                 a.addend, a.addend_frame_div = addend.data_ptr(), rpb
+            self._set_split(a, f"dec.{name}.f16a" if hoist16 else f"dec.{name}")
             Gl = lib.gcpx_conv3x3_grid(C.byref(a))
             assert Gl > 0, rt.lib().gcpx_last_error()
             st = self._buf(f"dec.st.{name}", (Gl, 2, cpad)) if self.training else None
             a.stats_partial = st.data_ptr() if st is not None else None
             plan.keep.append(a)
-            self._set_split(a, f"dec.{name}")
             plan.add(f"dec.{name}", lib.gcpx_conv3x3, C.byref(a))
             plan.rec["dec"]["blocks"].append(dict(name=name, srcs=srcs, out=o, res_in=res, cout=cout, c_prev=c_prev, c_skip=c_skip,
                                                   skip_idx=skip_idx))

@@ -411,6 +411,40 @@ def conv3x3_fold_index():
     return conv3x3_fold_gather(ids).reshape(-1).to(torch.int32)
 
 
+def conv3x3_fold16_gather(fw, cbase=0):
+    """fw [24, 16, Cin] (fold_up_weights, any dtype), 16 of its input channels from `cbase` -> [16][64][8] for conv3x3_up16_fold16_kernel
+    (GCPX_SPLIT_ROWFOLD16): a k-step holds two horizontal taps x 16 channels.  Fragment py 6 + dyl 2 + kind (12 of them), then the border
+    corrections 12 + kind (rows above the image) and 14 + kind (below): lane (i = lane & 15, q = lane >> 4) element el =
+    fw[set][i][cbase + 8 (q & 1) + el] with set = base + (q >> 1) for kind 0 (taps tx 0 | 1) and base + 2 for kind 1 (tap tx 2; lane
+    groups q >> 1 = 1 hold zeros), base = py 9 + dyl 3, 18 or 21."""
+    assert fw.shape[0] == 24 and fw.shape[1] == 16 and fw.shape[2] >= cbase + 16
+    dev = fw.device
+    bases = [py * 9 + dyl * 3 for py in range(2) for dyl in range(3)] + [18, 21]
+    fz = torch.cat([fw, torch.zeros((1,) + tuple(fw.shape[1:]), dtype=fw.dtype, device=dev)], 0)      # set 24 = zeros
+    li, lq = _LI.to(dev)[:, None], _LQ.to(dev)[:, None]
+    el = torch.arange(8, device=dev)[None, :]
+    frags = []
+    for b in bases:
+        for kind in range(2):
+            tset = (b + lq // 2) if kind == 0 else torch.where(lq // 2 == 0, torch.full_like(lq, b + 2), torch.full_like(lq, 24))
+            frags.append(fz[tset, li, cbase + 8 * (lq % 2) + el])
+    # order: [py][dyl][kind] x 12, then [top, bottom][kind]
+    return torch.stack(frags, 0).contiguous()
+
+
+def pack_conv3x3_fold16(w, cbase=0):
+    """w [16, Cin, 3, 3] -> (int16 [16][2][64][8], e): the two f16 pieces of the row-folded weights of input channels cbase .. cbase + 15
+    in the two-taps-per-k-step order of conv3x3_fold16_gather"""
+    w1, w2, e = split_f16(conv3x3_fold16_gather(fold_up_weights(w), cbase))
+    return torch.stack([w1, w2], 1).contiguous().view(torch.int16), e
+
+
+def conv3x3_fold16_index(cin, cbase):
+    """int32 [16 * 512]: index into the flat [24, 16, cin] folded-weight scratch of every element of conv3x3_fold16_gather (-1 = zero)"""
+    ids = (torch.arange(24 * 16 * cin, dtype=torch.float64) + 1).view(24, 16, cin)
+    return (conv3x3_fold16_gather(ids, cbase).reshape(-1) - 1).to(torch.int32)
+
+
 def lstm_gate_interleave(w_ih, w_hh, b_ih, b_hh):
     """[4H, H] x2 (torch gate order i, f, g, o) -> W [4H, 2H] with row n = 4u + gate, bias [4H] likewise."""
     H = w_hh.shape[1]                                       # (w_ih may be wider than H: embedding folded into layer 0)

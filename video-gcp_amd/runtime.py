@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgcpx.so")
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 HEAD_RAW, HEAD_DLM_MEAN, HEAD_DLM_BOTH, HEAD_TANH_NCHW, HEAD_DLM_NLL, HEAD_DLM_NLL_GRAD = 0, 1, 2, 3, 4, 5
-SPLIT_PLAIN, SPLIT_ROWFOLD, SPLIT_HEAD32 = 0, 1, 2
+SPLIT_PLAIN, SPLIT_ROWFOLD, SPLIT_HEAD32, SPLIT_ROWFOLD16 = 0, 1, 2, 3
 EPI_NONE, EPI_LRELU, EPI_LSTM, EPI_GAUSS_SAMPLE = 0, 1, 2, 3
 MLP_PLAIN, MLP_GAUSS, MLP_TANH = 0, 1, 2
 

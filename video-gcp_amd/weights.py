@@ -111,6 +111,15 @@ class WeightsMixin:
             d.update(idx=idx, out=torch.zeros(2 * idx.numel(), dtype=torch.int16, device=self.device),
                      log2=torch.zeros(1, dtype=torch.int32, device=self.device))
             self.pk_split[name] = d
+            if perm == "rowfold" and shp[1] == 32:
+                # the same folded weights as two 16-channel packs (two horizontal taps per k-step, GCPX_SPLIT_ROWFOLD16): the node half
+                # and the skip half of a block whose skip channels are convolved once per sequence (forward_plan: gcpx_conv_args.addend).
+                # They gather from the block's fold scratch (folded once, above)
+                for tag, cbase in (("f16a", 0), ("f16b", 16)):
+                    i16 = pk.conv3x3_fold16_index(shp[1], cbase).to(self.device)
+                    self.pk_split[f"{name}.{tag}"] = dict(fold=d["fold"], fold16=True, idx=i16,
+                                                          out=torch.zeros(2 * i16.numel(), dtype=torch.int16, device=self.device),
+                                                          log2=torch.zeros(1, dtype=torch.int32, device=self.device))
         self.repack_split()
 
     def repack_split(self, stream=None):
@@ -132,7 +141,7 @@ class WeightsMixin:
             dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             tab = self._split_tab = (dev, len(descs), key, torch.zeros(len(descs), dtype=torch.int32, device=self.device))
         for name, d in self.pk_split.items():
-            if "fold" in d:
+            if "fold_src" in d:
                 off, cout, cin = d["fold_src"]
                 rt.check(self.lib.gcpx_fold_upsample_weights(self.theta.data_ptr() + 4 * off, cout, cin, d["fold"].data_ptr(), st), "fold_upsample_weights")
         rt.check(self.lib.gcpx_split_pack_group2(tab[0].data_ptr(), tab[1], tab[3].data_ptr(), st), "split_pack_group2")
@@ -173,7 +182,9 @@ class WeightsMixin:
             d, layout = self.pk_split["dec.head32"], rt.SPLIT_HEAD32
         if self.split_f16 and d is not None:
             a.wpk_split, a.w_split_log2_dev = d["out"].data_ptr(), d["log2"].data_ptr()
-            a.split_layout = layout if layout is not None else (rt.SPLIT_ROWFOLD if "fold" in d else rt.SPLIT_PLAIN)
+            if layout is None:
+                layout = rt.SPLIT_ROWFOLD16 if d.get("fold16") else (rt.SPLIT_ROWFOLD if "fold" in d else rt.SPLIT_PLAIN)
+            a.split_layout = layout
 
     def _pack_fused_embed(self):
         """Inference only: the input embedding Linear and LSTM layer 0's input projection are two Linears with nothing in between
