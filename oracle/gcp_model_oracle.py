@@ -177,7 +177,10 @@ def decode_seq(sd, hp, inputs, enc, training):
 
 
 def seq_encoder(sd, hp, enc_seq, training, prefix="inf_encoder"):
-    """ConvSeqEncodingModule (base_gcp.py:133-134): [B,T,C] -> conv1d stack over time -> [B,T,C]."""
+    """build_temporal_inf_encoder (base_gcp.py:130-138): seq_enc 'none' -> Identity; 'conv' -> ConvSeqEncodingModule, [B,T,C] -> conv1d
+    stack over time -> [B,T,C].  ('lstm' / 'bi-lstm' are blox modules: not built.)"""
+    if hp.seq_enc == "none":
+        return enc_seq
     x = enc_seq.transpose(1, 2)
     pad = hp.conv_inf_enc_kernel_size // 2
     q = f"{prefix}.net"

@@ -107,6 +107,12 @@ def test_adaptive_base_config_and_errors(tmp_path):
     (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'tree_lstm': 'gru'}\n")
     with pytest.raises(ValueError):
         CL.load_conf(str(tmp_path))
+    # seq_enc (base_gcp.py:130-138): 'conv' and 'none' (Identity) load; the parameter table of 'none' has no temporal encoder
+    (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'seq_enc': 'none'}\n")
+    hp, _, _ = CL.load_conf(str(tmp_path))
+    assert hp.seq_enc == "none"
+    from video_gcp_amd.params import param_table
+    assert not any(k.startswith("inf_encoder.") for k in param_table(hp)) and any(k.startswith("inf_encoder.") for k in param_table(CL.load_conf(None, default="c1")[0]))
     (tmp_path / "conf.py").write_text("x = 1\n")
     with pytest.raises(ValueError):
         CL.load_conf(str(tmp_path))

@@ -423,3 +423,24 @@ def test_kl_weight_burn_in_follows_the_step_counter():
         assert abs(float(out.raw["losses"][5]) - float(total)) <= 2e-5 * abs(float(total)), (steps, float(out.raw["losses"][5]), float(total))
         assert abs(float(model.loss(dev_in, out)["kl"].weight) - w * hp.kl_weight) < 1e-12
         _compare_grads(gref, tr.named_grads(), rtol=2e-3)
+
+
+@pytest.mark.parametrize("cfg", ["c1", "c5s"])
+def test_seq_enc_none_forward_and_gradients(cfg):
+    """seq_enc = 'none' (base_gcp.py:131-132: build_temporal_inf_encoder returns Identity — the posterior gathers / attends over the
+    encoded frames themselves, and so does the attention-key encoder's temporal part): no inf_encoder parameters, the forward against
+    the oracle and every parameter gradient against autograd over it"""
+    from oracle import gcp_model_oracle as O
+    import video_gcp_amd as V
+    hp, sd, model, tr = _setup(cfg, False, seq_enc="none")
+    assert not any(k.startswith("inf_encoder.") or k.startswith("inf_key_encoder.0.") for k in sd)
+    inputs, noise, _ = make_inputs(hp, seed=11, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    out = tr.backward(dev_in, noise.cuda())
+    torch.cuda.synchronize()
+    gref, res, total, ref = O.gradients(sd, hp, inputs, noise)
+    assert abs(float(out.raw["losses"][5]) - float(total)) <= (1e-4 if cfg == "c5s" else 2e-5) * abs(float(total))
+    _compare_grads(gref, tr.named_grads(), rtol=5e-3)
+    from video_gcp_amd.model import GCPTreeModel
+    with pytest.raises(ValueError):                                  # 'lstm' / 'bi-lstm' are blox modules: refused, not approximated
+        GCPTreeModel(V.config("c1", seq_enc="lstm"), device="cuda")

@@ -191,6 +191,8 @@ class BackwardStagesMixin:
     def _seq_backward(self, plan, fplan, d_inf, B, tag="seq", prefix="inf_encoder.net"):
         """backward of one ConvSeqEncodingModule (`tag` = "seq": inf_encoder, "kseq": the attention-key encoder)"""
         m, hp, lib = self.m, self.m._hp, self.m.lib
+        if hp.seq_enc == "none":                 # Identity (base_gcp.py:131-132): the gradient is the encoded frames' as it is
+            return d_inf
         rec, o = fplan.rec, fplan.outs
         T, nz, nm = hp.max_seq_len, hp.nz_enc, hp.nz_mid
         buf = m._buf

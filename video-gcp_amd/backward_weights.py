@@ -155,7 +155,7 @@ class BackwardWeightsMixin:
         wk = torch.zeros((len(perm),) + tuple(hw.shape[1:]), dtype=hw.dtype, device=hw.device)
         wk[perm >= 0] = hw[perm[perm >= 0]]
         X["dec.head.wT"] = pk.pack_conv3x3(wk.flip(2, 3).transpose(0, 1).contiguous(), 16)
-        for nm in ["input"] + [f"pyramid-{i}" for i in range(hp.conv_inf_enc_layers)] + ["head"]:
+        for nm in (["input"] + [f"pyramid-{i}" for i in range(hp.conv_inf_enc_layers)] + ["head"]) if hp.seq_enc == "conv" else []:
             w = sd[f"inf_encoder.net.{nm}.conv.weight"]                     # [co, ci, 3] -> [n = ci][k = (tap, co)]
             X[f"seq.{nm}.wT"] = pk.pack_gemm(w.permute(1, 2, 0).reshape(w.shape[1], -1))
         if hp.regress_length:
@@ -171,7 +171,7 @@ class BackwardWeightsMixin:
         else:
             X["existence"] = self._pack_predictor_T(sd, "tree_module.tree_modules.0.binding.existence_predictor", [(0, nz)])
         if hp.attentive_inference:
-            for nm in ["input"] + [f"pyramid-{i}" for i in range(hp.conv_inf_enc_layers)] + ["head"]:
+            for nm in (["input"] + [f"pyramid-{i}" for i in range(hp.conv_inf_enc_layers)] + ["head"]) if hp.seq_enc == "conv" else []:
                 w = sd[f"inf_key_encoder.0.net.{nm}.conv.weight"]
                 X[f"kseq.{nm}.wT"] = pk.pack_gemm(w.permute(1, 2, 0).reshape(w.shape[1], -1))
             X["kseq.key.wT"] = pk.pack_gemm(sd["inf_key_encoder.1.linear.weight"].t().contiguous())                # [nz][dk]

@@ -129,7 +129,7 @@ def model_kind(configuration):
     name = v if isinstance(v, str) else getattr(v, "__name__", repr(v))
     return "sequential" if "sequential" in name.lower() else "tree"
 # model_config keys that are settled by what this build implements (checked, not mapped)
-_FIXED = {"one_step_planner": ("sh_pred", "continuous"), "binding": ("loss",), "seq_enc": ("conv",),
+_FIXED = {"one_step_planner": ("sh_pred", "continuous"), "binding": ("loss",),
           "dense_rec_type": ("node_prob", "svg", "none", None)}
 
 

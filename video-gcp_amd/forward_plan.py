@@ -258,15 +258,21 @@ class ForwardPlanMixin:
             if has_traj:
                 enc_traj = self._buf("enc_traj", (B * T, nz))
                 self._plan_encoder(plan, "traj", tin["traj_seq"].data_ptr(), B * T, enc_traj.data_ptr(), T * nz, nz, T)
-                inf_enc = self._buf("inf_enc_seq", (B * T, nz))
-                self._plan_seq_encoder(plan, "seq", "inf_encoder", enc_traj, inf_enc, B)
+                if hp.seq_enc == "none":                       # build_temporal_inf_encoder -> Identity (base_gcp.py:131-132)
+                    inf_enc = enc_traj
+                else:
+                    inf_enc = self._buf("inf_enc_seq", (B * T, nz))
+                    self._plan_seq_encoder(plan, "seq", "inf_encoder", enc_traj, inf_enc, B)
                 if attentive:
                     # attention keys: second temporal encoder + per-frame Linear (base_gcp.py:122-123, :200); then the key /
                     # value projections of every level's attention in one batched launch each
                     dk = hp.nz_attn_key
                     n_mod = L if hp.untied_layers else 1
-                    kenc = self._buf("inf_key_enc", (B * T, nz))
-                    self._plan_seq_encoder(plan, "kseq", "inf_key_encoder.0", enc_traj, kenc, B)
+                    if hp.seq_enc == "none":
+                        kenc = enc_traj
+                    else:
+                        kenc = self._buf("inf_key_enc", (B * T, nz))
+                        self._plan_seq_encoder(plan, "kseq", "inf_key_encoder.0", enc_traj, kenc, B)
                     keys = self._buf("inf_enc_key_seq", (B * T, dk))
                     dense = lambda t, w: self._rowsrc(t.data_ptr(), 0, w, w)
                     self._gemm(plan, "kseq.key", [dense(kenc, nz)], B * T, dk, B * T, P["kseq.key.w"], P["kseq.key.b"],

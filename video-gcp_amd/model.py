@@ -119,6 +119,9 @@ class GCPTreeModel(WeightsMixin, PlanOpsMixin, ForwardPlanMixin, ReplayMixin):
         assert hp.matching_type in ("balanced", "dtw_image")
         if hp.tree_lstm not in ("split_linear", "linear", "sum", ""):              # tree_lstm.py:52-60; '' = the non-LSTM subgoal
             raise ValueError("don't know this TreeLSTM type")                      # predictor (tree_module.py:45-46,109-110)
+        if hp.seq_enc not in ("conv", "none"):
+            # base_gcp.py:130-138: 'lstm' / 'bi-lstm' are blox's RecurrentSeqEncodingModule / BidirectionalSeqEncodingModule (absent)
+            raise ValueError(f"seq_enc = {hp.seq_enc!r}: 'conv' (ConvSeqEncodingModule) and 'none' (Identity) are built")
         if hp.lstm_init not in ("mlp", "zero"):
             raise ValueError("dont know lstm init type {}!".format(hp.lstm_init))  # tree_lstm.py:74
         if hp.attentive_inference:

@@ -99,26 +99,29 @@ def param_table(hp):
         tab["decoder.log_sigma"] = ((1,), "zeros")           # adaptive loss reads decoder.log_sigma (adaptive.py:133)
     # ---- temporal inference encoder (ConvSeqEncodingModule, base_gcp.py:130-134) -----------------
     k = hp.conv_inf_enc_kernel_size
-    tab["inf_encoder.net.input.conv.weight"] = ((hp.nz_mid, hp.nz_enc, k), "xavier")
-    tab["inf_encoder.net.input.conv.bias"] = ((hp.nz_mid,), "zeros")
-    for i in range(hp.conv_inf_enc_layers):
-        tab[f"inf_encoder.net.pyramid-{i}.conv.weight"] = ((hp.nz_mid, hp.nz_mid, k), "xavier")
-        tab[f"inf_encoder.net.pyramid-{i}.conv.bias"] = ((hp.nz_mid,), "zeros")
-        _bn(tab, f"inf_encoder.net.pyramid-{i}.norm", hp.nz_mid)
-    tab["inf_encoder.net.head.conv.weight"] = ((hp.nz_enc, hp.nz_mid, k), "xavier")
-    tab["inf_encoder.net.head.conv.bias"] = ((hp.nz_enc,), "zeros")
+    # seq_enc = 'none' (base_gcp.py:131-132): build_temporal_inf_encoder returns Identity — no parameters
+    if hp.seq_enc == "conv":
+        tab["inf_encoder.net.input.conv.weight"] = ((hp.nz_mid, hp.nz_enc, k), "xavier")
+        tab["inf_encoder.net.input.conv.bias"] = ((hp.nz_mid,), "zeros")
+        for i in range(hp.conv_inf_enc_layers):
+            tab[f"inf_encoder.net.pyramid-{i}.conv.weight"] = ((hp.nz_mid, hp.nz_mid, k), "xavier")
+            tab[f"inf_encoder.net.pyramid-{i}.conv.bias"] = ((hp.nz_mid,), "zeros")
+            _bn(tab, f"inf_encoder.net.pyramid-{i}.norm", hp.nz_mid)
+        tab["inf_encoder.net.head.conv.weight"] = ((hp.nz_enc, hp.nz_mid, k), "xavier")
+        tab["inf_encoder.net.head.conv.bias"] = ((hp.nz_enc,), "zeros")
     if hp.attentive_inference:
         # inf_key_encoder = Sequential(ConvSeqEncodingModule, AttnKeyEncodingModule) (base_gcp.py:122-123); it is only
         # read by the attentive posterior, so the balanced model does not allocate it
         q = "inf_key_encoder.0.net"
-        tab[f"{q}.input.conv.weight"] = ((hp.nz_mid, hp.nz_enc, k), "xavier")
-        tab[f"{q}.input.conv.bias"] = ((hp.nz_mid,), "zeros")
-        for i in range(hp.conv_inf_enc_layers):
-            tab[f"{q}.pyramid-{i}.conv.weight"] = ((hp.nz_mid, hp.nz_mid, k), "xavier")
-            tab[f"{q}.pyramid-{i}.conv.bias"] = ((hp.nz_mid,), "zeros")
-            _bn(tab, f"{q}.pyramid-{i}.norm", hp.nz_mid)
-        tab[f"{q}.head.conv.weight"] = ((hp.nz_enc, hp.nz_mid, k), "xavier")
-        tab[f"{q}.head.conv.bias"] = ((hp.nz_enc,), "zeros")
+        if hp.seq_enc == "conv":
+            tab[f"{q}.input.conv.weight"] = ((hp.nz_mid, hp.nz_enc, k), "xavier")
+            tab[f"{q}.input.conv.bias"] = ((hp.nz_mid,), "zeros")
+            for i in range(hp.conv_inf_enc_layers):
+                tab[f"{q}.pyramid-{i}.conv.weight"] = ((hp.nz_mid, hp.nz_mid, k), "xavier")
+                tab[f"{q}.pyramid-{i}.conv.bias"] = ((hp.nz_mid,), "zeros")
+                _bn(tab, f"{q}.pyramid-{i}.norm", hp.nz_mid)
+            tab[f"{q}.head.conv.weight"] = ((hp.nz_enc, hp.nz_mid, k), "xavier")
+            tab[f"{q}.head.conv.bias"] = ((hp.nz_enc,), "zeros")
         tab["inf_key_encoder.1.linear.weight"] = ((hp.nz_attn_key, hp.nz_enc), "xavier")
         tab["inf_key_encoder.1.linear.bias"] = ((hp.nz_attn_key,), "zeros")
     # ---- heads ---------------------------------------------------------------------------------

@@ -241,6 +241,8 @@ class WeightsMixin:
             P["dec.head.b"] = pk.pad_vec(hb, 16)
             self._head_pitch = 16
         seq_encs = [("seq", "inf_encoder")] + ([("kseq", "inf_key_encoder.0")] if hp.attentive_inference else [])
+        if hp.seq_enc == "none":                                   # Identity (base_gcp.py:131-132): nothing to pack
+            seq_encs = []
         for tag, pre in seq_encs:
             for nm in ["input"] + [f"pyramid-{i}" for i in range(hp.conv_inf_enc_layers)] + ["head"]:
                 w = sd[f"{pre}.net.{nm}.conv.weight"]              # [Cout, Cin, k] -> K = (tap, ci)
