@@ -490,7 +490,7 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     # ---- run_auxilliary_models (base_gcp.py:234-262) ---------------------------------------------------
     mes = torch.nn.utils.rnn.pad_sequence(out["model_enc_seq_list"], batch_first=True)   # :242
     out["model_enc_seq"] = mes
-    if hp.attach_state_regressor:
+    if hp.run_state_regressor:                                                   # (supervised_decoder=True: never computed, base_gcp.py:254-256)
         reg_in = mes.detach()                                                     # base_gcp.py:253-255 (supervised_decoder=False)
         out["regressed_state"] = predictor(sd, "state_regressor", hp, reg_in.reshape(-1, mes.shape[-1])).reshape(B, mes.shape[1], -1)
     if hp.attach_inv_mdl and phase == "train":
@@ -573,7 +573,7 @@ def losses(sd, hp, inputs, out):
         # existence BCE (frame_binding.py:80-86): target = tree.df.match_dist.sum(2)
         tgt_ex = out["leave_df"].float()
         res["existence_predictor"] = (F.binary_cross_entropy_with_logits(out["existence"], tgt_ex), 1.0)
-    if hp.attach_state_regressor and "traj_seq_states" in inputs:
+    if hp.run_state_regressor and "traj_seq_states" in inputs:
         rl = out["regressed_state"].shape[1]
         e = (out["regressed_state"] - inputs["traj_seq_states"][:, :rl]) ** 2 * pm[:, :rl, None]
         res["state_regression"] = (e.mean(), 1.0)

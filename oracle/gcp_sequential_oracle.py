@@ -109,7 +109,7 @@ def forward(sd, hp, inputs, noise=None, sample_prior=False, training_bn=False, p
     out["model_enc_seq_list"] = [full[b, :int(end_ind[b]) + 1] for b in range(B)]
     mes = torch.nn.utils.rnn.pad_sequence(out["model_enc_seq_list"], batch_first=True)
     out["model_enc_seq"] = mes
-    if hp.attach_state_regressor:
+    if hp.run_state_regressor:
         reg_in = mes.detach()                                         # base_gcp.py:253-255 (supervised_decoder=False)
         out["regressed_state"] = O.predictor(sd, "state_regressor", hp, reg_in.reshape(-1, mes.shape[-1])).reshape(B, mes.shape[1], -1)
     # run_auxilliary_models (base_gcp.py:234-262) is BaseGCPModel's: the same branches as in gcp_model_oracle.forward

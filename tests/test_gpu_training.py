@@ -444,3 +444,24 @@ def test_seq_enc_none_forward_and_gradients(cfg):
     from video_gcp_amd.model import GCPTreeModel
     with pytest.raises(ValueError):                                  # 'lstm' / 'bi-lstm' are blox modules: refused, not approximated
         GCPTreeModel(V.config("c1", seq_enc="lstm"), device="cuda")
+
+
+def test_supervised_decoder_leaves_the_state_regressor_out():
+    """supervised_decoder=True (hyperparameters.py:118) as base_gcp.py:252-256 is written: the regressor call sits inside
+    `if not supervised_decoder:`, so no `regressed_state`, no state-regression loss, zero gradient for the regressor's (still present)
+    parameters; everything else trains as before — total loss and every gradient against autograd over the oracle"""
+    from oracle import gcp_model_oracle as O
+    hp, sd, model, tr = _setup("c1", False, supervised_decoder=True)
+    assert hp.attach_state_regressor and not hp.run_state_regressor and any(k.startswith("state_regressor.") for k in sd)
+    inputs, noise, _ = make_inputs(hp, seed=13, variant="B")
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    out = tr.backward(dev_in, noise.cuda())
+    torch.cuda.synchronize()
+    gref, res, total, ref = O.gradients(sd, hp, inputs, noise)
+    assert "state_regression" not in res and "regressed_state" not in ref
+    assert abs(float(out.raw["losses"][5]) - float(total)) <= 2e-5 * abs(float(total))
+    got = tr.named_grads()
+    _compare_grads(gref, got)
+    assert all(float(got[k].abs().max()) == 0.0 for k in got if k.startswith("state_regressor."))
+    fwd = model(dev_in, "train", noise=noise.cuda())
+    assert "regressed_state" not in fwd

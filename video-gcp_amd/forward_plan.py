@@ -467,7 +467,7 @@ class ForwardPlanMixin:
             mes = self._buf("model_enc_seq", (B, Wd, nz))
             plan.add("gather.model_enc_seq", lib.gcpx_gather_rows, E.data_ptr(), idx.data_ptr(), mes.data_ptr(), B, Wd, PS, 1, nz)
             outs["model_enc_seq_padded"] = mes
-            if hp.attach_state_regressor:
+            if hp.run_state_regressor:
                 rs = self._buf("regressed_state", (B, Wd, hp.state_dim))
                 self._mlp(plan, "state_regressor", P["state_regressor"], [self._rowsrc(mes.data_ptr(), Wd * nz, nz, nz)],
                           B * Wd, Wd, out=rs.data_ptr(), ob=Wd * hp.state_dim, orow=hp.state_dim, group=heads)

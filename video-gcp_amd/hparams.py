@@ -58,6 +58,7 @@ class GCPHParams:
     prior_type: str = "learned"
     regress_length: bool = True
     attach_state_regressor: bool = True
+    supervised_decoder: bool = False   # hyperparameters.py:118; consumed at base_gcp.py:252-256 (see run_state_regressor)
     attach_inv_mdl: bool = True
     attach_cost_mdl: bool = True
     run_cost_mdl: bool = True          # hyperparameters.py:63
@@ -93,6 +94,13 @@ class GCPHParams:
         assert self.var_inf in ("standard", "deterministic"), "var_inf '2layer' is not built"
         assert (self.var_inf == "deterministic") == (self.nz_vae == 0), "a deterministic predictor has no latent: nz_vae = 0 (vmpc.py:14-15)"
         assert self.nz_attn_key % self.n_attention_heads == 0 and self.nz_enc % self.n_attention_heads == 0
+
+    @property
+    def run_state_regressor(self):
+        """base_gcp.py:252-256 as written: `regressed_state` is computed INSIDE `if not supervised_decoder:` (the detach of its input and
+        the regressor call share the indentation), so with supervised_decoder=True the state regressor — still built, its parameters
+        still in the state_dict — produces nothing and the state-regression loss is absent.  Mirrored, not repaired."""
+        return self.attach_state_regressor and not self.supervised_decoder
 
     @property
     def deterministic(self):

@@ -332,7 +332,7 @@ class GCPSequentialModel(GCPTreeModel):
         mes = self._buf("model_enc_seq", (B, T, nz))
         plan.add("gather.model_enc_seq", lib.gcpx_gather_rows, X.data_ptr(), idx.data_ptr(), mes.data_ptr(), B, T, T, 0, nz)
         outs["model_enc_seq_padded"] = mes
-        if hp.attach_state_regressor:
+        if hp.run_state_regressor:
             rs = self._buf("regressed_state", (B, T, hp.state_dim))
             self._mlp(plan, "state_regressor", P["state_regressor"], [self._rowsrc(mes.data_ptr(), T * nz, nz, nz)],
                       B * T, T, out=rs.data_ptr(), ob=T * hp.state_dim, orow=hp.state_dim)
