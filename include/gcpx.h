@@ -851,6 +851,16 @@ int gcpx_cdist(const float* x, const float* y, int32_t B, int32_t N, int32_t T, 
 int gcpx_soft_dtw(const float* dsum, float D, const float* temp, const int64_t* end_ind, int32_t B, int32_t N, int32_t T,
                   double* acc, float* w, void* stream);
 
+/* d loss / d temp of a LEARNED matching temperature (hyperparameters.py:132 learn_matching_temp = True; adaptive.py:19-21 keeps
+ * `temp` trainable, adaptive.py:51 divides the detached cost by it inside the autograd graph): the averaging criterion
+ * (binding_loss.py:24-35)  coef * sum_{b,n,t} w[b][n][t] * pad[b][t] * (0.5 dsum exp(-2 ls) + D (ls + 0.5 log 2 pi))  differentiated
+ * through w = normalize(soft_dtw(cost / temp)) in forward mode along the alignment lattice, float64 inside.
+ *   acc: the [2*B][N][T] accumulators gcpx_soft_dtw left for the same dsum / temp / end_ind;
+ *   tangent [2*B][N][T] and partial [B]: caller-owned float64 scratch;  dtemp[0] += the gradient. */
+int gcpx_soft_dtw_dtemp(const float* dsum, float D, const float* temp, const int64_t* end_ind, const double* acc,
+                        const float* pad_mask, const float* log_sigma, float coef, int32_t B, int32_t N, int32_t T,
+                        double* tangent, double* partial, float* dtemp, void* stream);
+
 /* Bookkeeping on the matching distribution w [B][N = 2^L - 1][T] (depth-first):
  *   frame2node [B][T]  depth-first position of argmax over nodes, first maximum in BREADTH-first order
  *                      (tree.bf.match_dist.argmax(1), frame_binding.py:30; all-zero column -> root)

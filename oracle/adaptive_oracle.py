@@ -76,6 +76,41 @@ def soft_dtw(cost, end_inds=None):
     return w.astype(np.float32)
 
 
+def soft_dtw_autograd(cost, end_inds):
+    """soft_dtw (probabilistic_dtw.py:82-122) as torch float64 ops, for a cost that carries a gradient (the learned matching
+    temperature, adaptive.py:19-21, :51).  Same cell recurrence as fast_gak above, swept row by row instead of along anti-diagonals
+    (a 'nohor' cell reads the previous row only, so every cell sees the same two operands); test_adaptive_cpu checks its values
+    against soft_dtw() bit for bit where both apply.  cost [B, r, c] torch -> w float32 [B, r, c] with grad."""
+    C = (-cost).double()
+    B, r, c = C.shape
+    end = torch.as_tensor(end_inds, dtype=torch.long)
+    ninf = torch.full((B, 1), -np.inf, dtype=torch.float64)
+
+    def sweep(Cm, begin):
+        first = torch.full((B, c), -np.inf, dtype=torch.float64)
+        first = first.scatter(1, begin[:, None], Cm[:, 0].gather(1, begin[:, None]))
+        rows = [first]
+        for i in range(1, r):
+            skip = rows[-1]
+            step = torch.cat([ninf, skip[:, :-1]], 1)
+            m = torch.maximum(skip, step)
+            dead = torch.isinf(m)                  # neither predecessor is reachable: the cell is -inf and carries no derivative
+            zero = torch.zeros_like(m)             # (the reference's logsumexp gives such cells a NaN derivative, see the goldens' header)
+            sk, st, m0 = torch.where(dead, zero, skip), torch.where(dead, zero, step), torch.where(dead, zero, m)
+            lse = torch.log(torch.exp(sk - m0) + torch.exp(st - m0)) + m0
+            rows.append(torch.where(dead, m, Cm[:, i] + lse))
+        return torch.stack(rows, 1)
+
+    fwd = sweep(C, torch.zeros_like(end))
+    bwd = sweep(C.flip(1, 2), c - end - 1).flip(1, 2)
+    z = fwd[torch.arange(B), -1, end][:, None, None]
+    e = fwd + bwd - C
+    # cells no alignment passes through are -inf in one of the two sweeps: w = 0 and no gradient
+    reach = torch.isfinite(e)
+    w = torch.where(reach, torch.exp(torch.where(reach, e, torch.zeros_like(e)) - z), torch.zeros_like(e))
+    return w.float()
+
+
 # ---------------------------------------------------------------------------------------------------
 # hard DTW of the evaluation harness (dtw_utils.py)
 # ---------------------------------------------------------------------------------------------------
@@ -198,7 +233,10 @@ def get_w(hp, sd, images_df, traj_seq, end_ind):
     and the depth-first image cost matrix."""
     assert hp.matching_type == "dtw_image"
     cost = hack_weights_df(batch_cdist(images_df, traj_seq, reduction="mean"), hp)
-    w = soft_dtw((cost.detach() / sd["tree_module.tree_modules.0.binding.temp"].detach()).numpy(), end_ind.numpy())
+    temp = sd["tree_module.tree_modules.0.binding.temp"]
+    if hp.learn_matching_temp and temp.requires_grad:                    # adaptive.py:19-21: the division by temp stays in the graph
+        return normalize(soft_dtw_autograd(cost.detach() / temp, end_ind), 1), cost
+    w = soft_dtw((cost.detach() / temp.detach()).numpy(), end_ind.numpy())
     return normalize(torch.from_numpy(w), 1), cost
 
 

@@ -65,3 +65,45 @@ def test_dtw_matches_pick_path_cells():
     cells = set(zip(path[0].tolist(), path[1].tolist()))
     assert all((int(inds[j]), j) in cells for j in range(9))
     assert inds[0] == 0 and np.all(np.diff(inds) >= 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# learned matching temperature (hyperparameters.py:132, adaptive.py:19-21, :51)
+# ---------------------------------------------------------------------------------------------------
+GT = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_dtw_dtemp.npz"))
+
+
+@pytest.mark.parametrize("i", range(int(GT["n"])))
+def test_soft_dtw_autograd_values_and_temperature_derivative(i):
+    """soft_dtw_autograd (a) returns soft_dtw's values, (b) differentiates w.r.t. the temperature like central differences of the
+    reference's forward executed at temp +- h (the goldens), cell by cell; the reference's OWN autograd through soft_dtw is NaN for
+    this parameter (stored in the goldens: the -inf cells of the lattice), so there is no finite reference gradient to match."""
+    cost, end, t0, h = torch.from_numpy(GT[f"c{i}_cost"]), GT[f"c{i}_end"], float(GT[f"c{i}_temp"]), float(GT["h"])
+    assert np.all(np.isnan(GT[f"c{i}_ref_autograd_dtemp"]))
+    temp = torch.full((1,), t0, requires_grad=True)
+    w = A.soft_dtw_autograd(cost / temp, end)
+    w_np = A.soft_dtw((cost / t0).numpy(), end)
+    assert np.max(np.abs(w.detach().numpy() - w_np)) < 1e-6 and np.max(np.abs(w_np - GT[f"c{i}_w"])) < 1e-6
+    # forward-mode derivative of every cell at once: d w / d temp = jvp along temp
+    _, dw = torch.autograd.functional.jvp(lambda t: A.soft_dtw_autograd(cost / t, end), temp.detach(), torch.ones(1))
+    fd = (GT[f"c{i}_w_plus"].astype(np.float64) - GT[f"c{i}_w_minus"]) / (2 * h)
+    scale = np.abs(fd).max()
+    assert scale > 1e-3
+    assert np.max(np.abs(dw.numpy() - fd)) < 5e-4 * scale + 5e-5
+    (g,) = torch.autograd.grad((w * torch.from_numpy(GT[f"c{i}_G"])).sum(), temp)
+    assert torch.isfinite(g).all()
+    assert abs(float(g) - float((fd * GT[f"c{i}_G"]).sum())) < 3e-3 * float(np.abs(fd * GT[f"c{i}_G"]).sum())
+
+
+def test_get_w_keeps_the_temperature_in_the_graph_only_when_it_is_learned():
+    from video_gcp_amd.hparams import config
+    hp_off, hp_on = config("c5s"), config("c5s", learn_matching_temp=True)
+    g = torch.Generator().manual_seed(3)
+    img, traj = torch.rand(2, 15, 3, 8, 8, generator=g), torch.rand(2, 12, 3, 8, 8, generator=g)
+    end = torch.tensor([11, 6])
+    temp = torch.full((1,), 0.7, requires_grad=True)
+    sd = {"tree_module.tree_modules.0.binding.temp": temp}
+    w_off, _ = A.get_w(hp_off, sd, img, traj, end)
+    w_on, _ = A.get_w(hp_on, sd, img, traj, end)
+    assert not w_off.requires_grad and w_on.requires_grad
+    assert torch.allclose(w_off, w_on.detach(), atol=1e-6)

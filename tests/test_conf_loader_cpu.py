@@ -98,6 +98,12 @@ def test_adaptive_base_config_and_errors(tmp_path):
     '''))
     hp, trainer, _ = CL.load_conf(str(tmp_path), max_seq_len=200)
     assert hp.adaptive and hp.attentive_inference and hp.batch_size == 8
+    assert hp.learn_matching_temp is False                              # base_configs/gcp_adaptive.py:9
+    # a DTW conf that does not mention it gets hyperparameters.py:132's default, one that sets it keeps its value
+    (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'matching_type': 'dtw_image', 'attentive_inference': True}\n")
+    assert CL.load_conf(str(tmp_path), max_seq_len=12, img_sz=32)[0].learn_matching_temp is True
+    (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'matching_type': 'dtw_image', 'learn_matching_temp': False}\n")
+    assert CL.load_conf(str(tmp_path), max_seq_len=12, img_sz=32)[0].learn_matching_temp is False
     (tmp_path / "conf.py").write_text("configuration = {}\nmodel_config = {'tree_lstm': 'sum', 'lstm_init': 'zero'}\n")
     hp, _, _ = CL.load_conf(str(tmp_path))
     assert hp.tree_lstm == "sum" and hp.lstm_init == "zero"             # tree_lstm.py:52-74: sum / linear / split_linear, zero / mlp

@@ -53,6 +53,53 @@ def test_soft_dtw_kernel_matches_reference_goldens(i):
         assert torch.allclose(w[b, :, :e + 1].sum(0).cpu(), torch.ones(e + 1), atol=1e-5)
 
 
+GT = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_dtw_dtemp.npz"))
+
+
+@pytest.mark.parametrize("i", list(range(int(GT["n"]))) + ["c5"])
+def test_soft_dtw_temperature_gradient_kernel(i):
+    """gcpx_soft_dtw_dtemp (learn_matching_temp, adaptive.py:19-21, :51): d / d temp of the averaging criterion through
+    normalize(soft_dtw(cost / temp)), against torch autograd over the oracle's soft_dtw_autograd — which the CPU suite pins to central
+    differences of the reference's forward executed at temp +- h (tests/golden/ref_dtw_dtemp.npz; the reference's own autograd
+    gives NaN there).  Tolerance 2e-5 relative (float64 inside, float32 cost and weights)."""
+    from oracle import adaptive_oracle as A
+    rt, lib = _lib()
+    D, coef, ls0 = 3.0, 0.37, 0.2
+    if i == "c5":                                                     # c5's lattice (255 nodes x 200 frames), ragged lengths
+        g = torch.Generator().manual_seed(5)
+        dsum, end, t0 = torch.rand(4, 255, 200, generator=g) * 1.5 * D, torch.tensor([199, 120, 37, 1]), 0.4
+    else:
+        dsum, end, t0 = torch.tensor(GT[f"c{i}_cost"]) * D, torch.tensor(GT[f"c{i}_end"]), float(GT[f"c{i}_temp"])
+    B, N, T = dsum.shape
+    pad = (torch.arange(T)[None] <= end[:, None]).float()
+    pad[0, 1] = 0.0                                                   # the mask is an input, not derived from end_ind
+    temp = torch.full((1,), t0, requires_grad=True)
+    ls = torch.full((1,), ls0)
+    w = A.normalize(A.soft_dtw_autograd((dsum / D) / temp, end), 1)
+    val = 0.5 * dsum * torch.exp(-ls) ** 2 + D * (ls + 0.5 * math.log(2 * math.pi))
+    (want,) = torch.autograd.grad(coef * (val * w * pad[:, None]).sum(), temp)
+    acc = torch.zeros(2 * B, N, T, dtype=torch.float64, device="cuda")
+    tan = torch.full((2 * B, N, T), float("nan"), dtype=torch.float64, device="cuda")
+    part = torch.zeros(B, dtype=torch.float64, device="cuda")
+    wd = torch.zeros(B, N, T, device="cuda")
+    tp, dd, ed, pd_, lsd = temp.detach().cuda(), dsum.cuda(), end.cuda(), pad.cuda(), ls.cuda()
+    got = torch.full((1,), 0.25, device="cuda")                       # the kernel ACCUMULATES into the gradient slot
+    rt.check(lib.gcpx_soft_dtw(dd.data_ptr(), D, tp.data_ptr(), ed.data_ptr(), B, N, T, acc.data_ptr(), wd.data_ptr(), _st()), "soft_dtw")
+    rt.check(lib.gcpx_soft_dtw_dtemp(dd.data_ptr(), D, tp.data_ptr(), ed.data_ptr(), acc.data_ptr(), pd_.data_ptr(), lsd.data_ptr(), coef,
+                                     B, N, T, tan.data_ptr(), part.data_ptr(), got.data_ptr(), _st()), "soft_dtw_dtemp")
+    torch.cuda.synchronize()
+    assert_close(wd, w.detach(), 2e-6, 0, "w")
+    g = float(got) - 0.25
+    assert abs(float(want)) > 1e-3
+    assert abs(g - float(want)) <= 2e-5 * abs(float(want)) + 1e-6, (g, float(want))
+    # twice the same launch: bit-identical (fixed summation order)
+    got2 = torch.full((1,), 0.25, device="cuda")
+    rt.check(lib.gcpx_soft_dtw_dtemp(dd.data_ptr(), D, tp.data_ptr(), ed.data_ptr(), acc.data_ptr(), pd_.data_ptr(), lsd.data_ptr(), coef,
+                                     B, N, T, tan.data_ptr(), part.data_ptr(), got2.data_ptr(), _st()), "soft_dtw_dtemp")
+    torch.cuda.synchronize()
+    assert float(got2) == float(got)
+
+
 def test_soft_dtw_full_size_properties():
     """c5 size (255 nodes x 200 frames): agreement with the oracle and the structural properties of the alignment posterior"""
     from oracle import adaptive_oracle as A
@@ -351,15 +398,18 @@ def _compare_grads(gref, got, rtol=1e-3, atol=5e-7):
     assert not bad, bad[:12]
 
 
+@pytest.mark.parametrize("learn_temp", [False, True])
 @pytest.mark.parametrize("graph", [False, True])
-def test_adaptive_gradients_match_autograd_c5s(graph):
+def test_adaptive_gradients_match_autograd_c5s(graph, learn_temp):
     """training step of the adaptive model (explicit backward through the averaging loss, the mixture mean, the attentive
     posterior and both temporal encoders) against torch autograd over the oracle.  Stated tolerance: 1e-3 of each gradient's
-    max-abs (+5e-7), as for the balanced model (tests/test_gpu_training.py)."""
+    max-abs (+5e-7), as for the balanced model (tests/test_gpu_training.py).  learn_temp: hyperparameters.py:132's default — the
+    matching temperature receives the criterion's gradient through the matching weights (zero otherwise)."""
     from oracle import gcp_model_oracle as O
     from video_gcp_amd.training import GCPTrainStep
-    hp, sd, model = _build("c5s")
-    sd["tree_module.tree_modules.0.binding.temp"].fill_(0.3)
+    hp, sd, model = _build("c5s", learn_matching_temp=learn_temp)
+    # a sharp posterior where the temperature is learned: its gradient is ~1e-3 there (8e-6 at 0.3, below the absolute tolerance)
+    sd["tree_module.tree_modules.0.binding.temp"].fill_(0.02 if learn_temp else 0.3)
     model.load_state_dict({"tree_module.tree_modules.0.binding.temp": sd["tree_module.tree_modules.0.binding.temp"]}, strict=False)
     model.use_graph = graph
     tr = GCPTrainStep(model, lr=1e-3)
@@ -369,8 +419,11 @@ def test_adaptive_gradients_match_autograd_c5s(graph):
         out = tr.backward(dev_in, noise.cuda())
     torch.cuda.synchronize()
     gref, res, total, _ = O.gradients(sd, hp, inputs, noise)
-    assert abs(float(out.raw["losses"][5]) - float(total)) <= 1e-4 * abs(float(total))
-    _compare_grads(gref, tr.named_grads())
+    assert abs(float(out.raw["losses"][5]) - float(total.detach())) <= 1e-4 * abs(float(total.detach()))
+    got = tr.named_grads()
+    _compare_grads(gref, got)
+    gt = float(got["tree_module.tree_modules.0.binding.temp"].abs().max())
+    assert (gt > 1e-4) if learn_temp else (gt == 0.0)
 
 
 def test_adaptive_training_step_c5_shapes_decreases_loss():

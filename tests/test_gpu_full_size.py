@@ -317,11 +317,13 @@ def test_c2_forward_is_deterministic_at_full_size(phase):
     assert not diff, diff
 
 
-def test_c5_adaptive_training_gradient_is_deterministic_at_full_size():
+@pytest.mark.parametrize("learn_temp", [False, True])
+def test_c5_adaptive_training_gradient_is_deterministic_at_full_size(learn_temp):
     """The adaptive (soft-DTW binding, attentive inference) training step of the c5 shard (B = 8, T = 200, 255 nodes): losses and the
-    whole flat gradient bit for bit over three backward passes."""
+    whole flat gradient bit for bit over three backward passes; with the learned matching temperature (hyperparameters.py:132) too,
+    whose gradient must then be finite and non-zero."""
     from video_gcp_amd.training import GCPTrainStep
-    hp, sd, model = _build("c5")
+    hp, sd, model = _build("c5", learn_matching_temp=learn_temp)
     tr = GCPTrainStep(model)
     inputs, noise, _ = make_inputs(hp, seed=2, variant="A")
     dev_in = {k: v.cuda() for k, v in inputs.items()}
@@ -334,6 +336,8 @@ def test_c5_adaptive_training_gradient_is_deterministic_at_full_size():
     assert torch.equal(gs[0], gs[1]) and torch.equal(gs[0], gs[2])
     assert torch.equal(ls[0], ls[1]) and torch.equal(ls[0], ls[2])
     assert torch.isfinite(gs[0]).all() and float(gs[0].abs().max()) > 0
+    gt = float(tr.named_grads()["tree_module.tree_modules.0.binding.temp"].abs().max())
+    assert (gt > 0) if learn_temp else (gt == 0.0)
 
 
 def test_sequential_training_gradient_is_deterministic_at_full_size():

@@ -269,16 +269,17 @@ def test_training_step_c2_shapes_runs_and_decreases_loss():
     assert losses[-1] < losses[0], losses
 
 
-@pytest.mark.parametrize("name", ["c1", "c5s"])
+@pytest.mark.parametrize("name", ["c1", "c5s", "c5s+temp"])
 def test_bucket_marks_follow_every_write_of_their_slice(name):
     """The data-parallel exchange starts a bucket's all-reduce at its `mark` in the backward plan (training.py: plan.mark("bucket", i)
     behind the level's flush).  That is only right if NOTHING writes into the bucket's slice of the flat gradient after the mark: a late
     write either races the collective or leaves a rank-local gradient that RAdam still scales by 1 / world.  The real backward plan of
     GCPTrainStep is replayed eagerly with the mark hook taking a snapshot of the bucket's slice (after waiting for every lane); the
     final gradient must equal the snapshots bit for bit.  c5s covers the attentive posterior, whose k_proj / v_proj weight gradients
-    were once issued after the tree loop, i.e. after their level's mark (round-2 advisor finding)."""
+    were once issued after the tree loop, i.e. after their level's mark (round-2 advisor finding); "c5s+temp": the learned matching
+    temperature, a parameter of tree module 0 whose gradient is issued from the loss section on a side lane."""
     from video_gcp_amd.dist import gradient_bucket_ranges
-    hp, sd, model, tr = _setup(name, False)
+    hp, sd, model, tr = _setup(name.split("+")[0], False, **({"learn_matching_temp": True} if name.endswith("+temp") else {}))
     ranges = gradient_bucket_ranges(model._poff, hp.hierarchy_levels, hp.untied_layers)
     assert len(ranges) == hp.hierarchy_levels + 1               # one bucket per level L-1 .. 0, then the rest
     tr._bucket_index = {n: i for i, (n, _, _) in enumerate(ranges)}      # what a process group switches on (training.py:53)

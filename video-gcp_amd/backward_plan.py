@@ -59,13 +59,22 @@ class BackwardPlanMixin:
         adaptive, attentive = hp.adaptive, hp.attentive_inference
         if adaptive:
             # LossAveragingCriterion (binding_loss.py:19-42): gradient w.r.t. the decoded image of EVERY node, then back through
-            # the mixture mean to the head's raw parameters; the matching weights are constants (adaptive.py:50 detaches)
+            # the mixture mean to the head's raw parameters; the matching weights carry no gradient to the images (adaptive.py:50 detaches the cost)
             Dd = hp.input_nc * S * S
             dImg = buf("bw.dImg", (B, N, hp.input_nc, S, S))
             plan.add("bw.avg_nll", lib.gcpx_averaging_nll_bwd, o["match_dist_df"].data_ptr(), tin["pad_mask"].data_ptr(),
                      o["images_df"].data_ptr(), tin["traj_seq"].data_ptr(), o["cdist_sum"].data_ptr(),
                      m.sd["decoder.log_sigma"].data_ptr(), C.c_float(hp.dense_img_rec_weight / (B * div)), B, N, T, Dd, dImg.data_ptr(),
                      self.g("decoder.log_sigma"))
+            if hp.learn_matching_temp:
+                # adaptive.py:19-21, :51: only the COST is detached; the division by the learned temperature is not, so the criterion
+                # reaches `temp` through the matching weights (forward-mode sweep along the forward pass's accumulators)
+                self._side(plan, "bw.dtw_dtemp", lib.gcpx_soft_dtw_dtemp, o["cdist_sum"].data_ptr(), C.c_float(float(Dd)),
+                           m.sd["tree_module.tree_modules.0.binding.temp"].data_ptr(), tin["end_ind"].data_ptr(),
+                           o["dtw_acc"].data_ptr(), tin["pad_mask"].data_ptr(), m.sd["decoder.log_sigma"].data_ptr(),
+                           C.c_float(hp.dense_img_rec_weight / (B * div)), B, N, T,
+                           buf("bw.dtw.tangent", (2 * B, N, T), torch.float64).data_ptr(),
+                           buf("bw.dtw.partial", (B,), torch.float64).data_ptr(), self.g("tree_module.tree_modules.0.binding.temp"))
             dMD = buf("bw.dMD", (B * N, S, S, pitch))
             plan.add("bw.dlm_mean", lib.gcpx_dlm_mean_bwd, o["distr_df_kernel_order"].data_ptr(), dImg.data_ptr(), dMD.data_ptr(),
                      buf("bw.dMD.colsum", (B * N, pitch)).data_ptr(), B * N, S * S, pitch, hp.n_mixtures)

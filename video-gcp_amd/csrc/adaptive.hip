@@ -312,6 +312,139 @@ __global__ void dtw_combine_kernel(const float* __restrict__ dsum, const float D
     for (int n = g; n < r; n += G) wb[(size_t)n * c + t] /= den;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// learn_matching_temp (hyperparameters.py:132, adaptive.py:19-21): `soft_dtw(cost.detach() / self.temp, ...)` (adaptive.py:51) keeps
+// the division by the temperature in the autograd graph, so the averaging criterion's loss (binding_loss.py:31-35) reaches `temp`
+// through the matching weights.  d w / d temp in FORWARD mode along the same lattice: with C = -cost / temp, Cdot = cost / temp^2,
+//   Ddot[0][begin] = Cdot;  Ddot[i][j] = Cdot[i][j] + s Ddot[i-1][j] + (1 - s) Ddot[i-1][j-1],  s = e^{D[i-1][j]} / (e^{D[i-1][j]} + e^{D[i-1][j-1]})
+// (the derivative of the logsumexp of the sweep above), for the forward and the flipped problem; the values D are the forward pass's
+// `acc`, so this sweep's dependent chain is two fmas, an LDS exchange and a barrier per row.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double neg_cost_dtemp(const float dsum, const float D, const float temp) {
+    return (double)(dsum / D) / ((double)temp * (double)temp);
+}
+
+__global__ void dtw_tangent_sweep_kernel(const float* __restrict__ dsum, const float D, const float* __restrict__ temp_p,
+                                         const int64_t* __restrict__ end_ind, const double* __restrict__ acc,
+                                         double* __restrict__ tan, const int B, const int r, const int c) {
+    extern __shared__ double sh[];                      // [2][cp] values, [2][cp] tangents of the previous rows
+    const int dir = blockIdx.x / B, b = blockIdx.x % B;
+    const int j = threadIdx.x;
+    const int cp = blockDim.x;
+    double* shv = sh;
+    double* sht = sh + 2 * cp;
+    const int end = (int)end_ind[b];
+    const int begin = dir ? c - end - 1 : 0;
+    const float temp = temp_p[0];
+    const float* Cb = dsum + (size_t)b * r * c;
+    const double* Ab = acc + (size_t)blockIdx.x * r * c;
+    double* Tb = tan + (size_t)blockIdx.x * r * c;
+    const int sj = dir ? c - 1 - j : j;
+    double vprev = -INFINITY, tprev = 0.0;
+    // row i + 1's value and cost are requested before row i is combined (neither is on the dependent chain)
+    double vnext = -INFINITY;
+    float cnext = 0.f;
+    if (j < c) {
+        const size_t o = (size_t)(dir ? r - 1 : 0) * c + sj;
+        vnext = Ab[o];
+        cnext = Cb[o];
+    }
+    for (int i = 0; i < r; ++i) {
+        const int si = dir ? r - 1 - i : i;
+        const double vcur = vnext;
+        const float craw = cnext;
+        if (j < c && i + 1 < r) {
+            const size_t o = (size_t)(dir ? r - 2 - i : i + 1) * c + sj;
+            vnext = Ab[o];
+            cnext = Cb[o];
+        }
+        double tcur = 0.0;
+        if (j < c) {
+            const double cdot = neg_cost_dtemp(craw, D, temp);
+            if (i == 0) {
+                tcur = (j == begin) ? cdot : 0.0;
+            } else if (!isinf(vcur)) {
+                const double vleft = j > 0 ? shv[((i - 1) & 1) * cp + j - 1] : -INFINITY;
+                const double tleft = j > 0 ? sht[((i - 1) & 1) * cp + j - 1] : 0.0;
+                // share of the same-column predecessor in e^{D[i-1][j]} + e^{D[i-1][j-1]}
+                const double s = isinf(vprev) ? 0.0 : (isinf(vleft) ? 1.0 : 1.0 / (1.0 + exp(vleft - vprev)));
+                tcur = cdot + fma(s, tprev, (1.0 - s) * tleft);
+            }
+            shv[(i & 1) * cp + j] = vcur;
+            sht[(i & 1) * cp + j] = tcur;
+            Tb[(size_t)si * c + sj] = tcur;
+        }
+        vprev = vcur;
+        tprev = tcur;
+        __syncthreads();
+    }
+}
+
+// d loss / d temp of the averaging criterion through the normalised matching weights: what = w / max(sum_n w, 1e-7) (adaptive.py:58),
+// loss = coef * sum_{b,n,t} what * pad * (0.5 d exp(-2 ls) + D (ls + 0.5 log 2 pi)) (binding_loss.py:24-35).  One workgroup per
+// sequence, thread (t, g) takes the nodes g, g + G, ... of frame t; all sums in float64 in a fixed order.
+__global__ void dtw_dtemp_combine_kernel(const float* __restrict__ dsum, const float D, const float* __restrict__ temp_p,
+                                         const int64_t* __restrict__ end_ind, const double* __restrict__ acc,
+                                         const double* __restrict__ tan, const float* __restrict__ pad,
+                                         const float* __restrict__ log_sigma, double* __restrict__ partial, const int B, const int r,
+                                         const int c) {
+    extern __shared__ double red[];                     // [4][G][cp]
+    const int b = blockIdx.x, t = threadIdx.x, g = threadIdx.y, cp = blockDim.x, G = blockDim.y;
+    const float temp = temp_p[0];
+    const size_t rc = (size_t)r * c;
+    const double* F = acc + (size_t)b * rc;
+    const double* Bw = acc + (size_t)(B + b) * rc;
+    const double* TF = tan + (size_t)b * rc;
+    const double* TB = tan + (size_t)(B + b) * rc;
+    const float* Cb = dsum + (size_t)b * rc;
+    const size_t zo = (size_t)(r - 1) * c + (int)end_ind[b];
+    const double z = F[zo], zdot = TF[zo];
+    const float ls = log_sigma[0];
+    const double iv2 = exp(-2.0 * (double)ls), c0 = (double)D * ((double)ls + 0.91893853320467274178);
+    double s = 0.0, sd = 0.0, a = 0.0, q = 0.0;
+    if (t < c) {
+        for (int n = g; n < r; n += G) {
+            const size_t o = (size_t)n * c + t;
+            const float craw = Cb[o];
+            const double e = F[o] + Bw[o] - neg_cost(craw, D, temp);
+            if (isinf(e) || isnan(e)) continue;         // unreachable cell: w = 0 for every temp
+            const double wv = (double)(float)exp(e - z);
+            const double wd = wv * (TF[o] + TB[o] - neg_cost_dtemp(craw, D, temp) - zdot);
+            const double gl = fma(0.5 * (double)craw, iv2, c0);
+            s += wv;
+            sd += wd;
+            a = fma(gl, wd, a);
+            q = fma(gl, wv, q);
+        }
+    }
+    const int slot = g * cp + t, plane = G * cp;
+    red[slot] = s; red[plane + slot] = sd; red[2 * plane + slot] = a; red[3 * plane + slot] = q;
+    __syncthreads();
+    double contrib = 0.0;
+    if (g == 0 && t < c) {
+        double S = 0.0, SD = 0.0, A = 0.0, Q = 0.0;
+        for (int k = 0; k < G; ++k) {
+            S += red[k * cp + t]; SD += red[plane + k * cp + t]; A += red[2 * plane + k * cp + t]; Q += red[3 * plane + k * cp + t];
+        }
+        // below the clamp the denominator is the constant 1e-7 (blox normalize as the forward applies it)
+        contrib = (double)pad[(size_t)b * c + t] * (S > 1e-7 ? (A - Q * SD / S) / S : A / 1e-7);
+    }
+    __syncthreads();
+    if (g == 0) red[t] = contrib;
+    __syncthreads();
+    if (g == 0 && t == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < c; ++k) tot += red[k];
+        partial[b] = tot;
+    }
+}
+
+__global__ void dtw_dtemp_finish_kernel(const double* __restrict__ partial, const int B, const float coef, float* __restrict__ dst) {
+    double tot = 0.0;
+    for (int b = 0; b < B; ++b) tot += partial[b];
+    dst[0] += (float)((double)coef * tot);
+}
+
 // breadth-first index q -> depth-first position
 __device__ __forceinline__ int bf2df(const int q, const int L) {
     const int l = 31 - __clz(q + 1);
@@ -759,6 +892,27 @@ extern "C" int gcpx_soft_dtw(const float* dsum, float D, const float* temp, cons
     const int G = threads <= 256 ? 4 : (threads <= 512 ? 2 : 1);
     hipLaunchKernelGGL(dtw_combine_kernel, dim3(B), dim3(threads, G), G * threads * sizeof(float), stream, dsum, D, temp, end_ind, acc, w,
                        B, N, T);
+    GCPX_CHECK_LAUNCH();
+    return GCPX_OK;
+}
+
+extern "C" int gcpx_soft_dtw_dtemp(const float* dsum, float D, const float* temp, const int64_t* end_ind, const double* acc,
+                                   const float* pad_mask, const float* log_sigma, float coef, int32_t B, int32_t N, int32_t T,
+                                   double* tangent, double* partial, float* dtemp, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GCPX_CHECK_ARG(dsum && temp && end_ind && acc && pad_mask && log_sigma && tangent && partial && dtemp, "null pointer");
+    GCPX_CHECK_ARG(B > 0 && N >= T && T > 0, "needs at least as many nodes as frames (probabilistic_dtw.py:36)");
+    if (T > 1024) {
+        gcpx_set_error("gcpx_soft_dtw_dtemp: sequences longer than 1024 frames are not built");
+        return GCPX_ERR_UNSUPPORTED;
+    }
+    const int threads = (T + 63) / 64 * 64;
+    hipLaunchKernelGGL(dtw_tangent_sweep_kernel, dim3(2 * B), dim3(threads), 4 * threads * sizeof(double), stream, dsum, D, temp,
+                       end_ind, acc, tangent, B, N, T);
+    const int G = threads <= 256 ? 4 : (threads <= 512 ? 2 : 1);
+    hipLaunchKernelGGL(dtw_dtemp_combine_kernel, dim3(B), dim3(threads, G), 4 * G * threads * sizeof(double), stream, dsum, D, temp,
+                       end_ind, acc, tangent, pad_mask, log_sigma, partial, B, N, T);
+    hipLaunchKernelGGL(dtw_dtemp_finish_kernel, dim3(1), dim3(1), 0, stream, partial, B, coef, dtemp);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

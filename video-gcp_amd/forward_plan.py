@@ -647,6 +647,7 @@ class ForwardPlanMixin:
                 temp = self.sd["tree_module.tree_modules.0.binding.temp"]
                 plan.add("soft_dtw", lib.gcpx_soft_dtw, dsum.data_ptr(), C.c_float(float(row)), temp.data_ptr(), tin["end_ind"].data_ptr(),
                          B, N, T, self._buf("dtw.acc", (2 * B, N, T), torch.float64).data_ptr(), wdf.data_ptr())
+                outs["dtw_acc"] = self._buf("dtw.acc", (2 * B, N, T), torch.float64)
                 matched_idx = self._buf("matched_idx", (B, T), torch.int32)
                 best_t = self._buf("best_t", (B, N), torch.int32)
                 entropy, p_n = self._buf("entropy", (B, N)), self._buf("p_n", (B, N))

@@ -49,7 +49,8 @@ class GCPHParams:
     matching_type: str = "balanced"    # or "dtw_image" (adaptive binding, base_configs/gcp_adaptive.py:8)
     attentive_inference: bool = False  # base_configs/gcp_adaptive.py:10
     attention_temperature: float = 1.0  # hyperparameters.py:60 (learn_attn_temp=True: a parameter)
-    matching_temp: float = 1.0         # hyperparameters.py:94 (learn_matching_temp=False in gcp_adaptive.py:9)
+    matching_temp: float = 1.0         # hyperparameters.py:94
+    learn_matching_temp: bool = True   # hyperparameters.py:132 (adaptive binding only; base_configs/gcp_adaptive.py:9 turns it off)
     learned_pruning_threshold: float = 0.5   # hyperparameters.py:116
     top_bias: float = 1.0              # hyperparameters.py:100
     leaves_bias: float = 0.0           # hyperparameters.py:99
@@ -148,9 +149,10 @@ def config(name, **over):
         "c3": dict(batch_size=16, max_seq_len=80, img_sz=64),      # per-GPU shard of 128
         "c4": dict(batch_size=64, max_seq_len=80, img_sz=64),      # per-GPU shard of 512 candidates
         "c5": dict(batch_size=8, max_seq_len=200, img_sz=64,       # per-GPU shard of 64; adaptive binding + attentive
-                   matching_type="dtw_image", attentive_inference=True),       # inference (base_configs/gcp_adaptive.py:6-11)
+                   matching_type="dtw_image", attentive_inference=True,        # inference (base_configs/gcp_adaptive.py:6-11)
+                   learn_matching_temp=False),
         "c5s": dict(batch_size=2, max_seq_len=12, img_sz=32,       # small adaptive case for parity tests (L=4, N=15)
-                    matching_type="dtw_image", attentive_inference=True),
+                    matching_type="dtw_image", attentive_inference=True, learn_matching_temp=False),
         # the visual-MPC style flat predictor of base_configs/vmpc.py at the parity-test size (gcp_sequential only)
         "vmpc_s": dict(batch_size=2, max_seq_len=8, img_sz=32, action_conditioned_pred=True, non_goal_conditioned=True,
                        nz_vae=0, var_inf="deterministic"),

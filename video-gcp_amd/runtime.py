@@ -215,6 +215,7 @@ SYMBOLS = [
     ("gcpx_cdist_splits", C.c_int, [i64]),
     ("gcpx_cdist", C.c_int, [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp]),
     ("gcpx_soft_dtw", C.c_int, [vp, C.c_float, vp, vp, i32, i32, i32, vp, vp, vp]),
+    ("gcpx_soft_dtw_dtemp", C.c_int, [vp, C.c_float, vp, vp, vp, vp, vp, C.c_float, i32, i32, i32, vp, vp, vp, vp]),
     ("gcpx_match_stats", C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     ("gcpx_distance_prune", C.c_int, [vp, C.c_float, vp, i32, i32, vp, vp, vp, vp, vp]),
     ("gcpx_averaging_nll", C.c_int, [vp, vp, vp, C.c_float, i32, i32, i32, vp, vp]),
