@@ -60,6 +60,16 @@ class _Plan:
         ahead on a side lane hands over chunk by chunk instead of being joined at every step)"""
         self.ops.append(("@wait", None, (waiter, signaler, self._events(1)[0]), 0))
 
+    def record(self, lane):
+        """an event at lane's current position, for a LATER `await_event` on another lane (a chain that runs far ahead hands over
+        step by step to one that starts much later in plan order)"""
+        ev = self._events(1)[0]
+        self.ops.append(("@record", None, (lane, ev), 0))
+        return ev
+
+    def await_event(self, lane, ev):
+        self.ops.append(("@await", None, (lane, ev), 0))
+
     def mark(self, tag, payload):
         """a host-side callback point in the launch sequence (eager replay only): `run(..., on_mark=f)` calls f(tag, payload)"""
         self.ops.append(("@mark", None, (tag, payload), 0))
@@ -79,6 +89,10 @@ class _Plan:
                 waiter, signaler, ev = args
                 rt.check(lib.gcpx_event_record(ev, streams[signaler]), "wait")
                 rt.check(lib.gcpx_stream_wait_event(streams[waiter], ev), "wait")
+            elif name == "@record":
+                rt.check(lib.gcpx_event_record(args[1], streams[args[0]]), "record")
+            elif name == "@await":
+                rt.check(lib.gcpx_stream_wait_event(streams[args[0]], args[1]), "await")
             elif name == "@join":
                 lanes, evs = args
                 for l, e in zip(lanes, evs):

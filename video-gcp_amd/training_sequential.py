@@ -40,6 +40,7 @@ class SequentialTrainStep(GCPTrainStep):
         assert model._hp.context_every_step, "the recurrent nets are built with the (e_0, e_g) context at every step (hyperparameters.py default)"
         super().__init__(model, lr=lr, betas=betas, eps=eps, process_group=process_group, **optim)
         self.side_lanes = True
+        self.chains_overlap = __import__("os").environ.get("GCPX_SEQ_CHAINS", "overlap") == "overlap"
 
     # ------------------------------------------------------------------------------------------------
     def _pack_backward(self, sd):
@@ -77,6 +78,11 @@ class SequentialTrainStep(GCPTrainStep):
             p = f"dense_rec.lstm.cell.{net}"
             T_ = {"embed.wT": pk.pack_gemm(sd[f"{p}.embed.weight"].t().contiguous()),          # [n = in_dim][k = H]
                   "out.wT": pk.pack_gemm(sd[f"{p}.out.weight"].t().contiguous())}               # [n = H][k = out]
+            if net == "gen_lstm" and len(m._nets) > 1:
+                # the same weights twice along k: d out = [d x (decoder + generator terms) | d x (prior term)] @ [W^T; W^T] sums the two
+                # gradient sources of x_{t+1} inside the GEMM, so the generator chain need not wait for the prior chain's LAST step
+                wt = sd[f"{p}.out.weight"].t().contiguous()
+                T_["out.wT2"] = pk.pack_gemm(torch.cat([wt, wt], 1).contiguous())
             for i in range(hp.n_lstm_layers):
                 # d [x | h] = d gates @ [W_ih | W_hh]: both data gradients of a cell in one GEMM
                 w = torch.cat([sd[f"{p}.lstm.{i}.weight_ih"], sd[f"{p}.lstm.{i}.weight_hh"]], 1)          # [4H, 2H]
@@ -88,10 +94,12 @@ class SequentialTrainStep(GCPTrainStep):
     def _rows(self, plan, name, dst, dst_sb, dst_sr, src, src_sb, src_sr, B, rpb, width, mode):
         plan.add(name, self.m.lib.gcpx_rows_strided, dst, dst_sb, dst_sr, src, src_sb, src_sr, B, rpb, width, mode)
 
-    def _chain(self, plan, net, dout_of, B, T, dIn, nrec):
+    def _chain(self, plan, net, dout_of, B, T, dIn, nrec, events=None, before_step=None):
         """Backward of one recurrent net through all T - 1 steps, last step first.  dout_of(t) -> row source of the gradient of the
         step's output.  Writes dIn [B, T-1, in_dim] (gradient of every step's embedding input), the stacked gate gradients dG[i]
-        [(T-1) B, 4H] and embedding-output gradients DX0 [(T-1) B, 2H] (columns < H) for the weight gradients."""
+        [(T-1) B, 4H] and embedding-output gradients DX0 [(T-1) B, 2H] (columns < H) for the weight gradients.
+        dout_of(t) may return a LIST of row sources (summed by the doubled `out.wT2`).  events: dict filled with one recorded event per
+        finished step (on the lane the chain is issued on); before_step(t): called before step t's first launch."""
         m, hp, lib = self.m, self.m._hp, self.m.lib
         H, nl = hp.nz_mid_lstm, hp.n_lstm_layers
         rec, Wt = nrec["rec"], self.bk[net]
@@ -123,7 +131,11 @@ class SequentialTrainStep(GCPTrainStep):
                 a.M, a.H, a.rpb = B, H, 1
                 plan.keep.append(a)
                 cells.append(a)
-            self._dgemm(plan, f"{net}{t}.out", [dout_of(t)], B, H, 1, Wt["out.wT"], dtop.data_ptr(), H, 0,
+            if before_step is not None:
+                before_step(t)
+            dsrc = dout_of(t)
+            dsrc = dsrc if isinstance(dsrc, list) else [dsrc]
+            self._dgemm(plan, f"{net}{t}.out", dsrc, B, H, 1, Wt["out.wT" if len(dsrc) == 1 else "out.wT2"], dtop.data_ptr(), H, 0,
                         lstm_bwd=(cells[nl - 1] if fuse_cell else None))
             for i in reversed(range(nl)):
                 out_i = DX0[t] if i == 0 else dxh[i - 1]
@@ -133,6 +145,8 @@ class SequentialTrainStep(GCPTrainStep):
                             out_i.data_ptr(), 0, 2 * H, lstm_bwd=(cells[i - 1] if (fuse_cell and i > 0) else None))
             self._dgemm(plan, f"{net}{t}.embed", [m._rowsrc(DX0[t].data_ptr(), 2 * H, 0, H)], B, in_dim, 1, Wt["embed.wT"],
                         _addr(dIn, t * in_dim), (T - 1) * in_dim, 0)
+            if events is not None:
+                events[t] = plan.record(plan.lane)
             yield t
         nrec.setdefault("dG", {})[net] = dG
         nrec.setdefault("DX0", {})[net] = DX0
@@ -204,10 +218,16 @@ class SequentialTrainStep(GCPTrainStep):
             self._rows(plan, "bw.len.eg", dEG.data_ptr(), nz, 0, _addr(dXl, nz), 2 * nz, 0, B, 1, nz, 1)
 
         # ---- prior chain on a side lane (needs the KL gradient only), decoder backward on the main lane ----
+        # chains_overlap: the generator's step t needs the prior's input gradient of step t + 1 only, so it follows the prior chain
+        # step by step (one event per prior step) instead of waiting for its last one: the prior chain starts beside the decoder
+        # backward as before, the generator starts when the decoder backward ends, wherever the prior chain is by then
+        overlap = self.chains_overlap and not det
+        prior_done = {} if overlap else None
         plan.fork([1])
         plan.lane = 1
         if not det:
-            for _ in self._chain(plan, "prior_lstm", lambda t: m._rowsrc(_addr(dPZ, t * 2 * nv), (T - 1) * 2 * nv, 0, 2 * nv), B, T, dIn["prior_lstm"], nrec):
+            for _ in self._chain(plan, "prior_lstm", lambda t: m._rowsrc(_addr(dPZ, t * 2 * nv), (T - 1) * 2 * nv, 0, 2 * nv), B, T, dIn["prior_lstm"], nrec,
+                                 events=prior_done):
                 pass
         plan.lane = 0
         F = B * (T - 1)
@@ -220,13 +240,22 @@ class SequentialTrainStep(GCPTrainStep):
         row2frame_inv.copy_(inv.reshape(-1).to(torch.int32))
         dE_dec, dskip = self._decoder_backward(plan, fplan, dMD, B, maps=dict(R=B * T, row2src=row2frame, frame2row=rec["seq_row_map"],
                                                                                row2frame=row2frame_inv))
-        plan.join([1])
-        self._flush(plan, only_lane=2)                        # decoder weight gradients: on lane 2, beside the generator / inference chains
+        pd = in_dim["prior_lstm"]
+        prior_dx = lambda: self._rows(plan, "bw.prior.dx", DX.data_ptr(), T * nz, nz, dIn["prior_lstm"].data_ptr(), (T - 1) * pd, pd, B, T - 1, nz, 1)
+        if overlap:
+            # decoder weight gradients behind the prior chain on lane 1 (they are due at the end of the step only); lane 2 is the
+            # inference chain's
+            self._flush(plan, only_lane=1)
+            inf_lane = 2
+            plan.fork([inf_lane])
+        else:
+            plan.join([1])
+            self._flush(plan, only_lane=2)                    # decoder weight gradients: on lane 2, beside the generator / inference chains
+            inf_lane = 1
         # gradient of x_{t+1}, t = 0 .. T-2: decoder + the prior's input at step t + 1
         plan.add("bw.addrows.dec", lib.gcpx_add_rows, _addr(DX, nz), T * nz, nz, dE_dec.data_ptr(), None, B, T - 1, nz)
-        if not det:
-            pd = in_dim["prior_lstm"]
-            self._rows(plan, "bw.prior.dx", DX.data_ptr(), T * nz, nz, dIn["prior_lstm"].data_ptr(), (T - 1) * pd, pd, B, T - 1, nz, 1)
+        if not det and not overlap:
+            prior_dx()
 
         # ---- generator chain on the main lane, inference chain one step behind it on lane 1 ----
         # gen(t): the gradient of x_t is complete once step t has added its input gradient.  z_t = mu_q + exp(log_sigma_q) eps
@@ -236,20 +265,32 @@ class SequentialTrainStep(GCPTrainStep):
         gd = in_dim["gen_lstm"]
         inf_chain = iter(()) if det else \
             self._chain(plan, "inf_lstm", lambda t: m._rowsrc(DQ[t].data_ptr(), 2 * nv, 0, 2 * nv), B, T, dIn["inf_lstm"], nrec)
-        for t in self._chain(plan, "gen_lstm", lambda t: m._rowsrc(_addr(DX, (t + 1) * nz), T * nz, 0, nz), B, T, dIn["gen_lstm"], nrec):
+
+        def gen_dout(t):
+            own = m._rowsrc(_addr(DX, (t + 1) * nz), T * nz, 0, nz)
+            if not overlap or t + 1 > T - 2:                  # (the last frame is no input of the prior)
+                return own
+            return [own, m._rowsrc(_addr(dIn["prior_lstm"], (t + 1) * pd), (T - 1) * pd, 0, nz)]
+
+        def gen_before(t):
+            if overlap and t + 1 <= T - 2:
+                plan.await_event(0, prior_done[t + 1])
+        for t in self._chain(plan, "gen_lstm", gen_dout, B, T, dIn["gen_lstm"], nrec, before_step=gen_before):
             self._rows(plan, f"bw.gen.dx{t}", _addr(DX, t * nz), T * nz, 0, _addr(dIn["gen_lstm"], t * gd), (T - 1) * gd, 0, B, 1, nz, 1)
             if det:
                 continue
             plan.add(f"bw.latent{t}", lib.gcpx_latent_bwd, _addr(dQZ, t * 2 * nv), _addr(dPZ, t * 2 * nv), _addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 0,
                      _addr(tin["eps"], t * nv), tin["eps"].shape[1] * nv, 0, _addr(dIn["gen_lstm"], t * gd + nz), (T - 1) * gd, None, 0,
                      DQ[t].data_ptr(), DPd.data_ptr(), B, 1, nv)
-            plan.wait(1, 0)
-            plan.lane = 1
+            plan.wait(inf_lane, 0)
+            plan.lane = inf_lane
             next(inf_chain)
             plan.lane = 0
         for _ in inf_chain:                                   # (exhausts the generator: it records its stacked buffers on the way out)
             pass
-        plan.join([1])
+        plan.join([1, 2] if overlap else [1])
+        if overlap:
+            prior_dx()                                        # x_t's prior term joins DX for the weight gradients and the I_0 encoder
 
         # ---- weight gradients of the three nets: stacked rows r = (t, b) ----
         def stacked(t_stride, b_stride):
