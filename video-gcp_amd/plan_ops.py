@@ -74,6 +74,31 @@ class _Plan:
         """a host-side callback point in the launch sequence (eager replay only): `run(..., on_mark=f)` calls f(tag, payload)"""
         self.ops.append(("@mark", None, (tag, payload), 0))
 
+    def compact(self, streams, min_len=3):
+        """The op list with every run of >= min_len consecutive launches on ONE lane replaced by a captured linear graph (`@graph`):
+        lane order, events and marks stay what they are — only the host issues one call per run instead of one per launch."""
+        lib, out, run = self.lib, [], []
+
+        def flush():
+            if len(run) >= min_len:
+                st = streams[run[0][3]]
+                rt.check(lib.gcpx_graph_begin(st), "graph_begin")
+                for name, fn, args, _ in run:
+                    rt.check(fn(*args, st), name)
+                g = C.c_void_p()
+                rt.check(lib.gcpx_graph_end(st, C.byref(g)), "graph_end")
+                out.append(("@graph", None, (g, tuple(o[0] for o in run)), run[0][3]))
+            else:
+                out.extend(run)
+            run.clear()
+        for op in self.ops:
+            ctl = op[0].startswith("@")
+            if ctl or (run and op[3] != run[0][3]):
+                flush()
+            (out if ctl else run).append(op)
+        flush()
+        return out
+
     def run(self, streams, ops=None, on_mark=None):
         lib = self.lib
         for name, fn, args, lane in (self.ops if ops is None else ops):
@@ -89,6 +114,8 @@ class _Plan:
                 waiter, signaler, ev = args
                 rt.check(lib.gcpx_event_record(ev, streams[signaler]), "wait")
                 rt.check(lib.gcpx_stream_wait_event(streams[waiter], ev), "wait")
+            elif name == "@graph":
+                rt.check(lib.gcpx_graph_launch(args[0], streams[lane]), "graph_launch")
             elif name == "@record":
                 rt.check(lib.gcpx_event_record(args[1], streams[args[0]]), "record")
             elif name == "@await":

@@ -133,6 +133,8 @@ class GCPTrainStep(BackwardWeightsMixin, BackwardOpsMixin, BackwardPlanMixin, Ba
         # maps nodes of the critical chain onto the same hardware queue as multi-millisecond weight-gradient kernels and
         # serialises them (measured: 32.0 ms / step as a graph, 28.0 ms eager, c2).
         self.backward_graph = False
+        # GCPX_BWD_SEGMENTS=n: runs of >= n consecutive launches on one lane are replayed as small linear hipGraphs (plan_ops.compact)
+        self.segment_graphs = int(os.environ.get("GCPX_BWD_SEGMENTS", "0"))
         # posterior / prior / merge chains of a level on three lanes: measured SLOWER (30.0 vs 28.2 ms / step) — the side lanes are
         # busy with the previous level's weight gradients, so the forked chains queue behind them.  Kept for experiments.
         self.parallel_level_chains = False
@@ -171,7 +173,19 @@ class GCPTrainStep(BackwardWeightsMixin, BackwardOpsMixin, BackwardPlanMixin, Ba
             rt.check(m.lib.gcpx_graph_launch(bplan.graph, stream), "graph_launch")
         else:
             # (the caller's stream is the plan's last lane: the levels' merge chains, and step()'s early optimizer slices behind them)
-            bplan.run(self._backward_streams() + [caller.cuda_stream], on_mark=self._on_mark)
+            lanes = self._backward_streams() + [caller.cuda_stream]
+            ops = None
+            if self.segment_graphs and not bplan.rec.get("caller_lane"):
+                # runs of launches on one lane as small linear graphs (fewer host calls; lanes, events and marks unchanged)
+                if bplan.rec.get("_segments") is None:
+                    bplan.run(lanes, on_mark=self._on_mark)
+                    torch.cuda.synchronize(m.device)
+                    bplan.rec["_segments"] = bplan.compact(self._backward_streams(), self.segment_graphs)
+                    self.last_bplan = bplan
+                    caller.wait_stream(m._stream)
+                    return out
+                ops = bplan.rec["_segments"]
+            bplan.run(lanes, ops=ops, on_mark=self._on_mark)
         caller.wait_stream(m._stream)
         self.last_bplan = bplan
         return out

@@ -79,10 +79,11 @@ class SequentialTrainStep(GCPTrainStep):
             T_ = {"embed.wT": pk.pack_gemm(sd[f"{p}.embed.weight"].t().contiguous()),          # [n = in_dim][k = H]
                   "out.wT": pk.pack_gemm(sd[f"{p}.out.weight"].t().contiguous())}               # [n = H][k = out]
             if net == "gen_lstm" and len(m._nets) > 1:
-                # the same weights twice along k: d out = [d x (decoder + generator terms) | d x (prior term)] @ [W^T; W^T] sums the two
-                # gradient sources of x_{t+1} inside the GEMM, so the generator chain need not wait for the prior chain's LAST step
+                # the same weights three times along k: d out = [d x (decoder) | d x (prior's input) | d x (generator's input)] @ [W^T; W^T; W^T]
+                # sums the three gradient sources of x_{t+1} inside the GEMM: the generator chain need not wait for the prior chain's
+                # LAST step, and no add-rows launch sits between two of its steps
                 wt = sd[f"{p}.out.weight"].t().contiguous()
-                T_["out.wT2"] = pk.pack_gemm(torch.cat([wt, wt], 1).contiguous())
+                T_["out.wT3"] = pk.pack_gemm(torch.cat([wt, wt, wt], 1).contiguous())
             for i in range(hp.n_lstm_layers):
                 # d [x | h] = d gates @ [W_ih | W_hh]: both data gradients of a cell in one GEMM
                 w = torch.cat([sd[f"{p}.lstm.{i}.weight_ih"], sd[f"{p}.lstm.{i}.weight_hh"]], 1)          # [4H, 2H]
@@ -98,7 +99,7 @@ class SequentialTrainStep(GCPTrainStep):
         """Backward of one recurrent net through all T - 1 steps, last step first.  dout_of(t) -> row source of the gradient of the
         step's output.  Writes dIn [B, T-1, in_dim] (gradient of every step's embedding input), the stacked gate gradients dG[i]
         [(T-1) B, 4H] and embedding-output gradients DX0 [(T-1) B, 2H] (columns < H) for the weight gradients.
-        dout_of(t) may return a LIST of row sources (summed by the doubled `out.wT2`).  events: dict filled with one recorded event per
+        dout_of(t) may return a LIST of three row sources (summed by the tripled `out.wT3`).  events: dict filled with one recorded event per
         finished step (on the lane the chain is issued on); before_step(t): called before step t's first launch."""
         m, hp, lib = self.m, self.m._hp, self.m.lib
         H, nl = hp.nz_mid_lstm, hp.n_lstm_layers
@@ -135,7 +136,7 @@ class SequentialTrainStep(GCPTrainStep):
                 before_step(t)
             dsrc = dout_of(t)
             dsrc = dsrc if isinstance(dsrc, list) else [dsrc]
-            self._dgemm(plan, f"{net}{t}.out", dsrc, B, H, 1, Wt["out.wT" if len(dsrc) == 1 else "out.wT2"], dtop.data_ptr(), H, 0,
+            self._dgemm(plan, f"{net}{t}.out", dsrc, B, H, 1, Wt["out.wT" if len(dsrc) == 1 else "out.wT3"], dtop.data_ptr(), H, 0,
                         lstm_bwd=(cells[nl - 1] if fuse_cell else None))
             for i in reversed(range(nl)):
                 out_i = DX0[t] if i == 0 else dxh[i - 1]
@@ -270,19 +271,25 @@ class SequentialTrainStep(GCPTrainStep):
             own = m._rowsrc(_addr(DX, (t + 1) * nz), T * nz, 0, nz)
             if not overlap or t + 1 > T - 2:                  # (the last frame is no input of the prior)
                 return own
-            return [own, m._rowsrc(_addr(dIn["prior_lstm"], (t + 1) * pd), (T - 1) * pd, 0, nz)]
+            return [own, m._rowsrc(_addr(dIn["prior_lstm"], (t + 1) * pd), (T - 1) * pd, 0, nz),
+                    m._rowsrc(_addr(dIn["gen_lstm"], (t + 1) * gd), (T - 1) * gd, 0, nz)]
 
         def gen_before(t):
             if overlap and t + 1 <= T - 2:
                 plan.await_event(0, prior_done[t + 1])
         for t in self._chain(plan, "gen_lstm", gen_dout, B, T, dIn["gen_lstm"], nrec, before_step=gen_before):
-            self._rows(plan, f"bw.gen.dx{t}", _addr(DX, t * nz), T * nz, 0, _addr(dIn["gen_lstm"], t * gd), (T - 1) * gd, 0, B, 1, nz, 1)
+            if not overlap:
+                self._rows(plan, f"bw.gen.dx{t}", _addr(DX, t * nz), T * nz, 0, _addr(dIn["gen_lstm"], t * gd), (T - 1) * gd, 0, B, 1, nz, 1)
             if det:
                 continue
+            if overlap:                                       # the sample's backward feeds the inference chain only: on its lane
+                plan.wait(inf_lane, 0)
+                plan.lane = inf_lane
             plan.add(f"bw.latent{t}", lib.gcpx_latent_bwd, _addr(dQZ, t * 2 * nv), _addr(dPZ, t * 2 * nv), _addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 0,
                      _addr(tin["eps"], t * nv), tin["eps"].shape[1] * nv, 0, _addr(dIn["gen_lstm"], t * gd + nz), (T - 1) * gd, None, 0,
                      DQ[t].data_ptr(), DPd.data_ptr(), B, 1, nv)
-            plan.wait(inf_lane, 0)
+            if not overlap:
+                plan.wait(inf_lane, 0)
             plan.lane = inf_lane
             next(inf_chain)
             plan.lane = 0
@@ -290,7 +297,9 @@ class SequentialTrainStep(GCPTrainStep):
             pass
         plan.join([1, 2] if overlap else [1])
         if overlap:
-            prior_dx()                                        # x_t's prior term joins DX for the weight gradients and the I_0 encoder
+            # x_t's prior and generator terms join DX for the weight gradients and the I_0 encoder
+            prior_dx()
+            self._rows(plan, "bw.gen.dx", DX.data_ptr(), T * nz, nz, dIn["gen_lstm"].data_ptr(), (T - 1) * gd, gd, B, T - 1, nz, 1)
 
         # ---- weight gradients of the three nets: stacked rows r = (t, b) ----
         def stacked(t_stride, b_stride):
