@@ -222,15 +222,16 @@ class BackwardOpsMixin:
             self._side(plan, f"bw.creduce:{tag}", lib.gcpx_wgrad_reduce, part.data_ptr(), nsplit, N, 1, dst, rt.WMAP_CONV, 1, 1, 0,
                        n_map.data_ptr(), 0, 0, 1)
 
-    def _dgemm(self, plan, tag, srcs, M, N, rpb, wpk, out, ob, orow, batch=None, lstm_bwd=None):
+    def _dgemm(self, plan, tag, srcs, M, N, rpb, wpk, out, ob, orow, batch=None, lstm_bwd=None, group=None):
         """data-gradient GEMM: out = concat(srcs) @ packed(W^T).  lstm_bwd: LstmBwdArgs of the LSTM layer this gradient is the d h of —
-        its cell backward then runs in the GEMM's epilogue (gcpx_gemm_args.lstm_bwd) instead of a launch of its own."""
+        its cell backward then runs in the GEMM's epilogue (gcpx_gemm_args.lstm_bwd) instead of a launch of its own.  group: a list —
+        the problem is appended to it instead of being launched (`_gemm_group` issues the list as one launch)."""
         dev = None
         if lstm_bwd is not None:
             t = torch.frombuffer(bytearray(bytes(lstm_bwd)), dtype=torch.uint8).to(self.m.device)
             plan.keep += [t, lstm_bwd]
             dev = t.data_ptr()
-        self.m._gemm(plan, f"bw.dgrad:{tag}", srcs, M, N, rpb, wpk, None, out=out, ob=ob, orow=orow, batch=batch, lstm_bwd=dev)
+        self.m._gemm(plan, f"bw.dgrad:{tag}", srcs, M, N, rpb, wpk, None, out=out, ob=ob, orow=orow, batch=batch, lstm_bwd=dev, group=group)
 
     def _dense(self, ptr, ld, width, M):
         return self.m._rowsrc(ptr, M * ld, ld, width)

@@ -74,10 +74,12 @@ class _Plan:
         """a host-side callback point in the launch sequence (eager replay only): `run(..., on_mark=f)` calls f(tag, payload)"""
         self.ops.append(("@mark", None, (tag, payload), 0))
 
-    def compact(self, streams, min_len=3):
+    def compact(self, streams, min_len=3, ranges=None):
         """The op list with every run of >= min_len consecutive launches on ONE lane replaced by a captured linear graph (`@graph`):
-        lane order, events and marks stay what they are — only the host issues one call per run instead of one per launch."""
+        lane order, events and marks stay what they are — only the host issues one call per run instead of one per launch.
+        ranges: [(first, end)] index ranges of self.ops to look at (None: everywhere)."""
         lib, out, run = self.lib, [], []
+        inside = (lambda i: True) if ranges is None else (lambda i: any(a <= i < b for a, b in ranges))
 
         def flush():
             if len(run) >= min_len:
@@ -91,8 +93,8 @@ class _Plan:
             else:
                 out.extend(run)
             run.clear()
-        for op in self.ops:
-            ctl = op[0].startswith("@")
+        for i, op in enumerate(self.ops):
+            ctl = op[0].startswith("@") or not inside(i)
             if ctl or (run and op[3] != run[0][3]):
                 flush()
             (out if ctl else run).append(op)

@@ -133,7 +133,8 @@ class GCPTrainStep(BackwardWeightsMixin, BackwardOpsMixin, BackwardPlanMixin, Ba
         # maps nodes of the critical chain onto the same hardware queue as multi-millisecond weight-gradient kernels and
         # serialises them (measured: 32.0 ms / step as a graph, 28.0 ms eager, c2).
         self.backward_graph = False
-        # GCPX_BWD_SEGMENTS=n: runs of >= n consecutive launches on one lane are replayed as small linear hipGraphs (plan_ops.compact)
+        # GCPX_BWD_SEGMENTS=n > 0: EVERY run of >= n consecutive launches on one lane is replayed as a small linear hipGraph
+        # (plan_ops.compact); 0: only where the plan asks for it (rec["segment_ranges"]); -1: nowhere
         self.segment_graphs = int(os.environ.get("GCPX_BWD_SEGMENTS", "0"))
         # posterior / prior / merge chains of a level on three lanes: measured SLOWER (30.0 vs 28.2 ms / step) — the side lanes are
         # busy with the previous level's weight gradients, so the forked chains queue behind them.  Kept for experiments.
@@ -175,12 +176,14 @@ class GCPTrainStep(BackwardWeightsMixin, BackwardOpsMixin, BackwardPlanMixin, Ba
             # (the caller's stream is the plan's last lane: the levels' merge chains, and step()'s early optimizer slices behind them)
             lanes = self._backward_streams() + [caller.cuda_stream]
             ops = None
-            if self.segment_graphs and not bplan.rec.get("caller_lane"):
-                # runs of launches on one lane as small linear graphs (fewer host calls; lanes, events and marks unchanged)
+            seg_ranges = None if self.segment_graphs > 0 else bplan.rec.get("segment_ranges")
+            if (self.segment_graphs > 0 or (seg_ranges and self.segment_graphs == 0)) and not bplan.rec.get("caller_lane"):
+                # runs of launches on one lane as small linear graphs (fewer host calls; lanes, events and marks unchanged): everywhere
+                # (GCPX_BWD_SEGMENTS=n) or where the plan asks for it (`segment_ranges`: chains with slack, GCPX_BWD_SEGMENTS=-1: nowhere)
                 if bplan.rec.get("_segments") is None:
                     bplan.run(lanes, on_mark=self._on_mark)
                     torch.cuda.synchronize(m.device)
-                    bplan.rec["_segments"] = bplan.compact(self._backward_streams(), self.segment_graphs)
+                    bplan.rec["_segments"] = bplan.compact(self._backward_streams(), max(self.segment_graphs, 3), seg_ranges)
                     self.last_bplan = bplan
                     caller.wait_stream(m._stream)
                     return out

@@ -40,7 +40,11 @@ class SequentialTrainStep(GCPTrainStep):
         assert model._hp.context_every_step, "the recurrent nets are built with the (e_0, e_g) context at every step (hyperparameters.py default)"
         super().__init__(model, lr=lr, betas=betas, eps=eps, process_group=process_group, **optim)
         self.side_lanes = True
-        self.chains_overlap = __import__("os").environ.get("GCPX_SEQ_CHAINS", "overlap") == "overlap"
+        # GCPX_SEQ_CHAINS: "lockstep" (default): prior chain ahead on its own lane, generator step t and inference step t + 1 in the SAME
+        # five launches (gcpx_gemm_group) on the main lane; "overlap": three lanes, step-by-step events; "serial": round-5 order
+        mode = __import__("os").environ.get("GCPX_SEQ_CHAINS", "lockstep")
+        self.chains_overlap = mode in ("overlap", "lockstep")
+        self.chains_lockstep = mode == "lockstep"
 
     # ------------------------------------------------------------------------------------------------
     def _pack_backward(self, sd):
@@ -95,12 +99,14 @@ class SequentialTrainStep(GCPTrainStep):
     def _rows(self, plan, name, dst, dst_sb, dst_sr, src, src_sb, src_sr, B, rpb, width, mode):
         plan.add(name, self.m.lib.gcpx_rows_strided, dst, dst_sb, dst_sr, src, src_sb, src_sr, B, rpb, width, mode)
 
-    def _chain(self, plan, net, dout_of, B, T, dIn, nrec, events=None, before_step=None):
+    def _chain(self, plan, net, dout_of, B, T, dIn, nrec, events=None, before_step=None, slots=None, event_every=1):
         """Backward of one recurrent net through all T - 1 steps, last step first.  dout_of(t) -> row source of the gradient of the
         step's output.  Writes dIn [B, T-1, in_dim] (gradient of every step's embedding input), the stacked gate gradients dG[i]
         [(T-1) B, 4H] and embedding-output gradients DX0 [(T-1) B, 2H] (columns < H) for the weight gradients.
         dout_of(t) may return a LIST of three row sources (summed by the tripled `out.wT3`).  events: dict filled with one recorded event per
-        finished step (on the lane the chain is issued on); before_step(t): called before step t's first launch."""
+        finished step (on the lane the chain is issued on; event_every = n: only behind steps t % n == 0); before_step(t): called before
+        step t's first launch.  slots: nl + 2 lists — the step's GEMMs (cell backward in their epilogues) are appended to them, one per
+        dependent launch of the step, instead of being launched: the caller groups them with another chain's (`_gemm_group`)."""
         m, hp, lib = self.m, self.m._hp, self.m.lib
         H, nl = hp.nz_mid_lstm, hp.n_lstm_layers
         rec, Wt = nrec["rec"], self.bk[net]
@@ -111,7 +117,8 @@ class SequentialTrainStep(GCPTrainStep):
         DX0 = buf(f"bw.{net}.dxh0", (T - 1, B, 2 * H))                                 # layer 0: kept per step (embedding weight gradient)
         dtop = buf(f"bw.{net}.dtop", (B, H))
         dcrec = [buf(f"bw.{net}.dc{i}", (B, 2 * H)) for i in range(nl)]                 # (pitch 2H: addressed with the strides of [h | c])
-        fuse_cell = self.fuse_lstm_bwd        # a layer's cell backward in the epilogue of the GEMM that produces its d h (training.py)
+        fuse_cell = self.fuse_lstm_bwd or slots is not None   # a layer's cell backward in the epilogue of the GEMM that produces its d h (training.py)
+        slot = (lambda k: slots[k]) if slots is not None else (lambda k: None)
         for t in reversed(range(T - 1)):
             last = t == T - 2
             cells = []
@@ -137,16 +144,16 @@ class SequentialTrainStep(GCPTrainStep):
             dsrc = dout_of(t)
             dsrc = dsrc if isinstance(dsrc, list) else [dsrc]
             self._dgemm(plan, f"{net}{t}.out", dsrc, B, H, 1, Wt["out.wT" if len(dsrc) == 1 else "out.wT3"], dtop.data_ptr(), H, 0,
-                        lstm_bwd=(cells[nl - 1] if fuse_cell else None))
+                        lstm_bwd=(cells[nl - 1] if fuse_cell else None), group=slot(0))
             for i in reversed(range(nl)):
                 out_i = DX0[t] if i == 0 else dxh[i - 1]
                 if not fuse_cell:
                     plan.add(f"bw.lstm:{net}{t}.{i}", lib.gcpx_lstm_bwd, C.byref(cells[i]))
                 self._dgemm(plan, f"{net}{t}.lstm{i}", [self._dense(dG[i][t].data_ptr(), 4 * H, 4 * H, B)], B, 2 * H, B, Wt[f"lstm{i}.wxhT"],
-                            out_i.data_ptr(), 0, 2 * H, lstm_bwd=(cells[i - 1] if (fuse_cell and i > 0) else None))
+                            out_i.data_ptr(), 0, 2 * H, lstm_bwd=(cells[i - 1] if (fuse_cell and i > 0) else None), group=slot(nl - i))
             self._dgemm(plan, f"{net}{t}.embed", [m._rowsrc(DX0[t].data_ptr(), 2 * H, 0, H)], B, in_dim, 1, Wt["embed.wT"],
-                        _addr(dIn, t * in_dim), (T - 1) * in_dim, 0)
-            if events is not None:
+                        _addr(dIn, t * in_dim), (T - 1) * in_dim, 0, group=slot(nl + 1))
+            if events is not None and t % event_every == 0:
                 events[t] = plan.record(plan.lane)
             yield t
         nrec.setdefault("dG", {})[net] = dG
@@ -223,14 +230,26 @@ class SequentialTrainStep(GCPTrainStep):
         # step by step (one event per prior step) instead of waiting for its last one: the prior chain starts beside the decoder
         # backward as before, the generator starts when the decoder backward ends, wherever the prior chain is by then
         overlap = self.chains_overlap and not det
+        lockstep = overlap and self.chains_lockstep
         prior_done = {} if overlap else None
-        plan.fork([1])
-        plan.lane = 1
-        if not det:
-            for _ in self._chain(plan, "prior_lstm", lambda t: m._rowsrc(_addr(dPZ, t * 2 * nv), (T - 1) * 2 * nv, 0, 2 * nv), B, T, dIn["prior_lstm"], nrec,
-                                 events=prior_done):
-                pass
-        plan.lane = 0
+        PE = 4 if lockstep else 1                             # the prior chain hands over every PE steps (it is far ahead anyway)
+
+        def prior_chain():
+            plan.lane = 1
+            i0 = len(plan.ops)
+            if not det:
+                for _ in self._chain(plan, "prior_lstm", lambda t: m._rowsrc(_addr(dPZ, t * 2 * nv), (T - 1) * 2 * nv, 0, 2 * nv), B, T, dIn["prior_lstm"],
+                                     nrec, events=prior_done, event_every=PE):
+                    pass
+            plan.lane = 0
+            return i0
+        if overlap:
+            # the HOST issues the plan in order: the decoder backward's launches go out first (the main lane starts at once), the prior
+            # chain's ~870 host calls follow while the device is busy with them; lane 1 starts from where the main lane stood HERE
+            prior_start = plan.record(0)
+        else:
+            plan.fork([1])
+            prior_chain()
         F = B * (T - 1)
         row2frame = buf("bw.seq.row2frame", (B * T,), torch.int32)       # row (b, t) of the matched arrays <- decoded frame (b, t - 1); (b, 0): none
         r2f = torch.arange(B * T, dtype=torch.int64).view(B, T)
@@ -244,6 +263,11 @@ class SequentialTrainStep(GCPTrainStep):
         pd = in_dim["prior_lstm"]
         prior_dx = lambda: self._rows(plan, "bw.prior.dx", DX.data_ptr(), T * nz, nz, dIn["prior_lstm"].data_ptr(), (T - 1) * pd, pd, B, T - 1, nz, 1)
         if overlap:
+            plan.await_event(1, prior_start)
+            i0 = prior_chain()
+            # the prior chain has hours of slack (it runs beside the decoder backward and only has to stay ahead of the generator): its
+            # steps are replayed as small linear graphs, one host call per step instead of eight (training.py: segment_ranges)
+            plan.rec.setdefault("segment_ranges", []).append((i0, len(plan.ops)))
             # decoder weight gradients behind the prior chain on lane 1 (they are due at the end of the step only); lane 2 is the
             # inference chain's
             self._flush(plan, only_lane=1)
@@ -274,10 +298,38 @@ class SequentialTrainStep(GCPTrainStep):
             return [own, m._rowsrc(_addr(dIn["prior_lstm"], (t + 1) * pd), (T - 1) * pd, 0, nz),
                     m._rowsrc(_addr(dIn["gen_lstm"], (t + 1) * gd), (T - 1) * gd, 0, nz)]
 
+        awaited = set()
+
         def gen_before(t):
             if overlap and t + 1 <= T - 2:
-                plan.await_event(0, prior_done[t + 1])
-        for t in self._chain(plan, "gen_lstm", gen_dout, B, T, dIn["gen_lstm"], nrec, before_step=gen_before):
+                tp = (t + 1) // PE * PE                        # the hand-over that covers the prior's step t + 1 (it counts t downwards)
+                if tp not in awaited:
+                    awaited.add(tp)
+                    plan.await_event(0, prior_done[tp])
+
+        def latent(t):
+            plan.add(f"bw.latent{t}", lib.gcpx_latent_bwd, _addr(dQZ, t * 2 * nv), _addr(dPZ, t * 2 * nv), _addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 0,
+                     _addr(tin["eps"], t * nv), tin["eps"].shape[1] * nv, 0, _addr(dIn["gen_lstm"], t * gd + nz), (T - 1) * gd, None, 0,
+                     DQ[t].data_ptr(), DPd.data_ptr(), B, 1, nv)
+        if lockstep:
+            # super-step k: generator step T-2-k and inference step T-1-k (one behind: it needs that step's d z) share five launches on
+            # the main lane — no lane of its own, no events between the two chains
+            slots = [[] for _ in range(nl + 2)]
+            gen_chain = self._chain(plan, "gen_lstm", gen_dout, B, T, dIn["gen_lstm"], nrec, before_step=gen_before, slots=slots)
+            inf_chain = self._chain(plan, "inf_lstm", lambda t: m._rowsrc(DQ[t].data_ptr(), 2 * nv, 0, 2 * nv), B, T, dIn["inf_lstm"], nrec, slots=slots)
+            for k in range(T):
+                if k < T - 1:
+                    next(gen_chain)
+                if k >= 1:
+                    latent(T - 1 - k)
+                    next(inf_chain)
+                for j, g in enumerate(slots):
+                    m._gemm_group(plan, f"bw.dgrad:gen{T - 2 - k}+inf{T - 1 - k}.{j}", list(g))
+                    g.clear()
+            for ch in (gen_chain, inf_chain):
+                for _ in ch:                                  # (exhausts the generators: they record their stacked buffers on the way out)
+                    pass
+        for t in (() if lockstep else self._chain(plan, "gen_lstm", gen_dout, B, T, dIn["gen_lstm"], nrec, before_step=gen_before)):
             if not overlap:
                 self._rows(plan, f"bw.gen.dx{t}", _addr(DX, t * nz), T * nz, 0, _addr(dIn["gen_lstm"], t * gd), (T - 1) * gd, 0, B, 1, nz, 1)
             if det:
@@ -285,9 +337,7 @@ class SequentialTrainStep(GCPTrainStep):
             if overlap:                                       # the sample's backward feeds the inference chain only: on its lane
                 plan.wait(inf_lane, 0)
                 plan.lane = inf_lane
-            plan.add(f"bw.latent{t}", lib.gcpx_latent_bwd, _addr(dQZ, t * 2 * nv), _addr(dPZ, t * 2 * nv), _addr(QZ, t * 2 * nv), (T - 1) * 2 * nv, 0,
-                     _addr(tin["eps"], t * nv), tin["eps"].shape[1] * nv, 0, _addr(dIn["gen_lstm"], t * gd + nz), (T - 1) * gd, None, 0,
-                     DQ[t].data_ptr(), DPd.data_ptr(), B, 1, nv)
+            latent(t)
             if not overlap:
                 plan.wait(inf_lane, 0)
             plan.lane = inf_lane
