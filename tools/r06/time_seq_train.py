@@ -21,4 +21,4 @@ for rep in range(3):
     for _ in range(10):
         h0 = time.perf_counter(); tr.step(dev); th += time.perf_counter() - h0
     torch.cuda.synchronize()
-    print(f"GCPX_SEQ_CHAINS={os.environ.get('GCPX_SEQ_CHAINS', 'overlap')} width {hp.nz_mid_lstm}: {(time.perf_counter() - t0) * 100:.2f} ms / step (host {th * 100:.2f})", flush=True)
+    print(f"GCPX_SEQ_CHAINS={os.environ.get('GCPX_SEQ_CHAINS', 'lockstep')} width {hp.nz_mid_lstm}: {(time.perf_counter() - t0) * 100:.2f} ms / step (host {th * 100:.2f})", flush=True)

@@ -225,6 +225,44 @@ class SequentialTrainStep(GCPTrainStep):
             self._rows(plan, "bw.len.e0", DX.data_ptr(), T * nz, 0, dXl.data_ptr(), 2 * nz, 0, B, 1, nz, 1)
             self._rows(plan, "bw.len.eg", dEG.data_ptr(), nz, 0, _addr(dXl, nz), 2 * nz, 0, B, 1, nz, 1)
 
+        DQ, DPd = buf("bw.seq.DQ", (T - 1, B, 2 * nv)), buf("bw.seq.DPd", (B, 2 * nv))
+        # ---- weight gradients of a recurrent net: ONE GEMM per weight over the stacked rows r = (t, b) of all its steps ----
+        def stacked(t_stride, b_stride):
+            return dict(rpb=B, sb=t_stride, sr=b_stride)
+        e0s = dict(ptr=_addr(X), **stacked(0, T * nz))
+        egs = dict(ptr=_addr(EG), **stacked(0, nz))
+        eas = [dict(ptr=_addr(EA), w=nz, **stacked(nz, (T - 1) * nz))] if EA is not None else []
+        zs_ = [dict(ptr=_addr(Z), w=nv, **stacked(nv, (T - 1) * nv))] if not det else []
+        srcs = {"gen_lstm": [dict(ptr=_addr(X), w=nz, **stacked(nz, T * nz))] + zs_ + [dict(w=nz, **e0s), dict(w=nz, **egs)] + eas}
+        if not det:
+            srcs["prior_lstm"] = [dict(ptr=_addr(X), w=nz, **stacked(nz, T * nz)), dict(w=nz, **e0s), dict(w=nz, **egs)] + eas
+            srcs["inf_lstm"] = [dict(ptr=_addr(enc_traj, nz), w=nz, **stacked(nz, T * nz)), dict(w=nz, **e0s), dict(w=nz, **egs)] + eas
+        # (gradient of a net's output, rows (t, b): pointer, pitch of b, stride of t — 0 = dense t-major rows —, width)
+        douts = {"prior_lstm": (dPZ.data_ptr(), (T - 1) * 2 * nv, 2 * nv, 2 * nv), "inf_lstm": (DQ.data_ptr(), 2 * nv, 0, 2 * nv),
+                 "gen_lstm": (_addr(DX, nz), T * nz, nz, nz)}
+        R = (T - 1) * B
+        wgrads_out = set()
+
+        def net_wgrads(net):
+            wgrads_out.add(net)
+            p = f"dense_rec.lstm.cell.{net}"
+            XS, S = sq["XS"][net], sq["S"][net]
+            dG, DX0 = nrec["dG"][net], nrec["DX0"][net]
+            dy, ldy, dy_sb, N_out = douts[net]
+            self._wgrad(plan, f"{net}.out", dy, ldy, R, N_out, XS[0, nl].data_ptr(), H, self.g(f"{p}.out.weight"), ldw=H, rpb=B,
+                        sb=(nl + 1) * B * H, sr=H, dy_rpb=(B if dy_sb else 0), dy_sb=dy_sb, dbias=self.g(f"{p}.out.bias"))
+            for i in range(nl):
+                self._wgrad(plan, f"{net}.lstm{i}.ih", dG[i].data_ptr(), 4 * H, R, 4 * H, XS[0, i].data_ptr(), H, self.g(f"{p}.lstm.{i}.weight_ih"),
+                            ldw=H, rpb=B, sb=(nl + 1) * B * H, sr=H, dbias=self.g(f"{p}.lstm.{i}.bias_ih"), dbias2=self.g(f"{p}.lstm.{i}.bias_hh"))
+                self._wgrad(plan, f"{net}.lstm{i}.hh", dG[i].data_ptr(), 4 * H, R, 4 * H, S[0, i].data_ptr(), H, self.g(f"{p}.lstm.{i}.weight_hh"),
+                            ldw=H, rpb=B, sb=nl * B * 2 * H, sr=2 * H)
+            koff = 0
+            for k, sc in enumerate(srcs[net]):
+                self._wgrad(plan, f"{net}.embed{k}", DX0.data_ptr(), 2 * H, R, H, sc["ptr"], sc["w"], self.g(f"{p}.embed.weight"),
+                            ldw=in_dim[net], k_off=koff, rpb=sc["rpb"], sb=sc["sb"], sr=sc["sr"],
+                            dbias=(self.g(f"{p}.embed.bias") if k == 0 else None))
+                koff += sc["w"]
+
         # ---- prior chain on a side lane (needs the KL gradient only), decoder backward on the main lane ----
         # chains_overlap: the generator's step t needs the prior's input gradient of step t + 1 only, so it follows the prior chain
         # step by step (one event per prior step) instead of waiting for its last one: the prior chain starts beside the decoder
@@ -268,6 +306,8 @@ class SequentialTrainStep(GCPTrainStep):
             # the prior chain has hours of slack (it runs beside the decoder backward and only has to stay ahead of the generator): its
             # steps are replayed as small linear graphs, one host call per step instead of eight (training.py: segment_ranges)
             plan.rec.setdefault("segment_ranges", []).append((i0, len(plan.ops)))
+            net_wgrads("prior_lstm")                          # due at the end of the step: behind the chain on its lane, with the decoder's
+                                                              # (measured: no gain, no loss — the tail is the trajectory encoder's backward)
             # decoder weight gradients behind the prior chain on lane 1 (they are due at the end of the step only); lane 2 is the
             # inference chain's
             self._flush(plan, only_lane=1)
@@ -286,7 +326,6 @@ class SequentialTrainStep(GCPTrainStep):
         # gen(t): the gradient of x_t is complete once step t has added its input gradient.  z_t = mu_q + exp(log_sigma_q) eps
         # (sequential.py:51-54): step t's d z_t turns into d q_t right away (one tiny launch), lane 1 waits for exactly that and runs the
         # inference net's step t while the generator goes on to step t - 1 — the two 79-step chains overlap instead of queueing.
-        DQ, DPd = buf("bw.seq.DQ", (T - 1, B, 2 * nv)), buf("bw.seq.DPd", (B, 2 * nv))
         gd = in_dim["gen_lstm"]
         inf_chain = iter(()) if det else \
             self._chain(plan, "inf_lstm", lambda t: m._rowsrc(DQ[t].data_ptr(), 2 * nv, 0, 2 * nv), B, T, dIn["inf_lstm"], nrec)
@@ -351,39 +390,10 @@ class SequentialTrainStep(GCPTrainStep):
             prior_dx()
             self._rows(plan, "bw.gen.dx", DX.data_ptr(), T * nz, nz, dIn["gen_lstm"].data_ptr(), (T - 1) * gd, gd, B, T - 1, nz, 1)
 
-        # ---- weight gradients of the three nets: stacked rows r = (t, b) ----
-        def stacked(t_stride, b_stride):
-            return dict(rpb=B, sb=t_stride, sr=b_stride)
-        e0s = dict(ptr=_addr(X), **stacked(0, T * nz))
-        egs = dict(ptr=_addr(EG), **stacked(0, nz))
-        eas = [dict(ptr=_addr(EA), w=nz, **stacked(nz, (T - 1) * nz))] if EA is not None else []
-        zs_ = [dict(ptr=_addr(Z), w=nv, **stacked(nv, (T - 1) * nv))] if not det else []
-        srcs = {"gen_lstm": [dict(ptr=_addr(X), w=nz, **stacked(nz, T * nz))] + zs_ + [dict(w=nz, **e0s), dict(w=nz, **egs)] + eas}
-        if not det:
-            srcs["prior_lstm"] = [dict(ptr=_addr(X), w=nz, **stacked(nz, T * nz)), dict(w=nz, **e0s), dict(w=nz, **egs)] + eas
-            srcs["inf_lstm"] = [dict(ptr=_addr(enc_traj, nz), w=nz, **stacked(nz, T * nz)), dict(w=nz, **e0s), dict(w=nz, **egs)] + eas
-        # (gradient of a net's output, rows (t, b): pointer, pitch of b, stride of t — 0 = dense t-major rows —, width)
-        douts = {"prior_lstm": (dPZ.data_ptr(), (T - 1) * 2 * nv, 2 * nv, 2 * nv), "inf_lstm": (DQ.data_ptr(), 2 * nv, 0, 2 * nv),
-                 "gen_lstm": (_addr(DX, nz), T * nz, nz, nz)}
-        R = (T - 1) * B
+        # ---- weight gradients of the generator's and the inference net's chains (the prior's went out behind its chain) ----
         for net in NETS:
-            p = f"dense_rec.lstm.cell.{net}"
-            XS, S = sq["XS"][net], sq["S"][net]
-            dG, DX0 = nrec["dG"][net], nrec["DX0"][net]
-            dy, ldy, dy_sb, N_out = douts[net]
-            self._wgrad(plan, f"{net}.out", dy, ldy, R, N_out, XS[0, nl].data_ptr(), H, self.g(f"{p}.out.weight"), ldw=H, rpb=B,
-                        sb=(nl + 1) * B * H, sr=H, dy_rpb=(B if dy_sb else 0), dy_sb=dy_sb, dbias=self.g(f"{p}.out.bias"))
-            for i in range(nl):
-                self._wgrad(plan, f"{net}.lstm{i}.ih", dG[i].data_ptr(), 4 * H, R, 4 * H, XS[0, i].data_ptr(), H, self.g(f"{p}.lstm.{i}.weight_ih"),
-                            ldw=H, rpb=B, sb=(nl + 1) * B * H, sr=H, dbias=self.g(f"{p}.lstm.{i}.bias_ih"), dbias2=self.g(f"{p}.lstm.{i}.bias_hh"))
-                self._wgrad(plan, f"{net}.lstm{i}.hh", dG[i].data_ptr(), 4 * H, R, 4 * H, S[0, i].data_ptr(), H, self.g(f"{p}.lstm.{i}.weight_hh"),
-                            ldw=H, rpb=B, sb=nl * B * 2 * H, sr=2 * H)
-            koff = 0
-            for k, sc in enumerate(srcs[net]):
-                self._wgrad(plan, f"{net}.embed{k}", DX0.data_ptr(), 2 * H, R, H, sc["ptr"], sc["w"], self.g(f"{p}.embed.weight"),
-                            ldw=in_dim[net], k_off=koff, rpb=sc["rpb"], sb=sc["sb"], sr=sc["sr"],
-                            dbias=(self.g(f"{p}.embed.bias") if k == 0 else None))
-                koff += sc["w"]
+            if net not in wgrads_out:
+                net_wgrads(net)
         self._flush(plan)
 
         # ---- context and x_0 gradients -> the I_0 / I_g encoder outputs; inference inputs -> the trajectory encoder ----
