@@ -71,6 +71,55 @@ class GCPSequentialModel(GCPTreeModel):
                 self.pk[net]["lstm0ff.w"], self.pk[net]["lstm0ff.b"] = pk.pack_gemm(w), b
 
     # ------------------------------------------------------------------------------------------------
+    # A trainer's model keeps the folded packs too (GCPX_SEQ_LIVE_FOLDS=0: not): they are products of parameters, which the arena's gather
+    # cannot express, so they are re-formed on the device behind every re-pack — three float64 GEMMs of 4H x H x in_dim (torch.matmul:
+    # plain library GEMMs on weights) + one gather each into the packed layout.  The training forward then runs the same 3-launch
+    # generator steps as the plain forward instead of 5 (embed and out Linear off the dependent chain): 7.4 -> ~6 ms at c2.
+    live_folds = __import__("os").environ.get("GCPX_SEQ_LIVE_FOLDS", "1") == "1"
+
+    def repack(self, stream=None, bucket=None, max_blocks=0):
+        super().repack(stream, bucket, max_blocks)
+        if self._arena is not None and self.live_folds and self._hp.tree_lstm and (bucket is None or bucket == self._arena_ranges[-1][0]):
+            self._refresh_folds(stream)
+
+    def _fold_index(self, net, key, rows, cols, H):
+        """gather index of pack_gemm(lstm_gate_interleave([W | W_hh])) over the flat buffer [W.flatten(), W_hh.flatten()], and of the bias"""
+        from . import packing as pk
+        cache = self.__dict__.setdefault("_fold_idx", {})
+        if (net, key) not in cache:
+            dev = self.device
+            iw = torch.arange(rows * cols, device=dev).view(rows, cols)
+            ih = rows * cols + torch.arange(rows * H, device=dev).view(rows, H)
+            z = torch.zeros(rows, dtype=torch.int64, device=dev)
+            w_idx, _ = pk.lstm_gate_interleave(iw, ih, z, z)
+            _, b_idx = pk.lstm_gate_interleave(iw, ih, torch.arange(rows, device=dev), z)
+            cache[(net, key)] = (pk.pack_gemm(w_idx).contiguous(), b_idx.contiguous())
+        return cache[(net, key)]
+
+    def _refresh_folds(self, stream=None):
+        sd, hp = self.sd, self._hp
+        H, nz = hp.nz_mid_lstm, hp.nz_enc
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=self.device)) if stream is not None else \
+            torch.cuda.device(self.device)
+        with ctx, torch.no_grad():
+            for net in self._nets:
+                p, W = f"dense_rec.lstm.cell.{net}", self.pk[net]
+                Wih = sd[f"{p}.lstm.0.weight_ih"].double()
+                Whh, bsum = sd[f"{p}.lstm.0.weight_hh"], sd[f"{p}.lstm.0.bias_ih"] + sd[f"{p}.lstm.0.bias_hh"]
+                Wf, bf = Wih @ sd[f"{p}.embed.weight"].double(), Wih @ sd[f"{p}.embed.bias"].double()
+                forms = [("lstm0f", Wf, bf)]
+                if net == "gen_lstm":
+                    Wo, bo = sd[f"{p}.out.weight"].double(), sd[f"{p}.out.bias"].double()
+                    forms.append(("lstm0ff", torch.cat([Wf[:, :nz] @ Wo, Wf[:, nz:]], 1), bf + Wf[:, :nz] @ bo))
+                for key, W64, b64 in forms:
+                    w_idx, b_idx = self._fold_index(net, key, W64.shape[0], W64.shape[1], H)
+                    if key + ".w" not in W:
+                        W[key + ".w"] = torch.empty(w_idx.shape, dtype=torch.float32, device=self.device)
+                        W[key + ".b"] = torch.empty(b_idx.shape, dtype=torch.float32, device=self.device)
+                    src = torch.cat([W64.float().reshape(-1), Whh.reshape(-1)])
+                    torch.index_select(src, 0, w_idx.view(-1), out=W[key + ".w"].view(-1))
+                    torch.index_select(b64.float() + bsum, 0, b_idx, out=W[key + ".b"])
+
     def _hsp_stages(self, plan, name, W, srcs, B, state, par, out_ptr, out_ob, N_out, w0="lstm0f", xs_buf=None):
         """One step of a recurrent predictor as its dependent stages: [LSTM layer 0 (with the folded embedding), layer 1, ...,
         out Linear].  Each stage is a function(group) that appends its GEMM to `group` — the same stage of nets that do not
@@ -79,7 +128,7 @@ class GCPSequentialModel(GCPTreeModel):
         buffer that keeps every step's state, and `xs_buf`, the step's slice of the stacked layer inputs)."""
         hp = self._hp
         H, nl = hp.nz_mid_lstm, hp.n_lstm_layers
-        fused = "lstm0f.w" in W and not self.save_for_backward
+        fused = "lstm0f.w" in W and (not self.save_for_backward or self._arena is not None)
         if xs_buf is None:
             xs_buf = [self._buf(f"{name}.x{i}", (B, H)) for i in range(nl + 1)]
         stages = []
@@ -250,17 +299,21 @@ class GCPSequentialModel(GCPTreeModel):
                 g.append((f"sample{t}", a))
             return [st]
 
+        # folded packs in a training forward: only a trainer's model has them live (repack above); the top hidden state of step t is
+        # then row block [t, nl] of the stacked layer inputs
+        folds_ok = not self.save_for_backward or self._arena is not None
+        gen_top = lambda t: self._rowsrc((xs_of("gen_lstm", t)[nl] if keep else self._buf(f"gen{t}.x{nl}", (B, H))).data_ptr(), H, 0, H)
         z_from_prior = not has_z and not posterior          # prior sampling: z_t needs prior(t), which needs x_t: one serial chain
         if hp.deterministic:
             # x_{t+1} = gen([x_t, e_0, e_g, a_t]): ONE chain of T - 1 steps, nl dependent launches each when layer 0 reads the previous
             # step's top hidden state through the folded output projection (x_{t+1} itself is then computed beside layer 0 of the next step)
-            fold = "lstm0ff.w" in P["gen_lstm"] and not self.save_for_backward
-            top = lambda t: self._rowsrc(self._buf(f"gen{t}.x{nl}", (B, H)).data_ptr(), H, 0, H)
+            fold = "lstm0ff.w" in P["gen_lstm"] and folds_ok
+            top = gen_top
             pending = None
             for t in range(T - 1):
                 if fold and t > 0:
                     g_st = self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [top(t - 1)] + ctx(t), B, state_of("gen_lstm", t), t & 1,
-                                            _addr(X, (t + 1) * nz), T * nz, nz, w0="lstm0ff")
+                                            _addr(X, (t + 1) * nz), T * nz, nz, w0="lstm0ff", xs_buf=xs_of("gen_lstm", t))
                 else:
                     g_st = gen_stages(t, None)
                 if not fold:
@@ -272,9 +325,9 @@ class GCPSequentialModel(GCPTreeModel):
                 pending = g_st[-1:]
             if pending:
                 run(pending)
-        elif has_traj and not (posterior and "lstm0ff.w" in P["gen_lstm"] and not self.save_for_backward):
+        elif has_traj and not (posterior and "lstm0ff.w" in P["gen_lstm"] and folds_ok):
             run(inf_stages(0))
-        fold_out = posterior and "lstm0ff.w" in P["gen_lstm"] and not self.save_for_backward
+        fold_out = posterior and "lstm0ff.w" in P["gen_lstm"] and folds_ok
         if posterior and fold_out:
             # Launch schedule of the posterior rollout.  A generator step is THREE dependent launches (layer 0 reads the previous
             # step's top hidden state through the folded output projection); everything else rides in those launches:
@@ -288,7 +341,7 @@ class GCPSequentialModel(GCPTreeModel):
             def place(chain, start):
                 for i, st in enumerate(chain):
                     sched.setdefault(start + i, []).append(st)
-            top = lambda t: self._rowsrc(self._buf(f"gen{t}.x{nl}", (B, H)).data_ptr(), H, 0, H)
+            top = gen_top
             for t in range(T - 1):
                 place(inf_stages(t), 3 * t)
                 place(sample_stage(t), 3 * t + 5)
@@ -297,7 +350,7 @@ class GCPSequentialModel(GCPTreeModel):
                     g_st = gen_stages(0, zsrc)
                 else:
                     g_st = self._hsp_stages(plan, f"gen{t}", P["gen_lstm"], [top(t - 1), zsrc] + ctx(t), B, state_of("gen_lstm", t), t & 1,
-                                            _addr(X, (t + 1) * nz), T * nz, nz, w0="lstm0ff")
+                                            _addr(X, (t + 1) * nz), T * nz, nz, w0="lstm0ff", xs_buf=xs_of("gen_lstm", t))
                 place(g_st[:-1], 3 * t + 6)
                 place(g_st[-1:], 3 * t + 9)
                 place(prior_stages(t), 3 * t + 7)
@@ -329,6 +382,21 @@ class GCPSequentialModel(GCPTreeModel):
         # ---- latent-space heads next to the decoder ----
         plan.fork([1])
         plan.lane = 1
+        if keep and folds_ok and "lstm0f.w" in P[NETS[0]]:
+            # the folded steps never formed their embeddings, which the backward's weight gradients read (XS[net][t, 0]): ONE GEMM per
+            # net over the stacked rows (t, b) of all steps, beside the decoder
+            st = lambda ptr, w, t_stride, b_stride: self._rowsrc(ptr, t_stride, b_stride, w)
+            cx = [st(_addr(X), nz, 0, T * nz), st(_addr(EG), nz, 0, nz)] if hp.context_every_step else []
+            cx += [st(_addr(EA), nz, nz, (T - 1) * nz)] if EA is not None else []
+            xs = st(_addr(X), nz, nz, T * nz)
+            zs = [] if hp.deterministic else [st(_addr(tin["z"]) if has_z else _addr(Z), nv, nv, (T - 1) * nv)]
+            per_net = {"gen_lstm": [xs] + zs + cx, "prior_lstm": [xs] + cx}
+            if has_traj:
+                per_net["inf_lstm"] = [st(_addr(enc_traj, nz), nz, nz, T * nz)] + cx
+            for net in NETS:
+                if net in per_net:
+                    self._gemm(plan, f"{net}.embed_all", per_net[net], (T - 1) * B, H, B, P[net]["embed.w"], P[net]["embed.b"],
+                               out=XSall[net][0, 0].data_ptr(), ob=(nl + 1) * B * H, orow=H)
         mes = self._buf("model_enc_seq", (B, T, nz))
         plan.add("gather.model_enc_seq", lib.gcpx_gather_rows, X.data_ptr(), idx.data_ptr(), mes.data_ptr(), B, T, T, 0, nz)
         outs["model_enc_seq_padded"] = mes
