@@ -122,6 +122,35 @@ def test_sequential_cell_backward_in_the_gemm_epilogue_gives_the_same_gradient()
     assert torch.equal(tr.grad, tr2.grad)
 
 
+@pytest.mark.parametrize("env", [{"GCPX_SEQ_CHAINS": "serial"}, {"GCPX_SEQ_CHAINS": "overlap"}, {"GCPX_SEQ_LIVE_FOLDS": "0"},
+                                 {"GCPX_BWD_SEGMENTS": "3"}, {"GCPX_BWD_SEGMENTS": "-1"}])
+def test_sequential_backward_schedules_agree(env, monkeypatch):
+    """The default schedule of the flat model's training step (prior chain ahead on its lane as small graphs, generator step t and
+    inference step t + 1 in the same grouped launches, folded 3-launch forward steps) against the other ones the switches select: the
+    round-5 serial order, three lanes with step-by-step events, the unfolded training forward, every run of launches as a graph / none.
+    Same mathematics, different summation order inside the `out` data-gradient GEMM (the tripled weights) and a float64-folded
+    forward: 2e-4 of each gradient's max-abs; the graph switches replay the very same launches: bit for bit."""
+    hp, sd, model, tr = _train_setup(False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _, _, model2, tr2 = _train_setup(False)
+    inputs, noise, _ = make_inputs(hp, seed=9, variant="B")
+    noise = noise[:, :hp.max_seq_len - 1].contiguous()
+    dev_in = {k: v.cuda() for k, v in inputs.items()}
+    for _ in range(3):                                    # (the third call of a trainer with segment graphs replays them)
+        tr.backward(dev_in, noise.cuda())
+        tr2.backward(dev_in, noise.cuda())
+    torch.cuda.synchronize()
+    if "GCPX_BWD_SEGMENTS" in env:
+        assert any(op[0] == "@graph" for op in (tr2.last_bplan.rec.get("_segments") or [])) == (env["GCPX_BWD_SEGMENTS"] != "-1")
+        assert torch.equal(tr.grad, tr2.grad)
+        return
+    g1, g2 = tr.named_grads(), tr2.named_grads()
+    bad = [(k, float((g1[k] - g2[k]).abs().max()), float(g1[k].abs().max())) for k in g1
+           if float((g1[k] - g2[k]).abs().max()) > 2e-4 * float(g1[k].abs().max()) + 1e-7]
+    assert not bad, bad[:8]
+
+
 def test_sequential_two_training_steps():
     """losses of two consecutive optimisation steps and the updated parameters against the oracle loop (RAdam)"""
     from oracle import gcp_sequential_oracle as S

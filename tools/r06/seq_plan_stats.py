@@ -25,42 +25,38 @@ for label, ops in (("plan", bp.ops), ("replayed", bp.rec.get("_segments") or bp.
     torch.cuda.synchronize(); t0 = time.perf_counter(); bp.run(lanes, ops=ops); t1 = time.perf_counter(); torch.cuda.synchronize()
     print(label, "host issue %.2f ms, until done %.2f ms" % ((t1 - t0) * 1e3, (time.perf_counter() - t0) * 1e3))
 
-# ---- pieces of the backward on their own (eager, one stream, no events): where the 12 ms are ----
-names = [o[0] for o in bp.ops]
-def timed(label, ops, reps=3):
-    st = lanes[0]
+# ---- pieces of the backward on their own (eager, no events): where the 12 ms are ----
+def timed(label, ops, reps=3, keep_events=False):
     best = 1e9
     for _ in range(reps):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for name, fn, args, lane in ops:
-            fn(*args, st)
+        if keep_events:
+            bp.run(lanes, ops=ops)
+        else:
+            for name, fn, args, lane in ops:
+                fn(*args, lanes[0])
         th = time.perf_counter() - t0
         torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-    print("%-44s %5d launches  %7.2f ms  (host %.2f)" % (label, len(ops), best * 1e3, th * 1e3))
-K = [o for o in bp.ops if not o[0].startswith("@")]
-for net in ("prior_lstm", "gen_lstm", "inf_lstm"):
-    timed(f"{net} chain alone", [o for o in K if (f":{net}" in o[0] and o[0].startswith(("bw.dgrad", "bw.lstm"))) and ".out" not in o[0].split(net)[0]])
-first_chain = min(i for i, o in enumerate(bp.ops) if "prior_lstm" in o[0] or "gen_lstm" in o[0])
-last_chain = max(i for i, o in enumerate(bp.ops) if o[0].startswith(("bw.dgrad:inf_lstm", "bw.lstm:inf_lstm", "bw.dgrad:gen_lstm")))
-timed("before the chains (losses, decoder backward)", [o for o in bp.ops[:first_chain] if not o[0].startswith("@")])
-timed("decoder weight gradients etc. (lane 1, not prior)", [o for o in bp.ops[first_chain:last_chain] if not o[0].startswith("@") and "_lstm" not in o[0] and "latent" not in o[0]])
-timed("behind the chains (weight gradients, encoders)", [o for o in bp.ops[last_chain + 1:] if not o[0].startswith("@")])
-print([o[0] for o in bp.ops[first_chain:last_chain] if not o[0].startswith("@") and "_lstm" not in o[0] and "latent" not in o[0]][:40])
+    print("%-60s %5d ops  %7.2f ms  (host %.2f)" % (label, len(ops), best * 1e3, th * 1e3))
+ops = bp.ops
+is_chain = lambda n: ("_lstm" in n and n.startswith(("bw.dgrad", "bw.lstm"))) or n.startswith("bw.dgrad:gen") or "latent" in n
+first = min(i for i, o in enumerate(ops) if is_chain(o[0]))
+last = max(i for i, o in enumerate(ops) if is_chain(o[0]))
+first_main = min(i for i, o in enumerate(ops) if o[0].startswith("bw.dgrad:gen"))
+K = lambda sel: [o for o in sel if not o[0].startswith("@")]
+timed("before the first chain launch (losses)", K(ops[:first]))
+timed("decoder backward .. before the main-lane chain (lane 0 only)", [o for o in K(ops[first:first_main]) if o[3] == 0])
+timed("prior chain (lane 1 launches that are chain ops)", [o for o in K(ops[first:last + 1]) if o[3] == 1 and is_chain(o[0])])
+timed("other lane-1 work (decoder / prior weight gradients)", [o for o in K(ops[first:last + 1]) if o[3] == 1 and not is_chain(o[0])])
+timed("main-lane chain (gen + inf lockstep), launches only", [o for o in K(ops[first_main:last + 1]) if o[3] == 0])
+timed("main-lane chain with its events, nothing beside it", [o for o in ops[first_main:last + 1] if o[0].startswith("@") or o[3] == 0], keep_events=True)
+timed("behind the chains", K(ops[last + 1:]))
+timed("whole backward as planned", ops, keep_events=True)
 
-# ---- the chain phase with its events, lanes taken out one at a time ----
-def timed_plan(label, keep, reps=3):
-    ops = [o for o in bp.ops[first_chain:last_chain + 1] if o[0].startswith("@") or keep(o[0])]
-    best = 1e9
-    for _ in range(reps):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        bp.run(lanes, ops=ops)
-        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-    print("%-64s %5d ops %7.2f ms" % (label, len(ops), best * 1e3))
-chain = lambda n, net: f":{net}" in n and n.startswith(("bw.dgrad", "bw.lstm"))
-timed_plan("chain phase as planned", lambda n: True)
-timed_plan("generator launches + all events", lambda n: chain(n, "gen_lstm"))
-timed_plan("generator + inference (+ latent)", lambda n: chain(n, "gen_lstm") or chain(n, "inf_lstm") or "latent" in n)
-timed_plan("generator + prior", lambda n: chain(n, "gen_lstm") or chain(n, "prior_lstm"))
-timed_plan("three chains, no decoder weight gradients", lambda n: "_lstm" in n or "latent" in n)
-ops_noev = [o for o in bp.ops[first_chain:last_chain + 1] if chain(o[0], "gen_lstm")]
-timed("generator launches, no events (one stream)", ops_noev)
+# ---- what slows the main-lane chain: the chain phase with parts of lane 1 taken out ----
+seg = ops[first:last + 1]
+ctl = lambda o: o[0].startswith("@")
+timed("chain phase: everything", seg, keep_events=True)
+timed("chain phase: main lane + prior chain (no weight gradients)", [o for o in seg if ctl(o) or o[3] == 0 or is_chain(o[0])], keep_events=True)
+timed("chain phase: main lane + lane-1 weight gradients (no prior chain)", [o for o in seg if ctl(o) or o[3] == 0 or not is_chain(o[0])], keep_events=True)
+timed("chain phase: main lane only", [o for o in seg if ctl(o) or o[3] == 0], keep_events=True)

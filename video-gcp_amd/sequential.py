@@ -75,11 +75,10 @@ class GCPSequentialModel(GCPTreeModel):
     # cannot express, so they are re-formed on the device behind every re-pack — three float64 GEMMs of 4H x H x in_dim (torch.matmul:
     # plain library GEMMs on weights) + one gather each into the packed layout.  The training forward then runs the same 3-launch
     # generator steps as the plain forward instead of 5 (embed and out Linear off the dependent chain): 7.4 -> ~6 ms at c2.
-    live_folds = __import__("os").environ.get("GCPX_SEQ_LIVE_FOLDS", "1") == "1"
-
     def repack(self, stream=None, bucket=None, max_blocks=0):
         super().repack(stream, bucket, max_blocks)
-        if self._arena is not None and self.live_folds and self._hp.tree_lstm and (bucket is None or bucket == self._arena_ranges[-1][0]):
+        live = self.__dict__.setdefault("_live_folds", __import__("os").environ.get("GCPX_SEQ_LIVE_FOLDS", "1") == "1")   # (read once per model)
+        if self._arena is not None and live and self._hp.tree_lstm and (bucket is None or bucket == self._arena_ranges[-1][0]):
             self._refresh_folds(stream)
 
     def _fold_index(self, net, key, rows, cols, H):
