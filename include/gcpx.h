@@ -901,9 +901,13 @@ int gcpx_averaging_nll_bwd(const float* w, const float* pad_mask, const float* i
                            const float* log_sigma, float coef, int32_t B, int32_t N, int32_t T, int64_t D, float* dimg,
                            float* dlog_sigma, void* stream);
 /* backward of the mixture mean (`images` of the discrete-logistic-mixture head): params / dparams [rows][npix][pitch] in the head's
- *   slot order, dimg NCHW [rows][3][npix]; colsum [rows][pitch] (per-frame column sums for the bias gradient) or NULL */
+ *   slot order, dimg NCHW [rows][3][npix]; colsum [rows][pitch] (per-frame column sums for the bias gradient) or NULL.
+ *   used_slots = pitch: every slot of dparams is written (zeros where the mean does not depend on the parameter: the log-scales);
+ *   used_slots = 8 * n_mix: only slots 0 .. 8 n_mix - 1 are read and written (the green / blue log-scales and the padding behind them
+ *   carry no gradient) — for a head backward that walks the leading 8 n_mix channels only (gcpx_conv3x3 with Cin < src[0].C,
+ *   gcpx_wgrad_conv3x3_split_src with Cout = 8 n_mix); slots >= used_slots of dparams are left untouched, of colsum written as 0 */
 int gcpx_dlm_mean_bwd(const float* params, const float* dimg, float* dparams, float* colsum, int32_t rows, int32_t npix, int32_t pitch,
-                      int32_t n_mix, void* stream);
+                      int32_t n_mix, int32_t used_slots, void* stream);
 /* backward of gcpx_attention (one head): from d_out [M][nz] and the saved weights att [M][T]:
  *   dS [M][T] (scratch, gradient w.r.t. the scaled scores), dq [M][dk], dtemp_row [M] (per-row terms of d temperature),
  *   dK [B][T] rows of dk floats with leading dimension ldk, dV [B][T] rows of nz floats with leading dimension ldv

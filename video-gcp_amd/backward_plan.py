@@ -76,8 +76,11 @@ class BackwardPlanMixin:
                            buf("bw.dtw.tangent", (2 * B, N, T), torch.float64).data_ptr(),
                            buf("bw.dtw.partial", (B,), torch.float64).data_ptr(), self.g("tree_module.tree_modules.0.binding.temp"))
             dMD = buf("bw.dMD", (B * N, S, S, pitch))
+            # (lean: the mean depends on the leading 8 x mixtures slots only — the gradient's other slots are neither written here nor read
+            # by the head's data / weight gradient launches, backward_stages._lean_head)
             plan.add("bw.dlm_mean", lib.gcpx_dlm_mean_bwd, o["distr_df_kernel_order"].data_ptr(), dImg.data_ptr(), dMD.data_ptr(),
-                     buf("bw.dMD.colsum", (B * N, pitch)).data_ptr(), B * N, S * S, pitch, hp.n_mixtures)
+                     buf("bw.dMD.colsum", (B * N, pitch)).data_ptr(), B * N, S * S, pitch, hp.n_mixtures,
+                     8 * hp.n_mixtures if self._lean_head(rec) else pitch)
         else:
             dMD = buf("bw.dMD", (B * T, S, S, pitch))
             if not rec.get("nll_bwd_fused"):        # otherwise the forward plan already produced dMD together with the loss

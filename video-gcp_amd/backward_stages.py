@@ -19,6 +19,14 @@ def _c16(n):
 class BackwardStagesMixin:
 
     # ---- decoder ----
+    def _lean_head(self, rec):
+        """adaptive model, 10-mixture head at pitch 112 on the split-f16 kernels: the head's backward launches walk the 80 slots the mixture
+        mean reads (GCPX_NO_LEAN_MEAN_GRAD: all 112)"""
+        m, hp = self.m, self.m._hp
+        hs = rec["head_src"]
+        return (self.lean_mean_grad and hp.adaptive and m._head_pitch == 112 and hp.n_mixtures == 10 and self.fuse_stage and m.split_f16 and
+                self.split_wgrad and hp.ngf == 16 and hs[2] == 1 and hs[5] == rt.ACT_LRELU and hs[3] is not None and hp.img_sz % 32 == 0)
+
     def _decoder_backward(self, plan, fplan, dMD, B, maps=None):
         """maps (models whose decoded frames are not tree nodes — the flat VRNN): dict(R = rows of dMD, row2src [R] int32 = the
         decoded frame whose features row r of the head's weight gradient reads, frame2row [F] = row of frame f (-1: none),
@@ -36,6 +44,9 @@ class BackwardStagesMixin:
         # output head: weight gradient over the frames that carry a loss gradient, data gradient to every node frame.
         # balanced: the matched frames (row b*T+t of dMD <- node matched to frame t); adaptive: every node frame
         all_frames = hp.adaptive and maps is None
+        # adaptive: the gradient comes through the mixture MEAN, which the green / blue log-scales (slots 80..99) do not enter: the head's
+        # weight and data gradients walk the 80 leading slots of the 112 (5 of 7 channel tiles) and gcpx_dlm_mean_bwd moves only those
+        hslots = 8 * hp.n_mixtures if (all_frames and self._lean_head(rec)) else pitch
         R = maps["R"] if maps is not None else (F if all_frames else B * T)
         row_map = None
         if maps is not None:
@@ -48,7 +59,7 @@ class BackwardStagesMixin:
                 hs[3] is not None and (S in (8, 16) or S % 32 == 0)):
             # the split-f16 kernel reads the last block's raw output at the rows' frames and applies BatchNorm affine + LeakyReLU on load
             head_bias_fused = bool(rec.get("head_grad_fused")) and pitch == 112
-            self._wgrad_conv3(plan, "dec.head", dMD.data_ptr(), pitch, None, R, S, S, ngf, pitch, self.g("decoder.gen_head.conv.weight"),
+            self._wgrad_conv3(plan, "dec.head", dMD.data_ptr(), pitch, None, R, S, S, ngf, hslots, self.g("decoder.gen_head.conv.weight"),
                               n_map=perm32, src=(hs[0], rt.ptr(row_map), rt.ptr(hs[3]), rt.ptr(hs[4])),
                               dbias=(self.g("decoder.gen_head.conv.bias") if head_bias_fused else None))
         else:
@@ -87,6 +98,9 @@ class BackwardStagesMixin:
             plan.add("bw.row2frame", lib.gcpx_index_inverse, o["node2row"].data_ptr(), F, row2frame.data_ptr(), B * T)
             a.src_row_frames, a.n_src_rows = row2frame.data_ptr(), B * T
         m._set_split(a, "bw.dec.head")
+        if hslots != pitch:
+            assert bool(a.wpk_split), "the lean head gradient runs on the split-f16 wave kernel"
+            a.Cin = hslots                       # the leading slots of every pixel; src[0].C stays the pitch (gcpx_conv3x3: Cin < src[0].C)
         # the head's data gradient is the gradient of the last block's BatchNorm + LeakyReLU output: the split-f16 kernel applies the
         # activation's derivative and sums the BatchNorm statistics in its epilogue (gcpx_conv_args.bwd_r) — gcpx_act_bwd's pass over
         # 2 x 533 MB (c2) on the critical lane is gone

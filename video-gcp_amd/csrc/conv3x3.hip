@@ -1253,7 +1253,11 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
     GCPX_CHECK_ARG(a != nullptr, "null args");
     GCPX_CHECK_ARG(a->nsrc == 1 || a->nsrc == 2, "nsrc must be 1 or 2");
     GCPX_CHECK_ARG(a->src[0].C % 16 == 0 && (a->nsrc == 1 || a->src[1].C % 16 == 0), "source channels must be multiples of 16");
-    GCPX_CHECK_ARG(a->Cin == a->src[0].C + (a->nsrc == 2 ? a->src[1].C : 0), "Cin != sum of sources");
+    // (a 16-output-channel data gradient on the split-f16 wave kernel may walk only the LEADING Cin channels of a wider source —
+    //  src[0].C stays the pixel pitch: the adaptive model's head gradient, whose slots behind 8 x mixtures are zero)
+    const bool leading = !a->upsample && a->nsrc == 1 && a->Cin < a->src[0].C && a->Cin >= 32 && a->Cin % 16 == 0 && a->Cout == 16 && a->wpk_split &&
+                         a->split_layout == GCPX_SPLIT_PLAIN && (!a->src_row_map || a->src_row_frames) && !getenv("GCPX_DGRAD_TILED");
+    GCPX_CHECK_ARG(leading || a->Cin == a->src[0].C + (a->nsrc == 2 ? a->src[1].C : 0), "Cin != sum of sources");
     GCPX_CHECK_ARG(a->wpk && a->bias, "weights/bias missing");
     GCPX_CHECK_ARG(a->F > 0, "F <= 0");
     if (a->upsample) GCPX_CHECK_ARG(a->Hout == 2 * a->Hin && a->Wout == 2 * a->Win, "upsample: Hout != 2*Hin");
@@ -1303,8 +1307,10 @@ static int conv3x3_dispatch(const gcpx_conv_args* a, hipStream_t stream, bool qu
                 const int st = gcpx_launch_wave_split(a, stream, 1, depth);
                 if (st != -1) return st;
             }
+            GCPX_CHECK_ARG(!leading, "Cin < src[0].C: the split-f16 wave kernel did not take the problem");
             return depth == 2 ? launch_wave<1, 2>(a, stream) : launch_wave<1, 1>(a, stream);
         }
+        GCPX_CHECK_ARG(!leading, "Cin < src[0].C is built for the 16-output-channel wave kernel only (W % 16 == 0, H % 4 == 0)");
         static const bool wave32 = getenv("GCPX_DGRAD_NOWAVE32") == nullptr;     // 32 output channels (16-channel decoder blocks): 874 vs 912 us tiled
         if (wave32 && !tiled_only && W % 16 == 0 && a->Hout % 4 == 0 && a->Cout == 32 && a->out_pitch % 4 == 0 && a->Cin % 16 == 0 &&
             (!a->src_row_map || a->src_row_frames) && WaveCfg<2>::lds_bytes(a->Cin / 16) <= 152 * 1024) {

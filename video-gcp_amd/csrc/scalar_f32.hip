@@ -169,9 +169,14 @@ __global__ void __launch_bounds__(256) dlm_nll_bwd_kernel(const float* __restric
 // Backward of the mixture MEAN (images of the discrete-logistic-mixture head; oracle dlm_mean): params [F][npix][PITCH] in the
 // head's slot order, dimg NCHW [F][3][npix] -> dparams [F][npix][PITCH] (+ per-frame column sums for the bias gradient).
 // A wavefront stages 16 pixels x PITCH parameters in LDS; lane (j = pixel, q) owns mixtures q, q + 4, q + 8.
-template <int NMIX, int PITCH>
+// USED: slots of a pixel that are read and written.  The mean depends on slots 0 .. 8 NMIX - 1 only (logit, means, colour coefficients of
+// every mixture; the green / blue log-scales live behind them, packing.dlm_log_scale_slot): USED = 8 NMIX moves 80 of 112 floats per
+// pixel each way and leaves slots >= USED of dparams UNWRITTEN — for callers whose data / weight gradient kernels walk the leading USED
+// channels only (the adaptive model's head backward); colsum's slots >= USED are written as 0.
+template <int NMIX, int PITCH, int USED>
 __global__ void __launch_bounds__(256) dlm_mean_bwd_kernel(const float* __restrict__ params, const float* __restrict__ dimg,
                                                            float* __restrict__ dparams, float* __restrict__ colsum, const int npix) {
+    static_assert(USED == PITCH || USED == 8 * NMIX, "all slots or the 8 NMIX slots of the mean");
     __shared__ float4 stage4[4 * 16 * PITCH / 4];
     __shared__ float csum[4][2][64];
     float cs0 = 0.f, cs1 = 0.f;
@@ -185,7 +190,15 @@ __global__ void __launch_bounds__(256) dlm_mean_bwd_kernel(const float* __restri
     float* drow = dparams + (size_t)row * npix * PITCH;
     for (int p0 = wave * 16; p0 < npix; p0 += 64) {
         const float4* src = reinterpret_cast<const float4*>(prow + (size_t)p0 * PITCH);
-        for (int i = lane; i < F4; i += 64) reinterpret_cast<float4*>(st)[i] = src[i];
+        if constexpr (USED == PITCH) {
+            for (int i = lane; i < F4; i += 64) reinterpret_cast<float4*>(st)[i] = src[i];
+        } else {
+            constexpr int U4 = USED / 4;
+            for (int i = lane; i < 16 * U4; i += 64) {
+                const int px = i / U4, c4 = i - px * U4;
+                reinterpret_cast<float4*>(st)[px * (PITCH / 4) + c4] = src[px * (PITCH / 4) + c4];
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         float* pp = st + j * PITCH;
         float lmax = pp[0];
@@ -242,7 +255,15 @@ __global__ void __launch_bounds__(256) dlm_mean_bwd_kernel(const float* __restri
             for (int s = 8 * NMIX; s < PITCH; ++s) pp[s] = 0.f;
         __builtin_amdgcn_wave_barrier();
         float4* dst = reinterpret_cast<float4*>(drow + (size_t)p0 * PITCH);
-        for (int i = lane; i < F4; i += 64) dst[i] = reinterpret_cast<float4*>(st)[i];
+        if constexpr (USED == PITCH) {
+            for (int i = lane; i < F4; i += 64) dst[i] = reinterpret_cast<float4*>(st)[i];
+        } else {
+            constexpr int U4 = USED / 4;
+            for (int i = lane; i < 16 * U4; i += 64) {
+                const int px = i / U4, c4 = i - px * U4;
+                dst[px * (PITCH / 4) + c4] = reinterpret_cast<float4*>(st)[px * (PITCH / 4) + c4];
+            }
+        }
         if (colsum) {
 #pragma unroll
             for (int px = 0; px < 16; ++px) {
@@ -417,11 +438,15 @@ extern "C" int gcpx_dlm_nll_bwd(const float* params, const float* target, const 
 }
 
 extern "C" int gcpx_dlm_mean_bwd(const float* params, const float* dimg, float* dparams, float* colsum, int32_t rows, int32_t npix,
-                                 int32_t pitch, int32_t n_mix, void* stream_) {
+                                 int32_t pitch, int32_t n_mix, int32_t used_slots, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GCPX_CHECK_ARG(params && dimg && dparams && rows > 0, "bad arguments");
     GCPX_CHECK_ARG(n_mix == 10 && pitch == 112 && npix % 64 == 0, "supports 10 mixtures, pitch 112, npix % 64 == 0");
-    hipLaunchKernelGGL((dlm_mean_bwd_kernel<10, 112>), dim3(rows), dim3(256), 0, stream, params, dimg, dparams, colsum, npix);
+    GCPX_CHECK_ARG(used_slots == pitch || used_slots == 8 * n_mix, "used_slots: the pitch (every slot written) or 8 * n_mix (the slots the mean reads)");
+    if (used_slots == pitch)
+        hipLaunchKernelGGL((dlm_mean_bwd_kernel<10, 112, 112>), dim3(rows), dim3(256), 0, stream, params, dimg, dparams, colsum, npix);
+    else
+        hipLaunchKernelGGL((dlm_mean_bwd_kernel<10, 112, 80>), dim3(rows), dim3(256), 0, stream, params, dimg, dparams, colsum, npix);
     GCPX_CHECK_LAUNCH();
     return GCPX_OK;
 }

@@ -727,6 +727,8 @@ extern "C" int gcpx_wgrad_conv3x3_split_src(const float* dy, int32_t ldy, const 
     int st = GCPX_ERR_UNSUPPORTED;
     GCPX_CHECK_ARG(!bias_partial || (NT == 7 && Cin == 16), "bias_partial: the 112-column head form only");
     if (NT == 7 && Cin == 16) st = launch_ws<7, 1>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift, bias_partial);
+    // the head's 80 leading slots only (the adaptive model's mixture-mean gradient: the log-scale slots behind them are zero, gcpx_dlm_mean_bwd)
+    else if (NT == 5 && Cin == 16) st = launch_ws<5, 1>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift);
     else if (NT == 1 && Cin % 32 == 0) st = launch_ws<1, 2>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift);
     else if (NT == 2 && Cin % 32 == 0) st = launch_ws<2, 2>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift);
     else if (NT == 4 && Cin % 32 == 0) st = launch_ws<4, 2>(dy, x, partial, F, H, W, Cin, ldy, grid, stream, frame_map, scale, shift);

@@ -221,7 +221,7 @@ SYMBOLS = [
     ("gcpx_averaging_nll", C.c_int, [vp, vp, vp, C.c_float, i32, i32, i32, vp, vp]),
     ("gcpx_soft_average", C.c_int, [vp, vp, vp, i32, i32, i32, i64, vp]),
     ("gcpx_averaging_nll_bwd", C.c_int, [vp, vp, vp, vp, vp, vp, C.c_float, i32, i32, i32, i64, vp, vp, vp]),
-    ("gcpx_dlm_mean_bwd", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    ("gcpx_dlm_mean_bwd", C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     ("gcpx_attention_bwd", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]),
     ("gcpx_dtw_align", C.c_int, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     ("gcpx_graph_begin", C.c_int, [vp]),
