@@ -122,7 +122,7 @@ def test_sequential_cell_backward_in_the_gemm_epilogue_gives_the_same_gradient()
     assert torch.equal(tr.grad, tr2.grad)
 
 
-@pytest.mark.parametrize("env", [{"GCPX_SEQ_CHAINS": "serial"}, {"GCPX_SEQ_CHAINS": "overlap"}, {"GCPX_SEQ_LIVE_FOLDS": "0"},
+@pytest.mark.parametrize("env", [{"GCPX_SEQ_CHAINS": "serial"}, {"GCPX_SEQ_CHAINS": "overlap"}, {"GCPX_SEQ_CHAINS": "lockstep3"}, {"GCPX_SEQ_LIVE_FOLDS": "0"},
                                  {"GCPX_BWD_SEGMENTS": "3"}, {"GCPX_BWD_SEGMENTS": "-1"}])
 def test_sequential_backward_schedules_agree(env, monkeypatch):
     """The default schedule of the flat model's training step (prior chain ahead on its lane as small graphs, generator step t and

@@ -42,9 +42,11 @@ class SequentialTrainStep(GCPTrainStep):
         self.side_lanes = True
         # GCPX_SEQ_CHAINS: "lockstep" (default): prior chain ahead on its own lane, generator step t and inference step t + 1 in the SAME
         # five launches (gcpx_gemm_group) on the main lane; "overlap": three lanes, step-by-step events; "serial": round-5 order
+        # "lockstep3": the prior net's step t rides in the same launches too (three problems each; no side chain, no events at all)
         mode = __import__("os").environ.get("GCPX_SEQ_CHAINS", "lockstep")
-        self.chains_overlap = mode in ("overlap", "lockstep")
-        self.chains_lockstep = mode == "lockstep"
+        self.chains_overlap = mode in ("overlap", "lockstep", "lockstep3")
+        self.chains_lockstep = mode in ("lockstep", "lockstep3")
+        self.chains_lockstep3 = mode == "lockstep3"
 
     # ------------------------------------------------------------------------------------------------
     def _pack_backward(self, sd):
@@ -269,7 +271,8 @@ class SequentialTrainStep(GCPTrainStep):
         # backward as before, the generator starts when the decoder backward ends, wherever the prior chain is by then
         overlap = self.chains_overlap and not det
         lockstep = overlap and self.chains_lockstep
-        prior_done = {} if overlap else None
+        lock3 = lockstep and self.chains_lockstep3
+        prior_done = {} if (overlap and not lock3) else None
         PE = 4 if lockstep else 1                             # the prior chain hands over every PE steps (it is far ahead anyway)
 
         def prior_chain():
@@ -281,7 +284,9 @@ class SequentialTrainStep(GCPTrainStep):
                     pass
             plan.lane = 0
             return i0
-        if overlap:
+        if lock3:
+            pass                                              # (the prior's steps are issued with the generator's, below)
+        elif overlap:
             # the HOST issues the plan in order: the decoder backward's launches go out first (the main lane starts at once), the prior
             # chain's ~870 host calls follow while the device is busy with them; lane 1 starts from where the main lane stood HERE
             prior_start = plan.record(0)
@@ -300,7 +305,10 @@ class SequentialTrainStep(GCPTrainStep):
                                                                                row2frame=row2frame_inv))
         pd = in_dim["prior_lstm"]
         prior_dx = lambda: self._rows(plan, "bw.prior.dx", DX.data_ptr(), T * nz, nz, dIn["prior_lstm"].data_ptr(), (T - 1) * pd, pd, B, T - 1, nz, 1)
-        if overlap:
+        if lock3:
+            self._flush(plan, only_lane=1)                    # decoder weight gradients on lane 1, beside the one chain
+            inf_lane = 2
+        elif overlap:
             plan.await_event(1, prior_start)
             i0 = prior_chain()
             # the prior chain has hours of slack (it runs beside the decoder backward and only has to stay ahead of the generator): its
@@ -340,7 +348,7 @@ class SequentialTrainStep(GCPTrainStep):
         awaited = set()
 
         def gen_before(t):
-            if overlap and t + 1 <= T - 2:
+            if overlap and not lock3 and t + 1 <= T - 2:
                 tp = (t + 1) // PE * PE                        # the hand-over that covers the prior's step t + 1 (it counts t downwards)
                 if tp not in awaited:
                     awaited.add(tp)
@@ -356,16 +364,22 @@ class SequentialTrainStep(GCPTrainStep):
             slots = [[] for _ in range(nl + 2)]
             gen_chain = self._chain(plan, "gen_lstm", gen_dout, B, T, dIn["gen_lstm"], nrec, before_step=gen_before, slots=slots)
             inf_chain = self._chain(plan, "inf_lstm", lambda t: m._rowsrc(DQ[t].data_ptr(), 2 * nv, 0, 2 * nv), B, T, dIn["inf_lstm"], nrec, slots=slots)
+            # lockstep3: the prior's step t in the same launches as the generator's step t (which reads the prior's step t + 1: issued one
+            # super-step earlier)
+            pri_chain = self._chain(plan, "prior_lstm", lambda t: m._rowsrc(_addr(dPZ, t * 2 * nv), (T - 1) * 2 * nv, 0, 2 * nv), B, T,
+                                    dIn["prior_lstm"], nrec, slots=slots) if lock3 else iter(())
             for k in range(T):
                 if k < T - 1:
                     next(gen_chain)
+                    if lock3:
+                        next(pri_chain)
                 if k >= 1:
                     latent(T - 1 - k)
                     next(inf_chain)
                 for j, g in enumerate(slots):
                     m._gemm_group(plan, f"bw.dgrad:gen{T - 2 - k}+inf{T - 1 - k}.{j}", list(g))
                     g.clear()
-            for ch in (gen_chain, inf_chain):
+            for ch in (gen_chain, inf_chain, pri_chain):
                 for _ in ch:                                  # (exhausts the generators: they record their stacked buffers on the way out)
                     pass
         for t in (() if lockstep else self._chain(plan, "gen_lstm", gen_dout, B, T, dIn["gen_lstm"], nrec, before_step=gen_before)):
