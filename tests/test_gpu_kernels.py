@@ -1610,14 +1610,17 @@ def test_aux_sample_indices_uniform_and_gauss(env):
         assert bool(((t0 >= 0) & (t1 > t0) & (t1 <= end) & (cs >= 0) & (ce > cs) & (ce <= end)).all())
 
 
+@pytest.mark.parametrize("tiles", ["4x16", "2x32"])
 @pytest.mark.parametrize("Cout,Cin,S,Fr", [(100, 16, 64, 5), (16, 32, 64, 5), (16, 64, 64, 3), (32, 64, 32, 7), (64, 128, 16, 9),
                                            (64, 128, 8, 12), (32, 64, 8, 10)])
 @pytest.mark.parametrize("case", ["plain", "frame_scales", "tiny", "zero_frames"])
-def test_wgrad_conv3x3_split_error_vs_float64(env, Cout, Cin, S, Fr, case):
+def test_wgrad_conv3x3_split_error_vs_float64(env, Cout, Cin, S, Fr, case, tiles, monkeypatch):
     """Weight gradient of the decoder's 3x3 convs on the split-f16 kernel (csrc/wgrad_conv_split.hip: both operands split in the
     kernel, quad transposes on the way into LDS, running power-of-two scales per workgroup) against float64, next to the exact f32
     MFMA kernel.  Frames whose magnitudes differ by six orders (the running scale drops, the sums are rescaled), gradients of
     order 1e-6, all-zero frames; every tile shape (W = 64 / 32 / 16 / 8) and channel configuration of the decoder."""
+    if tiles == "2x32":          # 64-pixel tiles as 2 rows x 32 columns (the form before round 6; images of 32+ columns)
+        monkeypatch.setenv("GCPX_WS_TW32", "1")
     rt, pk, lib, dev = env
     torch.manual_seed(Cout + Cin + S)
     N16 = (Cout + 15) // 16 * 16
@@ -1717,13 +1720,16 @@ def test_conv_stage(env, Hin, c_prev, c_skip, Fr, nodes, up):
         assert_close(out.permute(0, 3, 1, 2), w2, atol=2e-6, rtol=1e-6, name="conv_stage mapped")
 
 
+@pytest.mark.parametrize("tiles", ["4x16", "2x32"])
 @pytest.mark.parametrize("Hin,c_prev,c_skip,Fr,nodes", [(32, 16, 16, 6, 3), (16, 32, 0, 5, 1), (8, 32, 0, 7, 1), (4, 16, 16, 8, 2)])
 @pytest.mark.parametrize("case", ["plain", "tiny"])
-def test_wgrad_conv3x3_split_up_reads_the_blocks_sources(env, Hin, c_prev, c_skip, Fr, nodes, case):
+def test_wgrad_conv3x3_split_up_reads_the_blocks_sources(env, Hin, c_prev, c_skip, Fr, nodes, case, tiles, monkeypatch):
     """gcpx_wgrad_conv3x3_split_up: weight gradient of a 16-output-channel upsampling block that forms its operand (bilinear x2 of the
     concatenated, normalised + activated low-resolution sources; skip source shared by `nodes` frames) inside the kernel — against
     float64 on torch's own interpolation, and against gcpx_conv_stage + gcpx_wgrad_conv3x3_split on the same data (the path it
     replaces: same operand values, same scales, same sums).  Every tile shape (W = 64 / 32 / 16 / 8)."""
+    if tiles == "2x32":          # 64-pixel tiles as 2 rows x 32 columns (the form before round 6; images of 32+ columns)
+        monkeypatch.setenv("GCPX_WS_TW32", "1")
     rt, pk, lib, dev = env
     torch.manual_seed(Hin + c_prev + c_skip)
     Cout, S = 16, 2 * Hin
@@ -1758,11 +1764,14 @@ def test_wgrad_conv3x3_split_up_reads_the_blocks_sources(env, Hin, c_prev, c_ski
     assert_close(got.float(), ref_.float(), atol=2e-6 * scale, rtol=0, name="fused vs staged")
 
 
+@pytest.mark.parametrize("tiles", ["4x16", "2x32"])
 @pytest.mark.parametrize("Cout,Cin,S", [(100, 16, 64), (16, 32, 32), (32, 64, 16)])
-def test_wgrad_conv3x3_split_src_applies_affine_and_frame_map(env, Cout, Cin, S):
+def test_wgrad_conv3x3_split_src_applies_affine_and_frame_map(env, Cout, Cin, S, tiles, monkeypatch):
     """gcpx_wgrad_conv3x3_split_src: the operand is LeakyReLU(scale x + shift) of a raw tensor read through a frame map (the output
     head's weight gradient over the matched rows) — against gcpx_conv_stage (gathered, activated copy) + gcpx_wgrad_conv3x3_split, the
     path it replaces (same operand values: identical sums), and against float64."""
+    if tiles == "2x32":          # 64-pixel tiles as 2 rows x 32 columns (the form before round 6; images of 32+ columns)
+        monkeypatch.setenv("GCPX_WS_TW32", "1")
     rt, pk, lib, dev = env
     torch.manual_seed(Cout + S)
     Fx, R = 9, 6

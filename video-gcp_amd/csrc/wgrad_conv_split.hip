@@ -654,7 +654,7 @@ int launch_ws2(const float* dy, const float* u, float* partial, int F, int H, in
 template <int NT, int CIT>
 int launch_ws(const float* dy, const float* u, float* partial, int F, int H, int W, int Cin, int ldy, int grid, hipStream_t stream,
               const int* fmap = nullptr, const float* usc = nullptr, const float* ush = nullptr, float* bias_partial = nullptr) {
-    static const bool tall = getenv("GCPX_WS_TW32") == nullptr;             // 4 x 16 tiles (see launch_ws_up's caller): the head's weight gradient 794-836 -> 759-775 us
+    const bool tall = getenv("GCPX_WS_TW32") == nullptr;             // 4 x 16 tiles (see launch_ws_up's caller): the head's weight gradient 794-836 -> 759-775 us
     if (W >= 32 && W % 32 == 0 && !(tall && H % 4 == 0)) return launch_ws2<NT, CIT, 32>(dy, u, partial, F, H, W, Cin, ldy, grid, stream, fmap, usc, ush, bias_partial);
     if (W % 16 == 0 && (W == 16 || tall)) return launch_ws2<NT, CIT, 16>(dy, u, partial, F, H, W, Cin, ldy, grid, stream, fmap, usc, ush, bias_partial);
     if (W == 8) return launch_ws2<NT, CIT, 8>(dy, u, partial, F, H, W, Cin, ldy, grid, stream, fmap, usc, ush, bias_partial);
@@ -705,7 +705,7 @@ extern "C" int gcpx_wgrad_conv3x3_split_up(const float* dy, int32_t ldy, const g
     int st = GCPX_ERR_UNSUPPORTED;
     // 64-pixel tiles as 4 rows x 16 columns wherever the image allows it: the interpolated region with its halo is 6 x 18 = 108 pixels
     // instead of 4 x 34 = 136 for a 2 x 32 tile (additional_conv_layer at c2: 725 -> 630-660 us, pyramid-0: 172 -> 150; GCPX_WS_TW32=1: wide tiles)
-    static const bool up_tall = getenv("GCPX_WS_TW32") == nullptr;
+    const bool up_tall = getenv("GCPX_WS_TW32") == nullptr;                // (read per call: the tests run both tile shapes in one process)
     if (W >= 32 && W % 32 == 0 && !(up_tall && H % 4 == 0)) st = launch_ws_up<32>(dy, us, partial, a->F, H, W, a->Cin, ldy, grid, stream);
     else if (W % 16 == 0 && (W == 16 || up_tall)) st = launch_ws_up<16>(dy, us, partial, a->F, H, W, a->Cin, ldy, grid, stream);
     else if (W == 8) st = launch_ws_up<8>(dy, us, partial, a->F, H, W, a->Cin, ldy, grid, stream);
