@@ -151,6 +151,26 @@ def test_sequential_backward_schedules_agree(env, monkeypatch):
     assert not bad, bad[:8]
 
 
+def test_sequential_two_trainers_keep_identical_parameters():
+    """Two trainers of the flat model fed the same minibatches hold bit-identical parameters, optimizer moments and folded packs after three
+    steps: no float atomics in the backward, and the folded layer-0 packs of the training forward — products formed by a library GEMM behind
+    every optimizer step — are formed under torch's deterministic switch (rocBLAS without atomics)."""
+    hp, sd, m1, tr1 = _train_setup()
+    _, _, m2, tr2 = _train_setup()
+    for step in range(3):
+        inputs, noise, _ = make_inputs(hp, seed=40 + step, variant="B")
+        noise = noise[:, :hp.max_seq_len - 1].contiguous().cuda()
+        dev_in = {k: v.cuda() for k, v in inputs.items()}
+        tr1.step(dev_in, noise)
+        tr2.step(dev_in, noise)
+    torch.cuda.synchronize()
+    assert torch.equal(m1.theta, m2.theta) and torch.equal(tr1.exp_avg, tr2.exp_avg) and torch.equal(tr1.exp_avg_sq, tr2.exp_avg_sq)
+    for net in m1._nets:
+        for key in ("lstm0f.w", "lstm0f.b") + (("lstm0ff.w", "lstm0ff.b") if net == "gen_lstm" else ()):
+            assert torch.equal(m1.pk[net][key], m2.pk[net][key]), (net, key)
+    assert not torch.are_deterministic_algorithms_enabled()        # the switch is restored behind every re-fold
+
+
 def test_sequential_two_training_steps():
     """losses of two consecutive optimisation steps and the updated parameters against the oracle loop (RAdam)"""
     from oracle import gcp_sequential_oracle as S

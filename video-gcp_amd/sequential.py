@@ -72,12 +72,14 @@ class GCPSequentialModel(GCPTreeModel):
 
     # ------------------------------------------------------------------------------------------------
     # A trainer's model keeps the folded packs too (GCPX_SEQ_LIVE_FOLDS=0: not): they are products of parameters, which the arena's gather
-    # cannot express, so they are re-formed on the device behind every re-pack — three float64 GEMMs of 4H x H x in_dim (torch.matmul:
-    # plain library GEMMs on weights) + one gather each into the packed layout.  The training forward then runs the same 3-launch
+    # cannot express, so they are re-formed on the device behind every re-pack — exact-f32 row GEMMs of this library (4H x H x in_dim)
+    # against the trainer's live transposed packs + one gather each into the packed layout.  The training forward then runs the same 3-launch
     # generator steps as the plain forward instead of 5 (embed and out Linear off the dependent chain): 7.4 -> ~6 ms at c2.
     def repack(self, stream=None, bucket=None, max_blocks=0):
         super().repack(stream, bucket, max_blocks)
         live = self.__dict__.setdefault("_live_folds", __import__("os").environ.get("GCPX_SEQ_LIVE_FOLDS", "1") == "1")   # (read once per model)
+        xp = getattr(self, "_extra_packs", None) or {}
+        live = live and all(n in xp and "embed.wT" in xp[n] and "out.wT" in xp[n] for n in self._nets)   # (the trainer's transposed packs)
         if self._arena is not None and live and self._hp.tree_lstm and (bucket is None or bucket == self._arena_ranges[-1][0]):
             self._refresh_folds(stream)
 
@@ -96,28 +98,58 @@ class GCPSequentialModel(GCPTreeModel):
         return cache[(net, key)]
 
     def _refresh_folds(self, stream=None):
-        sd, hp = self.sd, self._hp
+        """W_ih0 @ W_e (and, for the generator, its x columns @ W_out) on the exact-f32 row GEMM of this library against the transposed
+        packs the trainer keeps live for its data gradients (`embed.wT`, `out.wT`): fixed summation order.  (A library GEMM was tried
+        first: torch.matmul in float64 gave different last bits from call to call — rocBLAS splitting k with atomics, torch's
+        deterministic switch notwithstanding — and two trainers fed the same data drifted apart by the third step.)  Biases: products
+        and row sums in torch (no atomics); then one gather each into the packed, gate-interleaved layout."""
+        sd, hp, lib = self.sd, self._hp, self.lib
         H, nz = hp.nz_mid_lstm, hp.nz_enc
-        ctx = torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=self.device)) if stream is not None else \
-            torch.cuda.device(self.device)
+        bw = self._extra_packs
+        st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        cur = torch.cuda.current_stream(self.device)
+        # (torch ops of this function go to `st`: normally torch's current stream itself — wrapping the raw pointer of the DEFAULT stream
+        # in an ExternalStream gave a stream torch did not order with its own default-stream launches: folds read half-updated parameters)
+        ctx = torch.cuda.device(self.device) if int(st) == int(cur.cuda_stream) else \
+            torch.cuda.stream(torch.cuda.ExternalStream(int(st), device=self.device))
+        scratch = self.__dict__.setdefault("_fold_scratch", {})
+
+        def gemm(rows_ptr, row_stride, M, K, wpk, N, out, out_stride):
+            a = rt.GemmArgs()
+            a.src[0] = self._rowsrc(rows_ptr, 0, row_stride, K)
+            a.nsrc, a.M, a.N, a.K, a.rpb = 1, M, N, K, M
+            a.wpk, a.bias, a.out, a.ob, a.orow, a.epi = wpk.data_ptr(), None, out, 0, out_stride, rt.EPI_NONE
+            rt.check(lib.gcpx_gemm(C.byref(a), st), "fold gemm")
         with ctx, torch.no_grad():
             for net in self._nets:
                 p, W = f"dense_rec.lstm.cell.{net}", self.pk[net]
-                Wih = sd[f"{p}.lstm.0.weight_ih"].double()
-                Whh, bsum = sd[f"{p}.lstm.0.weight_hh"], sd[f"{p}.lstm.0.bias_ih"] + sd[f"{p}.lstm.0.bias_hh"]
-                Wf, bf = Wih @ sd[f"{p}.embed.weight"].double(), Wih @ sd[f"{p}.embed.bias"].double()
-                forms = [("lstm0f", Wf, bf)]
+                Wih, Whh = sd[f"{p}.lstm.0.weight_ih"], sd[f"{p}.lstm.0.weight_hh"]
+                be, bsum = sd[f"{p}.embed.bias"], sd[f"{p}.lstm.0.bias_ih"] + sd[f"{p}.lstm.0.bias_hh"]
+                in_dim = sd[f"{p}.embed.weight"].shape[1]
+                key = (net, in_dim)
+                if key not in scratch:
+                    scratch[key] = (torch.empty(4 * H * in_dim + 4 * H * H, device=self.device),
+                                    torch.empty(4 * H * (H + in_dim - nz) + 4 * H * H, device=self.device))
+                src1, src2 = scratch[key]
+                Wf = src1[:4 * H * in_dim].view(4 * H, in_dim)
+                gemm(Wih.data_ptr(), H, 4 * H, H, bw[net]["embed.wT"], in_dim, Wf.data_ptr(), in_dim)
+                bf = (Wih * be[None, :]).sum(1)
+                forms = [("lstm0f", src1, 4 * H * in_dim, in_dim, bf)]
                 if net == "gen_lstm":
-                    Wo, bo = sd[f"{p}.out.weight"].double(), sd[f"{p}.out.bias"].double()
-                    forms.append(("lstm0ff", torch.cat([Wf[:, :nz] @ Wo, Wf[:, nz:]], 1), bf + Wf[:, :nz] @ bo))
-                for key, W64, b64 in forms:
-                    w_idx, b_idx = self._fold_index(net, key, W64.shape[0], W64.shape[1], H)
-                    if key + ".w" not in W:
-                        W[key + ".w"] = torch.empty(w_idx.shape, dtype=torch.float32, device=self.device)
-                        W[key + ".b"] = torch.empty(b_idx.shape, dtype=torch.float32, device=self.device)
-                    src = torch.cat([W64.float().reshape(-1), Whh.reshape(-1)])
-                    torch.index_select(src, 0, w_idx.view(-1), out=W[key + ".w"].view(-1))
-                    torch.index_select(b64.float() + bsum, 0, b_idx, out=W[key + ".b"])
+                    w2c = H + in_dim - nz
+                    W2 = src2[:4 * H * w2c].view(4 * H, w2c)
+                    gemm(Wf.data_ptr(), in_dim, 4 * H, nz, bw[net]["out.wT"], H, W2.data_ptr(), w2c)
+                    W2[:, H:].copy_(Wf[:, nz:])
+                    Wo_b = sd[f"{p}.out.bias"]
+                    forms.append(("lstm0ff", src2, 4 * H * w2c, w2c, bf + (Wf[:, :nz] * Wo_b[None, :]).sum(1)))
+                for fkey, src, nW, cols, bvec in forms:
+                    w_idx, b_idx = self._fold_index(net, fkey, 4 * H, cols, H)
+                    if fkey + ".w" not in W:
+                        W[fkey + ".w"] = torch.empty(w_idx.shape, dtype=torch.float32, device=self.device)
+                        W[fkey + ".b"] = torch.empty(b_idx.shape, dtype=torch.float32, device=self.device)
+                    src[nW:].copy_(Whh.reshape(-1))
+                    torch.index_select(src, 0, w_idx.view(-1), out=W[fkey + ".w"].view(-1))
+                    torch.index_select(bvec + bsum, 0, b_idx, out=W[fkey + ".b"])
 
     def _hsp_stages(self, plan, name, W, srcs, B, state, par, out_ptr, out_ob, N_out, w0="lstm0f", xs_buf=None):
         """One step of a recurrent predictor as its dependent stages: [LSTM layer 0 (with the folded embedding), layer 1, ...,

@@ -338,6 +338,7 @@ class WeightsMixin:
         self._arena_idx0, self._arena_idx1 = idx0, idx1
         self._psd = self.sd
         self.pk = P0
+        self._extra_packs = X0                       # (the caller's packs live in the same arena: a model's re-pack may read them)
         self._clear_plans()
         self.repack()
         return X0
