@@ -180,6 +180,11 @@ class BackwardOpsMixin:
         ntiles = F * max(1, (Hh * Ww) // 64)
         # workgroups per CU that are resident at once (registers): 2 x 4 wavefronts for the 112-column head and the 64-column block (about 200 registers), 3 otherwise
         per_cu = 2 if N16 in (112, 64) else 3
+        # ... but a weight gradient is side-lane work: with ONE workgroup per CU the launches take 1.3-1.8x longer alone (head 760 -> 1016 us)
+        # and the c2 step is 0.1-0.2 ms SHORTER (c5: 0.33) — the data-gradient chain on the main lane gets the other half of every CU.  Not
+        # for the flat model (its weight gradients run beside chains of 10 us launches: +0.5 ms).  training.py: wgrad_per_cu
+        if self.wgrad_per_cu:
+            per_cu = self.wgrad_per_cu
         grid = max(1, min((lib.gcpx_conv_grid() // 2) * per_cu // ych, ntiles))
         part = m._buf(f"bw.part:{tag}", (grid, N16, 9 * Cin))
         # split-f16 kernel (f32-equivalent, csrc/wgrad_conv_split.hip) unless the model runs on the exact f32 kernels (GCPX_EXACT_F32)

@@ -92,6 +92,7 @@ class GCPTrainStep(BackwardWeightsMixin, BackwardOpsMixin, BackwardPlanMixin, Ba
         # the I_0 / I_g encoder backward chains on the side lanes beside the trajectory pass's: the backward's tail gets 0.15 ms shorter in
         # tools/train_phase_times.py, the step does not (8 same-box pairs, c2: 14.94 ms with, 14.64 without) — off
         self.parallel_encoder_passes = os.environ.get("GCPX_PARALLEL_ENCODER_BWD") is not None
+        self.wgrad_per_cu = int(os.environ.get("GCPX_WGRAD_PER_CU", "1"))         # conv weight gradients: workgroups per CU (0: the kernel's own occupancy)
         self.lean_mean_grad = os.environ.get("GCPX_NO_LEAN_MEAN_GRAD") is None   # adaptive: head backward over the 80 slots of the mixture mean
         self.fuse_stage = os.environ.get("GCPX_NO_STAGE_FUSION") is None     # 16-channel upsampling blocks: weight gradient without gcpx_conv_stage
         self.fuse_head_act = os.environ.get("GCPX_NO_HEAD_ACT_FUSION") is None     # activation backward of the last decoder block in the head's data gradient

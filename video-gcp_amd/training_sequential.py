@@ -40,6 +40,7 @@ class SequentialTrainStep(GCPTrainStep):
         assert model._hp.context_every_step, "the recurrent nets are built with the (e_0, e_g) context at every step (hyperparameters.py default)"
         super().__init__(model, lr=lr, betas=betas, eps=eps, process_group=process_group, **optim)
         self.side_lanes = True
+        self.wgrad_per_cu = int(__import__("os").environ.get("GCPX_WGRAD_PER_CU", "0"))   # (full occupancy here: backward_ops._wgrad_conv3)
         # GCPX_SEQ_CHAINS: "lockstep" (default): prior chain ahead on its own lane, generator step t and inference step t + 1 in the SAME
         # five launches (gcpx_gemm_group) on the main lane; "overlap": three lanes, step-by-step events; "serial": round-5 order
         # "lockstep3": the prior net's step t rides in the same launches too (three problems each; no side chain, no events at all)
