@@ -74,9 +74,9 @@ class GCPTrainStep(BackwardWeightsMixin, BackwardOpsMixin, BackwardPlanMixin, Ba
         # (profiles/r04n_train_timeline.txt) and took back 0.4 of the 0.58 ms; with the levels' merge chains on the caller's stream
         # (merge_on_caller_lane) the slices are held until the last chain is out and run under the encoder backward (_on_mark): -0.24 ms
         # per step (tools/ab_train_attr.py early_optimizer 1 0).  `early_blocks` > 0 holds their launches to that many workgroups
-        # (128: +0.07 ms, 32: +3.5 ms; 0 = full grids).
+        # (one workgroup per CU, 256, is the default since round 6: -0.1 ms against full grids; 128: +0.3 ms, 64: +1.6).
         self.early_optimizer = os.environ.get("GCPX_NO_EARLY_OPTIMIZER") is None
-        self.early_blocks = int(os.environ.get("GCPX_EARLY_BLOCKS", "0"))
+        self.early_blocks = int(os.environ.get("GCPX_EARLY_BLOCKS", "256"))     # (round 6 sweep: 0 = full grids 12.00 ms, 64: 13.6, 128: 12.3, 256: 11.90, 512: 11.96)
         self.early_on_caller = os.environ.get("GCPX_EARLY_STREAM", "caller") == "caller"     # else: communication stream / last side lane
         self._early_on, self._applied, self._caller = False, set(), None
         self.split_dgrad_wide = os.environ.get("GCPX_NO_SPLIT_DGRAD_WIDE") is None     # data gradients of the 32- / 64-channel decoder blocks on the split-f16 kernel
