@@ -236,6 +236,23 @@ def test_cell_backward_in_the_gemm_epilogue_gives_the_same_gradient():
     assert torch.equal(ta.grad, tb.grad)
 
 
+@pytest.mark.parametrize("name,over", [("c1", {}), ("c5s", {"learn_matching_temp": True})])
+def test_two_trainers_keep_identical_parameters(name, over):
+    """Two trainers fed the same minibatches hold bit-identical parameters and optimizer moments after three steps (balanced model;
+    adaptive model with the learned matching temperature): no float atomics, fixed summation orders, every hand-over between the lanes,
+    the optimizer's stream and torch's own launches ordered (the flat model's twin test found one that was not)."""
+    hp, sd, m1, t1 = _setup(name, "auto", **over)
+    _, _, m2, t2 = _setup(name, "auto", **over)
+    for step in range(3):
+        inputs, noise, _ = make_inputs(hp, seed=60 + step, variant="B")
+        dev_in, nz = {k: v.cuda() for k, v in inputs.items()}, noise.cuda()
+        t1.step(dev_in, nz)
+        t2.step(dev_in, nz)
+    torch.cuda.synchronize()
+    assert torch.equal(m1.theta, m2.theta) and torch.equal(t1.exp_avg, t2.exp_avg) and torch.equal(t1.exp_avg_sq, t2.exp_avg_sq)
+    assert torch.equal(t1.grad, t2.grad)
+
+
 def test_two_training_steps_c1():
     """losses of two consecutive optimisation steps and the updated parameters against the oracle loop"""
     from oracle import gcp_model_oracle as O
